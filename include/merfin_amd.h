@@ -1,0 +1,213 @@
+/*
+ * merfin_amd.h -- C ABI of the MI355X-native k-mer multiplicity evaluator.
+ *
+ * This is the drop-in boundary for merfin's evaluation hot path (reference:
+ * arangrhie/merfin, paths below relative to /root/reference).  merfin has no
+ * plugin/FFI interface; the seams that exist in its source are
+ *   (1) the sweatShop callback triple  load / process / output
+ *       (src/merfin/merfin.C:30-31,59-65, wired at :377,383,389),
+ *   (2) the lookup object  merylExactLookup::{estimateMemoryUsage,load,value}
+ *       (src/merfin/merfin-globals.C:135-159,107-108),
+ *   (3) the K* parameter fields of merfinGlobal
+ *       (src/merfin/merfin-globals.H:172,222-227,239).
+ * Each entry point below names the seam it replaces.  Plain pointers and
+ * sizes only: no C++/torch types cross this boundary.  INTEGRATION.md shows
+ * the binding a merfin maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - every function returning int returns 0 on success or a negative MFX_E_*
+ *     code; mfx_last_error() then returns a thread-local description.  The
+ *     library never calls exit() (the reference does: merfin-globals.C:31,152).
+ *   - objects are bound to the HIP device they were created on; calls may come
+ *     from any host thread; one object must not be used from two threads at
+ *     once.  `stream` arguments are hipStream_t passed as void* (NULL = the
+ *     device's default stream).
+ *   - k-mers are 2k-bit integers, A=0 C=1 T=2 G=3, first base most significant
+ *     (meryl's kmerTiny encoding), 1 <= k <= 31.
+ */
+#ifndef MERFIN_AMD_H
+#define MERFIN_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MFX_OK            0
+#define MFX_E_INVAL      -1   /* bad argument                                  */
+#define MFX_E_NOMEM      -2   /* host or device allocation failed              */
+#define MFX_E_HIP        -3   /* a HIP runtime call failed                     */
+#define MFX_E_FULL       -4   /* index capacity exceeded                       */
+#define MFX_E_OVERFLOW   -5   /* histogram overflow list exhausted             */
+#define MFX_E_IO         -6   /* file could not be read / parsed               */
+#define MFX_E_FORMAT     -7   /* file magic / version / layout not recognised  */
+#define MFX_E_NODEVICE   -8   /* no usable HIP device                          */
+
+const char *mfx_last_error(void);
+int         mfx_last_error_code(void);   /* code of the last failing call on this thread */
+const char *mfx_version(void);
+int         mfx_device_count(void);
+
+/* ------------------------------------------------------------------------ */
+/* Index: replaces the two merylExactLookup objects readLookup / asmLookup  */
+/* (merfin-globals.H:217,220).  One device-resident table holds BOTH counts */
+/* of every k-mer, so one probe serves merfinGlobal::getK(kmer,kmer,...)    */
+/* (merfin-globals.C:101-110), which does four.                             */
+/* ------------------------------------------------------------------------ */
+typedef struct mfx_index mfx_index;
+
+/* merylExactLookup() + estimateMemoryUsage (merfin-globals.C:134-153):
+ * capacity_kmers = upper bound on distinct k-mers over both sets.  max_gb is
+ * the -memory cap in GB (0 = none): creation fails with MFX_E_NOMEM when the
+ * table would not fit, mirroring "Not enough memory to load databases". */
+mfx_index *mfx_index_create(int k, uint64_t capacity_kmers, double max_gb, int device);
+void       mfx_index_free(mfx_index *ix);
+double     mfx_index_estimate_gb(int k, uint64_t capacity_kmers);
+
+/* merylExactLookup::load(reader, maxMem, 0, minV, maxV), merfin-globals.C:156
+ * (read DB: values outside [minV,maxV] are dropped at load, merfin.C:199-200)
+ * and :159 (asm DB: unfiltered).  kmers/values: n pairs, any order; on_device
+ * != 0 means the arrays already live on this index's device. */
+int mfx_index_add_read(mfx_index *ix, const uint64_t *kmers, const uint32_t *values, uint64_t n,
+                       uint64_t minV, uint64_t maxV, int on_device);
+int mfx_index_add_asm(mfx_index *ix, const uint64_t *kmers, const uint32_t *values, uint64_t n,
+                      int on_device);
+
+typedef struct mfx_seq mfx_seq;
+
+/* Native replacement of the `meryl count k=.. <seq> output <seq>.meryl` child
+ * process (merfin-globals.C:182-186): counts the canonical k-mers of every
+ * contig of `seq` into the assembly side of the index, on the GPU. */
+int mfx_index_count_asm(mfx_index *ix, const mfx_seq *seq, void *stream);
+
+/* merylExactLookup::value(kmer), merfin-globals.C:107-108, batched: for each
+ * query returns the stored read and asm counts (0 when absent).  Queries are
+ * looked up as given (no canonicalisation). */
+int mfx_index_value(const mfx_index *ix, const uint64_t *kmers, uint64_t n,
+                    uint32_t *readV, uint32_t *asmV);
+
+typedef struct {
+  int      k;
+  int      canonical;      /* 1: every stored k-mer <= its reverse complement */
+  uint64_t capacity;       /* slots                                           */
+  uint64_t distinct;       /* occupied slots                                  */
+  uint64_t bytes;          /* device bytes held by the table                  */
+} mfx_index_info;
+int mfx_index_get_info(const mfx_index *ix, mfx_index_info *out);
+
+/* copy out every stored (kmer, readV, asmV); arrays sized >= info.distinct.
+ * Order unspecified.  (Test / -completeness support.) */
+int mfx_index_export(const mfx_index *ix, uint64_t *kmers, uint32_t *readV, uint32_t *asmV,
+                     uint64_t *n_out);
+
+/* ------------------------------------------------------------------------ */
+/* Sequences: replaces the loader callback loadSequence (merfin.C:30-53) +  */
+/* merfinInput::{seq,kiter} (merfin-globals.H:64-65).  All contigs are      */
+/* packed into one HBM buffer once; k-mer extraction happens on the device. */
+/* ------------------------------------------------------------------------ */
+mfx_seq *mfx_seq_upload(int device, const char *const *bases, const uint64_t *lens, uint32_t ncontigs);
+/* contigs already resident on the device, each at d_bases[i] */
+mfx_seq *mfx_seq_from_device(int device, const void *const *d_bases, const uint64_t *lens, uint32_t ncontigs,
+                             void *stream);
+void     mfx_seq_free(mfx_seq *s);
+uint32_t mfx_seq_num_contigs(const mfx_seq *s);
+uint64_t mfx_seq_num_bases(const mfx_seq *s);
+/* work units (contig-aligned position tiles) -- the sharding granule for
+ * multi-GPU runs: rank r of N evaluates tiles [T*r/N, T*(r+1)/N). */
+uint64_t mfx_seq_num_tiles(const mfx_seq *s);
+
+/* ------------------------------------------------------------------------ */
+/* Evaluator: the K* parameters of merfinGlobal (merfin-globals.H:222-239)  */
+/* bound to an index.                                                       */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+  double          peak;      /* -peak (merfin.C:89-90)                         */
+  uint32_t        n_prob;    /* rows of the -prob table, 0 = none              */
+  const uint32_t *probK;     /* copyKmerK (merfin-globals.H:226)               */
+  const double   *probP;     /* copyKmerP (merfin-globals.H:227)               */
+} mfx_kparams;
+
+typedef struct mfx_eval mfx_eval;
+
+/* nbins: dense K* bins kept per side on the device (0 = default 65536); bins
+ * beyond go through an overflow list, so results do not depend on it. */
+mfx_eval *mfx_eval_create(const mfx_index *ix, const mfx_kparams *kp, uint32_t nbins);
+void      mfx_eval_free(mfx_eval *ev);
+uint32_t  mfx_eval_nbins(const mfx_eval *ev);
+
+/* merfinGlobal::getK(kmvalu,kmvalu,...) + getKmetric on the host, bit-exact
+ * with the device code (merfin-globals.C:66-98, merfin-globals.H:248-261). */
+void mfx_getK(const mfx_kparams *kp, uint32_t readV, uint32_t asmV,
+              double *readK, double *asmK, double *prob);
+double mfx_getKmetric(double readK, double asmK);
+/* histoQV (merfin-histogram.C:22-31) */
+double mfx_histoQV(double kval, double ktot, int k);
+
+/* ------------------------------------------------------------------------ */
+/* -hist: replaces processHistogram + outputHistogram                       */
+/* (merfin-histogram.C:35-92, 96-136).                                      */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+  uint64_t  kasm;              /* histKasm     (merfin-globals.H:184)          */
+  uint64_t  kmissing;          /* histKmissing (:185)                          */
+  double    koverCpy;          /* histKoverCpy (:186)                          */
+  uint32_t  undrMax, overMax;  /* histUndrMax / histOverMax (:188,191)         */
+  uint64_t *undr, *over;       /* histUndr / histOver                          */
+  uint32_t  ncontigs;
+  uint64_t *contig_kasm;       /* per-contig s->kasm     (merfin-histogram.C:58)  */
+  uint64_t *contig_kmissing;   /* per-contig s->kmissing (merfin-histogram.C:67)  */
+} mfx_hist_result;
+
+/* whole assembly on this object's device; result arrays are allocated by the
+ * library, release with mfx_hist_result_free. */
+int  mfx_hist_run(mfx_eval *ev, const mfx_seq *seq, mfx_hist_result *out);
+void mfx_hist_result_free(mfx_hist_result *r);
+
+/* Device-side accumulate for sharded runs.  d_counts: uint64[MFX_HIST_WORDS]
+ * caller-owned device memory, added into (zero it first), layout
+ *   [0,nbins) undr | [nbins,2nbins) over | kasm | kmissing | novf |
+ *   contig_kasm[ncontigs] | contig_kmissing[ncontigs]
+ * d_kover: double[1], receives (+=) this launch's koverCpy.  Evaluates tiles
+ * [tile_begin, tile_end).  Asynchronous on `stream`.  All-reduce d_counts and
+ * d_kover over ranks to obtain the global result (the only collective). */
+#define MFX_HIST_WORDS(nbins, ncontigs) (2ull * (nbins) + 3ull + 2ull * (ncontigs))
+int mfx_hist_launch(mfx_eval *ev, const mfx_seq *seq, uint64_t tile_begin, uint64_t tile_end,
+                    uint64_t *d_counts, double *d_kover, void *stream);
+/* turn an (all-reduced, host-resident) d_counts/d_kover image into a result */
+int mfx_hist_result_from_counts(const mfx_eval *ev, const uint64_t *h_counts, double kover,
+                                uint32_t ncontigs, mfx_hist_result *out);
+/* K* bins >= nbins seen by launches on this evaluator since the last call:
+ * copies up to `cap` records (bit 63 = 1 for `over`, low bits = bin index). */
+int mfx_hist_take_overflow(mfx_eval *ev, uint64_t *records, uint64_t cap, uint64_t *n_out);
+
+/* reportHistogram (merfin-histogram.C:140-176): the histogram file text and
+ * the stderr summary, byte-identical formatting.  Either path may be NULL;
+ * a path ending in .gz/.bz2/.xz is piped through the matching compressor as
+ * compressedFileWriter does. */
+int mfx_hist_report(const mfx_hist_result *r, int k, const char *hist_path, const char *summary_path);
+
+/* ------------------------------------------------------------------------ */
+/* -dump: replaces processDump + outputDump (merfin-dump.C:20-68, 72-104).  */
+/* ------------------------------------------------------------------------ */
+/* Raw per-position values: for k-mer start positions [pos_begin,pos_end) of
+ * contig `contig`, readV[i]/asmV[i] = summed read / asm counts of the k-mer
+ * starting there (0,0 where no valid k-mer starts).  Host output arrays. */
+int mfx_dump_values(mfx_eval *ev, const mfx_seq *seq, uint32_t contig, uint64_t pos_begin, uint64_t pos_end,
+                    uint32_t *readV, uint32_t *asmV, uint64_t *kasm, uint64_t *kmissing);
+/* The complete -dump of one contig appended to `path` in the reference's text
+ * format "%s\t%lu\t%.2f\t%.2f\t%.2f\n" (merfin-dump.C:88-93). */
+int mfx_dump_contig(mfx_eval *ev, const mfx_seq *seq, uint32_t contig, const char *name,
+                    const char *path, int append, uint64_t *kasm, uint64_t *kmissing);
+
+/* ------------------------------------------------------------------------ */
+/* -completeness: replaces computeCompleteness (merfin-completeness.C:48-144)*/
+/* as one streaming pass over the joint table.                              */
+/* ------------------------------------------------------------------------ */
+int mfx_completeness(mfx_eval *ev, double *total, double *undrcpy);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MERFIN_AMD_H */

@@ -1,0 +1,17 @@
+"""merfin_amd -- MI355X-native k-mer multiplicity evaluator (merfin's -hist /
+-dump / -completeness evaluation path on gfx950).
+
+This package is a thin ctypes binding of the C ABI in include/merfin_amd.h
+(libmerfin_amd.so, hand-written HIP).  It exists for the parity tests and
+bench.py; the product host program is the C++ `merfin` CLI in merfin_amd/cli.
+There is no CPU fallback: importing works anywhere, but creating an index
+without the HIP library or without a GPU raises.
+"""
+from .binding import (  # noqa: F401
+    MfxError, Index, Sequences, Evaluator, HistResult, KParams,
+    lib_path, load_library, device_count, getK, getKmetric, histoQV, hist_words,
+    TILE,
+)
+
+__all__ = ["MfxError", "Index", "Sequences", "Evaluator", "HistResult", "KParams", "lib_path",
+           "load_library", "device_count", "getK", "getKmetric", "histoQV", "hist_words", "TILE"]

@@ -1,0 +1,391 @@
+"""ctypes binding of include/merfin_amd.h.  Names follow the reference's
+objects: Index <-> the merylExactLookup pair (merfin-globals.H:217,220),
+Sequences <-> the dnaSeq records loadSequence produces (merfin.C:30-53),
+Evaluator <-> merfinGlobal's K* parameters + process*/output* callbacks."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+TILE = 4096
+
+MFX_ERRORS = {-1: "INVAL", -2: "NOMEM", -3: "HIP", -4: "FULL", -5: "OVERFLOW", -6: "IO", -7: "FORMAT", -8: "NODEVICE"}
+
+
+class MfxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("merfin_amd error %s (%d): %s" % (MFX_ERRORS.get(code, "?"), code, msg))
+        self.code = code
+
+
+def lib_path():
+    return os.path.join(_HERE, "libmerfin_amd.so")
+
+
+class _KP(C.Structure):
+    _fields_ = [("peak", C.c_double), ("n_prob", C.c_uint32),
+                ("probK", C.POINTER(C.c_uint32)), ("probP", C.POINTER(C.c_double))]
+
+
+class _Info(C.Structure):
+    _fields_ = [("k", C.c_int), ("canonical", C.c_int), ("capacity", C.c_uint64),
+                ("distinct", C.c_uint64), ("bytes", C.c_uint64)]
+
+
+class _HistResult(C.Structure):
+    _fields_ = [("kasm", C.c_uint64), ("kmissing", C.c_uint64), ("koverCpy", C.c_double),
+                ("undrMax", C.c_uint32), ("overMax", C.c_uint32),
+                ("undr", C.POINTER(C.c_uint64)), ("over", C.POINTER(C.c_uint64)),
+                ("ncontigs", C.c_uint32),
+                ("contig_kasm", C.POINTER(C.c_uint64)), ("contig_kmissing", C.POINTER(C.c_uint64))]
+
+
+_lib = None
+
+# every symbol include/merfin_amd.h declares (tests check the .so exports all of them)
+SYMBOLS = [
+    "mfx_last_error", "mfx_last_error_code", "mfx_version", "mfx_device_count",
+    "mfx_index_create", "mfx_index_free", "mfx_index_estimate_gb", "mfx_index_add_read", "mfx_index_add_asm",
+    "mfx_index_count_asm", "mfx_index_value", "mfx_index_get_info", "mfx_index_export",
+    "mfx_seq_upload", "mfx_seq_from_device", "mfx_seq_free", "mfx_seq_num_contigs", "mfx_seq_num_bases",
+    "mfx_seq_num_tiles",
+    "mfx_eval_create", "mfx_eval_free", "mfx_eval_nbins", "mfx_getK", "mfx_getKmetric", "mfx_histoQV",
+    "mfx_hist_run", "mfx_hist_result_free", "mfx_hist_launch", "mfx_hist_result_from_counts",
+    "mfx_hist_take_overflow", "mfx_hist_report",
+    "mfx_dump_values", "mfx_dump_contig", "mfx_completeness",
+]
+
+
+def load_library():
+    """Load libmerfin_amd.so.  Fails loudly when the HIP library was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not os.path.exists(p):
+        raise ImportError("merfin_amd: %s is missing -- build it with `make -C merfin_amd/csrc` "
+                          "(or __graft_entry__.build()); there is no CPU fallback" % p)
+    L = C.CDLL(p)
+    u64p, u32p, f64p, vp = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.c_void_p
+    L.mfx_last_error.restype = C.c_char_p
+    L.mfx_version.restype = C.c_char_p
+    L.mfx_last_error_code.restype = C.c_int
+    L.mfx_device_count.restype = C.c_int
+    L.mfx_index_create.restype = vp
+    L.mfx_index_create.argtypes = [C.c_int, C.c_uint64, C.c_double, C.c_int]
+    L.mfx_index_free.argtypes = [vp]
+    L.mfx_index_estimate_gb.restype = C.c_double
+    L.mfx_index_estimate_gb.argtypes = [C.c_int, C.c_uint64]
+    L.mfx_index_add_read.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int]
+    L.mfx_index_add_asm.argtypes = [vp, vp, vp, C.c_uint64, C.c_int]
+    L.mfx_index_count_asm.argtypes = [vp, vp, vp]
+    L.mfx_index_value.argtypes = [vp, u64p, C.c_uint64, u32p, u32p]
+    L.mfx_index_get_info.argtypes = [vp, C.POINTER(_Info)]
+    L.mfx_index_export.argtypes = [vp, u64p, u32p, u32p, u64p]
+    L.mfx_seq_upload.restype = vp
+    L.mfx_seq_upload.argtypes = [C.c_int, C.POINTER(C.c_char_p), u64p, C.c_uint32]
+    L.mfx_seq_from_device.restype = vp
+    L.mfx_seq_from_device.argtypes = [C.c_int, C.POINTER(vp), u64p, C.c_uint32, vp]
+    L.mfx_seq_free.argtypes = [vp]
+    L.mfx_seq_num_contigs.restype = C.c_uint32
+    L.mfx_seq_num_contigs.argtypes = [vp]
+    L.mfx_seq_num_bases.restype = C.c_uint64
+    L.mfx_seq_num_bases.argtypes = [vp]
+    L.mfx_seq_num_tiles.restype = C.c_uint64
+    L.mfx_seq_num_tiles.argtypes = [vp]
+    L.mfx_eval_create.restype = vp
+    L.mfx_eval_create.argtypes = [vp, C.POINTER(_KP), C.c_uint32]
+    L.mfx_eval_free.argtypes = [vp]
+    L.mfx_eval_nbins.restype = C.c_uint32
+    L.mfx_eval_nbins.argtypes = [vp]
+    L.mfx_getK.argtypes = [C.POINTER(_KP), C.c_uint32, C.c_uint32, f64p, f64p, f64p]
+    L.mfx_getKmetric.restype = C.c_double
+    L.mfx_getKmetric.argtypes = [C.c_double, C.c_double]
+    L.mfx_histoQV.restype = C.c_double
+    L.mfx_histoQV.argtypes = [C.c_double, C.c_double, C.c_int]
+    L.mfx_hist_run.argtypes = [vp, vp, C.POINTER(_HistResult)]
+    L.mfx_hist_result_free.argtypes = [C.POINTER(_HistResult)]
+    L.mfx_hist_launch.argtypes = [vp, vp, C.c_uint64, C.c_uint64, vp, vp, vp]
+    L.mfx_hist_result_from_counts.argtypes = [vp, u64p, C.c_double, C.c_uint32, C.POINTER(_HistResult)]
+    L.mfx_hist_take_overflow.argtypes = [vp, u64p, C.c_uint64, u64p]
+    L.mfx_hist_report.argtypes = [C.POINTER(_HistResult), C.c_int, C.c_char_p, C.c_char_p]
+    L.mfx_dump_values.argtypes = [vp, vp, C.c_uint32, C.c_uint64, C.c_uint64, u32p, u32p, u64p, u64p]
+    L.mfx_dump_contig.argtypes = [vp, vp, C.c_uint32, C.c_char_p, C.c_char_p, C.c_int, u64p, u64p]
+    L.mfx_completeness.argtypes = [vp, f64p, f64p]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise MfxError(rc, load_library().mfx_last_error().decode())
+
+
+def _need(ptr):
+    if not ptr:
+        L = load_library()
+        raise MfxError(L.mfx_last_error_code() or -3, L.mfx_last_error().decode())
+    return ptr
+
+
+def device_count():
+    return load_library().mfx_device_count()
+
+
+def hist_words(nbins, ncontigs):
+    return 2 * nbins + 3 + 2 * ncontigs
+
+
+class KParams:
+    """-peak and the -prob table (merfin-globals.H:226-227,239)."""
+
+    def __init__(self, peak, probK=None, probP=None):
+        self.peak = float(peak)
+        self.probK = np.ascontiguousarray(probK if probK is not None else [], dtype=np.uint32)
+        self.probP = np.ascontiguousarray(probP if probP is not None else [], dtype=np.float64)
+        assert len(self.probK) == len(self.probP)
+        self.c = _KP(self.peak, len(self.probK),
+                     self.probK.ctypes.data_as(C.POINTER(C.c_uint32)), self.probP.ctypes.data_as(C.POINTER(C.c_double)))
+
+    @staticmethod
+    def from_file(peak, path):
+        """load_Kmetric (merfin-globals.C:21-62): lines with exactly two comma-separated fields."""
+        K, P = [], []
+        with open(path) as f:
+            for line in f:
+                w = [x for x in line.rstrip("\r\n").split(",") if x != ""]
+                if len(w) == 2:
+                    K.append(int(w[0]))
+                    P.append(float(w[1]))
+        return KParams(peak, K, P)
+
+
+def getK(kp, readV, asmV):
+    a, b, c = C.c_double(), C.c_double(), C.c_double()
+    load_library().mfx_getK(C.byref(kp.c), readV, asmV, C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value
+
+
+def getKmetric(readK, asmK):
+    return load_library().mfx_getKmetric(readK, asmK)
+
+
+def histoQV(kval, ktot, k):
+    return load_library().mfx_histoQV(kval, ktot, k)
+
+
+def _ptr(x):
+    """host numpy array or device pointer (int / torch tensor) -> (void*, on_device, keepalive)"""
+    if isinstance(x, np.ndarray):
+        return C.c_void_p(x.ctypes.data), 0, x
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr()), (1 if x.is_cuda else 0), x
+    return C.c_void_p(int(x)), 1, None
+
+
+class Index:
+    """Joint read+assembly k-mer count table resident in HBM."""
+
+    def __init__(self, k, capacity_kmers, max_gb=0.0, device=0):
+        L = load_library()
+        self.k = k
+        self.device = device
+        self.h = _need(L.mfx_index_create(k, int(capacity_kmers), float(max_gb), device))
+
+    def add_read(self, kmers, values, minV=0, maxV=2**64 - 1):
+        if isinstance(kmers, np.ndarray):
+            kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
+            values = np.ascontiguousarray(values, dtype=np.uint32)
+        pk, dev, _k1 = _ptr(kmers)
+        pv, _, _k2 = _ptr(values)
+        _check(load_library().mfx_index_add_read(self.h, pk, pv, len(kmers), minV, maxV, dev))
+
+    def add_asm(self, kmers, values):
+        if isinstance(kmers, np.ndarray):
+            kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
+            values = np.ascontiguousarray(values, dtype=np.uint32)
+        pk, dev, _k1 = _ptr(kmers)
+        pv, _, _k2 = _ptr(values)
+        _check(load_library().mfx_index_add_asm(self.h, pk, pv, len(kmers), dev))
+
+    def count_asm(self, seqs, stream=None):
+        _check(load_library().mfx_index_count_asm(self.h, seqs.h, C.c_void_p(stream or 0)))
+
+    def value(self, kmers):
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
+        r = np.zeros(len(kmers), dtype=np.uint32)
+        a = np.zeros(len(kmers), dtype=np.uint32)
+        _check(load_library().mfx_index_value(self.h, kmers.ctypes.data_as(C.POINTER(C.c_uint64)), len(kmers),
+                                              r.ctypes.data_as(C.POINTER(C.c_uint32)), a.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return r, a
+
+    def info(self):
+        i = _Info()
+        _check(load_library().mfx_index_get_info(self.h, C.byref(i)))
+        return {"k": i.k, "canonical": bool(i.canonical), "capacity": i.capacity, "distinct": i.distinct, "bytes": i.bytes}
+
+    def export(self):
+        n = self.info()["distinct"]
+        k = np.zeros(max(n, 1), dtype=np.uint64)
+        r = np.zeros(max(n, 1), dtype=np.uint32)
+        a = np.zeros(max(n, 1), dtype=np.uint32)
+        cnt = C.c_uint64(0)
+        _check(load_library().mfx_index_export(self.h, k.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                               r.ctypes.data_as(C.POINTER(C.c_uint32)), a.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                               C.byref(cnt)))
+        o = np.argsort(k[:cnt.value])
+        return k[:cnt.value][o], r[:cnt.value][o], a[:cnt.value][o]
+
+    def close(self):
+        if getattr(self, "h", None):
+            load_library().mfx_index_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+class Sequences:
+    """All contigs of the assembly packed into one HBM buffer."""
+
+    def __init__(self, contigs=None, device=0, names=None, _handle=None):
+        L = load_library()
+        self.device = device
+        if _handle is not None:
+            self.h = _handle
+        else:
+            n = len(contigs)
+            arr = (C.c_char_p * n)(*contigs)
+            lens = np.array([len(c) for c in contigs], dtype=np.uint64)
+            self.h = _need(L.mfx_seq_upload(device, arr, lens.ctypes.data_as(C.POINTER(C.c_uint64)), n))
+        self.names = names
+
+    @staticmethod
+    def from_device(ptrs, lens, device=0, stream=None, names=None):
+        L = load_library()
+        n = len(ptrs)
+        arr = (C.c_void_p * n)(*[int(p) for p in ptrs])
+        ln = np.array(lens, dtype=np.uint64)
+        h = _need(L.mfx_seq_from_device(device, arr, ln.ctypes.data_as(C.POINTER(C.c_uint64)), n, C.c_void_p(stream or 0)))
+        return Sequences(device=device, names=names, _handle=h)
+
+    @property
+    def ncontigs(self):
+        return load_library().mfx_seq_num_contigs(self.h)
+
+    @property
+    def nbases(self):
+        return load_library().mfx_seq_num_bases(self.h)
+
+    @property
+    def ntiles(self):
+        return load_library().mfx_seq_num_tiles(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            load_library().mfx_seq_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+class HistResult:
+    """merfinGlobal's histogram accumulators (merfin-globals.H:184-192)."""
+
+    def __init__(self):
+        self.c = _HistResult()
+
+    kasm = property(lambda s: s.c.kasm)
+    kmissing = property(lambda s: s.c.kmissing)
+    koverCpy = property(lambda s: s.c.koverCpy)
+
+    def undr(self):
+        return np.ctypeslib.as_array(self.c.undr, shape=(self.c.undrMax,)).copy()
+
+    def over(self):
+        return np.ctypeslib.as_array(self.c.over, shape=(self.c.overMax,)).copy()
+
+    def contig_kasm(self):
+        return np.ctypeslib.as_array(self.c.contig_kasm, shape=(max(self.c.ncontigs, 1),))[:self.c.ncontigs].copy()
+
+    def contig_kmissing(self):
+        return np.ctypeslib.as_array(self.c.contig_kmissing, shape=(max(self.c.ncontigs, 1),))[:self.c.ncontigs].copy()
+
+    def report(self, k, hist_path=None, summary_path=None):
+        _check(load_library().mfx_hist_report(C.byref(self.c), k, hist_path.encode() if hist_path else None,
+                                              summary_path.encode() if summary_path else None))
+
+    def __del__(self):
+        try:
+            load_library().mfx_hist_result_free(C.byref(self.c))
+        except Exception:
+            pass
+
+
+class Evaluator:
+    """K* parameters bound to an Index; runs -hist / -dump / -completeness."""
+
+    def __init__(self, index, kparams, nbins=0):
+        self.index = index
+        self.kp = kparams
+        self.h = _need(load_library().mfx_eval_create(index.h, C.byref(kparams.c), nbins))
+
+    @property
+    def nbins(self):
+        return load_library().mfx_eval_nbins(self.h)
+
+    def hist(self, seqs):
+        r = HistResult()
+        _check(load_library().mfx_hist_run(self.h, seqs.h, C.byref(r.c)))
+        return r
+
+    def hist_launch(self, seqs, tile_begin, tile_end, d_counts, d_kover, stream=None):
+        """Asynchronous accumulate into caller-owned device buffers (torch tensors or raw pointers)."""
+        pc = d_counts.data_ptr() if hasattr(d_counts, "data_ptr") else int(d_counts)
+        pk = d_kover.data_ptr() if hasattr(d_kover, "data_ptr") else int(d_kover)
+        _check(load_library().mfx_hist_launch(self.h, seqs.h, tile_begin, tile_end, C.c_void_p(pc), C.c_void_p(pk),
+                                              C.c_void_p(stream or 0)))
+
+    def result_from_counts(self, h_counts, kover, ncontigs):
+        h_counts = np.ascontiguousarray(h_counts, dtype=np.uint64)
+        r = HistResult()
+        _check(load_library().mfx_hist_result_from_counts(self.h, h_counts.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                          float(kover), ncontigs, C.byref(r.c)))
+        return r
+
+    def take_overflow(self, cap=1 << 20):
+        rec = np.zeros(cap, dtype=np.uint64)
+        n = C.c_uint64(0)
+        _check(load_library().mfx_hist_take_overflow(self.h, rec.ctypes.data_as(C.POINTER(C.c_uint64)), cap, C.byref(n)))
+        return rec[:n.value]
+
+    def dump_values(self, seqs, contig, pos_begin, pos_end):
+        n = pos_end - pos_begin
+        r = np.zeros(max(n, 1), dtype=np.uint32)
+        a = np.zeros(max(n, 1), dtype=np.uint32)
+        ka, km = C.c_uint64(0), C.c_uint64(0)
+        _check(load_library().mfx_dump_values(self.h, seqs.h, contig, pos_begin, pos_end,
+                                              r.ctypes.data_as(C.POINTER(C.c_uint32)), a.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                              C.byref(ka), C.byref(km)))
+        return r[:n], a[:n], ka.value, km.value
+
+    def dump_contig(self, seqs, contig, name, path, append=False):
+        ka, km = C.c_uint64(0), C.c_uint64(0)
+        _check(load_library().mfx_dump_contig(self.h, seqs.h, contig, name.encode(), path.encode(), 1 if append else 0,
+                                              C.byref(ka), C.byref(km)))
+        return ka.value, km.value
+
+    def completeness(self):
+        t, u = C.c_double(), C.c_double()
+        _check(load_library().mfx_completeness(self.h, C.byref(t), C.byref(u)))
+        return t.value, u.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            load_library().mfx_eval_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()

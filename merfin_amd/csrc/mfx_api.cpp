@@ -1,0 +1,724 @@
+// mfx_api.cpp -- C-ABI entry points of libmerfin_amd (include/merfin_amd.h).
+// Host-side orchestration only; all evaluation work is done by the HIP
+// kernels in mfx_kernels.hip.  There is deliberately NO CPU fallback: without
+// a usable HIP device every entry point fails with MFX_E_NODEVICE / MFX_E_HIP.
+#include "mfx_internal.h"
+#include "mfx_kernels.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+static thread_local int  g_err_code = 0;
+
+void mfx_set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int mfx_fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  g_err_code = code;
+  return code;
+}
+
+extern "C" const char *mfx_last_error(void) { return g_err; }
+extern "C" int mfx_last_error_code(void) { return g_err_code; }
+extern "C" const char *mfx_version(void) { return "merfin_amd 0.1 (gfx950)"; }
+
+extern "C" int mfx_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+namespace {
+struct DevGuard {
+  int prev = -1;
+  bool ok = false;
+  explicit DevGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    ok = (hipSetDevice(dev) == hipSuccess);
+  }
+  ~DevGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+template <class T>
+struct DevBuf {   // scoped device scratch
+  T *p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t n) { return hipMalloc((void **)&p, (n ? n : 1) * sizeof(T)); }
+};
+
+double load_factor() {
+  const char *e = getenv("MFX_LOAD_FACTOR");
+  double lf = e ? atof(e) : 0.7;
+  if (!(lf > 0.05 && lf <= 0.9)) lf = 0.7;
+  return lf;
+}
+
+uint64_t lines_for(uint64_t capacity_kmers) {
+  double slots = (double)capacity_kmers / load_factor();
+  uint64_t nlines = (uint64_t)ceil(slots / MFX_SLOTS_LINE);
+  if (nlines < 1024) nlines = 1024;      // probe sequences may span 512 lines
+  return nlines;
+}
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// index
+// ---------------------------------------------------------------------------
+mfx_table_view mfx_index::view() const {
+  mfx_table_view v;
+  v.slots = d_slots;
+  v.nlines = nlines;
+  v.minV = minV > 0xffffffffull ? 0xffffffffu : (uint32_t)minV;
+  v.maxV = maxV > 0xffffffffull ? 0xffffffffu : (uint32_t)maxV;
+  v.k = k;
+  return v;
+}
+
+extern "C" double mfx_index_estimate_gb(int k, uint64_t capacity_kmers) {
+  (void)k;
+  return (double)lines_for(capacity_kmers) * MFX_ALIGN / 1e9;
+}
+
+extern "C" mfx_index *mfx_index_create(int k, uint64_t capacity_kmers, double max_gb, int device) {
+  if (k < 1 || k > 31) {
+    mfx_fail(MFX_E_INVAL, "k=%d unsupported: this build handles 1 <= k <= 31 (64-bit k-mers)", k);
+    return nullptr;
+  }
+  if (mfx_device_count() <= device || device < 0) {
+    mfx_fail(MFX_E_NODEVICE, "HIP device %d not available (%d visible); merfin_amd has no CPU path", device, mfx_device_count());
+    return nullptr;
+  }
+  double need = mfx_index_estimate_gb(k, capacity_kmers);
+  if (max_gb > 0 && need > max_gb) {
+    // merfin-globals.C:148-153
+    mfx_fail(MFX_E_NOMEM, "Not enough memory to load databases.  Increase -memory. (need %.3f GB, limit %.3f GB)", need, max_gb);
+    return nullptr;
+  }
+  DevGuard g(device);
+  if (!g.ok) { mfx_fail(MFX_E_HIP, "hipSetDevice(%d) failed", device); return nullptr; }
+  mfx_index *ix = new mfx_index;
+  ix->device = device;
+  ix->k = k;
+  ix->capacity_kmers = capacity_kmers;
+  ix->nlines = lines_for(capacity_kmers);
+  hipError_t e = hipMalloc((void **)&ix->d_slots, ix->nlines * MFX_ALIGN);
+  if (e != hipSuccess) {
+    mfx_fail(MFX_E_NOMEM, "hipMalloc of %.3f GB for the k-mer table failed: %s", need, hipGetErrorString(e));
+    delete ix;
+    return nullptr;
+  }
+  if (hipMalloc((void **)&ix->d_meta, 4 * sizeof(uint64_t)) != hipSuccess ||
+      hipMemset(ix->d_meta, 0, 4 * sizeof(uint64_t)) != hipSuccess ||
+      mfx_k_table_init(ix->d_slots, ix->nlines * MFX_SLOTS_LINE, nullptr) != hipSuccess ||
+      hipDeviceSynchronize() != hipSuccess) {
+    mfx_fail(MFX_E_HIP, "k-mer table initialisation failed: %s", hipGetErrorString(hipGetLastError()));
+    mfx_index_free(ix);
+    return nullptr;
+  }
+  return ix;
+}
+
+extern "C" void mfx_index_free(mfx_index *ix) {
+  if (!ix) return;
+  DevGuard g(ix->device);
+  if (ix->d_slots) (void)hipFree(ix->d_slots);
+  if (ix->d_meta) (void)hipFree(ix->d_meta);
+  delete ix;
+}
+
+static int index_check(mfx_index *ix) {
+  uint64_t meta[4];
+  MFX_HIP(hipMemcpy(meta, ix->d_meta, sizeof(meta), hipMemcpyDeviceToHost));
+  if (meta[2] != 0)
+    return mfx_fail(MFX_E_FULL, "k-mer table full: %lu inserts hit the probe limit (capacity %lu k-mers, %lu stored)",
+                    (unsigned long)meta[2], (unsigned long)ix->capacity_kmers, (unsigned long)meta[0]);
+  if ((double)meta[0] > 0.92 * (double)(ix->nlines * MFX_SLOTS_LINE))
+    return mfx_fail(MFX_E_FULL, "k-mer table over-full: %lu k-mers in %lu slots; create the index with a larger capacity",
+                    (unsigned long)meta[0], (unsigned long)(ix->nlines * MFX_SLOTS_LINE));
+  return MFX_OK;
+}
+
+static int index_add(mfx_index *ix, const uint64_t *kmers, const uint32_t *values, uint64_t n, int side, int on_device) {
+  if (!ix || (n && (!kmers || !values))) return mfx_fail(MFX_E_INVAL, "mfx_index_add: null argument");
+  DevGuard g(ix->device);
+  if (on_device) {
+    MFX_HIP(mfx_k_table_add(ix->view(), kmers, values, n, side, ix->d_meta, nullptr));
+    MFX_HIP(hipDeviceSynchronize());
+    return index_check(ix);
+  }
+  const uint64_t CH = 1ull << 24;
+  DevBuf<uint64_t> dk;
+  DevBuf<uint32_t> dv;
+  MFX_HIP(dk.alloc(std::min(n, CH)));
+  MFX_HIP(dv.alloc(std::min(n, CH)));
+  for (uint64_t o = 0; o < n; o += CH) {
+    uint64_t m = std::min(CH, n - o);
+    MFX_HIP(hipMemcpy(dk.p, kmers + o, m * sizeof(uint64_t), hipMemcpyHostToDevice));
+    MFX_HIP(hipMemcpy(dv.p, values + o, m * sizeof(uint32_t), hipMemcpyHostToDevice));
+    MFX_HIP(mfx_k_table_add(ix->view(), dk.p, dv.p, m, side, ix->d_meta, nullptr));
+    MFX_HIP(hipDeviceSynchronize());
+  }
+  return index_check(ix);
+}
+
+extern "C" int mfx_index_add_read(mfx_index *ix, const uint64_t *kmers, const uint32_t *values, uint64_t n,
+                                  uint64_t minV, uint64_t maxV, int on_device) {
+  if (!ix) return mfx_fail(MFX_E_INVAL, "mfx_index_add_read: null index");
+  if (ix->filter_set && (ix->minV != minV || ix->maxV != maxV))
+    return mfx_fail(MFX_E_INVAL, "mfx_index_add_read: -min/-max must be the same for every batch of one index");
+  ix->minV = minV;
+  ix->maxV = maxV;
+  ix->filter_set = true;
+  return index_add(ix, kmers, values, n, 0, on_device);
+}
+
+extern "C" int mfx_index_add_asm(mfx_index *ix, const uint64_t *kmers, const uint32_t *values, uint64_t n, int on_device) {
+  return index_add(ix, kmers, values, n, 1, on_device);
+}
+
+extern "C" int mfx_index_count_asm(mfx_index *ix, const mfx_seq *seq, void *stream) {
+  if (!ix || !seq) return mfx_fail(MFX_E_INVAL, "mfx_index_count_asm: null argument");
+  if (ix->device != seq->device) return mfx_fail(MFX_E_INVAL, "index and sequence live on different devices");
+  DevGuard g(ix->device);
+  mfx_count_args a;
+  a.t = ix->view();
+  a.bases = seq->d_bases;
+  a.contig_off = seq->d_contig_off;
+  a.contig_len = seq->d_contig_len;
+  a.tile_start = seq->d_tile_start;
+  a.ncontigs = seq->ncontigs;
+  a.ntiles = seq->ntiles;
+  a.meta = ix->d_meta;
+  MFX_HIP(mfx_k_count(a, (hipStream_t)stream));
+  MFX_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return index_check(ix);
+}
+
+extern "C" int mfx_index_value(const mfx_index *ix, const uint64_t *kmers, uint64_t n, uint32_t *readV, uint32_t *asmV) {
+  if (!ix || (n && (!kmers || !readV || !asmV))) return mfx_fail(MFX_E_INVAL, "mfx_index_value: null argument");
+  DevGuard g(ix->device);
+  DevBuf<uint64_t> dk;
+  DevBuf<uint32_t> dr, da;
+  MFX_HIP(dk.alloc(n));
+  MFX_HIP(dr.alloc(n));
+  MFX_HIP(da.alloc(n));
+  MFX_HIP(hipMemcpy(dk.p, kmers, n * sizeof(uint64_t), hipMemcpyHostToDevice));
+  MFX_HIP(mfx_k_table_value(ix->view(), dk.p, n, dr.p, da.p, nullptr));
+  MFX_HIP(hipMemcpy(readV, dr.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  MFX_HIP(hipMemcpy(asmV, da.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return MFX_OK;
+}
+
+extern "C" int mfx_index_get_info(const mfx_index *ix, mfx_index_info *out) {
+  if (!ix || !out) return mfx_fail(MFX_E_INVAL, "mfx_index_get_info: null argument");
+  DevGuard g(ix->device);
+  uint64_t meta[4];
+  MFX_HIP(hipMemcpy(meta, ix->d_meta, sizeof(meta), hipMemcpyDeviceToHost));
+  out->k = ix->k;
+  out->canonical = (meta[1] == 0) ? 1 : 0;
+  out->capacity = ix->nlines * MFX_SLOTS_LINE;
+  out->distinct = meta[0];
+  out->bytes = ix->nlines * MFX_ALIGN;
+  return MFX_OK;
+}
+
+extern "C" int mfx_index_export(const mfx_index *ix, uint64_t *kmers, uint32_t *readV, uint32_t *asmV, uint64_t *n_out) {
+  if (!ix || !kmers || !readV || !asmV || !n_out) return mfx_fail(MFX_E_INVAL, "mfx_index_export: null argument");
+  DevGuard g(ix->device);
+  mfx_index_info info;
+  int rc = mfx_index_get_info(ix, &info);
+  if (rc) return rc;
+  DevBuf<uint64_t> dk;
+  DevBuf<uint32_t> dr, da;
+  DevBuf<unsigned long long> dc;
+  MFX_HIP(dk.alloc(info.distinct));
+  MFX_HIP(dr.alloc(info.distinct));
+  MFX_HIP(da.alloc(info.distinct));
+  MFX_HIP(dc.alloc(1));
+  MFX_HIP(hipMemset(dc.p, 0, sizeof(unsigned long long)));
+  MFX_HIP(mfx_k_table_export(ix->view(), dk.p, dr.p, da.p, dc.p, nullptr));
+  unsigned long long cnt = 0;
+  MFX_HIP(hipMemcpy(&cnt, dc.p, sizeof(cnt), hipMemcpyDeviceToHost));
+  MFX_HIP(hipMemcpy(kmers, dk.p, cnt * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  MFX_HIP(hipMemcpy(readV, dr.p, cnt * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  MFX_HIP(hipMemcpy(asmV, da.p, cnt * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  *n_out = cnt;
+  return MFX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// sequences
+// ---------------------------------------------------------------------------
+static mfx_seq *seq_layout(int device, const uint64_t *lens, uint32_t ncontigs) {
+  mfx_seq *s = new mfx_seq;
+  s->device = device;
+  s->ncontigs = ncontigs;
+  s->off.resize(ncontigs);
+  s->len.assign(lens, lens + ncontigs);
+  s->tile_start.resize((size_t)ncontigs + 1);
+  uint64_t o = 0, t = 0;
+  for (uint32_t c = 0; c < ncontigs; ++c) {
+    s->off[c] = o;
+    s->tile_start[c] = t;
+    t += (lens[c] + MFX_TILE - 1) / MFX_TILE;
+    s->total_bases += lens[c];
+    o = (o + lens[c] + 1 + MFX_ALIGN - 1) / MFX_ALIGN * MFX_ALIGN;   // >= 1 separator byte, next contig 128-byte aligned
+  }
+  s->tile_start[ncontigs] = t;
+  s->ntiles = t;
+  s->buf_bytes = o + MFX_TILE + 2 * MFX_ALIGN;                        // tail tiles read one tile + halo past the end
+  return s;
+}
+
+static int seq_alloc(mfx_seq *s) {
+  MFX_HIP(hipMalloc((void **)&s->d_bases, s->buf_bytes));
+  MFX_HIP(hipMemset(s->d_bases, 0, s->buf_bytes));                    // byte 0 is not ACGT: separators + padding
+  size_t nc = s->ncontigs ? s->ncontigs : 1;
+  MFX_HIP(hipMalloc((void **)&s->d_contig_off, nc * sizeof(uint64_t)));
+  MFX_HIP(hipMalloc((void **)&s->d_contig_len, nc * sizeof(uint64_t)));
+  MFX_HIP(hipMalloc((void **)&s->d_tile_start, (nc + 1) * sizeof(uint64_t)));
+  if (s->ncontigs) {
+    MFX_HIP(hipMemcpy(s->d_contig_off, s->off.data(), s->ncontigs * sizeof(uint64_t), hipMemcpyHostToDevice));
+    MFX_HIP(hipMemcpy(s->d_contig_len, s->len.data(), s->ncontigs * sizeof(uint64_t), hipMemcpyHostToDevice));
+  }
+  MFX_HIP(hipMemcpy(s->d_tile_start, s->tile_start.data(), (s->ncontigs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+  return MFX_OK;
+}
+
+extern "C" mfx_seq *mfx_seq_upload(int device, const char *const *bases, const uint64_t *lens, uint32_t ncontigs) {
+  if ((ncontigs && (!bases || !lens)) || device < 0 || device >= mfx_device_count()) {
+    mfx_fail(device < 0 || device >= mfx_device_count() ? MFX_E_NODEVICE : MFX_E_INVAL,
+             "mfx_seq_upload: bad argument (device %d of %d)", device, mfx_device_count());
+    return nullptr;
+  }
+  DevGuard g(device);
+  mfx_seq *s = seq_layout(device, lens, ncontigs);
+  if (seq_alloc(s) != MFX_OK) { mfx_seq_free(s); return nullptr; }
+  for (uint32_t c = 0; c < ncontigs; ++c)
+    if (lens[c] && hipMemcpy(s->d_bases + s->off[c], bases[c], lens[c], hipMemcpyHostToDevice) != hipSuccess) {
+      mfx_fail(MFX_E_HIP, "H2D copy of contig %u failed", c);
+      mfx_seq_free(s);
+      return nullptr;
+    }
+  return s;
+}
+
+extern "C" mfx_seq *mfx_seq_from_device(int device, const void *const *d_bases, const uint64_t *lens, uint32_t ncontigs,
+                                        void *stream) {
+  if ((ncontigs && (!d_bases || !lens)) || device < 0 || device >= mfx_device_count()) {
+    mfx_fail(MFX_E_INVAL, "mfx_seq_from_device: bad argument");
+    return nullptr;
+  }
+  DevGuard g(device);
+  mfx_seq *s = seq_layout(device, lens, ncontigs);
+  if (seq_alloc(s) != MFX_OK) { mfx_seq_free(s); return nullptr; }
+  for (uint32_t c = 0; c < ncontigs; ++c)
+    if (lens[c] && hipMemcpyAsync(s->d_bases + s->off[c], d_bases[c], lens[c], hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
+      mfx_fail(MFX_E_HIP, "D2D copy of contig %u failed", c);
+      mfx_seq_free(s);
+      return nullptr;
+    }
+  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {
+    mfx_fail(MFX_E_HIP, "D2D copy sync failed");
+    mfx_seq_free(s);
+    return nullptr;
+  }
+  return s;
+}
+
+extern "C" void mfx_seq_free(mfx_seq *s) {
+  if (!s) return;
+  DevGuard g(s->device);
+  if (s->d_bases) (void)hipFree(s->d_bases);
+  if (s->d_contig_off) (void)hipFree(s->d_contig_off);
+  if (s->d_contig_len) (void)hipFree(s->d_contig_len);
+  if (s->d_tile_start) (void)hipFree(s->d_tile_start);
+  delete s;
+}
+
+extern "C" uint32_t mfx_seq_num_contigs(const mfx_seq *s) { return s ? s->ncontigs : 0; }
+extern "C" uint64_t mfx_seq_num_bases(const mfx_seq *s) { return s ? s->total_bases : 0; }
+extern "C" uint64_t mfx_seq_num_tiles(const mfx_seq *s) { return s ? s->ntiles : 0; }
+
+// ---------------------------------------------------------------------------
+// evaluator
+// ---------------------------------------------------------------------------
+extern "C" mfx_eval *mfx_eval_create(const mfx_index *ix, const mfx_kparams *kp, uint32_t nbins) {
+  if (!ix || !kp || (kp->n_prob && (!kp->probK || !kp->probP))) {
+    mfx_fail(MFX_E_INVAL, "mfx_eval_create: null argument");
+    return nullptr;
+  }
+  DevGuard g(ix->device);
+  mfx_eval *ev = new mfx_eval;
+  ev->ix = ix;
+  ev->device = ix->device;
+  ev->peak = kp->peak;
+  ev->n_prob = kp->n_prob;
+  ev->probK.assign(kp->probK, kp->probK + kp->n_prob);
+  ev->probP.assign(kp->probP, kp->probP + kp->n_prob);
+  ev->nbins = nbins ? std::max<uint32_t>(nbins, MFX_NB_LDS) : 65536;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, ix->device) != hipSuccess) {
+    mfx_fail(MFX_E_HIP, "hipGetDeviceProperties failed");
+    delete ev;
+    return nullptr;
+  }
+  const char *e = getenv("MFX_BLOCKS_PER_CU");
+  int bpc = e ? atoi(e) : 16;
+  if (bpc < 1) bpc = 1;
+  ev->grid = prop.multiProcessorCount * bpc;
+  size_t np = ev->n_prob ? ev->n_prob : 1;
+  if (hipMalloc((void **)&ev->d_probK, np * sizeof(uint32_t)) != hipSuccess ||
+      hipMalloc((void **)&ev->d_probP, np * sizeof(double)) != hipSuccess ||
+      hipMalloc((void **)&ev->d_partials, 2 * (size_t)ev->grid * sizeof(double)) != hipSuccess ||
+      hipMalloc((void **)&ev->d_ovf, (1 + (size_t)MFX_OVF_CAP) * sizeof(uint64_t)) != hipSuccess ||
+      hipMemset(ev->d_ovf, 0, sizeof(uint64_t)) != hipSuccess ||
+      (ev->n_prob && hipMemcpy(ev->d_probK, ev->probK.data(), ev->n_prob * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) ||
+      (ev->n_prob && hipMemcpy(ev->d_probP, ev->probP.data(), ev->n_prob * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)) {
+    mfx_fail(MFX_E_HIP, "mfx_eval_create: device setup failed: %s", hipGetErrorString(hipGetLastError()));
+    mfx_eval_free(ev);
+    return nullptr;
+  }
+  return ev;
+}
+
+extern "C" void mfx_eval_free(mfx_eval *ev) {
+  if (!ev) return;
+  DevGuard g(ev->device);
+  if (ev->d_probK) (void)hipFree(ev->d_probK);
+  if (ev->d_probP) (void)hipFree(ev->d_probP);
+  if (ev->d_partials) (void)hipFree(ev->d_partials);
+  if (ev->d_ovf) (void)hipFree(ev->d_ovf);
+  delete ev;
+}
+
+extern "C" uint32_t mfx_eval_nbins(const mfx_eval *ev) { return ev ? ev->nbins : 0; }
+
+extern "C" void mfx_getK(const mfx_kparams *kp, uint32_t readV, uint32_t asmV, double *readK, double *asmK, double *prob) {
+  double rk, pr;
+  mfx_getK_core(kp->peak, kp->n_prob, kp->probK, kp->probP, readV, rk, pr);
+  *readK = rk;
+  *asmK = (double)asmV;   // merfin-globals.C:81
+  *prob = pr;
+}
+
+extern "C" double mfx_getKmetric(double readK, double asmK) { return mfx_kmetric(readK, asmK); }
+
+// merfin-histogram.C:22-31
+extern "C" double mfx_histoQV(double kval, double ktot, int k) {
+  double base = kval / ktot;
+  double kinv = 1.0 / k;
+  double qv = -10.0 * log10(1.0 - pow(1.0 - base, kinv));
+  return qv;
+}
+
+// ---------------------------------------------------------------------------
+// -hist
+// ---------------------------------------------------------------------------
+static int index_canonical(const mfx_index *ix, int *canon) {
+  uint64_t meta[4];
+  MFX_HIP(hipMemcpy(meta, ix->d_meta, sizeof(meta), hipMemcpyDeviceToHost));
+  // single probe of min(f,r) equals value(f)+value(r) only for a canonical DB
+  // and odd k (no palindromes); otherwise probe both strands (SURVEY A-7).
+  *canon = (meta[1] == 0 && (ix->k & 1)) ? 1 : 0;
+  return MFX_OK;
+}
+
+extern "C" int mfx_hist_launch(mfx_eval *ev, const mfx_seq *seq, uint64_t tile_begin, uint64_t tile_end,
+                               uint64_t *d_counts, double *d_kover, void *stream) {
+  if (!ev || !seq || !d_counts || !d_kover) return mfx_fail(MFX_E_INVAL, "mfx_hist_launch: null argument");
+  if (ev->device != seq->device) return mfx_fail(MFX_E_INVAL, "evaluator and sequence live on different devices");
+  if (tile_begin > tile_end || tile_end > seq->ntiles) return mfx_fail(MFX_E_INVAL, "tile range [%lu,%lu) outside [0,%lu)",
+                                                                      (unsigned long)tile_begin, (unsigned long)tile_end, (unsigned long)seq->ntiles);
+  DevGuard g(ev->device);
+  int canon = 0;
+  int rc = index_canonical(ev->ix, &canon);
+  if (rc) return rc;
+  const char *force = getenv("MFX_FORCE_TWO_STRAND");
+  if (force && atoi(force)) canon = 0;
+  mfx_hist_args a;
+  a.t = ev->ix->view();
+  a.canonical = canon;
+  a.bases = seq->d_bases;
+  a.contig_off = seq->d_contig_off;
+  a.contig_len = seq->d_contig_len;
+  a.tile_start = seq->d_tile_start;
+  a.ncontigs = seq->ncontigs;
+  a.tile_begin = tile_begin;
+  a.tile_end = tile_end;
+  a.peak = ev->peak;
+  a.n_prob = ev->n_prob;
+  a.probK = ev->d_probK;
+  a.probP = ev->d_probP;
+  a.nbins = ev->nbins;
+  a.counts = d_counts;
+  a.partials = ev->d_partials;
+  a.ovf = ev->d_ovf;
+  MFX_HIP(mfx_k_hist(a, ev->grid, (hipStream_t)stream));
+  MFX_HIP(mfx_k_sum_partials(ev->d_partials, (uint32_t)ev->grid, d_kover, (hipStream_t)stream));
+  return MFX_OK;
+}
+
+extern "C" int mfx_hist_take_overflow(mfx_eval *ev, uint64_t *records, uint64_t cap, uint64_t *n_out) {
+  if (!ev || !n_out) return mfx_fail(MFX_E_INVAL, "mfx_hist_take_overflow: null argument");
+  DevGuard g(ev->device);
+  uint64_t n = 0;
+  MFX_HIP(hipMemcpy(&n, ev->d_ovf, sizeof(n), hipMemcpyDeviceToHost));
+  if (n > MFX_OVF_CAP)
+    return mfx_fail(MFX_E_OVERFLOW, "%lu k-mers fell beyond the %u dense K* bins but the overflow list holds %u; "
+                    "create the evaluator with a larger nbins", (unsigned long)n, ev->nbins, MFX_OVF_CAP);
+  uint64_t m = std::min(n, cap);
+  if (m && records) MFX_HIP(hipMemcpy(records, ev->d_ovf + 1, m * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  MFX_HIP(hipMemset(ev->d_ovf, 0, sizeof(uint64_t)));
+  *n_out = n;
+  return (n > cap) ? mfx_fail(MFX_E_OVERFLOW, "overflow list has %lu records, caller buffer %lu", (unsigned long)n, (unsigned long)cap) : MFX_OK;
+}
+
+static void result_grow(uint64_t *&a, uint32_t &max, uint64_t need) {
+  if (need <= max) return;
+  uint64_t nm = (need + 1023) / 1024 * 1024;
+  a = (uint64_t *)realloc(a, nm * sizeof(uint64_t));
+  memset(a + max, 0, (nm - max) * sizeof(uint64_t));
+  max = (uint32_t)nm;
+}
+
+extern "C" int mfx_hist_result_from_counts(const mfx_eval *ev, const uint64_t *h, double kover, uint32_t ncontigs,
+                                           mfx_hist_result *out) {
+  if (!ev || !h || !out) return mfx_fail(MFX_E_INVAL, "mfx_hist_result_from_counts: null argument");
+  memset(out, 0, sizeof(*out));
+  const uint32_t nb = ev->nbins;
+  uint32_t um = 0, om = 0;
+  for (uint32_t i = 0; i < nb; ++i) {
+    if (h[i]) um = i + 1;
+    if (h[nb + i]) om = i + 1;
+  }
+  // merfin-histogram.C:105-108: the global arrays start at 2048 entries
+  result_grow(out->undr, out->undrMax, std::max<uint32_t>(um, 2048));
+  result_grow(out->over, out->overMax, std::max<uint32_t>(om, 2048));
+  memcpy(out->undr, h, um * sizeof(uint64_t));
+  memcpy(out->over, h + nb, om * sizeof(uint64_t));
+  out->kasm = h[2ull * nb + 0];
+  out->kmissing = h[2ull * nb + 1];
+  out->koverCpy = kover;
+  out->ncontigs = ncontigs;
+  out->contig_kasm = (uint64_t *)calloc(ncontigs ? ncontigs : 1, sizeof(uint64_t));
+  out->contig_kmissing = (uint64_t *)calloc(ncontigs ? ncontigs : 1, sizeof(uint64_t));
+  memcpy(out->contig_kasm, h + 2ull * nb + 3, ncontigs * sizeof(uint64_t));
+  memcpy(out->contig_kmissing, h + 2ull * nb + 3 + ncontigs, ncontigs * sizeof(uint64_t));
+  return MFX_OK;
+}
+
+static void result_add_overflow(mfx_hist_result *r, const std::vector<uint64_t> &rec) {
+  for (uint64_t x : rec) {
+    uint64_t idx = x & ~(1ull << 63);
+    if (x >> 63) { result_grow(r->over, r->overMax, idx + 1); r->over[idx]++; }
+    else         { result_grow(r->undr, r->undrMax, idx + 1); r->undr[idx]++; }
+  }
+}
+
+extern "C" int mfx_hist_run(mfx_eval *ev, const mfx_seq *seq, mfx_hist_result *out) {
+  if (!ev || !seq || !out) return mfx_fail(MFX_E_INVAL, "mfx_hist_run: null argument");
+  DevGuard g(ev->device);
+  const size_t words = MFX_HIST_WORDS(ev->nbins, seq->ncontigs);
+  DevBuf<uint64_t> dc;
+  DevBuf<double> dk;
+  MFX_HIP(dc.alloc(words));
+  MFX_HIP(dk.alloc(1));
+  MFX_HIP(hipMemset(dc.p, 0, words * sizeof(uint64_t)));
+  MFX_HIP(hipMemset(dk.p, 0, sizeof(double)));
+  int rc = mfx_hist_launch(ev, seq, 0, seq->ntiles, dc.p, dk.p, nullptr);
+  if (rc) return rc;
+  MFX_HIP(hipDeviceSynchronize());
+  std::vector<uint64_t> h(words);
+  double kover = 0;
+  MFX_HIP(hipMemcpy(h.data(), dc.p, words * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  MFX_HIP(hipMemcpy(&kover, dk.p, sizeof(double), hipMemcpyDeviceToHost));
+  rc = mfx_hist_result_from_counts(ev, h.data(), kover, seq->ncontigs, out);
+  if (rc) return rc;
+  uint64_t novf = h[2ull * ev->nbins + 2];
+  if (novf) {
+    std::vector<uint64_t> rec(novf);
+    uint64_t n = 0;
+    rc = mfx_hist_take_overflow(ev, rec.data(), novf, &n);
+    if (rc) { mfx_hist_result_free(out); return rc; }
+    rec.resize(std::min(n, novf));
+    result_add_overflow(out, rec);
+  }
+  return MFX_OK;
+}
+
+extern "C" void mfx_hist_result_free(mfx_hist_result *r) {
+  if (!r) return;
+  free(r->undr); free(r->over); free(r->contig_kasm); free(r->contig_kmissing);
+  memset(r, 0, sizeof(*r));
+}
+
+// compressedFileWriter: the compressor is chosen from the file name suffix
+static FILE *open_writer(const char *path, bool append, bool *is_pipe) {
+  std::string p(path);
+  auto ends = [&](const char *suf) { size_t n = strlen(suf); return p.size() >= n && p.compare(p.size() - n, n, suf) == 0; };
+  const char *tool = ends(".gz") ? "gzip -c" : ends(".bz2") ? "bzip2 -c" : ends(".xz") ? "xz -c" : nullptr;
+  *is_pipe = tool != nullptr;
+  if (!tool) return fopen(path, append ? "a" : "w");
+  std::string cmd = std::string(tool) + (append ? " >> '" : " > '") + p + "'";
+  return popen(cmd.c_str(), "w");
+}
+static void close_writer(FILE *f, bool is_pipe) {
+  if (!f) return;
+  if (is_pipe) pclose(f); else fclose(f);
+}
+
+// reportHistogram, merfin-histogram.C:140-176
+extern "C" int mfx_hist_report(const mfx_hist_result *r, int k, const char *hist_path, const char *summary_path) {
+  if (!r || !r->undr || !r->over) return mfx_fail(MFX_E_INVAL, "mfx_hist_report: empty result");
+  if (hist_path) {
+    bool pipe;
+    FILE *f = open_writer(hist_path, false, &pipe);
+    if (!f) return mfx_fail(MFX_E_IO, "cannot open '%s' for writing", hist_path);
+    for (uint64_t ii = r->undrMax - 1; ii > 0; ii--)
+      if (r->undr[ii] > 0)
+        fprintf(f, "%.1f\t%lu\n", ((double)ii * -0.2), (unsigned long)r->undr[ii]);
+    fprintf(f, "%.1f\t%lu\n", 0.0, (unsigned long)(r->undr[0] + r->over[0]));
+    for (uint64_t ii = 1; ii < r->overMax; ii++)
+      if (r->over[ii] > 0)
+        fprintf(f, "%.1f\t%lu\n", ((double)ii * 0.2), (unsigned long)r->over[ii]);
+    close_writer(f, pipe);
+  }
+  if (summary_path) {
+    FILE *f = strcmp(summary_path, "-") == 0 ? stderr : fopen(summary_path, "w");
+    if (!f) return mfx_fail(MFX_E_IO, "cannot open '%s' for writing", summary_path);
+    fprintf(f, "\n");
+    fprintf(f, "K-mers not found in reads (missing) : %lu\n", (unsigned long)r->kmissing);
+    fprintf(f, "K-mers overly represented in assembly: %.2f\n", r->koverCpy);
+    fprintf(f, "K-mers found in the assembly: %lu\n", (unsigned long)r->kasm);
+    fprintf(f, "Missing QV: %.2f\n", mfx_histoQV((double)r->kmissing, (double)r->kasm, k));
+    fprintf(f, "Merfin QV*: %.2f\n", mfx_histoQV(r->kmissing + r->koverCpy, (double)r->kasm, k));
+    fprintf(f, "*** Note this QV is valid only if -seqmer was generated with -sequence ***\n\n");
+    fprintf(f, "*** Missing QV only considers missing kmers as errors. Merfin QV* includes overrepresented kmers. ***\n\n");
+    fprintf(f, "*** When the lookup table is provided, missing QV includes weighted low frequency kmers, otherwise it is identical to Merqury QV. ***\n\n");
+    if (f != stderr) fclose(f);
+  }
+  return MFX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// -dump
+// ---------------------------------------------------------------------------
+extern "C" int mfx_dump_values(mfx_eval *ev, const mfx_seq *seq, uint32_t contig, uint64_t pos_begin, uint64_t pos_end,
+                               uint32_t *readV, uint32_t *asmV, uint64_t *kasm, uint64_t *kmissing) {
+  if (!ev || !seq || !readV || !asmV) return mfx_fail(MFX_E_INVAL, "mfx_dump_values: null argument");
+  if (contig >= seq->ncontigs || pos_begin > pos_end || pos_end > seq->len[contig])
+    return mfx_fail(MFX_E_INVAL, "mfx_dump_values: range [%lu,%lu) outside contig %u of length %lu",
+                    (unsigned long)pos_begin, (unsigned long)pos_end, contig,
+                    (unsigned long)(contig < seq->ncontigs ? seq->len[contig] : 0));
+  DevGuard g(ev->device);
+  int canon = 0;
+  int rc = index_canonical(ev->ix, &canon);
+  if (rc) return rc;
+  uint64_t n = pos_end - pos_begin;
+  if (kasm) *kasm = 0;
+  if (kmissing) *kmissing = 0;
+  if (n == 0) return MFX_OK;
+  uint64_t tb = pos_begin / MFX_TILE * MFX_TILE;     // tile-aligned start keeps the 16-byte loads aligned
+  DevBuf<uint32_t> dr, da;
+  DevBuf<uint64_t> ds;
+  MFX_HIP(dr.alloc(n));
+  MFX_HIP(da.alloc(n));
+  MFX_HIP(ds.alloc(2));
+  MFX_HIP(hipMemset(ds.p, 0, 2 * sizeof(uint64_t)));
+  mfx_dump_args a;
+  a.t = ev->ix->view();
+  a.canonical = canon;
+  a.src = seq->d_bases + seq->off[contig] + tb;
+  a.npos = pos_end - tb;
+  a.skip = pos_begin - tb;
+  a.clen_left = seq->len[contig] - tb;
+  a.readV = dr.p;
+  a.asmV = da.p;
+  a.peak = ev->peak;
+  a.n_prob = ev->n_prob;
+  a.probK = ev->d_probK;
+  a.probP = ev->d_probP;
+  a.stats = ds.p;
+  MFX_HIP(mfx_k_dump(a, nullptr));
+  MFX_HIP(hipMemcpy(readV, dr.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  MFX_HIP(hipMemcpy(asmV, da.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  uint64_t st[2];
+  MFX_HIP(hipMemcpy(st, ds.p, sizeof(st), hipMemcpyDeviceToHost));
+  if (kasm) *kasm = st[0];
+  if (kmissing) *kmissing = st[1];
+  return MFX_OK;
+}
+
+// outputDump, merfin-dump.C:87-93: a line for every position where any of
+// readK, asmK, K* is non-zero.
+extern "C" int mfx_dump_contig(mfx_eval *ev, const mfx_seq *seq, uint32_t contig, const char *name,
+                               const char *path, int append, uint64_t *kasm, uint64_t *kmissing) {
+  if (!ev || !seq || !name || !path) return mfx_fail(MFX_E_INVAL, "mfx_dump_contig: null argument");
+  if (contig >= seq->ncontigs) return mfx_fail(MFX_E_INVAL, "mfx_dump_contig: contig %u out of range", contig);
+  bool pipe;
+  FILE *f = open_writer(path, append != 0, &pipe);
+  if (!f) return mfx_fail(MFX_E_IO, "cannot open '%s' for writing", path);
+  const uint64_t len = seq->len[contig];
+  const uint64_t CH = 1ull << 24;
+  std::vector<uint32_t> rv(std::min(len, CH) + 1), av(std::min(len, CH) + 1);
+  mfx_kparams kp{ev->peak, ev->n_prob, ev->probK.data(), ev->probP.data()};
+  uint64_t ka = 0, km = 0;
+  int rc = MFX_OK;
+  for (uint64_t o = 0; o < len && rc == MFX_OK; o += CH) {
+    uint64_t e = std::min(len, o + CH), a1 = 0, m1 = 0;
+    rc = mfx_dump_values(ev, seq, contig, o, e, rv.data(), av.data(), &a1, &m1);
+    if (rc) break;
+    ka += a1;
+    km += m1;
+    for (uint64_t i = 0; i < e - o; ++i) {
+      if (rv[i] == 0 && av[i] == 0) continue;          // all three values are zero
+      double readK, asmK, prob;
+      mfx_getK(&kp, rv[i], av[i], &readK, &asmK, &prob);
+      double km_ = mfx_kmetric(readK, asmK);
+      if ((readK != 0.0) || (asmK != 0.0) || (km_ != 0.0))
+        fprintf(f, "%s\t%lu\t%.2f\t%.2f\t%.2f\n", name, (unsigned long)(o + i), readK, asmK, km_);
+    }
+  }
+  close_writer(f, pipe);
+  if (kasm) *kasm = ka;
+  if (kmissing) *kmissing = km;
+  return rc;
+}
+
+// ---------------------------------------------------------------------------
+// -completeness
+// ---------------------------------------------------------------------------
+extern "C" int mfx_completeness(mfx_eval *ev, double *total, double *undrcpy) {
+  if (!ev || !total || !undrcpy) return mfx_fail(MFX_E_INVAL, "mfx_completeness: null argument");
+  DevGuard g(ev->device);
+  MFX_HIP(mfx_k_completeness(ev->ix->view(), ev->peak, ev->n_prob, ev->d_probK, ev->d_probP, ev->d_partials, ev->grid, nullptr));
+  std::vector<double> h(2 * (size_t)ev->grid);
+  MFX_HIP(hipMemcpy(h.data(), ev->d_partials, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+  double t = 0, u = 0;
+  for (int b = 0; b < ev->grid; ++b) { t += h[2 * b]; u += h[2 * b + 1]; }
+  *total = t;
+  *undrcpy = u;
+  return MFX_OK;
+}

@@ -1,0 +1,94 @@
+// mfx_internal.h -- shared declarations of the merfin_amd library (host side).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/merfin_amd.h"
+#include "mfx_kstar.h"
+
+// ---- error plumbing -------------------------------------------------------
+void mfx_set_error(const char *fmt, ...);
+int  mfx_fail(int code, const char *fmt, ...);
+#define MFX_HIP(call)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return mfx_fail(MFX_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+#define MFX_HIP_NULL(call)                                                                    \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      mfx_fail(MFX_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return nullptr;                                                                         \
+    }                                                                                         \
+  } while (0)
+
+// ---- geometry --------------------------------------------------------------
+// A tile = MFX_TILE consecutive k-mer start positions of one contig.  Contigs
+// start at 128-byte aligned offsets of the packed HBM buffer and are followed
+// by at least one invalid byte, so no k-mer can span two contigs.
+constexpr uint32_t MFX_TILE       = 4096;
+constexpr uint32_t MFX_BLOCK      = 256;
+constexpr uint32_t MFX_ALIGN      = 128;
+constexpr uint32_t MFX_SLOTS_LINE = 8;          // 8 x 16-byte slots = one 128-byte HBM line
+constexpr uint32_t MFX_NB_LDS     = 1024;       // K* bins per side privatised in LDS
+constexpr uint32_t MFX_MAXP_LDS   = 1024;       // -prob rows cached in LDS
+constexpr uint32_t MFX_OVF_CAP    = 1u << 20;   // histogram overflow records per evaluator
+
+struct mfx_slot {               // 16 bytes: one dwordx4 load per probe
+  uint64_t key;                 // 2k-bit k-mer, ~0 = empty
+  uint32_t readV;               // raw read-DB count (the -min/-max filter is applied at query time)
+  uint32_t asmV;                // assembly count
+};
+constexpr uint64_t MFX_EMPTY = ~0ull;
+
+struct mfx_table_view {
+  mfx_slot *slots;
+  uint64_t  nlines;             // 128-byte lines; slots = 8 * nlines
+  uint32_t  minV, maxV;         // read-count filter (merfin.C:199-200), clamped to uint32
+  int       k;
+};
+
+struct mfx_index {
+  int       device = 0;
+  int       k = 0;
+  uint64_t  capacity_kmers = 0;
+  uint64_t  nlines = 0;
+  mfx_slot *d_slots = nullptr;
+  uint64_t *d_meta = nullptr;   // [0] distinct  [1] non-canonical inserts  [2] probe-limit failures
+  uint64_t  minV = 0, maxV = ~0ull;
+  bool      filter_set = false;
+  mfx_table_view view() const;
+};
+
+struct mfx_seq {
+  int       device = 0;
+  uint32_t  ncontigs = 0;
+  uint64_t  total_bases = 0;
+  uint64_t  ntiles = 0;
+  uint64_t  buf_bytes = 0;
+  uint8_t  *d_bases = nullptr;       // packed, padded contigs
+  uint64_t *d_contig_off = nullptr;  // [ncontigs]   byte offset of each contig
+  uint64_t *d_contig_len = nullptr;  // [ncontigs]
+  uint64_t *d_tile_start = nullptr;  // [ncontigs+1] first tile of each contig
+  std::vector<uint64_t> off, len, tile_start;
+};
+
+struct mfx_eval {
+  const mfx_index *ix = nullptr;
+  int       device = 0;
+  double    peak = 0;
+  uint32_t  n_prob = 0;
+  std::vector<uint32_t> probK;
+  std::vector<double>   probP;
+  uint32_t *d_probK = nullptr;
+  double   *d_probP = nullptr;
+  uint32_t  nbins = 65536;
+  int       grid = 0;
+  double   *d_partials = nullptr;    // [grid] per-block koverCpy partial sums
+  uint64_t *d_ovf = nullptr;         // [0] count, [1..] records
+};

@@ -1,0 +1,58 @@
+// mfx_kernels.h -- kernel argument blocks and launch wrappers (mfx_kernels.hip)
+#pragma once
+#include "mfx_internal.h"
+
+struct mfx_hist_args {
+  mfx_table_view  t;
+  int             canonical;          // 1: single probe of min(f,r); 0: probe both strands and sum
+  const uint8_t  *bases;
+  const uint64_t *contig_off, *contig_len, *tile_start;
+  uint32_t        ncontigs;
+  uint64_t        tile_begin, tile_end;
+  double          peak;
+  uint32_t        n_prob;
+  const uint32_t *probK;
+  const double   *probP;
+  uint32_t        nbins;
+  uint64_t       *counts;             // layout: include/merfin_amd.h MFX_HIST_WORDS
+  double         *partials;           // [gridDim.x]
+  uint64_t       *ovf;                // [0] count, [1..MFX_OVF_CAP] records
+};
+
+struct mfx_dump_args {
+  mfx_table_view  t;
+  int             canonical;
+  const uint8_t  *src;         // contig base + first tile offset (128-byte aligned)
+  uint64_t        npos;        // start positions to evaluate from src (tile-aligned begin)
+  uint64_t        skip;        // first `skip` positions are not written (pos_begin % TILE)
+  uint64_t        clen_left;   // contig bases remaining from src
+  uint32_t       *readV, *asmV;// device output, index = position - skip
+  double          peak;
+  uint32_t        n_prob;
+  const uint32_t *probK;
+  const double   *probP;
+  uint64_t       *stats;       // [0] kasm [1] kmissing
+};
+
+struct mfx_count_args {
+  mfx_table_view  t;
+  const uint8_t  *bases;
+  const uint64_t *contig_off, *contig_len, *tile_start;
+  uint32_t        ncontigs;
+  uint64_t        ntiles;
+  uint64_t       *meta;
+};
+
+hipError_t mfx_k_table_init(mfx_slot *slots, uint64_t nslots, hipStream_t st);
+hipError_t mfx_k_table_add(mfx_table_view t, const uint64_t *kmers, const uint32_t *values, uint64_t n, int side,
+                           uint64_t *meta, hipStream_t st);
+hipError_t mfx_k_table_value(mfx_table_view t, const uint64_t *kmers, uint64_t n, uint32_t *readV, uint32_t *asmV,
+                             hipStream_t st);
+hipError_t mfx_k_table_export(mfx_table_view t, uint64_t *kmers, uint32_t *readV, uint32_t *asmV,
+                              unsigned long long *count, hipStream_t st);
+hipError_t mfx_k_hist(const mfx_hist_args &a, int grid, hipStream_t st);
+hipError_t mfx_k_sum_partials(const double *partials, uint32_t n, double *out, hipStream_t st);
+hipError_t mfx_k_dump(const mfx_dump_args &a, hipStream_t st);
+hipError_t mfx_k_count(const mfx_count_args &a, hipStream_t st);
+hipError_t mfx_k_completeness(mfx_table_view t, double peak, uint32_t n_prob, const uint32_t *probK, const double *probP,
+                              double *partials, int grid, hipStream_t st);

@@ -1,0 +1,554 @@
+// mfx_kernels.hip -- hand-written gfx950 (CDNA4) kernels of the merfin_amd
+// evaluation path.  Written for MI355X only: 64-wide wavefronts, 160 KiB LDS,
+// 128-byte HBM fetch granularity.  No MFMA: this is integer hashing and fp64
+// scalar arithmetic bounded by random-access HBM line rate.
+//
+// Reference semantics implemented here (paths relative to /root/reference):
+//   kmerIterator (meryl-utility; call sites merfin-histogram.C:54-64)
+//   merfinGlobal::getK(kmer,kmer)        merfin-globals.C:101-110
+//   processHistogram hot loop            merfin-histogram.C:54-91
+//   processDump hot loop                 merfin-dump.C:44-67
+//   computeCompleteness merge loop       merfin-completeness.C:70-117
+//   `meryl count` of the assembly        merfin-globals.C:182-186
+#include "mfx_internal.h"
+#include "mfx_kernels.h"
+
+// ===========================================================================
+// joint k-mer table: 128-byte lines of 8 x {key, readV, asmV}
+// ===========================================================================
+__device__ __forceinline__ uint64_t mfx_hash64(uint64_t x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
+  x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL;
+  x ^= x >> 33;
+  return x;
+}
+
+// home line (high hash bits, multiply-range) and home slot (low hash bits)
+__device__ __forceinline__ uint64_t mfx_home(const mfx_table_view &t, uint64_t key, uint32_t &p1) {
+  uint64_t h = mfx_hash64(key);
+  p1 = (uint32_t)h & (MFX_SLOTS_LINE - 1);
+  return __umul64hi(h, t.nlines);
+}
+
+// j-th slot of the probe sequence: cyclic inside the home line, then on to the
+// following lines.  Insert-only table => lookups may stop at the first empty.
+__device__ __forceinline__ uint64_t mfx_probe_slot(const mfx_table_view &t, uint64_t line, uint32_t p1, uint32_t j) {
+  uint64_t ln = line + (j >> 3);
+  if (ln >= t.nlines) ln -= t.nlines;
+  return ln * MFX_SLOTS_LINE + ((p1 + j) & (MFX_SLOTS_LINE - 1));
+}
+
+constexpr uint32_t MFX_MAX_PROBE = 8 * 512;
+
+__device__ __forceinline__ uint4 mfx_load_slot(const mfx_table_view &t, uint64_t s) {
+  return *reinterpret_cast<const uint4 *>(t.slots + s);
+}
+
+// finish a lookup whose first slot is already in registers
+__device__ __forceinline__ uint2 mfx_resolve(const mfx_table_view &t, uint64_t key, uint64_t line, uint32_t p1, uint4 s) {
+  uint32_t j = 0;
+  while (true) {
+    uint64_t sk = (uint64_t)s.x | ((uint64_t)s.y << 32);
+    if (sk == key) {
+      uint32_t rv = s.z;
+      if (rv < t.minV || rv > t.maxV) rv = 0;      // -min / -max (merfin.C:199-200)
+      return make_uint2(rv, s.w);
+    }
+    if (sk == MFX_EMPTY || ++j >= MFX_MAX_PROBE)
+      return make_uint2(0u, 0u);                   // absent -> value 0 (merfin-globals.C:84)
+    s = mfx_load_slot(t, mfx_probe_slot(t, line, p1, j));
+  }
+}
+
+__device__ __forceinline__ uint2 mfx_lookup(const mfx_table_view &t, uint64_t key) {
+  uint32_t p1;
+  uint64_t line = mfx_home(t, key, p1);
+  return mfx_resolve(t, key, line, p1, mfx_load_slot(t, line * MFX_SLOTS_LINE + p1));
+}
+
+// find-or-claim the slot of `key`; nullptr when the probe limit is hit
+__device__ __forceinline__ mfx_slot *mfx_claim(const mfx_table_view &t, uint64_t key, uint64_t *meta) {
+  uint32_t p1;
+  uint64_t line = mfx_home(t, key, p1);
+  for (uint32_t j = 0; j < MFX_MAX_PROBE; ++j) {
+    mfx_slot *sl = t.slots + mfx_probe_slot(t, line, p1, j);
+    unsigned long long *kp = reinterpret_cast<unsigned long long *>(&sl->key);
+    unsigned long long cur = __hip_atomic_load(kp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == MFX_EMPTY) {
+      cur = atomicCAS(kp, (unsigned long long)MFX_EMPTY, (unsigned long long)key);
+      if (cur == MFX_EMPTY) {
+        atomicAdd((unsigned long long *)&meta[0], 1ull);
+        return sl;
+      }
+    }
+    if (cur == key)
+      return sl;
+  }
+  atomicAdd((unsigned long long *)&meta[2], 1ull);
+  return nullptr;
+}
+
+__device__ __forceinline__ uint64_t mfx_revcomp(uint64_t fwd, int k) {
+  uint64_t x = __brevll(fwd) >> (64 - 2 * k);                       // groups reversed, bits in each pair swapped
+  x = ((x & 0x5555555555555555ULL) << 1) | ((x >> 1) & 0x5555555555555555ULL);
+  uint64_t mask = (~0ULL) >> (64 - 2 * k);
+  return (x ^ 0xAAAAAAAAAAAAAAAAULL) & mask;                         // complement = code ^ 2
+}
+
+__global__ void mfx_table_init_kernel(mfx_slot *slots, uint64_t nslots) {
+  uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  uint4 e = make_uint4(0xffffffffu, 0xffffffffu, 0u, 0u);
+  for (; i < nslots; i += stride)
+    reinterpret_cast<uint4 *>(slots)[i] = e;
+}
+
+// side 0: read counts, side 1: asm counts
+__global__ void mfx_table_add_kernel(mfx_table_view t, const uint64_t *kmers, const uint32_t *values, uint64_t n,
+                                     int side, uint64_t *meta) {
+  uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    uint64_t key = kmers[i];
+    uint32_t v = values[i];
+    if (v == 0) continue;
+    if (key > mfx_revcomp(key, t.k))
+      atomicAdd((unsigned long long *)&meta[1], 1ull);
+    mfx_slot *sl = mfx_claim(t, key, meta);
+    if (sl) atomicAdd(side ? &sl->asmV : &sl->readV, v);
+  }
+}
+
+__global__ void mfx_table_value_kernel(mfx_table_view t, const uint64_t *kmers, uint64_t n, uint32_t *readV, uint32_t *asmV) {
+  uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    uint2 v = mfx_lookup(t, kmers[i]);
+    readV[i] = v.x;
+    asmV[i] = v.y;
+  }
+}
+
+__global__ void mfx_table_export_kernel(mfx_table_view t, uint64_t *kmers, uint32_t *readV, uint32_t *asmV,
+                                        unsigned long long *count) {
+  uint64_t nslots = t.nlines * MFX_SLOTS_LINE;
+  uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < nslots; i += stride) {
+    mfx_slot s = t.slots[i];
+    if (s.key == MFX_EMPTY) continue;
+    unsigned long long w = atomicAdd(count, 1ull);
+    kmers[w] = s.key;
+    readV[w] = s.readV;
+    asmV[w] = s.asmV;
+  }
+}
+
+// ===========================================================================
+// sequence tile in LDS: 2-bit codes packed MSB-first in 64-bit words + one
+// validity bit per base, so a lane extracts the k-mer starting at ANY position
+// with two LDS reads and a funnel shift (no rolling dependency between lanes).
+// ===========================================================================
+constexpr uint32_t MFX_TILE_BYTES  = MFX_TILE + 32;          // tile + (k-1) halo, k <= 32
+constexpr uint32_t MFX_TILE_CHUNKS = MFX_TILE_BYTES / 16;    // 16-byte global loads per tile
+constexpr uint32_t MFX_TILE_WORDS  = MFX_TILE_BYTES / 32;    // 64-bit code words (32 bases each)
+
+struct mfx_tile_lds {
+  uint64_t codes[MFX_TILE_WORDS + 1];
+  uint32_t valid[MFX_TILE_WORDS + 1];
+};
+
+// A=0 C=1 T=2 G=3 for either case = (c >> 1) & 3; valid iff (c & 0xDF) in ACGT.
+__device__ __forceinline__ void mfx_pack16(uint4 v, uint32_t &codes, uint32_t &valid) {
+  uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  codes = 0;
+  valid = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      uint32_t c = (w[q] >> (8 * b)) & 0xffu;
+      uint32_t u = (c & 0xDFu) - 0x41u;                       // 'A'->0 'C'->2 'G'->6 'T'->19
+      uint32_t ok = (u < 32u) ? ((0x00080045u >> u) & 1u) : 0u;
+      int i = q * 4 + b;
+      codes |= ((c >> 1) & 3u) << (30 - 2 * i);
+      valid |= ok << (15 - i);
+    }
+  }
+}
+
+// cooperative fill by a 256-thread block; src is 128-byte aligned
+__device__ __forceinline__ void mfx_tile_fill(mfx_tile_lds &L, const uint8_t *__restrict__ src) {
+  uint32_t *c32 = reinterpret_cast<uint32_t *>(L.codes);
+  uint16_t *v16 = reinterpret_cast<uint16_t *>(L.valid);
+  for (uint32_t ch = threadIdx.x; ch < MFX_TILE_CHUNKS; ch += MFX_BLOCK) {
+    uint4 v = *reinterpret_cast<const uint4 *>(src + 16ull * ch);
+    uint32_t codes, valid;
+    mfx_pack16(v, codes, valid);
+    c32[ch ^ 1] = codes;                // first 16 bases of a 32-base word are its HIGH half
+    v16[ch ^ 1] = (uint16_t)valid;
+  }
+}
+
+// k-mer starting at tile position p; returns validity (all k bases ACGT)
+__device__ __forceinline__ bool mfx_tile_kmer(const mfx_tile_lds &L, int k, uint32_t p, uint64_t &fwd) {
+  uint32_t w = p >> 5, o = p & 31;
+  uint64_t w0 = L.codes[w], w1 = L.codes[w + 1];
+  uint32_t sh = 2 * o;
+  uint64_t hi = (w0 << sh) | ((w1 >> 1) >> (63 - sh));
+  fwd = hi >> (64 - 2 * k);
+  uint64_t vv = (((uint64_t)L.valid[w] << 32) | L.valid[w + 1]) << o;
+  return (vv >> (64 - k)) == ((~0ULL) >> (64 - k));
+}
+
+// ===========================================================================
+// -hist
+// ===========================================================================
+
+__device__ __forceinline__ uint64_t mfx_wave_sum(uint64_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// block-wide sum of up to 3 uint64 values; result valid in thread 0
+__device__ __forceinline__ void mfx_block_sum3(uint64_t &a, uint64_t &b, uint64_t &c, uint64_t (*scratch)[3]) {
+  a = mfx_wave_sum(a); b = mfx_wave_sum(b); c = mfx_wave_sum(c);
+  uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) { scratch[wave][0] = a; scratch[wave][1] = b; scratch[wave][2] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a = b = c = 0;
+    for (uint32_t w = 0; w < MFX_BLOCK / 64; ++w) { a += scratch[w][0]; b += scratch[w][1]; c += scratch[w][2]; }
+  }
+}
+
+constexpr int MFX_BATCH = 4;          // independent probes in flight per lane
+
+template <bool CANON>
+__global__ __launch_bounds__(MFX_BLOCK) void mfx_hist_kernel(mfx_hist_args a) {
+  __shared__ mfx_tile_lds L;
+  __shared__ uint32_t s_hist[2 * MFX_NB_LDS];
+  __shared__ uint32_t s_probK[MFX_MAXP_LDS];
+  __shared__ double   s_probP[MFX_MAXP_LDS];
+  __shared__ uint64_t s_red[MFX_BLOCK / 64][3];
+  __shared__ double   s_dred[MFX_BLOCK];
+
+  const uint32_t tid = threadIdx.x;
+  const int k = a.t.k;
+
+  for (uint32_t i = tid; i < 2 * MFX_NB_LDS; i += MFX_BLOCK) s_hist[i] = 0;
+  const uint32_t np_lds = a.n_prob < MFX_MAXP_LDS ? a.n_prob : MFX_MAXP_LDS;
+  for (uint32_t i = tid; i < np_lds; i += MFX_BLOCK) { s_probK[i] = a.probK[i]; s_probP[i] = a.probP[i]; }
+
+  // contiguous run of tiles for this (persistent) block
+  const uint64_t ntl = a.tile_end - a.tile_begin;
+  const uint64_t per = (ntl + gridDim.x - 1) / gridDim.x;
+  uint64_t t0 = a.tile_begin + blockIdx.x * per;
+  uint64_t t1 = t0 + per < a.tile_end ? t0 + per : a.tile_end;
+
+  uint64_t n_valid = 0, n_missing = 0, n_over0 = 0;     // per-lane counters
+  double   kover = 0.0;                                  // per-lane koverCpy partial
+  uint64_t *c_undr = a.counts, *c_over = a.counts + a.nbins;
+  uint64_t *c_glob = a.counts + 2ull * a.nbins;          // kasm, kmissing, novf
+  uint64_t *c_kasm = c_glob + 3, *c_kmis = c_kasm + a.ncontigs;
+
+  if (t0 < t1) {
+    // contig of the first tile: largest c with tile_start[c] <= t0
+    uint32_t lo = 0, hi = a.ncontigs;
+    while (hi - lo > 1) {
+      uint32_t mid = lo + (hi - lo) / 2;
+      if (a.tile_start[mid] <= t0) lo = mid; else hi = mid;
+    }
+    uint32_t c = lo;
+
+    for (uint64_t tile = t0; tile < t1; ++tile) {
+      while (tile >= a.tile_start[c + 1]) {
+        // contig change (block-uniform): flush the per-contig counters
+        uint64_t x = n_valid, y = n_missing, z = 0;
+        mfx_block_sum3(x, y, z, s_red);
+        if (tid == 0 && (x | y)) {
+          atomicAdd((unsigned long long *)&c_kasm[c], x);
+          atomicAdd((unsigned long long *)&c_kmis[c], y);
+          atomicAdd((unsigned long long *)&c_glob[0], x);
+          atomicAdd((unsigned long long *)&c_glob[1], y);
+        }
+        n_valid = n_missing = 0;
+        ++c;
+      }
+      const uint64_t pos0 = (tile - a.tile_start[c]) * MFX_TILE;
+      const uint64_t clen = a.contig_len[c];
+      const uint32_t n = (clen - pos0 < MFX_TILE) ? (uint32_t)(clen - pos0) : MFX_TILE;
+      const uint8_t *src = a.bases + a.contig_off[c] + pos0;
+
+      __syncthreads();                       // previous tile fully consumed
+      mfx_tile_fill(L, src);
+      __syncthreads();
+
+      for (uint32_t b = 0; b < MFX_TILE / MFX_BLOCK; b += MFX_BATCH) {
+        uint64_t key[MFX_BATCH], key2[MFX_BATCH], line[MFX_BATCH], line2[MFX_BATCH];
+        uint32_t p1[MFX_BATCH], p2[MFX_BATCH];
+        uint4    s1[MFX_BATCH], s2[MFX_BATCH];
+        bool     ok[MFX_BATCH];
+#pragma unroll
+        for (int j = 0; j < MFX_BATCH; ++j) {
+          uint32_t p = (b + j) * MFX_BLOCK + tid;     // lane-consecutive positions
+          uint64_t f;
+          ok[j] = mfx_tile_kmer(L, k, p, f) && (p < n);
+          uint64_t r = mfx_revcomp(f, k);
+          if (CANON) {
+            key[j] = f < r ? f : r;
+          } else {
+            key[j] = f; key2[j] = r;
+          }
+          if (ok[j]) {
+            line[j] = mfx_home(a.t, key[j], p1[j]);
+            s1[j] = mfx_load_slot(a.t, line[j] * MFX_SLOTS_LINE + p1[j]);
+            if (!CANON) {
+              line2[j] = mfx_home(a.t, key2[j], p2[j]);
+              s2[j] = mfx_load_slot(a.t, line2[j] * MFX_SLOTS_LINE + p2[j]);
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < MFX_BATCH; ++j) {
+          if (!ok[j]) continue;
+          uint2 v = mfx_resolve(a.t, key[j], line[j], p1[j], s1[j]);
+          if (!CANON) {
+            // value(fmer) + value(rmer), uint32 arithmetic (merfin-globals.C:107-108)
+            uint2 v2 = mfx_resolve(a.t, key2[j], line2[j], p2[j], s2[j]);
+            v.x += v2.x; v.y += v2.y;
+          }
+          n_valid++;                                                   // merfin-histogram.C:58
+          double readK, prob;
+          const uint32_t rv = v.x;
+          if (rv > 0 && rv <= np_lds) {                                // LDS-resident -prob rows
+            readK = (double)s_probK[rv - 1]; prob = s_probP[rv - 1];
+          } else {
+            mfx_getK_core(a.peak, a.n_prob, a.probK, a.probP, rv, readK, prob);
+          }
+          const double asmK = (double)v.y;
+          if (readK == 0) { n_missing++; continue; }                   // :66-69
+          bool under = asmK > readK;                                   // :71
+          uint32_t idx = under ? mfx_bin_index(asmK, readK) : mfx_bin_index(readK, asmK);
+          if (under) kover += mfx_overcopy_term(readK, asmK, prob);    // :81
+          if (!under && idx == 0) { n_over0++; continue; }             // the dominant bin stays in a register
+          if (idx < MFX_NB_LDS) atomicAdd(&s_hist[(under ? 0 : MFX_NB_LDS) + idx], 1u);
+          else if (idx < a.nbins) atomicAdd((unsigned long long *)&(under ? c_undr : c_over)[idx], 1ull);
+          else {
+            unsigned long long w = atomicAdd((unsigned long long *)&a.ovf[0], 1ull);
+            if (w < MFX_OVF_CAP) a.ovf[1 + w] = (under ? 0ull : (1ull << 63)) | idx;
+            atomicAdd((unsigned long long *)&c_glob[2], 1ull);
+          }
+        }
+      }
+    }
+    // final per-contig flush
+    {
+      uint64_t x = n_valid, y = n_missing, z = n_over0;
+      mfx_block_sum3(x, y, z, s_red);
+      if (tid == 0) {
+        if (x | y) {
+          atomicAdd((unsigned long long *)&c_kasm[c], x);
+          atomicAdd((unsigned long long *)&c_kmis[c], y);
+          atomicAdd((unsigned long long *)&c_glob[0], x);
+          atomicAdd((unsigned long long *)&c_glob[1], y);
+        }
+        if (z) atomicAdd((unsigned long long *)&c_over[0], z);
+      }
+    }
+  }
+
+  // LDS bins -> global (non-zero only)
+  __syncthreads();
+  for (uint32_t i = tid; i < 2 * MFX_NB_LDS; i += MFX_BLOCK) {
+    uint32_t v = s_hist[i];
+    if (v) atomicAdd((unsigned long long *)&(i < MFX_NB_LDS ? c_undr[i] : c_over[i - MFX_NB_LDS]), (unsigned long long)v);
+  }
+
+  // koverCpy: fixed-order tree inside the block, one partial per block
+  s_dred[tid] = kover;
+  __syncthreads();
+  for (uint32_t s = MFX_BLOCK / 2; s > 0; s >>= 1) {
+    if (tid < s) s_dred[tid] = s_dred[tid] + s_dred[tid + s];
+    __syncthreads();
+  }
+  if (tid == 0) a.partials[blockIdx.x] = s_dred[0];
+}
+
+// sums the per-block partials in a fixed order and adds the result to *out
+__global__ __launch_bounds__(MFX_BLOCK) void mfx_sum_partials_kernel(const double *partials, uint32_t n, double *out) {
+  __shared__ double s[MFX_BLOCK];
+  double v = 0.0;
+  for (uint32_t i = threadIdx.x; i < n; i += MFX_BLOCK) v = v + partials[i];
+  s[threadIdx.x] = v;
+  __syncthreads();
+  for (uint32_t st = MFX_BLOCK / 2; st > 0; st >>= 1) {
+    if (threadIdx.x < st) s[threadIdx.x] = s[threadIdx.x] + s[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = out[0] + s[0];
+}
+
+// ===========================================================================
+// -dump: raw (readV, asmV) per k-mer start position of one contig range
+// ===========================================================================
+
+template <bool CANON>
+__global__ __launch_bounds__(MFX_BLOCK) void mfx_dump_kernel(mfx_dump_args a) {
+  __shared__ mfx_tile_lds L;
+  __shared__ uint64_t s_red[MFX_BLOCK / 64][3];
+  const uint32_t tid = threadIdx.x;
+  const int k = a.t.k;
+  const uint64_t pos0 = (uint64_t)blockIdx.x * MFX_TILE;
+  mfx_tile_fill(L, a.src + pos0);
+  __syncthreads();
+  uint64_t n_valid = 0, n_missing = 0, zz = 0;
+  for (uint32_t b = 0; b < MFX_TILE / MFX_BLOCK; ++b) {
+    uint32_t p = b * MFX_BLOCK + tid;
+    uint64_t gp = pos0 + p;
+    if (gp >= a.npos || gp < a.skip) continue;
+    uint64_t f;
+    bool ok = mfx_tile_kmer(L, k, p, f) && (gp < a.clen_left);
+    uint2 v = make_uint2(0u, 0u);
+    if (ok) {
+      uint64_t r = mfx_revcomp(f, k);
+      if (CANON) v = mfx_lookup(a.t, f < r ? f : r);
+      else { uint2 v1 = mfx_lookup(a.t, f), v2 = mfx_lookup(a.t, r); v = make_uint2(v1.x + v2.x, v1.y + v2.y); }
+      n_valid++;                                                    // merfin-dump.C:48
+      double readK, prob;
+      mfx_getK_core(a.peak, a.n_prob, a.probK, a.probP, v.x, readK, prob);
+      if (readK == 0) n_missing++;                                  // :56-58
+    }
+    a.readV[gp - a.skip] = v.x;
+    a.asmV[gp - a.skip] = v.y;
+  }
+  mfx_block_sum3(n_valid, n_missing, zz, s_red);
+  if (tid == 0 && (n_valid | n_missing)) {
+    atomicAdd((unsigned long long *)&a.stats[0], n_valid);
+    atomicAdd((unsigned long long *)&a.stats[1], n_missing);
+  }
+}
+
+// ===========================================================================
+// assembly k-mer counting (`meryl count` of -sequence): canonical k-mers of
+// every tile are inserted with asmV += 1.
+// ===========================================================================
+
+__global__ __launch_bounds__(MFX_BLOCK) void mfx_count_kernel(mfx_count_args a) {
+  __shared__ mfx_tile_lds L;
+  const uint32_t tid = threadIdx.x;
+  const int k = a.t.k;
+  for (uint64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    uint32_t lo = 0, hi = a.ncontigs;
+    while (hi - lo > 1) {
+      uint32_t mid = lo + (hi - lo) / 2;
+      if (a.tile_start[mid] <= tile) lo = mid; else hi = mid;
+    }
+    // skip empty contigs that share this tile_start
+    uint32_t c = lo;
+    const uint64_t pos0 = (tile - a.tile_start[c]) * MFX_TILE;
+    const uint64_t clen = a.contig_len[c];
+    const uint32_t n = (clen - pos0 < MFX_TILE) ? (uint32_t)(clen - pos0) : MFX_TILE;
+    __syncthreads();
+    mfx_tile_fill(L, a.bases + a.contig_off[c] + pos0);
+    __syncthreads();
+    for (uint32_t b = 0; b < MFX_TILE / MFX_BLOCK; ++b) {
+      uint32_t p = b * MFX_BLOCK + tid;
+      uint64_t f;
+      if (!(mfx_tile_kmer(L, k, p, f) && p < n)) continue;
+      uint64_t r = mfx_revcomp(f, k);
+      mfx_slot *sl = mfx_claim(a.t, f < r ? f : r, a.meta);
+      if (sl) atomicAdd(&sl->asmV, 1u);
+    }
+  }
+}
+
+// ===========================================================================
+// -completeness: one streaming pass over the joint table
+// (merfin-completeness.C:70-117; asm-only k-mers are skipped, :106-109; the
+// raw read value is used -- -min/-max do not apply there).
+// ===========================================================================
+__global__ __launch_bounds__(MFX_BLOCK) void mfx_completeness_kernel(mfx_table_view t, double peak, uint32_t n_prob,
+                                                                     const uint32_t *probK, const double *probP,
+                                                                     double *partials /* [2*grid] */) {
+  __shared__ double s0[MFX_BLOCK], s1[MFX_BLOCK];
+  uint64_t nslots = t.nlines * MFX_SLOTS_LINE;
+  uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  double total = 0.0, undrc = 0.0;
+  for (; i < nslots; i += stride) {
+    uint4 s = reinterpret_cast<const uint4 *>(t.slots)[i];
+    uint64_t key = (uint64_t)s.x | ((uint64_t)s.y << 32);
+    if (key == MFX_EMPTY || s.z == 0) continue;
+    double readK, prob;
+    mfx_getK_core(peak, n_prob, probK, probP, s.z, readK, prob);
+    double asmK = (double)s.w;
+    total = total + readK;                             // :113
+    if (readK > asmK) undrc = undrc + (readK - asmK);  // :115-116
+  }
+  s0[threadIdx.x] = total; s1[threadIdx.x] = undrc;
+  __syncthreads();
+  for (uint32_t st = MFX_BLOCK / 2; st > 0; st >>= 1) {
+    if (threadIdx.x < st) { s0[threadIdx.x] += s0[threadIdx.x + st]; s1[threadIdx.x] += s1[threadIdx.x + st]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { partials[2 * blockIdx.x] = s0[0]; partials[2 * blockIdx.x + 1] = s1[0]; }
+}
+
+// ===========================================================================
+// launch wrappers (called from mfx_api.cpp, which is compiled as plain C++)
+// ===========================================================================
+hipError_t mfx_k_table_init(mfx_slot *slots, uint64_t nslots, hipStream_t st) {
+  mfx_table_init_kernel<<<4096, 256, 0, st>>>(slots, nslots);
+  return hipGetLastError();
+}
+hipError_t mfx_k_table_add(mfx_table_view t, const uint64_t *kmers, const uint32_t *values, uint64_t n, int side,
+                           uint64_t *meta, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  uint64_t blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  mfx_table_add_kernel<<<(unsigned)blocks, 256, 0, st>>>(t, kmers, values, n, side, meta);
+  return hipGetLastError();
+}
+hipError_t mfx_k_table_value(mfx_table_view t, const uint64_t *kmers, uint64_t n, uint32_t *readV, uint32_t *asmV,
+                             hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  uint64_t blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  mfx_table_value_kernel<<<(unsigned)blocks, 256, 0, st>>>(t, kmers, n, readV, asmV);
+  return hipGetLastError();
+}
+hipError_t mfx_k_table_export(mfx_table_view t, uint64_t *kmers, uint32_t *readV, uint32_t *asmV,
+                              unsigned long long *count, hipStream_t st) {
+  mfx_table_export_kernel<<<4096, 256, 0, st>>>(t, kmers, readV, asmV, count);
+  return hipGetLastError();
+}
+hipError_t mfx_k_hist(const mfx_hist_args &a, int grid, hipStream_t st) {
+  if (a.canonical) mfx_hist_kernel<true><<<grid, MFX_BLOCK, 0, st>>>(a);
+  else             mfx_hist_kernel<false><<<grid, MFX_BLOCK, 0, st>>>(a);
+  return hipGetLastError();
+}
+hipError_t mfx_k_sum_partials(const double *partials, uint32_t n, double *out, hipStream_t st) {
+  mfx_sum_partials_kernel<<<1, MFX_BLOCK, 0, st>>>(partials, n, out);
+  return hipGetLastError();
+}
+hipError_t mfx_k_dump(const mfx_dump_args &a, hipStream_t st) {
+  uint64_t blocks = (a.npos + MFX_TILE - 1) / MFX_TILE;
+  if (blocks == 0) return hipSuccess;
+  if (a.canonical) mfx_dump_kernel<true><<<(unsigned)blocks, MFX_BLOCK, 0, st>>>(a);
+  else             mfx_dump_kernel<false><<<(unsigned)blocks, MFX_BLOCK, 0, st>>>(a);
+  return hipGetLastError();
+}
+hipError_t mfx_k_count(const mfx_count_args &a, hipStream_t st) {
+  if (a.ntiles == 0) return hipSuccess;
+  uint64_t blocks = a.ntiles < 8192 ? a.ntiles : 8192;
+  mfx_count_kernel<<<(unsigned)blocks, MFX_BLOCK, 0, st>>>(a);
+  return hipGetLastError();
+}
+hipError_t mfx_k_completeness(mfx_table_view t, double peak, uint32_t n_prob, const uint32_t *probK, const double *probP,
+                              double *partials, int grid, hipStream_t st) {
+  mfx_completeness_kernel<<<grid, MFX_BLOCK, 0, st>>>(t, peak, n_prob, probK, probP, partials);
+  return hipGetLastError();
+}

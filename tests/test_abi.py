@@ -1,0 +1,64 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol the
+header declares, its host-side K* helpers agree bit-for-bit with the oracle,
+and it refuses to run without a GPU (no CPU fallback)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _lib():
+    import merfin_amd as m
+    from merfin_amd import binding
+    return m, binding, m.load_library()
+
+
+def test_library_exports_every_declared_symbol():
+    m, binding, L = _lib()
+    hdr = open(os.path.join(ROOT, "include", "merfin_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(mfx_[a-z_A-Z0-9]+)\s*\(", hdr))
+    assert declared == set(binding.SYMBOLS), declared ^ set(binding.SYMBOLS)
+    for s in sorted(declared):
+        assert hasattr(L, s), s
+    assert b"gfx950" in L.mfx_version()
+
+
+def test_host_kstar_helpers_match_oracle(golden_dir):
+    m, _, _ = _lib()
+    K, P = po.load_kmetric(os.path.join(golden_dir, "example_lookup_table.txt"))
+    for kp, op in ((m.KParams(30.0), po.Params(21, 30.0)), (m.KParams(26.0, K, P), po.Params(21, 26.0, K, P)),
+                   (m.KParams(10.5), po.Params(21, 10.5))):
+        for rv in list(range(0, 260)) + [1000, 65535, 2**32 - 1]:
+            for av in (0, 1, 2, 3, 7, 1000):
+                a = m.getK(kp, rv, av)
+                assert a == po.getK_values(op, rv, av)
+                assert m.getKmetric(a[0], a[1]) == po.getKmetric(a[0], a[1])
+    assert m.histoQV(100, 1e6, 21) == po.histoQV(100, 1e6, 21)
+    kp2 = m.KParams.from_file(26.0, os.path.join(golden_dir, "example_lookup_table.txt"))
+    assert list(kp2.probK) == list(K) and list(kp2.probP) == list(P)
+
+
+def test_no_cpu_fallback_without_gpu():
+    m, _, _ = _lib()
+    if m.device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(m.MfxError) as e:
+        m.Index(21, 1000)
+    assert e.value.code == -8 and "no CPU path" in str(e.value)
+    with pytest.raises(m.MfxError):
+        m.Sequences([b"ACGT"])
+
+
+def test_product_never_touches_the_oracle():
+    """Nothing under merfin_amd/ may import, link or execute oracle/."""
+    for d, _, files in os.walk(os.path.join(ROOT, "merfin_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp", "Makefile", ".txt")):
+                s = open(os.path.join(d, f), errors="ignore").read()
+                assert "oracle" not in s.replace("no CPU fallback", ""), os.path.join(d, f)

@@ -1,0 +1,340 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the
+same seeded inputs.  Bar: bit-exact for every integer (histogram bins, kasm,
+kmissing, per-contig counts, dump values, index values); |rel| <= 1e-6 for
+koverCpy / QV / QV* (north_star); in practice koverCpy agrees to ~1e-15."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-6      # north_star tolerance for K*/QV* floats
+
+
+def _mfx():
+    import merfin_amd as m
+    if m.device_count() < 1:
+        pytest.fail("no HIP device visible: the GPU tests must run on the MI355X box")
+    return m
+
+
+def _trim(a):
+    a = np.asarray(a)
+    nz = np.nonzero(a)[0]
+    return a[: (nz[-1] + 1 if len(nz) else 0)]
+
+
+def build_index(m, k, read, asm, minV=0, maxV=2**64 - 1, cap=None):
+    rk, rv = read
+    ak, av = asm
+    ix = m.Index(k, cap or (len(rk) + len(ak) + 16))
+    ix.add_read(rk, rv, minV, maxV)
+    ix.add_asm(ak, av)
+    return ix
+
+
+def oracle_hist(k, peak, contigs, read, asm, probK=None, probP=None, minV=0, maxV=2**64 - 1):
+    p = po.Params(k, peak, probK, probP)
+    R = po.Lookup(k, read[0], read[1], minV, maxV)
+    A = po.Lookup(k, asm[0], asm[1])
+    g, ka, km, _ = po.hist_run(p, R, A, contigs, threads=4, mode=0)
+    return p, g, ka, km
+
+
+def assert_hist_equal(res, g, ka, km, k):
+    assert res.kasm == g.kasm
+    assert res.kmissing == g.kmissing
+    np.testing.assert_array_equal(_trim(res.undr()), _trim(g.undr()))
+    np.testing.assert_array_equal(_trim(res.over()), _trim(g.over()))
+    np.testing.assert_array_equal(res.contig_kasm(), ka)
+    np.testing.assert_array_equal(res.contig_kmissing(), km)
+    assert res.koverCpy == pytest.approx(g.koverCpy, rel=REL_TOL, abs=1e-9)
+    # tighter than the bar: only the summation order differs
+    assert res.koverCpy == pytest.approx(g.koverCpy, rel=1e-12, abs=1e-9)
+    if g.kasm:
+        import merfin_amd as m
+        qv_g = po.histoQV(g.kmissing, g.kasm, k)
+        qv_r = m.histoQV(res.kmissing, res.kasm, k)
+        assert qv_r == qv_g or (np.isinf(qv_r) and np.isinf(qv_g))
+        qs_g = po.histoQV(g.kmissing + g.koverCpy, g.kasm, k)
+        qs_r = m.histoQV(res.kmissing + res.koverCpy, res.kasm, k)
+        assert qs_r == pytest.approx(qs_g, rel=REL_TOL) or (np.isinf(qs_r) and np.isinf(qs_g))
+
+
+@pytest.mark.parametrize("k,peak,use_prob", [(21, 17.3, False), (21, 26.0, True), (31, 17.3, False), (15, 9.0, False)])
+def test_hist_matches_oracle(k, peak, use_prob, golden_dir):
+    m = _mfx()
+    contigs, read, asm = synth.world(k=k, peak=peak)
+    probK = probP = None
+    if use_prob:
+        probK, probP = po.load_kmetric(os.path.join(golden_dir, "example_lookup_table.txt"))
+    p, g, ka, km = oracle_hist(k, peak, contigs, read, asm, probK, probP)
+    ix = build_index(m, k, read, asm)
+    assert ix.info()["canonical"]
+    ev = m.Evaluator(ix, m.KParams(peak, probK, probP))
+    res = ev.hist(m.Sequences(contigs))
+    assert g.kasm > 40000 and g.kmissing > 0 and g.koverCpy > 0 and g.undr().sum() > 0
+    assert_hist_equal(res, g, ka, km, k)
+
+
+def test_hist_report_text_identical(tmp_path, golden_dir):
+    m = _mfx()
+    k, peak = 21, 26.0
+    contigs, read, asm = synth.world(k=k, peak=peak, seed=7)
+    probK, probP = po.load_kmetric(os.path.join(golden_dir, "example_lookup_table.txt"))
+    p, g, ka, km = oracle_hist(k, peak, contigs, read, asm, probK, probP)
+    po.report_histogram(p, g, str(tmp_path / "o.hist"), str(tmp_path / "o.sum"))
+    ix = build_index(m, k, read, asm)
+    res = m.Evaluator(ix, m.KParams(peak, probK, probP)).hist(m.Sequences(contigs))
+    res.report(k, str(tmp_path / "g.hist"), str(tmp_path / "g.sum"))
+    assert (tmp_path / "g.hist").read_bytes() == (tmp_path / "o.hist").read_bytes()
+    # summary: identical text (koverCpy printed %.2f)
+    assert (tmp_path / "g.sum").read_text() == (tmp_path / "o.sum").read_text()
+
+
+@pytest.mark.parametrize("k", [6, 8])
+def test_even_k_palindromes_two_strand_path(k):
+    """Even k: palindromic k-mers are their own reverse complement and the
+    reference adds value(f)+value(r) twice (merfin-globals.C:107-108)."""
+    m = _mfx()
+    contigs, read, asm = synth.world(k=k, peak=3.0, sizes=(3000, 700, 4100), err_kmers=0, tandem=None)
+    p, g, ka, km = oracle_hist(k, 3.0, contigs, read, asm)
+    ix = build_index(m, k, read, asm)
+    res = m.Evaluator(ix, m.KParams(3.0)).hist(m.Sequences(contigs))
+    assert_hist_equal(res, g, ka, km, k)
+
+
+def test_non_canonical_db_two_strand_path():
+    """A DB holding forward (non-canonical) k-mers: both strands are probed and summed."""
+    m = _mfx()
+    k = 11
+    r = synth.rng(3)
+    contigs = synth.as_bytes(synth.decorate(r, synth.make_truth(r, (6000, 2500))))
+    # forward-strand k-mer counts (not canonicalised)
+    fw = {}
+    for c in contigs:
+        for _, f, _r in po.kiter(k, c):
+            fw[f] = fw.get(f, 0) + 1
+    ak = np.array(sorted(fw), dtype=np.uint64)
+    av = np.array([fw[x] for x in ak.tolist()], dtype=np.uint32)
+    rv = (av * 5 + (ak % 3).astype(np.uint32)).astype(np.uint32)
+    p, g, ka, km = oracle_hist(k, 5.0, contigs, (ak, rv), (ak, av))
+    ix = build_index(m, k, (ak, rv), (ak, av))
+    assert not ix.info()["canonical"]
+    res = m.Evaluator(ix, m.KParams(5.0)).hist(m.Sequences(contigs))
+    assert_hist_equal(res, g, ka, km, k)
+
+
+def test_forced_two_strand_equals_canonical(monkeypatch):
+    m = _mfx()
+    k, peak = 21, 17.3
+    contigs, read, asm = synth.world(k=k, peak=peak, seed=11)
+    ix = build_index(m, k, read, asm)
+    ev = m.Evaluator(ix, m.KParams(peak))
+    seqs = m.Sequences(contigs)
+    a = ev.hist(seqs)
+    monkeypatch.setenv("MFX_FORCE_TWO_STRAND", "1")
+    b = ev.hist(seqs)
+    assert a.kasm == b.kasm and a.kmissing == b.kmissing
+    np.testing.assert_array_equal(a.undr(), b.undr())
+    np.testing.assert_array_equal(a.over(), b.over())
+
+
+def test_min_max_filter():
+    m = _mfx()
+    k, peak = 21, 17.3
+    contigs, read, asm = synth.world(k=k, peak=peak, seed=5)
+    p, g, ka, km = oracle_hist(k, peak, contigs, read, asm, minV=4, maxV=40)
+    ix = build_index(m, k, read, asm, minV=4, maxV=40)
+    res = m.Evaluator(ix, m.KParams(peak)).hist(m.Sequences(contigs))
+    assert_hist_equal(res, g, ka, km, k)
+    # value() applies the same load-time filter semantics
+    R = po.Lookup(k, read[0], read[1], 4, 40)
+    q = read[0][:5000]
+    rv, _ = ix.value(q)
+    np.testing.assert_array_equal(rv, np.array([R.value(x) for x in q.tolist()], dtype=np.uint32))
+
+
+def test_index_value_and_export():
+    m = _mfx()
+    k = 21
+    contigs, read, asm = synth.world(k=k, seed=9)
+    ix = build_index(m, k, read, asm)
+    R, A = po.Lookup(k, *read), po.Lookup(k, *asm)
+    r = synth.rng(1)
+    q = np.concatenate([read[0][::7], asm[0][::5], r.integers(0, 4 ** k, size=3000, dtype=np.uint64)])
+    rv, av = ix.value(q)
+    np.testing.assert_array_equal(rv, np.array([R.value(x) for x in q.tolist()], dtype=np.uint32))
+    np.testing.assert_array_equal(av, np.array([A.value(x) for x in q.tolist()], dtype=np.uint32))
+    ek, er, ea = ix.export()
+    union = np.union1d(read[0], asm[0])
+    np.testing.assert_array_equal(ek, union)
+    assert ix.info()["distinct"] == len(union)
+    np.testing.assert_array_equal(er, np.array([R.value(x) for x in ek.tolist()], dtype=np.uint32))
+    np.testing.assert_array_equal(ea, np.array([A.value(x) for x in ek.tolist()], dtype=np.uint32))
+
+
+def test_count_asm_matches_meryl_count_restatement():
+    """mfx_index_count_asm replaces `meryl count` of -sequence (merfin-globals.C:182-186)."""
+    m = _mfx()
+    k = 21
+    contigs, read, asm = synth.world(k=k, seed=13)
+    ix = m.Index(k, len(read[0]) + len(asm[0]) + 16)
+    ix.add_read(*read)
+    seqs = m.Sequences(contigs)
+    ix.count_asm(seqs)
+    _, av = ix.value(asm[0])
+    np.testing.assert_array_equal(av, asm[1])
+    ek, er, ea = ix.export()
+    assert int(ea.sum()) == int(asm[1].sum())
+    assert ix.info()["canonical"]
+
+
+def test_dump_values_and_text(tmp_path, golden_dir):
+    m = _mfx()
+    k, peak = 21, 26.0
+    contigs, read, asm = synth.world(k=k, peak=peak, seed=21, sizes=(20000, 4096, 4117, 300, 10))
+    probK, probP = po.load_kmetric(os.path.join(golden_dir, "example_lookup_table.txt"))
+    p = po.Params(k, peak, probK, probP)
+    R, A = po.Lookup(k, *read), po.Lookup(k, *asm)
+    ix = build_index(m, k, read, asm)
+    kp = m.KParams(peak, probK, probP)
+    ev = m.Evaluator(ix, kp)
+    seqs = m.Sequences(contigs)
+    opath, gpath = str(tmp_path / "o.dump"), str(tmp_path / "g.dump")
+    for ci, c in enumerate(contigs):
+        rk, ak_, km_, kasm, kmiss = po.process_dump(p, R, A, c)
+        po.output_dump(opath, "ctg%d" % ci, rk, ak_, km_, append=ci > 0)
+        rv, av, gkasm, gkmiss = ev.dump_values(seqs, ci, 0, len(c))
+        assert (gkasm, gkmiss) == (kasm, kmiss)
+        # readK/asmK/K* recomputed on the host from the raw values are bit-identical
+        for i in range(0, len(c), 37):
+            a, b, _ = m.getK(kp, int(rv[i]), int(av[i]))
+            assert (a, b, m.getKmetric(a, b)) == (rk[i], ak_[i], km_[i])
+        # a sub-range that does not start on a tile boundary
+        if len(c) > 5000:
+            rv2, av2, _, _ = ev.dump_values(seqs, ci, 4099, 4999)
+            np.testing.assert_array_equal(rv2, rv[4099:4999])
+            np.testing.assert_array_equal(av2, av[4099:4999])
+        ka2, km2 = ev.dump_contig(seqs, ci, "ctg%d" % ci, gpath, append=ci > 0)
+        assert (ka2, km2) == (kasm, kmiss)
+    assert open(gpath, "rb").read() == open(opath, "rb").read()
+    assert os.path.getsize(gpath) > 100000
+
+
+def test_completeness_matches_merge_loop():
+    m = _mfx()
+    k, peak = 21, 17.3
+    contigs, read, asm = synth.world(k=k, peak=peak, seed=17)
+    p = po.Params(k, peak)
+    # the reference merges 64 pieces (top 6 bits of the k-mer); sums are of integers, so exact
+    tot = und = 0.0
+    for piece in range(64):
+        lo, hi = piece << (2 * k - 6), (piece + 1) << (2 * k - 6)
+        rs = (read[0] >= lo) & (read[0] < hi)
+        as_ = (asm[0] >= lo) & (asm[0] < hi)
+        t, u = po.completeness_piece(p, read[0][rs], read[1][rs], asm[0][as_], asm[1][as_])
+        tot += t
+        und += u
+    ix = build_index(m, k, read, asm)
+    t, u = m.Evaluator(ix, m.KParams(peak)).completeness()
+    assert (t, u) == (tot, und) and tot > 0 and und > 0
+
+
+def test_large_bins_overflow_path():
+    """asmK/readK ratios beyond the dense device bins go through the overflow list."""
+    m = _mfx()
+    k = 9
+    seq = (b"ACGTTGCAAGGCTTAACCGGTTAAGCGCTAGCTAGGATCCGATCGATTACGCGCGATATATCGCGGCTA" * 3)
+    ak, av = po.count_kmers(k, [seq])
+    av = av.copy()
+    av[0] = 3000000            # readK=1 -> idx ~ 1.5e7  (beyond nbins)
+    av[1] = 7001               # idx 35000: beyond the LDS bins, inside the dense device bins
+    av[2] = 1500               # idx 7495
+    rv = np.ones(len(ak), dtype=np.uint32) * 5
+    p, g, ka, km = oracle_hist(k, 5.0, [seq], (ak, rv), (ak, av))
+    ix = build_index(m, k, (ak, rv), (ak, av))
+    res = m.Evaluator(ix, m.KParams(5.0), nbins=40000).hist(m.Sequences([seq]))
+    assert g.undrMax > 40000
+    assert_hist_equal(res, g, ka, km, k)
+
+
+def test_tile_and_contig_edge_cases():
+    """Empty / shorter-than-k / tile-sized contigs, N at tile edges, lower case."""
+    m = _mfx()
+    k = 21
+    r = synth.rng(99)
+    base = synth.random_contig(r, 3 * 4096 + 50)
+    base[4095] = ord("N"); base[4096 + 20] = ord("n"); base[8191 - 10: 8191 + 10] |= 0x20
+    contigs = [b"", b"ACGT", base.tobytes(), synth.random_contig(r, 4096).tobytes(), b"N" * 5000,
+               synth.random_contig(r, 20).tobytes(), synth.random_contig(r, 21).tobytes(),
+               synth.random_contig(r, 4096 + 20).tobytes(), b""]
+    ak, av = po.count_kmers(k, contigs)
+    rv = (3 + (ak % 40)).astype(np.uint32)
+    p, g, ka, km = oracle_hist(k, 9.5, contigs, (ak, rv), (ak, av))
+    ix = build_index(m, k, (ak, rv), (ak, av))
+    ev = m.Evaluator(ix, m.KParams(9.5))
+    seqs = m.Sequences(contigs)
+    assert seqs.ncontigs == len(contigs) and seqs.nbases == sum(len(c) for c in contigs)
+    res = ev.hist(seqs)
+    assert_hist_equal(res, g, ka, km, k)
+    assert list(ka[[0, 1, 4, 5, 8]]) == [0, 0, 0, 0, 0] and ka[6] == 1
+
+
+def test_sharded_launch_equals_whole(golden_dir):
+    """Position-tile sharding (the multi-GPU decomposition): any split of the tile
+    range accumulates to the same integers; koverCpy to the same value within 1e-12."""
+    torch = pytest.importorskip("torch")
+    m = _mfx()
+    k, peak = 21, 17.3
+    contigs, read, asm = synth.world(k=k, peak=peak, seed=23)
+    ix = build_index(m, k, read, asm)
+    ev = m.Evaluator(ix, m.KParams(peak))
+    seqs = m.Sequences(contigs)
+    whole = ev.hist(seqs)
+    T = seqs.ntiles
+    words = m.hist_words(ev.nbins, seqs.ncontigs)
+    for nshard in (2, 3, 8):
+        counts = torch.zeros(words, dtype=torch.int64, device="cuda")
+        kover = torch.zeros(1, dtype=torch.float64, device="cuda")
+        s = torch.cuda.current_stream().cuda_stream
+        for rnk in range(nshard):
+            ev.hist_launch(seqs, T * rnk // nshard, T * (rnk + 1) // nshard, counts, kover, stream=s)
+        torch.cuda.synchronize()
+        res = ev.result_from_counts(counts.cpu().numpy().view(np.uint64), float(kover.item()), seqs.ncontigs)
+        assert res.kasm == whole.kasm and res.kmissing == whole.kmissing
+        np.testing.assert_array_equal(res.undr(), whole.undr())
+        np.testing.assert_array_equal(res.over(), whole.over())
+        np.testing.assert_array_equal(res.contig_kasm(), whole.contig_kasm())
+        assert res.koverCpy == pytest.approx(whole.koverCpy, rel=1e-12)
+
+
+def test_revcomp_symmetry():
+    """Property: the reverse-complemented assembly has the same histogram (both strands are summed)."""
+    m = _mfx()
+    k, peak = 21, 17.3
+    contigs, read, asm = synth.world(k=k, peak=peak, seed=29, sizes=(30000, 5000))
+    comp = bytes.maketrans(b"ACGTacgt", b"TGCAtgca")
+    rc = [c.translate(comp)[::-1] for c in contigs]
+    ix = build_index(m, k, read, asm)
+    ev = m.Evaluator(ix, m.KParams(peak))
+    a, b = ev.hist(m.Sequences(contigs)), ev.hist(m.Sequences(rc))
+    assert (a.kasm, a.kmissing) == (b.kasm, b.kmissing)
+    np.testing.assert_array_equal(a.undr(), b.undr())
+    np.testing.assert_array_equal(a.over(), b.over())
+    assert a.koverCpy == pytest.approx(b.koverCpy, rel=1e-12)
+
+
+def test_index_full_is_reported():
+    m = _mfx()
+    k = 21
+    r = synth.rng(4)
+    kmers = np.unique(r.integers(0, 4 ** k, size=200000, dtype=np.uint64))
+    ix = m.Index(k, 1000)        # far too small (1024 lines = 8192 slots minimum)
+    with pytest.raises(m.MfxError) as e:
+        ix.add_asm(kmers, np.ones(len(kmers), dtype=np.uint32))
+    assert e.value.code == -4
