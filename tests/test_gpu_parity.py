@@ -259,7 +259,7 @@ def test_large_bins_overflow_path():
     p, g, ka, km = oracle_hist(k, 5.0, [seq], (ak, rv), (ak, av))
     ix = build_index(m, k, (ak, rv), (ak, av))
     res = m.Evaluator(ix, m.KParams(5.0), nbins=40000).hist(m.Sequences([seq]))
-    assert g.undrMax > 40000
+    assert g.c.undrMax > 40000
     assert_hist_equal(res, g, ka, km, k)
 
 
