@@ -57,6 +57,23 @@ SYMBOLS = [
 ]
 
 
+def _share_hip_runtime_with_torch():
+    """A process must hold ONE HIP/HSA runtime.  PyTorch-ROCm wheels bundle their
+    own libamdhip64.so; if libmerfin_amd.so pulled in /opt/rocm's copy first, a
+    later `import torch` would start a second runtime that sees no GPU.  So when
+    torch is installed, map its copy first (same SONAME: ours then binds to it)."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        p = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(p):
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def load_library():
     """Load libmerfin_amd.so.  Fails loudly when the HIP library was not built."""
     global _lib
@@ -66,6 +83,7 @@ def load_library():
     if not os.path.exists(p):
         raise ImportError("merfin_amd: %s is missing -- build it with `make -C merfin_amd/csrc` "
                           "(or __graft_entry__.build()); there is no CPU fallback" % p)
+    _share_hip_runtime_with_torch()
     L = C.CDLL(p)
     u64p, u32p, f64p, vp = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.c_void_p
     L.mfx_last_error.restype = C.c_char_p
