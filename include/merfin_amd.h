@@ -175,8 +175,9 @@ void mfx_hist_result_free(mfx_hist_result *r);
 #define MFX_HIST_WORDS(nbins, ncontigs) (2ull * (nbins) + 3ull + 2ull * (ncontigs))
 int mfx_hist_launch(mfx_eval *ev, const mfx_seq *seq, uint64_t tile_begin, uint64_t tile_end,
                     uint64_t *d_counts, double *d_kover, void *stream);
-/* turn an (all-reduced, host-resident) d_counts/d_kover image into a result */
-int mfx_hist_result_from_counts(const mfx_eval *ev, const uint64_t *h_counts, double kover,
+/* turn an (all-reduced, host-resident) d_counts/d_kover image into a result
+ * (pure host code: usable without a device, e.g. on the reducing rank) */
+int mfx_hist_result_from_counts(uint32_t nbins, const uint64_t *h_counts, double kover,
                                 uint32_t ncontigs, mfx_hist_result *out);
 /* K* bins >= nbins seen by launches on this evaluator since the last call:
  * copies up to `cap` records (bit 63 = 1 for `over`, low bits = bin index). */

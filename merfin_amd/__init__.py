@@ -9,9 +9,9 @@ without the HIP library or without a GPU raises.
 """
 from .binding import (  # noqa: F401
     MfxError, Index, Sequences, Evaluator, HistResult, KParams,
-    lib_path, load_library, device_count, getK, getKmetric, histoQV, hist_words,
+    lib_path, load_library, device_count, getK, getKmetric, histoQV, hist_words, result_from_counts,
     TILE,
 )
 
 __all__ = ["MfxError", "Index", "Sequences", "Evaluator", "HistResult", "KParams", "lib_path",
-           "load_library", "device_count", "getK", "getKmetric", "histoQV", "hist_words", "TILE"]
+           "load_library", "device_count", "getK", "getKmetric", "histoQV", "hist_words", "result_from_counts", "TILE"]

@@ -125,7 +125,7 @@ def load_library():
     L.mfx_hist_run.argtypes = [vp, vp, C.POINTER(_HistResult)]
     L.mfx_hist_result_free.argtypes = [C.POINTER(_HistResult)]
     L.mfx_hist_launch.argtypes = [vp, vp, C.c_uint64, C.c_uint64, vp, vp, vp]
-    L.mfx_hist_result_from_counts.argtypes = [vp, u64p, C.c_double, C.c_uint32, C.POINTER(_HistResult)]
+    L.mfx_hist_result_from_counts.argtypes = [C.c_uint32, u64p, C.c_double, C.c_uint32, C.POINTER(_HistResult)]
     L.mfx_hist_take_overflow.argtypes = [vp, u64p, C.c_uint64, u64p]
     L.mfx_hist_report.argtypes = [C.POINTER(_HistResult), C.c_int, C.c_char_p, C.c_char_p]
     L.mfx_dump_values.argtypes = [vp, vp, C.c_uint32, C.c_uint64, C.c_uint64, u32p, u32p, u64p, u64p]
@@ -342,6 +342,16 @@ class HistResult:
             pass
 
 
+def result_from_counts(nbins, h_counts, kover, ncontigs):
+    """(all-reduced) counts image -> HistResult; host-only, needs no device"""
+    h_counts = np.ascontiguousarray(h_counts, dtype=np.uint64)
+    assert len(h_counts) >= hist_words(nbins, ncontigs)
+    r = HistResult()
+    _check(load_library().mfx_hist_result_from_counts(nbins, h_counts.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                      float(kover), ncontigs, C.byref(r.c)))
+    return r
+
+
 class Evaluator:
     """K* parameters bound to an Index; runs -hist / -dump / -completeness."""
 
@@ -367,11 +377,7 @@ class Evaluator:
                                               C.c_void_p(stream or 0)))
 
     def result_from_counts(self, h_counts, kover, ncontigs):
-        h_counts = np.ascontiguousarray(h_counts, dtype=np.uint64)
-        r = HistResult()
-        _check(load_library().mfx_hist_result_from_counts(self.h, h_counts.ctypes.data_as(C.POINTER(C.c_uint64)),
-                                                          float(kover), ncontigs, C.byref(r.c)))
-        return r
+        return result_from_counts(self.nbins, h_counts, kover, ncontigs)
 
     def take_overflow(self, cap=1 << 20):
         rec = np.zeros(cap, dtype=np.uint64)

@@ -503,11 +503,11 @@ static void result_grow(uint64_t *&a, uint32_t &max, uint64_t need) {
   max = (uint32_t)nm;
 }
 
-extern "C" int mfx_hist_result_from_counts(const mfx_eval *ev, const uint64_t *h, double kover, uint32_t ncontigs,
+extern "C" int mfx_hist_result_from_counts(uint32_t nbins, const uint64_t *h, double kover, uint32_t ncontigs,
                                            mfx_hist_result *out) {
-  if (!ev || !h || !out) return mfx_fail(MFX_E_INVAL, "mfx_hist_result_from_counts: null argument");
+  if (!nbins || !h || !out) return mfx_fail(MFX_E_INVAL, "mfx_hist_result_from_counts: null argument");
   memset(out, 0, sizeof(*out));
-  const uint32_t nb = ev->nbins;
+  const uint32_t nb = nbins;
   uint32_t um = 0, om = 0;
   for (uint32_t i = 0; i < nb; ++i) {
     if (h[i]) um = i + 1;
@@ -554,7 +554,7 @@ extern "C" int mfx_hist_run(mfx_eval *ev, const mfx_seq *seq, mfx_hist_result *o
   double kover = 0;
   MFX_HIP(hipMemcpy(h.data(), dc.p, words * sizeof(uint64_t), hipMemcpyDeviceToHost));
   MFX_HIP(hipMemcpy(&kover, dk.p, sizeof(double), hipMemcpyDeviceToHost));
-  rc = mfx_hist_result_from_counts(ev, h.data(), kover, seq->ncontigs, out);
+  rc = mfx_hist_result_from_counts(ev->nbins, h.data(), kover, seq->ncontigs, out);
   if (rc) return rc;
   uint64_t novf = h[2ull * ev->nbins + 2];
   if (novf) {

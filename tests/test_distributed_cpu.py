@@ -1,0 +1,83 @@
+"""N>1 path on CPU (gloo, world_size 2): tile sharding covers every k-mer once,
+the counts image survives the all-reduce, and the reduced result equals the
+single-process oracle result.  Each rank fabricates its partial image with the
+ORACLE over its tile shard (the HIP kernel needs a GPU; the decomposition,
+image layout, collective and result assembly are what is under test here)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from oracle import pyoracle as po
+    from tests import synth
+    import merfin_amd as m
+    from merfin_amd import distributed as D
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    k, peak, nbins = 21, 17.3, 2048
+    contigs, read, asm = synth.world(k=k, peak=peak, seed=31, sizes=(30000, 9000, 4096, 4097, 500, 20, 0, 8191))
+    p = po.Params(k, peak)
+    R, A = po.Lookup(k, *read), po.Lookup(k, *asm)
+    tiles = D.tile_table([len(c) for c in contigs])
+    lo, hi = D.shard(len(tiles), rank, world)
+    nc = len(contigs)
+    undr = np.zeros(nbins, dtype=np.uint64)
+    over = np.zeros(nbins, dtype=np.uint64)
+    ka, km = np.zeros(nc, dtype=np.uint64), np.zeros(nc, dtype=np.uint64)
+    kover = 0.0
+    for c, p0, n in tiles[lo:hi]:
+        # k-mers STARTING in [p0, p0+n): bases up to p0+n+k-2
+        h = po.process_histogram(p, R, A, contigs[c][p0:p0 + n + k - 1])
+        u, o = h.undr(), h.over()
+        undr[:len(u)] += u
+        over[:len(o)] += o
+        ka[c] += h.kasm
+        km[c] += h.kmissing
+        kover += h.koverCpy
+    img = D.pack_counts(nbins, nc, undr, over, int(ka.sum()), int(km.sum()), ka, km)
+    counts = torch.from_numpy(img.view(np.int64).copy())
+    kov = torch.tensor([kover], dtype=torch.float64)
+    D.all_reduce_hist(counts, kov)
+    res = D.reduced_result(nbins, nc, counts, kov)
+    if rank == 0:
+        g, gka, gkm, _ = po.hist_run(p, R, A, contigs, threads=2)
+        ok = (res.kasm == g.kasm and res.kmissing == g.kmissing
+              and (res.undr()[:nbins] == np.pad(g.undr(), (0, nbins))[:nbins]).all()
+              and (res.over()[:nbins] == np.pad(g.over(), (0, nbins))[:nbins]).all()
+              and (res.contig_kasm() == gka).all() and (res.contig_kmissing() == gkm).all()
+              and abs(res.koverCpy - g.koverCpy) <= 1e-9 * max(1.0, g.koverCpy) and g.kasm > 50000)
+        open(os.path.join(tmp, "ok"), "w").write("1" if ok else "0 %r %r" % ((res.kasm, res.kmissing), (g.kasm, g.kmissing)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_reduction(tmp_path):
+    torch = pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok").read_text() == "1"
+
+
+def test_shard_partition_properties():
+    sys.path.insert(0, ROOT)
+    from merfin_amd import distributed as D
+    for T in (0, 1, 7, 732436):
+        for world in (1, 2, 3, 4, 8):
+            r = [D.shard(T, i, world) for i in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == T
+            assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
+            assert max(h - l for l, h in r) - min(h - l for l, h in r) <= 1
+    tt = D.tile_table([0, 5, 4096, 4097, 10000])
+    assert [t for t in tt if t[0] == 3] == [(3, 0, 4096), (3, 4096, 1)]
+    assert sum(n for _, _, n in tt) == 5 + 4096 + 4097 + 10000
