@@ -75,6 +75,25 @@ int mfx_index_add_read(mfx_index *ix, const uint64_t *kmers, const uint32_t *val
 int mfx_index_add_asm(mfx_index *ix, const uint64_t *kmers, const uint32_t *values, uint64_t n,
                       int on_device);
 
+/* merylFileReader(path) (merfin-globals.C:118-119,139): open a k-mer database
+ * and learn k ("Make readDB first so we know the k size") and its size.
+ * Accepted forms: a meryl database directory (decoder UNVALIDATED, see
+ * csrc/mfx_db.cpp), `meryl print` text (<kmer>\t<count>, optionally .gz/.bz2/.xz)
+ * and this library's flat binary (mfx_db_write_flat). */
+#define MFX_DB_MERYL 1
+#define MFX_DB_TEXT  2
+#define MFX_DB_FLAT  3
+typedef struct {
+  int      k;
+  int      format;         /* MFX_DB_*                                        */
+  uint64_t n_kmers;        /* distinct k-mers stored                          */
+} mfx_db_info;
+int mfx_db_probe(const char *path, mfx_db_info *out);
+/* merylExactLookup::load from disk: side 0 = read DB (-min/-max apply,
+ * merfin-globals.C:156), side 1 = assembly DB (:159). */
+int mfx_index_load_db(mfx_index *ix, const char *path, int side, uint64_t minV, uint64_t maxV);
+int mfx_db_write_flat(const char *path, int k, const uint64_t *kmers, const uint32_t *values, uint64_t n);
+
 typedef struct mfx_seq mfx_seq;
 
 /* Native replacement of the `meryl count k=.. <seq> output <seq>.meryl` child

@@ -33,6 +33,10 @@ class _Info(C.Structure):
                 ("distinct", C.c_uint64), ("bytes", C.c_uint64)]
 
 
+class _DbInfo(C.Structure):
+    _fields_ = [("k", C.c_int), ("format", C.c_int), ("n_kmers", C.c_uint64)]
+
+
 class _HistResult(C.Structure):
     _fields_ = [("kasm", C.c_uint64), ("kmissing", C.c_uint64), ("koverCpy", C.c_double),
                 ("undrMax", C.c_uint32), ("overMax", C.c_uint32),
@@ -48,6 +52,7 @@ SYMBOLS = [
     "mfx_last_error", "mfx_last_error_code", "mfx_version", "mfx_device_count",
     "mfx_index_create", "mfx_index_free", "mfx_index_estimate_gb", "mfx_index_add_read", "mfx_index_add_asm",
     "mfx_index_count_asm", "mfx_index_value", "mfx_index_get_info", "mfx_index_export",
+    "mfx_db_probe", "mfx_index_load_db", "mfx_db_write_flat",
     "mfx_seq_upload", "mfx_seq_from_device", "mfx_seq_free", "mfx_seq_num_contigs", "mfx_seq_num_bases",
     "mfx_seq_num_tiles",
     "mfx_eval_create", "mfx_eval_free", "mfx_eval_nbins", "mfx_getK", "mfx_getKmetric", "mfx_histoQV",
@@ -101,6 +106,9 @@ def load_library():
     L.mfx_index_value.argtypes = [vp, u64p, C.c_uint64, u32p, u32p]
     L.mfx_index_get_info.argtypes = [vp, C.POINTER(_Info)]
     L.mfx_index_export.argtypes = [vp, u64p, u32p, u32p, u64p]
+    L.mfx_db_probe.argtypes = [C.c_char_p, C.POINTER(_DbInfo)]
+    L.mfx_index_load_db.argtypes = [vp, C.c_char_p, C.c_int, C.c_uint64, C.c_uint64]
+    L.mfx_db_write_flat.argtypes = [C.c_char_p, C.c_int, u64p, u32p, C.c_uint64]
     L.mfx_seq_upload.restype = vp
     L.mfx_seq_upload.argtypes = [C.c_int, C.POINTER(C.c_char_p), u64p, C.c_uint32]
     L.mfx_seq_from_device.restype = vp
@@ -193,6 +201,20 @@ def histoQV(kval, ktot, k):
     return load_library().mfx_histoQV(kval, ktot, k)
 
 
+def db_probe(path):
+    """merylFileReader(path): (k, format, n_kmers) of a k-mer database on disk"""
+    i = _DbInfo()
+    _check(load_library().mfx_db_probe(path.encode(), C.byref(i)))
+    return {"k": i.k, "format": {1: "meryl", 2: "text", 3: "flat"}.get(i.format), "n_kmers": i.n_kmers}
+
+
+def db_write_flat(path, k, kmers, values):
+    kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
+    values = np.ascontiguousarray(values, dtype=np.uint32)
+    _check(load_library().mfx_db_write_flat(path.encode(), k, kmers.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                            values.ctypes.data_as(C.POINTER(C.c_uint32)), len(kmers)))
+
+
 def _ptr(x):
     """host numpy array or device pointer (int / torch tensor) -> (void*, on_device, keepalive)"""
     if isinstance(x, np.ndarray):
@@ -226,6 +248,10 @@ class Index:
         pk, dev, _k1 = _ptr(kmers)
         pv, _, _k2 = _ptr(values)
         _check(load_library().mfx_index_add_asm(self.h, pk, pv, len(kmers), dev))
+
+    def load_db(self, path, side, minV=0, maxV=2**64 - 1):
+        """side 0: read DB (-min/-max), side 1: assembly DB"""
+        _check(load_library().mfx_index_load_db(self.h, path.encode(), side, minV, maxV))
 
     def count_asm(self, seqs, stream=None):
         _check(load_library().mfx_index_count_asm(self.h, seqs.h, C.c_void_p(stream or 0)))

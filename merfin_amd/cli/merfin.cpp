@@ -1,0 +1,266 @@
+// merfin (MI355X) -- command-line driver with the flag surface of the reference
+// driver (src/merfin/merfin.C:79-155, validation :159-181) on top of the
+// merfin_amd C ABI.  The pthread sweatShop pipeline (merfin.C:366-414) is
+// replaced by: read all contigs -> pack into HBM -> one kernel launch per mode.
+//
+// Implemented report types: -hist, -dump, -completeness.
+// -filter/-polish/-better/-strict/-loose (varMer scoring) are recognised and
+// rejected with a clear message in this build.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <libgen.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/merfin_amd.h"
+#include "fasta.h"
+
+enum { OP_NONE, OP_HIST, OP_COMPL, OP_DUMP, OP_FILTER, OP_POLISH, OP_BETTER, OP_STRICT, OP_LOOSE };
+
+struct Globals {
+  const char *seqName = nullptr, *seqDBname = nullptr, *readDBname = nullptr, *pLookupTable = nullptr;
+  const char *vcfName = nullptr, *outName = nullptr;
+  double peak = 0, maxMemory = 0;
+  uint64_t minV = 0, maxV = ~0ull;
+  int threads = 0, reportType = OP_NONE, device = 0;
+  unsigned comb = 15;
+  bool nosplit = false, debug = false, skipMissing = false;
+  std::vector<uint32_t> copyKmerK;
+  std::vector<double> copyKmerP;
+};
+
+static void usage(const char *exe) {
+  fprintf(stderr,
+          "usage: %s <report-type> -sequence <seq.fasta> -readmers <read.meryl> -peak <haploid_peak>\n"
+          "          [-prob <lookup_table>] [-seqmers <seq.meryl>] [-vcf <input.vcf>] -output <output>\n\n"
+          "  Evaluates every k-mer of <seq.fasta> against the read k-mer database on an MI355X GPU.\n"
+          "  Inputs: FASTA/FASTQ, plain or gz/bz2/xz.  K-mer databases: meryl directory, `meryl print`\n"
+          "  text, or the flat binary written by mfx_db_write_flat.  k is taken from -readmers.\n\n"
+          "    -min m / -max m   ignore read k-mers with value below / above m\n"
+          "    -memory m         do not use more than m GB (of HBM) for the k-mer tables\n"
+          "    -threads t        accepted for compatibility (host threads)\n"
+          "    -peak m           haploid k-mer coverage peak (required except -filter)\n"
+          "    -prob file        readK,prob rows; row n overrides -peak for multiplicity n\n"
+          "    -seqmers db       assembly k-mer database; default: counted from -sequence on the GPU\n"
+          "    -device d         HIP device (default 0)\n\n"
+          "  Report types (exactly one):\n"
+          "    -hist           0-centred K* histogram to <output>; QV and QV* on stderr\n"
+          "    -dump           seqName, seqPos, readK, asmK, K* per k-mer to <output>  [-skipMissing]\n"
+          "    -completeness   k-mer completeness from -seqmers (or -sequence) and -readmers\n"
+          "    -filter -polish -better -strict -loose   variant scoring with -vcf: NOT in this build\n\n",
+          exe);
+}
+
+// load_Kmetric, merfin-globals.C:21-62
+static bool load_Kmetric(Globals &G) {
+  if (!G.pLookupTable) return true;
+  fprintf(stderr, "-- Loading probability table '%s'.\n\n", G.pLookupTable);
+  FILE *f = fopen(G.pLookupTable, "r");
+  if (!f) {
+    fprintf(stderr, "ERROR: Probability table (-prob) file '%s' doesn't exist!\n", G.pLookupTable);
+    return false;
+  }
+  char line[4096];
+  unsigned lineNum = 0;
+  while (fgets(line, sizeof(line), f)) {
+    size_t L = strlen(line);
+    while (L && (line[L - 1] == '\n' || line[L - 1] == '\r')) line[--L] = 0;
+    std::string keep(line);
+    std::vector<char *> w;
+    for (char *s = line; *s;) {
+      while (*s == ',') *s++ = 0;
+      if (!*s) break;
+      w.push_back(s);
+      while (*s && *s != ',') ++s;
+    }
+    if (w.size() == 2) {
+      unsigned k = (unsigned)strtoul(w[0], nullptr, 10);
+      double p = strtod(w[1], nullptr);
+      G.copyKmerK.push_back(k);
+      G.copyKmerP.push_back(p);
+      lineNum++;
+      fprintf(stderr, "Copy-number: %u\t\tReadK: %u\tProbability: %f\n", lineNum, k, p);
+    } else {
+      fprintf(stderr, "Copy-number: invalid line %u:  '%s'\n", lineNum, keep.c_str());
+    }
+  }
+  fclose(f);
+  return true;
+}
+
+#define DIE_MFX(what)                                                       \
+  do {                                                                      \
+    fprintf(stderr, "ERROR: %s: %s\n", what, mfx_last_error());             \
+    return 1;                                                               \
+  } while (0)
+
+int main(int argc, char **argv) {
+  Globals G;
+  std::vector<std::string> err;
+  for (int arg = 1; arg < argc; arg++) {
+    auto is = [&](const char *f) { return strcmp(argv[arg], f) == 0; };
+    auto val = [&]() -> const char * { return arg + 1 < argc ? argv[++arg] : ""; };
+    if (is("-sequence")) G.seqName = val();
+    else if (is("-seqmers")) G.seqDBname = val();
+    else if (is("-readmers")) G.readDBname = val();
+    else if (is("-peak")) G.peak = strtod(val(), nullptr);
+    else if (is("-prob")) G.pLookupTable = val();
+    else if (is("-vcf")) G.vcfName = val();
+    else if (is("-output")) G.outName = val();
+    else if (is("-min")) G.minV = strtoull(val(), nullptr, 10);
+    else if (is("-max")) G.maxV = strtoull(val(), nullptr, 10);
+    else if (is("-threads")) G.threads = atoi(val());
+    else if (is("-memory")) G.maxMemory = strtod(val(), nullptr);
+    else if (is("-device")) G.device = atoi(val());
+    else if (is("-nosplit")) G.nosplit = true;
+    else if (is("-filter")) G.reportType = OP_FILTER;
+    else if (is("-better")) G.reportType = OP_BETTER;
+    else if (is("-strict")) G.reportType = OP_STRICT;
+    else if (is("-loose")) { fprintf(stderr, "*EXPERIMENTAL* Running in -loose mode\n"); G.reportType = OP_LOOSE; }
+    else if (is("-polish")) G.reportType = OP_POLISH;
+    else if (is("-hist")) G.reportType = OP_HIST;
+    else if (is("-dump")) G.reportType = OP_DUMP;
+    else if (is("-skipMissing")) G.skipMissing = true;
+    else if (is("-completeness")) G.reportType = OP_COMPL;
+    else if (is("-comb")) G.comb = (unsigned)strtoul(val(), nullptr, 10);
+    else if (is("-debug")) G.debug = true;
+    else err.push_back(std::string("Unknown option '") + argv[arg] + "'.\n");
+  }
+
+  // merfin.C:159-181
+  const bool variantMode = G.reportType == OP_POLISH || G.reportType == OP_FILTER || G.reportType == OP_BETTER ||
+                           G.reportType == OP_STRICT || G.reportType == OP_LOOSE;
+  if (G.reportType != OP_COMPL) {
+    if (!G.seqName) err.push_back("No input sequences (-sequence) supplied.\n");
+    if (!G.outName) err.push_back("No output (-output) supplied.\n");
+  }
+  if (variantMode && !G.vcfName) err.push_back("No variant call input (-vcf) supplied; mandatory for -filter or -polish.\n");
+  if (G.reportType != OP_FILTER && G.peak == 0) err.push_back("No haploid peak (-peak) supplied.\n");
+  if (G.reportType == OP_COMPL && !G.seqName && !G.seqDBname)
+    err.push_back("No sequence meryl database (-seqmers) nor sequence (-sequence) supplied.\n");
+  if (G.reportType == OP_NONE) err.push_back("No report type (-filter, -polish, -hist, -dump, -completeness) supplied.\n");
+  if (!G.readDBname) err.push_back("No read meryl database (-readmers) supplied.\n");
+  if (!err.empty()) {
+    usage(argv[0]);
+    for (auto &e : err) fputs(e.c_str(), stderr);
+    return 1;
+  }
+  if (variantMode) {
+    fprintf(stderr, "ERROR: variant scoring (-filter/-polish/-better/-strict/-loose) is not part of this build; "
+                    "-hist, -dump and -completeness are.\n");
+    return 1;
+  }
+  if (mfx_device_count() <= G.device) {
+    fprintf(stderr, "ERROR: HIP device %d not available (%d visible). This program has no CPU path.\n", G.device, mfx_device_count());
+    return 1;
+  }
+
+  if (!load_Kmetric(G)) return 1;
+
+  // load_Kmers, merfin-globals.C:114-163: the read DB defines k
+  mfx_db_info rdb, adb;
+  if (mfx_db_probe(G.readDBname, &rdb)) DIE_MFX("opening -readmers");
+  const int k = rdb.k;
+  memset(&adb, 0, sizeof(adb));
+  if (G.seqDBname) {
+    if (mfx_db_probe(G.seqDBname, &adb)) DIE_MFX("opening -seqmers");
+    if (adb.k != k) { fprintf(stderr, "ERROR: -seqmers holds %d-mers but -readmers holds %d-mers.\n", adb.k, k); return 1; }
+  }
+
+  // sequences (load_Sequence, merfin-globals.C:165-197; loadSequence, merfin.C:30-53)
+  std::vector<SeqRecord> recs;
+  if (G.seqName) {
+    fprintf(stderr, "-- Opening sequences in '%s'.\n", G.seqName);
+    SeqFile sf(G.seqName);
+    if (!sf.ok()) { fprintf(stderr, "ERROR: cannot open '%s'.\n", G.seqName); return 1; }
+    SeqRecord r;
+    while (sf.next(r)) recs.push_back(std::move(r));
+  }
+  std::vector<const char *> bases(recs.size());
+  std::vector<uint64_t> lens(recs.size());
+  uint64_t totalBases = 0;
+  for (size_t i = 0; i < recs.size(); ++i) { bases[i] = recs[i].bases.data(); lens[i] = recs[i].bases.size(); totalBases += lens[i]; }
+
+  const uint64_t capacity = rdb.n_kmers + (G.seqDBname ? adb.n_kmers : totalBases) + 1024;
+  fprintf(stderr, "--\n-- Memory needed: %.3f GB\n-- Memory limit:  %.3f GB%s\n--\n", mfx_index_estimate_gb(k, capacity),
+          G.maxMemory, G.maxMemory > 0 ? "" : " (none)");
+  mfx_index *ix = mfx_index_create(k, capacity, G.maxMemory, G.device);
+  if (!ix) {
+    fprintf(stderr, "\n%s\n\n", mfx_last_error());
+    return 1;
+  }
+  fprintf(stderr, "-- Loading kmers from '%s' into lookup table.\n", G.readDBname);
+  if (mfx_index_load_db(ix, G.readDBname, 0, G.minV, G.maxV)) DIE_MFX("loading -readmers");
+
+  mfx_seq *seq = nullptr;
+  if (!recs.empty() || G.seqName) {
+    seq = mfx_seq_upload(G.device, bases.data(), lens.data(), (uint32_t)recs.size());
+    if (!seq) DIE_MFX("uploading sequences");
+  }
+  if (G.seqDBname) {
+    fprintf(stderr, "-- Loading kmers from '%s' into lookup table.\n", G.seqDBname);
+    if (mfx_index_load_db(ix, G.seqDBname, 1, 0, ~0ull)) DIE_MFX("loading -seqmers");
+  } else {
+    // replaces `meryl count k=.. <seq> output <seq>.meryl` (merfin-globals.C:182-186)
+    fprintf(stderr, "-- No -seqmer given. Counting the %d-mers of '%s' on the GPU.\n", k, G.seqName);
+    if (mfx_index_count_asm(ix, seq, nullptr)) DIE_MFX("counting sequence k-mers");
+  }
+
+  mfx_kparams kp{G.peak, (uint32_t)G.copyKmerK.size(), G.copyKmerK.data(), G.copyKmerP.data()};
+  mfx_eval *ev = mfx_eval_create(ix, &kp, 0);
+  if (!ev) DIE_MFX("creating evaluator");
+
+  int rc = 0;
+  if (G.reportType == OP_HIST) {
+    fprintf(stderr, "-- Generate histogram of the k* metric to '%s'.\n", G.outName);
+    mfx_hist_result r;
+    if (mfx_hist_run(ev, seq, &r)) DIE_MFX("-hist");
+    uint64_t cum = 0;
+    for (size_t c = 0; c < recs.size(); ++c) {   // outputHistogram's per-sequence line, in input order
+      cum += r.contig_kmissing[c];
+      fprintf(stderr, "%s\t%lu\t%lu\t%lu\t%.2f\n", recs[c].name.c_str(), (unsigned long)r.contig_kmissing[c], (unsigned long)cum,
+              (unsigned long)r.contig_kasm[c], mfx_histoQV((double)r.contig_kmissing[c], (double)r.contig_kasm[c], k));
+    }
+    if (mfx_hist_report(&r, k, G.outName, "-")) DIE_MFX("writing histogram");
+    mfx_hist_result_free(&r);
+  } else if (G.reportType == OP_DUMP) {
+    fprintf(stderr, "-- Dump per-base k* metric to '%s'.\n", G.outName);
+    uint64_t cumMissing = 0, cumAsm = 0;
+    if (G.skipMissing) {
+      // merfin-dump.C:34,81-87: -skipMissing suppresses the dump file entirely; only the counts remain
+      mfx_hist_result r;
+      if (mfx_hist_run(ev, seq, &r)) DIE_MFX("-dump -skipMissing");
+      for (size_t c = 0; c < recs.size(); ++c) {
+        cumMissing += r.contig_kmissing[c];
+        cumAsm += r.contig_kasm[c];
+        fprintf(stderr, "%s\t%lu\t%lu\t%lu\n", recs[c].name.c_str(), (unsigned long)r.contig_kmissing[c], (unsigned long)cumMissing, (unsigned long)cumAsm);
+      }
+      mfx_hist_result_free(&r);
+    } else {
+      for (size_t c = 0; c < recs.size(); ++c) {
+        uint64_t ka = 0, km = 0;
+        if (mfx_dump_contig(ev, seq, (uint32_t)c, recs[c].name.c_str(), G.outName, c > 0, &ka, &km)) DIE_MFX("-dump");
+        cumMissing += km;
+        cumAsm += ka;
+        fprintf(stderr, "%s\t%lu\t%lu\t%lu\n", recs[c].name.c_str(), (unsigned long)km, (unsigned long)cumMissing, (unsigned long)cumAsm);
+      }
+      if (recs.empty()) { FILE *f = fopen(G.outName, "w"); if (f) fclose(f); }
+    }
+  } else if (G.reportType == OP_COMPL) {
+    fprintf(stderr, "-- Compute completeness.\n");
+    double total = 0, undrc = 0;
+    if (mfx_completeness(ev, &total, &undrc)) DIE_MFX("-completeness");
+    fprintf(stderr, "\n");
+    fprintf(stderr, "TOTAL readK:   %15.2f\n", total);
+    fprintf(stderr, "TOTAL undrcpy:    %15.5f\n", undrc);
+    fprintf(stderr, "COMPLETENESS:             %0.5f\n", 1.0 - undrc / total);
+  }
+
+  mfx_eval_free(ev);
+  if (seq) mfx_seq_free(seq);
+  mfx_index_free(ix);
+  fprintf(stderr, "Bye!\n");
+  return rc;
+}

@@ -1,0 +1,415 @@
+// mfx_db.cpp -- k-mer database ingest: disk -> device index.
+//
+// Replaces merylFileReader + merylExactLookup::load as used by
+// merfinGlobal::load_Kmers (src/merfin/merfin-globals.C:114-163).  Three
+// on-disk forms are accepted:
+//   MFX_DB_FLAT   this repo's flat binary (header + u64 k-mers + u32 counts);
+//                 always verifiable, used by the tests and by fixtures.
+//   MFX_DB_TEXT   `meryl print` text: "<kmer>\t<count>\n" (plain or .gz/.bz2/.xz).
+//   MFX_DB_MERYL  a meryl database directory (merylIndex + 64 x 0xBBBBBB.merylData).
+//                 The decoder follows the layout of marbl/meryl-utility as
+//                 recalled in SURVEY.md Appendix C.  It is UNVALIDATED: the
+//                 reference checkout contains no meryl source and no database,
+//                 so the decoder has only been exercised against this repo's
+//                 own writer of the same layout (tests/meryl_layout.py).  It
+//                 refuses anything whose magic numbers / sizes do not match
+//                 rather than guessing.
+#include "mfx_internal.h"
+
+#include <dirent.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+namespace {
+
+bool ends_with(const std::string &p, const char *suf) {
+  size_t n = strlen(suf);
+  return p.size() >= n && p.compare(p.size() - n, n, suf) == 0;
+}
+
+FILE *open_reader(const std::string &path, bool *is_pipe) {
+  const char *tool = ends_with(path, ".gz") ? "gzip -dc" : ends_with(path, ".bz2") ? "bzip2 -dc" : ends_with(path, ".xz") ? "xz -dc" : nullptr;
+  *is_pipe = tool != nullptr;
+  if (!tool) return fopen(path.c_str(), "rb");
+  std::string cmd = std::string(tool) + " '" + path + "'";
+  return popen(cmd.c_str(), "r");
+}
+void close_reader(FILE *f, bool is_pipe) {
+  if (!f) return;
+  if (is_pipe) pclose(f); else fclose(f);
+}
+
+bool is_dir(const std::string &p) {
+  struct stat st;
+  return stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode);
+}
+bool is_file(const std::string &p) {
+  struct stat st;
+  return stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode);
+}
+
+int base_code(unsigned char c) {
+  switch (c) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'T': case 't': return 2;
+    case 'G': case 'g': return 3;
+    default: return -1;
+  }
+}
+
+// ---- flat binary ------------------------------------------------------------
+struct FlatHeader {
+  char     magic[8];     // "MFXKMER1"
+  uint32_t k;
+  uint32_t flags;        // bit 0: canonical
+  uint64_t n;
+  uint64_t reserved;
+};
+
+// ---- meryl stuffedBits reader (UNVALIDATED) -----------
+// A stuffedBits file image: u64 dataBlockLenMax (bits), u32 dataBlocksLen,
+// u32 dataBlocksMax, u64 bgn[dataBlocksLen], u64 len[dataBlocksLen] (bits),
+// then ceil(len/64) little-endian u64 words per block; values are packed
+// MSB-first inside each word.
+struct BitReader {
+  const uint64_t *w = nullptr;
+  uint64_t nbits = 0, pos = 0;
+  bool ok = true;
+  uint64_t get(uint32_t n) {               // n <= 64
+    if (n == 0) return 0;
+    if (pos + n > nbits) { ok = false; return 0; }
+    uint64_t wi = pos >> 6, bo = pos & 63, v;
+    if (bo + n <= 64) {
+      v = (w[wi] << bo) >> (64 - n);
+    } else {
+      uint32_t n1 = 64 - (uint32_t)bo, n2 = n - n1;
+      v = (((w[wi] << bo) >> bo) << n2) | (w[wi + 1] >> (64 - n2));
+    }
+    pos += n;
+    return v;
+  }
+  uint64_t unary() {                        // number of 0 bits before the next 1 (the 1 is consumed)
+    uint64_t z = 0;
+    while (true) {
+      if (pos >= nbits) { ok = false; return 0; }
+      uint64_t wi = pos >> 6, bo = pos & 63;
+      uint64_t rest = w[wi] << bo;
+      if (rest) {
+        uint32_t lz = (uint32_t)__builtin_clzll(rest);
+        z += lz;
+        pos += lz + 1;
+        return z;
+      }
+      z += 64 - bo;
+      pos += 64 - bo;
+    }
+  }
+};
+
+const uint64_t MERYL_IDX_MAGIC1 = 0x646e496c7972656dULL;   // "merylInd"
+const uint64_t MERYL_DAT_MAGIC1 = 0x7461446c7972656dULL;   // "merylDat"
+const uint64_t MERYL_DAT_MAGIC2 = 0x0a3030656c694661ULL;   // "aFile00\n"
+
+struct StuffedFile {
+  std::vector<uint64_t> words;     // all block payloads, concatenated
+  std::vector<uint64_t> blk_word;  // first word of each block
+  std::vector<uint64_t> blk_bits;  // bit length of each block
+};
+
+// reads ONE stuffedBits image starting at the current file offset; returns
+// false at clean EOF, sets *err on a malformed image.
+bool read_stuffed(FILE *f, StuffedFile &out, std::string *err) {
+  uint64_t lenmax;
+  uint32_t nblk, maxblk;
+  size_t r = fread(&lenmax, 8, 1, f);
+  if (r != 1) return false;                                   // EOF
+  if (fread(&nblk, 4, 1, f) != 1 || fread(&maxblk, 4, 1, f) != 1) { *err = "truncated stuffedBits header"; return false; }
+  if (nblk == 0 || nblk > maxblk || maxblk > (1u << 24)) { *err = "implausible stuffedBits block count"; return false; }
+  std::vector<uint64_t> bgn(nblk), len(nblk);
+  if (fread(bgn.data(), 8, nblk, f) != nblk || fread(len.data(), 8, nblk, f) != nblk) { *err = "truncated stuffedBits tables"; return false; }
+  out.words.clear(); out.blk_word.clear(); out.blk_bits.clear();
+  for (uint32_t b = 0; b < nblk; ++b) {
+    if (len[b] > lenmax) { *err = "stuffedBits block longer than its declared maximum"; return false; }
+    uint64_t nw = (len[b] + 63) / 64;
+    size_t at = out.words.size();
+    out.words.resize(at + nw + 1);
+    if (nw && fread(out.words.data() + at, 8, nw, f) != nw) { *err = "truncated stuffedBits payload"; return false; }
+    out.words[at + nw] = 0;
+    out.blk_word.push_back(at);
+    out.blk_bits.push_back(len[b]);
+  }
+  return true;
+}
+
+struct MerylIndex {
+  uint32_t prefixSize = 0, suffixSize = 0, numFilesBits = 0, numBlocksBits = 0, flags = 0;
+  int version = 0;
+};
+
+int read_meryl_master(const std::string &dir, MerylIndex &mi) {
+  std::string p = dir + "/merylIndex";
+  FILE *f = fopen(p.c_str(), "rb");
+  if (!f) return mfx_fail(MFX_E_IO, "cannot open '%s'", p.c_str());
+  StuffedFile sf;
+  std::string err;
+  bool ok = read_stuffed(f, sf, &err);
+  fclose(f);
+  if (!ok) return mfx_fail(MFX_E_FORMAT, "'%s': %s", p.c_str(), err.empty() ? "empty file" : err.c_str());
+  BitReader br;
+  br.w = sf.words.data() + sf.blk_word[0];
+  br.nbits = sf.blk_bits[0];
+  uint64_t m1 = br.get(64), m2 = br.get(64);
+  if (m1 != MERYL_IDX_MAGIC1)
+    return mfx_fail(MFX_E_FORMAT, "'%s': bad magic %016lx (not a meryl index)", p.c_str(), (unsigned long)m1);
+  // "ex__v.0N": 0x3N302e765f5f7865
+  if ((m2 & 0xf0ffffffffffffffULL) != 0x30302e765f5f7865ULL)
+    return mfx_fail(MFX_E_FORMAT, "'%s': unrecognised index version word %016lx", p.c_str(), (unsigned long)m2);
+  mi.version = (int)((m2 >> 56) & 0x0f);
+  if (mi.version < 1 || mi.version > 9)
+    return mfx_fail(MFX_E_FORMAT, "'%s': unsupported meryl index version %d", p.c_str(), mi.version);
+  mi.prefixSize = (uint32_t)br.get(32);
+  mi.suffixSize = (uint32_t)br.get(32);
+  mi.numFilesBits = (uint32_t)br.get(32);
+  mi.numBlocksBits = (uint32_t)br.get(32);
+  if (mi.version >= 2) mi.flags = (uint32_t)br.get(32);
+  if (!br.ok || mi.numFilesBits != 6 || mi.prefixSize < 6 || mi.prefixSize + mi.suffixSize == 0 ||
+      ((mi.prefixSize + mi.suffixSize) & 1) || mi.prefixSize + mi.suffixSize > 128 ||
+      mi.numFilesBits + mi.numBlocksBits != mi.prefixSize)
+    return mfx_fail(MFX_E_FORMAT, "'%s': inconsistent sizes (prefix %u suffix %u files %u blocks %u)", p.c_str(),
+                    mi.prefixSize, mi.suffixSize, mi.numFilesBits, mi.numBlocksBits);
+  return MFX_OK;
+}
+
+std::string meryl_file_name(const std::string &dir, uint32_t file, const char *ext) {
+  char b[16];
+  for (int i = 0; i < 6; ++i) b[i] = ((file >> (5 - i)) & 1) ? '1' : '0';
+  b[6] = 0;
+  return dir + "/0x" + b + ext;
+}
+
+// decode every block of one .merylData file; emit(kmer, value)
+template <class F>
+int read_meryl_data(const std::string &path, uint32_t file, const MerylIndex &mi, F &&emit, uint64_t *count) {
+  FILE *f = fopen(path.c_str(), "rb");
+  if (!f) return MFX_OK;                                    // a piece with no k-mers may be absent
+  StuffedFile sf;
+  std::string err;
+  int rc = MFX_OK;
+  while (rc == MFX_OK && read_stuffed(f, sf, &err)) {
+    // a data block may be split over several stuffedBits chunks; treat them as one bit stream
+    std::vector<uint64_t> stream;
+    uint64_t bits = 0;
+    bool aligned = true;
+    for (size_t b = 0; b < sf.blk_word.size(); ++b) {
+      if (!aligned) { rc = mfx_fail(MFX_E_FORMAT, "'%s': non-word-aligned interior chunk", path.c_str()); break; }
+      uint64_t nw = (sf.blk_bits[b] + 63) / 64;
+      stream.insert(stream.end(), sf.words.begin() + sf.blk_word[b], sf.words.begin() + sf.blk_word[b] + nw);
+      bits += sf.blk_bits[b];
+      aligned = (sf.blk_bits[b] % 64) == 0;
+    }
+    if (rc) break;
+    stream.push_back(0);
+    BitReader br;
+    br.w = stream.data();
+    br.nbits = bits;
+    if (br.get(64) != MERYL_DAT_MAGIC1 || br.get(64) != MERYL_DAT_MAGIC2) { rc = mfx_fail(MFX_E_FORMAT, "'%s': bad data-block magic", path.c_str()); break; }
+    uint64_t prefix = br.get(64), nk = br.get(64);
+    uint32_t kcode = (uint32_t)br.get(8), ubits = (uint32_t)br.get(32), bbits = (uint32_t)br.get(32);
+    (void)br.get(64);                                        // k1 (unused)
+    uint32_t ccode = (uint32_t)br.get(8);
+    (void)br.get(64); (void)br.get(64);                      // c1, c2 (unused)
+    if (!br.ok || kcode != 1 || (ccode != 1 && ccode != 2) || ubits + bbits != mi.suffixSize || bbits > 64 ||
+        (prefix >> mi.numBlocksBits) != file || mi.suffixSize > 64) {
+      rc = mfx_fail(MFX_E_FORMAT, "'%s': unsupported / inconsistent data block (kCode %u cCode %u unary %u binary %u suffix %u prefix %lx)",
+                    path.c_str(), kcode, ccode, ubits, bbits, mi.suffixSize, (unsigned long)prefix);
+      break;
+    }
+    std::vector<uint64_t> sfx(nk);
+    uint64_t hi = 0;
+    for (uint64_t i = 0; i < nk; ++i) {
+      hi += br.unary();
+      sfx[i] = (bbits == 64 ? 0 : (hi << bbits)) | br.get(bbits);
+      if (i && sfx[i] <= sfx[i - 1]) { rc = mfx_fail(MFX_E_FORMAT, "'%s': suffixes not strictly increasing", path.c_str()); break; }
+    }
+    if (rc) break;
+    for (uint64_t i = 0; i < nk; ++i) {
+      uint64_t v = br.get(ccode == 1 ? 32 : 64);
+      uint64_t km = (mi.suffixSize >= 64 ? 0 : (prefix << mi.suffixSize)) | sfx[i];
+      emit(km, v > 0xffffffffull ? 0xffffffffu : (uint32_t)v);
+    }
+    if (!br.ok) { rc = mfx_fail(MFX_E_FORMAT, "'%s': data block shorter than its header claims", path.c_str()); break; }
+    *count += nk;
+  }
+  fclose(f);
+  if (rc == MFX_OK && !err.empty()) rc = mfx_fail(MFX_E_FORMAT, "'%s': %s", path.c_str(), err.c_str());
+  return rc;
+}
+
+int detect(const std::string &path) {
+  if (is_dir(path)) return MFX_DB_MERYL;
+  if (!is_file(path)) return 0;
+  FILE *f = fopen(path.c_str(), "rb");
+  if (!f) return 0;
+  char m[8] = {0};
+  size_t r = fread(m, 1, 8, f);
+  fclose(f);
+  if (r == 8 && memcmp(m, "MFXKMER1", 8) == 0) return MFX_DB_FLAT;
+  return MFX_DB_TEXT;
+}
+
+// batches (kmer,value) pairs into the index
+struct Feeder {
+  mfx_index *ix;
+  int side;
+  uint64_t minV, maxV;
+  std::vector<uint64_t> k;
+  std::vector<uint32_t> v;
+  int rc = MFX_OK;
+  void flush() {
+    if (k.empty() || rc) return;
+    rc = side ? mfx_index_add_asm(ix, k.data(), v.data(), k.size(), 0)
+              : mfx_index_add_read(ix, k.data(), v.data(), k.size(), minV, maxV, 0);
+    k.clear(); v.clear();
+  }
+  void push(uint64_t km, uint32_t val) {
+    k.push_back(km); v.push_back(val);
+    if (k.size() >= (1u << 24)) flush();
+  }
+};
+
+template <class F>
+int scan_text(const std::string &path, int *k_out, F &&emit, uint64_t *count) {
+  bool pipe;
+  FILE *f = open_reader(path, &pipe);
+  if (!f) return mfx_fail(MFX_E_IO, "cannot open '%s'", path.c_str());
+  char line[512];
+  int k = 0, rc = MFX_OK;
+  uint64_t ln = 0;
+  while (fgets(line, sizeof(line), f)) {
+    ++ln;
+    char *p = line;
+    uint64_t km = 0;
+    int n = 0;
+    while (base_code((unsigned char)*p) >= 0) { km = (km << 2) | (uint64_t)base_code((unsigned char)*p); ++p; ++n; }
+    if (n == 0 && (*p == '\n' || *p == 0)) continue;
+    if (n == 0 || n > 31 || (*p != '\t' && *p != ' ')) { rc = mfx_fail(MFX_E_FORMAT, "'%s' line %lu: expected '<kmer>\\t<count>'", path.c_str(), (unsigned long)ln); break; }
+    if (k == 0) k = n;
+    if (n != k) { rc = mfx_fail(MFX_E_FORMAT, "'%s' line %lu: k-mer length %d differs from %d", path.c_str(), (unsigned long)ln, n, k); break; }
+    unsigned long long v = strtoull(p, nullptr, 10);
+    emit(km, v > 0xffffffffull ? 0xffffffffu : (uint32_t)v);
+    ++*count;
+  }
+  close_reader(f, pipe);
+  if (k_out) *k_out = k;
+  return rc;
+}
+
+}  // namespace
+
+// merylFileReader(path): opens the DB and reveals k (merfin-globals.C:118-119:
+// "Make readDB first so we know the k size").
+extern "C" int mfx_db_probe(const char *path, mfx_db_info *out) {
+  if (!path || !out) return mfx_fail(MFX_E_INVAL, "mfx_db_probe: null argument");
+  memset(out, 0, sizeof(*out));
+  std::string p(path);
+  int fmt = detect(p);
+  if (!fmt) return mfx_fail(MFX_E_IO, "k-mer database '%s' does not exist", path);
+  out->format = fmt;
+  if (fmt == MFX_DB_FLAT) {
+    FILE *f = fopen(path, "rb");
+    FlatHeader h;
+    if (!f || fread(&h, sizeof(h), 1, f) != 1) { if (f) fclose(f); return mfx_fail(MFX_E_FORMAT, "'%s': truncated header", path); }
+    fclose(f);
+    out->k = (int)h.k;
+    out->n_kmers = h.n;
+    return MFX_OK;
+  }
+  if (fmt == MFX_DB_TEXT) {
+    uint64_t n = 0;
+    int k = 0;
+    int rc = scan_text(p, &k, [](uint64_t, uint32_t) {}, &n);
+    if (rc) return rc;
+    if (k == 0) return mfx_fail(MFX_E_FORMAT, "'%s': no k-mers found", path);
+    out->k = k;
+    out->n_kmers = n;
+    return MFX_OK;
+  }
+  MerylIndex mi;
+  int rc = read_meryl_master(p, mi);
+  if (rc) return rc;
+  out->k = (int)((mi.prefixSize + mi.suffixSize) / 2);
+  // distinct k-mer count: sum of the block headers (cheap pass over the 64 data files)
+  uint64_t n = 0;
+  for (uint32_t fl = 0; fl < 64 && rc == MFX_OK; ++fl)
+    rc = read_meryl_data(meryl_file_name(p, fl, ".merylData"), fl, mi, [](uint64_t, uint32_t) {}, &n);
+  out->n_kmers = n;
+  return rc;
+}
+
+// merylExactLookup::load (merfin-globals.C:156,159): side 0 = read DB with the
+// -min/-max filter, side 1 = assembly DB.
+extern "C" int mfx_index_load_db(mfx_index *ix, const char *path, int side, uint64_t minV, uint64_t maxV) {
+  if (!ix || !path) return mfx_fail(MFX_E_INVAL, "mfx_index_load_db: null argument");
+  std::string p(path);
+  int fmt = detect(p);
+  if (!fmt) return mfx_fail(MFX_E_IO, "k-mer database '%s' does not exist", path);
+  Feeder fd{ix, side, minV, maxV};
+  uint64_t n = 0;
+  int rc = MFX_OK;
+  if (fmt == MFX_DB_FLAT) {
+    FILE *f = fopen(path, "rb");
+    FlatHeader h;
+    if (!f || fread(&h, sizeof(h), 1, f) != 1) { if (f) fclose(f); return mfx_fail(MFX_E_FORMAT, "'%s': truncated header", path); }
+    if ((int)h.k != ix->k) { fclose(f); return mfx_fail(MFX_E_INVAL, "'%s' holds %u-mers but the index is built for k=%d", path, h.k, ix->k); }
+    const uint64_t CH = 1u << 22;
+    std::vector<uint64_t> kb(CH);
+    std::vector<uint32_t> vb(CH);
+    long base = (long)sizeof(h);
+    for (uint64_t o = 0; o < h.n && rc == MFX_OK; o += CH) {
+      uint64_t m = std::min<uint64_t>(CH, h.n - o);
+      if (fseek(f, base + (long)(o * 8), SEEK_SET) || fread(kb.data(), 8, m, f) != m ||
+          fseek(f, base + (long)(h.n * 8 + o * 4), SEEK_SET) || fread(vb.data(), 4, m, f) != m) {
+        rc = mfx_fail(MFX_E_FORMAT, "'%s': truncated payload", path);
+        break;
+      }
+      for (uint64_t i = 0; i < m; ++i) fd.push(kb[i], vb[i]);
+    }
+    fclose(f);
+  } else if (fmt == MFX_DB_TEXT) {
+    int k = 0;
+    rc = scan_text(p, &k, [&](uint64_t km, uint32_t v) { fd.push(km, v); }, &n);
+    if (rc == MFX_OK && k != ix->k) rc = mfx_fail(MFX_E_INVAL, "'%s' holds %d-mers but the index is built for k=%d", path, k, ix->k);
+  } else {
+    MerylIndex mi;
+    rc = read_meryl_master(p, mi);
+    if (rc == MFX_OK && (int)((mi.prefixSize + mi.suffixSize) / 2) != ix->k)
+      rc = mfx_fail(MFX_E_INVAL, "'%s' holds %u-mers but the index is built for k=%d", path, (mi.prefixSize + mi.suffixSize) / 2, ix->k);
+    for (uint32_t fl = 0; fl < 64 && rc == MFX_OK; ++fl)
+      rc = read_meryl_data(meryl_file_name(p, fl, ".merylData"), fl, mi, [&](uint64_t km, uint32_t v) { fd.push(km, v); }, &n);
+  }
+  if (rc == MFX_OK) fd.flush();
+  return rc ? rc : fd.rc;
+}
+
+// writes this repo's flat binary form (fixtures, interchange)
+extern "C" int mfx_db_write_flat(const char *path, int k, const uint64_t *kmers, const uint32_t *values, uint64_t n) {
+  if (!path || (n && (!kmers || !values))) return mfx_fail(MFX_E_INVAL, "mfx_db_write_flat: null argument");
+  FILE *f = fopen(path, "wb");
+  if (!f) return mfx_fail(MFX_E_IO, "cannot open '%s' for writing", path);
+  FlatHeader h;
+  memcpy(h.magic, "MFXKMER1", 8);
+  h.k = (uint32_t)k;
+  h.flags = 0;
+  h.n = n;
+  h.reserved = 0;
+  bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && (n == 0 || (fwrite(kmers, 8, n, f) == n && fwrite(values, 4, n, f) == n));
+  fclose(f);
+  return ok ? MFX_OK : mfx_fail(MFX_E_IO, "short write to '%s'", path);
+}
