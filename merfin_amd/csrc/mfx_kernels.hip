@@ -144,6 +144,105 @@ __global__ void mfx_table_export_kernel(mfx_table_view t, uint64_t *kmers, uint3
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// Wave-cooperative lookup.  A 128-byte table line is what HBM delivers for any
+// access into it (measured: profiles/r01_ubench_gather.txt), so a query should
+// look at the WHOLE line at once.  Each 8-lane group of the wave fetches the 8
+// slots of one query's home line with one coalesced 128-byte access (lane
+// `sub` reads slot `sub`), the match is found with a ballot, and the values go
+// back to the owning lane through the LDS crossbar.  Per wave-instruction 8
+// lines are requested; S=8 owners per group are served per round, so 64 lines
+// are in flight per wave.  The rare queries whose home line is full without a
+// match (overflow into the following lines) finish per lane afterwards.
+// ---------------------------------------------------------------------------
+template <int S>
+__device__ __forceinline__ uint32_t mfx_group_bcast(uint32_t v) {
+  // lane' = (lane & 0x18) | S inside each 32-lane half: broadcast of sub-lane S in every 8-lane group
+  return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x18 | (S << 5));
+}
+
+struct mfx_group_round {
+  uint32_t ls[8], klo[8], khi[8];
+  uint4    v[8];
+};
+
+template <int S>
+__device__ __forceinline__ void mfx_group_issue(const mfx_table_view &t, mfx_group_round &R, uint32_t line, uint32_t klo,
+                                                uint32_t khi, uint32_t sub) {
+  R.ls[S] = mfx_group_bcast<S>(line);
+  R.klo[S] = mfx_group_bcast<S>(klo);
+  R.khi[S] = mfx_group_bcast<S>(khi);
+  R.v[S] = make_uint4(0xffffffffu, 0xffffffffu, 0u, 0u);
+  if (R.ls[S] != 0xffffffffu)
+    R.v[S] = *reinterpret_cast<const uint4 *>(t.slots + (uint64_t)R.ls[S] * MFX_SLOTS_LINE + sub);
+}
+
+template <int S>
+__device__ __forceinline__ void mfx_group_collect(const mfx_table_view &t, const mfx_group_round &R, uint32_t sub,
+                                                  uint32_t gbase, uint32_t &rv, uint32_t &av, bool &pending) {
+  const uint4 v = R.v[S];
+  const bool live = R.ls[S] != 0xffffffffu;
+  const bool match = live && v.x == R.klo[S] && v.y == R.khi[S];
+  const bool empty = (v.x & v.y) == 0xffffffffu;
+  const uint32_t mb = (uint32_t)(__ballot(match) >> gbase) & 0xffu;
+  const uint32_t eb = (uint32_t)(__ballot(empty) >> gbase) & 0xffu;
+  const uint32_t src = gbase | (mb ? (uint32_t)__builtin_ctz(mb) : 0u);
+  const uint32_t r = (uint32_t)__shfl((int)v.z, (int)src, 64);
+  const uint32_t a = (uint32_t)__shfl((int)v.w, (int)src, 64);
+  if (sub == S) {
+    if (mb) {
+      rv = (r < t.minV || r > t.maxV) ? 0u : r;     // -min / -max (merfin.C:199-200)
+      av = a;
+    } else {
+      rv = 0u; av = 0u;                               // absent -> 0 (merfin-globals.C:84)
+      pending = live && (eb == 0);                    // home line full, no match: continue in the next lines
+    }
+  }
+}
+
+// B queries per lane; ok[j] false = no query.  Results: rv[j], av[j].
+template <int B>
+__device__ __forceinline__ void mfx_group_lookup(const mfx_table_view &t, const uint64_t (&key)[B], const bool (&ok)[B],
+                                                 uint32_t (&rv)[B], uint32_t (&av)[B]) {
+  const uint32_t lane = threadIdx.x & 63u, sub = lane & 7u, gbase = lane & ~7u;
+  uint32_t line[B];
+  bool pending[B];
+#pragma unroll
+  for (int j = 0; j < B; ++j) {
+    uint32_t p1;
+    line[j] = ok[j] ? (uint32_t)mfx_home(t, key[j], p1) : 0xffffffffu;
+    pending[j] = false;
+    rv[j] = av[j] = 0u;
+  }
+#pragma unroll
+  for (int j = 0; j < B; ++j) {
+    mfx_group_round R;
+    const uint32_t klo = (uint32_t)key[j], khi = (uint32_t)(key[j] >> 32);
+    mfx_group_issue<0>(t, R, line[j], klo, khi, sub); mfx_group_issue<1>(t, R, line[j], klo, khi, sub);
+    mfx_group_issue<2>(t, R, line[j], klo, khi, sub); mfx_group_issue<3>(t, R, line[j], klo, khi, sub);
+    mfx_group_issue<4>(t, R, line[j], klo, khi, sub); mfx_group_issue<5>(t, R, line[j], klo, khi, sub);
+    mfx_group_issue<6>(t, R, line[j], klo, khi, sub); mfx_group_issue<7>(t, R, line[j], klo, khi, sub);
+    mfx_group_collect<0>(t, R, sub, gbase, rv[j], av[j], pending[j]); mfx_group_collect<1>(t, R, sub, gbase, rv[j], av[j], pending[j]);
+    mfx_group_collect<2>(t, R, sub, gbase, rv[j], av[j], pending[j]); mfx_group_collect<3>(t, R, sub, gbase, rv[j], av[j], pending[j]);
+    mfx_group_collect<4>(t, R, sub, gbase, rv[j], av[j], pending[j]); mfx_group_collect<5>(t, R, sub, gbase, rv[j], av[j], pending[j]);
+    mfx_group_collect<6>(t, R, sub, gbase, rv[j], av[j], pending[j]); mfx_group_collect<7>(t, R, sub, gbase, rv[j], av[j], pending[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < B; ++j)
+    if (pending[j]) {
+      // per-lane continuation from the line after the home line (probe index 8 with home slot 0)
+      uint4 s = mfx_load_slot(t, mfx_probe_slot(t, line[j], 0u, 8u));
+      uint32_t q = 8;
+      while (true) {
+        uint64_t sk = (uint64_t)s.x | ((uint64_t)s.y << 32);
+        if (sk == key[j]) { rv[j] = (s.z < t.minV || s.z > t.maxV) ? 0u : s.z; av[j] = s.w; break; }
+        if (sk == MFX_EMPTY || ++q >= MFX_MAX_PROBE) break;
+        s = mfx_load_slot(t, mfx_probe_slot(t, line[j], 0u, q));
+      }
+    }
+}
+
 // ===========================================================================
 // sequence tile in LDS: 2-bit codes packed MSB-first in 64-bit words + one
 // validity bit per base, so a lane extracts the k-mer starting at ANY position
@@ -287,9 +386,8 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_hist_kernel(mfx_hist_args a) {
       __syncthreads();
 
       for (uint32_t b = 0; b < MFX_TILE / MFX_BLOCK; b += MFX_BATCH) {
-        uint64_t key[MFX_BATCH], key2[MFX_BATCH], line[MFX_BATCH], line2[MFX_BATCH];
-        uint32_t p1[MFX_BATCH], p2[MFX_BATCH];
-        uint4    s1[MFX_BATCH], s2[MFX_BATCH];
+        uint64_t key[MFX_BATCH], key2[MFX_BATCH];
+        uint32_t rv[MFX_BATCH], av[MFX_BATCH];
         bool     ok[MFX_BATCH];
 #pragma unroll
         for (int j = 0; j < MFX_BATCH; ++j) {
@@ -302,33 +400,27 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_hist_kernel(mfx_hist_args a) {
           } else {
             key[j] = f; key2[j] = r;
           }
-          if (ok[j]) {
-            line[j] = mfx_home(a.t, key[j], p1[j]);
-            s1[j] = mfx_load_slot(a.t, line[j] * MFX_SLOTS_LINE + p1[j]);
-            if (!CANON) {
-              line2[j] = mfx_home(a.t, key2[j], p2[j]);
-              s2[j] = mfx_load_slot(a.t, line2[j] * MFX_SLOTS_LINE + p2[j]);
-            }
-          }
+        }
+        mfx_group_lookup<MFX_BATCH>(a.t, key, ok, rv, av);
+        if (!CANON) {
+          // value(fmer) + value(rmer), uint32 arithmetic (merfin-globals.C:107-108)
+          uint32_t rv2[MFX_BATCH], av2[MFX_BATCH];
+          mfx_group_lookup<MFX_BATCH>(a.t, key2, ok, rv2, av2);
+#pragma unroll
+          for (int j = 0; j < MFX_BATCH; ++j) { rv[j] += rv2[j]; av[j] += av2[j]; }
         }
 #pragma unroll
         for (int j = 0; j < MFX_BATCH; ++j) {
           if (!ok[j]) continue;
-          uint2 v = mfx_resolve(a.t, key[j], line[j], p1[j], s1[j]);
-          if (!CANON) {
-            // value(fmer) + value(rmer), uint32 arithmetic (merfin-globals.C:107-108)
-            uint2 v2 = mfx_resolve(a.t, key2[j], line2[j], p2[j], s2[j]);
-            v.x += v2.x; v.y += v2.y;
-          }
           n_valid++;                                                   // merfin-histogram.C:58
           double readK, prob;
-          const uint32_t rv = v.x;
-          if (rv > 0 && rv <= np_lds) {                                // LDS-resident -prob rows
-            readK = (double)s_probK[rv - 1]; prob = s_probP[rv - 1];
+          const uint32_t readV = rv[j];
+          if (readV > 0 && readV <= np_lds) {                          // LDS-resident -prob rows
+            readK = (double)s_probK[readV - 1]; prob = s_probP[readV - 1];
           } else {
-            mfx_getK_core(a.peak, a.n_prob, a.probK, a.probP, rv, readK, prob);
+            mfx_getK_core(a.peak, a.n_prob, a.probK, a.probP, readV, readK, prob);
           }
-          const double asmK = (double)v.y;
+          const double asmK = (double)av[j];
           if (readK == 0) { n_missing++; continue; }                   // :66-69
           bool under = asmK > readK;                                   // :71
           uint32_t idx = under ? mfx_bin_index(asmK, readK) : mfx_bin_index(readK, asmK);

@@ -78,6 +78,38 @@ __global__ __launch_bounds__(256) void gather_kernel(const uint4 *__restrict__ t
   if (acc == 0x1234567ULL) out[0] = acc;   // defeat DCE
 }
 
+// two DEPENDENT-address-free 16-byte loads per lane at byte offsets 0 and OFF2 of
+// a random 128-byte-aligned line: OFF2=48 same 64-B half, 64 other half, 128 next line.
+template <int OFF2>
+__global__ __launch_bounds__(256) void pair_kernel(const uint4 *__restrict__ t, uint64_t nlines128, int iters,
+                                                   uint64_t seed, uint64_t *out) {
+  uint64_t tid = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  uint64_t acc = 0;
+  uint64_t ctr = seed + tid * 0x9e3779b97f4a7c15ULL;
+  for (int it = 0; it < iters; ++it) {
+    ctr += 0xD1B54A32D192ED03ULL;
+    uint64_t h = mix64(ctr);
+    uint64_t ln = (uint64_t)(((unsigned __int128)h * (nlines128 - 2)) >> 64);
+    uint4 a = t[ln * 8];
+    uint4 b = t[ln * 8 + OFF2 / 16];
+    acc += a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w;
+  }
+  if (acc == 0x1234567ULL) out[0] = acc;
+}
+
+template <int OFF2>
+static void run_pair(const uint4 *t, uint64_t bytes, uint64_t *out) {
+  int grid = 2048, block = 256, iters = 2048;
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  CK(hipEventRecord(e0));
+  pair_kernel<OFF2><<<grid, block>>>(t, bytes / 128, iters, 91, out);
+  CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  double n = (double)grid * block * iters;
+  printf("  pair of 16-B loads, second at +%3d B : %7.2f G-pairs/s  %.1f ms\n", OFF2, n / ms * 1e-6, ms);
+  fflush(stdout);
+}
+
 __global__ __launch_bounds__(256) void stream_kernel(const uint4 *__restrict__ t, uint64_t n16, uint64_t *out) {
   uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
   uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -141,6 +173,9 @@ int main(int argc, char **argv) {
     run<64, 1>(t, bytes, out, 8);
     run<64, 4>(t, bytes, out, 8);
     run<128, 2>(t, bytes, out, 8);
+    run_pair<48>(t, bytes, out);
+    run_pair<64>(t, bytes, out);
+    run_pair<128>(t, bytes, out);
     CK(hipFree(t));
   }
   return 0;
