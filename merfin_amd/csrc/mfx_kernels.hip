@@ -231,14 +231,18 @@ __device__ __forceinline__ void mfx_group_lookup(const mfx_table_view &t, const 
 #pragma unroll
   for (int j = 0; j < B; ++j)
     if (pending[j]) {
-      // per-lane continuation from the line after the home line (probe index 8 with home slot 0)
-      uint4 s = mfx_load_slot(t, mfx_probe_slot(t, line[j], 0u, 8u));
-      uint32_t q = 8;
-      while (true) {
-        uint64_t sk = (uint64_t)s.x | ((uint64_t)s.y << 32);
-        if (sk == key[j]) { rv[j] = (s.z < t.minV || s.z > t.maxV) ? 0u : s.z; av[j] = s.w; break; }
-        if (sk == MFX_EMPTY || ++q >= MFX_MAX_PROBE) break;
-        s = mfx_load_slot(t, mfx_probe_slot(t, line[j], 0u, q));
+      // per-lane continuation over the following lines.  The stop rule is per LINE
+      // (a key lives in line L+d only if L..L+d-1 were full when it was inserted,
+      // but inside a line it may sit after empty slots), so scan all 8 slots.
+      for (uint32_t d = 1; d < MFX_MAX_PROBE / MFX_SLOTS_LINE; ++d) {
+        bool any_empty = false, found = false;
+        for (uint32_t q = 0; q < MFX_SLOTS_LINE && !found; ++q) {
+          uint4 s = mfx_load_slot(t, mfx_probe_slot(t, line[j], 0u, d * MFX_SLOTS_LINE + q));
+          uint64_t sk = (uint64_t)s.x | ((uint64_t)s.y << 32);
+          if (sk == key[j]) { rv[j] = (s.z < t.minV || s.z > t.maxV) ? 0u : s.z; av[j] = s.w; found = true; }
+          any_empty |= (sk == MFX_EMPTY);
+        }
+        if (found || any_empty) break;
       }
     }
 }
