@@ -385,7 +385,7 @@ extern "C" mfx_eval *mfx_eval_create(const mfx_index *ix, const mfx_kparams *kp,
     return nullptr;
   }
   const char *e = getenv("MFX_BLOCKS_PER_CU");
-  int bpc = e ? atoi(e) : 16;
+  int bpc = e ? atoi(e) : 32;   // 4 resident blocks/CU x 8 rounds: keeps the static tile split's tail < 3 %
   if (bpc < 1) bpc = 1;
   ev->grid = prop.multiProcessorCount * bpc;
   size_t np = ev->n_prob ? ev->n_prob : 1;

@@ -329,6 +329,29 @@ def test_revcomp_symmetry():
     assert a.koverCpy == pytest.approx(b.koverCpy, rel=1e-12)
 
 
+@pytest.mark.parametrize("lf", ["0.9", "0.3"])
+def test_heavy_line_overflow_and_sparse_tables(lf, monkeypatch):
+    """Load factor 0.9: ~25 % of the k-mers overflow their 128-byte home line, so the
+    continuation path of the cooperative probe carries real weight; 0.3: sparse lines."""
+    m = _mfx()
+    monkeypatch.setenv("MFX_LOAD_FACTOR", lf)
+    k, peak = 21, 17.3
+    contigs, read, asm = synth.world(k=k, peak=peak, seed=37, err_kmers=20000)
+    p, g, ka, km = oracle_hist(k, peak, contigs, read, asm)
+    ix = build_index(m, k, read, asm, cap=len(np.union1d(read[0], asm[0])))
+    info = ix.info()
+    assert abs(info["distinct"] / info["capacity"] - float(lf)) < 0.05 or info["capacity"] == 8192
+    ev = m.Evaluator(ix, m.KParams(peak))
+    seqs = m.Sequences(contigs)
+    assert_hist_equal(ev.hist(seqs), g, ka, km, k)
+    # the per-lane probe (dump / value kernels) agrees with the cooperative one
+    R, A = po.Lookup(k, *read), po.Lookup(k, *asm)
+    q = np.concatenate([read[0][::3], asm[0][::3]])
+    rv, av = ix.value(q)
+    np.testing.assert_array_equal(rv, np.array([R.value(x) for x in q.tolist()], dtype=np.uint32))
+    np.testing.assert_array_equal(av, np.array([A.value(x) for x in q.tolist()], dtype=np.uint32))
+
+
 def test_index_full_is_reported():
     m = _mfx()
     k = 21
