@@ -13,6 +13,8 @@
 
 #include <algorithm>
 #include <string>
+#include <thread>
+#include <unordered_map>
 #include <vector>
 
 // ---------------------------------------------------------------------------
@@ -671,8 +673,63 @@ extern "C" int mfx_dump_values(mfx_eval *ev, const mfx_seq *seq, uint32_t contig
   return MFX_OK;
 }
 
+// host threads the library may use for text formatting: min(hardware, cgroup quota, 64)
+static unsigned host_threads() {
+  const char *e = getenv("MFX_HOST_THREADS");
+  if (e && atoi(e) > 0) return (unsigned)atoi(e);
+  unsigned n = std::thread::hardware_concurrency();
+  if (n == 0) n = 1;
+  if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[64], per[64];
+    if (fscanf(f, "%63s %63s", q, per) == 2 && strcmp(q, "max") != 0 && atof(per) > 0) {
+      unsigned lim = (unsigned)(atof(q) / atof(per));
+      if (lim >= 1 && lim < n) n = lim;
+    }
+    fclose(f);
+  }
+  return std::min(n, 64u);
+}
+
+// Formats the lines of outputDump (merfin-dump.C:87-93) for positions
+// [o, o+cnt) into `out`.  The text after the position depends only on the
+// (readV, asmV) pair, so it is produced once per distinct pair by the very
+// same printf("%.2f") the reference uses and then reused.
+static void dump_format_range(const mfx_kparams &kp, const char *name, size_t name_len, uint64_t o, uint64_t cnt,
+                              const uint32_t *rv, const uint32_t *av, std::string &out) {
+  std::unordered_map<uint64_t, std::string> tail;
+  tail.reserve(4096);
+  char buf[128], num[24];
+  out.clear();
+  out.reserve(cnt * 24);
+  for (uint64_t i = 0; i < cnt; ++i) {
+    if (rv[i] == 0 && av[i] == 0) continue;            // readK = asmK = K* = 0: no line
+    const uint64_t key = ((uint64_t)rv[i] << 32) | av[i];
+    auto it = tail.find(key);
+    if (it == tail.end()) {
+      double readK, asmK, prob;
+      mfx_getK(&kp, rv[i], av[i], &readK, &asmK, &prob);
+      double km = mfx_kmetric(readK, asmK);
+      std::string t;
+      if ((readK != 0.0) || (asmK != 0.0) || (km != 0.0)) {
+        int n = snprintf(buf, sizeof(buf), "\t%.2f\t%.2f\t%.2f\n", readK, asmK, km);
+        t.assign(buf, (size_t)n);
+      }
+      it = tail.emplace(key, std::move(t)).first;
+    }
+    if (it->second.empty()) continue;
+    uint64_t pos = o + i;
+    int d = 0;
+    do { num[d++] = (char)('0' + pos % 10); pos /= 10; } while (pos);
+    out.append(name, name_len);
+    out.push_back('\t');
+    while (d) out.push_back(num[--d]);
+    out.append(it->second);
+  }
+}
+
 // outputDump, merfin-dump.C:87-93: a line for every position where any of
-// readK, asmK, K* is non-zero.
+// readK, asmK, K* is non-zero.  Values come from the GPU in 16 M-position
+// chunks; host threads format disjoint sub-ranges, written back in order.
 extern "C" int mfx_dump_contig(mfx_eval *ev, const mfx_seq *seq, uint32_t contig, const char *name,
                                const char *path, int append, uint64_t *kasm, uint64_t *kmissing) {
   if (!ev || !seq || !name || !path) return mfx_fail(MFX_E_INVAL, "mfx_dump_contig: null argument");
@@ -684,6 +741,9 @@ extern "C" int mfx_dump_contig(mfx_eval *ev, const mfx_seq *seq, uint32_t contig
   const uint64_t CH = 1ull << 24;
   std::vector<uint32_t> rv(std::min(len, CH) + 1), av(std::min(len, CH) + 1);
   mfx_kparams kp{ev->peak, ev->n_prob, ev->probK.data(), ev->probP.data()};
+  const size_t name_len = strlen(name);
+  const unsigned nthr = host_threads();
+  std::vector<std::string> parts(nthr);
   uint64_t ka = 0, km = 0;
   int rc = MFX_OK;
   for (uint64_t o = 0; o < len && rc == MFX_OK; o += CH) {
@@ -692,14 +752,18 @@ extern "C" int mfx_dump_contig(mfx_eval *ev, const mfx_seq *seq, uint32_t contig
     if (rc) break;
     ka += a1;
     km += m1;
-    for (uint64_t i = 0; i < e - o; ++i) {
-      if (rv[i] == 0 && av[i] == 0) continue;          // all three values are zero
-      double readK, asmK, prob;
-      mfx_getK(&kp, rv[i], av[i], &readK, &asmK, &prob);
-      double km_ = mfx_kmetric(readK, asmK);
-      if ((readK != 0.0) || (asmK != 0.0) || (km_ != 0.0))
-        fprintf(f, "%s\t%lu\t%.2f\t%.2f\t%.2f\n", name, (unsigned long)(o + i), readK, asmK, km_);
+    const uint64_t cnt = e - o, per = (cnt + nthr - 1) / nthr;
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nthr; ++t) {
+      uint64_t b = std::min(cnt, t * per), n = std::min(cnt, b + per) - b;
+      th.emplace_back([&, t, b, n]() { dump_format_range(kp, name, name_len, o + b, n, rv.data() + b, av.data() + b, parts[t]); });
     }
+    for (auto &x : th) x.join();
+    for (unsigned t = 0; t < nthr; ++t)
+      if (!parts[t].empty() && fwrite(parts[t].data(), 1, parts[t].size(), f) != parts[t].size()) {
+        rc = mfx_fail(MFX_E_IO, "short write to '%s'", path);
+        break;
+      }
   }
   close_writer(f, pipe);
   if (kasm) *kasm = ka;

@@ -501,24 +501,40 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_dump_kernel(mfx_dump_args a) {
   mfx_tile_fill(L, a.src + pos0);
   __syncthreads();
   uint64_t n_valid = 0, n_missing = 0, zz = 0;
-  for (uint32_t b = 0; b < MFX_TILE / MFX_BLOCK; ++b) {
-    uint32_t p = b * MFX_BLOCK + tid;
-    uint64_t gp = pos0 + p;
-    if (gp >= a.npos || gp < a.skip) continue;
-    uint64_t f;
-    bool ok = mfx_tile_kmer(L, k, p, f) && (gp < a.clen_left);
-    uint2 v = make_uint2(0u, 0u);
-    if (ok) {
+  for (uint32_t b = 0; b < MFX_TILE / MFX_BLOCK; b += MFX_BATCH) {
+    uint64_t key[MFX_BATCH], key2[MFX_BATCH];
+    uint32_t rv[MFX_BATCH], av[MFX_BATCH];
+    bool     ok[MFX_BATCH], wr[MFX_BATCH];
+#pragma unroll
+    for (int j = 0; j < MFX_BATCH; ++j) {
+      uint32_t p = (b + j) * MFX_BLOCK + tid;
+      uint64_t gp = pos0 + p, f;
+      wr[j] = gp < a.npos && gp >= a.skip;
+      ok[j] = mfx_tile_kmer(L, k, p, f) && wr[j] && (gp < a.clen_left);
       uint64_t r = mfx_revcomp(f, k);
-      if (CANON) v = mfx_lookup(a.t, f < r ? f : r);
-      else { uint2 v1 = mfx_lookup(a.t, f), v2 = mfx_lookup(a.t, r); v = make_uint2(v1.x + v2.x, v1.y + v2.y); }
-      n_valid++;                                                    // merfin-dump.C:48
-      double readK, prob;
-      mfx_getK_core(a.peak, a.n_prob, a.probK, a.probP, v.x, readK, prob);
-      if (readK == 0) n_missing++;                                  // :56-58
+      if (CANON) key[j] = f < r ? f : r;
+      else { key[j] = f; key2[j] = r; }
     }
-    a.readV[gp - a.skip] = v.x;
-    a.asmV[gp - a.skip] = v.y;
+    mfx_group_lookup<MFX_BATCH>(a.t, key, ok, rv, av);
+    if (!CANON) {
+      uint32_t rv2[MFX_BATCH], av2[MFX_BATCH];
+      mfx_group_lookup<MFX_BATCH>(a.t, key2, ok, rv2, av2);
+#pragma unroll
+      for (int j = 0; j < MFX_BATCH; ++j) { rv[j] += rv2[j]; av[j] += av2[j]; }
+    }
+#pragma unroll
+    for (int j = 0; j < MFX_BATCH; ++j) {
+      if (!wr[j]) continue;
+      uint64_t gp = pos0 + (b + j) * MFX_BLOCK + tid;
+      if (ok[j]) {
+        n_valid++;                                                    // merfin-dump.C:48
+        double readK, prob;
+        mfx_getK_core(a.peak, a.n_prob, a.probK, a.probP, rv[j], readK, prob);
+        if (readK == 0) n_missing++;                                  // :56-58
+      }
+      a.readV[gp - a.skip] = ok[j] ? rv[j] : 0u;
+      a.asmV[gp - a.skip] = ok[j] ? av[j] : 0u;
+    }
   }
   mfx_block_sum3(n_valid, n_missing, zz, s_red);
   if (tid == 0 && (n_valid | n_missing)) {
