@@ -222,6 +222,33 @@ int mfx_dump_contig(mfx_eval *ev, const mfx_seq *seq, uint32_t contig, const cha
                     const char *path, int append, uint64_t *kasm, uint64_t *kmissing);
 
 /* ------------------------------------------------------------------------ */
+/* -filter / -polish / -better / -strict / -loose: replaces processVariants */
+/* + outputVariants (merfin-variants.C:131-345), vcfFile (vcf.C) and varMer  */
+/* (varMer.C).  The host enumerates the allele-combination paths of many     */
+/* clusters, the GPU scores every k-mer of every path in one launch of the   */
+/* -dump lookup kernel, the host applies the mode's selector.                */
+/* ------------------------------------------------------------------------ */
+#define MFX_VAR_FILTER 4      /* OP_FILTER .. OP_LOOSE, merfin-globals.H:34-38 */
+#define MFX_VAR_POLISH 5
+#define MFX_VAR_BETTER 6
+#define MFX_VAR_STRICT 7
+#define MFX_VAR_LOOSE  8
+typedef struct {
+  int         mode;         /* MFX_VAR_*                                       */
+  uint32_t    comb;         /* -comb (0 = default 15), merfin.C:144-145        */
+  int         nosplit;      /* -nosplit                                        */
+  const char *debug_path;   /* -debug log (merfin-variants.C:240-276) or NULL; */
+                            /* a name ending in .gz is gzip-compressed         */
+} mfx_variant_opts;
+/* names/bases/lens: the contigs of -sequence (ident() = first header token is
+ * matched against VCF CHROM, merfin-variants.C:141).  Writes headers + the
+ * selected records to out_path (contigs in input order).  log_path receives
+ * the PANIC / WARNING / progress lines (NULL = stderr). */
+int mfx_variants_run(mfx_eval *ev, const char *vcf_path, const char *const *names, const char *const *bases,
+                     const uint64_t *lens, uint32_t ncontigs, const mfx_variant_opts *opts,
+                     const char *out_path, const char *log_path, uint64_t *n_clusters);
+
+/* ------------------------------------------------------------------------ */
 /* -completeness: replaces computeCompleteness (merfin-completeness.C:48-144)*/
 /* as one streaming pass over the joint table.                              */
 /* ------------------------------------------------------------------------ */

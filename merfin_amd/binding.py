@@ -37,6 +37,13 @@ class _DbInfo(C.Structure):
     _fields_ = [("k", C.c_int), ("format", C.c_int), ("n_kmers", C.c_uint64)]
 
 
+class _VarOpts(C.Structure):
+    _fields_ = [("mode", C.c_int), ("comb", C.c_uint32), ("nosplit", C.c_int), ("debug_path", C.c_char_p)]
+
+
+VARIANT_MODES = {"filter": 4, "polish": 5, "better": 6, "strict": 7, "loose": 8}
+
+
 class _HistResult(C.Structure):
     _fields_ = [("kasm", C.c_uint64), ("kmissing", C.c_uint64), ("koverCpy", C.c_double),
                 ("undrMax", C.c_uint32), ("overMax", C.c_uint32),
@@ -58,7 +65,7 @@ SYMBOLS = [
     "mfx_eval_create", "mfx_eval_free", "mfx_eval_nbins", "mfx_getK", "mfx_getKmetric", "mfx_histoQV",
     "mfx_hist_run", "mfx_hist_result_free", "mfx_hist_launch", "mfx_hist_result_from_counts",
     "mfx_hist_take_overflow", "mfx_hist_report",
-    "mfx_dump_values", "mfx_dump_contig", "mfx_completeness",
+    "mfx_dump_values", "mfx_dump_contig", "mfx_completeness", "mfx_variants_run",
 ]
 
 
@@ -139,6 +146,8 @@ def load_library():
     L.mfx_dump_values.argtypes = [vp, vp, C.c_uint32, C.c_uint64, C.c_uint64, u32p, u32p, u64p, u64p]
     L.mfx_dump_contig.argtypes = [vp, vp, C.c_uint32, C.c_char_p, C.c_char_p, C.c_int, u64p, u64p]
     L.mfx_completeness.argtypes = [vp, f64p, f64p]
+    L.mfx_variants_run.argtypes = [vp, C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), u64p, C.c_uint32,
+                                   C.POINTER(_VarOpts), C.c_char_p, C.c_char_p, u64p]
     _lib = L
     return L
 
@@ -426,6 +435,18 @@ class Evaluator:
         _check(load_library().mfx_dump_contig(self.h, seqs.h, contig, name.encode(), path.encode(), 1 if append else 0,
                                               C.byref(ka), C.byref(km)))
         return ka.value, km.value
+
+    def variants(self, mode, vcf_path, names, contigs, out_path, comb=15, nosplit=False, debug_path=None, log_path=None):
+        """-filter/-polish/-better/-strict/-loose over all contigs; returns clusters evaluated"""
+        n = len(contigs)
+        nm = (C.c_char_p * n)(*[x.encode() for x in names])
+        arr = (C.c_char_p * n)(*contigs)
+        lens = np.array([len(c) for c in contigs], dtype=np.uint64)
+        o = _VarOpts(VARIANT_MODES[mode], comb, 1 if nosplit else 0, debug_path.encode() if debug_path else None)
+        ncl = C.c_uint64(0)
+        _check(load_library().mfx_variants_run(self.h, vcf_path.encode(), nm, arr, lens.ctypes.data_as(C.POINTER(C.c_uint64)), n,
+                                               C.byref(o), out_path.encode(), log_path.encode() if log_path else None, C.byref(ncl)))
+        return ncl.value
 
     def completeness(self):
         t, u = C.c_double(), C.c_double()

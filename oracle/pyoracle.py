@@ -15,7 +15,7 @@ _LIB_PATH = os.path.join(_HERE, "_build", "libmerfin_oracle.so")
 
 
 def build(force=False):
-    src = [os.path.join(_HERE, f) for f in ("merfin_oracle.c", "merfin_oracle.h", "Makefile")]
+    src = [os.path.join(_HERE, f) for f in ("merfin_oracle.c", "merfin_oracle.h", "merfin_oracle_variants.cpp", "Makefile")]
     if (not force and os.path.exists(_LIB_PATH)
             and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in src)):
         return _LIB_PATH
@@ -100,6 +100,9 @@ def lib():
     L.orc_output_dump.restype = C.c_uint64
     L.orc_output_dump.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, f64p, f64p, f64p]
     L.orc_completeness_piece.argtypes = [C.POINTER(_Params), u64p, u32p, C.c_uint64, u64p, u32p, C.c_uint64, f64p, f64p]
+    L.orc_variants_run.restype = C.c_long
+    L.orc_variants_run.argtypes = [C.POINTER(_Params), C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_char_p,
+                                   C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), u64p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_char_p]
     _lib = L
     return L
 
@@ -298,3 +301,20 @@ def kiter(k, bases):
     while L.orc_kiter_next_base(C.byref(it)):
         if L.orc_kiter_is_valid(C.byref(it)):
             yield L.orc_kiter_position(C.byref(it)), it.fmer, it.rmer
+
+
+VARIANT_MODES = {"filter": 4, "polish": 5, "better": 6, "strict": 7, "loose": 8}
+
+
+def variants_run(p, R, A, mode, vcf_path, names, contigs, out_path, comb=15, nosplit=False, debug_path=None, log_path=None):
+    """processVariants + outputVariants (merfin-variants.C) over all contigs, input order."""
+    n = len(contigs)
+    nm = (C.c_char_p * n)(*[x.encode() for x in names])
+    arr = (C.c_char_p * n)(*contigs)
+    lens = np.array([len(c) for c in contigs], dtype=np.uint64)
+    rc = lib().orc_variants_run(p.ref(), R.h, A.h, VARIANT_MODES[mode], comb, 1 if nosplit else 0, vcf_path.encode(),
+                                nm, arr, _u64(lens), n, out_path.encode(),
+                                debug_path.encode() if debug_path else None, log_path.encode() if log_path else None)
+    if rc < 0:
+        raise RuntimeError("orc_variants_run failed: %d" % rc)
+    return rc

@@ -1,0 +1,75 @@
+"""-filter / -polish / -better / -strict / -loose: the GPU-scored path against
+the oracle's line-by-line restatement of vcf.C / merfin-variants.C / varMer.C.
+Outputs are text and must be byte-identical (VCF records, -debug statistics)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from tests import synth
+
+MODES = ["filter", "polish", "better", "strict", "loose"]
+
+
+def _run_both(tmp_path, mode, k=21, peak=17.3, seed=synth.SEED, comb=15, nosplit=False, use_prob=False, golden_dir=None, **kw):
+    import merfin_amd as m
+    names, asm, vcf, read, amers = synth.variant_world(k=k, peak=peak, seed=seed, **kw)
+    vp = str(tmp_path / "in.vcf")
+    open(vp, "w").write(vcf)
+    K = P = None
+    if use_prob:
+        K, P = po.load_kmetric(os.path.join(golden_dir, "example_lookup_table.txt"))
+    p = po.Params(k, peak, K, P)
+    R, A = po.Lookup(k, *read), po.Lookup(k, *amers)
+    tag = "%s_%d" % (mode, seed)
+    o_out, o_dbg, o_log = [str(tmp_path / ("o_%s.%s" % (tag, e))) for e in ("vcf", "dbg", "log")]
+    g_out, g_dbg, g_log = [str(tmp_path / ("g_%s.%s" % (tag, e))) for e in ("vcf", "dbg", "log")]
+    n_o = po.variants_run(p, R, A, mode, vp, names, asm, o_out, comb=comb, nosplit=nosplit, debug_path=o_dbg, log_path=o_log)
+    ix = m.Index(k, len(read[0]) + len(amers[0]) + 16)
+    ix.add_read(*read)
+    ix.add_asm(*amers)
+    ev = m.Evaluator(ix, m.KParams(peak, K, P))
+    n_g = ev.variants(mode, vp, names, asm, g_out, comb=comb, nosplit=nosplit, debug_path=g_dbg, log_path=g_log)
+    return (n_o, o_out, o_dbg, o_log), (n_g, g_out, g_dbg, g_log)
+
+
+def _special(path):
+    return sorted(l for l in open(path).read().splitlines() if l.startswith("PANIC") or l.startswith("[ WARNING ]"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", MODES)
+def test_variant_modes_match_oracle(tmp_path, mode):
+    (n_o, o_out, o_dbg, o_log), (n_g, g_out, g_dbg, g_log) = _run_both(tmp_path, mode, comb=10)
+    assert n_o == n_g and n_o > 50
+    out = open(o_out).read()
+    assert open(g_out).read() == out
+    body = [l for l in out.splitlines() if not l.startswith("#")]
+    assert len(body) > 50                       # the mode actually selected records
+    assert open(g_dbg).read() == open(o_dbg).read()
+    assert os.path.getsize(o_dbg) > 20000
+    assert _special(g_log) == _special(o_log)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,seed,comb,nosplit,k", [("polish", 7, 4, False, 21), ("polish", 8, 12, True, 21), ("loose", 9, 6, False, 15),
+                                                      ("filter", 10, 15, False, 31), ("strict", 11, 3, True, 11)])
+def test_variant_options_and_k(tmp_path, mode, seed, comb, nosplit, k, golden_dir):
+    (n_o, o_out, o_dbg, o_log), (n_g, g_out, g_dbg, g_log) = _run_both(tmp_path, mode, k=k, seed=seed, comb=comb, nosplit=nosplit,
+                                                                      use_prob=(seed % 2 == 1), golden_dir=golden_dir, peak=26.0)
+    assert n_o == n_g
+    assert open(g_out).read() == open(o_out).read()
+    assert open(g_dbg).read() == open(o_dbg).read()
+    assert _special(g_log) == _special(o_log)
+    if nosplit:
+        assert any(l.startswith("PANIC : Combination") for l in _special(o_log))
+
+
+@pytest.mark.gpu
+def test_polish_fixes_the_assembly(tmp_path):
+    """Sanity of the whole idea (not a parity claim): applying -polish's 1/1 records
+    removes most of the k-mers that were missing from the reads."""
+    (n_o, o_out, _, _), _ = _run_both(tmp_path, "polish", seed=21, decoys=0)
+    recs = [l.split("\t") for l in open(o_out).read().splitlines() if not l.startswith("#")]
+    assert sum(1 for r in recs if r[9] == "1/1") > 100
