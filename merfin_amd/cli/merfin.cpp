@@ -3,9 +3,9 @@
 // merfin_amd C ABI.  The pthread sweatShop pipeline (merfin.C:366-414) is
 // replaced by: read all contigs -> pack into HBM -> one kernel launch per mode.
 //
-// Implemented report types: -hist, -dump, -completeness.
-// -filter/-polish/-better/-strict/-loose (varMer scoring) are recognised and
-// rejected with a clear message in this build.
+// Report types: -hist, -dump, -completeness, and the variant modes -filter /
+// -polish / -better / -strict / -loose (paths enumerated on the host, every
+// path k-mer scored on the GPU).
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -49,7 +49,10 @@ static void usage(const char *exe) {
           "    -hist           0-centred K* histogram to <output>; QV and QV* on stderr\n"
           "    -dump           seqName, seqPos, readK, asmK, K* per k-mer to <output>  [-skipMissing]\n"
           "    -completeness   k-mer completeness from -seqmers (or -sequence) and -readmers\n"
-          "    -filter -polish -better -strict -loose   variant scoring with -vcf: NOT in this build\n\n",
+          "    -filter         keep variants (and combinations within k) that minimise missing k-mers -> <output>.filter.vcf\n"
+          "    -polish         choose variant combinations by missing k-mers, ties by k* -> <output>.polish.vcf\n"
+          "    -better -strict -loose   k*-free variants of -polish -> <output>.filter.vcf\n"
+          "                    [-comb N (15)] [-nosplit] [-debug -> <output>.00.debug.gz]\n\n",
           exe);
 }
 
@@ -145,11 +148,6 @@ int main(int argc, char **argv) {
   if (!err.empty()) {
     usage(argv[0]);
     for (auto &e : err) fputs(e.c_str(), stderr);
-    return 1;
-  }
-  if (variantMode) {
-    fprintf(stderr, "ERROR: variant scoring (-filter/-polish/-better/-strict/-loose) is not part of this build; "
-                    "-hist, -dump and -completeness are.\n");
     return 1;
   }
   if (mfx_device_count() <= G.device) {
@@ -248,6 +246,22 @@ int main(int argc, char **argv) {
       }
       if (recs.empty()) { FILE *f = fopen(G.outName, "w"); if (f) fclose(f); }
     }
+  } else if (variantMode) {
+    // open_Inputs + processVariants + outputVariants (merfin-globals.C:201-219, merfin-variants.C:131-345)
+    fprintf(stderr, "-- Opening vcf file '%s'.\n", G.vcfName);
+    fprintf(stderr, "-- Generate variant mers and score them.\n");
+    std::string outName = std::string(G.outName) + (G.reportType == OP_POLISH ? ".polish.vcf" : ".filter.vcf");   // :324-327
+    std::string dbgName = std::string(G.outName) + ".00.debug.gz";
+    std::vector<const char *> names(recs.size());
+    for (size_t c = 0; c < recs.size(); ++c) names[c] = recs[c].name.c_str();
+    mfx_variant_opts vo;
+    vo.mode = G.reportType;           // OP_* values are the MFX_VAR_* values
+    vo.comb = G.comb;
+    vo.nosplit = G.nosplit ? 1 : 0;
+    vo.debug_path = G.debug ? dbgName.c_str() : nullptr;
+    uint64_t ncl = 0;
+    if (mfx_variants_run(ev, G.vcfName, names.data(), bases.data(), lens.data(), (uint32_t)recs.size(), &vo, outName.c_str(), nullptr, &ncl))
+      DIE_MFX("variant scoring");
   } else if (G.reportType == OP_COMPL) {
     fprintf(stderr, "-- Compute completeness.\n");
     double total = 0, undrc = 0;

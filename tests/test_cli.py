@@ -121,3 +121,32 @@ def test_cli_hist_dump_completeness_end_to_end(tmp_path, golden_dir):
     r6 = run(["-hist", "-sequence", fa, "-readmers", str(tmp_path / "read.mfxk"), "-peak", "26", "-memory", "0.0001",
               "-output", str(tmp_path / "x")])
     assert r6.returncode == 1 and "Not enough memory to load databases.  Increase -memory." in r6.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["polish", "filter", "loose"])
+def test_cli_variant_modes(tmp_path, mode):
+    import merfin_amd as m
+    k, peak = 21, 17.3
+    names, asm, vcf, read, amers = synth.variant_world(k=k, peak=peak, seed=61)
+    vp = str(tmp_path / "in.vcf")
+    open(vp, "w").write(vcf)
+    p = po.Params(k, peak)
+    R, A = po.Lookup(k, *read), po.Lookup(k, *amers)
+    po.variants_run(p, R, A, mode, vp, names, asm, str(tmp_path / "o.vcf"), comb=8, debug_path=str(tmp_path / "o.dbg"))
+    fa = str(tmp_path / "asm.fasta")
+    with open(fa, "wb") as f:
+        for n, c in zip(names, asm):
+            f.write(b">" + n.encode() + b" extra words\n" + c + b"\n")
+    m.db_write_flat(str(tmp_path / "read.mfxk"), k, *read)
+    m.db_write_flat(str(tmp_path / "asm.mfxk"), k, *amers)
+    args = ["-" + mode, "-sequence", fa, "-readmers", str(tmp_path / "read.mfxk"), "-seqmers", str(tmp_path / "asm.mfxk"),
+            "-vcf", vp, "-comb", "8", "-debug", "-output", str(tmp_path / "out")]
+    if mode != "filter":
+        args += ["-peak", str(peak)]
+    r = run(args)
+    assert r.returncode == 0, r.stderr
+    suffix = ".polish.vcf" if mode == "polish" else ".filter.vcf"       # merfin-variants.C:324-327
+    assert (tmp_path / ("out" + suffix)).read_text() == (tmp_path / "o.vcf").read_text()
+    assert gzip.open(str(tmp_path / "out.00.debug.gz"), "rt").read() == (tmp_path / "o.dbg").read_text()
+    assert "Processing sequence ctg0 for variants" in r.stderr
