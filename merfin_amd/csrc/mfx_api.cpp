@@ -94,6 +94,7 @@ mfx_table_view mfx_index::view() const {
   v.minV = minV > 0xffffffffull ? 0xffffffffu : (uint32_t)minV;
   v.maxV = maxV > 0xffffffffull ? 0xffffffffu : (uint32_t)maxV;
   v.k = k;
+  v.mz_w = mz_w;
   return v;
 }
 
@@ -124,6 +125,12 @@ extern "C" mfx_index *mfx_index_create(int k, uint64_t capacity_kmers, double ma
   ix->k = k;
   ix->capacity_kmers = capacity_kmers;
   ix->nlines = lines_for(capacity_kmers);
+  {
+    // placement: "mz" = minimizer-keyed home line (consecutive k-mers share lines), "plain" = k-mer hash only
+    const char *hm = getenv("MFX_HOME_MODE");
+    bool mz = hm ? (strcmp(hm, "mz") == 0) : false;
+    ix->mz_w = mz ? std::min(5, k) : 0;
+  }
   hipError_t e = hipMalloc((void **)&ix->d_slots, ix->nlines * MFX_ALIGN);
   if (e != hipSuccess) {
     mfx_fail(MFX_E_NOMEM, "hipMalloc of %.3f GB for the k-mer table failed: %s", need, hipGetErrorString(e));

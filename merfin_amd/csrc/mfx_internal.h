@@ -51,6 +51,7 @@ struct mfx_table_view {
   uint64_t  nlines;             // 128-byte lines; slots = 8 * nlines
   uint32_t  minV, maxV;         // read-count filter (merfin.C:199-200), clamped to uint32
   int       k;
+  int       mz_w;               // minimizer windows (0 = plain k-mer hashing; else m = k - mz_w + 1)
 };
 
 struct mfx_index {
@@ -62,6 +63,7 @@ struct mfx_index {
   uint64_t *d_meta = nullptr;   // [0] distinct  [1] non-canonical inserts  [2] probe-limit failures
   uint64_t  minV = 0, maxV = ~0ull;
   bool      filter_set = false;
+  int       mz_w = 0;
   mfx_table_view view() const;
 };
 

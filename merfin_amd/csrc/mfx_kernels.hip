@@ -23,76 +23,122 @@ __device__ __forceinline__ uint64_t mfx_hash64(uint64_t x) {
   return x;
 }
 
-// home line (high hash bits, multiply-range) and home slot (low hash bits)
-__device__ __forceinline__ uint64_t mfx_home(const mfx_table_view &t, uint64_t key, uint32_t &p1) {
-  uint64_t h = mfx_hash64(key);
-  p1 = (uint32_t)h & (MFX_SLOTS_LINE - 1);
-  return __umul64hi(h, t.nlines);
-}
-
-// j-th slot of the probe sequence: cyclic inside the home line, then on to the
-// following lines.  Insert-only table => lookups may stop at the first empty.
-__device__ __forceinline__ uint64_t mfx_probe_slot(const mfx_table_view &t, uint64_t line, uint32_t p1, uint32_t j) {
-  uint64_t ln = line + (j >> 3);
-  if (ln >= t.nlines) ln -= t.nlines;
-  return ln * MFX_SLOTS_LINE + ((p1 + j) & (MFX_SLOTS_LINE - 1));
-}
-
-constexpr uint32_t MFX_MAX_PROBE = 8 * 512;
-
-__device__ __forceinline__ uint4 mfx_load_slot(const mfx_table_view &t, uint64_t s) {
-  return *reinterpret_cast<const uint4 *>(t.slots + s);
-}
-
-// finish a lookup whose first slot is already in registers
-__device__ __forceinline__ uint2 mfx_resolve(const mfx_table_view &t, uint64_t key, uint64_t line, uint32_t p1, uint4 s) {
-  uint32_t j = 0;
-  while (true) {
-    uint64_t sk = (uint64_t)s.x | ((uint64_t)s.y << 32);
-    if (sk == key) {
-      uint32_t rv = s.z;
-      if (rv < t.minV || rv > t.maxV) rv = 0;      // -min / -max (merfin.C:199-200)
-      return make_uint2(rv, s.w);
-    }
-    if (sk == MFX_EMPTY || ++j >= MFX_MAX_PROBE)
-      return make_uint2(0u, 0u);                   // absent -> value 0 (merfin-globals.C:84)
-    s = mfx_load_slot(t, mfx_probe_slot(t, line, p1, j));
-  }
-}
-
-__device__ __forceinline__ uint2 mfx_lookup(const mfx_table_view &t, uint64_t key) {
-  uint32_t p1;
-  uint64_t line = mfx_home(t, key, p1);
-  return mfx_resolve(t, key, line, p1, mfx_load_slot(t, line * MFX_SLOTS_LINE + p1));
-}
-
-// find-or-claim the slot of `key`; nullptr when the probe limit is hit
-__device__ __forceinline__ mfx_slot *mfx_claim(const mfx_table_view &t, uint64_t key, uint64_t *meta) {
-  uint32_t p1;
-  uint64_t line = mfx_home(t, key, p1);
-  for (uint32_t j = 0; j < MFX_MAX_PROBE; ++j) {
-    mfx_slot *sl = t.slots + mfx_probe_slot(t, line, p1, j);
-    unsigned long long *kp = reinterpret_cast<unsigned long long *>(&sl->key);
-    unsigned long long cur = __hip_atomic_load(kp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (cur == MFX_EMPTY) {
-      cur = atomicCAS(kp, (unsigned long long)MFX_EMPTY, (unsigned long long)key);
-      if (cur == MFX_EMPTY) {
-        atomicAdd((unsigned long long *)&meta[0], 1ull);
-        return sl;
-      }
-    }
-    if (cur == key)
-      return sl;
-  }
-  atomicAdd((unsigned long long *)&meta[2], 1ull);
-  return nullptr;
-}
-
 __device__ __forceinline__ uint64_t mfx_revcomp(uint64_t fwd, int k) {
   uint64_t x = __brevll(fwd) >> (64 - 2 * k);                       // groups reversed, bits in each pair swapped
   x = ((x & 0x5555555555555555ULL) << 1) | ((x >> 1) & 0x5555555555555555ULL);
   uint64_t mask = (~0ULL) >> (64 - 2 * k);
   return (x ^ 0xAAAAAAAAAAAAAAAAULL) & mask;                         // complement = code ^ 2
+}
+
+
+// ---------------------------------------------------------------------------
+// Probe sequence.  A k-mer's candidate lines are
+//   region A: MFX_MZ_REGION consecutive lines starting at the line of its
+//             canonical MINIMIZER (only when t.mz_w > 0), then
+//   region B: consecutive lines starting at the line of the k-mer's own hash.
+// Insert-only table; a k-mer lives in candidate line d only if lines 0..d-1
+// were full when it was inserted, so a lookup stops at the first candidate
+// line that holds the key or still has an empty slot.
+//
+// Why the minimizer: consecutive k-mers of a sequence share their minimizer
+// for runs of ~(w+1)/2 positions, so their probes fall into the SAME 128-byte
+// line -- fewer than one HBM line fetch per k-mer.  w = 5 windows (m = k-4)
+// keeps a minimizer's bucket (~2 k-mers, size-biased) inside one line.
+// ---------------------------------------------------------------------------
+constexpr uint32_t MFX_MZ_REGION = 4;
+constexpr uint32_t MFX_MAX_LINES = 512;
+
+struct mfx_probe {
+  uint32_t lineA, lineB, p1;
+};
+
+__device__ __forceinline__ uint64_t mfx_minimizer_hash(uint64_t key, int k, int w) {
+  const int m = k - w + 1;
+  const uint64_t mmask = (~0ULL) >> (64 - 2 * m);
+  const uint64_t rc = mfx_revcomp(key, k);
+  uint64_t best = ~0ULL;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    if (j < w) {
+      uint64_t a = (key >> (2 * j)) & mmask;                 // m-mer starting at base w-1-j
+      uint64_t b = (rc >> (2 * (w - 1 - j))) & mmask;        // its reverse complement
+      uint64_t c = a < b ? a : b;                            // canonical m-mer: strand independent
+      uint64_t h = c * 0x9E3779B97F4A7C15ULL;                // bijective on 64 bits: a total random-ish order
+      best = h < best ? h : best;
+    }
+  }
+  return best;
+}
+
+__device__ __forceinline__ mfx_probe mfx_home(const mfx_table_view &t, uint64_t key) {
+  mfx_probe pr;
+  uint64_t h = mfx_hash64(key);
+  pr.p1 = (uint32_t)h & (MFX_SLOTS_LINE - 1);
+  pr.lineB = (uint32_t)__umul64hi(h, t.nlines);
+  pr.lineA = pr.lineB;
+  if (t.mz_w > 0)
+    pr.lineA = (uint32_t)__umul64hi(mfx_hash64(mfx_minimizer_hash(key, t.k, t.mz_w)), t.nlines);
+  return pr;
+}
+
+// d-th candidate line
+__device__ __forceinline__ uint64_t mfx_probe_line(const mfx_table_view &t, const mfx_probe &pr, uint32_t d) {
+  const uint32_t ra = t.mz_w > 0 ? MFX_MZ_REGION : 0u;
+  uint64_t ln = d < ra ? (uint64_t)pr.lineA + d : (uint64_t)pr.lineB + (d - ra);
+  if (ln >= t.nlines) ln -= t.nlines;
+  return ln;
+}
+
+__device__ __forceinline__ uint4 mfx_load_slot(const mfx_table_view &t, uint64_t s) {
+  return *reinterpret_cast<const uint4 *>(t.slots + s);
+}
+
+// per-lane scan of candidate lines d0, d0+1, ... (8 slots each)
+__device__ __forceinline__ uint2 mfx_scan_lines(const mfx_table_view &t, uint64_t key, const mfx_probe &pr, uint32_t d0) {
+  for (uint32_t d = d0; d < MFX_MAX_LINES; ++d) {
+    const uint64_t base = mfx_probe_line(t, pr, d) * MFX_SLOTS_LINE;
+    bool any_empty = false;
+    for (uint32_t q = 0; q < MFX_SLOTS_LINE; ++q) {
+      uint4 s = mfx_load_slot(t, base + ((pr.p1 + q) & (MFX_SLOTS_LINE - 1)));
+      uint64_t sk = (uint64_t)s.x | ((uint64_t)s.y << 32);
+      if (sk == key) {
+        uint32_t rv = s.z;
+        if (rv < t.minV || rv > t.maxV) rv = 0;      // -min / -max (merfin.C:199-200)
+        return make_uint2(rv, s.w);
+      }
+      if (sk == MFX_EMPTY) { any_empty = true; break; }   // first empty slot of THIS key's own probe order: the key was never inserted
+    }
+    if (any_empty) break;
+  }
+  return make_uint2(0u, 0u);                          // absent -> value 0 (merfin-globals.C:84)
+}
+
+__device__ __forceinline__ uint2 mfx_lookup(const mfx_table_view &t, uint64_t key) {
+  return mfx_scan_lines(t, key, mfx_home(t, key), 0);
+}
+
+// find-or-claim the slot of `key`; nullptr when the probe limit is hit
+__device__ __forceinline__ mfx_slot *mfx_claim(const mfx_table_view &t, uint64_t key, uint64_t *meta) {
+  const mfx_probe pr = mfx_home(t, key);
+  for (uint32_t d = 0; d < MFX_MAX_LINES; ++d) {
+    const uint64_t base = mfx_probe_line(t, pr, d) * MFX_SLOTS_LINE;
+    for (uint32_t q = 0; q < MFX_SLOTS_LINE; ++q) {
+      mfx_slot *sl = t.slots + base + ((pr.p1 + q) & (MFX_SLOTS_LINE - 1));
+      unsigned long long *kp = reinterpret_cast<unsigned long long *>(&sl->key);
+      unsigned long long cur = __hip_atomic_load(kp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (cur == MFX_EMPTY) {
+        cur = atomicCAS(kp, (unsigned long long)MFX_EMPTY, (unsigned long long)key);
+        if (cur == MFX_EMPTY) {
+          atomicAdd((unsigned long long *)&meta[0], 1ull);
+          return sl;
+        }
+      }
+      if (cur == key)
+        return sl;
+    }
+  }
+  atomicAdd((unsigned long long *)&meta[2], 1ull);
+  return nullptr;
 }
 
 __global__ void mfx_table_init_kernel(mfx_slot *slots, uint64_t nslots) {
@@ -207,11 +253,12 @@ __device__ __forceinline__ void mfx_group_lookup(const mfx_table_view &t, const 
                                                  uint32_t (&rv)[B], uint32_t (&av)[B]) {
   const uint32_t lane = threadIdx.x & 63u, sub = lane & 7u, gbase = lane & ~7u;
   uint32_t line[B];
+  mfx_probe pr[B];
   bool pending[B];
 #pragma unroll
   for (int j = 0; j < B; ++j) {
-    uint32_t p1;
-    line[j] = ok[j] ? (uint32_t)mfx_home(t, key[j], p1) : 0xffffffffu;
+    pr[j] = mfx_home(t, key[j]);
+    line[j] = ok[j] ? (uint32_t)mfx_probe_line(t, pr[j], 0) : 0xffffffffu;
     pending[j] = false;
     rv[j] = av[j] = 0u;
   }
@@ -231,19 +278,9 @@ __device__ __forceinline__ void mfx_group_lookup(const mfx_table_view &t, const 
 #pragma unroll
   for (int j = 0; j < B; ++j)
     if (pending[j]) {
-      // per-lane continuation over the following lines.  The stop rule is per LINE
-      // (a key lives in line L+d only if L..L+d-1 were full when it was inserted,
-      // but inside a line it may sit after empty slots), so scan all 8 slots.
-      for (uint32_t d = 1; d < MFX_MAX_PROBE / MFX_SLOTS_LINE; ++d) {
-        bool any_empty = false, found = false;
-        for (uint32_t q = 0; q < MFX_SLOTS_LINE && !found; ++q) {
-          uint4 s = mfx_load_slot(t, mfx_probe_slot(t, line[j], 0u, d * MFX_SLOTS_LINE + q));
-          uint64_t sk = (uint64_t)s.x | ((uint64_t)s.y << 32);
-          if (sk == key[j]) { rv[j] = (s.z < t.minV || s.z > t.maxV) ? 0u : s.z; av[j] = s.w; found = true; }
-          any_empty |= (sk == MFX_EMPTY);
-        }
-        if (found || any_empty) break;
-      }
+      // home line full without a match: continue per lane over the next candidate lines
+      uint2 v = mfx_scan_lines(t, key[j], pr[j], 1);
+      rv[j] = v.x; av[j] = v.y;
     }
 }
 
