@@ -129,7 +129,10 @@ extern "C" mfx_index *mfx_index_create(int k, uint64_t capacity_kmers, double ma
     // placement: "mz" = minimizer-keyed home line (consecutive k-mers share lines), "plain" = k-mer hash only
     const char *hm = getenv("MFX_HOME_MODE");
     bool mz = hm ? (strcmp(hm, "mz") == 0) : false;
-    ix->mz_w = mz ? std::min(5, k) : 0;
+    const char *ws = getenv("MFX_MZ_W");
+    int w = ws ? atoi(ws) : 5;
+    if (w < 1 || w > 5) w = 5;
+    ix->mz_w = mz ? std::min(w, k) : 0;
   }
   hipError_t e = hipMalloc((void **)&ix->d_slots, ix->nlines * MFX_ALIGN);
   if (e != hipSuccess) {

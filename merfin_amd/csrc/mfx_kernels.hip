@@ -93,24 +93,31 @@ __device__ __forceinline__ uint4 mfx_load_slot(const mfx_table_view &t, uint64_t
   return *reinterpret_cast<const uint4 *>(t.slots + s);
 }
 
-// per-lane scan of candidate lines d0, d0+1, ... (8 slots each)
+// per-lane scan of candidate lines d0, d0+1, ...  All 8 slots of a line are
+// requested back to back (one memory round trip per line, not eight): a lane on
+// this path stalls its whole wave, so latency matters more than the extra loads.
 __device__ __forceinline__ uint2 mfx_scan_lines(const mfx_table_view &t, uint64_t key, const mfx_probe &pr, uint32_t d0) {
   for (uint32_t d = d0; d < MFX_MAX_LINES; ++d) {
-    const uint64_t base = mfx_probe_line(t, pr, d) * MFX_SLOTS_LINE;
+    const uint4 *ln = reinterpret_cast<const uint4 *>(t.slots + mfx_probe_line(t, pr, d) * MFX_SLOTS_LINE);
+    uint4 s[MFX_SLOTS_LINE];
+#pragma unroll
+    for (uint32_t q = 0; q < MFX_SLOTS_LINE; ++q) s[q] = ln[q];
     bool any_empty = false;
+    uint2 hit = make_uint2(0u, 0u);
+    bool found = false;
+#pragma unroll
     for (uint32_t q = 0; q < MFX_SLOTS_LINE; ++q) {
-      uint4 s = mfx_load_slot(t, base + ((pr.p1 + q) & (MFX_SLOTS_LINE - 1)));
-      uint64_t sk = (uint64_t)s.x | ((uint64_t)s.y << 32);
-      if (sk == key) {
-        uint32_t rv = s.z;
-        if (rv < t.minV || rv > t.maxV) rv = 0;      // -min / -max (merfin.C:199-200)
-        return make_uint2(rv, s.w);
-      }
-      if (sk == MFX_EMPTY) { any_empty = true; break; }   // first empty slot of THIS key's own probe order: the key was never inserted
+      uint64_t sk = (uint64_t)s[q].x | ((uint64_t)s[q].y << 32);
+      if (sk == key) { found = true; hit = make_uint2(s[q].z, s[q].w); }
+      any_empty |= (sk == MFX_EMPTY);
     }
-    if (any_empty) break;
+    if (found) {
+      if (hit.x < t.minV || hit.x > t.maxV) hit.x = 0;   // -min / -max (merfin.C:199-200)
+      return hit;
+    }
+    if (any_empty) break;                                 // the line still has room: the key was never inserted
   }
-  return make_uint2(0u, 0u);                          // absent -> value 0 (merfin-globals.C:84)
+  return make_uint2(0u, 0u);                              // absent -> value 0 (merfin-globals.C:84)
 }
 
 __device__ __forceinline__ uint2 mfx_lookup(const mfx_table_view &t, uint64_t key) {
@@ -209,40 +216,47 @@ __device__ __forceinline__ uint32_t mfx_group_bcast(uint32_t v) {
 }
 
 struct mfx_group_round {
-  uint32_t ls[8], klo[8], khi[8];
+  uint32_t klo[8];
   uint4    v[8];
 };
 
+// owner S of every 8-lane group announces (line, low key word); its 7 neighbours
+// and itself fetch one slot each of that line: one coalesced 128-byte request.
 template <int S>
 __device__ __forceinline__ void mfx_group_issue(const mfx_table_view &t, mfx_group_round &R, uint32_t line, uint32_t klo,
-                                                uint32_t khi, uint32_t sub) {
-  R.ls[S] = mfx_group_bcast<S>(line);
+                                                uint32_t sub) {
+  const uint32_t ls = mfx_group_bcast<S>(line);
   R.klo[S] = mfx_group_bcast<S>(klo);
-  R.khi[S] = mfx_group_bcast<S>(khi);
-  R.v[S] = make_uint4(0xffffffffu, 0xffffffffu, 0u, 0u);
-  if (R.ls[S] != 0xffffffffu)
-    R.v[S] = *reinterpret_cast<const uint4 *>(t.slots + (uint64_t)R.ls[S] * MFX_SLOTS_LINE + sub);
+  R.v[S] = make_uint4(0xffffffffu, 0xffffffffu, 0u, 0u);      // dead owner: looks like an empty line, never matches
+  if (ls != 0xffffffffu)
+    R.v[S] = *reinterpret_cast<const uint4 *>(t.slots + (uint64_t)ls * MFX_SLOTS_LINE + sub);
 }
 
+// The lanes compare only the LOW key word; the owner checks the high word of
+// the slot it is handed (a low-word-only coincidence, ~2e-9 per query, sends
+// the query to the exact per-lane path).
 template <int S>
 __device__ __forceinline__ void mfx_group_collect(const mfx_table_view &t, const mfx_group_round &R, uint32_t sub,
-                                                  uint32_t gbase, uint32_t &rv, uint32_t &av, bool &pending) {
+                                                  uint32_t gbase, uint32_t khi, bool live, uint32_t &rv, uint32_t &av,
+                                                  bool &pending) {
   const uint4 v = R.v[S];
-  const bool live = R.ls[S] != 0xffffffffu;
-  const bool match = live && v.x == R.klo[S] && v.y == R.khi[S];
   const bool empty = (v.x & v.y) == 0xffffffffu;
+  const bool match = !empty && v.x == R.klo[S];
   const uint32_t mb = (uint32_t)(__ballot(match) >> gbase) & 0xffu;
   const uint32_t eb = (uint32_t)(__ballot(empty) >> gbase) & 0xffu;
   const uint32_t src = gbase | (mb ? (uint32_t)__builtin_ctz(mb) : 0u);
+  const uint32_t h = (uint32_t)__shfl((int)v.y, (int)src, 64);
   const uint32_t r = (uint32_t)__shfl((int)v.z, (int)src, 64);
   const uint32_t a = (uint32_t)__shfl((int)v.w, (int)src, 64);
-  if (sub == S) {
-    if (mb) {
-      rv = (r < t.minV || r > t.maxV) ? 0u : r;     // -min / -max (merfin.C:199-200)
+  if (sub == S && live) {
+    const bool one = (mb & (mb - 1)) == 0;                  // exactly one low-word candidate
+    if (mb && one && h == khi) {
+      rv = (r < t.minV || r > t.maxV) ? 0u : r;             // -min / -max (merfin.C:199-200)
       av = a;
     } else {
-      rv = 0u; av = 0u;                               // absent -> 0 (merfin-globals.C:84)
-      pending = live && (eb == 0);                    // home line full, no match: continue in the next lines
+      rv = 0u; av = 0u;                                     // absent -> 0 (merfin-globals.C:84)
+      // unresolved here: home line full without a match, or an ambiguous low-word match
+      pending = mb ? true : (eb == 0);
     }
   }
 }
@@ -253,12 +267,10 @@ __device__ __forceinline__ void mfx_group_lookup(const mfx_table_view &t, const 
                                                  uint32_t (&rv)[B], uint32_t (&av)[B]) {
   const uint32_t lane = threadIdx.x & 63u, sub = lane & 7u, gbase = lane & ~7u;
   uint32_t line[B];
-  mfx_probe pr[B];
   bool pending[B];
 #pragma unroll
   for (int j = 0; j < B; ++j) {
-    pr[j] = mfx_home(t, key[j]);
-    line[j] = ok[j] ? (uint32_t)mfx_probe_line(t, pr[j], 0) : 0xffffffffu;
+    line[j] = ok[j] ? (uint32_t)mfx_probe_line(t, mfx_home(t, key[j]), 0) : 0xffffffffu;
     pending[j] = false;
     rv[j] = av[j] = 0u;
   }
@@ -266,20 +278,20 @@ __device__ __forceinline__ void mfx_group_lookup(const mfx_table_view &t, const 
   for (int j = 0; j < B; ++j) {
     mfx_group_round R;
     const uint32_t klo = (uint32_t)key[j], khi = (uint32_t)(key[j] >> 32);
-    mfx_group_issue<0>(t, R, line[j], klo, khi, sub); mfx_group_issue<1>(t, R, line[j], klo, khi, sub);
-    mfx_group_issue<2>(t, R, line[j], klo, khi, sub); mfx_group_issue<3>(t, R, line[j], klo, khi, sub);
-    mfx_group_issue<4>(t, R, line[j], klo, khi, sub); mfx_group_issue<5>(t, R, line[j], klo, khi, sub);
-    mfx_group_issue<6>(t, R, line[j], klo, khi, sub); mfx_group_issue<7>(t, R, line[j], klo, khi, sub);
-    mfx_group_collect<0>(t, R, sub, gbase, rv[j], av[j], pending[j]); mfx_group_collect<1>(t, R, sub, gbase, rv[j], av[j], pending[j]);
-    mfx_group_collect<2>(t, R, sub, gbase, rv[j], av[j], pending[j]); mfx_group_collect<3>(t, R, sub, gbase, rv[j], av[j], pending[j]);
-    mfx_group_collect<4>(t, R, sub, gbase, rv[j], av[j], pending[j]); mfx_group_collect<5>(t, R, sub, gbase, rv[j], av[j], pending[j]);
-    mfx_group_collect<6>(t, R, sub, gbase, rv[j], av[j], pending[j]); mfx_group_collect<7>(t, R, sub, gbase, rv[j], av[j], pending[j]);
+    mfx_group_issue<0>(t, R, line[j], klo, sub); mfx_group_issue<1>(t, R, line[j], klo, sub);
+    mfx_group_issue<2>(t, R, line[j], klo, sub); mfx_group_issue<3>(t, R, line[j], klo, sub);
+    mfx_group_issue<4>(t, R, line[j], klo, sub); mfx_group_issue<5>(t, R, line[j], klo, sub);
+    mfx_group_issue<6>(t, R, line[j], klo, sub); mfx_group_issue<7>(t, R, line[j], klo, sub);
+    mfx_group_collect<0>(t, R, sub, gbase, khi, ok[j], rv[j], av[j], pending[j]); mfx_group_collect<1>(t, R, sub, gbase, khi, ok[j], rv[j], av[j], pending[j]);
+    mfx_group_collect<2>(t, R, sub, gbase, khi, ok[j], rv[j], av[j], pending[j]); mfx_group_collect<3>(t, R, sub, gbase, khi, ok[j], rv[j], av[j], pending[j]);
+    mfx_group_collect<4>(t, R, sub, gbase, khi, ok[j], rv[j], av[j], pending[j]); mfx_group_collect<5>(t, R, sub, gbase, khi, ok[j], rv[j], av[j], pending[j]);
+    mfx_group_collect<6>(t, R, sub, gbase, khi, ok[j], rv[j], av[j], pending[j]); mfx_group_collect<7>(t, R, sub, gbase, khi, ok[j], rv[j], av[j], pending[j]);
   }
 #pragma unroll
   for (int j = 0; j < B; ++j)
     if (pending[j]) {
-      // home line full without a match: continue per lane over the next candidate lines
-      uint2 v = mfx_scan_lines(t, key[j], pr[j], 1);
+      // exact per-lane path over all candidate lines (rare)
+      uint2 v = mfx_scan_lines(t, key[j], mfx_home(t, key[j]), 0);
       rv[j] = v.x; av[j] = v.y;
     }
 }
