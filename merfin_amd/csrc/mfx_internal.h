@@ -36,7 +36,8 @@ constexpr uint32_t MFX_BLOCK      = 256;
 constexpr uint32_t MFX_ALIGN      = 128;
 constexpr uint32_t MFX_SLOTS_LINE = 8;          // 8 x 16-byte slots = one 128-byte HBM line
 constexpr uint32_t MFX_NB_LDS     = 1024;       // K* bins per side privatised in LDS
-constexpr uint32_t MFX_MAXP_LDS   = 1024;       // -prob rows cached in LDS
+constexpr uint32_t MFX_MAXP_LDS   = 1024;       // read counts whose (readK, prob) is tabulated in LDS
+constexpr uint32_t MFX_KLUT       = 32;         // (readK, asmK) pairs below this use tabulated bin index / over-copy term
 constexpr uint32_t MFX_OVF_CAP    = 1u << 20;   // histogram overflow records per evaluator
 
 struct mfx_slot {               // 16 bytes: one dwordx4 load per probe

@@ -52,10 +52,9 @@ struct mfx_probe {
   uint32_t lineA, lineB, p1;
 };
 
-__device__ __forceinline__ uint64_t mfx_minimizer_hash(uint64_t key, int k, int w) {
+__device__ __forceinline__ uint64_t mfx_minimizer_hash(uint64_t key, uint64_t rc, int k, int w) {
   const int m = k - w + 1;
   const uint64_t mmask = (~0ULL) >> (64 - 2 * m);
-  const uint64_t rc = mfx_revcomp(key, k);
   uint64_t best = ~0ULL;
 #pragma unroll
   for (int j = 0; j < 5; ++j) {
@@ -70,6 +69,15 @@ __device__ __forceinline__ uint64_t mfx_minimizer_hash(uint64_t key, int k, int 
   return best;
 }
 
+// line of a k-mer's minimizer.  `best` is a minimum (biased towards small values), so it is
+// re-spread with one more odd multiplication before the multiply-range reduction.
+__device__ __forceinline__ uint32_t mfx_mz_line(const mfx_table_view &t, uint64_t key, uint64_t krc) {
+  uint64_t best = mfx_minimizer_hash(key, krc, t.k, t.mz_w);
+  uint64_t x = best * 0xD6E8FEB86659FD93ULL;
+  x ^= x >> 32;
+  return (uint32_t)__umul64hi(x * 0xFF51AFD7ED558CCDULL, t.nlines);
+}
+
 __device__ __forceinline__ mfx_probe mfx_home(const mfx_table_view &t, uint64_t key) {
   mfx_probe pr;
   uint64_t h = mfx_hash64(key);
@@ -77,8 +85,14 @@ __device__ __forceinline__ mfx_probe mfx_home(const mfx_table_view &t, uint64_t 
   pr.lineB = (uint32_t)__umul64hi(h, t.nlines);
   pr.lineA = pr.lineB;
   if (t.mz_w > 0)
-    pr.lineA = (uint32_t)__umul64hi(mfx_hash64(mfx_minimizer_hash(key, t.k, t.mz_w)), t.nlines);
+    pr.lineA = mfx_mz_line(t, key, mfx_revcomp(key, t.k));
   return pr;
+}
+
+// first candidate line only (the hot path needs nothing else); krc = revcomp(key)
+__device__ __forceinline__ uint32_t mfx_first_line(const mfx_table_view &t, uint64_t key, uint64_t krc) {
+  if (t.mz_w > 0) return mfx_mz_line(t, key, krc);
+  return (uint32_t)__umul64hi(mfx_hash64(key), t.nlines);
 }
 
 // d-th candidate line
@@ -215,83 +229,82 @@ __device__ __forceinline__ uint32_t mfx_group_bcast(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x18 | (S << 5));
 }
 
-struct mfx_group_round {
-  uint32_t klo[8];
-  uint4    v[8];
+// Result hand-off goes through a per-wave LDS mailbox (one 16-byte record per
+// lane/owner): the lane that holds the matching slot writes {key_hi, readV,
+// asmV} straight into the owner's record, a lane that sees an empty slot raises
+// the owner's "line has room" flag.  LDS requests of one wave are served in
+// order, so the owner's later read needs no barrier.  This replaces three
+// cross-lane permutes + ballot decoding per served query with one predicated
+// store.
+struct mfx_mailbox {
+  uint4 rec[MFX_BLOCK];      // x = key_hi of the matching slot (0xffffffff: none), y = readV, z = asmV, w = empty seen
 };
 
-// owner S of every 8-lane group announces (line, low key word); its 7 neighbours
-// and itself fetch one slot each of that line: one coalesced 128-byte request.
 template <int S>
-__device__ __forceinline__ void mfx_group_issue(const mfx_table_view &t, mfx_group_round &R, uint32_t line, uint32_t klo,
-                                                uint32_t sub) {
+__device__ __forceinline__ void mfx_group_issue(const mfx_table_view &t, uint4 (&v)[8], uint32_t (&klo)[8], uint32_t line,
+                                                uint32_t key_lo, uint32_t sub) {
   const uint32_t ls = mfx_group_bcast<S>(line);
-  R.klo[S] = mfx_group_bcast<S>(klo);
-  R.v[S] = make_uint4(0xffffffffu, 0xffffffffu, 0u, 0u);      // dead owner: looks like an empty line, never matches
+  klo[S] = mfx_group_bcast<S>(key_lo);
+  v[S] = make_uint4(0xffffffffu, 0xffffffffu, 0u, 0u);        // dead owner: looks like an empty line, never matches
   if (ls != 0xffffffffu)
-    R.v[S] = *reinterpret_cast<const uint4 *>(t.slots + (uint64_t)ls * MFX_SLOTS_LINE + sub);
+    v[S] = *reinterpret_cast<const uint4 *>(t.slots + (uint64_t)ls * MFX_SLOTS_LINE + sub);
 }
 
-// The lanes compare only the LOW key word; the owner checks the high word of
-// the slot it is handed (a low-word-only coincidence, ~2e-9 per query, sends
-// the query to the exact per-lane path).
 template <int S>
-__device__ __forceinline__ void mfx_group_collect(const mfx_table_view &t, const mfx_group_round &R, uint32_t sub,
-                                                  uint32_t gbase, uint32_t khi, bool live, uint32_t &rv, uint32_t &av,
-                                                  bool &pending) {
-  const uint4 v = R.v[S];
-  const bool empty = (v.x & v.y) == 0xffffffffu;
-  const bool match = !empty && v.x == R.klo[S];
-  const uint32_t mb = (uint32_t)(__ballot(match) >> gbase) & 0xffu;
-  const uint32_t eb = (uint32_t)(__ballot(empty) >> gbase) & 0xffu;
-  const uint32_t src = gbase | (mb ? (uint32_t)__builtin_ctz(mb) : 0u);
-  const uint32_t h = (uint32_t)__shfl((int)v.y, (int)src, 64);
-  const uint32_t r = (uint32_t)__shfl((int)v.z, (int)src, 64);
-  const uint32_t a = (uint32_t)__shfl((int)v.w, (int)src, 64);
-  if (sub == S && live) {
-    const bool one = (mb & (mb - 1)) == 0;                  // exactly one low-word candidate
-    if (mb && one && h == khi) {
-      rv = (r < t.minV || r > t.maxV) ? 0u : r;             // -min / -max (merfin.C:199-200)
-      av = a;
-    } else {
-      rv = 0u; av = 0u;                                     // absent -> 0 (merfin-globals.C:84)
-      // unresolved here: home line full without a match, or an ambiguous low-word match
-      pending = mb ? true : (eb == 0);
-    }
+__device__ __forceinline__ void mfx_group_post(mfx_mailbox &M, const uint4 (&v)[8], const uint32_t (&klo)[8], uint32_t obase) {
+  const uint4 s = v[S];
+  uint32_t *rec = reinterpret_cast<uint32_t *>(&M.rec[obase + S]);
+  if ((s.x & s.y) == 0xffffffffu) {
+    rec[3] = 1u;                                              // this line still has an empty slot
+  } else if (s.x == klo[S]) {
+    // low-word match (the owner verifies the high word); two low-word matches in one
+    // line (~1e-9) would race here -- the owner detects any mismatch and re-probes exactly
+    rec[0] = s.y; rec[1] = s.z; rec[2] = s.w;
   }
 }
 
 // B queries per lane; ok[j] false = no query.  Results: rv[j], av[j].
 template <int B>
-__device__ __forceinline__ void mfx_group_lookup(const mfx_table_view &t, const uint64_t (&key)[B], const bool (&ok)[B],
-                                                 uint32_t (&rv)[B], uint32_t (&av)[B]) {
-  const uint32_t lane = threadIdx.x & 63u, sub = lane & 7u, gbase = lane & ~7u;
+__device__ __forceinline__ void mfx_group_lookup(const mfx_table_view &t, mfx_mailbox &M, const uint64_t (&key)[B],
+                                                 const uint64_t (&krc)[B], const bool (&ok)[B], uint32_t (&rv)[B],
+                                                 uint32_t (&av)[B]) {
+  const uint32_t tid = threadIdx.x, sub = tid & 7u, obase = tid & ~7u;
   uint32_t line[B];
   bool pending[B];
 #pragma unroll
   for (int j = 0; j < B; ++j) {
-    line[j] = ok[j] ? (uint32_t)mfx_probe_line(t, mfx_home(t, key[j]), 0) : 0xffffffffu;
+    line[j] = ok[j] ? mfx_first_line(t, key[j], krc[j]) : 0xffffffffu;
     pending[j] = false;
     rv[j] = av[j] = 0u;
   }
 #pragma unroll
   for (int j = 0; j < B; ++j) {
-    mfx_group_round R;
-    const uint32_t klo = (uint32_t)key[j], khi = (uint32_t)(key[j] >> 32);
-    mfx_group_issue<0>(t, R, line[j], klo, sub); mfx_group_issue<1>(t, R, line[j], klo, sub);
-    mfx_group_issue<2>(t, R, line[j], klo, sub); mfx_group_issue<3>(t, R, line[j], klo, sub);
-    mfx_group_issue<4>(t, R, line[j], klo, sub); mfx_group_issue<5>(t, R, line[j], klo, sub);
-    mfx_group_issue<6>(t, R, line[j], klo, sub); mfx_group_issue<7>(t, R, line[j], klo, sub);
-    mfx_group_collect<0>(t, R, sub, gbase, khi, ok[j], rv[j], av[j], pending[j]); mfx_group_collect<1>(t, R, sub, gbase, khi, ok[j], rv[j], av[j], pending[j]);
-    mfx_group_collect<2>(t, R, sub, gbase, khi, ok[j], rv[j], av[j], pending[j]); mfx_group_collect<3>(t, R, sub, gbase, khi, ok[j], rv[j], av[j], pending[j]);
-    mfx_group_collect<4>(t, R, sub, gbase, khi, ok[j], rv[j], av[j], pending[j]); mfx_group_collect<5>(t, R, sub, gbase, khi, ok[j], rv[j], av[j], pending[j]);
-    mfx_group_collect<6>(t, R, sub, gbase, khi, ok[j], rv[j], av[j], pending[j]); mfx_group_collect<7>(t, R, sub, gbase, khi, ok[j], rv[j], av[j], pending[j]);
+    uint4 v[8];
+    uint32_t klo[8];
+    const uint32_t key_lo = (uint32_t)key[j], key_hi = (uint32_t)(key[j] >> 32);
+    M.rec[tid] = make_uint4(0xffffffffu, 0u, 0u, 0u);
+    mfx_group_issue<0>(t, v, klo, line[j], key_lo, sub); mfx_group_issue<1>(t, v, klo, line[j], key_lo, sub);
+    mfx_group_issue<2>(t, v, klo, line[j], key_lo, sub); mfx_group_issue<3>(t, v, klo, line[j], key_lo, sub);
+    mfx_group_issue<4>(t, v, klo, line[j], key_lo, sub); mfx_group_issue<5>(t, v, klo, line[j], key_lo, sub);
+    mfx_group_issue<6>(t, v, klo, line[j], key_lo, sub); mfx_group_issue<7>(t, v, klo, line[j], key_lo, sub);
+    mfx_group_post<0>(M, v, klo, obase); mfx_group_post<1>(M, v, klo, obase); mfx_group_post<2>(M, v, klo, obase);
+    mfx_group_post<3>(M, v, klo, obase); mfx_group_post<4>(M, v, klo, obase); mfx_group_post<5>(M, v, klo, obase);
+    mfx_group_post<6>(M, v, klo, obase); mfx_group_post<7>(M, v, klo, obase);
+    const uint4 r = M.rec[tid];
+    if (ok[j]) {
+      if (r.x == key_hi) {
+        rv[j] = (r.y < t.minV || r.y > t.maxV) ? 0u : r.y;    // -min / -max (merfin.C:199-200)
+        av[j] = r.z;
+      } else {
+        // no (verified) match: absent if the home line has room, else continue exactly per lane
+        pending[j] = (r.x != 0xffffffffu) || (r.w == 0u);
+      }
+    }
   }
 #pragma unroll
   for (int j = 0; j < B; ++j)
     if (pending[j]) {
-      // exact per-lane path over all candidate lines (rare)
-      uint2 v = mfx_scan_lines(t, key[j], mfx_home(t, key[j]), 0);
+      uint2 v = mfx_scan_lines(t, key[j], mfx_home(t, key[j]), 0);   // exact per-lane path (rare)
       rv[j] = v.x; av[j] = v.y;
     }
 }
@@ -381,9 +394,16 @@ constexpr int MFX_BATCH = 4;          // independent probes in flight per lane
 template <bool CANON>
 __global__ __launch_bounds__(MFX_BLOCK) void mfx_hist_kernel(mfx_hist_args a) {
   __shared__ mfx_tile_lds L;
+  __shared__ mfx_mailbox MB;
   __shared__ uint32_t s_hist[2 * MFX_NB_LDS];
-  __shared__ uint32_t s_probK[MFX_MAXP_LDS];
-  __shared__ double   s_probP[MFX_MAXP_LDS];
+  // Exact lookup tables, filled below with the SAME fp64 routines the slow path uses:
+  //   s_rk/s_pr[v]   readK and prob of read count v < MFX_MAXP_LDS (prob table and peak rule merged)
+  //   s_bin[h][l]    bin index of the ratio h/l, s_term[h][l] = 1 - l/h     (h, l < MFX_KLUT)
+  __shared__ uint32_t s_rk[MFX_MAXP_LDS];
+  __shared__ double   s_pr[MFX_MAXP_LDS];
+  __shared__ uint16_t s_bin[MFX_KLUT * MFX_KLUT];
+  __shared__ double   s_term[MFX_KLUT * MFX_KLUT];
+  __shared__ uint32_t s_lut_ok;
   __shared__ uint64_t s_red[MFX_BLOCK / 64][3];
   __shared__ double   s_dred[MFX_BLOCK];
 
@@ -391,8 +411,25 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_hist_kernel(mfx_hist_args a) {
   const int k = a.t.k;
 
   for (uint32_t i = tid; i < 2 * MFX_NB_LDS; i += MFX_BLOCK) s_hist[i] = 0;
-  const uint32_t np_lds = a.n_prob < MFX_MAXP_LDS ? a.n_prob : MFX_MAXP_LDS;
-  for (uint32_t i = tid; i < np_lds; i += MFX_BLOCK) { s_probK[i] = a.probK[i]; s_probP[i] = a.probP[i]; }
+  if (tid == 0) s_lut_ok = 1u;
+  __syncthreads();
+  for (uint32_t v = tid; v < MFX_MAXP_LDS; v += MFX_BLOCK) {
+    double rk, pr;
+    mfx_getK_core(a.peak, a.n_prob, a.probK, a.probP, v, rk, pr);
+    // the table holds readK as an integer; a non-integral / huge readK (only possible with a
+    // fractional -peak < 1 ... never for round()) disables the fast path for this launch
+    if (!(rk >= 0.0 && rk < 4294967296.0 && rk == (double)(uint32_t)rk)) s_lut_ok = 0u;
+    s_rk[v] = (uint32_t)rk;
+    s_pr[v] = pr;
+  }
+  for (uint32_t i = tid; i < MFX_KLUT * MFX_KLUT; i += MFX_BLOCK) {
+    uint32_t h = i / MFX_KLUT, l = i % MFX_KLUT;
+    uint32_t b = (h >= 1 && l >= 1 && h >= l) ? mfx_bin_index((double)h, (double)l) : 0u;
+    s_bin[i] = (uint16_t)b;
+    s_term[i] = (h >= 1 && l >= 1 && h > l) ? mfx_overcopy_term((double)l, (double)h, 1.0) : 0.0;
+  }
+  __syncthreads();
+  const bool lut_ok = s_lut_ok != 0u;
 
   // contiguous run of tiles for this (persistent) block
   const uint64_t ntl = a.tile_end - a.tile_begin;
@@ -449,16 +486,16 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_hist_kernel(mfx_hist_args a) {
           ok[j] = mfx_tile_kmer(L, k, p, f) && (p < n);
           uint64_t r = mfx_revcomp(f, k);
           if (CANON) {
-            key[j] = f < r ? f : r;
+            key[j] = f < r ? f : r; key2[j] = f < r ? r : f;     // canonical k-mer and its reverse complement
           } else {
             key[j] = f; key2[j] = r;
           }
         }
-        mfx_group_lookup<MFX_BATCH>(a.t, key, ok, rv, av);
+        mfx_group_lookup<MFX_BATCH>(a.t, MB, key, key2, ok, rv, av);
         if (!CANON) {
           // value(fmer) + value(rmer), uint32 arithmetic (merfin-globals.C:107-108)
           uint32_t rv2[MFX_BATCH], av2[MFX_BATCH];
-          mfx_group_lookup<MFX_BATCH>(a.t, key2, ok, rv2, av2);
+          mfx_group_lookup<MFX_BATCH>(a.t, MB, key2, key, ok, rv2, av2);
 #pragma unroll
           for (int j = 0; j < MFX_BATCH; ++j) { rv[j] += rv2[j]; av[j] += av2[j]; }
         }
@@ -467,17 +504,25 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_hist_kernel(mfx_hist_args a) {
           if (!ok[j]) continue;
           n_valid++;                                                   // merfin-histogram.C:58
           double readK, prob;
-          const uint32_t readV = rv[j];
-          if (readV > 0 && readV <= np_lds) {                          // LDS-resident -prob rows
-            readK = (double)s_probK[readV - 1]; prob = s_probP[readV - 1];
+          const uint32_t readV = rv[j], asmV = av[j];
+          uint32_t rki = 0xffffffffu;                                  // readK as an integer when the tables apply
+          if (lut_ok && readV < MFX_MAXP_LDS) {
+            rki = s_rk[readV]; prob = s_pr[readV]; readK = (double)rki;
           } else {
             mfx_getK_core(a.peak, a.n_prob, a.probK, a.probP, readV, readK, prob);
           }
-          const double asmK = (double)av[j];
+          const double asmK = (double)asmV;
           if (readK == 0) { n_missing++; continue; }                   // :66-69
           bool under = asmK > readK;                                   // :71
-          uint32_t idx = under ? mfx_bin_index(asmK, readK) : mfx_bin_index(readK, asmK);
-          if (under) kover += mfx_overcopy_term(readK, asmK, prob);    // :81
+          uint32_t idx;
+          if (rki < MFX_KLUT && asmV < MFX_KLUT && asmV >= 1) {        // exact tables (same fp64 code, evaluated once)
+            const uint32_t hi = under ? asmV : rki, lo = under ? rki : asmV;
+            idx = s_bin[hi * MFX_KLUT + lo];
+            if (under) kover += s_term[hi * MFX_KLUT + lo] * prob;     // :81  (1 - readK/asmK) * prob
+          } else {
+            idx = under ? mfx_bin_index(asmK, readK) : mfx_bin_index(readK, asmK);
+            if (under) kover += mfx_overcopy_term(readK, asmK, prob);  // :81
+          }
           if (!under && idx == 0) { n_over0++; continue; }             // the dominant bin stays in a register
           if (idx < MFX_NB_LDS) atomicAdd(&s_hist[(under ? 0 : MFX_NB_LDS) + idx], 1u);
           else if (idx < a.nbins) atomicAdd((unsigned long long *)&(under ? c_undr : c_over)[idx], 1ull);
@@ -543,6 +588,7 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_sum_partials_kernel(const doubl
 template <bool CANON>
 __global__ __launch_bounds__(MFX_BLOCK) void mfx_dump_kernel(mfx_dump_args a) {
   __shared__ mfx_tile_lds L;
+  __shared__ mfx_mailbox MB;
   __shared__ uint64_t s_red[MFX_BLOCK / 64][3];
   const uint32_t tid = threadIdx.x;
   const int k = a.t.k;
@@ -561,13 +607,13 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_dump_kernel(mfx_dump_args a) {
       wr[j] = gp < a.npos && gp >= a.skip;
       ok[j] = mfx_tile_kmer(L, k, p, f) && wr[j] && (gp < a.clen_left);
       uint64_t r = mfx_revcomp(f, k);
-      if (CANON) key[j] = f < r ? f : r;
+      if (CANON) { key[j] = f < r ? f : r; key2[j] = f < r ? r : f; }
       else { key[j] = f; key2[j] = r; }
     }
-    mfx_group_lookup<MFX_BATCH>(a.t, key, ok, rv, av);
+    mfx_group_lookup<MFX_BATCH>(a.t, MB, key, key2, ok, rv, av);
     if (!CANON) {
       uint32_t rv2[MFX_BATCH], av2[MFX_BATCH];
-      mfx_group_lookup<MFX_BATCH>(a.t, key2, ok, rv2, av2);
+      mfx_group_lookup<MFX_BATCH>(a.t, MB, key2, key, ok, rv2, av2);
 #pragma unroll
       for (int j = 0; j < MFX_BATCH; ++j) { rv[j] += rv2[j]; av[j] += av2[j]; }
     }
