@@ -270,11 +270,11 @@ __device__ __forceinline__ void mfx_group_lookup(const mfx_table_view &t, mfx_ma
                                                  uint32_t (&av)[B]) {
   const uint32_t tid = threadIdx.x, sub = tid & 7u, obase = tid & ~7u;
   uint32_t line[B];
-  bool pending[B];
+  uint32_t pending[B];          // 0 resolved, 1 home line full (continue at candidate 1), 2 ambiguous (redo exactly)
 #pragma unroll
   for (int j = 0; j < B; ++j) {
     line[j] = ok[j] ? mfx_first_line(t, key[j], krc[j]) : 0xffffffffu;
-    pending[j] = false;
+    pending[j] = 0u;
     rv[j] = av[j] = 0u;
   }
 #pragma unroll
@@ -296,17 +296,58 @@ __device__ __forceinline__ void mfx_group_lookup(const mfx_table_view &t, mfx_ma
         rv[j] = (r.y < t.minV || r.y > t.maxV) ? 0u : r.y;    // -min / -max (merfin.C:199-200)
         av[j] = r.z;
       } else {
-        // no (verified) match: absent if the home line has room, else continue exactly per lane
-        pending[j] = (r.x != 0xffffffffu) || (r.w == 0u);
+        // no (verified) match: absent if the home line has room, else continue per lane
+        pending[j] = (r.x != 0xffffffffu) ? 2u : (r.w == 0u ? 1u : 0u);
       }
     }
   }
+  // ---- second cooperative pass: queries whose home line was full continue at their
+  // next candidate line.  They are compacted into this wave's 64 mailbox records
+  // (ballot prefix), then served 8 per step exactly like the first pass, now with
+  // the full key in the record (exact compare).  Without this, each such lane
+  // fetched 8 slots on its own while its 63 neighbours waited.
+  const uint32_t lane = tid & 63u, wbase = tid & ~63u;
+  uint32_t qpos[B];
+  uint32_t nq = 0;
 #pragma unroll
-  for (int j = 0; j < B; ++j)
-    if (pending[j]) {
-      uint2 v = mfx_scan_lines(t, key[j], mfx_home(t, key[j]), 0);   // exact per-lane path (rare)
-      rv[j] = v.x; av[j] = v.y;
+  for (int j = 0; j < B; ++j) {
+    const bool p = pending[j] == 1u;
+    const uint64_t m = __ballot(p);
+    const uint32_t pos = nq + (uint32_t)__popcll(m & ((1ULL << lane) - 1ULL));
+    qpos[j] = 0xffffffffu;
+    if (p && pos < 64u) {
+      qpos[j] = pos;
+      const uint32_t l1 = (uint32_t)mfx_probe_line(t, mfx_home(t, key[j]), 1);
+      M.rec[wbase + pos] = make_uint4((uint32_t)key[j], (uint32_t)(key[j] >> 32), l1, 0u);
     }
+    nq += (uint32_t)__popcll(m);
+  }
+  if (nq > 64u) nq = 64u;
+  for (uint32_t q0 = 0; q0 < nq; q0 += 8u) {                 // wave-uniform trip count
+    const uint32_t e = q0 + (lane >> 3);
+    const bool live = e < nq;
+    const uint4 ent = M.rec[wbase + (live ? e : 0u)];
+    uint4 sl = make_uint4(0u, 0u, 0u, 0u);
+    if (live) sl = *reinterpret_cast<const uint4 *>(t.slots + (uint64_t)ent.z * MFX_SLOTS_LINE + sub);
+    uint32_t *rec = reinterpret_cast<uint32_t *>(&M.rec[wbase + e]);
+    if (live) {
+      if ((sl.x & sl.y) == 0xffffffffu) rec[3] = 1u;                         // candidate line has room
+      else if (sl.x == ent.x && sl.y == ent.y) { rec[0] = sl.z; rec[1] = sl.w; rec[2] = 0xffffffffu; }   // found (marker: no line has this index)
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < B; ++j) {
+    if (pending[j] == 0u) continue;
+    uint32_t from = pending[j] == 1u ? 1u : 0u;
+    if (qpos[j] != 0xffffffffu) {
+      const uint4 r = M.rec[wbase + qpos[j]];
+      if (r.z == 0xffffffffu) { rv[j] = (r.x < t.minV || r.x > t.maxV) ? 0u : r.x; av[j] = r.y; continue; }
+      if (r.w == 1u) continue;                                 // absent (rv = av = 0 already)
+      from = 2u;                                               // that line was full too
+    }
+    uint2 v = mfx_scan_lines(t, key[j], mfx_home(t, key[j]), from);   // exact per-lane path (rare)
+    rv[j] = v.x; av[j] = v.y;
+  }
 }
 
 // ===========================================================================
