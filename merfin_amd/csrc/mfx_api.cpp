@@ -126,12 +126,14 @@ extern "C" mfx_index *mfx_index_create(int k, uint64_t capacity_kmers, double ma
   ix->capacity_kmers = capacity_kmers;
   ix->nlines = lines_for(capacity_kmers);
   {
-    // placement: "mz" = minimizer-keyed home line (consecutive k-mers share lines), "plain" = k-mer hash only
+    // placement: "mz" (default) = minimizer-keyed home line, consecutive k-mers share 128-byte lines;
+    // "plain" = k-mer hash only.  w = 2 windows (m = k-1): a (k-1)-mer is contained in at most 8
+    // k-mers, so a minimizer's bucket always fits one line -- no skew even on repetitive genomes.
     const char *hm = getenv("MFX_HOME_MODE");
-    bool mz = hm ? (strcmp(hm, "mz") == 0) : false;
+    bool mz = hm ? (strcmp(hm, "plain") != 0) : true;
     const char *ws = getenv("MFX_MZ_W");
-    int w = ws ? atoi(ws) : 5;
-    if (w < 1 || w > 5) w = 5;
+    int w = ws ? atoi(ws) : 2;
+    if (w < 1 || w > 5) w = 2;
     ix->mz_w = mz ? std::min(w, k) : 0;
   }
   hipError_t e = hipMalloc((void **)&ix->d_slots, ix->nlines * MFX_ALIGN);

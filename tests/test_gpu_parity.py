@@ -81,6 +81,24 @@ def test_hist_matches_oracle(k, peak, use_prob, golden_dir):
     assert_hist_equal(res, g, ka, km, k)
 
 
+@pytest.mark.parametrize("mode,w", [("plain", "2"), ("mz", "2"), ("mz", "3"), ("mz", "5")])
+def test_hist_matches_oracle_under_every_placement(mode, w, monkeypatch, golden_dir):
+    """The index placement (plain k-mer hash / minimizer-keyed with w windows) is an
+    internal layout choice: results must not depend on it."""
+    m = _mfx()
+    monkeypatch.setenv("MFX_HOME_MODE", mode)
+    monkeypatch.setenv("MFX_MZ_W", w)
+    for k, lf in ((21, "0.7"), (9, "0.9")):
+        monkeypatch.setenv("MFX_LOAD_FACTOR", lf)
+        contigs, read, asm = synth.world(k=k, peak=9.0, seed=71, err_kmers=3000 if k > 12 else 0)
+        p, g, ka, km = oracle_hist(k, 9.0, contigs, read, asm)
+        ix = build_index(m, k, read, asm, cap=len(np.union1d(read[0], asm[0])))
+        res = m.Evaluator(ix, m.KParams(9.0)).hist(m.Sequences(contigs))
+        assert_hist_equal(res, g, ka, km, k)
+        rv, av = ix.value(asm[0][::5])
+        np.testing.assert_array_equal(av, asm[1][::5])
+
+
 def test_hist_report_text_identical(tmp_path, golden_dir):
     m = _mfx()
     k, peak = 21, 26.0
