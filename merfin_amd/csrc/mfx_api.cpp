@@ -686,7 +686,7 @@ extern "C" int mfx_dump_values(mfx_eval *ev, const mfx_seq *seq, uint32_t contig
 }
 
 // host threads the library may use for text formatting: min(hardware, cgroup quota, 64)
-static unsigned host_threads() {
+unsigned mfx_host_threads() {
   const char *e = getenv("MFX_HOST_THREADS");
   if (e && atoi(e) > 0) return (unsigned)atoi(e);
   unsigned n = std::thread::hardware_concurrency();
@@ -754,7 +754,7 @@ extern "C" int mfx_dump_contig(mfx_eval *ev, const mfx_seq *seq, uint32_t contig
   std::vector<uint32_t> rv(std::min(len, CH) + 1), av(std::min(len, CH) + 1);
   mfx_kparams kp{ev->peak, ev->n_prob, ev->probK.data(), ev->probP.data()};
   const size_t name_len = strlen(name);
-  const unsigned nthr = host_threads();
+  const unsigned nthr = mfx_host_threads();
   std::vector<std::string> parts(nthr);
   uint64_t ka = 0, km = 0;
   int rc = MFX_OK;

@@ -27,6 +27,9 @@ int  mfx_fail(int code, const char *fmt, ...);
     }                                                                                         \
   } while (0)
 
+// host threads the library may use: min(hardware, cgroup CPU quota, 64), or MFX_HOST_THREADS
+unsigned mfx_host_threads();
+
 // ---- geometry --------------------------------------------------------------
 // A tile = MFX_TILE consecutive k-mer start positions of one contig.  Contigs
 // start at 128-byte aligned offsets of the packed HBM buffer and are followed

@@ -24,9 +24,11 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <list>
 #include <map>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -266,7 +268,21 @@ struct Job {                          // one cluster waiting for its GPU values
   uint32_t rStart, rEnd;
   PathSet ps;
   std::vector<uint64_t> off;          // offset of each path in the packed buffer
+  uint64_t first_id = 0;              // varMerId of its first path (-debug numbering)
+  std::string out, dbg, log;          // produced by a worker thread, written in input order
 };
+
+// dynamic parallel-for over [0, n) on the host threads the library may use
+template <class F>
+void parallel_for(size_t n, F &&fn) {
+  unsigned nt = std::min<size_t>(mfx_host_threads(), n);
+  if (nt <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
+  std::atomic<size_t> next(0);
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < nt; ++t)
+    th.emplace_back([&]() { for (size_t i; (i = next.fetch_add(1)) < n;) fn(i); });
+  for (auto &x : th) x.join();
+}
 
 std::string hom_record(const Cluster &cl, const std::vector<int> &g, const char *chr) {     // varMer.C:531-550
   std::string out;
@@ -312,7 +328,7 @@ std::vector<int> min_missing(const Job &jb, const Scored &sc, uint32_t k, bool f
   return idxs;
 }
 
-std::string select_records(const Job &jb, const Scored &sc, int mode, uint32_t k, const char *chr, FILE *log) {
+std::string select_records(const Job &jb, const Scored &sc, int mode, uint32_t k, const char *chr, std::string *log) {
   const PathSet &ps = jb.ps;
   const Cluster &cl = *jb.cl;
   if (mode == MFX_VAR_FILTER) {                                          // bestFilter, varMer.C:150-199
@@ -377,8 +393,8 @@ std::string select_records(const Job &jb, const Scored &sc, int mode, uint32_t k
     if (cnt > maxVars) { maxVars = cnt; maxIdx = idxs[i]; }
   }
   if (log) {
-    fprintf(log, "[ WARNING ] :: Multiple (%lu) alternate pathes detected in a path beginning with variant : %s", idxs.size(), cl.vars[0]->rec->line().c_str());
-    fprintf(log, "[ WARNING ] :: Max. %d ALT variants selected\n", maxVars);
+    *log += "[ WARNING ] :: Multiple (" + std::to_string(idxs.size()) + ") alternate pathes detected in a path beginning with variant : " + cl.vars[0]->rec->line();
+    *log += "[ WARNING ] :: Max. " + std::to_string(maxVars) + " ALT variants selected\n";
   }
   return hom_record(cl, ps.gt[maxIdx], chr);
 }
@@ -441,19 +457,42 @@ extern "C" int mfx_variants_run(mfx_eval *ev, const char *vcf_path, const char *
   std::string packed;
   std::vector<uint32_t> rv, av;
 
-  // scores the queued jobs with one GPU launch and emits their records (input order)
+  // Enumerates the queued clusters' paths (host threads), scores every path k-mer
+  // with ONE GPU launch, applies the selectors (host threads), writes in input order.
   auto flush = [&]() -> int {
     if (jobs.empty()) return MFX_OK;
-    const char *pb = packed.data();
-    uint64_t plen = packed.size();
-    mfx_seq *ps = mfx_seq_upload(ev->device, &pb, &plen, 1);
-    if (!ps) return mfx_last_error_code();
-    rv.resize(plen + 1);
-    av.resize(plen + 1);
-    int r = mfx_dump_values(ev, ps, 0, 0, plen, rv.data(), av.data(), nullptr, nullptr);
-    mfx_seq_free(ps);
-    if (r) return r;
+    parallel_for(jobs.size(), [&](size_t i) {
+      Job &jb = jobs[i];
+      std::vector<uint32_t> offs, vl;
+      for (const Variant *v : jb.cl->vars) { offs.push_back(v->pos - jb.rStart); vl.push_back(v->refLen); }
+      std::vector<int> path;
+      enumerate(0, offs, vl, *jb.cl, std::string(bases[jb.contig] + jb.rStart, bases[jb.contig] + jb.rEnd), path, jb.ps);
+    });
+    uint64_t total = 0;
     for (Job &jb : jobs) {
+      jb.first_id = varMerId;
+      varMerId += jb.ps.seqs.size();
+      for (const std::string &s : jb.ps.seqs) { jb.off.push_back(total); total += s.size() + 1; }
+    }
+    packed.assign(total, '\n');                                          // '\n' is not ACGT: k-mers never span two paths
+    parallel_for(jobs.size(), [&](size_t i) {
+      Job &jb = jobs[i];
+      for (size_t p = 0; p < jb.ps.seqs.size(); ++p) memcpy(&packed[jb.off[p]], jb.ps.seqs[p].data(), jb.ps.seqs[p].size());
+    });
+    if (total) {
+      const char *pb = packed.data();
+      uint64_t plen = packed.size();
+      mfx_seq *ps = mfx_seq_upload(ev->device, &pb, &plen, 1);
+      if (!ps) return mfx_last_error_code();
+      rv.resize(plen + 1);
+      av.resize(plen + 1);
+      int r = mfx_dump_values(ev, ps, 0, 0, plen, rv.data(), av.data(), nullptr, nullptr);
+      mfx_seq_free(ps);
+      if (r) return r;
+    }
+    const bool want_dbg = dbg != nullptr;
+    parallel_for(jobs.size(), [&](size_t ji) {
+      Job &jb = jobs[ji];
       // `prob` is a local of varMer::score (one per cluster) that the reference reads
       // uninitialised until the first valid k-mer writes it; before that it only
       // multiplies |0-0|, so any finite start value is equivalent.  We fix 1.0.
@@ -492,19 +531,31 @@ extern "C" int mfx_variants_run(mfx_eval *ev, const char *vcf_path, const char *
         sc.numM[p] = numM;
       }
       const char *chr = names[jb.contig];
-      if (dbg)                                                           // merfin-variants.C:240-276
+      if (want_dbg) {                                                    // merfin-variants.C:240-276
+        char buf[512];
         for (size_t p = 0; p < np; ++p) {
-          fprintf(dbg, "%lu\t%s:%u-%u\t%s\t%u\t%.5f\t%.5f\t%.5f\t%.5f\t%.5f\t", (unsigned long)varMerId++, chr, jb.rStart, jb.rEnd,
-                  jb.ps.seqs[p].c_str(), sc.numM[p], min_abs_k(sc.ks[p]), max_abs_k(sc.ks[p]), med_abs_k(sc.ks[p]),
-                  avg_abs_k(sc.ks[p], sc.numM[p]), tot_dk(sc.dks[p]));
+          snprintf(buf, sizeof(buf), "%lu\t%s:%u-%u\t", (unsigned long)(jb.first_id + p), chr, jb.rStart, jb.rEnd);
+          jb.dbg += buf;
+          jb.dbg += jb.ps.seqs[p];
+          snprintf(buf, sizeof(buf), "\t%u\t%.5f\t%.5f\t%.5f\t%.5f\t%.5f\t", sc.numM[p], min_abs_k(sc.ks[p]), max_abs_k(sc.ks[p]),
+                   med_abs_k(sc.ks[p]), avg_abs_k(sc.ks[p], sc.numM[p]), tot_dk(sc.dks[p]));
+          jb.dbg += buf;
           for (size_t i = 0; i < jb.ps.gt[p].size(); ++i) {
             int a = jb.ps.gt[p][i];
-            if (a > 0) fprintf(dbg, "%s %u . %s %s . PASS . GT 1/1  ", chr, jb.cl->vars[i]->pos + 1, jb.cl->vars[i]->alleles[0]->c_str(), jb.cl->vars[i]->alleles[a]->c_str());
+            if (a > 0)
+              jb.dbg += std::string(chr) + " " + std::to_string(jb.cl->vars[i]->pos + 1) + " . " + *jb.cl->vars[i]->alleles[0] + " " +
+                        *jb.cl->vars[i]->alleles[a] + " . PASS . GT 1/1  ";
           }
-          fprintf(dbg, "\n");
+          jb.dbg += "\n";
         }
-      std::string recs = select_records(jb, sc, mode, K, chr, log);
-      fputs(recs.c_str(), out);
+      }
+      jb.out = select_records(jb, sc, mode, K, chr, &jb.log);
+      PathSet().seqs.swap(jb.ps.seqs);                                   // release the path text early
+    });
+    for (Job &jb : jobs) {
+      if (!jb.log.empty()) fputs(jb.log.c_str(), log);
+      if (dbg && !jb.dbg.empty()) fputs(jb.dbg.c_str(), dbg);
+      fputs(jb.out.c_str(), out);
       clusters++;
     }
     jobs.clear();
@@ -512,6 +563,7 @@ extern "C" int mfx_variants_run(mfx_eval *ev, const char *vcf_path, const char *
     return MFX_OK;
   };
 
+  uint64_t est_bytes = 0;
   for (uint32_t c = 0; c < ncontigs && rc == MFX_OK; ++c) {
     auto it = db.by_chr.find(names[c]);
     if (it == db.by_chr.end()) continue;                                 // merfin-variants.C:141-142
@@ -534,16 +586,17 @@ extern "C" int mfx_variants_run(mfx_eval *ev, const char *vcf_path, const char *
       jobs.emplace_back();
       Job &jb = jobs.back();
       jb.cl = cl; jb.contig = c; jb.rStart = rStart; jb.rEnd = rEnd;
-      std::vector<uint32_t> offs, vl;
-      for (const Variant *v : cl->vars) { offs.push_back(v->pos - rStart); vl.push_back(v->refLen); }
-      std::vector<int> path;
-      enumerate(0, offs, vl, *cl, std::string(bases[c] + rStart, bases[c] + rEnd), path, jb.ps);
-      for (const std::string &s : jb.ps.seqs) {
-        jb.off.push_back(packed.size());
-        packed += s;
-        packed.push_back('\n');                                          // not ACGT: k-mers never span two paths
+      // upper bound of this cluster's path text: (product of allele counts) x (window + longest ALTs)
+      double npaths = 1;
+      uint64_t plen = (uint64_t)(rEnd - rStart) + 1;
+      for (const Variant *v : cl->vars) {
+        npaths *= (double)std::max<size_t>(v->alleles.size(), 1);
+        size_t longest = 0;
+        for (const std::string *a : v->alleles) longest = std::max(longest, a->size());
+        plen += longest;
       }
-      if (packed.size() >= BATCH_BYTES) rc = flush();
+      est_bytes += (uint64_t)std::min(npaths, 4194304.0) * plen;
+      if (est_bytes >= BATCH_BYTES || jobs.size() >= 65536) { rc = flush(); est_bytes = 0; }
       if (rc) break;
     }
   }
