@@ -209,6 +209,34 @@ int mfx_hist_take_overflow(mfx_eval *ev, uint64_t *records, uint64_t cap, uint64
 int mfx_hist_report(const mfx_hist_result *r, int k, const char *hist_path, const char *summary_path);
 
 /* ------------------------------------------------------------------------ */
+/* Sharded index (BASELINE config 5: a read DB too large for one GPU).  The  */
+/* reference has no counterpart (it needs the whole DB in one host's RAM,    */
+/* merfin-globals.C:148-153).  Every rank keeps the k-mers it OWNS (owner =  */
+/* f(minimizer)); -hist routes each k-mer of the rank's sequence tiles to its */
+/* owner, which probes, computes K* and bins; one all-reduce of the counts   */
+/* image finishes.  Requires a canonical DB and odd k.                       */
+/* ------------------------------------------------------------------------ */
+/* call before any add/load/count: afterwards they silently skip foreign k-mers */
+int mfx_index_set_shard(mfx_index *ix, uint32_t rank, uint32_t nranks);
+
+typedef struct mfx_router mfx_router;
+mfx_router *mfx_router_create(const mfx_index *ix, uint32_t nranks, uint32_t max_tiles);
+void        mfx_router_free(mfx_router *r);
+/* Source side: canonical k-mers of tiles [tile_begin, tile_end) grouped by owner
+ * rank (sequence order kept inside a group), written to the caller's device
+ * buffers d_keys_out / d_contigs_out (capacity (tile_end-tile_begin)*4096);
+ * h_dest_counts[nranks] receives the group sizes.  The valid-k-mer counts
+ * (kasm, per-contig kasm; merfin-histogram.C:58) are added to d_counts.
+ * Synchronises `stream` once (the group sizes are needed on the host). */
+int mfx_route_tiles(mfx_router *r, const mfx_seq *seq, uint64_t tile_begin, uint64_t tile_end, uint32_t nbins,
+                    uint64_t *d_counts, uint64_t *d_keys_out, uint32_t *d_contigs_out, uint64_t *h_dest_counts,
+                    void *stream);
+/* Owner side: probe + K* + bin n received k-mers; adds bins, kmissing (global
+ * and per contig) and koverCpy -- NOT kasm, which the source counted. */
+int mfx_hist_keys_launch(mfx_eval *ev, const uint64_t *d_keys, const uint32_t *d_contigs, uint64_t n,
+                         uint32_t ncontigs, uint64_t *d_counts, double *d_kover, void *stream);
+
+/* ------------------------------------------------------------------------ */
 /* -dump: replaces processDump + outputDump (merfin-dump.C:20-68, 72-104).  */
 /* ------------------------------------------------------------------------ */
 /* Raw per-position values: for k-mer start positions [pos_begin,pos_end) of

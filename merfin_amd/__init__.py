@@ -8,10 +8,10 @@ There is no CPU fallback: importing works anywhere, but creating an index
 without the HIP library or without a GPU raises.
 """
 from .binding import (  # noqa: F401
-    MfxError, Index, Sequences, Evaluator, HistResult, KParams,
+    MfxError, Index, Sequences, Evaluator, Router, HistResult, KParams,
     lib_path, load_library, device_count, getK, getKmetric, histoQV, hist_words, result_from_counts,
     TILE, db_probe, db_write_flat,
 )
 
-__all__ = ["MfxError", "Index", "Sequences", "Evaluator", "HistResult", "KParams", "lib_path",
+__all__ = ["MfxError", "Index", "Sequences", "Evaluator", "Router", "HistResult", "KParams", "lib_path",
            "load_library", "device_count", "getK", "getKmetric", "histoQV", "hist_words", "result_from_counts", "TILE", "db_probe", "db_write_flat"]

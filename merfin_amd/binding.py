@@ -66,6 +66,7 @@ SYMBOLS = [
     "mfx_hist_run", "mfx_hist_result_free", "mfx_hist_launch", "mfx_hist_result_from_counts",
     "mfx_hist_take_overflow", "mfx_hist_report",
     "mfx_dump_values", "mfx_dump_contig", "mfx_completeness", "mfx_variants_run",
+    "mfx_index_set_shard", "mfx_router_create", "mfx_router_free", "mfx_route_tiles", "mfx_hist_keys_launch",
 ]
 
 
@@ -146,6 +147,12 @@ def load_library():
     L.mfx_dump_values.argtypes = [vp, vp, C.c_uint32, C.c_uint64, C.c_uint64, u32p, u32p, u64p, u64p]
     L.mfx_dump_contig.argtypes = [vp, vp, C.c_uint32, C.c_char_p, C.c_char_p, C.c_int, u64p, u64p]
     L.mfx_completeness.argtypes = [vp, f64p, f64p]
+    L.mfx_index_set_shard.argtypes = [vp, C.c_uint32, C.c_uint32]
+    L.mfx_router_create.restype = vp
+    L.mfx_router_create.argtypes = [vp, C.c_uint32, C.c_uint32]
+    L.mfx_router_free.argtypes = [vp]
+    L.mfx_route_tiles.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_uint32, vp, vp, vp, u64p, vp]
+    L.mfx_hist_keys_launch.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp]
     L.mfx_variants_run.argtypes = [vp, C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), u64p, C.c_uint32,
                                    C.POINTER(_VarOpts), C.c_char_p, C.c_char_p, u64p]
     _lib = L
@@ -257,6 +264,10 @@ class Index:
         pk, dev, _k1 = _ptr(kmers)
         pv, _, _k2 = _ptr(values)
         _check(load_library().mfx_index_add_asm(self.h, pk, pv, len(kmers), dev))
+
+    def set_shard(self, rank, nranks):
+        """Sharded index: keep only the k-mers owned by `rank` of `nranks` (call before loading)."""
+        _check(load_library().mfx_index_set_shard(self.h, rank, nranks))
 
     def load_db(self, path, side, minV=0, maxV=2**64 - 1):
         """side 0: read DB (-min/-max), side 1: assembly DB"""
@@ -387,6 +398,31 @@ def result_from_counts(nbins, h_counts, kover, ncontigs):
     return r
 
 
+class Router:
+    """Source side of the sharded -hist: groups the k-mers of sequence tiles by owner rank."""
+
+    def __init__(self, index, nranks, max_tiles):
+        self.index = index
+        self.nranks = nranks
+        self.max_tiles = max_tiles
+        self.h = _need(load_library().mfx_router_create(index.h, nranks, max_tiles))
+
+    def route(self, seqs, tile_begin, tile_end, nbins, d_counts, d_keys_out, d_contigs_out, stream=None):
+        p = lambda x: C.c_void_p(x.data_ptr() if hasattr(x, "data_ptr") else int(x))
+        dest = np.zeros(self.nranks, dtype=np.uint64)
+        _check(load_library().mfx_route_tiles(self.h, seqs.h, tile_begin, tile_end, nbins, p(d_counts), p(d_keys_out),
+                                              p(d_contigs_out), dest.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_void_p(stream or 0)))
+        return dest
+
+    def close(self):
+        if getattr(self, "h", None):
+            load_library().mfx_router_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
 class Evaluator:
     """K* parameters bound to an Index; runs -hist / -dump / -completeness."""
 
@@ -419,6 +455,12 @@ class Evaluator:
         n = C.c_uint64(0)
         _check(load_library().mfx_hist_take_overflow(self.h, rec.ctypes.data_as(C.POINTER(C.c_uint64)), cap, C.byref(n)))
         return rec[:n.value]
+
+    def hist_keys_launch(self, d_keys, d_contigs, n, ncontigs, d_counts, d_kover, stream=None):
+        """Owner side of the sharded -hist: probe/K*/bin n received canonical k-mers (device buffers)."""
+        p = lambda x: C.c_void_p(x.data_ptr() if hasattr(x, "data_ptr") else int(x))
+        _check(load_library().mfx_hist_keys_launch(self.h, p(d_keys), p(d_contigs), n, ncontigs, p(d_counts), p(d_kover),
+                                                   C.c_void_p(stream or 0)))
 
     def dump_values(self, seqs, contig, pos_begin, pos_end):
         n = pos_end - pos_begin

@@ -95,6 +95,8 @@ mfx_table_view mfx_index::view() const {
   v.maxV = maxV > 0xffffffffull ? 0xffffffffu : (uint32_t)maxV;
   v.k = k;
   v.mz_w = mz_w;
+  v.shard_rank = shard_rank;
+  v.shard_n = shard_n;
   return v;
 }
 
@@ -481,14 +483,15 @@ extern "C" int mfx_hist_launch(mfx_eval *ev, const mfx_seq *seq, uint64_t tile_b
   a.ncontigs = seq->ncontigs;
   a.tile_begin = tile_begin;
   a.tile_end = tile_end;
-  a.peak = ev->peak;
-  a.n_prob = ev->n_prob;
-  a.probK = ev->d_probK;
-  a.probP = ev->d_probP;
-  a.nbins = ev->nbins;
-  a.counts = d_counts;
-  a.partials = ev->d_partials;
-  a.ovf = ev->d_ovf;
+  a.ks.peak = ev->peak;
+  a.ks.n_prob = ev->n_prob;
+  a.ks.probK = ev->d_probK;
+  a.ks.probP = ev->d_probP;
+  a.ks.nbins = ev->nbins;
+  a.ks.ncontigs = seq->ncontigs;
+  a.ks.counts = d_counts;
+  a.ks.partials = ev->d_partials;
+  a.ks.ovf = ev->d_ovf;
   MFX_HIP(mfx_k_hist(a, ev->grid, (hipStream_t)stream));
   MFX_HIP(mfx_k_sum_partials(ev->d_partials, (uint32_t)ev->grid, d_kover, (hipStream_t)stream));
   return MFX_OK;
@@ -633,6 +636,135 @@ extern "C" int mfx_hist_report(const mfx_hist_result *r, int k, const char *hist
     fprintf(f, "*** When the lookup table is provided, missing QV includes weighted low frequency kmers, otherwise it is identical to Merqury QV. ***\n\n");
     if (f != stderr) fclose(f);
   }
+  return MFX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// sharded index (BASELINE config 5)
+// ---------------------------------------------------------------------------
+extern "C" int mfx_index_set_shard(mfx_index *ix, uint32_t rank, uint32_t nranks) {
+  if (!ix || nranks == 0 || rank >= nranks || nranks > 254)
+    return mfx_fail(MFX_E_INVAL, "mfx_index_set_shard: need rank < nranks <= 254");
+  DevGuard g(ix->device);
+  uint64_t meta[4];
+  MFX_HIP(hipMemcpy(meta, ix->d_meta, sizeof(meta), hipMemcpyDeviceToHost));
+  if (meta[0] != 0) return mfx_fail(MFX_E_INVAL, "mfx_index_set_shard: the index already holds k-mers");
+  ix->shard_rank = rank;
+  ix->shard_n = nranks;
+  return MFX_OK;
+}
+
+struct mfx_router {
+  const mfx_index *ix = nullptr;
+  int       device = 0;
+  uint32_t  nranks = 1, max_tiles = 0;
+  uint64_t *d_keys = nullptr;        // [max_tiles * TILE]
+  uint8_t  *d_owner = nullptr, *d_owner2 = nullptr;
+  uint32_t *d_idx = nullptr, *d_idx2 = nullptr;
+  uint64_t *d_dest = nullptr;        // [256]
+  void     *d_tmp = nullptr;
+  size_t    tmp_bytes = 0;
+};
+
+int mfx_sort_by_owner(void *tmp, size_t &tmp_bytes, const uint8_t *kin, uint8_t *kout, const uint32_t *vin, uint32_t *vout,
+                      uint64_t n, hipStream_t st);   // mfx_sort.hip (hipcub stable radix sort)
+
+extern "C" mfx_router *mfx_router_create(const mfx_index *ix, uint32_t nranks, uint32_t max_tiles) {
+  if (!ix || nranks == 0 || nranks > 254 || max_tiles == 0 || (uint64_t)max_tiles * MFX_TILE >= (1ull << 32)) {
+    mfx_fail(MFX_E_INVAL, "mfx_router_create: bad argument (nranks <= 254, max_tiles * %u < 2^32)", MFX_TILE);
+    return nullptr;
+  }
+  DevGuard g(ix->device);
+  mfx_router *r = new mfx_router;
+  r->ix = ix; r->device = ix->device; r->nranks = nranks; r->max_tiles = max_tiles;
+  const size_t n = (size_t)max_tiles * MFX_TILE;
+  size_t tb = 0;
+  mfx_sort_by_owner(nullptr, tb, nullptr, nullptr, nullptr, nullptr, n, nullptr);
+  r->tmp_bytes = tb;
+  if (hipMalloc((void **)&r->d_keys, n * 8) != hipSuccess || hipMalloc((void **)&r->d_owner, n) != hipSuccess ||
+      hipMalloc((void **)&r->d_owner2, n) != hipSuccess || hipMalloc((void **)&r->d_idx, n * 4) != hipSuccess ||
+      hipMalloc((void **)&r->d_idx2, n * 4) != hipSuccess || hipMalloc((void **)&r->d_dest, 256 * 8) != hipSuccess ||
+      hipMalloc(&r->d_tmp, tb ? tb : 1) != hipSuccess) {
+    mfx_fail(MFX_E_NOMEM, "mfx_router_create: device allocation failed (%zu positions)", n);
+    mfx_router_free(r);
+    return nullptr;
+  }
+  return r;
+}
+
+extern "C" void mfx_router_free(mfx_router *r) {
+  if (!r) return;
+  DevGuard g(r->device);
+  void *p[] = {r->d_keys, r->d_owner, r->d_owner2, r->d_idx, r->d_idx2, r->d_dest, r->d_tmp};
+  for (void *x : p) if (x) (void)hipFree(x);
+  delete r;
+}
+
+extern "C" int mfx_route_tiles(mfx_router *r, const mfx_seq *seq, uint64_t tile_begin, uint64_t tile_end, uint32_t nbins,
+                               uint64_t *d_counts, uint64_t *d_keys_out, uint32_t *d_contigs_out, uint64_t *h_dest_counts,
+                               void *stream) {
+  if (!r || !seq || !d_counts || !d_keys_out || !d_contigs_out || !h_dest_counts)
+    return mfx_fail(MFX_E_INVAL, "mfx_route_tiles: null argument");
+  if (tile_begin > tile_end || tile_end > seq->ntiles || tile_end - tile_begin > r->max_tiles)
+    return mfx_fail(MFX_E_INVAL, "mfx_route_tiles: tile range [%lu,%lu) invalid (max %u tiles per call)",
+                    (unsigned long)tile_begin, (unsigned long)tile_end, r->max_tiles);
+  DevGuard g(r->device);
+  hipStream_t st = (hipStream_t)stream;
+  int canon = 0;
+  int rc = index_canonical(r->ix, &canon);
+  if (rc) return rc;
+  if (!canon) return mfx_fail(MFX_E_INVAL, "a sharded index needs a canonical k-mer database and odd k");
+  const uint64_t n = (tile_end - tile_begin) * MFX_TILE;
+  mfx_route_args a;
+  a.t = r->ix->view();
+  a.bases = seq->d_bases;
+  a.contig_off = seq->d_contig_off;
+  a.contig_len = seq->d_contig_len;
+  a.tile_start = seq->d_tile_start;
+  a.ncontigs = seq->ncontigs;
+  a.tile_begin = tile_begin;
+  a.tile_end = tile_end;
+  a.nranks = r->nranks;
+  a.keys = r->d_keys;
+  a.owner = r->d_owner;
+  a.dest_counts = r->d_dest;
+  a.counts = d_counts;
+  a.nbins = nbins;
+  MFX_HIP(hipMemsetAsync(r->d_dest, 0, 256 * 8, st));
+  MFX_HIP(mfx_k_route(a, st));
+  MFX_HIP(mfx_k_iota(r->d_idx, n, st));
+  // stable sort by owner: within a destination the k-mers keep their sequence order,
+  // so the owner's fp64 koverCpy sum is reproducible
+  rc = mfx_sort_by_owner(r->d_tmp, r->tmp_bytes, r->d_owner, r->d_owner2, r->d_idx, r->d_idx2, n, st);
+  if (rc) return rc;
+  MFX_HIP(hipMemcpyAsync(h_dest_counts, r->d_dest, r->nranks * 8, hipMemcpyDeviceToHost, st));
+  MFX_HIP(hipStreamSynchronize(st));
+  uint64_t nvalid = 0;
+  for (uint32_t i = 0; i < r->nranks; ++i) nvalid += h_dest_counts[i];
+  MFX_HIP(mfx_k_route_gather(a, r->d_idx2, nvalid, d_keys_out, d_contigs_out, st));
+  return MFX_OK;
+}
+
+extern "C" int mfx_hist_keys_launch(mfx_eval *ev, const uint64_t *d_keys, const uint32_t *d_contigs, uint64_t n,
+                                    uint32_t ncontigs, uint64_t *d_counts, double *d_kover, void *stream) {
+  if (!ev || !d_counts || !d_kover || (n && (!d_keys || !d_contigs))) return mfx_fail(MFX_E_INVAL, "mfx_hist_keys_launch: null argument");
+  DevGuard g(ev->device);
+  mfx_hist_keys_args a;
+  a.t = ev->ix->view();
+  a.keys = d_keys;
+  a.contig = d_contigs;
+  a.n = n;
+  a.ks.peak = ev->peak;
+  a.ks.n_prob = ev->n_prob;
+  a.ks.probK = ev->d_probK;
+  a.ks.probP = ev->d_probP;
+  a.ks.nbins = ev->nbins;
+  a.ks.ncontigs = ncontigs;
+  a.ks.counts = d_counts;
+  a.ks.partials = ev->d_partials;
+  a.ks.ovf = ev->d_ovf;
+  MFX_HIP(mfx_k_hist_keys(a, ev->grid, (hipStream_t)stream));
+  MFX_HIP(mfx_k_sum_partials(ev->d_partials, (uint32_t)ev->grid, d_kover, (hipStream_t)stream));
   return MFX_OK;
 }
 

@@ -56,6 +56,7 @@ struct mfx_table_view {
   uint32_t  minV, maxV;         // read-count filter (merfin.C:199-200), clamped to uint32
   int       k;
   int       mz_w;               // minimizer windows (0 = plain k-mer hashing; else m = k - mz_w + 1)
+  uint32_t  shard_rank, shard_n;  // sharded index: this table keeps only the k-mers owned by shard_rank of shard_n
 };
 
 struct mfx_index {
@@ -68,6 +69,7 @@ struct mfx_index {
   uint64_t  minV = 0, maxV = ~0ull;
   bool      filter_set = false;
   int       mz_w = 0;
+  uint32_t  shard_rank = 0, shard_n = 1;
   mfx_table_view view() const;
 };
 

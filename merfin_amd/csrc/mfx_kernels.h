@@ -2,6 +2,19 @@
 #pragma once
 #include "mfx_internal.h"
 
+// K* parameters + accumulators shared by every histogram-producing kernel
+struct mfx_kstar_args {
+  double          peak;
+  uint32_t        n_prob;
+  const uint32_t *probK;
+  const double   *probP;
+  uint32_t        nbins;
+  uint32_t        ncontigs;
+  uint64_t       *counts;             // layout: include/merfin_amd.h MFX_HIST_WORDS
+  double         *partials;           // [gridDim.x]
+  uint64_t       *ovf;                // [0] count, [1..MFX_OVF_CAP] records
+};
+
 struct mfx_hist_args {
   mfx_table_view  t;
   int             canonical;          // 1: single probe of min(f,r); 0: probe both strands and sum
@@ -9,14 +22,29 @@ struct mfx_hist_args {
   const uint64_t *contig_off, *contig_len, *tile_start;
   uint32_t        ncontigs;
   uint64_t        tile_begin, tile_end;
-  double          peak;
-  uint32_t        n_prob;
-  const uint32_t *probK;
-  const double   *probP;
+  mfx_kstar_args  ks;
+};
+
+struct mfx_route_args {
+  mfx_table_view  t;
+  const uint8_t  *bases;
+  const uint64_t *contig_off, *contig_len, *tile_start;
+  uint32_t        ncontigs;
+  uint64_t        tile_begin, tile_end;
+  uint32_t        nranks;
+  uint64_t       *keys;               // [ntiles * MFX_TILE] canonical k-mer per position (~0: none)
+  uint8_t        *owner;              // [ntiles * MFX_TILE] owner rank (255: none)
+  uint64_t       *dest_counts;        // [nranks]
+  uint64_t       *counts;             // counts image: kasm + per-contig kasm are added here
   uint32_t        nbins;
-  uint64_t       *counts;             // layout: include/merfin_amd.h MFX_HIST_WORDS
-  double         *partials;           // [gridDim.x]
-  uint64_t       *ovf;                // [0] count, [1..MFX_OVF_CAP] records
+};
+
+struct mfx_hist_keys_args {
+  mfx_table_view  t;
+  const uint64_t *keys;
+  const uint32_t *contig;
+  uint64_t        n;
+  mfx_kstar_args  ks;
 };
 
 struct mfx_dump_args {
@@ -51,6 +79,11 @@ hipError_t mfx_k_table_value(mfx_table_view t, const uint64_t *kmers, uint64_t n
 hipError_t mfx_k_table_export(mfx_table_view t, uint64_t *kmers, uint32_t *readV, uint32_t *asmV,
                               unsigned long long *count, hipStream_t st);
 hipError_t mfx_k_hist(const mfx_hist_args &a, int grid, hipStream_t st);
+hipError_t mfx_k_route(const mfx_route_args &a, hipStream_t st);
+hipError_t mfx_k_route_gather(const mfx_route_args &a, const uint32_t *idx, uint64_t nvalid, uint64_t *keys_out,
+                              uint32_t *contig_out, hipStream_t st);
+hipError_t mfx_k_iota(uint32_t *v, uint64_t n, hipStream_t st);
+hipError_t mfx_k_hist_keys(const mfx_hist_keys_args &a, int grid, hipStream_t st);
 hipError_t mfx_k_sum_partials(const double *partials, uint32_t n, double *out, hipStream_t st);
 hipError_t mfx_k_dump(const mfx_dump_args &a, hipStream_t st);
 hipError_t mfx_k_count(const mfx_count_args &a, hipStream_t st);

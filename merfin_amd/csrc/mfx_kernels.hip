@@ -95,6 +95,12 @@ __device__ __forceinline__ uint32_t mfx_first_line(const mfx_table_view &t, uint
   return (uint32_t)__umul64hi(mfx_hash64(key), t.nlines);
 }
 
+// owner rank of a k-mer in a sharded index (independent of the line hash bits)
+__device__ __forceinline__ uint32_t mfx_owner(const mfx_table_view &t, uint64_t key, uint64_t krc, uint32_t nranks) {
+  uint64_t h = t.mz_w > 0 ? mfx_minimizer_hash(key, krc, t.k, t.mz_w) : key * 0xA24BAED4963EE407ULL;
+  return (uint32_t)__umul64hi(mfx_hash64(h ^ 0x5851F42D4C957F2DULL), (uint64_t)nranks);
+}
+
 // d-th candidate line
 __device__ __forceinline__ uint64_t mfx_probe_line(const mfx_table_view &t, const mfx_probe &pr, uint32_t d) {
   const uint32_t ra = t.mz_w > 0 ? MFX_MZ_REGION : 0u;
@@ -179,8 +185,11 @@ __global__ void mfx_table_add_kernel(mfx_table_view t, const uint64_t *kmers, co
     uint64_t key = kmers[i];
     uint32_t v = values[i];
     if (v == 0) continue;
-    if (key > mfx_revcomp(key, t.k))
+    const uint64_t krc = mfx_revcomp(key, t.k);
+    if (key > krc)
       atomicAdd((unsigned long long *)&meta[1], 1ull);
+    if (t.shard_n > 1 && mfx_owner(t, key < krc ? key : krc, key < krc ? krc : key, t.shard_n) != t.shard_rank)
+      continue;                                              // another rank owns this k-mer
     mfx_slot *sl = mfx_claim(t, key, meta);
     if (sl) atomicAdd(side ? &sl->asmV : &sl->readV, v);
   }
@@ -432,45 +441,108 @@ __device__ __forceinline__ void mfx_block_sum3(uint64_t &a, uint64_t &b, uint64_
 
 constexpr int MFX_BATCH = 4;          // independent probes in flight per lane
 
-template <bool CANON>
-__global__ __launch_bounds__(MFX_BLOCK) void mfx_hist_kernel(mfx_hist_args a) {
-  __shared__ mfx_tile_lds L;
-  __shared__ mfx_mailbox MB;
-  __shared__ uint32_t s_hist[2 * MFX_NB_LDS];
-  // Exact lookup tables, filled below with the SAME fp64 routines the slow path uses:
-  //   s_rk/s_pr[v]   readK and prob of read count v < MFX_MAXP_LDS (prob table and peak rule merged)
-  //   s_bin[h][l]    bin index of the ratio h/l, s_term[h][l] = 1 - l/h     (h, l < MFX_KLUT)
-  __shared__ uint32_t s_rk[MFX_MAXP_LDS];
-  __shared__ double   s_pr[MFX_MAXP_LDS];
-  __shared__ uint16_t s_bin[MFX_KLUT * MFX_KLUT];
-  __shared__ double   s_term[MFX_KLUT * MFX_KLUT];
-  __shared__ uint32_t s_lut_ok;
-  __shared__ uint64_t s_red[MFX_BLOCK / 64][3];
-  __shared__ double   s_dred[MFX_BLOCK];
+// LDS state of the K* / histogram stage, shared by the sequence-driven kernel
+// (mfx_hist_kernel) and the key-driven one (mfx_hist_keys_kernel, sharded index).
+struct mfx_hist_lds {
+  uint32_t hist[2 * MFX_NB_LDS];
+  // Exact lookup tables, filled with the SAME fp64 routines the generic path uses:
+  //   rk/pr[v]     readK and prob of read count v < MFX_MAXP_LDS (prob table and peak rule merged)
+  //   bin[h][l]    bin index of the ratio h/l, term[h][l] = 1 - l/h     (h, l < MFX_KLUT)
+  uint32_t rk[MFX_MAXP_LDS];
+  double   pr[MFX_MAXP_LDS];
+  uint16_t bin[MFX_KLUT * MFX_KLUT];
+  double   term[MFX_KLUT * MFX_KLUT];
+  uint32_t lut_ok;
+  uint64_t red[MFX_BLOCK / 64][3];
+  double   dred[MFX_BLOCK];
+};
 
+__device__ __forceinline__ void mfx_hist_lds_init(mfx_hist_lds &H, const mfx_kstar_args &ka) {
   const uint32_t tid = threadIdx.x;
-  const int k = a.t.k;
-
-  for (uint32_t i = tid; i < 2 * MFX_NB_LDS; i += MFX_BLOCK) s_hist[i] = 0;
-  if (tid == 0) s_lut_ok = 1u;
+  for (uint32_t i = tid; i < 2 * MFX_NB_LDS; i += MFX_BLOCK) H.hist[i] = 0;
+  if (tid == 0) H.lut_ok = 1u;
   __syncthreads();
   for (uint32_t v = tid; v < MFX_MAXP_LDS; v += MFX_BLOCK) {
     double rk, pr;
-    mfx_getK_core(a.peak, a.n_prob, a.probK, a.probP, v, rk, pr);
-    // the table holds readK as an integer; a non-integral / huge readK (only possible with a
-    // fractional -peak < 1 ... never for round()) disables the fast path for this launch
-    if (!(rk >= 0.0 && rk < 4294967296.0 && rk == (double)(uint32_t)rk)) s_lut_ok = 0u;
-    s_rk[v] = (uint32_t)rk;
-    s_pr[v] = pr;
+    mfx_getK_core(ka.peak, ka.n_prob, ka.probK, ka.probP, v, rk, pr);
+    // the table holds readK as an integer; anything else disables the fast path for this launch
+    if (!(rk >= 0.0 && rk < 4294967296.0 && rk == (double)(uint32_t)rk)) H.lut_ok = 0u;
+    H.rk[v] = (uint32_t)rk;
+    H.pr[v] = pr;
   }
   for (uint32_t i = tid; i < MFX_KLUT * MFX_KLUT; i += MFX_BLOCK) {
     uint32_t h = i / MFX_KLUT, l = i % MFX_KLUT;
     uint32_t b = (h >= 1 && l >= 1 && h >= l) ? mfx_bin_index((double)h, (double)l) : 0u;
-    s_bin[i] = (uint16_t)b;
-    s_term[i] = (h >= 1 && l >= 1 && h > l) ? mfx_overcopy_term((double)l, (double)h, 1.0) : 0.0;
+    H.bin[i] = (uint16_t)b;
+    H.term[i] = (h >= 1 && l >= 1 && h > l) ? mfx_overcopy_term((double)l, (double)h, 1.0) : 0.0;
   }
   __syncthreads();
-  const bool lut_ok = s_lut_ok != 0u;
+}
+
+// One evaluated k-mer: merfin-histogram.C:63-90 after the lookups.  Returns true when the
+// k-mer is "missing" (readK == 0).
+__device__ __forceinline__ bool mfx_hist_eval(mfx_hist_lds &H, const mfx_kstar_args &ka, bool lut_ok, uint32_t readV,
+                                              uint32_t asmV, uint64_t &n_over0, double &kover) {
+  double readK, prob;
+  uint32_t rki = 0xffffffffu;                                  // readK as an integer when the tables apply
+  if (lut_ok && readV < MFX_MAXP_LDS) {
+    rki = H.rk[readV]; prob = H.pr[readV]; readK = (double)rki;
+  } else {
+    mfx_getK_core(ka.peak, ka.n_prob, ka.probK, ka.probP, readV, readK, prob);
+  }
+  const double asmK = (double)asmV;
+  if (readK == 0) return true;                                 // :66-69
+  const bool under = asmK > readK;                             // :71
+  uint32_t idx;
+  if (rki < MFX_KLUT && asmV < MFX_KLUT && asmV >= 1) {        // exact tables (same fp64 code, evaluated once)
+    const uint32_t hi = under ? asmV : rki, lo = under ? rki : asmV;
+    idx = H.bin[hi * MFX_KLUT + lo];
+    if (under) kover += H.term[hi * MFX_KLUT + lo] * prob;     // :81  (1 - readK/asmK) * prob
+  } else {
+    idx = under ? mfx_bin_index(asmK, readK) : mfx_bin_index(readK, asmK);
+    if (under) kover += mfx_overcopy_term(readK, asmK, prob);  // :81
+  }
+  if (!under && idx == 0) { n_over0++; return false; }         // the dominant bin stays in a register
+  uint64_t *c_undr = ka.counts, *c_over = ka.counts + ka.nbins;
+  if (idx < MFX_NB_LDS) atomicAdd(&H.hist[(under ? 0 : MFX_NB_LDS) + idx], 1u);
+  else if (idx < ka.nbins) atomicAdd((unsigned long long *)&(under ? c_undr : c_over)[idx], 1ull);
+  else {
+    unsigned long long w = atomicAdd((unsigned long long *)&ka.ovf[0], 1ull);
+    if (w < MFX_OVF_CAP) ka.ovf[1 + w] = (under ? 0ull : (1ull << 63)) | idx;
+    atomicAdd((unsigned long long *)&ka.counts[2ull * ka.nbins + 2], 1ull);
+  }
+  return false;
+}
+
+// LDS bins -> global (non-zero only); koverCpy: fixed-order tree, one partial per block
+__device__ __forceinline__ void mfx_hist_lds_flush(mfx_hist_lds &H, const mfx_kstar_args &ka, double kover) {
+  const uint32_t tid = threadIdx.x;
+  uint64_t *c_undr = ka.counts, *c_over = ka.counts + ka.nbins;
+  __syncthreads();
+  for (uint32_t i = tid; i < 2 * MFX_NB_LDS; i += MFX_BLOCK) {
+    uint32_t v = H.hist[i];
+    if (v) atomicAdd((unsigned long long *)&(i < MFX_NB_LDS ? c_undr[i] : c_over[i - MFX_NB_LDS]), (unsigned long long)v);
+  }
+  H.dred[tid] = kover;
+  __syncthreads();
+  for (uint32_t s = MFX_BLOCK / 2; s > 0; s >>= 1) {
+    if (tid < s) H.dred[tid] = H.dred[tid] + H.dred[tid + s];
+    __syncthreads();
+  }
+  if (tid == 0) ka.partials[blockIdx.x] = H.dred[0];
+}
+
+template <bool CANON>
+__global__ __launch_bounds__(MFX_BLOCK) void mfx_hist_kernel(mfx_hist_args a) {
+  __shared__ mfx_tile_lds L;
+  __shared__ mfx_mailbox MB;
+  __shared__ mfx_hist_lds H;
+
+  const uint32_t tid = threadIdx.x;
+  const int k = a.t.k;
+  const mfx_kstar_args &ka = a.ks;
+  mfx_hist_lds_init(H, ka);
+  const bool lut_ok = H.lut_ok != 0u;
 
   // contiguous run of tiles for this (persistent) block
   const uint64_t ntl = a.tile_end - a.tile_begin;
@@ -480,9 +552,8 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_hist_kernel(mfx_hist_args a) {
 
   uint64_t n_valid = 0, n_missing = 0, n_over0 = 0;     // per-lane counters
   double   kover = 0.0;                                  // per-lane koverCpy partial
-  uint64_t *c_undr = a.counts, *c_over = a.counts + a.nbins;
-  uint64_t *c_glob = a.counts + 2ull * a.nbins;          // kasm, kmissing, novf
-  uint64_t *c_kasm = c_glob + 3, *c_kmis = c_kasm + a.ncontigs;
+  uint64_t *c_glob = ka.counts + 2ull * ka.nbins;        // kasm, kmissing, novf
+  uint64_t *c_kasm = c_glob + 3, *c_kmis = c_kasm + ka.ncontigs;
 
   if (t0 < t1) {
     // contig of the first tile: largest c with tile_start[c] <= t0
@@ -497,7 +568,7 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_hist_kernel(mfx_hist_args a) {
       while (tile >= a.tile_start[c + 1]) {
         // contig change (block-uniform): flush the per-contig counters
         uint64_t x = n_valid, y = n_missing, z = 0;
-        mfx_block_sum3(x, y, z, s_red);
+        mfx_block_sum3(x, y, z, H.red);
         if (tid == 0 && (x | y)) {
           atomicAdd((unsigned long long *)&c_kasm[c], x);
           atomicAdd((unsigned long long *)&c_kmis[c], y);
@@ -544,41 +615,14 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_hist_kernel(mfx_hist_args a) {
         for (int j = 0; j < MFX_BATCH; ++j) {
           if (!ok[j]) continue;
           n_valid++;                                                   // merfin-histogram.C:58
-          double readK, prob;
-          const uint32_t readV = rv[j], asmV = av[j];
-          uint32_t rki = 0xffffffffu;                                  // readK as an integer when the tables apply
-          if (lut_ok && readV < MFX_MAXP_LDS) {
-            rki = s_rk[readV]; prob = s_pr[readV]; readK = (double)rki;
-          } else {
-            mfx_getK_core(a.peak, a.n_prob, a.probK, a.probP, readV, readK, prob);
-          }
-          const double asmK = (double)asmV;
-          if (readK == 0) { n_missing++; continue; }                   // :66-69
-          bool under = asmK > readK;                                   // :71
-          uint32_t idx;
-          if (rki < MFX_KLUT && asmV < MFX_KLUT && asmV >= 1) {        // exact tables (same fp64 code, evaluated once)
-            const uint32_t hi = under ? asmV : rki, lo = under ? rki : asmV;
-            idx = s_bin[hi * MFX_KLUT + lo];
-            if (under) kover += s_term[hi * MFX_KLUT + lo] * prob;     // :81  (1 - readK/asmK) * prob
-          } else {
-            idx = under ? mfx_bin_index(asmK, readK) : mfx_bin_index(readK, asmK);
-            if (under) kover += mfx_overcopy_term(readK, asmK, prob);  // :81
-          }
-          if (!under && idx == 0) { n_over0++; continue; }             // the dominant bin stays in a register
-          if (idx < MFX_NB_LDS) atomicAdd(&s_hist[(under ? 0 : MFX_NB_LDS) + idx], 1u);
-          else if (idx < a.nbins) atomicAdd((unsigned long long *)&(under ? c_undr : c_over)[idx], 1ull);
-          else {
-            unsigned long long w = atomicAdd((unsigned long long *)&a.ovf[0], 1ull);
-            if (w < MFX_OVF_CAP) a.ovf[1 + w] = (under ? 0ull : (1ull << 63)) | idx;
-            atomicAdd((unsigned long long *)&c_glob[2], 1ull);
-          }
+          if (mfx_hist_eval(H, ka, lut_ok, rv[j], av[j], n_over0, kover)) n_missing++;
         }
       }
     }
     // final per-contig flush
     {
       uint64_t x = n_valid, y = n_missing, z = n_over0;
-      mfx_block_sum3(x, y, z, s_red);
+      mfx_block_sum3(x, y, z, H.red);
       if (tid == 0) {
         if (x | y) {
           atomicAdd((unsigned long long *)&c_kasm[c], x);
@@ -586,26 +630,136 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_hist_kernel(mfx_hist_args a) {
           atomicAdd((unsigned long long *)&c_glob[0], x);
           atomicAdd((unsigned long long *)&c_glob[1], y);
         }
-        if (z) atomicAdd((unsigned long long *)&c_over[0], z);
+        if (z) atomicAdd((unsigned long long *)&ka.counts[ka.nbins], z);
       }
     }
   }
+  mfx_hist_lds_flush(H, ka, kover);
+}
 
-  // LDS bins -> global (non-zero only)
-  __syncthreads();
-  for (uint32_t i = tid; i < 2 * MFX_NB_LDS; i += MFX_BLOCK) {
-    uint32_t v = s_hist[i];
-    if (v) atomicAdd((unsigned long long *)&(i < MFX_NB_LDS ? c_undr[i] : c_over[i - MFX_NB_LDS]), (unsigned long long)v);
-  }
-
-  // koverCpy: fixed-order tree inside the block, one partial per block
-  s_dred[tid] = kover;
-  __syncthreads();
-  for (uint32_t s = MFX_BLOCK / 2; s > 0; s >>= 1) {
-    if (tid < s) s_dred[tid] = s_dred[tid] + s_dred[tid + s];
+// ===========================================================================
+// Sharded index (BASELINE config 5: the read DB does not fit one GPU).
+// The table is split by OWNER rank = f(minimizer) (f(k-mer) under plain hashing);
+// every rank keeps the k-mers it owns in an ordinary local table.  -hist then is
+//   source rank : extract canonical k-mers of its tiles, label each with its owner
+//                 (mfx_route_kernel), group by owner (stable radix sort), exchange;
+//   owner rank  : probe + K* + bin the k-mers it receives (mfx_hist_keys_kernel);
+//   all ranks   : one all-reduce of the counts image.
+// ===========================================================================
+__global__ __launch_bounds__(MFX_BLOCK) void mfx_route_kernel(mfx_route_args a) {
+  __shared__ mfx_tile_lds L;
+  __shared__ uint64_t s_red[MFX_BLOCK / 64][3];
+  __shared__ uint32_t s_dest[256];
+  const uint32_t tid = threadIdx.x;
+  const int k = a.t.k;
+  s_dest[tid] = 0;
+  for (uint64_t tile = a.tile_begin + blockIdx.x; tile < a.tile_end; tile += gridDim.x) {
+    uint32_t lo = 0, hi = a.ncontigs;
+    while (hi - lo > 1) {
+      uint32_t mid = lo + (hi - lo) / 2;
+      if (a.tile_start[mid] <= tile) lo = mid; else hi = mid;
+    }
+    const uint32_t c = lo;
+    const uint64_t pos0 = (tile - a.tile_start[c]) * MFX_TILE;
+    const uint64_t clen = a.contig_len[c];
+    const uint32_t n = (clen - pos0 < MFX_TILE) ? (uint32_t)(clen - pos0) : MFX_TILE;
     __syncthreads();
+    mfx_tile_fill(L, a.bases + a.contig_off[c] + pos0);
+    __syncthreads();
+    uint64_t n_valid = 0, z1 = 0, z2 = 0;
+    const uint64_t obase = (tile - a.tile_begin) * MFX_TILE;
+    for (uint32_t b = 0; b < MFX_TILE / MFX_BLOCK; ++b) {
+      const uint32_t p = b * MFX_BLOCK + tid;
+      uint64_t f;
+      const bool ok = mfx_tile_kmer(L, k, p, f) && p < n;
+      uint64_t key = ~0ULL;
+      uint32_t own = 255u;
+      if (ok) {
+        const uint64_t r = mfx_revcomp(f, k);
+        key = f < r ? f : r;
+        own = mfx_owner(a.t, key, f < r ? r : f, a.nranks);
+        atomicAdd(&s_dest[own], 1u);
+        n_valid++;
+      }
+      a.keys[obase + p] = key;
+      a.owner[obase + p] = (uint8_t)own;
+    }
+    mfx_block_sum3(n_valid, z1, z2, s_red);
+    if (tid == 0 && n_valid) {                                   // merfin-histogram.C:58, counted where the sequence lives
+      atomicAdd((unsigned long long *)&a.counts[2ull * a.nbins + 0], n_valid);
+      atomicAdd((unsigned long long *)&a.counts[2ull * a.nbins + 3 + c], n_valid);
+    }
   }
-  if (tid == 0) a.partials[blockIdx.x] = s_dred[0];
+  __syncthreads();
+  if (tid < a.nranks && s_dest[tid]) atomicAdd((unsigned long long *)&a.dest_counts[tid], (unsigned long long)s_dest[tid]);
+}
+
+// gathers the routed k-mers into owner order (idx = stable-sorted positions) and attaches the contig id
+__global__ void mfx_route_gather_kernel(mfx_route_args a, const uint32_t *idx, uint64_t nvalid, uint64_t *keys_out, uint32_t *contig_out) {
+  uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < nvalid; i += stride) {
+    const uint32_t p = idx[i];
+    keys_out[i] = a.keys[p];
+    const uint64_t tile = a.tile_begin + p / MFX_TILE;
+    uint32_t lo = 0, hi = a.ncontigs;
+    while (hi - lo > 1) {
+      uint32_t mid = lo + (hi - lo) / 2;
+      if (a.tile_start[mid] <= tile) lo = mid; else hi = mid;
+    }
+    contig_out[i] = lo;
+  }
+}
+
+__global__ void mfx_iota_kernel(uint32_t *v, uint64_t n) {
+  uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) v[i] = (uint32_t)i;
+}
+
+// owner side: canonical k-mers (grouped by source order) -> lookup -> K* -> bins.
+// kasm was counted by the source; this adds kmissing (global + per contig), bins, koverCpy.
+__global__ __launch_bounds__(MFX_BLOCK) void mfx_hist_keys_kernel(mfx_hist_keys_args a) {
+  __shared__ mfx_mailbox MB;
+  __shared__ mfx_hist_lds H;
+  const uint32_t tid = threadIdx.x;
+  const int k = a.t.k;
+  const mfx_kstar_args &ka = a.ks;
+  mfx_hist_lds_init(H, ka);
+  const bool lut_ok = H.lut_ok != 0u;
+  const uint64_t per = ((a.n + gridDim.x - 1) / gridDim.x + MFX_BLOCK * MFX_BATCH - 1) / (MFX_BLOCK * MFX_BATCH) * (MFX_BLOCK * MFX_BATCH);
+  const uint64_t i0 = blockIdx.x * per, i1 = i0 + per < a.n ? i0 + per : a.n;
+  uint64_t n_missing = 0, n_over0 = 0, zz = 0;
+  double kover = 0.0;
+  uint64_t *c_glob = ka.counts + 2ull * ka.nbins;
+  uint64_t *c_kmis = c_glob + 3 + ka.ncontigs;
+  for (uint64_t base = i0; base < i1; base += MFX_BLOCK * MFX_BATCH) {       // block-uniform trip count
+    uint64_t key[MFX_BATCH], krc[MFX_BATCH];
+    uint32_t rv[MFX_BATCH], av[MFX_BATCH];
+    bool ok[MFX_BATCH];
+#pragma unroll
+    for (int j = 0; j < MFX_BATCH; ++j) {
+      const uint64_t i = base + (uint64_t)j * MFX_BLOCK + tid;
+      ok[j] = i < i1;
+      key[j] = ok[j] ? a.keys[i] : 0ULL;
+      krc[j] = mfx_revcomp(key[j], k);
+    }
+    mfx_group_lookup<MFX_BATCH>(a.t, MB, key, krc, ok, rv, av);
+#pragma unroll
+    for (int j = 0; j < MFX_BATCH; ++j) {
+      if (!ok[j]) continue;
+      if (mfx_hist_eval(H, ka, lut_ok, rv[j], av[j], n_over0, kover)) {
+        n_missing++;
+        atomicAdd((unsigned long long *)&c_kmis[a.contig[base + (uint64_t)j * MFX_BLOCK + tid]], 1ull);
+      }
+    }
+  }
+  mfx_block_sum3(n_missing, n_over0, zz, H.red);
+  if (tid == 0) {
+    if (n_missing) atomicAdd((unsigned long long *)&c_glob[1], n_missing);
+    if (n_over0) atomicAdd((unsigned long long *)&ka.counts[ka.nbins], n_over0);
+  }
+  mfx_hist_lds_flush(H, ka, kover);
 }
 
 // sums the per-block partials in a fixed order and adds the result to *out
@@ -707,6 +861,7 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_count_kernel(mfx_count_args a) 
       uint64_t f;
       if (!(mfx_tile_kmer(L, k, p, f) && p < n)) continue;
       uint64_t r = mfx_revcomp(f, k);
+      if (a.t.shard_n > 1 && mfx_owner(a.t, f < r ? f : r, f < r ? r : f, a.t.shard_n) != a.t.shard_rank) continue;
       mfx_slot *sl = mfx_claim(a.t, f < r ? f : r, a.meta);
       if (sl) atomicAdd(&sl->asmV, 1u);
     }
@@ -776,6 +931,27 @@ hipError_t mfx_k_table_export(mfx_table_view t, uint64_t *kmers, uint32_t *readV
 hipError_t mfx_k_hist(const mfx_hist_args &a, int grid, hipStream_t st) {
   if (a.canonical) mfx_hist_kernel<true><<<grid, MFX_BLOCK, 0, st>>>(a);
   else             mfx_hist_kernel<false><<<grid, MFX_BLOCK, 0, st>>>(a);
+  return hipGetLastError();
+}
+hipError_t mfx_k_route(const mfx_route_args &a, hipStream_t st) {
+  uint64_t nt = a.tile_end - a.tile_begin;
+  if (nt == 0) return hipSuccess;
+  mfx_route_kernel<<<(unsigned)(nt < 4096 ? nt : 4096), MFX_BLOCK, 0, st>>>(a);
+  return hipGetLastError();
+}
+hipError_t mfx_k_route_gather(const mfx_route_args &a, const uint32_t *idx, uint64_t nvalid, uint64_t *keys_out,
+                              uint32_t *contig_out, hipStream_t st) {
+  if (nvalid == 0) return hipSuccess;
+  mfx_route_gather_kernel<<<2048, 256, 0, st>>>(a, idx, nvalid, keys_out, contig_out);
+  return hipGetLastError();
+}
+hipError_t mfx_k_iota(uint32_t *v, uint64_t n, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  mfx_iota_kernel<<<2048, 256, 0, st>>>(v, n);
+  return hipGetLastError();
+}
+hipError_t mfx_k_hist_keys(const mfx_hist_keys_args &a, int grid, hipStream_t st) {
+  mfx_hist_keys_kernel<<<grid, MFX_BLOCK, 0, st>>>(a);
   return hipGetLastError();
 }
 hipError_t mfx_k_sum_partials(const double *partials, uint32_t n, double *out, hipStream_t st) {

@@ -48,3 +48,49 @@ def all_reduce_hist(counts, kover):
 def reduced_result(nbins, ncontigs, counts, kover):
     h = counts.detach().cpu().numpy().view(np.uint64)
     return result_from_counts(nbins, h, float(kover.item()), ncontigs)
+
+
+# ---------------------------------------------------------------------------
+# Sharded index (BASELINE config 5): the table does not fit one GPU, every rank
+# owns the k-mers whose minimizer hashes to it.  -hist = route -> exchange ->
+# evaluate at the owner -> one all-reduce.
+# ---------------------------------------------------------------------------
+def exchange_device(keys, contigs, send_counts):
+    """all-to-all of the routed k-mers on the device (RCCL over xGMI with backend "nccl")"""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    sc = torch.tensor([int(x) for x in send_counts], dtype=torch.int64, device=keys.device)
+    rc = torch.empty(world, dtype=torch.int64, device=keys.device)
+    dist.all_to_all_single(rc, sc)
+    rcl = [int(x) for x in rc.tolist()]
+    scl = [int(x) for x in send_counts]
+    n_in = sum(scl)
+    rk = torch.empty(sum(rcl), dtype=keys.dtype, device=keys.device)
+    rcg = torch.empty(sum(rcl), dtype=contigs.dtype, device=keys.device)
+    dist.all_to_all_single(rk, keys[:n_in], output_split_sizes=rcl, input_split_sizes=scl)
+    dist.all_to_all_single(rcg, contigs[:n_in], output_split_sizes=rcl, input_split_sizes=scl)
+    return rk, rcg
+
+
+def sharded_hist(ev, router, seqs, rank, world, counts, kover, stream=None, exchange=exchange_device):
+    """-hist over a sharded index.  `ev`/`router` are bound to THIS rank's shard of
+    the index; `seqs` is the whole assembly (every rank holds it); this rank routes
+    its tile range.  Accumulates into counts/kover (device tensors) and all-reduces."""
+    import torch
+    T = seqs.ntiles
+    lo, hi = shard(T, rank, world)
+    per = router.max_tiles
+    rounds = (-(-T // world) + per - 1) // per            # identical on every rank (collectives inside)
+    cap = per * TILE
+    keys = torch.empty(cap, dtype=torch.int64, device=counts.device)
+    ctg = torch.empty(cap, dtype=torch.int32, device=counts.device)
+    for r in range(rounds):
+        tb = min(hi, lo + r * per)
+        te = min(hi, tb + per)
+        send = router.route(seqs, tb, te, ev.nbins, counts, keys, ctg, stream=stream)
+        rk, rc = exchange(keys, ctg, send)
+        if rk.numel():
+            ev.hist_keys_launch(rk, rc, rk.numel(), seqs.ncontigs, counts, kover, stream=stream)
+        torch.cuda.synchronize()                           # rk/rc are released after this round
+    return all_reduce_hist(counts, kover)

@@ -1,0 +1,140 @@
+"""Sharded index (BASELINE config 5): every rank owns a hash-slice of the k-mer
+table; -hist routes each k-mer to its owner.  The GPU box has one GPU, so the
+ranks are (a) simulated in one process with a virtual exchange and (b) run as
+two real processes sharing GPU 0, exchanging through gloo (host memory) --
+RCCL refuses two ranks on one device.  Results must equal the oracle's."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from tests import synth
+from tests.test_gpu_parity import assert_hist_equal, oracle_hist
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build_shards(m, k, read, asm, world, contigs=None, count_from_seq=False):
+    shards = []
+    for r in range(world):
+        ix = m.Index(k, len(read[0]) + len(asm[0]) + 16)      # generous: every shard sized for the whole set
+        ix.set_shard(r, world)
+        ix.add_read(*read)
+        if count_from_seq:
+            ix.count_asm(m.Sequences(contigs))
+        else:
+            ix.add_asm(*asm)
+        shards.append(ix)
+    return shards
+
+
+@pytest.mark.parametrize("world,mode", [(2, "mz"), (3, "mz"), (4, "plain")])
+def test_sharded_hist_virtual_exchange(world, mode, monkeypatch):
+    torch = pytest.importorskip("torch")
+    import merfin_amd as m
+    from merfin_amd import distributed as D
+    monkeypatch.setenv("MFX_HOME_MODE", mode)
+    k, peak = 21, 17.3
+    contigs, read, asm = synth.world(k=k, peak=peak, seed=81)
+    p, g, ka, km = oracle_hist(k, peak, contigs, read, asm)
+    shards = _build_shards(m, k, read, asm, world, contigs, count_from_seq=True)
+    # the shards partition the k-mer set
+    union = np.union1d(read[0], asm[0])
+    sizes = [s.info()["distinct"] for s in shards]
+    assert sum(sizes) == len(union) and min(sizes) > 0.5 * len(union) / world
+    evs = [m.Evaluator(s, m.KParams(peak)) for s in shards]
+    seqs = m.Sequences(contigs)
+    T = seqs.ntiles
+    words = m.hist_words(evs[0].nbins, seqs.ncontigs)
+    counts = torch.zeros(words, dtype=torch.int64, device="cuda")
+    kover = torch.zeros(1, dtype=torch.float64, device="cuda")
+    per = 3                                                   # several routing rounds per rank
+    keys = torch.empty(per * m.TILE, dtype=torch.int64, device="cuda")
+    ctg = torch.empty(per * m.TILE, dtype=torch.int32, device="cuda")
+    for src in range(world):
+        router = m.Router(shards[src], world, per)
+        lo, hi = D.shard(T, src, world)
+        for tb in range(lo, hi, per):
+            send = router.route(seqs, tb, min(hi, tb + per), evs[0].nbins, counts, keys, ctg)
+            off = 0
+            for dst in range(world):
+                n = int(send[dst])
+                if n:
+                    evs[dst].hist_keys_launch(keys[off:off + n], ctg[off:off + n], n, seqs.ncontigs, counts, kover)
+                off += n
+            torch.cuda.synchronize()
+    res = m.result_from_counts(evs[0].nbins, counts.cpu().numpy().view(np.uint64), float(kover.item()), seqs.ncontigs)
+    assert_hist_equal(res, g, ka, km, k)
+
+
+def _worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    import merfin_amd as m
+    from merfin_amd import distributed as D
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    k, peak = 21, 17.3
+    contigs, read, asm = synth.world(k=k, peak=peak, seed=83)
+    ix = m.Index(k, len(read[0]) + len(asm[0]) + 16)
+    ix.set_shard(rank, world)
+    ix.add_read(*read)
+    ix.add_asm(*asm)
+    ev = m.Evaluator(ix, m.KParams(peak))
+    seqs = m.Sequences(contigs)
+    router = m.Router(ix, world, 4)
+    counts = torch.zeros(m.hist_words(ev.nbins, seqs.ncontigs), dtype=torch.int64, device="cuda")
+    kover = torch.zeros(1, dtype=torch.float64, device="cuda")
+
+    def exchange_host(keys, contigs_, send):                 # gloo: through host memory
+        sc = torch.tensor([int(x) for x in send], dtype=torch.int64)
+        rc = torch.empty(world, dtype=torch.int64)
+        dist.all_to_all_single(rc, sc)
+        rcl, scl = [int(x) for x in rc.tolist()], [int(x) for x in send]
+        n_in = sum(scl)
+        rk = torch.empty(sum(rcl), dtype=torch.int64)
+        rg = torch.empty(sum(rcl), dtype=torch.int32)
+        dist.all_to_all_single(rk, keys[:n_in].cpu(), output_split_sizes=rcl, input_split_sizes=scl)
+        dist.all_to_all_single(rg, contigs_[:n_in].cpu(), output_split_sizes=rcl, input_split_sizes=scl)
+        return rk.cuda(), rg.cuda()
+
+    T = seqs.ntiles
+    lo, hi = D.shard(T, rank, world)
+    per = router.max_tiles
+    rounds = (-(-T // world) + per - 1) // per
+    keys = torch.empty(per * m.TILE, dtype=torch.int64, device="cuda")
+    ctg = torch.empty(per * m.TILE, dtype=torch.int32, device="cuda")
+    for r in range(rounds):
+        tb = min(hi, lo + r * per)
+        te = min(hi, tb + per)
+        send = router.route(seqs, tb, te, ev.nbins, counts, keys, ctg)
+        rk, rg = exchange_host(keys, ctg, send)
+        if rk.numel():
+            ev.hist_keys_launch(rk, rg, rk.numel(), seqs.ncontigs, counts, kover)
+        torch.cuda.synchronize()
+    c, kv = counts.cpu(), kover.cpu()
+    D.all_reduce_hist(c, kv)
+    if rank == 0:
+        res = m.result_from_counts(ev.nbins, c.numpy().view(np.uint64), float(kv.item()), seqs.ncontigs)
+        p, g, ka, km = oracle_hist(k, peak, contigs, read, asm)
+        try:
+            assert_hist_equal(res, g, ka, km, k)
+            open(os.path.join(tmp, "ok"), "w").write("1")
+        except AssertionError as e:
+            open(os.path.join(tmp, "ok"), "w").write("0 %r" % (e,))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_hist_two_processes_one_gpu(tmp_path):
+    torch = pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    port = 29700 + os.getpid() % 1500
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok").read_text() == "1"
