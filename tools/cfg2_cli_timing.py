@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""End-to-end timing of the C++ CLI on a BASELINE-config-2-sized case (64 Mb,
+one contig, k=21, 30x-like read counts): writes FASTA + flat k-mer DBs, then
+runs `merfin -hist` and `merfin -dump` and reports wall times.  Run on the GPU
+box:  python tools/cfg2_cli_timing.py [bases]"""
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import merfin_amd as m
+from tools import synth_torch as st
+
+bases = int(float(sys.argv[1])) if len(sys.argv) > 1 else 64_000_000
+out = os.environ.get("MFX_TMP", "/tmp/mfx_cfg2")
+os.makedirs(out, exist_ok=True)
+t0 = time.time()
+ix, seqs, asm, info = st.build_world(m, bases, k=21, lam=26.0, ncontigs=1)
+ek, er, ea = ix.export()
+m.db_write_flat(out + "/read.mfxk", 21, ek[er > 0], er[er > 0])
+m.db_write_flat(out + "/asm.mfxk", 21, ek[ea > 0], ea[ea > 0])
+seq = asm[0].cpu().numpy().tobytes()
+with open(out + "/asm.fasta", "wb") as f:
+    f.write(b">chr20_like synthetic\n")
+    for o in range(0, len(seq), 1 << 20):
+        f.write(seq[o:o + (1 << 20)] + b"\n")
+del ix, seqs, asm
+torch.cuda.empty_cache()
+print("inputs written in %.1fs: %d read k-mers, %d asm k-mers" % (time.time() - t0, int((er > 0).sum()), int((ea > 0).sum())), flush=True)
+exe = os.path.join(ROOT, "merfin_amd", "bin", "merfin")
+prob = os.path.join(ROOT, "tests", "golden", "example_lookup_table.txt")
+common = ["-sequence", out + "/asm.fasta", "-readmers", out + "/read.mfxk", "-seqmers", out + "/asm.mfxk", "-peak", "26", "-prob", prob]
+for mode, o in (("-hist", out + "/out.hist"), ("-dump", out + "/out.dump")):
+    t = time.time()
+    r = subprocess.run([exe, mode] + common + ["-output", o], capture_output=True, text=True)
+    dt = time.time() - t
+    tail = [l for l in r.stderr.splitlines() if l and not l.startswith("Copy-number")][-8:]
+    print("%s: rc=%d wall=%.2fs output=%.1f MB" % (mode, r.returncode, dt, os.path.getsize(o) / 1e6))
+    for l in tail:
+        print("    " + l)
+# -hist without -seqmers: assembly k-mers counted on the GPU
+t = time.time()
+r = subprocess.run([exe, "-hist", "-sequence", out + "/asm.fasta", "-readmers", out + "/read.mfxk", "-peak", "26", "-prob", prob,
+                    "-output", out + "/out2.hist"], capture_output=True, text=True)
+print("-hist (asm counted on GPU): rc=%d wall=%.2fs same_hist=%s" % (r.returncode, time.time() - t,
+      open(out + "/out.hist").read() == open(out + "/out2.hist").read()))
