@@ -331,12 +331,48 @@ extern "C" mfx_seq *mfx_seq_upload(int device, const char *const *bases, const u
   DevGuard g(device);
   mfx_seq *s = seq_layout(device, lens, ncontigs);
   if (seq_alloc(s) != MFX_OK) { mfx_seq_free(s); return nullptr; }
-  for (uint32_t c = 0; c < ncontigs; ++c)
-    if (lens[c] && hipMemcpy(s->d_bases + s->off[c], bases[c], lens[c], hipMemcpyHostToDevice) != hipSuccess) {
-      mfx_fail(MFX_E_HIP, "H2D copy of contig %u failed", c);
-      mfx_seq_free(s);
-      return nullptr;
+  // The packed image (contigs at their padded offsets, zero filler in between) is assembled in a
+  // pinned staging buffer and sent in large pieces: an assembly of a million small contigs must not
+  // become a million tiny hipMemcpy calls.
+  const size_t STAGE = 256ull << 20;
+  uint8_t *stage = nullptr;
+  if (hipHostMalloc((void **)&stage, STAGE, hipHostMallocDefault) != hipSuccess) {
+    mfx_fail(MFX_E_NOMEM, "pinned staging buffer allocation failed");
+    mfx_seq_free(s);
+    return nullptr;
+  }
+  uint64_t win = 0;                      // device offset the staging buffer currently mirrors
+  size_t used = 0;                       // bytes of it that are meaningful
+  bool ok = true;
+  auto flush = [&]() {
+    if (used && hipMemcpy(s->d_bases + win, stage, used, hipMemcpyHostToDevice) != hipSuccess) ok = false;
+    win += used;
+    used = 0;
+  };
+  for (uint32_t c = 0; c < ncontigs && ok; ++c) {
+    uint64_t done = 0;
+    while (done < lens[c] && ok) {
+      const uint64_t dst = s->off[c] + done;                 // device offset of the next byte of this contig
+      if (dst < win + used || dst - win >= STAGE) {          // not appendable to the current window
+        flush();
+        win = dst;
+      }
+      const size_t at = (size_t)(dst - win);
+      if (at > used) memset(stage + used, 0, at - used);      // inter-contig padding stays non-ACGT
+      const size_t m = (size_t)std::min<uint64_t>(lens[c] - done, STAGE - at);
+      memcpy(stage + at, bases[c] + done, m);
+      used = at + m;
+      done += m;
+      if (used == STAGE) flush();
     }
+  }
+  if (ok) flush();
+  (void)hipHostFree(stage);
+  if (!ok) {
+    mfx_fail(MFX_E_HIP, "H2D copy of the packed assembly failed");
+    mfx_seq_free(s);
+    return nullptr;
+  }
   return s;
 }
 

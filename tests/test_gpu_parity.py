@@ -303,6 +303,23 @@ def test_tile_and_contig_edge_cases():
     assert list(ka[[0, 1, 4, 5, 8]]) == [0, 0, 0, 0, 0] and ka[6] == 1
 
 
+def test_many_small_contigs():
+    """A fragmented assembly: thousands of contigs shorter than a tile (and than the staging window logic's pieces)."""
+    m = _mfx()
+    k = 21
+    r = synth.rng(123)
+    contigs = [synth.random_contig(r, int(n)).tobytes() for n in r.integers(0, 900, size=3000)]
+    contigs[17] = b""
+    ak, av = po.count_kmers(k, contigs)
+    rv = (2 + (ak % 30)).astype(np.uint32)
+    p, g, ka, km = oracle_hist(k, 7.5, contigs, (ak, rv), (ak, av))
+    ix = build_index(m, k, (ak, rv), (ak, av))
+    seqs = m.Sequences(contigs)
+    assert seqs.ncontigs == 3000
+    res = m.Evaluator(ix, m.KParams(7.5)).hist(seqs)
+    assert_hist_equal(res, g, ka, km, k)
+
+
 def test_sharded_launch_equals_whole(golden_dir):
     """Position-tile sharding (the multi-GPU decomposition): any split of the tile
     range accumulates to the same integers; koverCpy to the same value within 1e-12."""
