@@ -334,18 +334,38 @@ extern "C" mfx_seq *mfx_seq_upload(int device, const char *const *bases, const u
   // The packed image (contigs at their padded offsets, zero filler in between) is assembled in a
   // pinned staging buffer and sent in large pieces: an assembly of a million small contigs must not
   // become a million tiny hipMemcpy calls.
-  const size_t STAGE = 256ull << 20;
-  uint8_t *stage = nullptr;
-  if (hipHostMalloc((void **)&stage, STAGE, hipHostMallocDefault) != hipSuccess) {
-    mfx_fail(MFX_E_NOMEM, "pinned staging buffer allocation failed");
+  // Two staging buffers alternate: while one is in flight over PCIe the host fills the other.
+  const size_t STAGE = 64ull << 20;
+  uint8_t *stages[2] = {nullptr, nullptr};
+  hipStream_t cs = nullptr;
+  hipEvent_t done_ev[2] = {nullptr, nullptr};
+  bool ok = hipHostMalloc((void **)&stages[0], STAGE, hipHostMallocDefault) == hipSuccess &&
+            hipHostMalloc((void **)&stages[1], STAGE, hipHostMallocDefault) == hipSuccess &&
+            hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&done_ev[0], hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&done_ev[1], hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
+    mfx_fail(MFX_E_NOMEM, "pinned staging setup failed");
+    for (int i = 0; i < 2; ++i) { if (stages[i]) (void)hipHostFree(stages[i]); if (done_ev[i]) (void)hipEventDestroy(done_ev[i]); }
+    if (cs) (void)hipStreamDestroy(cs);
     mfx_seq_free(s);
     return nullptr;
   }
+  int cur = 0;
+  bool inflight[2] = {false, false};
+  uint8_t *stage = stages[0];
   uint64_t win = 0;                      // device offset the staging buffer currently mirrors
   size_t used = 0;                       // bytes of it that are meaningful
-  bool ok = true;
   auto flush = [&]() {
-    if (used && hipMemcpy(s->d_bases + win, stage, used, hipMemcpyHostToDevice) != hipSuccess) ok = false;
+    if (used) {
+      if (hipMemcpyAsync(s->d_bases + win, stage, used, hipMemcpyHostToDevice, cs) != hipSuccess ||
+          hipEventRecord(done_ev[cur], cs) != hipSuccess) ok = false;
+      inflight[cur] = true;
+      cur ^= 1;
+      if (inflight[cur] && hipEventSynchronize(done_ev[cur]) != hipSuccess) ok = false;   // the other buffer is free again
+      inflight[cur] = false;
+      stage = stages[cur];
+    }
     win += used;
     used = 0;
   };
@@ -367,7 +387,9 @@ extern "C" mfx_seq *mfx_seq_upload(int device, const char *const *bases, const u
     }
   }
   if (ok) flush();
-  (void)hipHostFree(stage);
+  if (hipStreamSynchronize(cs) != hipSuccess) ok = false;
+  for (int i = 0; i < 2; ++i) { (void)hipHostFree(stages[i]); (void)hipEventDestroy(done_ev[i]); }
+  (void)hipStreamDestroy(cs);
   if (!ok) {
     mfx_fail(MFX_E_HIP, "H2D copy of the packed assembly failed");
     mfx_seq_free(s);
