@@ -164,6 +164,7 @@ extern "C" void mfx_index_free(mfx_index *ix) {
 }
 
 static int index_check(mfx_index *ix) {
+  ix->version++;
   uint64_t meta[4];
   MFX_HIP(hipMemcpy(meta, ix->d_meta, sizeof(meta), hipMemcpyDeviceToHost));
   if (meta[2] != 0)
@@ -533,6 +534,18 @@ static int index_canonical(const mfx_index *ix, int *canon) {
   return MFX_OK;
 }
 
+// the canonical/odd-k decision costs a blocking D2H read; evaluators cache it per index version so
+// that mfx_hist_launch stays asynchronous (it is called once per step in the multi-GPU loop)
+static int eval_canonical(mfx_eval *ev, int *canon) {
+  if (ev->canon_version != ev->ix->version) {
+    int rc = index_canonical(ev->ix, &ev->canon);
+    if (rc) return rc;
+    ev->canon_version = ev->ix->version;
+  }
+  *canon = ev->canon;
+  return MFX_OK;
+}
+
 extern "C" int mfx_hist_launch(mfx_eval *ev, const mfx_seq *seq, uint64_t tile_begin, uint64_t tile_end,
                                uint64_t *d_counts, double *d_kover, void *stream) {
   if (!ev || !seq || !d_counts || !d_kover) return mfx_fail(MFX_E_INVAL, "mfx_hist_launch: null argument");
@@ -541,7 +554,7 @@ extern "C" int mfx_hist_launch(mfx_eval *ev, const mfx_seq *seq, uint64_t tile_b
                                                                       (unsigned long)tile_begin, (unsigned long)tile_end, (unsigned long)seq->ntiles);
   DevGuard g(ev->device);
   int canon = 0;
-  int rc = index_canonical(ev->ix, &canon);
+  int rc = eval_canonical(ev, &canon);
   if (rc) return rc;
   const char *force = getenv("MFX_FORCE_TWO_STRAND");
   if (force && atoi(force)) canon = 0;

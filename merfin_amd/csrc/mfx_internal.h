@@ -70,6 +70,7 @@ struct mfx_index {
   bool      filter_set = false;
   int       mz_w = 0;
   uint32_t  shard_rank = 0, shard_n = 1;
+  uint64_t  version = 0;        // bumped by every insert batch; lets evaluators cache index-derived facts
   mfx_table_view view() const;
 };
 
@@ -97,6 +98,8 @@ struct mfx_eval {
   double   *d_probP = nullptr;
   uint32_t  nbins = 65536;
   int       grid = 0;
+  uint64_t  canon_version = ~0ull;   // index version the cached `canon` flag belongs to
+  int       canon = 0;
   double   *d_partials = nullptr;    // [grid] per-block koverCpy partial sums
   uint64_t *d_ovf = nullptr;         // [0] count, [1..] records
 };
