@@ -249,14 +249,20 @@ struct mfx_mailbox {
   uint4 rec[MFX_BLOCK];      // x = key_hi of the matching slot (0xffffffff: none), y = readV, z = asmV, w = empty seen
 };
 
+// Issue phase of a round, in two steps so that nothing serialises: first ALL the
+// cross-lane broadcasts (16 LDS-crossbar ops back to back), then ALL 8 loads back
+// to back.  A position without a k-mer still "owns" a query -- of line 0, whose
+// outcome its lane ignores (ok[j] is false) -- so the hot sequence has no
+// exec-mask branches and no dead-owner bookkeeping.
 template <int S>
-__device__ __forceinline__ void mfx_group_issue(const mfx_table_view &t, uint4 (&v)[8], uint32_t (&klo)[8], uint32_t line,
-                                                uint32_t key_lo, uint32_t sub) {
-  const uint32_t ls = mfx_group_bcast<S>(line);
+__device__ __forceinline__ void mfx_group_announce(uint32_t (&ls)[8], uint32_t (&klo)[8], uint32_t line, uint32_t key_lo) {
+  ls[S] = mfx_group_bcast<S>(line);
   klo[S] = mfx_group_bcast<S>(key_lo);
-  v[S] = make_uint4(0xffffffffu, 0xffffffffu, 0u, 0u);        // dead owner: looks like an empty line, never matches
-  if (ls != 0xffffffffu)
-    v[S] = *reinterpret_cast<const uint4 *>(t.slots + (uint64_t)ls * MFX_SLOTS_LINE + sub);
+}
+
+template <int S>
+__device__ __forceinline__ void mfx_group_fetch(const mfx_table_view &t, uint4 (&v)[8], const uint32_t (&ls)[8], uint32_t sub) {
+  v[S] = *reinterpret_cast<const uint4 *>(t.slots + (uint64_t)ls[S] * MFX_SLOTS_LINE + sub);
 }
 
 template <int S>
@@ -282,7 +288,7 @@ __device__ __forceinline__ void mfx_group_lookup(const mfx_table_view &t, mfx_ma
   uint32_t pending[B];          // 0 resolved, 1 home line full (continue at candidate 1), 2 ambiguous (redo exactly)
 #pragma unroll
   for (int j = 0; j < B; ++j) {
-    line[j] = ok[j] ? mfx_first_line(t, key[j], krc[j]) : 0xffffffffu;
+    line[j] = ok[j] ? mfx_first_line(t, key[j], krc[j]) : 0u;      // no k-mer here: a dummy query of line 0, ignored below
     pending[j] = 0u;
     rv[j] = av[j] = 0u;
   }
@@ -292,10 +298,14 @@ __device__ __forceinline__ void mfx_group_lookup(const mfx_table_view &t, mfx_ma
     uint32_t klo[8];
     const uint32_t key_lo = (uint32_t)key[j], key_hi = (uint32_t)(key[j] >> 32);
     M.rec[tid] = make_uint4(0xffffffffu, 0u, 0u, 0u);
-    mfx_group_issue<0>(t, v, klo, line[j], key_lo, sub); mfx_group_issue<1>(t, v, klo, line[j], key_lo, sub);
-    mfx_group_issue<2>(t, v, klo, line[j], key_lo, sub); mfx_group_issue<3>(t, v, klo, line[j], key_lo, sub);
-    mfx_group_issue<4>(t, v, klo, line[j], key_lo, sub); mfx_group_issue<5>(t, v, klo, line[j], key_lo, sub);
-    mfx_group_issue<6>(t, v, klo, line[j], key_lo, sub); mfx_group_issue<7>(t, v, klo, line[j], key_lo, sub);
+    uint32_t ls[8];
+    mfx_group_announce<0>(ls, klo, line[j], key_lo); mfx_group_announce<1>(ls, klo, line[j], key_lo);
+    mfx_group_announce<2>(ls, klo, line[j], key_lo); mfx_group_announce<3>(ls, klo, line[j], key_lo);
+    mfx_group_announce<4>(ls, klo, line[j], key_lo); mfx_group_announce<5>(ls, klo, line[j], key_lo);
+    mfx_group_announce<6>(ls, klo, line[j], key_lo); mfx_group_announce<7>(ls, klo, line[j], key_lo);
+    mfx_group_fetch<0>(t, v, ls, sub); mfx_group_fetch<1>(t, v, ls, sub); mfx_group_fetch<2>(t, v, ls, sub);
+    mfx_group_fetch<3>(t, v, ls, sub); mfx_group_fetch<4>(t, v, ls, sub); mfx_group_fetch<5>(t, v, ls, sub);
+    mfx_group_fetch<6>(t, v, ls, sub); mfx_group_fetch<7>(t, v, ls, sub);
     mfx_group_post<0>(M, v, klo, obase); mfx_group_post<1>(M, v, klo, obase); mfx_group_post<2>(M, v, klo, obase);
     mfx_group_post<3>(M, v, klo, obase); mfx_group_post<4>(M, v, klo, obase); mfx_group_post<5>(M, v, klo, obase);
     mfx_group_post<6>(M, v, klo, obase); mfx_group_post<7>(M, v, klo, obase);
