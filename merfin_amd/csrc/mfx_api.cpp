@@ -755,8 +755,8 @@ int mfx_sort_by_owner(void *tmp, size_t &tmp_bytes, const uint8_t *kin, uint8_t 
                       uint64_t n, hipStream_t st);   // mfx_sort.hip (hipcub stable radix sort)
 
 extern "C" mfx_router *mfx_router_create(const mfx_index *ix, uint32_t nranks, uint32_t max_tiles) {
-  if (!ix || nranks == 0 || nranks > 254 || max_tiles == 0 || (uint64_t)max_tiles * MFX_TILE >= (1ull << 32)) {
-    mfx_fail(MFX_E_INVAL, "mfx_router_create: bad argument (nranks <= 254, max_tiles * %u < 2^32)", MFX_TILE);
+  if (!ix || nranks == 0 || nranks > 254 || max_tiles == 0 || (uint64_t)max_tiles * MFX_TILE >= (1ull << 31)) {
+    mfx_fail(MFX_E_INVAL, "mfx_router_create: bad argument (nranks <= 254, max_tiles * %u < 2^31: the sort counts items in an int)", MFX_TILE);
     return nullptr;
   }
   DevGuard g(ix->device);

@@ -150,3 +150,22 @@ def test_cli_variant_modes(tmp_path, mode):
     assert (tmp_path / ("out" + suffix)).read_text() == (tmp_path / "o.vcf").read_text()
     assert gzip.open(str(tmp_path / "out.00.debug.gz"), "rt").read() == (tmp_path / "o.dbg").read_text()
     assert "Processing sequence ctg0 for variants" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_fastq_input_and_lowercase(tmp_path):
+    """-sequence may be FASTQ (merfin.C:195); quality lines must not be parsed as bases."""
+    import merfin_amd as m
+    k, peak = 21, 17.3
+    contigs, read, asm = synth.world(k=k, peak=peak, seed=67, sizes=(9000, 2000, 30))
+    p = po.Params(k, peak)
+    g, ka, km, _ = po.hist_run(p, po.Lookup(k, *read), po.Lookup(k, *asm), contigs, threads=2)
+    po.report_histogram(p, g, str(tmp_path / "o.hist"), None)
+    fq = str(tmp_path / "asm.fastq.gz")
+    with gzip.open(fq, "wb") as f:
+        for i, c in enumerate(contigs):
+            f.write(b"@ctg%d desc\n" % i + c + b"\n+\n" + b"I" * len(c) + b"\n")
+    m.db_write_flat(str(tmp_path / "read.mfxk"), k, *read)
+    r = run(["-hist", "-sequence", fq, "-readmers", str(tmp_path / "read.mfxk"), "-peak", str(peak), "-output", str(tmp_path / "g.hist")])
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "g.hist").read_bytes() == (tmp_path / "o.hist").read_bytes()
