@@ -144,8 +144,10 @@ __device__ __forceinline__ uint2 mfx_lookup(const mfx_table_view &t, uint64_t ke
   return mfx_scan_lines(t, key, mfx_home(t, key), 0);
 }
 
-// find-or-claim the slot of `key`; nullptr when the probe limit is hit
-__device__ __forceinline__ mfx_slot *mfx_claim(const mfx_table_view &t, uint64_t key, uint64_t *meta) {
+// find-or-claim the slot of `key`; nullptr when the probe limit is hit.  New k-mers are
+// counted in the caller's register (`fresh`) -- one shared counter word bumped by every
+// insert serialises the whole build (a single address takes ~90 M atomics/s).
+__device__ __forceinline__ mfx_slot *mfx_claim(const mfx_table_view &t, uint64_t key, uint64_t *meta, uint32_t &fresh) {
   const mfx_probe pr = mfx_home(t, key);
   for (uint32_t d = 0; d < MFX_MAX_LINES; ++d) {
     const uint64_t base = mfx_probe_line(t, pr, d) * MFX_SLOTS_LINE;
@@ -156,7 +158,7 @@ __device__ __forceinline__ mfx_slot *mfx_claim(const mfx_table_view &t, uint64_t
       if (cur == MFX_EMPTY) {
         cur = atomicCAS(kp, (unsigned long long)MFX_EMPTY, (unsigned long long)key);
         if (cur == MFX_EMPTY) {
-          atomicAdd((unsigned long long *)&meta[0], 1ull);
+          ++fresh;
           return sl;
         }
       }
@@ -166,6 +168,17 @@ __device__ __forceinline__ mfx_slot *mfx_claim(const mfx_table_view &t, uint64_t
   }
   atomicAdd((unsigned long long *)&meta[2], 1ull);
   return nullptr;
+}
+
+// wave-reduce the per-lane insert statistics, one atomic per wave
+__device__ __forceinline__ void mfx_meta_flush(uint64_t *meta, uint32_t fresh, uint32_t noncanon) {
+  uint64_t f = fresh, c = noncanon;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { f += __shfl_down(f, o, 64); c += __shfl_down(c, o, 64); }
+  if ((threadIdx.x & 63u) == 0) {
+    if (f) atomicAdd((unsigned long long *)&meta[0], (unsigned long long)f);
+    if (c) atomicAdd((unsigned long long *)&meta[1], (unsigned long long)c);
+  }
 }
 
 __global__ void mfx_table_init_kernel(mfx_slot *slots, uint64_t nslots) {
@@ -181,18 +194,19 @@ __global__ void mfx_table_add_kernel(mfx_table_view t, const uint64_t *kmers, co
                                      int side, uint64_t *meta) {
   uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
   uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  uint32_t fresh = 0, noncanon = 0;
   for (; i < n; i += stride) {
     uint64_t key = kmers[i];
     uint32_t v = values[i];
     if (v == 0) continue;
     const uint64_t krc = mfx_revcomp(key, t.k);
-    if (key > krc)
-      atomicAdd((unsigned long long *)&meta[1], 1ull);
+    if (key > krc) ++noncanon;
     if (t.shard_n > 1 && mfx_owner(t, key < krc ? key : krc, key < krc ? krc : key, t.shard_n) != t.shard_rank)
       continue;                                              // another rank owns this k-mer
-    mfx_slot *sl = mfx_claim(t, key, meta);
+    mfx_slot *sl = mfx_claim(t, key, meta, fresh);
     if (sl) atomicAdd(side ? &sl->asmV : &sl->readV, v);
   }
+  mfx_meta_flush(meta, fresh, noncanon);
 }
 
 __global__ void mfx_table_value_kernel(mfx_table_view t, const uint64_t *kmers, uint64_t n, uint32_t *readV, uint32_t *asmV) {
@@ -852,6 +866,7 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_count_kernel(mfx_count_args a) 
   __shared__ mfx_tile_lds L;
   const uint32_t tid = threadIdx.x;
   const int k = a.t.k;
+  uint32_t fresh = 0;
   for (uint64_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     uint32_t lo = 0, hi = a.ncontigs;
     while (hi - lo > 1) {
@@ -872,10 +887,11 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_count_kernel(mfx_count_args a) 
       if (!(mfx_tile_kmer(L, k, p, f) && p < n)) continue;
       uint64_t r = mfx_revcomp(f, k);
       if (a.t.shard_n > 1 && mfx_owner(a.t, f < r ? f : r, f < r ? r : f, a.t.shard_n) != a.t.shard_rank) continue;
-      mfx_slot *sl = mfx_claim(a.t, f < r ? f : r, a.meta);
+      mfx_slot *sl = mfx_claim(a.t, f < r ? f : r, a.meta, fresh);
       if (sl) atomicAdd(&sl->asmV, 1u);
     }
   }
+  mfx_meta_flush(a.meta, fresh, 0u);
 }
 
 // ===========================================================================
