@@ -17,3 +17,17 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built_artifacts():
+    """The in-tree HIP library / CLI are git-ignored build products.  If a checkout
+    arrives without them, build them once (hipcc cross-compiles without a GPU) --
+    the product itself never auto-builds or falls back: merfin_amd.load_library()
+    raises when the .so is missing."""
+    lib = os.path.join(ROOT, "merfin_amd", "libmerfin_amd.so")
+    exe = os.path.join(ROOT, "merfin_amd", "bin", "merfin")
+    if not (os.path.exists(lib) and os.path.exists(exe)):
+        import __graft_entry__
+        __graft_entry__.build()
+    yield
