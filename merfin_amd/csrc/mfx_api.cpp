@@ -84,6 +84,20 @@ uint64_t lines_for(uint64_t capacity_kmers) {
 }
 }  // namespace
 
+// host-side copy into the pinned staging buffer, split over a few threads for large pieces
+// (a single thread moves ~12 GB/s, well under PCIe Gen5)
+static void par_memcpy(uint8_t *dst, const char *src, size_t n) {
+  const unsigned nt = std::min<unsigned>(8u, std::max(1u, mfx_host_threads()));
+  if (n < (8u << 20) || nt == 1) { memcpy(dst, src, n); return; }
+  std::vector<std::thread> th;
+  const size_t per = (n + nt - 1) / nt;
+  for (unsigned t = 0; t < nt; ++t) {
+    size_t b = std::min(n, t * per), e = std::min(n, b + per);
+    if (e > b) th.emplace_back([=]() { memcpy(dst + b, src + b, e - b); });
+  }
+  for (auto &x : th) x.join();
+}
+
 // ---------------------------------------------------------------------------
 // index
 // ---------------------------------------------------------------------------
@@ -184,18 +198,50 @@ static int index_add(mfx_index *ix, const uint64_t *kmers, const uint32_t *value
     MFX_HIP(hipDeviceSynchronize());
     return index_check(ix);
   }
-  const uint64_t CH = 1ull << 24;
-  DevBuf<uint64_t> dk;
-  DevBuf<uint32_t> dv;
-  MFX_HIP(dk.alloc(std::min(n, CH)));
-  MFX_HIP(dv.alloc(std::min(n, CH)));
-  for (uint64_t o = 0; o < n; o += CH) {
-    uint64_t m = std::min(CH, n - o);
-    MFX_HIP(hipMemcpy(dk.p, kmers + o, m * sizeof(uint64_t), hipMemcpyHostToDevice));
-    MFX_HIP(hipMemcpy(dv.p, values + o, m * sizeof(uint32_t), hipMemcpyHostToDevice));
-    MFX_HIP(mfx_k_table_add(ix->view(), dk.p, dv.p, m, side, ix->d_meta, nullptr));
-    MFX_HIP(hipDeviceSynchronize());
+  // Host arrays: stream them through two alternating sets of pinned staging + device buffers,
+  // so the threaded host copy of chunk i+1 overlaps the PCIe transfer and the insert kernel of chunk i.
+  const uint64_t CH = std::min<uint64_t>(n ? n : 1, 1ull << 23);
+  struct Lane {
+    uint64_t *hk = nullptr, *dk = nullptr;
+    uint32_t *hv = nullptr, *dv = nullptr;
+    hipEvent_t done = nullptr;
+    bool busy = false;
+  } L[2];
+  hipStream_t st = nullptr;
+  auto cleanup = [&]() {
+    if (st) (void)hipStreamSynchronize(st);
+    for (auto &l : L) {
+      if (l.hk) (void)hipHostFree(l.hk);
+      if (l.hv) (void)hipHostFree(l.hv);
+      if (l.dk) (void)hipFree(l.dk);
+      if (l.dv) (void)hipFree(l.dv);
+      if (l.done) (void)hipEventDestroy(l.done);
+    }
+    if (st) (void)hipStreamDestroy(st);
+  };
+  bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+  for (auto &l : L)
+    ok = ok && hipHostMalloc((void **)&l.hk, CH * 8, hipHostMallocDefault) == hipSuccess &&
+         hipHostMalloc((void **)&l.hv, CH * 4, hipHostMallocDefault) == hipSuccess &&
+         hipMalloc((void **)&l.dk, CH * 8) == hipSuccess && hipMalloc((void **)&l.dv, CH * 4) == hipSuccess &&
+         hipEventCreateWithFlags(&l.done, hipEventDisableTiming) == hipSuccess;
+  if (!ok) { cleanup(); return mfx_fail(MFX_E_NOMEM, "mfx_index_add: staging allocation failed"); }
+  int cur = 0;
+  for (uint64_t o = 0; o < n && ok; o += CH, cur ^= 1) {
+    Lane &l = L[cur];
+    const uint64_t m = std::min(CH, n - o);
+    if (l.busy && hipEventSynchronize(l.done) != hipSuccess) { ok = false; break; }
+    par_memcpy((uint8_t *)l.hk, (const char *)(kmers + o), m * 8);
+    par_memcpy((uint8_t *)l.hv, (const char *)(values + o), m * 4);
+    ok = hipMemcpyAsync(l.dk, l.hk, m * 8, hipMemcpyHostToDevice, st) == hipSuccess &&
+         hipMemcpyAsync(l.dv, l.hv, m * 4, hipMemcpyHostToDevice, st) == hipSuccess &&
+         mfx_k_table_add(ix->view(), l.dk, l.dv, m, side, ix->d_meta, st) == hipSuccess &&
+         hipEventRecord(l.done, st) == hipSuccess;
+    l.busy = true;
   }
+  if (ok && hipStreamSynchronize(st) != hipSuccess) ok = false;
+  cleanup();
+  if (!ok) return mfx_fail(MFX_E_HIP, "mfx_index_add: transfer / insert failed: %s", hipGetErrorString(hipGetLastError()));
   return index_check(ix);
 }
 
@@ -287,20 +333,6 @@ extern "C" int mfx_index_export(const mfx_index *ix, uint64_t *kmers, uint32_t *
 // ---------------------------------------------------------------------------
 // sequences
 // ---------------------------------------------------------------------------
-// host-side copy into the pinned staging buffer, split over a few threads for large pieces
-// (a single thread moves ~12 GB/s, well under PCIe Gen5)
-static void par_memcpy(uint8_t *dst, const char *src, size_t n) {
-  const unsigned nt = std::min<unsigned>(8u, std::max(1u, mfx_host_threads()));
-  if (n < (8u << 20) || nt == 1) { memcpy(dst, src, n); return; }
-  std::vector<std::thread> th;
-  const size_t per = (n + nt - 1) / nt;
-  for (unsigned t = 0; t < nt; ++t) {
-    size_t b = std::min(n, t * per), e = std::min(n, b + per);
-    if (e > b) th.emplace_back([=]() { memcpy(dst + b, src + b, e - b); });
-  }
-  for (auto &x : th) x.join();
-}
-
 static mfx_seq *seq_layout(int device, const uint64_t *lens, uint32_t ncontigs) {
   mfx_seq *s = new mfx_seq;
   s->device = device;
