@@ -128,6 +128,11 @@ extern "C" mfx_index *mfx_index_create(int k, uint64_t capacity_kmers, double ma
     mfx_fail(MFX_E_NODEVICE, "HIP device %d not available (%d visible); merfin_amd has no CPU path", device, mfx_device_count());
     return nullptr;
   }
+  if (lines_for(capacity_kmers) >= 0xfffffff0ull) {
+    mfx_fail(MFX_E_INVAL, "capacity of %lu k-mers needs more than 2^32 table lines (512 GB); shard the index instead",
+             (unsigned long)capacity_kmers);
+    return nullptr;
+  }
   double need = mfx_index_estimate_gb(k, capacity_kmers);
   if (max_gb > 0 && need > max_gb) {
     // merfin-globals.C:148-153
