@@ -91,3 +91,41 @@ def test_revcomp_symmetry_and_count_mass(world):
     r, a, ka, km = ev.dump_values(seqs, 23, 0, min(5_000_000, info["sizes"][23]))
     valid = (r > 0) | (a > 0)
     assert ka == int(valid.sum()) and (a[valid] >= 1).all()
+
+
+def test_hist_kernel_equals_dump_kernel_plus_host_kstar(world, golden_dir):
+    """Cross-kernel consistency at scale: the K* histogram rebuilt on the host from the
+    -dump kernel's raw (readV, asmV) values (numpy float64, the same IEEE operations as
+    merfin-histogram.C:66-90) equals the -hist kernel's bins for the same contig."""
+    m, st, torch, ix, seqs, asm, info = world
+    kp = m.KParams.from_file(26.0, os.path.join(golden_dir, "example_lookup_table.txt"))
+    ev = m.Evaluator(ix, kp)
+    c = 21                                              # one of the smaller contigs
+    n = int(asm[c].numel())
+    rv, av, ka, km = ev.dump_values(seqs, c, 0, n)
+    valid = (rv > 0) | (av > 0)                         # asm k-mers were counted from this sequence: asmV >= 1 when valid
+    # readK / prob per distinct read count through the library's host getK (bit-identical to the device)
+    urv = np.unique(rv[valid])
+    rk_of = {int(v): m.getK(kp, int(v), 1)[0] for v in urv.tolist()}
+    pr_of = {int(v): m.getK(kp, int(v), 1)[2] for v in urv.tolist()}
+    readK = np.vectorize(rk_of.get, otypes=[np.float64])(rv[valid])
+    prob = np.vectorize(pr_of.get, otypes=[np.float64])(rv[valid])
+    asmK = av[valid].astype(np.float64)
+    missing = readK == 0
+    assert int(valid.sum()) == ka and int(missing.sum()) == km
+    rK, aK, pr = readK[~missing], asmK[~missing], prob[~missing]
+    under = aK > rK
+    with np.errstate(divide="ignore"):
+        iu = ((((aK[under] / rK[under]) - 1) + 0.1) / 0.2).astype(np.int64)
+        io = ((((rK[~under] / aK[~under]) - 1) + 0.1) / 0.2).astype(np.int64)
+    undr = np.bincount(iu, minlength=1)
+    over = np.bincount(io, minlength=1)
+    one = m.Sequences.from_device([asm[c].data_ptr()], [n])
+    res = ev.hist(one)
+    assert (res.kasm, res.kmissing) == (ka, km)
+    ru, ro = res.undr(), res.over()
+    np.testing.assert_array_equal(ru[:len(undr)], undr)
+    np.testing.assert_array_equal(ro[:len(over)], over)
+    assert ru[len(undr):].sum() == 0 and ro[len(over):].sum() == 0
+    kover = float(((1.0 - rK[under] / aK[under]) * pr[under]).sum())
+    assert res.koverCpy == pytest.approx(kover, rel=1e-9)
