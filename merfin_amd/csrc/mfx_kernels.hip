@@ -13,6 +13,8 @@
 #include "mfx_internal.h"
 #include "mfx_kernels.h"
 
+#include <stdlib.h>
+
 // ===========================================================================
 // joint k-mer table: 128-byte lines of 8 x {key, readV, asmV}
 // ===========================================================================
@@ -955,8 +957,10 @@ hipError_t mfx_k_table_export(mfx_table_view t, uint64_t *kmers, uint32_t *readV
   return hipGetLastError();
 }
 hipError_t mfx_k_hist(const mfx_hist_args &a, int grid, hipStream_t st) {
-  if (a.canonical) mfx_hist_kernel<true><<<grid, MFX_BLOCK, 0, st>>>(a);
-  else             mfx_hist_kernel<false><<<grid, MFX_BLOCK, 0, st>>>(a);
+  // MFX_DEBUG_DYN_LDS: extra dynamic LDS per block, an occupancy knob for experiments only
+  static const unsigned dyn = getenv("MFX_DEBUG_DYN_LDS") ? (unsigned)atoi(getenv("MFX_DEBUG_DYN_LDS")) : 0u;
+  if (a.canonical) mfx_hist_kernel<true><<<grid, MFX_BLOCK, dyn, st>>>(a);
+  else             mfx_hist_kernel<false><<<grid, MFX_BLOCK, dyn, st>>>(a);
   return hipGetLastError();
 }
 hipError_t mfx_k_route(const mfx_route_args &a, hipStream_t st) {
