@@ -10,6 +10,7 @@
 //   processDump hot loop                 merfin-dump.C:44-67
 //   computeCompleteness merge loop       merfin-completeness.C:70-117
 //   `meryl count` of the assembly        merfin-globals.C:182-186
+// plus the two kernels of the sharded index (no reference counterpart).
 #include "mfx_internal.h"
 #include "mfx_kernels.h"
 
@@ -44,8 +45,9 @@ __device__ __forceinline__ uint64_t mfx_revcomp(uint64_t fwd, int k) {
 //
 // Why the minimizer: consecutive k-mers of a sequence share their minimizer
 // for runs of ~(w+1)/2 positions, so their probes fall into the SAME 128-byte
-// line -- fewer than one HBM line fetch per k-mer.  w = 5 windows (m = k-4)
-// keeps a minimizer's bucket (~2 k-mers, size-biased) inside one line.
+// line -- fewer than one HBM line fetch per k-mer.  Default w = 2 windows
+// (m = k-1): a (k-1)-mer occurs in at most 8 k-mers, so a minimizer's bucket
+// always fits one line (no skew on repetitive genomes); w up to 5 is selectable.
 // ---------------------------------------------------------------------------
 constexpr uint32_t MFX_MZ_REGION = 4;
 constexpr uint32_t MFX_MAX_LINES = 512;
