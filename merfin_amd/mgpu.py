@@ -1,0 +1,168 @@
+"""Multi-GPU `merfin -hist`: one process per GPU, launched with torchrun.
+
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
+      -m merfin_amd.mgpu -sequence asm.fasta.gz -readmers reads.meryl [-seqmers asm.meryl] \\
+      -peak 26 [-prob lookup_table.txt] -output out.hist [-sharded]
+
+Every rank reads the inputs, builds the index on its own GPU and evaluates its
+share of the sequence tiles; the only collective is the all-reduce of the counts
+image (RCCL over xGMI with the default backend "nccl").  With -sharded each rank
+keeps only the k-mers it owns (read DBs larger than one GPU, BASELINE config 5)
+and the k-mers are exchanged with one all-to-all per chunk of tiles.  Rank 0
+writes the histogram and prints the summary, byte-identical to the single-GPU
+`merfin -hist` (merfin-histogram.C:140-176).  The reference's multi-process story
+is SLURM contig sharding + concatenation (scripts/parallel1/merfin.sh:68-85).
+
+MFX_MGPU_BACKEND=gloo MFX_MGPU_SHARE_GPU=1 rehearse the multi-rank flow on a
+single GPU (collectives through host memory; RCCL refuses two ranks per device).
+"""
+import argparse
+import gzip
+import os
+import sys
+
+import numpy as np
+
+
+def read_sequences(path):
+    """FASTA/FASTQ (plain or .gz): [(ident, bases)], ident = first header token (merfin.C:38, merfin-variants.C:141)"""
+    op = gzip.open if path.endswith(".gz") else open
+    names, seqs = [], []
+    with op(path, "rb") as f:
+        data = f.read()
+    if not data:
+        return names, seqs
+    if data[:1] == b">":
+        for rec in data.split(b"\n>"):
+            head, _, body = rec.partition(b"\n")
+            names.append(head.lstrip(b">").split()[0].decode() if head.strip(b">").strip() else "")
+            seqs.append(body.replace(b"\n", b"").replace(b"\r", b""))
+    else:                                                  # FASTQ, 4-line records
+        lines = data.split(b"\n")
+        for i in range(0, len(lines) - 1, 4):
+            if lines[i].startswith(b"@"):
+                names.append(lines[i][1:].split()[0].decode())
+                seqs.append(lines[i + 1].strip())
+    return names, seqs
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="merfin_amd.mgpu", add_help=True)
+    for flag in ("-sequence", "-readmers", "-seqmers", "-prob", "-output"):
+        ap.add_argument(flag)
+    ap.add_argument("-peak", type=float, default=0.0)
+    ap.add_argument("-min", type=int, default=0)
+    ap.add_argument("-max", type=int, default=2**64 - 1)
+    ap.add_argument("-sharded", action="store_true")
+    ap.add_argument("-chunk-tiles", type=int, default=16384)
+    a = ap.parse_args(argv)
+    if not (a.sequence and a.readmers and a.output and a.peak):
+        ap.error("-sequence, -readmers, -peak and -output are required")
+
+    import torch
+    import torch.distributed as dist
+    import merfin_amd as m
+    from merfin_amd import distributed as D
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = 0 if os.environ.get("MFX_MGPU_SHARE_GPU") else int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("MFX_MGPU_BACKEND", "nccl")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    log = (lambda *x: print(*x, file=sys.stderr, flush=True)) if rank == 0 else (lambda *x: None)
+
+    names, seqs = read_sequences(a.sequence)
+    rdb = m.db_probe(a.readmers)
+    k = rdb["k"]
+    n_asm = m.db_probe(a.seqmers)["n_kmers"] if a.seqmers else sum(len(s) for s in seqs)
+    cap = rdb["n_kmers"] + n_asm + 1024
+    if a.sharded and world > 1:
+        cap = int(cap / world * 1.15) + 1024               # owners are hash-balanced
+    ix = m.Index(k, cap, device=local)
+    if a.sharded and world > 1:
+        ix.set_shard(rank, world)
+    log("-- Loading kmers from '%s' into lookup table." % a.readmers)
+    ix.load_db(a.readmers, 0, a.min, a.max)
+    sq = m.Sequences(seqs, device=local, names=names)
+    if a.seqmers:
+        log("-- Loading kmers from '%s' into lookup table." % a.seqmers)
+        ix.load_db(a.seqmers, 1)
+    else:
+        ix.count_asm(sq)
+    kp = m.KParams.from_file(a.peak, a.prob) if a.prob else m.KParams(a.peak)
+    ev = m.Evaluator(ix, kp)
+    counts = torch.zeros(m.hist_words(ev.nbins, sq.ncontigs), dtype=torch.int64, device="cuda")
+    kover = torch.zeros(1, dtype=torch.float64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def host_exchange(keys, contigs_, send):               # gloo rehearsal only
+        sc = torch.tensor([int(x) for x in send], dtype=torch.int64)
+        rc = torch.empty(world, dtype=torch.int64)
+        dist.all_to_all_single(rc, sc)
+        rcl, scl = [int(x) for x in rc.tolist()], [int(x) for x in send]
+        n_in = sum(scl)
+        rk = torch.empty(sum(rcl), dtype=torch.int64)
+        rg = torch.empty(sum(rcl), dtype=torch.int32)
+        dist.all_to_all_single(rk, keys[:n_in].cpu(), output_split_sizes=rcl, input_split_sizes=scl)
+        dist.all_to_all_single(rg, contigs_[:n_in].cpu(), output_split_sizes=rcl, input_split_sizes=scl)
+        return rk.cuda(), rg.cuda()
+
+    def reduce_all():
+        if world == 1:
+            return
+        if backend == "nccl":
+            D.all_reduce_hist(counts, kover)
+        else:
+            c, kv = counts.cpu(), kover.cpu()
+            D.all_reduce_hist(c, kv)
+            counts.copy_(c)
+            kover.copy_(kv)
+
+    log("-- Generate histogram of the k* metric to '%s' on %d GPU(s)%s." % (a.output, world, " (sharded index)" if a.sharded else ""))
+    if a.sharded and world > 1:
+        router = m.Router(ix, world, min(a.chunk_tiles, max(1, sq.ntiles)))
+        if backend == "nccl":
+            D.sharded_hist(ev, router, sq, rank, world, counts, kover, stream=stream)
+        else:
+            T = sq.ntiles
+            lo, hi = D.shard(T, rank, world)
+            per = router.max_tiles
+            keys = torch.empty(per * m.TILE, dtype=torch.int64, device="cuda")
+            ctg = torch.empty(per * m.TILE, dtype=torch.int32, device="cuda")
+            for r in range((-(-T // world) + per - 1) // per):
+                tb = min(hi, lo + r * per)
+                te = min(hi, tb + per)
+                send = router.route(sq, tb, te, ev.nbins, counts, keys, ctg, stream=stream)
+                rk, rg = host_exchange(keys, ctg, send)
+                if rk.numel():
+                    ev.hist_keys_launch(rk, rg, rk.numel(), sq.ncontigs, counts, kover, stream=stream)
+                torch.cuda.synchronize()
+            reduce_all()
+    else:
+        lo, hi = D.shard(sq.ntiles, rank, world)
+        ev.hist_launch(sq, lo, hi, counts, kover, stream=stream)
+        torch.cuda.synchronize()
+        reduce_all()
+    torch.cuda.synchronize()
+
+    if rank == 0:
+        res = m.result_from_counts(ev.nbins, counts.cpu().numpy().view(np.uint64), float(kover.item()), sq.ncontigs)
+        cum = 0
+        for c, nm in enumerate(names):                     # outputHistogram's per-sequence line, input order
+            cum += int(res.contig_kmissing()[c])
+            print("%s\t%d\t%d\t%d\t%.2f" % (nm, res.contig_kmissing()[c], cum, res.contig_kasm()[c],
+                                            m.histoQV(float(res.contig_kmissing()[c]), float(res.contig_kasm()[c]), k)), file=sys.stderr)
+        res.report(k, a.output, "-")
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,33 @@
+"""merfin_amd.mgpu (torchrun launcher of the multi-GPU -hist) rehearsed with two
+ranks on the single GPU of the test box: gloo collectives through host memory,
+both ranks on device 0.  Replicated and sharded index; output must equal the
+golden -hist fixture and the single-process CLI."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sharded", [False, True])
+@pytest.mark.parametrize("with_seqmers", [True, False])
+def test_two_rank_launcher_matches_golden(tmp_path, sharded, with_seqmers):
+    out = str(tmp_path / "out.hist")
+    env = dict(os.environ, MFX_MGPU_BACKEND="gloo", MFX_MGPU_SHARE_GPU="1")
+    port = 29800 + (os.getpid() + 7 * sharded + 3 * with_seqmers) % 1000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", "merfin_amd.mgpu", "-sequence", G + "/case1.fasta", "-readmers", G + "/case1.read.kmers.txt",
+           "-peak", "17.3", "-prob", G + "/example_lookup_table.txt", "-output", out, "-chunk-tiles", "2"]
+    if with_seqmers:
+        cmd += ["-seqmers", G + "/case1.asm.kmers.txt"]
+    if sharded:
+        cmd += ["-sharded"]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert open(out, "rb").read() == open(G + "/case1.hist", "rb").read()
+    assert open(G + "/case1.summary").read() in r.stderr
+    assert "ctg0\t" in r.stderr
