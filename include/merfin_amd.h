@@ -281,6 +281,9 @@ int mfx_variants_run(mfx_eval *ev, const char *vcf_path, const char *const *name
 /* as one streaming pass over the joint table.                              */
 /* ------------------------------------------------------------------------ */
 int mfx_completeness(mfx_eval *ev, double *total, double *undrcpy);
+/* the 64 per-piece sums the reference prints (piece = top 6 bits of the k-mer = meryl file number,
+ * merfin-completeness.C:56-66,119-120); arrays of 64 doubles each */
+int mfx_completeness_pieces(mfx_eval *ev, double *total64, double *undrcpy64);
 
 #ifdef __cplusplus
 }

@@ -65,7 +65,7 @@ SYMBOLS = [
     "mfx_eval_create", "mfx_eval_free", "mfx_eval_nbins", "mfx_getK", "mfx_getKmetric", "mfx_histoQV",
     "mfx_hist_run", "mfx_hist_result_free", "mfx_hist_launch", "mfx_hist_result_from_counts",
     "mfx_hist_take_overflow", "mfx_hist_report",
-    "mfx_dump_values", "mfx_dump_contig", "mfx_completeness", "mfx_variants_run",
+    "mfx_dump_values", "mfx_dump_contig", "mfx_completeness", "mfx_completeness_pieces", "mfx_variants_run",
     "mfx_index_set_shard", "mfx_router_create", "mfx_router_free", "mfx_route_tiles", "mfx_hist_keys_launch",
 ]
 
@@ -147,6 +147,7 @@ def load_library():
     L.mfx_dump_values.argtypes = [vp, vp, C.c_uint32, C.c_uint64, C.c_uint64, u32p, u32p, u64p, u64p]
     L.mfx_dump_contig.argtypes = [vp, vp, C.c_uint32, C.c_char_p, C.c_char_p, C.c_int, u64p, u64p]
     L.mfx_completeness.argtypes = [vp, f64p, f64p]
+    L.mfx_completeness_pieces.argtypes = [vp, f64p, f64p]
     L.mfx_index_set_shard.argtypes = [vp, C.c_uint32, C.c_uint32]
     L.mfx_router_create.restype = vp
     L.mfx_router_create.argtypes = [vp, C.c_uint32, C.c_uint32]
@@ -489,6 +490,12 @@ class Evaluator:
         _check(load_library().mfx_variants_run(self.h, vcf_path.encode(), nm, arr, lens.ctypes.data_as(C.POINTER(C.c_uint64)), n,
                                                C.byref(o), out_path.encode(), log_path.encode() if log_path else None, C.byref(ncl)))
         return ncl.value
+
+    def completeness_pieces(self):
+        t = np.zeros(64)
+        u = np.zeros(64)
+        _check(load_library().mfx_completeness_pieces(self.h, t.ctypes.data_as(C.POINTER(C.c_double)), u.ctypes.data_as(C.POINTER(C.c_double))))
+        return t, u
 
     def completeness(self):
         t, u = C.c_double(), C.c_double()

@@ -264,8 +264,13 @@ int main(int argc, char **argv) {
       DIE_MFX("variant scoring");
   } else if (G.reportType == OP_COMPL) {
     fprintf(stderr, "-- Compute completeness.\n");
-    double total = 0, undrc = 0;
-    if (mfx_completeness(ev, &total, &undrc)) DIE_MFX("-completeness");
+    double t64[64], u64[64], total = 0, undrc = 0;
+    if (mfx_completeness_pieces(ev, t64, u64)) DIE_MFX("-completeness");
+    for (int ii = 0; ii < 64; ii++) {                     // merfin-completeness.C:119-120, here in piece order
+      fprintf(stderr, "thread %2u total %12.2f underc %15.5f completeness %0.8f\n", ii, t64[ii], u64[ii], 1.0 - u64[ii] / t64[ii]);
+      total += t64[ii];
+      undrc += u64[ii];
+    }
     fprintf(stderr, "\n");
     fprintf(stderr, "TOTAL readK:   %15.2f\n", total);
     fprintf(stderr, "TOTAL undrcpy:    %15.5f\n", undrc);

@@ -1040,14 +1040,27 @@ extern "C" int mfx_dump_contig(mfx_eval *ev, const mfx_seq *seq, uint32_t contig
 // ---------------------------------------------------------------------------
 // -completeness
 // ---------------------------------------------------------------------------
+extern "C" int mfx_completeness_pieces(mfx_eval *ev, double *total64, double *undrcpy64) {
+  if (!ev || !total64 || !undrcpy64) return mfx_fail(MFX_E_INVAL, "mfx_completeness_pieces: null argument");
+  DevGuard g(ev->device);
+  DevBuf<double> dp;
+  MFX_HIP(dp.alloc(128));
+  MFX_HIP(hipMemset(dp.p, 0, 128 * sizeof(double)));
+  MFX_HIP(mfx_k_completeness(ev->ix->view(), ev->peak, ev->n_prob, ev->d_probK, ev->d_probP, dp.p, ev->grid, nullptr));
+  double h[128];
+  MFX_HIP(hipMemcpy(h, dp.p, sizeof(h), hipMemcpyDeviceToHost));
+  memcpy(total64, h, 64 * sizeof(double));
+  memcpy(undrcpy64, h + 64, 64 * sizeof(double));
+  return MFX_OK;
+}
+
 extern "C" int mfx_completeness(mfx_eval *ev, double *total, double *undrcpy) {
   if (!ev || !total || !undrcpy) return mfx_fail(MFX_E_INVAL, "mfx_completeness: null argument");
-  DevGuard g(ev->device);
-  MFX_HIP(mfx_k_completeness(ev->ix->view(), ev->peak, ev->n_prob, ev->d_probK, ev->d_probP, ev->d_partials, ev->grid, nullptr));
-  std::vector<double> h(2 * (size_t)ev->grid);
-  MFX_HIP(hipMemcpy(h.data(), ev->d_partials, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+  double t64[64], u64[64];
+  int rc = mfx_completeness_pieces(ev, t64, u64);
+  if (rc) return rc;
   double t = 0, u = 0;
-  for (int b = 0; b < ev->grid; ++b) { t += h[2 * b]; u += h[2 * b + 1]; }
+  for (int i = 0; i < 64; ++i) { t += t64[i]; u += u64[i]; }     // merfin-completeness.C:135-138
   *total = t;
   *undrcpy = u;
   return MFX_OK;

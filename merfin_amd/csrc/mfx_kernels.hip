@@ -905,29 +905,33 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_count_kernel(mfx_count_args a) 
 // ===========================================================================
 __global__ __launch_bounds__(MFX_BLOCK) void mfx_completeness_kernel(mfx_table_view t, double peak, uint32_t n_prob,
                                                                      const uint32_t *probK, const double *probP,
-                                                                     double *partials /* [2*grid] */) {
-  __shared__ double s0[MFX_BLOCK], s1[MFX_BLOCK];
-  uint64_t nslots = t.nlines * MFX_SLOTS_LINE;
+                                                                     double *pieces /* [128]: total[64], undrc[64] */) {
+  // The reference merges the 64 file pieces of the two databases separately
+  // (piece = top 6 bits of the 2k-bit k-mer, merfin-completeness.C:56-66) and prints one
+  // line per piece; readK values are integers, so the fp64 sums are exact in any order.
+  __shared__ double s_tot[64], s_und[64];
+  if (threadIdx.x < 64) { s_tot[threadIdx.x] = 0.0; s_und[threadIdx.x] = 0.0; }
+  __syncthreads();
+  const uint64_t nslots = t.nlines * MFX_SLOTS_LINE;
+  const int pshift = 2 * t.k >= 6 ? 2 * t.k - 6 : 0;
   uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  double total = 0.0, undrc = 0.0;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (; i < nslots; i += stride) {
     uint4 s = reinterpret_cast<const uint4 *>(t.slots)[i];
     uint64_t key = (uint64_t)s.x | ((uint64_t)s.y << 32);
-    if (key == MFX_EMPTY || s.z == 0) continue;
+    if (key == MFX_EMPTY || s.z == 0) continue;          // empty slot / asm-only k-mer (:106-109)
     double readK, prob;
     mfx_getK_core(peak, n_prob, probK, probP, s.z, readK, prob);
-    double asmK = (double)s.w;
-    total = total + readK;                             // :113
-    if (readK > asmK) undrc = undrc + (readK - asmK);  // :115-116
+    const double asmK = (double)s.w;
+    const uint32_t piece = (uint32_t)(key >> pshift) & 63u;
+    atomicAdd(&s_tot[piece], readK);                     // :113
+    if (readK > asmK) atomicAdd(&s_und[piece], readK - asmK);   // :115-116
   }
-  s0[threadIdx.x] = total; s1[threadIdx.x] = undrc;
   __syncthreads();
-  for (uint32_t st = MFX_BLOCK / 2; st > 0; st >>= 1) {
-    if (threadIdx.x < st) { s0[threadIdx.x] += s0[threadIdx.x + st]; s1[threadIdx.x] += s1[threadIdx.x + st]; }
-    __syncthreads();
+  if (threadIdx.x < 64) {
+    if (s_tot[threadIdx.x] != 0.0) atomicAdd(&pieces[threadIdx.x], s_tot[threadIdx.x]);
+    if (s_und[threadIdx.x] != 0.0) atomicAdd(&pieces[64 + threadIdx.x], s_und[threadIdx.x]);
   }
-  if (threadIdx.x == 0) { partials[2 * blockIdx.x] = s0[0]; partials[2 * blockIdx.x + 1] = s1[0]; }
 }
 
 // ===========================================================================

@@ -116,6 +116,7 @@ def test_cli_hist_dump_completeness_end_to_end(tmp_path, golden_dir):
     assert "TOTAL readK:   %15.2f\n" % tot in r5.stderr
     assert "TOTAL undrcpy:    %15.5f\n" % und in r5.stderr
     assert "COMPLETENESS:             %0.5f\n" % (1.0 - und / tot) in r5.stderr
+    assert r5.stderr.count("thread ") == 64 and "thread  0 total " in r5.stderr        # merfin-completeness.C:119-120
 
     # -memory gate (merfin-globals.C:148-153)
     r6 = run(["-hist", "-sequence", fa, "-readmers", str(tmp_path / "read.mfxk"), "-peak", "26", "-memory", "0.0001",

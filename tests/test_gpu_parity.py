@@ -259,8 +259,14 @@ def test_completeness_matches_merge_loop():
         tot += t
         und += u
     ix = build_index(m, k, read, asm)
-    t, u = m.Evaluator(ix, m.KParams(peak)).completeness()
+    ev = m.Evaluator(ix, m.KParams(peak))
+    t, u = ev.completeness()
     assert (t, u) == (tot, und) and tot > 0 and und > 0
+    t64, u64 = ev.completeness_pieces()
+    for piece in range(64):
+        lo, hi = piece << (2 * k - 6), (piece + 1) << (2 * k - 6)
+        rs, as_ = (read[0] >= lo) & (read[0] < hi), (asm[0] >= lo) & (asm[0] < hi)
+        assert (t64[piece], u64[piece]) == po.completeness_piece(p, read[0][rs], read[1][rs], asm[0][as_], asm[1][as_])
 
 
 def test_large_bins_overflow_path():
