@@ -94,6 +94,11 @@ int mfx_db_probe(const char *path, mfx_db_info *out);
 int mfx_index_load_db(mfx_index *ix, const char *path, int side, uint64_t minV, uint64_t maxV);
 int mfx_db_write_flat(const char *path, int k, const uint64_t *kmers, const uint32_t *values, uint64_t n);
 
+/* The built table as a device-format image on disk: later runs on the same databases skip the decode +
+ * insert (no reference counterpart; merfin rebuilds its lookup tables on every start, merfin.C:361). */
+int        mfx_index_save(const mfx_index *ix, const char *path);
+mfx_index *mfx_index_load(const char *path, double max_gb, int device);
+
 typedef struct mfx_seq mfx_seq;
 
 /* Native replacement of the `meryl count k=.. <seq> output <seq>.meryl` child

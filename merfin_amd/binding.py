@@ -59,7 +59,7 @@ SYMBOLS = [
     "mfx_last_error", "mfx_last_error_code", "mfx_version", "mfx_device_count",
     "mfx_index_create", "mfx_index_free", "mfx_index_estimate_gb", "mfx_index_add_read", "mfx_index_add_asm",
     "mfx_index_count_asm", "mfx_index_value", "mfx_index_get_info", "mfx_index_export",
-    "mfx_db_probe", "mfx_index_load_db", "mfx_db_write_flat",
+    "mfx_db_probe", "mfx_index_load_db", "mfx_db_write_flat", "mfx_index_save", "mfx_index_load",
     "mfx_seq_upload", "mfx_seq_from_device", "mfx_seq_free", "mfx_seq_num_contigs", "mfx_seq_num_bases",
     "mfx_seq_num_tiles",
     "mfx_eval_create", "mfx_eval_free", "mfx_eval_nbins", "mfx_getK", "mfx_getKmetric", "mfx_histoQV",
@@ -117,6 +117,9 @@ def load_library():
     L.mfx_db_probe.argtypes = [C.c_char_p, C.POINTER(_DbInfo)]
     L.mfx_index_load_db.argtypes = [vp, C.c_char_p, C.c_int, C.c_uint64, C.c_uint64]
     L.mfx_db_write_flat.argtypes = [C.c_char_p, C.c_int, u64p, u32p, C.c_uint64]
+    L.mfx_index_save.argtypes = [vp, C.c_char_p]
+    L.mfx_index_load.restype = vp
+    L.mfx_index_load.argtypes = [C.c_char_p, C.c_double, C.c_int]
     L.mfx_seq_upload.restype = vp
     L.mfx_seq_upload.argtypes = [C.c_int, C.POINTER(C.c_char_p), u64p, C.c_uint32]
     L.mfx_seq_from_device.restype = vp
@@ -244,11 +247,22 @@ def _ptr(x):
 class Index:
     """Joint read+assembly k-mer count table resident in HBM."""
 
-    def __init__(self, k, capacity_kmers, max_gb=0.0, device=0):
+    def __init__(self, k, capacity_kmers, max_gb=0.0, device=0, _handle=None):
         L = load_library()
         self.k = k
         self.device = device
-        self.h = _need(L.mfx_index_create(k, int(capacity_kmers), float(max_gb), device))
+        self.h = _handle if _handle is not None else _need(L.mfx_index_create(k, int(capacity_kmers), float(max_gb), device))
+
+    def save(self, path):
+        """write the built table as a device-format image"""
+        _check(load_library().mfx_index_save(self.h, path.encode()))
+
+    @staticmethod
+    def load(path, max_gb=0.0, device=0):
+        h = _need(load_library().mfx_index_load(path.encode(), float(max_gb), device))
+        ix = Index(0, 0, device=device, _handle=h)
+        ix.k = ix.info()["k"]
+        return ix
 
     def add_read(self, kmers, values, minV=0, maxV=2**64 - 1):
         if isinstance(kmers, np.ndarray):

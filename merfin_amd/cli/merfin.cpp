@@ -21,7 +21,7 @@ enum { OP_NONE, OP_HIST, OP_COMPL, OP_DUMP, OP_FILTER, OP_POLISH, OP_BETTER, OP_
 
 struct Globals {
   const char *seqName = nullptr, *seqDBname = nullptr, *readDBname = nullptr, *pLookupTable = nullptr;
-  const char *vcfName = nullptr, *outName = nullptr;
+  const char *vcfName = nullptr, *outName = nullptr, *indexName = nullptr;
   double peak = 0, maxMemory = 0;
   uint64_t minV = 0, maxV = ~0ull;
   int threads = 0, reportType = OP_NONE, device = 0;
@@ -44,7 +44,9 @@ static void usage(const char *exe) {
           "    -peak m           haploid k-mer coverage peak (required except -filter)\n"
           "    -prob file        readK,prob rows; row n overrides -peak for multiplicity n\n"
           "    -seqmers db       assembly k-mer database; default: counted from -sequence on the GPU\n"
-          "    -device d         HIP device (default 0)\n\n"
+          "    -device d         HIP device (default 0)\n"
+          "    -index file       cache of the built HBM index: loaded if it exists (the k-mer databases are then not\n"
+          "                      read), otherwise written after the build\n\n"
           "  Report types (exactly one):\n"
           "    -hist           0-centred K* histogram to <output>; QV and QV* on stderr\n"
           "    -dump           seqName, seqPos, readK, asmK, K* per k-mer to <output>  [-skipMissing]\n"
@@ -117,6 +119,7 @@ int main(int argc, char **argv) {
     else if (is("-threads")) G.threads = atoi(val());
     else if (is("-memory")) G.maxMemory = strtod(val(), nullptr);
     else if (is("-device")) G.device = atoi(val());
+    else if (is("-index")) G.indexName = val();
     else if (is("-nosplit")) G.nosplit = true;
     else if (is("-filter")) G.reportType = OP_FILTER;
     else if (is("-better")) G.reportType = OP_BETTER;
@@ -181,29 +184,44 @@ int main(int argc, char **argv) {
   uint64_t totalBases = 0;
   for (size_t i = 0; i < recs.size(); ++i) { bases[i] = recs[i].bases.data(); lens[i] = recs[i].bases.size(); totalBases += lens[i]; }
 
-  const uint64_t capacity = rdb.n_kmers + (G.seqDBname ? adb.n_kmers : totalBases) + 1024;
-  fprintf(stderr, "--\n-- Memory needed: %.3f GB\n-- Memory limit:  %.3f GB%s\n--\n", mfx_index_estimate_gb(k, capacity),
-          G.maxMemory, G.maxMemory > 0 ? "" : " (none)");
-  mfx_index *ix = mfx_index_create(k, capacity, G.maxMemory, G.device);
-  if (!ix) {
-    fprintf(stderr, "\n%s\n\n", mfx_last_error());
-    return 1;
-  }
-  fprintf(stderr, "-- Loading kmers from '%s' into lookup table.\n", G.readDBname);
-  if (mfx_index_load_db(ix, G.readDBname, 0, G.minV, G.maxV)) DIE_MFX("loading -readmers");
-
+  mfx_index *ix = nullptr;
   mfx_seq *seq = nullptr;
   if (!recs.empty() || G.seqName) {
     seq = mfx_seq_upload(G.device, bases.data(), lens.data(), (uint32_t)recs.size());
     if (!seq) DIE_MFX("uploading sequences");
   }
-  if (G.seqDBname) {
-    fprintf(stderr, "-- Loading kmers from '%s' into lookup table.\n", G.seqDBname);
-    if (mfx_index_load_db(ix, G.seqDBname, 1, 0, ~0ull)) DIE_MFX("loading -seqmers");
+  FILE *probe = G.indexName ? fopen(G.indexName, "rb") : nullptr;
+  if (probe) {
+    fclose(probe);
+    fprintf(stderr, "-- Loading the index image '%s' (k-mer databases are not read).\n", G.indexName);
+    ix = mfx_index_load(G.indexName, G.maxMemory, G.device);
+    if (!ix) { fprintf(stderr, "\n%s\n\n", mfx_last_error()); return 1; }
+    mfx_index_info info;
+    if (mfx_index_get_info(ix, &info)) DIE_MFX("reading the index image");
+    if (info.k != k) { fprintf(stderr, "ERROR: the index image holds %d-mers but -readmers holds %d-mers.\n", info.k, k); return 1; }
   } else {
-    // replaces `meryl count k=.. <seq> output <seq>.meryl` (merfin-globals.C:182-186)
-    fprintf(stderr, "-- No -seqmer given. Counting the %d-mers of '%s' on the GPU.\n", k, G.seqName);
-    if (mfx_index_count_asm(ix, seq, nullptr)) DIE_MFX("counting sequence k-mers");
+    const uint64_t capacity = rdb.n_kmers + (G.seqDBname ? adb.n_kmers : totalBases) + 1024;
+    fprintf(stderr, "--\n-- Memory needed: %.3f GB\n-- Memory limit:  %.3f GB%s\n--\n", mfx_index_estimate_gb(k, capacity),
+            G.maxMemory, G.maxMemory > 0 ? "" : " (none)");
+    ix = mfx_index_create(k, capacity, G.maxMemory, G.device);
+    if (!ix) {
+      fprintf(stderr, "\n%s\n\n", mfx_last_error());
+      return 1;
+    }
+    fprintf(stderr, "-- Loading kmers from '%s' into lookup table.\n", G.readDBname);
+    if (mfx_index_load_db(ix, G.readDBname, 0, G.minV, G.maxV)) DIE_MFX("loading -readmers");
+    if (G.seqDBname) {
+      fprintf(stderr, "-- Loading kmers from '%s' into lookup table.\n", G.seqDBname);
+      if (mfx_index_load_db(ix, G.seqDBname, 1, 0, ~0ull)) DIE_MFX("loading -seqmers");
+    } else {
+      // replaces `meryl count k=.. <seq> output <seq>.meryl` (merfin-globals.C:182-186)
+      fprintf(stderr, "-- No -seqmer given. Counting the %d-mers of '%s' on the GPU.\n", k, G.seqName);
+      if (mfx_index_count_asm(ix, seq, nullptr)) DIE_MFX("counting sequence k-mers");
+    }
+    if (G.indexName) {
+      fprintf(stderr, "-- Writing the index image '%s'.\n", G.indexName);
+      if (mfx_index_save(ix, G.indexName)) DIE_MFX("writing the index image");
+    }
   }
 
   mfx_kparams kp{G.peak, (uint32_t)G.copyKmerK.size(), G.copyKmerK.data(), G.copyKmerP.data()};

@@ -413,3 +413,95 @@ extern "C" int mfx_db_write_flat(const char *path, int k, const uint64_t *kmers,
   fclose(f);
   return ok ? MFX_OK : mfx_fail(MFX_E_IO, "short write to '%s'", path);
 }
+
+// ---------------------------------------------------------------------------
+// Device-format index image: the built table written to / read from disk as is,
+// so that repeated runs (-hist, then -dump, then -polish on the same databases)
+// skip the decode + insert of the k-mer databases.  Layout: IndexImageHeader,
+// then the table lines (128 bytes each) in order.
+// ---------------------------------------------------------------------------
+struct IndexImageHeader {
+  char     magic[8];         // "MFXINDX1"
+  uint32_t k, mz_w;
+  uint32_t shard_rank, shard_n;
+  uint64_t nlines, capacity_kmers;
+  uint64_t minV, maxV;
+  uint64_t meta[4];          // distinct, non-canonical inserts, probe failures, reserved
+  uint32_t slot_bytes, line_slots;
+  uint32_t filter_set, reserved;
+};
+
+extern "C" int mfx_index_save(const mfx_index *ix, const char *path) {
+  if (!ix || !path) return mfx_fail(MFX_E_INVAL, "mfx_index_save: null argument");
+  if (hipSetDevice(ix->device) != hipSuccess) return mfx_fail(MFX_E_HIP, "hipSetDevice(%d) failed", ix->device);
+  FILE *f = fopen(path, "wb");
+  if (!f) return mfx_fail(MFX_E_IO, "cannot open '%s' for writing", path);
+  IndexImageHeader h;
+  memset(&h, 0, sizeof(h));
+  memcpy(h.magic, "MFXINDX1", 8);
+  h.k = (uint32_t)ix->k; h.mz_w = (uint32_t)ix->mz_w;
+  h.shard_rank = ix->shard_rank; h.shard_n = ix->shard_n;
+  h.nlines = ix->nlines; h.capacity_kmers = ix->capacity_kmers;
+  h.minV = ix->minV; h.maxV = ix->maxV;
+  h.slot_bytes = (uint32_t)sizeof(mfx_slot); h.line_slots = MFX_SLOTS_LINE;
+  h.filter_set = ix->filter_set ? 1u : 0u;
+  int rc = MFX_OK;
+  if (hipMemcpy(h.meta, ix->d_meta, sizeof(h.meta), hipMemcpyDeviceToHost) != hipSuccess) rc = mfx_fail(MFX_E_HIP, "reading index metadata failed");
+  if (rc == MFX_OK && fwrite(&h, sizeof(h), 1, f) != 1) rc = mfx_fail(MFX_E_IO, "short write to '%s'", path);
+  const size_t CH = 256ull << 20;
+  std::vector<char> buf(rc == MFX_OK ? CH : 1);
+  const uint64_t total = ix->nlines * MFX_ALIGN;
+  for (uint64_t o = 0; o < total && rc == MFX_OK; o += CH) {
+    size_t m = (size_t)std::min<uint64_t>(CH, total - o);
+    if (hipMemcpy(buf.data(), (const char *)ix->d_slots + o, m, hipMemcpyDeviceToHost) != hipSuccess) rc = mfx_fail(MFX_E_HIP, "D2H copy of the table failed");
+    else if (fwrite(buf.data(), 1, m, f) != m) rc = mfx_fail(MFX_E_IO, "short write to '%s'", path);
+  }
+  fclose(f);
+  return rc;
+}
+
+extern "C" mfx_index *mfx_index_load(const char *path, double max_gb, int device) {
+  if (!path) { mfx_fail(MFX_E_INVAL, "mfx_index_load: null argument"); return nullptr; }
+  FILE *f = fopen(path, "rb");
+  if (!f) { mfx_fail(MFX_E_IO, "cannot open '%s'", path); return nullptr; }
+  IndexImageHeader h;
+  if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "MFXINDX1", 8) != 0 || h.slot_bytes != sizeof(mfx_slot) ||
+      h.line_slots != MFX_SLOTS_LINE || h.k < 1 || h.k > 31 || h.nlines == 0) {
+    fclose(f);
+    mfx_fail(MFX_E_FORMAT, "'%s' is not an index image of this build", path);
+    return nullptr;
+  }
+  // create an index of exactly the saved geometry, then overwrite its lines
+  mfx_index *ix = mfx_index_create((int)h.k, 1, 0.0, device);
+  if (!ix) { fclose(f); return nullptr; }
+  if (max_gb > 0 && (double)h.nlines * MFX_ALIGN / 1e9 > max_gb) {
+    mfx_fail(MFX_E_NOMEM, "Not enough memory to load databases.  Increase -memory. (need %.3f GB, limit %.3f GB)", (double)h.nlines * MFX_ALIGN / 1e9, max_gb);
+    mfx_index_free(ix); fclose(f);
+    return nullptr;
+  }
+  (void)hipSetDevice(device);
+  (void)hipFree(ix->d_slots);
+  ix->d_slots = nullptr;
+  ix->nlines = h.nlines;
+  ix->capacity_kmers = h.capacity_kmers;
+  ix->mz_w = (int)h.mz_w;
+  ix->shard_rank = h.shard_rank; ix->shard_n = h.shard_n ? h.shard_n : 1;
+  ix->minV = h.minV; ix->maxV = h.maxV; ix->filter_set = h.filter_set != 0;
+  bool ok = hipMalloc((void **)&ix->d_slots, h.nlines * MFX_ALIGN) == hipSuccess &&
+            hipMemcpy(ix->d_meta, h.meta, sizeof(h.meta), hipMemcpyHostToDevice) == hipSuccess;
+  const size_t CH = 256ull << 20;
+  std::vector<char> buf(ok ? CH : 1);
+  const uint64_t total = h.nlines * MFX_ALIGN;
+  for (uint64_t o = 0; o < total && ok; o += CH) {
+    size_t m = (size_t)std::min<uint64_t>(CH, total - o);
+    ok = fread(buf.data(), 1, m, f) == m && hipMemcpy((char *)ix->d_slots + o, buf.data(), m, hipMemcpyHostToDevice) == hipSuccess;
+  }
+  fclose(f);
+  if (!ok) {
+    mfx_fail(MFX_E_IO, "'%s': truncated image or device copy failed", path);
+    mfx_index_free(ix);
+    return nullptr;
+  }
+  ix->version++;
+  return ix;
+}

@@ -75,6 +75,13 @@ def test_cli_reproduces_golden(tmp_path):
                         "-prob", G + "/example_lookup_table.txt", "-output", str(tmp_path / "h2")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert (tmp_path / "h2").read_bytes() == open(G + "/case1.hist", "rb").read()
+    # -index: first run writes the image, second run loads it and skips the k-mer databases
+    img = str(tmp_path / "case1.mfxi")
+    for attempt in (0, 1):
+        r = subprocess.run([EXE, "-hist"] + common + ["-index", img, "-output", str(tmp_path / ("hi%d" % attempt))], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert (tmp_path / ("hi%d" % attempt)).read_bytes() == open(G + "/case1.hist", "rb").read()
+        assert ("Writing the index image" in r.stderr) == (attempt == 0) and ("Loading the index image" in r.stderr) == (attempt == 1)
     r = subprocess.run([EXE, "-dump"] + common + ["-output", str(tmp_path / "d")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert (tmp_path / "d").read_bytes() == open(G + "/case1.dump", "rb").read()

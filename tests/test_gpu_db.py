@@ -52,3 +52,31 @@ def test_db_errors_are_reported(tmp_path):
     with pytest.raises(m.MfxError) as e:
         ix.load_db(str(tmp_path / "k9.mfxk"), 0)
     assert e.value.code == -1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["mz", "plain"])
+def test_index_image_round_trip(tmp_path, mode, monkeypatch):
+    """save -> load of the device-format index: identical contents and identical -hist."""
+    import merfin_amd as m
+    from tests.test_gpu_parity import assert_hist_equal, oracle_hist
+    monkeypatch.setenv("MFX_HOME_MODE", mode)
+    k, peak = 21, 17.3
+    contigs, read, asm = synth.world(k=k, peak=peak, seed=91)
+    ix = m.Index(k, len(read[0]) + len(asm[0]) + 16)
+    ix.add_read(read[0], read[1], 2, 500)
+    ix.add_asm(*asm)
+    img = str(tmp_path / "index.mfxi")
+    ix.save(img)
+    monkeypatch.setenv("MFX_HOME_MODE", "plain" if mode == "mz" else "mz")      # the image carries its own placement
+    ix2 = m.Index.load(img)
+    assert ix2.info() == ix.info()
+    for a, b in zip(ix.export(), ix2.export()):
+        np.testing.assert_array_equal(a, b)
+    p, g, ka, km = oracle_hist(k, peak, contigs, read, asm, minV=2, maxV=500)
+    res = m.Evaluator(ix2, m.KParams(peak)).hist(m.Sequences(contigs))
+    assert_hist_equal(res, g, ka, km, k)
+    (tmp_path / "bad").write_bytes(b"not an image" * 10)
+    with pytest.raises(m.MfxError) as e:
+        m.Index.load(str(tmp_path / "bad"))
+    assert e.value.code == -7
