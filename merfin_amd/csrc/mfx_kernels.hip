@@ -244,11 +244,12 @@ __global__ void mfx_table_export_kernel(mfx_table_view t, uint64_t *kmers, uint3
 // access into it (measured: profiles/r01_ubench_gather.txt), so a query should
 // look at the WHOLE line at once.  Each 8-lane group of the wave fetches the 8
 // slots of one query's home line with one coalesced 128-byte access (lane
-// `sub` reads slot `sub`), the match is found with a ballot, and the values go
-// back to the owning lane through the LDS crossbar.  Per wave-instruction 8
-// lines are requested; S=8 owners per group are served per round, so 64 lines
-// are in flight per wave.  The rare queries whose home line is full without a
-// match (overflow into the following lines) finish per lane afterwards.
+// `sub` reads slot `sub`) and the lane holding the matching slot hands the counts
+// to the owning lane through an LDS mailbox.  Per wave-instruction 8 lines are
+// requested; 8 owners per group are served per round, so 64 lines are in flight
+// per wave.  Queries whose home line is full without a match continue on their
+// next candidate line in a second, compacted cooperative pass; the few left after
+// that finish per lane.
 // ---------------------------------------------------------------------------
 template <int S>
 __device__ __forceinline__ uint32_t mfx_group_bcast(uint32_t v) {
@@ -257,14 +258,14 @@ __device__ __forceinline__ uint32_t mfx_group_bcast(uint32_t v) {
 }
 
 // Result hand-off goes through a per-wave LDS mailbox (one 16-byte record per
-// lane/owner): the lane that holds the matching slot writes {key_hi, readV,
-// asmV} straight into the owner's record, a lane that sees an empty slot raises
+// lane/owner): the lane that holds the matching slot writes {readV, asmV,
+// found} straight into the owner's record, a lane that sees an empty slot raises
 // the owner's "line has room" flag.  LDS requests of one wave are served in
 // order, so the owner's later read needs no barrier.  This replaces three
 // cross-lane permutes + ballot decoding per served query with one predicated
 // store.
 struct mfx_mailbox {
-  uint4 rec[MFX_BLOCK];      // x = key_hi of the matching slot (0xffffffff: none), y = readV, z = asmV, w = empty seen
+  uint4 rec[MFX_BLOCK];      // x = readV, y = asmV, z = found, w = the line has an empty slot
 };
 
 // Issue phase of a round, in two steps so that nothing serialises: first ALL the
@@ -273,9 +274,11 @@ struct mfx_mailbox {
 // outcome its lane ignores (ok[j] is false) -- so the hot sequence has no
 // exec-mask branches and no dead-owner bookkeeping.
 template <int S>
-__device__ __forceinline__ void mfx_group_announce(uint32_t (&ls)[8], uint32_t (&klo)[8], uint32_t line, uint32_t key_lo) {
+__device__ __forceinline__ void mfx_group_announce(uint32_t (&ls)[8], uint32_t (&klo)[8], uint32_t (&khi)[8], uint32_t line,
+                                                   uint32_t key_lo, uint32_t key_hi) {
   ls[S] = mfx_group_bcast<S>(line);
   klo[S] = mfx_group_bcast<S>(key_lo);
+  khi[S] = mfx_group_bcast<S>(key_hi);
 }
 
 template <int S>
@@ -283,16 +286,19 @@ __device__ __forceinline__ void mfx_group_fetch(const mfx_table_view &t, uint4 (
   v[S] = *reinterpret_cast<const uint4 *>(t.slots + (uint64_t)ls[S] * MFX_SLOTS_LINE + sub);
 }
 
+// Post phase.  The slot lane compares the FULL key: keys are unique in the table, so at
+// most one lane of the group stores into the owner's record -- no two writers can ever
+// interleave their words (a low-word-only pre-match would let that happen ~1e-9 per query,
+// i.e. a few times per 3 Gb launch).
 template <int S>
-__device__ __forceinline__ void mfx_group_post(mfx_mailbox &M, const uint4 (&v)[8], const uint32_t (&klo)[8], uint32_t obase) {
+__device__ __forceinline__ void mfx_group_post(mfx_mailbox &M, const uint4 (&v)[8], const uint32_t (&klo)[8],
+                                               const uint32_t (&khi)[8], uint32_t obase) {
   const uint4 s = v[S];
   uint32_t *rec = reinterpret_cast<uint32_t *>(&M.rec[obase + S]);
   if ((s.x & s.y) == 0xffffffffu) {
     rec[3] = 1u;                                              // this line still has an empty slot
-  } else if (s.x == klo[S]) {
-    // low-word match (the owner verifies the high word); two low-word matches in one
-    // line (~1e-9) would race here -- the owner detects any mismatch and re-probes exactly
-    rec[0] = s.y; rec[1] = s.z; rec[2] = s.w;
+  } else if (s.x == klo[S] && s.y == khi[S]) {
+    rec[0] = s.z; rec[1] = s.w; rec[2] = 1u;                  // {readV, asmV, found}
   }
 }
 
@@ -303,7 +309,7 @@ __device__ __forceinline__ void mfx_group_lookup(const mfx_table_view &t, mfx_ma
                                                  uint32_t (&av)[B]) {
   const uint32_t tid = threadIdx.x, sub = tid & 7u, obase = tid & ~7u;
   uint32_t line[B];
-  uint32_t pending[B];          // 0 resolved, 1 home line full (continue at candidate 1), 2 ambiguous (redo exactly)
+  uint32_t pending[B];          // 0 resolved, 1 home line full: continue at candidate line 1
 #pragma unroll
   for (int j = 0; j < B; ++j) {
     line[j] = ok[j] ? mfx_first_line(t, key[j], krc[j]) : 0u;      // no k-mer here: a dummy query of line 0, ignored below
@@ -313,28 +319,28 @@ __device__ __forceinline__ void mfx_group_lookup(const mfx_table_view &t, mfx_ma
 #pragma unroll
   for (int j = 0; j < B; ++j) {
     uint4 v[8];
-    uint32_t klo[8];
+    uint32_t klo[8], khi[8];
     const uint32_t key_lo = (uint32_t)key[j], key_hi = (uint32_t)(key[j] >> 32);
-    M.rec[tid] = make_uint4(0xffffffffu, 0u, 0u, 0u);
+    M.rec[tid] = make_uint4(0u, 0u, 0u, 0u);
     uint32_t ls[8];
-    mfx_group_announce<0>(ls, klo, line[j], key_lo); mfx_group_announce<1>(ls, klo, line[j], key_lo);
-    mfx_group_announce<2>(ls, klo, line[j], key_lo); mfx_group_announce<3>(ls, klo, line[j], key_lo);
-    mfx_group_announce<4>(ls, klo, line[j], key_lo); mfx_group_announce<5>(ls, klo, line[j], key_lo);
-    mfx_group_announce<6>(ls, klo, line[j], key_lo); mfx_group_announce<7>(ls, klo, line[j], key_lo);
+    mfx_group_announce<0>(ls, klo, khi, line[j], key_lo, key_hi); mfx_group_announce<1>(ls, klo, khi, line[j], key_lo, key_hi);
+    mfx_group_announce<2>(ls, klo, khi, line[j], key_lo, key_hi); mfx_group_announce<3>(ls, klo, khi, line[j], key_lo, key_hi);
+    mfx_group_announce<4>(ls, klo, khi, line[j], key_lo, key_hi); mfx_group_announce<5>(ls, klo, khi, line[j], key_lo, key_hi);
+    mfx_group_announce<6>(ls, klo, khi, line[j], key_lo, key_hi); mfx_group_announce<7>(ls, klo, khi, line[j], key_lo, key_hi);
     mfx_group_fetch<0>(t, v, ls, sub); mfx_group_fetch<1>(t, v, ls, sub); mfx_group_fetch<2>(t, v, ls, sub);
     mfx_group_fetch<3>(t, v, ls, sub); mfx_group_fetch<4>(t, v, ls, sub); mfx_group_fetch<5>(t, v, ls, sub);
     mfx_group_fetch<6>(t, v, ls, sub); mfx_group_fetch<7>(t, v, ls, sub);
-    mfx_group_post<0>(M, v, klo, obase); mfx_group_post<1>(M, v, klo, obase); mfx_group_post<2>(M, v, klo, obase);
-    mfx_group_post<3>(M, v, klo, obase); mfx_group_post<4>(M, v, klo, obase); mfx_group_post<5>(M, v, klo, obase);
-    mfx_group_post<6>(M, v, klo, obase); mfx_group_post<7>(M, v, klo, obase);
+    mfx_group_post<0>(M, v, klo, khi, obase); mfx_group_post<1>(M, v, klo, khi, obase); mfx_group_post<2>(M, v, klo, khi, obase);
+    mfx_group_post<3>(M, v, klo, khi, obase); mfx_group_post<4>(M, v, klo, khi, obase); mfx_group_post<5>(M, v, klo, khi, obase);
+    mfx_group_post<6>(M, v, klo, khi, obase); mfx_group_post<7>(M, v, klo, khi, obase);
     const uint4 r = M.rec[tid];
     if (ok[j]) {
-      if (r.x == key_hi) {
-        rv[j] = (r.y < t.minV || r.y > t.maxV) ? 0u : r.y;    // -min / -max (merfin.C:199-200)
-        av[j] = r.z;
+      if (r.z == 1u) {
+        rv[j] = (r.x < t.minV || r.x > t.maxV) ? 0u : r.x;    // -min / -max (merfin.C:199-200)
+        av[j] = r.y;
       } else {
-        // no (verified) match: absent if the home line has room, else continue per lane
-        pending[j] = (r.x != 0xffffffffu) ? 2u : (r.w == 0u ? 1u : 0u);
+        // not in the home line: absent if that line has room, else continue at the next candidate line
+        pending[j] = r.w == 0u ? 1u : 0u;
       }
     }
   }
@@ -375,7 +381,7 @@ __device__ __forceinline__ void mfx_group_lookup(const mfx_table_view &t, mfx_ma
 #pragma unroll
   for (int j = 0; j < B; ++j) {
     if (pending[j] == 0u) continue;
-    uint32_t from = pending[j] == 1u ? 1u : 0u;
+    uint32_t from = 1u;
     if (qpos[j] != 0xffffffffu) {
       const uint4 r = M.rec[wbase + qpos[j]];
       if (r.z == 0xffffffffu) { rv[j] = (r.x < t.minV || r.x > t.maxV) ? 0u : r.x; av[j] = r.y; continue; }
