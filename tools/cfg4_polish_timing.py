@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Timing of the -polish path on a config-4-shaped case: an assembly with SNP
+errors, a VCF proposing their corrections (+ decoys), read k-mers from the
+truth genome.  Run on the GPU box:  python tools/cfg4_polish_timing.py [bases] [variants]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import merfin_amd as m
+from tools import synth_torch as st
+
+bases = int(float(sys.argv[1])) if len(sys.argv) > 1 else 64_000_000
+nvar = int(float(sys.argv[2])) if len(sys.argv) > 2 else 100_000
+k, lam = 21, 26.0
+out = os.environ.get("MFX_TMP", "/tmp/mfx_cfg4")
+os.makedirs(out, exist_ok=True)
+r = np.random.default_rng(7)
+ncontig = 8
+sizes = st.contig_sizes(bases, ncontig)
+t0 = time.time()
+truth = [st.random_bases(n, st.SEED + 17 * (i + 1), "cuda") for i, n in enumerate(sizes)]
+names = ["ctg%d" % i for i in range(ncontig)]
+lines = ["##fileformat=VCFv4.2"] + ["##contig=<ID=%s,length=%d>" % (n, s) for n, s in zip(names, sizes)]
+lines.append("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tSAMPLE")
+asm = []
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+for ci, t in enumerate(truth):
+    a = t.cpu().numpy().copy()
+    n = len(a)
+    nv = max(1, nvar * n // bases)
+    # bursts: half of the variants come in tight groups (clusters of 2-6 within 2k)
+    pos = np.unique(np.concatenate([r.integers(30, n - 30, size=nv // 2),
+                                    (r.integers(30, n - 200, size=nv // 8)[:, None] + r.integers(0, 40, size=(nv // 8, 4))).ravel()]))
+    tru = a[pos].copy()
+    code = np.searchsorted(ACGT, tru)
+    wrong = ACGT[(code + r.integers(1, 4, size=len(pos))) % 4]
+    is_err = r.random(len(pos)) < 0.8                 # 80 % real assembly errors, 20 % decoys (REF is right, ALT is wrong)
+    a[pos[is_err]] = wrong[is_err]
+    for p, te, w, e in zip(pos.tolist(), tru.tolist(), wrong.tolist(), is_err.tolist()):
+        ref, alt = (chr(w), chr(te)) if e else (chr(te), chr(w))
+        lines.append("%s\t%d\t.\t%s\t%s\t30\tPASS\t.\tGT\t1/1" % (names[ci], p + 1, ref, alt))
+    asm.append(a.tobytes())
+vcf = out + "/in.vcf"
+open(vcf, "w").write("\n".join(lines) + "\n")
+print("inputs: %d bp, %d variants, generated in %.1fs" % (bases, len(lines) - ncontig - 2, time.time() - t0), flush=True)
+t0 = time.time()
+ix = m.Index(k, int(bases * 2.2))
+st.add_reads_from_truth(ix, truth, k, lam)
+seqs = m.Sequences(asm)
+ix.count_asm(seqs)
+print("index built in %.1fs (%d k-mers)" % (time.time() - t0, ix.info()["distinct"]), flush=True)
+ev = m.Evaluator(ix, m.KParams(lam))
+for mode in ("polish", "filter"):
+    t0 = time.time()
+    ncl = ev.variants(mode, vcf, names, asm, out + "/out.%s.vcf" % mode, log_path=out + "/log.txt")
+    dt = time.time() - t0
+    nrec = sum(1 for l in open(out + "/out.%s.vcf" % mode) if not l.startswith("#"))
+    print("-%s: %d clusters in %.2fs = %.0f clusters/s, %d records selected" % (mode, ncl, dt, ncl / dt, nrec), flush=True)
