@@ -371,6 +371,13 @@ static int seq_alloc(mfx_seq *s) {
     MFX_HIP(hipMemcpy(s->d_contig_len, s->len.data(), s->ncontigs * sizeof(uint64_t), hipMemcpyHostToDevice));
   }
   MFX_HIP(hipMemcpy(s->d_tile_start, s->tile_start.data(), (s->ncontigs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+  {
+    std::vector<uint32_t> tc((size_t)s->ntiles);
+    for (uint32_t c = 0; c < s->ncontigs; ++c)
+      std::fill(tc.begin() + (size_t)s->tile_start[c], tc.begin() + (size_t)s->tile_start[c + 1], c);
+    MFX_HIP(hipMalloc((void **)&s->d_tile_contig, (tc.size() ? tc.size() : 1) * sizeof(uint32_t)));
+    if (!tc.empty()) MFX_HIP(hipMemcpy(s->d_tile_contig, tc.data(), tc.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
   return MFX_OK;
 }
 
@@ -480,6 +487,7 @@ extern "C" void mfx_seq_free(mfx_seq *s) {
   if (s->d_contig_off) (void)hipFree(s->d_contig_off);
   if (s->d_contig_len) (void)hipFree(s->d_contig_len);
   if (s->d_tile_start) (void)hipFree(s->d_tile_start);
+  if (s->d_tile_contig) (void)hipFree(s->d_tile_contig);
   delete s;
 }
 
@@ -511,13 +519,15 @@ extern "C" mfx_eval *mfx_eval_create(const mfx_index *ix, const mfx_kparams *kp,
     return nullptr;
   }
   const char *e = getenv("MFX_BLOCKS_PER_CU");
-  int bpc = e ? atoi(e) : 32;   // 4 resident blocks/CU x 8 rounds: keeps the static tile split's tail < 3 %
+  int bpc = e ? atoi(e) : mfx_k_hist_resident_blocks();   // persistent blocks: as many as are resident at once
   if (bpc < 1) bpc = 1;
   ev->grid = prop.multiProcessorCount * bpc;
   size_t np = ev->n_prob ? ev->n_prob : 1;
   if (hipMalloc((void **)&ev->d_probK, np * sizeof(uint32_t)) != hipSuccess ||
       hipMalloc((void **)&ev->d_probP, np * sizeof(double)) != hipSuccess ||
       hipMalloc((void **)&ev->d_partials, 2 * (size_t)ev->grid * sizeof(double)) != hipSuccess ||
+      hipMalloc((void **)&ev->d_tile_ctr, sizeof(uint64_t)) != hipSuccess ||
+      hipMemset(ev->d_tile_ctr, 0, sizeof(uint64_t)) != hipSuccess ||
       hipMalloc((void **)&ev->d_ovf, (1 + (size_t)MFX_OVF_CAP) * sizeof(uint64_t)) != hipSuccess ||
       hipMemset(ev->d_ovf, 0, sizeof(uint64_t)) != hipSuccess ||
       (ev->n_prob && hipMemcpy(ev->d_probK, ev->probK.data(), ev->n_prob * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) ||
@@ -535,6 +545,8 @@ extern "C" void mfx_eval_free(mfx_eval *ev) {
   if (ev->d_probK) (void)hipFree(ev->d_probK);
   if (ev->d_probP) (void)hipFree(ev->d_probP);
   if (ev->d_partials) (void)hipFree(ev->d_partials);
+  if (ev->d_tile_ctr) (void)hipFree(ev->d_tile_ctr);
+  if (ev->d_tile_partials) (void)hipFree(ev->d_tile_partials);
   if (ev->d_ovf) (void)hipFree(ev->d_ovf);
   delete ev;
 }
@@ -589,12 +601,22 @@ extern "C" int mfx_hist_launch(mfx_eval *ev, const mfx_seq *seq, uint64_t tile_b
   if (ev->device != seq->device) return mfx_fail(MFX_E_INVAL, "evaluator and sequence live on different devices");
   if (tile_begin > tile_end || tile_end > seq->ntiles) return mfx_fail(MFX_E_INVAL, "tile range [%lu,%lu) outside [0,%lu)",
                                                                       (unsigned long)tile_begin, (unsigned long)tile_end, (unsigned long)seq->ntiles);
+  if (tile_begin == tile_end) return MFX_OK;
   DevGuard g(ev->device);
   int canon = 0;
   int rc = eval_canonical(ev, &canon);
   if (rc) return rc;
   const char *force = getenv("MFX_FORCE_TWO_STRAND");
   if (force && atoi(force)) canon = 0;
+  const uint64_t ntl = tile_end - tile_begin;
+  const uint64_t need = mfx_k_tile_partials_words(ntl);
+  if (need > ev->tile_partials_cap) {
+    if (ev->d_tile_partials) (void)hipFree(ev->d_tile_partials);
+    ev->d_tile_partials = nullptr;
+    ev->tile_partials_cap = 0;
+    MFX_HIP(hipMalloc((void **)&ev->d_tile_partials, need * sizeof(double)));
+    ev->tile_partials_cap = need;
+  }
   mfx_hist_args a;
   a.t = ev->ix->view();
   a.canonical = canon;
@@ -605,6 +627,9 @@ extern "C" int mfx_hist_launch(mfx_eval *ev, const mfx_seq *seq, uint64_t tile_b
   a.ncontigs = seq->ncontigs;
   a.tile_begin = tile_begin;
   a.tile_end = tile_end;
+  a.tile_contig = seq->d_tile_contig;
+  a.tile_ctr = ev->d_tile_ctr;
+  a.tile_partials = ev->d_tile_partials;
   a.ks.peak = ev->peak;
   a.ks.n_prob = ev->n_prob;
   a.ks.probK = ev->d_probK;
@@ -614,8 +639,8 @@ extern "C" int mfx_hist_launch(mfx_eval *ev, const mfx_seq *seq, uint64_t tile_b
   a.ks.counts = d_counts;
   a.ks.partials = ev->d_partials;
   a.ks.ovf = ev->d_ovf;
-  MFX_HIP(mfx_k_hist(a, ev->grid, (hipStream_t)stream));
-  MFX_HIP(mfx_k_sum_partials(ev->d_partials, (uint32_t)ev->grid, d_kover, (hipStream_t)stream));
+  MFX_HIP(mfx_k_hist(a, (int)std::min<uint64_t>((uint64_t)ev->grid, ntl), (hipStream_t)stream));
+  MFX_HIP(mfx_k_sum_tile_partials(ev->d_tile_partials, ntl, d_kover, ev->d_tile_ctr, (hipStream_t)stream));
   return MFX_OK;
 }
 

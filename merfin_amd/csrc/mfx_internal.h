@@ -84,6 +84,7 @@ struct mfx_seq {
   uint64_t *d_contig_off = nullptr;  // [ncontigs]   byte offset of each contig
   uint64_t *d_contig_len = nullptr;  // [ncontigs]
   uint64_t *d_tile_start = nullptr;  // [ncontigs+1] first tile of each contig
+  uint32_t *d_tile_contig = nullptr; // [ntiles] contig of each tile
   std::vector<uint64_t> off, len, tile_start;
 };
 
@@ -100,6 +101,9 @@ struct mfx_eval {
   int       grid = 0;
   uint64_t  canon_version = ~0ull;   // index version the cached `canon` flag belongs to
   int       canon = 0;
-  double   *d_partials = nullptr;    // [grid] per-block koverCpy partial sums
+  double   *d_partials = nullptr;    // [2*grid] per-block koverCpy partial sums (key-driven kernel)
+  uint64_t *d_tile_ctr = nullptr;    // dynamic tile scheduler counter of mfx_hist_kernel (0 between launches)
+  double   *d_tile_partials = nullptr; // per-(tile,wave) koverCpy of the last launch + the chunk sums behind them
+  uint64_t  tile_partials_cap = 0;   // doubles allocated
   uint64_t *d_ovf = nullptr;         // [0] count, [1..] records
 };

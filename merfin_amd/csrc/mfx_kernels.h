@@ -22,6 +22,9 @@ struct mfx_hist_args {
   const uint64_t *contig_off, *contig_len, *tile_start;
   uint32_t        ncontigs;
   uint64_t        tile_begin, tile_end;
+  const uint32_t *tile_contig;        // [ntiles] contig of every tile
+  uint64_t       *tile_ctr;           // dynamic tile scheduler: tiles handed out beyond the first gridDim.x (0 at launch)
+  double         *tile_partials;      // [(tile_end - tile_begin) * MFX_BLOCK/64] koverCpy of every (tile, wave)
   mfx_kstar_args  ks;
 };
 
@@ -85,6 +88,9 @@ hipError_t mfx_k_route_gather(const mfx_route_args &a, const uint32_t *idx, uint
 hipError_t mfx_k_iota(uint32_t *v, uint64_t n, hipStream_t st);
 hipError_t mfx_k_hist_keys(const mfx_hist_keys_args &a, int grid, hipStream_t st);
 hipError_t mfx_k_sum_partials(const double *partials, uint32_t n, double *out, hipStream_t st);
+uint64_t mfx_k_tile_partials_words(uint64_t ntiles);
+hipError_t mfx_k_sum_tile_partials(double *tile_partials, uint64_t ntiles, double *out, uint64_t *ctr_reset, hipStream_t st);
+int mfx_k_hist_resident_blocks();
 hipError_t mfx_k_dump(const mfx_dump_args &a, hipStream_t st);
 hipError_t mfx_k_count(const mfx_count_args &a, hipStream_t st);
 hipError_t mfx_k_completeness(mfx_table_view t, double peak, uint32_t n_prob, const uint32_t *probK, const double *probP,

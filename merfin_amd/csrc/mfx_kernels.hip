@@ -487,6 +487,7 @@ struct mfx_hist_lds {
   uint16_t bin[MFX_KLUT * MFX_KLUT];
   double   term[MFX_KLUT * MFX_KLUT];
   uint32_t lut_ok;
+  uint64_t next[2];                       // dynamic tile scheduler: the tile fetched for the next iteration
   uint64_t red[MFX_BLOCK / 64][3];
   double   dred[MFX_BLOCK];
 };
@@ -548,8 +549,8 @@ __device__ __forceinline__ bool mfx_hist_eval(mfx_hist_lds &H, const mfx_kstar_a
   return false;
 }
 
-// LDS bins -> global (non-zero only); koverCpy: fixed-order tree, one partial per block
-__device__ __forceinline__ void mfx_hist_lds_flush(mfx_hist_lds &H, const mfx_kstar_args &ka, double kover) {
+// LDS bins -> global (non-zero only)
+__device__ __forceinline__ void mfx_hist_lds_flush_bins(mfx_hist_lds &H, const mfx_kstar_args &ka) {
   const uint32_t tid = threadIdx.x;
   uint64_t *c_undr = ka.counts, *c_over = ka.counts + ka.nbins;
   __syncthreads();
@@ -557,6 +558,12 @@ __device__ __forceinline__ void mfx_hist_lds_flush(mfx_hist_lds &H, const mfx_ks
     uint32_t v = H.hist[i];
     if (v) atomicAdd((unsigned long long *)&(i < MFX_NB_LDS ? c_undr[i] : c_over[i - MFX_NB_LDS]), (unsigned long long)v);
   }
+}
+
+// koverCpy of a block with a fixed launch-wide work split: fixed-order tree, one partial per block
+__device__ __forceinline__ void mfx_hist_lds_flush(mfx_hist_lds &H, const mfx_kstar_args &ka, double kover) {
+  const uint32_t tid = threadIdx.x;
+  mfx_hist_lds_flush_bins(H, ka);
   H.dred[tid] = kover;
   __syncthreads();
   for (uint32_t s = MFX_BLOCK / 2; s > 0; s >>= 1) {
@@ -567,7 +574,7 @@ __device__ __forceinline__ void mfx_hist_lds_flush(mfx_hist_lds &H, const mfx_ks
 }
 
 template <bool CANON>
-__global__ __launch_bounds__(MFX_BLOCK) void mfx_hist_kernel(mfx_hist_args a) {
+__global__ __launch_bounds__(MFX_BLOCK, 4) void mfx_hist_kernel(mfx_hist_args a) {
   __shared__ mfx_tile_lds L;
   __shared__ mfx_mailbox MB;
   __shared__ mfx_hist_lds H;
@@ -578,28 +585,24 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_hist_kernel(mfx_hist_args a) {
   mfx_hist_lds_init(H, ka);
   const bool lut_ok = H.lut_ok != 0u;
 
-  // contiguous run of tiles for this (persistent) block
-  const uint64_t ntl = a.tile_end - a.tile_begin;
-  const uint64_t per = (ntl + gridDim.x - 1) / gridDim.x;
-  uint64_t t0 = a.tile_begin + blockIdx.x * per;
-  uint64_t t1 = t0 + per < a.tile_end ? t0 + per : a.tile_end;
-
   uint64_t n_valid = 0, n_missing = 0, n_over0 = 0;     // per-lane counters
-  double   kover = 0.0;                                  // per-lane koverCpy partial
   uint64_t *c_glob = ka.counts + 2ull * ka.nbins;        // kasm, kmissing, novf
   uint64_t *c_kasm = c_glob + 3, *c_kmis = c_kasm + ka.ncontigs;
 
-  if (t0 < t1) {
-    // contig of the first tile: largest c with tile_start[c] <= t0
-    uint32_t lo = 0, hi = a.ncontigs;
-    while (hi - lo > 1) {
-      uint32_t mid = lo + (hi - lo) / 2;
-      if (a.tile_start[mid] <= t0) lo = mid; else hi = mid;
-    }
-    uint32_t c = lo;
-
-    for (uint64_t tile = t0; tile < t1; ++tile) {
-      while (tile >= a.tile_start[c + 1]) {
+  // Persistent block, tiles handed out dynamically: block b starts on tile_begin + b and
+  // draws every further tile from one global counter (the draw for the NEXT tile is issued
+  // before the current one is processed, so its latency is never waited on).  The k-mer
+  // counters are integers and koverCpy is kept per (tile, wave), so the result does not
+  // depend on which block evaluated which tile.
+  const uint32_t none = 0xffffffffu;
+  uint32_t c = none;
+  uint64_t tile = a.tile_begin + blockIdx.x;
+  for (uint32_t it = 0; tile < a.tile_end; ++it) {
+    if (tid == 0)
+      H.next[it & 1] = a.tile_begin + gridDim.x + atomicAdd((unsigned long long *)a.tile_ctr, 1ull);
+    const uint32_t cn = a.tile_contig[tile];
+    if (cn != c) {
+      if (c != none) {
         // contig change (block-uniform): flush the per-contig counters
         uint64_t x = n_valid, y = n_missing, z = 0;
         mfx_block_sum3(x, y, z, H.red);
@@ -610,65 +613,74 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_hist_kernel(mfx_hist_args a) {
           atomicAdd((unsigned long long *)&c_glob[1], y);
         }
         n_valid = n_missing = 0;
-        ++c;
       }
-      const uint64_t pos0 = (tile - a.tile_start[c]) * MFX_TILE;
-      const uint64_t clen = a.contig_len[c];
-      const uint32_t n = (clen - pos0 < MFX_TILE) ? (uint32_t)(clen - pos0) : MFX_TILE;
-      const uint8_t *src = a.bases + a.contig_off[c] + pos0;
+      c = cn;
+    }
+    const uint64_t pos0 = (tile - a.tile_start[c]) * MFX_TILE;
+    const uint64_t clen = a.contig_len[c];
+    const uint32_t n = (clen - pos0 < MFX_TILE) ? (uint32_t)(clen - pos0) : MFX_TILE;
+    const uint8_t *src = a.bases + a.contig_off[c] + pos0;
 
-      __syncthreads();                       // previous tile fully consumed
-      mfx_tile_fill(L, src);
-      __syncthreads();
+    mfx_tile_fill(L, src);                   // the previous tile was fully consumed at the barrier below
+    __syncthreads();
 
-      for (uint32_t b = 0; b < MFX_TILE / MFX_BLOCK; b += MFX_BATCH) {
-        uint64_t key[MFX_BATCH], key2[MFX_BATCH];
-        uint32_t rv[MFX_BATCH], av[MFX_BATCH];
-        bool     ok[MFX_BATCH];
+    double kover = 0.0;                      // this lane's koverCpy terms of this tile
+    for (uint32_t b = 0; b < MFX_TILE / MFX_BLOCK; b += MFX_BATCH) {
+      uint64_t key[MFX_BATCH], key2[MFX_BATCH];
+      uint32_t rv[MFX_BATCH], av[MFX_BATCH];
+      bool     ok[MFX_BATCH];
 #pragma unroll
-        for (int j = 0; j < MFX_BATCH; ++j) {
-          uint32_t p = (b + j) * MFX_BLOCK + tid;     // lane-consecutive positions
-          uint64_t f;
-          ok[j] = mfx_tile_kmer(L, k, p, f) && (p < n);
-          uint64_t r = mfx_revcomp(f, k);
-          if (CANON) {
-            key[j] = f < r ? f : r; key2[j] = f < r ? r : f;     // canonical k-mer and its reverse complement
-          } else {
-            key[j] = f; key2[j] = r;
-          }
+      for (int j = 0; j < MFX_BATCH; ++j) {
+        uint32_t p = (b + j) * MFX_BLOCK + tid;     // lane-consecutive positions
+        uint64_t f;
+        ok[j] = mfx_tile_kmer(L, k, p, f) && (p < n);
+        uint64_t r = mfx_revcomp(f, k);
+        if (CANON) {
+          key[j] = f < r ? f : r; key2[j] = f < r ? r : f;     // canonical k-mer and its reverse complement
+        } else {
+          key[j] = f; key2[j] = r;
         }
-        mfx_group_lookup<MFX_BATCH>(a.t, MB, key, key2, ok, rv, av);
-        if (!CANON) {
-          // value(fmer) + value(rmer), uint32 arithmetic (merfin-globals.C:107-108)
-          uint32_t rv2[MFX_BATCH], av2[MFX_BATCH];
-          mfx_group_lookup<MFX_BATCH>(a.t, MB, key2, key, ok, rv2, av2);
+      }
+      mfx_group_lookup<MFX_BATCH>(a.t, MB, key, key2, ok, rv, av);
+      if (!CANON) {
+        // value(fmer) + value(rmer), uint32 arithmetic (merfin-globals.C:107-108)
+        uint32_t rv2[MFX_BATCH], av2[MFX_BATCH];
+        mfx_group_lookup<MFX_BATCH>(a.t, MB, key2, key, ok, rv2, av2);
 #pragma unroll
-          for (int j = 0; j < MFX_BATCH; ++j) { rv[j] += rv2[j]; av[j] += av2[j]; }
-        }
+        for (int j = 0; j < MFX_BATCH; ++j) { rv[j] += rv2[j]; av[j] += av2[j]; }
+      }
 #pragma unroll
-        for (int j = 0; j < MFX_BATCH; ++j) {
-          if (!ok[j]) continue;
-          n_valid++;                                                   // merfin-histogram.C:58
-          if (mfx_hist_eval(H, ka, lut_ok, rv[j], av[j], n_over0, kover)) n_missing++;
-        }
+      for (int j = 0; j < MFX_BATCH; ++j) {
+        if (!ok[j]) continue;
+        n_valid++;                                                   // merfin-histogram.C:58
+        if (mfx_hist_eval(H, ka, lut_ok, rv[j], av[j], n_over0, kover)) n_missing++;
       }
     }
-    // final per-contig flush
-    {
-      uint64_t x = n_valid, y = n_missing, z = n_over0;
-      mfx_block_sum3(x, y, z, H.red);
-      if (tid == 0) {
-        if (x | y) {
-          atomicAdd((unsigned long long *)&c_kasm[c], x);
-          atomicAdd((unsigned long long *)&c_kmis[c], y);
-          atomicAdd((unsigned long long *)&c_glob[0], x);
-          atomicAdd((unsigned long long *)&c_glob[1], y);
-        }
-        if (z) atomicAdd((unsigned long long *)&ka.counts[ka.nbins], z);
+    // koverCpy of this (tile, wave): fixed-order tree over the 64 lanes
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) kover = kover + __shfl_down(kover, off, 64);
+    if ((tid & 63u) == 0) a.tile_partials[(tile - a.tile_begin) * (MFX_BLOCK / 64) + (tid >> 6)] = kover;
+
+    __syncthreads();                         // tile consumed; H.next[it & 1] written
+    const uint64_t nx = H.next[it & 1];
+    tile = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(nx >> 32)) << 32) |
+           (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)nx);
+  }
+  // last contig of this block + the register-held dominant bin
+  {
+    uint64_t x = n_valid, y = n_missing, z = n_over0;
+    mfx_block_sum3(x, y, z, H.red);
+    if (tid == 0) {
+      if (c != none && (x | y)) {
+        atomicAdd((unsigned long long *)&c_kasm[c], x);
+        atomicAdd((unsigned long long *)&c_kmis[c], y);
+        atomicAdd((unsigned long long *)&c_glob[0], x);
+        atomicAdd((unsigned long long *)&c_glob[1], y);
       }
+      if (z) atomicAdd((unsigned long long *)&ka.counts[ka.nbins], z);
     }
   }
-  mfx_hist_lds_flush(H, ka, kover);
+  mfx_hist_lds_flush_bins(H, ka);
 }
 
 // ===========================================================================
@@ -796,8 +808,9 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_hist_keys_kernel(mfx_hist_keys_
   mfx_hist_lds_flush(H, ka, kover);
 }
 
-// sums the per-block partials in a fixed order and adds the result to *out
-__global__ __launch_bounds__(MFX_BLOCK) void mfx_sum_partials_kernel(const double *partials, uint32_t n, double *out) {
+// sums the partials in a fixed order and adds the result to *out; re-arms the tile scheduler counter
+__global__ __launch_bounds__(MFX_BLOCK) void mfx_sum_partials_kernel(const double *partials, uint32_t n, double *out,
+                                                                     uint64_t *ctr_reset) {
   __shared__ double s[MFX_BLOCK];
   double v = 0.0;
   for (uint32_t i = threadIdx.x; i < n; i += MFX_BLOCK) v = v + partials[i];
@@ -807,7 +820,27 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_sum_partials_kernel(const doubl
     if (threadIdx.x < st) s[threadIdx.x] = s[threadIdx.x] + s[threadIdx.x + st];
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[0] = out[0] + s[0];
+  if (threadIdx.x == 0) {
+    out[0] = out[0] + s[0];
+    if (ctr_reset) ctr_reset[0] = 0;
+  }
+}
+
+// first level over the per-(tile, wave) values: block b sums in[b*MFX_SUM_CHUNK ...) in a fixed order
+#define MFX_SUM_CHUNK 4096u
+__global__ __launch_bounds__(MFX_BLOCK) void mfx_sum_chunks_kernel(const double *in, uint64_t n, double *out) {
+  __shared__ double s[MFX_BLOCK];
+  const uint64_t base = (uint64_t)blockIdx.x * MFX_SUM_CHUNK;
+  double v = 0.0;
+  for (uint32_t i = threadIdx.x; i < MFX_SUM_CHUNK; i += MFX_BLOCK)
+    if (base + i < n) v = v + in[base + i];
+  s[threadIdx.x] = v;
+  __syncthreads();
+  for (uint32_t st = MFX_BLOCK / 2; st > 0; st >>= 1) {
+    if (threadIdx.x < st) s[threadIdx.x] = s[threadIdx.x] + s[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = s[0];
 }
 
 // ===========================================================================
@@ -997,8 +1030,25 @@ hipError_t mfx_k_hist_keys(const mfx_hist_keys_args &a, int grid, hipStream_t st
   return hipGetLastError();
 }
 hipError_t mfx_k_sum_partials(const double *partials, uint32_t n, double *out, hipStream_t st) {
-  mfx_sum_partials_kernel<<<1, MFX_BLOCK, 0, st>>>(partials, n, out);
+  mfx_sum_partials_kernel<<<1, MFX_BLOCK, 0, st>>>(partials, n, out, nullptr);
   return hipGetLastError();
+}
+uint64_t mfx_k_tile_partials_words(uint64_t ntiles) {
+  const uint64_t n = ntiles * (MFX_BLOCK / 64);
+  return n + (n + MFX_SUM_CHUNK - 1) / MFX_SUM_CHUNK;
+}
+// koverCpy of a tile-driven launch: two fixed-order levels over the per-(tile, wave) values, then += *out
+hipError_t mfx_k_sum_tile_partials(double *tile_partials, uint64_t ntiles, double *out, uint64_t *ctr_reset, hipStream_t st) {
+  const uint64_t n = ntiles * (MFX_BLOCK / 64);
+  const uint64_t nch = (n + MFX_SUM_CHUNK - 1) / MFX_SUM_CHUNK;
+  if (nch) mfx_sum_chunks_kernel<<<(unsigned)nch, MFX_BLOCK, 0, st>>>(tile_partials, n, tile_partials + n);
+  mfx_sum_partials_kernel<<<1, MFX_BLOCK, 0, st>>>(tile_partials + n, (uint32_t)nch, out, ctr_reset);
+  return hipGetLastError();
+}
+int mfx_k_hist_resident_blocks() {
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mfx_hist_kernel<true>, MFX_BLOCK, 0) != hipSuccess || nb < 1) nb = 4;
+  return nb;
 }
 hipError_t mfx_k_dump(const mfx_dump_args &a, hipStream_t st) {
   uint64_t blocks = (a.npos + MFX_TILE - 1) / MFX_TILE;
