@@ -326,6 +326,32 @@ def test_many_small_contigs():
     assert_hist_equal(res, g, ka, km, k)
 
 
+def test_result_independent_of_grid_and_repeatable(monkeypatch):
+    """Tiles are handed out dynamically, so which block evaluates which tile varies from launch to launch;
+    every integer and koverCpy (kept per (tile, wave), summed in fixed order) must not: bit-identical for
+    any persistent grid size and across repeated launches, on an assembly with very uneven tiles."""
+    m = _mfx()
+    k, peak = 21, 17.3
+    contigs, read, asm = synth.world(k=k, peak=peak, seed=41)
+    r = synth.rng(5)
+    contigs = list(contigs) + [synth.random_contig(r, int(n)).tobytes() for n in r.integers(1, 9000, size=300)]
+    contigs.insert(3, b"N" * 50000)
+    ak, av = po.count_kmers(k, contigs)
+    ix = build_index(m, k, read, (ak, av))
+    seqs = m.Sequences(contigs)
+    outs = []
+    for bpc in ("1", "3", None, None):
+        if bpc is None:
+            monkeypatch.delenv("MFX_BLOCKS_PER_CU", raising=False)
+        else:
+            monkeypatch.setenv("MFX_BLOCKS_PER_CU", bpc)
+        res = m.Evaluator(ix, m.KParams(peak)).hist(seqs)
+        outs.append((res.kasm, res.kmissing, np.float64(res.koverCpy).tobytes(), res.undr().tobytes(), res.over().tobytes(),
+                     res.contig_kasm().tobytes(), res.contig_kmissing().tobytes()))
+    assert all(o == outs[0] for o in outs[1:])
+    assert outs[0][0] > 0 and np.frombuffer(outs[0][2], dtype=np.float64)[0] > 0
+
+
 def test_sharded_launch_equals_whole(golden_dir):
     """Position-tile sharding (the multi-GPU decomposition): any split of the tile
     range accumulates to the same integers; koverCpy to the same value within 1e-12."""
