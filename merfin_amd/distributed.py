@@ -94,3 +94,24 @@ def sharded_hist(ev, router, seqs, rank, world, counts, kover, stream=None, exch
             ev.hist_keys_launch(rk, rc, rk.numel(), seqs.ncontigs, counts, kover, stream=stream)
         torch.cuda.synchronize()                           # rk/rc are released after this round
     return all_reduce_hist(counts, kover)
+
+
+def reduce_completeness(total64, undrcpy64, device=None):
+    """-completeness over a sharded index: every rank evaluates the k-mers it owns (the per-piece sums of
+    merfin-completeness.C:56-66 restricted to its shard), the 2x64 sums are all-reduced and then added in piece
+    order exactly as the reference's final loop does (merfin-completeness.C:117-123).  The per-piece sums are
+    integer-valued doubles as long as the K table holds integers, so the split over ranks changes nothing.
+    Returns (total, undrcpy, total64, undrcpy64)."""
+    import torch
+    import torch.distributed as dist
+    img = torch.from_numpy(np.stack([np.asarray(total64, dtype=np.float64), np.asarray(undrcpy64, dtype=np.float64)]))
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if device is not None:
+            img = img.to(device)
+        dist.all_reduce(img)
+    t64, u64 = img.cpu().numpy()
+    total = undr = 0.0
+    for piece in range(64):
+        total += float(t64[piece])
+        undr += float(u64[piece])
+    return total, undr, t64, u64

@@ -1,8 +1,9 @@
-"""Multi-GPU `merfin -hist`: one process per GPU, launched with torchrun.
+"""Multi-GPU `merfin -hist` / `-completeness`: one process per GPU, launched with torchrun.
 
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
       -m merfin_amd.mgpu -sequence asm.fasta.gz -readmers reads.meryl [-seqmers asm.meryl] \\
       -peak 26 [-prob lookup_table.txt] -output out.hist [-sharded]
+  ... -m merfin_amd.mgpu -completeness -readmers reads.meryl -seqmers asm.meryl -peak 26 [-sharded]
 
 Every rank reads the inputs, builds the index on its own GPU and evaluates its
 share of the sequence tiles; the only collective is the all-reduce of the counts
@@ -54,9 +55,13 @@ def main(argv=None):
     ap.add_argument("-min", type=int, default=0)
     ap.add_argument("-max", type=int, default=2**64 - 1)
     ap.add_argument("-sharded", action="store_true")
+    ap.add_argument("-completeness", action="store_true")
     ap.add_argument("-chunk-tiles", type=int, default=16384)
     a = ap.parse_args(argv)
-    if not (a.sequence and a.readmers and a.output and a.peak):
+    if a.completeness:
+        if not (a.readmers and a.peak and (a.seqmers or a.sequence)):
+            ap.error("-completeness needs -readmers, -peak and -seqmers (or -sequence)")
+    elif not (a.sequence and a.readmers and a.output and a.peak):
         ap.error("-sequence, -readmers, -peak and -output are required")
 
     import torch
@@ -77,7 +82,7 @@ def main(argv=None):
             dist.init_process_group(backend)
     log = (lambda *x: print(*x, file=sys.stderr, flush=True)) if rank == 0 else (lambda *x: None)
 
-    names, seqs = read_sequences(a.sequence)
+    names, seqs = read_sequences(a.sequence) if a.sequence else ([], [])
     rdb = m.db_probe(a.readmers)
     k = rdb["k"]
     n_asm = m.db_probe(a.seqmers)["n_kmers"] if a.seqmers else sum(len(s) for s in seqs)
@@ -97,6 +102,24 @@ def main(argv=None):
         ix.count_asm(sq)
     kp = m.KParams.from_file(a.peak, a.prob) if a.prob else m.KParams(a.peak)
     ev = m.Evaluator(ix, kp)
+    if a.completeness:
+        # every rank sums over the k-mers it holds; with a replicated index only rank 0 contributes
+        log("-- Compute completeness on %d GPU(s)%s." % (world, " (sharded index)" if a.sharded else ""))
+        own = (a.sharded and world > 1) or rank == 0
+        t64, u64 = ev.completeness_pieces() if own else (np.zeros(64), np.zeros(64))
+        total, undr, t64, u64 = D.reduce_completeness(t64, u64, device="cuda" if backend == "nccl" else None)
+        if rank == 0:
+            for piece in range(64):                        # merfin-completeness.C:119-120, in piece order
+                c = 1.0 - u64[piece] / t64[piece] if t64[piece] else float("nan")
+                print("thread %2d total %12.2f underc %15.5f completeness %0.8f" % (piece, t64[piece], u64[piece], c), file=sys.stderr)
+            print("", file=sys.stderr)
+            print("TOTAL readK:   %15.2f" % total, file=sys.stderr)
+            print("TOTAL undrcpy:    %15.5f" % undr, file=sys.stderr)
+            print("COMPLETENESS:             %0.5f" % (1.0 - undr / total if total else float("nan")), file=sys.stderr)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     counts = torch.zeros(m.hist_words(ev.nbins, sq.ncontigs), dtype=torch.int64, device="cuda")
     kover = torch.zeros(1, dtype=torch.float64, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream

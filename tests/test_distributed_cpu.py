@@ -61,6 +61,54 @@ def _worker(rank, world, port, tmp):
     dist.destroy_process_group()
 
 
+def _completeness_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from oracle import pyoracle as po
+    from tests import synth
+    from merfin_amd import distributed as D
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    k, peak = 21, 17.3
+    contigs, read, asm = synth.world(k=k, peak=peak, seed=37)
+    p = po.Params(k, peak)
+
+    def pieces(rk, rv, ak, av):
+        t64, u64 = np.zeros(64), np.zeros(64)
+        for piece in range(64):
+            lo, hi = piece << (2 * k - 6), (piece + 1) << (2 * k - 6)
+            rs, as_ = (rk >= lo) & (rk < hi), (ak >= lo) & (ak < hi)
+            t64[piece], u64[piece] = po.completeness_piece(p, rk[rs], rv[rs], ak[as_], av[as_])
+        return t64, u64
+
+    # any partition of the K-MER SPACE works (the sharded index uses a hash of the minimizer): here a bit mix
+    own = lambda keys: ((keys * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(40)) % np.uint64(world) == np.uint64(rank)
+    mr, ma = own(read[0]), own(asm[0])
+    t64, u64 = pieces(read[0][mr], read[1][mr], asm[0][ma], asm[1][ma])
+    total, undr, rt, ru = D.reduce_completeness(t64, u64)
+    if rank == 0:
+        wt, wu = pieces(read[0], read[1], asm[0], asm[1])
+        tt = uu = 0.0
+        for i in range(64):
+            tt += wt[i]
+            uu += wu[i]
+        ok = (rt == wt).all() and (ru == wu).all() and (total, undr) == (tt, uu) and tt > 0 and uu > 0 and 0 < mr.sum() < len(mr)
+        open(os.path.join(tmp, "okc"), "w").write("1" if ok else "0 %r %r" % ((total, undr), (tt, uu)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_completeness(tmp_path):
+    """-completeness over a sharded index: per-piece sums all-reduced, then added in piece order"""
+    pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_completeness_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "okc").read_text() == "1"
+
+
 def test_two_rank_gloo_reduction(tmp_path):
     torch = pytest.importorskip("torch")
     import torch.multiprocessing as mp

@@ -31,3 +31,21 @@ def test_two_rank_launcher_matches_golden(tmp_path, sharded, with_seqmers):
     assert open(out, "rb").read() == open(G + "/case1.hist", "rb").read()
     assert open(G + "/case1.summary").read() in r.stderr
     assert "ctg0\t" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sharded", [False, True])
+def test_two_rank_launcher_completeness(tmp_path, sharded):
+    """-completeness through the launcher prints what the single-process CLI prints (merfin-completeness.C:117-123)"""
+    env = dict(os.environ, MFX_MGPU_BACKEND="gloo", MFX_MGPU_SHARE_GPU="1")
+    port = 30800 + (os.getpid() + 11 * sharded) % 1000
+    common = ["-completeness", "-readmers", G + "/case1.read.kmers.txt", "-seqmers", G + "/case1.asm.kmers.txt", "-peak", "17.3"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", "merfin_amd.mgpu"] + common + (["-sharded"] if sharded else [])
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    cli = subprocess.run([os.path.join(ROOT, "merfin_amd", "bin", "merfin")] + common, capture_output=True, text=True, timeout=600)
+    assert cli.returncode == 0, cli.stderr[-3000:]
+    pick = lambda txt: [l for l in txt.splitlines() if l.startswith(("thread ", "TOTAL ", "COMPLETENESS:"))]
+    want = pick(cli.stderr)
+    assert len(want) == 64 + 3 and pick(r.stderr) == want

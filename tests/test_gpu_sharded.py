@@ -70,6 +70,24 @@ def test_sharded_hist_virtual_exchange(world, mode, monkeypatch):
     assert_hist_equal(res, g, ka, km, k)
 
 
+@pytest.mark.parametrize("world", [2, 5])
+def test_sharded_completeness_sums_to_whole(world):
+    """every shard evaluates the k-mers it owns; the per-piece sums add up to the unsharded ones, bit for bit"""
+    import merfin_amd as m
+    k, peak = 21, 17.3
+    contigs, read, asm = synth.world(k=k, peak=peak, seed=85)
+    whole = m.Index(k, len(read[0]) + len(asm[0]) + 16)
+    whole.add_read(*read)
+    whole.add_asm(*asm)
+    wt, wu = m.Evaluator(whole, m.KParams(peak)).completeness_pieces()
+    st, su = np.zeros(64), np.zeros(64)
+    for ix in _build_shards(m, k, read, asm, world):
+        t, u = m.Evaluator(ix, m.KParams(peak)).completeness_pieces()
+        st += t
+        su += u
+    assert (st == wt).all() and (su == wu).all() and wt.sum() > 0 and wu.sum() > 0
+
+
 def _worker(rank, world, port, tmp):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
