@@ -23,6 +23,24 @@ def shard(ntiles, rank, world):
     return ntiles * rank // world, ntiles * (rank + 1) // world
 
 
+def contig_partition(weights, world):
+    """Contiguous split of the contigs (input order) into `world` runs of about equal total weight: [(lo, hi)] per
+    rank.  Used where the output is per contig and ordered (-dump text, VCF records): every rank writes its run,
+    the parts are concatenated in rank order -- what the reference's SLURM array does by hand
+    (scripts/parallel1/merfin.sh:68-85)."""
+    w = np.asarray(weights, dtype=np.float64)
+    n = len(w)
+    cum = np.concatenate([[0.0], np.cumsum(w)])
+    tot = cum[-1]
+    cuts = [0]
+    for r in range(1, world):
+        # first contig boundary at or past r/world of the weight, never before the previous cut
+        c = int(np.searchsorted(cum, tot * r / world, side="left")) if tot > 0 else n * r // world
+        cuts.append(min(n, max(cuts[-1], c)))
+    cuts.append(n)
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
 def pack_counts(nbins, ncontigs, undr, over, kasm, kmissing, contig_kasm, contig_kmissing):
     """host-side image with the device layout (include/merfin_amd.h MFX_HIST_WORDS)"""
     h = np.zeros(hist_words(nbins, ncontigs), dtype=np.uint64)

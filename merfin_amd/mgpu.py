@@ -4,6 +4,12 @@
       -m merfin_amd.mgpu -sequence asm.fasta.gz -readmers reads.meryl [-seqmers asm.meryl] \\
       -peak 26 [-prob lookup_table.txt] -output out.hist [-sharded]
   ... -m merfin_amd.mgpu -completeness -readmers reads.meryl -seqmers asm.meryl -peak 26 [-sharded]
+  ... -m merfin_amd.mgpu -dump   -sequence asm.fasta -readmers reads.meryl -peak 26 -output out.dump
+  ... -m merfin_amd.mgpu -polish -sequence asm.fasta -readmers reads.meryl -peak 26 -vcf calls.vcf -output out
+      (-filter / -better / -strict / -loose likewise; -comb N, -nosplit as in merfin)
+
+-dump and the variant modes have per-contig, ordered output: the contigs are split into one contiguous run per
+rank (balanced by bases / by VCF records), every rank writes its part, rank 0 concatenates them in rank order.
 
 Every rank reads the inputs, builds the index on its own GPU and evaluates its
 share of the sequence tiles; the only collective is the all-reduce of the counts
@@ -47,6 +53,29 @@ def read_sequences(path):
     return names, seqs
 
 
+VARIANT_MODES = ("filter", "polish", "better", "strict", "loose")
+
+
+def concat_parts(out_path, parts, skip_header):
+    """rank-ordered concatenation; `skip_header`: drop the '#' lines of every part but the first (VCF)"""
+    with open(out_path, "wb") as o:
+        for i, p in enumerate(parts):
+            with open(p, "rb") as f:
+                if skip_header and i:
+                    for line in f:
+                        if not line.startswith(b"#"):
+                            o.write(line)
+                            break
+                    else:
+                        continue
+                while True:
+                    blk = f.read(1 << 24)
+                    if not blk:
+                        break
+                    o.write(blk)
+            os.remove(p)
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="merfin_amd.mgpu", add_help=True)
     for flag in ("-sequence", "-readmers", "-seqmers", "-prob", "-output"):
@@ -56,6 +85,12 @@ def main(argv=None):
     ap.add_argument("-max", type=int, default=2**64 - 1)
     ap.add_argument("-sharded", action="store_true")
     ap.add_argument("-completeness", action="store_true")
+    ap.add_argument("-dump", action="store_true")
+    for mode in VARIANT_MODES:
+        ap.add_argument("-" + mode, action="store_true")
+    ap.add_argument("-vcf")
+    ap.add_argument("-comb", type=int, default=15)
+    ap.add_argument("-nosplit", action="store_true")
     ap.add_argument("-chunk-tiles", type=int, default=16384)
     a = ap.parse_args(argv)
     if a.completeness:
@@ -63,6 +98,13 @@ def main(argv=None):
             ap.error("-completeness needs -readmers, -peak and -seqmers (or -sequence)")
     elif not (a.sequence and a.readmers and a.output and a.peak):
         ap.error("-sequence, -readmers, -peak and -output are required")
+    vmode = [x for x in VARIANT_MODES if getattr(a, x)]
+    if len(vmode) > 1 or (vmode and (a.dump or a.completeness)):
+        ap.error("one report type at a time")
+    if vmode and not a.vcf:
+        ap.error("No variant call input (-vcf) supplied.")
+    if (vmode or a.dump) and a.sharded:
+        ap.error("-sharded applies to -hist and -completeness")
 
     import torch
     import torch.distributed as dist
@@ -117,6 +159,45 @@ def main(argv=None):
             print("TOTAL undrcpy:    %15.5f" % undr, file=sys.stderr)
             print("COMPLETENESS:             %0.5f" % (1.0 - undr / total if total else float("nan")), file=sys.stderr)
         if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    if a.dump or vmode:
+        # per-contig ordered output: contiguous run of contigs per rank, parts concatenated by rank 0
+        if vmode:
+            per = dict.fromkeys(names, 0)
+            with (gzip.open if a.vcf.endswith(".gz") else open)(a.vcf, "rb") as f:
+                for line in f:
+                    if line[:1] != b"#":
+                        c = line.split(b"\t", 1)[0].decode()
+                        if c in per:
+                            per[c] += 1
+            weights = [per[n] + 1e-9 * len(s) for n, s in zip(names, seqs)]
+            out = a.output + (".polish.vcf" if vmode[0] == "polish" else ".filter.vcf")      # merfin-variants.C:324-327
+        else:
+            weights = [len(s) for s in seqs]
+            out = a.output
+        lo, hi = D.contig_partition(weights, world)[rank]
+        part = "%s.part%04d" % (out, rank) if world > 1 else out
+        log("-- %s on %d GPU(s): rank 0 takes contigs [%d,%d) of %d." % ("-dump" if a.dump else "-" + vmode[0], world, lo, hi, len(names)))
+        if a.dump:
+            open(part, "wb").close()
+            tot_a = tot_m = 0
+            for c in range(lo, hi):
+                ka, km = ev.dump_contig(sq, c, names[c], part, append=True)
+                tot_a += ka
+                tot_m += km
+            cnt = torch.tensor([tot_a, tot_m], dtype=torch.int64)
+            if world > 1:
+                cnt = cnt.cuda() if backend == "nccl" else cnt
+                dist.all_reduce(cnt)
+            log("K-mers found in the assembly: %d, missing: %d" % (int(cnt[0]), int(cnt[1])))
+        else:
+            ev.variants(vmode[0], a.vcf, names[lo:hi], seqs[lo:hi], part, comb=a.comb, nosplit=a.nosplit)
+        if world > 1:
+            dist.barrier()
+            if rank == 0:
+                concat_parts(out, ["%s.part%04d" % (out, r) for r in range(world)], skip_header=bool(vmode))
             dist.barrier()
             dist.destroy_process_group()
         return
