@@ -27,6 +27,7 @@
 #include <atomic>
 #include <list>
 #include <map>
+#include <chrono>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -277,10 +278,14 @@ template <class F>
 void parallel_for(size_t n, F &&fn) {
   unsigned nt = std::min<size_t>(mfx_host_threads(), n);
   if (nt <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
+  const size_t chunk = std::max<size_t>(1, std::min<size_t>(64, n / (nt * 8)));
   std::atomic<size_t> next(0);
   std::vector<std::thread> th;
   for (unsigned t = 0; t < nt; ++t)
-    th.emplace_back([&]() { for (size_t i; (i = next.fetch_add(1)) < n;) fn(i); });
+    th.emplace_back([&]() {
+      for (size_t b; (b = next.fetch_add(chunk)) < n;)
+        for (size_t i = b, e = std::min(n, b + chunk); i < e; ++i) fn(i);
+    });
   for (auto &x : th) x.join();
 }
 
@@ -430,6 +435,13 @@ extern "C" int mfx_variants_run(mfx_eval *ev, const char *vcf_path, const char *
   FILE *log = log_path ? fopen(log_path, "w") : stderr;
   if (!log) return mfx_fail(MFX_E_IO, "cannot open '%s'", log_path);
 
+  // MFX_VAR_TIMING=1: per-phase wall time on stderr (diagnostics only)
+  const bool timing = getenv("MFX_VAR_TIMING") && atoi(getenv("MFX_VAR_TIMING"));
+  double t_phase[6] = {0, 0, 0, 0, 0, 0};                                // load+cluster, enumerate, pack, gpu, score+select, write
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_mark = now();
+  auto lap = [&](int i) { double t = now(); t_phase[i] += t - t_mark; t_mark = t; };
+
   VcfDB db;
   int rc = load_vcf(vcf_path, db);
   if (rc) { if (log != stderr) fclose(log); return rc; }
@@ -437,6 +449,7 @@ extern "C" int mfx_variants_run(mfx_eval *ev, const char *vcf_path, const char *
           db.headers.size(), db.records.size(), db.by_chr.size(), db.by_chr.size() == 1 ? "" : "s", (unsigned)db.contig_ids, (unsigned long)db.excluded);
   fprintf(log, "Merge variants within %u-mer bases, splitting combinations greater than %u.\n", K, comb);
   merge_clusters(db, K, comb, opts->nosplit != 0, log);
+  lap(0);
 
   FILE *out = fopen(out_path, "w");
   if (!out) { if (log != stderr) fclose(log); return mfx_fail(MFX_E_IO, "cannot open '%s' for writing", out_path); }
@@ -454,6 +467,9 @@ extern "C" int mfx_variants_run(mfx_eval *ev, const char *vcf_path, const char *
   const uint64_t BATCH_BYTES = 256ull << 20;                             // packed path text per GPU launch
 
   std::vector<Job> jobs;
+  jobs.reserve(65536);
+  std::vector<char> out_buf(4u << 20);
+  setvbuf(out, out_buf.data(), _IOFBF, out_buf.size());
   std::string packed;
   std::vector<uint32_t> rv, av;
 
@@ -461,6 +477,7 @@ extern "C" int mfx_variants_run(mfx_eval *ev, const char *vcf_path, const char *
   // with ONE GPU launch, applies the selectors (host threads), writes in input order.
   auto flush = [&]() -> int {
     if (jobs.empty()) return MFX_OK;
+    lap(5);
     parallel_for(jobs.size(), [&](size_t i) {
       Job &jb = jobs[i];
       std::vector<uint32_t> offs, vl;
@@ -468,6 +485,7 @@ extern "C" int mfx_variants_run(mfx_eval *ev, const char *vcf_path, const char *
       std::vector<int> path;
       enumerate(0, offs, vl, *jb.cl, std::string(bases[jb.contig] + jb.rStart, bases[jb.contig] + jb.rEnd), path, jb.ps);
     });
+    lap(1);
     uint64_t total = 0;
     for (Job &jb : jobs) {
       jb.first_id = varMerId;
@@ -479,6 +497,7 @@ extern "C" int mfx_variants_run(mfx_eval *ev, const char *vcf_path, const char *
       Job &jb = jobs[i];
       for (size_t p = 0; p < jb.ps.seqs.size(); ++p) memcpy(&packed[jb.off[p]], jb.ps.seqs[p].data(), jb.ps.seqs[p].size());
     });
+    lap(2);
     if (total) {
       const char *pb = packed.data();
       uint64_t plen = packed.size();
@@ -490,6 +509,7 @@ extern "C" int mfx_variants_run(mfx_eval *ev, const char *vcf_path, const char *
       mfx_seq_free(ps);
       if (r) return r;
     }
+    lap(3);
     const bool want_dbg = dbg != nullptr;
     parallel_for(jobs.size(), [&](size_t ji) {
       Job &jb = jobs[ji];
@@ -550,8 +570,10 @@ extern "C" int mfx_variants_run(mfx_eval *ev, const char *vcf_path, const char *
         }
       }
       jb.out = select_records(jb, sc, mode, K, chr, &jb.log);
-      PathSet().seqs.swap(jb.ps.seqs);                                   // release the path text early
+      jb.ps = PathSet();                                                 // release the per-path containers here, on the worker
+      std::vector<uint64_t>().swap(jb.off);
     });
+    lap(4);
     for (Job &jb : jobs) {
       if (!jb.log.empty()) fputs(jb.log.c_str(), log);
       if (dbg && !jb.dbg.empty()) fputs(jb.dbg.c_str(), dbg);
@@ -560,6 +582,7 @@ extern "C" int mfx_variants_run(mfx_eval *ev, const char *vcf_path, const char *
     }
     jobs.clear();
     packed.clear();
+    lap(5);
     return MFX_OK;
   };
 
@@ -601,6 +624,10 @@ extern "C" int mfx_variants_run(mfx_eval *ev, const char *vcf_path, const char *
     }
   }
   if (rc == MFX_OK) rc = flush();
+  lap(5);
+  if (timing)
+    fprintf(stderr, "[mfx_variants] load+cluster %.2fs  enumerate %.2fs  pack %.2fs  gpu %.2fs  score+select %.2fs  queue+write %.2fs\n",
+            t_phase[0], t_phase[1], t_phase[2], t_phase[3], t_phase[4], t_phase[5]);
   fclose(out);
   if (dbg) { if (dbg_pipe) pclose(dbg); else fclose(dbg); }
   if (log != stderr) fclose(log);
