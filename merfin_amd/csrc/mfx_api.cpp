@@ -146,15 +146,21 @@ extern "C" mfx_index *mfx_index_create(int k, uint64_t capacity_kmers, double ma
   ix->k = k;
   ix->capacity_kmers = capacity_kmers;
   ix->nlines = lines_for(capacity_kmers);
+  if (ix->nlines >= (1ull << 32)) {        // line numbers are 32-bit on the device (550 GB of table: beyond one GPU anyway)
+    mfx_fail(MFX_E_NOMEM, "Not enough memory to load databases.  %lu k-mers need %.0f GB on one GPU; shard the index (mfx_index_set_shard).",
+             (unsigned long)capacity_kmers, (double)ix->nlines * MFX_ALIGN / 1e9);
+    delete ix;
+    return nullptr;
+  }
   {
     // placement: "mz" (default) = minimizer-keyed home line, consecutive k-mers share 128-byte lines;
-    // "plain" = k-mer hash only.  w = 2 windows (m = k-1): a (k-1)-mer is contained in at most 8
-    // k-mers, so a minimizer's bucket always fits one line -- no skew even on repetitive genomes.
+    // "plain" = k-mer hash only.  w = 3 windows (m = k-2) by default; w = 2 bounds every minimizer's bucket by
+    // one line (a (k-1)-mer is contained in at most 8 k-mers) at 0.69 instead of 0.53 line fetches per k-mer.
     const char *hm = getenv("MFX_HOME_MODE");
     bool mz = hm ? (strcmp(hm, "plain") != 0) : true;
     const char *ws = getenv("MFX_MZ_W");
-    int w = ws ? atoi(ws) : 2;
-    if (w < 1 || w > 5) w = 2;
+    int w = ws ? atoi(ws) : 3;
+    if (w < 1 || w > 5) w = 3;
     ix->mz_w = mz ? std::min(w, k) : 0;
   }
   hipError_t e = hipMalloc((void **)&ix->d_slots, ix->nlines * MFX_ALIGN);

@@ -428,7 +428,7 @@ struct IndexImageHeader {
   uint64_t minV, maxV;
   uint64_t meta[4];          // distinct, non-canonical inserts, probe failures, reserved
   uint32_t slot_bytes, line_slots;
-  uint32_t filter_set, reserved;
+  uint32_t filter_set, layout;   // layout = MFX_LAYOUT_VERSION of the build that wrote the image
 };
 
 extern "C" int mfx_index_save(const mfx_index *ix, const char *path) {
@@ -445,6 +445,7 @@ extern "C" int mfx_index_save(const mfx_index *ix, const char *path) {
   h.minV = ix->minV; h.maxV = ix->maxV;
   h.slot_bytes = (uint32_t)sizeof(mfx_slot); h.line_slots = MFX_SLOTS_LINE;
   h.filter_set = ix->filter_set ? 1u : 0u;
+  h.layout = MFX_LAYOUT_VERSION;
   int rc = MFX_OK;
   if (hipMemcpy(h.meta, ix->d_meta, sizeof(h.meta), hipMemcpyDeviceToHost) != hipSuccess) rc = mfx_fail(MFX_E_HIP, "reading index metadata failed");
   if (rc == MFX_OK && fwrite(&h, sizeof(h), 1, f) != 1) rc = mfx_fail(MFX_E_IO, "short write to '%s'", path);
@@ -466,7 +467,7 @@ extern "C" mfx_index *mfx_index_load(const char *path, double max_gb, int device
   if (!f) { mfx_fail(MFX_E_IO, "cannot open '%s'", path); return nullptr; }
   IndexImageHeader h;
   if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "MFXINDX1", 8) != 0 || h.slot_bytes != sizeof(mfx_slot) ||
-      h.line_slots != MFX_SLOTS_LINE || h.k < 1 || h.k > 31 || h.nlines == 0) {
+      h.line_slots != MFX_SLOTS_LINE || h.k < 1 || h.k > 31 || h.nlines == 0 || h.nlines >= (1ull << 32) || h.layout != MFX_LAYOUT_VERSION) {
     fclose(f);
     mfx_fail(MFX_E_FORMAT, "'%s' is not an index image of this build", path);
     return nullptr;

@@ -41,6 +41,9 @@ constexpr uint32_t MFX_SLOTS_LINE = 8;          // 8 x 16-byte slots = one 128-b
 constexpr uint32_t MFX_NB_LDS     = 1024;       // K* bins per side privatised in LDS
 constexpr uint32_t MFX_MAXP_LDS   = 1024;       // read counts whose (readK, prob) is tabulated in LDS
 constexpr uint32_t MFX_KLUT       = 32;         // (readK, asmK) pairs below this use tabulated bin index / over-copy term
+// placement functions of the table (mfx_kernels.hip: mfx_minimizer, mfx_mz_line, mfx_home); index images
+// written under another version are refused by mfx_index_load
+constexpr uint32_t MFX_LAYOUT_VERSION = 2u;
 constexpr uint32_t MFX_OVF_CAP    = 1u << 20;   // histogram overflow records per evaluator
 
 struct mfx_slot {               // 16 bytes: one dwordx4 load per probe

@@ -26,6 +26,14 @@ __device__ __forceinline__ uint64_t mfx_hash64(uint64_t x) {
   return x;
 }
 
+// floor(x * n / 2^64) for n < 2^32 (the table never has more lines: mfx_index_create): two 32-bit
+// multiplies instead of the four a general 64x64 high product takes.  Same value as __umul64hi(x, n).
+__device__ __forceinline__ uint32_t mfx_range32(uint64_t x, uint64_t n) {
+  const uint32_t n32 = (uint32_t)n;
+  const uint64_t t = (uint64_t)(uint32_t)(x >> 32) * n32 + (uint64_t)__umulhi((uint32_t)x, n32);
+  return (uint32_t)(t >> 32);
+}
+
 __device__ __forceinline__ uint64_t mfx_revcomp(uint64_t fwd, int k) {
   uint64_t x = __brevll(fwd) >> (64 - 2 * k);                       // groups reversed, bits in each pair swapped
   x = ((x & 0x5555555555555555ULL) << 1) | ((x >> 1) & 0x5555555555555555ULL);
@@ -45,9 +53,13 @@ __device__ __forceinline__ uint64_t mfx_revcomp(uint64_t fwd, int k) {
 //
 // Why the minimizer: consecutive k-mers of a sequence share their minimizer
 // for runs of ~(w+1)/2 positions, so their probes fall into the SAME 128-byte
-// line -- fewer than one HBM line fetch per k-mer.  Default w = 2 windows
-// (m = k-1): a (k-1)-mer occurs in at most 8 k-mers, so a minimizer's bucket
-// always fits one line (no skew on repetitive genomes); w up to 5 is selectable.
+// line -- fewer than one HBM line fetch per k-mer.  Default w = 3 windows
+// (m = k-2, 0.53 line fetches per k-mer): a (k-2)-mer occurs in at most 48 k-mers,
+// in practice a handful (its 2-3 genomic k-mers plus their sequencing-error
+// neighbours), and a bucket that outgrows its line spills into region A's next
+// lines.  w = 2 (m = k-1) bounds every bucket by 8 = one line (0.69 fetches per
+// k-mer); w up to 5 is selectable (MFX_MZ_W); larger w costs more hashing per k-mer
+// than the saved fetches return (profiles/r01_placement_w.txt).
 // ---------------------------------------------------------------------------
 constexpr uint32_t MFX_MZ_REGION = 4;
 constexpr uint32_t MFX_MAX_LINES = 512;
@@ -56,37 +68,43 @@ struct mfx_probe {
   uint32_t lineA, lineB, p1;
 };
 
-__device__ __forceinline__ uint64_t mfx_minimizer_hash(uint64_t key, uint64_t rc, int k, int w) {
+// Canonical minimizer of a k-mer: of its w windows of m = k-w+1 bases, the canonical m-mer
+// whose ORDER hash is smallest.  Only the order matters, so the order hash is cheap (the
+// m-mer folded to 32 bits, one 32-bit multiply; equal hashes: the first window wins -- a pure
+// function of (key, rc), which is all insert and lookup need to agree on).
+__device__ __forceinline__ uint64_t mfx_minimizer(uint64_t key, uint64_t rc, int k, int w) {
   const int m = k - w + 1;
   const uint64_t mmask = (~0ULL) >> (64 - 2 * m);
-  uint64_t best = ~0ULL;
+  uint64_t best = 0;
+  uint32_t best_o = 0;
 #pragma unroll
   for (int j = 0; j < 5; ++j) {
     if (j < w) {
       uint64_t a = (key >> (2 * j)) & mmask;                 // m-mer starting at base w-1-j
       uint64_t b = (rc >> (2 * (w - 1 - j))) & mmask;        // its reverse complement
       uint64_t c = a < b ? a : b;                            // canonical m-mer: strand independent
-      uint64_t h = c * 0x9E3779B97F4A7C15ULL;                // bijective on 64 bits: a total random-ish order
-      best = h < best ? h : best;
+      uint32_t o = ((uint32_t)c ^ (uint32_t)(c >> 32)) * 0x9E3779B1u;
+      const bool take = (j == 0) || (o < best_o);
+      best = take ? c : best;
+      best_o = take ? o : best_o;
     }
   }
   return best;
 }
 
-// line of a k-mer's minimizer.  `best` is a minimum (biased towards small values), so it is
-// re-spread with one more odd multiplication before the multiply-range reduction.
+// line of a k-mer's minimizer: one odd 64-bit multiplication (the high half of the product
+// depends on every bit of the m-mer), then the multiply-range reduction.  The multiplier must
+// be unrelated to the order hash's: the minimizer is the window with the SMALLEST order hash,
+// so a line hash correlated with it would crowd the low lines.
 __device__ __forceinline__ uint32_t mfx_mz_line(const mfx_table_view &t, uint64_t key, uint64_t krc) {
-  uint64_t best = mfx_minimizer_hash(key, krc, t.k, t.mz_w);
-  uint64_t x = best * 0xD6E8FEB86659FD93ULL;
-  x ^= x >> 32;
-  return (uint32_t)__umul64hi(x * 0xFF51AFD7ED558CCDULL, t.nlines);
+  return mfx_range32(mfx_minimizer(key, krc, t.k, t.mz_w) * 0xD6E8FEB86659FD93ULL, t.nlines);
 }
 
 __device__ __forceinline__ mfx_probe mfx_home(const mfx_table_view &t, uint64_t key) {
   mfx_probe pr;
   uint64_t h = mfx_hash64(key);
   pr.p1 = (uint32_t)h & (MFX_SLOTS_LINE - 1);
-  pr.lineB = (uint32_t)__umul64hi(h, t.nlines);
+  pr.lineB = mfx_range32(h, t.nlines);
   pr.lineA = pr.lineB;
   if (t.mz_w > 0)
     pr.lineA = mfx_mz_line(t, key, mfx_revcomp(key, t.k));
@@ -96,12 +114,12 @@ __device__ __forceinline__ mfx_probe mfx_home(const mfx_table_view &t, uint64_t 
 // first candidate line only (the hot path needs nothing else); krc = revcomp(key)
 __device__ __forceinline__ uint32_t mfx_first_line(const mfx_table_view &t, uint64_t key, uint64_t krc) {
   if (t.mz_w > 0) return mfx_mz_line(t, key, krc);
-  return (uint32_t)__umul64hi(mfx_hash64(key), t.nlines);
+  return mfx_range32(mfx_hash64(key), t.nlines);
 }
 
 // owner rank of a k-mer in a sharded index (independent of the line hash bits)
 __device__ __forceinline__ uint32_t mfx_owner(const mfx_table_view &t, uint64_t key, uint64_t krc, uint32_t nranks) {
-  uint64_t h = t.mz_w > 0 ? mfx_minimizer_hash(key, krc, t.k, t.mz_w) : key * 0xA24BAED4963EE407ULL;
+  uint64_t h = t.mz_w > 0 ? mfx_minimizer(key, krc, t.k, t.mz_w) : key * 0xA24BAED4963EE407ULL;
   return (uint32_t)__umul64hi(mfx_hash64(h ^ 0x5851F42D4C957F2DULL), (uint64_t)nranks);
 }
 

@@ -165,6 +165,27 @@ def _codes(seq):
     return _LUT[seq.long()]
 
 
+def strand_kmers(seq, k):
+    """(forward k-mer, reverse-complement k-mer, valid) int64/int64/bool [n-k+1] of an ASCII uint8 tensor"""
+    n = seq.numel()
+    if n < k:
+        z = torch.zeros(0, dtype=torch.int64, device=seq.device)
+        return z, z, z.bool()
+    c = _codes(seq)
+    inv = (c > 3)
+    c = c & 3
+    m = n - k + 1
+    f = torch.zeros(m, dtype=torch.int64, device=seq.device)
+    r = torch.zeros(m, dtype=torch.int64, device=seq.device)
+    for j in range(k):
+        w = c[j:j + m]
+        f = (f << 2) | w
+        r = r | ((w ^ 2) << (2 * j))
+    cs = torch.cumsum(inv.to(torch.int32), 0)
+    win = cs[k - 1:] - torch.cat([torch.zeros(1, dtype=cs.dtype, device=cs.device), cs[:m - 1]])
+    return f, r, win == 0
+
+
 def canonical_kmers(seq, k):
     """(canonical k-mer int64 [n-k+1], valid bool [n-k+1]) of an ASCII uint8 tensor"""
     n = seq.numel()
@@ -237,7 +258,32 @@ def add_error_kmers(ix, n_err, k, seed=SEED, chunk=1 << 25):
         ix.add_read(km.contiguous(), v.contiguous())
 
 
-def build_world(m, total_bases, k=21, lam=26.0, ncontigs=24, seed=SEED, device=0, err_factor=1.0, verbose=None):
+def add_neighbor_error_kmers(ix, truth, k, seed=SEED, per_position=1.0, chunk=1 << 25):
+    """Error k-mers the way sequencing makes them: single-base substitutions of TRUE k-mers (about `per_position`
+    per genome position, counts {1: 80 %, 2: 15 %, 3: 5 %}).  Unlike uniformly random k-mers they share (k-1)- and
+    (k-2)-mers with their parent, i.e. they land in the parent's minimizer bucket -- the harder case for the
+    minimizer-keyed placement.  Not the bench workload (SURVEY 8d specifies random error k-mers); robustness check."""
+    for ci, t in enumerate(truth):
+        dev = t.device
+        n = t.numel()
+        for o in range(0, max(n - k + 1, 0), chunk):
+            m = min(chunk, n - k + 1 - o)
+            f, r, ok = strand_kmers(t[o:o + m + k - 1], k)
+            h = _hash_range(seed + 7770001 * (ci + 1), o, m, dev)
+            keep = ok & ((_lsr(h, 40).double() * (1.0 / (1 << 24))) < per_position)
+            j = _lsr(h, 3) % k                                  # substituted base, 0 = leftmost
+            d = 1 + (_lsr(h, 17) % 3)                           # code xor 1..3: always a different base
+            f2 = f ^ (d << (2 * (k - 1 - j)))
+            r2 = r ^ (d << (2 * j))
+            km = torch.minimum(f2, r2)
+            u = _lsr(splitmix64(h), 11).double() * (1.0 / (1 << 53))
+            v = (1 + (u >= 0.8).to(torch.int32) + (u >= 0.95).to(torch.int32))
+            v = torch.where(keep, v, torch.zeros_like(v))
+            ix.add_read(km.contiguous(), v.contiguous())
+
+
+def build_world(m, total_bases, k=21, lam=26.0, ncontigs=24, seed=SEED, device=0, err_factor=1.0, verbose=None,
+                err_mode="random"):
     """Full synthetic -hist workload resident on `device`: returns (index, sequences, info)."""
     import time
     torch.cuda.set_device(device)
@@ -255,8 +301,11 @@ def build_world(m, total_bases, k=21, lam=26.0, ncontigs=24, seed=SEED, device=0
     add_reads_from_truth(ix, truth, k, lam, seed)
     torch.cuda.synchronize()
     say("read counts from truth added: %.1fs" % (time.time() - t0))
+    if err_mode == "neighbor":
+        add_neighbor_error_kmers(ix, truth, k, seed, per_position=err_factor)
     del truth
-    add_error_kmers(ix, n_err, k, seed)
+    if err_mode != "neighbor":
+        add_error_kmers(ix, n_err, k, seed)
     torch.cuda.synchronize()
     say("error k-mers added: %.1fs" % (time.time() - t0))
     seqs = m.Sequences.from_device([a.data_ptr() for a in asm], [a.numel() for a in asm], device=device)
