@@ -159,8 +159,8 @@ extern "C" mfx_index *mfx_index_create(int k, uint64_t capacity_kmers, double ma
     const char *hm = getenv("MFX_HOME_MODE");
     bool mz = hm ? (strcmp(hm, "plain") != 0) : true;
     const char *ws = getenv("MFX_MZ_W");
-    int w = ws ? atoi(ws) : 3;
-    if (w < 1 || w > 5) w = 3;
+    int w = ws ? atoi(ws) : MFX_MZ_W_DEFAULT;
+    if (w < 1 || w > 5) w = MFX_MZ_W_DEFAULT;
     ix->mz_w = mz ? std::min(w, k) : 0;
   }
   hipError_t e = hipMalloc((void **)&ix->d_slots, ix->nlines * MFX_ALIGN);

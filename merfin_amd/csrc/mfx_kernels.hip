@@ -111,8 +111,11 @@ __device__ __forceinline__ mfx_probe mfx_home(const mfx_table_view &t, uint64_t 
   return pr;
 }
 
-// first candidate line only (the hot path needs nothing else); krc = revcomp(key)
+// first candidate line only (the hot path needs nothing else); krc = revcomp(key).
+// W > 0: the caller guarantees t.mz_w == W, so the window loop unrolls into straight-line code.
+template <int W = 0>
 __device__ __forceinline__ uint32_t mfx_first_line(const mfx_table_view &t, uint64_t key, uint64_t krc) {
+  if (W > 0) return mfx_range32(mfx_minimizer(key, krc, t.k, W) * 0xD6E8FEB86659FD93ULL, t.nlines);
   if (t.mz_w > 0) return mfx_mz_line(t, key, krc);
   return mfx_range32(mfx_hash64(key), t.nlines);
 }
@@ -321,7 +324,7 @@ __device__ __forceinline__ void mfx_group_post(mfx_mailbox &M, const uint4 (&v)[
 }
 
 // B queries per lane; ok[j] false = no query.  Results: rv[j], av[j].
-template <int B>
+template <int B, int W = 0>
 __device__ __forceinline__ void mfx_group_lookup(const mfx_table_view &t, mfx_mailbox &M, const uint64_t (&key)[B],
                                                  const uint64_t (&krc)[B], const bool (&ok)[B], uint32_t (&rv)[B],
                                                  uint32_t (&av)[B]) {
@@ -330,7 +333,8 @@ __device__ __forceinline__ void mfx_group_lookup(const mfx_table_view &t, mfx_ma
   uint32_t pending[B];          // 0 resolved, 1 home line full: continue at candidate line 1
 #pragma unroll
   for (int j = 0; j < B; ++j) {
-    line[j] = ok[j] ? mfx_first_line(t, key[j], krc[j]) : 0u;      // no k-mer here: a dummy query of line 0, ignored below
+    const uint32_t fl = mfx_first_line<W>(t, key[j], krc[j]);
+    line[j] = ok[j] ? fl : 0u;                                     // no k-mer here: a dummy query of line 0, ignored below
     pending[j] = 0u;
     rv[j] = av[j] = 0u;
   }
@@ -591,7 +595,8 @@ __device__ __forceinline__ void mfx_hist_lds_flush(mfx_hist_lds &H, const mfx_ks
   if (tid == 0) ka.partials[blockIdx.x] = H.dred[0];
 }
 
-template <bool CANON>
+// W: the table's minimizer window count when it is the default one (straight-line placement code), else 0
+template <bool CANON, int W>
 __global__ __launch_bounds__(MFX_BLOCK, 4) void mfx_hist_kernel(mfx_hist_args a) {
   __shared__ mfx_tile_lds L;
   __shared__ mfx_mailbox MB;
@@ -659,11 +664,11 @@ __global__ __launch_bounds__(MFX_BLOCK, 4) void mfx_hist_kernel(mfx_hist_args a)
           key[j] = f; key2[j] = r;
         }
       }
-      mfx_group_lookup<MFX_BATCH>(a.t, MB, key, key2, ok, rv, av);
+      mfx_group_lookup<MFX_BATCH, W>(a.t, MB, key, key2, ok, rv, av);
       if (!CANON) {
         // value(fmer) + value(rmer), uint32 arithmetic (merfin-globals.C:107-108)
         uint32_t rv2[MFX_BATCH], av2[MFX_BATCH];
-        mfx_group_lookup<MFX_BATCH>(a.t, MB, key2, key, ok, rv2, av2);
+        mfx_group_lookup<MFX_BATCH, W>(a.t, MB, key2, key, ok, rv2, av2);
 #pragma unroll
         for (int j = 0; j < MFX_BATCH; ++j) { rv[j] += rv2[j]; av[j] += av2[j]; }
       }
@@ -1022,8 +1027,10 @@ hipError_t mfx_k_table_export(mfx_table_view t, uint64_t *kmers, uint32_t *readV
 hipError_t mfx_k_hist(const mfx_hist_args &a, int grid, hipStream_t st) {
   // MFX_DEBUG_DYN_LDS: extra dynamic LDS per block, an occupancy knob for experiments only
   static const unsigned dyn = getenv("MFX_DEBUG_DYN_LDS") ? (unsigned)atoi(getenv("MFX_DEBUG_DYN_LDS")) : 0u;
-  if (a.canonical) mfx_hist_kernel<true><<<grid, MFX_BLOCK, dyn, st>>>(a);
-  else             mfx_hist_kernel<false><<<grid, MFX_BLOCK, dyn, st>>>(a);
+  // the common case (canonical DB, default placement) gets the window loop unrolled at compile time
+  if (a.canonical && a.t.mz_w == MFX_MZ_W_DEFAULT) mfx_hist_kernel<true, MFX_MZ_W_DEFAULT><<<grid, MFX_BLOCK, dyn, st>>>(a);
+  else if (a.canonical)                            mfx_hist_kernel<true, 0><<<grid, MFX_BLOCK, dyn, st>>>(a);
+  else                                             mfx_hist_kernel<false, 0><<<grid, MFX_BLOCK, dyn, st>>>(a);
   return hipGetLastError();
 }
 hipError_t mfx_k_route(const mfx_route_args &a, hipStream_t st) {
@@ -1065,7 +1072,7 @@ hipError_t mfx_k_sum_tile_partials(double *tile_partials, uint64_t ntiles, doubl
 }
 int mfx_k_hist_resident_blocks() {
   int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mfx_hist_kernel<true>, MFX_BLOCK, 0) != hipSuccess || nb < 1) nb = 4;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mfx_hist_kernel<true, MFX_MZ_W_DEFAULT>, MFX_BLOCK, 0) != hipSuccess || nb < 1) nb = 4;
   return nb;
 }
 hipError_t mfx_k_dump(const mfx_dump_args &a, hipStream_t st) {
