@@ -23,6 +23,9 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <atomic>
+#include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -195,8 +198,9 @@ std::string meryl_file_name(const std::string &dir, uint32_t file, const char *e
 }
 
 // decode every block of one .merylData file; emit(kmer, value)
+// count_only: stop after each block's header (the k-mer count lives there)
 template <class F>
-int read_meryl_data(const std::string &path, uint32_t file, const MerylIndex &mi, F &&emit, uint64_t *count) {
+int read_meryl_data(const std::string &path, uint32_t file, const MerylIndex &mi, F &&emit, uint64_t *count, bool count_only = false) {
   FILE *f = fopen(path.c_str(), "rb");
   if (!f) return MFX_OK;                                    // a piece with no k-mers may be absent
   StuffedFile sf;
@@ -231,6 +235,7 @@ int read_meryl_data(const std::string &path, uint32_t file, const MerylIndex &mi
                     path.c_str(), kcode, ccode, ubits, bbits, mi.suffixSize, (unsigned long)prefix);
       break;
     }
+    if (count_only) { *count += nk; continue; }
     std::vector<uint64_t> sfx(nk);
     uint64_t hi = 0;
     for (uint64_t i = 0; i < nk; ++i) {
@@ -252,6 +257,35 @@ int read_meryl_data(const std::string &path, uint32_t file, const MerylIndex &mi
   return rc;
 }
 
+// The 64 files of a meryl database are independent: decode them on the host threads the library may use.
+// fn(file) returns MFX_OK or a failure whose message is in the CALLING thread's mfx_last_error(); the first
+// failure (lowest file number wins) is re-raised on this thread.
+template <class F>
+int for_each_meryl_file(F &&fn) {
+  const unsigned nt = std::max(1u, std::min(64u, (unsigned)mfx_host_threads()));
+  std::atomic<uint32_t> next(0);
+  std::mutex emu;
+  int bad_rc = MFX_OK;
+  uint32_t bad_file = 64;
+  std::string bad_msg;
+  auto work = [&]() {
+    for (uint32_t fl; (fl = next.fetch_add(1)) < 64;) {
+      int rc = fn(fl);
+      if (rc != MFX_OK) {
+        std::lock_guard<std::mutex> g(emu);
+        if (fl < bad_file) { bad_file = fl; bad_rc = rc; bad_msg = mfx_last_error(); }
+      }
+    }
+  };
+  if (nt == 1) work();
+  else {
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t) th.emplace_back(work);
+    for (auto &x : th) x.join();
+  }
+  return bad_rc == MFX_OK ? MFX_OK : mfx_fail(bad_rc, "%s", bad_msg.c_str());
+}
+
 int detect(const std::string &path) {
   if (is_dir(path)) return MFX_DB_MERYL;
   if (!is_file(path)) return 0;
@@ -269,11 +303,14 @@ struct Feeder {
   mfx_index *ix;
   int side;
   uint64_t minV, maxV;
+  std::mutex *mu = nullptr;            // several decoder threads feed one index: inserts are serialised
   std::vector<uint64_t> k;
   std::vector<uint32_t> v;
   int rc = MFX_OK;
   void flush() {
     if (k.empty() || rc) return;
+    std::unique_lock<std::mutex> lk;
+    if (mu) lk = std::unique_lock<std::mutex>(*mu);
     rc = side ? mfx_index_add_asm(ix, k.data(), v.data(), k.size(), 0)
               : mfx_index_add_read(ix, k.data(), v.data(), k.size(), minV, maxV, 0);
     k.clear(); v.clear();
@@ -346,9 +383,12 @@ extern "C" int mfx_db_probe(const char *path, mfx_db_info *out) {
   if (rc) return rc;
   out->k = (int)((mi.prefixSize + mi.suffixSize) / 2);
   // distinct k-mer count: sum of the block headers (cheap pass over the 64 data files)
+  std::vector<uint64_t> per(64, 0);
+  rc = for_each_meryl_file([&](uint32_t fl) {
+    return read_meryl_data(meryl_file_name(p, fl, ".merylData"), fl, mi, [](uint64_t, uint32_t) {}, &per[fl], true);
+  });
   uint64_t n = 0;
-  for (uint32_t fl = 0; fl < 64 && rc == MFX_OK; ++fl)
-    rc = read_meryl_data(meryl_file_name(p, fl, ".merylData"), fl, mi, [](uint64_t, uint32_t) {}, &n);
+  for (uint64_t x : per) n += x;
   out->n_kmers = n;
   return rc;
 }
@@ -391,8 +431,16 @@ extern "C" int mfx_index_load_db(mfx_index *ix, const char *path, int side, uint
     rc = read_meryl_master(p, mi);
     if (rc == MFX_OK && (int)((mi.prefixSize + mi.suffixSize) / 2) != ix->k)
       rc = mfx_fail(MFX_E_INVAL, "'%s' holds %u-mers but the index is built for k=%d", path, (mi.prefixSize + mi.suffixSize) / 2, ix->k);
-    for (uint32_t fl = 0; fl < 64 && rc == MFX_OK; ++fl)
-      rc = read_meryl_data(meryl_file_name(p, fl, ".merylData"), fl, mi, [&](uint64_t km, uint32_t v) { fd.push(km, v); }, &n);
+    if (rc == MFX_OK) {
+      std::mutex mu;
+      rc = for_each_meryl_file([&](uint32_t fl) {
+        Feeder tf{ix, side, minV, maxV, &mu};
+        uint64_t cnt = 0;
+        int r = read_meryl_data(meryl_file_name(p, fl, ".merylData"), fl, mi, [&](uint64_t km, uint32_t v) { tf.push(km, v); }, &cnt);
+        if (r == MFX_OK) tf.flush();
+        return r ? r : tf.rc;
+      });
+    }
   }
   if (rc == MFX_OK) fd.flush();
   return rc ? rc : fd.rc;

@@ -55,6 +55,35 @@ def test_db_errors_are_reported(tmp_path):
 
 
 @pytest.mark.gpu
+def test_corrupt_meryl_piece_is_reported_from_the_decoder_threads(tmp_path, monkeypatch):
+    """the 64 data files are decoded on several host threads; a failure in any of them must reach the caller
+    (code + the message naming the lowest-numbered bad file), and a single-threaded run must say the same"""
+    import glob
+    import os
+    import merfin_amd as m
+    k = 21
+    contigs, read, asm = synth.world(k=k, seed=52, sizes=(20000,), err_kmers=0)
+    mdir = str(tmp_path / "r.meryl")
+    meryl_layout.write_db(mdir, k, read[0], read[1], prefix_bits=12)
+    files = sorted(f for f in glob.glob(mdir + "/*.merylData") if os.path.getsize(f) > 200)
+    assert len(files) >= 8
+    for f in (files[5], files[2]):                           # damage two pieces: the payload after the block tables
+        raw = bytearray(open(f, "rb").read())
+        raw[-64:] = b"\xff" * 64
+        raw[40:48] = b"\x00" * 8
+        open(f, "wb").write(bytes(raw))
+    msgs = []
+    for threads in ("8", "1"):
+        monkeypatch.setenv("MFX_HOST_THREADS", threads)
+        ix = m.Index(k, len(read[0]) + 16)
+        with pytest.raises(m.MfxError) as e:
+            ix.load_db(mdir, 0)
+        assert e.value.code == -7
+        msgs.append(str(e.value))
+    assert msgs[0] == msgs[1] and os.path.basename(files[2]) in msgs[0]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["mz", "plain"])
 def test_index_image_round_trip(tmp_path, mode, monkeypatch):
     """save -> load of the device-format index: identical contents and identical -hist."""
