@@ -11,6 +11,7 @@
 #include <string.h>
 #include <libgen.h>
 
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -158,6 +159,16 @@ int main(int argc, char **argv) {
     return 1;
   }
 
+  // MFX_CLI_TIMING=1: wall time per phase on stderr at exit (diagnostics; not part of merfin's output)
+  const bool timing = getenv("MFX_CLI_TIMING") && atoi(getenv("MFX_CLI_TIMING"));
+  auto t_last = std::chrono::steady_clock::now();
+  std::vector<std::pair<const char *, double>> phases;
+  auto lap = [&](const char *what) {
+    auto t = std::chrono::steady_clock::now();
+    phases.emplace_back(what, std::chrono::duration<double>(t - t_last).count());
+    t_last = t;
+  };
+
   if (!load_Kmetric(G)) return 1;
 
   // load_Kmers, merfin-globals.C:114-163: the read DB defines k
@@ -170,6 +181,7 @@ int main(int argc, char **argv) {
     if (adb.k != k) { fprintf(stderr, "ERROR: -seqmers holds %d-mers but -readmers holds %d-mers.\n", adb.k, k); return 1; }
   }
 
+  lap("probe k-mer databases");
   // sequences (load_Sequence, merfin-globals.C:165-197; loadSequence, merfin.C:30-53)
   std::vector<SeqRecord> recs;
   if (G.seqName) {
@@ -184,12 +196,14 @@ int main(int argc, char **argv) {
   uint64_t totalBases = 0;
   for (size_t i = 0; i < recs.size(); ++i) { bases[i] = recs[i].bases.data(); lens[i] = recs[i].bases.size(); totalBases += lens[i]; }
 
+  lap("read sequences");
   mfx_index *ix = nullptr;
   mfx_seq *seq = nullptr;
   if (!recs.empty() || G.seqName) {
     seq = mfx_seq_upload(G.device, bases.data(), lens.data(), (uint32_t)recs.size());
     if (!seq) DIE_MFX("uploading sequences");
   }
+  lap("upload sequences");
   FILE *probe = G.indexName ? fopen(G.indexName, "rb") : nullptr;
   if (probe) {
     fclose(probe);
@@ -224,6 +238,7 @@ int main(int argc, char **argv) {
     }
   }
 
+  lap("build / load index");
   mfx_kparams kp{G.peak, (uint32_t)G.copyKmerK.size(), G.copyKmerK.data(), G.copyKmerP.data()};
   mfx_eval *ev = mfx_eval_create(ix, &kp, 0);
   if (!ev) DIE_MFX("creating evaluator");
@@ -295,9 +310,16 @@ int main(int argc, char **argv) {
     fprintf(stderr, "COMPLETENESS:             %0.5f\n", 1.0 - undrc / total);
   }
 
+  lap("evaluate + write");
   mfx_eval_free(ev);
   if (seq) mfx_seq_free(seq);
   mfx_index_free(ix);
+  lap("release");
+  if (timing) {
+    fprintf(stderr, "-- timing:");
+    for (auto &ph : phases) fprintf(stderr, "  %s %.2fs", ph.first, ph.second);
+    fprintf(stderr, "\n");
+  }
   fprintf(stderr, "Bye!\n");
   return rc;
 }

@@ -21,6 +21,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
+#include <unistd.h>
+#include <sys/mman.h>
+#include <fcntl.h>
 
 #include <algorithm>
 #include <atomic>
@@ -404,24 +407,33 @@ extern "C" int mfx_index_load_db(mfx_index *ix, const char *path, int side, uint
   uint64_t n = 0;
   int rc = MFX_OK;
   if (fmt == MFX_DB_FLAT) {
-    FILE *f = fopen(path, "rb");
+    // The file is mapped and handed to the insert path in large chunks: the staging copies into pinned memory
+    // (threaded, mfx_index_add_*) then read the page cache / disk in parallel instead of one fread stream.
+    int fdn = open(path, O_RDONLY);
+    struct stat st;
+    if (fdn < 0 || fstat(fdn, &st) != 0) { if (fdn >= 0) close(fdn); return mfx_fail(MFX_E_IO, "cannot open '%s'", path); }
     FlatHeader h;
-    if (!f || fread(&h, sizeof(h), 1, f) != 1) { if (f) fclose(f); return mfx_fail(MFX_E_FORMAT, "'%s': truncated header", path); }
-    if ((int)h.k != ix->k) { fclose(f); return mfx_fail(MFX_E_INVAL, "'%s' holds %u-mers but the index is built for k=%d", path, h.k, ix->k); }
-    const uint64_t CH = 1u << 22;
-    std::vector<uint64_t> kb(CH);
-    std::vector<uint32_t> vb(CH);
-    long base = (long)sizeof(h);
-    for (uint64_t o = 0; o < h.n && rc == MFX_OK; o += CH) {
-      uint64_t m = std::min<uint64_t>(CH, h.n - o);
-      if (fseek(f, base + (long)(o * 8), SEEK_SET) || fread(kb.data(), 8, m, f) != m ||
-          fseek(f, base + (long)(h.n * 8 + o * 4), SEEK_SET) || fread(vb.data(), 4, m, f) != m) {
-        rc = mfx_fail(MFX_E_FORMAT, "'%s': truncated payload", path);
-        break;
-      }
-      for (uint64_t i = 0; i < m; ++i) fd.push(kb[i], vb[i]);
+    if ((uint64_t)st.st_size < sizeof(h) || pread(fdn, &h, sizeof(h), 0) != (ssize_t)sizeof(h)) {
+      close(fdn);
+      return mfx_fail(MFX_E_FORMAT, "'%s': truncated header", path);
     }
-    fclose(f);
+    if ((int)h.k != ix->k) { close(fdn); return mfx_fail(MFX_E_INVAL, "'%s' holds %u-mers but the index is built for k=%d", path, h.k, ix->k); }
+    if ((uint64_t)st.st_size < sizeof(h) + h.n * 12) { close(fdn); return mfx_fail(MFX_E_FORMAT, "'%s': truncated payload", path); }
+    if (h.n) {
+      void *map = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fdn, 0);
+      if (map == MAP_FAILED) { close(fdn); return mfx_fail(MFX_E_IO, "cannot map '%s'", path); }
+      (void)madvise(map, (size_t)st.st_size, MADV_SEQUENTIAL);
+      const uint64_t *kb = reinterpret_cast<const uint64_t *>((const char *)map + sizeof(h));
+      const uint32_t *vb = reinterpret_cast<const uint32_t *>((const char *)map + sizeof(h) + h.n * 8);
+      const uint64_t CH = 1u << 26;
+      for (uint64_t o = 0; o < h.n && rc == MFX_OK; o += CH) {
+        const uint64_t m = std::min<uint64_t>(CH, h.n - o);
+        rc = side ? mfx_index_add_asm(ix, kb + o, vb + o, m, 0)
+                  : mfx_index_add_read(ix, kb + o, vb + o, m, minV, maxV, 0);
+      }
+      munmap(map, (size_t)st.st_size);
+    }
+    close(fdn);
   } else if (fmt == MFX_DB_TEXT) {
     int k = 0;
     rc = scan_text(p, &k, [&](uint64_t km, uint32_t v) { fd.push(km, v); }, &n);
