@@ -802,6 +802,14 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_hist_keys_kernel(mfx_hist_keys_
   double kover = 0.0;
   uint64_t *c_glob = ka.counts + 2ull * ka.nbins;
   uint64_t *c_kmis = c_glob + 3 + ka.ncontigs;
+  // Per-contig kmissing: the k-mers arrive in sequence order per source, so a block's slice is almost always
+  // inside ONE contig.  Misses of that contig are counted in LDS (one wave-aggregated add) and flushed once;
+  // only a slice that straddles contigs sends the others straight to the global counters.  (One global atomic
+  // per missing k-mer made every block queue on the same few addresses: 5x the kernel time.)
+  __shared__ uint32_t s_kmis;
+  const uint32_t bctg = i0 < i1 ? a.contig[i0] : 0u;               // block-uniform
+  if (tid == 0) s_kmis = 0u;
+  __syncthreads();
   for (uint64_t base = i0; base < i1; base += MFX_BLOCK * MFX_BATCH) {       // block-uniform trip count
     uint64_t key[MFX_BATCH], krc[MFX_BATCH];
     uint32_t rv[MFX_BATCH], av[MFX_BATCH];
@@ -816,17 +824,22 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_hist_keys_kernel(mfx_hist_keys_
     mfx_group_lookup<MFX_BATCH>(a.t, MB, key, krc, ok, rv, av);
 #pragma unroll
     for (int j = 0; j < MFX_BATCH; ++j) {
-      if (!ok[j]) continue;
-      if (mfx_hist_eval(H, ka, lut_ok, rv[j], av[j], n_over0, kover)) {
+      const bool miss = ok[j] && mfx_hist_eval(H, ka, lut_ok, rv[j], av[j], n_over0, kover);
+      const uint32_t cg = miss ? a.contig[base + (uint64_t)j * MFX_BLOCK + tid] : bctg;
+      const bool here = miss && cg == bctg;
+      const uint64_t m = __ballot(here);                                      // wave-uniform control flow up to here
+      if (m != 0ull && (tid & 63u) == (uint32_t)__ffsll((long long)m) - 1u) atomicAdd(&s_kmis, (uint32_t)__popcll(m));
+      if (miss) {
         n_missing++;
-        atomicAdd((unsigned long long *)&c_kmis[a.contig[base + (uint64_t)j * MFX_BLOCK + tid]], 1ull);
+        if (!here) atomicAdd((unsigned long long *)&c_kmis[cg], 1ull);
       }
     }
   }
-  mfx_block_sum3(n_missing, n_over0, zz, H.red);
+  mfx_block_sum3(n_missing, n_over0, zz, H.red);                              // has barriers: s_kmis is complete after it
   if (tid == 0) {
     if (n_missing) atomicAdd((unsigned long long *)&c_glob[1], n_missing);
     if (n_over0) atomicAdd((unsigned long long *)&ka.counts[ka.nbins], n_over0);
+    if (s_kmis) atomicAdd((unsigned long long *)&c_kmis[bctg], (unsigned long long)s_kmis);
   }
   mfx_hist_lds_flush(H, ka, kover);
 }
