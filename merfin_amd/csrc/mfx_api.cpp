@@ -817,6 +817,8 @@ struct mfx_router {
   uint64_t *d_dest = nullptr;        // [256]
   void     *d_tmp = nullptr;
   size_t    tmp_bytes = 0;
+  uint32_t *d_tile_cnt = nullptr;    // [max_tiles * nranks] sort-free path (nranks <= MFX_SPLIT_MAX_RANKS)
+  bool      split = false;
 };
 
 int mfx_sort_by_owner(void *tmp, size_t &tmp_bytes, const uint8_t *kin, uint8_t *kout, const uint32_t *vin, uint32_t *vout,
@@ -831,6 +833,18 @@ extern "C" mfx_router *mfx_router_create(const mfx_index *ix, uint32_t nranks, u
   mfx_router *r = new mfx_router;
   r->ix = ix; r->device = ix->device; r->nranks = nranks; r->max_tiles = max_tiles;
   const size_t n = (size_t)max_tiles * MFX_TILE;
+  // small worlds: counting split, no position-sized scratch; MFX_ROUTE_SORT=1 forces the radix-sort path (A/B, tests)
+  const char *fs = getenv("MFX_ROUTE_SORT");
+  r->split = nranks <= MFX_SPLIT_MAX_RANKS && !(fs && atoi(fs));
+  if (r->split) {
+    if (hipMalloc((void **)&r->d_tile_cnt, (size_t)max_tiles * nranks * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc((void **)&r->d_dest, 256 * 8) != hipSuccess) {
+      mfx_fail(MFX_E_NOMEM, "mfx_router_create: device allocation failed (%u tiles)", max_tiles);
+      mfx_router_free(r);
+      return nullptr;
+    }
+    return r;
+  }
   size_t tb = 0;
   mfx_sort_by_owner(nullptr, tb, nullptr, nullptr, nullptr, nullptr, n, nullptr);
   r->tmp_bytes = tb;
@@ -848,7 +862,7 @@ extern "C" mfx_router *mfx_router_create(const mfx_index *ix, uint32_t nranks, u
 extern "C" void mfx_router_free(mfx_router *r) {
   if (!r) return;
   DevGuard g(r->device);
-  void *p[] = {r->d_keys, r->d_owner, r->d_owner2, r->d_idx, r->d_idx2, r->d_dest, r->d_tmp};
+  void *p[] = {r->d_keys, r->d_owner, r->d_owner2, r->d_idx, r->d_idx2, r->d_dest, r->d_tmp, r->d_tile_cnt};
   for (void *x : p) if (x) (void)hipFree(x);
   delete r;
 }
@@ -883,6 +897,17 @@ extern "C" int mfx_route_tiles(mfx_router *r, const mfx_seq *seq, uint64_t tile_
   a.dest_counts = r->d_dest;
   a.counts = d_counts;
   a.nbins = nbins;
+  a.tile_contig = seq->d_tile_contig;
+  a.tile_cnt = r->d_tile_cnt;
+  if (r->split) {
+    MFX_HIP(mfx_k_route_split(a, d_keys_out, d_contigs_out, st));
+    for (uint32_t i = 0; i < r->nranks; ++i) h_dest_counts[i] = 0;
+    if (tile_end > tile_begin) {
+      MFX_HIP(hipMemcpyAsync(h_dest_counts, r->d_dest, r->nranks * 8, hipMemcpyDeviceToHost, st));
+      MFX_HIP(hipStreamSynchronize(st));
+    }
+    return MFX_OK;
+  }
   MFX_HIP(hipMemsetAsync(r->d_dest, 0, 256 * 8, st));
   MFX_HIP(mfx_k_route(a, st));
   MFX_HIP(mfx_k_iota(r->d_idx, n, st));

@@ -40,6 +40,10 @@ struct mfx_route_args {
   uint64_t       *dest_counts;        // [nranks]
   uint64_t       *counts;             // counts image: kasm + per-contig kasm are added here
   uint32_t        nbins;
+  // direct split (nranks <= MFX_SPLIT_MAX_RANKS): no sort, no position-sized scratch
+  const uint32_t *tile_contig;        // [ntiles of the sequence set]
+  uint32_t       *tile_cnt;           // [(tile_end - tile_begin) * nranks] k-mers of each tile per owner; then, in place,
+                                      //   their exclusive prefix over the tiles (per owner)
 };
 
 struct mfx_hist_keys_args {
@@ -83,6 +87,7 @@ hipError_t mfx_k_table_export(mfx_table_view t, uint64_t *kmers, uint32_t *readV
                               unsigned long long *count, hipStream_t st);
 hipError_t mfx_k_hist(const mfx_hist_args &a, int grid, hipStream_t st);
 hipError_t mfx_k_route(const mfx_route_args &a, hipStream_t st);
+hipError_t mfx_k_route_split(const mfx_route_args &a, uint64_t *keys_out, uint32_t *contig_out, hipStream_t st);
 hipError_t mfx_k_route_gather(const mfx_route_args &a, const uint32_t *idx, uint64_t nvalid, uint64_t *keys_out,
                               uint32_t *contig_out, hipStream_t st);
 hipError_t mfx_k_iota(uint32_t *v, uint64_t n, hipStream_t st);

@@ -763,6 +763,135 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_route_kernel(mfx_route_args a) 
   if (tid < a.nranks && s_dest[tid]) atomicAdd((unsigned long long *)&a.dest_counts[tid], (unsigned long long)s_dest[tid]);
 }
 
+// ---------------------------------------------------------------------------
+// Sort-free router for small worlds (nranks <= MFX_SPLIT_MAX_RANKS).  The output is the one the
+// stable sort produces -- k-mers grouped by owner, sequence order inside an owner -- but it is
+// computed as a counting split with the tile as the unit:
+//   count   : k-mers of every tile per owner (also kasm, as mfx_route_kernel)
+//   scan    : per owner, exclusive prefix of those counts over the tiles; owner totals
+//   scatter : every tile again; wave w owns positions [1024w, 1024w+1024) of the tile, so
+//             rank-in-owner = (owner's base) + (tile prefix) + (earlier waves of the tile) +
+//             (earlier rounds of this wave) + (lower lanes of this round: one ballot).
+// No position-sized scratch (the sort path writes 9 B, sorts 5 B and gathers 12 B per position).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(MFX_BLOCK) void mfx_route_count_kernel(mfx_route_args a) {
+  __shared__ mfx_tile_lds L;
+  __shared__ uint64_t s_red[MFX_BLOCK / 64][3];
+  __shared__ uint32_t s_cnt[MFX_SPLIT_MAX_RANKS];
+  const uint32_t tid = threadIdx.x;
+  const int k = a.t.k;
+  for (uint64_t tile = a.tile_begin + blockIdx.x; tile < a.tile_end; tile += gridDim.x) {
+    const uint32_t c = a.tile_contig[tile];
+    const uint64_t pos0 = (tile - a.tile_start[c]) * MFX_TILE;
+    const uint64_t clen = a.contig_len[c];
+    const uint32_t n = (clen - pos0 < MFX_TILE) ? (uint32_t)(clen - pos0) : MFX_TILE;
+    __syncthreads();
+    if (tid < MFX_SPLIT_MAX_RANKS) s_cnt[tid] = 0u;
+    mfx_tile_fill(L, a.bases + a.contig_off[c] + pos0);
+    __syncthreads();
+    uint64_t n_valid = 0, z1 = 0, z2 = 0;
+    for (uint32_t b = 0; b < MFX_TILE / MFX_BLOCK; ++b) {
+      const uint32_t p = b * MFX_BLOCK + tid;
+      uint64_t f;
+      if (mfx_tile_kmer(L, k, p, f) && p < n) {
+        const uint64_t r = mfx_revcomp(f, k);
+        atomicAdd(&s_cnt[mfx_owner(a.t, f < r ? f : r, f < r ? r : f, a.nranks)], 1u);
+        n_valid++;
+      }
+    }
+    mfx_block_sum3(n_valid, z1, z2, s_red);                       // barriers inside: s_cnt is complete after it
+    if (tid == 0 && n_valid) {                                   // merfin-histogram.C:58, counted where the sequence lives
+      atomicAdd((unsigned long long *)&a.counts[2ull * a.nbins + 0], n_valid);
+      atomicAdd((unsigned long long *)&a.counts[2ull * a.nbins + 3 + c], n_valid);
+    }
+    if (tid < a.nranks) a.tile_cnt[(tile - a.tile_begin) * a.nranks + tid] = s_cnt[tid];
+  }
+}
+
+// block d: exclusive prefix over the tiles of owner d's counts (in place), total -> dest_counts[d]
+__global__ __launch_bounds__(MFX_BLOCK) void mfx_route_scan_kernel(uint32_t *tile_cnt, uint64_t ntiles, uint32_t nranks, uint64_t *dest_counts) {
+  __shared__ uint64_t s[MFX_BLOCK];
+  const uint32_t d = blockIdx.x, tid = threadIdx.x;
+  const uint64_t per = (ntiles + MFX_BLOCK - 1) / MFX_BLOCK;
+  const uint64_t t0 = (uint64_t)tid * per, t1 = t0 + per < ntiles ? t0 + per : ntiles;
+  uint64_t sum = 0;
+  for (uint64_t t = t0; t < t1; ++t) sum += tile_cnt[t * nranks + d];
+  s[tid] = sum;
+  __syncthreads();
+  if (tid == 0) {                                                 // 256 values: a serial pass is cheaper than it looks
+    uint64_t run = 0;
+    for (uint32_t i = 0; i < MFX_BLOCK; ++i) { const uint64_t v = s[i]; s[i] = run; run += v; }
+    dest_counts[d] = run;
+  }
+  __syncthreads();
+  uint64_t run = s[tid];
+  for (uint64_t t = t0; t < t1; ++t) {
+    const uint32_t v = tile_cnt[t * nranks + d];
+    tile_cnt[t * nranks + d] = (uint32_t)run;                     // < 2^31 positions per call
+    run += v;
+  }
+}
+
+__global__ __launch_bounds__(MFX_BLOCK) void mfx_route_scatter_kernel(mfx_route_args a, uint64_t *keys_out, uint32_t *contig_out) {
+  __shared__ mfx_tile_lds L;
+  __shared__ uint32_t s_wtot[MFX_BLOCK / 64][MFX_SPLIT_MAX_RANKS];
+  __shared__ uint64_t s_base[MFX_SPLIT_MAX_RANKS];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const int k = a.t.k;
+  constexpr uint32_t ROUNDS = MFX_TILE / MFX_BLOCK;               // 16 rounds of 64 positions per wave
+  constexpr uint32_t WSPAN = MFX_TILE / (MFX_BLOCK / 64);         // 1024 positions per wave
+  if (tid == 0) {
+    uint64_t run = 0;
+    for (uint32_t d = 0; d < a.nranks; ++d) { s_base[d] = run; run += a.dest_counts[d]; }
+  }
+  for (uint64_t tile = a.tile_begin + blockIdx.x; tile < a.tile_end; tile += gridDim.x) {
+    const uint32_t c = a.tile_contig[tile];
+    const uint64_t pos0 = (tile - a.tile_start[c]) * MFX_TILE;
+    const uint64_t clen = a.contig_len[c];
+    const uint32_t n = (clen - pos0 < MFX_TILE) ? (uint32_t)(clen - pos0) : MFX_TILE;
+    __syncthreads();                                              // previous tile consumed (L, s_wtot); s_base visible
+    mfx_tile_fill(L, a.bases + a.contig_off[c] + pos0);
+    __syncthreads();
+    uint64_t key[ROUNDS];
+    uint32_t own[ROUNDS];
+#pragma unroll
+    for (uint32_t r = 0; r < ROUNDS; ++r) {
+      const uint32_t p = wave * WSPAN + r * 64u + lane;
+      uint64_t f;
+      own[r] = 0xffu;
+      key[r] = 0;
+      if (mfx_tile_kmer(L, k, p, f) && p < n) {
+        const uint64_t rc = mfx_revcomp(f, k);
+        key[r] = f < rc ? f : rc;
+        own[r] = mfx_owner(a.t, key[r], f < rc ? rc : f, a.nranks);
+      }
+    }
+    for (uint32_t d = 0; d < a.nranks; ++d) {                      // this wave's k-mers per owner
+      uint32_t cnt = 0;
+#pragma unroll
+      for (uint32_t r = 0; r < ROUNDS; ++r) cnt += (uint32_t)__popcll(__ballot(own[r] == d));
+      if (lane == 0) s_wtot[wave][d] = cnt;
+    }
+    __syncthreads();
+    const uint32_t *toff = a.tile_cnt + (tile - a.tile_begin) * a.nranks;
+    for (uint32_t d = 0; d < a.nranks; ++d) {
+      uint64_t run = s_base[d] + toff[d];
+      for (uint32_t w = 0; w < wave; ++w) run += s_wtot[w][d];
+#pragma unroll
+      for (uint32_t r = 0; r < ROUNDS; ++r) {
+        const bool mine = own[r] == d;
+        const uint64_t m = __ballot(mine);
+        if (mine) {
+          const uint64_t o = run + (uint64_t)__popcll(m & ((1ULL << lane) - 1ULL));
+          keys_out[o] = key[r];
+          contig_out[o] = c;
+        }
+        run += (uint64_t)__popcll(m);
+      }
+    }
+  }
+}
+
 // gathers the routed k-mers into owner order (idx = stable-sorted positions) and attaches the contig id
 __global__ void mfx_route_gather_kernel(mfx_route_args a, const uint32_t *idx, uint64_t nvalid, uint64_t *keys_out, uint32_t *contig_out) {
   uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
@@ -1050,6 +1179,15 @@ hipError_t mfx_k_route(const mfx_route_args &a, hipStream_t st) {
   uint64_t nt = a.tile_end - a.tile_begin;
   if (nt == 0) return hipSuccess;
   mfx_route_kernel<<<(unsigned)(nt < 4096 ? nt : 4096), MFX_BLOCK, 0, st>>>(a);
+  return hipGetLastError();
+}
+hipError_t mfx_k_route_split(const mfx_route_args &a, uint64_t *keys_out, uint32_t *contig_out, hipStream_t st) {
+  const uint64_t nt = a.tile_end - a.tile_begin;
+  if (nt == 0) return hipSuccess;
+  const unsigned grid = (unsigned)(nt < 4096 ? nt : 4096);
+  mfx_route_count_kernel<<<grid, MFX_BLOCK, 0, st>>>(a);
+  mfx_route_scan_kernel<<<a.nranks, MFX_BLOCK, 0, st>>>(a.tile_cnt, nt, a.nranks, a.dest_counts);
+  mfx_route_scatter_kernel<<<grid, MFX_BLOCK, 0, st>>>(a, keys_out, contig_out);
   return hipGetLastError();
 }
 hipError_t mfx_k_route_gather(const mfx_route_args &a, const uint32_t *idx, uint64_t nvalid, uint64_t *keys_out,

@@ -88,6 +88,46 @@ def test_sharded_completeness_sums_to_whole(world):
     assert (st == wt).all() and (su == wu).all() and wt.sum() > 0 and wu.sum() > 0
 
 
+@pytest.mark.parametrize("world", [2, 8, 13])
+def test_split_router_equals_sort_router(world, monkeypatch):
+    """the sort-free counting split must emit exactly what the stable radix sort emits: k-mers grouped by owner,
+    sequence order inside an owner, the contig id of every k-mer, the per-owner counts and the kasm counters"""
+    torch = pytest.importorskip("torch")
+    import merfin_amd as m
+    k, peak = 21, 17.3
+    contigs, read, asm = synth.world(k=k, peak=peak, seed=87)
+    r = synth.rng(9)
+    contigs = list(contigs) + [synth.random_contig(r, int(n)).tobytes() for n in r.integers(0, 6000, size=40)] + [b"N" * 9000]
+    ix = m.Index(k, len(read[0]) + 16)
+    ix.set_shard(0, world)
+    ix.add_read(*read)
+    seqs = m.Sequences(contigs)
+    T = seqs.ntiles
+    nb = 2048
+    words = m.hist_words(nb, seqs.ncontigs)
+    outs = []
+    for force_sort in ("1", "0"):
+        monkeypatch.setenv("MFX_ROUTE_SORT", force_sort)
+        router = m.Router(ix, world, T)
+        counts = torch.zeros(words, dtype=torch.int64, device="cuda")
+        keys = torch.full((T * m.TILE,), -1, dtype=torch.int64, device="cuda")
+        ctg = torch.full((T * m.TILE,), -1, dtype=torch.int32, device="cuda")
+        got = []
+        for tb, te in ((0, T // 3), (T // 3, T // 3), (T // 3, T)):      # includes an empty range
+            send = router.route(seqs, tb, te, nb, counts, keys, ctg)
+            n = int(send.sum())
+            got.append((send.copy(), keys[:n].cpu().numpy().copy(), ctg[:n].cpu().numpy().copy()))
+        outs.append((got, counts.cpu().numpy().copy()))
+    (a, ca), (b, cb) = outs
+    np.testing.assert_array_equal(ca, cb)
+    assert int(ca[2 * nb]) > 0
+    for (sa, ka, ga), (sb, kb, gb) in zip(a, b):
+        np.testing.assert_array_equal(sa, sb)
+        np.testing.assert_array_equal(ka, kb)
+        np.testing.assert_array_equal(ga, gb)
+    assert sum(int(x[0].sum()) for x in a) == int(ca[2 * nb])
+
+
 def _worker(rank, world, port, tmp):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
