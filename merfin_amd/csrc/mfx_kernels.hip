@@ -917,7 +917,8 @@ __global__ void mfx_iota_kernel(uint32_t *v, uint64_t n) {
 
 // owner side: canonical k-mers (grouped by source order) -> lookup -> K* -> bins.
 // kasm was counted by the source; this adds kmissing (global + per contig), bins, koverCpy.
-__global__ __launch_bounds__(MFX_BLOCK) void mfx_hist_keys_kernel(mfx_hist_keys_args a) {
+template <int W>
+__global__ __launch_bounds__(MFX_BLOCK, 4) void mfx_hist_keys_kernel(mfx_hist_keys_args a) {
   __shared__ mfx_mailbox MB;
   __shared__ mfx_hist_lds H;
   const uint32_t tid = threadIdx.x;
@@ -950,7 +951,7 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_hist_keys_kernel(mfx_hist_keys_
       key[j] = ok[j] ? a.keys[i] : 0ULL;
       krc[j] = mfx_revcomp(key[j], k);
     }
-    mfx_group_lookup<MFX_BATCH>(a.t, MB, key, krc, ok, rv, av);
+    mfx_group_lookup<MFX_BATCH, W>(a.t, MB, key, krc, ok, rv, av);
 #pragma unroll
     for (int j = 0; j < MFX_BATCH; ++j) {
       const bool miss = ok[j] && mfx_hist_eval(H, ka, lut_ok, rv[j], av[j], n_over0, kover);
@@ -1202,7 +1203,8 @@ hipError_t mfx_k_iota(uint32_t *v, uint64_t n, hipStream_t st) {
   return hipGetLastError();
 }
 hipError_t mfx_k_hist_keys(const mfx_hist_keys_args &a, int grid, hipStream_t st) {
-  mfx_hist_keys_kernel<<<grid, MFX_BLOCK, 0, st>>>(a);
+  if (a.t.mz_w == MFX_MZ_W_DEFAULT) mfx_hist_keys_kernel<MFX_MZ_W_DEFAULT><<<grid, MFX_BLOCK, 0, st>>>(a);
+  else                              mfx_hist_keys_kernel<0><<<grid, MFX_BLOCK, 0, st>>>(a);
   return hipGetLastError();
 }
 hipError_t mfx_k_sum_partials(const double *partials, uint32_t n, double *out, hipStream_t st) {
