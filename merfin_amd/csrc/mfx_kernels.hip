@@ -609,6 +609,7 @@ __global__ __launch_bounds__(MFX_BLOCK, 4) void mfx_hist_kernel(mfx_hist_args a)
   const bool lut_ok = H.lut_ok != 0u;
 
   uint64_t n_valid = 0, n_missing = 0, n_over0 = 0;     // per-lane counters
+  uint64_t tot_valid = 0, tot_missing = 0;               // block totals of the contigs already flushed (thread 0)
   uint64_t *c_glob = ka.counts + 2ull * ka.nbins;        // kasm, kmissing, novf
   uint64_t *c_kasm = c_glob + 3, *c_kmis = c_kasm + ka.ncontigs;
 
@@ -632,8 +633,8 @@ __global__ __launch_bounds__(MFX_BLOCK, 4) void mfx_hist_kernel(mfx_hist_args a)
         if (tid == 0 && (x | y)) {
           atomicAdd((unsigned long long *)&c_kasm[c], x);
           atomicAdd((unsigned long long *)&c_kmis[c], y);
-          atomicAdd((unsigned long long *)&c_glob[0], x);
-          atomicAdd((unsigned long long *)&c_glob[1], y);
+          tot_valid += x;                                // the global totals leave the block once, at its end:
+          tot_missing += y;                              // a fragmented assembly changes contig on every tile
         }
         n_valid = n_missing = 0;
       }
@@ -649,6 +650,7 @@ __global__ __launch_bounds__(MFX_BLOCK, 4) void mfx_hist_kernel(mfx_hist_args a)
 
     double kover = 0.0;                      // this lane's koverCpy terms of this tile
     for (uint32_t b = 0; b < MFX_TILE / MFX_BLOCK; b += MFX_BATCH) {
+      if (b * MFX_BLOCK >= n) break;         // short last tile of a contig (block-uniform): nothing starts beyond n
       uint64_t key[MFX_BATCH], key2[MFX_BATCH];
       uint32_t rv[MFX_BATCH], av[MFX_BATCH];
       bool     ok[MFX_BATCH];
@@ -697,9 +699,9 @@ __global__ __launch_bounds__(MFX_BLOCK, 4) void mfx_hist_kernel(mfx_hist_args a)
       if (c != none && (x | y)) {
         atomicAdd((unsigned long long *)&c_kasm[c], x);
         atomicAdd((unsigned long long *)&c_kmis[c], y);
-        atomicAdd((unsigned long long *)&c_glob[0], x);
-        atomicAdd((unsigned long long *)&c_glob[1], y);
       }
+      if (tot_valid + x) atomicAdd((unsigned long long *)&c_glob[0], tot_valid + x);
+      if (tot_missing + y) atomicAdd((unsigned long long *)&c_glob[1], tot_missing + y);
       if (z) atomicAdd((unsigned long long *)&ka.counts[ka.nbins], z);
     }
   }
