@@ -69,18 +69,48 @@ struct DevBuf {   // scoped device scratch
   hipError_t alloc(size_t n) { return hipMalloc((void **)&p, (n ? n : 1) * sizeof(T)); }
 };
 
-double load_factor() {
+// Table fill target.  MFX_LOAD_FACTOR fixes it; otherwise it is chosen per index between MFX_LF_MAX (the least
+// memory a table may take: what mfx_index_estimate_gb reports and -memory is checked against) and MFX_LF_MIN,
+// as low as a share of the free HBM (and of max_gb) allows: emptier lines mean fewer full home lines and fewer
+// second probes (3 Gb -hist, w = 3: 0.7 -> 80, 0.6 -> 85, 0.5 -> 88, 0.4 -> 91 G k-mers/s), and 288 GB of HBM
+// are there to be used.
+constexpr double MFX_LF_MAX = 0.7, MFX_LF_MIN = 0.4, MFX_LF_HBM_SHARE = 0.62;
+
+bool load_factor_fixed(double *lf) {
   const char *e = getenv("MFX_LOAD_FACTOR");
-  double lf = e ? atof(e) : 0.7;
-  if (!(lf > 0.05 && lf <= 0.9)) lf = 0.7;
-  return lf;
+  if (!e) return false;
+  double v = atof(e);
+  if (!(v > 0.05 && v <= 0.9)) v = MFX_LF_MAX;
+  *lf = v;
+  return true;
 }
 
-uint64_t lines_for(uint64_t capacity_kmers) {
-  double slots = (double)capacity_kmers / load_factor();
+uint64_t lines_at(uint64_t capacity_kmers, double lf) {
+  double slots = (double)capacity_kmers / lf;
   uint64_t nlines = (uint64_t)ceil(slots / MFX_SLOTS_LINE);
   if (nlines < 1024) nlines = 1024;      // probe sequences may span 512 lines
   return nlines;
+}
+
+// smallest table this build makes for `capacity_kmers`
+uint64_t lines_for(uint64_t capacity_kmers) {
+  double lf = MFX_LF_MAX;
+  (void)load_factor_fixed(&lf);
+  return lines_at(capacity_kmers, lf);
+}
+
+// the table actually allocated: budget_bytes = what the table may take (0: unknown, use the smallest)
+uint64_t lines_auto(uint64_t capacity_kmers, double budget_bytes) {
+  double lf;
+  if (load_factor_fixed(&lf)) return lines_at(capacity_kmers, lf);
+  lf = MFX_LF_MAX;
+  if (budget_bytes > 0) {
+    lf = (double)capacity_kmers * sizeof(mfx_slot) / budget_bytes;
+    lf = std::min(MFX_LF_MAX, std::max(MFX_LF_MIN, lf));
+  }
+  uint64_t nl = lines_at(capacity_kmers, lf);
+  if (nl >= (1ull << 32)) nl = std::max<uint64_t>(lines_at(capacity_kmers, MFX_LF_MAX), (1ull << 32) - 16);
+  return nl;
 }
 }  // namespace
 
@@ -145,7 +175,13 @@ extern "C" mfx_index *mfx_index_create(int k, uint64_t capacity_kmers, double ma
   ix->device = device;
   ix->k = k;
   ix->capacity_kmers = capacity_kmers;
-  ix->nlines = lines_for(capacity_kmers);
+  {
+    size_t free_b = 0, total_b = 0;
+    double budget = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = MFX_LF_HBM_SHARE * (double)free_b;
+    if (max_gb > 0) budget = budget > 0 ? std::min(budget, max_gb * 1e9) : max_gb * 1e9;
+    ix->nlines = lines_auto(capacity_kmers, budget);
+  }
   if (ix->nlines >= (1ull << 32)) {        // line numbers are 32-bit on the device (550 GB of table: beyond one GPU anyway)
     mfx_fail(MFX_E_NOMEM, "Not enough memory to load databases.  %lu k-mers need %.0f GB on one GPU; shard the index (mfx_index_set_shard).",
              (unsigned long)capacity_kmers, (double)ix->nlines * MFX_ALIGN / 1e9);
