@@ -99,6 +99,19 @@ int mfx_db_write_flat(const char *path, int k, const uint64_t *kmers, const uint
 int        mfx_index_save(const mfx_index *ix, const char *path);
 mfx_index *mfx_index_load(const char *path, double max_gb, int device);
 
+/* The same image in memory, for handing a built table to the other GPUs of a node (one rank decodes the
+ * k-mer databases and builds, the table then travels over xGMI -- an RCCL broadcast -- instead of every rank
+ * decoding and building its own; merfin_amd/distributed.py::broadcast_index).
+ *   source rank : mfx_index_image_header(ix, hdr)  -> MFX_INDEX_HEADER_BYTES describing geometry + filter
+ *   other ranks : ix = mfx_index_create_from_header(hdr, max_gb, device)   (empty table of that geometry)
+ *   all ranks   : mfx_index_device_image(ix, &lines, &line_bytes, &meta, &meta_bytes); move `lines` and `meta`
+ *                 from the source's device buffers into the others'; then mfx_index_commit(ix) on the receivers. */
+#define MFX_INDEX_HEADER_BYTES 128
+int        mfx_index_image_header(const mfx_index *ix, void *hdr);
+mfx_index *mfx_index_create_from_header(const void *hdr, double max_gb, int device);
+int        mfx_index_device_image(mfx_index *ix, void **d_lines, uint64_t *line_bytes, void **d_meta, uint64_t *meta_bytes);
+int        mfx_index_commit(mfx_index *ix);
+
 typedef struct mfx_seq mfx_seq;
 
 /* Native replacement of the `meryl count k=.. <seq> output <seq>.meryl` child

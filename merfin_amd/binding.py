@@ -41,6 +41,8 @@ class _VarOpts(C.Structure):
     _fields_ = [("mode", C.c_int), ("comb", C.c_uint32), ("nosplit", C.c_int), ("debug_path", C.c_char_p)]
 
 
+INDEX_HEADER_BYTES = 128          # MFX_INDEX_HEADER_BYTES
+
 VARIANT_MODES = {"filter": 4, "polish": 5, "better": 6, "strict": 7, "loose": 8}
 
 
@@ -60,6 +62,7 @@ SYMBOLS = [
     "mfx_index_create", "mfx_index_free", "mfx_index_estimate_gb", "mfx_index_add_read", "mfx_index_add_asm",
     "mfx_index_count_asm", "mfx_index_value", "mfx_index_get_info", "mfx_index_export",
     "mfx_db_probe", "mfx_index_load_db", "mfx_db_write_flat", "mfx_index_save", "mfx_index_load",
+    "mfx_index_image_header", "mfx_index_create_from_header", "mfx_index_device_image", "mfx_index_commit",
     "mfx_seq_upload", "mfx_seq_from_device", "mfx_seq_free", "mfx_seq_num_contigs", "mfx_seq_num_bases",
     "mfx_seq_num_tiles",
     "mfx_eval_create", "mfx_eval_free", "mfx_eval_nbins", "mfx_getK", "mfx_getKmetric", "mfx_histoQV",
@@ -120,6 +123,11 @@ def load_library():
     L.mfx_index_save.argtypes = [vp, C.c_char_p]
     L.mfx_index_load.restype = vp
     L.mfx_index_load.argtypes = [C.c_char_p, C.c_double, C.c_int]
+    L.mfx_index_image_header.argtypes = [vp, vp]
+    L.mfx_index_create_from_header.restype = vp
+    L.mfx_index_create_from_header.argtypes = [vp, C.c_double, C.c_int]
+    L.mfx_index_device_image.argtypes = [vp, C.POINTER(vp), u64p, C.POINTER(vp), u64p]
+    L.mfx_index_commit.argtypes = [vp]
     L.mfx_seq_upload.restype = vp
     L.mfx_seq_upload.argtypes = [C.c_int, C.POINTER(C.c_char_p), u64p, C.c_uint32]
     L.mfx_seq_from_device.restype = vp
@@ -263,6 +271,31 @@ class Index:
         ix = Index(0, 0, device=device, _handle=h)
         ix.k = ix.info()["k"]
         return ix
+
+    def image_header(self):
+        """geometry + filter of the built table (INDEX_HEADER_BYTES bytes), see Index.from_header"""
+        buf = np.zeros(INDEX_HEADER_BYTES, dtype=np.uint8)
+        _check(load_library().mfx_index_image_header(self.h, C.c_void_p(buf.ctypes.data)))
+        return buf
+
+    @staticmethod
+    def from_header(header, max_gb=0.0, device=0):
+        """an empty index of exactly that geometry; fill device_image() (e.g. by a broadcast), then commit()"""
+        header = np.ascontiguousarray(header, dtype=np.uint8)
+        h = _need(load_library().mfx_index_create_from_header(C.c_void_p(header.ctypes.data), float(max_gb), device))
+        ix = Index(0, 0, device=device, _handle=h)
+        ix.k = ix.info()["k"]
+        return ix
+
+    def device_image(self):
+        """(lines device pointer, bytes, meta device pointer, bytes) of the table in HBM"""
+        pl, pm = C.c_void_p(), C.c_void_p()
+        nl, nm = C.c_uint64(), C.c_uint64()
+        _check(load_library().mfx_index_device_image(self.h, C.byref(pl), C.byref(nl), C.byref(pm), C.byref(nm)))
+        return pl.value, nl.value, pm.value, nm.value
+
+    def commit(self):
+        _check(load_library().mfx_index_commit(self.h))
 
     def add_read(self, kmers, values, minV=0, maxV=2**64 - 1):
         if isinstance(kmers, np.ndarray):

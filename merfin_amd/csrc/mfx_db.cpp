@@ -491,12 +491,10 @@ struct IndexImageHeader {
   uint32_t filter_set, layout;   // layout = MFX_LAYOUT_VERSION of the build that wrote the image
 };
 
-extern "C" int mfx_index_save(const mfx_index *ix, const char *path) {
-  if (!ix || !path) return mfx_fail(MFX_E_INVAL, "mfx_index_save: null argument");
+static_assert(sizeof(IndexImageHeader) <= MFX_INDEX_HEADER_BYTES, "index image header outgrew its public size");
+
+static int fill_header(const mfx_index *ix, IndexImageHeader &h) {
   if (hipSetDevice(ix->device) != hipSuccess) return mfx_fail(MFX_E_HIP, "hipSetDevice(%d) failed", ix->device);
-  FILE *f = fopen(path, "wb");
-  if (!f) return mfx_fail(MFX_E_IO, "cannot open '%s' for writing", path);
-  IndexImageHeader h;
   memset(&h, 0, sizeof(h));
   memcpy(h.magic, "MFXINDX1", 8);
   h.k = (uint32_t)ix->k; h.mz_w = (uint32_t)ix->mz_w;
@@ -506,9 +504,82 @@ extern "C" int mfx_index_save(const mfx_index *ix, const char *path) {
   h.slot_bytes = (uint32_t)sizeof(mfx_slot); h.line_slots = MFX_SLOTS_LINE;
   h.filter_set = ix->filter_set ? 1u : 0u;
   h.layout = MFX_LAYOUT_VERSION;
-  int rc = MFX_OK;
-  if (hipMemcpy(h.meta, ix->d_meta, sizeof(h.meta), hipMemcpyDeviceToHost) != hipSuccess) rc = mfx_fail(MFX_E_HIP, "reading index metadata failed");
-  if (rc == MFX_OK && fwrite(&h, sizeof(h), 1, f) != 1) rc = mfx_fail(MFX_E_IO, "short write to '%s'", path);
+  if (hipMemcpy(h.meta, ix->d_meta, sizeof(h.meta), hipMemcpyDeviceToHost) != hipSuccess) return mfx_fail(MFX_E_HIP, "reading index metadata failed");
+  return MFX_OK;
+}
+
+static bool header_ok(const IndexImageHeader &h) {
+  return memcmp(h.magic, "MFXINDX1", 8) == 0 && h.slot_bytes == sizeof(mfx_slot) && h.line_slots == MFX_SLOTS_LINE && h.k >= 1 &&
+         h.k <= 31 && h.nlines != 0 && h.nlines < (1ull << 32) && h.layout == MFX_LAYOUT_VERSION;
+}
+
+// an index of exactly the header's geometry; its lines are allocated but hold nothing yet
+static mfx_index *index_from_header(const IndexImageHeader &h, double max_gb, int device) {
+  mfx_index *ix = mfx_index_create((int)h.k, 1, 0.0, device);
+  if (!ix) return nullptr;
+  if (max_gb > 0 && (double)h.nlines * MFX_ALIGN / 1e9 > max_gb) {
+    mfx_fail(MFX_E_NOMEM, "Not enough memory to load databases.  Increase -memory. (need %.3f GB, limit %.3f GB)", (double)h.nlines * MFX_ALIGN / 1e9, max_gb);
+    mfx_index_free(ix);
+    return nullptr;
+  }
+  (void)hipSetDevice(device);
+  (void)hipFree(ix->d_slots);
+  ix->d_slots = nullptr;
+  ix->nlines = h.nlines;
+  ix->capacity_kmers = h.capacity_kmers;
+  ix->mz_w = (int)h.mz_w;
+  ix->shard_rank = h.shard_rank; ix->shard_n = h.shard_n ? h.shard_n : 1;
+  ix->minV = h.minV; ix->maxV = h.maxV; ix->filter_set = h.filter_set != 0;
+  if (hipMalloc((void **)&ix->d_slots, h.nlines * MFX_ALIGN) != hipSuccess ||
+      hipMemcpy(ix->d_meta, h.meta, sizeof(h.meta), hipMemcpyHostToDevice) != hipSuccess) {
+    mfx_fail(MFX_E_NOMEM, "cannot allocate %.3f GB for the index image on device %d", (double)h.nlines * MFX_ALIGN / 1e9, device);
+    mfx_index_free(ix);
+    return nullptr;
+  }
+  return ix;
+}
+
+extern "C" int mfx_index_image_header(const mfx_index *ix, void *hdr) {
+  if (!ix || !hdr) return mfx_fail(MFX_E_INVAL, "mfx_index_image_header: null argument");
+  IndexImageHeader h;
+  int rc = fill_header(ix, h);
+  if (rc) return rc;
+  memset(hdr, 0, MFX_INDEX_HEADER_BYTES);
+  memcpy(hdr, &h, sizeof(h));
+  return MFX_OK;
+}
+
+extern "C" mfx_index *mfx_index_create_from_header(const void *hdr, double max_gb, int device) {
+  if (!hdr) { mfx_fail(MFX_E_INVAL, "mfx_index_create_from_header: null argument"); return nullptr; }
+  IndexImageHeader h;
+  memcpy(&h, hdr, sizeof(h));
+  if (!header_ok(h)) { mfx_fail(MFX_E_FORMAT, "not an index image header of this build"); return nullptr; }
+  return index_from_header(h, max_gb, device);
+}
+
+extern "C" int mfx_index_device_image(mfx_index *ix, void **d_lines, uint64_t *line_bytes, void **d_meta, uint64_t *meta_bytes) {
+  if (!ix || !d_lines || !line_bytes || !d_meta || !meta_bytes) return mfx_fail(MFX_E_INVAL, "mfx_index_device_image: null argument");
+  *d_lines = ix->d_slots;
+  *line_bytes = ix->nlines * MFX_ALIGN;
+  *d_meta = ix->d_meta;
+  *meta_bytes = 4 * sizeof(uint64_t);
+  return MFX_OK;
+}
+
+extern "C" int mfx_index_commit(mfx_index *ix) {
+  if (!ix) return mfx_fail(MFX_E_INVAL, "mfx_index_commit: null argument");
+  ix->version++;                       // cached per-index facts (canonical or not) are re-read from the new contents
+  return MFX_OK;
+}
+
+extern "C" int mfx_index_save(const mfx_index *ix, const char *path) {
+  if (!ix || !path) return mfx_fail(MFX_E_INVAL, "mfx_index_save: null argument");
+  IndexImageHeader h;
+  int rc = fill_header(ix, h);
+  if (rc) return rc;
+  FILE *f = fopen(path, "wb");
+  if (!f) return mfx_fail(MFX_E_IO, "cannot open '%s' for writing", path);
+  if (fwrite(&h, sizeof(h), 1, f) != 1) rc = mfx_fail(MFX_E_IO, "short write to '%s'", path);
   const size_t CH = 256ull << 20;
   std::vector<char> buf(rc == MFX_OK ? CH : 1);
   const uint64_t total = ix->nlines * MFX_ALIGN;
@@ -526,30 +597,14 @@ extern "C" mfx_index *mfx_index_load(const char *path, double max_gb, int device
   FILE *f = fopen(path, "rb");
   if (!f) { mfx_fail(MFX_E_IO, "cannot open '%s'", path); return nullptr; }
   IndexImageHeader h;
-  if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "MFXINDX1", 8) != 0 || h.slot_bytes != sizeof(mfx_slot) ||
-      h.line_slots != MFX_SLOTS_LINE || h.k < 1 || h.k > 31 || h.nlines == 0 || h.nlines >= (1ull << 32) || h.layout != MFX_LAYOUT_VERSION) {
+  if (fread(&h, sizeof(h), 1, f) != 1 || !header_ok(h)) {
     fclose(f);
     mfx_fail(MFX_E_FORMAT, "'%s' is not an index image of this build", path);
     return nullptr;
   }
-  // create an index of exactly the saved geometry, then overwrite its lines
-  mfx_index *ix = mfx_index_create((int)h.k, 1, 0.0, device);
+  mfx_index *ix = index_from_header(h, max_gb, device);
   if (!ix) { fclose(f); return nullptr; }
-  if (max_gb > 0 && (double)h.nlines * MFX_ALIGN / 1e9 > max_gb) {
-    mfx_fail(MFX_E_NOMEM, "Not enough memory to load databases.  Increase -memory. (need %.3f GB, limit %.3f GB)", (double)h.nlines * MFX_ALIGN / 1e9, max_gb);
-    mfx_index_free(ix); fclose(f);
-    return nullptr;
-  }
-  (void)hipSetDevice(device);
-  (void)hipFree(ix->d_slots);
-  ix->d_slots = nullptr;
-  ix->nlines = h.nlines;
-  ix->capacity_kmers = h.capacity_kmers;
-  ix->mz_w = (int)h.mz_w;
-  ix->shard_rank = h.shard_rank; ix->shard_n = h.shard_n ? h.shard_n : 1;
-  ix->minV = h.minV; ix->maxV = h.maxV; ix->filter_set = h.filter_set != 0;
-  bool ok = hipMalloc((void **)&ix->d_slots, h.nlines * MFX_ALIGN) == hipSuccess &&
-            hipMemcpy(ix->d_meta, h.meta, sizeof(h.meta), hipMemcpyHostToDevice) == hipSuccess;
+  bool ok = true;
   const size_t CH = 256ull << 20;
   std::vector<char> buf(ok ? CH : 1);
   const uint64_t total = h.nlines * MFX_ALIGN;

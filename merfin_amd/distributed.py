@@ -133,3 +133,46 @@ def reduce_completeness(total64, undrcpy64, device=None):
         total += float(t64[piece])
         undr += float(u64[piece])
     return total, undr, t64, u64
+
+
+class _DeviceBytes:
+    """a raw HBM range as a zero-copy uint8 tensor (torch.as_tensor reads __cuda_array_interface__)"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def broadcast_index(ix, src=0, device=0, max_gb=0.0, chunk_bytes=1 << 30):
+    """Replicated index without N builds: rank `src` passes its built Index, every other rank passes None; the
+    table then travels rank-to-rank -- `torch.distributed.broadcast` of the HBM lines in `chunk_bytes` pieces (RCCL
+    over xGMI with backend "nccl"; staged through host memory with "gloo") -- and every rank returns an Index
+    with identical contents.  Only `src` decodes the k-mer databases and runs the insert kernels."""
+    import torch
+    import torch.distributed as dist
+    from .binding import INDEX_HEADER_BYTES, Index
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return ix
+    rank = dist.get_rank()
+    on_device = dist.get_backend() == "nccl"
+    hdr = torch.from_numpy(ix.image_header().copy()) if rank == src else torch.zeros(INDEX_HEADER_BYTES, dtype=torch.uint8)
+    if on_device:
+        hdr = hdr.cuda()
+    dist.broadcast(hdr, src)
+    if rank != src:
+        ix = Index.from_header(hdr.cpu().numpy(), max_gb=max_gb, device=device)
+    pl, nl, pm, nm = ix.device_image()
+    for ptr, nbytes in ((pl, nl), (pm, nm)):
+        for o in range(0, nbytes, chunk_bytes):
+            n = min(chunk_bytes, nbytes - o)
+            view = torch.as_tensor(_DeviceBytes(ptr + o, n), device="cuda")
+            if on_device:
+                dist.broadcast(view, src)
+            else:
+                host = view.cpu() if rank == src else torch.empty(n, dtype=torch.uint8)
+                dist.broadcast(host, src)
+                if rank != src:
+                    view.copy_(host)
+    torch.cuda.synchronize()
+    if rank != src:
+        ix.commit()
+    return ix

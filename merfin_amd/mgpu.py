@@ -84,6 +84,8 @@ def main(argv=None):
     ap.add_argument("-min", type=int, default=0)
     ap.add_argument("-max", type=int, default=2**64 - 1)
     ap.add_argument("-sharded", action="store_true")
+    ap.add_argument("-broadcast-index", dest="broadcast_index", action="store_true",
+                    help="replicated index: rank 0 reads the k-mer databases and builds, the table is broadcast to the other GPUs")
     ap.add_argument("-completeness", action="store_true")
     ap.add_argument("-dump", action="store_true")
     for mode in VARIANT_MODES:
@@ -131,17 +133,23 @@ def main(argv=None):
     cap = rdb["n_kmers"] + n_asm + 1024
     if a.sharded and world > 1:
         cap = int(cap / world * 1.15) + 1024               # owners are hash-balanced
-    ix = m.Index(k, cap, device=local)
-    if a.sharded and world > 1:
-        ix.set_shard(rank, world)
-    log("-- Loading kmers from '%s' into lookup table." % a.readmers)
-    ix.load_db(a.readmers, 0, a.min, a.max)
     sq = m.Sequences(seqs, device=local, names=names)
-    if a.seqmers:
-        log("-- Loading kmers from '%s' into lookup table." % a.seqmers)
-        ix.load_db(a.seqmers, 1)
-    else:
-        ix.count_asm(sq)
+    bcast = a.broadcast_index and world > 1 and not a.sharded
+    ix = None
+    if not bcast or rank == 0:
+        ix = m.Index(k, cap, device=local)
+        if a.sharded and world > 1:
+            ix.set_shard(rank, world)
+        log("-- Loading kmers from '%s' into lookup table." % a.readmers)
+        ix.load_db(a.readmers, 0, a.min, a.max)
+        if a.seqmers:
+            log("-- Loading kmers from '%s' into lookup table." % a.seqmers)
+            ix.load_db(a.seqmers, 1)
+        else:
+            ix.count_asm(sq)
+    if bcast:
+        log("-- Broadcasting the built table to %d GPUs." % world)
+        ix = D.broadcast_index(ix, src=0, device=local)
     kp = m.KParams.from_file(a.peak, a.prob) if a.prob else m.KParams(a.peak)
     ev = m.Evaluator(ix, kp)
     if a.completeness:

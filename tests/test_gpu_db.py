@@ -109,3 +109,39 @@ def test_index_image_round_trip(tmp_path, mode, monkeypatch):
     with pytest.raises(m.MfxError) as e:
         m.Index.load(str(tmp_path / "bad"))
     assert e.value.code == -7
+
+
+@pytest.mark.gpu
+def test_in_memory_image_moves_a_built_table(monkeypatch):
+    """header -> empty index of the same geometry -> raw copy of lines + meta -> commit: what broadcast_index does
+    between ranks, here between two indexes on one GPU; contents and -hist must be identical"""
+    torch = pytest.importorskip("torch")
+    import merfin_amd as m
+    from merfin_amd.distributed import _DeviceBytes
+    k, peak = 21, 17.3
+    contigs, read, asm = synth.world(k=k, peak=peak, seed=57)
+    src = m.Index(k, len(read[0]) + len(asm[0]) + 16)
+    src.add_read(read[0], read[1], 2, 1000)
+    src.add_asm(*asm)
+    hdr = src.image_header()
+    assert hdr.nbytes == m.binding.INDEX_HEADER_BYTES
+    dst = m.Index.from_header(hdr)
+    sl, snl, sm, snm = src.device_image()
+    dl, dnl, dm, dnm = dst.device_image()
+    assert (snl, snm) == (dnl, dnm) and dl != sl
+    for a, b, n in ((sl, dl, snl), (sm, dm, snm)):
+        torch.as_tensor(_DeviceBytes(b, n), device="cuda").copy_(torch.as_tensor(_DeviceBytes(a, n), device="cuda"))
+    torch.cuda.synchronize()
+    dst.commit()
+    assert dst.info() == src.info()
+    for x, y in zip(src.export(), dst.export()):
+        np.testing.assert_array_equal(x, y)
+    seqs = m.Sequences(contigs)
+    ra, rb = m.Evaluator(src, m.KParams(peak)).hist(seqs), m.Evaluator(dst, m.KParams(peak)).hist(seqs)
+    assert (ra.kasm, ra.kmissing, ra.koverCpy) == (rb.kasm, rb.kmissing, rb.koverCpy) and ra.kmissing > 0
+    np.testing.assert_array_equal(ra.over(), rb.over())
+    bad = hdr.copy()
+    bad[0] ^= 0xff
+    with pytest.raises(m.MfxError) as e:
+        m.Index.from_header(bad)
+    assert e.value.code == -7

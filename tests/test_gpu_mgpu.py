@@ -83,3 +83,13 @@ def test_launcher_variant_modes_match_golden(tmp_path, mode, nproc):
     _launch(nproc, ["-" + mode, "-vcf", G + "/case1.vcf", "-comb", "8"] + COMMON + ["-output", out], 5 * nproc + len(mode))
     suffix = ".polish.vcf" if mode == "polish" else ".filter.vcf"
     assert open(out + suffix, "rb").read() == open(G + "/case1.%s.vcf" % mode, "rb").read()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc", [2, 3])
+def test_launcher_broadcast_index_matches_golden(tmp_path, nproc):
+    """-broadcast-index: only rank 0 reads the k-mer databases; the others receive the built table"""
+    out = str(tmp_path / "out.hist")
+    r = _launch(nproc, COMMON + ["-output", out, "-broadcast-index"], 23 * nproc)
+    assert open(out, "rb").read() == open(G + "/case1.hist", "rb").read()
+    assert open(G + "/case1.summary").read() in r.stderr and "Broadcasting the built table" in r.stderr
