@@ -170,3 +170,36 @@ def test_cli_fastq_input_and_lowercase(tmp_path):
     r = run(["-hist", "-sequence", fq, "-readmers", str(tmp_path / "read.mfxk"), "-peak", str(peak), "-output", str(tmp_path / "g.hist")])
     assert r.returncode == 0, r.stderr
     assert (tmp_path / "g.hist").read_bytes() == (tmp_path / "o.hist").read_bytes()
+
+
+@pytest.mark.gpu
+def test_cli_min_max_filter_and_peak_only(tmp_path):
+    """-min / -max drop read k-mers outside [min, max] at load (merfin.C:199-200 -> merylExactLookup::load);
+    -dump too; no -prob: the -peak rounding rule alone (merfin-globals.C:80-89)"""
+    import merfin_amd as m
+    k, peak = 21, 17.3
+    contigs, read, asm = synth.world(k=k, peak=peak, seed=43, sizes=(18000, 5000, 333))
+    lo, hi = 4, 40
+    assert ((read[1] < lo).sum() > 0) and ((read[1] > hi).sum() > 0)
+    p = po.Params(k, peak)
+    R, A = po.Lookup(k, read[0], read[1], lo, hi), po.Lookup(k, *asm)
+    g, ka, km, _ = po.hist_run(p, R, A, contigs, threads=2)
+    g0 = po.hist_run(p, po.Lookup(k, *read), A, contigs, threads=2)[0]
+    assert g.kmissing > g0.kmissing                        # the filter changes the answer
+    po.report_histogram(p, g, str(tmp_path / "o.hist"), str(tmp_path / "o.sum"))
+    for ci, c in enumerate(contigs):
+        rk, ak_, km_, _, _ = po.process_dump(p, R, A, c)
+        po.output_dump(str(tmp_path / "o.dump"), "ctg%d" % ci, rk, ak_, km_, append=ci > 0)
+    fa = str(tmp_path / "asm.fasta")
+    _write_fasta(fa, contigs, gz=False)
+    m.db_write_flat(str(tmp_path / "read.mfxk"), k, *read)
+    m.db_write_flat(str(tmp_path / "asm.mfxk"), k, *asm)
+    common = ["-sequence", fa, "-readmers", str(tmp_path / "read.mfxk"), "-seqmers", str(tmp_path / "asm.mfxk"),
+              "-peak", str(peak), "-min", str(lo), "-max", str(hi), "-threads", "3"]
+    r = run(["-hist"] + common + ["-output", str(tmp_path / "g.hist")])
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "g.hist").read_bytes() == (tmp_path / "o.hist").read_bytes()
+    assert (tmp_path / "o.sum").read_text() in r.stderr
+    r = run(["-dump"] + common + ["-output", str(tmp_path / "g.dump")])
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "g.dump").read_bytes() == (tmp_path / "o.dump").read_bytes()
