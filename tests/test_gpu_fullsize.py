@@ -7,7 +7,9 @@ and checked through invariants of the domain:
   - the tile-sharded evaluation (the multi-GPU decomposition) sums to the whole,
   - the index placement (plain / minimizer-keyed) does not change any integer,
   - the reverse-complemented assembly gives the same histogram.
-MFX_TEST_BASES scales it (default 256 Mb: ~12 s; 3e9 reproduces config 3)."""
+MFX_TEST_BASES scales it (default 256 Mb: ~12 s).  The placement test holds TWO indexes at once, so the
+largest size that fits one GPU is about 1.2e9; config 3's 3 Gb is exercised by bench.py (hist_sum_check, and the
+GPU-vs-oracle parity of its cpu_baseline sample)."""
 import os
 
 import numpy as np
