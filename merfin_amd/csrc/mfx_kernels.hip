@@ -177,7 +177,7 @@ __device__ __forceinline__ mfx_slot *mfx_claim(const mfx_table_view &t, uint64_t
   for (uint32_t d = 0; d < MFX_MAX_LINES; ++d) {
     const uint64_t base = mfx_probe_line(t, pr, d) * MFX_SLOTS_LINE;
     for (uint32_t q = 0; q < MFX_SLOTS_LINE; ++q) {
-      mfx_slot *sl = t.slots + base + ((pr.p1 + q) & (MFX_SLOTS_LINE - 1));
+      mfx_slot *sl = t.slots + base + q;                 // slots fill in order: a line has room <=> its LAST slot is empty
       unsigned long long *kp = reinterpret_cast<unsigned long long *>(&sl->key);
       unsigned long long cur = __hip_atomic_load(kp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (cur == MFX_EMPTY) {
@@ -302,9 +302,21 @@ __device__ __forceinline__ void mfx_group_announce(uint32_t (&ls)[8], uint32_t (
   khi[S] = mfx_group_bcast<S>(key_hi);
 }
 
+typedef uint32_t mfx_u32x4 __attribute__((ext_vector_type(4)));
+
+// The slot loads are written as instructions: left to the compiler, a slot whose value half is only used inside
+// the "key matches" branch gets its load split -- key half here, value half as a second, dependent load behind a
+// vmcnt(0) inside the branch.  So: eight global_load_dwordx4 back to back, and before slot S is looked at, a
+// counted wait (vmcnt(7 - S): the S+1 oldest of the eight have landed; other loads in flight can only make
+// that wait longer, never too short).
 template <int S>
-__device__ __forceinline__ void mfx_group_fetch(const mfx_table_view &t, uint4 (&v)[8], const uint32_t (&ls)[8], uint32_t sub) {
-  v[S] = *reinterpret_cast<const uint4 *>(t.slots + (uint64_t)ls[S] * MFX_SLOTS_LINE + sub);
+__device__ __forceinline__ void mfx_group_fetch(const mfx_table_view &t, mfx_u32x4 (&v)[8], const uint32_t (&ls)[8], uint32_t sub) {
+  const mfx_slot *p = t.slots + (uint64_t)ls[S] * MFX_SLOTS_LINE + sub;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[S]) : "v"(p));
+}
+template <int S>
+__device__ __forceinline__ void mfx_group_landed(mfx_u32x4 (&v)[8]) {
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v[S]) : "n"(7 - S));
 }
 
 // Post phase.  The slot lane compares the FULL key: keys are unique in the table, so at
@@ -312,15 +324,23 @@ __device__ __forceinline__ void mfx_group_fetch(const mfx_table_view &t, uint4 (
 // interleave their words (a low-word-only pre-match would let that happen ~1e-9 per query,
 // i.e. a few times per 3 Gb launch).
 template <int S>
-__device__ __forceinline__ void mfx_group_post(mfx_mailbox &M, const uint4 (&v)[8], const uint32_t (&klo)[8],
+__device__ __forceinline__ void mfx_group_post(mfx_mailbox &M, const mfx_u32x4 (&v)[8], const uint32_t (&klo)[8],
                                                const uint32_t (&khi)[8], uint32_t obase) {
-  const uint4 s = v[S];
+  const mfx_u32x4 s = v[S];
   uint32_t *rec = reinterpret_cast<uint32_t *>(&M.rec[obase + S]);
-  if ((s.x & s.y) == 0xffffffffu) {
-    rec[3] = 1u;                                              // this line still has an empty slot
-  } else if (s.x == klo[S] && s.y == khi[S]) {
+  if (s.x == klo[S] && s.y == khi[S]) {                      // an empty slot (key ~0) never equals a k-mer
     rec[0] = s.z; rec[1] = s.w; rec[2] = 1u;                  // {readV, asmV, found}
   }
+}
+
+// "The line still has room" travels without LDS: slots fill in order (mfx_claim), so a line has room
+// exactly when its LAST slot is empty -- the lane with sub == 7 knows.  One ballot per round; bit 8g+7 of
+// it belongs to the owner (g, S), i.e. to lane 8g+S: shifted there, the 8 rounds OR into ONE wave-wide
+// mask whose bit `lane` is that lane's own answer.  Scalar work only.
+template <int S>
+__device__ __forceinline__ uint64_t mfx_group_room(const mfx_u32x4 (&v)[8]) {
+  const uint64_t m = __ballot((v[S].x & v[S].y) == 0xffffffffu);
+  return ((m >> 7) & 0x0101010101010101ULL) << S;
 }
 
 // B queries per lane; ok[j] false = no query.  Results: rv[j], av[j].
@@ -340,7 +360,7 @@ __device__ __forceinline__ void mfx_group_lookup(const mfx_table_view &t, mfx_ma
   }
 #pragma unroll
   for (int j = 0; j < B; ++j) {
-    uint4 v[8];
+    mfx_u32x4 v[8];
     uint32_t klo[8], khi[8];
     const uint32_t key_lo = (uint32_t)key[j], key_hi = (uint32_t)(key[j] >> 32);
     M.rec[tid] = make_uint4(0u, 0u, 0u, 0u);
@@ -352,9 +372,15 @@ __device__ __forceinline__ void mfx_group_lookup(const mfx_table_view &t, mfx_ma
     mfx_group_fetch<0>(t, v, ls, sub); mfx_group_fetch<1>(t, v, ls, sub); mfx_group_fetch<2>(t, v, ls, sub);
     mfx_group_fetch<3>(t, v, ls, sub); mfx_group_fetch<4>(t, v, ls, sub); mfx_group_fetch<5>(t, v, ls, sub);
     mfx_group_fetch<6>(t, v, ls, sub); mfx_group_fetch<7>(t, v, ls, sub);
-    mfx_group_post<0>(M, v, klo, khi, obase); mfx_group_post<1>(M, v, klo, khi, obase); mfx_group_post<2>(M, v, klo, khi, obase);
-    mfx_group_post<3>(M, v, klo, khi, obase); mfx_group_post<4>(M, v, klo, khi, obase); mfx_group_post<5>(M, v, klo, khi, obase);
-    mfx_group_post<6>(M, v, klo, khi, obase); mfx_group_post<7>(M, v, klo, khi, obase);
+    uint64_t room = 0;
+    mfx_group_landed<0>(v); mfx_group_post<0>(M, v, klo, khi, obase); room |= mfx_group_room<0>(v);
+    mfx_group_landed<1>(v); mfx_group_post<1>(M, v, klo, khi, obase); room |= mfx_group_room<1>(v);
+    mfx_group_landed<2>(v); mfx_group_post<2>(M, v, klo, khi, obase); room |= mfx_group_room<2>(v);
+    mfx_group_landed<3>(v); mfx_group_post<3>(M, v, klo, khi, obase); room |= mfx_group_room<3>(v);
+    mfx_group_landed<4>(v); mfx_group_post<4>(M, v, klo, khi, obase); room |= mfx_group_room<4>(v);
+    mfx_group_landed<5>(v); mfx_group_post<5>(M, v, klo, khi, obase); room |= mfx_group_room<5>(v);
+    mfx_group_landed<6>(v); mfx_group_post<6>(M, v, klo, khi, obase); room |= mfx_group_room<6>(v);
+    mfx_group_landed<7>(v); mfx_group_post<7>(M, v, klo, khi, obase); room |= mfx_group_room<7>(v);
     const uint4 r = M.rec[tid];
     if (ok[j]) {
       if (r.z == 1u) {
@@ -362,7 +388,7 @@ __device__ __forceinline__ void mfx_group_lookup(const mfx_table_view &t, mfx_ma
         av[j] = r.y;
       } else {
         // not in the home line: absent if that line has room, else continue at the next candidate line
-        pending[j] = r.w == 0u ? 1u : 0u;
+        pending[j] = ((room >> (tid & 63u)) & 1ULL) ? 0u : 1u;
       }
     }
   }
