@@ -436,7 +436,8 @@ extern "C" mfx_seq *mfx_seq_upload(int device, const char *const *bases, const u
   // pinned staging buffer and sent in large pieces: an assembly of a million small contigs must not
   // become a million tiny hipMemcpy calls.
   // Two staging buffers alternate: while one is in flight over PCIe the host fills the other.
-  const size_t STAGE = 64ull << 20;
+  // (sized to the upload: pinning memory costs ~0.4 ms per MB, which a small upload should not pay 128 MB of)
+  const size_t STAGE = (size_t)std::min<uint64_t>(64ull << 20, std::max<uint64_t>(1ull << 20, ((s->buf_bytes / 2 + (1ull << 20)) >> 20) << 20));
   uint8_t *stages[2] = {nullptr, nullptr};
   hipStream_t cs = nullptr;
   hipEvent_t done_ev[2] = {nullptr, nullptr};

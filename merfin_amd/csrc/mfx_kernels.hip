@@ -1053,6 +1053,7 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_dump_kernel(mfx_dump_args a) {
   __syncthreads();
   uint64_t n_valid = 0, n_missing = 0, zz = 0;
   for (uint32_t b = 0; b < MFX_TILE / MFX_BLOCK; b += MFX_BATCH) {
+    if (pos0 + (uint64_t)b * MFX_BLOCK >= a.npos) break;          // last block of the range (block-uniform)
     uint64_t key[MFX_BATCH], key2[MFX_BATCH];
     uint32_t rv[MFX_BATCH], av[MFX_BATCH];
     bool     ok[MFX_BATCH], wr[MFX_BATCH];
