@@ -65,7 +65,7 @@ constexpr uint32_t MFX_MZ_REGION = 4;
 constexpr uint32_t MFX_MAX_LINES = 512;
 
 struct mfx_probe {
-  uint32_t lineA, lineB, p1;
+  uint32_t lineA, lineB;
 };
 
 // Canonical minimizer of a k-mer: of its w windows of m = k-w+1 bases, the canonical m-mer
@@ -103,7 +103,6 @@ __device__ __forceinline__ uint32_t mfx_mz_line(const mfx_table_view &t, uint64_
 __device__ __forceinline__ mfx_probe mfx_home(const mfx_table_view &t, uint64_t key) {
   mfx_probe pr;
   uint64_t h = mfx_hash64(key);
-  pr.p1 = (uint32_t)h & (MFX_SLOTS_LINE - 1);
   pr.lineB = mfx_range32(h, t.nlines);
   pr.lineA = pr.lineB;
   if (t.mz_w > 0)
@@ -280,13 +279,12 @@ __device__ __forceinline__ uint32_t mfx_group_bcast(uint32_t v) {
 
 // Result hand-off goes through a per-wave LDS mailbox (one 16-byte record per
 // lane/owner): the lane that holds the matching slot writes {readV, asmV,
-// found} straight into the owner's record, a lane that sees an empty slot raises
-// the owner's "line has room" flag.  LDS requests of one wave are served in
+// found} straight into the owner's record.  LDS requests of one wave are served in
 // order, so the owner's later read needs no barrier.  This replaces three
 // cross-lane permutes + ballot decoding per served query with one predicated
-// store.
+// store.  ("The line has room" does not go through LDS in the first pass: mfx_group_room.)
 struct mfx_mailbox {
-  uint4 rec[MFX_BLOCK];      // x = readV, y = asmV, z = found, w = the line has an empty slot
+  uint4 rec[MFX_BLOCK];      // x = readV, y = asmV, z = found; w = "candidate line has room" in the second pass only
 };
 
 // Issue phase of a round, in two steps so that nothing serialises: first ALL the
