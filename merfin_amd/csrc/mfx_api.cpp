@@ -200,6 +200,12 @@ extern "C" mfx_index *mfx_index_create(int k, uint64_t capacity_kmers, double ma
     ix->mz_w = mz ? std::min(w, k) : 0;
   }
   hipError_t e = hipMalloc((void **)&ix->d_slots, ix->nlines * MFX_ALIGN);
+  if (e != hipSuccess && ix->nlines > lines_for(capacity_kmers)) {
+    // the roomier table did not fit after all (fragmentation, another process): fall back to the smallest one
+    (void)hipGetLastError();
+    ix->nlines = lines_for(capacity_kmers);
+    e = hipMalloc((void **)&ix->d_slots, ix->nlines * MFX_ALIGN);
+  }
   if (e != hipSuccess) {
     mfx_fail(MFX_E_NOMEM, "hipMalloc of %.3f GB for the k-mer table failed: %s", need, hipGetErrorString(e));
     delete ix;
