@@ -110,11 +110,8 @@ __device__ __forceinline__ mfx_probe mfx_home(const mfx_table_view &t, uint64_t 
   return pr;
 }
 
-// first candidate line only (the hot path needs nothing else); krc = revcomp(key).
-// W > 0: the caller guarantees t.mz_w == W, so the window loop unrolls into straight-line code.
-template <int W = 0>
+// first candidate line only (the hot path needs nothing else); krc = revcomp(key)
 __device__ __forceinline__ uint32_t mfx_first_line(const mfx_table_view &t, uint64_t key, uint64_t krc) {
-  if (W > 0) return mfx_range32(mfx_minimizer(key, krc, t.k, W) * 0xD6E8FEB86659FD93ULL, t.nlines);
   if (t.mz_w > 0) return mfx_mz_line(t, key, krc);
   return mfx_range32(mfx_hash64(key), t.nlines);
 }
@@ -342,7 +339,7 @@ __device__ __forceinline__ uint64_t mfx_group_room(const mfx_u32x4 (&v)[8]) {
 }
 
 // B queries per lane; ok[j] false = no query.  Results: rv[j], av[j].
-template <int B, int W = 0>
+template <int B>
 __device__ __forceinline__ void mfx_group_lookup(const mfx_table_view &t, mfx_mailbox &M, const uint64_t (&key)[B],
                                                  const uint64_t (&krc)[B], const bool (&ok)[B], uint32_t (&rv)[B],
                                                  uint32_t (&av)[B]) {
@@ -350,11 +347,10 @@ __device__ __forceinline__ void mfx_group_lookup(const mfx_table_view &t, mfx_ma
   uint32_t line[B];
   uint32_t pending[B];          // 0 resolved, 1 home line full: continue at candidate line 1
 #pragma unroll
-  for (int j = 0; j < B; ++j) {
-    const uint32_t fl = mfx_first_line<W>(t, key[j], krc[j]);
-    line[j] = ok[j] ? fl : 0u;                                     // no k-mer here: a dummy query of line 0, ignored below
-    pending[j] = 0u;
-    rv[j] = av[j] = 0u;
+  for (int j = 0; j < B; ++j) { pending[j] = 0u; rv[j] = av[j] = 0u; }
+  {
+    const uint32_t fl = mfx_first_line(t, key[0], krc[0]);
+    line[0] = ok[0] ? fl : 0u;                                     // no k-mer here: a dummy query of line 0, ignored below
   }
 #pragma unroll
   for (int j = 0; j < B; ++j) {
@@ -370,6 +366,11 @@ __device__ __forceinline__ void mfx_group_lookup(const mfx_table_view &t, mfx_ma
     mfx_group_fetch<0>(t, v, ls, sub); mfx_group_fetch<1>(t, v, ls, sub); mfx_group_fetch<2>(t, v, ls, sub);
     mfx_group_fetch<3>(t, v, ls, sub); mfx_group_fetch<4>(t, v, ls, sub); mfx_group_fetch<5>(t, v, ls, sub);
     mfx_group_fetch<6>(t, v, ls, sub); mfx_group_fetch<7>(t, v, ls, sub);
+    // the next query's placement hash is computed HERE, under this query's eight loads
+    if (j + 1 < B) {
+      const uint32_t fl = mfx_first_line(t, key[j + 1], krc[j + 1]);
+      line[j + 1] = ok[j + 1] ? fl : 0u;
+    }
     uint64_t room = 0;
     mfx_group_landed<0>(v); mfx_group_post<0>(M, v, klo, khi, obase); room |= mfx_group_room<0>(v);
     mfx_group_landed<1>(v); mfx_group_post<1>(M, v, klo, khi, obase); room |= mfx_group_room<1>(v);
@@ -619,8 +620,7 @@ __device__ __forceinline__ void mfx_hist_lds_flush(mfx_hist_lds &H, const mfx_ks
   if (tid == 0) ka.partials[blockIdx.x] = H.dred[0];
 }
 
-// W: the table's minimizer window count when it is the default one (straight-line placement code), else 0
-template <bool CANON, int W>
+template <bool CANON>
 __global__ __launch_bounds__(MFX_BLOCK, 4) void mfx_hist_kernel(mfx_hist_args a) {
   __shared__ mfx_tile_lds L;
   __shared__ mfx_mailbox MB;
@@ -690,11 +690,11 @@ __global__ __launch_bounds__(MFX_BLOCK, 4) void mfx_hist_kernel(mfx_hist_args a)
           key[j] = f; key2[j] = r;
         }
       }
-      mfx_group_lookup<MFX_BATCH, W>(a.t, MB, key, key2, ok, rv, av);
+      mfx_group_lookup<MFX_BATCH>(a.t, MB, key, key2, ok, rv, av);
       if (!CANON) {
         // value(fmer) + value(rmer), uint32 arithmetic (merfin-globals.C:107-108)
         uint32_t rv2[MFX_BATCH], av2[MFX_BATCH];
-        mfx_group_lookup<MFX_BATCH, W>(a.t, MB, key2, key, ok, rv2, av2);
+        mfx_group_lookup<MFX_BATCH>(a.t, MB, key2, key, ok, rv2, av2);
 #pragma unroll
         for (int j = 0; j < MFX_BATCH; ++j) { rv[j] += rv2[j]; av[j] += av2[j]; }
       }
@@ -943,7 +943,6 @@ __global__ void mfx_iota_kernel(uint32_t *v, uint64_t n) {
 
 // owner side: canonical k-mers (grouped by source order) -> lookup -> K* -> bins.
 // kasm was counted by the source; this adds kmissing (global + per contig), bins, koverCpy.
-template <int W>
 __global__ __launch_bounds__(MFX_BLOCK, 4) void mfx_hist_keys_kernel(mfx_hist_keys_args a) {
   __shared__ mfx_mailbox MB;
   __shared__ mfx_hist_lds H;
@@ -977,7 +976,7 @@ __global__ __launch_bounds__(MFX_BLOCK, 4) void mfx_hist_keys_kernel(mfx_hist_ke
       key[j] = ok[j] ? a.keys[i] : 0ULL;
       krc[j] = mfx_revcomp(key[j], k);
     }
-    mfx_group_lookup<MFX_BATCH, W>(a.t, MB, key, krc, ok, rv, av);
+    mfx_group_lookup<MFX_BATCH>(a.t, MB, key, krc, ok, rv, av);
 #pragma unroll
     for (int j = 0; j < MFX_BATCH; ++j) {
       const bool miss = ok[j] && mfx_hist_eval(H, ka, lut_ok, rv[j], av[j], n_over0, kover);
@@ -1197,10 +1196,8 @@ hipError_t mfx_k_table_export(mfx_table_view t, uint64_t *kmers, uint32_t *readV
 hipError_t mfx_k_hist(const mfx_hist_args &a, int grid, hipStream_t st) {
   // MFX_DEBUG_DYN_LDS: extra dynamic LDS per block, an occupancy knob for experiments only
   static const unsigned dyn = getenv("MFX_DEBUG_DYN_LDS") ? (unsigned)atoi(getenv("MFX_DEBUG_DYN_LDS")) : 0u;
-  // the common case (canonical DB, default placement) gets the window loop unrolled at compile time
-  if (a.canonical && a.t.mz_w == MFX_MZ_W_DEFAULT) mfx_hist_kernel<true, MFX_MZ_W_DEFAULT><<<grid, MFX_BLOCK, dyn, st>>>(a);
-  else if (a.canonical)                            mfx_hist_kernel<true, 0><<<grid, MFX_BLOCK, dyn, st>>>(a);
-  else                                             mfx_hist_kernel<false, 0><<<grid, MFX_BLOCK, dyn, st>>>(a);
+  if (a.canonical) mfx_hist_kernel<true><<<grid, MFX_BLOCK, dyn, st>>>(a);
+  else             mfx_hist_kernel<false><<<grid, MFX_BLOCK, dyn, st>>>(a);
   return hipGetLastError();
 }
 hipError_t mfx_k_route(const mfx_route_args &a, hipStream_t st) {
@@ -1230,8 +1227,7 @@ hipError_t mfx_k_iota(uint32_t *v, uint64_t n, hipStream_t st) {
   return hipGetLastError();
 }
 hipError_t mfx_k_hist_keys(const mfx_hist_keys_args &a, int grid, hipStream_t st) {
-  if (a.t.mz_w == MFX_MZ_W_DEFAULT) mfx_hist_keys_kernel<MFX_MZ_W_DEFAULT><<<grid, MFX_BLOCK, 0, st>>>(a);
-  else                              mfx_hist_keys_kernel<0><<<grid, MFX_BLOCK, 0, st>>>(a);
+  mfx_hist_keys_kernel<<<grid, MFX_BLOCK, 0, st>>>(a);
   return hipGetLastError();
 }
 hipError_t mfx_k_sum_partials(const double *partials, uint32_t n, double *out, hipStream_t st) {
@@ -1252,7 +1248,7 @@ hipError_t mfx_k_sum_tile_partials(double *tile_partials, uint64_t ntiles, doubl
 }
 int mfx_k_hist_resident_blocks() {
   int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mfx_hist_kernel<true, MFX_MZ_W_DEFAULT>, MFX_BLOCK, 0) != hipSuccess || nb < 1) nb = 4;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mfx_hist_kernel<true>, MFX_BLOCK, 0) != hipSuccess || nb < 1) nb = 4;
   return nb;
 }
 hipError_t mfx_k_dump(const mfx_dump_args &a, hipStream_t st) {
