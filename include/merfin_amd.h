@@ -215,6 +215,12 @@ void mfx_hist_result_free(mfx_hist_result *r);
 #define MFX_HIST_WORDS(nbins, ncontigs) (2ull * (nbins) + 3ull + 2ull * (ncontigs))
 int mfx_hist_launch(mfx_eval *ev, const mfx_seq *seq, uint64_t tile_begin, uint64_t tile_end,
                     uint64_t *d_counts, double *d_kover, void *stream);
+/* The same for the block-cyclic share of `rank` out of `nranks`: the tiles are cut into blocks of `block_tiles`
+ * (a power of two) and rank r evaluates blocks r, r + nranks, ...  Every rank then sees every region of the assembly,
+ * so a positional skew of the per-k-mer cost (repeats, k-mers that sit in overflow lines of the table) cannot make
+ * one rank the straggler, which a contiguous split allows (profiles/r01_shard_timing.txt). */
+int mfx_hist_launch_cyclic(mfx_eval *ev, const mfx_seq *seq, uint32_t rank, uint32_t nranks, uint32_t block_tiles,
+                           uint64_t *d_counts, double *d_kover, void *stream);
 /* turn an (all-reduced, host-resident) d_counts/d_kover image into a result
  * (pure host code: usable without a device, e.g. on the reducing rank) */
 int mfx_hist_result_from_counts(uint32_t nbins, const uint64_t *h_counts, double kover,

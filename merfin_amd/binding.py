@@ -66,7 +66,7 @@ SYMBOLS = [
     "mfx_seq_upload", "mfx_seq_from_device", "mfx_seq_free", "mfx_seq_num_contigs", "mfx_seq_num_bases",
     "mfx_seq_num_tiles",
     "mfx_eval_create", "mfx_eval_free", "mfx_eval_nbins", "mfx_getK", "mfx_getKmetric", "mfx_histoQV",
-    "mfx_hist_run", "mfx_hist_result_free", "mfx_hist_launch", "mfx_hist_result_from_counts",
+    "mfx_hist_run", "mfx_hist_result_free", "mfx_hist_launch", "mfx_hist_launch_cyclic", "mfx_hist_result_from_counts",
     "mfx_hist_take_overflow", "mfx_hist_report",
     "mfx_dump_values", "mfx_dump_contig", "mfx_completeness", "mfx_completeness_pieces", "mfx_variants_run",
     "mfx_index_set_shard", "mfx_router_create", "mfx_router_free", "mfx_route_tiles", "mfx_hist_keys_launch",
@@ -152,6 +152,7 @@ def load_library():
     L.mfx_hist_run.argtypes = [vp, vp, C.POINTER(_HistResult)]
     L.mfx_hist_result_free.argtypes = [C.POINTER(_HistResult)]
     L.mfx_hist_launch.argtypes = [vp, vp, C.c_uint64, C.c_uint64, vp, vp, vp]
+    L.mfx_hist_launch_cyclic.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]
     L.mfx_hist_result_from_counts.argtypes = [C.c_uint32, u64p, C.c_double, C.c_uint32, C.POINTER(_HistResult)]
     L.mfx_hist_take_overflow.argtypes = [vp, u64p, C.c_uint64, u64p]
     L.mfx_hist_report.argtypes = [C.POINTER(_HistResult), C.c_int, C.c_char_p, C.c_char_p]
@@ -494,6 +495,12 @@ class Evaluator:
         pk = d_kover.data_ptr() if hasattr(d_kover, "data_ptr") else int(d_kover)
         _check(load_library().mfx_hist_launch(self.h, seqs.h, tile_begin, tile_end, C.c_void_p(pc), C.c_void_p(pk),
                                               C.c_void_p(stream or 0)))
+
+    def hist_launch_cyclic(self, seqs, rank, nranks, d_counts, d_kover, block_tiles=256, stream=None):
+        """the block-cyclic share of `rank`: blocks of `block_tiles` tiles dealt round-robin to the ranks"""
+        p = lambda x: C.c_void_p(x.data_ptr() if hasattr(x, "data_ptr") else int(x))
+        _check(load_library().mfx_hist_launch_cyclic(self.h, seqs.h, rank, nranks, block_tiles, p(d_counts), p(d_kover),
+                                                     C.c_void_p(stream or 0)))
 
     def result_from_counts(self, h_counts, kover, ncontigs):
         return result_from_counts(self.nbins, h_counts, kover, ncontigs)

@@ -644,20 +644,22 @@ static int eval_canonical(mfx_eval *ev, int *canon) {
   return MFX_OK;
 }
 
-extern "C" int mfx_hist_launch(mfx_eval *ev, const mfx_seq *seq, uint64_t tile_begin, uint64_t tile_end,
-                               uint64_t *d_counts, double *d_kover, void *stream) {
-  if (!ev || !seq || !d_counts || !d_kover) return mfx_fail(MFX_E_INVAL, "mfx_hist_launch: null argument");
-  if (ev->device != seq->device) return mfx_fail(MFX_E_INVAL, "evaluator and sequence live on different devices");
-  if (tile_begin > tile_end || tile_end > seq->ntiles) return mfx_fail(MFX_E_INVAL, "tile range [%lu,%lu) outside [0,%lu)",
-                                                                      (unsigned long)tile_begin, (unsigned long)tile_end, (unsigned long)seq->ntiles);
-  if (tile_begin == tile_end) return MFX_OK;
+// part_n == 1: tiles [tile_begin, tile_end); part_n > 1: the block-cyclic share of part_rank over ALL tiles
+static int hist_launch(mfx_eval *ev, const mfx_seq *seq, uint64_t tile_begin, uint64_t tile_end, uint32_t part_rank, uint32_t part_n,
+                       uint32_t part_shift, uint64_t *d_counts, double *d_kover, void *stream) {
+  uint64_t ntl = tile_end - tile_begin;
+  if (part_n > 1) {
+    const uint64_t blk = 1ull << part_shift, nblk = (seq->ntiles + blk - 1) / blk;
+    ntl = 0;
+    for (uint64_t b = part_rank; b < nblk; b += part_n) ntl += std::min<uint64_t>(blk, seq->ntiles - b * blk);
+  }
+  if (ntl == 0) return MFX_OK;
   DevGuard g(ev->device);
   int canon = 0;
   int rc = eval_canonical(ev, &canon);
   if (rc) return rc;
   const char *force = getenv("MFX_FORCE_TWO_STRAND");
   if (force && atoi(force)) canon = 0;
-  const uint64_t ntl = tile_end - tile_begin;
   const uint64_t need = mfx_k_tile_partials_words(ntl);
   if (need > ev->tile_partials_cap) {
     if (ev->d_tile_partials) (void)hipFree(ev->d_tile_partials);
@@ -679,6 +681,10 @@ extern "C" int mfx_hist_launch(mfx_eval *ev, const mfx_seq *seq, uint64_t tile_b
   a.tile_contig = seq->d_tile_contig;
   a.tile_ctr = ev->d_tile_ctr;
   a.tile_partials = ev->d_tile_partials;
+  a.n_logical = ntl;
+  a.part_rank = part_rank;
+  a.part_n = part_n;
+  a.part_shift = part_shift;
   a.ks.peak = ev->peak;
   a.ks.n_prob = ev->n_prob;
   a.ks.probK = ev->d_probK;
@@ -691,6 +697,27 @@ extern "C" int mfx_hist_launch(mfx_eval *ev, const mfx_seq *seq, uint64_t tile_b
   MFX_HIP(mfx_k_hist(a, (int)std::min<uint64_t>((uint64_t)ev->grid, ntl), (hipStream_t)stream));
   MFX_HIP(mfx_k_sum_tile_partials(ev->d_tile_partials, ntl, d_kover, ev->d_tile_ctr, (hipStream_t)stream));
   return MFX_OK;
+}
+
+extern "C" int mfx_hist_launch(mfx_eval *ev, const mfx_seq *seq, uint64_t tile_begin, uint64_t tile_end,
+                               uint64_t *d_counts, double *d_kover, void *stream) {
+  if (!ev || !seq || !d_counts || !d_kover) return mfx_fail(MFX_E_INVAL, "mfx_hist_launch: null argument");
+  if (ev->device != seq->device) return mfx_fail(MFX_E_INVAL, "evaluator and sequence live on different devices");
+  if (tile_begin > tile_end || tile_end > seq->ntiles) return mfx_fail(MFX_E_INVAL, "tile range [%lu,%lu) outside [0,%lu)",
+                                                                      (unsigned long)tile_begin, (unsigned long)tile_end, (unsigned long)seq->ntiles);
+  return hist_launch(ev, seq, tile_begin, tile_end, 0, 1, 0, d_counts, d_kover, stream);
+}
+
+extern "C" int mfx_hist_launch_cyclic(mfx_eval *ev, const mfx_seq *seq, uint32_t rank, uint32_t nranks, uint32_t block_tiles,
+                                      uint64_t *d_counts, double *d_kover, void *stream) {
+  if (!ev || !seq || !d_counts || !d_kover) return mfx_fail(MFX_E_INVAL, "mfx_hist_launch_cyclic: null argument");
+  if (ev->device != seq->device) return mfx_fail(MFX_E_INVAL, "evaluator and sequence live on different devices");
+  if (nranks == 0 || rank >= nranks || block_tiles == 0 || (block_tiles & (block_tiles - 1)))
+    return mfx_fail(MFX_E_INVAL, "mfx_hist_launch_cyclic: rank %u of %u, block of %u tiles (a power of two)", rank, nranks, block_tiles);
+  uint32_t shift = 0;
+  while ((1u << shift) < block_tiles) ++shift;
+  if (nranks == 1) return hist_launch(ev, seq, 0, seq->ntiles, 0, 1, 0, d_counts, d_kover, stream);
+  return hist_launch(ev, seq, 0, seq->ntiles, rank, nranks, shift, d_counts, d_kover, stream);
 }
 
 extern "C" int mfx_hist_take_overflow(mfx_eval *ev, uint64_t *records, uint64_t cap, uint64_t *n_out) {

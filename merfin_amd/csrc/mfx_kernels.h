@@ -24,7 +24,12 @@ struct mfx_hist_args {
   uint64_t        tile_begin, tile_end;
   const uint32_t *tile_contig;        // [ntiles] contig of every tile
   uint64_t       *tile_ctr;           // dynamic tile scheduler: tiles handed out beyond the first gridDim.x (0 at launch)
-  double         *tile_partials;      // [(tile_end - tile_begin) * MFX_BLOCK/64] koverCpy of every (tile, wave)
+  double         *tile_partials;      // [n_logical * MFX_BLOCK/64] koverCpy of every (tile, wave) of this launch
+  // The launch evaluates n_logical tiles, numbered li = 0 .. n_logical-1:
+  //   part_n == 1 : the contiguous range, tile = tile_begin + li
+  //   part_n  > 1 : block-cyclic share of rank part_rank: tile = ((li >> part_shift) * part_n + part_rank << part_shift) + (li & mask)
+  uint64_t        n_logical;
+  uint32_t        part_rank, part_n, part_shift;
   mfx_kstar_args  ks;
 };
 

@@ -644,10 +644,12 @@ __global__ __launch_bounds__(MFX_BLOCK, 4) void mfx_hist_kernel(mfx_hist_args a)
   // depend on which block evaluated which tile.
   const uint32_t none = 0xffffffffu;
   uint32_t c = none;
-  uint64_t tile = a.tile_begin + blockIdx.x;
-  for (uint32_t it = 0; tile < a.tile_end; ++it) {
+  uint64_t li = blockIdx.x;                    // number of the tile within this launch
+  for (uint32_t it = 0; li < a.n_logical; ++it) {
     if (tid == 0)
-      H.next[it & 1] = a.tile_begin + gridDim.x + atomicAdd((unsigned long long *)a.tile_ctr, 1ull);
+      H.next[it & 1] = (uint64_t)gridDim.x + atomicAdd((unsigned long long *)a.tile_ctr, 1ull);
+    const uint64_t tile = a.part_n == 1 ? a.tile_begin + li
+                                         : ((((li >> a.part_shift) * a.part_n + a.part_rank) << a.part_shift) | (li & ((1ull << a.part_shift) - 1ull)));
     const uint32_t cn = a.tile_contig[tile];
     if (cn != c) {
       if (c != none) {
@@ -708,12 +710,12 @@ __global__ __launch_bounds__(MFX_BLOCK, 4) void mfx_hist_kernel(mfx_hist_args a)
     // koverCpy of this (tile, wave): fixed-order tree over the 64 lanes
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) kover = kover + __shfl_down(kover, off, 64);
-    if ((tid & 63u) == 0) a.tile_partials[(tile - a.tile_begin) * (MFX_BLOCK / 64) + (tid >> 6)] = kover;
+    if ((tid & 63u) == 0) a.tile_partials[li * (MFX_BLOCK / 64) + (tid >> 6)] = kover;
 
     __syncthreads();                         // tile consumed; H.next[it & 1] written
     const uint64_t nx = H.next[it & 1];
-    tile = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(nx >> 32)) << 32) |
-           (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)nx);
+    li = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(nx >> 32)) << 32) |
+         (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)nx);
   }
   // last contig of this block + the register-held dominant bin
   {

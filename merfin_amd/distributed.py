@@ -41,6 +41,15 @@ def contig_partition(weights, world):
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
 
 
+def cyclic_tiles(ntiles, rank, world, block_tiles=256):
+    """tiles of `rank` under the block-cyclic partition of mfx_hist_launch_cyclic (blocks of `block_tiles` dealt
+    round-robin), as a list of (lo, hi) runs -- every rank sees every region of the assembly"""
+    out = []
+    for b in range(rank, -(-ntiles // block_tiles), world):
+        out.append((b * block_tiles, min(ntiles, (b + 1) * block_tiles)))
+    return out
+
+
 def pack_counts(nbins, ncontigs, undr, over, kasm, kmissing, contig_kasm, contig_kmissing):
     """host-side image with the device layout (include/merfin_amd.h MFX_HIST_WORDS)"""
     h = np.zeros(hist_words(nbins, ncontigs), dtype=np.uint64)

@@ -257,8 +257,7 @@ def main(argv=None):
                 torch.cuda.synchronize()
             reduce_all()
     else:
-        lo, hi = D.shard(sq.ntiles, rank, world)
-        ev.hist_launch(sq, lo, hi, counts, kover, stream=stream)
+        ev.hist_launch_cyclic(sq, rank, world, counts, kover, stream=stream)      # block-cyclic share of the tiles
         torch.cuda.synchronize()
         reduce_all()
     torch.cuda.synchronize()

@@ -380,6 +380,47 @@ def test_sharded_launch_equals_whole(golden_dir):
         assert res.koverCpy == pytest.approx(whole.koverCpy, rel=1e-12)
 
 
+@pytest.mark.parametrize("nranks,blk", [(2, 1), (3, 4), (8, 2), (5, 256)])
+def test_cyclic_launches_equal_whole(nranks, blk):
+    """block-cyclic tile partition (multi-GPU -hist): the ranks' shares cover every tile once, so they
+    accumulate to the whole-assembly integers; and each share equals the contiguous launches of its runs"""
+    torch = pytest.importorskip("torch")
+    m = _mfx()
+    from merfin_amd import distributed as D
+    k, peak = 21, 17.3
+    contigs, read, asm = synth.world(k=k, peak=peak, seed=29)
+    ix = build_index(m, k, read, asm)
+    ev = m.Evaluator(ix, m.KParams(peak))
+    seqs = m.Sequences(contigs)
+    whole = ev.hist(seqs)
+    T = seqs.ntiles
+    assert T > 2 * blk or blk == 256
+    words = m.hist_words(ev.nbins, seqs.ncontigs)
+    counts = torch.zeros(words, dtype=torch.int64, device="cuda")
+    kover = torch.zeros(1, dtype=torch.float64, device="cuda")
+    for rnk in range(nranks):
+        c1 = torch.zeros(words, dtype=torch.int64, device="cuda")
+        k1 = torch.zeros(1, dtype=torch.float64, device="cuda")
+        ev.hist_launch_cyclic(seqs, rnk, nranks, c1, k1, block_tiles=blk)
+        c2 = torch.zeros(words, dtype=torch.int64, device="cuda")
+        k2 = torch.zeros(1, dtype=torch.float64, device="cuda")
+        for lo, hi in D.cyclic_tiles(T, rnk, nranks, blk):
+            ev.hist_launch(seqs, lo, hi, c2, k2)
+        torch.cuda.synchronize()
+        assert torch.equal(c1, c2) and float(k1.item()) == pytest.approx(float(k2.item()), rel=1e-12, abs=1e-12)
+        counts += c1
+        kover += k1
+    res = ev.result_from_counts(counts.cpu().numpy().view(np.uint64), float(kover.item()), seqs.ncontigs)
+    assert res.kasm == whole.kasm and res.kmissing == whole.kmissing
+    np.testing.assert_array_equal(res.undr(), whole.undr())
+    np.testing.assert_array_equal(res.over(), whole.over())
+    np.testing.assert_array_equal(res.contig_kasm(), whole.contig_kasm())
+    np.testing.assert_array_equal(res.contig_kmissing(), whole.contig_kmissing())
+    assert res.koverCpy == pytest.approx(whole.koverCpy, rel=1e-12)
+    with pytest.raises(m.MfxError):
+        ev.hist_launch_cyclic(seqs, 0, 2, counts, kover, block_tiles=3)
+
+
 def test_revcomp_symmetry():
     """Property: the reverse-complemented assembly has the same histogram (both strands are summed)."""
     m = _mfx()

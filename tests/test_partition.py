@@ -23,3 +23,18 @@ def test_contig_partition_examples():
     assert D.contig_partition([5, 1, 1, 1, 8, 2, 2], 3) == [(0, 3), (3, 5), (5, 7)]
     assert D.contig_partition([1], 4) == [(0, 1), (1, 1), (1, 1), (1, 1)]
     assert D.contig_partition([], 2) == [(0, 0), (0, 0)]
+
+
+def test_cyclic_tiles_cover_every_tile_once():
+    r = np.random.default_rng(4)
+    for trial in range(100):
+        T = int(r.integers(0, 5000))
+        world = int(r.integers(1, 9))
+        blk = int(2 ** r.integers(0, 9))
+        seen = np.zeros(T, dtype=np.int32)
+        for rank in range(world):
+            runs = D.cyclic_tiles(T, rank, world, blk)
+            for lo, hi in runs:
+                assert 0 <= lo < hi <= T and hi - lo <= blk and lo % blk == 0 and (lo // blk) % world == rank
+                seen[lo:hi] += 1
+        assert (seen == 1).all()
