@@ -101,6 +101,12 @@ int mfx_db_write_flat(const char *path, int k, const uint64_t *kmers, const uint
  * insert (no reference counterpart; merfin rebuilds its lookup tables on every start, merfin.C:361). */
 int        mfx_index_save(const mfx_index *ix, const char *path);
 mfx_index *mfx_index_load(const char *path, double max_gb, int device);
+/* An image is only as good as the inputs it was built from: the caller stores a digest of them (database and
+ * sequence files: path, size, modification time; -min/-max) with the table and compares it on the next start;
+ * mfx_index_get_origin also returns the read-count filter baked into the table, so that a run with other
+ * -min/-max values can refuse the image instead of silently evaluating with the stored ones. */
+int        mfx_index_set_fingerprint(mfx_index *ix, uint64_t fingerprint);
+int        mfx_index_get_origin(const mfx_index *ix, uint64_t *fingerprint, uint64_t *minV, uint64_t *maxV);
 
 /* The same image in memory, for handing a built table to the other GPUs of a node (one rank decodes the
  * k-mer databases and builds, the table then travels over xGMI -- an RCCL broadcast -- instead of every rank

@@ -62,6 +62,7 @@ SYMBOLS = [
     "mfx_index_create", "mfx_index_free", "mfx_index_estimate_gb", "mfx_index_add_read", "mfx_index_add_asm",
     "mfx_index_count_asm", "mfx_index_value", "mfx_index_get_info", "mfx_index_export",
     "mfx_db_probe", "mfx_index_load_db", "mfx_db_write_flat", "mfx_index_save", "mfx_index_load",
+    "mfx_index_set_fingerprint", "mfx_index_get_origin",
     "mfx_index_image_header", "mfx_index_create_from_header", "mfx_index_device_image", "mfx_index_commit",
     "mfx_seq_upload", "mfx_seq_from_device", "mfx_seq_free", "mfx_seq_num_contigs", "mfx_seq_num_bases",
     "mfx_seq_num_tiles",

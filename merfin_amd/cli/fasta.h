@@ -9,6 +9,8 @@
 #include <string>
 #include <vector>
 
+#include "../csrc/mfx_pipe.h"
+
 struct SeqRecord {
   std::string name;
   std::string bases;
@@ -17,14 +19,11 @@ struct SeqRecord {
 class SeqFile {
  public:
   explicit SeqFile(const std::string &path) {
-    auto ends = [&](const char *s) { size_t n = strlen(s); return path.size() >= n && path.compare(path.size() - n, n, s) == 0; };
-    const char *tool = ends(".gz") ? "gzip -dc" : ends(".bz2") ? "bzip2 -dc" : ends(".xz") ? "xz -dc" : nullptr;
-    pipe_ = tool != nullptr;
-    if (tool) { std::string cmd = std::string(tool) + " '" + path + "'"; f_ = popen(cmd.c_str(), "r"); }
-    else f_ = fopen(path.c_str(), "rb");
+    h_ = mfx_open_reader(path.c_str());        // decompressor by suffix, started without a shell (csrc/mfx_pipe.h)
+    f_ = h_.f;
     buf_.resize(1 << 22);
   }
-  ~SeqFile() { if (f_) { if (pipe_) pclose(f_); else fclose(f_); } }
+  ~SeqFile() { if (f_) (void)mfx_close(h_, true); }
   bool ok() const { return f_ != nullptr; }
 
   // one record per call; false at end of input
@@ -80,7 +79,7 @@ class SeqFile {
     }
   }
   FILE *f_ = nullptr;
-  bool pipe_ = false;
+  mfx_file h_;
   std::vector<char> buf_;
   size_t pos_ = 0, len_ = 0;
   bool have_header_ = false;

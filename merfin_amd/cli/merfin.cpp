@@ -10,7 +10,10 @@
 #include <stdlib.h>
 #include <string.h>
 #include <libgen.h>
+#include <dirent.h>
+#include <sys/stat.h>
 
+#include <algorithm>
 #include <chrono>
 #include <string>
 #include <vector>
@@ -94,6 +97,48 @@ static bool load_Kmetric(Globals &G) {
   }
   fclose(f);
   return true;
+}
+
+// Digest of what an index image was built from: every input's path, size and modification time (for a meryl
+// directory: of each file in it) plus -min/-max.  A changed assembly -- the iterative polish workflow -- or a
+// changed filter gives another digest, and the cached image is rebuilt instead of silently reused.
+static void fp_mix(uint64_t &h, const void *p, size_t n) {
+  const unsigned char *b = (const unsigned char *)p;
+  for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 0x100000001b3ULL; }       // FNV-1a
+}
+static void fp_path(uint64_t &h, const char *path) {
+  if (!path) { fp_mix(h, "-", 1); return; }
+  fp_mix(h, path, strlen(path) + 1);
+  struct stat st;
+  if (stat(path, &st) != 0) return;
+  if (S_ISDIR(st.st_mode)) {
+    std::vector<std::string> names;
+    if (DIR *d = opendir(path)) {
+      while (struct dirent *e = readdir(d)) if (e->d_name[0] != '.') names.push_back(e->d_name);
+      closedir(d);
+    }
+    std::sort(names.begin(), names.end());
+    for (auto &n : names) {
+      std::string f = std::string(path) + "/" + n;
+      struct stat fs;
+      if (stat(f.c_str(), &fs) != 0) continue;
+      fp_mix(h, n.c_str(), n.size() + 1);
+      uint64_t v[3] = {(uint64_t)fs.st_size, (uint64_t)fs.st_mtim.tv_sec, (uint64_t)fs.st_mtim.tv_nsec};
+      fp_mix(h, v, sizeof(v));
+    }
+  } else {
+    uint64_t v[3] = {(uint64_t)st.st_size, (uint64_t)st.st_mtim.tv_sec, (uint64_t)st.st_mtim.tv_nsec};
+    fp_mix(h, v, sizeof(v));
+  }
+}
+static uint64_t input_fingerprint(const Globals &G) {
+  uint64_t h = 0xcbf29ce484222325ULL;
+  fp_path(h, G.readDBname);
+  fp_path(h, G.seqDBname);
+  if (!G.seqDBname) fp_path(h, G.seqName);        // the assembly side is counted from -sequence
+  uint64_t v[2] = {G.minV, G.maxV};
+  fp_mix(h, v, sizeof(v));
+  return h ? h : 1;
 }
 
 #define DIE_MFX(what)                                                       \
@@ -181,6 +226,10 @@ int main(int argc, char **argv) {
     if (adb.k != k) { fprintf(stderr, "ERROR: -seqmers holds %d-mers but -readmers holds %d-mers.\n", adb.k, k); return 1; }
   }
 
+  if (rdb.format == MFX_DB_MERYL || (G.seqDBname && adb.format == MFX_DB_MERYL))
+    fprintf(stderr, "-- NOTE: meryl database directories are decoded from a recalled description of the format; it has not been\n"
+                    "--       checked against upstream meryl.  The decoder cross-checks every database against its own index\n"
+                    "--       statistics; `meryl print` text is the verified interchange form (tools/meryl_conformance.py).\n");
   lap("probe k-mer databases");
   // sequences (load_Sequence, merfin-globals.C:165-197; loadSequence, merfin.C:30-53)
   std::vector<SeqRecord> recs;
@@ -205,6 +254,7 @@ int main(int argc, char **argv) {
   }
   lap("upload sequences");
   FILE *probe = G.indexName ? fopen(G.indexName, "rb") : nullptr;
+  const uint64_t fingerprint = G.indexName ? input_fingerprint(G) : 0;
   if (probe) {
     fclose(probe);
     fprintf(stderr, "-- Loading the index image '%s' (k-mer databases are not read).\n", G.indexName);
@@ -213,7 +263,18 @@ int main(int argc, char **argv) {
     mfx_index_info info;
     if (mfx_index_get_info(ix, &info)) DIE_MFX("reading the index image");
     if (info.k != k) { fprintf(stderr, "ERROR: the index image holds %d-mers but -readmers holds %d-mers.\n", info.k, k); return 1; }
-  } else {
+    uint64_t fp = 0, imin = 0, imax = 0;
+    if (mfx_index_get_origin(ix, &fp, &imin, &imax)) DIE_MFX("reading the index image");
+    if (fp != fingerprint || imin != G.minV || imax != G.maxV) {
+      // the image was built from other inputs (a re-polished -sequence, another database, other -min/-max):
+      // using it would give wrong asmK / readK with no diagnostic
+      fprintf(stderr, "-- The index image '%s' was built from other inputs (%s); rebuilding it.\n", G.indexName,
+              (imin != G.minV || imax != G.maxV) ? "-min/-max differ" : "a database or the sequence file changed");
+      mfx_index_free(ix);
+      ix = nullptr;
+    }
+  }
+  if (!ix) {
     const uint64_t capacity = rdb.n_kmers + (G.seqDBname ? adb.n_kmers : totalBases) + 1024;
     fprintf(stderr, "--\n-- Memory needed: %.3f GB\n-- Memory limit:  %.3f GB%s\n--\n", mfx_index_estimate_gb(k, capacity),
             G.maxMemory, G.maxMemory > 0 ? "" : " (none)");
@@ -234,7 +295,7 @@ int main(int argc, char **argv) {
     }
     if (G.indexName) {
       fprintf(stderr, "-- Writing the index image '%s'.\n", G.indexName);
-      if (mfx_index_save(ix, G.indexName)) DIE_MFX("writing the index image");
+      if (mfx_index_set_fingerprint(ix, fingerprint) || mfx_index_save(ix, G.indexName)) DIE_MFX("writing the index image");
     }
   }
 

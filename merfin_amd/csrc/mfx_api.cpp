@@ -4,6 +4,7 @@
 // a usable HIP device every entry point fails with MFX_E_NODEVICE / MFX_E_HIP.
 #include "mfx_internal.h"
 #include "mfx_kernels.h"
+#include "mfx_pipe.h"
 
 #include <math.h>
 #include <stdarg.h>
@@ -814,27 +815,13 @@ extern "C" void mfx_hist_result_free(mfx_hist_result *r) {
   memset(r, 0, sizeof(*r));
 }
 
-// compressedFileWriter: the compressor is chosen from the file name suffix
-static FILE *open_writer(const char *path, bool append, bool *is_pipe) {
-  std::string p(path);
-  auto ends = [&](const char *suf) { size_t n = strlen(suf); return p.size() >= n && p.compare(p.size() - n, n, suf) == 0; };
-  const char *tool = ends(".gz") ? "gzip -c" : ends(".bz2") ? "bzip2 -c" : ends(".xz") ? "xz -c" : nullptr;
-  *is_pipe = tool != nullptr;
-  if (!tool) return fopen(path, append ? "a" : "w");
-  std::string cmd = std::string(tool) + (append ? " >> '" : " > '") + p + "'";
-  return popen(cmd.c_str(), "w");
-}
-static void close_writer(FILE *f, bool is_pipe) {
-  if (!f) return;
-  if (is_pipe) pclose(f); else fclose(f);
-}
 
 // reportHistogram, merfin-histogram.C:140-176
 extern "C" int mfx_hist_report(const mfx_hist_result *r, int k, const char *hist_path, const char *summary_path) {
   if (!r || !r->undr || !r->over) return mfx_fail(MFX_E_INVAL, "mfx_hist_report: empty result");
   if (hist_path) {
-    bool pipe;
-    FILE *f = open_writer(hist_path, false, &pipe);
+    mfx_file fh = mfx_open_writer(hist_path, false);     // compressedFileWriter: compressor chosen by suffix (mfx_pipe.h)
+    FILE *f = fh.f;
     if (!f) return mfx_fail(MFX_E_IO, "cannot open '%s' for writing", hist_path);
     for (uint64_t ii = r->undrMax - 1; ii > 0; ii--)
       if (r->undr[ii] > 0)
@@ -843,7 +830,7 @@ extern "C" int mfx_hist_report(const mfx_hist_result *r, int k, const char *hist
     for (uint64_t ii = 1; ii < r->overMax; ii++)
       if (r->over[ii] > 0)
         fprintf(f, "%.1f\t%lu\n", ((double)ii * 0.2), (unsigned long)r->over[ii]);
-    close_writer(f, pipe);
+    if (mfx_close(fh)) return mfx_fail(MFX_E_IO, "writing '%s' failed (stream error or the compressor exited with an error)", hist_path);
   }
   if (summary_path) {
     FILE *f = strcmp(summary_path, "-") == 0 ? stderr : fopen(summary_path, "w");
@@ -1126,8 +1113,8 @@ extern "C" int mfx_dump_contig(mfx_eval *ev, const mfx_seq *seq, uint32_t contig
                                const char *path, int append, uint64_t *kasm, uint64_t *kmissing) {
   if (!ev || !seq || !name || !path) return mfx_fail(MFX_E_INVAL, "mfx_dump_contig: null argument");
   if (contig >= seq->ncontigs) return mfx_fail(MFX_E_INVAL, "mfx_dump_contig: contig %u out of range", contig);
-  bool pipe;
-  FILE *f = open_writer(path, append != 0, &pipe);
+  mfx_file fh = mfx_open_writer(path, append != 0);
+  FILE *f = fh.f;
   if (!f) return mfx_fail(MFX_E_IO, "cannot open '%s' for writing", path);
   const uint64_t len = seq->len[contig];
   const uint64_t CH = 1ull << 24;
@@ -1157,7 +1144,7 @@ extern "C" int mfx_dump_contig(mfx_eval *ev, const mfx_seq *seq, uint32_t contig
         break;
       }
   }
-  close_writer(f, pipe);
+  if (mfx_close(fh) && rc == MFX_OK) rc = mfx_fail(MFX_E_IO, "writing '%s' failed (stream error or the compressor exited with an error)", path);
   if (kasm) *kasm = ka;
   if (kmissing) *kmissing = km;
   return rc;

@@ -15,6 +15,7 @@
 //                 refuses anything whose magic numbers / sizes do not match
 //                 rather than guessing.
 #include "mfx_internal.h"
+#include "mfx_pipe.h"
 
 #include <dirent.h>
 #include <stdio.h>
@@ -34,22 +35,6 @@
 
 namespace {
 
-bool ends_with(const std::string &p, const char *suf) {
-  size_t n = strlen(suf);
-  return p.size() >= n && p.compare(p.size() - n, n, suf) == 0;
-}
-
-FILE *open_reader(const std::string &path, bool *is_pipe) {
-  const char *tool = ends_with(path, ".gz") ? "gzip -dc" : ends_with(path, ".bz2") ? "bzip2 -dc" : ends_with(path, ".xz") ? "xz -dc" : nullptr;
-  *is_pipe = tool != nullptr;
-  if (!tool) return fopen(path.c_str(), "rb");
-  std::string cmd = std::string(tool) + " '" + path + "'";
-  return popen(cmd.c_str(), "r");
-}
-void close_reader(FILE *f, bool is_pipe) {
-  if (!f) return;
-  if (is_pipe) pclose(f); else fclose(f);
-}
 
 bool is_dir(const std::string &p) {
   struct stat st;
@@ -157,7 +142,26 @@ bool read_stuffed(FILE *f, StuffedFile &out, std::string *err) {
 struct MerylIndex {
   uint32_t prefixSize = 0, suffixSize = 0, numFilesBits = 0, numBlocksBits = 0, flags = 0;
   int version = 0;
+  // statistics block that follows the sizes (merylHistogram, first three 64-bit fields)
+  bool     has_stats = false;
+  uint64_t numUnique = 0, numDistinct = 0, numTotal = 0;
 };
+
+// What one decoded .merylData file amounts to; summed over the 64 files it must reproduce the master
+// index's statistics (conformance checks of SURVEY App. C, applied on every load).
+struct MerylFileSums {
+  uint64_t kmers = 0;      // sum of the block headers' nKmers
+  uint64_t unique = 0;     // k-mers with value 1
+  uint64_t total = 0;      // sum of the values
+  uint64_t blocks = 0;
+};
+
+// MFX_MERYL_LENIENT=1 turns the statistics cross-check into a warning (the statistics layout is the least
+// certain part of the recalled format); the structural checks always fail hard.
+bool meryl_lenient() {
+  const char *e = getenv("MFX_MERYL_LENIENT");
+  return e && atoi(e) != 0;
+}
 
 int read_meryl_master(const std::string &dir, MerylIndex &mi) {
   std::string p = dir + "/merylIndex";
@@ -190,7 +194,47 @@ int read_meryl_master(const std::string &dir, MerylIndex &mi) {
       mi.numFilesBits + mi.numBlocksBits != mi.prefixSize)
     return mfx_fail(MFX_E_FORMAT, "'%s': inconsistent sizes (prefix %u suffix %u files %u blocks %u)", p.c_str(),
                     mi.prefixSize, mi.suffixSize, mi.numFilesBits, mi.numBlocksBits);
+  if (br.pos + 192 <= br.nbits) {
+    mi.numUnique = br.get(64);
+    mi.numDistinct = br.get(64);
+    mi.numTotal = br.get(64);
+    mi.has_stats = br.ok;
+    if (mi.has_stats && (mi.numUnique > mi.numDistinct || mi.numDistinct > mi.numTotal)) {
+      if (!meryl_lenient())
+        return mfx_fail(MFX_E_FORMAT, "'%s': statistics are not ordered (unique %lu <= distinct %lu <= total %lu expected); "
+                        "MFX_MERYL_LENIENT=1 skips the statistics checks", p.c_str(), (unsigned long)mi.numUnique,
+                        (unsigned long)mi.numDistinct, (unsigned long)mi.numTotal);
+      mi.has_stats = false;
+    }
+  }
   return MFX_OK;
+}
+
+// Σ over the 64 files against the master statistics: a decoder (or a database) that disagrees with itself must
+// not load quietly.  with_values: the values were decoded too (a full load), not only the block headers.
+int check_meryl_sums(const std::string &dir, const MerylIndex &mi, const std::vector<MerylFileSums> &per, bool with_values) {
+  if (!mi.has_stats) return MFX_OK;
+  MerylFileSums s;
+  for (const auto &x : per) { s.kmers += x.kmers; s.unique += x.unique; s.total += x.total; }
+  std::string why;
+  char b[256];
+  if (s.kmers != mi.numDistinct) {
+    snprintf(b, sizeof(b), "the data blocks hold %lu k-mers, the index statistics say %lu distinct", (unsigned long)s.kmers, (unsigned long)mi.numDistinct);
+    why = b;
+  } else if (with_values && s.total != mi.numTotal) {
+    snprintf(b, sizeof(b), "the values sum to %lu, the index statistics say %lu total", (unsigned long)s.total, (unsigned long)mi.numTotal);
+    why = b;
+  } else if (with_values && s.unique != mi.numUnique) {
+    snprintf(b, sizeof(b), "%lu k-mers have value 1, the index statistics say %lu unique", (unsigned long)s.unique, (unsigned long)mi.numUnique);
+    why = b;
+  }
+  if (why.empty()) return MFX_OK;
+  if (meryl_lenient()) {
+    fprintf(stderr, "WARNING: meryl database '%s': %s (MFX_MERYL_LENIENT=1: continuing).\n", dir.c_str(), why.c_str());
+    return MFX_OK;
+  }
+  return mfx_fail(MFX_E_FORMAT, "meryl database '%s' is inconsistent: %s (a truncated copy, or a layout this decoder does not "
+                  "know; MFX_MERYL_LENIENT=1 downgrades this to a warning)", dir.c_str(), why.c_str());
 }
 
 std::string meryl_file_name(const std::string &dir, uint32_t file, const char *ext) {
@@ -203,12 +247,16 @@ std::string meryl_file_name(const std::string &dir, uint32_t file, const char *e
 // decode every block of one .merylData file; emit(kmer, value)
 // count_only: stop after each block's header (the k-mer count lives there)
 template <class F>
-int read_meryl_data(const std::string &path, uint32_t file, const MerylIndex &mi, F &&emit, uint64_t *count, bool count_only = false) {
+int read_meryl_data(const std::string &path, uint32_t file, const MerylIndex &mi, F &&emit, MerylFileSums *sums, bool count_only = false) {
   FILE *f = fopen(path.c_str(), "rb");
-  if (!f) return MFX_OK;                                    // a piece with no k-mers may be absent
+  // meryl writes all 64 data files, empty pieces included: a missing one means a truncated / partially copied
+  // database, which must not load as "no k-mers here"
+  if (!f) return mfx_fail(MFX_E_IO, "cannot open '%s': a meryl database has all 64 data files (partial copy?)", path.c_str());
   StuffedFile sf;
   std::string err;
   int rc = MFX_OK;
+  bool have_prev = false;
+  uint64_t prev_prefix = 0;
   while (rc == MFX_OK && read_stuffed(f, sf, &err)) {
     // a data block may be split over several stuffedBits chunks; treat them as one bit stream
     std::vector<uint64_t> stream;
@@ -238,7 +286,19 @@ int read_meryl_data(const std::string &path, uint32_t file, const MerylIndex &mi
                     path.c_str(), kcode, ccode, ubits, bbits, mi.suffixSize, (unsigned long)prefix);
       break;
     }
-    if (count_only) { *count += nk; continue; }
+    // blocks appear in increasing prefix order, so the k-mers of a file are strictly increasing across blocks too
+    if (have_prev && prefix <= prev_prefix) {
+      rc = mfx_fail(MFX_E_FORMAT, "'%s': block prefixes not strictly increasing (%lx after %lx)", path.c_str(), (unsigned long)prefix, (unsigned long)prev_prefix);
+      break;
+    }
+    have_prev = true;
+    prev_prefix = prefix;
+    if (mi.numBlocksBits < 64 && (prefix >> mi.prefixSize) != 0) {
+      rc = mfx_fail(MFX_E_FORMAT, "'%s': block prefix %lx wider than %u bits", path.c_str(), (unsigned long)prefix, mi.prefixSize);
+      break;
+    }
+    sums->blocks++;
+    if (count_only) { sums->kmers += nk; continue; }
     std::vector<uint64_t> sfx(nk);
     uint64_t hi = 0;
     for (uint64_t i = 0; i < nk; ++i) {
@@ -247,13 +307,20 @@ int read_meryl_data(const std::string &path, uint32_t file, const MerylIndex &mi
       if (i && sfx[i] <= sfx[i - 1]) { rc = mfx_fail(MFX_E_FORMAT, "'%s': suffixes not strictly increasing", path.c_str()); break; }
     }
     if (rc) break;
+    const uint64_t smask = mi.suffixSize >= 64 ? ~0ull : ((1ull << mi.suffixSize) - 1);
+    if (nk && (sfx[nk - 1] & ~smask)) { rc = mfx_fail(MFX_E_FORMAT, "'%s': suffix wider than %u bits", path.c_str(), mi.suffixSize); break; }
+    uint64_t uniq = 0, tot = 0;
     for (uint64_t i = 0; i < nk; ++i) {
       uint64_t v = br.get(ccode == 1 ? 32 : 64);
       uint64_t km = (mi.suffixSize >= 64 ? 0 : (prefix << mi.suffixSize)) | sfx[i];
+      uniq += (v == 1);
+      tot += v;
       emit(km, v > 0xffffffffull ? 0xffffffffu : (uint32_t)v);
     }
     if (!br.ok) { rc = mfx_fail(MFX_E_FORMAT, "'%s': data block shorter than its header claims", path.c_str()); break; }
-    *count += nk;
+    sums->kmers += nk;
+    sums->unique += uniq;
+    sums->total += tot;
   }
   fclose(f);
   if (rc == MFX_OK && !err.empty()) rc = mfx_fail(MFX_E_FORMAT, "'%s': %s", path.c_str(), err.c_str());
@@ -326,8 +393,8 @@ struct Feeder {
 
 template <class F>
 int scan_text(const std::string &path, int *k_out, F &&emit, uint64_t *count) {
-  bool pipe;
-  FILE *f = open_reader(path, &pipe);
+  mfx_file h = mfx_open_reader(path.c_str());          // compressedFileReader: decompressor chosen by suffix, no shell
+  FILE *f = h.f;
   if (!f) return mfx_fail(MFX_E_IO, "cannot open '%s'", path.c_str());
   char line[512];
   int k = 0, rc = MFX_OK;
@@ -346,7 +413,8 @@ int scan_text(const std::string &path, int *k_out, F &&emit, uint64_t *count) {
     emit(km, v > 0xffffffffull ? 0xffffffffu : (uint32_t)v);
     ++*count;
   }
-  close_reader(f, pipe);
+  if (mfx_close(h, rc != MFX_OK) && rc == MFX_OK)
+    rc = mfx_fail(MFX_E_IO, "reading '%s' failed (stream error or the decompressor exited with an error)", path.c_str());
   if (k_out) *k_out = k;
   return rc;
 }
@@ -386,13 +454,14 @@ extern "C" int mfx_db_probe(const char *path, mfx_db_info *out) {
   if (rc) return rc;
   out->k = (int)((mi.prefixSize + mi.suffixSize) / 2);
   // distinct k-mer count: sum of the block headers (cheap pass over the 64 data files)
-  std::vector<uint64_t> per(64, 0);
+  std::vector<MerylFileSums> per(64);
   rc = for_each_meryl_file([&](uint32_t fl) {
     return read_meryl_data(meryl_file_name(p, fl, ".merylData"), fl, mi, [](uint64_t, uint32_t) {}, &per[fl], true);
   });
   uint64_t n = 0;
-  for (uint64_t x : per) n += x;
+  for (const auto &x : per) n += x.kmers;
   out->n_kmers = n;
+  if (rc == MFX_OK) rc = check_meryl_sums(p, mi, per, false);
   return rc;
 }
 
@@ -445,13 +514,14 @@ extern "C" int mfx_index_load_db(mfx_index *ix, const char *path, int side, uint
       rc = mfx_fail(MFX_E_INVAL, "'%s' holds %u-mers but the index is built for k=%d", path, (mi.prefixSize + mi.suffixSize) / 2, ix->k);
     if (rc == MFX_OK) {
       std::mutex mu;
+      std::vector<MerylFileSums> per(64);
       rc = for_each_meryl_file([&](uint32_t fl) {
         Feeder tf{ix, side, minV, maxV, &mu};
-        uint64_t cnt = 0;
-        int r = read_meryl_data(meryl_file_name(p, fl, ".merylData"), fl, mi, [&](uint64_t km, uint32_t v) { tf.push(km, v); }, &cnt);
+        int r = read_meryl_data(meryl_file_name(p, fl, ".merylData"), fl, mi, [&](uint64_t km, uint32_t v) { tf.push(km, v); }, &per[fl]);
         if (r == MFX_OK) tf.flush();
         return r ? r : tf.rc;
       });
+      if (rc == MFX_OK) rc = check_meryl_sums(p, mi, per, true);
     }
   }
   if (rc == MFX_OK) fd.flush();
@@ -481,7 +551,7 @@ extern "C" int mfx_db_write_flat(const char *path, int k, const uint64_t *kmers,
 // then the table lines (128 bytes each) in order.
 // ---------------------------------------------------------------------------
 struct IndexImageHeader {
-  char     magic[8];         // "MFXINDX1"
+  char     magic[8];         // "MFXINDX2"
   uint32_t k, mz_w;
   uint32_t shard_rank, shard_n;
   uint64_t nlines, capacity_kmers;
@@ -489,6 +559,7 @@ struct IndexImageHeader {
   uint64_t meta[4];          // distinct, non-canonical inserts, probe failures, reserved
   uint32_t slot_bytes, line_slots;
   uint32_t filter_set, layout;   // layout = MFX_LAYOUT_VERSION of the build that wrote the image
+  uint64_t fingerprint;          // caller's digest of the inputs the table was built from (mfx_index_set_fingerprint)
 };
 
 static_assert(sizeof(IndexImageHeader) <= MFX_INDEX_HEADER_BYTES, "index image header outgrew its public size");
@@ -496,7 +567,7 @@ static_assert(sizeof(IndexImageHeader) <= MFX_INDEX_HEADER_BYTES, "index image h
 static int fill_header(const mfx_index *ix, IndexImageHeader &h) {
   if (hipSetDevice(ix->device) != hipSuccess) return mfx_fail(MFX_E_HIP, "hipSetDevice(%d) failed", ix->device);
   memset(&h, 0, sizeof(h));
-  memcpy(h.magic, "MFXINDX1", 8);
+  memcpy(h.magic, "MFXINDX2", 8);
   h.k = (uint32_t)ix->k; h.mz_w = (uint32_t)ix->mz_w;
   h.shard_rank = ix->shard_rank; h.shard_n = ix->shard_n;
   h.nlines = ix->nlines; h.capacity_kmers = ix->capacity_kmers;
@@ -504,12 +575,13 @@ static int fill_header(const mfx_index *ix, IndexImageHeader &h) {
   h.slot_bytes = (uint32_t)sizeof(mfx_slot); h.line_slots = MFX_SLOTS_LINE;
   h.filter_set = ix->filter_set ? 1u : 0u;
   h.layout = MFX_LAYOUT_VERSION;
+  h.fingerprint = ix->fingerprint;
   if (hipMemcpy(h.meta, ix->d_meta, sizeof(h.meta), hipMemcpyDeviceToHost) != hipSuccess) return mfx_fail(MFX_E_HIP, "reading index metadata failed");
   return MFX_OK;
 }
 
 static bool header_ok(const IndexImageHeader &h) {
-  return memcmp(h.magic, "MFXINDX1", 8) == 0 && h.slot_bytes == sizeof(mfx_slot) && h.line_slots == MFX_SLOTS_LINE && h.k >= 1 &&
+  return memcmp(h.magic, "MFXINDX2", 8) == 0 && h.slot_bytes == sizeof(mfx_slot) && h.line_slots == MFX_SLOTS_LINE && h.k >= 1 &&
          h.k <= 31 && h.nlines != 0 && h.nlines < (1ull << 32) && h.layout == MFX_LAYOUT_VERSION;
 }
 
@@ -530,6 +602,7 @@ static mfx_index *index_from_header(const IndexImageHeader &h, double max_gb, in
   ix->mz_w = (int)h.mz_w;
   ix->shard_rank = h.shard_rank; ix->shard_n = h.shard_n ? h.shard_n : 1;
   ix->minV = h.minV; ix->maxV = h.maxV; ix->filter_set = h.filter_set != 0;
+  ix->fingerprint = h.fingerprint;
   if (hipMalloc((void **)&ix->d_slots, h.nlines * MFX_ALIGN) != hipSuccess ||
       hipMemcpy(ix->d_meta, h.meta, sizeof(h.meta), hipMemcpyHostToDevice) != hipSuccess) {
     mfx_fail(MFX_E_NOMEM, "cannot allocate %.3f GB for the index image on device %d", (double)h.nlines * MFX_ALIGN / 1e9, device);
@@ -569,6 +642,20 @@ extern "C" int mfx_index_device_image(mfx_index *ix, void **d_lines, uint64_t *l
 extern "C" int mfx_index_commit(mfx_index *ix) {
   if (!ix) return mfx_fail(MFX_E_INVAL, "mfx_index_commit: null argument");
   ix->version++;                       // cached per-index facts (canonical or not) are re-read from the new contents
+  return MFX_OK;
+}
+
+extern "C" int mfx_index_set_fingerprint(mfx_index *ix, uint64_t fingerprint) {
+  if (!ix) return mfx_fail(MFX_E_INVAL, "mfx_index_set_fingerprint: null index");
+  ix->fingerprint = fingerprint;
+  return MFX_OK;
+}
+
+extern "C" int mfx_index_get_origin(const mfx_index *ix, uint64_t *fingerprint, uint64_t *minV, uint64_t *maxV) {
+  if (!ix) return mfx_fail(MFX_E_INVAL, "mfx_index_get_origin: null index");
+  if (fingerprint) *fingerprint = ix->fingerprint;
+  if (minV) *minV = ix->filter_set ? ix->minV : 0;
+  if (maxV) *maxV = ix->filter_set ? ix->maxV : ~0ull;
   return MFX_OK;
 }
 

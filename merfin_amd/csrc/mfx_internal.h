@@ -76,6 +76,7 @@ struct mfx_index {
   int       mz_w = 0;
   uint32_t  shard_rank = 0, shard_n = 1;
   uint64_t  version = 0;        // bumped by every insert batch; lets evaluators cache index-derived facts
+  uint64_t  fingerprint = 0;    // caller-supplied digest of the inputs (travels with the index image)
   mfx_table_view view() const;
 };
 

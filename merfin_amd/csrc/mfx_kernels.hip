@@ -280,6 +280,13 @@ __device__ __forceinline__ uint32_t mfx_group_bcast(uint32_t v) {
 // order, so the owner's later read needs no barrier.  This replaces three
 // cross-lane permutes + ballot decoding per served query with one predicated
 // store.  ("The line has room" does not go through LDS in the first pass: mfx_group_room.)
+// Hand-off points of the mailbox protocol.  The hardware serves one wave's LDS requests in order; this keeps the
+// COMPILER from moving an LDS access across a hand-off (wavefront-scope fence + scheduling barrier: no instructions).
+__device__ __forceinline__ void mfx_wave_handoff() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 struct mfx_mailbox {
   uint4 rec[MFX_BLOCK];      // x = readV, y = asmV, z = found; w = "candidate line has room" in the second pass only
 };
@@ -358,6 +365,7 @@ __device__ __forceinline__ void mfx_group_lookup(const mfx_table_view &t, mfx_ma
     uint32_t klo[8], khi[8];
     const uint32_t key_lo = (uint32_t)key[j], key_hi = (uint32_t)(key[j] >> 32);
     M.rec[tid] = make_uint4(0u, 0u, 0u, 0u);
+    mfx_wave_handoff();                                            // records cleared before any slot lane posts
     uint32_t ls[8];
     mfx_group_announce<0>(ls, klo, khi, line[j], key_lo, key_hi); mfx_group_announce<1>(ls, klo, khi, line[j], key_lo, key_hi);
     mfx_group_announce<2>(ls, klo, khi, line[j], key_lo, key_hi); mfx_group_announce<3>(ls, klo, khi, line[j], key_lo, key_hi);
@@ -380,7 +388,9 @@ __device__ __forceinline__ void mfx_group_lookup(const mfx_table_view &t, mfx_ma
     mfx_group_landed<5>(v); mfx_group_post<5>(M, v, klo, khi, obase); room |= mfx_group_room<5>(v);
     mfx_group_landed<6>(v); mfx_group_post<6>(M, v, klo, khi, obase); room |= mfx_group_room<6>(v);
     mfx_group_landed<7>(v); mfx_group_post<7>(M, v, klo, khi, obase); room |= mfx_group_room<7>(v);
+    mfx_wave_handoff();                                            // all posts of this round precede the owners' reads
     const uint4 r = M.rec[tid];
+    mfx_wave_handoff();                                            // ... which precede the next round's clear
     if (ok[j]) {
       if (r.z == 1u) {
         rv[j] = (r.x < t.minV || r.x > t.maxV) ? 0u : r.x;    // -min / -max (merfin.C:199-200)
@@ -412,11 +422,13 @@ __device__ __forceinline__ void mfx_group_lookup(const mfx_table_view &t, mfx_ma
     }
     nq += (uint32_t)__popcll(m);
   }
+  mfx_wave_handoff();                                              // compacted queries written before the slot lanes read them
   if (nq > 64u) nq = 64u;
   for (uint32_t q0 = 0; q0 < nq; q0 += 8u) {                 // wave-uniform trip count
     const uint32_t e = q0 + (lane >> 3);
     const bool live = e < nq;
     const uint4 ent = M.rec[wbase + (live ? e : 0u)];
+    mfx_wave_handoff();                                            // every lane of the group has the entry before one answers into it
     uint4 sl = make_uint4(0u, 0u, 0u, 0u);
     if (live) sl = *reinterpret_cast<const uint4 *>(t.slots + (uint64_t)ent.z * MFX_SLOTS_LINE + sub);
     uint32_t *rec = reinterpret_cast<uint32_t *>(&M.rec[wbase + e]);
@@ -425,6 +437,7 @@ __device__ __forceinline__ void mfx_group_lookup(const mfx_table_view &t, mfx_ma
       else if (sl.x == ent.x && sl.y == ent.y) { rec[0] = sl.z; rec[1] = sl.w; rec[2] = 0xffffffffu; }   // found (marker: no line has this index)
     }
   }
+  mfx_wave_handoff();                                              // answers posted before the owners read them
 #pragma unroll
   for (int j = 0; j < B; ++j) {
     if (pending[j] == 0u) continue;

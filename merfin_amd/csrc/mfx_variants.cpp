@@ -16,6 +16,7 @@
 // the selector of the chosen mode.  merfin scores cluster by cluster with four
 // CPU probes per base (varMer.C:76-84).
 #include "mfx_internal.h"
+#include "mfx_pipe.h"
 
 #include <float.h>
 #include <math.h>
@@ -51,18 +52,6 @@ std::vector<std::string> split_any(const std::string &s, const char *seps) {
   return out;
 }
 
-bool ends_with(const std::string &p, const char *suf) {
-  size_t n = strlen(suf);
-  return p.size() >= n && p.compare(p.size() - n, n, suf) == 0;
-}
-
-FILE *open_in(const std::string &path, bool *is_pipe) {
-  const char *tool = ends_with(path, ".gz") ? "gzip -dc" : ends_with(path, ".bz2") ? "bzip2 -dc" : ends_with(path, ".xz") ? "xz -dc" : nullptr;
-  *is_pipe = tool != nullptr;
-  if (!tool) return fopen(path.c_str(), "r");
-  std::string cmd = std::string(tool) + " '" + path + "'";
-  return popen(cmd.c_str(), "r");
-}
 
 // ---- VCF model -------------------------------------------------------------
 struct Record {                       // vcfRecord
@@ -131,8 +120,8 @@ Variant *make_variant(const Record *r) {
 }
 
 int load_vcf(const char *path, VcfDB &db) {             // vcfFile::loadFile, vcf.C:93-149
-  bool pipe;
-  FILE *f = open_in(path, &pipe);
+  mfx_file fh = mfx_open_reader(path);
+  FILE *f = fh.f;
   if (!f) return mfx_fail(MFX_E_IO, "cannot open VCF '%s'", path);
   char *L = nullptr;
   size_t cap = 0;
@@ -165,7 +154,7 @@ int load_vcf(const char *path, VcfDB &db) {             // vcfFile::loadFile, vc
     db.by_chr[r->chr].push_back(c);
   }
   free(L);
-  if (pipe) pclose(f); else fclose(f);
+  if (mfx_close(fh)) return mfx_fail(MFX_E_IO, "reading VCF '%s' failed (stream error or the decompressor exited with an error)", path);
   return MFX_OK;
 }
 
@@ -454,12 +443,11 @@ extern "C" int mfx_variants_run(mfx_eval *ev, const char *vcf_path, const char *
   FILE *out = fopen(out_path, "w");
   if (!out) { if (log != stderr) fclose(log); return mfx_fail(MFX_E_IO, "cannot open '%s' for writing", out_path); }
   for (auto &h : db.headers) fprintf(out, "%s\n", h.c_str());              // merfin-variants.C:332-333
-  bool dbg_pipe = false;
+  mfx_file dbgh;
   FILE *dbg = nullptr;
   if (opts->debug_path) {
-    std::string dp(opts->debug_path);
-    dbg_pipe = ends_with(dp, ".gz");
-    dbg = dbg_pipe ? popen(("gzip -c > '" + dp + "'").c_str(), "w") : fopen(dp.c_str(), "w");
+    dbgh = mfx_open_writer(opts->debug_path, false);                       // compressedFileWriter, merfin-variants.C:149
+    dbg = dbgh.f;
   }
 
   mfx_kparams kp{ev->peak, ev->n_prob, ev->probK.data(), ev->probP.data()};
@@ -629,7 +617,7 @@ extern "C" int mfx_variants_run(mfx_eval *ev, const char *vcf_path, const char *
     fprintf(stderr, "[mfx_variants] load+cluster %.2fs  enumerate %.2fs  pack %.2fs  gpu %.2fs  score+select %.2fs  queue+write %.2fs\n",
             t_phase[0], t_phase[1], t_phase[2], t_phase[3], t_phase[4], t_phase[5]);
   fclose(out);
-  if (dbg) { if (dbg_pipe) pclose(dbg); else fclose(dbg); }
+  if (dbg && mfx_close(dbgh) && rc == MFX_OK) rc = mfx_fail(MFX_E_IO, "writing '%s' failed", opts->debug_path);
   if (log != stderr) fclose(log);
   if (n_clusters) *n_clusters = clusters;
   return rc;

@@ -47,8 +47,10 @@ class BitWriter:
         return out
 
 
-def write_db(path, k, kmers, values, prefix_bits=12, unary_bits=None, version=3):
-    """kmers: sorted unique uint64 array, values: uint32"""
+def write_db(path, k, kmers, values, prefix_bits=12, unary_bits=None, version=3, stats=True, stats_override=None):
+    """kmers: sorted unique uint64 array, values: uint32.  stats: append the statistics block (numUnique,
+    numDistinct, numTotal as 64-bit fields) to the master index; stats_override = (unique, distinct, total) writes
+    other numbers there (corrupt-field tests)."""
     os.makedirs(path, exist_ok=True)
     suffix_bits = 2 * k - prefix_bits
     blocks_bits = prefix_bits - 6
@@ -62,14 +64,19 @@ def write_db(path, k, kmers, values, prefix_bits=12, unary_bits=None, version=3)
         w.put(v, 32)
     if version >= 2:
         w.put(0, 32)
-    open(os.path.join(path, "merylIndex"), "wb").write(w.image())
     kmers = np.asarray(kmers, dtype=np.uint64)
     values = np.asarray(values, dtype=np.uint32)
+    if stats:
+        st = stats_override or (int((values == 1).sum()), len(kmers), int(values.astype(np.uint64).sum()))
+        for v in st:
+            w.put(int(v), 64)
+    open(os.path.join(path, "merylIndex"), "wb").write(w.image())
     prefixes = (kmers >> np.uint64(suffix_bits)).astype(np.uint64)
     for fl in range(64):
         name = "0x" + format(fl, "06b") + ".merylData"
         sel = (prefixes >> np.uint64(blocks_bits)) == fl
         if not sel.any():
+            open(os.path.join(path, name), "wb").close()       # all 64 data files exist, empty pieces included
             continue
         with open(os.path.join(path, name), "wb") as f:
             for pfx in np.unique(prefixes[sel]).tolist():

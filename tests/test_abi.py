@@ -62,3 +62,39 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp", "Makefile", ".txt")):
                 s = open(os.path.join(d, f), errors="ignore").read()
                 assert "oracle" not in s.replace("no CPU fallback", ""), os.path.join(d, f)
+
+
+def test_compressed_files_with_shell_metacharacters_in_the_name(tmp_path):
+    """compressedFileWriter / compressedFileReader (merfin-histogram.C:151, merfin.C:195) start the compressor with an
+    argv array (csrc/mfx_pipe.h): a quote, a space or a `;` in a path is part of the name, never shell syntax.  Host-only
+    entry points, so this runs without a GPU."""
+    import gzip
+    m, _, _ = _lib()
+    from merfin_amd import distributed as D
+    nb = 2048
+    undr = np.zeros(8, dtype=np.uint64)
+    over = np.zeros(8, dtype=np.uint64)
+    undr[[0, 3]] = (5, 2)
+    over[[0, 7]] = (9, 1)
+    h = D.pack_counts(nb, 1, undr, over, 17, 0, [17], [0])
+    res = m.result_from_counts(nb, h, 0.25, 1)
+    d = tmp_path / "it's a; dir"
+    d.mkdir()
+    weird = str(d / "o'u t$(touch pwned).hist.gz")
+    res.report(21, weird, None)
+    res.report(21, str(tmp_path / "plain.hist"), None)
+    assert gzip.open(weird, "rb").read() == (tmp_path / "plain.hist").read_bytes() == b"-0.6\t2\n0.0\t14\n1.4\t1\n"
+    assert not os.path.exists("pwned") and not (tmp_path / "pwned").exists()
+    # read side: a `meryl print` text database behind gzip, same kind of name
+    db = str(d / "re'ad \"db\".txt.gz")
+    with gzip.open(db, "wb") as f:
+        f.write(b"ACGTA\t3\nCCCCC\t9\n")
+    assert m.db_probe(db) == {"k": 5, "format": "text", "n_kmers": 2}
+    # a compressor that fails is an I/O error, not a silent success
+    bad = str(tmp_path / "truncated.txt.gz")
+    open(bad, "wb").write(open(db, "rb").read()[:-6])
+    with pytest.raises(m.MfxError):
+        m.db_probe(bad)
+    # an output directory that does not exist
+    with pytest.raises(m.MfxError):
+        res.report(21, str(tmp_path / "no such dir" / "x.hist.gz"), None)

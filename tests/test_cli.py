@@ -203,3 +203,46 @@ def test_cli_min_max_filter_and_peak_only(tmp_path):
     r = run(["-dump"] + common + ["-output", str(tmp_path / "g.dump")])
     assert r.returncode == 0, r.stderr
     assert (tmp_path / "g.dump").read_bytes() == (tmp_path / "o.dump").read_bytes()
+
+
+@pytest.mark.gpu
+def test_cli_index_cache_is_bound_to_its_inputs(tmp_path):
+    """-index caches the built HBM table.  The cache must be reused only for the inputs it was built from: the
+    iterative polish workflow changes -sequence between runs (asm counts are baked into the table), and -min/-max
+    are applied from the table's stored filter.  A stale image is rebuilt, never silently used."""
+    import merfin_amd as m
+    k, peak = 21, 17.3
+    contigs, read, asm = synth.world(k=k, peak=peak, seed=47, sizes=(15000, 4000))
+    p = po.Params(k, peak)
+    R = po.Lookup(k, *read)
+
+    def oracle_text(ctgs, name, lo=0, hi=2**64 - 1):
+        ak, av = po.count_kmers(k, ctgs)
+        g = po.hist_run(p, po.Lookup(k, read[0], read[1], lo, hi), po.Lookup(k, ak, av), ctgs, threads=2)[0]
+        po.report_histogram(p, g, str(tmp_path / name), str(tmp_path / (name + ".sum")))
+        return (tmp_path / name).read_bytes()
+
+    fa, img = str(tmp_path / "asm.fasta"), str(tmp_path / "cache.mfxi")
+    _write_fasta(fa, contigs)
+    m.db_write_flat(str(tmp_path / "read.mfxk"), k, *read)
+    base = ["-hist", "-sequence", fa, "-readmers", str(tmp_path / "read.mfxk"), "-peak", str(peak), "-index", img]
+    want = oracle_text(contigs, "o1.hist")
+    r = run(base + ["-output", str(tmp_path / "g1.hist")])
+    assert r.returncode == 0 and "Writing the index image" in r.stderr, r.stderr
+    assert (tmp_path / "g1.hist").read_bytes() == want
+    r = run(base + ["-output", str(tmp_path / "g2.hist")])           # same inputs: the image is used
+    assert r.returncode == 0 and "Loading the index image" in r.stderr and "rebuilding" not in r.stderr, r.stderr
+    assert (tmp_path / "g2.hist").read_bytes() == want
+    # a "polished" assembly under the same file name
+    polished = [bytes(c) for c in synth.mutate(synth.rng(5), [np.frombuffer(c, dtype=np.uint8) for c in contigs], sub_rate=3e-3)]
+    _write_fasta(fa, polished)
+    want2 = oracle_text(polished, "o3.hist")
+    assert want2 != want
+    r = run(base + ["-output", str(tmp_path / "g3.hist")])
+    assert r.returncode == 0 and "rebuilding" in r.stderr and "sequence file changed" in r.stderr, r.stderr
+    assert (tmp_path / "g3.hist").read_bytes() == want2
+    # other -min/-max than the image's
+    want3 = oracle_text(polished, "o4.hist", 4, 40)
+    r = run(base + ["-min", "4", "-max", "40", "-output", str(tmp_path / "g4.hist")])
+    assert r.returncode == 0 and "rebuilding" in r.stderr and "-min/-max differ" in r.stderr, r.stderr
+    assert (tmp_path / "g4.hist").read_bytes() == want3

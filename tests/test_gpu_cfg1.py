@@ -1,4 +1,4 @@
-"""BASELINE config 1 in small: a synthetic genome, ACTUAL simulated reads (20x, 150 bp, both strands, 0.5 %
+"""BASELINE config 1 at its named size (5 Mb, 20x reads; MFX_TEST_CFG1_MB scales it): a synthetic genome, ACTUAL simulated reads (20x, 150 bp, both strands, 0.5 %
 substitution errors), their canonical 21-mers counted by a sort-based counter in the harness (numpy) -- the
 read database a `meryl count` would produce -- then `-hist` with -peak 17.3 on the CPU oracle and on the GPU.
 Also checks the GPU's own counting route: every k-mer OCCURRENCE inserted with value 1 must sum to the same
@@ -36,7 +36,7 @@ def test_simulated_reads_counted_in_the_harness():
     import merfin_amd as m
     k, peak, cov, L = 21, 17.3, 20, 150
     r = synth.rng(20260928)
-    scale = float(os.environ.get("MFX_TEST_CFG1_MB", "1"))   # 1 Mb by default (seconds); 5 = the size BASELINE names
+    scale = float(os.environ.get("MFX_TEST_CFG1_MB", "5"))   # 5 Mb = the size BASELINE config 1 names (1 = quick run)
     truth = synth.make_truth(r, tuple(int(x * scale) for x in (400000, 250000, 150000, 100000, 60000, 30000, 9000, 1000)))
     asm = synth.mutate(r, truth, sub_rate=2e-4)
     genome = np.concatenate(truth)

@@ -1,0 +1,118 @@
+"""BASELINE config 3 at its FULL size: 3 Gb assembly in 24 human-proportioned contigs, k=21, -peak 26 with the
+-prob lookup table, one MI355X (the 1-GPU leg of "contig-sharded across 1/2/4/8"; the 8-way shards are evaluated one
+after the other on the same GPU and must sum to the whole).  The CPU oracle cannot reach this size, so the checks are
+the size-independent properties of the domain (merfin-histogram.C:54-91):
+  - every valid k-mer is either missing or lands in exactly one bin (binned + kmissing == kasm), globally and per
+    contig (sum of the per-contig counters == the global ones; valid k-mers <= len - k + 1),
+  - the 8-way CONTIGUOUS tile split and the 8-way BLOCK-CYCLIC split (what bench.py --gpus 8 runs) both sum to the
+    single-launch result, integers bit-exact, koverCpy to 1e-12,
+  - the -hist kernel equals the -dump kernel + host-side K* (numpy float64, the reference's IEEE operations) on one
+    whole contig.
+The two-index placement leg of test_gpu_fullsize.py is skipped here: two 181 GB tables do not fit one GPU.
+Needs ~200 GB of free HBM; MFX_TEST_CFG3_BASES scales it down for a smaller device (the test then says so).
+Config 5 (15 Gb, k=31, index sharded over 8 GPUs) cannot run at full size on the 1-GPU box: its code path is
+covered at k=31 by tests/test_gpu_sharded.py."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+BASES = int(float(os.environ.get("MFX_TEST_CFG3_BASES", "3e9")))
+
+
+@pytest.fixture(scope="module")
+def world():
+    torch = pytest.importorskip("torch")
+    import merfin_amd as m
+    from tools import synth_torch as st
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    free, _tot = torch.cuda.mem_get_info()
+    need = (BASES * 2.03 + 1024) / 0.7 * 16 + 3.5 * BASES + 8e9
+    if need > free:
+        pytest.skip("config 3 at %d bases needs %.0f GB of free HBM, %.0f GB available" % (BASES, need / 1e9, free / 1e9))
+    ix, seqs, asm, info = st.build_world(m, BASES, k=21, lam=26.0, ncontigs=24)
+    torch.cuda.empty_cache()
+    yield m, st, torch, ix, seqs, asm, info
+    del ix, seqs, asm
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def _image_result(m, ev, seqs, counts, kover):
+    return ev.result_from_counts(counts.cpu().numpy().view(np.uint64), float(kover.item()), seqs.ncontigs)
+
+
+def test_cfg3_every_kmer_accounted_and_shards_sum_to_whole(world, golden_dir):
+    m, st, torch, ix, seqs, asm, info = world
+    kp = m.KParams.from_file(26.0, os.path.join(golden_dir, "example_lookup_table.txt"))
+    ev = m.Evaluator(ix, kp)
+    whole = ev.hist(seqs)
+    lens = np.array(info["sizes"])
+    assert whole.kasm > 0.97 * BASES
+    assert int(whole.undr().sum() + whole.over().sum()) + whole.kmissing == whole.kasm
+    assert int(whole.contig_kasm().sum()) == whole.kasm and int(whole.contig_kmissing().sum()) == whole.kmissing
+    assert (whole.contig_kasm() <= lens - 20).all() and (whole.contig_kasm() > 0.95 * lens).all()
+    assert 0 < whole.kmissing < 0.02 * whole.kasm and whole.koverCpy > 0
+    if BASES == 3_000_000_000:
+        # the workload is a pure function of the seed: the same numbers on every box and in bench.py's JSON line
+        assert whole.kasm == 2998736313
+
+    T = seqs.ntiles
+    words = m.hist_words(ev.nbins, seqs.ncontigs)
+    s = torch.cuda.current_stream().cuda_stream
+    for kind in ("contiguous", "cyclic"):
+        counts = torch.zeros(words, dtype=torch.int64, device="cuda")
+        kover = torch.zeros(1, dtype=torch.float64, device="cuda")
+        for r in range(8):
+            if kind == "contiguous":
+                ev.hist_launch(seqs, T * r // 8, T * (r + 1) // 8, counts, kover, stream=s)
+            else:
+                ev.hist_launch_cyclic(seqs, r, 8, counts, kover, block_tiles=256, stream=s)
+        torch.cuda.synchronize()
+        part = _image_result(m, ev, seqs, counts, kover)
+        assert (part.kasm, part.kmissing) == (whole.kasm, whole.kmissing), kind
+        np.testing.assert_array_equal(part.undr(), whole.undr())
+        np.testing.assert_array_equal(part.over(), whole.over())
+        np.testing.assert_array_equal(part.contig_kasm(), whole.contig_kasm())
+        np.testing.assert_array_equal(part.contig_kmissing(), whole.contig_kmissing())
+        assert part.koverCpy == pytest.approx(whole.koverCpy, rel=1e-12)
+
+
+def test_cfg3_hist_kernel_equals_dump_kernel_plus_host_kstar(world, golden_dir):
+    m, st, torch, ix, seqs, asm, info = world
+    kp = m.KParams.from_file(26.0, os.path.join(golden_dir, "example_lookup_table.txt"))
+    ev = m.Evaluator(ix, kp)
+    c = 20                                              # the smallest contig (47/3036 of the genome, 46 Mb at 3 Gb)
+    n = int(asm[c].numel())
+    rv, av, ka, km = ev.dump_values(seqs, c, 0, n)
+    valid = (rv > 0) | (av > 0)
+    urv = np.unique(rv[valid])
+    lut_rk = np.zeros(int(urv.max()) + 1, dtype=np.float64)
+    lut_pr = np.zeros(int(urv.max()) + 1, dtype=np.float64)
+    for v in urv.tolist():
+        rk, _ak, pr = m.getK(kp, int(v), 1)
+        lut_rk[v], lut_pr[v] = rk, pr
+    readK, prob = lut_rk[rv[valid]], lut_pr[rv[valid]]
+    asmK = av[valid].astype(np.float64)
+    missing = readK == 0
+    assert int(valid.sum()) == ka and int(missing.sum()) == km
+    rK, aK, pr = readK[~missing], asmK[~missing], prob[~missing]
+    under = aK > rK
+    iu = ((((aK[under] / rK[under]) - 1) + 0.1) / 0.2).astype(np.int64)
+    io = ((((rK[~under] / aK[~under]) - 1) + 0.1) / 0.2).astype(np.int64)
+    undr, over = np.bincount(iu, minlength=1), np.bincount(io, minlength=1)
+    whole = ev.hist(seqs)
+    assert (int(whole.contig_kasm()[c]), int(whole.contig_kmissing()[c])) == (ka, km)
+    one = m.Sequences.from_device([asm[c].data_ptr()], [n])
+    res = ev.hist(one)
+    assert (res.kasm, res.kmissing) == (ka, km)
+    ru, ro = res.undr(), res.over()
+    np.testing.assert_array_equal(ru[:len(undr)], undr)
+    np.testing.assert_array_equal(ro[:len(over)], over)
+    assert ru[len(undr):].sum() == 0 and ro[len(over):].sum() == 0
+    kover = float(((1.0 - rK[under] / aK[under]) * pr[under]).sum())
+    assert res.koverCpy == pytest.approx(kover, rel=1e-9)

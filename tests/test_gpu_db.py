@@ -145,3 +145,84 @@ def test_in_memory_image_moves_a_built_table(monkeypatch):
     with pytest.raises(m.MfxError) as e:
         m.Index.from_header(bad)
     assert e.value.code == -7
+
+
+def _small_meryl(tmp_path, name="r.meryl", **kw):
+    k = 21
+    contigs, read, asm = synth.world(k=k, seed=53, sizes=(9000,), err_kmers=100)
+    mdir = str(tmp_path / name)
+    meryl_layout.write_db(mdir, k, read[0], read[1], prefix_bits=12, **kw)
+    return k, read, mdir
+
+
+def test_meryl_self_validation_on_probe(tmp_path, monkeypatch):
+    """Conformance checks of SURVEY App. C that need no GPU (mfx_db_probe reads the block headers only): the 64 data
+    files must all exist, block prefixes must increase and carry their file number, and the block headers must add up
+    to the master index's statistics.  Each corrupt field fails loudly with its own message."""
+    import glob
+    import os
+    import shutil
+    import merfin_amd as m
+    k, read, mdir = _small_meryl(tmp_path)
+    assert m.db_probe(mdir) == {"k": k, "format": "meryl", "n_kmers": len(read[0])}
+    # a database without the statistics block still opens (older index versions)
+    _, _, nostat = _small_meryl(tmp_path, "nostat.meryl", stats=False)
+    assert m.db_probe(nostat)["n_kmers"] == len(read[0])
+
+    def damaged(name, fn):
+        d = str(tmp_path / name)
+        shutil.copytree(mdir, d)
+        fn(d)
+        with pytest.raises(m.MfxError) as e:
+            m.db_probe(d)
+        return e.value
+
+    files = sorted(f for f in glob.glob(mdir + "/*.merylData") if os.path.getsize(f) > 200)
+    victim = os.path.basename(files[3])
+    # (1) a missing piece (partial copy): I/O error, not "no k-mers in that piece"
+    e = damaged("missing.meryl", lambda d: os.remove(os.path.join(d, victim)))
+    assert e.code == -6 and victim in str(e) and "64 data files" in str(e)
+    # (2) an emptied piece: the headers no longer add up to the statistics
+    e = damaged("emptied.meryl", lambda d: open(os.path.join(d, victim), "wb").close())
+    assert e.code == -7 and "statistics say" in str(e)
+    # (3) statistics that disagree with the data
+    _, _, wrong = _small_meryl(tmp_path, "wrongstat.meryl", stats_override=(0, len(read[0]) + 1, 10 ** 9))
+    with pytest.raises(m.MfxError) as e2:
+        m.db_probe(wrong)
+    assert e2.value.code == -7 and "distinct" in str(e2.value)
+    monkeypatch.setenv("MFX_MERYL_LENIENT", "1")
+    assert m.db_probe(wrong)["n_kmers"] == len(read[0])        # downgraded to a warning on request
+    monkeypatch.delenv("MFX_MERYL_LENIENT")
+    # (4) a piece under another file's name: the block prefix's top 6 bits must equal the file number
+    other = os.path.basename(files[4])
+
+    def swap(d):
+        shutil.copyfile(os.path.join(d, other), os.path.join(d, victim))
+    e = damaged("swapped.meryl", swap)
+    assert e.code == -7 and "inconsistent data block" in str(e)
+    # (5) blocks out of order inside a file: append the file's first block again
+    def dup(d):
+        raw = open(os.path.join(d, victim), "rb").read()
+        import struct
+        nbits = struct.unpack_from("<Q", raw, 24)[0]
+        first = raw[:32 + 8 * ((nbits + 63) // 64)]
+        open(os.path.join(d, victim), "ab").write(first)
+    e = damaged("unordered.meryl", dup)
+    assert e.code == -7 and "not strictly increasing" in str(e)
+
+
+@pytest.mark.gpu
+def test_meryl_value_statistics_checked_on_load(tmp_path):
+    """a full load also decodes the values: their sum and the number of 1s must match the statistics"""
+    import merfin_amd as m
+    k, read, mdir = _small_meryl(tmp_path)
+    ix = m.Index(k, len(read[0]) + 16)
+    ix.load_db(mdir, 0)
+    assert ix.info()["distinct"] == len(read[0])
+    uniq, tot = int((read[1] == 1).sum()), int(read[1].astype(np.uint64).sum())
+    for name, st, word in (("t.meryl", (uniq, len(read[0]), tot + 5), "total"), ("u.meryl", (uniq - 1, len(read[0]), tot), "unique")):
+        _, _, d = _small_meryl(tmp_path, name, stats_override=st)
+        ix2 = m.Index(k, len(read[0]) + 16)
+        with pytest.raises(m.MfxError) as e:
+            ix2.load_db(d, 0)
+        assert e.value.code == -7 and word in str(e.value)

@@ -31,13 +31,15 @@ def _build_shards(m, k, read, asm, world, contigs=None, count_from_seq=False):
     return shards
 
 
-@pytest.mark.parametrize("world,mode", [(2, "mz"), (3, "mz"), (4, "plain")])
-def test_sharded_hist_virtual_exchange(world, mode, monkeypatch):
+# k = 31 is BASELINE config 5's k-mer size (hexaploid wheat, index sharded over 8 GPUs): the full 15 Gb / 2e10-k-mer
+# size needs the 8-GPU node; here the same code path runs at k = 31 with 2...8 ranks at oracle-checkable size.
+@pytest.mark.parametrize("world,mode,k", [(2, "mz", 21), (3, "mz", 21), (4, "plain", 21), (2, "mz", 31), (8, "mz", 31), (3, "plain", 31)])
+def test_sharded_hist_virtual_exchange(world, mode, k, monkeypatch):
     torch = pytest.importorskip("torch")
     import merfin_amd as m
     from merfin_amd import distributed as D
     monkeypatch.setenv("MFX_HOME_MODE", mode)
-    k, peak = 21, 17.3
+    peak = 17.3
     contigs, read, asm = synth.world(k=k, peak=peak, seed=81)
     p, g, ka, km = oracle_hist(k, peak, contigs, read, asm)
     shards = _build_shards(m, k, read, asm, world, contigs, count_from_seq=True)
@@ -70,11 +72,12 @@ def test_sharded_hist_virtual_exchange(world, mode, monkeypatch):
     assert_hist_equal(res, g, ka, km, k)
 
 
-@pytest.mark.parametrize("world", [2, 5])
-def test_sharded_completeness_sums_to_whole(world):
-    """every shard evaluates the k-mers it owns; the per-piece sums add up to the unsharded ones, bit for bit"""
+@pytest.mark.parametrize("world,k", [(2, 21), (5, 21), (8, 31)])
+def test_sharded_completeness_sums_to_whole(world, k):
+    """every shard evaluates the k-mers it owns; the per-piece sums add up to the unsharded ones, bit for bit,
+    and the total equals the oracle's computeCompleteness (merfin-completeness.C:70-123)"""
     import merfin_amd as m
-    k, peak = 21, 17.3
+    peak = 17.3
     contigs, read, asm = synth.world(k=k, peak=peak, seed=85)
     whole = m.Index(k, len(read[0]) + len(asm[0]) + 16)
     whole.add_read(*read)
@@ -86,6 +89,11 @@ def test_sharded_completeness_sums_to_whole(world):
         st += t
         su += u
     assert (st == wt).all() and (su == wu).all() and wt.sum() > 0 and wu.sum() > 0
+    p = po.Params(k, peak)
+    for piece in range(64):                                   # oracle: the reference's per-piece merge loop
+        lo, hi = piece << (2 * k - 6), (piece + 1) << (2 * k - 6)
+        rs, as_ = (read[0] >= lo) & (read[0] < hi), (asm[0] >= lo) & (asm[0] < hi)
+        assert (st[piece], su[piece]) == po.completeness_piece(p, read[0][rs], read[1][rs], asm[0][as_], asm[1][as_])
 
 
 @pytest.mark.parametrize("world", [2, 8, 13])
