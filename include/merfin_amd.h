@@ -211,6 +211,50 @@ typedef struct {
 int  mfx_hist_run(mfx_eval *ev, const mfx_seq *seq, mfx_hist_result *out);
 void mfx_hist_result_free(mfx_hist_result *r);
 
+/* The same with the upload inside: SURVEY 8(d)'s evaluate phase, "first tile H2D start -> final reduced histogram
+ * on host".  `seq` = mfx_seq_create(device, lens, n) (layout + device buffers, no bases yet); bases[i] = host
+ * buffer of contig i.  The tiles are uploaded in 64 MB chunks on a copy stream while the -hist kernel of the
+ * previous chunk runs; buffers obtained from mfx_host_alloc (pinned: what a loader should read the FASTA into)
+ * are DMA'd in place, pageable ones are staged through pinned memory by host threads.  The result is
+ * bit-identical to mfx_seq_upload + mfx_hist_run (koverCpy included: the per-tile values are summed once, at the
+ * end).  Afterwards `seq` holds the whole assembly and can be used like an uploaded one. */
+void    *mfx_host_alloc(size_t bytes);
+void     mfx_host_free(void *p);
+mfx_seq *mfx_seq_create(int device, const uint64_t *lens, uint32_t ncontigs);
+int      mfx_hist_run_streamed(mfx_eval *ev, mfx_seq *seq, const char *const *bases, mfx_hist_result *out);
+
+/* Several GPUs of one node driven by ONE process -- the reference is one binary driving all its workers
+ * (merfin.C:366-414).  The index is replicated (mfx_index_replicate: peer copy over xGMI, instead of N builds),
+ * so is the packed assembly; slot d evaluates the block-cyclic share d of ndev of the tiles (blocks of 256 tiles)
+ * on its own device and stream, all at once; the ndev counts images (~1 MB) are added on the host in slot order,
+ * the overflow lists of all evaluators folded in.  Integers are exact, koverCpy is a fixed-order sum: results are
+ * bit-stable and equal to the single-device ones in every integer.  Two slots may name the same device (each
+ * needs its own evaluator; they may share one index and one mfx_seq). */
+mfx_index *mfx_index_replicate(const mfx_index *src, int device);
+mfx_seq   *mfx_seq_replicate(const mfx_seq *src, int device);
+int        mfx_hist_run_multi(mfx_eval *const *evs, const mfx_seq *const *seqs, uint32_t ndev, mfx_hist_result *out);
+
+/* One process per GPU (torchrun / mpirun style launchers): the collective of the path, on RCCL over xGMI.
+ * Rank 0 makes an id (mfx_comm_unique_id), the launcher hands its MFX_COMM_ID_BYTES to every rank by any
+ * out-of-band channel, every rank calls mfx_comm_create (collective).  mfx_hist_allreduce turns the ranks'
+ * counts images (mfx_hist_launch / mfx_hist_launch_cyclic output) into the global one IN PLACE on every rank:
+ * ncclAllReduce(sum, uint64) of the image; koverCpy = the ranks' values all-gathered and added in rank order
+ * (bit-stable, whatever algorithm RCCL picks).  If the reduced image's novf word (index 2*nbins + 2) is
+ * non-zero, K* bins >= nbins were seen: every rank then calls mfx_hist_allgather_overflow (collective) and folds
+ * the records of all ranks with mfx_hist_result_add_overflow.  Asynchronous on `stream` except where noted. */
+#define MFX_COMM_ID_BYTES 128
+typedef struct mfx_comm mfx_comm;
+int       mfx_comm_unique_id(void *id);
+mfx_comm *mfx_comm_create(const void *id, int rank, int nranks, int device);
+void      mfx_comm_free(mfx_comm *c);
+int       mfx_comm_rank(const mfx_comm *c);
+int       mfx_comm_size(const mfx_comm *c);
+int       mfx_hist_allreduce(mfx_comm *c, uint64_t *d_counts, double *d_kover, uint32_t nbins, uint32_t ncontigs, void *stream);
+/* synchronises `stream`; records[] receives the records of all ranks in rank order */
+int       mfx_hist_allgather_overflow(mfx_comm *c, mfx_eval *ev, uint64_t *records, uint64_t cap, uint64_t *n_out, void *stream);
+/* fold overflow records (mfx_hist_take_overflow / mfx_hist_allgather_overflow format) into a result */
+int       mfx_hist_result_add_overflow(mfx_hist_result *r, const uint64_t *records, uint64_t n);
+
 /* Device-side accumulate for sharded runs.  d_counts: uint64[MFX_HIST_WORDS]
  * caller-owned device memory, added into (zero it first), layout
  *   [0,nbins) undr | [nbins,2nbins) over | kasm | kmissing | novf |

@@ -63,6 +63,10 @@ SYMBOLS = [
     "mfx_index_count_asm", "mfx_index_value", "mfx_index_get_info", "mfx_index_export",
     "mfx_db_probe", "mfx_index_load_db", "mfx_db_write_flat", "mfx_index_save", "mfx_index_load",
     "mfx_index_set_fingerprint", "mfx_index_get_origin",
+    "mfx_host_alloc", "mfx_host_free", "mfx_seq_create", "mfx_hist_run_streamed",
+    "mfx_index_replicate", "mfx_seq_replicate", "mfx_hist_run_multi",
+    "mfx_comm_unique_id", "mfx_comm_create", "mfx_comm_free", "mfx_comm_rank", "mfx_comm_size",
+    "mfx_hist_allreduce", "mfx_hist_allgather_overflow", "mfx_hist_result_add_overflow",
     "mfx_index_image_header", "mfx_index_create_from_header", "mfx_index_device_image", "mfx_index_commit",
     "mfx_seq_upload", "mfx_seq_from_device", "mfx_seq_free", "mfx_seq_num_contigs", "mfx_seq_num_bases",
     "mfx_seq_num_tiles",
@@ -169,6 +173,30 @@ def load_library():
     L.mfx_hist_keys_launch.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp]
     L.mfx_variants_run.argtypes = [vp, C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), u64p, C.c_uint32,
                                    C.POINTER(_VarOpts), C.c_char_p, C.c_char_p, u64p]
+    L.mfx_index_set_fingerprint.argtypes = [vp, C.c_uint64]
+    L.mfx_index_get_origin.argtypes = [vp, u64p, u64p, u64p]
+    L.mfx_host_alloc.restype = vp
+    L.mfx_host_alloc.argtypes = [C.c_size_t]
+    L.mfx_host_free.restype = None
+    L.mfx_host_free.argtypes = [vp]
+    L.mfx_seq_create.restype = vp
+    L.mfx_seq_create.argtypes = [C.c_int, u64p, C.c_uint32]
+    L.mfx_hist_run_streamed.argtypes = [vp, vp, C.POINTER(vp), C.POINTER(_HistResult)]
+    L.mfx_index_replicate.restype = vp
+    L.mfx_index_replicate.argtypes = [vp, C.c_int]
+    L.mfx_seq_replicate.restype = vp
+    L.mfx_seq_replicate.argtypes = [vp, C.c_int]
+    L.mfx_hist_run_multi.argtypes = [C.POINTER(vp), C.POINTER(vp), C.c_uint32, C.POINTER(_HistResult)]
+    L.mfx_comm_unique_id.argtypes = [vp]
+    L.mfx_comm_create.restype = vp
+    L.mfx_comm_create.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.mfx_comm_free.restype = None
+    L.mfx_comm_free.argtypes = [vp]
+    L.mfx_comm_rank.argtypes = [vp]
+    L.mfx_comm_size.argtypes = [vp]
+    L.mfx_hist_allreduce.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, vp]
+    L.mfx_hist_allgather_overflow.argtypes = [vp, vp, u64p, C.c_uint64, u64p, vp]
+    L.mfx_hist_result_add_overflow.argtypes = [C.POINTER(_HistResult), u64p, C.c_uint64]
     _lib = L
     return L
 
@@ -299,6 +327,22 @@ class Index:
     def commit(self):
         _check(load_library().mfx_index_commit(self.h))
 
+    def replicate(self, device):
+        """a copy of the built table on another device of the node (peer copy over xGMI), no second build"""
+        h = _need(load_library().mfx_index_replicate(self.h, device))
+        ix = Index(0, 0, device=device, _handle=h)
+        ix.k = self.k
+        return ix
+
+    def set_fingerprint(self, fp):
+        _check(load_library().mfx_index_set_fingerprint(self.h, int(fp)))
+
+    def origin(self):
+        """(fingerprint, minV, maxV) stored with the table"""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _check(load_library().mfx_index_get_origin(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
     def add_read(self, kmers, values, minV=0, maxV=2**64 - 1):
         if isinstance(kmers, np.ndarray):
             kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
@@ -384,6 +428,17 @@ class Sequences:
         h = _need(L.mfx_seq_from_device(device, arr, ln.ctypes.data_as(C.POINTER(C.c_uint64)), n, C.c_void_p(stream or 0)))
         return Sequences(device=device, names=names, _handle=h)
 
+    @staticmethod
+    def create(lens, device=0, names=None):
+        """layout + device buffers of an assembly whose bases arrive later (Evaluator.hist_streamed)"""
+        ln = np.array(lens, dtype=np.uint64)
+        h = _need(load_library().mfx_seq_create(device, ln.ctypes.data_as(C.POINTER(C.c_uint64)), len(ln)))
+        return Sequences(device=device, names=names, _handle=h)
+
+    def replicate(self, device):
+        """a copy of the packed assembly on another device of the node"""
+        return Sequences(device=device, names=self.names, _handle=_need(load_library().mfx_seq_replicate(self.h, device)))
+
     @property
     def ncontigs(self):
         return load_library().mfx_seq_num_contigs(self.h)
@@ -426,6 +481,13 @@ class HistResult:
 
     def contig_kmissing(self):
         return np.ctypeslib.as_array(self.c.contig_kmissing, shape=(max(self.c.ncontigs, 1),))[:self.c.ncontigs].copy()
+
+    def add_overflow(self, records):
+        """fold K* bins >= nbins (Evaluator.take_overflow / Comm.allgather_overflow records) into this result"""
+        rec = np.ascontiguousarray(records, dtype=np.uint64)
+        if len(rec):
+            _check(load_library().mfx_hist_result_add_overflow(C.byref(self.c), rec.ctypes.data_as(C.POINTER(C.c_uint64)), len(rec)))
+        return self
 
     def report(self, k, hist_path=None, summary_path=None):
         _check(load_library().mfx_hist_report(C.byref(self.c), k, hist_path.encode() if hist_path else None,
@@ -473,6 +535,77 @@ class Router:
         self.close()
 
 
+class PinnedBuffer:
+    """page-locked host memory from the library (mfx_host_alloc): what a loader should read the assembly into, so that
+    the streamed upload DMAs it in place.  .array is a uint8 numpy view."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        self.p = _need(load_library().mfx_host_alloc(self.nbytes))
+        self.array = np.ctypeslib.as_array(C.cast(self.p, C.POINTER(C.c_uint8)), shape=(max(self.nbytes, 1),))[:self.nbytes]
+
+    def close(self):
+        if getattr(self, "p", None):
+            self.array = None
+            load_library().mfx_host_free(self.p)
+            self.p = None
+
+    def __del__(self):
+        self.close()
+
+
+def hist_multi(evaluators, sequences):
+    """-hist over several devices driven by this one process (mfx_hist_run_multi): evaluators[d] / sequences[d] are
+    replicas on device d; slot d evaluates the block-cyclic share d of N of the tiles, all at once."""
+    n = len(evaluators)
+    assert n == len(sequences) and n >= 1
+    ev = (C.c_void_p * n)(*[e.h for e in evaluators])
+    sq = (C.c_void_p * n)(*[s.h for s in sequences])
+    r = HistResult()
+    _check(load_library().mfx_hist_run_multi(ev, sq, n, C.byref(r.c)))
+    return r
+
+
+COMM_ID_BYTES = 128          # MFX_COMM_ID_BYTES
+
+
+class Comm:
+    """One rank of the multi-process -hist: RCCL communicator + the path's collective (csrc/mfx_comm.cpp)."""
+
+    @staticmethod
+    def unique_id():
+        buf = np.zeros(COMM_ID_BYTES, dtype=np.uint8)
+        _check(load_library().mfx_comm_unique_id(C.c_void_p(buf.ctypes.data)))
+        return buf
+
+    def __init__(self, uid, rank, nranks, device=0):
+        uid = np.ascontiguousarray(uid, dtype=np.uint8)
+        assert len(uid) == COMM_ID_BYTES
+        self.rank, self.nranks, self.device = rank, nranks, device
+        self.h = _need(load_library().mfx_comm_create(C.c_void_p(uid.ctypes.data), rank, nranks, device))
+
+    def hist_allreduce(self, ev, d_counts, d_kover, ncontigs, stream=None):
+        """counts image + koverCpy of every rank -> the global ones, in place on every rank (async on `stream`)"""
+        p = lambda x: C.c_void_p(x.data_ptr() if hasattr(x, "data_ptr") else int(x))
+        _check(load_library().mfx_hist_allreduce(self.h, p(d_counts), p(d_kover), ev.nbins, ncontigs, C.c_void_p(stream or 0)))
+
+    def allgather_overflow(self, ev, cap=1 << 20, stream=None):
+        """records of ALL ranks (collective; call on every rank when the reduced image's novf word is non-zero)"""
+        rec = np.zeros(cap, dtype=np.uint64)
+        n = C.c_uint64(0)
+        _check(load_library().mfx_hist_allgather_overflow(self.h, ev.h, rec.ctypes.data_as(C.POINTER(C.c_uint64)), cap, C.byref(n),
+                                                          C.c_void_p(stream or 0)))
+        return rec[:n.value]
+
+    def close(self):
+        if getattr(self, "h", None):
+            load_library().mfx_comm_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
 class Evaluator:
     """K* parameters bound to an Index; runs -hist / -dump / -completeness."""
 
@@ -488,6 +621,25 @@ class Evaluator:
     def hist(self, seqs):
         r = HistResult()
         _check(load_library().mfx_hist_run(self.h, seqs.h, C.byref(r.c)))
+        return r
+
+    def hist_streamed(self, seqs, host_contigs):
+        """-hist with the upload inside (SURVEY 8d's evaluate phase): `seqs` = Sequences.create(lens); host_contigs =
+        bytes / numpy uint8 arrays / PinnedBuffer views, one per contig.  Chunked H2D overlapped with the kernel."""
+        n = len(host_contigs)
+        keep = []
+        ptrs = (C.c_void_p * max(n, 1))()
+        for i, c in enumerate(host_contigs):
+            if isinstance(c, (bytes, bytearray)):
+                b = C.c_char_p(bytes(c))
+                keep.append(b)
+                ptrs[i] = C.cast(b, C.c_void_p).value
+            else:
+                a = np.ascontiguousarray(c, dtype=np.uint8)
+                keep.append(a)
+                ptrs[i] = a.ctypes.data
+        r = HistResult()
+        _check(load_library().mfx_hist_run_streamed(self.h, seqs.h, ptrs, C.byref(r.c)))
         return r
 
     def hist_launch(self, seqs, tile_begin, tile_end, d_counts, d_kover, stream=None):

@@ -29,6 +29,7 @@ struct Globals {
   double peak = 0, maxMemory = 0;
   uint64_t minV = 0, maxV = ~0ull;
   int threads = 0, reportType = OP_NONE, device = 0;
+  std::vector<int> devices;          // -devices: the GPUs of this node one process drives (-hist); [0] == device
   unsigned comb = 15;
   bool nosplit = false, debug = false, skipMissing = false;
   std::vector<uint32_t> copyKmerK;
@@ -49,6 +50,9 @@ static void usage(const char *exe) {
           "    -prob file        readK,prob rows; row n overrides -peak for multiplicity n\n"
           "    -seqmers db       assembly k-mer database; default: counted from -sequence on the GPU\n"
           "    -device d         HIP device (default 0)\n"
+          "    -devices list     several GPUs of this node driven by this one process, e.g. 0-7 or 0,2,5 (-hist: the index is\n"
+          "                      built once and copied to the others over xGMI, every GPU evaluates its share of the\n"
+          "                      sequence, the histograms are added; other report types use the first device)\n"
           "    -index file       cache of the built HBM index: loaded if it exists (the k-mer databases are then not\n"
           "                      read), otherwise written after the build\n\n"
           "  Report types (exactly one):\n"
@@ -165,6 +169,26 @@ int main(int argc, char **argv) {
     else if (is("-threads")) G.threads = atoi(val());
     else if (is("-memory")) G.maxMemory = strtod(val(), nullptr);
     else if (is("-device")) G.device = atoi(val());
+    else if (is("-devices")) {
+      // "0-7", "0,2,5", "0-3,6": a device may be named twice (two evaluation contexts on one GPU)
+      std::string spec = val();
+      bool ok = !spec.empty();
+      for (size_t i = 0; ok && i < spec.size();) {
+        char *e = nullptr;
+        long a = strtol(spec.c_str() + i, &e, 10), b = a;
+        ok = e != spec.c_str() + i && a >= 0;
+        i = (size_t)(e - spec.c_str());
+        if (ok && i < spec.size() && spec[i] == '-') {
+          const char *s2 = spec.c_str() + i + 1;
+          b = strtol(s2, &e, 10);
+          ok = e != s2 && b >= a;
+          i = (size_t)(e - spec.c_str());
+        }
+        for (long d = a; ok && d <= b && d < 1024; ++d) G.devices.push_back((int)d);
+        if (ok && i < spec.size()) { ok = spec[i] == ','; ++i; }
+      }
+      if (!ok || G.devices.empty()) { G.devices.clear(); err.push_back(std::string("Invalid device list '") + spec + "' (-devices 0-7 or 0,2,5).\n"); }
+    }
     else if (is("-index")) G.indexName = val();
     else if (is("-nosplit")) G.nosplit = true;
     else if (is("-filter")) G.reportType = OP_FILTER;
@@ -199,10 +223,13 @@ int main(int argc, char **argv) {
     for (auto &e : err) fputs(e.c_str(), stderr);
     return 1;
   }
-  if (mfx_device_count() <= G.device) {
-    fprintf(stderr, "ERROR: HIP device %d not available (%d visible). This program has no CPU path.\n", G.device, mfx_device_count());
-    return 1;
-  }
+  if (!G.devices.empty()) G.device = G.devices[0];
+  else G.devices.push_back(G.device);
+  for (int d : G.devices)
+    if (mfx_device_count() <= d) {
+      fprintf(stderr, "ERROR: HIP device %d not available (%d visible). This program has no CPU path.\n", d, mfx_device_count());
+      return 1;
+    }
 
   // MFX_CLI_TIMING=1: wall time per phase on stderr at exit (diagnostics; not part of merfin's output)
   const bool timing = getenv("MFX_CLI_TIMING") && atoi(getenv("MFX_CLI_TIMING"));
@@ -248,8 +275,13 @@ int main(int argc, char **argv) {
   lap("read sequences");
   mfx_index *ix = nullptr;
   mfx_seq *seq = nullptr;
+  // -hist on one device with the assembly k-mers coming from -seqmers: nothing needs the sequence in HBM before the
+  // evaluation, so its upload is streamed under the -hist kernel (mfx_hist_run_streamed).  Otherwise the index build
+  // counts the assembly k-mers from the packed sequence and it goes up first.
+  const bool streamHist = G.reportType == OP_HIST && G.seqDBname && G.devices.size() == 1;
   if (!recs.empty() || G.seqName) {
-    seq = mfx_seq_upload(G.device, bases.data(), lens.data(), (uint32_t)recs.size());
+    seq = streamHist ? mfx_seq_create(G.device, lens.data(), (uint32_t)recs.size())
+                     : mfx_seq_upload(G.device, bases.data(), lens.data(), (uint32_t)recs.size());
     if (!seq) DIE_MFX("uploading sequences");
   }
   lap("upload sequences");
@@ -308,7 +340,38 @@ int main(int argc, char **argv) {
   if (G.reportType == OP_HIST) {
     fprintf(stderr, "-- Generate histogram of the k* metric to '%s'.\n", G.outName);
     mfx_hist_result r;
-    if (mfx_hist_run(ev, seq, &r)) DIE_MFX("-hist");
+    if (G.devices.size() > 1) {
+      // one process, N devices (the reference drives all its workers from one binary, merfin.C:366-414): replicas of
+      // the table and of the packed assembly by peer copy, every device evaluates its block-cyclic share
+      const size_t N = G.devices.size();
+      std::vector<mfx_index *> ixs(N, nullptr);
+      std::vector<mfx_seq *> sqs(N, nullptr);
+      std::vector<mfx_eval *> evs(N, nullptr);
+      ixs[0] = ix; sqs[0] = seq; evs[0] = ev;
+      int bad = 0;
+      for (size_t d = 1; d < N && !bad; ++d) {
+        size_t same = d;
+        for (size_t e = 0; e < d; ++e) if (G.devices[e] == G.devices[d]) { same = e; break; }
+        // a device named twice shares the table and the sequence; every slot has its own evaluator
+        ixs[d] = same < d ? ixs[same] : mfx_index_replicate(ix, G.devices[d]);
+        sqs[d] = same < d ? sqs[same] : mfx_seq_replicate(seq, G.devices[d]);
+        evs[d] = (ixs[d] && sqs[d]) ? mfx_eval_create(ixs[d], &kp, 0) : nullptr;
+        if (!evs[d]) bad = 1;
+      }
+      lap("replicate index");
+      fprintf(stderr, "-- Evaluating on %zu devices.\n", N);
+      if (!bad && mfx_hist_run_multi(evs.data(), sqs.data(), (uint32_t)N, &r)) bad = 1;
+      std::string why = bad ? mfx_last_error() : "";
+      for (size_t d = 1; d < N; ++d) {
+        if (evs[d]) mfx_eval_free(evs[d]);
+        bool shared = false;
+        for (size_t e = 0; e < d; ++e) if (G.devices[e] == G.devices[d]) shared = true;
+        if (!shared) { if (sqs[d]) mfx_seq_free(sqs[d]); if (ixs[d]) mfx_index_free(ixs[d]); }
+      }
+      if (bad) { fprintf(stderr, "ERROR: -hist on %zu devices: %s\n", N, why.c_str()); return 1; }
+    } else if (streamHist) {
+      if (mfx_hist_run_streamed(ev, seq, bases.data(), &r)) DIE_MFX("-hist");
+    } else if (mfx_hist_run(ev, seq, &r)) DIE_MFX("-hist");
     uint64_t cum = 0;
     for (size_t c = 0; c < recs.size(); ++c) {   // outputHistogram's per-sequence line, in input order
       cum += r.contig_kmissing[c];

@@ -645,9 +645,25 @@ static int eval_canonical(mfx_eval *ev, int *canon) {
   return MFX_OK;
 }
 
-// part_n == 1: tiles [tile_begin, tile_end); part_n > 1: the block-cyclic share of part_rank over ALL tiles
+static int ensure_tile_partials(mfx_eval *ev, uint64_t ntiles) {
+  const uint64_t need = mfx_k_tile_partials_words(ntiles);
+  if (need > ev->tile_partials_cap) {
+    if (ev->d_tile_partials) (void)hipFree(ev->d_tile_partials);
+    ev->d_tile_partials = nullptr;
+    ev->tile_partials_cap = 0;
+    MFX_HIP(hipMalloc((void **)&ev->d_tile_partials, need * sizeof(double)));
+    ev->tile_partials_cap = need;
+  }
+  return MFX_OK;
+}
+
+// part_n == 1: tiles [tile_begin, tile_end); part_n > 1: the block-cyclic share of part_rank over ALL tiles.
+// chunk_of_total == 0: a complete evaluation -- the koverCpy values of its (tile, wave)s are summed into *d_kover.
+// chunk_of_total  > 0: one chunk of a streamed evaluation over `chunk_of_total` tiles in all: the values land at
+// their tile's place in ev->d_tile_partials (sized by the caller) and are summed ONCE after the last chunk, so
+// koverCpy is bit-identical to a single launch over the whole range, however the upload was cut.
 static int hist_launch(mfx_eval *ev, const mfx_seq *seq, uint64_t tile_begin, uint64_t tile_end, uint32_t part_rank, uint32_t part_n,
-                       uint32_t part_shift, uint64_t *d_counts, double *d_kover, void *stream) {
+                       uint32_t part_shift, uint64_t *d_counts, double *d_kover, void *stream, uint64_t chunk_of_total = 0) {
   uint64_t ntl = tile_end - tile_begin;
   if (part_n > 1) {
     const uint64_t blk = 1ull << part_shift, nblk = (seq->ntiles + blk - 1) / blk;
@@ -661,13 +677,9 @@ static int hist_launch(mfx_eval *ev, const mfx_seq *seq, uint64_t tile_begin, ui
   if (rc) return rc;
   const char *force = getenv("MFX_FORCE_TWO_STRAND");
   if (force && atoi(force)) canon = 0;
-  const uint64_t need = mfx_k_tile_partials_words(ntl);
-  if (need > ev->tile_partials_cap) {
-    if (ev->d_tile_partials) (void)hipFree(ev->d_tile_partials);
-    ev->d_tile_partials = nullptr;
-    ev->tile_partials_cap = 0;
-    MFX_HIP(hipMalloc((void **)&ev->d_tile_partials, need * sizeof(double)));
-    ev->tile_partials_cap = need;
+  if (!chunk_of_total) {
+    rc = ensure_tile_partials(ev, ntl);
+    if (rc) return rc;
   }
   mfx_hist_args a;
   a.t = ev->ix->view();
@@ -681,7 +693,7 @@ static int hist_launch(mfx_eval *ev, const mfx_seq *seq, uint64_t tile_begin, ui
   a.tile_end = tile_end;
   a.tile_contig = seq->d_tile_contig;
   a.tile_ctr = ev->d_tile_ctr;
-  a.tile_partials = ev->d_tile_partials;
+  a.tile_partials = ev->d_tile_partials + (chunk_of_total ? tile_begin * (MFX_BLOCK / 64) : 0);
   a.n_logical = ntl;
   a.part_rank = part_rank;
   a.part_n = part_n;
@@ -696,7 +708,8 @@ static int hist_launch(mfx_eval *ev, const mfx_seq *seq, uint64_t tile_begin, ui
   a.ks.partials = ev->d_partials;
   a.ks.ovf = ev->d_ovf;
   MFX_HIP(mfx_k_hist(a, (int)std::min<uint64_t>((uint64_t)ev->grid, ntl), (hipStream_t)stream));
-  MFX_HIP(mfx_k_sum_tile_partials(ev->d_tile_partials, ntl, d_kover, ev->d_tile_ctr, (hipStream_t)stream));
+  if (chunk_of_total) MFX_HIP(hipMemsetAsync(ev->d_tile_ctr, 0, sizeof(uint64_t), (hipStream_t)stream));   // re-arm the tile scheduler
+  else MFX_HIP(mfx_k_sum_tile_partials(ev->d_tile_partials, ntl, d_kover, ev->d_tile_ctr, (hipStream_t)stream));
   return MFX_OK;
 }
 
@@ -778,9 +791,18 @@ static void result_add_overflow(mfx_hist_result *r, const std::vector<uint64_t> 
   }
 }
 
+static int result_take_overflow(mfx_eval *ev, uint64_t novf, mfx_hist_result *out);
+
+extern "C" int mfx_hist_result_add_overflow(mfx_hist_result *r, const uint64_t *records, uint64_t n) {
+  if (!r || !r->undr || !r->over || (n && !records)) return mfx_fail(MFX_E_INVAL, "mfx_hist_result_add_overflow: null argument");
+  result_add_overflow(r, std::vector<uint64_t>(records, records + n));
+  return MFX_OK;
+}
+
 extern "C" int mfx_hist_run(mfx_eval *ev, const mfx_seq *seq, mfx_hist_result *out) {
   if (!ev || !seq || !out) return mfx_fail(MFX_E_INVAL, "mfx_hist_run: null argument");
   DevGuard g(ev->device);
+  MFX_HIP(hipMemset(ev->d_ovf, 0, sizeof(uint64_t)));      // records nobody collected from an earlier launch are not this run's
   const size_t words = MFX_HIST_WORDS(ev->nbins, seq->ncontigs);
   DevBuf<uint64_t> dc;
   DevBuf<double> dk;
@@ -797,16 +819,302 @@ extern "C" int mfx_hist_run(mfx_eval *ev, const mfx_seq *seq, mfx_hist_result *o
   MFX_HIP(hipMemcpy(&kover, dk.p, sizeof(double), hipMemcpyDeviceToHost));
   rc = mfx_hist_result_from_counts(ev->nbins, h.data(), kover, seq->ncontigs, out);
   if (rc) return rc;
-  uint64_t novf = h[2ull * ev->nbins + 2];
-  if (novf) {
-    std::vector<uint64_t> rec(novf);
-    uint64_t n = 0;
-    rc = mfx_hist_take_overflow(ev, rec.data(), novf, &n);
-    if (rc) { mfx_hist_result_free(out); return rc; }
-    rec.resize(std::min(n, novf));
-    result_add_overflow(out, rec);
-  }
+  rc = result_take_overflow(ev, h[2ull * ev->nbins + 2], out);
+  if (rc) mfx_hist_result_free(out);
+  return rc;
+}
+
+// fold the overflow list of `ev` (K* bins >= nbins) into a result
+static int result_take_overflow(mfx_eval *ev, uint64_t novf, mfx_hist_result *out) {
+  if (!novf) return MFX_OK;
+  std::vector<uint64_t> rec(novf);
+  uint64_t n = 0;
+  int rc = mfx_hist_take_overflow(ev, rec.data(), novf, &n);
+  if (rc) return rc;
+  rec.resize(std::min(n, novf));
+  result_add_overflow(out, rec);
   return MFX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Streamed -hist: the assembly arrives as HOST buffers (what loadSequence hands over, merfin.C:30-53) and its
+// upload is overlapped with the evaluation -- SURVEY 8(d)'s timed region "first tile H2D start -> final reduced
+// histogram on host".  The tiles are cut into chunks; chunk i's bytes travel on a copy stream while the -hist
+// kernel of chunk i-1 runs on the compute stream (one event per chunk orders them), and the counts image comes
+// back with one D2H copy at the end.  Buffers from mfx_host_alloc (pinned) are DMA'd in place; pageable buffers
+// go through two pinned staging buffers filled by host threads.
+// ---------------------------------------------------------------------------
+extern "C" void *mfx_host_alloc(size_t bytes) {
+  void *p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    mfx_fail(MFX_E_NOMEM, "mfx_host_alloc: cannot pin %zu bytes of host memory", bytes);
+    return nullptr;
+  }
+  return p;
+}
+
+extern "C" void mfx_host_free(void *p) {
+  if (p) (void)hipHostFree(p);
+}
+
+extern "C" mfx_seq *mfx_seq_create(int device, const uint64_t *lens, uint32_t ncontigs) {
+  if ((ncontigs && !lens) || device < 0 || device >= mfx_device_count()) {
+    mfx_fail(device < 0 || device >= mfx_device_count() ? MFX_E_NODEVICE : MFX_E_INVAL,
+             "mfx_seq_create: bad argument (device %d of %d)", device, mfx_device_count());
+    return nullptr;
+  }
+  DevGuard g(device);
+  mfx_seq *s = seq_layout(device, lens, ncontigs);
+  if (seq_alloc(s) != MFX_OK) { mfx_seq_free(s); return nullptr; }
+  return s;
+}
+
+static bool host_ptr_is_pinned(const void *p) {
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return at.type == hipMemoryTypeHost;
+}
+
+namespace {
+struct Piece { uint32_t contig; uint64_t pos, n; };      // bases [pos, pos+n) of a contig
+
+// the bases the tiles [t0, t1) read: their own positions plus the (k-1)-base halo behind the last tile of a contig
+// piece (a whole 128-byte line of it: the next chunk re-sends those bytes, same values)
+void chunk_pieces(const mfx_seq *s, uint64_t t0, uint64_t t1, std::vector<Piece> &out) {
+  out.clear();
+  uint32_t c = (uint32_t)(std::upper_bound(s->tile_start.begin(), s->tile_start.end(), t0) - s->tile_start.begin()) - 1;
+  for (; c < s->ncontigs && s->tile_start[c] < t1; ++c) {
+    const uint64_t cb = std::max(t0, s->tile_start[c]), ce = std::min(t1, s->tile_start[c + 1]);
+    if (ce <= cb) continue;                                 // an empty contig owns no tile
+    const uint64_t p0 = (cb - s->tile_start[c]) * MFX_TILE;
+    const uint64_t p1 = std::min<uint64_t>(s->len[c], (ce - s->tile_start[c]) * MFX_TILE + MFX_ALIGN);
+    if (p1 > p0) out.push_back({c, p0, p1 - p0});
+  }
+}
+}  // namespace
+
+extern "C" int mfx_hist_run_streamed(mfx_eval *ev, mfx_seq *seq, const char *const *bases, mfx_hist_result *out) {
+  if (!ev || !seq || !out || (seq->ncontigs && !bases)) return mfx_fail(MFX_E_INVAL, "mfx_hist_run_streamed: null argument");
+  if (ev->device != seq->device) return mfx_fail(MFX_E_INVAL, "evaluator and sequence live on different devices");
+  DevGuard g(ev->device);
+  const size_t words = MFX_HIST_WORDS(ev->nbins, seq->ncontigs);
+  const uint64_t T = seq->ntiles;
+  const uint64_t CH = 16384;                                // tiles per chunk: 64 MB of bases
+  const size_t STAGE = (size_t)CH * (MFX_TILE + 2 * MFX_ALIGN) + MFX_TILE;   // worst case: every tile its own contig
+  DevBuf<uint64_t> dc;
+  DevBuf<double> dk;
+  uint64_t *h_img = nullptr;                                // pinned: counts image + koverCpy
+  uint8_t *stage[2] = {nullptr, nullptr};
+  hipStream_t cs = nullptr, ks = nullptr;
+  hipEvent_t up[2] = {nullptr, nullptr}, staged[2] = {nullptr, nullptr};
+  int rc = MFX_OK;
+  auto cleanup = [&]() {
+    if (cs) (void)hipStreamSynchronize(cs);
+    if (ks) (void)hipStreamSynchronize(ks);
+    for (int i = 0; i < 2; ++i) {
+      if (stage[i]) (void)hipHostFree(stage[i]);
+      if (up[i]) (void)hipEventDestroy(up[i]);
+      if (staged[i]) (void)hipEventDestroy(staged[i]);
+    }
+    if (h_img) (void)hipHostFree(h_img);
+    if (cs) (void)hipStreamDestroy(cs);
+    if (ks) (void)hipStreamDestroy(ks);
+  };
+#define STREAMED_HIP(call)                                                                                        \
+  do {                                                                                                            \
+    hipError_t e_ = (call);                                                                                       \
+    if (e_ != hipSuccess) { rc = mfx_fail(MFX_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); cleanup(); return rc; } \
+  } while (0)
+  STREAMED_HIP(dc.alloc(words));
+  STREAMED_HIP(dk.alloc(1));
+  STREAMED_HIP(hipHostMalloc((void **)&h_img, (words + 1) * sizeof(uint64_t), hipHostMallocDefault));
+  STREAMED_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+  STREAMED_HIP(hipStreamCreateWithFlags(&ks, hipStreamNonBlocking));
+  for (int i = 0; i < 2; ++i) {
+    STREAMED_HIP(hipEventCreateWithFlags(&up[i], hipEventDisableTiming));
+    STREAMED_HIP(hipEventCreateWithFlags(&staged[i], hipEventDisableTiming));
+  }
+  STREAMED_HIP(hipMemsetAsync(dc.p, 0, words * sizeof(uint64_t), ks));
+  STREAMED_HIP(hipMemsetAsync(dk.p, 0, sizeof(double), ks));
+  STREAMED_HIP(hipMemsetAsync(ev->d_tile_ctr, 0, sizeof(uint64_t), ks));
+  STREAMED_HIP(hipMemsetAsync(ev->d_ovf, 0, sizeof(uint64_t), ks));
+  if ((rc = ensure_tile_partials(ev, T)) != MFX_OK) { cleanup(); return rc; }
+  std::vector<char> pinned(seq->ncontigs);
+  for (uint32_t c = 0; c < seq->ncontigs; ++c) pinned[c] = seq->len[c] && host_ptr_is_pinned(bases[c]);
+  std::vector<Piece> pieces;
+  bool stage_busy[2] = {false, false};
+  for (uint64_t t0 = 0, ci = 0; t0 < T; t0 += CH, ++ci) {
+    const uint64_t t1 = std::min(T, t0 + CH);
+    const int b = (int)(ci & 1);
+    chunk_pieces(seq, t0, t1, pieces);
+    bool direct = pieces.size() <= 64;                       // many small contigs: one assembled copy instead of many tiny ones
+    for (const Piece &pc : pieces) direct = direct && pinned[pc.contig];
+    if (direct) {
+      for (const Piece &pc : pieces)
+        STREAMED_HIP(hipMemcpyAsync(seq->d_bases + seq->off[pc.contig] + pc.pos, bases[pc.contig] + pc.pos, pc.n, hipMemcpyHostToDevice, cs));
+    } else if (!pieces.empty()) {
+      if (!stage[b]) STREAMED_HIP(hipHostMalloc((void **)&stage[b], STAGE, hipHostMallocDefault));
+      if (stage_busy[b]) STREAMED_HIP(hipEventSynchronize(staged[b]));   // its previous copy has left the buffer
+      // the staging buffer mirrors the device range [lo, hi) of this chunk; gaps between contigs stay non-ACGT
+      const uint64_t lo = seq->off[pieces.front().contig] + pieces.front().pos;
+      const uint64_t hi = seq->off[pieces.back().contig] + pieces.back().pos + pieces.back().n;
+      if (hi - lo > STAGE) { rc = mfx_fail(MFX_E_INVAL, "mfx_hist_run_streamed: chunk of %lu bytes exceeds the staging buffer", (unsigned long)(hi - lo)); cleanup(); return rc; }
+      uint64_t filled = lo;
+      for (const Piece &pc : pieces) {
+        const uint64_t at = seq->off[pc.contig] + pc.pos;
+        if (at > filled) memset(stage[b] + (filled - lo), 0, at - filled);
+        par_memcpy(stage[b] + (at - lo), bases[pc.contig] + pc.pos, pc.n);
+        filled = at + pc.n;
+      }
+      STREAMED_HIP(hipMemcpyAsync(seq->d_bases + lo, stage[b], hi - lo, hipMemcpyHostToDevice, cs));
+      STREAMED_HIP(hipEventRecord(staged[b], cs));
+      stage_busy[b] = true;
+    }
+    STREAMED_HIP(hipEventRecord(up[b], cs));
+    STREAMED_HIP(hipStreamWaitEvent(ks, up[b], 0));
+    rc = hist_launch(ev, seq, t0, t1, 0, 1, 0, dc.p, dk.p, ks, T);
+    if (rc) { cleanup(); return rc; }
+  }
+  if (T) STREAMED_HIP(mfx_k_sum_tile_partials(ev->d_tile_partials, T, dk.p, ev->d_tile_ctr, ks));
+  STREAMED_HIP(hipMemcpyAsync(h_img, dc.p, words * sizeof(uint64_t), hipMemcpyDeviceToHost, ks));
+  STREAMED_HIP(hipMemcpyAsync(h_img + words, dk.p, sizeof(double), hipMemcpyDeviceToHost, ks));
+  STREAMED_HIP(hipStreamSynchronize(ks));
+#undef STREAMED_HIP
+  double kover;
+  memcpy(&kover, h_img + words, sizeof(double));
+  rc = mfx_hist_result_from_counts(ev->nbins, h_img, kover, seq->ncontigs, out);
+  const uint64_t novf = h_img[2ull * ev->nbins + 2];
+  cleanup();
+  if (rc) return rc;
+  rc = result_take_overflow(ev, novf, out);
+  if (rc) mfx_hist_result_free(out);
+  return rc;
+}
+
+// ---------------------------------------------------------------------------
+// Several devices, ONE process (the reference is one binary driving all its workers, merfin.C:366-414): the index
+// is replicated, device d evaluates the block-cyclic share d of N of the tiles (mfx_hist_launch_cyclic), and the
+// per-device counts images (~1 MB each) are added on the host in device order -- integers exactly, koverCpy as
+// a fixed-order fp64 sum, so the result is bit-stable run to run.  K* bins beyond the dense image travel in
+// every evaluator's overflow list and are folded in as well.
+// ---------------------------------------------------------------------------
+extern "C" mfx_index *mfx_index_replicate(const mfx_index *src, int device) {
+  if (!src || device < 0 || device >= mfx_device_count()) {
+    mfx_fail(MFX_E_INVAL, "mfx_index_replicate: bad argument (device %d of %d)", device, mfx_device_count());
+    return nullptr;
+  }
+  uint8_t hdr[MFX_INDEX_HEADER_BYTES];
+  if (mfx_index_image_header(src, hdr) != MFX_OK) return nullptr;
+  mfx_index *dst = mfx_index_create_from_header(hdr, 0.0, device);
+  if (!dst) return nullptr;
+  const uint64_t bytes = src->nlines * MFX_ALIGN;
+  hipError_t e = hipSuccess;
+  {
+    DevGuard g(device);
+    if (src->device != device) {
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, device, src->device) == hipSuccess && can) {
+        hipError_t pe = hipDeviceEnablePeerAccess(src->device, 0);          // xGMI path; "already enabled" is fine
+        if (pe != hipSuccess) (void)hipGetLastError();
+      }
+    }
+    const uint64_t CH = 1ull << 30;
+    for (uint64_t o = 0; o < bytes && e == hipSuccess; o += CH)
+      e = hipMemcpyPeerAsync((char *)dst->d_slots + o, device, (const char *)src->d_slots + o, src->device, std::min(CH, bytes - o), nullptr);
+    if (e == hipSuccess) e = hipMemcpyPeer(dst->d_meta, device, src->d_meta, src->device, 4 * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+  }
+  if (e != hipSuccess) {
+    mfx_fail(MFX_E_HIP, "copying the k-mer table from device %d to device %d failed: %s", src->device, device, hipGetErrorString(e));
+    mfx_index_free(dst);
+    return nullptr;
+  }
+  dst->fingerprint = src->fingerprint;
+  (void)mfx_index_commit(dst);
+  return dst;
+}
+
+extern "C" mfx_seq *mfx_seq_replicate(const mfx_seq *src, int device) {
+  if (!src || device < 0 || device >= mfx_device_count()) {
+    mfx_fail(MFX_E_INVAL, "mfx_seq_replicate: bad argument (device %d of %d)", device, mfx_device_count());
+    return nullptr;
+  }
+  mfx_seq *s = mfx_seq_create(device, src->len.data(), src->ncontigs);
+  if (!s) return nullptr;
+  DevGuard g(device);
+  hipError_t e = hipMemcpyPeer(s->d_bases, device, src->d_bases, src->device, src->buf_bytes);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) {
+    mfx_fail(MFX_E_HIP, "copying the packed assembly from device %d to device %d failed: %s", src->device, device, hipGetErrorString(e));
+    mfx_seq_free(s);
+    return nullptr;
+  }
+  return s;
+}
+
+extern "C" int mfx_hist_run_multi(mfx_eval *const *evs, const mfx_seq *const *seqs, uint32_t ndev, mfx_hist_result *out) {
+  if (!evs || !seqs || !out || ndev == 0) return mfx_fail(MFX_E_INVAL, "mfx_hist_run_multi: null argument");
+  for (uint32_t d = 0; d < ndev; ++d) {
+    if (!evs[d] || !seqs[d]) return mfx_fail(MFX_E_INVAL, "mfx_hist_run_multi: null evaluator / sequence for slot %u", d);
+    if (evs[d]->device != seqs[d]->device) return mfx_fail(MFX_E_INVAL, "slot %u: evaluator and sequence live on different devices", d);
+    if (evs[d]->nbins != evs[0]->nbins || seqs[d]->ntiles != seqs[0]->ntiles || seqs[d]->ncontigs != seqs[0]->ncontigs)
+      return mfx_fail(MFX_E_INVAL, "slot %u: evaluators / sequences of one run must be replicas of each other", d);
+    for (uint32_t e = 0; e < d; ++e)
+      if (evs[e] == evs[d]) return mfx_fail(MFX_E_INVAL, "slots %u and %u share one evaluator (each slot launches concurrently)", e, d);
+  }
+  if (ndev == 1) return mfx_hist_run(evs[0], seqs[0], out);
+  const uint32_t nbins = evs[0]->nbins, ncontigs = seqs[0]->ncontigs;
+  const size_t words = MFX_HIST_WORDS(nbins, ncontigs);
+  struct Slot {
+    uint64_t *d_counts = nullptr; double *d_kover = nullptr; uint64_t *h = nullptr; hipStream_t st = nullptr;
+  };
+  std::vector<Slot> sl(ndev);
+  int rc = MFX_OK;
+  auto fail_hip = [&](const char *what, hipError_t e) { if (rc == MFX_OK) rc = mfx_fail(MFX_E_HIP, "mfx_hist_run_multi: %s failed: %s", what, hipGetErrorString(e)); };
+  // launch on every device before waiting for any
+  for (uint32_t d = 0; d < ndev && rc == MFX_OK; ++d) {
+    DevGuard g(evs[d]->device);
+    hipError_t e;
+    if ((e = hipStreamCreateWithFlags(&sl[d].st, hipStreamNonBlocking)) != hipSuccess) { fail_hip("hipStreamCreate", e); break; }
+    if ((e = hipMalloc((void **)&sl[d].d_counts, words * sizeof(uint64_t))) != hipSuccess ||
+        (e = hipMalloc((void **)&sl[d].d_kover, sizeof(double))) != hipSuccess ||
+        (e = hipHostMalloc((void **)&sl[d].h, (words + 1) * sizeof(uint64_t), hipHostMallocDefault)) != hipSuccess ||
+        (e = hipMemsetAsync(sl[d].d_counts, 0, words * sizeof(uint64_t), sl[d].st)) != hipSuccess ||
+        (e = hipMemsetAsync(sl[d].d_kover, 0, sizeof(double), sl[d].st)) != hipSuccess ||
+        (e = hipMemsetAsync(evs[d]->d_ovf, 0, sizeof(uint64_t), sl[d].st)) != hipSuccess) { fail_hip("buffer setup", e); break; }
+    rc = mfx_hist_launch_cyclic(evs[d], seqs[d], d, ndev, 256, sl[d].d_counts, sl[d].d_kover, sl[d].st);
+    if (rc) break;
+    if ((e = hipMemcpyAsync(sl[d].h, sl[d].d_counts, words * sizeof(uint64_t), hipMemcpyDeviceToHost, sl[d].st)) != hipSuccess ||
+        (e = hipMemcpyAsync(sl[d].h + words, sl[d].d_kover, sizeof(double), hipMemcpyDeviceToHost, sl[d].st)) != hipSuccess) fail_hip("D2H of the counts image", e);
+  }
+  std::vector<uint64_t> sum(words, 0);
+  double kover = 0.0;
+  for (uint32_t d = 0; d < ndev; ++d) {
+    if (!sl[d].st) continue;
+    DevGuard g(evs[d]->device);
+    hipError_t e = hipStreamSynchronize(sl[d].st);
+    if (e != hipSuccess) fail_hip("hipStreamSynchronize", e);
+    if (rc == MFX_OK) {
+      for (size_t i = 0; i < words; ++i) sum[i] += sl[d].h[i];
+      double kv;
+      memcpy(&kv, sl[d].h + words, sizeof(double));
+      kover = kover + kv;                                   // device order: a fixed-order fp64 sum
+    }
+  }
+  if (rc == MFX_OK) rc = mfx_hist_result_from_counts(nbins, sum.data(), kover, ncontigs, out);
+  if (rc == MFX_OK) {
+    for (uint32_t d = 0; d < ndev && rc == MFX_OK; ++d) rc = result_take_overflow(evs[d], sl[d].h[2ull * nbins + 2], out);
+    if (rc) mfx_hist_result_free(out);
+  }
+  for (uint32_t d = 0; d < ndev; ++d) {
+    DevGuard g(evs[d]->device);
+    if (sl[d].d_counts) (void)hipFree(sl[d].d_counts);
+    if (sl[d].d_kover) (void)hipFree(sl[d].d_kover);
+    if (sl[d].h) (void)hipHostFree(sl[d].h);
+    if (sl[d].st) (void)hipStreamDestroy(sl[d].st);
+  }
+  return rc;
 }
 
 extern "C" void mfx_hist_result_free(mfx_hist_result *r) {

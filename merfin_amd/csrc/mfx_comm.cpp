@@ -1,0 +1,133 @@
+// mfx_comm.cpp -- the one collective of the multi-process -hist path, on RCCL (xGMI inside a node).
+//
+// One process per GPU: every rank evaluates its block-cyclic share of the tiles into a device counts image
+// (include/merfin_amd.h MFX_HIST_WORDS) and the images are all-reduced.  What the reference does with one
+// writer thread merging per-contig results (merfin-histogram.C:96-136) is here
+//   - ncclAllReduce(sum, uint64) of the counts image                                 (integers: exact in any order)
+//   - ncclAllGather of ONE fp64 koverCpy per rank, summed in RANK ORDER on every rank (a plain fp64 all-reduce
+//     is only reproducible as long as RCCL picks the same algorithm; SURVEY 8(e) asks for the ordered form)
+//   - K* bins beyond the dense image (the reference's arrays are unbounded, merfin-histogram.C:74,87) travel as
+//     (side, bin) records: all-gather of the per-rank record lists when the reduced image says there are any.
+// Messages are ~1 MB: latency-bound, xGMI bandwidth is irrelevant here.  The unique id is exchanged by the
+// caller's launcher (any out-of-band channel: a file, MPI, torch.distributed's store).
+#include "mfx_internal.h"
+
+#include <rccl/rccl.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+static_assert(sizeof(ncclUniqueId) <= MFX_COMM_ID_BYTES, "ncclUniqueId outgrew MFX_COMM_ID_BYTES");
+
+struct mfx_comm {
+  ncclComm_t comm = nullptr;
+  int rank = 0, nranks = 1, device = 0;
+  double   *d_gather = nullptr;      // [nranks] one koverCpy per rank
+  uint64_t *d_novf = nullptr;        // [nranks] overflow records per rank
+};
+
+#define MFX_NCCL(call)                                                                                   \
+  do {                                                                                                   \
+    ncclResult_t r_ = (call);                                                                            \
+    if (r_ != ncclSuccess) return mfx_fail(MFX_E_HIP, "%s failed: %s (%s:%d)", #call, ncclGetErrorString(r_), __FILE__, __LINE__); \
+  } while (0)
+
+extern "C" int mfx_comm_unique_id(void *id) {
+  if (!id) return mfx_fail(MFX_E_INVAL, "mfx_comm_unique_id: null argument");
+  ncclUniqueId u;
+  MFX_NCCL(ncclGetUniqueId(&u));
+  memset(id, 0, MFX_COMM_ID_BYTES);
+  memcpy(id, &u, sizeof(u));
+  return MFX_OK;
+}
+
+extern "C" mfx_comm *mfx_comm_create(const void *id, int rank, int nranks, int device) {
+  if (!id || nranks < 1 || rank < 0 || rank >= nranks || device < 0 || device >= mfx_device_count()) {
+    mfx_fail(device < 0 || device >= mfx_device_count() ? MFX_E_NODEVICE : MFX_E_INVAL,
+             "mfx_comm_create: bad argument (rank %d of %d, device %d of %d)", rank, nranks, device, mfx_device_count());
+    return nullptr;
+  }
+  if (hipSetDevice(device) != hipSuccess) { mfx_fail(MFX_E_HIP, "hipSetDevice(%d) failed", device); return nullptr; }
+  mfx_comm *c = new mfx_comm;
+  c->rank = rank; c->nranks = nranks; c->device = device;
+  ncclUniqueId u;
+  memcpy(&u, id, sizeof(u));
+  ncclResult_t r = ncclCommInitRank(&c->comm, nranks, u, rank);
+  if (r != ncclSuccess) {
+    mfx_fail(MFX_E_HIP, "ncclCommInitRank(rank %d of %d, device %d) failed: %s", rank, nranks, device, ncclGetErrorString(r));
+    delete c;
+    return nullptr;
+  }
+  if (hipMalloc((void **)&c->d_gather, (size_t)nranks * sizeof(double)) != hipSuccess ||
+      hipMalloc((void **)&c->d_novf, (size_t)nranks * sizeof(uint64_t)) != hipSuccess) {
+    mfx_fail(MFX_E_NOMEM, "mfx_comm_create: device allocation failed");
+    mfx_comm_free(c);
+    return nullptr;
+  }
+  return c;
+}
+
+extern "C" void mfx_comm_free(mfx_comm *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->d_gather) (void)hipFree(c->d_gather);
+  if (c->d_novf) (void)hipFree(c->d_novf);
+  if (c->comm) (void)ncclCommDestroy(c->comm);
+  delete c;
+}
+
+extern "C" int mfx_comm_rank(const mfx_comm *c) { return c ? c->rank : -1; }
+extern "C" int mfx_comm_size(const mfx_comm *c) { return c ? c->nranks : 0; }
+
+hipError_t mfx_k_ordered_sum(const double *v, uint32_t n, double *out, hipStream_t st);   // mfx_kernels.hip
+
+// in place on every rank; asynchronous on `stream`
+extern "C" int mfx_hist_allreduce(mfx_comm *c, uint64_t *d_counts, double *d_kover, uint32_t nbins, uint32_t ncontigs, void *stream) {
+  if (!c || !d_counts || !d_kover || !nbins) return mfx_fail(MFX_E_INVAL, "mfx_hist_allreduce: null argument");
+  if (hipSetDevice(c->device) != hipSuccess) return mfx_fail(MFX_E_HIP, "hipSetDevice(%d) failed", c->device);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t words = MFX_HIST_WORDS(nbins, ncontigs);
+  MFX_NCCL(ncclAllReduce(d_counts, d_counts, words, ncclUint64, ncclSum, c->comm, st));
+  MFX_NCCL(ncclAllGather(d_kover, c->d_gather, 1, ncclDouble, c->comm, st));
+  MFX_HIP(mfx_k_ordered_sum(c->d_gather, (uint32_t)c->nranks, d_kover, st));
+  return MFX_OK;
+}
+
+// Every rank ends with the records of ALL ranks (rank order).  Collective: all ranks must call it when the
+// reduced image's novf word (counts[2*nbins + 2]) is non-zero -- it is the same on every rank after the all-reduce.
+extern "C" int mfx_hist_allgather_overflow(mfx_comm *c, mfx_eval *ev, uint64_t *records, uint64_t cap, uint64_t *n_out, void *stream) {
+  if (!c || !ev || !n_out) return mfx_fail(MFX_E_INVAL, "mfx_hist_allgather_overflow: null argument");
+  if (hipSetDevice(c->device) != hipSuccess) return mfx_fail(MFX_E_HIP, "hipSetDevice(%d) failed", c->device);
+  hipStream_t st = (hipStream_t)stream;
+  // ev->d_ovf: [0] = this rank's count, [1..] = its records
+  MFX_NCCL(ncclAllGather(ev->d_ovf, c->d_novf, 1, ncclUint64, c->comm, st));
+  std::vector<uint64_t> cnt((size_t)c->nranks);
+  MFX_HIP(hipMemcpyAsync(cnt.data(), c->d_novf, cnt.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  MFX_HIP(hipStreamSynchronize(st));
+  uint64_t mx = 0, total = 0;
+  for (uint64_t x : cnt) { mx = std::max(mx, x); total += x; }
+  *n_out = total;
+  if (mx > MFX_OVF_CAP)
+    return mfx_fail(MFX_E_OVERFLOW, "a rank saw %lu k-mers beyond the dense K* bins but its overflow list holds %u; create the evaluators with a larger nbins",
+                    (unsigned long)mx, MFX_OVF_CAP);
+  if (total == 0) return MFX_OK;
+  // fixed-size exchange: every rank contributes `mx` slots (its own records, then filler)
+  uint64_t *d_all = nullptr;
+  MFX_HIP(hipMalloc((void **)&d_all, (size_t)c->nranks * mx * sizeof(uint64_t)));
+  ncclResult_t r = ncclAllGather(ev->d_ovf + 1, d_all, mx, ncclUint64, c->comm, st);
+  std::vector<uint64_t> all((size_t)c->nranks * mx);
+  hipError_t e = hipSuccess;
+  if (r == ncclSuccess) e = hipMemcpyAsync(all.data(), d_all, all.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, st);
+  if (r == ncclSuccess && e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(d_all);
+  if (r != ncclSuccess) return mfx_fail(MFX_E_HIP, "ncclAllGather of the overflow records failed: %s", ncclGetErrorString(r));
+  MFX_HIP(e);
+  MFX_HIP(hipMemsetAsync(ev->d_ovf, 0, sizeof(uint64_t), st));
+  uint64_t w = 0;
+  for (int rk = 0; rk < c->nranks; ++rk)
+    for (uint64_t i = 0; i < cnt[rk]; ++i, ++w)
+      if (records && w < cap) records[w] = all[(size_t)rk * mx + i];
+  if (total > cap) return mfx_fail(MFX_E_OVERFLOW, "overflow list has %lu records, caller buffer %lu", (unsigned long)total, (unsigned long)cap);
+  return MFX_OK;
+}

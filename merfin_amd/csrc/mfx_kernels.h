@@ -98,6 +98,7 @@ hipError_t mfx_k_route_gather(const mfx_route_args &a, const uint32_t *idx, uint
 hipError_t mfx_k_iota(uint32_t *v, uint64_t n, hipStream_t st);
 hipError_t mfx_k_hist_keys(const mfx_hist_keys_args &a, int grid, hipStream_t st);
 hipError_t mfx_k_sum_partials(const double *partials, uint32_t n, double *out, hipStream_t st);
+hipError_t mfx_k_ordered_sum(const double *v, uint32_t n, double *out, hipStream_t st);
 uint64_t mfx_k_tile_partials_words(uint64_t ntiles);
 hipError_t mfx_k_sum_tile_partials(double *tile_partials, uint64_t ntiles, double *out, uint64_t *ctr_reset, hipStream_t st);
 int mfx_k_hist_resident_blocks();

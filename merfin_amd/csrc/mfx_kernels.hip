@@ -1032,6 +1032,15 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_sum_partials_kernel(const doubl
   }
 }
 
+// out[0] = v[0] + v[1] + ... in index order (one thread: n = number of ranks); the multi-process koverCpy
+__global__ void mfx_ordered_sum_kernel(const double *v, uint32_t n, double *out) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    double s = 0.0;
+    for (uint32_t i = 0; i < n; ++i) s = s + v[i];
+    out[0] = s;
+  }
+}
+
 // first level over the per-(tile, wave) values: block b sums in[b*MFX_SUM_CHUNK ...) in a fixed order
 #define MFX_SUM_CHUNK 4096u
 __global__ __launch_bounds__(MFX_BLOCK) void mfx_sum_chunks_kernel(const double *in, uint64_t n, double *out) {
@@ -1247,6 +1256,10 @@ hipError_t mfx_k_hist_keys(const mfx_hist_keys_args &a, int grid, hipStream_t st
 }
 hipError_t mfx_k_sum_partials(const double *partials, uint32_t n, double *out, hipStream_t st) {
   mfx_sum_partials_kernel<<<1, MFX_BLOCK, 0, st>>>(partials, n, out, nullptr);
+  return hipGetLastError();
+}
+hipError_t mfx_k_ordered_sum(const double *v, uint32_t n, double *out, hipStream_t st) {
+  mfx_ordered_sum_kernel<<<1, 64, 0, st>>>(v, n, out);
   return hipGetLastError();
 }
 uint64_t mfx_k_tile_partials_words(uint64_t ntiles) {

@@ -212,6 +212,7 @@ def main(argv=None):
     counts = torch.zeros(m.hist_words(ev.nbins, sq.ncontigs), dtype=torch.int64, device="cuda")
     kover = torch.zeros(1, dtype=torch.float64, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
+    ev.take_overflow()                                     # start from an empty overflow list
 
     def host_exchange(keys, contigs_, send):               # gloo rehearsal only
         sc = torch.tensor([int(x) for x in send], dtype=torch.int64)
@@ -262,8 +263,18 @@ def main(argv=None):
         reduce_all()
     torch.cuda.synchronize()
 
+    # K* bins beyond the dense image (the reference's arrays are unbounded, merfin-histogram.C:74,87) stay in each
+    # evaluator's overflow list: the reduced novf word is the same on every rank, so all ranks agree on gathering them
+    h = counts.cpu().numpy().view(np.uint64)
+    overflow = np.zeros(0, dtype=np.uint64)
+    if int(h[2 * ev.nbins + 2]):
+        overflow = ev.take_overflow()
+        if world > 1:
+            parts = [None] * world
+            dist.all_gather_object(parts, overflow)
+            overflow = np.concatenate(parts)
     if rank == 0:
-        res = m.result_from_counts(ev.nbins, counts.cpu().numpy().view(np.uint64), float(kover.item()), sq.ncontigs)
+        res = m.result_from_counts(ev.nbins, h, float(kover.item()), sq.ncontigs).add_overflow(overflow)
         cum = 0
         for c, nm in enumerate(names):                     # outputHistogram's per-sequence line, input order
             cum += int(res.contig_kmissing()[c])

@@ -246,3 +246,28 @@ def test_cli_index_cache_is_bound_to_its_inputs(tmp_path):
     r = run(base + ["-min", "4", "-max", "40", "-output", str(tmp_path / "g4.hist")])
     assert r.returncode == 0 and "rebuilding" in r.stderr and "-min/-max differ" in r.stderr, r.stderr
     assert (tmp_path / "g4.hist").read_bytes() == want3
+
+
+def test_cli_device_list_validation():
+    r = run(["-hist", "-devices", "0-x", "-sequence", "a", "-output", "o", "-readmers", "r", "-peak", "3"])
+    assert r.returncode == 1 and "Invalid device list '0-x'" in r.stderr
+    r = run(["-hist", "-devices", "3-1", "-sequence", "a", "-output", "o", "-readmers", "r", "-peak", "3"])
+    assert r.returncode == 1 and "Invalid device list" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", ["0,0", "0-0,0,0"])
+def test_cli_hist_on_several_devices_of_one_process(tmp_path, golden_dir, devices):
+    """`merfin -hist -devices ...`: one process drives N evaluation contexts (here all on GPU 0, the box has one);
+    histogram file and summary byte-identical to the committed golden fixture (= the single-device output)."""
+    g = lambda n: os.path.join(golden_dir, n)
+    args = ["-hist", "-sequence", g("case1.fasta"), "-readmers", g("case1.read.kmers.txt"), "-peak", "17.3",
+            "-output", str(tmp_path / "m.hist"), "-devices", devices]
+    r = run(args)
+    assert r.returncode == 0, r.stderr
+    assert "-- Evaluating on %d devices." % (2 if devices == "0,0" else 3) in r.stderr
+    r1 = run(args[:-2] + ["-output", str(tmp_path / "s.hist")])
+    assert r1.returncode == 0, r1.stderr
+    assert (tmp_path / "m.hist").read_bytes() == (tmp_path / "s.hist").read_bytes() == open(g("case1.hist"), "rb").read()
+    tail = lambda s: s[s.index("K-mers not found in reads"):]
+    assert tail(r.stderr) == tail(r1.stderr)

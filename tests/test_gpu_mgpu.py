@@ -93,3 +93,29 @@ def test_launcher_broadcast_index_matches_golden(tmp_path, nproc):
     r = _launch(nproc, COMMON + ["-output", out, "-broadcast-index"], 23 * nproc)
     assert open(out, "rb").read() == open(G + "/case1.hist", "rb").read()
     assert open(G + "/case1.summary").read() in r.stderr and "Broadcasting the built table" in r.stderr
+
+
+@pytest.mark.gpu
+def test_two_rank_launcher_keeps_bins_beyond_the_dense_image(tmp_path):
+    """asmK/readK > 13107 lands in K* bins >= 65536, beyond the all-reduced dense image: the records must be gathered
+    from every rank (the reference's histogram arrays are unbounded, merfin-histogram.C:74,87)"""
+    import merfin_amd as m
+    from oracle import pyoracle as po
+    from tests.test_cli import _write_fasta
+    from tests.test_gpu_parity import oracle_hist
+    from tests.test_gpu_streamed_multi import _overflow_world
+    k, peak, contigs, read, asm = _overflow_world(m)
+    p, g, ka, km = oracle_hist(k, peak, contigs, read, asm)
+    assert g.c.undrMax > 65536 and g.c.overMax > 65536
+    po.report_histogram(p, g, str(tmp_path / "o.hist"), str(tmp_path / "o.sum"))
+    _write_fasta(str(tmp_path / "a.fasta"), contigs)
+    m.db_write_flat(str(tmp_path / "r.mfxk"), k, *read)
+    m.db_write_flat(str(tmp_path / "a.mfxk"), k, *asm)
+    env = dict(os.environ, MFX_MGPU_BACKEND="gloo", MFX_MGPU_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29950 + os.getpid() % 40), "-m", "merfin_amd.mgpu", "-sequence", str(tmp_path / "a.fasta"),
+           "-readmers", str(tmp_path / "r.mfxk"), "-seqmers", str(tmp_path / "a.mfxk"), "-peak", str(peak), "-output", str(tmp_path / "g.hist")]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert (tmp_path / "g.hist").read_bytes() == (tmp_path / "o.hist").read_bytes()
+    assert (tmp_path / "o.sum").read_text() in r.stderr

@@ -1,0 +1,190 @@
+"""The two C++ host paths added around the -hist kernel:
+  * streamed evaluation (mfx_hist_run_streamed): host buffers -> chunked H2D overlapped with the kernel -> histogram on
+    the host, SURVEY 8(d)'s timed region; must equal upload-then-evaluate bit for bit (koverCpy included);
+  * several devices driven by ONE process (mfx_index_replicate / mfx_seq_replicate / mfx_hist_run_multi) -- the GPU
+    box has one GPU, so the slots are several contexts on device 0 ("-devices 0,0"); results vs the CPU oracle,
+    including K* bins beyond the dense device image (the reference's arrays are unbounded, merfin-histogram.C:74,87);
+  * the RCCL communicator of the one-process-per-GPU path (csrc/mfx_comm.cpp) with a world of ONE rank (RCCL refuses
+    two ranks per device): the collective calls run, the result is the identity."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from tests import synth
+from tests.test_gpu_parity import assert_hist_equal, build_index, oracle_hist
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b):
+    assert (a.kasm, a.kmissing) == (b.kasm, b.kmissing)
+    np.testing.assert_array_equal(a.undr(), b.undr())
+    np.testing.assert_array_equal(a.over(), b.over())
+    np.testing.assert_array_equal(a.contig_kasm(), b.contig_kasm())
+    np.testing.assert_array_equal(a.contig_kmissing(), b.contig_kmissing())
+    assert a.koverCpy == b.koverCpy                      # bit-identical: same values, same summation tree
+
+
+@pytest.mark.parametrize("shape", ["few_large", "many_small", "edges"])
+def test_streamed_equals_resident_and_oracle(shape):
+    import merfin_amd as m
+    k, peak = 21, 17.3
+    r = synth.rng(311)
+    if shape == "few_large":
+        contigs, read, asm = synth.world(k=k, peak=peak, seed=312, sizes=(300000, 70000, 4096, 4097, 20, 0, 8191))
+    elif shape == "many_small":                               # > 64 pieces per chunk: the assembled-copy path
+        contigs = [synth.random_contig(r, int(n)).tobytes() for n in r.integers(0, 900, size=3000)]
+        contigs[5] = b""
+        ak, av = po.count_kmers(k, contigs)
+        read, asm = (ak, (2 + (ak % 30)).astype(np.uint32)), (ak, av)
+    else:
+        base = synth.random_contig(r, 3 * 4096 + 50)
+        base[4095] = ord("N"); base[4096 + 20] = ord("n")
+        contigs = [b"", b"ACGT", base.tobytes(), synth.random_contig(r, 4096).tobytes(), b"N" * 5000,
+                   synth.random_contig(r, 21).tobytes(), synth.random_contig(r, 4096 + 20).tobytes(), b""]
+        ak, av = po.count_kmers(k, contigs)
+        read, asm = (ak, (3 + (ak % 40)).astype(np.uint32)), (ak, av)
+    p, g, ka, km = oracle_hist(k, peak, contigs, read, asm)
+    ix = build_index(m, k, read, asm)
+    ev = m.Evaluator(ix, m.KParams(peak))
+    resident = ev.hist(m.Sequences(contigs))
+    assert_hist_equal(resident, g, ka, km, k)
+    lens = [len(c) for c in contigs]
+    # (a) pageable host buffers: staged through pinned memory by the library
+    s1 = m.Sequences.create(lens)
+    _same(ev.hist_streamed(s1, contigs), resident)
+    _same(ev.hist(s1), resident)                              # afterwards the sequence object is a normal resident one
+    # (b) pinned buffers (mfx_host_alloc), DMA'd in place
+    pins = [m.PinnedBuffer(n) for n in lens]
+    for pb, c in zip(pins, contigs):
+        pb.array[:] = np.frombuffer(c, dtype=np.uint8)
+    s2 = m.Sequences.create(lens)
+    _same(ev.hist_streamed(s2, [pb.array for pb in pins]), resident)
+    # (c) a second run on the same objects (buffers re-armed)
+    _same(ev.hist_streamed(s2, [pb.array for pb in pins]), resident)
+
+
+def test_streamed_spans_several_chunks():
+    """more tiles than one 16384-tile chunk: chunk boundaries inside and between contigs, halo bytes re-sent"""
+    import merfin_amd as m
+    k, peak = 21, 9.0
+    r = synth.rng(313)
+    sizes = (16384 * 4096 + 777, 3 * 4096 * 4096 + 5, 1000)   # 67 M + 50 M bases: 3 chunks
+    contigs = [synth.random_contig(r, n) for n in sizes]
+    contigs[0][16384 * 4096 - 10:16384 * 4096 + 10] |= 0x20   # lower case across the first chunk boundary
+    contigs[1][12345] = ord("N")
+    seqs = m.Sequences([c.tobytes() for c in contigs])
+    ix = m.Index(k, sum(sizes) + 1024)
+    ix.count_asm(seqs)
+    # read counts for the k-mers around both chunk boundaries and at the contig ends (the rest stay "missing")
+    b1 = 16384 * 4096
+    spots = [contigs[0][:200000], contigs[0][b1 - 100000:b1 + 100000], contigs[0][-50000:], contigs[1][:50000],
+             contigs[1][12000:13000], contigs[1][-50000:], contigs[2]]
+    rk = po.count_kmers(k, [x.tobytes() for x in spots])[0]
+    ix.add_read(rk, (1 + (rk % 50)).astype(np.uint32))
+    ev = m.Evaluator(ix, m.KParams(peak))
+    resident = ev.hist(seqs)
+    assert resident.kasm == sum(n - 20 for n in sizes) - 21    # one N: 21 k-mers lost
+    assert 0 < resident.kmissing < resident.kasm and int(resident.undr().sum() + resident.over().sum()) > 400000
+    s = m.Sequences.create(list(sizes))
+    _same(ev.hist_streamed(s, contigs), resident)
+    pins = [m.PinnedBuffer(n) for n in sizes]
+    for pb, c in zip(pins, contigs):
+        pb.array[:] = c
+    _same(ev.hist_streamed(m.Sequences.create(list(sizes)), [pb.array for pb in pins]), resident)
+
+
+@pytest.fixture(scope="module")
+def five_mb_world():
+    k, peak = 21, 17.3
+    contigs, read, asm = synth.world(k=k, peak=peak, seed=321, sizes=(4200000, 1100000, 4097, 500, 0, 8191), err_kmers=3000)
+    p, g, ka, km = oracle_hist(k, peak, contigs, read, asm)
+    return k, peak, contigs, read, asm, g, ka, km
+
+
+@pytest.mark.parametrize("nslots", [2, 3, 5])
+def test_one_process_several_slots_matches_oracle(nslots, five_mb_world):
+    import merfin_amd as m
+    k, peak, contigs, read, asm, g, ka, km = five_mb_world
+    ix = build_index(m, k, read, asm)
+    seqs = m.Sequences(contigs)
+    assert seqs.ntiles > 256 * nslots                         # every slot gets several 256-tile blocks
+    # slot 0 uses the original objects, the others replicas made by device-to-device copy (no second build)
+    ixs = [ix] + [ix.replicate(0) for _ in range(nslots - 1)]
+    sqs = [seqs] + [seqs.replicate(0) for _ in range(nslots - 1)]
+    for rep in ixs[1:]:
+        assert rep.info() == ix.info()
+    evs = [m.Evaluator(x, m.KParams(peak)) for x in ixs]
+    res = m.hist_multi(evs, sqs)
+    assert_hist_equal(res, g, ka, km, k)
+    single = evs[0].hist(seqs)
+    assert (res.kasm, res.kmissing) == (single.kasm, single.kmissing)
+    again = m.hist_multi(evs, sqs)
+    assert again.koverCpy == res.koverCpy                     # fixed-order sum: bit-stable run to run
+    # slots may also share one index and one sequence object (only the evaluators must be distinct)
+    shared = m.hist_multi([m.Evaluator(ix, m.KParams(peak)) for _ in range(nslots)], [seqs] * nslots)
+    assert_hist_equal(shared, g, ka, km, k)
+    with pytest.raises(m.MfxError):
+        m.hist_multi([evs[0], evs[0]], [seqs, seqs])
+
+
+def _overflow_world(m):
+    """asmK/readK ratios > 13107 (K* bin >= 65536: beyond the default dense image) on both halves of the tile range"""
+    k = 21
+    r = synth.rng(331)
+    contigs = [synth.random_contig(r, 300 * 4096).tobytes(), synth.random_contig(r, 300 * 4096 + 11).tobytes()]
+    ak, av = po.count_kmers(k, contigs)
+    av = av.copy()
+    rv = np.full(len(ak), 5, dtype=np.uint32)
+    first = po.count_kmers(k, [contigs[0][:60], contigs[0][-60:], contigs[1][:60], contigs[1][-60:]])[0]
+    hot = np.isin(ak, first)
+    av[hot] = 70000 + (np.arange(hot.sum()) % 7) * 100000     # undr bins 349 995 ... 3.3 M
+    rv[np.isin(ak, po.count_kmers(k, [contigs[1][5000:5040]])[0])] = 900000   # over bins ~ 900 000
+    return k, 5.0, contigs, (ak, rv), (ak, av)
+
+
+def test_overflow_bins_survive_the_multi_slot_reduction():
+    import merfin_amd as m
+    k, peak, contigs, read, asm = _overflow_world(m)
+    p, g, ka, km = oracle_hist(k, peak, contigs, read, asm)
+    assert g.c.undrMax > 65536 and g.c.overMax > 65536
+    ix = build_index(m, k, read, asm)
+    seqs = m.Sequences(contigs)
+    assert_hist_equal(m.Evaluator(ix, m.KParams(peak)).hist(seqs), g, ka, km, k)
+    for n in (2, 3):
+        evs = [m.Evaluator(ix, m.KParams(peak)) for _ in range(n)]
+        assert_hist_equal(m.hist_multi(evs, [seqs] * n), g, ka, km, k)
+    # the streamed path folds them too
+    assert_hist_equal(m.Evaluator(ix, m.KParams(peak)).hist_streamed(m.Sequences.create([len(c) for c in contigs]), contigs), g, ka, km, k)
+
+
+def test_rccl_communicator_world_of_one():
+    """the C path's collective with nranks = 1: ncclCommInitRank / ncclAllReduce(uint64) / ncclAllGather run on the
+    device; one rank's image is already the global one, so every word must come back unchanged"""
+    torch = pytest.importorskip("torch")
+    import merfin_amd as m
+    k, peak, contigs, read, asm = _overflow_world(m)
+    p, g, ka, km = oracle_hist(k, peak, contigs, read, asm)
+    ix = build_index(m, k, read, asm)
+    seqs = m.Sequences(contigs)
+    ev = m.Evaluator(ix, m.KParams(peak))
+    comm = m.Comm(m.Comm.unique_id(), 0, 1, device=0)
+    counts = torch.zeros(m.hist_words(ev.nbins, seqs.ncontigs), dtype=torch.int64, device="cuda")
+    kover = torch.zeros(1, dtype=torch.float64, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    ev.take_overflow()                                        # start from an empty list
+    ev.hist_launch_cyclic(seqs, 0, 1, counts, kover, stream=s)
+    torch.cuda.synchronize()
+    before, kb = counts.clone(), float(kover.item())
+    comm.hist_allreduce(ev, counts, kover, seqs.ncontigs, stream=s)
+    torch.cuda.synchronize()
+    assert torch.equal(before, counts) and float(kover.item()) == kb
+    h = counts.cpu().numpy().view(np.uint64)
+    novf = int(h[2 * ev.nbins + 2])
+    assert novf > 0
+    rec = comm.allgather_overflow(ev, stream=s)
+    assert len(rec) == novf
+    res = ev.result_from_counts(h, kb, seqs.ncontigs).add_overflow(rec)
+    assert_hist_equal(res, g, ka, km, k)
+    assert len(ev.take_overflow()) == 0                       # the gather consumed the list
+    comm.close()
