@@ -249,6 +249,7 @@ mfx_comm *mfx_comm_create(const void *id, int rank, int nranks, int device);
 void      mfx_comm_free(mfx_comm *c);
 int       mfx_comm_rank(const mfx_comm *c);
 int       mfx_comm_size(const mfx_comm *c);
+int       mfx_comm_barrier(mfx_comm *c, void *stream);      /* all ranks arrived and `stream` drained (synchronous) */
 int       mfx_hist_allreduce(mfx_comm *c, uint64_t *d_counts, double *d_kover, uint32_t nbins, uint32_t ncontigs, void *stream);
 /* synchronises `stream`; records[] receives the records of all ranks in rank order */
 int       mfx_hist_allgather_overflow(mfx_comm *c, mfx_eval *ev, uint64_t *records, uint64_t cap, uint64_t *n_out, void *stream);

@@ -65,7 +65,7 @@ SYMBOLS = [
     "mfx_index_set_fingerprint", "mfx_index_get_origin",
     "mfx_host_alloc", "mfx_host_free", "mfx_seq_create", "mfx_hist_run_streamed",
     "mfx_index_replicate", "mfx_seq_replicate", "mfx_hist_run_multi",
-    "mfx_comm_unique_id", "mfx_comm_create", "mfx_comm_free", "mfx_comm_rank", "mfx_comm_size",
+    "mfx_comm_unique_id", "mfx_comm_create", "mfx_comm_free", "mfx_comm_rank", "mfx_comm_size", "mfx_comm_barrier",
     "mfx_hist_allreduce", "mfx_hist_allgather_overflow", "mfx_hist_result_add_overflow",
     "mfx_index_image_header", "mfx_index_create_from_header", "mfx_index_device_image", "mfx_index_commit",
     "mfx_seq_upload", "mfx_seq_from_device", "mfx_seq_free", "mfx_seq_num_contigs", "mfx_seq_num_bases",
@@ -194,6 +194,7 @@ def load_library():
     L.mfx_comm_free.argtypes = [vp]
     L.mfx_comm_rank.argtypes = [vp]
     L.mfx_comm_size.argtypes = [vp]
+    L.mfx_comm_barrier.argtypes = [vp, vp]
     L.mfx_hist_allreduce.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, vp]
     L.mfx_hist_allgather_overflow.argtypes = [vp, vp, u64p, C.c_uint64, u64p, vp]
     L.mfx_hist_result_add_overflow.argtypes = [C.POINTER(_HistResult), u64p, C.c_uint64]
@@ -588,6 +589,10 @@ class Comm:
         """counts image + koverCpy of every rank -> the global ones, in place on every rank (async on `stream`)"""
         p = lambda x: C.c_void_p(x.data_ptr() if hasattr(x, "data_ptr") else int(x))
         _check(load_library().mfx_hist_allreduce(self.h, p(d_counts), p(d_kover), ev.nbins, ncontigs, C.c_void_p(stream or 0)))
+
+    def barrier(self, stream=None):
+        """every rank has arrived and `stream` has drained"""
+        _check(load_library().mfx_comm_barrier(self.h, C.c_void_p(stream or 0)))
 
     def allgather_overflow(self, ev, cap=1 << 20, stream=None):
         """records of ALL ranks (collective; call on every rank when the reduced image's novf word is non-zero)"""

@@ -80,6 +80,17 @@ extern "C" void mfx_comm_free(mfx_comm *c) {
 extern "C" int mfx_comm_rank(const mfx_comm *c) { return c ? c->rank : -1; }
 extern "C" int mfx_comm_size(const mfx_comm *c) { return c ? c->nranks : 0; }
 
+// all ranks have reached this point and `stream` has drained (a one-word all-reduce + a stream synchronise)
+extern "C" int mfx_comm_barrier(mfx_comm *c, void *stream) {
+  if (!c) return mfx_fail(MFX_E_INVAL, "mfx_comm_barrier: null argument");
+  if (hipSetDevice(c->device) != hipSuccess) return mfx_fail(MFX_E_HIP, "hipSetDevice(%d) failed", c->device);
+  hipStream_t st = (hipStream_t)stream;
+  MFX_HIP(hipMemsetAsync(c->d_novf, 0, sizeof(uint64_t), st));
+  MFX_NCCL(ncclAllReduce(c->d_novf, c->d_novf, 1, ncclUint64, ncclSum, c->comm, st));
+  MFX_HIP(hipStreamSynchronize(st));
+  return MFX_OK;
+}
+
 hipError_t mfx_k_ordered_sum(const double *v, uint32_t n, double *out, hipStream_t st);   // mfx_kernels.hip
 
 // in place on every rank; asynchronous on `stream`

@@ -202,6 +202,124 @@ __device__ __forceinline__ void mfx_meta_flush(uint64_t *meta, uint32_t fresh, u
   }
 }
 
+// ---------------------------------------------------------------------------
+// Wave-cooperative insert (index build, assembly k-mer counting): the mirror image of the cooperative lookup.
+// Each lane brings one key; the 8 lanes of a lane-group serve their 8 keys one after the other ("owner" S = 0..7),
+// and for the key being served they read the 8 slots of its candidate line with ONE coalesced 128-byte request
+// (lane `sub` reads slot `sub`), so that
+//   - "is the key there" and "where is the first empty slot" are two ballots, and
+//   - exactly one lane per key issues the claiming compare-and-swap and the count update,
+// instead of every lane walking up to 8 slots of its own line with dependent atomic loads (which is the divergent
+// access pattern the lookup path was built to avoid: ~10 G inserts/s).  All eight first-candidate lines of a group
+// are requested back to back before the first is looked at.
+// Slots of a line fill in order: the claim goes to the LOWEST empty slot, and a lost race re-reads the line, so a
+// slot can only be taken when every lower slot was seen occupied -- lookups rely on "the line has room <=> its last
+// slot is empty".  Keys are read with agent-scope atomic loads (a plain load could be served from this CU's L1,
+// which other CUs' claims never refresh: a lost race would then spin on the stale line).
+// ---------------------------------------------------------------------------
+template <int S>
+__device__ __forceinline__ uint32_t mfx_group_bcast(uint32_t v);          // defined with the lookup path below
+
+__device__ __forceinline__ unsigned long long mfx_slot_key_load(const mfx_table_view &t, uint64_t line, uint32_t sub) {
+  return __hip_atomic_load(reinterpret_cast<unsigned long long *>(&t.slots[line * MFX_SLOTS_LINE + sub].key), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct mfx_ins_round {          // what the 8 lanes of a group know about the key they are serving (group-uniform)
+  uint32_t klo, khi, lineA, lineB, val, ok;
+};
+
+template <int S>
+__device__ __forceinline__ void mfx_ins_announce(mfx_ins_round (&R)[8], uint64_t key, const mfx_probe &pr, uint32_t v, bool ok) {
+  R[S].klo = mfx_group_bcast<S>((uint32_t)key);
+  R[S].khi = mfx_group_bcast<S>((uint32_t)(key >> 32));
+  R[S].lineA = mfx_group_bcast<S>(pr.lineA);
+  R[S].lineB = mfx_group_bcast<S>(pr.lineB);
+  R[S].val = mfx_group_bcast<S>(v);
+  R[S].ok = mfx_group_bcast<S>(ok ? 1u : 0u);
+}
+
+// serves owner S's key; cur = this lane's slot of the key's first candidate line as loaded in the issue phase.
+// Returns the (line, slot) a NEW key was written to (slot 8 = none): later rounds of the group that pre-loaded
+// the same line patch their copy instead of losing a guaranteed race against their own group.
+template <int S>
+__device__ __forceinline__ uint32_t mfx_ins_serve(const mfx_table_view &t, const mfx_ins_round (&R)[8], unsigned long long cur, int side,
+                                                  uint64_t *meta, uint32_t &fresh, uint64_t &claimed_line) {
+  const uint32_t lane = threadIdx.x & 63u, sub = lane & 7u, gsh = lane & ~7u;
+  const unsigned long long key = (unsigned long long)R[S].klo | ((unsigned long long)R[S].khi << 32);
+  mfx_probe pr;
+  pr.lineA = R[S].lineA; pr.lineB = R[S].lineB;
+  uint32_t d = 0, claimed_slot = 8u;
+  uint64_t line = mfx_probe_line(t, pr, 0);
+  bool pend = R[S].ok != 0u;                               // group-uniform: the loop below diverges between groups only
+  while (pend) {
+    const uint32_t m_match = (uint32_t)(__ballot(cur == key) >> gsh) & 0xffu;
+    const uint32_t m_empty = (uint32_t)(__ballot(cur == MFX_EMPTY) >> gsh) & 0xffu;
+    mfx_slot *sl = t.slots + line * MFX_SLOTS_LINE + sub;
+    if (m_match) {
+      if (sub == (uint32_t)__ffs((int)m_match) - 1u) atomicAdd(side ? &sl->asmV : &sl->readV, R[S].val);
+      pend = false;
+    } else if (m_empty) {
+      const uint32_t f = (uint32_t)__ffs((int)m_empty) - 1u;          // lowest empty slot: slots fill in order
+      unsigned long long old = ~0ull - 1ull;
+      if (sub == f) old = atomicCAS(reinterpret_cast<unsigned long long *>(&sl->key), (unsigned long long)MFX_EMPTY, key);
+      const bool won = sub == f && (old == MFX_EMPTY || old == key);    // old == key: another group inserted the same k-mer first
+      if ((uint32_t)(__ballot(won) >> gsh) & 0xffu) {
+        if (won) {
+          atomicAdd(side ? &sl->asmV : &sl->readV, R[S].val);
+          if (old == MFX_EMPTY) ++fresh;
+        }
+        if ((uint32_t)(__ballot(won && old == MFX_EMPTY) >> gsh) & 0xffu) { claimed_slot = f; claimed_line = line; }
+        pend = false;
+      } else {
+        cur = mfx_slot_key_load(t, line, sub);              // lost the slot to another key: look at the line again
+      }
+    } else if (++d >= MFX_MAX_LINES) {
+      if (sub == 0) atomicAdd((unsigned long long *)&meta[2], 1ull);   // probe limit: reported as MFX_E_FULL by the host
+      pend = false;
+    } else {
+      line = mfx_probe_line(t, pr, d);                      // candidate line full without the key: next one
+      cur = mfx_slot_key_load(t, line, sub);
+    }
+  }
+  return claimed_slot;
+}
+
+// one key per lane (ok = false: none); adds v to the key's read (side 0) or assembly (side 1) count
+__device__ __forceinline__ void mfx_group_insert(const mfx_table_view &t, uint64_t key, bool ok, uint32_t v, int side, uint64_t *meta,
+                                                 uint32_t &fresh) {
+  const uint32_t sub = threadIdx.x & 7u;
+  mfx_probe pr;
+  pr.lineA = pr.lineB = 0u;
+  if (ok) pr = mfx_home(t, key);
+  mfx_ins_round R[8];
+  mfx_ins_announce<0>(R, key, pr, v, ok); mfx_ins_announce<1>(R, key, pr, v, ok); mfx_ins_announce<2>(R, key, pr, v, ok);
+  mfx_ins_announce<3>(R, key, pr, v, ok); mfx_ins_announce<4>(R, key, pr, v, ok); mfx_ins_announce<5>(R, key, pr, v, ok);
+  mfx_ins_announce<6>(R, key, pr, v, ok); mfx_ins_announce<7>(R, key, pr, v, ok);
+  unsigned long long cur[8];
+  uint64_t line0[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    mfx_probe p2;
+    p2.lineA = R[s].lineA; p2.lineB = R[s].lineB;
+    line0[s] = mfx_probe_line(t, p2, 0);
+    cur[s] = mfx_slot_key_load(t, line0[s], sub);           // eight independent requests in flight
+  }
+#define MFX_INS_ROUND(S_)                                                                                   \
+  {                                                                                                         \
+    uint64_t cl = ~0ull;                                                                                    \
+    const uint32_t cs = mfx_ins_serve<S_>(t, R, cur[S_], side, meta, fresh, cl);                            \
+    if (cs < 8u) {                                                                                          \
+      const unsigned long long nk = (unsigned long long)R[S_].klo | ((unsigned long long)R[S_].khi << 32);  \
+      _Pragma("unroll") for (int s2 = S_ + 1; s2 < 8; ++s2)                                                 \
+        if (line0[s2] == cl && sub == cs) cur[s2] = nk;   /* consecutive k-mers share their minimizer's line */ \
+    }                                                                                                       \
+  }
+  MFX_INS_ROUND(0) MFX_INS_ROUND(1) MFX_INS_ROUND(2) MFX_INS_ROUND(3)
+  MFX_INS_ROUND(4) MFX_INS_ROUND(5) MFX_INS_ROUND(6) MFX_INS_ROUND(7)
+#undef MFX_INS_ROUND
+}
+
 __global__ void mfx_table_init_kernel(mfx_slot *slots, uint64_t nslots) {
   uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
   uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -211,21 +329,23 @@ __global__ void mfx_table_init_kernel(mfx_slot *slots, uint64_t nslots) {
 }
 
 // side 0: read counts, side 1: asm counts
-__global__ void mfx_table_add_kernel(mfx_table_view t, const uint64_t *kmers, const uint32_t *values, uint64_t n,
-                                     int side, uint64_t *meta) {
-  uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+__global__ __launch_bounds__(256) void mfx_table_add_kernel(mfx_table_view t, const uint64_t *kmers, const uint32_t *values, uint64_t n,
+                                                            int side, uint64_t *meta) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   uint32_t fresh = 0, noncanon = 0;
-  for (; i < n; i += stride) {
-    uint64_t key = kmers[i];
-    uint32_t v = values[i];
-    if (v == 0) continue;
-    const uint64_t krc = mfx_revcomp(key, t.k);
-    if (key > krc) ++noncanon;
-    if (t.shard_n > 1 && mfx_owner(t, key < krc ? key : krc, key < krc ? krc : key, t.shard_n) != t.shard_rank)
-      continue;                                              // another rank owns this k-mer
-    mfx_slot *sl = mfx_claim(t, key, meta, fresh);
-    if (sl) atomicAdd(side ? &sl->asmV : &sl->readV, v);
+  for (uint64_t base = blockIdx.x * (uint64_t)blockDim.x; base < n; base += stride) {     // wave-uniform trip count
+    const uint64_t i = base + threadIdx.x;
+    uint64_t key = 0;
+    uint32_t v = 0;
+    if (i < n) { key = kmers[i]; v = values[i]; }
+    bool ok = v != 0;
+    if (ok) {
+      const uint64_t krc = mfx_revcomp(key, t.k);
+      if (key > krc) ++noncanon;
+      if (t.shard_n > 1 && mfx_owner(t, key < krc ? key : krc, key < krc ? krc : key, t.shard_n) != t.shard_rank)
+        ok = false;                                          // another rank owns this k-mer
+    }
+    mfx_group_insert(t, key, ok, v, side, meta, fresh);
   }
   mfx_meta_flush(meta, fresh, noncanon);
 }
@@ -1141,13 +1261,14 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_count_kernel(mfx_count_args a) 
     mfx_tile_fill(L, a.bases + a.contig_off[c] + pos0);
     __syncthreads();
     for (uint32_t b = 0; b < MFX_TILE / MFX_BLOCK; ++b) {
-      uint32_t p = b * MFX_BLOCK + tid;
+      if (b * MFX_BLOCK >= n) break;                         // short last tile (block-uniform)
+      uint32_t p = b * MFX_BLOCK + tid;                      // lane-consecutive positions: a group's 8 keys are neighbours
       uint64_t f;
-      if (!(mfx_tile_kmer(L, k, p, f) && p < n)) continue;
-      uint64_t r = mfx_revcomp(f, k);
-      if (a.t.shard_n > 1 && mfx_owner(a.t, f < r ? f : r, f < r ? r : f, a.t.shard_n) != a.t.shard_rank) continue;
-      mfx_slot *sl = mfx_claim(a.t, f < r ? f : r, a.meta, fresh);
-      if (sl) atomicAdd(&sl->asmV, 1u);
+      bool ok = mfx_tile_kmer(L, k, p, f) && p < n;
+      const uint64_t r = mfx_revcomp(f, k);
+      const uint64_t key = f < r ? f : r;
+      if (ok && a.t.shard_n > 1 && mfx_owner(a.t, key, f < r ? r : f, a.t.shard_n) != a.t.shard_rank) ok = false;
+      mfx_group_insert(a.t, key, ok, 1u, 1, a.meta, fresh);
     }
   }
   mfx_meta_flush(a.meta, fresh, 0u);

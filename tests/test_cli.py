@@ -262,7 +262,7 @@ def test_cli_hist_on_several_devices_of_one_process(tmp_path, golden_dir, device
     histogram file and summary byte-identical to the committed golden fixture (= the single-device output)."""
     g = lambda n: os.path.join(golden_dir, n)
     args = ["-hist", "-sequence", g("case1.fasta"), "-readmers", g("case1.read.kmers.txt"), "-peak", "17.3",
-            "-output", str(tmp_path / "m.hist"), "-devices", devices]
+            "-prob", g("example_lookup_table.txt"), "-output", str(tmp_path / "m.hist"), "-devices", devices]
     r = run(args)
     assert r.returncode == 0, r.stderr
     assert "-- Evaluating on %d devices." % (2 if devices == "0,0" else 3) in r.stderr

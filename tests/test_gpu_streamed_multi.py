@@ -169,6 +169,7 @@ def test_rccl_communicator_world_of_one():
     seqs = m.Sequences(contigs)
     ev = m.Evaluator(ix, m.KParams(peak))
     comm = m.Comm(m.Comm.unique_id(), 0, 1, device=0)
+    comm.barrier()
     counts = torch.zeros(m.hist_words(ev.nbins, seqs.ncontigs), dtype=torch.int64, device="cuda")
     kover = torch.zeros(1, dtype=torch.float64, device="cuda")
     s = torch.cuda.current_stream().cuda_stream
