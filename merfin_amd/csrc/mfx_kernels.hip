@@ -204,120 +204,126 @@ __device__ __forceinline__ void mfx_meta_flush(uint64_t *meta, uint32_t fresh, u
 
 // ---------------------------------------------------------------------------
 // Wave-cooperative insert (index build, assembly k-mer counting): the mirror image of the cooperative lookup.
-// Each lane brings one key; the 8 lanes of a lane-group serve their 8 keys one after the other ("owner" S = 0..7),
-// and for the key being served they read the 8 slots of its candidate line with ONE coalesced 128-byte request
-// (lane `sub` reads slot `sub`), so that
-//   - "is the key there" and "where is the first empty slot" are two ballots, and
-//   - exactly one lane per key issues the claiming compare-and-swap and the count update,
-// instead of every lane walking up to 8 slots of its own line with dependent atomic loads (which is the divergent
-// access pattern the lookup path was built to avoid: ~10 G inserts/s).  All eight first-candidate lines of a group
-// are requested back to back before the first is looked at.
-// Slots of a line fill in order: the claim goes to the LOWEST empty slot, and a lost race re-reads the line, so a
-// slot can only be taken when every lower slot was seen occupied -- lookups rely on "the line has room <=> its last
-// slot is empty".  Keys are read with agent-scope atomic loads (a plain load could be served from this CU's L1,
-// which other CUs' claims never refresh: a lost race would then spin on the stale line).
+// Each lane brings one key; the 8 lanes of a lane-group serve their group's 8 keys ("rounds" S = 0..7), and for
+// the key of a round they read the 8 slots of its candidate line with ONE coalesced 128-byte request (lane `sub`
+// reads slot `sub`), so that "is the key there" and "where is the first empty slot" are two ballots and exactly
+// one lane per key issues the claiming compare-and-swap and the count update -- instead of every lane walking up
+// to 8 slots of its own line with dependent atomic loads (the divergent access pattern the lookup path avoids).
+//
+// Nothing waits per key: a pass first DECIDES every pending round (match -> add, fire and forget; empty slot -> the
+// CAS is issued; line full -> next candidate line), then collects all CAS results at once, then re-reads the lines
+// of the rounds still pending, all requests of a phase in flight together.  Rounds of a group that target the SAME
+// line (consecutive k-mers share their minimizer's line) are serialised: only the first pending one acts in a
+// pass, the others see the line as it is afterwards.  Random keys finish in one pass (load, CAS: two round trips
+// for 64 keys per wave); chains of neighbours take one more pass per link.
+//
+// Slots of a line fill in order: the claim goes to the LOWEST empty slot of a freshly read line, and a lost race
+// re-reads the line.  A slot never changes once written, so when slot j is claimed for a key, every slot below j was
+// SEEN occupied by another key -- the key cannot be in the line twice, and lookups may rely on "the line has room
+// <=> its last slot is empty".  Keys are read with agent-scope atomic loads: a plain load could be served from
+// this CU's L1, which other CUs' claims never refresh (a lost race would then spin on the stale line).
 // ---------------------------------------------------------------------------
 template <int S>
 __device__ __forceinline__ uint32_t mfx_group_bcast(uint32_t v);          // defined with the lookup path below
 
-__device__ __forceinline__ unsigned long long mfx_slot_key_load(const mfx_table_view &t, uint64_t line, uint32_t sub) {
-  return __hip_atomic_load(reinterpret_cast<unsigned long long *>(&t.slots[line * MFX_SLOTS_LINE + sub].key), __ATOMIC_RELAXED,
+__device__ __forceinline__ unsigned long long mfx_slot_key_load(const mfx_table_view &t, uint32_t line, uint32_t sub) {
+  return __hip_atomic_load(reinterpret_cast<unsigned long long *>(&t.slots[(uint64_t)line * MFX_SLOTS_LINE + sub].key), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
 }
 
-struct mfx_ins_round {          // what the 8 lanes of a group know about the key they are serving (group-uniform)
-  uint32_t klo, khi, lineA, lineB, val, ok;
+struct mfx_ins_rounds {         // what the 8 lanes of a group know about their group's 8 keys (group-uniform values)
+  uint32_t klo[8], khi[8], lineA[8], lineB[8], val[8];      // val == 0: no key in this round
+  uint32_t line[8], d[8];                                    // current candidate line and its number in the probe sequence
 };
 
 template <int S>
-__device__ __forceinline__ void mfx_ins_announce(mfx_ins_round (&R)[8], uint64_t key, const mfx_probe &pr, uint32_t v, bool ok) {
-  R[S].klo = mfx_group_bcast<S>((uint32_t)key);
-  R[S].khi = mfx_group_bcast<S>((uint32_t)(key >> 32));
-  R[S].lineA = mfx_group_bcast<S>(pr.lineA);
-  R[S].lineB = mfx_group_bcast<S>(pr.lineB);
-  R[S].val = mfx_group_bcast<S>(v);
-  R[S].ok = mfx_group_bcast<S>(ok ? 1u : 0u);
+__device__ __forceinline__ void mfx_ins_announce(mfx_ins_rounds &R, uint64_t key, const mfx_probe &pr, uint32_t v) {
+  R.klo[S] = mfx_group_bcast<S>((uint32_t)key);
+  R.khi[S] = mfx_group_bcast<S>((uint32_t)(key >> 32));
+  R.lineA[S] = mfx_group_bcast<S>(pr.lineA);
+  R.lineB[S] = mfx_group_bcast<S>(pr.lineB);
+  R.val[S] = mfx_group_bcast<S>(v);
 }
 
-// serves owner S's key; cur = this lane's slot of the key's first candidate line as loaded in the issue phase.
-// Returns the (line, slot) a NEW key was written to (slot 8 = none): later rounds of the group that pre-loaded
-// the same line patch their copy instead of losing a guaranteed race against their own group.
-template <int S>
-__device__ __forceinline__ uint32_t mfx_ins_serve(const mfx_table_view &t, const mfx_ins_round (&R)[8], unsigned long long cur, int side,
-                                                  uint64_t *meta, uint32_t &fresh, uint64_t &claimed_line) {
-  const uint32_t lane = threadIdx.x & 63u, sub = lane & 7u, gsh = lane & ~7u;
-  const unsigned long long key = (unsigned long long)R[S].klo | ((unsigned long long)R[S].khi << 32);
-  mfx_probe pr;
-  pr.lineA = R[S].lineA; pr.lineB = R[S].lineB;
-  uint32_t d = 0, claimed_slot = 8u;
-  uint64_t line = mfx_probe_line(t, pr, 0);
-  bool pend = R[S].ok != 0u;                               // group-uniform: the loop below diverges between groups only
-  while (pend) {
-    const uint32_t m_match = (uint32_t)(__ballot(cur == key) >> gsh) & 0xffu;
-    const uint32_t m_empty = (uint32_t)(__ballot(cur == MFX_EMPTY) >> gsh) & 0xffu;
-    mfx_slot *sl = t.slots + line * MFX_SLOTS_LINE + sub;
-    if (m_match) {
-      if (sub == (uint32_t)__ffs((int)m_match) - 1u) atomicAdd(side ? &sl->asmV : &sl->readV, R[S].val);
-      pend = false;
-    } else if (m_empty) {
-      const uint32_t f = (uint32_t)__ffs((int)m_empty) - 1u;          // lowest empty slot: slots fill in order
-      unsigned long long old = ~0ull - 1ull;
-      if (sub == f) old = atomicCAS(reinterpret_cast<unsigned long long *>(&sl->key), (unsigned long long)MFX_EMPTY, key);
-      const bool won = sub == f && (old == MFX_EMPTY || old == key);    // old == key: another group inserted the same k-mer first
-      if ((uint32_t)(__ballot(won) >> gsh) & 0xffu) {
-        if (won) {
-          atomicAdd(side ? &sl->asmV : &sl->readV, R[S].val);
-          if (old == MFX_EMPTY) ++fresh;
-        }
-        if ((uint32_t)(__ballot(won && old == MFX_EMPTY) >> gsh) & 0xffu) { claimed_slot = f; claimed_line = line; }
-        pend = false;
-      } else {
-        cur = mfx_slot_key_load(t, line, sub);              // lost the slot to another key: look at the line again
-      }
-    } else if (++d >= MFX_MAX_LINES) {
-      if (sub == 0) atomicAdd((unsigned long long *)&meta[2], 1ull);   // probe limit: reported as MFX_E_FULL by the host
-      pend = false;
-    } else {
-      line = mfx_probe_line(t, pr, d);                      // candidate line full without the key: next one
-      cur = mfx_slot_key_load(t, line, sub);
-    }
-  }
-  return claimed_slot;
-}
-
-// one key per lane (ok = false: none); adds v to the key's read (side 0) or assembly (side 1) count
-__device__ __forceinline__ void mfx_group_insert(const mfx_table_view &t, uint64_t key, bool ok, uint32_t v, int side, uint64_t *meta,
+// one key per lane (v == 0: none); adds v to the key's read (side 0) or assembly (side 1) count
+__device__ __forceinline__ void mfx_group_insert(const mfx_table_view &t, uint64_t key, uint32_t v, int side, uint64_t *meta,
                                                  uint32_t &fresh) {
-  const uint32_t sub = threadIdx.x & 7u;
+  const uint32_t lane = threadIdx.x & 63u, sub = lane & 7u, gsh = lane & ~7u;
   mfx_probe pr;
   pr.lineA = pr.lineB = 0u;
-  if (ok) pr = mfx_home(t, key);
-  mfx_ins_round R[8];
-  mfx_ins_announce<0>(R, key, pr, v, ok); mfx_ins_announce<1>(R, key, pr, v, ok); mfx_ins_announce<2>(R, key, pr, v, ok);
-  mfx_ins_announce<3>(R, key, pr, v, ok); mfx_ins_announce<4>(R, key, pr, v, ok); mfx_ins_announce<5>(R, key, pr, v, ok);
-  mfx_ins_announce<6>(R, key, pr, v, ok); mfx_ins_announce<7>(R, key, pr, v, ok);
+  if (v) pr = mfx_home(t, key);
+  mfx_ins_rounds R;
+  mfx_ins_announce<0>(R, key, pr, v); mfx_ins_announce<1>(R, key, pr, v); mfx_ins_announce<2>(R, key, pr, v);
+  mfx_ins_announce<3>(R, key, pr, v); mfx_ins_announce<4>(R, key, pr, v); mfx_ins_announce<5>(R, key, pr, v);
+  mfx_ins_announce<6>(R, key, pr, v); mfx_ins_announce<7>(R, key, pr, v);
   unsigned long long cur[8];
-  uint64_t line0[8];
+  uint32_t pending = 0u;                                     // bit S: round S still has to place its key (group-uniform)
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
     mfx_probe p2;
-    p2.lineA = R[s].lineA; p2.lineB = R[s].lineB;
-    line0[s] = mfx_probe_line(t, p2, 0);
-    cur[s] = mfx_slot_key_load(t, line0[s], sub);           // eight independent requests in flight
+    p2.lineA = R.lineA[s]; p2.lineB = R.lineB[s];
+    R.d[s] = 0u;
+    R.line[s] = (uint32_t)mfx_probe_line(t, p2, 0);
+    if (R.val[s]) pending |= 1u << s;
+    cur[s] = mfx_slot_key_load(t, R.line[s], sub);          // eight independent requests in flight
   }
-#define MFX_INS_ROUND(S_)                                                                                   \
-  {                                                                                                         \
-    uint64_t cl = ~0ull;                                                                                    \
-    const uint32_t cs = mfx_ins_serve<S_>(t, R, cur[S_], side, meta, fresh, cl);                            \
-    if (cs < 8u) {                                                                                          \
-      const unsigned long long nk = (unsigned long long)R[S_].klo | ((unsigned long long)R[S_].khi << 32);  \
-      _Pragma("unroll") for (int s2 = S_ + 1; s2 < 8; ++s2)                                                 \
-        if (line0[s2] == cl && sub == cs) cur[s2] = nk;   /* consecutive k-mers share their minimizer's line */ \
-    }                                                                                                       \
+  while (pending) {                                          // diverges between the groups of a wave only
+    const uint32_t at_start = pending;
+    uint32_t issued = 0u;
+    unsigned long long old[8];
+    // ---- decide: every pending round that is the first pending one on its line
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      old[s] = 0ull;
+      if (!((at_start >> s) & 1u)) continue;
+      bool blocked = false;
+#pragma unroll
+      for (int s2 = 0; s2 < s; ++s2) blocked = blocked || (((at_start >> s2) & 1u) && R.line[s2] == R.line[s]);
+      if (blocked) continue;                                 // an earlier round of the group works on this line: next pass
+      const unsigned long long k64 = (unsigned long long)R.klo[s] | ((unsigned long long)R.khi[s] << 32);
+      const uint32_t m_match = (uint32_t)(__ballot(cur[s] == k64) >> gsh) & 0xffu;
+      const uint32_t m_empty = (uint32_t)(__ballot(cur[s] == MFX_EMPTY) >> gsh) & 0xffu;
+      mfx_slot *sl = t.slots + (uint64_t)R.line[s] * MFX_SLOTS_LINE + sub;
+      if (m_match) {
+        if (sub == (uint32_t)__ffs((int)m_match) - 1u) atomicAdd(side ? &sl->asmV : &sl->readV, R.val[s]);
+        pending &= ~(1u << s);
+      } else if (m_empty) {
+        if (sub == (uint32_t)__ffs((int)m_empty) - 1u)       // lowest empty slot
+          old[s] = atomicCAS(reinterpret_cast<unsigned long long *>(&sl->key), (unsigned long long)MFX_EMPTY, k64);
+        issued |= 1u << s;
+      } else if (++R.d[s] >= MFX_MAX_LINES) {
+        if (sub == 0) atomicAdd((unsigned long long *)&meta[2], 1ull);   // probe limit: reported as MFX_E_FULL by the host
+        pending &= ~(1u << s);
+      } else {
+        mfx_probe p2;
+        p2.lineA = R.lineA[s]; p2.lineB = R.lineB[s];
+        R.line[s] = (uint32_t)mfx_probe_line(t, p2, R.d[s]);  // candidate line full without the key: the next one (read below)
+      }
+    }
+    // ---- collect the compare-and-swap results
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      if (!((issued >> s) & 1u)) continue;
+      const unsigned long long k64 = (unsigned long long)R.klo[s] | ((unsigned long long)R.khi[s] << 32);
+      // the issuing lane = the lowest empty slot of the view the round decided on (cur[s] is unchanged since)
+      const uint32_t m_empty = (uint32_t)(__ballot(cur[s] == MFX_EMPTY) >> gsh) & 0xffu;
+      const bool me = sub == (uint32_t)__ffs((int)m_empty) - 1u;
+      const unsigned long long was = old[s];
+      const bool won = me && (was == MFX_EMPTY || was == k64);   // was == key: another group inserted the same k-mer first
+      if ((uint32_t)(__ballot(won) >> gsh) & 0xffu) {
+        if (won) {
+          mfx_slot *sl = t.slots + (uint64_t)R.line[s] * MFX_SLOTS_LINE + sub;
+          atomicAdd(side ? &sl->asmV : &sl->readV, R.val[s]);
+          if (was == MFX_EMPTY) ++fresh;
+        }
+        pending &= ~(1u << s);
+      }
+    }
+    // ---- the rounds still pending look at their line as it is now
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+      if ((pending >> s) & 1u) cur[s] = mfx_slot_key_load(t, R.line[s], sub);
   }
-  MFX_INS_ROUND(0) MFX_INS_ROUND(1) MFX_INS_ROUND(2) MFX_INS_ROUND(3)
-  MFX_INS_ROUND(4) MFX_INS_ROUND(5) MFX_INS_ROUND(6) MFX_INS_ROUND(7)
-#undef MFX_INS_ROUND
 }
 
 __global__ void mfx_table_init_kernel(mfx_slot *slots, uint64_t nslots) {
@@ -329,6 +335,12 @@ __global__ void mfx_table_init_kernel(mfx_slot *slots, uint64_t nslots) {
 }
 
 // side 0: read counts, side 1: asm counts
+// MODE 1 (default): cooperative batched passes (mfx_group_insert); MODE 0: per-lane walk (mfx_claim).  Measured on
+// MI355X (profiles/r02_insert_modes.txt): both -- and a third variant, cooperative read + per-lane CAS -- land within
+// 10 % of each other (2^28 random keys: 11.9-12.6 G fresh inserts/s, 17-18.4 G/s when every key is already present):
+// an insert is bound by what it does to the memory system (the line is read, modified by one or two L2 atomics and
+// written back: 268 B of HBM traffic per key), not by how the lanes find the slot.
+template <int MODE>
 __global__ __launch_bounds__(256) void mfx_table_add_kernel(mfx_table_view t, const uint64_t *kmers, const uint32_t *values, uint64_t n,
                                                             int side, uint64_t *meta) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -345,7 +357,11 @@ __global__ __launch_bounds__(256) void mfx_table_add_kernel(mfx_table_view t, co
       if (t.shard_n > 1 && mfx_owner(t, key < krc ? key : krc, key < krc ? krc : key, t.shard_n) != t.shard_rank)
         ok = false;                                          // another rank owns this k-mer
     }
-    mfx_group_insert(t, key, ok, v, side, meta, fresh);
+    if (MODE == 1) mfx_group_insert(t, key, ok ? v : 0u, side, meta, fresh);
+    else if (ok) {
+      mfx_slot *sl = mfx_claim(t, key, meta, fresh);
+      if (sl) atomicAdd(side ? &sl->asmV : &sl->readV, v);
+    }
   }
   mfx_meta_flush(meta, fresh, noncanon);
 }
@@ -1241,6 +1257,11 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_dump_kernel(mfx_dump_args a) {
 // every tile are inserted with asmV += 1.
 // ===========================================================================
 
+// MODE 0 (default): per-lane walk; MODE 1: cooperative batched passes.  Consecutive k-mers share their minimizer's
+// line, so neighbouring lanes contend for the same slots: the per-lane walk simply retries on its own, while the
+// cooperative passes serialise a group's same-line keys (1 Gb: 27.6 vs 14.0 G k-mers/s when the k-mers are already
+// in the table -- the real case, the read database holds most assembly k-mers -- and 10.7 vs 9.0 into an empty one).
+template <int MODE>
 __global__ __launch_bounds__(MFX_BLOCK) void mfx_count_kernel(mfx_count_args a) {
   __shared__ mfx_tile_lds L;
   const uint32_t tid = threadIdx.x;
@@ -1268,7 +1289,11 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_count_kernel(mfx_count_args a) 
       const uint64_t r = mfx_revcomp(f, k);
       const uint64_t key = f < r ? f : r;
       if (ok && a.t.shard_n > 1 && mfx_owner(a.t, key, f < r ? r : f, a.t.shard_n) != a.t.shard_rank) ok = false;
-      mfx_group_insert(a.t, key, ok, 1u, 1, a.meta, fresh);
+      if (MODE == 1) mfx_group_insert(a.t, key, ok ? 1u : 0u, 1, a.meta, fresh);
+      else if (ok) {
+        mfx_slot *sl = mfx_claim(a.t, key, a.meta, fresh);
+        if (sl) atomicAdd(&sl->asmV, 1u);
+      }
     }
   }
   mfx_meta_flush(a.meta, fresh, 0u);
@@ -1322,7 +1347,9 @@ hipError_t mfx_k_table_add(mfx_table_view t, const uint64_t *kmers, const uint32
   if (n == 0) return hipSuccess;
   uint64_t blocks = (n + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  mfx_table_add_kernel<<<(unsigned)blocks, 256, 0, st>>>(t, kmers, values, n, side, meta);
+  static const int mode = getenv("MFX_INSERT_MODE") ? atoi(getenv("MFX_INSERT_MODE")) : 1;
+  if (mode == 0)      mfx_table_add_kernel<0><<<(unsigned)blocks, 256, 0, st>>>(t, kmers, values, n, side, meta);
+  else                mfx_table_add_kernel<1><<<(unsigned)blocks, 256, 0, st>>>(t, kmers, values, n, side, meta);
   return hipGetLastError();
 }
 hipError_t mfx_k_table_value(mfx_table_view t, const uint64_t *kmers, uint64_t n, uint32_t *readV, uint32_t *asmV,
@@ -1410,7 +1437,9 @@ hipError_t mfx_k_dump(const mfx_dump_args &a, hipStream_t st) {
 hipError_t mfx_k_count(const mfx_count_args &a, hipStream_t st) {
   if (a.ntiles == 0) return hipSuccess;
   uint64_t blocks = a.ntiles < 8192 ? a.ntiles : 8192;
-  mfx_count_kernel<<<(unsigned)blocks, MFX_BLOCK, 0, st>>>(a);
+  static const int mode = getenv("MFX_COUNT_MODE") ? atoi(getenv("MFX_COUNT_MODE")) : 0;
+  if (mode == 1)      mfx_count_kernel<1><<<(unsigned)blocks, MFX_BLOCK, 0, st>>>(a);
+  else                mfx_count_kernel<0><<<(unsigned)blocks, MFX_BLOCK, 0, st>>>(a);
   return hipGetLastError();
 }
 hipError_t mfx_k_completeness(mfx_table_view t, double peak, uint32_t n_prob, const uint32_t *probK, const double *probP,
