@@ -23,7 +23,12 @@
  *     once.  `stream` arguments are hipStream_t passed as void* (NULL = the
  *     device's default stream).
  *   - k-mers are 2k-bit integers, A=0 C=1 T=2 G=3, first base most significant
- *     (meryl's kmerTiny encoding), 1 <= k <= 31.
+ *     (meryl's kmerTiny encoding), 1 <= k <= 64 as in the reference (its kmer type holds
+ *     2k <= 128 bits).  For k <= 31 a k-mer is ONE uint64_t in every array of this ABI; for
+ *     32 <= k <= 64 it is TWO consecutive uint64_t words {low 64 bits, high bits}, so a
+ *     `const uint64_t *kmers` argument then points to 2*n words.  The k <= 31 path is the tuned
+ *     one (BASELINE's configurations use k = 21 and 31); 32 <= k <= 64 runs the plain per-lane
+ *     kernels of csrc/mfx_wide.hip and does not support a sharded index.
  */
 #ifndef MERFIN_AMD_H
 #define MERFIN_AMD_H

@@ -385,7 +385,18 @@ class Index:
         return {"k": i.k, "canonical": bool(i.canonical), "capacity": i.capacity, "distinct": i.distinct, "bytes": i.bytes}
 
     def export(self):
+        """every stored (k-mer, readV, asmV), sorted by k-mer.  k > 31: k-mers are rows [low 64 bits, high bits]"""
         n = self.info()["distinct"]
+        if self.k > 31:
+            k = np.zeros((max(n, 1), 2), dtype=np.uint64)
+            r = np.zeros(max(n, 1), dtype=np.uint32)
+            a = np.zeros(max(n, 1), dtype=np.uint32)
+            cnt = C.c_uint64(0)
+            _check(load_library().mfx_index_export(self.h, k.ctypes.data_as(C.POINTER(C.c_uint64)), r.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                   a.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(cnt)))
+            k, r, a = k[:cnt.value], r[:cnt.value], a[:cnt.value]
+            o = np.lexsort((k[:, 0], k[:, 1]))
+            return k[o], r[o], a[o]
         k = np.zeros(max(n, 1), dtype=np.uint64)
         r = np.zeros(max(n, 1), dtype=np.uint32)
         a = np.zeros(max(n, 1), dtype=np.uint32)

@@ -86,31 +86,31 @@ bool load_factor_fixed(double *lf) {
   return true;
 }
 
-uint64_t lines_at(uint64_t capacity_kmers, double lf) {
+uint64_t lines_at(uint64_t capacity_kmers, double lf, uint32_t slots_line) {
   double slots = (double)capacity_kmers / lf;
-  uint64_t nlines = (uint64_t)ceil(slots / MFX_SLOTS_LINE);
+  uint64_t nlines = (uint64_t)ceil(slots / slots_line);
   if (nlines < 1024) nlines = 1024;      // probe sequences may span 512 lines
   return nlines;
 }
 
 // smallest table this build makes for `capacity_kmers`
-uint64_t lines_for(uint64_t capacity_kmers) {
+uint64_t lines_for(uint64_t capacity_kmers, uint32_t slots_line = MFX_SLOTS_LINE) {
   double lf = MFX_LF_MAX;
   (void)load_factor_fixed(&lf);
-  return lines_at(capacity_kmers, lf);
+  return lines_at(capacity_kmers, lf, slots_line);
 }
 
 // the table actually allocated: budget_bytes = what the table may take (0: unknown, use the smallest)
-uint64_t lines_auto(uint64_t capacity_kmers, double budget_bytes) {
+uint64_t lines_auto(uint64_t capacity_kmers, double budget_bytes, uint32_t slots_line) {
   double lf;
-  if (load_factor_fixed(&lf)) return lines_at(capacity_kmers, lf);
+  if (load_factor_fixed(&lf)) return lines_at(capacity_kmers, lf, slots_line);
   lf = MFX_LF_MAX;
   if (budget_bytes > 0) {
-    lf = (double)capacity_kmers * sizeof(mfx_slot) / budget_bytes;
+    lf = (double)capacity_kmers * (MFX_ALIGN / slots_line) / budget_bytes;
     lf = std::min(MFX_LF_MAX, std::max(MFX_LF_MIN, lf));
   }
-  uint64_t nl = lines_at(capacity_kmers, lf);
-  if (nl >= (1ull << 32)) nl = std::max<uint64_t>(lines_at(capacity_kmers, MFX_LF_MAX), (1ull << 32) - 16);
+  uint64_t nl = lines_at(capacity_kmers, lf, slots_line);
+  if (nl >= (1ull << 32)) nl = std::max<uint64_t>(lines_at(capacity_kmers, MFX_LF_MAX, slots_line), (1ull << 32) - 16);
   return nl;
 }
 }  // namespace
@@ -142,24 +142,25 @@ mfx_table_view mfx_index::view() const {
   v.mz_w = mz_w;
   v.shard_rank = shard_rank;
   v.shard_n = shard_n;
+  v.wide = wide() ? 1 : 0;
   return v;
 }
 
 extern "C" double mfx_index_estimate_gb(int k, uint64_t capacity_kmers) {
-  (void)k;
-  return (double)lines_for(capacity_kmers) * MFX_ALIGN / 1e9;
+  return (double)lines_for(capacity_kmers, k > MFX_MAX_K_NARROW ? MFX_WSLOTS_LINE : MFX_SLOTS_LINE) * MFX_ALIGN / 1e9;
 }
 
 extern "C" mfx_index *mfx_index_create(int k, uint64_t capacity_kmers, double max_gb, int device) {
-  if (k < 1 || k > 31) {
-    mfx_fail(MFX_E_INVAL, "k=%d unsupported: this build handles 1 <= k <= 31 (64-bit k-mers)", k);
+  if (k < 1 || k > MFX_MAX_K) {
+    mfx_fail(MFX_E_INVAL, "k=%d unsupported: k-mers hold 2k <= 128 bits, 1 <= k <= 64", k);
     return nullptr;
   }
+  const uint32_t slots_line = k > MFX_MAX_K_NARROW ? MFX_WSLOTS_LINE : MFX_SLOTS_LINE;
   if (mfx_device_count() <= device || device < 0) {
     mfx_fail(MFX_E_NODEVICE, "HIP device %d not available (%d visible); merfin_amd has no CPU path", device, mfx_device_count());
     return nullptr;
   }
-  if (lines_for(capacity_kmers) >= 0xfffffff0ull) {
+  if (lines_for(capacity_kmers, slots_line) >= 0xfffffff0ull) {
     mfx_fail(MFX_E_INVAL, "capacity of %lu k-mers needs more than 2^32 table lines (512 GB); shard the index instead",
              (unsigned long)capacity_kmers);
     return nullptr;
@@ -181,7 +182,7 @@ extern "C" mfx_index *mfx_index_create(int k, uint64_t capacity_kmers, double ma
     double budget = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = MFX_LF_HBM_SHARE * (double)free_b;
     if (max_gb > 0) budget = budget > 0 ? std::min(budget, max_gb * 1e9) : max_gb * 1e9;
-    ix->nlines = lines_auto(capacity_kmers, budget);
+    ix->nlines = lines_auto(capacity_kmers, budget, slots_line);
   }
   if (ix->nlines >= (1ull << 32)) {        // line numbers are 32-bit on the device (550 GB of table: beyond one GPU anyway)
     mfx_fail(MFX_E_NOMEM, "Not enough memory to load databases.  %lu k-mers need %.0f GB on one GPU; shard the index (mfx_index_set_shard).",
@@ -198,13 +199,13 @@ extern "C" mfx_index *mfx_index_create(int k, uint64_t capacity_kmers, double ma
     const char *ws = getenv("MFX_MZ_W");
     int w = ws ? atoi(ws) : MFX_MZ_W_DEFAULT;
     if (w < 1 || w > 5) w = MFX_MZ_W_DEFAULT;
-    ix->mz_w = mz ? std::min(w, k) : 0;
+    ix->mz_w = (mz && !ix->wide()) ? std::min(w, k) : 0;    // 128-bit k-mers: plain hashing (mfx_wide.hip)
   }
   hipError_t e = hipMalloc((void **)&ix->d_slots, ix->nlines * MFX_ALIGN);
-  if (e != hipSuccess && ix->nlines > lines_for(capacity_kmers)) {
+  if (e != hipSuccess && ix->nlines > lines_for(capacity_kmers, slots_line)) {
     // the roomier table did not fit after all (fragmentation, another process): fall back to the smallest one
     (void)hipGetLastError();
-    ix->nlines = lines_for(capacity_kmers);
+    ix->nlines = lines_for(capacity_kmers, slots_line);
     e = hipMalloc((void **)&ix->d_slots, ix->nlines * MFX_ALIGN);
   }
   if (e != hipSuccess) {
@@ -214,7 +215,8 @@ extern "C" mfx_index *mfx_index_create(int k, uint64_t capacity_kmers, double ma
   }
   if (hipMalloc((void **)&ix->d_meta, 4 * sizeof(uint64_t)) != hipSuccess ||
       hipMemset(ix->d_meta, 0, 4 * sizeof(uint64_t)) != hipSuccess ||
-      mfx_k_table_init(ix->d_slots, ix->nlines * MFX_SLOTS_LINE, nullptr) != hipSuccess ||
+      (ix->wide() ? hipMemsetAsync(ix->d_slots, 0, ix->nlines * MFX_ALIGN, nullptr)           // state 0 = empty
+                  : mfx_k_table_init(ix->d_slots, ix->nlines * MFX_SLOTS_LINE, nullptr)) != hipSuccess ||
       hipDeviceSynchronize() != hipSuccess) {
     mfx_fail(MFX_E_HIP, "k-mer table initialisation failed: %s", hipGetErrorString(hipGetLastError()));
     mfx_index_free(ix);
@@ -238,17 +240,21 @@ static int index_check(mfx_index *ix) {
   if (meta[2] != 0)
     return mfx_fail(MFX_E_FULL, "k-mer table full: %lu inserts hit the probe limit (capacity %lu k-mers, %lu stored)",
                     (unsigned long)meta[2], (unsigned long)ix->capacity_kmers, (unsigned long)meta[0]);
-  if ((double)meta[0] > 0.92 * (double)(ix->nlines * MFX_SLOTS_LINE))
+  if ((double)meta[0] > 0.92 * (double)(ix->nlines * ix->slots_per_line()))
     return mfx_fail(MFX_E_FULL, "k-mer table over-full: %lu k-mers in %lu slots; create the index with a larger capacity",
-                    (unsigned long)meta[0], (unsigned long)(ix->nlines * MFX_SLOTS_LINE));
+                    (unsigned long)meta[0], (unsigned long)(ix->nlines * ix->slots_per_line()));
   return MFX_OK;
 }
 
 static int index_add(mfx_index *ix, const uint64_t *kmers, const uint32_t *values, uint64_t n, int side, int on_device) {
   if (!ix || (n && (!kmers || !values))) return mfx_fail(MFX_E_INVAL, "mfx_index_add: null argument");
   DevGuard g(ix->device);
+  const size_t kw = ix->key_words();                      // uint64 words per k-mer (2 for k > 31)
+  auto table_add = [&](const uint64_t *dk, const uint32_t *dv, uint64_t m, hipStream_t s) {
+    return ix->wide() ? mfx_kw_table_add(ix->view(), dk, dv, m, side, ix->d_meta, s) : mfx_k_table_add(ix->view(), dk, dv, m, side, ix->d_meta, s);
+  };
   if (on_device) {
-    MFX_HIP(mfx_k_table_add(ix->view(), kmers, values, n, side, ix->d_meta, nullptr));
+    MFX_HIP(table_add(kmers, values, n, nullptr));
     MFX_HIP(hipDeviceSynchronize());
     return index_check(ix);
   }
@@ -275,9 +281,9 @@ static int index_add(mfx_index *ix, const uint64_t *kmers, const uint32_t *value
   };
   bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
   for (auto &l : L)
-    ok = ok && hipHostMalloc((void **)&l.hk, CH * 8, hipHostMallocDefault) == hipSuccess &&
+    ok = ok && hipHostMalloc((void **)&l.hk, CH * 8 * kw, hipHostMallocDefault) == hipSuccess &&
          hipHostMalloc((void **)&l.hv, CH * 4, hipHostMallocDefault) == hipSuccess &&
-         hipMalloc((void **)&l.dk, CH * 8) == hipSuccess && hipMalloc((void **)&l.dv, CH * 4) == hipSuccess &&
+         hipMalloc((void **)&l.dk, CH * 8 * kw) == hipSuccess && hipMalloc((void **)&l.dv, CH * 4) == hipSuccess &&
          hipEventCreateWithFlags(&l.done, hipEventDisableTiming) == hipSuccess;
   if (!ok) { cleanup(); return mfx_fail(MFX_E_NOMEM, "mfx_index_add: staging allocation failed"); }
   int cur = 0;
@@ -285,11 +291,11 @@ static int index_add(mfx_index *ix, const uint64_t *kmers, const uint32_t *value
     Lane &l = L[cur];
     const uint64_t m = std::min(CH, n - o);
     if (l.busy && hipEventSynchronize(l.done) != hipSuccess) { ok = false; break; }
-    par_memcpy((uint8_t *)l.hk, (const char *)(kmers + o), m * 8);
+    par_memcpy((uint8_t *)l.hk, (const char *)(kmers + o * kw), m * 8 * kw);
     par_memcpy((uint8_t *)l.hv, (const char *)(values + o), m * 4);
-    ok = hipMemcpyAsync(l.dk, l.hk, m * 8, hipMemcpyHostToDevice, st) == hipSuccess &&
+    ok = hipMemcpyAsync(l.dk, l.hk, m * 8 * kw, hipMemcpyHostToDevice, st) == hipSuccess &&
          hipMemcpyAsync(l.dv, l.hv, m * 4, hipMemcpyHostToDevice, st) == hipSuccess &&
-         mfx_k_table_add(ix->view(), l.dk, l.dv, m, side, ix->d_meta, st) == hipSuccess &&
+         table_add(l.dk, l.dv, m, st) == hipSuccess &&
          hipEventRecord(l.done, st) == hipSuccess;
     l.busy = true;
   }
@@ -327,7 +333,7 @@ extern "C" int mfx_index_count_asm(mfx_index *ix, const mfx_seq *seq, void *stre
   a.ncontigs = seq->ncontigs;
   a.ntiles = seq->ntiles;
   a.meta = ix->d_meta;
-  MFX_HIP(mfx_k_count(a, (hipStream_t)stream));
+  MFX_HIP(ix->wide() ? mfx_kw_count(a, (hipStream_t)stream) : mfx_k_count(a, (hipStream_t)stream));
   MFX_HIP(hipStreamSynchronize((hipStream_t)stream));
   return index_check(ix);
 }
@@ -337,11 +343,11 @@ extern "C" int mfx_index_value(const mfx_index *ix, const uint64_t *kmers, uint6
   DevGuard g(ix->device);
   DevBuf<uint64_t> dk;
   DevBuf<uint32_t> dr, da;
-  MFX_HIP(dk.alloc(n));
+  MFX_HIP(dk.alloc(n * ix->key_words()));
   MFX_HIP(dr.alloc(n));
   MFX_HIP(da.alloc(n));
-  MFX_HIP(hipMemcpy(dk.p, kmers, n * sizeof(uint64_t), hipMemcpyHostToDevice));
-  MFX_HIP(mfx_k_table_value(ix->view(), dk.p, n, dr.p, da.p, nullptr));
+  MFX_HIP(hipMemcpy(dk.p, kmers, n * ix->key_words() * sizeof(uint64_t), hipMemcpyHostToDevice));
+  MFX_HIP(ix->wide() ? mfx_kw_table_value(ix->view(), dk.p, n, dr.p, da.p, nullptr) : mfx_k_table_value(ix->view(), dk.p, n, dr.p, da.p, nullptr));
   MFX_HIP(hipMemcpy(readV, dr.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
   MFX_HIP(hipMemcpy(asmV, da.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
   return MFX_OK;
@@ -354,7 +360,7 @@ extern "C" int mfx_index_get_info(const mfx_index *ix, mfx_index_info *out) {
   MFX_HIP(hipMemcpy(meta, ix->d_meta, sizeof(meta), hipMemcpyDeviceToHost));
   out->k = ix->k;
   out->canonical = (meta[1] == 0) ? 1 : 0;
-  out->capacity = ix->nlines * MFX_SLOTS_LINE;
+  out->capacity = ix->nlines * ix->slots_per_line();
   out->distinct = meta[0];
   out->bytes = ix->nlines * MFX_ALIGN;
   return MFX_OK;
@@ -369,15 +375,15 @@ extern "C" int mfx_index_export(const mfx_index *ix, uint64_t *kmers, uint32_t *
   DevBuf<uint64_t> dk;
   DevBuf<uint32_t> dr, da;
   DevBuf<unsigned long long> dc;
-  MFX_HIP(dk.alloc(info.distinct));
+  MFX_HIP(dk.alloc(info.distinct * ix->key_words()));
   MFX_HIP(dr.alloc(info.distinct));
   MFX_HIP(da.alloc(info.distinct));
   MFX_HIP(dc.alloc(1));
   MFX_HIP(hipMemset(dc.p, 0, sizeof(unsigned long long)));
-  MFX_HIP(mfx_k_table_export(ix->view(), dk.p, dr.p, da.p, dc.p, nullptr));
+  MFX_HIP(ix->wide() ? mfx_kw_table_export(ix->view(), dk.p, dr.p, da.p, dc.p, nullptr) : mfx_k_table_export(ix->view(), dk.p, dr.p, da.p, dc.p, nullptr));
   unsigned long long cnt = 0;
   MFX_HIP(hipMemcpy(&cnt, dc.p, sizeof(cnt), hipMemcpyDeviceToHost));
-  MFX_HIP(hipMemcpy(kmers, dk.p, cnt * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  MFX_HIP(hipMemcpy(kmers, dk.p, cnt * ix->key_words() * sizeof(uint64_t), hipMemcpyDeviceToHost));
   MFX_HIP(hipMemcpy(readV, dr.p, cnt * sizeof(uint32_t), hipMemcpyDeviceToHost));
   MFX_HIP(hipMemcpy(asmV, da.p, cnt * sizeof(uint32_t), hipMemcpyDeviceToHost));
   *n_out = cnt;
@@ -707,7 +713,8 @@ static int hist_launch(mfx_eval *ev, const mfx_seq *seq, uint64_t tile_begin, ui
   a.ks.counts = d_counts;
   a.ks.partials = ev->d_partials;
   a.ks.ovf = ev->d_ovf;
-  MFX_HIP(mfx_k_hist(a, (int)std::min<uint64_t>((uint64_t)ev->grid, ntl), (hipStream_t)stream));
+  MFX_HIP(ev->ix->wide() ? mfx_kw_hist(a, (int)std::min<uint64_t>((uint64_t)ev->grid, ntl), (hipStream_t)stream)
+                          : mfx_k_hist(a, (int)std::min<uint64_t>((uint64_t)ev->grid, ntl), (hipStream_t)stream));
   if (chunk_of_total) MFX_HIP(hipMemsetAsync(ev->d_tile_ctr, 0, sizeof(uint64_t), (hipStream_t)stream));   // re-arm the tile scheduler
   else MFX_HIP(mfx_k_sum_tile_partials(ev->d_tile_partials, ntl, d_kover, ev->d_tile_ctr, (hipStream_t)stream));
   return MFX_OK;
@@ -1163,6 +1170,7 @@ extern "C" int mfx_hist_report(const mfx_hist_result *r, int k, const char *hist
 extern "C" int mfx_index_set_shard(mfx_index *ix, uint32_t rank, uint32_t nranks) {
   if (!ix || nranks == 0 || rank >= nranks || nranks > 254)
     return mfx_fail(MFX_E_INVAL, "mfx_index_set_shard: need rank < nranks <= 254");
+  if (ix->wide() && nranks > 1) return mfx_fail(MFX_E_INVAL, "a sharded index handles k <= 31; this index holds %d-mers", ix->k);
   DevGuard g(ix->device);
   uint64_t meta[4];
   MFX_HIP(hipMemcpy(meta, ix->d_meta, sizeof(meta), hipMemcpyDeviceToHost));
@@ -1190,6 +1198,10 @@ int mfx_sort_by_owner(void *tmp, size_t &tmp_bytes, const uint8_t *kin, uint8_t 
                       uint64_t n, hipStream_t st);   // mfx_sort.hip (hipcub stable radix sort)
 
 extern "C" mfx_router *mfx_router_create(const mfx_index *ix, uint32_t nranks, uint32_t max_tiles) {
+  if (ix && ix->wide()) {
+    mfx_fail(MFX_E_INVAL, "mfx_router_create: a sharded index handles k <= 31; this index holds %d-mers", ix->k);
+    return nullptr;
+  }
   if (!ix || nranks == 0 || nranks > 254 || max_tiles == 0 || (uint64_t)max_tiles * MFX_TILE >= (1ull << 31)) {
     mfx_fail(MFX_E_INVAL, "mfx_router_create: bad argument (nranks <= 254, max_tiles * %u < 2^31: the sort counts items in an int)", MFX_TILE);
     return nullptr;
@@ -1291,6 +1303,7 @@ extern "C" int mfx_route_tiles(mfx_router *r, const mfx_seq *seq, uint64_t tile_
 extern "C" int mfx_hist_keys_launch(mfx_eval *ev, const uint64_t *d_keys, const uint32_t *d_contigs, uint64_t n,
                                     uint32_t ncontigs, uint64_t *d_counts, double *d_kover, void *stream) {
   if (!ev || !d_counts || !d_kover || (n && (!d_keys || !d_contigs))) return mfx_fail(MFX_E_INVAL, "mfx_hist_keys_launch: null argument");
+  if (ev->ix->wide()) return mfx_fail(MFX_E_INVAL, "mfx_hist_keys_launch: a sharded index handles k <= 31");
   DevGuard g(ev->device);
   mfx_hist_keys_args a;
   a.t = ev->ix->view();
@@ -1350,7 +1363,7 @@ extern "C" int mfx_dump_values(mfx_eval *ev, const mfx_seq *seq, uint32_t contig
   a.probK = ev->d_probK;
   a.probP = ev->d_probP;
   a.stats = ds.p;
-  MFX_HIP(mfx_k_dump(a, nullptr));
+  MFX_HIP(ev->ix->wide() ? mfx_kw_dump(a, nullptr) : mfx_k_dump(a, nullptr));
   MFX_HIP(hipMemcpy(readV, dr.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
   MFX_HIP(hipMemcpy(asmV, da.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
   uint64_t st[2];
@@ -1467,7 +1480,8 @@ extern "C" int mfx_completeness_pieces(mfx_eval *ev, double *total64, double *un
   DevBuf<double> dp;
   MFX_HIP(dp.alloc(128));
   MFX_HIP(hipMemset(dp.p, 0, 128 * sizeof(double)));
-  MFX_HIP(mfx_k_completeness(ev->ix->view(), ev->peak, ev->n_prob, ev->d_probK, ev->d_probP, dp.p, ev->grid, nullptr));
+  MFX_HIP(ev->ix->wide() ? mfx_kw_completeness(ev->ix->view(), ev->peak, ev->n_prob, ev->d_probK, ev->d_probP, dp.p, ev->grid, nullptr)
+                          : mfx_k_completeness(ev->ix->view(), ev->peak, ev->n_prob, ev->d_probK, ev->d_probP, dp.p, ev->grid, nullptr));
   double h[128];
   MFX_HIP(hipMemcpy(h, dp.p, sizeof(h), hipMemcpyDeviceToHost));
   memcpy(total64, h, 64 * sizeof(double));

@@ -35,6 +35,8 @@
 
 namespace {
 
+typedef unsigned __int128 u128;
+
 
 bool is_dir(const std::string &p) {
   struct stat st;
@@ -280,8 +282,8 @@ int read_meryl_data(const std::string &path, uint32_t file, const MerylIndex &mi
     (void)br.get(64);                                        // k1 (unused)
     uint32_t ccode = (uint32_t)br.get(8);
     (void)br.get(64); (void)br.get(64);                      // c1, c2 (unused)
-    if (!br.ok || kcode != 1 || (ccode != 1 && ccode != 2) || ubits + bbits != mi.suffixSize || bbits > 64 ||
-        (prefix >> mi.numBlocksBits) != file || mi.suffixSize > 64) {
+    if (!br.ok || kcode != 1 || (ccode != 1 && ccode != 2) || ubits + bbits != mi.suffixSize || bbits > 128 ||
+        (prefix >> mi.numBlocksBits) != file || mi.suffixSize > 122) {
       rc = mfx_fail(MFX_E_FORMAT, "'%s': unsupported / inconsistent data block (kCode %u cCode %u unary %u binary %u suffix %u prefix %lx)",
                     path.c_str(), kcode, ccode, ubits, bbits, mi.suffixSize, (unsigned long)prefix);
       break;
@@ -299,23 +301,25 @@ int read_meryl_data(const std::string &path, uint32_t file, const MerylIndex &mi
     }
     sums->blocks++;
     if (count_only) { sums->kmers += nk; continue; }
-    std::vector<uint64_t> sfx(nk);
-    uint64_t hi = 0;
+    std::vector<u128> sfx(nk);
+    u128 hi = 0;
     for (uint64_t i = 0; i < nk; ++i) {
       hi += br.unary();
-      sfx[i] = (bbits == 64 ? 0 : (hi << bbits)) | br.get(bbits);
+      // the binary part is read in two pieces when it is wider than a word (k > 32 + prefix bits)
+      u128 bin = bbits > 64 ? (((u128)br.get(bbits - 64) << 64) | br.get(64)) : (u128)br.get(bbits);
+      sfx[i] = (bbits >= 128 ? (u128)0 : (hi << bbits)) | bin;
       if (i && sfx[i] <= sfx[i - 1]) { rc = mfx_fail(MFX_E_FORMAT, "'%s': suffixes not strictly increasing", path.c_str()); break; }
     }
     if (rc) break;
-    const uint64_t smask = mi.suffixSize >= 64 ? ~0ull : ((1ull << mi.suffixSize) - 1);
+    const u128 smask = ((u128)1 << mi.suffixSize) - 1;          // suffixSize <= 122
     if (nk && (sfx[nk - 1] & ~smask)) { rc = mfx_fail(MFX_E_FORMAT, "'%s': suffix wider than %u bits", path.c_str(), mi.suffixSize); break; }
     uint64_t uniq = 0, tot = 0;
     for (uint64_t i = 0; i < nk; ++i) {
       uint64_t v = br.get(ccode == 1 ? 32 : 64);
-      uint64_t km = (mi.suffixSize >= 64 ? 0 : (prefix << mi.suffixSize)) | sfx[i];
+      const u128 km = ((u128)prefix << mi.suffixSize) | sfx[i];
       uniq += (v == 1);
       tot += v;
-      emit(km, v > 0xffffffffull ? 0xffffffffu : (uint32_t)v);
+      emit((uint64_t)km, (uint64_t)(km >> 64), v > 0xffffffffull ? 0xffffffffu : (uint32_t)v);
     }
     if (!br.ok) { rc = mfx_fail(MFX_E_FORMAT, "'%s': data block shorter than its header claims", path.c_str()); break; }
     sums->kmers += nk;
@@ -374,20 +378,22 @@ struct Feeder {
   int side;
   uint64_t minV, maxV;
   std::mutex *mu = nullptr;            // several decoder threads feed one index: inserts are serialised
-  std::vector<uint64_t> k;
+  std::vector<uint64_t> k;             // 1 word per k-mer, 2 (low, high) when the index holds k > 31
   std::vector<uint32_t> v;
   int rc = MFX_OK;
   void flush() {
-    if (k.empty() || rc) return;
+    if (v.empty() || rc) return;
     std::unique_lock<std::mutex> lk;
     if (mu) lk = std::unique_lock<std::mutex>(*mu);
-    rc = side ? mfx_index_add_asm(ix, k.data(), v.data(), k.size(), 0)
-              : mfx_index_add_read(ix, k.data(), v.data(), k.size(), minV, maxV, 0);
+    rc = side ? mfx_index_add_asm(ix, k.data(), v.data(), v.size(), 0)
+              : mfx_index_add_read(ix, k.data(), v.data(), v.size(), minV, maxV, 0);
     k.clear(); v.clear();
   }
-  void push(uint64_t km, uint32_t val) {
-    k.push_back(km); v.push_back(val);
-    if (k.size() >= (1u << 24)) flush();
+  void push(uint64_t lo, uint64_t hi, uint32_t val) {
+    k.push_back(lo);
+    if (ix->wide()) k.push_back(hi);
+    v.push_back(val);
+    if (v.size() >= (1u << 24)) flush();
   }
 };
 
@@ -402,15 +408,15 @@ int scan_text(const std::string &path, int *k_out, F &&emit, uint64_t *count) {
   while (fgets(line, sizeof(line), f)) {
     ++ln;
     char *p = line;
-    uint64_t km = 0;
+    u128 km = 0;
     int n = 0;
-    while (base_code((unsigned char)*p) >= 0) { km = (km << 2) | (uint64_t)base_code((unsigned char)*p); ++p; ++n; }
+    while (base_code((unsigned char)*p) >= 0) { km = (km << 2) | (u128)base_code((unsigned char)*p); ++p; ++n; }
     if (n == 0 && (*p == '\n' || *p == 0)) continue;
-    if (n == 0 || n > 31 || (*p != '\t' && *p != ' ')) { rc = mfx_fail(MFX_E_FORMAT, "'%s' line %lu: expected '<kmer>\\t<count>'", path.c_str(), (unsigned long)ln); break; }
+    if (n == 0 || n > MFX_MAX_K || (*p != '\t' && *p != ' ')) { rc = mfx_fail(MFX_E_FORMAT, "'%s' line %lu: expected '<kmer>\\t<count>'", path.c_str(), (unsigned long)ln); break; }
     if (k == 0) k = n;
     if (n != k) { rc = mfx_fail(MFX_E_FORMAT, "'%s' line %lu: k-mer length %d differs from %d", path.c_str(), (unsigned long)ln, n, k); break; }
     unsigned long long v = strtoull(p, nullptr, 10);
-    emit(km, v > 0xffffffffull ? 0xffffffffu : (uint32_t)v);
+    emit((uint64_t)km, (uint64_t)(km >> 64), v > 0xffffffffull ? 0xffffffffu : (uint32_t)v);
     ++*count;
   }
   if (mfx_close(h, rc != MFX_OK) && rc == MFX_OK)
@@ -442,7 +448,7 @@ extern "C" int mfx_db_probe(const char *path, mfx_db_info *out) {
   if (fmt == MFX_DB_TEXT) {
     uint64_t n = 0;
     int k = 0;
-    int rc = scan_text(p, &k, [](uint64_t, uint32_t) {}, &n);
+    int rc = scan_text(p, &k, [](uint64_t, uint64_t, uint32_t) {}, &n);
     if (rc) return rc;
     if (k == 0) return mfx_fail(MFX_E_FORMAT, "'%s': no k-mers found", path);
     out->k = k;
@@ -456,7 +462,7 @@ extern "C" int mfx_db_probe(const char *path, mfx_db_info *out) {
   // distinct k-mer count: sum of the block headers (cheap pass over the 64 data files)
   std::vector<MerylFileSums> per(64);
   rc = for_each_meryl_file([&](uint32_t fl) {
-    return read_meryl_data(meryl_file_name(p, fl, ".merylData"), fl, mi, [](uint64_t, uint32_t) {}, &per[fl], true);
+    return read_meryl_data(meryl_file_name(p, fl, ".merylData"), fl, mi, [](uint64_t, uint64_t, uint32_t) {}, &per[fl], true);
   });
   uint64_t n = 0;
   for (const auto &x : per) n += x.kmers;
@@ -487,25 +493,26 @@ extern "C" int mfx_index_load_db(mfx_index *ix, const char *path, int side, uint
       return mfx_fail(MFX_E_FORMAT, "'%s': truncated header", path);
     }
     if ((int)h.k != ix->k) { close(fdn); return mfx_fail(MFX_E_INVAL, "'%s' holds %u-mers but the index is built for k=%d", path, h.k, ix->k); }
-    if ((uint64_t)st.st_size < sizeof(h) + h.n * 12) { close(fdn); return mfx_fail(MFX_E_FORMAT, "'%s': truncated payload", path); }
+    const uint64_t kw = ix->key_words();                     // k > 31: 16-byte k-mers {low, high}
+    if ((uint64_t)st.st_size < sizeof(h) + h.n * (8 * kw + 4)) { close(fdn); return mfx_fail(MFX_E_FORMAT, "'%s': truncated payload", path); }
     if (h.n) {
       void *map = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fdn, 0);
       if (map == MAP_FAILED) { close(fdn); return mfx_fail(MFX_E_IO, "cannot map '%s'", path); }
       (void)madvise(map, (size_t)st.st_size, MADV_SEQUENTIAL);
       const uint64_t *kb = reinterpret_cast<const uint64_t *>((const char *)map + sizeof(h));
-      const uint32_t *vb = reinterpret_cast<const uint32_t *>((const char *)map + sizeof(h) + h.n * 8);
+      const uint32_t *vb = reinterpret_cast<const uint32_t *>((const char *)map + sizeof(h) + h.n * 8 * kw);
       const uint64_t CH = 1u << 26;
       for (uint64_t o = 0; o < h.n && rc == MFX_OK; o += CH) {
         const uint64_t m = std::min<uint64_t>(CH, h.n - o);
-        rc = side ? mfx_index_add_asm(ix, kb + o, vb + o, m, 0)
-                  : mfx_index_add_read(ix, kb + o, vb + o, m, minV, maxV, 0);
+        rc = side ? mfx_index_add_asm(ix, kb + o * kw, vb + o, m, 0)
+                  : mfx_index_add_read(ix, kb + o * kw, vb + o, m, minV, maxV, 0);
       }
       munmap(map, (size_t)st.st_size);
     }
     close(fdn);
   } else if (fmt == MFX_DB_TEXT) {
     int k = 0;
-    rc = scan_text(p, &k, [&](uint64_t km, uint32_t v) { fd.push(km, v); }, &n);
+    rc = scan_text(p, &k, [&](uint64_t lo, uint64_t hi, uint32_t v) { fd.push(lo, hi, v); }, &n);
     if (rc == MFX_OK && k != ix->k) rc = mfx_fail(MFX_E_INVAL, "'%s' holds %d-mers but the index is built for k=%d", path, k, ix->k);
   } else {
     MerylIndex mi;
@@ -517,7 +524,7 @@ extern "C" int mfx_index_load_db(mfx_index *ix, const char *path, int side, uint
       std::vector<MerylFileSums> per(64);
       rc = for_each_meryl_file([&](uint32_t fl) {
         Feeder tf{ix, side, minV, maxV, &mu};
-        int r = read_meryl_data(meryl_file_name(p, fl, ".merylData"), fl, mi, [&](uint64_t km, uint32_t v) { tf.push(km, v); }, &per[fl]);
+        int r = read_meryl_data(meryl_file_name(p, fl, ".merylData"), fl, mi, [&](uint64_t lo, uint64_t hi, uint32_t v) { tf.push(lo, hi, v); }, &per[fl]);
         if (r == MFX_OK) tf.flush();
         return r ? r : tf.rc;
       });
@@ -539,7 +546,8 @@ extern "C" int mfx_db_write_flat(const char *path, int k, const uint64_t *kmers,
   h.flags = 0;
   h.n = n;
   h.reserved = 0;
-  bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && (n == 0 || (fwrite(kmers, 8, n, f) == n && fwrite(values, 4, n, f) == n));
+  const size_t kw = k > MFX_MAX_K_NARROW ? 2 : 1;           // k > 31: two words per k-mer {low 64 bits, high bits}
+  bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && (n == 0 || (fwrite(kmers, 8 * kw, n, f) == n && fwrite(values, 4, n, f) == n));
   fclose(f);
   return ok ? MFX_OK : mfx_fail(MFX_E_IO, "short write to '%s'", path);
 }
@@ -572,7 +580,7 @@ static int fill_header(const mfx_index *ix, IndexImageHeader &h) {
   h.shard_rank = ix->shard_rank; h.shard_n = ix->shard_n;
   h.nlines = ix->nlines; h.capacity_kmers = ix->capacity_kmers;
   h.minV = ix->minV; h.maxV = ix->maxV;
-  h.slot_bytes = (uint32_t)sizeof(mfx_slot); h.line_slots = MFX_SLOTS_LINE;
+  h.slot_bytes = MFX_ALIGN / ix->slots_per_line(); h.line_slots = ix->slots_per_line();
   h.filter_set = ix->filter_set ? 1u : 0u;
   h.layout = MFX_LAYOUT_VERSION;
   h.fingerprint = ix->fingerprint;
@@ -581,8 +589,10 @@ static int fill_header(const mfx_index *ix, IndexImageHeader &h) {
 }
 
 static bool header_ok(const IndexImageHeader &h) {
-  return memcmp(h.magic, "MFXINDX2", 8) == 0 && h.slot_bytes == sizeof(mfx_slot) && h.line_slots == MFX_SLOTS_LINE && h.k >= 1 &&
-         h.k <= 31 && h.nlines != 0 && h.nlines < (1ull << 32) && h.layout == MFX_LAYOUT_VERSION;
+  const bool wide = h.k > (uint32_t)MFX_MAX_K_NARROW;
+  return memcmp(h.magic, "MFXINDX2", 8) == 0 && h.slot_bytes == (wide ? sizeof(mfx_wslot) : sizeof(mfx_slot)) &&
+         h.line_slots == (wide ? MFX_WSLOTS_LINE : MFX_SLOTS_LINE) && h.k >= 1 && h.k <= (uint32_t)MFX_MAX_K && h.nlines != 0 &&
+         h.nlines < (1ull << 32) && h.layout == MFX_LAYOUT_VERSION;
 }
 
 // an index of exactly the header's geometry; its lines are allocated but hold nothing yet

@@ -55,6 +55,15 @@ struct mfx_slot {               // 16 bytes: one dwordx4 load per probe
 };
 constexpr uint64_t MFX_EMPTY = ~0ull;
 
+// 32 <= k <= 64: k-mers of up to 128 bits (mfx_wide.hip).  Four 32-byte slots per 128-byte line.
+struct mfx_wslot {
+  uint64_t lo, hi;              // the 2k-bit k-mer
+  uint32_t readV, asmV;
+  uint64_t state;               // 0 empty, 1 claimed (key being written), 2 ready
+};
+constexpr uint32_t MFX_WSLOTS_LINE = 4;
+constexpr int      MFX_MAX_K_NARROW = 31, MFX_MAX_K = 64;
+
 struct mfx_table_view {
   mfx_slot *slots;
   uint64_t  nlines;             // 128-byte lines; slots = 8 * nlines
@@ -62,6 +71,7 @@ struct mfx_table_view {
   int       k;
   int       mz_w;               // minimizer windows (0 = plain k-mer hashing; else m = k - mz_w + 1)
   uint32_t  shard_rank, shard_n;  // sharded index: this table keeps only the k-mers owned by shard_rank of shard_n
+  int       wide;               // k > 31: slots are mfx_wslot (mfx_wide.hip kernels)
 };
 
 struct mfx_index {
@@ -77,6 +87,9 @@ struct mfx_index {
   uint32_t  shard_rank = 0, shard_n = 1;
   uint64_t  version = 0;        // bumped by every insert batch; lets evaluators cache index-derived facts
   uint64_t  fingerprint = 0;    // caller-supplied digest of the inputs (travels with the index image)
+  bool      wide() const { return k > MFX_MAX_K_NARROW; }
+  uint32_t  slots_per_line() const { return wide() ? MFX_WSLOTS_LINE : MFX_SLOTS_LINE; }
+  uint32_t  key_words() const { return wide() ? 2u : 1u; }      // uint64 words per k-mer at the C ABI
   mfx_table_view view() const;
 };
 

@@ -102,6 +102,15 @@ hipError_t mfx_k_ordered_sum(const double *v, uint32_t n, double *out, hipStream
 uint64_t mfx_k_tile_partials_words(uint64_t ntiles);
 hipError_t mfx_k_sum_tile_partials(double *tile_partials, uint64_t ntiles, double *out, uint64_t *ctr_reset, hipStream_t st);
 int mfx_k_hist_resident_blocks();
+// 32 <= k <= 64 (mfx_wide.hip); kmers: two uint64 words per k-mer {low 64 bits, high bits}
+hipError_t mfx_kw_table_add(mfx_table_view t, const uint64_t *kmers, const uint32_t *values, uint64_t n, int side, uint64_t *meta, hipStream_t st);
+hipError_t mfx_kw_table_value(mfx_table_view t, const uint64_t *kmers, uint64_t n, uint32_t *readV, uint32_t *asmV, hipStream_t st);
+hipError_t mfx_kw_table_export(mfx_table_view t, uint64_t *kmers, uint32_t *readV, uint32_t *asmV, unsigned long long *count, hipStream_t st);
+hipError_t mfx_kw_hist(const mfx_hist_args &a, int grid, hipStream_t st);
+hipError_t mfx_kw_dump(const mfx_dump_args &a, hipStream_t st);
+hipError_t mfx_kw_count(const mfx_count_args &a, hipStream_t st);
+hipError_t mfx_kw_completeness(mfx_table_view t, double peak, uint32_t n_prob, const uint32_t *probK, const double *probP, double *partials,
+                               int grid, hipStream_t st);
 hipError_t mfx_k_dump(const mfx_dump_args &a, hipStream_t st);
 hipError_t mfx_k_count(const mfx_count_args &a, hipStream_t st);
 hipError_t mfx_k_completeness(mfx_table_view t, double peak, uint32_t n_prob, const uint32_t *probK, const double *probP,

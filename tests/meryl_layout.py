@@ -47,6 +47,14 @@ class BitWriter:
         return out
 
 
+def to_ints(kmers):
+    """k-mers as Python integers: a uint64 array (k <= 32) or rows [low 64 bits, high bits] (k > 32)"""
+    a = np.asarray(kmers)
+    if a.ndim == 2:
+        return [int(lo) | (int(hi) << 64) for lo, hi in a.tolist()]
+    return [int(x) for x in a.tolist()]
+
+
 def write_db(path, k, kmers, values, prefix_bits=12, unary_bits=None, version=3, stats=True, stats_override=None):
     """kmers: sorted unique uint64 array, values: uint32.  stats: append the statistics block (numUnique,
     numDistinct, numTotal as 64-bit fields) to the master index; stats_override = (unique, distinct, total) writes
@@ -64,25 +72,28 @@ def write_db(path, k, kmers, values, prefix_bits=12, unary_bits=None, version=3,
         w.put(v, 32)
     if version >= 2:
         w.put(0, 32)
-    kmers = np.asarray(kmers, dtype=np.uint64)
     values = np.asarray(values, dtype=np.uint32)
+    ks = to_ints(kmers)
+    assert all(a < b for a, b in zip(ks, ks[1:])), "k-mers must be sorted and unique"
     if stats:
-        st = stats_override or (int((values == 1).sum()), len(kmers), int(values.astype(np.uint64).sum()))
+        st = stats_override or (int((values == 1).sum()), len(ks), int(values.astype(np.uint64).sum()))
         for v in st:
             w.put(int(v), 64)
     open(os.path.join(path, "merylIndex"), "wb").write(w.image())
-    prefixes = (kmers >> np.uint64(suffix_bits)).astype(np.uint64)
+    vals_all = values.tolist()
+    per_file = {}
+    for km, v in zip(ks, vals_all):                            # k-mer = [prefix : prefix_bits][suffix : suffix_bits]
+        pfx = km >> suffix_bits
+        per_file.setdefault(pfx >> blocks_bits, {}).setdefault(pfx, []).append((km & ((1 << suffix_bits) - 1), v))
     for fl in range(64):
         name = "0x" + format(fl, "06b") + ".merylData"
-        sel = (prefixes >> np.uint64(blocks_bits)) == fl
-        if not sel.any():
+        if fl not in per_file:
             open(os.path.join(path, name), "wb").close()       # all 64 data files exist, empty pieces included
             continue
         with open(os.path.join(path, name), "wb") as f:
-            for pfx in np.unique(prefixes[sel]).tolist():
-                m = prefixes == pfx
-                sfx = (kmers[m] & np.uint64((1 << suffix_bits) - 1)).tolist()
-                vals = values[m].tolist()
+            for pfx in sorted(per_file[fl]):
+                sfx = [x[0] for x in per_file[fl][pfx]]
+                vals = [x[1] for x in per_file[fl][pfx]]
                 b = BitWriter()
                 b.put(DAT_MAGIC1, 64)
                 b.put(DAT_MAGIC2, 64)
@@ -96,11 +107,11 @@ def write_db(path, k, kmers, values, prefix_bits=12, unary_bits=None, version=3,
                 b.put(0, 64)
                 b.put(0, 64)
                 hi_prev = 0
-                for s in sfx:
-                    hi = s >> binary_bits
+                for s_ in sfx:
+                    hi = s_ >> binary_bits
                     b.unary(hi - hi_prev)
                     hi_prev = hi
-                    b.put(s & ((1 << binary_bits) - 1), binary_bits)
+                    b.put(s_ & ((1 << binary_bits) - 1), binary_bits)       # wider than 64 bits for large k: one bit stream
                 for v in vals:
                     b.put(v, 32)
                 f.write(b.image())

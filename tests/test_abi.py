@@ -55,6 +55,18 @@ def test_no_cpu_fallback_without_gpu():
         m.Sequences([b"ACGT"])
 
 
+def test_k_range_is_the_references():
+    """k-mers hold 2k <= 128 bits (meryl-utility's kmer): k = 64 is accepted (and then needs a GPU), k = 65 is not"""
+    m, _, _ = _lib()
+    with pytest.raises(m.MfxError) as e:
+        m.Index(65, 10)
+    assert e.value.code == -1 and "1 <= k <= 64" in str(e.value)
+    with pytest.raises(m.MfxError) as e:
+        m.Index(0, 10)
+    assert e.value.code == -1
+    assert m.load_library().mfx_index_estimate_gb(41, 7 * 10**8) == pytest.approx(2 * m.load_library().mfx_index_estimate_gb(31, 7 * 10**8), rel=1e-6)
+
+
 def test_product_never_touches_the_oracle():
     """Nothing under merfin_amd/ may import, link or execute oracle/."""
     for d, _, files in os.walk(os.path.join(ROOT, "merfin_amd")):

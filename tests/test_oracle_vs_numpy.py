@@ -3,80 +3,12 @@
 against the C oracle on random small inputs.  Two restatements written in
 different styles agreeing bit-for-bit is the strongest pin available here:
 the reference itself cannot be built (see oracle/merfin_oracle.h)."""
-import math
-
 import numpy as np
 import pytest
 
 from oracle import pyoracle as po
 
-COMP = {"A": "T", "C": "G", "G": "C", "T": "A"}
-CODE = {"A": 0, "C": 1, "T": 2, "G": 3}
-
-
-def enc(s):
-    v = 0
-    for ch in s:
-        v = (v << 2) | CODE[ch]
-    return v
-
-
-def revcomp(s):
-    return "".join(COMP[c] for c in reversed(s))
-
-
-def c_round(x):          # C round(): half away from zero (Python's round() is half-to-even)
-    return math.floor(x + 0.5) if x >= 0 else -math.floor(-x + 0.5)
-
-
-def getK(peak, probK, probP, readV, asmV):           # merfin-globals.C:66-98
-    readK, prob = 0.0, 1.0
-    if readV == 0:
-        readK = 0.0
-    elif readV < peak:
-        readK = 1.0
-    else:
-        readK = float(c_round(readV / peak))
-    if 0 < readV <= len(probK):
-        readK, prob = float(probK[readV - 1]), float(probP[readV - 1])
-    return readK, float(asmV), prob
-
-
-def kmetric(readK, asmK):                            # merfin-globals.H:248-261
-    if readK == 0:
-        return 0.0
-    if asmK > readK:
-        return (asmK / readK - 1) * -1
-    if asmK < readK:
-        return readK / asmK - 1
-    return 0.0
-
-
-def py_hist(k, peak, probK, probP, contig, R, A):    # merfin-histogram.C:54-91
-    undr, over = {}, {}
-    kasm = kmissing = 0
-    kover = 0.0
-    s = contig.upper()
-    for i in range(len(s) - k + 1):
-        w = s[i:i + k]
-        if any(c not in "ACGT" for c in w):
-            continue
-        kasm += 1
-        f, r = enc(w), enc(revcomp(w))
-        readV = (R.get(f, 0) + R.get(r, 0)) & 0xffffffff
-        asmV = (A.get(f, 0) + A.get(r, 0)) & 0xffffffff
-        readK, asmK, prob = getK(peak, probK, probP, readV, asmV)
-        if readK == 0:
-            kmissing += 1
-            continue
-        if asmK > readK:
-            idx = int(((asmK / readK - 1) + 0.1) / 0.2)
-            undr[idx] = undr.get(idx, 0) + 1
-            kover += (1.0 - readK / asmK) * prob
-        else:
-            idx = int(((readK / asmK - 1) + 0.1) / 0.2)
-            over[idx] = over.get(idx, 0) + 1
-    return undr, over, kasm, kmissing, kover
+from oracle.plain import enc, revcomp, getK, kmetric, py_hist          # the plain-Python restatement lives in oracle/plain.py
 
 
 @pytest.mark.parametrize("k,seed,use_prob", [(5, 1, False), (8, 2, True), (21, 3, False), (21, 4, True), (31, 5, False), (6, 6, False)])
@@ -138,3 +70,28 @@ def test_counter_and_canonical_against_python():
         assert dict(zip(kk.tolist(), vv.tolist())) == d
         for km in list(d)[:50]:
             assert po.lib().orc_canonical(km, k) == km
+
+
+def test_plain_completeness_and_filter_against_c_oracle():
+    """the remaining pieces of oracle/plain.py (used as THE oracle for 32 <= k <= 64): per-piece completeness sums and the
+    -min/-max read filter, against the C oracle at k = 21"""
+    from oracle import plain
+    from tests import synth
+    k, peak = 21, 17.3
+    contigs, read, asm = synth.world(k=k, peak=peak, seed=23, sizes=(6000, 2000, 300))
+    R = dict(zip(read[0].tolist(), read[1].tolist()))
+    A = dict(zip(asm[0].tolist(), asm[1].tolist()))
+    p = po.Params(k, peak)
+    wt, wu = plain.py_completeness(k, peak, [], [], R, A)
+    for piece in range(64):
+        lo, hi = piece << (2 * k - 6), (piece + 1) << (2 * k - 6)
+        rs, as_ = (read[0] >= lo) & (read[0] < hi), (asm[0] >= lo) & (asm[0] < hi)
+        assert (wt[piece], wu[piece]) == po.completeness_piece(p, read[0][rs], read[1][rs], asm[0][as_], asm[1][as_])
+    RL, AL = po.Lookup(k, read[0], read[1], 4, 40), po.Lookup(k, *asm)
+    for c in contigs:
+        undr, over, kasm, kmissing, kover = plain.py_hist(k, peak, [], [], c.decode(), R, A, 4, 40)
+        h = po.process_histogram(p, RL, AL, c)
+        assert (h.kasm, h.kmissing, h.koverCpy) == (kasm, kmissing, kover)
+        assert {i: int(v) for i, v in enumerate(h.undr()) if v} == undr and {i: int(v) for i, v in enumerate(h.over()) if v} == over
+    assert plain.count_kmers(k, [c.decode() for c in contigs]) == A
+    assert plain.dec(plain.enc("ACGTTGCA"), 8) == "ACGTTGCA"
