@@ -384,8 +384,9 @@ class Index:
         _check(load_library().mfx_index_get_info(self.h, C.byref(i)))
         return {"k": i.k, "canonical": bool(i.canonical), "capacity": i.capacity, "distinct": i.distinct, "bytes": i.bytes}
 
-    def export(self):
-        """every stored (k-mer, readV, asmV), sorted by k-mer.  k > 31: k-mers are rows [low 64 bits, high bits]"""
+    def export(self, sort=True):
+        """every stored (k-mer, readV, asmV), sorted by k-mer (sort=False: table order).  k > 31: k-mers are rows
+        [low 64 bits, high bits]"""
         n = self.info()["distinct"]
         if self.k > 31:
             k = np.zeros((max(n, 1), 2), dtype=np.uint64)
@@ -395,6 +396,8 @@ class Index:
             _check(load_library().mfx_index_export(self.h, k.ctypes.data_as(C.POINTER(C.c_uint64)), r.ctypes.data_as(C.POINTER(C.c_uint32)),
                                                    a.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(cnt)))
             k, r, a = k[:cnt.value], r[:cnt.value], a[:cnt.value]
+            if not sort:
+                return k, r, a
             o = np.lexsort((k[:, 0], k[:, 1]))
             return k[o], r[o], a[o]
         k = np.zeros(max(n, 1), dtype=np.uint64)
@@ -404,6 +407,8 @@ class Index:
         _check(load_library().mfx_index_export(self.h, k.ctypes.data_as(C.POINTER(C.c_uint64)),
                                                r.ctypes.data_as(C.POINTER(C.c_uint32)), a.ctypes.data_as(C.POINTER(C.c_uint32)),
                                                C.byref(cnt)))
+        if not sort:
+            return k[:cnt.value], r[:cnt.value], a[:cnt.value]
         o = np.argsort(k[:cnt.value])
         return k[:cnt.value][o], r[:cnt.value][o], a[:cnt.value][o]
 

@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <string>
@@ -228,6 +229,7 @@ extern "C" mfx_index *mfx_index_create(int k, uint64_t capacity_kmers, double ma
 extern "C" void mfx_index_free(mfx_index *ix) {
   if (!ix) return;
   DevGuard g(ix->device);
+  mfx_index_ingest_release(ix);
   if (ix->d_slots) (void)hipFree(ix->d_slots);
   if (ix->d_meta) (void)hipFree(ix->d_meta);
   delete ix;
@@ -246,6 +248,135 @@ static int index_check(mfx_index *ix) {
   return MFX_OK;
 }
 
+// Host -> table pipeline.  Two lanes of pinned staging + device buffers alternate: while lane A's chunk travels over
+// PCIe and is inserted, host threads fill lane B.  The lanes belong to the index and are REUSED by every load call
+// (pinning memory costs ~0.4 ms per MB: allocating them per call was 3.5 s of a 5.1 s ingest at 1 Gb); they are
+// released with the index (or by mfx_index_ingest_release once the loading is over).
+constexpr uint64_t MFX_INGEST_CHUNK = 1ull << 24;           // k-mers per lane: 128 MB of keys + 64 MB of counts
+struct mfx_ingest {
+  struct Lane {
+    uint64_t *hk = nullptr, *dk = nullptr;
+    uint32_t *hv = nullptr, *dv = nullptr;
+    hipEvent_t done = nullptr;
+    bool busy = false;
+  } L[2];
+  hipStream_t st = nullptr;
+  uint64_t cap = 0;            // k-mers per lane
+  size_t kw = 1;
+};
+
+static void ingest_free(mfx_ingest *g) {
+  if (!g) return;
+  if (g->st) (void)hipStreamSynchronize(g->st);
+  for (auto &l : g->L) {
+    if (l.hk) (void)hipHostFree(l.hk);
+    if (l.hv) (void)hipHostFree(l.hv);
+    if (l.dk) (void)hipFree(l.dk);
+    if (l.dv) (void)hipFree(l.dv);
+    if (l.done) (void)hipEventDestroy(l.done);
+  }
+  if (g->st) (void)hipStreamDestroy(g->st);
+  delete g;
+}
+
+void mfx_index_ingest_release(mfx_index *ix) {
+  if (!ix || !ix->ingest) return;
+  DevGuard g(ix->device);
+  ingest_free(ix->ingest);
+  ix->ingest = nullptr;
+}
+
+static mfx_ingest *ingest_get(mfx_index *ix, uint64_t n) {
+  const uint64_t want = std::min<uint64_t>(std::max<uint64_t>(n, 1), MFX_INGEST_CHUNK);
+  if (ix->ingest && ix->ingest->cap >= want) return ix->ingest;
+  mfx_index_ingest_release(ix);
+  // small loads (tests, single contigs) get small lanes; the first large one gets the full-size lanes
+  uint64_t cap = 1ull << 16;
+  while (cap < want) cap <<= 1;
+  mfx_ingest *g = new mfx_ingest;
+  g->cap = cap;
+  g->kw = ix->key_words();
+  bool ok = hipStreamCreateWithFlags(&g->st, hipStreamNonBlocking) == hipSuccess;
+  for (auto &l : g->L)
+    ok = ok && hipHostMalloc((void **)&l.hk, cap * 8 * g->kw, hipHostMallocDefault) == hipSuccess &&
+         hipHostMalloc((void **)&l.hv, cap * 4, hipHostMallocDefault) == hipSuccess &&
+         hipMalloc((void **)&l.dk, cap * 8 * g->kw) == hipSuccess && hipMalloc((void **)&l.dv, cap * 4) == hipSuccess &&
+         hipEventCreateWithFlags(&l.done, hipEventDisableTiming) == hipSuccess;
+  if (!ok) { (void)hipGetLastError(); ingest_free(g); return nullptr; }
+  ix->ingest = g;
+  return g;
+}
+
+// fill(o, m, hk, hv): put k-mers [o, o+m) of the source into the pinned lane buffers; false = the source failed
+template <class Fill>
+static int index_ingest(mfx_index *ix, uint64_t n, int side, Fill &&fill) {
+  mfx_ingest *g = ingest_get(ix, n);
+  if (!g) return mfx_fail(MFX_E_NOMEM, "mfx_index_add: staging allocation failed");
+  bool ok = true, src_ok = true;
+  int cur = 0;
+  for (uint64_t o = 0; o < n && ok; o += g->cap, cur ^= 1) {
+    mfx_ingest::Lane &l = g->L[cur];
+    const uint64_t m = std::min(g->cap, n - o);
+    if (l.busy && hipEventSynchronize(l.done) != hipSuccess) { ok = false; break; }
+    l.busy = false;
+    if (!fill(o, m, l.hk, l.hv)) { src_ok = false; break; }
+    ok = hipMemcpyAsync(l.dk, l.hk, m * 8 * g->kw, hipMemcpyHostToDevice, g->st) == hipSuccess &&
+         hipMemcpyAsync(l.dv, l.hv, m * 4, hipMemcpyHostToDevice, g->st) == hipSuccess &&
+         (ix->wide() ? mfx_kw_table_add(ix->view(), l.dk, l.dv, m, side, ix->d_meta, g->st)
+                     : mfx_k_table_add(ix->view(), l.dk, l.dv, m, side, ix->d_meta, g->st)) == hipSuccess &&
+         hipEventRecord(l.done, g->st) == hipSuccess;
+    l.busy = true;
+  }
+  if (hipStreamSynchronize(g->st) != hipSuccess) ok = false;
+  g->L[0].busy = g->L[1].busy = false;
+  if (!ok) return mfx_fail(MFX_E_HIP, "mfx_index_add: transfer / insert failed: %s", hipGetErrorString(hipGetLastError()));
+  if (!src_ok) return mfx_last_error_code() ? mfx_last_error_code() : MFX_E_IO;
+  return index_check(ix);
+}
+
+// n bytes at file offset `off` into dst, read by several threads (each pread copies straight out of the page cache:
+// no mapping to fault in page by page, which is what made the mmap + memcpy route top out at ~7 GB/s)
+static bool par_pread(int fd, uint8_t *dst, size_t n, uint64_t off) {
+  const unsigned nt = std::min<unsigned>(16u, std::max(1u, mfx_host_threads()));
+  auto rd = [fd](uint8_t *d, size_t len, uint64_t o) {
+    while (len) {
+      ssize_t r = pread(fd, d, len, (off_t)o);
+      if (r <= 0) return false;
+      d += r; o += (uint64_t)r; len -= (size_t)r;
+    }
+    return true;
+  };
+  if (n < (8u << 20) || nt == 1) return rd(dst, n, off);
+  std::vector<std::thread> th;
+  std::vector<char> good(nt, 1);
+  const size_t per = ((n + nt - 1) / nt + 4095) & ~(size_t)4095;
+  for (unsigned t = 0; t < nt; ++t) {
+    const size_t b = std::min(n, t * per), e = std::min(n, b + per);
+    if (e > b) th.emplace_back([&, t, b, e]() { good[t] = rd(dst + b, e - b, off + b) ? 1 : 0; });
+  }
+  for (auto &x : th) x.join();
+  for (char c : good) if (!c) return false;
+  return true;
+}
+
+// k-mers [0, n) of an open flat-binary database: keys at keys_off (8 * key_words bytes each), counts at vals_off
+int mfx_index_add_from_file(mfx_index *ix, int fd, const char *path, uint64_t keys_off, uint64_t vals_off, uint64_t n, int side,
+                            uint64_t minV, uint64_t maxV) {
+  if (!ix || fd < 0) return mfx_fail(MFX_E_INVAL, "mfx_index_add_from_file: bad argument");
+  if (side == 0) {
+    if (ix->filter_set && (ix->minV != minV || ix->maxV != maxV))
+      return mfx_fail(MFX_E_INVAL, "mfx_index_add_read: -min/-max must be the same for every batch of one index");
+    ix->minV = minV; ix->maxV = maxV; ix->filter_set = true;
+  }
+  DevGuard g(ix->device);
+  const size_t kw = ix->key_words();
+  return index_ingest(ix, n, side, [&](uint64_t o, uint64_t m, uint64_t *hk, uint32_t *hv) {
+    if (par_pread(fd, (uint8_t *)hk, m * 8 * kw, keys_off + o * 8 * kw) && par_pread(fd, (uint8_t *)hv, m * 4, vals_off + o * 4)) return true;
+    mfx_fail(MFX_E_IO, "reading '%s' failed", path);
+    return false;
+  });
+}
+
 static int index_add(mfx_index *ix, const uint64_t *kmers, const uint32_t *values, uint64_t n, int side, int on_device) {
   if (!ix || (n && (!kmers || !values))) return mfx_fail(MFX_E_INVAL, "mfx_index_add: null argument");
   DevGuard g(ix->device);
@@ -258,51 +389,11 @@ static int index_add(mfx_index *ix, const uint64_t *kmers, const uint32_t *value
     MFX_HIP(hipDeviceSynchronize());
     return index_check(ix);
   }
-  // Host arrays: stream them through two alternating sets of pinned staging + device buffers,
-  // so the threaded host copy of chunk i+1 overlaps the PCIe transfer and the insert kernel of chunk i.
-  const uint64_t CH = std::min<uint64_t>(n ? n : 1, 1ull << 23);
-  struct Lane {
-    uint64_t *hk = nullptr, *dk = nullptr;
-    uint32_t *hv = nullptr, *dv = nullptr;
-    hipEvent_t done = nullptr;
-    bool busy = false;
-  } L[2];
-  hipStream_t st = nullptr;
-  auto cleanup = [&]() {
-    if (st) (void)hipStreamSynchronize(st);
-    for (auto &l : L) {
-      if (l.hk) (void)hipHostFree(l.hk);
-      if (l.hv) (void)hipHostFree(l.hv);
-      if (l.dk) (void)hipFree(l.dk);
-      if (l.dv) (void)hipFree(l.dv);
-      if (l.done) (void)hipEventDestroy(l.done);
-    }
-    if (st) (void)hipStreamDestroy(st);
-  };
-  bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
-  for (auto &l : L)
-    ok = ok && hipHostMalloc((void **)&l.hk, CH * 8 * kw, hipHostMallocDefault) == hipSuccess &&
-         hipHostMalloc((void **)&l.hv, CH * 4, hipHostMallocDefault) == hipSuccess &&
-         hipMalloc((void **)&l.dk, CH * 8 * kw) == hipSuccess && hipMalloc((void **)&l.dv, CH * 4) == hipSuccess &&
-         hipEventCreateWithFlags(&l.done, hipEventDisableTiming) == hipSuccess;
-  if (!ok) { cleanup(); return mfx_fail(MFX_E_NOMEM, "mfx_index_add: staging allocation failed"); }
-  int cur = 0;
-  for (uint64_t o = 0; o < n && ok; o += CH, cur ^= 1) {
-    Lane &l = L[cur];
-    const uint64_t m = std::min(CH, n - o);
-    if (l.busy && hipEventSynchronize(l.done) != hipSuccess) { ok = false; break; }
-    par_memcpy((uint8_t *)l.hk, (const char *)(kmers + o * kw), m * 8 * kw);
-    par_memcpy((uint8_t *)l.hv, (const char *)(values + o), m * 4);
-    ok = hipMemcpyAsync(l.dk, l.hk, m * 8 * kw, hipMemcpyHostToDevice, st) == hipSuccess &&
-         hipMemcpyAsync(l.dv, l.hv, m * 4, hipMemcpyHostToDevice, st) == hipSuccess &&
-         table_add(l.dk, l.dv, m, st) == hipSuccess &&
-         hipEventRecord(l.done, st) == hipSuccess;
-    l.busy = true;
-  }
-  if (ok && hipStreamSynchronize(st) != hipSuccess) ok = false;
-  cleanup();
-  if (!ok) return mfx_fail(MFX_E_HIP, "mfx_index_add: transfer / insert failed: %s", hipGetErrorString(hipGetLastError()));
-  return index_check(ix);
+  return index_ingest(ix, n, side, [&](uint64_t o, uint64_t m, uint64_t *hk, uint32_t *hv) {
+    par_memcpy((uint8_t *)hk, (const char *)(kmers + o * kw), m * 8 * kw);
+    par_memcpy((uint8_t *)hv, (const char *)(values + o), m * 4);
+    return true;
+  });
 }
 
 extern "C" int mfx_index_add_read(mfx_index *ix, const uint64_t *kmers, const uint32_t *values, uint64_t n,

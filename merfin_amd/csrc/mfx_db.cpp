@@ -482,8 +482,8 @@ extern "C" int mfx_index_load_db(mfx_index *ix, const char *path, int side, uint
   uint64_t n = 0;
   int rc = MFX_OK;
   if (fmt == MFX_DB_FLAT) {
-    // The file is mapped and handed to the insert path in large chunks: the staging copies into pinned memory
-    // (threaded, mfx_index_add_*) then read the page cache / disk in parallel instead of one fread stream.
+    // Several threads pread() slices of the file straight into the index's pinned staging lanes (no mapping to
+    // fault in, no per-call pinning), overlapped with the PCIe transfer and the insert kernel of the previous chunk.
     int fdn = open(path, O_RDONLY);
     struct stat st;
     if (fdn < 0 || fstat(fdn, &st) != 0) { if (fdn >= 0) close(fdn); return mfx_fail(MFX_E_IO, "cannot open '%s'", path); }
@@ -495,20 +495,7 @@ extern "C" int mfx_index_load_db(mfx_index *ix, const char *path, int side, uint
     if ((int)h.k != ix->k) { close(fdn); return mfx_fail(MFX_E_INVAL, "'%s' holds %u-mers but the index is built for k=%d", path, h.k, ix->k); }
     const uint64_t kw = ix->key_words();                     // k > 31: 16-byte k-mers {low, high}
     if ((uint64_t)st.st_size < sizeof(h) + h.n * (8 * kw + 4)) { close(fdn); return mfx_fail(MFX_E_FORMAT, "'%s': truncated payload", path); }
-    if (h.n) {
-      void *map = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fdn, 0);
-      if (map == MAP_FAILED) { close(fdn); return mfx_fail(MFX_E_IO, "cannot map '%s'", path); }
-      (void)madvise(map, (size_t)st.st_size, MADV_SEQUENTIAL);
-      const uint64_t *kb = reinterpret_cast<const uint64_t *>((const char *)map + sizeof(h));
-      const uint32_t *vb = reinterpret_cast<const uint32_t *>((const char *)map + sizeof(h) + h.n * 8 * kw);
-      const uint64_t CH = 1u << 26;
-      for (uint64_t o = 0; o < h.n && rc == MFX_OK; o += CH) {
-        const uint64_t m = std::min<uint64_t>(CH, h.n - o);
-        rc = side ? mfx_index_add_asm(ix, kb + o * kw, vb + o, m, 0)
-                  : mfx_index_add_read(ix, kb + o * kw, vb + o, m, minV, maxV, 0);
-      }
-      munmap(map, (size_t)st.st_size);
-    }
+    if (h.n) rc = mfx_index_add_from_file(ix, fdn, path, sizeof(h), sizeof(h) + h.n * 8 * kw, h.n, side, minV, maxV);
     close(fdn);
   } else if (fmt == MFX_DB_TEXT) {
     int k = 0;

@@ -27,6 +27,11 @@ int  mfx_fail(int code, const char *fmt, ...);
     }                                                                                         \
   } while (0)
 
+// flat-binary database -> table, read with parallel pread into the index's staging lanes (mfx_api.cpp)
+int  mfx_index_add_from_file(struct mfx_index *ix, int fd, const char *path, uint64_t keys_off, uint64_t vals_off, uint64_t n, int side,
+                             uint64_t minV, uint64_t maxV);
+void mfx_index_ingest_release(struct mfx_index *ix);
+
 // host threads the library may use: min(hardware, cgroup CPU quota, 64), or MFX_HOST_THREADS
 unsigned mfx_host_threads();
 
@@ -74,8 +79,11 @@ struct mfx_table_view {
   int       wide;               // k > 31: slots are mfx_wslot (mfx_wide.hip kernels)
 };
 
+struct mfx_ingest;              // pinned staging lanes of the host -> table pipeline (mfx_api.cpp)
+
 struct mfx_index {
   int       device = 0;
+  mfx_ingest *ingest = nullptr; // allocated by the first host-side load, reused by the following ones
   int       k = 0;
   uint64_t  capacity_kmers = 0;
   uint64_t  nlines = 0;
