@@ -46,6 +46,7 @@ for mode, o in modes:
 # -hist without -seqmers: assembly k-mers counted on the GPU
 t = time.time()
 r = subprocess.run([exe, "-hist", "-sequence", out + "/asm.fasta", "-readmers", out + "/read.mfxk", "-peak", "26", "-prob", prob,
-                    "-output", out + "/out2.hist"], capture_output=True, text=True)
+                    "-output", out + "/out2.hist"], capture_output=True, text=True, env=dict(os.environ, MFX_CLI_TIMING="1"))
 print("-hist (asm counted on GPU): rc=%d wall=%.2fs same_hist=%s" % (r.returncode, time.time() - t,
       open(out + "/out.hist").read() == open(out + "/out2.hist").read()))
+print("    " + "\n    ".join(l for l in r.stderr.splitlines() if "timing" in l))

@@ -1,22 +1,17 @@
 #!/bin/bash
 # rocprofv3 evidence for bench.py (run on the GPU box via gpurun):
-#   1. --kernel-trace --stats of the default bench command
-#   2. PMC passes (FETCH_SIZE, WRITE_SIZE separately -- TCC slots) restricted to the hist kernel
-#   3. FETCH_SIZE calibration on a known count of random 16-byte loads (tools/ubench_gather)
+#   1. the default bench command, un-profiled; its own two PMC passes (FETCH_SIZE, WRITE_SIZE: separate runs, TCC slots)
+#      leave their raw rows in $OUT/pmc (MFX_BENCH_KEEP_PMC)
+#   2. --kernel-trace --stats of the same command (--no-pmc: the PMC children must not run under an outer rocprofv3; --no-streamed: every hist launch but the cpu-baseline sample is then a full-size one, so the stats row averages cleanly)
 # Outputs: gpurun_out/prof_$TAG/ ; copy the summaries you want judged into profiles/.
-TAG=${1:-r01}
+TAG=${1:-r02}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --gpus 1 --steps 5 --warmup 2"
-
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $BENCH > $OUT/bench_trace.json 2> $OUT/bench_trace.log
-for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --pmc $C --kernel-include-regex "mfx_hist" --output-format csv -d $OUT/pmc_$C -o bench -- $BENCH --no-cpu-baseline > $OUT/bench_pmc_$C.json 2> $OUT/bench_pmc_$C.log
-done
-timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "gather_kernel|stream_kernel" --output-format csv -d $OUT/calib -o ubench -- $REPO/tools/_build/ubench_gather 32 > $OUT/calib_ubench.txt 2>&1
+MFX_BENCH_KEEP_PMC=$OUT/pmc python $REPO/bench.py --gpus 1 --steps 10 --warmup 3 > $OUT/bench.json 2> $OUT/bench.log
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python $REPO/bench.py --gpus 1 --steps 10 --warmup 3 --no-pmc --no-streamed > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.log
 find $OUT -name "*.csv" | head -50
-# keep the merged-back payload small: drop per-launch traces of the torch kernels
+# keep the merged-back payload small: drop per-launch traces
 find $OUT -name "*kernel_trace.csv" -size +20M -delete
 du -sh $OUT
