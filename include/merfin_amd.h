@@ -318,6 +318,12 @@ int mfx_route_tiles(mfx_router *r, const mfx_seq *seq, uint64_t tile_begin, uint
  * and per contig) and koverCpy -- NOT kasm, which the source counted. */
 int mfx_hist_keys_launch(mfx_eval *ev, const uint64_t *d_keys, const uint32_t *d_contigs, uint64_t n,
                          uint32_t ncontigs, uint64_t *d_counts, double *d_kover, void *stream);
+/* The whole sharded -hist driven by ONE process: slot d = {evaluator on shard d of ndev, router on that shard,
+ * the packed assembly on the shard's device}.  Rounds of route -> peer copies of the groups to their owners (xGMI)
+ * -> mfx_hist_keys_launch at the owner -> counts images added on the host, overflow lists folded.  Slots may share a
+ * device.  (The one-process-per-GPU form of the same loop is merfin_amd/distributed.py::sharded_hist.) */
+int mfx_hist_run_sharded(mfx_eval *const *evs, mfx_router *const *routers, const mfx_seq *const *seqs, uint32_t ndev,
+                         mfx_hist_result *out);
 
 /* ------------------------------------------------------------------------ */
 /* -dump: replaces processDump + outputDump (merfin-dump.C:20-68, 72-104).  */

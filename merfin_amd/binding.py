@@ -64,7 +64,7 @@ SYMBOLS = [
     "mfx_db_probe", "mfx_index_load_db", "mfx_db_write_flat", "mfx_index_save", "mfx_index_load",
     "mfx_index_set_fingerprint", "mfx_index_get_origin",
     "mfx_host_alloc", "mfx_host_free", "mfx_seq_create", "mfx_hist_run_streamed",
-    "mfx_index_replicate", "mfx_seq_replicate", "mfx_hist_run_multi",
+    "mfx_index_replicate", "mfx_seq_replicate", "mfx_hist_run_multi", "mfx_hist_run_sharded",
     "mfx_comm_unique_id", "mfx_comm_create", "mfx_comm_free", "mfx_comm_rank", "mfx_comm_size", "mfx_comm_barrier",
     "mfx_hist_allreduce", "mfx_hist_allgather_overflow", "mfx_hist_result_add_overflow",
     "mfx_index_image_header", "mfx_index_create_from_header", "mfx_index_device_image", "mfx_index_commit",
@@ -187,6 +187,7 @@ def load_library():
     L.mfx_seq_replicate.restype = vp
     L.mfx_seq_replicate.argtypes = [vp, C.c_int]
     L.mfx_hist_run_multi.argtypes = [C.POINTER(vp), C.POINTER(vp), C.c_uint32, C.POINTER(_HistResult)]
+    L.mfx_hist_run_sharded.argtypes = [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.c_uint32, C.POINTER(_HistResult)]
     L.mfx_comm_unique_id.argtypes = [vp]
     L.mfx_comm_create.restype = vp
     L.mfx_comm_create.argtypes = [vp, C.c_int, C.c_int, C.c_int]
@@ -580,6 +581,19 @@ def hist_multi(evaluators, sequences):
     sq = (C.c_void_p * n)(*[s.h for s in sequences])
     r = HistResult()
     _check(load_library().mfx_hist_run_multi(ev, sq, n, C.byref(r.c)))
+    return r
+
+
+def hist_sharded(evaluators, routers, sequences):
+    """-hist over an index sharded across the slots of ONE process (mfx_hist_run_sharded): slot d = evaluator + router on
+    shard d of N, plus the packed assembly on that shard's device"""
+    n = len(evaluators)
+    assert n == len(routers) == len(sequences) and n >= 1
+    ev = (C.c_void_p * n)(*[e.h for e in evaluators])
+    ro = (C.c_void_p * n)(*[r.h for r in routers])
+    sq = (C.c_void_p * n)(*[s.h for s in sequences])
+    r = HistResult()
+    _check(load_library().mfx_hist_run_sharded(ev, ro, sq, n, C.byref(r.c)))
     return r
 
 

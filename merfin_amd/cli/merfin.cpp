@@ -31,7 +31,7 @@ struct Globals {
   int threads = 0, reportType = OP_NONE, device = 0;
   std::vector<int> devices;          // -devices: the GPUs of this node one process drives (-hist); [0] == device
   unsigned comb = 15;
-  bool nosplit = false, debug = false, skipMissing = false;
+  bool nosplit = false, debug = false, skipMissing = false, sharded = false;
   std::vector<uint32_t> copyKmerK;
   std::vector<double> copyKmerP;
 };
@@ -53,6 +53,8 @@ static void usage(const char *exe) {
           "    -devices list     several GPUs of this node driven by this one process, e.g. 0-7 or 0,2,5 (-hist: the index is\n"
           "                      built once and copied to the others over xGMI, every GPU evaluates its share of the\n"
           "                      sequence, the histograms are added; other report types use the first device)\n"
+          "    -sharded          with -devices, for -hist and -completeness: every GPU keeps only its share of the k-mer table\n"
+          "                      (read databases too large for one GPU); k-mers are routed to the GPU that owns them\n"
           "    -index file       cache of the built HBM index: loaded if it exists (the k-mer databases are then not\n"
           "                      read), otherwise written after the build\n\n"
           "  Report types (exactly one):\n"
@@ -145,6 +147,98 @@ static uint64_t input_fingerprint(const Globals &G) {
   return h ? h : 1;
 }
 
+static void print_hist(const std::vector<SeqRecord> &recs, const mfx_hist_result &r, int k, const char *outName, bool *ok) {
+  uint64_t cum = 0;
+  for (size_t c = 0; c < recs.size(); ++c) {   // outputHistogram's per-sequence line, in input order
+    cum += r.contig_kmissing[c];
+    fprintf(stderr, "%s\t%lu\t%lu\t%lu\t%.2f\n", recs[c].name.c_str(), (unsigned long)r.contig_kmissing[c], (unsigned long)cum,
+            (unsigned long)r.contig_kasm[c], mfx_histoQV((double)r.contig_kmissing[c], (double)r.contig_kasm[c], k));
+  }
+  *ok = mfx_hist_report(&r, k, outName, "-") == 0;
+}
+
+static void print_completeness(const double *t64, const double *u64) {
+  double total = 0, undrc = 0;
+  for (int ii = 0; ii < 64; ii++) {                     // merfin-completeness.C:119-120, here in piece order
+    fprintf(stderr, "thread %2u total %12.2f underc %15.5f completeness %0.8f\n", ii, t64[ii], u64[ii], 1.0 - u64[ii] / t64[ii]);
+    total += t64[ii];
+    undrc += u64[ii];
+  }
+  fprintf(stderr, "\n");
+  fprintf(stderr, "TOTAL readK:   %15.2f\n", total);
+  fprintf(stderr, "TOTAL undrcpy:    %15.5f\n", undrc);
+  fprintf(stderr, "COMPLETENESS:             %0.5f\n", 1.0 - undrc / total);
+}
+
+// -hist / -completeness over an index SHARDED across the devices of -devices (read databases beyond one GPU, BASELINE
+// config 5): slot d keeps the k-mers it owns (mfx_index_set_shard), loads skip foreign k-mers, -hist routes every k-mer
+// to its owner (mfx_hist_run_sharded), -completeness adds the per-piece sums of the shards in piece order
+// (merfin-completeness.C:117-123; the sums are integer-valued, so the split is exact).  Every shard reads the
+// databases itself (N passes over the files).
+static int run_sharded(const Globals &G, int k, const mfx_db_info &rdb, const mfx_db_info &adb, const std::vector<SeqRecord> &recs,
+                       const std::vector<const char *> &bases, const std::vector<uint64_t> &lens, uint64_t totalBases) {
+  const uint32_t N = (uint32_t)G.devices.size();
+  std::vector<mfx_index *> ixs(N, nullptr);
+  std::vector<mfx_seq *> sqs(N, nullptr);
+  std::vector<mfx_eval *> evs(N, nullptr);
+  std::vector<mfx_router *> rts(N, nullptr);
+  mfx_kparams kp{G.peak, (uint32_t)G.copyKmerK.size(), G.copyKmerK.data(), G.copyKmerP.data()};
+  const uint64_t whole = rdb.n_kmers + (G.seqDBname ? adb.n_kmers : totalBases) + 1024;
+  const uint64_t capacity = (uint64_t)((double)whole / N * 1.15) + 1024;      // owners are hash-balanced
+  int rc = 0;
+  auto fail = [&](const char *what) { fprintf(stderr, "ERROR: %s: %s\n", what, mfx_last_error()); rc = 1; };
+  for (uint32_t d = 0; d < N && !rc; ++d) {
+    uint32_t same = d;
+    for (uint32_t e = 0; e < d; ++e) if (G.devices[e] == G.devices[d]) { same = e; break; }
+    if (!recs.empty() || G.seqName) {
+      sqs[d] = same < d ? sqs[same] : mfx_seq_upload(G.devices[d], bases.data(), lens.data(), (uint32_t)recs.size());
+      if (!sqs[d]) { fail("uploading sequences"); break; }
+    }
+    fprintf(stderr, "-- Shard %u of %u on device %d: loading the k-mers it owns.\n", d, N, G.devices[d]);
+    ixs[d] = mfx_index_create(k, capacity, G.maxMemory, G.devices[d]);
+    if (!ixs[d]) { fprintf(stderr, "\n%s\n\n", mfx_last_error()); rc = 1; break; }
+    if (mfx_index_set_shard(ixs[d], d, N) || mfx_index_load_db(ixs[d], G.readDBname, 0, G.minV, G.maxV)) { fail("loading -readmers"); break; }
+    if (G.seqDBname ? mfx_index_load_db(ixs[d], G.seqDBname, 1, 0, ~0ull) : mfx_index_count_asm(ixs[d], sqs[d], nullptr)) { fail("loading the assembly k-mers"); break; }
+    evs[d] = mfx_eval_create(ixs[d], &kp, 0);
+    if (!evs[d]) { fail("creating evaluator"); break; }
+    if (G.reportType == OP_HIST) {
+      const uint64_t nt = mfx_seq_num_tiles(sqs[d]);
+      rts[d] = mfx_router_create(ixs[d], N, (uint32_t)std::min<uint64_t>(16384, std::max<uint64_t>(1, nt)));
+      if (!rts[d]) { fail("creating router"); break; }
+    }
+  }
+  if (!rc && G.reportType == OP_HIST) {
+    fprintf(stderr, "-- Generate histogram of the k* metric to '%s' on %u devices (sharded index).\n", G.outName, N);
+    mfx_hist_result r;
+    if (mfx_hist_run_sharded(evs.data(), rts.data(), sqs.data(), N, &r)) fail("-hist over the sharded index");
+    else {
+      bool ok = true;
+      print_hist(recs, r, k, G.outName, &ok);
+      if (!ok) fail("writing histogram");
+      mfx_hist_result_free(&r);
+    }
+  } else if (!rc) {
+    fprintf(stderr, "-- Compute completeness on %u devices (sharded index).\n", N);
+    double t64[64] = {0}, u64[64] = {0};
+    for (uint32_t d = 0; d < N && !rc; ++d) {
+      double t[64], u[64];
+      if (mfx_completeness_pieces(evs[d], t, u)) { fail("-completeness"); break; }
+      for (int i = 0; i < 64; ++i) { t64[i] += t[i]; u64[i] += u[i]; }
+    }
+    if (!rc) print_completeness(t64, u64);
+  }
+  for (uint32_t d = 0; d < N; ++d) {
+    if (rts[d]) mfx_router_free(rts[d]);
+    if (evs[d]) mfx_eval_free(evs[d]);
+    if (ixs[d]) mfx_index_free(ixs[d]);
+    bool shared = false;
+    for (uint32_t e = 0; e < d; ++e) if (G.devices[e] == G.devices[d]) shared = true;
+    if (sqs[d] && !shared) mfx_seq_free(sqs[d]);
+  }
+  if (!rc) fprintf(stderr, "Bye!\n");
+  return rc;
+}
+
 #define DIE_MFX(what)                                                       \
   do {                                                                      \
     fprintf(stderr, "ERROR: %s: %s\n", what, mfx_last_error());             \
@@ -190,6 +284,7 @@ int main(int argc, char **argv) {
       if (!ok || G.devices.empty()) { G.devices.clear(); err.push_back(std::string("Invalid device list '") + spec + "' (-devices 0-7 or 0,2,5).\n"); }
     }
     else if (is("-index")) G.indexName = val();
+    else if (is("-sharded")) G.sharded = true;
     else if (is("-nosplit")) G.nosplit = true;
     else if (is("-filter")) G.reportType = OP_FILTER;
     else if (is("-better")) G.reportType = OP_BETTER;
@@ -273,6 +368,14 @@ int main(int argc, char **argv) {
   for (size_t i = 0; i < recs.size(); ++i) { bases[i] = recs[i].bases.data(); lens[i] = recs[i].bases.size(); totalBases += lens[i]; }
 
   lap("read sequences");
+  if (G.sharded) {
+    if (G.devices.size() < 2 || !(G.reportType == OP_HIST || G.reportType == OP_COMPL)) {
+      fprintf(stderr, "ERROR: -sharded applies to -hist and -completeness with at least two -devices.\n");
+      return 1;
+    }
+    if (G.indexName) { fprintf(stderr, "ERROR: -index caches a whole table; it cannot be combined with -sharded.\n"); return 1; }
+    return run_sharded(G, k, rdb, adb, recs, bases, lens, totalBases);
+  }
   mfx_index *ix = nullptr;
   mfx_seq *seq = nullptr;
   // -hist on one device with the assembly k-mers coming from -seqmers: nothing needs the sequence in HBM before the
@@ -372,13 +475,9 @@ int main(int argc, char **argv) {
     } else if (streamHist) {
       if (mfx_hist_run_streamed(ev, seq, bases.data(), &r)) DIE_MFX("-hist");
     } else if (mfx_hist_run(ev, seq, &r)) DIE_MFX("-hist");
-    uint64_t cum = 0;
-    for (size_t c = 0; c < recs.size(); ++c) {   // outputHistogram's per-sequence line, in input order
-      cum += r.contig_kmissing[c];
-      fprintf(stderr, "%s\t%lu\t%lu\t%lu\t%.2f\n", recs[c].name.c_str(), (unsigned long)r.contig_kmissing[c], (unsigned long)cum,
-              (unsigned long)r.contig_kasm[c], mfx_histoQV((double)r.contig_kmissing[c], (double)r.contig_kasm[c], k));
-    }
-    if (mfx_hist_report(&r, k, G.outName, "-")) DIE_MFX("writing histogram");
+    bool ok = true;
+    print_hist(recs, r, k, G.outName, &ok);
+    if (!ok) DIE_MFX("writing histogram");
     mfx_hist_result_free(&r);
   } else if (G.reportType == OP_DUMP) {
     fprintf(stderr, "-- Dump per-base k* metric to '%s'.\n", G.outName);
@@ -421,17 +520,9 @@ int main(int argc, char **argv) {
       DIE_MFX("variant scoring");
   } else if (G.reportType == OP_COMPL) {
     fprintf(stderr, "-- Compute completeness.\n");
-    double t64[64], u64[64], total = 0, undrc = 0;
+    double t64[64], u64[64];
     if (mfx_completeness_pieces(ev, t64, u64)) DIE_MFX("-completeness");
-    for (int ii = 0; ii < 64; ii++) {                     // merfin-completeness.C:119-120, here in piece order
-      fprintf(stderr, "thread %2u total %12.2f underc %15.5f completeness %0.8f\n", ii, t64[ii], u64[ii], 1.0 - u64[ii] / t64[ii]);
-      total += t64[ii];
-      undrc += u64[ii];
-    }
-    fprintf(stderr, "\n");
-    fprintf(stderr, "TOTAL readK:   %15.2f\n", total);
-    fprintf(stderr, "TOTAL undrcpy:    %15.5f\n", undrc);
-    fprintf(stderr, "COMPLETENESS:             %0.5f\n", 1.0 - undrc / total);
+    print_completeness(t64, u64);
   }
 
   lap("evaluate + write");

@@ -1419,6 +1419,120 @@ extern "C" int mfx_hist_keys_launch(mfx_eval *ev, const uint64_t *d_keys, const 
   return MFX_OK;
 }
 
+// Sharded index driven by ONE process (BASELINE config 5 from the C++ side): slot d holds shard d of N of the
+// k-mer table on its own device.  Per round, every slot routes a chunk of ITS tile range (k-mers grouped by owner,
+// sequence order kept), the groups travel to their owners by peer copy over xGMI -- the all-to-all of the
+// one-process-per-GPU form (merfin_amd/distributed.py::sharded_hist) -- and every owner probes / computes K* / bins
+// what it received, source by source in slot order (so koverCpy is a fixed-order sum).  The N counts images are added
+// on the host; kasm was counted at the sources, kmissing / bins / koverCpy at the owners.
+extern "C" int mfx_hist_run_sharded(mfx_eval *const *evs, mfx_router *const *routers, const mfx_seq *const *seqs, uint32_t ndev,
+                                    mfx_hist_result *out) {
+  if (!evs || !routers || !seqs || !out || ndev == 0) return mfx_fail(MFX_E_INVAL, "mfx_hist_run_sharded: null argument");
+  for (uint32_t d = 0; d < ndev; ++d) {
+    if (!evs[d] || !routers[d] || !seqs[d]) return mfx_fail(MFX_E_INVAL, "mfx_hist_run_sharded: null object for slot %u", d);
+    const mfx_index *ix = evs[d]->ix;
+    if (ix->shard_n != ndev || ix->shard_rank != d || routers[d]->ix != ix || routers[d]->nranks != ndev)
+      return mfx_fail(MFX_E_INVAL, "slot %u: its index must be shard %u of %u (mfx_index_set_shard) and its router built on it for %u ranks", d, d, ndev, ndev);
+    if (evs[d]->device != seqs[d]->device || evs[d]->nbins != evs[0]->nbins || seqs[d]->ntiles != seqs[0]->ntiles ||
+        seqs[d]->ncontigs != seqs[0]->ncontigs || routers[d]->max_tiles != routers[0]->max_tiles)
+      return mfx_fail(MFX_E_INVAL, "slot %u: evaluators / sequences / routers of one run must match each other", d);
+  }
+  const uint32_t nbins = evs[0]->nbins, ncontigs = seqs[0]->ncontigs, per = routers[0]->max_tiles;
+  const uint64_t T = seqs[0]->ntiles;
+  const size_t words = MFX_HIST_WORDS(nbins, ncontigs), cap = (size_t)per * MFX_TILE;
+  struct Slot {
+    uint64_t *d_counts = nullptr, *d_keys = nullptr, *d_rkeys = nullptr;
+    uint32_t *d_ctg = nullptr, *d_rctg = nullptr;
+    double *d_kover = nullptr;
+    hipStream_t st = nullptr;
+    std::vector<uint64_t> dest;      // k-mers this slot routed to each owner in the current round
+    int rc = MFX_OK;
+    std::string err;
+  };
+  std::vector<Slot> sl(ndev);
+  int rc = MFX_OK;
+  auto release = [&]() {
+    for (uint32_t d = 0; d < ndev; ++d) {
+      DevGuard g(evs[d]->device);
+      if (sl[d].st) (void)hipStreamSynchronize(sl[d].st);
+      void *p[] = {sl[d].d_counts, sl[d].d_keys, sl[d].d_rkeys, sl[d].d_ctg, sl[d].d_rctg, sl[d].d_kover};
+      for (void *x : p) if (x) (void)hipFree(x);
+      if (sl[d].st) (void)hipStreamDestroy(sl[d].st);
+    }
+  };
+  for (uint32_t d = 0; d < ndev && rc == MFX_OK; ++d) {
+    DevGuard g(evs[d]->device);
+    sl[d].dest.assign(ndev, 0);
+    if (hipStreamCreateWithFlags(&sl[d].st, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc((void **)&sl[d].d_counts, words * sizeof(uint64_t)) != hipSuccess || hipMalloc((void **)&sl[d].d_kover, sizeof(double)) != hipSuccess ||
+        hipMalloc((void **)&sl[d].d_keys, cap * 8) != hipSuccess || hipMalloc((void **)&sl[d].d_rkeys, cap * 8) != hipSuccess ||
+        hipMalloc((void **)&sl[d].d_ctg, cap * 4) != hipSuccess || hipMalloc((void **)&sl[d].d_rctg, cap * 4) != hipSuccess ||
+        hipMemsetAsync(sl[d].d_counts, 0, words * sizeof(uint64_t), sl[d].st) != hipSuccess ||
+        hipMemsetAsync(sl[d].d_kover, 0, sizeof(double), sl[d].st) != hipSuccess ||
+        hipMemsetAsync(evs[d]->d_ovf, 0, sizeof(uint64_t), sl[d].st) != hipSuccess)
+      rc = mfx_fail(MFX_E_NOMEM, "mfx_hist_run_sharded: buffers for slot %u (%zu k-mers per round) could not be set up", d, cap);
+    for (uint32_t e = 0; e < d && rc == MFX_OK; ++e)
+      if (evs[e]->device != evs[d]->device) {
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, evs[d]->device, evs[e]->device) == hipSuccess && can && hipDeviceEnablePeerAccess(evs[e]->device, 0) != hipSuccess)
+          (void)hipGetLastError();                            // already enabled
+      }
+  }
+  const uint64_t rounds = ((T + ndev - 1) / ndev + per - 1) / per;
+  for (uint64_t r = 0; r < rounds && rc == MFX_OK; ++r) {
+    // ---- route: all slots at once (each call blocks until its group sizes are on the host)
+    std::vector<std::thread> th;
+    for (uint32_t d = 0; d < ndev; ++d)
+      th.emplace_back([&, d]() {
+        const uint64_t lo = T * d / ndev, hi = T * (d + 1) / ndev;
+        const uint64_t tb = std::min(hi, lo + r * per), te = std::min(hi, tb + per);
+        sl[d].rc = mfx_route_tiles(routers[d], seqs[d], tb, te, nbins, sl[d].d_counts, sl[d].d_keys, sl[d].d_ctg, sl[d].dest.data(), sl[d].st);
+        if (sl[d].rc) sl[d].err = mfx_last_error();
+      });
+    for (auto &x : th) x.join();
+    for (uint32_t d = 0; d < ndev && rc == MFX_OK; ++d)
+      if (sl[d].rc) rc = mfx_fail(sl[d].rc, "slot %u: %s", d, sl[d].err.c_str());
+    if (rc) break;
+    // ---- exchange + evaluate: owner o takes its group from every source in slot order
+    for (uint32_t o = 0; o < ndev && rc == MFX_OK; ++o) {
+      DevGuard g(evs[o]->device);
+      for (uint32_t s2 = 0; s2 < ndev && rc == MFX_OK; ++s2) {
+        const uint64_t n = sl[s2].dest[o];
+        if (!n) continue;
+        uint64_t off = 0;
+        for (uint32_t q = 0; q < o; ++q) off += sl[s2].dest[q];
+        hipError_t e = hipMemcpyPeerAsync(sl[o].d_rkeys, evs[o]->device, sl[s2].d_keys + off, evs[s2]->device, n * 8, sl[o].st);
+        if (e == hipSuccess) e = hipMemcpyPeerAsync(sl[o].d_rctg, evs[o]->device, sl[s2].d_ctg + off, evs[s2]->device, n * 4, sl[o].st);
+        if (e != hipSuccess) { rc = mfx_fail(MFX_E_HIP, "peer copy of %lu routed k-mers from slot %u to slot %u failed: %s", (unsigned long)n, s2, o, hipGetErrorString(e)); break; }
+        rc = mfx_hist_keys_launch(evs[o], sl[o].d_rkeys, sl[o].d_rctg, n, ncontigs, sl[o].d_counts, sl[o].d_kover, sl[o].st);
+      }
+    }
+    // the sources' buffers are rewritten by the next round's routing: every owner must have taken its groups
+    for (uint32_t d = 0; d < ndev; ++d) {
+      DevGuard g(evs[d]->device);
+      if (hipStreamSynchronize(sl[d].st) != hipSuccess && rc == MFX_OK) rc = mfx_fail(MFX_E_HIP, "mfx_hist_run_sharded: slot %u failed: %s", d, hipGetErrorString(hipGetLastError()));
+    }
+  }
+  std::vector<uint64_t> sum(words, 0), h(words);
+  double kover = 0.0;
+  for (uint32_t d = 0; d < ndev && rc == MFX_OK; ++d) {
+    DevGuard g(evs[d]->device);
+    double kv = 0.0;
+    if (hipMemcpy(h.data(), sl[d].d_counts, words * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(&kv, sl[d].d_kover, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { rc = mfx_fail(MFX_E_HIP, "mfx_hist_run_sharded: D2H of slot %u failed", d); break; }
+    for (size_t i = 0; i < words; ++i) sum[i] += h[i];
+    kover = kover + kv;                                       // slot order: fixed-order fp64 sum
+    sl[d].dest.assign(1, h[2ull * nbins + 2]);                // this slot's overflow count
+  }
+  if (rc == MFX_OK) rc = mfx_hist_result_from_counts(nbins, sum.data(), kover, ncontigs, out);
+  if (rc == MFX_OK) {
+    for (uint32_t d = 0; d < ndev && rc == MFX_OK; ++d) rc = result_take_overflow(evs[d], sl[d].dest[0], out);
+    if (rc) mfx_hist_result_free(out);
+  }
+  release();
+  return rc;
+}
+
 // ---------------------------------------------------------------------------
 // -dump
 // ---------------------------------------------------------------------------

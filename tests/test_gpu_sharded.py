@@ -204,3 +204,43 @@ def test_sharded_hist_two_processes_one_gpu(tmp_path):
     port = 29700 + os.getpid() % 1500
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok").read_text() == "1"
+
+
+@pytest.mark.parametrize("world,k,per", [(2, 21, 3), (4, 31, 2), (8, 31, 1000)])
+def test_sharded_hist_one_process(world, k, per):
+    """mfx_hist_run_sharded: the whole sharded -hist (route -> peer copies to the owners -> evaluate -> sum) driven by one
+    process; the slots are shards of one table, here all on device 0.  `per` = tiles routed per round (several rounds / one)."""
+    import merfin_amd as m
+    peak = 17.3
+    contigs, read, asm = synth.world(k=k, peak=peak, seed=91)
+    p, g, ka, km = oracle_hist(k, peak, contigs, read, asm)
+    shards = _build_shards(m, k, read, asm, world, contigs, count_from_seq=True)
+    evs = [m.Evaluator(s, m.KParams(peak)) for s in shards]
+    seqs = m.Sequences(contigs)
+    routers = [m.Router(s, world, min(per, seqs.ntiles)) for s in shards]
+    res = m.hist_sharded(evs, routers, [seqs] * world)
+    assert_hist_equal(res, g, ka, km, k)
+    again = m.hist_sharded(evs, routers, [seqs] * world)
+    assert again.koverCpy == res.koverCpy and again.kmissing == res.kmissing     # repeatable, buffers re-armed
+    with pytest.raises(m.MfxError):                          # the slots must be shard 0..N-1 in order
+        m.hist_sharded(evs[::-1], routers[::-1], [seqs] * world)
+
+
+def test_cli_sharded_hist_and_completeness(tmp_path, golden_dir):
+    """`merfin -hist -devices 0,0,0 -sharded` and `-completeness ... -sharded`: byte-identical to the unsharded CLI"""
+    import subprocess
+    exe = os.path.join(ROOT, "merfin_amd", "bin", "merfin")
+    g = lambda n: os.path.join(golden_dir, n)
+    common = ["-sequence", g("case1.fasta"), "-readmers", g("case1.read.kmers.txt"), "-peak", "17.3", "-prob", g("example_lookup_table.txt")]
+    r = subprocess.run([exe, "-hist"] + common + ["-output", str(tmp_path / "s.hist"), "-devices", "0,0,0", "-sharded"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "s.hist").read_bytes() == open(g("case1.hist"), "rb").read()
+    assert open(g("case1.summary")).read() in r.stderr and "Shard 2 of 3" in r.stderr
+    cargs = ["-completeness", "-readmers", g("case1.read.kmers.txt"), "-seqmers", g("case1.asm.kmers.txt"), "-peak", "17.3"]
+    a = subprocess.run([exe] + cargs, capture_output=True, text=True)
+    b = subprocess.run([exe] + cargs + ["-devices", "0,0", "-sharded"], capture_output=True, text=True)
+    assert a.returncode == 0 and b.returncode == 0, b.stderr
+    tail = lambda s: s[s.index("thread  0 total"):]
+    assert tail(a.stderr) == tail(b.stderr)
+    bad = subprocess.run([exe, "-dump"] + common + ["-output", str(tmp_path / "x"), "-devices", "0,0", "-sharded"], capture_output=True, text=True)
+    assert bad.returncode == 1 and "-sharded applies to -hist and -completeness" in bad.stderr
