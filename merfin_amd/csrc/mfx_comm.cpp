@@ -27,6 +27,18 @@ struct mfx_comm {
   uint64_t *d_novf = nullptr;        // [nranks] overflow records per rank
 };
 
+namespace {
+struct DeviceScope {             // run on `dev`, give the caller's device back afterwards
+  int prev = -1;
+  bool ok = false;
+  explicit DeviceScope(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    ok = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+}  // namespace
+
 #define MFX_NCCL(call)                                                                                   \
   do {                                                                                                   \
     ncclResult_t r_ = (call);                                                                            \
@@ -48,7 +60,8 @@ extern "C" mfx_comm *mfx_comm_create(const void *id, int rank, int nranks, int d
              "mfx_comm_create: bad argument (rank %d of %d, device %d of %d)", rank, nranks, device, mfx_device_count());
     return nullptr;
   }
-  if (hipSetDevice(device) != hipSuccess) { mfx_fail(MFX_E_HIP, "hipSetDevice(%d) failed", device); return nullptr; }
+  DeviceScope ds(device);
+  if (!ds.ok) { mfx_fail(MFX_E_HIP, "hipSetDevice(%d) failed", device); return nullptr; }
   mfx_comm *c = new mfx_comm;
   c->rank = rank; c->nranks = nranks; c->device = device;
   ncclUniqueId u;
@@ -70,7 +83,7 @@ extern "C" mfx_comm *mfx_comm_create(const void *id, int rank, int nranks, int d
 
 extern "C" void mfx_comm_free(mfx_comm *c) {
   if (!c) return;
-  (void)hipSetDevice(c->device);
+  DeviceScope ds(c->device);
   if (c->d_gather) (void)hipFree(c->d_gather);
   if (c->d_novf) (void)hipFree(c->d_novf);
   if (c->comm) (void)ncclCommDestroy(c->comm);
@@ -83,7 +96,8 @@ extern "C" int mfx_comm_size(const mfx_comm *c) { return c ? c->nranks : 0; }
 // all ranks have reached this point and `stream` has drained (a one-word all-reduce + a stream synchronise)
 extern "C" int mfx_comm_barrier(mfx_comm *c, void *stream) {
   if (!c) return mfx_fail(MFX_E_INVAL, "mfx_comm_barrier: null argument");
-  if (hipSetDevice(c->device) != hipSuccess) return mfx_fail(MFX_E_HIP, "hipSetDevice(%d) failed", c->device);
+  DeviceScope ds(c->device);
+  if (!ds.ok) return mfx_fail(MFX_E_HIP, "hipSetDevice(%d) failed", c->device);
   hipStream_t st = (hipStream_t)stream;
   MFX_HIP(hipMemsetAsync(c->d_novf, 0, sizeof(uint64_t), st));
   MFX_NCCL(ncclAllReduce(c->d_novf, c->d_novf, 1, ncclUint64, ncclSum, c->comm, st));
@@ -96,7 +110,8 @@ hipError_t mfx_k_ordered_sum(const double *v, uint32_t n, double *out, hipStream
 // in place on every rank; asynchronous on `stream`
 extern "C" int mfx_hist_allreduce(mfx_comm *c, uint64_t *d_counts, double *d_kover, uint32_t nbins, uint32_t ncontigs, void *stream) {
   if (!c || !d_counts || !d_kover || !nbins) return mfx_fail(MFX_E_INVAL, "mfx_hist_allreduce: null argument");
-  if (hipSetDevice(c->device) != hipSuccess) return mfx_fail(MFX_E_HIP, "hipSetDevice(%d) failed", c->device);
+  DeviceScope ds(c->device);
+  if (!ds.ok) return mfx_fail(MFX_E_HIP, "hipSetDevice(%d) failed", c->device);
   hipStream_t st = (hipStream_t)stream;
   const size_t words = MFX_HIST_WORDS(nbins, ncontigs);
   MFX_NCCL(ncclAllReduce(d_counts, d_counts, words, ncclUint64, ncclSum, c->comm, st));
@@ -109,7 +124,8 @@ extern "C" int mfx_hist_allreduce(mfx_comm *c, uint64_t *d_counts, double *d_kov
 // reduced image's novf word (counts[2*nbins + 2]) is non-zero -- it is the same on every rank after the all-reduce.
 extern "C" int mfx_hist_allgather_overflow(mfx_comm *c, mfx_eval *ev, uint64_t *records, uint64_t cap, uint64_t *n_out, void *stream) {
   if (!c || !ev || !n_out) return mfx_fail(MFX_E_INVAL, "mfx_hist_allgather_overflow: null argument");
-  if (hipSetDevice(c->device) != hipSuccess) return mfx_fail(MFX_E_HIP, "hipSetDevice(%d) failed", c->device);
+  DeviceScope ds(c->device);
+  if (!ds.ok) return mfx_fail(MFX_E_HIP, "hipSetDevice(%d) failed", c->device);
   hipStream_t st = (hipStream_t)stream;
   // ev->d_ovf: [0] = this rank's count, [1..] = its records
   MFX_NCCL(ncclAllGather(ev->d_ovf, c->d_novf, 1, ncclUint64, c->comm, st));
