@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -52,7 +53,8 @@ static void usage(const char *exe) {
           "    -device d         HIP device (default 0)\n"
           "    -devices list     several GPUs of this node driven by this one process, e.g. 0-7 or 0,2,5 (-hist: the index is\n"
           "                      built once and copied to the others over xGMI, every GPU evaluates its share of the\n"
-          "                      sequence, the histograms are added; other report types use the first device)\n"
+          "                      sequence, the histograms are added; -dump and the variant modes: every GPU takes a contiguous\n"
+          "                      run of contigs, the outputs are concatenated in order; -completeness uses the first device)\n"
           "    -sharded          with -devices, for -hist and -completeness: every GPU keeps only its share of the k-mer table\n"
           "                      (read databases too large for one GPU); k-mers are routed to the GPU that owns them\n"
           "    -index file       cache of the built HBM index: loaded if it exists (the k-mer databases are then not\n"
@@ -237,6 +239,91 @@ static int run_sharded(const Globals &G, int k, const mfx_db_info &rdb, const mf
   }
   if (!rc) fprintf(stderr, "Bye!\n");
   return rc;
+}
+
+// One evaluation context per entry of -devices: slot 0 is the index / sequence / evaluator the run built, the others
+// are replicas made by peer copy (a device named twice shares table and sequence; every slot has its own evaluator).
+struct Slots {
+  std::vector<mfx_index *> ixs;
+  std::vector<mfx_seq *> sqs;
+  std::vector<mfx_eval *> evs;
+  std::vector<int> devs;
+  bool make(const Globals &G, mfx_index *ix, mfx_seq *seq, mfx_eval *ev, const mfx_kparams *kp) {
+    const size_t N = G.devices.size();
+    devs = G.devices;
+    ixs.assign(N, nullptr); sqs.assign(N, nullptr); evs.assign(N, nullptr);
+    ixs[0] = ix; sqs[0] = seq; evs[0] = ev;
+    for (size_t d = 1; d < N; ++d) {
+      size_t same = d;
+      for (size_t e = 0; e < d; ++e) if (devs[e] == devs[d]) { same = e; break; }
+      ixs[d] = same < d ? ixs[same] : mfx_index_replicate(ix, devs[d]);
+      sqs[d] = same < d ? sqs[same] : (seq ? mfx_seq_replicate(seq, devs[d]) : nullptr);
+      evs[d] = (ixs[d] && (sqs[d] || !seq)) ? mfx_eval_create(ixs[d], kp, 0) : nullptr;
+      if (!evs[d]) return false;
+    }
+    return true;
+  }
+  void release() {                       // slot 0 belongs to the caller
+    for (size_t d = 1; d < evs.size(); ++d) {
+      if (evs[d]) mfx_eval_free(evs[d]);
+      bool shared = false;
+      for (size_t e = 0; e < d; ++e) if (devs[e] == devs[d]) shared = true;
+      if (!shared) { if (sqs[d]) mfx_seq_free(sqs[d]); if (ixs[d]) mfx_index_free(ixs[d]); }
+    }
+    evs.clear();
+  }
+};
+
+// contiguous split of the contigs (input order) into `parts` runs of about equal weight; every slot works on its run
+// and the outputs are concatenated in slot order -- the reference's SLURM-array recipe (scripts/parallel1/merfin.sh:68-85)
+static std::vector<std::pair<size_t, size_t>> contig_partition(const std::vector<double> &w, size_t parts) {
+  const size_t n = w.size();
+  std::vector<double> cum(n + 1, 0.0);
+  for (size_t i = 0; i < n; ++i) cum[i + 1] = cum[i] + w[i];
+  std::vector<size_t> cuts(1, 0);
+  for (size_t r = 1; r < parts; ++r) {
+    size_t c = cum[n] > 0 ? (size_t)(std::lower_bound(cum.begin(), cum.end(), cum[n] * (double)r / (double)parts) - cum.begin()) : n * r / parts;
+    cuts.push_back(std::min(n, std::max(cuts.back(), c)));
+  }
+  cuts.push_back(n);
+  std::vector<std::pair<size_t, size_t>> out;
+  for (size_t r = 0; r < parts; ++r) out.emplace_back(cuts[r], cuts[r + 1]);
+  return out;
+}
+
+// parts -> out (slot order); skip_header: the '#' lines of every part but the first are dropped (VCF)
+static bool concat_parts(const std::string &out, const std::vector<std::string> &parts, bool skip_header) {
+  FILE *o = fopen(out.c_str(), "wb");
+  if (!o) return false;
+  std::vector<char> buf(1 << 22);
+  bool ok = true;
+  for (size_t i = 0; i < parts.size() && ok; ++i) {
+    FILE *f = fopen(parts[i].c_str(), "rb");
+    if (!f) continue;                                         // a slot without contigs wrote nothing
+    bool at_line_start = true, in_header = false;
+    size_t n;
+    while ((n = fread(buf.data(), 1, buf.size(), f)) > 0 && ok) {
+      if (!(skip_header && i > 0)) { ok = fwrite(buf.data(), 1, n, o) == n; continue; }
+      size_t b = 0;                                           // copy everything except lines starting with '#'
+      for (size_t j = 0; j < n; ++j) {
+        if (at_line_start) {
+          if (!in_header && j > b) ok = ok && fwrite(buf.data() + b, 1, j - b, o) == j - b;
+          in_header = buf[j] == '#';
+          b = j;
+          at_line_start = false;
+        }
+        if (buf[j] == '\n') {
+          at_line_start = true;
+          if (in_header) b = j + 1;
+        }
+      }
+      if (!in_header && n > b) ok = ok && fwrite(buf.data() + b, 1, n - b, o) == n - b;
+      if (in_header) b = n;
+    }
+    fclose(f);
+    remove(parts[i].c_str());
+  }
+  return fclose(o) == 0 && ok;
 }
 
 #define DIE_MFX(what)                                                       \
@@ -447,30 +534,13 @@ int main(int argc, char **argv) {
       // one process, N devices (the reference drives all its workers from one binary, merfin.C:366-414): replicas of
       // the table and of the packed assembly by peer copy, every device evaluates its block-cyclic share
       const size_t N = G.devices.size();
-      std::vector<mfx_index *> ixs(N, nullptr);
-      std::vector<mfx_seq *> sqs(N, nullptr);
-      std::vector<mfx_eval *> evs(N, nullptr);
-      ixs[0] = ix; sqs[0] = seq; evs[0] = ev;
-      int bad = 0;
-      for (size_t d = 1; d < N && !bad; ++d) {
-        size_t same = d;
-        for (size_t e = 0; e < d; ++e) if (G.devices[e] == G.devices[d]) { same = e; break; }
-        // a device named twice shares the table and the sequence; every slot has its own evaluator
-        ixs[d] = same < d ? ixs[same] : mfx_index_replicate(ix, G.devices[d]);
-        sqs[d] = same < d ? sqs[same] : mfx_seq_replicate(seq, G.devices[d]);
-        evs[d] = (ixs[d] && sqs[d]) ? mfx_eval_create(ixs[d], &kp, 0) : nullptr;
-        if (!evs[d]) bad = 1;
-      }
+      Slots S;
+      int bad = S.make(G, ix, seq, ev, &kp) ? 0 : 1;
       lap("replicate index");
       fprintf(stderr, "-- Evaluating on %zu devices.\n", N);
-      if (!bad && mfx_hist_run_multi(evs.data(), sqs.data(), (uint32_t)N, &r)) bad = 1;
+      if (!bad && mfx_hist_run_multi(S.evs.data(), S.sqs.data(), (uint32_t)N, &r)) bad = 1;
       std::string why = bad ? mfx_last_error() : "";
-      for (size_t d = 1; d < N; ++d) {
-        if (evs[d]) mfx_eval_free(evs[d]);
-        bool shared = false;
-        for (size_t e = 0; e < d; ++e) if (G.devices[e] == G.devices[d]) shared = true;
-        if (!shared) { if (sqs[d]) mfx_seq_free(sqs[d]); if (ixs[d]) mfx_index_free(ixs[d]); }
-      }
+      S.release();
       if (bad) { fprintf(stderr, "ERROR: -hist on %zu devices: %s\n", N, why.c_str()); return 1; }
     } else if (streamHist) {
       if (mfx_hist_run_streamed(ev, seq, bases.data(), &r)) DIE_MFX("-hist");
@@ -492,6 +562,43 @@ int main(int argc, char **argv) {
         fprintf(stderr, "%s\t%lu\t%lu\t%lu\n", recs[c].name.c_str(), (unsigned long)r.contig_kmissing[c], (unsigned long)cumMissing, (unsigned long)cumAsm);
       }
       mfx_hist_result_free(&r);
+    } else if (G.devices.size() > 1) {
+      // per-contig ordered output on N devices: a contiguous run of contigs per slot (balanced by bases), one host
+      // thread per slot writes its part, the parts are concatenated in slot order
+      const size_t N = G.devices.size();
+      Slots S;
+      if (!S.make(G, ix, seq, ev, &kp)) { fprintf(stderr, "ERROR: -dump on %zu devices: %s\n", N, mfx_last_error()); return 1; }
+      lap("replicate index");
+      fprintf(stderr, "-- Evaluating on %zu devices.\n", N);
+      std::vector<double> w(recs.size());
+      for (size_t c = 0; c < recs.size(); ++c) w[c] = (double)lens[c];
+      const auto runs = contig_partition(w, N);
+      std::vector<std::string> parts(N), errs(N);
+      std::vector<std::vector<uint64_t>> ka(N), km(N);
+      std::vector<std::thread> th;
+      for (size_t d = 0; d < N; ++d) {
+        char suf[32];
+        snprintf(suf, sizeof(suf), ".part%04zu", d);
+        parts[d] = std::string(G.outName) + suf;
+        th.emplace_back([&, d]() {
+          for (size_t c = runs[d].first; c < runs[d].second; ++c) {
+            uint64_t a = 0, m2 = 0;
+            if (mfx_dump_contig(S.evs[d], S.sqs[d], (uint32_t)c, recs[c].name.c_str(), parts[d].c_str(), c > runs[d].first, &a, &m2)) { errs[d] = mfx_last_error(); return; }
+            ka[d].push_back(a);
+            km[d].push_back(m2);
+          }
+        });
+      }
+      for (auto &x : th) x.join();
+      S.release();
+      for (size_t d = 0; d < N; ++d) if (!errs[d].empty()) { fprintf(stderr, "ERROR: -dump (slot %zu): %s\n", d, errs[d].c_str()); return 1; }
+      if (!concat_parts(G.outName, parts, false)) { fprintf(stderr, "ERROR: cannot write '%s'.\n", G.outName); return 1; }
+      for (size_t d = 0; d < N; ++d)
+        for (size_t i = 0; i < ka[d].size(); ++i) {
+          cumMissing += km[d][i];
+          cumAsm += ka[d][i];
+          fprintf(stderr, "%s\t%lu\t%lu\t%lu\n", recs[runs[d].first + i].name.c_str(), (unsigned long)km[d][i], (unsigned long)cumMissing, (unsigned long)cumAsm);
+        }
     } else {
       for (size_t c = 0; c < recs.size(); ++c) {
         uint64_t ka = 0, km = 0;
@@ -516,7 +623,61 @@ int main(int argc, char **argv) {
     vo.nosplit = G.nosplit ? 1 : 0;
     vo.debug_path = G.debug ? dbgName.c_str() : nullptr;
     uint64_t ncl = 0;
-    if (mfx_variants_run(ev, G.vcfName, names.data(), bases.data(), lens.data(), (uint32_t)recs.size(), &vo, outName.c_str(), nullptr, &ncl))
+    if (G.devices.size() > 1) {
+      // BASELINE config 4 names 8 GPUs: contigs cut into one contiguous run per slot, balanced by their VCF records;
+      // every slot scores its clusters on its own device and writes its part; one VCF header in the concatenation
+      const size_t N = G.devices.size();
+      std::vector<double> w(recs.size(), 0.0);
+      {
+        mfx_file vf = mfx_open_reader(G.vcfName);
+        if (!vf.f) { fprintf(stderr, "ERROR: cannot open VCF '%s'.\n", G.vcfName); return 1; }
+        std::vector<std::pair<std::string, size_t>> idx;
+        for (size_t c = 0; c < recs.size(); ++c) idx.emplace_back(recs[c].name, c);
+        std::sort(idx.begin(), idx.end());
+        char *L = nullptr;
+        size_t cap = 0;
+        ssize_t n;
+        while ((n = getline(&L, &cap, vf.f)) >= 0) {
+          if (n == 0 || L[0] == '#') continue;
+          const char *tab = (const char *)memchr(L, '\t', (size_t)n);
+          if (!tab) continue;
+          std::string chr(L, tab - L);
+          auto it = std::lower_bound(idx.begin(), idx.end(), std::make_pair(chr, (size_t)0));
+          if (it != idx.end() && it->first == chr) w[it->second] += 1.0;
+        }
+        free(L);
+        (void)mfx_close(vf);
+        for (size_t c = 0; c < recs.size(); ++c) w[c] += 1e-9 * (double)lens[c];
+      }
+      Slots S;
+      if (!S.make(G, ix, nullptr, ev, &kp)) { fprintf(stderr, "ERROR: variant scoring on %zu devices: %s\n", N, mfx_last_error()); return 1; }
+      lap("replicate index");
+      fprintf(stderr, "-- Evaluating on %zu devices.\n", N);
+      const auto runs = contig_partition(w, N);
+      std::vector<std::string> parts(N), errs(N), dbgs(N);
+      std::vector<uint64_t> ncls(N, 0);
+      std::vector<std::thread> th;
+      for (size_t d = 0; d < N; ++d) {
+        char suf[48];
+        snprintf(suf, sizeof(suf), ".part%04zu", d);
+        parts[d] = outName + suf;
+        snprintf(suf, sizeof(suf), ".%02zu.debug.gz", d);
+        dbgs[d] = std::string(G.outName) + suf;
+        th.emplace_back([&, d]() {
+          mfx_variant_opts o = vo;
+          o.debug_path = G.debug ? dbgs[d].c_str() : nullptr;
+          const size_t lo = runs[d].first, hi = runs[d].second;
+          if (mfx_variants_run(S.evs[d], G.vcfName, names.data() + lo, bases.data() + lo, lens.data() + lo, (uint32_t)(hi - lo), &o, parts[d].c_str(),
+                               nullptr, &ncls[d]))
+            errs[d] = mfx_last_error();
+        });
+      }
+      for (auto &x : th) x.join();
+      S.release();
+      for (size_t d = 0; d < N; ++d) if (!errs[d].empty()) { fprintf(stderr, "ERROR: variant scoring (slot %zu): %s\n", d, errs[d].c_str()); return 1; }
+      if (!concat_parts(outName, parts, true)) { fprintf(stderr, "ERROR: cannot write '%s'.\n", outName.c_str()); return 1; }
+      for (uint64_t x : ncls) ncl += x;
+    } else if (mfx_variants_run(ev, G.vcfName, names.data(), bases.data(), lens.data(), (uint32_t)recs.size(), &vo, outName.c_str(), nullptr, &ncl))
       DIE_MFX("variant scoring");
   } else if (G.reportType == OP_COMPL) {
     fprintf(stderr, "-- Compute completeness.\n");

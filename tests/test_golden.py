@@ -91,3 +91,26 @@ def test_cli_reproduces_golden(tmp_path):
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
         assert open(out + suffix, "rb").read() == open(G + "/case1.%s.vcf" % mode, "rb").read()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0,0,0"])
+def test_cli_ordered_outputs_on_several_devices(tmp_path, devices):
+    """-dump and the variant modes with -devices: every slot (here all on GPU 0) takes a contiguous run of contigs, the
+    parts are concatenated in order -- byte-identical to the golden single-device outputs (BASELINE config 4 names 8 GPUs);
+    with more slots than contigs some slots stay empty"""
+    common = ["-sequence", G + "/case1.fasta", "-readmers", G + "/case1.read.kmers.txt", "-seqmers", G + "/case1.asm.kmers.txt",
+              "-peak", str(PEAK), "-prob", G + "/example_lookup_table.txt", "-devices", devices]
+    r = subprocess.run([EXE, "-dump"] + common + ["-output", str(tmp_path / "d")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "d").read_bytes() == open(G + "/case1.dump", "rb").read()
+    assert not [f for f in os.listdir(tmp_path) if ".part" in f]
+    r1 = subprocess.run([EXE, "-dump"] + common[:-2] + ["-output", str(tmp_path / "d1")], capture_output=True, text=True)
+    per_contig = lambda s: [l for l in s.splitlines() if l.count("\t") == 3 and not l.startswith("--")]
+    assert per_contig(r.stderr) == per_contig(r1.stderr) and len(per_contig(r.stderr)) > 1
+    for mode, suffix in (("polish", ".polish.vcf"), ("filter", ".filter.vcf"), ("loose", ".filter.vcf")):
+        out = str(tmp_path / mode)
+        r = subprocess.run([EXE, "-" + mode] + common + ["-vcf", G + "/case1.vcf", "-comb", str(COMB), "-output", out],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert open(out + suffix, "rb").read() == open(G + "/case1.%s.vcf" % mode, "rb").read()
