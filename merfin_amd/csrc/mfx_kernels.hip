@@ -1170,7 +1170,8 @@ hipError_t mfx_k_table_add(mfx_table_view t, const uint64_t *kmers, const uint32
   if (n == 0) return hipSuccess;
   uint64_t blocks = (n + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  static const int mode = getenv("MFX_INSERT_MODE") ? atoi(getenv("MFX_INSERT_MODE")) : 1;
+  const char *me = getenv("MFX_INSERT_MODE");             // read per call: tests switch it
+  const int mode = me ? atoi(me) : 1;
   if (mode == 0)      mfx_table_add_kernel<0><<<(unsigned)blocks, 256, 0, st>>>(t, kmers, values, n, side, meta);
   else                mfx_table_add_kernel<1><<<(unsigned)blocks, 256, 0, st>>>(t, kmers, values, n, side, meta);
   return hipGetLastError();
@@ -1260,7 +1261,8 @@ hipError_t mfx_k_dump(const mfx_dump_args &a, hipStream_t st) {
 hipError_t mfx_k_count(const mfx_count_args &a, hipStream_t st) {
   if (a.ntiles == 0) return hipSuccess;
   uint64_t blocks = a.ntiles < 8192 ? a.ntiles : 8192;
-  static const int mode = getenv("MFX_COUNT_MODE") ? atoi(getenv("MFX_COUNT_MODE")) : 0;
+  const char *me = getenv("MFX_COUNT_MODE");
+  const int mode = me ? atoi(me) : 0;
   if (mode == 1)      mfx_count_kernel<1><<<(unsigned)blocks, MFX_BLOCK, 0, st>>>(a);
   else                mfx_count_kernel<0><<<(unsigned)blocks, MFX_BLOCK, 0, st>>>(a);
   return hipGetLastError();

@@ -469,3 +469,32 @@ def test_index_full_is_reported():
     with pytest.raises(m.MfxError) as e:
         ix.add_asm(kmers, np.ones(len(kmers), dtype=np.uint32))
     assert e.value.code == -4
+
+
+@pytest.mark.parametrize("insert_mode,count_mode", [("0", "0"), ("1", "1"), ("0", "1"), ("1", "0")])
+def test_both_insert_strategies_build_the_same_table(insert_mode, count_mode, monkeypatch):
+    """The index build has two insert strategies per kernel (cooperative batched passes / per-lane walk; defaults: table
+    adds cooperative, assembly counter per-lane).  Either must produce the same table: duplicates summed, one slot per
+    k-mer, results equal to the oracle -- including many inserts of the SAME k-mer racing each other."""
+    m = _mfx()
+    monkeypatch.setenv("MFX_INSERT_MODE", insert_mode)
+    monkeypatch.setenv("MFX_COUNT_MODE", count_mode)
+    k, peak = 21, 17.3
+    contigs, read, asm = synth.world(k=k, peak=peak, seed=61, sizes=(60000, 9000, 4097, 20, 0), tandem=(5, 400))
+    p, g, ka, km = oracle_hist(k, peak, contigs, read, asm)
+    seqs = m.Sequences(contigs)
+    ix = m.Index(k, len(read[0]) + len(asm[0]) + 16)
+    # every read k-mer inserted as `value` separate inserts of 1, shuffled: heavy same-key contention
+    r = synth.rng(5)
+    occ = np.repeat(read[0], np.minimum(read[1], 40).astype(np.int64))
+    rest = (read[1] - np.minimum(read[1], 40)).astype(np.uint32)
+    r.shuffle(occ)
+    ix.add_read(occ, np.ones(len(occ), dtype=np.uint32))
+    ix.add_read(read[0][rest > 0], rest[rest > 0])
+    ix.count_asm(seqs)                                        # homopolymer / tandem stretches: the same k-mer from neighbouring lanes
+    ek, er, ea = ix.export()
+    union = np.union1d(read[0], asm[0])
+    np.testing.assert_array_equal(ek, union)                  # one slot per k-mer
+    np.testing.assert_array_equal(er[np.isin(ek, read[0])], read[1])
+    np.testing.assert_array_equal(ea[np.isin(ek, asm[0])], asm[1])
+    assert_hist_equal(m.Evaluator(ix, m.KParams(peak)).hist(seqs), g, ka, km, k)
