@@ -100,6 +100,9 @@ int mfx_db_probe(const char *path, mfx_db_info *out);
 /* merylExactLookup::load from disk: side 0 = read DB (-min/-max apply,
  * merfin-globals.C:156), side 1 = assembly DB (:159). */
 int mfx_index_load_db(mfx_index *ix, const char *path, int side, uint64_t minV, uint64_t maxV);
+/* the same into several tables with ONE pass over the database: the shards of one process (mfx_index_set_shard), each
+ * keeping the k-mers it owns -- the chunk is staged once and sent to every table's device */
+int mfx_index_load_db_multi(mfx_index *const *ixs, uint32_t nix, const char *path, int side, uint64_t minV, uint64_t maxV);
 int mfx_db_write_flat(const char *path, int k, const uint64_t *kmers, const uint32_t *values, uint64_t n);
 
 /* The built table as a device-format image on disk: later runs on the same databases skip the decode +

@@ -10,9 +10,9 @@ without the HIP library or without a GPU raises.
 from .binding import (  # noqa: F401
     MfxError, Index, Sequences, Evaluator, Router, HistResult, KParams,
     lib_path, load_library, device_count, getK, getKmetric, histoQV, hist_words, result_from_counts,
-    TILE, db_probe, db_write_flat, PinnedBuffer, Comm, hist_multi, hist_sharded,
+    TILE, db_probe, db_write_flat, PinnedBuffer, Comm, hist_multi, hist_sharded, load_db_multi,
 )
 
 __all__ = ["MfxError", "Index", "Sequences", "Evaluator", "Router", "HistResult", "KParams", "lib_path",
            "load_library", "device_count", "getK", "getKmetric", "histoQV", "hist_words", "result_from_counts", "TILE", "db_probe", "db_write_flat",
-           "PinnedBuffer", "Comm", "hist_multi", "hist_sharded"]
+           "PinnedBuffer", "Comm", "hist_multi", "hist_sharded", "load_db_multi"]

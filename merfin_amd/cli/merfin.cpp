@@ -175,8 +175,8 @@ static void print_completeness(const double *t64, const double *u64) {
 // -hist / -completeness over an index SHARDED across the devices of -devices (read databases beyond one GPU, BASELINE
 // config 5): slot d keeps the k-mers it owns (mfx_index_set_shard), loads skip foreign k-mers, -hist routes every k-mer
 // to its owner (mfx_hist_run_sharded), -completeness adds the per-piece sums of the shards in piece order
-// (merfin-completeness.C:117-123; the sums are integer-valued, so the split is exact).  Every shard reads the
-// databases itself (N passes over the files).
+// (merfin-completeness.C:117-123; the sums are integer-valued, so the split is exact).  The databases are decoded
+// once: every batch is sent to all shards (mfx_index_load_db_multi).
 static int run_sharded(const Globals &G, int k, const mfx_db_info &rdb, const mfx_db_info &adb, const std::vector<SeqRecord> &recs,
                        const std::vector<const char *> &bases, const std::vector<uint64_t> &lens, uint64_t totalBases) {
   const uint32_t N = (uint32_t)G.devices.size();
@@ -196,11 +196,22 @@ static int run_sharded(const Globals &G, int k, const mfx_db_info &rdb, const mf
       sqs[d] = same < d ? sqs[same] : mfx_seq_upload(G.devices[d], bases.data(), lens.data(), (uint32_t)recs.size());
       if (!sqs[d]) { fail("uploading sequences"); break; }
     }
-    fprintf(stderr, "-- Shard %u of %u on device %d: loading the k-mers it owns.\n", d, N, G.devices[d]);
+    fprintf(stderr, "-- Shard %u of %u on device %d.\n", d, N, G.devices[d]);
     ixs[d] = mfx_index_create(k, capacity, G.maxMemory, G.devices[d]);
     if (!ixs[d]) { fprintf(stderr, "\n%s\n\n", mfx_last_error()); rc = 1; break; }
-    if (mfx_index_set_shard(ixs[d], d, N) || mfx_index_load_db(ixs[d], G.readDBname, 0, G.minV, G.maxV)) { fail("loading -readmers"); break; }
-    if (G.seqDBname ? mfx_index_load_db(ixs[d], G.seqDBname, 1, 0, ~0ull) : mfx_index_count_asm(ixs[d], sqs[d], nullptr)) { fail("loading the assembly k-mers"); break; }
+    if (mfx_index_set_shard(ixs[d], d, N)) { fail("creating shard"); break; }
+  }
+  // one pass over each database feeds every shard (each keeps the k-mers it owns)
+  if (!rc) {
+    fprintf(stderr, "-- Loading kmers from '%s' into the %u shards.\n", G.readDBname, N);
+    if (mfx_index_load_db_multi(ixs.data(), N, G.readDBname, 0, G.minV, G.maxV)) fail("loading -readmers");
+  }
+  if (!rc && G.seqDBname) {
+    fprintf(stderr, "-- Loading kmers from '%s' into the %u shards.\n", G.seqDBname, N);
+    if (mfx_index_load_db_multi(ixs.data(), N, G.seqDBname, 1, 0, ~0ull)) fail("loading -seqmers");
+  }
+  for (uint32_t d = 0; d < N && !rc; ++d) {
+    if (!G.seqDBname && mfx_index_count_asm(ixs[d], sqs[d], nullptr)) { fail("counting sequence k-mers"); break; }
     evs[d] = mfx_eval_create(ixs[d], &kp, 0);
     if (!evs[d]) { fail("creating evaluator"); break; }
     if (G.reportType == OP_HIST) {

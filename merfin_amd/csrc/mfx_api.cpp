@@ -298,8 +298,8 @@ static mfx_ingest *ingest_get(mfx_index *ix, uint64_t n) {
   g->kw = ix->key_words();
   bool ok = hipStreamCreateWithFlags(&g->st, hipStreamNonBlocking) == hipSuccess;
   for (auto &l : g->L)
-    ok = ok && hipHostMalloc((void **)&l.hk, cap * 8 * g->kw, hipHostMallocDefault) == hipSuccess &&
-         hipHostMalloc((void **)&l.hv, cap * 4, hipHostMallocDefault) == hipSuccess &&
+    ok = ok && hipHostMalloc((void **)&l.hk, cap * 8 * g->kw, hipHostMallocPortable) == hipSuccess &&      // DMA source for any device
+         hipHostMalloc((void **)&l.hv, cap * 4, hipHostMallocPortable) == hipSuccess &&
          hipMalloc((void **)&l.dk, cap * 8 * g->kw) == hipSuccess && hipMalloc((void **)&l.dv, cap * 4) == hipSuccess &&
          hipEventCreateWithFlags(&l.done, hipEventDisableTiming) == hipSuccess;
   if (!ok) { (void)hipGetLastError(); ingest_free(g); return nullptr; }
@@ -307,31 +307,92 @@ static mfx_ingest *ingest_get(mfx_index *ix, uint64_t n) {
   return g;
 }
 
-// fill(o, m, hk, hv): put k-mers [o, o+m) of the source into the pinned lane buffers; false = the source failed
+// fill(o, m, hk, hv): put k-mers [o, o+m) of the source into the pinned lane buffers; false = the source failed.
+// ONE source, nix tables: the chunk is staged once (in the first index's pinned lane) and sent to every index's
+// device over that device's own PCIe link; each table inserts what it keeps (a sharded index skips the k-mers it
+// does not own in the insert kernel).  nix = 1 is the ordinary load.
 template <class Fill>
-static int index_ingest(mfx_index *ix, uint64_t n, int side, Fill &&fill) {
-  mfx_ingest *g = ingest_get(ix, n);
-  if (!g) return mfx_fail(MFX_E_NOMEM, "mfx_index_add: staging allocation failed");
+static int index_ingest_multi(mfx_index *const *ixs, uint32_t nix, uint64_t n, int side, Fill &&fill) {
+  std::vector<mfx_ingest *> gs(nix, nullptr);
+  for (uint32_t i = 0; i < nix; ++i) {
+    DevGuard dg(ixs[i]->device);
+    gs[i] = ingest_get(ixs[i], n);
+    if (!gs[i]) return mfx_fail(MFX_E_NOMEM, "mfx_index_add: staging allocation failed");
+  }
+  uint64_t cap = gs[0]->cap;
+  for (uint32_t i = 1; i < nix; ++i) cap = std::min(cap, gs[i]->cap);
   bool ok = true, src_ok = true;
   int cur = 0;
-  for (uint64_t o = 0; o < n && ok; o += g->cap, cur ^= 1) {
-    mfx_ingest::Lane &l = g->L[cur];
-    const uint64_t m = std::min(g->cap, n - o);
-    if (l.busy && hipEventSynchronize(l.done) != hipSuccess) { ok = false; break; }
-    l.busy = false;
-    if (!fill(o, m, l.hk, l.hv)) { src_ok = false; break; }
-    ok = hipMemcpyAsync(l.dk, l.hk, m * 8 * g->kw, hipMemcpyHostToDevice, g->st) == hipSuccess &&
-         hipMemcpyAsync(l.dv, l.hv, m * 4, hipMemcpyHostToDevice, g->st) == hipSuccess &&
-         (ix->wide() ? mfx_kw_table_add(ix->view(), l.dk, l.dv, m, side, ix->d_meta, g->st)
-                     : mfx_k_table_add(ix->view(), l.dk, l.dv, m, side, ix->d_meta, g->st)) == hipSuccess &&
-         hipEventRecord(l.done, g->st) == hipSuccess;
-    l.busy = true;
+  for (uint64_t o = 0; o < n && ok; o += cap, cur ^= 1) {
+    const uint64_t m = std::min(cap, n - o);
+    for (uint32_t i = 0; i < nix && ok; ++i) {               // the lane's previous chunk has left the pinned buffer everywhere
+      mfx_ingest::Lane &l = gs[i]->L[cur];
+      if (l.busy) { DevGuard dg(ixs[i]->device); if (hipEventSynchronize(l.done) != hipSuccess) ok = false; }
+      l.busy = false;
+    }
+    if (!ok) break;
+    mfx_ingest::Lane &src = gs[0]->L[cur];
+    if (!fill(o, m, src.hk, src.hv)) { src_ok = false; break; }
+    for (uint32_t i = 0; i < nix && ok; ++i) {
+      mfx_index *ix = ixs[i];
+      mfx_ingest *g = gs[i];
+      mfx_ingest::Lane &l = g->L[cur];
+      DevGuard dg(ix->device);
+      ok = hipMemcpyAsync(l.dk, src.hk, m * 8 * g->kw, hipMemcpyHostToDevice, g->st) == hipSuccess &&
+           hipMemcpyAsync(l.dv, src.hv, m * 4, hipMemcpyHostToDevice, g->st) == hipSuccess &&
+           (ix->wide() ? mfx_kw_table_add(ix->view(), l.dk, l.dv, m, side, ix->d_meta, g->st)
+                       : mfx_k_table_add(ix->view(), l.dk, l.dv, m, side, ix->d_meta, g->st)) == hipSuccess &&
+           hipEventRecord(l.done, g->st) == hipSuccess;
+      l.busy = true;
+    }
   }
-  if (hipStreamSynchronize(g->st) != hipSuccess) ok = false;
-  g->L[0].busy = g->L[1].busy = false;
+  for (uint32_t i = 0; i < nix; ++i) {
+    DevGuard dg(ixs[i]->device);
+    if (hipStreamSynchronize(gs[i]->st) != hipSuccess) ok = false;
+    gs[i]->L[0].busy = gs[i]->L[1].busy = false;
+  }
   if (!ok) return mfx_fail(MFX_E_HIP, "mfx_index_add: transfer / insert failed: %s", hipGetErrorString(hipGetLastError()));
   if (!src_ok) return mfx_last_error_code() ? mfx_last_error_code() : MFX_E_IO;
-  return index_check(ix);
+  for (uint32_t i = 0; i < nix; ++i) {
+    DevGuard dg(ixs[i]->device);
+    int rc = index_check(ixs[i]);
+    if (rc) return rc;
+  }
+  return MFX_OK;
+}
+
+template <class Fill>
+static int index_ingest(mfx_index *ix, uint64_t n, int side, Fill &&fill) {
+  return index_ingest_multi(&ix, 1, n, side, fill);
+}
+
+static int set_read_filter(mfx_index *ix, uint64_t minV, uint64_t maxV) {
+  if (ix->filter_set && (ix->minV != minV || ix->maxV != maxV))
+    return mfx_fail(MFX_E_INVAL, "mfx_index_add_read: -min/-max must be the same for every batch of one index");
+  ix->minV = minV; ix->maxV = maxV; ix->filter_set = true;
+  return MFX_OK;
+}
+
+static int check_same_kind(mfx_index *const *ixs, uint32_t nix, const char *who) {
+  if (!ixs || nix == 0) return mfx_fail(MFX_E_INVAL, "%s: no index", who);
+  for (uint32_t i = 0; i < nix; ++i)
+    if (!ixs[i] || ixs[i]->k != ixs[0]->k) return mfx_fail(MFX_E_INVAL, "%s: the indexes of one load must hold the same k", who);
+  return MFX_OK;
+}
+
+// host arrays into several tables at once (the shards of one process): side 0 read counts (filter applies), 1 assembly
+int mfx_index_add_multi(mfx_index *const *ixs, uint32_t nix, const uint64_t *kmers, const uint32_t *values, uint64_t n, int side,
+                        uint64_t minV, uint64_t maxV) {
+  int rc = check_same_kind(ixs, nix, "mfx_index_add_multi");
+  if (rc) return rc;
+  if (n && (!kmers || !values)) return mfx_fail(MFX_E_INVAL, "mfx_index_add_multi: null argument");
+  if (side == 0) for (uint32_t i = 0; i < nix; ++i) if ((rc = set_read_filter(ixs[i], minV, maxV)) != MFX_OK) return rc;
+  const size_t kw = ixs[0]->key_words();
+  return index_ingest_multi(ixs, nix, n, side, [&](uint64_t o, uint64_t m, uint64_t *hk, uint32_t *hv) {
+    par_memcpy((uint8_t *)hk, (const char *)(kmers + o * kw), m * 8 * kw);
+    par_memcpy((uint8_t *)hv, (const char *)(values + o), m * 4);
+    return true;
+  });
 }
 
 // n bytes at file offset `off` into dst, read by several threads (each pread copies straight out of the page cache:
@@ -364,17 +425,14 @@ static bool par_pread(int fd, uint8_t *dst, size_t n, uint64_t off) {
 }
 
 // k-mers [0, n) of an open flat-binary database: keys at keys_off (8 * key_words bytes each), counts at vals_off
-int mfx_index_add_from_file(mfx_index *ix, int fd, const char *path, uint64_t keys_off, uint64_t vals_off, uint64_t n, int side,
-                            uint64_t minV, uint64_t maxV) {
-  if (!ix || fd < 0) return mfx_fail(MFX_E_INVAL, "mfx_index_add_from_file: bad argument");
-  if (side == 0) {
-    if (ix->filter_set && (ix->minV != minV || ix->maxV != maxV))
-      return mfx_fail(MFX_E_INVAL, "mfx_index_add_read: -min/-max must be the same for every batch of one index");
-    ix->minV = minV; ix->maxV = maxV; ix->filter_set = true;
-  }
-  DevGuard g(ix->device);
-  const size_t kw = ix->key_words();
-  return index_ingest(ix, n, side, [&](uint64_t o, uint64_t m, uint64_t *hk, uint32_t *hv) {
+int mfx_index_add_from_file(mfx_index *const *ixs, uint32_t nix, int fd, const char *path, uint64_t keys_off, uint64_t vals_off, uint64_t n,
+                            int side, uint64_t minV, uint64_t maxV) {
+  int rc = check_same_kind(ixs, nix, "mfx_index_add_from_file");
+  if (rc) return rc;
+  if (fd < 0) return mfx_fail(MFX_E_INVAL, "mfx_index_add_from_file: bad argument");
+  if (side == 0) for (uint32_t i = 0; i < nix; ++i) if ((rc = set_read_filter(ixs[i], minV, maxV)) != MFX_OK) return rc;
+  const size_t kw = ixs[0]->key_words();
+  return index_ingest_multi(ixs, nix, n, side, [&](uint64_t o, uint64_t m, uint64_t *hk, uint32_t *hv) {
     if (par_pread(fd, (uint8_t *)hk, m * 8 * kw, keys_off + o * 8 * kw) && par_pread(fd, (uint8_t *)hv, m * 4, vals_off + o * 4)) return true;
     mfx_fail(MFX_E_IO, "reading '%s' failed", path);
     return false;

@@ -374,7 +374,8 @@ int detect(const std::string &path) {
 
 // batches (kmer,value) pairs into the index
 struct Feeder {
-  mfx_index *ix;
+  mfx_index *const *ixs;               // one table, or the shards of one process: every batch goes to all of them
+  uint32_t nix;
   int side;
   uint64_t minV, maxV;
   std::mutex *mu = nullptr;            // several decoder threads feed one index: inserts are serialised
@@ -385,13 +386,12 @@ struct Feeder {
     if (v.empty() || rc) return;
     std::unique_lock<std::mutex> lk;
     if (mu) lk = std::unique_lock<std::mutex>(*mu);
-    rc = side ? mfx_index_add_asm(ix, k.data(), v.data(), v.size(), 0)
-              : mfx_index_add_read(ix, k.data(), v.data(), v.size(), minV, maxV, 0);
+    rc = mfx_index_add_multi(ixs, nix, k.data(), v.data(), v.size(), side, minV, maxV);
     k.clear(); v.clear();
   }
   void push(uint64_t lo, uint64_t hi, uint32_t val) {
     k.push_back(lo);
-    if (ix->wide()) k.push_back(hi);
+    if (ixs[0]->wide()) k.push_back(hi);
     v.push_back(val);
     if (v.size() >= (1u << 24)) flush();
   }
@@ -474,11 +474,21 @@ extern "C" int mfx_db_probe(const char *path, mfx_db_info *out) {
 // merylExactLookup::load (merfin-globals.C:156,159): side 0 = read DB with the
 // -min/-max filter, side 1 = assembly DB.
 extern "C" int mfx_index_load_db(mfx_index *ix, const char *path, int side, uint64_t minV, uint64_t maxV) {
-  if (!ix || !path) return mfx_fail(MFX_E_INVAL, "mfx_index_load_db: null argument");
+  if (!ix) return mfx_fail(MFX_E_INVAL, "mfx_index_load_db: null argument");
+  return mfx_index_load_db_multi(&ix, 1, path, side, minV, maxV);
+}
+
+// One pass over the database feeds nix tables: the shards of one process each keep the k-mers they own
+// (mfx_index_set_shard), so a config-5-sized read database is decoded ONCE, not once per GPU.
+extern "C" int mfx_index_load_db_multi(mfx_index *const *ixs, uint32_t nix, const char *path, int side, uint64_t minV, uint64_t maxV) {
+  if (!ixs || nix == 0 || !path) return mfx_fail(MFX_E_INVAL, "mfx_index_load_db: null argument");
+  for (uint32_t i = 0; i < nix; ++i)
+    if (!ixs[i] || ixs[i]->k != ixs[0]->k) return mfx_fail(MFX_E_INVAL, "mfx_index_load_db_multi: the indexes of one load must hold the same k");
+  mfx_index *ix = ixs[0];
   std::string p(path);
   int fmt = detect(p);
   if (!fmt) return mfx_fail(MFX_E_IO, "k-mer database '%s' does not exist", path);
-  Feeder fd{ix, side, minV, maxV};
+  Feeder fd{ixs, nix, side, minV, maxV};
   uint64_t n = 0;
   int rc = MFX_OK;
   if (fmt == MFX_DB_FLAT) {
@@ -495,7 +505,7 @@ extern "C" int mfx_index_load_db(mfx_index *ix, const char *path, int side, uint
     if ((int)h.k != ix->k) { close(fdn); return mfx_fail(MFX_E_INVAL, "'%s' holds %u-mers but the index is built for k=%d", path, h.k, ix->k); }
     const uint64_t kw = ix->key_words();                     // k > 31: 16-byte k-mers {low, high}
     if ((uint64_t)st.st_size < sizeof(h) + h.n * (8 * kw + 4)) { close(fdn); return mfx_fail(MFX_E_FORMAT, "'%s': truncated payload", path); }
-    if (h.n) rc = mfx_index_add_from_file(ix, fdn, path, sizeof(h), sizeof(h) + h.n * 8 * kw, h.n, side, minV, maxV);
+    if (h.n) rc = mfx_index_add_from_file(ixs, nix, fdn, path, sizeof(h), sizeof(h) + h.n * 8 * kw, h.n, side, minV, maxV);
     close(fdn);
   } else if (fmt == MFX_DB_TEXT) {
     int k = 0;
@@ -510,7 +520,7 @@ extern "C" int mfx_index_load_db(mfx_index *ix, const char *path, int side, uint
       std::mutex mu;
       std::vector<MerylFileSums> per(64);
       rc = for_each_meryl_file([&](uint32_t fl) {
-        Feeder tf{ix, side, minV, maxV, &mu};
+        Feeder tf{ixs, nix, side, minV, maxV, &mu};
         int r = read_meryl_data(meryl_file_name(p, fl, ".merylData"), fl, mi, [&](uint64_t lo, uint64_t hi, uint32_t v) { tf.push(lo, hi, v); }, &per[fl]);
         if (r == MFX_OK) tf.flush();
         return r ? r : tf.rc;

@@ -28,8 +28,11 @@ int  mfx_fail(int code, const char *fmt, ...);
   } while (0)
 
 // flat-binary database -> table, read with parallel pread into the index's staging lanes (mfx_api.cpp)
-int  mfx_index_add_from_file(struct mfx_index *ix, int fd, const char *path, uint64_t keys_off, uint64_t vals_off, uint64_t n, int side,
-                             uint64_t minV, uint64_t maxV);
+int  mfx_index_add_from_file(struct mfx_index *const *ixs, uint32_t nix, int fd, const char *path, uint64_t keys_off, uint64_t vals_off,
+                             uint64_t n, int side, uint64_t minV, uint64_t maxV);
+// host arrays into several tables at once (one staging, one H2D per table; sharded tables keep what they own)
+int  mfx_index_add_multi(struct mfx_index *const *ixs, uint32_t nix, const uint64_t *kmers, const uint32_t *values, uint64_t n, int side,
+                         uint64_t minV, uint64_t maxV);
 void mfx_index_ingest_release(struct mfx_index *ix);
 
 // host threads the library may use: min(hardware, cgroup CPU quota, 64), or MFX_HOST_THREADS

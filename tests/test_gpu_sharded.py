@@ -244,3 +244,43 @@ def test_cli_sharded_hist_and_completeness(tmp_path, golden_dir):
     assert tail(a.stderr) == tail(b.stderr)
     bad = subprocess.run([exe, "-dump"] + common + ["-output", str(tmp_path / "x"), "-devices", "0,0", "-sharded"], capture_output=True, text=True)
     assert bad.returncode == 1 and "-sharded applies to -hist and -completeness" in bad.stderr
+
+
+@pytest.mark.parametrize("k", [21, 31])
+def test_one_pass_feeds_every_shard(tmp_path, k):
+    """mfx_index_load_db_multi: ONE decode of a database (flat binary, `meryl print` text, meryl-layout directory) feeds
+    all shards of a process, each keeping the k-mers it owns -- the same tables as N separate loads"""
+    import merfin_amd as m
+    from tests import meryl_layout
+    from tests.test_cli import _write_text_db
+    world = 4
+    contigs, read, asm = synth.world(k=k, peak=17.3, seed=95, sizes=(9000, 3000, 400), err_kmers=500)
+    flat, text, mdir = str(tmp_path / "r.mfxk"), str(tmp_path / "r.txt"), str(tmp_path / "r.meryl")
+    m.db_write_flat(flat, k, *read)
+    _write_text_db(text, k, *read)
+    meryl_layout.write_db(mdir, k, read[0], read[1], prefix_bits=12)
+    m.db_write_flat(str(tmp_path / "a.mfxk"), k, *asm)
+    separately = []
+    for r in range(world):
+        ix = m.Index(k, len(read[0]) + len(asm[0]) + 16)
+        ix.set_shard(r, world)
+        ix.load_db(flat, 0, 3, 60)
+        ix.load_db(str(tmp_path / "a.mfxk"), 1)
+        separately.append(ix.export())
+    assert sum(len(e[0]) for e in separately) == len(np.union1d(read[0], asm[0]))
+    for path in (flat, text, mdir):
+        shards = []
+        for r in range(world):
+            ix = m.Index(k, len(read[0]) + len(asm[0]) + 16)
+            ix.set_shard(r, world)
+            shards.append(ix)
+        m.load_db_multi(shards, path, 0, 3, 60)
+        m.load_db_multi(shards, str(tmp_path / "a.mfxk"), 1)
+        for ix, want in zip(shards, separately):
+            got = ix.export()
+            for a, b in zip(got, want):
+                np.testing.assert_array_equal(a, b)
+            assert ix.origin()[1:] == (3, 60)
+    # tables of different k cannot share a load
+    with pytest.raises(m.MfxError):
+        m.load_db_multi([m.Index(k, 100), m.Index(k - 2, 100)], flat, 0)
