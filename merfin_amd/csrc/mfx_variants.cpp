@@ -119,33 +119,65 @@ Variant *make_variant(const Record *r) {
   return v;
 }
 
-int load_vcf(const char *path, VcfDB &db) {             // vcfFile::loadFile, vcf.C:93-149
+// one data line -> record (nullptr: fewer than 10 columns, "excluded", vcfRecord.H:53-56)
+Record *parse_record(const char *L, size_t n) {
+  std::vector<std::string> w = split_any(std::string(L, n), "\t");
+  if (w.size() < 10) return nullptr;
+  Record *r = new Record;
+  r->chr = w[0];
+  r->pos = (uint32_t)strtoul(w[1].c_str(), nullptr, 10);
+  r->id = w[2]; r->ref = w[3]; r->alts = w[4];
+  r->qual = strtod(w[5].c_str(), nullptr);
+  r->filter = w[6]; r->info = w[7]; r->formats = w[8]; r->samples = w[9];
+  r->alt_list = split_any(r->alts, ",");
+  std::vector<std::string> smp = split_any(r->samples, ":");
+  r->gt_field = smp.empty() ? std::string() : smp[0];
+  return r;
+}
+
+template <class F> void parallel_for(size_t n, F &&fn);
+
+// vcfFile::loadFile, vcf.C:93-149.  The file is read whole, its data lines are parsed by the host threads (a
+// config-4-sized VCF has millions of records, and the per-record string work is most of the load time), and the
+// records enter the database in FILE ORDER, exactly as a sequential read would put them.
+int load_vcf(const char *path, VcfDB &db) {
   mfx_file fh = mfx_open_reader(path);
   FILE *f = fh.f;
   if (!f) return mfx_fail(MFX_E_IO, "cannot open VCF '%s'", path);
-  char *L = nullptr;
-  size_t cap = 0;
-  ssize_t n;
-  while ((n = getline(&L, &cap, f)) >= 0) {
-    while (n > 0 && (L[n - 1] == '\n' || L[n - 1] == '\r')) L[--n] = 0;
-    if (L[0] == '#') {
-      db.headers.emplace_back(L);
-      if (strncmp(L, "##contig=<ID", 12) == 0) db.contig_ids++;
-      continue;
+  std::string buf;
+  {
+    std::vector<char> blk(1 << 22);
+    size_t n;
+    while ((n = fread(blk.data(), 1, blk.size(), f)) > 0) buf.append(blk.data(), n);
+  }
+  if (mfx_close(fh)) return mfx_fail(MFX_E_IO, "reading VCF '%s' failed (stream error or the decompressor exited with an error)", path);
+  std::vector<std::pair<size_t, size_t>> lines;           // (offset, length) of every data line
+  for (size_t o = 0; o < buf.size();) {
+    const char *nl = (const char *)memchr(buf.data() + o, '\n', buf.size() - o);
+    size_t e = nl ? (size_t)(nl - buf.data()) : buf.size(), n = e - o;
+    while (n > 0 && (buf[o + n - 1] == '\n' || buf[o + n - 1] == '\r')) --n;
+    if (buf[o] == '#' && (nl || e > o)) {
+      db.headers.emplace_back(buf.data() + o, n);
+      if (n >= 12 && strncmp(buf.data() + o, "##contig=<ID", 12) == 0) db.contig_ids++;
+    } else if (nl || e > o) {
+      lines.emplace_back(o, n);
     }
-    std::vector<std::string> w = split_any(L, "\t");
-    if (w.size() < 10) { db.excluded++; continue; }      // vcfRecord.H:53-56
-    Record *r = new Record;
-    r->chr = w[0];
-    r->pos = (uint32_t)strtoul(w[1].c_str(), nullptr, 10);
-    r->id = w[2]; r->ref = w[3]; r->alts = w[4];
-    r->qual = strtod(w[5].c_str(), nullptr);
-    r->filter = w[6]; r->info = w[7]; r->formats = w[8]; r->samples = w[9];
-    r->alt_list = split_any(r->alts, ",");
-    std::vector<std::string> smp = split_any(r->samples, ":");
-    r->gt_field = smp.empty() ? std::string() : smp[0];
+    o = e + 1;
+  }
+  std::vector<Record *> recs(lines.size(), nullptr);
+  std::vector<Variant *> vars(lines.size(), nullptr);
+  const size_t CH = 4096;                                  // lines per task
+  parallel_for((lines.size() + CH - 1) / CH, [&](size_t c) {
+    for (size_t i = c * CH, e = std::min(lines.size(), (c + 1) * CH); i < e; ++i) {
+      recs[i] = parse_record(buf.data() + lines[i].first, lines[i].second);
+      if (recs[i]) vars[i] = make_variant(recs[i]);
+    }
+  });
+  for (size_t i = 0; i < lines.size(); ++i) {
+    Record *r = recs[i];
+    if (!r) { db.excluded++; continue; }
     db.records.push_back(r);
-    Variant *v = make_variant(r);
+    Variant *v = vars[i];
     db.variants.push_back(v);
     Cluster *c = new Cluster;
     c->rStart = v->pos;
@@ -153,8 +185,6 @@ int load_vcf(const char *path, VcfDB &db) {             // vcfFile::loadFile, vc
     c->vars.push_back(v);
     db.by_chr[r->chr].push_back(c);
   }
-  free(L);
-  if (mfx_close(fh)) return mfx_fail(MFX_E_IO, "reading VCF '%s' failed (stream error or the decompressor exited with an error)", path);
   return MFX_OK;
 }
 
