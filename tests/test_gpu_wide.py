@@ -205,3 +205,24 @@ def test_wide_database_forms_and_cli(tmp_path):
     # a sharded index is a k <= 31 feature: refused, not silently wrong
     with pytest.raises(m.MfxError):
         m.Index(k, 100).set_shard(0, 2)
+
+
+def test_wide_index_image_and_replica(tmp_path):
+    """the device-format image (-index) and the device-to-device replica carry 32-byte slots unchanged"""
+    import merfin_amd as m
+    k = 47
+    contigs, R, A = small_world(k, 91, n=6000)
+    ix = build(m, k, R, A)
+    img = str(tmp_path / "w.mfxi")
+    ix.set_fingerprint(0xABCDEF)
+    ix.save(img)
+    for other in (m.Index.load(img), ix.replicate(0)):
+        assert other.info() == ix.info() and other.origin() == ix.origin()
+        for a, b in zip(other.export(), ix.export()):
+            np.testing.assert_array_equal(a, b)
+        seqs = m.Sequences([c.encode() for c in contigs])
+        assert_hist(m.Evaluator(other, m.KParams(9.0)).hist(seqs), contigs, k, 9.0, [], [], R, A)
+    # an image of a narrow table cannot be mistaken for a wide one
+    ix31 = build(m, 31, *small_world(31, 92, n=3000)[1:])
+    ix31.save(str(tmp_path / "n.mfxi"))
+    assert m.Index.load(str(tmp_path / "n.mfxi")).info()["k"] == 31
