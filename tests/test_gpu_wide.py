@@ -223,6 +223,6 @@ def test_wide_index_image_and_replica(tmp_path):
         seqs = m.Sequences([c.encode() for c in contigs])
         assert_hist(m.Evaluator(other, m.KParams(9.0)).hist(seqs), contigs, k, 9.0, [], [], R, A)
     # an image of a narrow table cannot be mistaken for a wide one
-    ix31 = build(m, 31, *small_world(31, 92, n=3000)[1:])
+    ix31 = build(m, 31, *small_world(31, 92, n=6000)[1:])
     ix31.save(str(tmp_path / "n.mfxi"))
     assert m.Index.load(str(tmp_path / "n.mfxi")).info()["k"] == 31
