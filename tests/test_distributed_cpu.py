@@ -129,3 +129,31 @@ def test_shard_partition_properties():
     tt = D.tile_table([0, 5, 4096, 4097, 10000])
     assert [t for t in tt if t[0] == 3] == [(3, 0, 4096), (3, 4096, 1)]
     assert sum(n for _, _, n in tt) == 5 + 4096 + 4097 + 10000
+
+
+def _oob_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import struct
+    import bench
+    o = bench.Oob()
+    assert (o.rank, o.world) == (rank, world)
+    uid = o.bcast(b"\x07" * 128 if rank == 0 else b"")             # the RCCL unique id travels like this
+    assert uid == b"\x07" * 128
+    for _ in range(20):
+        o.barrier()
+    parts = o.allgather(struct.pack("<QQ", rank, rank * rank))      # the rehearsal's host-side reduction uses this
+    assert [struct.unpack("<QQ", b) for b in parts] == [(r, r * r) for r in range(world)]
+    assert o.max(1.0 + rank) == float(world)                         # max-over-ranks of the elapsed time
+    o.barrier()
+    open(os.path.join(tmp, "ok%d" % rank), "w").write("1")
+
+
+def test_bench_launcher_channel_three_ranks(tmp_path):
+    """bench.py's out-of-band channel for N > 1 (torchrun's rendezvous store: RCCL unique id, barriers, max of the
+    elapsed time) with three real processes on CPU.  The data-path collective itself (csrc/mfx_comm.cpp) needs GPUs."""
+    torch = pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    port = 29300 + os.getpid() % 500
+    mp.spawn(_oob_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    assert all((tmp_path / ("ok%d" % r)).exists() for r in range(3))
