@@ -340,6 +340,16 @@ int mfx_dump_values(mfx_eval *ev, const mfx_seq *seq, uint32_t contig, uint64_t 
  * format "%s\t%lu\t%.2f\t%.2f\t%.2f\n" (merfin-dump.C:88-93). */
 int mfx_dump_contig(mfx_eval *ev, const mfx_seq *seq, uint32_t contig, const char *name,
                     const char *path, int append, uint64_t *kasm, uint64_t *kmissing);
+/* -dump over an index SHARDED across nslots evaluators (slot d = shard d of nslots, mfx_index_set_shard; seqs[d] =
+ * the same sequences resident on slot d's device; slots may share a device).  Every k-mer has one owner and the
+ * other shards answer 0, so each slot looks its copy of the range up in its own shard and the value arrays are added
+ * on slot 0's device (8 B per position and slot over xGMI); kmissing is counted from the sums.  Same results as
+ * mfx_dump_values / mfx_dump_contig on the whole index (merfin-dump.C:44-67 sees one lookup object either way). */
+int mfx_dump_values_sharded(mfx_eval *const *evs, const mfx_seq *const *seqs, uint32_t nslots, uint32_t contig,
+                            uint64_t pos_begin, uint64_t pos_end, uint32_t *readV, uint32_t *asmV,
+                            uint64_t *kasm, uint64_t *kmissing);
+int mfx_dump_contig_sharded(mfx_eval *const *evs, const mfx_seq *const *seqs, uint32_t nslots, uint32_t contig,
+                            const char *name, const char *path, int append, uint64_t *kasm, uint64_t *kmissing);
 
 /* ------------------------------------------------------------------------ */
 /* -filter / -polish / -better / -strict / -loose: replaces processVariants */
@@ -367,6 +377,12 @@ typedef struct {
 int mfx_variants_run(mfx_eval *ev, const char *vcf_path, const char *const *names, const char *const *bases,
                      const uint64_t *lens, uint32_t ncontigs, const mfx_variant_opts *opts,
                      const char *out_path, const char *log_path, uint64_t *n_clusters);
+/* The same over an index sharded across nslots evaluators (slot d = shard d of nslots): every batch of path text is
+ * scored by mfx_dump_values_sharded; clustering, enumeration, selectors and output are the code above. */
+int mfx_variants_run_sharded(mfx_eval *const *evs, uint32_t nslots, const char *vcf_path, const char *const *names,
+                             const char *const *bases, const uint64_t *lens, uint32_t ncontigs,
+                             const mfx_variant_opts *opts, const char *out_path, const char *log_path,
+                             uint64_t *n_clusters);
 
 /* ------------------------------------------------------------------------ */
 /* -completeness: replaces computeCompleteness (merfin-completeness.C:48-144)*/

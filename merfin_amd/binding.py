@@ -73,7 +73,7 @@ SYMBOLS = [
     "mfx_eval_create", "mfx_eval_free", "mfx_eval_nbins", "mfx_getK", "mfx_getKmetric", "mfx_histoQV",
     "mfx_hist_run", "mfx_hist_result_free", "mfx_hist_launch", "mfx_hist_launch_cyclic", "mfx_hist_result_from_counts",
     "mfx_hist_take_overflow", "mfx_hist_report",
-    "mfx_dump_values", "mfx_dump_contig", "mfx_completeness", "mfx_completeness_pieces", "mfx_variants_run",
+    "mfx_dump_values", "mfx_dump_contig", "mfx_dump_values_sharded", "mfx_dump_contig_sharded", "mfx_variants_run_sharded", "mfx_completeness", "mfx_completeness_pieces", "mfx_variants_run",
     "mfx_index_set_shard", "mfx_router_create", "mfx_router_free", "mfx_route_tiles", "mfx_hist_keys_launch",
 ]
 
@@ -164,6 +164,10 @@ def load_library():
     L.mfx_hist_report.argtypes = [C.POINTER(_HistResult), C.c_int, C.c_char_p, C.c_char_p]
     L.mfx_dump_values.argtypes = [vp, vp, C.c_uint32, C.c_uint64, C.c_uint64, u32p, u32p, u64p, u64p]
     L.mfx_dump_contig.argtypes = [vp, vp, C.c_uint32, C.c_char_p, C.c_char_p, C.c_int, u64p, u64p]
+    L.mfx_dump_values_sharded.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, u32p, u32p, u64p, u64p]
+    L.mfx_dump_contig_sharded.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_char_p, C.c_char_p, C.c_int, u64p, u64p]
+    L.mfx_variants_run_sharded.argtypes = [vp, C.c_uint32, C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), u64p, C.c_uint32,
+                                           C.POINTER(_VarOpts), C.c_char_p, C.c_char_p, u64p]
     L.mfx_completeness.argtypes = [vp, f64p, f64p]
     L.mfx_completeness_pieces.argtypes = [vp, f64p, f64p]
     L.mfx_index_set_shard.argtypes = [vp, C.c_uint32, C.c_uint32]
@@ -603,6 +607,46 @@ def hist_sharded(evaluators, routers, sequences):
     r = HistResult()
     _check(load_library().mfx_hist_run_sharded(ev, ro, sq, n, C.byref(r.c)))
     return r
+
+
+def dump_values_sharded(evaluators, sequences, contig, pos_begin, pos_end):
+    """(readV, asmV) per k-mer start over an index sharded across the slots (mfx_dump_values_sharded)"""
+    ns = len(evaluators)
+    assert ns == len(sequences) and ns >= 1
+    ev = (C.c_void_p * ns)(*[e.h for e in evaluators])
+    sq = (C.c_void_p * ns)(*[s.h for s in sequences])
+    n = pos_end - pos_begin
+    r = np.zeros(max(n, 1), dtype=np.uint32)
+    a = np.zeros(max(n, 1), dtype=np.uint32)
+    ka, km = C.c_uint64(0), C.c_uint64(0)
+    _check(load_library().mfx_dump_values_sharded(ev, sq, ns, contig, pos_begin, pos_end, r.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                  a.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(ka), C.byref(km)))
+    return r[:n], a[:n], ka.value, km.value
+
+
+def dump_contig_sharded(evaluators, sequences, contig, name, path, append=False):
+    ns = len(evaluators)
+    ev = (C.c_void_p * ns)(*[e.h for e in evaluators])
+    sq = (C.c_void_p * ns)(*[s.h for s in sequences])
+    ka, km = C.c_uint64(0), C.c_uint64(0)
+    _check(load_library().mfx_dump_contig_sharded(ev, sq, ns, contig, name.encode(), path.encode(), 1 if append else 0,
+                                                  C.byref(ka), C.byref(km)))
+    return ka.value, km.value
+
+
+def variants_sharded(evaluators, mode, vcf_path, names, contigs, out_path, comb=15, nosplit=False, debug_path=None, log_path=None):
+    """the variant modes over an index sharded across the slots (mfx_variants_run_sharded); returns clusters evaluated"""
+    ns = len(evaluators)
+    ev = (C.c_void_p * ns)(*[e.h for e in evaluators])
+    n = len(contigs)
+    nm = (C.c_char_p * n)(*[x.encode() for x in names])
+    arr = (C.c_char_p * n)(*contigs)
+    lens = np.array([len(c) for c in contigs], dtype=np.uint64)
+    o = _VarOpts(VARIANT_MODES[mode], comb, 1 if nosplit else 0, debug_path.encode() if debug_path else None)
+    ncl = C.c_uint64(0)
+    _check(load_library().mfx_variants_run_sharded(ev, ns, vcf_path.encode(), nm, arr, lens.ctypes.data_as(C.POINTER(C.c_uint64)), n,
+                                                   C.byref(o), out_path.encode(), log_path.encode() if log_path else None, C.byref(ncl)))
+    return ncl.value
 
 
 COMM_ID_BYTES = 128          # MFX_COMM_ID_BYTES

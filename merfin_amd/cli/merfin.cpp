@@ -55,8 +55,9 @@ static void usage(const char *exe) {
           "                      built once and copied to the others over xGMI, every GPU evaluates its share of the\n"
           "                      sequence, the histograms are added; -dump and the variant modes: every GPU takes a contiguous\n"
           "                      run of contigs, the outputs are concatenated in order; -completeness uses the first device)\n"
-          "    -sharded          with -devices, for -hist and -completeness: every GPU keeps only its share of the k-mer table\n"
-          "                      (read databases too large for one GPU); k-mers are routed to the GPU that owns them\n"
+          "    -sharded          with -devices: every GPU keeps only its share of the k-mer table (read databases too large\n"
+          "                      for one GPU).  -hist routes every k-mer to the GPU that owns it; -dump and the variant modes\n"
+          "                      look every k-mer up in all shards and add the answers; -completeness adds per-shard sums\n"
           "    -index file       cache of the built HBM index: loaded if it exists (the k-mer databases are then not\n"
           "                      read), otherwise written after the build\n\n"
           "  Report types (exactly one):\n"
@@ -172,11 +173,12 @@ static void print_completeness(const double *t64, const double *u64) {
   fprintf(stderr, "COMPLETENESS:             %0.5f\n", 1.0 - undrc / total);
 }
 
-// -hist / -completeness over an index SHARDED across the devices of -devices (read databases beyond one GPU, BASELINE
+// Every report over an index SHARDED across the devices of -devices (read databases beyond one GPU, BASELINE
 // config 5): slot d keeps the k-mers it owns (mfx_index_set_shard), loads skip foreign k-mers, -hist routes every k-mer
 // to its owner (mfx_hist_run_sharded), -completeness adds the per-piece sums of the shards in piece order
-// (merfin-completeness.C:117-123; the sums are integer-valued, so the split is exact).  The databases are decoded
-// once: every batch is sent to all shards (mfx_index_load_db_multi).
+// (merfin-completeness.C:117-123; the sums are integer-valued, so the split is exact), -dump and the variant modes
+// look every k-mer up in all shards and add the answers (mfx_dump_contig_sharded, mfx_variants_run_sharded).  The
+// databases are decoded once: every batch is sent to all shards (mfx_index_load_db_multi).
 static int run_sharded(const Globals &G, int k, const mfx_db_info &rdb, const mfx_db_info &adb, const std::vector<SeqRecord> &recs,
                        const std::vector<const char *> &bases, const std::vector<uint64_t> &lens, uint64_t totalBases) {
   const uint32_t N = (uint32_t)G.devices.size();
@@ -214,7 +216,7 @@ static int run_sharded(const Globals &G, int k, const mfx_db_info &rdb, const mf
     if (!G.seqDBname && mfx_index_count_asm(ixs[d], sqs[d], nullptr)) { fail("counting sequence k-mers"); break; }
     evs[d] = mfx_eval_create(ixs[d], &kp, 0);
     if (!evs[d]) { fail("creating evaluator"); break; }
-    if (G.reportType == OP_HIST) {
+    if (G.reportType == OP_HIST || (G.reportType == OP_DUMP && G.skipMissing)) {
       const uint64_t nt = mfx_seq_num_tiles(sqs[d]);
       rts[d] = mfx_router_create(ixs[d], N, (uint32_t)std::min<uint64_t>(16384, std::max<uint64_t>(1, nt)));
       if (!rts[d]) { fail("creating router"); break; }
@@ -230,6 +232,45 @@ static int run_sharded(const Globals &G, int k, const mfx_db_info &rdb, const mf
       if (!ok) fail("writing histogram");
       mfx_hist_result_free(&r);
     }
+  } else if (!rc && G.reportType == OP_DUMP) {
+    fprintf(stderr, "-- Dump per-base k* metric to '%s' on %u devices (sharded index).\n", G.outName, N);
+    uint64_t cumMissing = 0, cumAsm = 0;
+    if (G.skipMissing) {                 // merfin-dump.C:34,81-87: no dump file, only the per-contig counts
+      mfx_hist_result r;
+      if (mfx_hist_run_sharded(evs.data(), rts.data(), sqs.data(), N, &r)) fail("-dump -skipMissing over the sharded index");
+      else {
+        for (size_t c = 0; c < recs.size(); ++c) {
+          cumMissing += r.contig_kmissing[c];
+          cumAsm += r.contig_kasm[c];
+          fprintf(stderr, "%s\t%lu\t%lu\t%lu\n", recs[c].name.c_str(), (unsigned long)r.contig_kmissing[c], (unsigned long)cumMissing, (unsigned long)cumAsm);
+        }
+        mfx_hist_result_free(&r);
+      }
+    } else {
+      for (size_t c = 0; c < recs.size() && !rc; ++c) {
+        uint64_t ka = 0, km = 0;
+        if (mfx_dump_contig_sharded(evs.data(), sqs.data(), N, (uint32_t)c, recs[c].name.c_str(), G.outName, c > 0, &ka, &km)) { fail("-dump over the sharded index"); break; }
+        cumMissing += km;
+        cumAsm += ka;
+        fprintf(stderr, "%s\t%lu\t%lu\t%lu\n", recs[c].name.c_str(), (unsigned long)km, (unsigned long)cumMissing, (unsigned long)cumAsm);
+      }
+      if (recs.empty()) { FILE *f = fopen(G.outName, "w"); if (f) fclose(f); }
+    }
+  } else if (!rc && G.reportType >= OP_FILTER) {
+    fprintf(stderr, "-- Opening vcf file '%s'.\n", G.vcfName);
+    fprintf(stderr, "-- Generate variant mers and score them on %u devices (sharded index).\n", N);
+    const std::string outName = std::string(G.outName) + (G.reportType == OP_POLISH ? ".polish.vcf" : ".filter.vcf");   // merfin-variants.C:324-327
+    const std::string dbgName = std::string(G.outName) + ".00.debug.gz";
+    std::vector<const char *> names(recs.size());
+    for (size_t c = 0; c < recs.size(); ++c) names[c] = recs[c].name.c_str();
+    mfx_variant_opts vo;
+    vo.mode = G.reportType;
+    vo.comb = G.comb;
+    vo.nosplit = G.nosplit ? 1 : 0;
+    vo.debug_path = G.debug ? dbgName.c_str() : nullptr;
+    uint64_t ncl = 0;
+    if (mfx_variants_run_sharded(evs.data(), N, G.vcfName, names.data(), bases.data(), lens.data(), (uint32_t)recs.size(), &vo, outName.c_str(), nullptr, &ncl))
+      fail("variant scoring over the sharded index");
   } else if (!rc) {
     fprintf(stderr, "-- Compute completeness on %u devices (sharded index).\n", N);
     double t64[64] = {0}, u64[64] = {0};
@@ -467,8 +508,8 @@ int main(int argc, char **argv) {
 
   lap("read sequences");
   if (G.sharded) {
-    if (G.devices.size() < 2 || !(G.reportType == OP_HIST || G.reportType == OP_COMPL)) {
-      fprintf(stderr, "ERROR: -sharded applies to -hist and -completeness with at least two -devices.\n");
+    if (G.devices.size() < 2) {
+      fprintf(stderr, "ERROR: -sharded needs at least two -devices.\n");
       return 1;
     }
     if (G.indexName) { fprintf(stderr, "ERROR: -index caches a whole table; it cannot be combined with -sharded.\n"); return 1; }

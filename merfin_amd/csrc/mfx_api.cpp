@@ -1646,6 +1646,120 @@ extern "C" int mfx_dump_values(mfx_eval *ev, const mfx_seq *seq, uint32_t contig
   return MFX_OK;
 }
 
+// The same values over an index SHARDED across N evaluators (mfx_index_set_shard): every k-mer has one owner and the
+// other shards answer 0, so each slot runs the lookup kernel over its copy of the sequence against its own shard and
+// the N value arrays are ADDED on slot 0's device (peer copies, 8 B per position and slot).  kmissing is then
+// counted from the summed values (readK == 0 is not additive over shards).
+extern "C" int mfx_dump_values_sharded(mfx_eval *const *evs, const mfx_seq *const *seqs, uint32_t nslots, uint32_t contig,
+                                       uint64_t pos_begin, uint64_t pos_end, uint32_t *readV, uint32_t *asmV,
+                                       uint64_t *kasm, uint64_t *kmissing) {
+  if (!evs || !seqs || nslots == 0 || !readV || !asmV) return mfx_fail(MFX_E_INVAL, "mfx_dump_values_sharded: null argument");
+  for (uint32_t d = 0; d < nslots; ++d) {
+    if (!evs[d] || !seqs[d]) return mfx_fail(MFX_E_INVAL, "mfx_dump_values_sharded: slot %u is null", d);
+    const mfx_index *ix = evs[d]->ix;
+    if (ix->shard_n != nslots || ix->shard_rank != d)
+      return mfx_fail(MFX_E_INVAL, "slot %u: its index must be shard %u of %u (mfx_index_set_shard)", d, d, nslots);
+    if (ix->wide()) return mfx_fail(MFX_E_INVAL, "a sharded index handles k <= 31");
+    if (evs[d]->device != seqs[d]->device || seqs[d]->ncontigs != seqs[0]->ncontigs || contig >= seqs[d]->ncontigs ||
+        seqs[d]->len[contig] != seqs[0]->len[contig])
+      return mfx_fail(MFX_E_INVAL, "slot %u: the sequences must be copies of one another, each on its evaluator's device", d);
+  }
+  const mfx_seq *seq0 = seqs[0];
+  if (pos_begin > pos_end || pos_end > seq0->len[contig])
+    return mfx_fail(MFX_E_INVAL, "mfx_dump_values_sharded: range [%lu,%lu) outside contig %u of length %lu",
+                    (unsigned long)pos_begin, (unsigned long)pos_end, contig, (unsigned long)seq0->len[contig]);
+  const uint64_t n = pos_end - pos_begin;
+  if (kasm) *kasm = 0;
+  if (kmissing) *kmissing = 0;
+  if (n == 0) return MFX_OK;
+  const uint64_t tb = pos_begin / MFX_TILE * MFX_TILE;
+  struct Slot { uint32_t *dr = nullptr, *da = nullptr; uint64_t *ds = nullptr; };
+  std::vector<Slot> sl(nslots);
+  uint32_t *tr = nullptr, *ta = nullptr;                       // slot 0's landing buffers for a peer's arrays
+  auto release = [&]() {
+    for (uint32_t d = 0; d < nslots; ++d) {
+      DevGuard g(evs[d]->device);
+      if (sl[d].dr) (void)hipFree(sl[d].dr);
+      if (sl[d].da) (void)hipFree(sl[d].da);
+      if (sl[d].ds) (void)hipFree(sl[d].ds);
+    }
+    DevGuard g(evs[0]->device);
+    if (tr) (void)hipFree(tr);
+    if (ta) (void)hipFree(ta);
+  };
+  auto args_of = [&](uint32_t d) {
+    mfx_dump_args a;
+    a.t = evs[d]->ix->view();
+    a.canonical = 0;
+    a.src = seqs[d]->d_bases + seqs[d]->off[contig] + tb;
+    a.npos = pos_end - tb;
+    a.skip = pos_begin - tb;
+    a.clen_left = seqs[d]->len[contig] - tb;
+    a.readV = sl[d].dr;
+    a.asmV = sl[d].da;
+    a.peak = evs[d]->peak;
+    a.n_prob = evs[d]->n_prob;
+    a.probK = evs[d]->d_probK;
+    a.probP = evs[d]->d_probP;
+    a.stats = sl[d].ds;
+    return a;
+  };
+  int rc = MFX_OK;
+  hipError_t e = hipSuccess;
+  for (uint32_t d = 0; d < nslots && rc == MFX_OK && e == hipSuccess; ++d) {          // every shard's lookup, all devices at once
+    DevGuard g(evs[d]->device);
+    int canon = 0;
+    rc = index_canonical(evs[d]->ix, &canon);
+    if (rc) break;
+    e = hipMalloc((void **)&sl[d].dr, n * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&sl[d].da, n * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&sl[d].ds, 2 * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMemsetAsync(sl[d].ds, 0, 2 * sizeof(uint64_t), nullptr);
+    if (e != hipSuccess) break;
+    mfx_dump_args a = args_of(d);
+    a.canonical = canon;
+    e = mfx_k_dump(a, nullptr);
+  }
+  for (uint32_t d = 0; d < nslots && rc == MFX_OK && e == hipSuccess; ++d) {
+    DevGuard g(evs[d]->device);
+    e = hipDeviceSynchronize();
+  }
+  if (rc == MFX_OK && e == hipSuccess && nslots > 1) {
+    DevGuard g(evs[0]->device);
+    e = hipMalloc((void **)&tr, n * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&ta, n * sizeof(uint32_t));
+    for (uint32_t d = 1; d < nslots && e == hipSuccess; ++d) {
+      if (evs[d]->device == evs[0]->device) {
+        e = mfx_k_add_u32(sl[0].dr, sl[d].dr, n, nullptr);
+        if (e == hipSuccess) e = mfx_k_add_u32(sl[0].da, sl[d].da, n, nullptr);
+        continue;
+      }
+      e = hipMemcpyPeerAsync(tr, evs[0]->device, sl[d].dr, evs[d]->device, n * sizeof(uint32_t), nullptr);
+      if (e == hipSuccess) e = hipMemcpyPeerAsync(ta, evs[0]->device, sl[d].da, evs[d]->device, n * sizeof(uint32_t), nullptr);
+      if (e == hipSuccess) e = mfx_k_add_u32(sl[0].dr, tr, n, nullptr);
+      if (e == hipSuccess) e = mfx_k_add_u32(sl[0].da, ta, n, nullptr);
+    }
+    if (e == hipSuccess) e = hipMemsetAsync(sl[0].ds, 0, 2 * sizeof(uint64_t), nullptr);
+    if (e == hipSuccess) {
+      mfx_dump_args a = args_of(0);
+      a.recount = 1;
+      e = mfx_k_dump(a, nullptr);
+    }
+  }
+  if (rc == MFX_OK && e == hipSuccess) {
+    DevGuard g(evs[0]->device);
+    uint64_t st[2] = {0, 0};
+    e = hipMemcpy(readV, sl[0].dr, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(asmV, sl[0].da, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(st, sl[0].ds, sizeof(st), hipMemcpyDeviceToHost);
+    if (kasm) *kasm = st[0];
+    if (kmissing) *kmissing = st[1];
+  }
+  release();
+  if (rc == MFX_OK && e != hipSuccess) rc = mfx_fail(MFX_E_HIP, "mfx_dump_values_sharded: %s", hipGetErrorString(e));
+  return rc;
+}
+
 // host threads the library may use for text formatting: min(hardware, cgroup quota, 64)
 unsigned mfx_host_threads() {
   const char *e = getenv("MFX_HOST_THREADS");
@@ -1703,10 +1817,10 @@ static void dump_format_range(const mfx_kparams &kp, const char *name, size_t na
 // outputDump, merfin-dump.C:87-93: a line for every position where any of
 // readK, asmK, K* is non-zero.  Values come from the GPU in 16 M-position
 // chunks; host threads format disjoint sub-ranges, written back in order.
-extern "C" int mfx_dump_contig(mfx_eval *ev, const mfx_seq *seq, uint32_t contig, const char *name,
-                               const char *path, int append, uint64_t *kasm, uint64_t *kmissing) {
-  if (!ev || !seq || !name || !path) return mfx_fail(MFX_E_INVAL, "mfx_dump_contig: null argument");
-  if (contig >= seq->ncontigs) return mfx_fail(MFX_E_INVAL, "mfx_dump_contig: contig %u out of range", contig);
+// values(o, e, rv, av, &kasm, &kmissing) fills the (readV, asmV) pairs of positions [o, e): one evaluator or the shards of one index
+template <class Values>
+static int dump_contig_impl(const mfx_eval *ev, const mfx_seq *seq, uint32_t contig, const char *name,
+                            const char *path, int append, uint64_t *kasm, uint64_t *kmissing, Values values) {
   mfx_file fh = mfx_open_writer(path, append != 0);
   FILE *f = fh.f;
   if (!f) return mfx_fail(MFX_E_IO, "cannot open '%s' for writing", path);
@@ -1721,7 +1835,7 @@ extern "C" int mfx_dump_contig(mfx_eval *ev, const mfx_seq *seq, uint32_t contig
   int rc = MFX_OK;
   for (uint64_t o = 0; o < len && rc == MFX_OK; o += CH) {
     uint64_t e = std::min(len, o + CH), a1 = 0, m1 = 0;
-    rc = mfx_dump_values(ev, seq, contig, o, e, rv.data(), av.data(), &a1, &m1);
+    rc = values(o, e, rv.data(), av.data(), &a1, &m1);
     if (rc) break;
     ka += a1;
     km += m1;
@@ -1742,6 +1856,27 @@ extern "C" int mfx_dump_contig(mfx_eval *ev, const mfx_seq *seq, uint32_t contig
   if (kasm) *kasm = ka;
   if (kmissing) *kmissing = km;
   return rc;
+}
+
+extern "C" int mfx_dump_contig(mfx_eval *ev, const mfx_seq *seq, uint32_t contig, const char *name,
+                               const char *path, int append, uint64_t *kasm, uint64_t *kmissing) {
+  if (!ev || !seq || !name || !path) return mfx_fail(MFX_E_INVAL, "mfx_dump_contig: null argument");
+  if (contig >= seq->ncontigs) return mfx_fail(MFX_E_INVAL, "mfx_dump_contig: contig %u out of range", contig);
+  return dump_contig_impl(ev, seq, contig, name, path, append, kasm, kmissing,
+                          [&](uint64_t o, uint64_t e, uint32_t *rv, uint32_t *av, uint64_t *a, uint64_t *m) {
+                            return mfx_dump_values(ev, seq, contig, o, e, rv, av, a, m);
+                          });
+}
+
+extern "C" int mfx_dump_contig_sharded(mfx_eval *const *evs, const mfx_seq *const *seqs, uint32_t nslots, uint32_t contig,
+                                       const char *name, const char *path, int append, uint64_t *kasm, uint64_t *kmissing) {
+  if (!evs || !seqs || nslots == 0 || !evs[0] || !seqs[0] || !name || !path)
+    return mfx_fail(MFX_E_INVAL, "mfx_dump_contig_sharded: null argument");
+  if (contig >= seqs[0]->ncontigs) return mfx_fail(MFX_E_INVAL, "mfx_dump_contig_sharded: contig %u out of range", contig);
+  return dump_contig_impl(evs[0], seqs[0], contig, name, path, append, kasm, kmissing,
+                          [&](uint64_t o, uint64_t e, uint32_t *rv, uint32_t *av, uint64_t *a, uint64_t *m) {
+                            return mfx_dump_values_sharded(evs, seqs, nslots, contig, o, e, rv, av, a, m);
+                          });
 }
 
 // ---------------------------------------------------------------------------

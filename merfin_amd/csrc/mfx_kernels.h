@@ -72,6 +72,7 @@ struct mfx_dump_args {
   const uint32_t *probK;
   const double   *probP;
   uint64_t       *stats;       // [0] kasm [1] kmissing
+  int             recount = 0; // 1: readV holds final values; only the counters are taken again (sharded index)
 };
 
 struct mfx_count_args {
@@ -112,6 +113,7 @@ hipError_t mfx_kw_count(const mfx_count_args &a, hipStream_t st);
 hipError_t mfx_kw_completeness(mfx_table_view t, double peak, uint32_t n_prob, const uint32_t *probK, const double *probP, double *partials,
                                int grid, hipStream_t st);
 hipError_t mfx_k_dump(const mfx_dump_args &a, hipStream_t st);
+hipError_t mfx_k_add_u32(uint32_t *dst, const uint32_t *src, uint64_t n, hipStream_t st);
 hipError_t mfx_k_count(const mfx_count_args &a, hipStream_t st);
 hipError_t mfx_k_completeness(mfx_table_view t, double peak, uint32_t n_prob, const uint32_t *probK, const double *probP,
                               double *partials, int grid, hipStream_t st);

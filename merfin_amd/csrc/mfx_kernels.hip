@@ -1021,7 +1021,9 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_sum_chunks_kernel(const double 
 // -dump: raw (readV, asmV) per k-mer start position of one contig range
 // ===========================================================================
 
-template <bool CANON>
+// RECOUNT: no lookup -- readV already holds the values (summed over the shards of a sharded index by
+// mfx_add_u32_kernel) and only the two counters are taken again from them: `readK == 0` is not additive over shards.
+template <bool CANON, bool RECOUNT>
 __global__ __launch_bounds__(MFX_BLOCK) void mfx_dump_kernel(mfx_dump_args a) {
   __shared__ mfx_tile_lds L;
   __shared__ mfx_mailbox MB;
@@ -1047,12 +1049,17 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_dump_kernel(mfx_dump_args a) {
       if (CANON) { key[j] = f < r ? f : r; key2[j] = f < r ? r : f; }
       else { key[j] = f; key2[j] = r; }
     }
-    mfx_group_lookup<MFX_BATCH>(a.t, MB, key, key2, ok, rv, av);
-    if (!CANON) {
-      uint32_t rv2[MFX_BATCH], av2[MFX_BATCH];
-      mfx_group_lookup<MFX_BATCH>(a.t, MB, key2, key, ok, rv2, av2);
+    if (RECOUNT) {
 #pragma unroll
-      for (int j = 0; j < MFX_BATCH; ++j) { rv[j] += rv2[j]; av[j] += av2[j]; }
+      for (int j = 0; j < MFX_BATCH; ++j) rv[j] = ok[j] ? a.readV[pos0 + (b + j) * MFX_BLOCK + tid - a.skip] : 0u;
+    } else {
+      mfx_group_lookup<MFX_BATCH>(a.t, MB, key, key2, ok, rv, av);
+      if (!CANON) {
+        uint32_t rv2[MFX_BATCH], av2[MFX_BATCH];
+        mfx_group_lookup<MFX_BATCH>(a.t, MB, key2, key, ok, rv2, av2);
+#pragma unroll
+        for (int j = 0; j < MFX_BATCH; ++j) { rv[j] += rv2[j]; av[j] += av2[j]; }
+      }
     }
 #pragma unroll
     for (int j = 0; j < MFX_BATCH; ++j) {
@@ -1064,8 +1071,10 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_dump_kernel(mfx_dump_args a) {
         mfx_getK_core(a.peak, a.n_prob, a.probK, a.probP, rv[j], readK, prob);
         if (readK == 0) n_missing++;                                  // :56-58
       }
-      a.readV[gp - a.skip] = ok[j] ? rv[j] : 0u;
-      a.asmV[gp - a.skip] = ok[j] ? av[j] : 0u;
+      if (!RECOUNT) {
+        a.readV[gp - a.skip] = ok[j] ? rv[j] : 0u;
+        a.asmV[gp - a.skip] = ok[j] ? av[j] : 0u;
+      }
     }
   }
   mfx_block_sum3(n_valid, n_missing, zz, s_red);
@@ -1073,6 +1082,13 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_dump_kernel(mfx_dump_args a) {
     atomicAdd((unsigned long long *)&a.stats[0], n_valid);
     atomicAdd((unsigned long long *)&a.stats[1], n_missing);
   }
+}
+
+// dst[i] += src[i]: the value arrays of the shards of one index add up to the whole index's values (every k-mer has
+// exactly one owner; the other shards answer 0)
+__global__ __launch_bounds__(MFX_BLOCK) void mfx_add_u32_kernel(uint32_t *dst, const uint32_t *src, uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * MFX_BLOCK;
+  for (uint64_t i = (uint64_t)blockIdx.x * MFX_BLOCK + threadIdx.x; i < n; i += stride) dst[i] += src[i];
 }
 
 // ===========================================================================
@@ -1251,11 +1267,19 @@ int mfx_k_hist_resident_blocks() {
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mfx_hist_kernel<true>, MFX_BLOCK, 0) != hipSuccess || nb < 1) nb = 4;
   return nb;
 }
+hipError_t mfx_k_add_u32(uint32_t *dst, const uint32_t *src, uint64_t n, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  uint64_t blocks = (n + 4 * MFX_BLOCK - 1) / (4 * MFX_BLOCK);
+  if (blocks > 65536) blocks = 65536;
+  mfx_add_u32_kernel<<<(unsigned)blocks, MFX_BLOCK, 0, st>>>(dst, src, n);
+  return hipGetLastError();
+}
 hipError_t mfx_k_dump(const mfx_dump_args &a, hipStream_t st) {
   uint64_t blocks = (a.npos + MFX_TILE - 1) / MFX_TILE;
   if (blocks == 0) return hipSuccess;
-  if (a.canonical) mfx_dump_kernel<true><<<(unsigned)blocks, MFX_BLOCK, 0, st>>>(a);
-  else             mfx_dump_kernel<false><<<(unsigned)blocks, MFX_BLOCK, 0, st>>>(a);
+  if (a.recount)        mfx_dump_kernel<true, true><<<(unsigned)blocks, MFX_BLOCK, 0, st>>>(a);
+  else if (a.canonical) mfx_dump_kernel<true, false><<<(unsigned)blocks, MFX_BLOCK, 0, st>>>(a);
+  else                  mfx_dump_kernel<false, false><<<(unsigned)blocks, MFX_BLOCK, 0, st>>>(a);
   return hipGetLastError();
 }
 hipError_t mfx_k_count(const mfx_count_args &a, hipStream_t st) {

@@ -29,6 +29,7 @@
 #include <list>
 #include <map>
 #include <chrono>
+#include <functional>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -442,9 +443,13 @@ double med_abs_k(std::vector<double> k) {
 
 }  // namespace
 
-extern "C" int mfx_variants_run(mfx_eval *ev, const char *vcf_path, const char *const *names, const char *const *bases,
-                                const uint64_t *lens, uint32_t ncontigs, const mfx_variant_opts *opts,
-                                const char *out_path, const char *log_path, uint64_t *n_clusters) {
+// values(text, len, rv, av): the (readV, asmV) pair of every k-mer start of the packed path text -- one evaluator
+// (mfx_dump_values) or the shards of one index (mfx_dump_values_sharded)
+using PathValues = std::function<int(const char *, uint64_t, uint32_t *, uint32_t *)>;
+
+static int variants_impl(const mfx_eval *ev, const PathValues &values, const char *vcf_path, const char *const *names, const char *const *bases,
+                         const uint64_t *lens, uint32_t ncontigs, const mfx_variant_opts *opts,
+                         const char *out_path, const char *log_path, uint64_t *n_clusters) {
   if (!ev || !vcf_path || !opts || !out_path || (ncontigs && (!names || !bases || !lens)))
     return mfx_fail(MFX_E_INVAL, "mfx_variants_run: null argument");
   const int mode = opts->mode;
@@ -517,14 +522,9 @@ extern "C" int mfx_variants_run(mfx_eval *ev, const char *vcf_path, const char *
     });
     lap(2);
     if (total) {
-      const char *pb = packed.data();
-      uint64_t plen = packed.size();
-      mfx_seq *ps = mfx_seq_upload(ev->device, &pb, &plen, 1);
-      if (!ps) return mfx_last_error_code();
-      rv.resize(plen + 1);
-      av.resize(plen + 1);
-      int r = mfx_dump_values(ev, ps, 0, 0, plen, rv.data(), av.data(), nullptr, nullptr);
-      mfx_seq_free(ps);
+      rv.resize(packed.size() + 1);
+      av.resize(packed.size() + 1);
+      int r = values(packed.data(), packed.size(), rv.data(), av.data());
       if (r) return r;
     }
     lap(3);
@@ -651,4 +651,48 @@ extern "C" int mfx_variants_run(mfx_eval *ev, const char *vcf_path, const char *
   if (log != stderr) fclose(log);
   if (n_clusters) *n_clusters = clusters;
   return rc;
+}
+
+extern "C" int mfx_variants_run(mfx_eval *ev, const char *vcf_path, const char *const *names, const char *const *bases,
+                                const uint64_t *lens, uint32_t ncontigs, const mfx_variant_opts *opts,
+                                const char *out_path, const char *log_path, uint64_t *n_clusters) {
+  if (!ev) return mfx_fail(MFX_E_INVAL, "mfx_variants_run: null argument");
+  PathValues values = [ev](const char *text, uint64_t len, uint32_t *rv, uint32_t *av) -> int {
+    mfx_seq *ps = mfx_seq_upload(ev->device, &text, &len, 1);
+    if (!ps) return mfx_last_error_code();
+    int r = mfx_dump_values(ev, ps, 0, 0, len, rv, av, nullptr, nullptr);
+    mfx_seq_free(ps);
+    return r;
+  };
+  return variants_impl(ev, values, vcf_path, names, bases, lens, ncontigs, opts, out_path, log_path, n_clusters);
+}
+
+// The variant modes over an index sharded across N evaluators (read databases beyond one GPU): the packed path text of
+// a batch goes to every slot's device and mfx_dump_values_sharded adds the shards' answers; everything else is the
+// single-evaluator code above.
+extern "C" int mfx_variants_run_sharded(mfx_eval *const *evs, uint32_t nslots, const char *vcf_path, const char *const *names,
+                                        const char *const *bases, const uint64_t *lens, uint32_t ncontigs,
+                                        const mfx_variant_opts *opts, const char *out_path, const char *log_path,
+                                        uint64_t *n_clusters) {
+  if (!evs || nslots == 0) return mfx_fail(MFX_E_INVAL, "mfx_variants_run_sharded: null argument");
+  for (uint32_t d = 0; d < nslots; ++d)
+    if (!evs[d]) return mfx_fail(MFX_E_INVAL, "mfx_variants_run_sharded: slot %u is null", d);
+  PathValues values = [evs, nslots](const char *text, uint64_t len, uint32_t *rv, uint32_t *av) -> int {
+    std::vector<mfx_seq *> sq(nslots, nullptr);
+    int r = MFX_OK;
+    for (uint32_t d = 0; d < nslots && r == MFX_OK; ++d) {
+      for (uint32_t e = 0; e < d; ++e)
+        if (evs[e]->device == evs[d]->device) { sq[d] = sq[e]; break; }           // one copy per device
+      if (!sq[d]) sq[d] = d == 0 ? mfx_seq_upload(evs[0]->device, &text, &len, 1) : mfx_seq_replicate(sq[0], evs[d]->device);
+      if (!sq[d]) r = mfx_last_error_code();
+    }
+    if (r == MFX_OK) r = mfx_dump_values_sharded(evs, sq.data(), nslots, 0, 0, len, rv, av, nullptr, nullptr);
+    for (uint32_t d = 0; d < nslots; ++d) {
+      bool shared = false;
+      for (uint32_t e = 0; e < d; ++e) if (sq[e] == sq[d]) shared = true;
+      if (sq[d] && !shared) mfx_seq_free(sq[d]);
+    }
+    return r;
+  };
+  return variants_impl(evs[0], values, vcf_path, names, bases, lens, ncontigs, opts, out_path, log_path, n_clusters);
 }

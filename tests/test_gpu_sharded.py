@@ -242,8 +242,8 @@ def test_cli_sharded_hist_and_completeness(tmp_path, golden_dir):
     assert a.returncode == 0 and b.returncode == 0, b.stderr
     tail = lambda s: s[s.index("thread  0 total"):]
     assert tail(a.stderr) == tail(b.stderr)
-    bad = subprocess.run([exe, "-dump"] + common + ["-output", str(tmp_path / "x"), "-devices", "0,0", "-sharded"], capture_output=True, text=True)
-    assert bad.returncode == 1 and "-sharded applies to -hist and -completeness" in bad.stderr
+    bad = subprocess.run([exe, "-dump"] + common + ["-output", str(tmp_path / "x"), "-devices", "0", "-sharded"], capture_output=True, text=True)
+    assert bad.returncode == 1 and "-sharded needs at least two -devices" in bad.stderr
 
 
 @pytest.mark.parametrize("k", [21, 31])
@@ -284,3 +284,96 @@ def test_one_pass_feeds_every_shard(tmp_path, k):
     # tables of different k cannot share a load
     with pytest.raises(m.MfxError):
         m.load_db_multi([m.Index(k, 100), m.Index(k - 2, 100)], flat, 0)
+
+
+@pytest.mark.parametrize("world,k,use_prob", [(2, 21, False), (3, 21, True), (4, 31, False), (8, 31, True)])
+def test_sharded_dump_equals_whole_index(world, k, use_prob, tmp_path, golden_dir):
+    """mfx_dump_values_sharded / mfx_dump_contig_sharded: every shard answers for the k-mers it owns and 0 otherwise, the value
+    arrays are added, kmissing is recounted from the sums -- same arrays as the oracle's processDump (merfin-dump.C:44-67),
+    same text as the unsharded -dump, for ranges that start inside a tile too"""
+    import merfin_amd as m
+    peak = 17.3
+    contigs, read, asm = synth.world(k=k, peak=peak, seed=97, sizes=(21000, 9000, 700, 10))
+    K = P = None
+    if use_prob:
+        K, P = po.load_kmetric(os.path.join(golden_dir, "example_lookup_table.txt"))
+        read = (read[0], (read[1] * 3).astype(np.uint32))            # reach the table's rows that are not 0
+    p = po.Params(k, peak, K, P)
+    RL, AL = po.Lookup(k, *read), po.Lookup(k, *asm)
+    shards = _build_shards(m, k, read, asm, world)
+    assert all(len(s.export()[0]) > 0 for s in shards)
+    evs = [m.Evaluator(s, m.KParams(peak, K, P)) for s in shards]
+    seqs = m.Sequences(contigs)
+    whole = m.Index(k, len(read[0]) + len(asm[0]) + 16)
+    whole.add_read(*read)
+    whole.add_asm(*asm)
+    wev = m.Evaluator(whole, m.KParams(peak, K, P))
+    for c, ctg in enumerate(contigs):
+        n = len(ctg)
+        rv, av, ka, km = m.dump_values_sharded(evs, [seqs] * world, c, 0, n)
+        wr, wa, wka, wkm = wev.dump_values(seqs, c, 0, n)
+        assert np.array_equal(rv, wr) and np.array_equal(av, wa) and (ka, km) == (wka, wkm)
+        rk, ak, kmet, dk, dm = po.process_dump(p, RL, AL, ctg)
+        assert (ka, km) == (dk, dm)
+        npos = max(n - k + 1, 0)
+        kp = m.KParams(peak, K, P)
+        for i in list(range(0, npos, 97))[:200]:
+            a, b, _ = m.getK(kp, int(rv[i]), int(av[i]))
+            assert (a, b) == (rk[i], ak[i])
+        if n > 5000:                                                     # a range that begins and ends inside tiles
+            r2, a2, ka2, km2 = m.dump_values_sharded(evs, [seqs] * world, c, 4099, n - 1001)
+            assert np.array_equal(r2, wr[4099:n - 1001]) and np.array_equal(a2, wa[4099:n - 1001])
+            w2 = wev.dump_values(seqs, c, 4099, n - 1001)
+            assert (ka2, km2) == (w2[2], w2[3])
+        sp, wp = str(tmp_path / "s.dump"), str(tmp_path / "w.dump")
+        assert m.dump_contig_sharded(evs, [seqs] * world, c, "ctg%d" % c, sp, append=c > 0) == (ka, km)
+        wev.dump_contig(seqs, c, "ctg%d" % c, wp, append=c > 0)
+    assert open(sp, "rb").read() == open(wp, "rb").read() and os.path.getsize(sp) > 100000
+    with pytest.raises(m.MfxError):                          # the slots must be shard 0..N-1 in order
+        m.dump_values_sharded(evs[::-1], [seqs] * world, 0, 0, 10)
+    with pytest.raises(m.MfxError):
+        m.dump_values_sharded([wev], [seqs], 0, 0, len(contigs[0]) + 1)
+
+
+@pytest.mark.parametrize("world,mode,k,seed", [(2, "polish", 21, 71), (3, "filter", 21, 72), (4, "loose", 31, 73), (2, "strict", 15, 74), (5, "better", 21, 75)])
+def test_sharded_variant_modes(world, mode, k, seed, tmp_path):
+    """mfx_variants_run_sharded: the variant modes with the path k-mers looked up in all shards of the index -- VCF and
+    -debug text byte-identical to the oracle's restatement of merfin-variants.C / varMer.C"""
+    import merfin_amd as m
+    peak = 17.3
+    names, asm, vcf, read, amers = synth.variant_world(k=k, peak=peak, seed=seed)
+    vp = str(tmp_path / "in.vcf")
+    open(vp, "w").write(vcf)
+    p = po.Params(k, peak)
+    R, A = po.Lookup(k, *read), po.Lookup(k, *amers)
+    n_o = po.variants_run(p, R, A, mode, vp, names, asm, str(tmp_path / "o.vcf"), comb=9, debug_path=str(tmp_path / "o.dbg"), log_path=str(tmp_path / "o.log"))
+    shards = _build_shards(m, k, read, amers, world)
+    evs = [m.Evaluator(s, m.KParams(peak)) for s in shards]
+    n_g = m.variants_sharded(evs, mode, vp, names, asm, str(tmp_path / "g.vcf"), comb=9, debug_path=str(tmp_path / "g.dbg"), log_path=str(tmp_path / "g.log"))
+    assert n_g == n_o and n_o > 20
+    assert open(tmp_path / "g.vcf").read() == open(tmp_path / "o.vcf").read()
+    assert open(tmp_path / "g.dbg").read() == open(tmp_path / "o.dbg").read()
+    assert len([l for l in open(tmp_path / "g.vcf") if not l.startswith("#")]) > 20
+
+
+def test_cli_sharded_dump_and_variants(tmp_path, golden_dir):
+    """`merfin -dump|-polish|-filter|-loose ... -devices 0,0,0 -sharded`: the committed golden outputs of the unsharded run"""
+    import subprocess
+    exe = os.path.join(ROOT, "merfin_amd", "bin", "merfin")
+    g = lambda n: os.path.join(golden_dir, n)
+    base = ["-sequence", g("case1.fasta"), "-readmers", g("case1.read.kmers.txt"), "-peak", "17.3", "-prob", g("example_lookup_table.txt")]
+    common = base + ["-devices", "0,0,0", "-sharded"]
+    r = subprocess.run([exe, "-dump"] + common + ["-output", str(tmp_path / "s.dump")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "s.dump").read_bytes() == open(g("case1.dump"), "rb").read()
+    one = subprocess.run([exe, "-dump", "-skipMissing"] + base + ["-output", str(tmp_path / "n1.dump")], capture_output=True, text=True)
+    r2 = subprocess.run([exe, "-dump", "-skipMissing"] + common + ["-output", str(tmp_path / "n.dump")], capture_output=True, text=True)
+    assert one.returncode == 0 and r2.returncode == 0 and not (tmp_path / "n.dump").exists(), r2.stderr
+    counts = lambda t: [l for l in t.splitlines() if l.count("\t") == 3 and not l.startswith("--")]
+    assert counts(r2.stderr) == counts(one.stderr) and len(counts(one.stderr)) > 1
+    assert counts(r.stderr) == counts(one.stderr)                        # the per-contig missing / cumulative columns of -dump
+    for mode, suffix in (("polish", ".polish.vcf"), ("filter", ".filter.vcf"), ("loose", ".filter.vcf")):
+        out = str(tmp_path / ("v_" + mode))
+        rv = subprocess.run([exe, "-" + mode] + common + ["-vcf", g("case1.vcf"), "-comb", "8", "-output", out], capture_output=True, text=True)
+        assert rv.returncode == 0, rv.stderr
+        assert open(out + suffix, "rb").read() == open(g("case1.%s.vcf" % mode), "rb").read()
