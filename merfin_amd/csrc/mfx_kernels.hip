@@ -414,14 +414,17 @@ struct mfx_mailbox {
 };
 
 // Issue phase of a round, in two steps so that nothing serialises: first ALL the
-// cross-lane broadcasts (16 LDS-crossbar ops back to back), then ALL 8 loads back
+// cross-lane broadcasts (32 LDS-crossbar ops back to back), then ALL 8 loads back
 // to back.  A position without a k-mer still "owns" a query -- of line 0, whose
 // outcome its lane ignores (ok[j] is false) -- so the hot sequence has no
 // exec-mask branches and no dead-owner bookkeeping.
+// What is broadcast is the line's ADDRESS (two words), computed once by the owner: a slot lane then needs one
+// 32-bit OR for its own slot's address (lines are 128-byte aligned) instead of a 64-bit shift-and-add per load.
 template <int S>
-__device__ __forceinline__ void mfx_group_announce(uint32_t (&ls)[8], uint32_t (&klo)[8], uint32_t (&khi)[8], uint32_t line,
-                                                   uint32_t key_lo, uint32_t key_hi) {
-  ls[S] = mfx_group_bcast<S>(line);
+__device__ __forceinline__ void mfx_group_announce(uint32_t (&alo)[8], uint32_t (&ahi)[8], uint32_t (&klo)[8], uint32_t (&khi)[8],
+                                                   uint64_t line_addr, uint32_t key_lo, uint32_t key_hi) {
+  alo[S] = mfx_group_bcast<S>((uint32_t)line_addr);
+  ahi[S] = mfx_group_bcast<S>((uint32_t)(line_addr >> 32));
   klo[S] = mfx_group_bcast<S>(key_lo);
   khi[S] = mfx_group_bcast<S>(key_hi);
 }
@@ -434,8 +437,8 @@ typedef uint32_t mfx_u32x4 __attribute__((ext_vector_type(4)));
 // counted wait (vmcnt(7 - S): the S+1 oldest of the eight have landed; other loads in flight can only make
 // that wait longer, never too short).
 template <int S>
-__device__ __forceinline__ void mfx_group_fetch(const mfx_table_view &t, mfx_u32x4 (&v)[8], const uint32_t (&ls)[8], uint32_t sub) {
-  const mfx_slot *p = t.slots + (uint64_t)ls[S] * MFX_SLOTS_LINE + sub;
+__device__ __forceinline__ void mfx_group_fetch(mfx_u32x4 (&v)[8], const uint32_t (&alo)[8], const uint32_t (&ahi)[8], uint32_t sub16) {
+  const uint64_t p = ((uint64_t)ahi[S] << 32) | (uint64_t)(alo[S] | sub16);
   asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[S]) : "v"(p));
 }
 template <int S>
@@ -446,24 +449,23 @@ __device__ __forceinline__ void mfx_group_landed(mfx_u32x4 (&v)[8]) {
 // Post phase.  The slot lane compares the FULL key: keys are unique in the table, so at
 // most one lane of the group stores into the owner's record -- no two writers can ever
 // interleave their words (a low-word-only pre-match would let that happen ~1e-9 per query,
-// i.e. a few times per 3 Gb launch).
+// i.e. a few times per 3 Gb launch).  The record is the value pair alone, stored straight from the
+// loaded registers: a k-mer found with both counts 0 reads like one not found, and value() of
+// either is 0 (merfin-globals.C:84) -- it only takes the longer way there.
 template <int S>
-__device__ __forceinline__ void mfx_group_post(mfx_mailbox &M, const mfx_u32x4 (&v)[8], const uint32_t (&klo)[8],
-                                               const uint32_t (&khi)[8], uint32_t obase) {
+__device__ __forceinline__ void mfx_group_post(uint2 *rec, const mfx_u32x4 (&v)[8], const uint32_t (&klo)[8], const uint32_t (&khi)[8]) {
   const mfx_u32x4 s = v[S];
-  uint32_t *rec = reinterpret_cast<uint32_t *>(&M.rec[obase + S]);
-  if (s.x == klo[S] && s.y == khi[S]) {                      // an empty slot (key ~0) never equals a k-mer
-    rec[0] = s.z; rec[1] = s.w; rec[2] = 1u;                  // {readV, asmV, found}
-  }
+  if (s.x == klo[S] && s.y == khi[S]) rec[S] = make_uint2(s.z, s.w);     // an empty slot (key ~0) never equals a k-mer
 }
 
 // "The line still has room" travels without LDS: slots fill in order (mfx_claim), so a line has room
 // exactly when its LAST slot is empty -- the lane with sub == 7 knows.  One ballot per round; bit 8g+7 of
 // it belongs to the owner (g, S), i.e. to lane 8g+S: shifted there, the 8 rounds OR into ONE wave-wide
-// mask whose bit `lane` is that lane's own answer.  Scalar work only.
+// mask whose bit `lane` is that lane's own answer.  Scalar work only.  (k <= 31: a k-mer's high word is
+// below 2^30, so the high word alone tells an empty slot.)
 template <int S>
 __device__ __forceinline__ uint64_t mfx_group_room(const mfx_u32x4 (&v)[8]) {
-  const uint64_t m = __ballot((v[S].x & v[S].y) == 0xffffffffu);
+  const uint64_t m = __ballot(v[S].y == 0xffffffffu);
   return ((m >> 7) & 0x0101010101010101ULL) << S;
 }
 
@@ -472,54 +474,58 @@ template <int B>
 __device__ __forceinline__ void mfx_group_lookup(const mfx_table_view &t, mfx_mailbox &M, const uint64_t (&key)[B],
                                                  const uint64_t (&krc)[B], const bool (&ok)[B], uint32_t (&rv)[B],
                                                  uint32_t (&av)[B]) {
-  const uint32_t tid = threadIdx.x, sub = tid & 7u, obase = tid & ~7u;
-  uint32_t line[B];
+  const uint32_t tid = threadIdx.x, sub16 = (tid & 7u) << 4, sub = tid & 7u;
+  const uint32_t lane = tid & 63u, wbase = tid & ~63u;
+  // first-pass records: 8 bytes per lane, dense in the front half of this wave's own 64 mailbox entries
+  uint2 *const own = reinterpret_cast<uint2 *>(&M.rec[wbase]) + lane;
+  uint2 *const grp = reinterpret_cast<uint2 *>(&M.rec[wbase]) + (lane & ~7u);
+  const uint64_t slots0 = reinterpret_cast<uint64_t>(t.slots);
+  uint64_t laddr[B];
   uint32_t pending[B];          // 0 resolved, 1 home line full: continue at candidate line 1
 #pragma unroll
   for (int j = 0; j < B; ++j) { pending[j] = 0u; rv[j] = av[j] = 0u; }
   {
     const uint32_t fl = mfx_first_line(t, key[0], krc[0]);
-    line[0] = ok[0] ? fl : 0u;                                     // no k-mer here: a dummy query of line 0, ignored below
+    laddr[0] = slots0 + ((uint64_t)(ok[0] ? fl : 0u) << 7);       // no k-mer here: a dummy query of line 0, ignored below
   }
 #pragma unroll
   for (int j = 0; j < B; ++j) {
     mfx_u32x4 v[8];
-    uint32_t klo[8], khi[8];
+    uint32_t klo[8], khi[8], alo[8], ahi[8];
     const uint32_t key_lo = (uint32_t)key[j], key_hi = (uint32_t)(key[j] >> 32);
-    M.rec[tid] = make_uint4(0u, 0u, 0u, 0u);
+    *own = make_uint2(0u, 0u);
     mfx_wave_handoff();                                            // records cleared before any slot lane posts
-    uint32_t ls[8];
-    mfx_group_announce<0>(ls, klo, khi, line[j], key_lo, key_hi); mfx_group_announce<1>(ls, klo, khi, line[j], key_lo, key_hi);
-    mfx_group_announce<2>(ls, klo, khi, line[j], key_lo, key_hi); mfx_group_announce<3>(ls, klo, khi, line[j], key_lo, key_hi);
-    mfx_group_announce<4>(ls, klo, khi, line[j], key_lo, key_hi); mfx_group_announce<5>(ls, klo, khi, line[j], key_lo, key_hi);
-    mfx_group_announce<6>(ls, klo, khi, line[j], key_lo, key_hi); mfx_group_announce<7>(ls, klo, khi, line[j], key_lo, key_hi);
-    mfx_group_fetch<0>(t, v, ls, sub); mfx_group_fetch<1>(t, v, ls, sub); mfx_group_fetch<2>(t, v, ls, sub);
-    mfx_group_fetch<3>(t, v, ls, sub); mfx_group_fetch<4>(t, v, ls, sub); mfx_group_fetch<5>(t, v, ls, sub);
-    mfx_group_fetch<6>(t, v, ls, sub); mfx_group_fetch<7>(t, v, ls, sub);
+    mfx_group_announce<0>(alo, ahi, klo, khi, laddr[j], key_lo, key_hi); mfx_group_announce<1>(alo, ahi, klo, khi, laddr[j], key_lo, key_hi);
+    mfx_group_announce<2>(alo, ahi, klo, khi, laddr[j], key_lo, key_hi); mfx_group_announce<3>(alo, ahi, klo, khi, laddr[j], key_lo, key_hi);
+    mfx_group_announce<4>(alo, ahi, klo, khi, laddr[j], key_lo, key_hi); mfx_group_announce<5>(alo, ahi, klo, khi, laddr[j], key_lo, key_hi);
+    mfx_group_announce<6>(alo, ahi, klo, khi, laddr[j], key_lo, key_hi); mfx_group_announce<7>(alo, ahi, klo, khi, laddr[j], key_lo, key_hi);
+    mfx_group_fetch<0>(v, alo, ahi, sub16); mfx_group_fetch<1>(v, alo, ahi, sub16); mfx_group_fetch<2>(v, alo, ahi, sub16);
+    mfx_group_fetch<3>(v, alo, ahi, sub16); mfx_group_fetch<4>(v, alo, ahi, sub16); mfx_group_fetch<5>(v, alo, ahi, sub16);
+    mfx_group_fetch<6>(v, alo, ahi, sub16); mfx_group_fetch<7>(v, alo, ahi, sub16);
     // the next query's placement hash is computed HERE, under this query's eight loads
     if (j + 1 < B) {
       const uint32_t fl = mfx_first_line(t, key[j + 1], krc[j + 1]);
-      line[j + 1] = ok[j + 1] ? fl : 0u;
+      laddr[j + 1] = slots0 + ((uint64_t)(ok[j + 1] ? fl : 0u) << 7);
     }
     uint64_t room = 0;
-    mfx_group_landed<0>(v); mfx_group_post<0>(M, v, klo, khi, obase); room |= mfx_group_room<0>(v);
-    mfx_group_landed<1>(v); mfx_group_post<1>(M, v, klo, khi, obase); room |= mfx_group_room<1>(v);
-    mfx_group_landed<2>(v); mfx_group_post<2>(M, v, klo, khi, obase); room |= mfx_group_room<2>(v);
-    mfx_group_landed<3>(v); mfx_group_post<3>(M, v, klo, khi, obase); room |= mfx_group_room<3>(v);
-    mfx_group_landed<4>(v); mfx_group_post<4>(M, v, klo, khi, obase); room |= mfx_group_room<4>(v);
-    mfx_group_landed<5>(v); mfx_group_post<5>(M, v, klo, khi, obase); room |= mfx_group_room<5>(v);
-    mfx_group_landed<6>(v); mfx_group_post<6>(M, v, klo, khi, obase); room |= mfx_group_room<6>(v);
-    mfx_group_landed<7>(v); mfx_group_post<7>(M, v, klo, khi, obase); room |= mfx_group_room<7>(v);
+    mfx_group_landed<0>(v); mfx_group_post<0>(grp, v, klo, khi); room |= mfx_group_room<0>(v);
+    mfx_group_landed<1>(v); mfx_group_post<1>(grp, v, klo, khi); room |= mfx_group_room<1>(v);
+    mfx_group_landed<2>(v); mfx_group_post<2>(grp, v, klo, khi); room |= mfx_group_room<2>(v);
+    mfx_group_landed<3>(v); mfx_group_post<3>(grp, v, klo, khi); room |= mfx_group_room<3>(v);
+    mfx_group_landed<4>(v); mfx_group_post<4>(grp, v, klo, khi); room |= mfx_group_room<4>(v);
+    mfx_group_landed<5>(v); mfx_group_post<5>(grp, v, klo, khi); room |= mfx_group_room<5>(v);
+    mfx_group_landed<6>(v); mfx_group_post<6>(grp, v, klo, khi); room |= mfx_group_room<6>(v);
+    mfx_group_landed<7>(v); mfx_group_post<7>(grp, v, klo, khi); room |= mfx_group_room<7>(v);
     mfx_wave_handoff();                                            // all posts of this round precede the owners' reads
-    const uint4 r = M.rec[tid];
+    const uint2 r = *own;
     mfx_wave_handoff();                                            // ... which precede the next round's clear
     if (ok[j]) {
-      if (r.z == 1u) {
+      if ((r.x | r.y) != 0u) {
         rv[j] = (r.x < t.minV || r.x > t.maxV) ? 0u : r.x;    // -min / -max (merfin.C:199-200)
         av[j] = r.y;
       } else {
         // not in the home line: absent if that line has room, else continue at the next candidate line
-        pending[j] = ((room >> (tid & 63u)) & 1ULL) ? 0u : 1u;
+        pending[j] = ((room >> lane) & 1ULL) ? 0u : 1u;
       }
     }
   }
@@ -528,7 +534,6 @@ __device__ __forceinline__ void mfx_group_lookup(const mfx_table_view &t, mfx_ma
   // (ballot prefix), then served 8 per step exactly like the first pass, now with
   // the full key in the record (exact compare).  Without this, each such lane
   // fetched 8 slots on its own while its 63 neighbours waited.
-  const uint32_t lane = tid & 63u, wbase = tid & ~63u;
   uint32_t qpos[B];
   uint32_t nq = 0;
 #pragma unroll
