@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <chrono>
 #include <thread>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -492,21 +493,36 @@ int main(int argc, char **argv) {
                     "--       checked against upstream meryl.  The decoder cross-checks every database against its own index\n"
                     "--       statistics; `meryl print` text is the verified interchange form (tools/meryl_conformance.py).\n");
   lap("probe k-mer databases");
-  // sequences (load_Sequence, merfin-globals.C:165-197; loadSequence, merfin.C:30-53)
+  // sequences (load_Sequence, merfin-globals.C:165-197; loadSequence, merfin.C:30-53).  The file is read (and, for
+  // .gz/.bz2/.xz, decompressed) by its own thread from here on; with -seqmers nothing needs the sequence before the
+  // evaluation, so the read then runs under the index build and is only waited for afterwards.
   std::vector<SeqRecord> recs;
+  std::vector<const char *> bases;
+  std::vector<uint64_t> lens;
+  uint64_t totalBases = 0;
+  std::thread seqReader;
+  struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } seqJoiner{seqReader};
   if (G.seqName) {
     fprintf(stderr, "-- Opening sequences in '%s'.\n", G.seqName);
-    SeqFile sf(G.seqName);
-    if (!sf.ok()) { fprintf(stderr, "ERROR: cannot open '%s'.\n", G.seqName); return 1; }
-    SeqRecord r;
-    while (sf.next(r)) recs.push_back(std::move(r));
+    auto sf = std::make_shared<SeqFile>(G.seqName);
+    if (!sf->ok()) { fprintf(stderr, "ERROR: cannot open '%s'.\n", G.seqName); return 1; }
+    seqReader = std::thread([&recs, sf]() {
+      SeqRecord r;
+      while (sf->next(r)) recs.push_back(std::move(r));
+    });
   }
-  std::vector<const char *> bases(recs.size());
-  std::vector<uint64_t> lens(recs.size());
-  uint64_t totalBases = 0;
-  for (size_t i = 0; i < recs.size(); ++i) { bases[i] = recs[i].bases.data(); lens[i] = recs[i].bases.size(); totalBases += lens[i]; }
-
-  lap("read sequences");
+  bool seqDone = false;
+  auto finish_seq = [&]() {
+    if (seqDone) return;
+    seqDone = true;
+    if (seqReader.joinable()) seqReader.join();
+    bases.resize(recs.size());
+    lens.resize(recs.size());
+    for (size_t i = 0; i < recs.size(); ++i) { bases[i] = recs[i].bases.data(); lens[i] = recs[i].bases.size(); totalBases += lens[i]; }
+    lap("read sequences");
+  };
+  const bool deferSeq = G.seqName && G.seqDBname && !G.sharded;
+  if (!deferSeq) finish_seq();
   if (G.sharded) {
     if (G.devices.size() < 2) {
       fprintf(stderr, "ERROR: -sharded needs at least two -devices.\n");
@@ -521,12 +537,16 @@ int main(int argc, char **argv) {
   // evaluation, so its upload is streamed under the -hist kernel (mfx_hist_run_streamed).  Otherwise the index build
   // counts the assembly k-mers from the packed sequence and it goes up first.
   const bool streamHist = G.reportType == OP_HIST && G.seqDBname && G.devices.size() == 1;
-  if (!recs.empty() || G.seqName) {
-    seq = streamHist ? mfx_seq_create(G.device, lens.data(), (uint32_t)recs.size())
-                     : mfx_seq_upload(G.device, bases.data(), lens.data(), (uint32_t)recs.size());
-    if (!seq) DIE_MFX("uploading sequences");
-  }
-  lap("upload sequences");
+  auto make_seq = [&]() -> bool {
+    if (!recs.empty() || G.seqName) {
+      seq = streamHist ? mfx_seq_create(G.device, lens.data(), (uint32_t)recs.size())
+                       : mfx_seq_upload(G.device, bases.data(), lens.data(), (uint32_t)recs.size());
+      if (!seq) return false;
+    }
+    lap("upload sequences");
+    return true;
+  };
+  if (!deferSeq && !make_seq()) DIE_MFX("uploading sequences");
   FILE *probe = G.indexName ? fopen(G.indexName, "rb") : nullptr;
   const uint64_t fingerprint = G.indexName ? input_fingerprint(G) : 0;
   if (probe) {
@@ -574,6 +594,10 @@ int main(int argc, char **argv) {
   }
 
   lap("build / load index");
+  if (deferSeq) {
+    finish_seq();
+    if (!make_seq()) DIE_MFX("uploading sequences");
+  }
   mfx_kparams kp{G.peak, (uint32_t)G.copyKmerK.size(), G.copyKmerK.data(), G.copyKmerP.data()};
   mfx_eval *ev = mfx_eval_create(ix, &kp, 0);
   if (!ev) DIE_MFX("creating evaluator");
