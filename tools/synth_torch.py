@@ -283,8 +283,9 @@ def add_neighbor_error_kmers(ix, truth, k, seed=SEED, per_position=1.0, chunk=1 
 
 
 def build_world(m, total_bases, k=21, lam=26.0, ncontigs=24, seed=SEED, device=0, err_factor=1.0, verbose=None,
-                err_mode="random"):
-    """Full synthetic -hist workload resident on `device`: returns (index, sequences, info)."""
+                err_mode="random", index_factory=None):
+    """Full synthetic -hist workload resident on `device`: returns (index, sequences, info).
+    index_factory(k, capacity, device=) may supply the index (e.g. a fan-out over the shards of a sharded index)."""
     import time
     torch.cuda.set_device(device)
     dev = "cuda:%d" % device
@@ -297,7 +298,7 @@ def build_world(m, total_bases, k=21, lam=26.0, ncontigs=24, seed=SEED, device=0
     say("genome+assembly generated: %.1fs" % (time.time() - t0))
     n_err = int(total_bases * err_factor)
     cap = int(total_bases * 1.03) + n_err + 1024
-    ix = m.Index(k, cap, device=device)
+    ix = (index_factory or m.Index)(k, cap, device=device)
     add_reads_from_truth(ix, truth, k, lam, seed)
     torch.cuda.synchronize()
     say("read counts from truth added: %.1fs" % (time.time() - t0))
