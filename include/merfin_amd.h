@@ -221,15 +221,25 @@ void mfx_hist_result_free(mfx_hist_result *r);
 
 /* The same with the upload inside: SURVEY 8(d)'s evaluate phase, "first tile H2D start -> final reduced histogram
  * on host".  `seq` = mfx_seq_create(device, lens, n) (layout + device buffers, no bases yet); bases[i] = host
- * buffer of contig i.  The tiles are uploaded in 64 MB chunks on a copy stream while the -hist kernel of the
- * previous chunk runs; buffers obtained from mfx_host_alloc (pinned: what a loader should read the FASTA into)
- * are DMA'd in place, pageable ones are staged through pinned memory by host threads.  The result is
- * bit-identical to mfx_seq_upload + mfx_hist_run (koverCpy included: the per-tile values are summed once, at the
- * end).  Afterwards `seq` holds the whole assembly and can be used like an uploaded one. */
+ * buffer of contig i (pinned or pageable, ASCII).  The assembly crosses PCIe PACKED: host threads encode it into
+ * 2-bit codes + one validity bit per base (0.375 B/base; mfx_pack_bases below -- the kmerIterator encoding of
+ * merfin.C:45 moved in front of the bus) chunk by chunk, while the previous chunk is on the copy stream and the one
+ * before is evaluated; the kernel reads its tiles from the packed planes.  Chunks grow from 8 MB to 128 MB of bases;
+ * consecutive launches alternate between two streams so that one's first blocks fill the CUs the other's last blocks
+ * leave.  3 Gb: 36.5 ms against 33.4 ms for the resident run (56 ms with one byte per base on the bus).  The result
+ * is bit-identical to mfx_seq_upload + mfx_hist_run (koverCpy included: the per-tile values are summed once, at the
+ * end).  Afterwards `seq` holds the whole assembly and can be used like an uploaded one (the kernels that read one
+ * byte per base unpack the planes on first use).  k > 31 and MFX_STREAM_ASCII=1: one byte per base, 64 MB chunks,
+ * pinned buffers DMA'd in place, pageable ones staged through pinned memory. */
 void    *mfx_host_alloc(size_t bytes);
 void     mfx_host_free(void *p);
 mfx_seq *mfx_seq_create(int device, const uint64_t *lens, uint32_t ncontigs);
 int      mfx_hist_run_streamed(mfx_eval *ev, mfx_seq *seq, const char *const *bases, mfx_hist_result *out);
+/* The host-side encoder of that transport (AVX-512 / AVX2 / scalar, chosen at run time; ~28 GB/s per core of an EPYC
+ * 9575F): n bases -> ceil(n/32) words.  codes[w] holds bases 32w..32w+31, the first in the two HIGHEST bits,
+ * code = (c >> 1) & 3 (A 0, C 1, T 2, G 3, either case); valid[w] holds one bit per base, the first in the highest
+ * bit, set iff the base is one of ACGTacgt.  A last partial word is zero-filled. */
+void     mfx_pack_bases(const uint8_t *src, uint64_t n, uint64_t *codes, uint32_t *valid);
 
 /* Several GPUs of one node driven by ONE process -- the reference is one binary driving all its workers
  * (merfin.C:366-414).  The index is replicated (mfx_index_replicate: peer copy over xGMI, instead of N builds),

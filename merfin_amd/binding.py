@@ -73,7 +73,7 @@ SYMBOLS = [
     "mfx_eval_create", "mfx_eval_free", "mfx_eval_nbins", "mfx_getK", "mfx_getKmetric", "mfx_histoQV",
     "mfx_hist_run", "mfx_hist_result_free", "mfx_hist_launch", "mfx_hist_launch_cyclic", "mfx_hist_result_from_counts",
     "mfx_hist_take_overflow", "mfx_hist_report",
-    "mfx_dump_values", "mfx_dump_contig", "mfx_dump_values_sharded", "mfx_dump_contig_sharded", "mfx_variants_run_sharded", "mfx_completeness", "mfx_completeness_pieces", "mfx_variants_run",
+    "mfx_pack_bases", "mfx_dump_values", "mfx_dump_contig", "mfx_dump_values_sharded", "mfx_dump_contig_sharded", "mfx_variants_run_sharded", "mfx_completeness", "mfx_completeness_pieces", "mfx_variants_run",
     "mfx_index_set_shard", "mfx_router_create", "mfx_router_free", "mfx_route_tiles", "mfx_hist_keys_launch",
 ]
 
@@ -180,6 +180,8 @@ def load_library():
                                    C.POINTER(_VarOpts), C.c_char_p, C.c_char_p, u64p]
     L.mfx_index_set_fingerprint.argtypes = [vp, C.c_uint64]
     L.mfx_index_get_origin.argtypes = [vp, u64p, u64p, u64p]
+    L.mfx_pack_bases.restype = None
+    L.mfx_pack_bases.argtypes = [vp, C.c_uint64, vp, vp]
     L.mfx_host_alloc.restype = vp
     L.mfx_host_alloc.argtypes = [C.c_size_t]
     L.mfx_host_free.restype = None
@@ -607,6 +609,16 @@ def hist_sharded(evaluators, routers, sequences):
     r = HistResult()
     _check(load_library().mfx_hist_run_sharded(ev, ro, sq, n, C.byref(r.c)))
     return r
+
+
+def pack_bases(seq):
+    """host-side encoding of the packed sequence transport: bytes -> (codes uint64[ceil(n/32)], valid uint32[ceil(n/32)])"""
+    src = np.frombuffer(bytes(seq), dtype=np.uint8)
+    nw = (len(src) + 31) // 32
+    codes = np.zeros(max(nw, 1), dtype=np.uint64)
+    valid = np.zeros(max(nw, 1), dtype=np.uint32)
+    load_library().mfx_pack_bases(C.c_void_p(src.ctypes.data), len(src), C.c_void_p(codes.ctypes.data), C.c_void_p(valid.ctypes.data))
+    return codes[:nw], valid[:nw]
 
 
 def dump_values_sharded(evaluators, sequences, contig, pos_begin, pos_end):

@@ -14,6 +14,8 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -476,6 +478,7 @@ extern "C" int mfx_index_add_asm(mfx_index *ix, const uint64_t *kmers, const uin
 extern "C" int mfx_index_count_asm(mfx_index *ix, const mfx_seq *seq, void *stream) {
   if (!ix || !seq) return mfx_fail(MFX_E_INVAL, "mfx_index_count_asm: null argument");
   if (ix->device != seq->device) return mfx_fail(MFX_E_INVAL, "index and sequence live on different devices");
+  if (int erc = mfx_seq_ensure_ascii(seq)) return erc;
   DevGuard g(ix->device);
   mfx_count_args a;
   a.t = ix->view();
@@ -589,6 +592,18 @@ static int seq_alloc(mfx_seq *s) {
   return MFX_OK;
 }
 
+// A packed upload (mfx_hist_run_streamed) leaves the sequence in its packed planes only; the kernels that read one byte
+// per base get them unpacked here, once, on first use.
+int mfx_seq_ensure_ascii(const mfx_seq *cs) {
+  if (!cs->bases_stale) return MFX_OK;
+  mfx_seq *s = const_cast<mfx_seq *>(cs);
+  DevGuard g(s->device);
+  MFX_HIP(mfx_k_unpack(s->d_codes, s->d_valid, s->d_bases, s->buf_bytes / 32, nullptr));
+  MFX_HIP(hipDeviceSynchronize());
+  s->bases_stale = false;
+  return MFX_OK;
+}
+
 extern "C" mfx_seq *mfx_seq_upload(int device, const char *const *bases, const uint64_t *lens, uint32_t ncontigs) {
   if ((ncontigs && (!bases || !lens)) || device < 0 || device >= mfx_device_count()) {
     mfx_fail(device < 0 || device >= mfx_device_count() ? MFX_E_NODEVICE : MFX_E_INVAL,
@@ -693,6 +708,8 @@ extern "C" void mfx_seq_free(mfx_seq *s) {
   if (!s) return;
   DevGuard g(s->device);
   if (s->d_bases) (void)hipFree(s->d_bases);
+  if (s->d_codes) (void)hipFree(s->d_codes);
+  if (s->d_valid) (void)hipFree(s->d_valid);
   if (s->d_contig_off) (void)hipFree(s->d_contig_off);
   if (s->d_contig_len) (void)hipFree(s->d_contig_len);
   if (s->d_tile_start) (void)hipFree(s->d_tile_start);
@@ -735,8 +752,8 @@ extern "C" mfx_eval *mfx_eval_create(const mfx_index *ix, const mfx_kparams *kp,
   if (hipMalloc((void **)&ev->d_probK, np * sizeof(uint32_t)) != hipSuccess ||
       hipMalloc((void **)&ev->d_probP, np * sizeof(double)) != hipSuccess ||
       hipMalloc((void **)&ev->d_partials, 2 * (size_t)ev->grid * sizeof(double)) != hipSuccess ||
-      hipMalloc((void **)&ev->d_tile_ctr, sizeof(uint64_t)) != hipSuccess ||
-      hipMemset(ev->d_tile_ctr, 0, sizeof(uint64_t)) != hipSuccess ||
+      hipMalloc((void **)&ev->d_tile_ctr, 2 * sizeof(uint64_t)) != hipSuccess ||
+      hipMemset(ev->d_tile_ctr, 0, 2 * sizeof(uint64_t)) != hipSuccess ||
       hipMalloc((void **)&ev->d_ovf, (1 + (size_t)MFX_OVF_CAP) * sizeof(uint64_t)) != hipSuccess ||
       hipMemset(ev->d_ovf, 0, sizeof(uint64_t)) != hipSuccess ||
       (ev->n_prob && hipMemcpy(ev->d_probK, ev->probK.data(), ev->n_prob * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) ||
@@ -758,6 +775,14 @@ extern "C" void mfx_eval_free(mfx_eval *ev) {
   if (ev->d_tile_partials) (void)hipFree(ev->d_tile_partials);
   if (ev->d_ovf) (void)hipFree(ev->d_ovf);
   for (auto &p : ev->h_stage) if (p) (void)hipHostFree(p);
+  for (auto &p : ev->h_pack) if (p) (void)hipHostFree(p);
+  if (ev->sr.d_counts) (void)hipFree(ev->sr.d_counts);
+  if (ev->sr.d_kover) (void)hipFree(ev->sr.d_kover);
+  if (ev->sr.h_img) (void)hipHostFree(ev->sr.h_img);
+  for (auto &e : ev->sr.up) if (e) (void)hipEventDestroy(e);
+  if (ev->sr.kdone) (void)hipEventDestroy(ev->sr.kdone);
+  if (ev->sr.copy) (void)hipStreamDestroy(ev->sr.copy);
+  for (auto &k : ev->sr.kern) if (k) (void)hipStreamDestroy(k);
   delete ev;
 }
 
@@ -823,7 +848,7 @@ static int ensure_tile_partials(mfx_eval *ev, uint64_t ntiles) {
 // their tile's place in ev->d_tile_partials (sized by the caller) and are summed ONCE after the last chunk, so
 // koverCpy is bit-identical to a single launch over the whole range, however the upload was cut.
 static int hist_launch(mfx_eval *ev, const mfx_seq *seq, uint64_t tile_begin, uint64_t tile_end, uint32_t part_rank, uint32_t part_n,
-                       uint32_t part_shift, uint64_t *d_counts, double *d_kover, void *stream, uint64_t chunk_of_total = 0) {
+                       uint32_t part_shift, uint64_t *d_counts, double *d_kover, void *stream, uint64_t chunk_of_total = 0, int ctr_slot = 0) {
   uint64_t ntl = tile_end - tile_begin;
   if (part_n > 1) {
     const uint64_t blk = 1ull << part_shift, nblk = (seq->ntiles + blk - 1) / blk;
@@ -841,10 +866,15 @@ static int hist_launch(mfx_eval *ev, const mfx_seq *seq, uint64_t tile_begin, ui
     rc = ensure_tile_partials(ev, ntl);
     if (rc) return rc;
   }
+  if (seq->bases_stale && ev->ix->wide()) {                 // the 128-bit kernels read one byte per base
+    rc = mfx_seq_ensure_ascii(seq);
+    if (rc) return rc;
+  }
   mfx_hist_args a;
   a.t = ev->ix->view();
   a.canonical = canon;
   a.bases = seq->d_bases;
+  if (seq->bases_stale) { a.codes = seq->d_codes; a.valid = seq->d_valid; }      // a packed upload: the planes are the sequence
   a.contig_off = seq->d_contig_off;
   a.contig_len = seq->d_contig_len;
   a.tile_start = seq->d_tile_start;
@@ -852,7 +882,7 @@ static int hist_launch(mfx_eval *ev, const mfx_seq *seq, uint64_t tile_begin, ui
   a.tile_begin = tile_begin;
   a.tile_end = tile_end;
   a.tile_contig = seq->d_tile_contig;
-  a.tile_ctr = ev->d_tile_ctr;
+  a.tile_ctr = ev->d_tile_ctr + ctr_slot;
   a.tile_partials = ev->d_tile_partials + (chunk_of_total ? tile_begin * (MFX_BLOCK / 64) : 0);
   a.n_logical = ntl;
   a.part_rank = part_rank;
@@ -869,7 +899,7 @@ static int hist_launch(mfx_eval *ev, const mfx_seq *seq, uint64_t tile_begin, ui
   a.ks.ovf = ev->d_ovf;
   MFX_HIP(ev->ix->wide() ? mfx_kw_hist(a, (int)std::min<uint64_t>((uint64_t)ev->grid, ntl), (hipStream_t)stream)
                           : mfx_k_hist(a, (int)std::min<uint64_t>((uint64_t)ev->grid, ntl), (hipStream_t)stream));
-  if (chunk_of_total) MFX_HIP(hipMemsetAsync(ev->d_tile_ctr, 0, sizeof(uint64_t), (hipStream_t)stream));   // re-arm the tile scheduler
+  if (chunk_of_total) MFX_HIP(hipMemsetAsync(ev->d_tile_ctr + ctr_slot, 0, sizeof(uint64_t), (hipStream_t)stream));   // re-arm the tile scheduler
   else MFX_HIP(mfx_k_sum_tile_partials(ev->d_tile_partials, ntl, d_kover, ev->d_tile_ctr, (hipStream_t)stream));
   return MFX_OK;
 }
@@ -1055,9 +1085,190 @@ void chunk_pieces(const mfx_seq *s, uint64_t t0, uint64_t t1, std::vector<Piece>
 }
 }  // namespace
 
+extern "C" void mfx_pack_bases(const uint8_t *src, uint64_t n, uint64_t *codes, uint32_t *valid);      // mfx_pack.cpp
+
+// The streamed -hist with the assembly crossing PCIe PACKED (0.375 B per base): host threads encode every chunk into
+// the tile form (2-bit codes + validity bits, csrc/mfx_pack.cpp) while the previous chunk is on the bus and the one
+// before is being evaluated; the kernel reads its tiles from the packed planes (mfx_tile_fill_packed).  One byte per
+// base never reaches the device (seq->bases_stale; unpacked on demand by mfx_seq_ensure_ascii).
+static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *const *bases, mfx_hist_result *out) {
+  DevGuard g(ev->device);
+  const bool timing = getenv("MFX_STREAM_TIMING") && atoi(getenv("MFX_STREAM_TIMING"));
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_begin = now();
+  double t_mark[6] = {0, 0, 0, 0, 0, 0};
+  const size_t words = MFX_HIST_WORDS(ev->nbins, seq->ncontigs);
+  const uint64_t T = seq->ntiles;
+  // chunks grow from 8 MB to 128 MB of bases: the first tile reaches the kernel after ~0.2 ms, and the bulk runs in few,
+  // long launches (every launch pays a ramp-up and a tail of its persistent blocks: 47 launches of 64 MB cost 38 ms of
+  // kernel time for 3 Gb, one launch 33.4 ms)
+  const uint64_t CH0 = 2048, CH = 32768;
+  constexpr int NB = 3;
+  const uint64_t plane_words = seq->buf_bytes / 32 + (MFX_TILE + 64) / 32 + 1;   // a tile reads 130 words from its first one
+  struct Chunk { std::vector<Piece> pieces; uint64_t lo = 0, hi = 0, t0 = 0, t1 = 0; };
+  std::vector<Chunk> chunks;
+  for (uint64_t t0 = 0, sz = CH0; t0 < T; sz = std::min(CH, sz * 2)) {
+    Chunk c;
+    c.t0 = t0;
+    c.t1 = std::min(T, t0 + sz);
+    if (T - c.t1 < sz / 2) c.t1 = T;                          // no short last launch (at most 1.5 x CH tiles)
+    t0 = c.t1;
+    chunk_pieces(seq, c.t0, c.t1, c.pieces);
+    if (!c.pieces.empty()) {
+      c.lo = seq->off[c.pieces.front().contig] + c.pieces.front().pos;                 // a multiple of 128
+      c.hi = (seq->off[c.pieces.back().contig] + c.pieces.back().pos + c.pieces.back().n + 31) / 32 * 32;
+    }
+    chunks.push_back(std::move(c));
+  }
+  size_t STAGE_W = 0;                                         // words of the largest chunk, rounded up to 1 MB of them
+  for (const Chunk &c : chunks) STAGE_W = std::max<size_t>(STAGE_W, (c.hi - c.lo) / 32);
+  STAGE_W = (STAGE_W + 2 + 131071) / 131072 * 131072;
+  std::vector<std::thread> workers;
+  std::atomic<int64_t> allowed{NB - 1};                     // chunks <= allowed may be packed (their staging buffer is free)
+  std::atomic<bool> stop{false};
+  std::vector<std::atomic<uint32_t>> done(chunks.size());
+  for (auto &d : done) d.store(0);
+  int rc = MFX_OK;
+  auto &R = ev->sr;
+  auto cleanup = [&]() {
+    stop.store(true);
+    for (auto &w : workers) w.join();
+    workers.clear();
+    if (R.copy) (void)hipStreamSynchronize(R.copy);
+    for (auto &k : R.kern) if (k) (void)hipStreamSynchronize(k);
+  };
+#define STREAMED_HIP(call)                                                                                        \
+  do {                                                                                                            \
+    hipError_t e_ = (call);                                                                                       \
+    if (e_ != hipSuccess) { rc = mfx_fail(MFX_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); cleanup(); return rc; } \
+  } while (0)
+  if (!seq->d_codes) {
+    STREAMED_HIP(hipMalloc((void **)&seq->d_codes, plane_words * sizeof(uint64_t)));
+    STREAMED_HIP(hipMalloc((void **)&seq->d_valid, plane_words * sizeof(uint32_t)));
+    STREAMED_HIP(hipMemset(seq->d_valid, 0, plane_words * sizeof(uint32_t)));           // no valid base outside the uploads
+    STREAMED_HIP(hipMemset(seq->d_codes, 0, plane_words * sizeof(uint64_t)));
+  }
+  // pinned staging (codes words, then validity words) belongs to the evaluator: pinning costs more than the evaluation
+  if (ev->h_pack_words != STAGE_W) {
+    for (auto &p : ev->h_pack) { if (p) (void)hipHostFree(p); p = nullptr; }
+    ev->h_pack_words = STAGE_W;
+  }
+  for (int b = 0; b < NB && b < (int)chunks.size(); ++b)
+    if (!ev->h_pack[b]) STREAMED_HIP(hipHostMalloc((void **)&ev->h_pack[b], STAGE_W * 12, hipHostMallocDefault));
+  seq->bases_stale = true;
+
+  // the packers: worker w encodes its share of the words of every chunk, in chunk order
+  const unsigned W = std::max(1u, std::min(mfx_host_threads(), 64u));
+  uint8_t *const *stage = ev->h_pack;
+  auto work = [&, W](unsigned w) {
+    for (size_t ci = 0; ci < chunks.size(); ++ci) {
+      while (allowed.load(std::memory_order_acquire) < (int64_t)ci) {
+        if (stop.load()) return;
+        std::this_thread::yield();
+      }
+      const Chunk &c = chunks[ci];
+      const uint64_t nw = (c.hi - c.lo) / 32, w0 = nw * w / W, w1 = nw * (w + 1) / W;
+      uint64_t *codes = reinterpret_cast<uint64_t *>(stage[ci % NB]);
+      uint32_t *valid = reinterpret_cast<uint32_t *>(stage[ci % NB] + (size_t)STAGE_W * 8);
+      if (w1 > w0) {
+        memset(codes + w0, 0, (w1 - w0) * 8);                // gaps between contigs and the words behind a contig's end
+        memset(valid + w0, 0, (w1 - w0) * 4);
+        const uint64_t my_lo = c.lo + 32 * w0, my_hi = c.lo + 32 * w1;
+        for (const Piece &pc : c.pieces) {
+          const uint64_t at = seq->off[pc.contig] + pc.pos;      // a multiple of 128
+          const uint64_t s = std::max(my_lo, at), e = std::min(my_hi, at + pc.n);
+          if (e > s) mfx_pack_bases(reinterpret_cast<const uint8_t *>(bases[pc.contig]) + pc.pos + (s - at), e - s, codes + (s - c.lo) / 32, valid + (s - c.lo) / 32);
+        }
+      }
+      done[ci].fetch_add(1, std::memory_order_release);
+    }
+  };
+  t_mark[0] = now();
+  for (unsigned w = 0; w < W; ++w) workers.emplace_back(work, w);
+  t_mark[1] = now();
+  // streams, events, the counts image and its pinned mirror: created once per evaluator (while the packers start)
+  if (R.words < words) {
+    if (R.d_counts) (void)hipFree(R.d_counts);
+    if (R.h_img) (void)hipHostFree(R.h_img);
+    R.d_counts = nullptr; R.h_img = nullptr; R.words = 0;
+    STREAMED_HIP(hipMalloc((void **)&R.d_counts, words * sizeof(uint64_t)));
+    STREAMED_HIP(hipHostMalloc((void **)&R.h_img, (words + 1) * sizeof(uint64_t), hipHostMallocDefault));
+    R.words = words;
+  }
+  if (!R.d_kover) STREAMED_HIP(hipMalloc((void **)&R.d_kover, sizeof(double)));
+  if (!R.copy) STREAMED_HIP(hipStreamCreateWithFlags(&R.copy, hipStreamNonBlocking));
+  for (auto &k : R.kern) if (!k) STREAMED_HIP(hipStreamCreateWithFlags(&k, hipStreamNonBlocking));
+  for (auto &e : R.up) if (!e) STREAMED_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  if (!R.kdone) STREAMED_HIP(hipEventCreateWithFlags(&R.kdone, hipEventDisableTiming));
+  hipStream_t cs = R.copy, ks = R.kern[0];
+  uint64_t *const d_counts = R.d_counts, *const h_img = R.h_img;
+  double *const d_kover = R.d_kover;
+  hipEvent_t *const up = R.up;
+  STREAMED_HIP(hipMemsetAsync(d_counts, 0, words * sizeof(uint64_t), ks));
+  STREAMED_HIP(hipMemsetAsync(d_kover, 0, sizeof(double), ks));
+  STREAMED_HIP(hipMemsetAsync(ev->d_tile_ctr, 0, 2 * sizeof(uint64_t), ks));
+  STREAMED_HIP(hipMemsetAsync(ev->d_ovf, 0, sizeof(uint64_t), ks));
+  STREAMED_HIP(hipEventRecord(R.kdone, ks));
+  STREAMED_HIP(hipStreamWaitEvent(R.kern[1], R.kdone, 0));          // the second kernel stream starts behind the clears
+  if ((rc = ensure_tile_partials(ev, T)) != MFX_OK) { cleanup(); return rc; }
+
+  for (size_t ci = 0; ci < chunks.size(); ++ci) {
+    const Chunk &c = chunks[ci];
+    const int b = (int)(ci % NB);
+    if (ci >= 1) {
+      // the copy of chunk ci-1 has left its buffer: chunk ci-1+NB may be packed into it
+      STREAMED_HIP(hipEventSynchronize(up[(ci - 1) % NB]));
+      allowed.store((int64_t)(ci - 1 + NB), std::memory_order_release);
+    }
+    while (done[ci].load(std::memory_order_acquire) < W) std::this_thread::yield();
+    if (c.hi > c.lo) {
+      const uint64_t nw = (c.hi - c.lo) / 32;
+      STREAMED_HIP(hipMemcpyAsync(seq->d_codes + c.lo / 32, stage[b], nw * 8, hipMemcpyHostToDevice, cs));
+      STREAMED_HIP(hipMemcpyAsync(seq->d_valid + c.lo / 32, stage[b] + (size_t)STAGE_W * 8, nw * 4, hipMemcpyHostToDevice, cs));
+    }
+    STREAMED_HIP(hipEventRecord(up[b], cs));
+    // two kernel streams (and tile counters) alternate: the first blocks of a launch fill the CUs the previous launch's
+    // last blocks leave behind, instead of waiting for its tail
+    hipStream_t kst = R.kern[ci & 1];
+    STREAMED_HIP(hipStreamWaitEvent(kst, up[b], 0));
+    rc = hist_launch(ev, seq, c.t0, c.t1, 0, 1, 0, d_counts, d_kover, kst, T, (int)(ci & 1));
+    if (rc) { cleanup(); return rc; }
+  }
+  t_mark[2] = now();
+  STREAMED_HIP(hipEventRecord(R.kdone, R.kern[1]));
+  STREAMED_HIP(hipStreamWaitEvent(ks, R.kdone, 0));
+  if (T) STREAMED_HIP(mfx_k_sum_tile_partials(ev->d_tile_partials, T, d_kover, ev->d_tile_ctr, ks));
+  STREAMED_HIP(hipMemcpyAsync(h_img, d_counts, words * sizeof(uint64_t), hipMemcpyDeviceToHost, ks));
+  STREAMED_HIP(hipMemcpyAsync(h_img + words, d_kover, sizeof(double), hipMemcpyDeviceToHost, ks));
+  STREAMED_HIP(hipStreamSynchronize(ks));
+  t_mark[3] = now();
+#undef STREAMED_HIP
+  double kover;
+  memcpy(&kover, h_img + words, sizeof(double));
+  rc = mfx_hist_result_from_counts(ev->nbins, h_img, kover, seq->ncontigs, out);
+  const uint64_t novf = h_img[2ull * ev->nbins + 2];
+  t_mark[4] = now();
+  cleanup();
+  t_mark[5] = now();
+  if (timing)
+    fprintf(stderr, "[mfx stream] %zu chunks: setup %.2f ms, spawn %.2f, enqueue loop %.2f, drain %.2f, result %.2f, cleanup %.2f\n", chunks.size(),
+            (t_mark[0] - t_begin) * 1e3, (t_mark[1] - t_mark[0]) * 1e3, (t_mark[2] - t_mark[1]) * 1e3, (t_mark[3] - t_mark[2]) * 1e3,
+            (t_mark[4] - t_mark[3]) * 1e3, (t_mark[5] - t_mark[4]) * 1e3);
+  if (rc) return rc;
+  rc = result_take_overflow(ev, novf, out);
+  if (rc) mfx_hist_result_free(out);
+  return rc;
+}
+
 extern "C" int mfx_hist_run_streamed(mfx_eval *ev, mfx_seq *seq, const char *const *bases, mfx_hist_result *out) {
   if (!ev || !seq || !out || (seq->ncontigs && !bases)) return mfx_fail(MFX_E_INVAL, "mfx_hist_run_streamed: null argument");
   if (ev->device != seq->device) return mfx_fail(MFX_E_INVAL, "evaluator and sequence live on different devices");
+  {
+    // default: the assembly crosses the bus packed; MFX_STREAM_ASCII=1 (and the 128-bit k-mer kernels) send one byte per base
+    const char *asc = getenv("MFX_STREAM_ASCII");
+    if (!ev->ix->wide() && !(asc && atoi(asc))) return hist_run_streamed_packed(ev, seq, bases, out);
+  }
+  seq->bases_stale = false;                                 // this path writes d_bases
   DevGuard g(ev->device);
   const size_t words = MFX_HIST_WORDS(ev->nbins, seq->ncontigs);
   const uint64_t T = seq->ntiles;
@@ -1206,6 +1417,7 @@ extern "C" mfx_seq *mfx_seq_replicate(const mfx_seq *src, int device) {
     mfx_fail(MFX_E_INVAL, "mfx_seq_replicate: bad argument (device %d of %d)", device, mfx_device_count());
     return nullptr;
   }
+  if (mfx_seq_ensure_ascii(src)) return nullptr;
   mfx_seq *s = mfx_seq_create(device, src->len.data(), src->ncontigs);
   if (!s) return nullptr;
   DevGuard g(device);
@@ -1418,6 +1630,7 @@ extern "C" int mfx_route_tiles(mfx_router *r, const mfx_seq *seq, uint64_t tile_
   if (rc) return rc;
   if (!canon) return mfx_fail(MFX_E_INVAL, "a sharded index needs a canonical k-mer database and odd k");
   const uint64_t n = (tile_end - tile_begin) * MFX_TILE;
+  if (int erc = mfx_seq_ensure_ascii(seq)) return erc;
   mfx_route_args a;
   a.t = r->ix->view();
   a.bases = seq->d_bases;
@@ -1607,6 +1820,7 @@ extern "C" int mfx_dump_values(mfx_eval *ev, const mfx_seq *seq, uint32_t contig
     return mfx_fail(MFX_E_INVAL, "mfx_dump_values: range [%lu,%lu) outside contig %u of length %lu",
                     (unsigned long)pos_begin, (unsigned long)pos_end, contig,
                     (unsigned long)(contig < seq->ncontigs ? seq->len[contig] : 0));
+  if (int erc = mfx_seq_ensure_ascii(seq)) return erc;
   DevGuard g(ev->device);
   int canon = 0;
   int rc = index_canonical(ev->ix, &canon);
@@ -1663,6 +1877,7 @@ extern "C" int mfx_dump_values_sharded(mfx_eval *const *evs, const mfx_seq *cons
     if (evs[d]->device != seqs[d]->device || seqs[d]->ncontigs != seqs[0]->ncontigs || contig >= seqs[d]->ncontigs ||
         seqs[d]->len[contig] != seqs[0]->len[contig])
       return mfx_fail(MFX_E_INVAL, "slot %u: the sequences must be copies of one another, each on its evaluator's device", d);
+    if (int erc = mfx_seq_ensure_ascii(seqs[d])) return erc;
   }
   const mfx_seq *seq0 = seqs[0];
   if (pos_begin > pos_end || pos_end > seq0->len[contig])

@@ -66,6 +66,15 @@ __device__ __forceinline__ void mfx_tile_fill(mfx_tile_lds &L, const uint8_t *__
   }
 }
 
+// the same tile from the PACKED planes of a sequence (mfx_seq::d_codes / d_valid: the whole buffer in the tile's own
+// form, written by the host packer csrc/mfx_pack.cpp): a straight copy of 130 words; w0 = first word of the tile
+__device__ __forceinline__ void mfx_tile_fill_packed(mfx_tile_lds &L, const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid) {
+  for (uint32_t i = threadIdx.x; i < MFX_TILE_WORDS; i += MFX_BLOCK) {
+    L.codes[i] = codes[i];
+    L.valid[i] = valid[i];
+  }
+}
+
 __device__ __forceinline__ uint64_t mfx_wave_sum(uint64_t v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);

@@ -110,13 +110,20 @@ struct mfx_seq {
   uint64_t  total_bases = 0;
   uint64_t  ntiles = 0;
   uint64_t  buf_bytes = 0;
-  uint8_t  *d_bases = nullptr;       // packed, padded contigs
+  uint8_t  *d_bases = nullptr;       // padded contigs, one byte per base
+  // packed planes of the same buffer (word i = bytes [32 i, 32 i + 32)), allocated and filled by a packed upload
+  // (mfx_hist_run_streamed); bases_stale: the planes are newer than d_bases (mfx_seq_ensure_ascii unpacks on demand)
+  uint64_t *d_codes = nullptr;
+  uint32_t *d_valid = nullptr;
+  bool      bases_stale = false;
   uint64_t *d_contig_off = nullptr;  // [ncontigs]   byte offset of each contig
   uint64_t *d_contig_len = nullptr;  // [ncontigs]
   uint64_t *d_tile_start = nullptr;  // [ncontigs+1] first tile of each contig
   uint32_t *d_tile_contig = nullptr; // [ntiles] contig of each tile
   std::vector<uint64_t> off, len, tile_start;
 };
+
+int mfx_seq_ensure_ascii(const mfx_seq *s);      // unpacks the planes into d_bases if a packed upload left them newer (mfx_api.cpp)
 
 struct mfx_eval {
   const mfx_index *ix = nullptr;
@@ -132,10 +139,21 @@ struct mfx_eval {
   uint64_t  canon_version = ~0ull;   // index version the cached `canon` flag belongs to
   int       canon = 0;
   double   *d_partials = nullptr;    // [2*grid] per-block koverCpy partial sums (key-driven kernel)
-  uint64_t *d_tile_ctr = nullptr;    // dynamic tile scheduler counter of mfx_hist_kernel (0 between launches)
+  uint64_t *d_tile_ctr = nullptr;    // [2] dynamic tile scheduler counters of mfx_hist_kernel (0 between launches); the second serves launches that overlap the first's
   double   *d_tile_partials = nullptr; // per-(tile,wave) koverCpy of the last launch + the chunk sums behind them
   uint64_t  tile_partials_cap = 0;   // doubles allocated
   uint64_t *d_ovf = nullptr;         // [0] count, [1..] records
   uint8_t  *h_stage[2] = {nullptr, nullptr};   // pinned staging of the streamed upload (pageable sources), kept between calls
   size_t    h_stage_bytes = 0;
+  uint8_t  *h_pack[3] = {nullptr, nullptr, nullptr};   // pinned staging of the PACKED streamed upload (codes then validity words)
+  size_t    h_pack_words = 0;
+  // what a streamed run needs besides, kept between calls (creating and releasing it costs ~2.5 ms, 7 % of a 3 Gb run)
+  struct {
+    uint64_t  *d_counts = nullptr;                      // counts image
+    size_t     words = 0;
+    double    *d_kover = nullptr;
+    uint64_t  *h_img = nullptr;                         // pinned: image + koverCpy
+    hipStream_t copy = nullptr, kern[2] = {nullptr, nullptr};
+    hipEvent_t up[3] = {nullptr, nullptr, nullptr}, kdone = nullptr;
+  } sr;
 };

@@ -19,6 +19,8 @@ struct mfx_hist_args {
   mfx_table_view  t;
   int             canonical;          // 1: single probe of min(f,r); 0: probe both strands and sum
   const uint8_t  *bases;
+  const uint64_t *codes = nullptr;    // non-null: read the tiles from the packed planes (same byte offsets / 32) instead of `bases`
+  const uint32_t *valid = nullptr;
   const uint64_t *contig_off, *contig_len, *tile_start;
   uint32_t        ncontigs;
   uint64_t        tile_begin, tile_end;
@@ -114,6 +116,7 @@ hipError_t mfx_kw_completeness(mfx_table_view t, double peak, uint32_t n_prob, c
                                int grid, hipStream_t st);
 hipError_t mfx_k_dump(const mfx_dump_args &a, hipStream_t st);
 hipError_t mfx_k_add_u32(uint32_t *dst, const uint32_t *src, uint64_t n, hipStream_t st);
+hipError_t mfx_k_unpack(const uint64_t *codes, const uint32_t *valid, uint8_t *bases, uint64_t nwords, hipStream_t st);
 hipError_t mfx_k_count(const mfx_count_args &a, hipStream_t st);
 hipError_t mfx_k_completeness(mfx_table_view t, double peak, uint32_t n_prob, const uint32_t *probK, const double *probP,
                               double *partials, int grid, hipStream_t st);

@@ -648,7 +648,12 @@ __global__ __launch_bounds__(MFX_BLOCK, 4) void mfx_hist_kernel(mfx_hist_args a)
     const uint32_t n = (clen - pos0 < MFX_TILE) ? (uint32_t)(clen - pos0) : MFX_TILE;
     const uint8_t *src = a.bases + a.contig_off[c] + pos0;
 
-    mfx_tile_fill(L, src);                   // the previous tile was fully consumed at the barrier below
+    if (a.codes) {                           // block-uniform: the sequence arrived packed (mfx_hist_run_streamed)
+      const uint64_t w0 = (a.contig_off[c] + pos0) >> 5;
+      mfx_tile_fill_packed(L, a.codes + w0, a.valid + w0);
+    } else {
+      mfx_tile_fill(L, src);                 // the previous tile was fully consumed at the barrier below
+    }
     __syncthreads();
 
     double kover = 0.0;                      // this lane's koverCpy terms of this tile
@@ -1089,6 +1094,32 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_dump_kernel(mfx_dump_args a) {
   }
 }
 
+// packed planes -> ASCII bases (for the kernels that read mfx_seq::d_bases after a packed upload): one thread per 16
+// bases; invalid positions become 'N'
+__global__ __launch_bounds__(MFX_BLOCK) void mfx_unpack_kernel(const uint64_t *codes, const uint32_t *valid, uint8_t *bases, uint64_t nwords) {
+  const uint64_t stride = (uint64_t)gridDim.x * MFX_BLOCK;
+  for (uint64_t i = (uint64_t)blockIdx.x * MFX_BLOCK + threadIdx.x; i < 2 * nwords; i += stride) {
+    const uint64_t w = i >> 1;
+    const uint32_t h = (uint32_t)i & 1u;
+    const uint32_t c = (uint32_t)(codes[w] >> (h ? 0 : 32));           // 16 codes, first in the two highest bits
+    const uint32_t v = (valid[w] >> (h ? 0 : 16)) & 0xffffu;
+    uint32_t out[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      uint32_t x = 0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int j = q * 4 + b;
+        const uint32_t code = (c >> (30 - 2 * j)) & 3u;
+        const uint32_t ch = ((v >> (15 - j)) & 1u) ? ((0x47544341u >> (8 * code)) & 0xffu) : 0x4Eu;    // "ACTG"[code] or 'N'
+        x |= ch << (8 * b);
+      }
+      out[q] = x;
+    }
+    *reinterpret_cast<uint4 *>(bases + 16 * i) = make_uint4(out[0], out[1], out[2], out[3]);
+  }
+}
+
 // dst[i] += src[i]: the value arrays of the shards of one index add up to the whole index's values (every k-mer has
 // exactly one owner; the other shards answer 0)
 __global__ __launch_bounds__(MFX_BLOCK) void mfx_add_u32_kernel(uint32_t *dst, const uint32_t *src, uint64_t n) {
@@ -1271,6 +1302,13 @@ int mfx_k_hist_resident_blocks() {
   int nb = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mfx_hist_kernel<true>, MFX_BLOCK, 0) != hipSuccess || nb < 1) nb = 4;
   return nb;
+}
+hipError_t mfx_k_unpack(const uint64_t *codes, const uint32_t *valid, uint8_t *bases, uint64_t nwords, hipStream_t st) {
+  if (nwords == 0) return hipSuccess;
+  uint64_t blocks = (2 * nwords + MFX_BLOCK - 1) / MFX_BLOCK;
+  if (blocks > 65536) blocks = 65536;
+  mfx_unpack_kernel<<<(unsigned)blocks, MFX_BLOCK, 0, st>>>(codes, valid, bases, nwords);
+  return hipGetLastError();
 }
 hipError_t mfx_k_add_u32(uint32_t *dst, const uint32_t *src, uint64_t n, hipStream_t st) {
   if (n == 0) return hipSuccess;

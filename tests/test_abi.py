@@ -110,3 +110,36 @@ def test_compressed_files_with_shell_metacharacters_in_the_name(tmp_path):
     # an output directory that does not exist
     with pytest.raises(m.MfxError):
         res.report(21, str(tmp_path / "no such dir" / "x.hist.gz"), None)
+
+
+def test_sequence_packer_bodies_agree(monkeypatch):
+    """mfx_pack_bases (host side of the packed sequence transport): the vector bodies the CPU offers equal the scalar
+    definition on every byte value, every length mod 64, and the documented bit layout (first base in the highest bits;
+    code = (c >> 1) & 3; valid iff ACGTacgt -- the device's own tile encoding, csrc/mfx_device.h)"""
+    import merfin_amd as m
+    r = np.random.default_rng(5)
+    allbytes = bytes(range(256))
+    text = allbytes + bytes(r.choice(np.frombuffer(b"ACGTacgtNn\x00 -*", dtype=np.uint8), size=5000)) + allbytes[::-1] + b"ACGT" * 40
+
+    def definition(b):
+        nw = (len(b) + 31) // 32
+        codes, valid = [0] * nw, [0] * nw
+        for i, c in enumerate(b):
+            codes[i // 32] |= ((c >> 1) & 3) << (62 - 2 * (i % 32))
+            valid[i // 32] |= (1 if chr(c) in "ACGTacgt" else 0) << (31 - (i % 32))
+        return np.array(codes, dtype=np.uint64), np.array(valid, dtype=np.uint32)
+
+    for isa in ("scalar", "avx2", None):               # None: the best body this CPU has (AVX-512 VBMI where present)
+        if isa:
+            monkeypatch.setenv("MFX_PACK_ISA", isa)
+        else:
+            monkeypatch.delenv("MFX_PACK_ISA", raising=False)
+        for cut in list(range(0, 70)) + [len(text) - 3, len(text)]:
+            c, v = m.pack_bases(text[:cut])
+            dc, dv = definition(text[:cut])
+            assert np.array_equal(c, dc) and np.array_equal(v, dv), (isa, cut)
+        c, v = m.pack_bases(text[7:])                      # unaligned source address
+        dc, dv = definition(text[7:])
+        assert np.array_equal(c, dc) and np.array_equal(v, dv)
+    c, v = m.pack_bases(b"ACGTNacgt")
+    assert int(c[0]) == 0x1EC7800000000000 and int(v[0]) == 0xF7800000

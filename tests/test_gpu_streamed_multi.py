@@ -25,9 +25,14 @@ def _same(a, b):
     assert a.koverCpy == b.koverCpy                      # bit-identical: same values, same summation tree
 
 
+@pytest.mark.parametrize("transport", ["packed", "ascii"])
 @pytest.mark.parametrize("shape", ["few_large", "many_small", "edges"])
-def test_streamed_equals_resident_and_oracle(shape):
+def test_streamed_equals_resident_and_oracle(shape, transport, monkeypatch):
+    """transport: "packed" = the default (2-bit codes + validity bits over PCIe, the kernel reads packed tiles),
+    "ascii" = MFX_STREAM_ASCII=1 (one byte per base; what k > 31 uses)"""
     import merfin_amd as m
+    if transport == "ascii":
+        monkeypatch.setenv("MFX_STREAM_ASCII", "1")
     k, peak = 21, 17.3
     r = synth.rng(311)
     if shape == "few_large":
@@ -54,6 +59,16 @@ def test_streamed_equals_resident_and_oracle(shape):
     s1 = m.Sequences.create(lens)
     _same(ev.hist_streamed(s1, contigs), resident)
     _same(ev.hist(s1), resident)                              # afterwards the sequence object is a normal resident one
+    # ... also for the kernels that read one byte per base (after a packed upload they unpack the planes first)
+    s0 = m.Sequences(contigs)
+    for c in [i for i, n in enumerate(lens) if n > 0][:4]:
+        a, b = ev.dump_values(s1, c, 0, lens[c]), ev.dump_values(s0, c, 0, lens[c])
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2:] == b[2:]
+    c1, c0 = m.Index(k, len(asm[0]) + 16), m.Index(k, len(asm[0]) + 16)
+    c1.count_asm(s1)
+    c0.count_asm(s0)
+    e1, e0 = c1.export(), c0.export()
+    assert all(np.array_equal(x, y) for x, y in zip(e1, e0)) and np.array_equal(e0[0], asm[0]) and np.array_equal(e0[2], asm[1])
     # (b) pinned buffers (mfx_host_alloc), DMA'd in place
     pins = [m.PinnedBuffer(n) for n in lens]
     for pb, c in zip(pins, contigs):
