@@ -68,7 +68,7 @@ typedef struct mfx_index mfx_index;
  * the -memory cap in GB (0 = none): creation fails with MFX_E_NOMEM when the
  * table would not fit, mirroring "Not enough memory to load databases".
  * mfx_index_estimate_gb is the SMALLEST table made for that capacity (load factor 0.7, what the cap is checked
- * against); when HBM is plentiful the table is made emptier -- down to load factor 0.4, within 0.62 of the free
+ * against); when HBM is plentiful the table is made emptier -- down to load factor 0.45, within 0.75 of the free
  * HBM and within max_gb -- because emptier lines mean fewer second probes (MFX_LOAD_FACTOR fixes the factor). */
 mfx_index *mfx_index_create(int k, uint64_t capacity_kmers, double max_gb, int device);
 void       mfx_index_free(mfx_index *ix);

@@ -76,9 +76,9 @@ struct DevBuf {   // scoped device scratch
 // Table fill target.  MFX_LOAD_FACTOR fixes it; otherwise it is chosen per index between MFX_LF_MAX (the least
 // memory a table may take: what mfx_index_estimate_gb reports and -memory is checked against) and MFX_LF_MIN,
 // as low as a share of the free HBM (and of max_gb) allows: emptier lines mean fewer full home lines and fewer
-// second probes (3 Gb -hist, w = 3: 0.7 -> 80, 0.6 -> 85, 0.5 -> 88, 0.4 -> 91 G k-mers/s), and 288 GB of HBM
-// are there to be used.
-constexpr double MFX_LF_MAX = 0.7, MFX_LF_MIN = 0.4, MFX_LF_HBM_SHARE = 0.62;
+// second probes (3 Gb -hist, w = 3: 0.7 -> 80, 0.6 -> 85, 0.52 -> 89.8, 0.45 -> 91.5, 0.40 -> 91.2 G k-mers/s: nothing is
+// gained below 0.45), and 288 GB of HBM are there to be used.
+constexpr double MFX_LF_MAX = 0.7, MFX_LF_MIN = 0.45, MFX_LF_HBM_SHARE = 0.75;
 
 bool load_factor_fixed(double *lf) {
   const char *e = getenv("MFX_LOAD_FACTOR");
