@@ -8,7 +8,7 @@ the size-independent properties of the domain (merfin-histogram.C:54-91):
     single-launch result, integers bit-exact, koverCpy to 1e-12,
   - the -hist kernel equals the -dump kernel + host-side K* (numpy float64, the reference's IEEE operations) on one
     whole contig.
-The two-index placement leg of test_gpu_fullsize.py is skipped here: two 181 GB tables do not fit one GPU.
+The two-index placement leg of test_gpu_fullsize.py is skipped here: two 200 GB-class tables do not fit one GPU.
 Needs ~200 GB of free HBM; MFX_TEST_CFG3_BASES scales it down for a smaller device (the test then says so).
 Config 5 (15 Gb, k=31, index sharded over 8 GPUs) cannot run at full size on the 1-GPU box: its code path is
 covered at k=31 by tests/test_gpu_sharded.py."""

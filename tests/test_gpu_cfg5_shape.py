@@ -1,6 +1,6 @@
 """BASELINE config 5's shape on one MI355X: k = 31, the index SHARDED over 8 slots (all on device 0 here -- the 15 Gb /
 2e10-k-mer wheat case needs the 8-GPU node for its 460 GB of table; what one GPU holds is a 3 Gb genome, i.e. the same
-181 GB-class table cut into 8 shards), `-hist` routed to the owners (mfx_hist_run_sharded) and `-completeness` summed
+200 GB-class table cut into 8 shards), `-hist` routed to the owners (mfx_hist_run_sharded) and `-completeness` summed
 over the shards.  The oracle cannot reach this size, so the sharded results are compared with the UNSHARDED run of the
 same library on the same world (built first, read out, freed): integers bit-exact, koverCpy to 1e-12, the 64 per-piece
 completeness sums exactly (they are integer-valued, merfin-completeness.C:117-123); plus the domain's own invariant
