@@ -174,6 +174,38 @@ static void print_completeness(const double *t64, const double *u64) {
   fprintf(stderr, "COMPLETENESS:             %0.5f\n", 1.0 - undrc / total);
 }
 
+// Upper bound of the bases in a sequence file WITHOUT reading it (0 = unknown): a plain file cannot hold more bases
+// than bytes; a gzip file records its uncompressed size modulo 2^32 in its last four bytes (RFC 1952 ISIZE), and DNA
+// text compresses 2-8x, which settles the multiple of 4 GiB.  Lets the k-mer table be sized -- and the read database
+// be loaded -- while the sequence file is still being read.
+static uint64_t bases_upper_bound(const char *path) {
+  struct stat st;
+  if (stat(path, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size <= 0) return 0;
+  const uint64_t size = (uint64_t)st.st_size;
+  const std::string p(path);
+  auto ends = [&](const char *suf) { const size_t n = strlen(suf); return p.size() >= n && p.compare(p.size() - n, n, suf) == 0; };
+  if (ends(".bz2") || ends(".xz") || ends(".zst")) return 0;
+  if (!ends(".gz")) return size;
+  if (size < 18) return 0;
+  FILE *f = fopen(path, "rb");
+  if (!f) return 0;
+  unsigned char t[4];
+  const bool ok = fseek(f, -4, SEEK_END) == 0 && fread(t, 1, 4, f) == 4;
+  fclose(f);
+  if (!ok) return 0;
+  const uint64_t isize = (uint64_t)t[0] | ((uint64_t)t[1] << 8) | ((uint64_t)t[2] << 16) | ((uint64_t)t[3] << 24);
+  // the largest isize + n * 2^32 that is at most 8x the compressed size (a file of several gzip members only records
+  // the last member's size: then the estimate may be LOW, so it must also be at least 2x the compressed size to be used)
+  uint64_t best = 0;
+  for (uint64_t n = 0; n < 4096; ++n) {
+    const uint64_t cand = isize + (n << 32);
+    if (cand > 8 * size + (1ull << 20)) break;
+    best = cand;
+  }
+  if (best < 2 * size) return 0;
+  return best;
+}
+
 // Every report over an index SHARDED across the devices of -devices (read databases beyond one GPU, BASELINE
 // config 5): slot d keeps the k-mers it owns (mfx_index_set_shard), loads skip foreign k-mers, -hist routes every k-mer
 // to its owner (mfx_hist_run_sharded), -completeness adds the per-piece sums of the shards in piece order
@@ -521,7 +553,10 @@ int main(int argc, char **argv) {
     for (size_t i = 0; i < recs.size(); ++i) { bases[i] = recs[i].bases.data(); lens[i] = recs[i].bases.size(); totalBases += lens[i]; }
     lap("read sequences");
   };
-  const bool deferSeq = G.seqName && G.seqDBname && !G.sharded;
+  // ... and without -seqmers whenever the file tells an upper bound of its bases: the table is sized by the bound, the
+  // read database is loaded while the file is read, the assembly k-mers are counted once it is in
+  const uint64_t basesBound = (G.seqName && !G.seqDBname) ? bases_upper_bound(G.seqName) : 0;
+  const bool deferSeq = G.seqName && !G.sharded && (G.seqDBname || basesBound > 0) && !(getenv("MFX_CLI_NO_OVERLAP") && atoi(getenv("MFX_CLI_NO_OVERLAP")));
   if (!deferSeq) finish_seq();
   if (G.sharded) {
     if (G.devices.size() < 2) {
@@ -569,21 +604,36 @@ int main(int argc, char **argv) {
     }
   }
   if (!ix) {
-    const uint64_t capacity = rdb.n_kmers + (G.seqDBname ? adb.n_kmers : totalBases) + 1024;
-    fprintf(stderr, "--\n-- Memory needed: %.3f GB\n-- Memory limit:  %.3f GB%s\n--\n", mfx_index_estimate_gb(k, capacity),
-            G.maxMemory, G.maxMemory > 0 ? "" : " (none)");
-    ix = mfx_index_create(k, capacity, G.maxMemory, G.device);
-    if (!ix) {
-      fprintf(stderr, "\n%s\n\n", mfx_last_error());
-      return 1;
-    }
-    fprintf(stderr, "-- Loading kmers from '%s' into lookup table.\n", G.readDBname);
-    if (mfx_index_load_db(ix, G.readDBname, 0, G.minV, G.maxV)) DIE_MFX("loading -readmers");
-    if (G.seqDBname) {
-      fprintf(stderr, "-- Loading kmers from '%s' into lookup table.\n", G.seqDBname);
-      if (mfx_index_load_db(ix, G.seqDBname, 1, 0, ~0ull)) DIE_MFX("loading -seqmers");
-    } else {
+    // the table is sized before the sequence is in when the file promised a bound on its bases; a file that breaks the
+    // promise (several gzip members, ...) costs a second build with the true number
+    for (int attempt = 0; !ix; ++attempt) {
+      const uint64_t capacity = rdb.n_kmers + (G.seqDBname ? adb.n_kmers : (seqDone ? totalBases : basesBound)) + 1024;
+      fprintf(stderr, "--\n-- Memory needed: %.3f GB\n-- Memory limit:  %.3f GB%s\n--\n", mfx_index_estimate_gb(k, capacity),
+              G.maxMemory, G.maxMemory > 0 ? "" : " (none)");
+      ix = mfx_index_create(k, capacity, G.maxMemory, G.device);
+      if (!ix) {
+        fprintf(stderr, "\n%s\n\n", mfx_last_error());
+        return 1;
+      }
+      fprintf(stderr, "-- Loading kmers from '%s' into lookup table.\n", G.readDBname);
+      if (mfx_index_load_db(ix, G.readDBname, 0, G.minV, G.maxV)) DIE_MFX("loading -readmers");
+      if (G.seqDBname) {
+        fprintf(stderr, "-- Loading kmers from '%s' into lookup table.\n", G.seqDBname);
+        if (mfx_index_load_db(ix, G.seqDBname, 1, 0, ~0ull)) DIE_MFX("loading -seqmers");
+        break;
+      }
       // replaces `meryl count k=.. <seq> output <seq>.meryl` (merfin-globals.C:182-186)
+      if (deferSeq && !seqDone) {            // the read database is in; now the sequence is needed
+        finish_seq();
+        if (totalBases > basesBound && attempt == 0) {
+          fprintf(stderr, "-- NOTE: '%s' holds %lu bases, more than its size promised (%lu); rebuilding the table.\n", G.seqName,
+                  (unsigned long)totalBases, (unsigned long)basesBound);
+          mfx_index_free(ix);
+          ix = nullptr;
+          continue;
+        }
+      }
+      if (!seq && !make_seq()) DIE_MFX("uploading sequences");
       fprintf(stderr, "-- No -seqmer given. Counting the %d-mers of '%s' on the GPU.\n", k, G.seqName);
       if (mfx_index_count_asm(ix, seq, nullptr)) DIE_MFX("counting sequence k-mers");
     }
@@ -594,7 +644,7 @@ int main(int argc, char **argv) {
   }
 
   lap("build / load index");
-  if (deferSeq) {
+  if (deferSeq && !seq) {
     finish_seq();
     if (!make_seq()) DIE_MFX("uploading sequences");
   }

@@ -271,3 +271,32 @@ def test_cli_hist_on_several_devices_of_one_process(tmp_path, golden_dir, device
     assert (tmp_path / "m.hist").read_bytes() == (tmp_path / "s.hist").read_bytes() == open(g("case1.hist"), "rb").read()
     tail = lambda s: s[s.index("K-mers not found in reads"):]
     assert tail(r.stderr) == tail(r1.stderr)
+
+
+@pytest.mark.gpu
+def test_cli_sequence_read_overlaps_the_index_build(tmp_path):
+    """Without -seqmers the k-mer table is sized from a bound the sequence FILE gives before it is read (plain: its size;
+    .gz: the ISIZE trailer), so that the read database loads while the file is read.  Same histogram with the overlap,
+    without it (MFX_CLI_NO_OVERLAP=1), from .gz, and from a .gz of two members whose trailer under-reports the size (the
+    table is then rebuilt with the true number)."""
+    import merfin_amd as m
+    k, peak = 21, 17.3
+    contigs, read, asm = synth.world(k=k, peak=peak, seed=71, sizes=(30000, 90000, 4000))
+    p = po.Params(k, peak)
+    g, ka, km, _ = po.hist_run(p, po.Lookup(k, *read), po.Lookup(k, *asm), contigs, threads=2)
+    po.report_histogram(p, g, str(tmp_path / "o.hist"), None)
+    want = (tmp_path / "o.hist").read_bytes()
+    m.db_write_flat(str(tmp_path / "read.mfxk"), k, *read)
+    plain, gz1, gz2 = str(tmp_path / "a.fasta"), str(tmp_path / "a1.fasta.gz"), str(tmp_path / "a2.fasta.gz")
+    _write_fasta(plain, contigs, gz=False)
+    _write_fasta(gz1, contigs, gz=True)
+    with open(gz2, "wb") as f:                               # two gzip members: ISIZE describes only the second
+        f.write(gzip.compress(b">ctg0\n" + contigs[0] + b"\n"))
+        f.write(gzip.compress(b">ctg1\n" + contigs[1] + b"\n>ctg2\n" + contigs[2] + b"\n"))
+    base = ["-hist", "-readmers", str(tmp_path / "read.mfxk"), "-peak", str(peak)]
+    for i, (fa, env, note) in enumerate([(plain, {}, False), (plain, {"MFX_CLI_NO_OVERLAP": "1"}, False), (gz1, {}, False), (gz2, {}, True)]):
+        out = str(tmp_path / ("g%d.hist" % i))
+        r = subprocess.run([EXE] + base + ["-sequence", fa, "-output", out], capture_output=True, text=True, env=dict(os.environ, MFX_CLI_TIMING="1", **env))
+        assert r.returncode == 0, r.stderr
+        assert open(out, "rb").read() == want, (fa, env)
+        assert ("more than its size promised" in r.stderr) == note, r.stderr
