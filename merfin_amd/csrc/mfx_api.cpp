@@ -940,12 +940,21 @@ extern "C" int mfx_hist_take_overflow(mfx_eval *ev, uint64_t *records, uint64_t 
   return (n > cap) ? mfx_fail(MFX_E_OVERFLOW, "overflow list has %lu records, caller buffer %lu", (unsigned long)n, (unsigned long)cap) : MFX_OK;
 }
 
-static void result_grow(uint64_t *&a, uint32_t &max, uint64_t need) {
-  if (need <= max) return;
-  uint64_t nm = (need + 1023) / 1024 * 1024;
-  a = (uint64_t *)realloc(a, nm * sizeof(uint64_t));
+// The reference's arrays grow in steps of 1024 under a uint32 bound (increaseArray(..., histOverMax, 1024),
+// merfin-histogram.C:74,87,116,121): a bin index above 2^32 - 1025 overflows that bound there (undefined behaviour);
+// here it is an error, as is running out of host memory (an index of 4e9 is 34 GB of bins, there as here).
+static int result_grow(uint64_t *&a, uint32_t &max, uint64_t need) {
+  if (need <= max) return MFX_OK;
+  const uint64_t nm = (need + 1023) / 1024 * 1024;
+  if (nm > 0xffffffffull)
+    return mfx_fail(MFX_E_INVAL, "K* histogram bin %lu is beyond the 32-bit array bound of merfin's histogram (merfin-histogram.C:74,87)",
+                    (unsigned long)(need - 1));
+  uint64_t *b = (uint64_t *)realloc(a, nm * sizeof(uint64_t));
+  if (!b) return mfx_fail(MFX_E_NOMEM, "no host memory for %lu K* histogram bins", (unsigned long)nm);
+  a = b;
   memset(a + max, 0, (nm - max) * sizeof(uint64_t));
   max = (uint32_t)nm;
+  return MFX_OK;
 }
 
 extern "C" int mfx_hist_result_from_counts(uint32_t nbins, const uint64_t *h, double kover, uint32_t ncontigs,
@@ -959,8 +968,12 @@ extern "C" int mfx_hist_result_from_counts(uint32_t nbins, const uint64_t *h, do
     if (h[nb + i]) om = i + 1;
   }
   // merfin-histogram.C:105-108: the global arrays start at 2048 entries
-  result_grow(out->undr, out->undrMax, std::max<uint32_t>(um, 2048));
-  result_grow(out->over, out->overMax, std::max<uint32_t>(om, 2048));
+  if (result_grow(out->undr, out->undrMax, std::max<uint32_t>(um, 2048)) || result_grow(out->over, out->overMax, std::max<uint32_t>(om, 2048))) {
+    free(out->undr);
+    free(out->over);
+    memset(out, 0, sizeof(*out));
+    return mfx_last_error_code();
+  }
   memcpy(out->undr, h, um * sizeof(uint64_t));
   memcpy(out->over, h + nb, om * sizeof(uint64_t));
   out->kasm = h[2ull * nb + 0];
@@ -974,20 +987,26 @@ extern "C" int mfx_hist_result_from_counts(uint32_t nbins, const uint64_t *h, do
   return MFX_OK;
 }
 
-static void result_add_overflow(mfx_hist_result *r, const std::vector<uint64_t> &rec) {
+static int result_add_overflow(mfx_hist_result *r, const std::vector<uint64_t> &rec) {
+  uint64_t mu = 0, mo = 0;                                   // grow once, to the largest index of the batch
   for (uint64_t x : rec) {
-    uint64_t idx = x & ~(1ull << 63);
-    if (x >> 63) { result_grow(r->over, r->overMax, idx + 1); r->over[idx]++; }
-    else         { result_grow(r->undr, r->undrMax, idx + 1); r->undr[idx]++; }
+    const uint64_t idx = x & ~(1ull << 63);
+    if (x >> 63) mo = std::max(mo, idx + 1); else mu = std::max(mu, idx + 1);
   }
+  if (int rc = result_grow(r->over, r->overMax, mo)) return rc;
+  if (int rc = result_grow(r->undr, r->undrMax, mu)) return rc;
+  for (uint64_t x : rec) {
+    const uint64_t idx = x & ~(1ull << 63);
+    if (x >> 63) r->over[idx]++; else r->undr[idx]++;
+  }
+  return MFX_OK;
 }
 
 static int result_take_overflow(mfx_eval *ev, uint64_t novf, mfx_hist_result *out);
 
 extern "C" int mfx_hist_result_add_overflow(mfx_hist_result *r, const uint64_t *records, uint64_t n) {
   if (!r || !r->undr || !r->over || (n && !records)) return mfx_fail(MFX_E_INVAL, "mfx_hist_result_add_overflow: null argument");
-  result_add_overflow(r, std::vector<uint64_t>(records, records + n));
-  return MFX_OK;
+  return result_add_overflow(r, std::vector<uint64_t>(records, records + n));
 }
 
 extern "C" int mfx_hist_run(mfx_eval *ev, const mfx_seq *seq, mfx_hist_result *out) {
@@ -1023,8 +1042,7 @@ static int result_take_overflow(mfx_eval *ev, uint64_t novf, mfx_hist_result *ou
   int rc = mfx_hist_take_overflow(ev, rec.data(), novf, &n);
   if (rc) return rc;
   rec.resize(std::min(n, novf));
-  result_add_overflow(out, rec);
-  return MFX_OK;
+  return result_add_overflow(out, rec);
 }
 
 // ---------------------------------------------------------------------------

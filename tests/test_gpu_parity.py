@@ -498,3 +498,76 @@ def test_both_insert_strategies_build_the_same_table(insert_mode, count_mode, mo
     np.testing.assert_array_equal(er[np.isin(ek, read[0])], read[1])
     np.testing.assert_array_equal(ea[np.isin(ek, asm[0])], asm[1])
     assert_hist_equal(m.Evaluator(ix, m.KParams(peak)).hist(seqs), g, ka, km, k)
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_randomized_worlds_match_oracle(seed, monkeypatch):
+    """A seeded sweep over what the fixed cases hold constant: k (3...31, odd and even), peak (also < 1 and huge), random
+    -prob tables (readK 0 for some counts, rows beyond and below the LDS look-up tables), read counts up to 200000, -min/-max,
+    table fill, minimizer windows, contig shapes (empty, shorter than k, N runs, lower case), -hist and -dump."""
+    m = _mfx()
+    r = np.random.default_rng(1000 + seed)
+    k = int(r.integers(3, 32))
+    peak = float(r.choice([0.37, 1.0, 2.5, 9.0, 17.3, 26.0, 333.3, 1e6]))
+    monkeypatch.setenv("MFX_LOAD_FACTOR", str(r.choice([0.3, 0.5, 0.7, 0.9])))
+    monkeypatch.setenv("MFX_MZ_W", str(int(r.integers(1, 6))))
+    if r.random() < 0.2:
+        monkeypatch.setenv("MFX_HOME_MODE", "plain")
+    sizes = tuple(int(x) for x in r.choice([0, 1, k - 1, k, k + 1, 37, 500, 4095, 4096, 4097, 9000, 20000], size=int(r.integers(1, 9))))
+    contigs, read, asm = synth.world(k=k, peak=max(peak, 1.0) if peak < 1e5 else 20.0, seed=2000 + seed, sizes=sizes, err_kmers=int(r.integers(0, 3000)) if k > 8 else 0)
+    rk, rv = read
+    rv = rv.astype(np.uint64)
+    if len(rv):
+        big = r.random(len(rv)) < 0.02                            # a few enormous and a few tiny counts
+        rv[big] = r.choice([1, 2, 1023, 1024, 1025, 65535, 200000], size=int(big.sum()))   # bins up to ~2.7 M (beyond the dense device image)
+    rv = rv.astype(np.uint32)
+    read = (rk, rv)
+    probK = probP = None
+    if r.random() < 0.6:
+        n = int(r.choice([1, 8, 184, 1500]))
+        probK = r.integers(0, 12, size=n).astype(np.uint32)
+        probK[r.random(n) < 0.3] = 0                              # present in the reads but treated as missing
+        probP = np.round(r.random(n), 4)
+    lo, hi = 0, 2**64 - 1
+    if r.random() < 0.4:
+        lo, hi = int(r.integers(0, 5)), int(r.choice([30, 1000, 2**31]))
+    p, g, ka, km = oracle_hist(k, peak, contigs, read, asm, probK, probP, lo, hi)
+    ix = build_index(m, k, read, asm, lo, hi)
+    ev = m.Evaluator(ix, m.KParams(peak, probK, probP))
+    seqs = m.Sequences(contigs)
+    assert_hist_equal(ev.hist(seqs), g, ka, km, k)
+    R, A = po.Lookup(k, read[0], read[1], lo, hi), po.Lookup(k, *asm)
+    kp = m.KParams(peak, probK, probP)
+    for c, ctg in enumerate(contigs[:3]):
+        n = len(ctg)
+        if n == 0:
+            continue
+        gv, av, dka, dkm = ev.dump_values(seqs, c, 0, n)
+        rkk, akk, kmm, oka, okm = po.process_dump(p, R, A, ctg)
+        assert (dka, dkm) == (oka, okm)
+        for i in range(0, max(n - k + 1, 0), max(1, n // 300)):
+            a, b, _ = m.getK(kp, int(gv[i]), int(av[i]))
+            assert (a, b) == (rkk[i], akk[i]) and m.getKmetric(a, b) == kmm[i]
+
+
+def test_bin_index_beyond_the_references_array_bound_is_an_error():
+    """merfin-histogram.C:74,87 grow the bin arrays under a uint32 bound in steps of 1024: a bin index above 2^32 - 1025
+    overflows that bound in the reference (undefined behaviour).  Here it is a clean error -- not a 34 GB allocation with
+    a wrapped bound, which is what a read count of 2^32 - 1 at -peak 1 used to produce."""
+    m = _mfx()
+    k = 11
+    contigs = [b"ACGTTGCATGCAAGCTTGCATGCAAGGTACCATGG"]
+    ak, av = po.count_kmers(k, contigs)
+    rv = np.full(len(ak), 3, dtype=np.uint32)
+    one = int(np.argmax(av == 1))                             # a k-mer that occurs once: bin of 4294967295 / 1
+    rv[one] = 2**32 - 1
+    ix = build_index(m, k, (ak, rv), (ak, av))
+    ev = m.Evaluator(ix, m.KParams(1.0))
+    with pytest.raises(m.MfxError, match="32-bit array bound"):
+        ev.hist(m.Sequences(contigs))
+    rv[one] = 400000                                          # a large but representable bin: 2 M bins, fine
+    ix2 = build_index(m, k, (ak, rv), (ak, av))
+    res = m.Evaluator(ix2, m.KParams(1.0)).hist(m.Sequences(contigs))
+    p, g, ka, km = oracle_hist(k, 1.0, contigs, (ak, rv), (ak, av))
+    assert_hist_equal(res, g, ka, km, k)
+    assert len(_trim(res.over())) > 1000000
