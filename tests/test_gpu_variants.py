@@ -73,3 +73,21 @@ def test_polish_fixes_the_assembly(tmp_path):
     (n_o, o_out, _, _), _ = _run_both(tmp_path, "polish", seed=21, decoys=0)
     recs = [l.split("\t") for l in open(o_out).read().splitlines() if not l.startswith("#")]
     assert sum(1 for r in recs if r[9] == "1/1") > 100
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(100, 116)))
+def test_randomized_variant_runs_match_oracle(tmp_path, seed, golden_dir):
+    """seeded sweep: mode, k (odd/even), -comb, -nosplit, -prob, peak, burst density -- VCF, -debug and PANIC/WARNING lines
+    byte-identical to the oracle's restatement every time"""
+    r = np.random.default_rng(seed)
+    mode = MODES[int(r.integers(0, len(MODES)))]
+    k = int(r.choice([9, 12, 15, 21, 22, 27, 31]))
+    (n_o, o_out, o_dbg, o_log), (n_g, g_out, g_dbg, g_log) = _run_both(
+        tmp_path, mode, k=k, seed=seed, comb=int(r.integers(2, 17)), nosplit=bool(r.random() < 0.3), use_prob=bool(r.random() < 0.5),
+        golden_dir=golden_dir, peak=float(r.choice([9.0, 17.3, 26.0])), burst=float(r.choice([0.03, 0.08, 0.15])),
+        sizes=tuple(int(x) for x in r.choice([300, 2500, 6000, 12000], size=int(r.integers(2, 5)))))
+    assert n_o == n_g
+    assert open(g_out).read() == open(o_out).read()
+    assert open(g_dbg).read() == open(o_dbg).read()
+    assert _special(g_log) == _special(o_log)
