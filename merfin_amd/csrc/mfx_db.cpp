@@ -28,6 +28,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <thread>
 #include <string>
@@ -386,7 +387,10 @@ struct Feeder {
     if (v.empty() || rc) return;
     std::unique_lock<std::mutex> lk;
     if (mu) lk = std::unique_lock<std::mutex>(*mu);
+    const bool timing = getenv("MFX_DB_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     rc = mfx_index_add_multi(ixs, nix, k.data(), v.data(), v.size(), side, minV, maxV);
+    if (timing) fprintf(stderr, "[mfx db] batch of %zu k-mers inserted in %.1f ms\n", v.size(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3);
     k.clear(); v.clear();
   }
   void push(uint64_t lo, uint64_t hi, uint32_t val) {
@@ -396,6 +400,20 @@ struct Feeder {
     if (v.size() >= (1u << 24)) flush();
   }
 };
+
+// One line of `meryl print` text at [p, end): "<kmer>\t<count>".  Returns 1 = k-mer parsed, 0 = blank line, -1 = malformed.
+inline int parse_text_line(const char *p, const char *end, u128 &km, int &n, unsigned long long &v) {
+  km = 0;
+  n = 0;
+  while (p < end && base_code((unsigned char)*p) >= 0) { km = (km << 2) | (u128)base_code((unsigned char)*p); ++p; ++n; }
+  if (n == 0 && (p == end || *p == '\n' || *p == '\r')) return 0;
+  if (n == 0 || n > MFX_MAX_K || p == end || (*p != '\t' && *p != ' ')) return -1;
+  while (p < end && (*p == '\t' || *p == ' ')) ++p;
+  if (p == end || *p < '0' || *p > '9') return -1;
+  v = 0;
+  while (p < end && *p >= '0' && *p <= '9') { v = v > (~0ull - 9) / 10 ? ~0ull : v * 10 + (unsigned)(*p - '0'); ++p; }
+  return 1;
+}
 
 template <class F>
 int scan_text(const std::string &path, int *k_out, F &&emit, uint64_t *count) {
@@ -407,15 +425,14 @@ int scan_text(const std::string &path, int *k_out, F &&emit, uint64_t *count) {
   uint64_t ln = 0;
   while (fgets(line, sizeof(line), f)) {
     ++ln;
-    char *p = line;
-    u128 km = 0;
-    int n = 0;
-    while (base_code((unsigned char)*p) >= 0) { km = (km << 2) | (u128)base_code((unsigned char)*p); ++p; ++n; }
-    if (n == 0 && (*p == '\n' || *p == 0)) continue;
-    if (n == 0 || n > MFX_MAX_K || (*p != '\t' && *p != ' ')) { rc = mfx_fail(MFX_E_FORMAT, "'%s' line %lu: expected '<kmer>\\t<count>'", path.c_str(), (unsigned long)ln); break; }
+    u128 km;
+    int n;
+    unsigned long long v = 0;
+    const int what = parse_text_line(line, line + strlen(line), km, n, v);
+    if (what == 0) continue;
+    if (what < 0) { rc = mfx_fail(MFX_E_FORMAT, "'%s' line %lu: expected '<kmer>\\t<count>'", path.c_str(), (unsigned long)ln); break; }
     if (k == 0) k = n;
     if (n != k) { rc = mfx_fail(MFX_E_FORMAT, "'%s' line %lu: k-mer length %d differs from %d", path.c_str(), (unsigned long)ln, n, k); break; }
-    unsigned long long v = strtoull(p, nullptr, 10);
     emit((uint64_t)km, (uint64_t)(km >> 64), v > 0xffffffffull ? 0xffffffffu : (uint32_t)v);
     ++*count;
   }
@@ -424,6 +441,99 @@ int scan_text(const std::string &path, int *k_out, F &&emit, uint64_t *count) {
   if (k_out) *k_out = k;
   return rc;
 }
+
+// An UNCOMPRESSED `meryl print` file parsed by the host threads: the file is cut into 32 MB pieces, a piece belongs to
+// the thread that draws it and covers the lines that START in it (pread of the piece plus the tail of its last
+// line).  make(t) returns thread t's sink: sink(lo, hi, v) per k-mer, sink.done() once (its return value is the
+// thread's status).  A 6 G-line database (150 GB of text) is minutes of single-threaded fgets otherwise.
+template <class Make>
+int scan_text_parallel(const std::string &path, int *k_out, uint64_t *count, Make &&make) {
+  const int fd = open(path.c_str(), O_RDONLY);
+  struct stat st;
+  if (fd < 0 || fstat(fd, &st) != 0) { if (fd >= 0) close(fd); return mfx_fail(MFX_E_IO, "cannot open '%s'", path.c_str()); }
+  uint64_t PIECE = 32ull << 20;
+  if (const char *e = getenv("MFX_TEXT_PIECE")) { const long v = atol(e); if (v >= 64) PIECE = (uint64_t)v; }   // tests: many pieces of a small file
+  const uint64_t size = (uint64_t)st.st_size, TAIL = 4096;
+  const uint64_t npieces = (size + PIECE - 1) / PIECE;
+  const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>({npieces, 64, (uint64_t)mfx_host_threads()}));
+  std::atomic<uint64_t> next(0), total(0);
+  std::atomic<int> kk(0);
+  std::mutex emu;
+  int bad_rc = MFX_OK;
+  uint64_t bad_at = ~0ull;
+  std::string bad_msg;
+  auto fail_at = [&](uint64_t at, int rc, const std::string &msg) {
+    std::lock_guard<std::mutex> g(emu);
+    if (at < bad_at) { bad_at = at; bad_rc = rc; bad_msg = msg; }
+  };
+  auto work = [&](unsigned t) {
+    auto sink = make(t);
+    std::vector<char> buf(PIECE + TAIL + 1);
+    uint64_t mine = 0;
+    for (uint64_t pc; (pc = next.fetch_add(1)) < npieces;) {
+      { std::lock_guard<std::mutex> g(emu); if (bad_rc != MFX_OK) break; }
+      const uint64_t b = pc * PIECE, want = std::min(size - (b ? b - 1 : 0), PIECE + TAIL + (b ? 1 : 0));
+      // one byte before the piece tells whether a line starts exactly at b
+      const uint64_t from = b ? b - 1 : 0;
+      uint64_t got = 0;
+      while (got < want) {
+        ssize_t r = pread(fd, buf.data() + got, want - got, (off_t)(from + got));
+        if (r <= 0) break;
+        got += (uint64_t)r;
+      }
+      if (got < want) { fail_at(b, MFX_E_IO, "reading '" + path + "' failed"); break; }
+      const char *p = buf.data(), *end = buf.data() + got;
+      const char *lim = buf.data() + std::min<uint64_t>(got, (b ? 1 : 0) + PIECE);     // lines starting before lim are this piece's
+      if (b) {                                               // skip the line that started in the previous piece
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        p = nl ? nl + 1 : end;
+      }
+      while (p < lim) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const char *le = nl ? nl : end;
+        if (!nl && from + got < size) { fail_at(from + (uint64_t)(p - buf.data()), MFX_E_FORMAT, "'" + path + "': a line longer than 4096 bytes"); break; }
+        u128 km;
+        int n;
+        unsigned long long v;
+        const int what = parse_text_line(p, le, km, n, v);
+        if (what < 0) {
+          char where[64];
+          snprintf(where, sizeof(where), "%lu", (unsigned long)(from + (uint64_t)(p - buf.data())));
+          fail_at(from + (uint64_t)(p - buf.data()), MFX_E_FORMAT, "'" + path + "' at byte " + where + ": expected '<kmer>\\t<count>'");
+          break;
+        }
+        if (what > 0) {
+          int k0 = kk.load(std::memory_order_relaxed);          // (a CAS per line would bounce the cache line between all threads)
+          if (k0 == 0) kk.compare_exchange_strong(k0, n);
+          if (k0 != 0 && k0 != n) {
+            char msg[160];
+            snprintf(msg, sizeof(msg), "' at byte %lu: k-mer length %d differs from %d", (unsigned long)(from + (uint64_t)(p - buf.data())), n, k0);
+            fail_at(from + (uint64_t)(p - buf.data()), MFX_E_FORMAT, "'" + path + msg);
+            break;
+          }
+          sink((uint64_t)km, (uint64_t)(km >> 64), v > 0xffffffffull ? 0xffffffffu : (uint32_t)v);
+          ++mine;
+        }
+        p = le + 1;
+      }
+    }
+    const int rc = sink.done();
+    if (rc != MFX_OK) fail_at(~0ull - 1, rc, mfx_last_error());
+    total.fetch_add(mine);
+  };
+  if (nt == 1) work(0);
+  else {
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t) th.emplace_back(work, t);
+    for (auto &x : th) x.join();
+  }
+  close(fd);
+  if (k_out) *k_out = kk.load();
+  if (count) *count = total.load();
+  return bad_rc == MFX_OK ? MFX_OK : mfx_fail(bad_rc, "%s", bad_msg.c_str());
+}
+
+inline bool text_is_plain(const std::string &path) { return mfx_suffix_tool(path) == nullptr; }
 
 }  // namespace
 
@@ -448,7 +558,9 @@ extern "C" int mfx_db_probe(const char *path, mfx_db_info *out) {
   if (fmt == MFX_DB_TEXT) {
     uint64_t n = 0;
     int k = 0;
-    int rc = scan_text(p, &k, [](uint64_t, uint64_t, uint32_t) {}, &n);
+    struct Count { void operator()(uint64_t, uint64_t, uint32_t) {} int done() { return MFX_OK; } };
+    int rc = text_is_plain(p) ? scan_text_parallel(p, &k, &n, [](unsigned) { return Count(); })
+                              : scan_text(p, &k, [](uint64_t, uint64_t, uint32_t) {}, &n);
     if (rc) return rc;
     if (k == 0) return mfx_fail(MFX_E_FORMAT, "'%s': no k-mers found", path);
     out->k = k;
@@ -509,7 +621,29 @@ extern "C" int mfx_index_load_db_multi(mfx_index *const *ixs, uint32_t nix, cons
     close(fdn);
   } else if (fmt == MFX_DB_TEXT) {
     int k = 0;
-    rc = scan_text(p, &k, [&](uint64_t lo, uint64_t hi, uint32_t v) { fd.push(lo, hi, v); }, &n);
+    if (text_is_plain(p)) {
+      std::mutex mu;
+      struct Sink {
+        Feeder f;
+        void operator()(uint64_t lo, uint64_t hi, uint32_t v) { f.push(lo, hi, v); }
+        int done() { f.flush(); return f.rc; }
+      };
+      // the k of the file is only known after its first line: a wrong k would insert garbage, so it is checked first
+      {
+        int k1 = 0;
+        if (FILE *f = fopen(path, "rb")) {
+          char line[512];
+          while (k1 == 0 && fgets(line, sizeof(line), f))
+            for (const char *q = line; base_code((unsigned char)*q) >= 0; ++q) ++k1;
+          fclose(f);
+        }
+        if (k1 != ix->k) rc = k1 ? mfx_fail(MFX_E_INVAL, "'%s' holds %d-mers but the index is built for k=%d", path, k1, ix->k)
+                                 : mfx_fail(MFX_E_FORMAT, "'%s': no k-mers found", path);
+      }
+      if (rc == MFX_OK) rc = scan_text_parallel(p, &k, &n, [&](unsigned) { return Sink{Feeder{ixs, nix, side, minV, maxV, &mu}}; });
+    } else {
+      rc = scan_text(p, &k, [&](uint64_t lo, uint64_t hi, uint32_t v) { fd.push(lo, hi, v); }, &n);
+    }
     if (rc == MFX_OK && k != ix->k) rc = mfx_fail(MFX_E_INVAL, "'%s' holds %d-mers but the index is built for k=%d", path, k, ix->k);
   } else {
     MerylIndex mi;

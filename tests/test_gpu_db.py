@@ -226,3 +226,63 @@ def test_meryl_value_statistics_checked_on_load(tmp_path):
         with pytest.raises(m.MfxError) as e:
             ix2.load_db(d, 0)
         assert e.value.code == -7 and word in str(e.value)
+
+
+@pytest.mark.parametrize("k,piece", [(21, 257), (31, 1000), (41, 4096), (21, 1 << 25)])
+def test_plain_text_database_is_parsed_in_pieces_by_the_host_threads(tmp_path, k, piece, monkeypatch):
+    """`meryl print` text, uncompressed: cut into pieces, every piece parsed by the thread that draws it (lines belong to the
+    piece they START in).  Same table as the flat form for every piece size (down to pieces shorter than ten lines), with
+    blank lines, CR LF endings, a last line without newline; malformed lines and a k-mer of another length are reported with
+    their byte offset wherever they sit; .gz text still goes through the serial reader."""
+    import gzip
+    import merfin_amd as m
+    from oracle import plain
+    monkeypatch.setenv("MFX_TEXT_PIECE", str(piece))
+    r = np.random.default_rng(k + piece)
+    n = 6000
+    if k <= 31:
+        kms = np.unique(r.integers(0, 1 << (2 * k), size=n, dtype=np.uint64))
+        vals = r.integers(1, 2000000, size=len(kms)).astype(np.uint32)
+        text = [plain.dec(int(x), k) for x in kms.tolist()]
+    else:
+        ints = sorted({int.from_bytes(r.bytes(16), "little") & ((1 << (2 * k)) - 1) for _ in range(n)})
+        kms = np.array([[x & (2**64 - 1), x >> 64] for x in ints], dtype=np.uint64)
+        vals = r.integers(1, 2000000, size=len(ints)).astype(np.uint32)
+        text = [plain.dec(x, k) for x in ints]
+    # the oracle's decoder spells A C G T by the reference's 2-bit codes; the text form is what `meryl print` writes
+    lines = []
+    for i, (t, v) in enumerate(zip(text, vals.tolist())):
+        lines.append("%s\t%d" % (t, v))
+        if i % 97 == 0:
+            lines.append("")                                   # blank lines are skipped
+    body = "\r\n".join(lines[:50]) + "\r\n" + "\n".join(lines[50:])          # CR LF for a while; no newline after the last line
+    path = str(tmp_path / "db.txt")
+    open(path, "w", newline="").write(body)
+    info = m.db_probe(path)
+    assert (info["format"], info["k"], info["n_kmers"]) == ("text", k, len(vals))
+    flat = str(tmp_path / "db.mfxk")
+    m.db_write_flat(flat, k, kms, vals)
+    a, b = m.Index(k, len(vals) + 16), m.Index(k, len(vals) + 16)
+    a.load_db(path, 0)
+    b.load_db(flat, 0)
+    ea, eb = a.export(), b.export()
+    assert len(ea[0]) == len(vals) and all(np.array_equal(x, y) for x, y in zip(ea, eb))
+    with gzip.open(path + ".gz", "wt", newline="") as f:
+        f.write(body)
+    c = m.Index(k, len(vals) + 16)
+    c.load_db(path + ".gz", 0)
+    assert all(np.array_equal(x, y) for x, y in zip(c.export(), eb))
+    # errors, in the first piece and in a late one
+    for at in (3, len(lines) - 5):
+        for bad, what in (("ACGT" + "x" * 5 + "\t7", "expected '<kmer>"), (text[0][:-1] + "\t9", "differs from")):
+            broken = list(lines)
+            broken[at] = bad
+            bp = str(tmp_path / "broken.txt")
+            open(bp, "w").write("\n".join(broken) + "\n")
+            off = len("\n".join(broken[:at])) + (1 if at else 0)
+            with pytest.raises(m.MfxError, match="at byte %d" % off):
+                m.Index(k, len(vals) + 16).load_db(bp, 0)
+            with pytest.raises(m.MfxError, match=what.replace("(", r"\(")):
+                m.db_probe(bp)
+    with pytest.raises(m.MfxError, match="built for k="):
+        m.Index(k - 2, 100).load_db(path, 0)
