@@ -228,6 +228,7 @@ def test_meryl_value_statistics_checked_on_load(tmp_path):
         assert e.value.code == -7 and word in str(e.value)
 
 
+@pytest.mark.gpu
 @pytest.mark.parametrize("k,piece", [(21, 257), (31, 1000), (41, 4096), (21, 1 << 25)])
 def test_plain_text_database_is_parsed_in_pieces_by_the_host_threads(tmp_path, k, piece, monkeypatch):
     """`meryl print` text, uncompressed: cut into pieces, every piece parsed by the thread that draws it (lines belong to the
