@@ -81,7 +81,7 @@ def test_cfg5_sharded_equals_whole_at_scale(monkeypatch):
     sizes = [s.info()["distinct"] for s in shards]
     assert max(sizes) < 1.1 * min(sizes)                       # the owner hash balances the shards
     evs = [m.Evaluator(s, kp) for s in shards]
-    routers = [m.Router(s, WORLD, min(2048, seqs.ntiles)) for s in shards]
+    routers = [m.Router(s, WORLD, min(16384, seqs.ntiles)) for s in shards]     # tiles per round, as the CLI
     t1 = time.time()
     res = m.hist_sharded(evs, routers, [seqs] * WORLD)
     t_hist = time.time() - t1
