@@ -16,6 +16,9 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <mutex>
+#include <functional>
+#include <condition_variable>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -52,6 +55,56 @@ extern "C" int mfx_device_count(void) {
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
 }
+
+// Host threads that stay parked between the streamed runs of an evaluator: starting 16 threads costs ~0.45 ms, 1.3 % of a
+// 3 Gb run, waking them ~0.05 ms.
+namespace {
+struct WorkerPool {
+  unsigned W;
+  std::vector<std::thread> th;
+  std::mutex m;
+  std::condition_variable wake, idle;
+  std::function<void(unsigned)> job;
+  uint64_t gen = 0;
+  unsigned running = 0;
+  bool quit = false;
+  explicit WorkerPool(unsigned w) : W(w) {
+    for (unsigned i = 0; i < W; ++i)
+      th.emplace_back([this, i]() {
+        uint64_t seen = 0;
+        for (;;) {
+          std::function<void(unsigned)> f;
+          {
+            std::unique_lock<std::mutex> lk(m);
+            wake.wait(lk, [&] { return quit || gen != seen; });
+            if (quit) return;
+            seen = gen;
+            f = job;
+          }
+          f(i);
+          std::lock_guard<std::mutex> lk(m);
+          if (--running == 0) idle.notify_all();
+        }
+      });
+  }
+  void start(std::function<void(unsigned)> f) {
+    std::lock_guard<std::mutex> lk(m);
+    job = std::move(f);
+    running = W;
+    ++gen;
+    wake.notify_all();
+  }
+  void wait() {
+    std::unique_lock<std::mutex> lk(m);
+    idle.wait(lk, [&] { return running == 0; });
+  }
+  ~WorkerPool() {
+    { std::lock_guard<std::mutex> lk(m); quit = true; }
+    wake.notify_all();
+    for (auto &t : th) t.join();
+  }
+};
+}  // namespace
 
 namespace {
 struct DevGuard {
@@ -776,6 +829,7 @@ extern "C" void mfx_eval_free(mfx_eval *ev) {
   if (ev->d_ovf) (void)hipFree(ev->d_ovf);
   for (auto &p : ev->h_stage) if (p) (void)hipHostFree(p);
   for (auto &p : ev->h_pack) if (p) (void)hipHostFree(p);
+  if (ev->pool) delete static_cast<WorkerPool *>(ev->pool);
   if (ev->sr.d_counts) (void)hipFree(ev->sr.d_counts);
   if (ev->sr.d_kover) (void)hipFree(ev->sr.d_kover);
   if (ev->sr.h_img) (void)hipHostFree(ev->sr.h_img);
@@ -1141,7 +1195,6 @@ static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *cons
   size_t STAGE_W = 0;                                         // words of the largest chunk, rounded up to 1 MB of them
   for (const Chunk &c : chunks) STAGE_W = std::max<size_t>(STAGE_W, (c.hi - c.lo) / 32);
   STAGE_W = (STAGE_W + 2 + 131071) / 131072 * 131072;
-  std::vector<std::thread> workers;
   std::atomic<int64_t> allowed{NB - 1};                     // chunks <= allowed may be packed (their staging buffer is free)
   std::atomic<bool> stop{false};
   std::vector<std::atomic<uint32_t>> done(chunks.size());
@@ -1150,8 +1203,7 @@ static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *cons
   auto &R = ev->sr;
   auto cleanup = [&]() {
     stop.store(true);
-    for (auto &w : workers) w.join();
-    workers.clear();
+    if (ev->pool) static_cast<WorkerPool *>(ev->pool)->wait();
     if (R.copy) (void)hipStreamSynchronize(R.copy);
     for (auto &k : R.kern) if (k) (void)hipStreamSynchronize(k);
   };
@@ -1177,6 +1229,8 @@ static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *cons
 
   // the packers: worker w encodes its share of the words of every chunk, in chunk order
   const unsigned W = std::max(1u, std::min(mfx_host_threads(), 64u));
+  if (ev->pool && static_cast<WorkerPool *>(ev->pool)->W != W) { delete static_cast<WorkerPool *>(ev->pool); ev->pool = nullptr; }
+  if (!ev->pool) ev->pool = new WorkerPool(W);
   uint8_t *const *stage = ev->h_pack;
   auto work = [&, W](unsigned w) {
     for (size_t ci = 0; ci < chunks.size(); ++ci) {
@@ -1202,7 +1256,7 @@ static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *cons
     }
   };
   t_mark[0] = now();
-  for (unsigned w = 0; w < W; ++w) workers.emplace_back(work, w);
+  static_cast<WorkerPool *>(ev->pool)->start(work);
   t_mark[1] = now();
   // streams, events, the counts image and its pinned mirror: created once per evaluator (while the packers start)
   if (R.words < words) {

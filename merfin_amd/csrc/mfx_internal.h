@@ -145,6 +145,7 @@ struct mfx_eval {
   uint64_t *d_ovf = nullptr;         // [0] count, [1..] records
   uint8_t  *h_stage[2] = {nullptr, nullptr};   // pinned staging of the streamed upload (pageable sources), kept between calls
   size_t    h_stage_bytes = 0;
+  void     *pool = nullptr;                             // host threads parked between streamed runs (mfx_api.cpp: WorkerPool)
   uint8_t  *h_pack[3] = {nullptr, nullptr, nullptr};   // pinned staging of the PACKED streamed upload (codes then validity words)
   size_t    h_pack_words = 0;
   // what a streamed run needs besides, kept between calls (creating and releasing it costs ~2.5 ms, 7 % of a 3 Gb run)
