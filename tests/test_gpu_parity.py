@@ -500,7 +500,7 @@ def test_both_insert_strategies_build_the_same_table(insert_mode, count_mode, mo
     assert_hist_equal(m.Evaluator(ix, m.KParams(peak)).hist(seqs), g, ka, km, k)
 
 
-@pytest.mark.parametrize("seed", list(range(24)))
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("MFX_RANDOM_SEEDS", "24")))))      # MFX_RANDOM_SEEDS=500 for a soak
 def test_randomized_worlds_match_oracle(seed, monkeypatch):
     """A seeded sweep over what the fixed cases hold constant: k (3...31, odd and even), peak (also < 1 and huge), random
     -prob tables (readK 0 for some counts, rows beyond and below the LDS look-up tables), read counts up to 200000, -min/-max,
