@@ -204,3 +204,49 @@ def test_rccl_communicator_world_of_one():
     assert_hist_equal(res, g, ka, km, k)
     assert len(ev.take_overflow()) == 0                       # the gather consumed the list
     comm.close()
+
+
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("MFX_RANDOM_SEEDS", "12")))))
+def test_randomized_host_paths_agree(seed, monkeypatch):
+    """Every way of getting the same -hist -- one resident launch, streamed packed, streamed one byte per base, N slots of one
+    process over replicas, N shards of one process with the k-mers routed to their owners -- on seeded random worlds (k, peak,
+    contig shapes with empty / tiny / N-riddled contigs, big read counts beyond the dense image, table fill, chunking):
+    the oracle's result from each, and bit-identical koverCpy between the paths that sum the same per-tile values."""
+    import merfin_amd as m
+    from tests.test_gpu_sharded import _build_shards
+    r = np.random.default_rng(7000 + seed)
+    k = int(r.choice([9, 15, 21, 27, 31]))
+    peak = float(r.choice([2.5, 9.0, 17.3, 26.0]))
+    monkeypatch.setenv("MFX_LOAD_FACTOR", str(r.choice([0.4, 0.6, 0.8])))
+    sizes = tuple(int(x) for x in r.choice([0, 5, k, 37, 4095, 4096, 4097, 20000, 70000, 300000], size=int(r.integers(1, 10))))
+    contigs, read, asm = synth.world(k=k, peak=peak, seed=8000 + seed, sizes=sizes, err_kmers=int(r.integers(0, 4000)) if k > 9 else 0)
+    rv = read[1].astype(np.uint64)
+    if len(rv):
+        big = r.random(len(rv)) < 0.01
+        rv[big] = r.choice([1, 1024, 65535, 300000], size=int(big.sum()))
+    read = (read[0], rv.astype(np.uint32))
+    p, g, ka, km = oracle_hist(k, peak, contigs, read, asm)
+    ix = build_index(m, k, read, asm)
+    kp = m.KParams(peak)
+    ev = m.Evaluator(ix, kp)
+    seqs = m.Sequences(contigs)
+    resident = ev.hist(seqs)
+    assert_hist_equal(resident, g, ka, km, k)
+    lens = [len(c) for c in contigs]
+    _same(ev.hist_streamed(m.Sequences.create(lens), contigs), resident)
+    monkeypatch.setenv("MFX_STREAM_ASCII", "1")
+    _same(ev.hist_streamed(m.Sequences.create(lens), contigs), resident)
+    monkeypatch.delenv("MFX_STREAM_ASCII")
+    n = int(r.integers(2, 6))
+    multi = m.hist_multi([m.Evaluator(ix, kp) for _ in range(n)], [seqs] * n)
+    assert_hist_equal(multi, g, ka, km, k)
+    if k % 2 == 1 and len(asm[0]):
+        w = int(r.integers(2, 9))
+        shards = _build_shards(m, k, read, asm, w)
+        evs = [m.Evaluator(s, kp) for s in shards]
+        per = max(1, min(int(r.choice([1, 3, 1000])), seqs.ntiles))        # tiles routed per round
+        routers = [m.Router(s, w, per) for s in shards]
+        assert_hist_equal(m.hist_sharded(evs, routers, [seqs] * w), g, ka, km, k)
+        for c in [i for i, L in enumerate(lens) if L > 0][:2]:
+            a, b = m.dump_values_sharded(evs, [seqs] * w, c, 0, lens[c]), ev.dump_values(seqs, c, 0, lens[c])
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2:] == b[2:]
