@@ -226,3 +226,19 @@ def test_wide_index_image_and_replica(tmp_path):
     ix31 = build(m, 31, *small_world(31, 92, n=6000)[1:])
     ix31.save(str(tmp_path / "n.mfxi"))
     assert m.Index.load(str(tmp_path / "n.mfxi")).info()["k"] == 31
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("MFX_RANDOM_SEEDS", "6")))))
+def test_randomized_wide_k_against_plain_oracle(seed, monkeypatch):
+    """seeded sweep over 32 <= k <= 64 (and table fill, peak): -hist resident and streamed against the plain-Python oracle"""
+    import merfin_amd as m
+    r = np.random.default_rng(9000 + seed)
+    k = int(r.integers(32, 65))
+    peak = float(r.choice([2.5, 9.0, 26.0]))
+    monkeypatch.setenv("MFX_LOAD_FACTOR", str(r.choice([0.3, 0.6, 0.9])))
+    contigs, R, A = small_world(k, 9100 + seed, n=int(r.choice([5200, 7000, 9000])))
+    ix = build(m, k, R, A)
+    ev = m.Evaluator(ix, m.KParams(peak))
+    seqs = m.Sequences([c.encode() for c in contigs])
+    assert_hist(ev.hist(seqs), contigs, k, peak, [], [], R, A)
+    assert_hist(ev.hist_streamed(m.Sequences.create([len(c) for c in contigs]), [c.encode() for c in contigs]), contigs, k, peak, [], [], R, A)
