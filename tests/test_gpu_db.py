@@ -287,3 +287,56 @@ def test_plain_text_database_is_parsed_in_pieces_by_the_host_threads(tmp_path, k
                 m.db_probe(bp)
     with pytest.raises(m.MfxError, match="built for k="):
         m.Index(k - 2, 100).load_db(path, 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("MFX_RANDOM_SEEDS", "8")))))
+def test_randomized_database_forms_agree(tmp_path, seed, monkeypatch):
+    """seeded sweep: k (narrow and 128-bit), number of k-mers (also 0 in most of the 64 pieces), values up to 2^32-1, the
+    meryl layout's prefix width, the text reader's piece size, one table or the shards of one process -- flat, text and
+    meryl-layout forms of one database always give the same table"""
+    import merfin_amd as m
+    from oracle import plain
+    r = np.random.default_rng(600 + seed)
+    k = int(r.choice([7, 11, 16, 21, 27, 31, 33, 48, 64]))
+    n = int(r.choice([1, 40, 3000, 20000]))
+    space = 1 << (2 * k)
+    ints = sorted({int.from_bytes(r.bytes(16), "little") % space for _ in range(n)})
+    vals = r.choice([1, 2, 3, 17, 255, 256, 65535, 65536, 2**32 - 1], size=len(ints)).astype(np.uint32)
+    wide = k > 31
+    keys = (np.array([[x & (2**64 - 1), x >> 64] for x in ints], dtype=np.uint64) if wide else np.array(ints, dtype=np.uint64))
+    flat, text, mdir = str(tmp_path / "d.mfxk"), str(tmp_path / "d.txt"), str(tmp_path / "d.meryl")
+    m.db_write_flat(flat, k, keys, vals)
+    with open(text, "w") as f:
+        for x, v in zip(ints, vals.tolist()):
+            f.write("%s\t%d\n" % (plain.dec(x, k), v))
+    prefix_bits = int(r.integers(6, min(2 * k - 4, 16) + 1))
+    meryl_layout.write_db(mdir, k, keys, vals, prefix_bits=prefix_bits)
+    monkeypatch.setenv("MFX_TEXT_PIECE", str(int(r.choice([64, 999, 1 << 25]))))
+    lo, hi = int(r.choice([0, 2, 300])), int(r.choice([250, 70000, 2**32 - 1]))
+    world = 1 if wide else int(r.choice([1, 1, 3]))
+    tables = []
+    for path in (flat, text, mdir):
+        assert m.db_probe(path)["n_kmers"] == len(ints) and m.db_probe(path)["k"] == k
+        shards = []
+        for rank in range(world):
+            ix = m.Index(k, len(ints) + 16)
+            if world > 1:
+                ix.set_shard(rank, world)
+            shards.append(ix)
+        if world > 1:
+            m.load_db_multi(shards, path, 0, lo, hi)
+        else:
+            shards[0].load_db(path, 0, lo, hi)
+        parts = [s.export() for s in shards]
+        assert sum(len(p[0]) for p in parts) == len(ints)
+        ks = sum(((meryl_layout.to_ints(p[0]) if wide else p[0].tolist()) for p in parts), [])
+        vs = sum((p[1].tolist() for p in parts), [])
+        merged = sorted(zip(ks, vs))
+        tables.append(merged)
+    assert tables[0] == tables[1] == tables[2] == sorted(zip(ints, vals.tolist()))
+    if world == 1:
+        ix = m.Index(k, len(ints) + 16)
+        ix.load_db(flat, 0, lo, hi)
+        got, _ = ix.value(keys)
+        assert got.tolist() == [v if lo <= v <= hi else 0 for v in vals.tolist()]
