@@ -300,3 +300,41 @@ def test_cli_sequence_read_overlaps_the_index_build(tmp_path):
         assert r.returncode == 0, r.stderr
         assert open(out, "rb").read() == want, (fa, env)
         assert ("more than its size promised" in r.stderr) == note, r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("MFX_RANDOM_SEEDS", "8")))))
+def test_randomized_fasta_layouts(tmp_path, seed):
+    """seeded sweep over how the same contigs can be laid out in a FASTA file -- line width (1 ... one line per record),
+    CR LF, blank lines, empty records, descriptions, no newline at the end, records straddling the reader's 4 MB buffer,
+    .gz -- the CLI's -hist must be the oracle's for the contigs, and the per-contig stderr lines must name them in order"""
+    import merfin_amd as m
+    r = np.random.default_rng(4000 + seed)
+    k, peak = 21, 17.3
+    sizes = tuple(int(x) for x in r.choice([0, 1, 20, 21, 400, 4096, 30000], size=int(r.integers(1, 7))))
+    if seed % 4 == 0:
+        sizes += (int(r.integers(4_200_000, 4_400_000)),)          # longer than the read buffer
+    contigs, read, asm = synth.world(k=k, peak=peak, seed=4100 + seed, sizes=sizes)
+    p = po.Params(k, peak)
+    g, ka, km, _ = po.hist_run(p, po.Lookup(k, *read), po.Lookup(k, *asm), contigs, threads=2)
+    po.report_histogram(p, g, str(tmp_path / "o.hist"), None)
+    eol = b"\r\n" if r.random() < 0.3 else b"\n"
+    body = b""
+    for i, c in enumerate(contigs):
+        body += b">ctg%d%s" % (i, (b" len=%d extra" % len(c)) if r.random() < 0.5 else b"") + eol
+        width = int(r.choice([1, 7, 60, 61, 4096, 10**9])) if len(c) < 100000 else int(r.choice([60, 80, 10**9]))
+        for o in range(0, len(c), width):
+            body += c[o:o + width] + eol
+        if r.random() < 0.3:
+            body += eol                                               # a blank line between records
+    if r.random() < 0.4 and body.endswith(eol):
+        body = body[:-len(eol)]                                       # no newline at the end of the file
+    gz = r.random() < 0.3
+    fa = str(tmp_path / ("a.fasta.gz" if gz else "a.fasta"))
+    (gzip.open if gz else open)(fa, "wb").write(body)
+    m.db_write_flat(str(tmp_path / "read.mfxk"), k, *read)
+    rr = run(["-hist", "-sequence", fa, "-readmers", str(tmp_path / "read.mfxk"), "-peak", str(peak), "-output", str(tmp_path / "g.hist")])
+    assert rr.returncode == 0, rr.stderr
+    assert (tmp_path / "g.hist").read_bytes() == (tmp_path / "o.hist").read_bytes()
+    named = [l.split("\t")[0] for l in rr.stderr.splitlines() if l.count("\t") == 4 and l.startswith("ctg")]
+    assert named == ["ctg%d" % i for i in range(len(contigs))]
