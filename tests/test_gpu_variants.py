@@ -91,3 +91,60 @@ def test_randomized_variant_runs_match_oracle(tmp_path, seed, golden_dir):
     assert open(g_out).read() == open(o_out).read()
     assert open(g_dbg).read() == open(o_dbg).read()
     assert _special(g_log) == _special(o_log)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(200, 200 + int(os.environ.get("MFX_RANDOM_SEEDS", "10")))))
+def test_randomized_vcf_records_parse_like_the_oracle(tmp_path, seed):
+    """seeded sweep over what a VCF line may look like (vcf.C:93-149, vcfRecord.H:53-97): fewer than 10 columns, several
+    samples, GT with phasing / missing alleles / indices past the ALT list, ALT '.', '*', symbolic, lower case, QUAL '.',
+    header lines in the middle, unknown CHROM, unsorted positions, duplicate lines -- same records kept, same clusters,
+    same output as the oracle"""
+    import merfin_amd as m
+    r = np.random.default_rng(seed)
+    k, peak = 21, 17.3
+    names, asm, vcf, read, amers = synth.variant_world(k=k, peak=peak, seed=seed, sizes=(9000, 3000, 500))
+    lines = vcf.splitlines()
+    head = [l for l in lines if l.startswith("#")]
+    body = [l for l in lines if not l.startswith("#")]
+    out = []
+    for l in body:
+        w = l.split("\t")
+        roll = r.random() if len(w) >= 10 else 0.5
+        if roll < 0.04:
+            w = w[:int(r.integers(5, 10))]                            # fewer than 10 columns: excluded
+        elif roll < 0.08:
+            w.append(r.choice(["0/1", "1/1", "./."]))                  # a second sample (only the first is read)
+        elif roll < 0.14:
+            w[9] = str(r.choice(["1|0", "0|1", "1", ".", "1/.", "./1", "2/2", "0/0:35", "1/1:12:0.5", "0|0", "1/2"]))
+        elif roll < 0.18:
+            w[4] = str(r.choice([".", "*", "<DEL>", w[4].lower(), w[4] + ",*", w[3]]))
+        elif roll < 0.20:
+            w[5] = "."
+        elif roll < 0.22:
+            w[0] = "chrUnknown"
+        elif roll < 0.24:
+            w[3] = w[3].lower()
+        out.append("\t".join(w))
+        if roll > 0.97:
+            out.append("\t".join(w))                                   # the same line twice
+        if 0.95 < roll < 0.96:
+            out.append("##a header line in the middle")
+    if r.random() < 0.5:                                               # a block moved out of order
+        i = int(r.integers(0, max(1, len(out) - 20)))
+        out = out[:i] + out[i + 10:i + 20] + out[i:i + 10] + out[i + 20:]
+    vp = str(tmp_path / "in.vcf")
+    open(vp, "w").write("\n".join(head + out) + "\n")
+    mode = MODES[int(r.integers(0, len(MODES)))]
+    p = po.Params(k, peak)
+    R, A = po.Lookup(k, *read), po.Lookup(k, *amers)
+    n_o = po.variants_run(p, R, A, mode, vp, names, asm, str(tmp_path / "o.vcf"), comb=10, debug_path=str(tmp_path / "o.dbg"), log_path=str(tmp_path / "o.log"))
+    ix = m.Index(k, len(read[0]) + len(amers[0]) + 16)
+    ix.add_read(*read)
+    ix.add_asm(*amers)
+    n_g = m.Evaluator(ix, m.KParams(peak)).variants(mode, vp, names, asm, str(tmp_path / "g.vcf"), comb=10, debug_path=str(tmp_path / "g.dbg"),
+                                                    log_path=str(tmp_path / "g.log"))
+    assert n_g == n_o
+    assert open(tmp_path / "g.vcf").read() == open(tmp_path / "o.vcf").read()
+    assert open(tmp_path / "g.dbg").read() == open(tmp_path / "o.dbg").read()
+    assert _special(str(tmp_path / "g.log")) == _special(str(tmp_path / "o.log"))
