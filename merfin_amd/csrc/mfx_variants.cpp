@@ -174,6 +174,10 @@ int load_vcf(const char *path, VcfDB &db) {
       if (recs[i]) vars[i] = make_variant(recs[i]);
     }
   });
+  db.records.reserve(lines.size());
+  db.variants.reserve(lines.size());
+  std::vector<Cluster *> *bucket = nullptr;                // records of one CHROM come in runs: one map lookup per run
+  const std::string *bucket_chr = nullptr;
   for (size_t i = 0; i < lines.size(); ++i) {
     Record *r = recs[i];
     if (!r) { db.excluded++; continue; }
@@ -184,7 +188,13 @@ int load_vcf(const char *path, VcfDB &db) {
     c->rStart = v->pos;
     c->rEnd = v->pos + v->refLen;
     c->vars.push_back(v);
-    db.by_chr[r->chr].push_back(c);
+    if (!bucket || *bucket_chr != r->chr) {
+      auto it = db.by_chr.find(r->chr);
+      if (it == db.by_chr.end()) it = db.by_chr.emplace(r->chr, std::vector<Cluster *>()).first;
+      bucket = &it->second;
+      bucket_chr = &it->first;
+    }
+    bucket->push_back(c);
   }
   return MFX_OK;
 }
@@ -486,6 +496,11 @@ static int variants_impl(const mfx_eval *ev, const PathValues &values, const cha
   }
 
   mfx_kparams kp{ev->peak, ev->n_prob, ev->probK.data(), ev->probP.data()};
+  // readK and prob depend on the read count alone (merfin-globals.C:80-97): evaluated once for the counts that occur all
+  // the time, by the same routine the scoring loop would call (identical doubles)
+  constexpr uint32_t KLUT = 4096;
+  std::vector<double> lutK(KLUT), lutP(KLUT);
+  for (uint32_t v = 0; v < KLUT; ++v) { double a; mfx_getK(&kp, v, 0, &lutK[v], &a, &lutP[v]); }
   uint64_t clusters = 0, varMerId = 0;
   const uint64_t BATCH_BYTES = 256ull << 20;                             // packed path text per GPU launch
 
@@ -549,7 +564,9 @@ static int variants_impl(const mfx_eval *ev, const PathValues &values, const cha
           double readK = 0, asmK = 0;
           if (run >= K) {                                                // k-mer ENDING at idx starts at idx-k+1
             const uint64_t sp = o + idx - (K - 1);
-            mfx_getK(&kp, rv[sp], av[sp], &readK, &asmK, &prob);
+            const uint32_t v = rv[sp];
+            if (v < KLUT) { readK = lutK[v]; prob = lutP[v]; asmK = (double)av[sp]; }
+            else mfx_getK(&kp, v, av[sp], &readK, &asmK, &prob);
           }
           if (readK == 0) numM++;
           if (mode == MFX_VAR_FILTER) continue;                          // :93-96
