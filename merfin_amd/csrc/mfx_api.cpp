@@ -48,7 +48,7 @@ int mfx_fail(int code, const char *fmt, ...) {
 
 extern "C" const char *mfx_last_error(void) { return g_err; }
 extern "C" int mfx_last_error_code(void) { return g_err_code; }
-extern "C" const char *mfx_version(void) { return "merfin_amd 0.1 (gfx950)"; }
+extern "C" const char *mfx_version(void) { return "merfin_amd 0.2 (gfx950)"; }
 
 extern "C" int mfx_device_count(void) {
   int n = 0;
