@@ -555,8 +555,14 @@ int main(int argc, char **argv) {
   };
   // ... and without -seqmers whenever the file tells an upper bound of its bases: the table is sized by the bound, the
   // read database is loaded while the file is read, the assembly k-mers are counted once it is in
-  const uint64_t basesBound = (G.seqName && !G.seqDBname) ? bases_upper_bound(G.seqName) : 0;
-  const bool deferSeq = G.seqName && !G.sharded && (G.seqDBname || basesBound > 0) && !(getenv("MFX_CLI_NO_OVERLAP") && atoi(getenv("MFX_CLI_NO_OVERLAP")));
+  // Only compressed files are worth it: their decompression takes seconds per Gb on one core, while a plain file is parsed
+  // at 2-5 GB/s and reading it under the build measurably slows the build's own readers (1 Gb: 1.8-3.0 s read first,
+  // 2.4-3.2 s overlapped; MFX_CLI_OVERLAP=1 / 0 forces either).
+  const char *ov = getenv("MFX_CLI_OVERLAP");
+  const bool compressed = G.seqName && mfx_suffix_tool(G.seqName) != nullptr;
+  const bool wantOverlap = ov ? atoi(ov) != 0 : compressed;
+  const uint64_t basesBound = (G.seqName && !G.seqDBname && wantOverlap) ? bases_upper_bound(G.seqName) : 0;
+  const bool deferSeq = G.seqName && !G.sharded && wantOverlap && (G.seqDBname || basesBound > 0);
   if (!deferSeq) finish_seq();
   if (G.sharded) {
     if (G.devices.size() < 2) {

@@ -277,7 +277,7 @@ def test_cli_hist_on_several_devices_of_one_process(tmp_path, golden_dir, device
 def test_cli_sequence_read_overlaps_the_index_build(tmp_path):
     """Without -seqmers the k-mer table is sized from a bound the sequence FILE gives before it is read (plain: its size;
     .gz: the ISIZE trailer), so that the read database loads while the file is read.  Same histogram with the overlap,
-    without it (MFX_CLI_NO_OVERLAP=1), from .gz, and from a .gz of two members whose trailer under-reports the size (the
+    without it, from .gz (where it is the default; MFX_CLI_OVERLAP forces either), and from a .gz of two members whose trailer under-reports the size (the
     table is then rebuilt with the true number)."""
     import merfin_amd as m
     k, peak = 21, 17.3
@@ -294,7 +294,7 @@ def test_cli_sequence_read_overlaps_the_index_build(tmp_path):
         f.write(gzip.compress(b">ctg0\n" + contigs[0] + b"\n"))
         f.write(gzip.compress(b">ctg1\n" + contigs[1] + b"\n>ctg2\n" + contigs[2] + b"\n"))
     base = ["-hist", "-readmers", str(tmp_path / "read.mfxk"), "-peak", str(peak)]
-    for i, (fa, env, note) in enumerate([(plain, {}, False), (plain, {"MFX_CLI_NO_OVERLAP": "1"}, False), (gz1, {}, False), (gz2, {}, True)]):
+    for i, (fa, env, note) in enumerate([(plain, {"MFX_CLI_OVERLAP": "1"}, False), (plain, {}, False), (gz1, {}, False), (gz1, {"MFX_CLI_OVERLAP": "0"}, False), (gz2, {}, True)]):
         out = str(tmp_path / ("g%d.hist" % i))
         r = subprocess.run([EXE] + base + ["-sequence", fa, "-output", out], capture_output=True, text=True, env=dict(os.environ, MFX_CLI_TIMING="1", **env))
         assert r.returncode == 0, r.stderr

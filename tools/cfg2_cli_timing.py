@@ -50,3 +50,10 @@ r = subprocess.run([exe, "-hist", "-sequence", out + "/asm.fasta", "-readmers", 
 print("-hist (asm counted on GPU): rc=%d wall=%.2fs same_hist=%s" % (r.returncode, time.time() - t,
       open(out + "/out.hist").read() == open(out + "/out2.hist").read()))
 print("    " + "\n    ".join(l for l in r.stderr.splitlines() if "timing" in l))
+for rep in range(2):
+    for env, what in (({"MFX_CLI_OVERLAP": "0"}, "sequence read first"), ({"MFX_CLI_OVERLAP": "1"}, "sequence read under the index build")):
+        t = time.time()
+        r = subprocess.run([exe, "-hist", "-sequence", out + "/asm.fasta", "-readmers", out + "/read.mfxk", "-peak", "26", "-prob", prob,
+                            "-output", out + "/out3.hist"], capture_output=True, text=True, env=dict(os.environ, MFX_CLI_TIMING="1", **env))
+        print("-hist without -seqmers, %s: wall=%.2fs" % (what, time.time() - t))
+        print("    " + "\n    ".join(l for l in r.stderr.splitlines() if "timing" in l))
