@@ -1789,6 +1789,7 @@ extern "C" int mfx_hist_run_sharded(mfx_eval *const *evs, mfx_router *const *rou
   const uint32_t nbins = evs[0]->nbins, ncontigs = seqs[0]->ncontigs, per = routers[0]->max_tiles;
   const uint64_t T = seqs[0]->ntiles;
   const size_t words = MFX_HIST_WORDS(nbins, ncontigs), cap = (size_t)per * MFX_TILE;
+  const size_t rcap = cap + cap / 2 + 4096;                  // receive side: a balanced owner gets ~cap k-mers per round
   struct Slot {
     uint64_t *d_counts = nullptr, *d_keys = nullptr, *d_rkeys = nullptr;
     uint32_t *d_ctg = nullptr, *d_rctg = nullptr;
@@ -1814,8 +1815,8 @@ extern "C" int mfx_hist_run_sharded(mfx_eval *const *evs, mfx_router *const *rou
     sl[d].dest.assign(ndev, 0);
     if (hipStreamCreateWithFlags(&sl[d].st, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void **)&sl[d].d_counts, words * sizeof(uint64_t)) != hipSuccess || hipMalloc((void **)&sl[d].d_kover, sizeof(double)) != hipSuccess ||
-        hipMalloc((void **)&sl[d].d_keys, cap * 8) != hipSuccess || hipMalloc((void **)&sl[d].d_rkeys, cap * 8) != hipSuccess ||
-        hipMalloc((void **)&sl[d].d_ctg, cap * 4) != hipSuccess || hipMalloc((void **)&sl[d].d_rctg, cap * 4) != hipSuccess ||
+        hipMalloc((void **)&sl[d].d_keys, cap * 8) != hipSuccess || hipMalloc((void **)&sl[d].d_rkeys, rcap * 8) != hipSuccess ||
+        hipMalloc((void **)&sl[d].d_ctg, cap * 4) != hipSuccess || hipMalloc((void **)&sl[d].d_rctg, rcap * 4) != hipSuccess ||
         hipMemsetAsync(sl[d].d_counts, 0, words * sizeof(uint64_t), sl[d].st) != hipSuccess ||
         hipMemsetAsync(sl[d].d_kover, 0, sizeof(double), sl[d].st) != hipSuccess ||
         hipMemsetAsync(evs[d]->d_ovf, 0, sizeof(uint64_t), sl[d].st) != hipSuccess)
@@ -1845,16 +1846,26 @@ extern "C" int mfx_hist_run_sharded(mfx_eval *const *evs, mfx_router *const *rou
     // ---- exchange + evaluate: owner o takes its group from every source in slot order
     for (uint32_t o = 0; o < ndev && rc == MFX_OK; ++o) {
       DevGuard g(evs[o]->device);
+      // the groups of all sources land one behind the other (slot order) and are evaluated by ONE launch: a launch per
+      // source was 8x the launches, each with its own ramp-up and tail.  (Should the owners be so unbalanced that one
+      // owner's share of a round outgrows its buffer, it takes its groups source by source.)
+      uint64_t total = 0;
+      for (uint32_t s2 = 0; s2 < ndev; ++s2) total += sl[s2].dest[o];
+      const bool merged = total <= rcap;
+      uint64_t at = 0;
       for (uint32_t s2 = 0; s2 < ndev && rc == MFX_OK; ++s2) {
         const uint64_t n = sl[s2].dest[o];
         if (!n) continue;
         uint64_t off = 0;
         for (uint32_t q = 0; q < o; ++q) off += sl[s2].dest[q];
-        hipError_t e = hipMemcpyPeerAsync(sl[o].d_rkeys, evs[o]->device, sl[s2].d_keys + off, evs[s2]->device, n * 8, sl[o].st);
-        if (e == hipSuccess) e = hipMemcpyPeerAsync(sl[o].d_rctg, evs[o]->device, sl[s2].d_ctg + off, evs[s2]->device, n * 4, sl[o].st);
+        hipError_t e = hipMemcpyPeerAsync(sl[o].d_rkeys + at, evs[o]->device, sl[s2].d_keys + off, evs[s2]->device, n * 8, sl[o].st);
+        if (e == hipSuccess) e = hipMemcpyPeerAsync(sl[o].d_rctg + at, evs[o]->device, sl[s2].d_ctg + off, evs[s2]->device, n * 4, sl[o].st);
         if (e != hipSuccess) { rc = mfx_fail(MFX_E_HIP, "peer copy of %lu routed k-mers from slot %u to slot %u failed: %s", (unsigned long)n, s2, o, hipGetErrorString(e)); break; }
-        rc = mfx_hist_keys_launch(evs[o], sl[o].d_rkeys, sl[o].d_rctg, n, ncontigs, sl[o].d_counts, sl[o].d_kover, sl[o].st);
+        if (merged) at += n;
+        else rc = mfx_hist_keys_launch(evs[o], sl[o].d_rkeys, sl[o].d_rctg, n, ncontigs, sl[o].d_counts, sl[o].d_kover, sl[o].st);
       }
+      if (merged && at && rc == MFX_OK)
+        rc = mfx_hist_keys_launch(evs[o], sl[o].d_rkeys, sl[o].d_rctg, at, ncontigs, sl[o].d_counts, sl[o].d_kover, sl[o].st);
     }
     // the sources' buffers are rewritten by the next round's routing: every owner must have taken its groups
     for (uint32_t d = 0; d < ndev; ++d) {
