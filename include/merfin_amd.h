@@ -350,6 +350,12 @@ int mfx_dump_values(mfx_eval *ev, const mfx_seq *seq, uint32_t contig, uint64_t 
  * format "%s\t%lu\t%.2f\t%.2f\t%.2f\n" (merfin-dump.C:88-93). */
 int mfx_dump_contig(mfx_eval *ev, const mfx_seq *seq, uint32_t contig, const char *name,
                     const char *path, int append, uint64_t *kasm, uint64_t *kmissing);
+/* Several host threads running library calls side by side (the slots of `merfin -devices`): a thread that declares
+ * itself one of `nsharers` gets 1/nsharers of the host threads in the calls it makes from then on (text formatting,
+ * VCF parsing, path enumeration, staging copies) instead of all of them -- N callers each spawning a full set only
+ * fight for the cores.  Thread-local; 1 = the default. */
+void mfx_host_threads_share(unsigned nsharers);
+
 /* -dump over an index SHARDED across nslots evaluators (slot d = shard d of nslots, mfx_index_set_shard; seqs[d] =
  * the same sequences resident on slot d's device; slots may share a device).  Every k-mer has one owner and the
  * other shards answer 0, so each slot looks its copy of the range up in its own shard and the value arrays are added

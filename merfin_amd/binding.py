@@ -73,7 +73,7 @@ SYMBOLS = [
     "mfx_eval_create", "mfx_eval_free", "mfx_eval_nbins", "mfx_getK", "mfx_getKmetric", "mfx_histoQV",
     "mfx_hist_run", "mfx_hist_result_free", "mfx_hist_launch", "mfx_hist_launch_cyclic", "mfx_hist_result_from_counts",
     "mfx_hist_take_overflow", "mfx_hist_report",
-    "mfx_pack_bases", "mfx_dump_values", "mfx_dump_contig", "mfx_dump_values_sharded", "mfx_dump_contig_sharded", "mfx_variants_run_sharded", "mfx_completeness", "mfx_completeness_pieces", "mfx_variants_run",
+    "mfx_pack_bases", "mfx_host_threads_share", "mfx_dump_values", "mfx_dump_contig", "mfx_dump_values_sharded", "mfx_dump_contig_sharded", "mfx_variants_run_sharded", "mfx_completeness", "mfx_completeness_pieces", "mfx_variants_run",
     "mfx_index_set_shard", "mfx_router_create", "mfx_router_free", "mfx_route_tiles", "mfx_hist_keys_launch",
 ]
 
@@ -180,6 +180,8 @@ def load_library():
                                    C.POINTER(_VarOpts), C.c_char_p, C.c_char_p, u64p]
     L.mfx_index_set_fingerprint.argtypes = [vp, C.c_uint64]
     L.mfx_index_get_origin.argtypes = [vp, u64p, u64p, u64p]
+    L.mfx_host_threads_share.restype = None
+    L.mfx_host_threads_share.argtypes = [C.c_uint]
     L.mfx_pack_bases.restype = None
     L.mfx_pack_bases.argtypes = [vp, C.c_uint64, vp, vp]
     L.mfx_host_alloc.restype = vp

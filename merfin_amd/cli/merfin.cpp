@@ -713,6 +713,7 @@ int main(int argc, char **argv) {
         snprintf(suf, sizeof(suf), ".part%04zu", d);
         parts[d] = std::string(G.outName) + suf;
         th.emplace_back([&, d]() {
+          mfx_host_threads_share((unsigned)N);
           for (size_t c = runs[d].first; c < runs[d].second; ++c) {
             uint64_t a = 0, m2 = 0;
             if (mfx_dump_contig(S.evs[d], S.sqs[d], (uint32_t)c, recs[c].name.c_str(), parts[d].c_str(), c > runs[d].first, &a, &m2)) { errs[d] = mfx_last_error(); return; }
@@ -760,25 +761,44 @@ int main(int argc, char **argv) {
       // every slot scores its clusters on its own device and writes its part; one VCF header in the concatenation
       const size_t N = G.devices.size();
       std::vector<double> w(recs.size(), 0.0);
+      // one pass over the VCF: the records per contig (for the balance), and the lines themselves, so that every slot is
+      // handed a VCF of ITS contigs only (each slot parsing all 4 M records of a human call set made N slots N times the
+      // host work of one; the host is what bounds these modes)
+      std::string vtext;
+      std::vector<std::pair<size_t, size_t>> vhead;                          // header lines (offset, length incl. newline)
+      std::vector<std::vector<std::pair<size_t, size_t>>> vlines(recs.size());   // data lines per contig, in file order
       {
         mfx_file vf = mfx_open_reader(G.vcfName);
         if (!vf.f) { fprintf(stderr, "ERROR: cannot open VCF '%s'.\n", G.vcfName); return 1; }
+        {
+          std::vector<char> blk(1 << 22);
+          size_t n;
+          while ((n = fread(blk.data(), 1, blk.size(), vf.f)) > 0) vtext.append(blk.data(), n);
+        }
+        if (mfx_close(vf)) { fprintf(stderr, "ERROR: reading VCF '%s' failed.\n", G.vcfName); return 1; }
         std::vector<std::pair<std::string, size_t>> idx;
         for (size_t c = 0; c < recs.size(); ++c) idx.emplace_back(recs[c].name, c);
         std::sort(idx.begin(), idx.end());
-        char *L = nullptr;
-        size_t cap = 0;
-        ssize_t n;
-        while ((n = getline(&L, &cap, vf.f)) >= 0) {
-          if (n == 0 || L[0] == '#') continue;
-          const char *tab = (const char *)memchr(L, '\t', (size_t)n);
-          if (!tab) continue;
-          std::string chr(L, tab - L);
-          auto it = std::lower_bound(idx.begin(), idx.end(), std::make_pair(chr, (size_t)0));
-          if (it != idx.end() && it->first == chr) w[it->second] += 1.0;
+        size_t last_c = recs.size();
+        std::string last_chr;
+        for (size_t o = 0; o < vtext.size();) {
+          const char *nl = (const char *)memchr(vtext.data() + o, '\n', vtext.size() - o);
+          const size_t e = nl ? (size_t)(nl - vtext.data()) + 1 : vtext.size(), n = e - o;
+          if (vtext[o] == '#') vhead.emplace_back(o, n);
+          else if (n > 1) {
+            const char *tab = (const char *)memchr(vtext.data() + o, '\t', n);
+            if (tab) {
+              const size_t cl = (size_t)(tab - (vtext.data() + o));
+              if (last_c == recs.size() || last_chr.size() != cl || memcmp(last_chr.data(), vtext.data() + o, cl) != 0) {
+                last_chr.assign(vtext.data() + o, cl);
+                auto it = std::lower_bound(idx.begin(), idx.end(), std::make_pair(last_chr, (size_t)0));
+                last_c = (it != idx.end() && it->first == last_chr) ? it->second : recs.size() + 1;   // + 1: not a contig of -sequence
+              }
+              if (last_c < recs.size()) { w[last_c] += 1.0; vlines[last_c].emplace_back(o, n); }
+            }
+          }
+          o = e;
         }
-        free(L);
-        (void)mfx_close(vf);
         for (size_t c = 0; c < recs.size(); ++c) w[c] += 1e-9 * (double)lens[c];
       }
       Slots S;
@@ -786,9 +806,25 @@ int main(int argc, char **argv) {
       lap("replicate index");
       fprintf(stderr, "-- Evaluating on %zu devices.\n", N);
       const auto runs = contig_partition(w, N);
-      std::vector<std::string> parts(N), errs(N), dbgs(N);
+      std::vector<std::string> parts(N), errs(N), dbgs(N), vins(N);
       std::vector<uint64_t> ncls(N, 0);
       std::vector<std::thread> th;
+      for (size_t d = 0; d < N; ++d) {                                      // slot d's VCF: all header lines + the lines of its contigs
+        char suf[48];
+        snprintf(suf, sizeof(suf), ".part%04zu.in.vcf", d);
+        vins[d] = outName + suf;
+        FILE *vf = fopen(vins[d].c_str(), "w");
+        bool ok = vf != nullptr;
+        for (const auto &h : vhead) ok = ok && fwrite(vtext.data() + h.first, 1, h.second, vf) == h.second;
+        for (size_t c = runs[d].first; c < runs[d].second && ok; ++c)
+          for (const auto &l : vlines[c]) {
+            ok = ok && fwrite(vtext.data() + l.first, 1, l.second, vf) == l.second;
+            if (ok && vtext[l.first + l.second - 1] != '\n') ok = fputc('\n', vf) != EOF;     // a last line without newline
+          }
+        if (vf && fclose(vf) != 0) ok = false;
+        if (!ok) { fprintf(stderr, "ERROR: cannot write '%s'.\n", vins[d].c_str()); for (size_t e = 0; e <= d; ++e) remove(vins[e].c_str()); return 1; }
+      }
+      std::string().swap(vtext);
       for (size_t d = 0; d < N; ++d) {
         char suf[48];
         snprintf(suf, sizeof(suf), ".part%04zu", d);
@@ -796,15 +832,17 @@ int main(int argc, char **argv) {
         snprintf(suf, sizeof(suf), ".%02zu.debug.gz", d);
         dbgs[d] = std::string(G.outName) + suf;
         th.emplace_back([&, d]() {
+          mfx_host_threads_share((unsigned)N);                 // N slots side by side: each takes its share of the host threads
           mfx_variant_opts o = vo;
           o.debug_path = G.debug ? dbgs[d].c_str() : nullptr;
           const size_t lo = runs[d].first, hi = runs[d].second;
-          if (mfx_variants_run(S.evs[d], G.vcfName, names.data() + lo, bases.data() + lo, lens.data() + lo, (uint32_t)(hi - lo), &o, parts[d].c_str(),
+          if (mfx_variants_run(S.evs[d], vins[d].c_str(), names.data() + lo, bases.data() + lo, lens.data() + lo, (uint32_t)(hi - lo), &o, parts[d].c_str(),
                                nullptr, &ncls[d]))
             errs[d] = mfx_last_error();
         });
       }
       for (auto &x : th) x.join();
+      for (size_t d = 0; d < N; ++d) remove(vins[d].c_str());
       S.release();
       for (size_t d = 0; d < N; ++d) if (!errs[d].empty()) { fprintf(stderr, "ERROR: variant scoring (slot %zu): %s\n", d, errs[d].c_str()); return 1; }
       if (!concat_parts(outName, parts, true)) { fprintf(stderr, "ERROR: cannot write '%s'.\n", outName.c_str()); return 1; }

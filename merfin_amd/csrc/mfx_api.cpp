@@ -2059,7 +2059,13 @@ extern "C" int mfx_dump_values_sharded(mfx_eval *const *evs, const mfx_seq *cons
 }
 
 // host threads the library may use for text formatting: min(hardware, cgroup quota, 64)
-unsigned mfx_host_threads() {
+static thread_local unsigned t_sharers = 1;
+extern "C" void mfx_host_threads_share(unsigned nsharers) { t_sharers = nsharers ? nsharers : 1; }
+
+static unsigned host_threads_total();
+unsigned mfx_host_threads() { return std::max(1u, host_threads_total() / t_sharers); }
+
+static unsigned host_threads_total() {
   const char *e = getenv("MFX_HOST_THREADS");
   if (e && atoi(e) > 0) return (unsigned)atoi(e);
   unsigned n = std::thread::hardware_concurrency();

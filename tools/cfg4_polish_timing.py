@@ -60,3 +60,27 @@ for mode in ("polish", "filter"):
     dt = time.time() - t0
     nrec = sum(1 for l in open(out + "/out.%s.vcf" % mode) if not l.startswith("#"))
     print("-%s: %d clusters in %.2fs = %.0f clusters/s, %d records selected" % (mode, ncl, dt, ncl / dt, nrec), flush=True)
+
+if len(sys.argv) > 3 and sys.argv[3] == "cli":
+    # the C++ CLI on one device and with 8 slots (all on this GPU: the host side is what is being looked at)
+    import subprocess
+    exe = os.path.join(ROOT, "merfin_amd", "bin", "merfin")
+    ek, er, ea = ix.export(sort=False)
+    m.db_write_flat(out + "/read.mfxk", k, ek[er > 0], er[er > 0])
+    m.db_write_flat(out + "/asm.mfxk", k, ek[ea > 0], ea[ea > 0])
+    del ek, er, ea
+    with open(out + "/asm.fasta", "wb") as f:
+        for nm, a in zip(names, asm):
+            f.write(b">" + nm.encode() + b"\n" + a + b"\n")
+    del ev, ix
+    torch.cuda.empty_cache()
+    for devs in ("0", "0,0,0,0,0,0,0,0"):
+        t0 = time.time()
+        r = subprocess.run([exe, "-polish", "-sequence", out + "/asm.fasta", "-readmers", out + "/read.mfxk", "-seqmers", out + "/asm.mfxk", "-peak", str(lam),
+                            "-vcf", vcf, "-output", out + "/cli_" + str(len(devs)), "-devices", devs], capture_output=True, text=True,
+                           env=dict(os.environ, MFX_CLI_TIMING="1"))
+        dt = time.time() - t0
+        print("merfin -polish -devices %s: rc=%d wall=%.2fs" % (devs, r.returncode, dt))
+        print("    " + "\n    ".join(l for l in r.stderr.splitlines() if "timing" in l or "ERROR" in l))
+    a_, b_ = open(out + "/cli_1.polish.vcf").read(), open(out + "/cli_15.polish.vcf").read()
+    print("8 slots == 1 device:", a_ == b_, len(a_))
