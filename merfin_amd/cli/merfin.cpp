@@ -756,6 +756,18 @@ int main(int argc, char **argv) {
     vo.nosplit = G.nosplit ? 1 : 0;
     vo.debug_path = G.debug ? dbgName.c_str() : nullptr;
     uint64_t ncl = 0;
+    // These modes are bound by the host (VCF parsing, path enumeration, selectors), whose phases alternate between
+    // parallel and serial stretches: several slots side by side fill one another's serial stretches (1 Gb, 1.3 M calls:
+    // 2.0 s in 8 slots vs 2.7 s in one).  So one device is also run as 4 slots sharing its table -- unless -debug asks
+    // for the single statistics file, or there is only one contig to hand out.  MFX_VARIANT_SLOTS overrides.
+    {
+      size_t want = G.devices.size();
+      const char *vs = getenv("MFX_VARIANT_SLOTS");
+      if (vs && atoi(vs) > 0) want = (size_t)atoi(vs);
+      else if (want < 4 && !G.debug && recs.size() >= 2) want = 4;
+      const std::vector<int> real = G.devices;
+      while (G.devices.size() < want) G.devices.push_back(real[G.devices.size() % real.size()]);
+    }
     if (G.devices.size() > 1) {
       // BASELINE config 4 names 8 GPUs: contigs cut into one contiguous run per slot, balanced by their VCF records;
       // every slot scores its clusters on its own device and writes its part; one VCF header in the concatenation
@@ -804,7 +816,7 @@ int main(int argc, char **argv) {
       Slots S;
       if (!S.make(G, ix, nullptr, ev, &kp)) { fprintf(stderr, "ERROR: variant scoring on %zu devices: %s\n", N, mfx_last_error()); return 1; }
       lap("replicate index");
-      fprintf(stderr, "-- Evaluating on %zu devices.\n", N);
+      fprintf(stderr, "-- Evaluating in %zu slots.\n", N);
       const auto runs = contig_partition(w, N);
       std::vector<std::string> parts(N), errs(N), dbgs(N), vins(N);
       std::vector<uint64_t> ncls(N, 0);
