@@ -143,3 +143,31 @@ def test_sequence_packer_bodies_agree(monkeypatch):
         assert np.array_equal(c, dc) and np.array_equal(v, dv)
     c, v = m.pack_bases(b"ACGTNacgt")
     assert int(c[0]) == 0x1EC7800000000000 and int(v[0]) == 0xF7800000
+
+
+@pytest.mark.parametrize("piece", [64, 300, 1 << 25])
+def test_text_database_probe_needs_no_gpu(tmp_path, piece, monkeypatch):
+    """mfx_db_probe of `meryl print` text (host only): k and the number of k-mers for every piece size of the parallel
+    reader, blank and CR LF lines skipped, malformed lines reported with their byte offset; .gz goes through the serial reader"""
+    import gzip
+    import merfin_amd as m
+    monkeypatch.setenv("MFX_TEXT_PIECE", str(piece))
+    r = np.random.default_rng(piece)
+    k = 21
+    lines = ["".join(r.choice(list("ACGT"), size=k)) + "\t%d" % v for v in r.integers(1, 10**6, size=2000)]
+    body = "\r\n".join(lines[:100]) + "\r\n\r\n" + "\n".join(lines[100:1500]) + "\n\n\n" + "\n".join(lines[1500:])   # no newline at the end
+    p = str(tmp_path / "db.txt")
+    open(p, "w", newline="").write(body)
+    assert m.db_probe(p) == {"k": k, "format": "text", "n_kmers": 2000}
+    with gzip.open(p + ".gz", "wt", newline="") as f:
+        f.write(body)
+    assert m.db_probe(p + ".gz") == {"k": k, "format": "text", "n_kmers": 2000}
+    for at, bad, what in ((0, "ACGTN\t3", "expected '<kmer>"), (1999, lines[5][:10] + "\t7", "differs from"), (700, lines[3].replace("\t", "\tx"), "expected '<kmer>")):
+        broken = list(lines)
+        broken[at] = bad
+        bp = str(tmp_path / "broken.txt")
+        open(bp, "w").write("\n".join(broken) + "\n")
+        off = len("\n".join(broken[:at])) + (1 if at else 0)
+        with pytest.raises(m.MfxError) as e:
+            m.db_probe(bp)
+        assert what in str(e.value) and ("at byte %d" % off) in str(e.value)
