@@ -304,7 +304,14 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_w_count_kernel(mfx_count_args a
 __global__ __launch_bounds__(MFX_BLOCK) void mfx_w_completeness_kernel(mfx_table_view t, double peak, uint32_t n_prob, const uint32_t *probK,
                                                                        const double *probP, double *pieces) {
   __shared__ double s_tot[64], s_und[64];
+  constexpr uint32_t NLUT = 1024;                              // readK per common read count, as in mfx_completeness_kernel
+  __shared__ double s_rk[NLUT];
   if (threadIdx.x < 64) { s_tot[threadIdx.x] = 0.0; s_und[threadIdx.x] = 0.0; }
+  for (uint32_t v = threadIdx.x; v < NLUT; v += blockDim.x) {
+    double rk, pr;
+    mfx_getK_core(peak, n_prob, probK, probP, v, rk, pr);
+    s_rk[v] = rk;
+  }
   __syncthreads();
   const uint64_t nslots = t.nlines * MFX_WSLOTS_LINE;
   const int pshift = 2 * t.k - 6;
@@ -315,7 +322,8 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_w_completeness_kernel(mfx_table
     const mfx_wslot s = S[i];
     if (s.state == 0 || s.readV == 0) continue;              // empty slot / asm-only k-mer (:106-109)
     double readK, prob;
-    mfx_getK_core(peak, n_prob, probK, probP, s.readV, readK, prob);
+    if (s.readV < NLUT) readK = s_rk[s.readV];
+    else mfx_getK_core(peak, n_prob, probK, probP, s.readV, readK, prob);
     const double asmK = (double)s.asmV;
     const uint32_t piece = (uint32_t)(mfx_w_make(s.lo, s.hi) >> pshift) & 63u;
     atomicAdd(&s_tot[piece], readK);                         // :113
