@@ -286,6 +286,7 @@ extern "C" void mfx_index_free(mfx_index *ix) {
   DevGuard g(ix->device);
   mfx_index_ingest_release(ix);
   if (ix->d_slots) (void)hipFree(ix->d_slots);
+  if (ix->d_compact) (void)hipFree(ix->d_compact);
   if (ix->d_meta) (void)hipFree(ix->d_meta);
   delete ix;
 }
@@ -901,6 +902,67 @@ static int ensure_tile_partials(mfx_eval *ev, uint64_t ntiles) {
 // chunk_of_total  > 0: one chunk of a streamed evaluation over `chunk_of_total` tiles in all: the values land at
 // their tile's place in ev->d_tile_partials (sized by the caller) and are summed ONCE after the last chunk, so
 // koverCpy is bit-identical to a single launch over the whole range, however the upload was cut.
+// The compact -hist index of a table (mfx_kernels.hip): the assembly's k-mers in 8-byte slots, 16 per line, minimizer
+// buckets of w = 4 windows.  OPT-IN (MFX_COMPACT=1): 3 Gb -hist runs at 99-101 G k-mers/s on it instead of 91 G, but
+// building it is a pass over the table plus 3 G inserts (~0.4 s) and 96-120 GB of HBM -- a single -hist evaluation
+// (33 ms) never earns that back, only a caller that evaluates the same index many times does.  Built on first use for
+// the table's current version; any failure (no memory, a bucket beyond the probe limit) leaves the standard table in charge.
+static mfx_table_view index_compact_view(const mfx_index *cix) {
+  mfx_table_view none = {nullptr, 0, 0, 0, 0, 0, 0, 1, 0};
+  const char *en = getenv("MFX_COMPACT");
+  if (!(en && atoi(en)) || cix->wide() || cix->k > 21 || cix->mz_w == 0 || cix->shard_n != 1) return none;
+  mfx_index *ix = const_cast<mfx_index *>(cix);
+  if (ix->compact_unusable && ix->compact_version == ix->version) return none;
+  if (ix->compact_version != ix->version || !ix->d_compact) {
+    if (ix->d_compact) { (void)hipFree(ix->d_compact); ix->d_compact = nullptr; }
+    ix->compact_version = ix->version;
+    ix->compact_unusable = true;
+    uint64_t meta[4];
+    if (hipMemcpy(meta, ix->d_meta, sizeof(meta), hipMemcpyDeviceToHost) != hipSuccess) return none;
+    const char *lfe = getenv("MFX_COMPACT_LF");
+    double lf = lfe ? atof(lfe) : 0.25;
+    if (!(lf > 0.1 && lf <= 0.9)) lf = 0.25;
+    // only the k-mers with an assembly count go in: count them (a pass over the table)
+    uint64_t n_asm = meta[0];
+    {
+      uint64_t *d_n = nullptr;
+      if (hipMalloc((void **)&d_n, 8) == hipSuccess && hipMemset(d_n, 0, 8) == hipSuccess &&
+          mfx_k_count_asm_slots(ix->view(), d_n, nullptr) == hipSuccess)
+        (void)hipMemcpy(&n_asm, d_n, 8, hipMemcpyDeviceToHost);
+      if (d_n) (void)hipFree(d_n);
+      (void)hipGetLastError();
+    }
+    uint64_t nl = (uint64_t)((double)(n_asm + 1024) / (16.0 * lf)) + 64;
+    if (nl >= (1ull << 32)) return none;
+    {
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (double)free_b < (double)nl * MFX_ALIGN + 4e9) { (void)hipGetLastError(); return none; }
+    }
+    if (hipMalloc((void **)&ix->d_compact, nl * MFX_ALIGN) != hipSuccess) { (void)hipGetLastError(); ix->d_compact = nullptr; return none; }
+    uint64_t *d_fail = nullptr;
+    bool ok = hipMemset(ix->d_compact, 0xff, nl * MFX_ALIGN) == hipSuccess && hipMalloc((void **)&d_fail, 8) == hipSuccess &&
+              hipMemset(d_fail, 0, 8) == hipSuccess;
+    mfx_table_view c = ix->view();
+    c.slots = reinterpret_cast<mfx_slot *>(ix->d_compact);
+    c.nlines = nl;
+    const char *we = getenv("MFX_COMPACT_W");
+    c.mz_w = std::min(ix->k, we && atoi(we) >= 1 && atoi(we) <= 5 ? atoi(we) : 4);
+    uint64_t fail = 1;
+    ok = ok && mfx_k_compact_build(ix->view(), c, d_fail, nullptr) == hipSuccess &&
+         hipMemcpy(&fail, d_fail, 8, hipMemcpyDeviceToHost) == hipSuccess && fail == 0;
+    if (d_fail) (void)hipFree(d_fail);
+    if (!ok) { (void)hipGetLastError(); (void)hipFree(ix->d_compact); ix->d_compact = nullptr; return none; }
+    ix->compact_lines = nl;
+    ix->compact_unusable = false;
+  }
+  mfx_table_view c = ix->view();
+  c.slots = reinterpret_cast<mfx_slot *>(ix->d_compact);
+  c.nlines = ix->compact_lines;
+  const char *we = getenv("MFX_COMPACT_W");
+  c.mz_w = std::min(ix->k, we && atoi(we) >= 1 && atoi(we) <= 5 ? atoi(we) : 4);
+  return c;
+}
+
 static int hist_launch(mfx_eval *ev, const mfx_seq *seq, uint64_t tile_begin, uint64_t tile_end, uint32_t part_rank, uint32_t part_n,
                        uint32_t part_shift, uint64_t *d_counts, double *d_kover, void *stream, uint64_t chunk_of_total = 0, int ctr_slot = 0) {
   uint64_t ntl = tile_end - tile_begin;
@@ -929,6 +991,7 @@ static int hist_launch(mfx_eval *ev, const mfx_seq *seq, uint64_t tile_begin, ui
   a.canonical = canon;
   a.bases = seq->d_bases;
   if (seq->bases_stale) { a.codes = seq->d_codes; a.valid = seq->d_valid; }      // a packed upload: the planes are the sequence
+  if (canon) a.t2 = index_compact_view(ev->ix);
   a.contig_off = seq->d_contig_off;
   a.contig_len = seq->d_contig_len;
   a.tile_start = seq->d_tile_start;

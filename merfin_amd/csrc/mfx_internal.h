@@ -98,6 +98,10 @@ struct mfx_index {
   uint32_t  shard_rank = 0, shard_n = 1;
   uint64_t  version = 0;        // bumped by every insert batch; lets evaluators cache index-derived facts
   uint64_t  fingerprint = 0;    // caller-supplied digest of the inputs (travels with the index image)
+  // compact -hist index (k <= 21, canonical database; mfx_kernels.hip): built from the table on first use per version
+  uint64_t *d_compact = nullptr;
+  uint64_t  compact_lines = 0, compact_version = ~0ull;
+  bool      compact_unusable = false;
   bool      wide() const { return k > MFX_MAX_K_NARROW; }
   uint32_t  slots_per_line() const { return wide() ? MFX_WSLOTS_LINE : MFX_SLOTS_LINE; }
   uint32_t  key_words() const { return wide() ? 2u : 1u; }      // uint64 words per k-mer at the C ABI

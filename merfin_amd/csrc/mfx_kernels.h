@@ -17,6 +17,7 @@ struct mfx_kstar_args {
 
 struct mfx_hist_args {
   mfx_table_view  t;
+  mfx_table_view  t2 = {nullptr, 0, 0, 0, 0, 0, 0, 1, 0};   // compact -hist index (slots == nullptr: none); see mfx_kernels.hip
   int             canonical;          // 1: single probe of min(f,r); 0: probe both strands and sum
   const uint8_t  *bases;
   const uint64_t *codes = nullptr;    // non-null: read the tiles from the packed planes (same byte offsets / 32) instead of `bases`
@@ -115,6 +116,8 @@ hipError_t mfx_kw_count(const mfx_count_args &a, hipStream_t st);
 hipError_t mfx_kw_completeness(mfx_table_view t, double peak, uint32_t n_prob, const uint32_t *probK, const double *probP, double *partials,
                                int grid, hipStream_t st);
 hipError_t mfx_k_dump(const mfx_dump_args &a, hipStream_t st);
+hipError_t mfx_k_count_asm_slots(mfx_table_view t, uint64_t *out, hipStream_t st);
+hipError_t mfx_k_compact_build(mfx_table_view t, mfx_table_view c, uint64_t *fail, hipStream_t st);
 hipError_t mfx_k_add_u32(uint32_t *dst, const uint32_t *src, uint64_t n, hipStream_t st);
 hipError_t mfx_k_unpack(const uint64_t *codes, const uint32_t *valid, uint8_t *bases, uint64_t nwords, hipStream_t st);
 hipError_t mfx_k_count(const mfx_count_args &a, hipStream_t st);

@@ -580,6 +580,197 @@ __device__ __forceinline__ void mfx_group_lookup(const mfx_table_view &t, mfx_ma
   }
 }
 
+// ===========================================================================
+// Compact -hist index (k <= 21, canonical database): the same k-mers in 8-byte slots, 16 per 128-byte line --
+// {key: 42 bits | readV: 11 | asmV: 11}, a count of 2047 meaning "saturated: the exact pair is in the standard table".
+// Twice the slots per line let a minimizer bucket of w = 5 windows (m = k - 4) stay in its home line, i.e. fewer
+// lines per k-mer (0.52 -> ~0.36) than the 16-byte table can afford.  Built from the standard table
+// (mfx_compact_build_kernel), read by mfx_hist_kernel<true, true> only; every other kernel keeps the standard table.
+// ===========================================================================
+constexpr uint32_t MFX_CSLOTS_LINE = 16;
+constexpr uint32_t MFX_CSAT = 2047u;
+
+__device__ __forceinline__ uint64_t mfx_c_pack(uint64_t key, uint32_t rv, uint32_t av) {
+  return (key << 22) | ((uint64_t)(rv < MFX_CSAT ? rv : MFX_CSAT) << 11) | (uint64_t)(av < MFX_CSAT ? av : MFX_CSAT);
+}
+
+// every (distinct) k-mer of the standard table claims the first free slot of its candidate lines in the compact one
+__global__ __launch_bounds__(MFX_BLOCK) void mfx_compact_build_kernel(mfx_table_view t, mfx_table_view c, unsigned long long *fail) {
+  const uint64_t nslots = t.nlines * MFX_SLOTS_LINE;
+  const uint64_t stride = (uint64_t)gridDim.x * MFX_BLOCK;
+  unsigned long long *cs = reinterpret_cast<unsigned long long *>(c.slots);
+  for (uint64_t i = (uint64_t)blockIdx.x * MFX_BLOCK + threadIdx.x; i < nslots; i += stride) {
+    const uint4 s = reinterpret_cast<const uint4 *>(t.slots)[i];
+    const uint64_t key = (uint64_t)s.x | ((uint64_t)s.y << 32);
+    if (key == MFX_EMPTY || s.w == 0u) continue;               // -hist asks for the k-mers of the assembly: the others stay in the standard table only
+    const unsigned long long packed = mfx_c_pack(key, s.z, s.w);
+    const mfx_probe pr = mfx_home(c, key);
+    bool placed = false;
+    for (uint32_t d = 0; d < MFX_MAX_LINES && !placed; ++d) {
+      unsigned long long *ln = cs + mfx_probe_line(c, pr, d) * MFX_CSLOTS_LINE;
+      for (uint32_t q = 0; q < MFX_CSLOTS_LINE && !placed; ++q) {
+        unsigned long long cur = __hip_atomic_load(ln + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == MFX_EMPTY) placed = atomicCAS(ln + q, (unsigned long long)MFX_EMPTY, packed) == MFX_EMPTY;
+      }
+    }
+    if (!placed) atomicAdd(fail, 1ull);
+  }
+}
+
+// exact per-lane path over the compact table from candidate line d0 on (rare); saturated entries and anything
+// unresolved are answered by the standard table
+__device__ __forceinline__ uint2 mfx_scan_lines8(const mfx_table_view &c, const mfx_table_view &t, uint64_t key, uint32_t d0) {
+  const mfx_probe pr = mfx_home(c, key);
+  const uint64_t *cs = reinterpret_cast<const uint64_t *>(c.slots);
+  for (uint32_t d = d0; d < MFX_MAX_LINES; ++d) {
+    const uint4 *ln = reinterpret_cast<const uint4 *>(cs + mfx_probe_line(c, pr, d) * MFX_CSLOTS_LINE);
+    uint4 s[8];
+#pragma unroll
+    for (uint32_t q = 0; q < 8; ++q) s[q] = ln[q];
+    bool any_empty = false;
+    uint64_t hit = MFX_EMPTY;
+#pragma unroll
+    for (uint32_t q = 0; q < 8; ++q) {
+      const uint64_t a = (uint64_t)s[q].x | ((uint64_t)s[q].y << 32), b = (uint64_t)s[q].z | ((uint64_t)s[q].w << 32);
+      if (a != MFX_EMPTY && (a >> 22) == key) hit = a;
+      if (b != MFX_EMPTY && (b >> 22) == key) hit = b;
+      any_empty |= (a == MFX_EMPTY) || (b == MFX_EMPTY);
+    }
+    if (hit != MFX_EMPTY) {
+      const uint32_t rv = (uint32_t)(hit >> 11) & MFX_CSAT, av = (uint32_t)hit & MFX_CSAT;
+      if (rv == MFX_CSAT || av == MFX_CSAT) return mfx_lookup(t, key);
+      return make_uint2((rv < t.minV || rv > t.maxV) ? 0u : rv, av);
+    }
+    if (any_empty) break;
+  }
+  return mfx_lookup(t, key);                                   // not an assembly k-mer
+}
+
+// the cooperative probe of mfx_group_lookup over 16-slot lines: a slot lane holds TWO slots of the line; the matching
+// lane posts the slot's low word (counts + low key bits, never 0 for a stored k-mer with a count) into the owner's
+// 4-byte record; the owner unpacks it.
+template <int S>
+__device__ __forceinline__ void mfx_group_post8(uint32_t *rec, const mfx_u32x4 (&v)[8], const uint32_t (&klo)[8], const uint32_t (&khi)[8]) {
+  const mfx_u32x4 s = v[S];
+  // (key << 22) was broadcast: equal high words and low words that differ only in the 22 count bits
+  if (s.y == khi[S] && ((s.x ^ klo[S]) >> 22) == 0u) rec[S] = s.x;
+  if (s.w == khi[S] && ((s.z ^ klo[S]) >> 22) == 0u) rec[S] = s.z;
+}
+template <int S>
+__device__ __forceinline__ uint64_t mfx_group_room8(const mfx_u32x4 (&v)[8]) {
+  const uint64_t m = __ballot(v[S].w == 0xffffffffu);        // the LAST slot of the line is lane 7's second one
+  return ((m >> 7) & 0x0101010101010101ULL) << S;
+}
+
+template <int B>
+__device__ __forceinline__ void mfx_group_lookup8(const mfx_table_view &c, const mfx_table_view &t, mfx_mailbox &M, const uint64_t (&key)[B],
+                                                  const uint64_t (&krc)[B], const bool (&ok)[B], uint32_t (&rv)[B], uint32_t (&av)[B]) {
+  const uint32_t tid = threadIdx.x, sub16 = (tid & 7u) << 4;
+  const uint32_t lane = tid & 63u, wbase = tid & ~63u;
+  uint32_t *const own = reinterpret_cast<uint32_t *>(&M.rec[wbase]) + lane;
+  uint32_t *const grp = reinterpret_cast<uint32_t *>(&M.rec[wbase]) + (lane & ~7u);
+  const uint64_t slots0 = reinterpret_cast<uint64_t>(c.slots);
+  uint64_t laddr[B];
+  uint32_t pending[B];          // 0 resolved, 1 home line full: continue per lane, 2 saturated: ask the standard table
+#pragma unroll
+  for (int j = 0; j < B; ++j) { pending[j] = 0u; rv[j] = av[j] = 0u; }
+  {
+    const uint32_t fl = mfx_first_line(c, key[0], krc[0]);
+    laddr[0] = slots0 + ((uint64_t)(ok[0] ? fl : 0u) << 7);
+  }
+#pragma unroll
+  for (int j = 0; j < B; ++j) {
+    mfx_u32x4 v[8];
+    uint32_t klo[8], khi[8], alo[8], ahi[8];
+    const uint64_t ks = key[j] << 22;
+    *own = 0u;
+    mfx_wave_handoff();
+    mfx_group_announce<0>(alo, ahi, klo, khi, laddr[j], (uint32_t)ks, (uint32_t)(ks >> 32)); mfx_group_announce<1>(alo, ahi, klo, khi, laddr[j], (uint32_t)ks, (uint32_t)(ks >> 32));
+    mfx_group_announce<2>(alo, ahi, klo, khi, laddr[j], (uint32_t)ks, (uint32_t)(ks >> 32)); mfx_group_announce<3>(alo, ahi, klo, khi, laddr[j], (uint32_t)ks, (uint32_t)(ks >> 32));
+    mfx_group_announce<4>(alo, ahi, klo, khi, laddr[j], (uint32_t)ks, (uint32_t)(ks >> 32)); mfx_group_announce<5>(alo, ahi, klo, khi, laddr[j], (uint32_t)ks, (uint32_t)(ks >> 32));
+    mfx_group_announce<6>(alo, ahi, klo, khi, laddr[j], (uint32_t)ks, (uint32_t)(ks >> 32)); mfx_group_announce<7>(alo, ahi, klo, khi, laddr[j], (uint32_t)ks, (uint32_t)(ks >> 32));
+    mfx_group_fetch<0>(v, alo, ahi, sub16); mfx_group_fetch<1>(v, alo, ahi, sub16); mfx_group_fetch<2>(v, alo, ahi, sub16);
+    mfx_group_fetch<3>(v, alo, ahi, sub16); mfx_group_fetch<4>(v, alo, ahi, sub16); mfx_group_fetch<5>(v, alo, ahi, sub16);
+    mfx_group_fetch<6>(v, alo, ahi, sub16); mfx_group_fetch<7>(v, alo, ahi, sub16);
+    if (j + 1 < B) {
+      const uint32_t fl = mfx_first_line(c, key[j + 1], krc[j + 1]);
+      laddr[j + 1] = slots0 + ((uint64_t)(ok[j + 1] ? fl : 0u) << 7);
+    }
+    uint64_t room = 0;
+    mfx_group_landed<0>(v); mfx_group_post8<0>(grp, v, klo, khi); room |= mfx_group_room8<0>(v);
+    mfx_group_landed<1>(v); mfx_group_post8<1>(grp, v, klo, khi); room |= mfx_group_room8<1>(v);
+    mfx_group_landed<2>(v); mfx_group_post8<2>(grp, v, klo, khi); room |= mfx_group_room8<2>(v);
+    mfx_group_landed<3>(v); mfx_group_post8<3>(grp, v, klo, khi); room |= mfx_group_room8<3>(v);
+    mfx_group_landed<4>(v); mfx_group_post8<4>(grp, v, klo, khi); room |= mfx_group_room8<4>(v);
+    mfx_group_landed<5>(v); mfx_group_post8<5>(grp, v, klo, khi); room |= mfx_group_room8<5>(v);
+    mfx_group_landed<6>(v); mfx_group_post8<6>(grp, v, klo, khi); room |= mfx_group_room8<6>(v);
+    mfx_group_landed<7>(v); mfx_group_post8<7>(grp, v, klo, khi); room |= mfx_group_room8<7>(v);
+    mfx_wave_handoff();
+    const uint32_t r = *own;
+    mfx_wave_handoff();
+    if (ok[j]) {
+      const uint32_t r_rv = (r >> 11) & MFX_CSAT, r_av = r & MFX_CSAT;
+      if ((r & 0x3fffffu) != 0u) {
+        if (r_rv == MFX_CSAT || r_av == MFX_CSAT) pending[j] = 2u;
+        else { rv[j] = (r_rv < t.minV || r_rv > t.maxV) ? 0u : r_rv; av[j] = r_av; }
+      } else {
+        pending[j] = ((room >> lane) & 1ULL) ? 2u : 1u;        // not in a line with room: not an assembly k-mer -> standard table
+      }
+    }
+  }
+  // ---- second cooperative pass (as in mfx_group_lookup): queries whose home line was full continue at their next
+  // candidate line, compacted into this wave's 64 mailbox records and served 8 per step
+  uint32_t qpos[B];
+  uint32_t nq = 0;
+#pragma unroll
+  for (int j = 0; j < B; ++j) {
+    const bool p = pending[j] == 1u;
+    const uint64_t m = __ballot(p);
+    const uint32_t pos = nq + (uint32_t)__popcll(m & ((1ULL << lane) - 1ULL));
+    qpos[j] = 0xffffffffu;
+    if (p && pos < 64u) {
+      qpos[j] = pos;
+      const uint32_t l1 = (uint32_t)mfx_probe_line(c, mfx_home(c, key[j]), 1);
+      const uint64_t ks = key[j] << 22;
+      M.rec[wbase + pos] = make_uint4((uint32_t)ks, (uint32_t)(ks >> 32), l1, 0u);
+    }
+    nq += (uint32_t)__popcll(m);
+  }
+  mfx_wave_handoff();
+  if (nq > 64u) nq = 64u;
+  for (uint32_t q0 = 0; q0 < nq; q0 += 8u) {                 // wave-uniform trip count
+    const uint32_t e = q0 + (lane >> 3);
+    const bool live = e < nq;
+    const uint4 ent = M.rec[wbase + (live ? e : 0u)];
+    mfx_wave_handoff();
+    uint4 sl = make_uint4(0u, 0u, 0u, 0u);
+    if (live) sl = *reinterpret_cast<const uint4 *>(slots0 + ((uint64_t)ent.z << 7) + sub16);
+    uint32_t *rec = reinterpret_cast<uint32_t *>(&M.rec[wbase + e]);
+    if (live) {
+      if ((tid & 7u) == 7u && sl.w == 0xffffffffu) rec[3] = 1u;                        // the line's last slot is free: it has room
+      if (sl.y == ent.y && ((sl.x ^ ent.x) >> 22) == 0u) { rec[0] = sl.x; rec[2] = 0xffffffffu; }    // found (marker: no line has this index)
+      else if (sl.w == ent.y && ((sl.z ^ ent.x) >> 22) == 0u) { rec[0] = sl.z; rec[2] = 0xffffffffu; }
+    }
+  }
+  mfx_wave_handoff();
+#pragma unroll
+  for (int j = 0; j < B; ++j) {
+    if (pending[j] == 0u) continue;
+    uint32_t from = 1u;
+    if (pending[j] == 1u && qpos[j] != 0xffffffffu) {
+      const uint4 r = M.rec[wbase + qpos[j]];
+      if (r.z == 0xffffffffu) {
+        const uint32_t r_rv = (r.x >> 11) & MFX_CSAT, r_av = r.x & MFX_CSAT;
+        if (r_rv != MFX_CSAT && r_av != MFX_CSAT) { rv[j] = (r_rv < t.minV || r_rv > t.maxV) ? 0u : r_rv; av[j] = r_av; continue; }
+        pending[j] = 2u;                                       // saturated: the standard table has the pair
+      } else if (r.w == 1u) pending[j] = 2u;                   // not an assembly k-mer: the standard table answers
+      else from = 2u;                                          // that line was full too
+    }
+    const uint2 x = pending[j] == 2u ? mfx_lookup(t, key[j]) : mfx_scan_lines8(c, t, key[j], from);
+    rv[j] = x.x; av[j] = x.y;
+  }
+}
+
 // k-mer starting at tile position p; returns validity (all k bases ACGT)
 __device__ __forceinline__ bool mfx_tile_kmer(const mfx_tile_lds &L, int k, uint32_t p, uint64_t &fwd) {
   uint32_t w = p >> 5, o = p & 31;
@@ -597,7 +788,7 @@ __device__ __forceinline__ bool mfx_tile_kmer(const mfx_tile_lds &L, int k, uint
 
 constexpr int MFX_BATCH = 4;          // independent probes in flight per lane
 
-template <bool CANON>
+template <bool CANON, bool COMPACT>
 __global__ __launch_bounds__(MFX_BLOCK, 4) void mfx_hist_kernel(mfx_hist_args a) {
   __shared__ mfx_tile_lds L;
   __shared__ mfx_mailbox MB;
@@ -674,7 +865,8 @@ __global__ __launch_bounds__(MFX_BLOCK, 4) void mfx_hist_kernel(mfx_hist_args a)
           key[j] = f; key2[j] = r;
         }
       }
-      mfx_group_lookup<MFX_BATCH>(a.t, MB, key, key2, ok, rv, av);
+      if (COMPACT) mfx_group_lookup8<MFX_BATCH>(a.t2, a.t, MB, key, key2, ok, rv, av);
+      else mfx_group_lookup<MFX_BATCH>(a.t, MB, key, key2, ok, rv, av);
       if (!CANON) {
         // value(fmer) + value(rmer), uint32 arithmetic (merfin-globals.C:107-108)
         uint32_t rv2[MFX_BATCH], av2[MFX_BATCH];
@@ -1251,11 +1443,30 @@ hipError_t mfx_k_table_export(mfx_table_view t, uint64_t *kmers, uint32_t *readV
   mfx_table_export_kernel<<<4096, 256, 0, st>>>(t, kmers, readV, asmV, count);
   return hipGetLastError();
 }
+__global__ __launch_bounds__(MFX_BLOCK) void mfx_count_asm_slots_kernel(mfx_table_view t, unsigned long long *out) {
+  const uint64_t nslots = t.nlines * MFX_SLOTS_LINE, stride = (uint64_t)gridDim.x * MFX_BLOCK;
+  uint64_t n = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * MFX_BLOCK + threadIdx.x; i < nslots; i += stride) {
+    const uint4 s = reinterpret_cast<const uint4 *>(t.slots)[i];
+    n += ((s.x & s.y) != 0xffffffffu && s.w != 0u) ? 1u : 0u;
+  }
+  n = mfx_wave_sum(n);
+  if ((threadIdx.x & 63u) == 0 && n) atomicAdd(out, (unsigned long long)n);
+}
+hipError_t mfx_k_count_asm_slots(mfx_table_view t, uint64_t *out, hipStream_t st) {
+  mfx_count_asm_slots_kernel<<<4096, MFX_BLOCK, 0, st>>>(t, reinterpret_cast<unsigned long long *>(out));
+  return hipGetLastError();
+}
+hipError_t mfx_k_compact_build(mfx_table_view t, mfx_table_view c, uint64_t *fail, hipStream_t st) {
+  mfx_compact_build_kernel<<<8192, MFX_BLOCK, 0, st>>>(t, c, reinterpret_cast<unsigned long long *>(fail));
+  return hipGetLastError();
+}
 hipError_t mfx_k_hist(const mfx_hist_args &a, int grid, hipStream_t st) {
   // MFX_DEBUG_DYN_LDS: extra dynamic LDS per block, an occupancy knob for experiments only
   static const unsigned dyn = getenv("MFX_DEBUG_DYN_LDS") ? (unsigned)atoi(getenv("MFX_DEBUG_DYN_LDS")) : 0u;
-  if (a.canonical) mfx_hist_kernel<true><<<grid, MFX_BLOCK, dyn, st>>>(a);
-  else             mfx_hist_kernel<false><<<grid, MFX_BLOCK, dyn, st>>>(a);
+  if (a.canonical && a.t2.slots) mfx_hist_kernel<true, true><<<grid, MFX_BLOCK, dyn, st>>>(a);
+  else if (a.canonical)          mfx_hist_kernel<true, false><<<grid, MFX_BLOCK, dyn, st>>>(a);
+  else                           mfx_hist_kernel<false, false><<<grid, MFX_BLOCK, dyn, st>>>(a);
   return hipGetLastError();
 }
 hipError_t mfx_k_route(const mfx_route_args &a, hipStream_t st) {
@@ -1310,7 +1521,7 @@ hipError_t mfx_k_sum_tile_partials(double *tile_partials, uint64_t ntiles, doubl
 }
 int mfx_k_hist_resident_blocks() {
   int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mfx_hist_kernel<true>, MFX_BLOCK, 0) != hipSuccess || nb < 1) nb = 4;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mfx_hist_kernel<true, false>, MFX_BLOCK, 0) != hipSuccess || nb < 1) nb = 4;
   return nb;
 }
 hipError_t mfx_k_unpack(const uint64_t *codes, const uint32_t *valid, uint8_t *bases, uint64_t nwords, hipStream_t st) {

@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for PASS in "FETCH_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
   N=$(echo $PASS | cut -d' ' -f1)
-  env "$@" timeout 600 rocprofv3 --pmc $PASS --kernel-include-regex "mfx_hist" --output-format csv -d $OUT/$N -o b -- python $REPO/bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --bases $BASES > $OUT/$N.json 2> $OUT/$N.log
+  env "$@" timeout 600 rocprofv3 --pmc $PASS --kernel-include-regex "mfx_hist" --output-format csv -d $OUT/$N -o b -- python $REPO/bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-streamed --no-pmc --bases $BASES < /dev/null > $OUT/$N.json 2> $OUT/$N.log
 done
 python - <<PY
 import csv, glob, collections
