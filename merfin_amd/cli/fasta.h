@@ -30,6 +30,16 @@ class SeqFile {
   }
   ~SeqFile() { if (f_) (void)mfx_close(h_, true); }
   bool ok() const { return f_ != nullptr; }
+  // Close the input and report how it ended: 0 = clean.  Once next() has returned false the whole stream was read, so a
+  // decompressor that exited non-zero (truncated / corrupt .gz) or a read error is a failure -- a shorter assembly must
+  // not be evaluated as if it were the file.  Before the end of input (a reader that stopped early) the child's SIGPIPE
+  // is not an error.
+  int finish() {
+    if (!f_) return 0;
+    const bool at_end = eof_;
+    f_ = nullptr;
+    return mfx_close(h_, !at_end);
+  }
 
   // one record per call; false at end of input
   bool next(SeqRecord &r) {
@@ -38,7 +48,7 @@ class SeqFile {
     std::string line;
     if (!have_header_) {
       while (getline(line)) if (!line.empty() && (line[0] == '>' || line[0] == '@')) { header_ = line; have_header_ = true; break; }
-      if (!have_header_) return false;
+      if (!have_header_) { eof_ = true; return false; }
     }
     bool fastq = header_[0] == '@';
     size_t e = 1;
@@ -115,6 +125,6 @@ class SeqFile {
   mfx_file h_;
   std::vector<char> buf_;
   size_t pos_ = 0, len_ = 0, size_hint_ = 0, total_ = 0;
-  bool have_header_ = false;
+  bool have_header_ = false, eof_ = false;
   std::string header_;
 };

@@ -533,14 +533,16 @@ int main(int argc, char **argv) {
   std::vector<uint64_t> lens;
   uint64_t totalBases = 0;
   std::thread seqReader;
+  bool seqReadFailed = false;            // written by the reader thread, read after the join
   struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } seqJoiner{seqReader};
   if (G.seqName) {
     fprintf(stderr, "-- Opening sequences in '%s'.\n", G.seqName);
     auto sf = std::make_shared<SeqFile>(G.seqName);
     if (!sf->ok()) { fprintf(stderr, "ERROR: cannot open '%s'.\n", G.seqName); return 1; }
-    seqReader = std::thread([&recs, sf]() {
+    seqReader = std::thread([&recs, &seqReadFailed, sf]() {
       SeqRecord r;
       while (sf->next(r)) recs.push_back(std::move(r));
+      seqReadFailed = sf->finish() != 0;      // a decompressor that died mid-stream: the records read so far are NOT the file
     });
   }
   bool seqDone = false;
@@ -548,6 +550,10 @@ int main(int argc, char **argv) {
     if (seqDone) return;
     seqDone = true;
     if (seqReader.joinable()) seqReader.join();
+    if (seqReadFailed) {
+      fprintf(stderr, "ERROR: reading '%s' failed (read error, or the decompressor exited with an error: truncated or corrupt file?).\n", G.seqName);
+      exit(1);
+    }
     bases.resize(recs.size());
     lens.resize(recs.size());
     for (size_t i = 0; i < recs.size(); ++i) { bases[i] = recs[i].bases.data(); lens[i] = recs[i].bases.size(); totalBases += lens[i]; }
@@ -617,6 +623,13 @@ int main(int argc, char **argv) {
       fprintf(stderr, "--\n-- Memory needed: %.3f GB\n-- Memory limit:  %.3f GB%s\n--\n", mfx_index_estimate_gb(k, capacity),
               G.maxMemory, G.maxMemory > 0 ? "" : " (none)");
       ix = mfx_index_create(k, capacity, G.maxMemory, G.device);
+      if (!ix && !G.seqDBname && !seqDone && basesBound > 0) {
+        // the capacity came from the file's BOUND on its bases (a .gz of a human assembly sits near the 4 GiB step of that
+        // bound): read the file to the end, as the reference does before anything else, and size the table by the truth
+        fprintf(stderr, "-- The table sized by the bound on the bases of '%s' does not fit; reading the file first.\n", G.seqName);
+        finish_seq();
+        continue;
+      }
       if (!ix) {
         fprintf(stderr, "\n%s\n\n", mfx_last_error());
         return 1;
@@ -818,8 +831,9 @@ int main(int argc, char **argv) {
       lap("replicate index");
       fprintf(stderr, "-- Evaluating in %zu slots.\n", N);
       const auto runs = contig_partition(w, N);
-      std::vector<std::string> parts(N), errs(N), dbgs(N), vins(N);
+      std::vector<std::string> parts(N), errs(N), dbgs(N), vins(N), logs(N);
       std::vector<uint64_t> ncls(N, 0);
+      auto drop_parts = [&]() { for (size_t e = 0; e < N; ++e) { if (!parts[e].empty()) remove(parts[e].c_str()); if (!vins[e].empty()) remove(vins[e].c_str()); if (!logs[e].empty()) remove(logs[e].c_str()); } };
       std::vector<std::thread> th;
       for (size_t d = 0; d < N; ++d) {                                      // slot d's VCF: all header lines + the lines of its contigs
         char suf[48];
@@ -834,7 +848,7 @@ int main(int argc, char **argv) {
             if (ok && vtext[l.first + l.second - 1] != '\n') ok = fputc('\n', vf) != EOF;     // a last line without newline
           }
         if (vf && fclose(vf) != 0) ok = false;
-        if (!ok) { fprintf(stderr, "ERROR: cannot write '%s'.\n", vins[d].c_str()); for (size_t e = 0; e <= d; ++e) remove(vins[e].c_str()); return 1; }
+        if (!ok) { fprintf(stderr, "ERROR: cannot write '%s'.\n", vins[d].c_str()); drop_parts(); return 1; }
       }
       std::string().swap(vtext);
       for (size_t d = 0; d < N; ++d) {
@@ -843,21 +857,36 @@ int main(int argc, char **argv) {
         parts[d] = outName + suf;
         snprintf(suf, sizeof(suf), ".%02zu.debug.gz", d);
         dbgs[d] = std::string(G.outName) + suf;
+        // every slot logs to its own file; they are replayed on stderr in slot order once all slots are done (N slots
+        // writing PANIC / progress lines to one stderr interleave them mid-line)
+        logs[d] = parts[d] + ".log";
         th.emplace_back([&, d]() {
           mfx_host_threads_share((unsigned)N);                 // N slots side by side: each takes its share of the host threads
           mfx_variant_opts o = vo;
           o.debug_path = G.debug ? dbgs[d].c_str() : nullptr;
           const size_t lo = runs[d].first, hi = runs[d].second;
           if (mfx_variants_run(S.evs[d], vins[d].c_str(), names.data() + lo, bases.data() + lo, lens.data() + lo, (uint32_t)(hi - lo), &o, parts[d].c_str(),
-                               nullptr, &ncls[d]))
+                               logs[d].c_str(), &ncls[d]))
             errs[d] = mfx_last_error();
         });
       }
       for (auto &x : th) x.join();
-      for (size_t d = 0; d < N; ++d) remove(vins[d].c_str());
+      for (size_t d = 0; d < N; ++d) {
+        remove(vins[d].c_str());
+        vins[d].clear();
+        if (FILE *lf = fopen(logs[d].c_str(), "r")) {
+          if (N > 1) fprintf(stderr, "-- slot %zu (contigs %zu..%zu):\n", d, runs[d].first, runs[d].second);
+          char lb[1 << 14];
+          size_t n;
+          while ((n = fread(lb, 1, sizeof(lb), lf)) > 0) fwrite(lb, 1, n, stderr);
+          fclose(lf);
+        }
+        remove(logs[d].c_str());
+        logs[d].clear();
+      }
       S.release();
-      for (size_t d = 0; d < N; ++d) if (!errs[d].empty()) { fprintf(stderr, "ERROR: variant scoring (slot %zu): %s\n", d, errs[d].c_str()); return 1; }
-      if (!concat_parts(outName, parts, true)) { fprintf(stderr, "ERROR: cannot write '%s'.\n", outName.c_str()); return 1; }
+      for (size_t d = 0; d < N; ++d) if (!errs[d].empty()) { fprintf(stderr, "ERROR: variant scoring (slot %zu): %s\n", d, errs[d].c_str()); drop_parts(); return 1; }
+      if (!concat_parts(outName, parts, true)) { fprintf(stderr, "ERROR: cannot write '%s'.\n", outName.c_str()); drop_parts(); return 1; }
       for (uint64_t x : ncls) ncl += x;
     } else if (mfx_variants_run(ev, G.vcfName, names.data(), bases.data(), lens.data(), (uint32_t)recs.size(), &vo, outName.c_str(), nullptr, &ncl))
       DIE_MFX("variant scoring");

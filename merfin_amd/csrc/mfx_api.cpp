@@ -1804,6 +1804,9 @@ extern "C" int mfx_route_tiles(mfx_router *r, const mfx_seq *seq, uint64_t tile_
   uint64_t nvalid = 0;
   for (uint32_t i = 0; i < r->nranks; ++i) nvalid += h_dest_counts[i];
   MFX_HIP(mfx_k_route_gather(a, r->d_idx2, nvalid, d_keys_out, d_contigs_out, st));
+  // the groups are complete when this returns, as on the split path: callers hand them to OTHER streams right away
+  // (mfx_hist_run_sharded: the owners' peer copies), which nothing else orders behind this gather
+  MFX_HIP(hipStreamSynchronize(st));
   return MFX_OK;
 }
 

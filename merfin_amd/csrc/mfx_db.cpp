@@ -296,7 +296,7 @@ int read_meryl_data(const std::string &path, uint32_t file, const MerylIndex &mi
     }
     have_prev = true;
     prev_prefix = prefix;
-    if (mi.numBlocksBits < 64 && (prefix >> mi.prefixSize) != 0) {
+    if (mi.prefixSize < 64 && (prefix >> mi.prefixSize) != 0) {      // prefixSize >= 64: every 64-bit prefix fits (and the shift would be undefined)
       rc = mfx_fail(MFX_E_FORMAT, "'%s': block prefix %lx wider than %u bits", path.c_str(), (unsigned long)prefix, mi.prefixSize);
       break;
     }

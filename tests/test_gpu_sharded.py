@@ -206,11 +206,14 @@ def test_sharded_hist_two_processes_one_gpu(tmp_path):
     assert (tmp_path / "ok").read_text() == "1"
 
 
-@pytest.mark.parametrize("world,k,per", [(2, 21, 3), (4, 31, 2), (8, 31, 1000)])
-def test_sharded_hist_one_process(world, k, per):
+@pytest.mark.parametrize("world,k,per,sort", [(2, 21, 3, "0"), (4, 31, 2, "0"), (8, 31, 1000, "0"), (3, 21, 2, "1"), (8, 31, 1000, "1")])
+def test_sharded_hist_one_process(world, k, per, sort, monkeypatch):
     """mfx_hist_run_sharded: the whole sharded -hist (route -> peer copies to the owners -> evaluate -> sum) driven by one
-    process; the slots are shards of one table, here all on device 0.  `per` = tiles routed per round (several rounds / one)."""
+    process; the slots are shards of one table, here all on device 0.  `per` = tiles routed per round (several rounds / one).
+    sort = "1": the radix-sort router (what more than 16 owners use), whose last kernel -- the gather that writes the
+    groups -- must be complete before the owners' streams copy them."""
     import merfin_amd as m
+    monkeypatch.setenv("MFX_ROUTE_SORT", sort)
     peak = 17.3
     contigs, read, asm = synth.world(k=k, peak=peak, seed=91)
     p, g, ka, km = oracle_hist(k, peak, contigs, read, asm)
