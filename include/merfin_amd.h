@@ -49,6 +49,7 @@ extern "C" {
 #define MFX_E_IO         -6   /* file could not be read / parsed               */
 #define MFX_E_FORMAT     -7   /* file magic / version / layout not recognised  */
 #define MFX_E_NODEVICE   -8   /* no usable HIP device                          */
+#define MFX_E_NONCANON   -9   /* a sequence-only index met a non-canonical k-mer database */
 
 const char *mfx_last_error(void);
 int         mfx_last_error_code(void);   /* code of the last failing call on this thread */
@@ -131,6 +132,26 @@ int        mfx_index_commit(mfx_index *ix);
 
 typedef struct mfx_seq mfx_seq;
 
+/* SEQUENCE-ONLY index: the lookup object for the report types that only ever ask it for the k-mers of -sequence --
+ * -hist and -dump (merfin-histogram.C:54-64 and merfin-dump.C:44-61 call getK with the kmerIterator's fmer/rmer and
+ * nothing else).  It holds exactly the canonical k-mers CLAIMED from a sequence; every later add / load only UPDATES
+ * the counts of those k-mers and drops the rest (for a 30x human read set: half of the database, the sequencing-error
+ * k-mers, never gets a slot).  value() of a claimed k-mer is what the full tables answer; value() of any other k-mer
+ * is 0, so -completeness (merfin-completeness.C:48-144 walks the whole read database) and the variant modes (alternative
+ * paths, varMer.C:76-84) need the full index of mfx_index_create and are refused on this one.
+ *   ix = mfx_index_create_for_seq(k, <upper bound of the sequence's distinct k-mers: its bases>, max_gb, device);
+ *   mfx_index_count_asm(ix, seq, 0)      -- claims the k-mers AND counts them into the assembly side (no -seqmers), or
+ *   mfx_index_claim_seq(ix, seq, 0)      -- claims them only; the assembly counts then come from -seqmers
+ *   mfx_index_load_db / mfx_index_add_*  -- update-only from here on; a further claim is an error
+ * For k <= 21 the table takes a compact layout -- 8-byte slots {key 42 bits | readV 11 | asmV 11}, 16 per 128-byte line,
+ * exact counts of saturated fields in a side table -- built directly in that form; a human assembly takes 96 GB and
+ * -hist runs on 0.42 table lines per k-mer (MFX_SEQ_COMPACT=0 keeps the 16-byte slots).  The databases must be canonical
+ * (one slot per canonical k-mer cannot answer value(fmer) + value(rmer) of a non-canonical one): a load that meets a
+ * non-canonical k-mer fails with MFX_E_NONCANON and the caller builds the full index instead. */
+mfx_index *mfx_index_create_for_seq(int k, uint64_t capacity_kmers, double max_gb, int device);
+double     mfx_index_estimate_gb_for_seq(int k, uint64_t capacity_kmers);
+int        mfx_index_claim_seq(mfx_index *ix, const mfx_seq *seq, void *stream);
+
 /* Native replacement of the `meryl count k=.. <seq> output <seq>.meryl` child
  * process (merfin-globals.C:182-186): counts the canonical k-mers of every
  * contig of `seq` into the assembly side of the index, on the GPU. */
@@ -148,6 +169,9 @@ typedef struct {
   uint64_t capacity;       /* slots                                           */
   uint64_t distinct;       /* occupied slots                                  */
   uint64_t bytes;          /* device bytes held by the table                  */
+  int      seq_only;       /* 1: sequence-only index (mfx_index_create_for_seq) */
+  int      compact;        /* 1: 8-byte slots, 16 per line (sequence-only, k <= 21) */
+  uint64_t dropped;        /* adds a sequence-only index dropped (k-mers never claimed) */
 } mfx_index_info;
 int mfx_index_get_info(const mfx_index *ix, mfx_index_info *out);
 

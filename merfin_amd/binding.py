@@ -10,7 +10,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 TILE = 4096
 
-MFX_ERRORS = {-1: "INVAL", -2: "NOMEM", -3: "HIP", -4: "FULL", -5: "OVERFLOW", -6: "IO", -7: "FORMAT", -8: "NODEVICE"}
+MFX_ERRORS = {-1: "INVAL", -2: "NOMEM", -3: "HIP", -4: "FULL", -5: "OVERFLOW", -6: "IO", -7: "FORMAT", -8: "NODEVICE", -9: "NONCANON"}
+E_NONCANON = -9
 
 
 class MfxError(RuntimeError):
@@ -30,7 +31,8 @@ class _KP(C.Structure):
 
 class _Info(C.Structure):
     _fields_ = [("k", C.c_int), ("canonical", C.c_int), ("capacity", C.c_uint64),
-                ("distinct", C.c_uint64), ("bytes", C.c_uint64)]
+                ("distinct", C.c_uint64), ("bytes", C.c_uint64), ("seq_only", C.c_int), ("compact", C.c_int),
+                ("dropped", C.c_uint64)]
 
 
 class _DbInfo(C.Structure):
@@ -60,7 +62,7 @@ _lib = None
 SYMBOLS = [
     "mfx_last_error", "mfx_last_error_code", "mfx_version", "mfx_device_count",
     "mfx_index_create", "mfx_index_free", "mfx_index_estimate_gb", "mfx_index_add_read", "mfx_index_add_asm",
-    "mfx_index_count_asm", "mfx_index_value", "mfx_index_get_info", "mfx_index_export",
+    "mfx_index_count_asm", "mfx_index_create_for_seq", "mfx_index_estimate_gb_for_seq", "mfx_index_claim_seq", "mfx_index_value", "mfx_index_get_info", "mfx_index_export",
     "mfx_db_probe", "mfx_index_load_db", "mfx_index_load_db_multi", "mfx_db_write_flat", "mfx_index_save", "mfx_index_load",
     "mfx_index_set_fingerprint", "mfx_index_get_origin",
     "mfx_host_alloc", "mfx_host_free", "mfx_seq_create", "mfx_hist_run_streamed",
@@ -119,6 +121,11 @@ def load_library():
     L.mfx_index_add_read.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int]
     L.mfx_index_add_asm.argtypes = [vp, vp, vp, C.c_uint64, C.c_int]
     L.mfx_index_count_asm.argtypes = [vp, vp, vp]
+    L.mfx_index_create_for_seq.restype = vp
+    L.mfx_index_create_for_seq.argtypes = [C.c_int, C.c_uint64, C.c_double, C.c_int]
+    L.mfx_index_estimate_gb_for_seq.restype = C.c_double
+    L.mfx_index_estimate_gb_for_seq.argtypes = [C.c_int, C.c_uint64]
+    L.mfx_index_claim_seq.argtypes = [vp, vp, vp]
     L.mfx_index_value.argtypes = [vp, u64p, C.c_uint64, u32p, u32p]
     L.mfx_index_get_info.argtypes = [vp, C.POINTER(_Info)]
     L.mfx_index_export.argtypes = [vp, u64p, u32p, u32p, u64p]
@@ -303,11 +310,25 @@ def _ptr(x):
 class Index:
     """Joint read+assembly k-mer count table resident in HBM."""
 
-    def __init__(self, k, capacity_kmers, max_gb=0.0, device=0, _handle=None):
+    def __init__(self, k, capacity_kmers, max_gb=0.0, device=0, _handle=None, seq_only=False):
         L = load_library()
         self.k = k
         self.device = device
-        self.h = _handle if _handle is not None else _need(L.mfx_index_create(k, int(capacity_kmers), float(max_gb), device))
+        if _handle is not None:
+            self.h = _handle
+        elif seq_only:
+            self.h = _need(L.mfx_index_create_for_seq(k, int(capacity_kmers), float(max_gb), device))
+        else:
+            self.h = _need(L.mfx_index_create(k, int(capacity_kmers), float(max_gb), device))
+
+    @staticmethod
+    def for_seq(k, capacity_kmers, max_gb=0.0, device=0):
+        """a SEQUENCE-ONLY index (mfx_index_create_for_seq): claim the k-mers of the sequence first (count_asm or
+        claim_seq), then add / load -- those only update the claimed k-mers.  For -hist and -dump."""
+        return Index(k, capacity_kmers, max_gb=max_gb, device=device, seq_only=True)
+
+    def claim_seq(self, seqs, stream=None):
+        _check(load_library().mfx_index_claim_seq(self.h, seqs.h, C.c_void_p(stream or 0)))
 
     def save(self, path):
         """write the built table as a device-format image"""
@@ -399,7 +420,8 @@ class Index:
     def info(self):
         i = _Info()
         _check(load_library().mfx_index_get_info(self.h, C.byref(i)))
-        return {"k": i.k, "canonical": bool(i.canonical), "capacity": i.capacity, "distinct": i.distinct, "bytes": i.bytes}
+        return {"k": i.k, "canonical": bool(i.canonical), "capacity": i.capacity, "distinct": i.distinct, "bytes": i.bytes,
+                "seq_only": bool(i.seq_only), "compact": bool(i.compact), "dropped": i.dropped}
 
     def export(self, sort=True):
         """every stored (k-mer, readV, asmV), sorted by k-mer (sort=False: table order).  k > 31: k-mers are rows

@@ -141,11 +141,12 @@ static void fp_path(uint64_t &h, const char *path) {
     fp_mix(h, v, sizeof(v));
   }
 }
-static uint64_t input_fingerprint(const Globals &G) {
+static uint64_t input_fingerprint(const Globals &G, bool seqOnly) {
   uint64_t h = 0xcbf29ce484222325ULL;
   fp_path(h, G.readDBname);
   fp_path(h, G.seqDBname);
-  if (!G.seqDBname) fp_path(h, G.seqName);        // the assembly side is counted from -sequence
+  if (!G.seqDBname || seqOnly) fp_path(h, G.seqName);   // the assembly side is counted from -sequence / the table holds ITS k-mers only
+  if (seqOnly) fp_mix(h, "seq-only", 9);
   uint64_t v[2] = {G.minV, G.maxV};
   fp_mix(h, v, sizeof(v));
   return h ? h : 1;
@@ -564,11 +565,17 @@ int main(int argc, char **argv) {
   // Only compressed files are worth it: their decompression takes seconds per Gb on one core, while a plain file is parsed
   // at 2-5 GB/s and reading it under the build measurably slows the build's own readers (1 Gb: 1.8-3.0 s read first,
   // 2.4-3.2 s overlapped; MFX_CLI_OVERLAP=1 / 0 forces either).
+  // -hist and -dump ask the lookup tables for the k-mers of -sequence and nothing else (merfin-histogram.C:54-64,
+  // merfin-dump.C:44-61): they get a SEQUENCE-ONLY index -- the sequence's k-mers are claimed first, the databases only
+  // update those (half of a 30x human read database, the error k-mers, never gets a slot; k <= 21: 8-byte slots).  The
+  // other report types need the whole read database.  MFX_CLI_FULL_INDEX=1 builds the full tables for every type.
+  bool seqOnly = (G.reportType == OP_HIST || G.reportType == OP_DUMP) && !G.sharded && k <= 31 &&
+                 !(getenv("MFX_CLI_FULL_INDEX") && atoi(getenv("MFX_CLI_FULL_INDEX")));
   const char *ov = getenv("MFX_CLI_OVERLAP");
   const bool compressed = G.seqName && mfx_suffix_tool(G.seqName) != nullptr;
   const bool wantOverlap = ov ? atoi(ov) != 0 : compressed;
-  const uint64_t basesBound = (G.seqName && !G.seqDBname && wantOverlap) ? bases_upper_bound(G.seqName) : 0;
-  const bool deferSeq = G.seqName && !G.sharded && wantOverlap && (G.seqDBname || basesBound > 0);
+  const uint64_t basesBound = (G.seqName && !G.seqDBname && wantOverlap && !seqOnly) ? bases_upper_bound(G.seqName) : 0;
+  const bool deferSeq = G.seqName && !G.sharded && !seqOnly && wantOverlap && (G.seqDBname || basesBound > 0);
   if (!deferSeq) finish_seq();
   if (G.sharded) {
     if (G.devices.size() < 2) {
@@ -583,7 +590,7 @@ int main(int argc, char **argv) {
   // -hist on one device with the assembly k-mers coming from -seqmers: nothing needs the sequence in HBM before the
   // evaluation, so its upload is streamed under the -hist kernel (mfx_hist_run_streamed).  Otherwise the index build
   // counts the assembly k-mers from the packed sequence and it goes up first.
-  const bool streamHist = G.reportType == OP_HIST && G.seqDBname && G.devices.size() == 1;
+  const bool streamHist = G.reportType == OP_HIST && G.seqDBname && G.devices.size() == 1 && !seqOnly;
   auto make_seq = [&]() -> bool {
     if (!recs.empty() || G.seqName) {
       seq = streamHist ? mfx_seq_create(G.device, lens.data(), (uint32_t)recs.size())
@@ -595,7 +602,7 @@ int main(int argc, char **argv) {
   };
   if (!deferSeq && !make_seq()) DIE_MFX("uploading sequences");
   FILE *probe = G.indexName ? fopen(G.indexName, "rb") : nullptr;
-  const uint64_t fingerprint = G.indexName ? input_fingerprint(G) : 0;
+  const uint64_t fingerprint = G.indexName ? input_fingerprint(G, seqOnly) : 0;
   if (probe) {
     fclose(probe);
     fprintf(stderr, "-- Loading the index image '%s' (k-mer databases are not read).\n", G.indexName);
@@ -606,13 +613,50 @@ int main(int argc, char **argv) {
     if (info.k != k) { fprintf(stderr, "ERROR: the index image holds %d-mers but -readmers holds %d-mers.\n", info.k, k); return 1; }
     uint64_t fp = 0, imin = 0, imax = 0;
     if (mfx_index_get_origin(ix, &fp, &imin, &imax)) DIE_MFX("reading the index image");
-    if (fp != fingerprint || imin != G.minV || imax != G.maxV) {
+    if (fp != fingerprint || imin != G.minV || imax != G.maxV || (info.seq_only != 0) != seqOnly) {
       // the image was built from other inputs (a re-polished -sequence, another database, other -min/-max):
       // using it would give wrong asmK / readK with no diagnostic
       fprintf(stderr, "-- The index image '%s' was built from other inputs (%s); rebuilding it.\n", G.indexName,
               (imin != G.minV || imax != G.maxV) ? "-min/-max differ" : "a database or the sequence file changed");
       mfx_index_free(ix);
       ix = nullptr;
+    }
+  }
+  if (!ix && seqOnly) {
+    const uint64_t capacity = totalBases + 1024;                  // a sequence has at most one new k-mer per base
+    fprintf(stderr, "--\n-- Memory needed: %.3f GB\n-- Memory limit:  %.3f GB%s\n--\n", mfx_index_estimate_gb_for_seq(k, capacity),
+            G.maxMemory, G.maxMemory > 0 ? "" : " (none)");
+    ix = mfx_index_create_for_seq(k, capacity, G.maxMemory, G.device);
+    if (!ix) {
+      fprintf(stderr, "\n%s\n\n", mfx_last_error());
+      return 1;
+    }
+    int lrc = 0;
+    if (G.seqDBname) {
+      fprintf(stderr, "-- Claiming the %d-mers of '%s' on the GPU.\n", k, G.seqName);
+      if (mfx_index_claim_seq(ix, seq, nullptr)) DIE_MFX("claiming sequence k-mers");
+      fprintf(stderr, "-- Loading kmers from '%s' into lookup table.\n", G.seqDBname);
+      lrc = mfx_index_load_db(ix, G.seqDBname, 1, 0, ~0ull);
+      if (lrc && lrc != MFX_E_NONCANON) DIE_MFX("loading -seqmers");
+    } else {
+      // replaces `meryl count k=.. <seq> output <seq>.meryl` (merfin-globals.C:182-186)
+      fprintf(stderr, "-- No -seqmer given. Counting the %d-mers of '%s' on the GPU.\n", k, G.seqName);
+      if (mfx_index_count_asm(ix, seq, nullptr)) DIE_MFX("counting sequence k-mers");
+    }
+    if (!lrc) {
+      fprintf(stderr, "-- Loading kmers from '%s' into lookup table.\n", G.readDBname);
+      lrc = mfx_index_load_db(ix, G.readDBname, 0, G.minV, G.maxV);
+      if (lrc && lrc != MFX_E_NONCANON) DIE_MFX("loading -readmers");
+    }
+    if (lrc == MFX_E_NONCANON) {
+      // one slot per canonical k-mer cannot answer value(fmer) + value(rmer) of a non-canonical database
+      fprintf(stderr, "-- A k-mer database is not canonical; building the full lookup tables instead.\n");
+      mfx_index_free(ix);
+      ix = nullptr;
+      seqOnly = false;
+    } else if (G.indexName) {
+      fprintf(stderr, "-- Writing the index image '%s'.\n", G.indexName);
+      if (mfx_index_set_fingerprint(ix, fingerprint) || mfx_index_save(ix, G.indexName)) DIE_MFX("writing the index image");
     }
   }
   if (!ix) {

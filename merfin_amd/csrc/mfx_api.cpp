@@ -132,6 +132,10 @@ struct DevBuf {   // scoped device scratch
 // second probes (3 Gb -hist, w = 3: 0.7 -> 80, 0.6 -> 85, 0.52 -> 89.8, 0.45 -> 91.5, 0.40 -> 91.2 G k-mers/s: nothing is
 // gained below 0.45), and 288 GB of HBM are there to be used.
 constexpr double MFX_LF_MAX = 0.7, MFX_LF_MIN = 0.45, MFX_LF_HBM_SHARE = 0.75;
+// The compact layout of a sequence-only index (16 slots per line, buckets of w = 4 windows): 3 Gb -hist runs at 85.8 /
+// 95.7 / 98.9 / 101.1 G k-mers/s at load factors 0.40 / 0.30 / 0.25 / 0.20 (profiles/r02_compact_index.txt); 0.25 is
+// 96 GB for a human assembly -- less than half of what the full table of reads + assembly takes at its 0.45.
+constexpr double MFX_CLF_MAX = 0.5, MFX_CLF_MIN = 0.25;
 
 bool load_factor_fixed(double *lf) {
   const char *e = getenv("MFX_LOAD_FACTOR");
@@ -151,23 +155,40 @@ uint64_t lines_at(uint64_t capacity_kmers, double lf, uint32_t slots_line) {
 
 // smallest table this build makes for `capacity_kmers`
 uint64_t lines_for(uint64_t capacity_kmers, uint32_t slots_line = MFX_SLOTS_LINE) {
-  double lf = MFX_LF_MAX;
+  double lf = slots_line == MFX_CSLOTS_LINE ? MFX_CLF_MAX : MFX_LF_MAX;
   (void)load_factor_fixed(&lf);
   return lines_at(capacity_kmers, lf, slots_line);
 }
 
 // the table actually allocated: budget_bytes = what the table may take (0: unknown, use the smallest)
 uint64_t lines_auto(uint64_t capacity_kmers, double budget_bytes, uint32_t slots_line) {
+  const double lf_max = slots_line == MFX_CSLOTS_LINE ? MFX_CLF_MAX : MFX_LF_MAX, lf_min = slots_line == MFX_CSLOTS_LINE ? MFX_CLF_MIN : MFX_LF_MIN;
   double lf;
   if (load_factor_fixed(&lf)) return lines_at(capacity_kmers, lf, slots_line);
-  lf = MFX_LF_MAX;
+  lf = lf_max;
   if (budget_bytes > 0) {
     lf = (double)capacity_kmers * (MFX_ALIGN / slots_line) / budget_bytes;
-    lf = std::min(MFX_LF_MAX, std::max(MFX_LF_MIN, lf));
+    lf = std::min(lf_max, std::max(lf_min, lf));
   }
   uint64_t nl = lines_at(capacity_kmers, lf, slots_line);
-  if (nl >= (1ull << 32)) nl = std::max<uint64_t>(lines_at(capacity_kmers, MFX_LF_MAX, slots_line), (1ull << 32) - 16);
+  if (nl >= (1ull << 32)) nl = std::max<uint64_t>(lines_at(capacity_kmers, lf_max, slots_line), (1ull << 32) - 16);
   return nl;
+}
+
+// does a sequence-only index of k-mers of this size take the compact layout?  (MFX_SEQ_COMPACT=0: never -- A/B, tests)
+bool seq_compact(int k) {
+  const char *e = getenv("MFX_SEQ_COMPACT");
+  const char *hm = getenv("MFX_HOME_MODE");
+  return k <= MFX_MAX_K_COMPACT && !(e && atoi(e) == 0) && !(hm && strcmp(hm, "plain") == 0);
+}
+
+// Side table of a compact index (exact counts of the saturated fields, 16-byte slots at load factor <= 0.5): room for
+// 1/64 of the capacity -- a count saturates at 2047, i.e. beyond ~70 copies at 30x coverage -- and never fewer than
+// 1024 lines.  MFX_SIDE_DIV overrides the divisor; a side table that fills up fails the load with MFX_E_FULL.
+uint64_t side_lines_for(uint64_t capacity_kmers) {
+  const char *e = getenv("MFX_SIDE_DIV");
+  uint64_t div = e && atoll(e) > 0 ? (uint64_t)atoll(e) : 64;
+  return std::max<uint64_t>(1024, (capacity_kmers / div) * 2 / MFX_SLOTS_LINE + 1);
 }
 }  // namespace
 
@@ -199,6 +220,10 @@ mfx_table_view mfx_index::view() const {
   v.shard_rank = shard_rank;
   v.shard_n = shard_n;
   v.wide = wide() ? 1 : 0;
+  v.seq_only = seq_only ? 1 : 0;
+  v.compact = compact ? 1 : 0;
+  v.side = compact ? d_slots + nlines * MFX_SLOTS_LINE : nullptr;      // the side table follows the main lines
+  v.side_nlines = side_nlines;
   return v;
 }
 
@@ -206,12 +231,33 @@ extern "C" double mfx_index_estimate_gb(int k, uint64_t capacity_kmers) {
   return (double)lines_for(capacity_kmers, k > MFX_MAX_K_NARROW ? MFX_WSLOTS_LINE : MFX_SLOTS_LINE) * MFX_ALIGN / 1e9;
 }
 
+extern "C" double mfx_index_estimate_gb_for_seq(int k, uint64_t capacity_kmers) {
+  if (k > MFX_MAX_K_NARROW) return mfx_index_estimate_gb(k, capacity_kmers);
+  if (!seq_compact(k)) return (double)lines_for(capacity_kmers, MFX_SLOTS_LINE) * MFX_ALIGN / 1e9;
+  return (double)(lines_for(capacity_kmers, MFX_CSLOTS_LINE) + side_lines_for(capacity_kmers)) * MFX_ALIGN / 1e9;
+}
+
+static mfx_index *index_create(int k, uint64_t capacity_kmers, double max_gb, int device, bool seq_only);
+
 extern "C" mfx_index *mfx_index_create(int k, uint64_t capacity_kmers, double max_gb, int device) {
+  return index_create(k, capacity_kmers, max_gb, device, false);
+}
+
+extern "C" mfx_index *mfx_index_create_for_seq(int k, uint64_t capacity_kmers, double max_gb, int device) {
+  if (k > MFX_MAX_K_NARROW) {
+    mfx_fail(MFX_E_INVAL, "a sequence-only index handles k <= %d; this one would hold %d-mers (use mfx_index_create)", MFX_MAX_K_NARROW, k);
+    return nullptr;
+  }
+  return index_create(k, capacity_kmers, max_gb, device, true);
+}
+
+static mfx_index *index_create(int k, uint64_t capacity_kmers, double max_gb, int device, bool seq_only) {
   if (k < 1 || k > MFX_MAX_K) {
     mfx_fail(MFX_E_INVAL, "k=%d unsupported: k-mers hold 2k <= 128 bits, 1 <= k <= 64", k);
     return nullptr;
   }
-  const uint32_t slots_line = k > MFX_MAX_K_NARROW ? MFX_WSLOTS_LINE : MFX_SLOTS_LINE;
+  const bool compact = seq_only && seq_compact(k);
+  const uint32_t slots_line = k > MFX_MAX_K_NARROW ? MFX_WSLOTS_LINE : compact ? MFX_CSLOTS_LINE : MFX_SLOTS_LINE;
   if (mfx_device_count() <= device || device < 0) {
     mfx_fail(MFX_E_NODEVICE, "HIP device %d not available (%d visible); merfin_amd has no CPU path", device, mfx_device_count());
     return nullptr;
@@ -221,7 +267,7 @@ extern "C" mfx_index *mfx_index_create(int k, uint64_t capacity_kmers, double ma
              (unsigned long)capacity_kmers);
     return nullptr;
   }
-  double need = mfx_index_estimate_gb(k, capacity_kmers);
+  double need = seq_only ? mfx_index_estimate_gb_for_seq(k, capacity_kmers) : mfx_index_estimate_gb(k, capacity_kmers);
   if (max_gb > 0 && need > max_gb) {
     // merfin-globals.C:148-153
     mfx_fail(MFX_E_NOMEM, "Not enough memory to load databases.  Increase -memory. (need %.3f GB, limit %.3f GB)", need, max_gb);
@@ -233,11 +279,15 @@ extern "C" mfx_index *mfx_index_create(int k, uint64_t capacity_kmers, double ma
   ix->device = device;
   ix->k = k;
   ix->capacity_kmers = capacity_kmers;
+  ix->seq_only = seq_only;
+  ix->compact = compact;
+  ix->side_nlines = compact ? side_lines_for(capacity_kmers) : 0;
   {
     size_t free_b = 0, total_b = 0;
     double budget = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = MFX_LF_HBM_SHARE * (double)free_b;
     if (max_gb > 0) budget = budget > 0 ? std::min(budget, max_gb * 1e9) : max_gb * 1e9;
+    if (budget > 0) budget = std::max(1.0, budget - (double)ix->side_nlines * MFX_ALIGN);
     ix->nlines = lines_auto(capacity_kmers, budget, slots_line);
   }
   if (ix->nlines >= (1ull << 32)) {        // line numbers are 32-bit on the device (550 GB of table: beyond one GPU anyway)
@@ -253,16 +303,17 @@ extern "C" mfx_index *mfx_index_create(int k, uint64_t capacity_kmers, double ma
     const char *hm = getenv("MFX_HOME_MODE");
     bool mz = hm ? (strcmp(hm, "plain") != 0) : true;
     const char *ws = getenv("MFX_MZ_W");
-    int w = ws ? atoi(ws) : MFX_MZ_W_DEFAULT;
-    if (w < 1 || w > 5) w = MFX_MZ_W_DEFAULT;
+    const int w_default = compact ? MFX_MZ_W_COMPACT : MFX_MZ_W_DEFAULT;
+    int w = ws ? atoi(ws) : w_default;
+    if (w < 1 || w > 5) w = w_default;
     ix->mz_w = (mz && !ix->wide()) ? std::min(w, k) : 0;    // 128-bit k-mers: plain hashing (mfx_wide.hip)
   }
-  hipError_t e = hipMalloc((void **)&ix->d_slots, ix->nlines * MFX_ALIGN);
+  hipError_t e = hipMalloc((void **)&ix->d_slots, ix->total_lines() * MFX_ALIGN);
   if (e != hipSuccess && ix->nlines > lines_for(capacity_kmers, slots_line)) {
     // the roomier table did not fit after all (fragmentation, another process): fall back to the smallest one
     (void)hipGetLastError();
     ix->nlines = lines_for(capacity_kmers, slots_line);
-    e = hipMalloc((void **)&ix->d_slots, ix->nlines * MFX_ALIGN);
+    e = hipMalloc((void **)&ix->d_slots, ix->total_lines() * MFX_ALIGN);
   }
   if (e != hipSuccess) {
     mfx_fail(MFX_E_NOMEM, "hipMalloc of %.3f GB for the k-mer table failed: %s", need, hipGetErrorString(e));
@@ -272,7 +323,9 @@ extern "C" mfx_index *mfx_index_create(int k, uint64_t capacity_kmers, double ma
   if (hipMalloc((void **)&ix->d_meta, 4 * sizeof(uint64_t)) != hipSuccess ||
       hipMemset(ix->d_meta, 0, 4 * sizeof(uint64_t)) != hipSuccess ||
       (ix->wide() ? hipMemsetAsync(ix->d_slots, 0, ix->nlines * MFX_ALIGN, nullptr)           // state 0 = empty
-                  : mfx_k_table_init(ix->d_slots, ix->nlines * MFX_SLOTS_LINE, nullptr)) != hipSuccess ||
+       : ix->compact ? hipMemsetAsync(ix->d_slots, 0xff, ix->nlines * MFX_ALIGN, nullptr)      // 8-byte slots: the all-ones word is empty
+                     : mfx_k_table_init(ix->d_slots, ix->nlines * MFX_SLOTS_LINE, nullptr)) != hipSuccess ||
+      (ix->compact && mfx_k_table_init(ix->d_slots + ix->nlines * MFX_SLOTS_LINE, ix->side_nlines * MFX_SLOTS_LINE, nullptr) != hipSuccess) ||
       hipDeviceSynchronize() != hipSuccess) {
     mfx_fail(MFX_E_HIP, "k-mer table initialisation failed: %s", hipGetErrorString(hipGetLastError()));
     mfx_index_free(ix);
@@ -286,7 +339,6 @@ extern "C" void mfx_index_free(mfx_index *ix) {
   DevGuard g(ix->device);
   mfx_index_ingest_release(ix);
   if (ix->d_slots) (void)hipFree(ix->d_slots);
-  if (ix->d_compact) (void)hipFree(ix->d_compact);
   if (ix->d_meta) (void)hipFree(ix->d_meta);
   delete ix;
 }
@@ -301,6 +353,9 @@ static int index_check(mfx_index *ix) {
   if ((double)meta[0] > 0.92 * (double)(ix->nlines * ix->slots_per_line()))
     return mfx_fail(MFX_E_FULL, "k-mer table over-full: %lu k-mers in %lu slots; create the index with a larger capacity",
                     (unsigned long)meta[0], (unsigned long)(ix->nlines * ix->slots_per_line()));
+  if (ix->seq_only && meta[1] != 0)
+    return mfx_fail(MFX_E_NONCANON, "the database holds %lu non-canonical k-mers: a sequence-only index keeps one slot per canonical k-mer of the "
+                    "sequence and cannot answer value(fmer) + value(rmer) for it; build a full index (mfx_index_create)", (unsigned long)meta[1]);
   return MFX_OK;
 }
 
@@ -372,6 +427,7 @@ static int index_ingest_multi(mfx_index *const *ixs, uint32_t nix, uint64_t n, i
   std::vector<mfx_ingest *> gs(nix, nullptr);
   for (uint32_t i = 0; i < nix; ++i) {
     DevGuard dg(ixs[i]->device);
+    ixs[i]->frozen = true;                                  // a sequence-only index takes no more claims once counts arrive
     gs[i] = ingest_get(ixs[i], n);
     if (!gs[i]) return mfx_fail(MFX_E_NOMEM, "mfx_index_add: staging allocation failed");
   }
@@ -503,6 +559,7 @@ static int index_add(mfx_index *ix, const uint64_t *kmers, const uint32_t *value
     return ix->wide() ? mfx_kw_table_add(ix->view(), dk, dv, m, side, ix->d_meta, s) : mfx_k_table_add(ix->view(), dk, dv, m, side, ix->d_meta, s);
   };
   if (on_device) {
+    ix->frozen = true;
     MFX_HIP(table_add(kmers, values, n, nullptr));
     MFX_HIP(hipDeviceSynchronize());
     return index_check(ix);
@@ -529,9 +586,12 @@ extern "C" int mfx_index_add_asm(mfx_index *ix, const uint64_t *kmers, const uin
   return index_add(ix, kmers, values, n, 1, on_device);
 }
 
-extern "C" int mfx_index_count_asm(mfx_index *ix, const mfx_seq *seq, void *stream) {
-  if (!ix || !seq) return mfx_fail(MFX_E_INVAL, "mfx_index_count_asm: null argument");
+static int index_count(mfx_index *ix, const mfx_seq *seq, int count, void *stream, const char *who) {
+  if (!ix || !seq) return mfx_fail(MFX_E_INVAL, "%s: null argument", who);
   if (ix->device != seq->device) return mfx_fail(MFX_E_INVAL, "index and sequence live on different devices");
+  if (ix->seq_only && ix->frozen)
+    return mfx_fail(MFX_E_INVAL, "%s: this sequence-only index already took counts; its k-mers must all be claimed before the first add / load "
+                    "(a k-mer claimed now would have missed them)", who);
   if (int erc = mfx_seq_ensure_ascii(seq)) return erc;
   DevGuard g(ix->device);
   mfx_count_args a;
@@ -543,9 +603,19 @@ extern "C" int mfx_index_count_asm(mfx_index *ix, const mfx_seq *seq, void *stre
   a.ncontigs = seq->ncontigs;
   a.ntiles = seq->ntiles;
   a.meta = ix->d_meta;
+  a.count = count;
   MFX_HIP(ix->wide() ? mfx_kw_count(a, (hipStream_t)stream) : mfx_k_count(a, (hipStream_t)stream));
   MFX_HIP(hipStreamSynchronize((hipStream_t)stream));
   return index_check(ix);
+}
+
+extern "C" int mfx_index_count_asm(mfx_index *ix, const mfx_seq *seq, void *stream) {
+  return index_count(ix, seq, 1, stream, "mfx_index_count_asm");
+}
+
+extern "C" int mfx_index_claim_seq(mfx_index *ix, const mfx_seq *seq, void *stream) {
+  if (ix && !ix->seq_only) return mfx_fail(MFX_E_INVAL, "mfx_index_claim_seq: not a sequence-only index (mfx_index_create_for_seq)");
+  return index_count(ix, seq, 0, stream, "mfx_index_claim_seq");
 }
 
 extern "C" int mfx_index_value(const mfx_index *ix, const uint64_t *kmers, uint64_t n, uint32_t *readV, uint32_t *asmV) {
@@ -572,7 +642,10 @@ extern "C" int mfx_index_get_info(const mfx_index *ix, mfx_index_info *out) {
   out->canonical = (meta[1] == 0) ? 1 : 0;
   out->capacity = ix->nlines * ix->slots_per_line();
   out->distinct = meta[0];
-  out->bytes = ix->nlines * MFX_ALIGN;
+  out->bytes = ix->total_lines() * MFX_ALIGN;
+  out->seq_only = ix->seq_only ? 1 : 0;
+  out->compact = ix->compact ? 1 : 0;
+  out->dropped = meta[3];
   return MFX_OK;
 }
 
@@ -799,7 +872,7 @@ extern "C" mfx_eval *mfx_eval_create(const mfx_index *ix, const mfx_kparams *kp,
     return nullptr;
   }
   const char *e = getenv("MFX_BLOCKS_PER_CU");
-  int bpc = e ? atoi(e) : mfx_k_hist_resident_blocks();   // persistent blocks: as many as are resident at once
+  int bpc = e ? atoi(e) : mfx_k_hist_resident_blocks(ix->compact ? 1 : 0);   // persistent blocks: as many as are resident at once
   if (bpc < 1) bpc = 1;
   ev->grid = prop.multiProcessorCount * bpc;
   size_t np = ev->n_prob ? ev->n_prob : 1;
@@ -902,67 +975,6 @@ static int ensure_tile_partials(mfx_eval *ev, uint64_t ntiles) {
 // chunk_of_total  > 0: one chunk of a streamed evaluation over `chunk_of_total` tiles in all: the values land at
 // their tile's place in ev->d_tile_partials (sized by the caller) and are summed ONCE after the last chunk, so
 // koverCpy is bit-identical to a single launch over the whole range, however the upload was cut.
-// The compact -hist index of a table (mfx_kernels.hip): the assembly's k-mers in 8-byte slots, 16 per line, minimizer
-// buckets of w = 4 windows.  OPT-IN (MFX_COMPACT=1): 3 Gb -hist runs at 99-101 G k-mers/s on it instead of 91 G, but
-// building it is a pass over the table plus 3 G inserts (~0.4 s) and 96-120 GB of HBM -- a single -hist evaluation
-// (33 ms) never earns that back, only a caller that evaluates the same index many times does.  Built on first use for
-// the table's current version; any failure (no memory, a bucket beyond the probe limit) leaves the standard table in charge.
-static mfx_table_view index_compact_view(const mfx_index *cix) {
-  mfx_table_view none = {nullptr, 0, 0, 0, 0, 0, 0, 1, 0};
-  const char *en = getenv("MFX_COMPACT");
-  if (!(en && atoi(en)) || cix->wide() || cix->k > 21 || cix->mz_w == 0 || cix->shard_n != 1) return none;
-  mfx_index *ix = const_cast<mfx_index *>(cix);
-  if (ix->compact_unusable && ix->compact_version == ix->version) return none;
-  if (ix->compact_version != ix->version || !ix->d_compact) {
-    if (ix->d_compact) { (void)hipFree(ix->d_compact); ix->d_compact = nullptr; }
-    ix->compact_version = ix->version;
-    ix->compact_unusable = true;
-    uint64_t meta[4];
-    if (hipMemcpy(meta, ix->d_meta, sizeof(meta), hipMemcpyDeviceToHost) != hipSuccess) return none;
-    const char *lfe = getenv("MFX_COMPACT_LF");
-    double lf = lfe ? atof(lfe) : 0.25;
-    if (!(lf > 0.1 && lf <= 0.9)) lf = 0.25;
-    // only the k-mers with an assembly count go in: count them (a pass over the table)
-    uint64_t n_asm = meta[0];
-    {
-      uint64_t *d_n = nullptr;
-      if (hipMalloc((void **)&d_n, 8) == hipSuccess && hipMemset(d_n, 0, 8) == hipSuccess &&
-          mfx_k_count_asm_slots(ix->view(), d_n, nullptr) == hipSuccess)
-        (void)hipMemcpy(&n_asm, d_n, 8, hipMemcpyDeviceToHost);
-      if (d_n) (void)hipFree(d_n);
-      (void)hipGetLastError();
-    }
-    uint64_t nl = (uint64_t)((double)(n_asm + 1024) / (16.0 * lf)) + 64;
-    if (nl >= (1ull << 32)) return none;
-    {
-      size_t free_b = 0, total_b = 0;
-      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (double)free_b < (double)nl * MFX_ALIGN + 4e9) { (void)hipGetLastError(); return none; }
-    }
-    if (hipMalloc((void **)&ix->d_compact, nl * MFX_ALIGN) != hipSuccess) { (void)hipGetLastError(); ix->d_compact = nullptr; return none; }
-    uint64_t *d_fail = nullptr;
-    bool ok = hipMemset(ix->d_compact, 0xff, nl * MFX_ALIGN) == hipSuccess && hipMalloc((void **)&d_fail, 8) == hipSuccess &&
-              hipMemset(d_fail, 0, 8) == hipSuccess;
-    mfx_table_view c = ix->view();
-    c.slots = reinterpret_cast<mfx_slot *>(ix->d_compact);
-    c.nlines = nl;
-    const char *we = getenv("MFX_COMPACT_W");
-    c.mz_w = std::min(ix->k, we && atoi(we) >= 1 && atoi(we) <= 5 ? atoi(we) : 4);
-    uint64_t fail = 1;
-    ok = ok && mfx_k_compact_build(ix->view(), c, d_fail, nullptr) == hipSuccess &&
-         hipMemcpy(&fail, d_fail, 8, hipMemcpyDeviceToHost) == hipSuccess && fail == 0;
-    if (d_fail) (void)hipFree(d_fail);
-    if (!ok) { (void)hipGetLastError(); (void)hipFree(ix->d_compact); ix->d_compact = nullptr; return none; }
-    ix->compact_lines = nl;
-    ix->compact_unusable = false;
-  }
-  mfx_table_view c = ix->view();
-  c.slots = reinterpret_cast<mfx_slot *>(ix->d_compact);
-  c.nlines = ix->compact_lines;
-  const char *we = getenv("MFX_COMPACT_W");
-  c.mz_w = std::min(ix->k, we && atoi(we) >= 1 && atoi(we) <= 5 ? atoi(we) : 4);
-  return c;
-}
-
 static int hist_launch(mfx_eval *ev, const mfx_seq *seq, uint64_t tile_begin, uint64_t tile_end, uint32_t part_rank, uint32_t part_n,
                        uint32_t part_shift, uint64_t *d_counts, double *d_kover, void *stream, uint64_t chunk_of_total = 0, int ctr_slot = 0) {
   uint64_t ntl = tile_end - tile_begin;
@@ -991,7 +1003,6 @@ static int hist_launch(mfx_eval *ev, const mfx_seq *seq, uint64_t tile_begin, ui
   a.canonical = canon;
   a.bases = seq->d_bases;
   if (seq->bases_stale) { a.codes = seq->d_codes; a.valid = seq->d_valid; }      // a packed upload: the planes are the sequence
-  if (canon) a.t2 = index_compact_view(ev->ix);
   a.contig_off = seq->d_contig_off;
   a.contig_len = seq->d_contig_len;
   a.tile_start = seq->d_tile_start;
@@ -1520,7 +1531,7 @@ extern "C" mfx_index *mfx_index_replicate(const mfx_index *src, int device) {
   if (mfx_index_image_header(src, hdr) != MFX_OK) return nullptr;
   mfx_index *dst = mfx_index_create_from_header(hdr, 0.0, device);
   if (!dst) return nullptr;
-  const uint64_t bytes = src->nlines * MFX_ALIGN;
+  const uint64_t bytes = src->total_lines() * MFX_ALIGN;
   hipError_t e = hipSuccess;
   {
     DevGuard g(device);
@@ -1676,6 +1687,7 @@ extern "C" int mfx_hist_report(const mfx_hist_result *r, int k, const char *hist
 extern "C" int mfx_index_set_shard(mfx_index *ix, uint32_t rank, uint32_t nranks) {
   if (!ix || nranks == 0 || rank >= nranks || nranks > 254)
     return mfx_fail(MFX_E_INVAL, "mfx_index_set_shard: need rank < nranks <= 254");
+  if (ix->seq_only && nranks > 1) return mfx_fail(MFX_E_INVAL, "a sequence-only index cannot be sharded (it is the small index: shard a full one)");
   if (ix->wide() && nranks > 1) return mfx_fail(MFX_E_INVAL, "a sharded index handles k <= 31; this index holds %d-mers", ix->k);
   DevGuard g(ix->device);
   uint64_t meta[4];
@@ -1706,6 +1718,10 @@ int mfx_sort_by_owner(void *tmp, size_t &tmp_bytes, const uint8_t *kin, uint8_t 
 extern "C" mfx_router *mfx_router_create(const mfx_index *ix, uint32_t nranks, uint32_t max_tiles) {
   if (ix && ix->wide()) {
     mfx_fail(MFX_E_INVAL, "mfx_router_create: a sharded index handles k <= 31; this index holds %d-mers", ix->k);
+    return nullptr;
+  }
+  if (ix && ix->seq_only) {
+    mfx_fail(MFX_E_INVAL, "mfx_router_create: a sequence-only index cannot be sharded");
     return nullptr;
   }
   if (!ix || nranks == 0 || nranks > 254 || max_tiles == 0 || (uint64_t)max_tiles * MFX_TILE >= (1ull << 31)) {
@@ -1814,6 +1830,7 @@ extern "C" int mfx_hist_keys_launch(mfx_eval *ev, const uint64_t *d_keys, const 
                                     uint32_t ncontigs, uint64_t *d_counts, double *d_kover, void *stream) {
   if (!ev || !d_counts || !d_kover || (n && (!d_keys || !d_contigs))) return mfx_fail(MFX_E_INVAL, "mfx_hist_keys_launch: null argument");
   if (ev->ix->wide()) return mfx_fail(MFX_E_INVAL, "mfx_hist_keys_launch: a sharded index handles k <= 31");
+  if (ev->ix->seq_only) return mfx_fail(MFX_E_INVAL, "mfx_hist_keys_launch: a sequence-only index holds the k-mers of one sequence, the sharded path needs a full (sharded) one; build a full index (mfx_index_create)");
   DevGuard g(ev->device);
   mfx_hist_keys_args a;
   a.t = ev->ix->view();
@@ -2254,6 +2271,7 @@ extern "C" int mfx_dump_contig_sharded(mfx_eval *const *evs, const mfx_seq *cons
 // ---------------------------------------------------------------------------
 extern "C" int mfx_completeness_pieces(mfx_eval *ev, double *total64, double *undrcpy64) {
   if (!ev || !total64 || !undrcpy64) return mfx_fail(MFX_E_INVAL, "mfx_completeness_pieces: null argument");
+  if (ev->ix->seq_only) return mfx_fail(MFX_E_INVAL, "mfx_completeness: a sequence-only index holds the k-mers of one sequence, -completeness needs every read k-mer; build a full index (mfx_index_create)");
   DevGuard g(ev->device);
   DevBuf<double> dp;
   MFX_HIP(dp.alloc(128));

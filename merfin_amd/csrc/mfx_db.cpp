@@ -699,6 +699,8 @@ struct IndexImageHeader {
   uint32_t slot_bytes, line_slots;
   uint32_t filter_set, layout;   // layout = MFX_LAYOUT_VERSION of the build that wrote the image
   uint64_t fingerprint;          // caller's digest of the inputs the table was built from (mfx_index_set_fingerprint)
+  uint64_t side_nlines;          // compact layout: lines of the side table that follow the nlines main lines
+  uint32_t flags, reserved;      // bit 0: sequence-only index, bit 1: compact layout, bit 2: frozen (counts were added)
 };
 
 static_assert(sizeof(IndexImageHeader) <= MFX_INDEX_HEADER_BYTES, "index image header outgrew its public size");
@@ -715,23 +717,28 @@ static int fill_header(const mfx_index *ix, IndexImageHeader &h) {
   h.filter_set = ix->filter_set ? 1u : 0u;
   h.layout = MFX_LAYOUT_VERSION;
   h.fingerprint = ix->fingerprint;
+  h.side_nlines = ix->side_nlines;
+  h.flags = (ix->seq_only ? 1u : 0u) | (ix->compact ? 2u : 0u) | (ix->frozen ? 4u : 0u);
   if (hipMemcpy(h.meta, ix->d_meta, sizeof(h.meta), hipMemcpyDeviceToHost) != hipSuccess) return mfx_fail(MFX_E_HIP, "reading index metadata failed");
   return MFX_OK;
 }
 
 static bool header_ok(const IndexImageHeader &h) {
-  const bool wide = h.k > (uint32_t)MFX_MAX_K_NARROW;
-  return memcmp(h.magic, "MFXINDX2", 8) == 0 && h.slot_bytes == (wide ? sizeof(mfx_wslot) : sizeof(mfx_slot)) &&
-         h.line_slots == (wide ? MFX_WSLOTS_LINE : MFX_SLOTS_LINE) && h.k >= 1 && h.k <= (uint32_t)MFX_MAX_K && h.nlines != 0 &&
-         h.nlines < (1ull << 32) && h.layout == MFX_LAYOUT_VERSION;
+  const bool wide = h.k > (uint32_t)MFX_MAX_K_NARROW, compact = (h.flags & 2u) != 0;
+  if (compact && (!(h.flags & 1u) || wide || h.k > (uint32_t)MFX_MAX_K_COMPACT || h.side_nlines == 0)) return false;
+  if (!compact && h.side_nlines != 0) return false;
+  const uint32_t line_slots = wide ? MFX_WSLOTS_LINE : compact ? MFX_CSLOTS_LINE : MFX_SLOTS_LINE;
+  return memcmp(h.magic, "MFXINDX2", 8) == 0 && h.slot_bytes == MFX_ALIGN / line_slots && h.line_slots == line_slots && h.k >= 1 &&
+         h.k <= (uint32_t)MFX_MAX_K && h.nlines != 0 && h.nlines < (1ull << 32) && h.side_nlines < (1ull << 32) && h.layout == MFX_LAYOUT_VERSION;
 }
 
 // an index of exactly the header's geometry; its lines are allocated but hold nothing yet
 static mfx_index *index_from_header(const IndexImageHeader &h, double max_gb, int device) {
   mfx_index *ix = mfx_index_create((int)h.k, 1, 0.0, device);
   if (!ix) return nullptr;
-  if (max_gb > 0 && (double)h.nlines * MFX_ALIGN / 1e9 > max_gb) {
-    mfx_fail(MFX_E_NOMEM, "Not enough memory to load databases.  Increase -memory. (need %.3f GB, limit %.3f GB)", (double)h.nlines * MFX_ALIGN / 1e9, max_gb);
+  const uint64_t total_lines = h.nlines + h.side_nlines;
+  if (max_gb > 0 && (double)total_lines * MFX_ALIGN / 1e9 > max_gb) {
+    mfx_fail(MFX_E_NOMEM, "Not enough memory to load databases.  Increase -memory. (need %.3f GB, limit %.3f GB)", (double)total_lines * MFX_ALIGN / 1e9, max_gb);
     mfx_index_free(ix);
     return nullptr;
   }
@@ -744,9 +751,11 @@ static mfx_index *index_from_header(const IndexImageHeader &h, double max_gb, in
   ix->shard_rank = h.shard_rank; ix->shard_n = h.shard_n ? h.shard_n : 1;
   ix->minV = h.minV; ix->maxV = h.maxV; ix->filter_set = h.filter_set != 0;
   ix->fingerprint = h.fingerprint;
-  if (hipMalloc((void **)&ix->d_slots, h.nlines * MFX_ALIGN) != hipSuccess ||
+  ix->side_nlines = h.side_nlines;
+  ix->seq_only = (h.flags & 1u) != 0; ix->compact = (h.flags & 2u) != 0; ix->frozen = (h.flags & 4u) != 0;
+  if (hipMalloc((void **)&ix->d_slots, total_lines * MFX_ALIGN) != hipSuccess ||
       hipMemcpy(ix->d_meta, h.meta, sizeof(h.meta), hipMemcpyHostToDevice) != hipSuccess) {
-    mfx_fail(MFX_E_NOMEM, "cannot allocate %.3f GB for the index image on device %d", (double)h.nlines * MFX_ALIGN / 1e9, device);
+    mfx_fail(MFX_E_NOMEM, "cannot allocate %.3f GB for the index image on device %d", (double)total_lines * MFX_ALIGN / 1e9, device);
     mfx_index_free(ix);
     return nullptr;
   }
@@ -774,7 +783,7 @@ extern "C" mfx_index *mfx_index_create_from_header(const void *hdr, double max_g
 extern "C" int mfx_index_device_image(mfx_index *ix, void **d_lines, uint64_t *line_bytes, void **d_meta, uint64_t *meta_bytes) {
   if (!ix || !d_lines || !line_bytes || !d_meta || !meta_bytes) return mfx_fail(MFX_E_INVAL, "mfx_index_device_image: null argument");
   *d_lines = ix->d_slots;
-  *line_bytes = ix->nlines * MFX_ALIGN;
+  *line_bytes = ix->total_lines() * MFX_ALIGN;
   *d_meta = ix->d_meta;
   *meta_bytes = 4 * sizeof(uint64_t);
   return MFX_OK;
@@ -810,7 +819,7 @@ extern "C" int mfx_index_save(const mfx_index *ix, const char *path) {
   if (fwrite(&h, sizeof(h), 1, f) != 1) rc = mfx_fail(MFX_E_IO, "short write to '%s'", path);
   const size_t CH = 256ull << 20;
   std::vector<char> buf(rc == MFX_OK ? CH : 1);
-  const uint64_t total = ix->nlines * MFX_ALIGN;
+  const uint64_t total = ix->total_lines() * MFX_ALIGN;
   for (uint64_t o = 0; o < total && rc == MFX_OK; o += CH) {
     size_t m = (size_t)std::min<uint64_t>(CH, total - o);
     if (hipMemcpy(buf.data(), (const char *)ix->d_slots + o, m, hipMemcpyDeviceToHost) != hipSuccess) rc = mfx_fail(MFX_E_HIP, "D2H copy of the table failed");
@@ -835,7 +844,7 @@ extern "C" mfx_index *mfx_index_load(const char *path, double max_gb, int device
   bool ok = true;
   const size_t CH = 256ull << 20;
   std::vector<char> buf(ok ? CH : 1);
-  const uint64_t total = h.nlines * MFX_ALIGN;
+  const uint64_t total = (h.nlines + h.side_nlines) * MFX_ALIGN;
   for (uint64_t o = 0; o < total && ok; o += CH) {
     size_t m = (size_t)std::min<uint64_t>(CH, total - o);
     ok = fread(buf.data(), 1, m, f) == m && hipMemcpy((char *)ix->d_slots + o, buf.data(), m, hipMemcpyHostToDevice) == hipSuccess;

@@ -72,14 +72,26 @@ struct mfx_wslot {
 constexpr uint32_t MFX_WSLOTS_LINE = 4;
 constexpr int      MFX_MAX_K_NARROW = 31, MFX_MAX_K = 64;
 
+// Sequence-only index, compact layout (k <= 21, see mfx_kernels.hip): 8-byte slots, 16 per 128-byte line --
+// {key: 42 bits | readV: 11 | asmV: 11}; a count field of MFX_CSAT means "saturated: the exact count of that side is in
+// the side table" (standard 16-byte slots, plain hashing, right behind the main lines in the same allocation).
+constexpr uint32_t MFX_CSLOTS_LINE = 16;
+constexpr uint32_t MFX_CSAT = 2047u;
+constexpr int      MFX_MAX_K_COMPACT = 21;
+constexpr int      MFX_MZ_W_COMPACT = 4;          // minimizer windows of the compact layout (MFX_MZ_W overrides)
+
 struct mfx_table_view {
   mfx_slot *slots;
-  uint64_t  nlines;             // 128-byte lines; slots = 8 * nlines
+  uint64_t  nlines;             // 128-byte lines; slots = 8 * nlines (16 * nlines in the compact layout)
   uint32_t  minV, maxV;         // read-count filter (merfin.C:199-200), clamped to uint32
   int       k;
   int       mz_w;               // minimizer windows (0 = plain k-mer hashing; else m = k - mz_w + 1)
   uint32_t  shard_rank, shard_n;  // sharded index: this table keeps only the k-mers owned by shard_rank of shard_n
   int       wide;               // k > 31: slots are mfx_wslot (mfx_wide.hip kernels)
+  int       seq_only;           // the key set is the k-mers claimed from a sequence: adds update, they never claim
+  int       compact;            // 8-byte slots (above); implies seq_only
+  mfx_slot *side;               // compact: the side table of saturated counts
+  uint64_t  side_nlines;
 };
 
 struct mfx_ingest;              // pinned staging lanes of the host -> table pipeline (mfx_api.cpp)
@@ -91,19 +103,24 @@ struct mfx_index {
   uint64_t  capacity_kmers = 0;
   uint64_t  nlines = 0;
   mfx_slot *d_slots = nullptr;
-  uint64_t *d_meta = nullptr;   // [0] distinct  [1] non-canonical inserts  [2] probe-limit failures
+  uint64_t *d_meta = nullptr;   // [0] distinct  [1] non-canonical inserts  [2] probe-limit failures  [3] adds dropped by a sequence-only index
   uint64_t  minV = 0, maxV = ~0ull;
   bool      filter_set = false;
   int       mz_w = 0;
   uint32_t  shard_rank = 0, shard_n = 1;
   uint64_t  version = 0;        // bumped by every insert batch; lets evaluators cache index-derived facts
   uint64_t  fingerprint = 0;    // caller-supplied digest of the inputs (travels with the index image)
-  // compact -hist index (k <= 21, canonical database; mfx_kernels.hip): built from the table on first use per version
-  uint64_t *d_compact = nullptr;
-  uint64_t  compact_lines = 0, compact_version = ~0ull;
-  bool      compact_unusable = false;
+  // Sequence-only index (mfx_index_create_for_seq): holds exactly the k-mers claimed from a sequence
+  // (mfx_index_claim_seq / mfx_index_count_asm); later adds and loads only UPDATE the counts of those k-mers, a k-mer
+  // that was not claimed is dropped.  What -hist and -dump ask the lookup tables is the k-mers of -sequence and nothing
+  // else (merfin-histogram.C:54-64, merfin-dump.C:44-61), so their answers are those of the full tables.
+  bool      seq_only = false;
+  bool      compact = false;    // seq_only, k <= 21: 8-byte slots, 16 per line (mfx_table_view)
+  bool      frozen = false;     // an add / load happened: no more claims
+  uint64_t  side_nlines = 0;    // compact: lines of the side table, which follows the nlines main lines in d_slots
+  uint64_t  total_lines() const { return nlines + side_nlines; }
   bool      wide() const { return k > MFX_MAX_K_NARROW; }
-  uint32_t  slots_per_line() const { return wide() ? MFX_WSLOTS_LINE : MFX_SLOTS_LINE; }
+  uint32_t  slots_per_line() const { return wide() ? MFX_WSLOTS_LINE : compact ? MFX_CSLOTS_LINE : MFX_SLOTS_LINE; }
   uint32_t  key_words() const { return wide() ? 2u : 1u; }      // uint64 words per k-mer at the C ABI
   mfx_table_view view() const;
 };

@@ -16,8 +16,7 @@ struct mfx_kstar_args {
 };
 
 struct mfx_hist_args {
-  mfx_table_view  t;
-  mfx_table_view  t2 = {nullptr, 0, 0, 0, 0, 0, 0, 1, 0};   // compact -hist index (slots == nullptr: none); see mfx_kernels.hip
+  mfx_table_view  t;                  // t.compact: the 8-byte-slot layout of a sequence-only index (mfx_kernels.hip)
   int             canonical;          // 1: single probe of min(f,r); 0: probe both strands and sum
   const uint8_t  *bases;
   const uint64_t *codes = nullptr;    // non-null: read the tiles from the packed planes (same byte offsets / 32) instead of `bases`
@@ -85,6 +84,7 @@ struct mfx_count_args {
   uint32_t        ncontigs;
   uint64_t        ntiles;
   uint64_t       *meta;
+  int             count = 1;          // 1: asmV += 1 per occurrence (`meryl count`); 0: claim the k-mers only (sequence-only index)
 };
 
 hipError_t mfx_k_table_init(mfx_slot *slots, uint64_t nslots, hipStream_t st);
@@ -105,7 +105,7 @@ hipError_t mfx_k_sum_partials(const double *partials, uint32_t n, double *out, h
 hipError_t mfx_k_ordered_sum(const double *v, uint32_t n, double *out, hipStream_t st);
 uint64_t mfx_k_tile_partials_words(uint64_t ntiles);
 hipError_t mfx_k_sum_tile_partials(double *tile_partials, uint64_t ntiles, double *out, uint64_t *ctr_reset, hipStream_t st);
-int mfx_k_hist_resident_blocks();
+int mfx_k_hist_resident_blocks(int compact);
 // 32 <= k <= 64 (mfx_wide.hip); kmers: two uint64 words per k-mer {low 64 bits, high bits}
 hipError_t mfx_kw_table_add(mfx_table_view t, const uint64_t *kmers, const uint32_t *values, uint64_t n, int side, uint64_t *meta, hipStream_t st);
 hipError_t mfx_kw_table_value(mfx_table_view t, const uint64_t *kmers, uint64_t n, uint32_t *readV, uint32_t *asmV, hipStream_t st);
@@ -116,8 +116,6 @@ hipError_t mfx_kw_count(const mfx_count_args &a, hipStream_t st);
 hipError_t mfx_kw_completeness(mfx_table_view t, double peak, uint32_t n_prob, const uint32_t *probK, const double *probP, double *partials,
                                int grid, hipStream_t st);
 hipError_t mfx_k_dump(const mfx_dump_args &a, hipStream_t st);
-hipError_t mfx_k_count_asm_slots(mfx_table_view t, uint64_t *out, hipStream_t st);
-hipError_t mfx_k_compact_build(mfx_table_view t, mfx_table_view c, uint64_t *fail, hipStream_t st);
 hipError_t mfx_k_add_u32(uint32_t *dst, const uint32_t *src, uint64_t n, hipStream_t st);
 hipError_t mfx_k_unpack(const uint64_t *codes, const uint32_t *valid, uint8_t *bases, uint64_t nwords, hipStream_t st);
 hipError_t mfx_k_count(const mfx_count_args &a, hipStream_t st);

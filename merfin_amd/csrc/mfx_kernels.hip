@@ -188,6 +188,142 @@ __device__ __forceinline__ void mfx_meta_flush(uint64_t *meta, uint32_t fresh, u
   }
 }
 
+// ===========================================================================
+// Sequence-only index, compact layout (k <= 21): the k-mers CLAIMED from a sequence in 8-byte slots, 16 per 128-byte
+// line -- {key: 42 bits | readV: 11 | asmV: 11}.  -hist and -dump ask the lookup tables for the k-mers of -sequence
+// and nothing else (merfin-histogram.C:54-64, merfin-dump.C:44-61), so a table that holds exactly those answers them
+// as the full tables would: half the keys of a human read database never get a slot, twice the slots fit a line, and a
+// minimizer bucket of w = 4 windows (assembly k-mers only: no sequencing-error neighbours) stays in its home line --
+// 0.42 lines per k-mer instead of 0.52.  The table is built DIRECTLY in this form: mfx_index_claim_seq claims the keys
+// (mfx_c_claim), every later add / load only updates (mfx_c_add) and drops what was not claimed.
+// A count field of MFX_CSAT = 2047 means "saturated": the exact count of that side lives in the side table (standard
+// 16-byte slots, plain hashing; mfx_side_view).  Counts are moved there by the add that crosses the limit, so a field
+// is either exact or saturated, never wrapped.  The all-ones word is the empty slot: its key field would be the
+// poly-G 21-mer, which is never canonical (poly-C is), and only canonical k-mers are claimed.
+// ===========================================================================
+__device__ __forceinline__ mfx_table_view mfx_side_view(const mfx_table_view &c) {
+  mfx_table_view s = c;
+  s.slots = c.side; s.nlines = c.side_nlines;
+  s.mz_w = 0; s.compact = 0; s.seq_only = 0;
+  s.minV = 0u; s.maxV = 0xffffffffu;                           // the read filter is applied to the resolved count
+  s.shard_rank = 0u; s.shard_n = 1u;
+  return s;
+}
+
+// the pair of a found compact slot from its low word (a saturated field: the side table has the exact count)
+__device__ __forceinline__ uint2 mfx_c_fields(const mfx_table_view &c, uint64_t key, uint32_t lo) {
+  uint32_t rv = (lo >> 11) & MFX_CSAT, av = lo & MFX_CSAT;
+  if (rv == MFX_CSAT || av == MFX_CSAT) {
+    const uint2 x = mfx_lookup(mfx_side_view(c), key);
+    if (rv == MFX_CSAT) rv = x.x;
+    if (av == MFX_CSAT) av = x.y;
+  }
+  if (rv < c.minV || rv > c.maxV) rv = 0;                      // -min / -max (merfin.C:199-200)
+  return make_uint2(rv, av);
+}
+
+// per-lane scan of candidate lines d0, d0+1, ...: the slot holding `key` (its word in `word`), or nullptr when the
+// first line with room does not hold it (never claimed).  The whole line is requested at once (8 x 16 bytes).
+__device__ __forceinline__ unsigned long long *mfx_c_find(const mfx_table_view &c, uint64_t key, const mfx_probe &pr, uint32_t d0,
+                                                          unsigned long long &word) {
+  unsigned long long *cs = reinterpret_cast<unsigned long long *>(c.slots);
+  for (uint32_t d = d0; d < MFX_MAX_LINES; ++d) {
+    unsigned long long *base = cs + mfx_probe_line(c, pr, d) * MFX_CSLOTS_LINE;
+    const uint4 *ln = reinterpret_cast<const uint4 *>(base);
+    uint4 s[8];
+#pragma unroll
+    for (uint32_t q = 0; q < 8; ++q) s[q] = ln[q];
+    bool any_empty = false;
+    int at = -1;
+#pragma unroll
+    for (uint32_t q = 0; q < 8; ++q) {
+      const uint64_t x = (uint64_t)s[q].x | ((uint64_t)s[q].y << 32), y = (uint64_t)s[q].z | ((uint64_t)s[q].w << 32);
+      if (x != MFX_EMPTY && (x >> 22) == key) { at = 2 * (int)q; word = x; }
+      if (y != MFX_EMPTY && (y >> 22) == key) { at = 2 * (int)q + 1; word = y; }
+      any_empty |= (x == MFX_EMPTY) || (y == MFX_EMPTY);
+    }
+    if (at >= 0) return base + at;
+    if (any_empty) break;
+  }
+  return nullptr;
+}
+
+__device__ __forceinline__ uint2 mfx_c_lookup(const mfx_table_view &c, uint64_t key) {
+  unsigned long long w = 0;
+  if (!mfx_c_find(c, key, mfx_home(c, key), 0, w)) return make_uint2(0u, 0u);      // absent -> value 0 (merfin-globals.C:84)
+  return mfx_c_fields(c, key, (uint32_t)w);
+}
+
+// find-or-claim the slot of `key` (mfx_claim for 8-byte slots): slots of a line fill in order, a slot never changes its
+// key once written.  cur = the slot's word as seen (a fresh claim: the key with both counts 0).
+__device__ __forceinline__ unsigned long long *mfx_c_claim(const mfx_table_view &c, uint64_t key, uint64_t *meta, uint32_t &fresh,
+                                                           unsigned long long &cur) {
+  const mfx_probe pr = mfx_home(c, key);
+  unsigned long long *cs = reinterpret_cast<unsigned long long *>(c.slots);
+  const unsigned long long mine = (unsigned long long)key << 22;
+  for (uint32_t d = 0; d < MFX_MAX_LINES; ++d) {
+    unsigned long long *base = cs + mfx_probe_line(c, pr, d) * MFX_CSLOTS_LINE;
+    for (uint32_t q = 0; q < MFX_CSLOTS_LINE; ++q) {
+      cur = __hip_atomic_load(base + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (cur == MFX_EMPTY) {
+        cur = atomicCAS(base + q, (unsigned long long)MFX_EMPTY, mine);
+        if (cur == MFX_EMPTY) { ++fresh; cur = mine; return base + q; }
+      }
+      if ((cur >> 22) == key) return base + q;               // cur is not the empty word here
+    }
+  }
+  atomicAdd((unsigned long long *)&meta[2], 1ull);
+  return nullptr;
+}
+
+// counts[side] += v of the slot at w (cur = its word as last seen).  A field that would reach MFX_CSAT is set to
+// MFX_CSAT by the same compare-and-swap and everything it held moves to the side table; once saturated, adds go there.
+__device__ __forceinline__ void mfx_c_add(const mfx_table_view &c, unsigned long long *w, unsigned long long cur, uint64_t key, uint32_t v,
+                                          int side, uint64_t *meta) {
+  if (v == 0u) return;
+  const int sh = side ? 0 : 11;
+  uint32_t amount;
+  while (true) {
+    const uint32_t f = (uint32_t)(cur >> sh) & MFX_CSAT;
+    if (f == MFX_CSAT) { amount = v; break; }
+    const uint64_t sum = (uint64_t)f + v;
+    const unsigned long long nw = sum >= MFX_CSAT ? (cur | ((unsigned long long)MFX_CSAT << sh)) : cur + ((unsigned long long)v << sh);
+    const unsigned long long old = atomicCAS(w, cur, nw);
+    if (old == cur) {
+      if (sum < MFX_CSAT) return;
+      amount = (uint32_t)sum;                                  // uint32 arithmetic, as the standard table's atomicAdd
+      break;
+    }
+    cur = old;
+  }
+  uint32_t side_fresh = 0;                                     // side-table claims are not new k-mers of the index
+  mfx_slot *sl = mfx_claim(mfx_side_view(c), key, meta, side_fresh);
+  if (sl) atomicAdd(side ? &sl->asmV : &sl->readV, amount);
+}
+
+// standard slots, no claim: the slot holding `key`, or nullptr (sequence-only index with 16-byte slots, k > 21)
+__device__ __forceinline__ mfx_slot *mfx_find(const mfx_table_view &t, uint64_t key) {
+  const mfx_probe pr = mfx_home(t, key);
+  for (uint32_t d = 0; d < MFX_MAX_LINES; ++d) {
+    mfx_slot *base = t.slots + mfx_probe_line(t, pr, d) * MFX_SLOTS_LINE;
+    const uint4 *ln = reinterpret_cast<const uint4 *>(base);
+    uint4 s[MFX_SLOTS_LINE];
+#pragma unroll
+    for (uint32_t q = 0; q < MFX_SLOTS_LINE; ++q) s[q] = ln[q];
+    bool any_empty = false;
+    int at = -1;
+#pragma unroll
+    for (uint32_t q = 0; q < MFX_SLOTS_LINE; ++q) {
+      const uint64_t sk = (uint64_t)s[q].x | ((uint64_t)s[q].y << 32);
+      if (sk == key) at = (int)q;
+      any_empty |= (sk == MFX_EMPTY);
+    }
+    if (at >= 0) return base + at;
+    if (any_empty) break;
+  }
+  return nullptr;
+}
+
 // ---------------------------------------------------------------------------
 // Wave-cooperative insert (index build, assembly k-mer counting): the mirror image of the cooperative lookup.
 // Each lane brings one key; the 8 lanes of a lane-group serve their group's 8 keys ("rounds" S = 0..7), and for
@@ -352,11 +488,42 @@ __global__ __launch_bounds__(256) void mfx_table_add_kernel(mfx_table_view t, co
   mfx_meta_flush(meta, fresh, noncanon);
 }
 
+// the same for a SEQUENCE-ONLY index: the key set is frozen (the k-mers claimed from the sequence), an add finds its
+// k-mer's slot and updates the count, or drops the k-mer (meta[3] counts those).  Only canonical k-mers were claimed:
+// a non-canonical k-mer of the database is counted in meta[1] and dropped, and the host refuses the load
+// (value(fmer) + value(rmer) of the reference would need the other strand's slot too).
+__global__ __launch_bounds__(256) void mfx_table_update_kernel(mfx_table_view t, const uint64_t *kmers, const uint32_t *values, uint64_t n,
+                                                               int side, uint64_t *meta) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  uint32_t dropped = 0, noncanon = 0;
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint64_t key = kmers[i];
+    const uint32_t v = values[i];
+    if (v == 0u) continue;
+    if (key > mfx_revcomp(key, t.k)) { ++noncanon; continue; }
+    if (t.compact) {
+      unsigned long long cur = 0;
+      unsigned long long *w = mfx_c_find(t, key, mfx_home(t, key), 0, cur);
+      if (w) mfx_c_add(t, w, cur, key, v, side, meta); else ++dropped;
+    } else {
+      mfx_slot *sl = mfx_find(t, key);
+      if (sl) atomicAdd(side ? &sl->asmV : &sl->readV, v); else ++dropped;
+    }
+  }
+  uint64_t d = dropped, c = noncanon;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { d += __shfl_down(d, o, 64); c += __shfl_down(c, o, 64); }
+  if ((threadIdx.x & 63u) == 0) {
+    if (d) atomicAdd((unsigned long long *)&meta[3], (unsigned long long)d);
+    if (c) atomicAdd((unsigned long long *)&meta[1], (unsigned long long)c);
+  }
+}
+
 __global__ void mfx_table_value_kernel(mfx_table_view t, const uint64_t *kmers, uint64_t n, uint32_t *readV, uint32_t *asmV) {
   uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
   uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
-    uint2 v = mfx_lookup(t, kmers[i]);
+    uint2 v = t.compact ? mfx_c_lookup(t, kmers[i]) : mfx_lookup(t, kmers[i]);
     readV[i] = v.x;
     asmV[i] = v.y;
   }
@@ -364,9 +531,24 @@ __global__ void mfx_table_value_kernel(mfx_table_view t, const uint64_t *kmers, 
 
 __global__ void mfx_table_export_kernel(mfx_table_view t, uint64_t *kmers, uint32_t *readV, uint32_t *asmV,
                                         unsigned long long *count) {
-  uint64_t nslots = t.nlines * MFX_SLOTS_LINE;
   uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
   uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  if (t.compact) {                                               // 8-byte slots; raw counts (no read filter), as below
+    mfx_table_view raw = t;
+    raw.minV = 0u; raw.maxV = 0xffffffffu;
+    const uint64_t *cs = reinterpret_cast<const uint64_t *>(t.slots);
+    for (; i < t.nlines * MFX_CSLOTS_LINE; i += stride) {
+      const uint64_t x = cs[i];
+      if (x == MFX_EMPTY) continue;
+      const uint2 v = mfx_c_fields(raw, x >> 22, (uint32_t)x);
+      unsigned long long w = atomicAdd(count, 1ull);
+      kmers[w] = x >> 22;
+      readV[w] = v.x;
+      asmV[w] = v.y;
+    }
+    return;
+  }
+  uint64_t nslots = t.nlines * MFX_SLOTS_LINE;
   for (; i < nslots; i += stride) {
     mfx_slot s = t.slots[i];
     if (s.key == MFX_EMPTY) continue;
@@ -580,90 +762,25 @@ __device__ __forceinline__ void mfx_group_lookup(const mfx_table_view &t, mfx_ma
   }
 }
 
-// ===========================================================================
-// Compact -hist index (k <= 21, canonical database): the same k-mers in 8-byte slots, 16 per 128-byte line --
-// {key: 42 bits | readV: 11 | asmV: 11}, a count of 2047 meaning "saturated: the exact pair is in the standard table".
-// Twice the slots per line let a minimizer bucket of w = 5 windows (m = k - 4) stay in its home line, i.e. fewer
-// lines per k-mer (0.52 -> ~0.36) than the 16-byte table can afford.  Built from the standard table
-// (mfx_compact_build_kernel), read by mfx_hist_kernel<true, true> only; every other kernel keeps the standard table.
-// ===========================================================================
-constexpr uint32_t MFX_CSLOTS_LINE = 16;
-constexpr uint32_t MFX_CSAT = 2047u;
-
-__device__ __forceinline__ uint64_t mfx_c_pack(uint64_t key, uint32_t rv, uint32_t av) {
-  return (key << 22) | ((uint64_t)(rv < MFX_CSAT ? rv : MFX_CSAT) << 11) | (uint64_t)(av < MFX_CSAT ? av : MFX_CSAT);
-}
-
-// every (distinct) k-mer of the standard table claims the first free slot of its candidate lines in the compact one
-__global__ __launch_bounds__(MFX_BLOCK) void mfx_compact_build_kernel(mfx_table_view t, mfx_table_view c, unsigned long long *fail) {
-  const uint64_t nslots = t.nlines * MFX_SLOTS_LINE;
-  const uint64_t stride = (uint64_t)gridDim.x * MFX_BLOCK;
-  unsigned long long *cs = reinterpret_cast<unsigned long long *>(c.slots);
-  for (uint64_t i = (uint64_t)blockIdx.x * MFX_BLOCK + threadIdx.x; i < nslots; i += stride) {
-    const uint4 s = reinterpret_cast<const uint4 *>(t.slots)[i];
-    const uint64_t key = (uint64_t)s.x | ((uint64_t)s.y << 32);
-    if (key == MFX_EMPTY || s.w == 0u) continue;               // -hist asks for the k-mers of the assembly: the others stay in the standard table only
-    const unsigned long long packed = mfx_c_pack(key, s.z, s.w);
-    const mfx_probe pr = mfx_home(c, key);
-    bool placed = false;
-    for (uint32_t d = 0; d < MFX_MAX_LINES && !placed; ++d) {
-      unsigned long long *ln = cs + mfx_probe_line(c, pr, d) * MFX_CSLOTS_LINE;
-      for (uint32_t q = 0; q < MFX_CSLOTS_LINE && !placed; ++q) {
-        unsigned long long cur = __hip_atomic_load(ln + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (cur == MFX_EMPTY) placed = atomicCAS(ln + q, (unsigned long long)MFX_EMPTY, packed) == MFX_EMPTY;
-      }
-    }
-    if (!placed) atomicAdd(fail, 1ull);
-  }
-}
-
-// exact per-lane path over the compact table from candidate line d0 on (rare); saturated entries and anything
-// unresolved are answered by the standard table
-__device__ __forceinline__ uint2 mfx_scan_lines8(const mfx_table_view &c, const mfx_table_view &t, uint64_t key, uint32_t d0) {
-  const mfx_probe pr = mfx_home(c, key);
-  const uint64_t *cs = reinterpret_cast<const uint64_t *>(c.slots);
-  for (uint32_t d = d0; d < MFX_MAX_LINES; ++d) {
-    const uint4 *ln = reinterpret_cast<const uint4 *>(cs + mfx_probe_line(c, pr, d) * MFX_CSLOTS_LINE);
-    uint4 s[8];
-#pragma unroll
-    for (uint32_t q = 0; q < 8; ++q) s[q] = ln[q];
-    bool any_empty = false;
-    uint64_t hit = MFX_EMPTY;
-#pragma unroll
-    for (uint32_t q = 0; q < 8; ++q) {
-      const uint64_t a = (uint64_t)s[q].x | ((uint64_t)s[q].y << 32), b = (uint64_t)s[q].z | ((uint64_t)s[q].w << 32);
-      if (a != MFX_EMPTY && (a >> 22) == key) hit = a;
-      if (b != MFX_EMPTY && (b >> 22) == key) hit = b;
-      any_empty |= (a == MFX_EMPTY) || (b == MFX_EMPTY);
-    }
-    if (hit != MFX_EMPTY) {
-      const uint32_t rv = (uint32_t)(hit >> 11) & MFX_CSAT, av = (uint32_t)hit & MFX_CSAT;
-      if (rv == MFX_CSAT || av == MFX_CSAT) return mfx_lookup(t, key);
-      return make_uint2((rv < t.minV || rv > t.maxV) ? 0u : rv, av);
-    }
-    if (any_empty) break;
-  }
-  return mfx_lookup(t, key);                                   // not an assembly k-mer
-}
-
 // the cooperative probe of mfx_group_lookup over 16-slot lines: a slot lane holds TWO slots of the line; the matching
-// lane posts the slot's low word (counts + low key bits, never 0 for a stored k-mer with a count) into the owner's
-// 4-byte record; the owner unpacks it.
+// lane posts the slot's low word (counts + low key bits) into the owner's 4-byte record; the owner unpacks it.  A
+// stored k-mer whose two counts are 0 reads like one that is not there -- value() of either is 0.
 template <int S>
 __device__ __forceinline__ void mfx_group_post8(uint32_t *rec, const mfx_u32x4 (&v)[8], const uint32_t (&klo)[8], const uint32_t (&khi)[8]) {
   const mfx_u32x4 s = v[S];
-  // (key << 22) was broadcast: equal high words and low words that differ only in the 22 count bits
+  // (key << 22) was broadcast: equal high words and low words that differ only in the 22 count bits (the empty word's
+  // key field is not a canonical k-mer)
   if (s.y == khi[S] && ((s.x ^ klo[S]) >> 22) == 0u) rec[S] = s.x;
   if (s.w == khi[S] && ((s.z ^ klo[S]) >> 22) == 0u) rec[S] = s.z;
 }
 template <int S>
 __device__ __forceinline__ uint64_t mfx_group_room8(const mfx_u32x4 (&v)[8]) {
-  const uint64_t m = __ballot(v[S].w == 0xffffffffu);        // the LAST slot of the line is lane 7's second one
+  const uint64_t m = __ballot(v[S].w == 0xffffffffu);        // the LAST slot of the line is lane 7's second one; a stored high word is < 2^20
   return ((m >> 7) & 0x0101010101010101ULL) << S;
 }
 
 template <int B>
-__device__ __forceinline__ void mfx_group_lookup8(const mfx_table_view &c, const mfx_table_view &t, mfx_mailbox &M, const uint64_t (&key)[B],
+__device__ __forceinline__ void mfx_group_lookup8(const mfx_table_view &c, mfx_mailbox &M, const uint64_t (&key)[B],
                                                   const uint64_t (&krc)[B], const bool (&ok)[B], uint32_t (&rv)[B], uint32_t (&av)[B]) {
   const uint32_t tid = threadIdx.x, sub16 = (tid & 7u) << 4;
   const uint32_t lane = tid & 63u, wbase = tid & ~63u;
@@ -671,7 +788,7 @@ __device__ __forceinline__ void mfx_group_lookup8(const mfx_table_view &c, const
   uint32_t *const grp = reinterpret_cast<uint32_t *>(&M.rec[wbase]) + (lane & ~7u);
   const uint64_t slots0 = reinterpret_cast<uint64_t>(c.slots);
   uint64_t laddr[B];
-  uint32_t pending[B];          // 0 resolved, 1 home line full: continue per lane, 2 saturated: ask the standard table
+  uint32_t pending[B];          // 0 resolved, 1 home line full: continue at candidate line 1, 2 a count field is saturated
 #pragma unroll
   for (int j = 0; j < B; ++j) { pending[j] = 0u; rv[j] = av[j] = 0u; }
   {
@@ -711,10 +828,11 @@ __device__ __forceinline__ void mfx_group_lookup8(const mfx_table_view &c, const
     if (ok[j]) {
       const uint32_t r_rv = (r >> 11) & MFX_CSAT, r_av = r & MFX_CSAT;
       if ((r & 0x3fffffu) != 0u) {
-        if (r_rv == MFX_CSAT || r_av == MFX_CSAT) pending[j] = 2u;
-        else { rv[j] = (r_rv < t.minV || r_rv > t.maxV) ? 0u : r_rv; av[j] = r_av; }
+        if (r_rv == MFX_CSAT || r_av == MFX_CSAT) { pending[j] = 2u; rv[j] = r; }           // the low word is parked in rv
+        else { rv[j] = (r_rv < c.minV || r_rv > c.maxV) ? 0u : r_rv; av[j] = r_av; }
       } else {
-        pending[j] = ((room >> lane) & 1ULL) ? 2u : 1u;        // not in a line with room: not an assembly k-mer -> standard table
+        // no counts in the home line: absent (or claimed without counts) if that line has room, else the next candidate line
+        pending[j] = ((room >> lane) & 1ULL) ? 0u : 1u;
       }
     }
   }
@@ -756,17 +874,24 @@ __device__ __forceinline__ void mfx_group_lookup8(const mfx_table_view &c, const
 #pragma unroll
   for (int j = 0; j < B; ++j) {
     if (pending[j] == 0u) continue;
-    uint32_t from = 1u;
-    if (pending[j] == 1u && qpos[j] != 0xffffffffu) {
-      const uint4 r = M.rec[wbase + qpos[j]];
-      if (r.z == 0xffffffffu) {
-        const uint32_t r_rv = (r.x >> 11) & MFX_CSAT, r_av = r.x & MFX_CSAT;
-        if (r_rv != MFX_CSAT && r_av != MFX_CSAT) { rv[j] = (r_rv < t.minV || r_rv > t.maxV) ? 0u : r_rv; av[j] = r_av; continue; }
-        pending[j] = 2u;                                       // saturated: the standard table has the pair
-      } else if (r.w == 1u) pending[j] = 2u;                   // not an assembly k-mer: the standard table answers
-      else from = 2u;                                          // that line was full too
+    uint32_t lo = rv[j];                                       // pending == 2: the found slot's low word
+    rv[j] = 0u;
+    if (pending[j] == 1u) {
+      uint32_t from = 1u;
+      bool have = false;
+      if (qpos[j] != 0xffffffffu) {
+        const uint4 r = M.rec[wbase + qpos[j]];
+        if (r.z == 0xffffffffu) { lo = r.x; have = true; }
+        else if (r.w == 1u) continue;                          // absent (rv = av = 0 already)
+        else from = 2u;                                        // that line was full too
+      }
+      if (!have) {
+        unsigned long long w = 0;
+        if (!mfx_c_find(c, key[j], mfx_home(c, key[j]), from, w)) continue;   // exact per-lane path (rare)
+        lo = (uint32_t)w;
+      }
     }
-    const uint2 x = pending[j] == 2u ? mfx_lookup(t, key[j]) : mfx_scan_lines8(c, t, key[j], from);
+    const uint2 x = mfx_c_fields(c, key[j], lo);
     rv[j] = x.x; av[j] = x.y;
   }
 }
@@ -865,12 +990,13 @@ __global__ __launch_bounds__(MFX_BLOCK, 4) void mfx_hist_kernel(mfx_hist_args a)
           key[j] = f; key2[j] = r;
         }
       }
-      if (COMPACT) mfx_group_lookup8<MFX_BATCH>(a.t2, a.t, MB, key, key2, ok, rv, av);
+      if (COMPACT) mfx_group_lookup8<MFX_BATCH>(a.t, MB, key, key2, ok, rv, av);
       else mfx_group_lookup<MFX_BATCH>(a.t, MB, key, key2, ok, rv, av);
       if (!CANON) {
         // value(fmer) + value(rmer), uint32 arithmetic (merfin-globals.C:107-108)
         uint32_t rv2[MFX_BATCH], av2[MFX_BATCH];
-        mfx_group_lookup<MFX_BATCH>(a.t, MB, key2, key, ok, rv2, av2);
+        if (COMPACT) mfx_group_lookup8<MFX_BATCH>(a.t, MB, key2, key, ok, rv2, av2);
+        else mfx_group_lookup<MFX_BATCH>(a.t, MB, key2, key, ok, rv2, av2);
 #pragma unroll
         for (int j = 0; j < MFX_BATCH; ++j) { rv[j] += rv2[j]; av[j] += av2[j]; }
       }
@@ -1225,7 +1351,7 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_sum_chunks_kernel(const double 
 
 // RECOUNT: no lookup -- readV already holds the values (summed over the shards of a sharded index by
 // mfx_add_u32_kernel) and only the two counters are taken again from them: `readK == 0` is not additive over shards.
-template <bool CANON, bool RECOUNT>
+template <bool CANON, bool RECOUNT, bool COMPACT>
 __global__ __launch_bounds__(MFX_BLOCK) void mfx_dump_kernel(mfx_dump_args a) {
   __shared__ mfx_tile_lds L;
   __shared__ mfx_mailbox MB;
@@ -1255,10 +1381,12 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_dump_kernel(mfx_dump_args a) {
 #pragma unroll
       for (int j = 0; j < MFX_BATCH; ++j) rv[j] = ok[j] ? a.readV[pos0 + (b + j) * MFX_BLOCK + tid - a.skip] : 0u;
     } else {
-      mfx_group_lookup<MFX_BATCH>(a.t, MB, key, key2, ok, rv, av);
+      if (COMPACT) mfx_group_lookup8<MFX_BATCH>(a.t, MB, key, key2, ok, rv, av);
+      else mfx_group_lookup<MFX_BATCH>(a.t, MB, key, key2, ok, rv, av);
       if (!CANON) {
         uint32_t rv2[MFX_BATCH], av2[MFX_BATCH];
-        mfx_group_lookup<MFX_BATCH>(a.t, MB, key2, key, ok, rv2, av2);
+        if (COMPACT) mfx_group_lookup8<MFX_BATCH>(a.t, MB, key2, key, ok, rv2, av2);
+        else mfx_group_lookup<MFX_BATCH>(a.t, MB, key2, key, ok, rv2, av2);
 #pragma unroll
         for (int j = 0; j < MFX_BATCH; ++j) { rv[j] += rv2[j]; av[j] += av2[j]; }
       }
@@ -1356,10 +1484,16 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_count_kernel(mfx_count_args a) 
       const uint64_t r = mfx_revcomp(f, k);
       const uint64_t key = f < r ? f : r;
       if (ok && a.t.shard_n > 1 && mfx_owner(a.t, key, f < r ? r : f, a.t.shard_n) != a.t.shard_rank) ok = false;
-      if (MODE == 1) mfx_group_insert(a.t, key, ok ? 1u : 0u, 1, a.meta, fresh);
+      if (a.t.compact) {                                      // 8-byte slots (sequence-only index)
+        if (ok) {
+          unsigned long long cur = 0;
+          unsigned long long *w = mfx_c_claim(a.t, key, a.meta, fresh, cur);
+          if (w && a.count) mfx_c_add(a.t, w, cur, key, 1u, 1, a.meta);
+        }
+      } else if (MODE == 1 && a.count) mfx_group_insert(a.t, key, ok ? 1u : 0u, 1, a.meta, fresh);
       else if (ok) {
         mfx_slot *sl = mfx_claim(a.t, key, a.meta, fresh);
-        if (sl) atomicAdd(&sl->asmV, 1u);
+        if (sl && a.count) atomicAdd(&sl->asmV, 1u);           // count == 0: the key is claimed, its counts come from the databases
       }
     }
   }
@@ -1424,6 +1558,10 @@ hipError_t mfx_k_table_add(mfx_table_view t, const uint64_t *kmers, const uint32
   if (n == 0) return hipSuccess;
   uint64_t blocks = (n + 255) / 256;
   if (blocks > 8192) blocks = 8192;
+  if (t.seq_only) {
+    mfx_table_update_kernel<<<(unsigned)blocks, 256, 0, st>>>(t, kmers, values, n, side, meta);
+    return hipGetLastError();
+  }
   const char *me = getenv("MFX_INSERT_MODE");             // read per call: tests switch it
   const int mode = me ? atoi(me) : 1;
   if (mode == 0)      mfx_table_add_kernel<0><<<(unsigned)blocks, 256, 0, st>>>(t, kmers, values, n, side, meta);
@@ -1443,30 +1581,13 @@ hipError_t mfx_k_table_export(mfx_table_view t, uint64_t *kmers, uint32_t *readV
   mfx_table_export_kernel<<<4096, 256, 0, st>>>(t, kmers, readV, asmV, count);
   return hipGetLastError();
 }
-__global__ __launch_bounds__(MFX_BLOCK) void mfx_count_asm_slots_kernel(mfx_table_view t, unsigned long long *out) {
-  const uint64_t nslots = t.nlines * MFX_SLOTS_LINE, stride = (uint64_t)gridDim.x * MFX_BLOCK;
-  uint64_t n = 0;
-  for (uint64_t i = (uint64_t)blockIdx.x * MFX_BLOCK + threadIdx.x; i < nslots; i += stride) {
-    const uint4 s = reinterpret_cast<const uint4 *>(t.slots)[i];
-    n += ((s.x & s.y) != 0xffffffffu && s.w != 0u) ? 1u : 0u;
-  }
-  n = mfx_wave_sum(n);
-  if ((threadIdx.x & 63u) == 0 && n) atomicAdd(out, (unsigned long long)n);
-}
-hipError_t mfx_k_count_asm_slots(mfx_table_view t, uint64_t *out, hipStream_t st) {
-  mfx_count_asm_slots_kernel<<<4096, MFX_BLOCK, 0, st>>>(t, reinterpret_cast<unsigned long long *>(out));
-  return hipGetLastError();
-}
-hipError_t mfx_k_compact_build(mfx_table_view t, mfx_table_view c, uint64_t *fail, hipStream_t st) {
-  mfx_compact_build_kernel<<<8192, MFX_BLOCK, 0, st>>>(t, c, reinterpret_cast<unsigned long long *>(fail));
-  return hipGetLastError();
-}
 hipError_t mfx_k_hist(const mfx_hist_args &a, int grid, hipStream_t st) {
   // MFX_DEBUG_DYN_LDS: extra dynamic LDS per block, an occupancy knob for experiments only
   static const unsigned dyn = getenv("MFX_DEBUG_DYN_LDS") ? (unsigned)atoi(getenv("MFX_DEBUG_DYN_LDS")) : 0u;
-  if (a.canonical && a.t2.slots) mfx_hist_kernel<true, true><<<grid, MFX_BLOCK, dyn, st>>>(a);
-  else if (a.canonical)          mfx_hist_kernel<true, false><<<grid, MFX_BLOCK, dyn, st>>>(a);
-  else                           mfx_hist_kernel<false, false><<<grid, MFX_BLOCK, dyn, st>>>(a);
+  if (a.canonical && a.t.compact) mfx_hist_kernel<true, true><<<grid, MFX_BLOCK, dyn, st>>>(a);
+  else if (a.canonical)           mfx_hist_kernel<true, false><<<grid, MFX_BLOCK, dyn, st>>>(a);
+  else if (a.t.compact)           mfx_hist_kernel<false, true><<<grid, MFX_BLOCK, dyn, st>>>(a);
+  else                            mfx_hist_kernel<false, false><<<grid, MFX_BLOCK, dyn, st>>>(a);
   return hipGetLastError();
 }
 hipError_t mfx_k_route(const mfx_route_args &a, hipStream_t st) {
@@ -1519,9 +1640,11 @@ hipError_t mfx_k_sum_tile_partials(double *tile_partials, uint64_t ntiles, doubl
   mfx_sum_partials_kernel<<<1, MFX_BLOCK, 0, st>>>(tile_partials + n, (uint32_t)nch, out, ctr_reset);
   return hipGetLastError();
 }
-int mfx_k_hist_resident_blocks() {
+int mfx_k_hist_resident_blocks(int compact) {
   int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mfx_hist_kernel<true, false>, MFX_BLOCK, 0) != hipSuccess || nb < 1) nb = 4;
+  const hipError_t e = compact ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mfx_hist_kernel<true, true>, MFX_BLOCK, 0)
+                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mfx_hist_kernel<true, false>, MFX_BLOCK, 0);
+  if (e != hipSuccess || nb < 1) nb = 4;
   return nb;
 }
 hipError_t mfx_k_unpack(const uint64_t *codes, const uint32_t *valid, uint8_t *bases, uint64_t nwords, hipStream_t st) {
@@ -1541,9 +1664,11 @@ hipError_t mfx_k_add_u32(uint32_t *dst, const uint32_t *src, uint64_t n, hipStre
 hipError_t mfx_k_dump(const mfx_dump_args &a, hipStream_t st) {
   uint64_t blocks = (a.npos + MFX_TILE - 1) / MFX_TILE;
   if (blocks == 0) return hipSuccess;
-  if (a.recount)        mfx_dump_kernel<true, true><<<(unsigned)blocks, MFX_BLOCK, 0, st>>>(a);
-  else if (a.canonical) mfx_dump_kernel<true, false><<<(unsigned)blocks, MFX_BLOCK, 0, st>>>(a);
-  else                  mfx_dump_kernel<false, false><<<(unsigned)blocks, MFX_BLOCK, 0, st>>>(a);
+  if (a.recount)                       mfx_dump_kernel<true, true, false><<<(unsigned)blocks, MFX_BLOCK, 0, st>>>(a);
+  else if (a.canonical && a.t.compact) mfx_dump_kernel<true, false, true><<<(unsigned)blocks, MFX_BLOCK, 0, st>>>(a);
+  else if (a.canonical)                mfx_dump_kernel<true, false, false><<<(unsigned)blocks, MFX_BLOCK, 0, st>>>(a);
+  else if (a.t.compact)                mfx_dump_kernel<false, false, true><<<(unsigned)blocks, MFX_BLOCK, 0, st>>>(a);
+  else                                 mfx_dump_kernel<false, false, false><<<(unsigned)blocks, MFX_BLOCK, 0, st>>>(a);
   return hipGetLastError();
 }
 hipError_t mfx_k_count(const mfx_count_args &a, hipStream_t st) {

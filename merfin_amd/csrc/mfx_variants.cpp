@@ -464,6 +464,8 @@ static int variants_impl(const mfx_eval *ev, const PathValues &values, const cha
     return mfx_fail(MFX_E_INVAL, "mfx_variants_run: null argument");
   const int mode = opts->mode;
   if (mode < MFX_VAR_FILTER || mode > MFX_VAR_LOOSE) return mfx_fail(MFX_E_INVAL, "mfx_variants_run: unknown mode %d", mode);
+  if (ev->ix->seq_only)      // the alternative paths ask for k-mers the sequence does not hold (varMer.C:76-84)
+    return mfx_fail(MFX_E_INVAL, "mfx_variants_run: a sequence-only index holds the k-mers of one sequence; the variant modes need a full index (mfx_index_create)");
   const uint32_t K = (uint32_t)ev->ix->k;
   const uint32_t comb = opts->comb ? opts->comb : 15;
   FILE *log = log_path ? fopen(log_path, "w") : stderr;

@@ -538,11 +538,23 @@ def test_randomized_worlds_match_oracle(seed, monkeypatch):
     assert_hist_equal(ev.hist(seqs), g, ka, km, k)
     R, A = po.Lookup(k, read[0], read[1], lo, hi), po.Lookup(k, *asm)
     kp = m.KParams(peak, probK, probP)
+    # the sequence-only index of the same world (what the CLI builds for -hist / -dump): k-mers claimed from the sequence,
+    # assembly counts from the database, read counts update-only -- same answers, raw values included
+    six = m.Index.for_seq(k, sum(len(c) for c in contigs) + 16)
+    six.claim_seq(seqs)
+    six.add_asm(*asm)
+    six.add_read(read[0], read[1], lo, hi)
+    sev = m.Evaluator(six, m.KParams(peak, probK, probP))
+    assert_hist_equal(sev.hist(seqs), g, ka, km, k)
     for c, ctg in enumerate(contigs[:3]):
         n = len(ctg)
         if n == 0:
             continue
         gv, av, dka, dkm = ev.dump_values(seqs, c, 0, n)
+        sgv, sav, sdka, sdkm = sev.dump_values(seqs, c, 0, n)
+        np.testing.assert_array_equal(sgv, gv)
+        np.testing.assert_array_equal(sav, av)
+        assert (sdka, sdkm) == (dka, dkm)
         rkk, akk, kmm, oka, okm = po.process_dump(p, R, A, ctg)
         assert (dka, dkm) == (oka, okm)
         for i in range(0, max(n - k + 1, 0), max(1, n // 300)):
@@ -571,47 +583,3 @@ def test_bin_index_beyond_the_references_array_bound_is_an_error():
     p, g, ka, km = oracle_hist(k, 1.0, contigs, (ak, rv), (ak, av))
     assert_hist_equal(res, g, ka, km, k)
     assert len(_trim(res.over())) > 1000000
-
-
-@pytest.mark.parametrize("seed", list(range(12)))
-def test_compact_hist_index_opt_in(seed, monkeypatch):
-    """MFX_COMPACT=1: -hist reads the assembly's k-mers from 8-byte slots (16 per line, counts saturating at 2047 with the
-    exact pair left in the standard table).  Same results as the oracle on the seeded random worlds (which hold counts far
-    beyond 2047, -min/-max, -prob tables, tiny and empty contigs), for a sequence whose k-mers the assembly database does not
-    hold (they are answered by the standard table), and after the table changed under a built compact index."""
-    m = _mfx()
-    monkeypatch.setenv("MFX_COMPACT", "1")
-    monkeypatch.setenv("MFX_COMPACT_W", str(3 + seed % 3))
-    monkeypatch.setenv("MFX_COMPACT_LF", str([0.25, 0.5, 0.85][seed % 3]))        # 0.85: lines overflow, the second pass and the per-lane path run
-    r = np.random.default_rng(5000 + seed)
-    k = int(r.choice([9, 13, 17, 21]))
-    peak = float(r.choice([2.5, 9.0, 26.0]))
-    contigs, read, asm = synth.world(k=k, peak=peak, seed=5100 + seed, sizes=(20000, 6000, 4097, 30, 0), err_kmers=1500)
-    rv = read[1].astype(np.uint64)
-    big = r.random(len(rv)) < 0.03
-    rv[big] = r.choice([2046, 2047, 2048, 5000, 200000], size=int(big.sum()))
-    read = (read[0], rv.astype(np.uint32))
-    av = asm[1].copy()
-    av[r.random(len(av)) < 0.01] = 3000                        # saturated assembly counts too
-    asm = (asm[0], av)
-    lo, hi = (2, 2500) if seed % 2 else (0, 2**64 - 1)
-    p, g, ka, km = oracle_hist(k, peak, contigs, read, asm, None, None, lo, hi)
-    ix = build_index(m, k, read, asm, lo, hi)
-    ev = m.Evaluator(ix, m.KParams(peak))
-    seqs = m.Sequences(contigs)
-    assert_hist_equal(ev.hist(seqs), g, ka, km, k)
-    assert_hist_equal(ev.hist_streamed(m.Sequences.create([len(c) for c in contigs]), contigs), g, ka, km, k)
-    # a foreign sequence: most of its k-mers are not assembly k-mers of this index
-    other = [synth.random_contig(r, 9000).tobytes(), contigs[0][:3000]]
-    p2, g2, ka2, km2 = oracle_hist(k, peak, other, read, asm, None, None, lo, hi)
-    assert_hist_equal(ev.hist(m.Sequences(other)), g2, ka2, km2, k)
-    # the table changes (more assembly counts): the compact index is rebuilt for the new version
-    extra = po.count_kmers(k, [other[0]])
-    ix.add_asm(*extra)
-    merged = {}
-    for kk, vv in zip(asm[0].tolist() + extra[0].tolist(), asm[1].tolist() + extra[1].tolist()):
-        merged[kk] = merged.get(kk, 0) + vv
-    mk = np.array(sorted(merged), dtype=np.uint64)
-    asm3 = (mk, np.array([merged[x] for x in mk.tolist()], dtype=np.uint32))
-    p3, g3, ka3, km3 = oracle_hist(k, peak, other, read, asm3, None, None, lo, hi)
-    assert_hist_equal(m.Evaluator(ix, m.KParams(peak)).hist(m.Sequences(other)), g3, ka3, km3, k)

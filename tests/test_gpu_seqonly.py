@@ -1,0 +1,210 @@
+"""The SEQUENCE-ONLY index (mfx_index_create_for_seq): the lookup object of -hist and -dump, which only ever ask for the
+k-mers of -sequence (merfin-histogram.C:54-64, merfin-dump.C:44-61).  It holds the k-mers claimed from the sequence;
+loads only update.  For k <= 21 it takes the compact layout (8-byte slots, 16 per line, saturated counts in a side
+table).  Everything it answers must equal what the full index -- and the oracle -- answer."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from tests import synth
+from tests.test_gpu_parity import assert_hist_equal, oracle_hist, build_index
+
+pytestmark = pytest.mark.gpu
+
+
+def _mfx():
+    import merfin_amd as m
+    if m.device_count() < 1:
+        pytest.fail("no HIP device visible: the GPU tests must run on the MI355X box")
+    return m
+
+
+def seq_index(m, k, contigs, read, asm=None, lo=0, hi=2**64 - 1, seqs=None):
+    """asm None: the assembly side is counted from the sequence (no -seqmers); else claimed, then loaded from `asm`"""
+    seqs = seqs or m.Sequences(contigs)
+    ix = m.Index.for_seq(k, sum(len(c) for c in contigs) + 16)
+    if asm is None:
+        ix.count_asm(seqs)
+    else:
+        ix.claim_seq(seqs)
+        ix.add_asm(*asm)
+    ix.add_read(read[0], read[1], lo, hi)
+    return ix, seqs
+
+
+@pytest.mark.parametrize("k,peak,use_prob,compact", [(21, 17.3, False, "1"), (21, 26.0, True, "1"), (21, 26.0, True, "0"), (31, 17.3, False, "1"),
+                                                     (15, 9.0, False, "1"), (8, 9.0, False, "1"), (12, 3.0, True, "0")])
+def test_seq_only_hist_and_dump_match_oracle(k, peak, use_prob, compact, golden_dir, monkeypatch):
+    m = _mfx()
+    monkeypatch.setenv("MFX_SEQ_COMPACT", compact)
+    contigs, read, asm = synth.world(k=k, peak=peak, seed=300 + k)
+    probK = probP = None
+    if use_prob:
+        probK, probP = po.load_kmetric(os.path.join(golden_dir, "example_lookup_table.txt"))
+    p, g, ka, km = oracle_hist(k, peak, contigs, read, asm, probK, probP)
+    for from_db in (False, True):
+        ix, seqs = seq_index(m, k, contigs, read, asm if from_db else None)
+        info = ix.info()
+        assert info["seq_only"] and info["compact"] == (compact == "1" and k <= 21)
+        assert info["distinct"] == len(asm[0])                    # one slot per distinct canonical k-mer of the sequence
+        # every read k-mer that is not a k-mer of the sequence was dropped, nothing else
+        assert info["dropped"] == int(np.count_nonzero(~np.isin(read[0], asm[0]) & (read[1] > 0)))
+        ev = m.Evaluator(ix, m.KParams(peak, probK, probP))
+        assert_hist_equal(ev.hist(seqs), g, ka, km, k)
+        assert_hist_equal(ev.hist_streamed(m.Sequences.create([len(c) for c in contigs]), contigs), g, ka, km, k)
+        # value(): the pair of every k-mer of the sequence, 0 for anything else
+        rd = dict(zip(read[0].tolist(), read[1].tolist()))
+        rv, av = ix.value(asm[0])
+        np.testing.assert_array_equal(av, asm[1])
+        np.testing.assert_array_equal(rv, np.array([rd.get(x, 0) for x in asm[0].tolist()], dtype=np.uint32))
+        foreign = read[0][~np.isin(read[0], asm[0])][:500]
+        rv, av = ix.value(foreign)
+        assert not rv.any() and not av.any()
+        ek, er, ea = ix.export()
+        np.testing.assert_array_equal(ek, asm[0])
+        np.testing.assert_array_equal(ea, asm[1])
+        # -dump raw values and text
+        full = m.Evaluator(build_index(m, k, read, asm), m.KParams(peak, probK, probP))
+        for c in range(min(3, len(contigs))):
+            if len(contigs[c]):
+                a = ev.dump_values(seqs, c, 0, len(contigs[c]))
+                b = full.dump_values(seqs, c, 0, len(contigs[c]))
+                np.testing.assert_array_equal(a[0], b[0])
+                np.testing.assert_array_equal(a[1], b[1])
+                assert a[2:] == b[2:]
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_seq_only_saturated_counts_and_crowded_lines(seed, monkeypatch):
+    """counts at and beyond the 11-bit fields (2046, 2047, 2048, 200000; reached in one add and by several adds), assembly
+    counts beyond them too, -min/-max, and tables so full that lines overflow (second cooperative pass, per-lane path)"""
+    m = _mfx()
+    monkeypatch.setenv("MFX_MZ_W", str(3 + seed % 3))
+    monkeypatch.setenv("MFX_LOAD_FACTOR", str([0.25, 0.5, 0.85][seed % 3]))
+    r = np.random.default_rng(5000 + seed)
+    k = int(r.choice([9, 13, 17, 21]))
+    peak = float(r.choice([2.5, 9.0, 26.0]))
+    contigs, read, asm = synth.world(k=k, peak=peak, seed=5100 + seed, sizes=(20000, 6000, 4097, 30, 0), err_kmers=1500)
+    rv = read[1].astype(np.uint64)
+    big = r.random(len(rv)) < 0.03
+    rv[big] = r.choice([2046, 2047, 2048, 5000, 200000], size=int(big.sum()))
+    read = (read[0], rv.astype(np.uint32))
+    av = asm[1].copy()
+    av[r.random(len(av)) < 0.01] = 3000                        # saturated assembly counts too
+    asm = (asm[0], av)
+    lo, hi = (2, 2500) if seed % 2 else (0, 2**64 - 1)
+    p, g, ka, km = oracle_hist(k, peak, contigs, read, asm, None, None, lo, hi)
+    seqs = m.Sequences(contigs)
+    ix = m.Index.for_seq(k, sum(len(c) for c in contigs) + 16)
+    ix.claim_seq(seqs)
+    ix.add_asm(*asm)
+    # the read counts arrive in three instalments: fields saturate both in one step and by accumulation
+    parts = [read[1] // 3, read[1] // 3, read[1] - 2 * (read[1] // 3)]
+    for part in parts:
+        ix.add_read(read[0], part, lo, hi)
+    ev = m.Evaluator(ix, m.KParams(peak))
+    assert_hist_equal(ev.hist(seqs), g, ka, km, k)
+    rd = dict(zip(read[0].tolist(), read[1].tolist()))
+    want = np.array([rd.get(x, 0) for x in asm[0].tolist()], dtype=np.uint32)
+    want_f = np.where((want < lo) | (want > min(hi, 2**32 - 1)), 0, want)
+    gr, ga = ix.value(asm[0])
+    np.testing.assert_array_equal(ga, asm[1])
+    np.testing.assert_array_equal(gr, want_f)
+    ek, er, ea = ix.export()                                  # raw counts, unfiltered
+    np.testing.assert_array_equal(er, want)
+    # the same counts when every k-mer OCCURRENCE of the sequence is counted one by one (fields saturate by +1 steps)
+    cx = m.Index.for_seq(k, sum(len(c) for c in contigs) + 16)
+    cx.count_asm(seqs)
+    true_asm = po.count_kmers(k, contigs)
+    _, ga2 = cx.value(true_asm[0])
+    np.testing.assert_array_equal(ga2, true_asm[1])
+
+
+def test_seq_only_counts_accumulate_beyond_the_field_by_unit_steps():
+    """a 3000-copy tandem repeat: its k-mers' assembly counts cross 2047 one occurrence at a time, from many lanes at once"""
+    m = _mfx()
+    k = 21
+    r = synth.rng(77)
+    unit = synth.random_contig(r, 37).tobytes()
+    contigs = [synth.random_contig(r, 5000).tobytes() + unit * 3000 + synth.random_contig(r, 5000).tobytes()]
+    ak, av = po.count_kmers(k, contigs)
+    assert av.max() >= 2990
+    seqs = m.Sequences(contigs)
+    ix = m.Index.for_seq(k, len(contigs[0]) + 16)
+    ix.count_asm(seqs)
+    read = (ak, (av.astype(np.uint64) * 17 % 5000).astype(np.uint32))
+    ix.add_read(*read)
+    gr, ga = ix.value(ak)
+    np.testing.assert_array_equal(ga, av)
+    np.testing.assert_array_equal(gr, read[1])
+    p, g, ka, km = oracle_hist(k, 17.0, contigs, read, (ak, av))
+    assert_hist_equal(m.Evaluator(ix, m.KParams(17.0)).hist(seqs), g, ka, km, k)
+
+
+def test_seq_only_rules():
+    m = _mfx()
+    k = 21
+    contigs, read, asm = synth.world(k=k, peak=9.0, seed=5)
+    ix, seqs = seq_index(m, k, contigs, read)
+    with pytest.raises(m.MfxError, match="claimed before"):      # no claims once counts arrived
+        ix.count_asm(seqs)
+    with pytest.raises(m.MfxError, match="claimed before"):
+        ix.claim_seq(seqs)
+    ev = m.Evaluator(ix, m.KParams(9.0))
+    with pytest.raises(m.MfxError, match="sequence-only"):
+        ev.completeness()
+    with pytest.raises(m.MfxError, match="sequence-only"):
+        ix.set_shard(0, 2)
+    with pytest.raises(m.MfxError, match="sequence-only"):
+        m.Router(ix, 2, 4)
+    with pytest.raises(m.MfxError, match="sequence-only"):
+        m.Index(k, 100).claim_seq(seqs)                          # a full index takes no claims
+    with pytest.raises(m.MfxError):
+        m.Index.for_seq(33, 100)                                 # k <= 31
+    # a non-canonical database cannot be answered from one slot per canonical k-mer
+    def rc(x):
+        y = 0
+        for _ in range(k):
+            y = (y << 2) | ((x & 3) ^ 2)
+            x >>= 2
+        return y
+    nc = np.array([rc(int(x)) for x in asm[0][:50].tolist()], dtype=np.uint64)
+    nc = nc[nc > asm[0][:50]]
+    assert len(nc)
+    ix2 = m.Index.for_seq(k, sum(len(c) for c in contigs) + 16)
+    ix2.count_asm(seqs)
+    with pytest.raises(m.MfxError, match="non-canonical") as ei:
+        ix2.add_read(nc, np.ones(len(nc), dtype=np.uint32))
+    assert ei.value.code == m.E_NONCANON
+
+
+@pytest.mark.parametrize("k", [21, 27])
+def test_seq_only_image_roundtrip_and_replica(k, tmp_path):
+    """the device-format image (-index cache) and the replica made for another slot carry the compact layout, its side
+    table and the sequence-only flag"""
+    m = _mfx()
+    peak = 17.3
+    contigs, read, asm = synth.world(k=k, peak=peak, seed=9)
+    read = (read[0], np.where(np.arange(len(read[1])) % 40 == 0, 60000, read[1]).astype(np.uint32))    # saturated fields in the image
+    p, g, ka, km = oracle_hist(k, peak, contigs, read, asm)
+    ix, seqs = seq_index(m, k, contigs, read)
+    ix.save(str(tmp_path / "img"))
+    for other in (m.Index.load(str(tmp_path / "img")), ix.replicate(0)):
+        info = other.info()
+        assert info["seq_only"] and info["compact"] == (k <= 21) and info["distinct"] == len(asm[0])
+        assert_hist_equal(m.Evaluator(other, m.KParams(peak)).hist(seqs), g, ka, km, k)
+        with pytest.raises(m.MfxError, match="claimed before"):
+            other.claim_seq(seqs)
+
+
+def test_seq_only_multi_slot_and_even_k():
+    m = _mfx()
+    for k in (20, 21):                                            # even k: both strands are probed and summed
+        peak = 9.0
+        contigs, read, asm = synth.world(k=k, peak=peak, seed=40 + k)
+        p, g, ka, km = oracle_hist(k, peak, contigs, read, asm)
+        ix, seqs = seq_index(m, k, contigs, read)
+        evs = [m.Evaluator(ix, m.KParams(peak)) for _ in range(3)]
+        assert_hist_equal(m.hist_multi(evs, [seqs] * 3), g, ka, km, k)

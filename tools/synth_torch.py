@@ -283,9 +283,12 @@ def add_neighbor_error_kmers(ix, truth, k, seed=SEED, per_position=1.0, chunk=1 
 
 
 def build_world(m, total_bases, k=21, lam=26.0, ncontigs=24, seed=SEED, device=0, err_factor=1.0, verbose=None,
-                err_mode="random", index_factory=None):
+                err_mode="random", index_factory=None, seq_only=False):
     """Full synthetic -hist workload resident on `device`: returns (index, sequences, info).
-    index_factory(k, capacity, device=) may supply the index (e.g. a fan-out over the shards of a sharded index)."""
+    index_factory(k, capacity, device=) may supply the index (e.g. a fan-out over the shards of a sharded index).
+    seq_only: the SEQUENCE-ONLY index the CLI builds for -hist / -dump (mfx_index_create_for_seq): the assembly's k-mers
+    are claimed and counted first, the read database -- the very same k-mers and counts as for the full index -- then
+    only updates them."""
     import time
     torch.cuda.set_device(device)
     dev = "cuda:%d" % device
@@ -297,6 +300,20 @@ def build_world(m, total_bases, k=21, lam=26.0, ncontigs=24, seed=SEED, device=0
     torch.cuda.synchronize()
     say("genome+assembly generated: %.1fs" % (time.time() - t0))
     n_err = int(total_bases * err_factor)
+    if seq_only:
+        seqs = m.Sequences.from_device([a.data_ptr() for a in asm], [a.numel() for a in asm], device=device)
+        ix = m.Index.for_seq(k, int(total_bases) + 1024, device=device)
+        ix.count_asm(seqs)
+        say("assembly k-mers claimed + counted: %.1fs" % (time.time() - t0))
+        add_reads_from_truth(ix, truth, k, lam, seed)
+        del truth
+        add_error_kmers(ix, n_err, k, seed)
+        torch.cuda.synchronize()
+        say("read database (truth counts + error k-mers) applied, update-only: %.1fs" % (time.time() - t0))
+        info = ix.info()
+        info["build_s"] = time.time() - t0
+        info["sizes"] = sizes
+        return ix, seqs, asm, info
     cap = int(total_bases * 1.03) + n_err + 1024
     ix = (index_factory or m.Index)(k, cap, device=device)
     add_reads_from_truth(ix, truth, k, lam, seed)
