@@ -274,6 +274,14 @@ void     mfx_pack_bases(const uint8_t *src, uint64_t n, uint64_t *codes, uint32_
  * needs its own evaluator; they may share one index and one mfx_seq). */
 mfx_index *mfx_index_replicate(const mfx_index *src, int device);
 mfx_seq   *mfx_seq_replicate(const mfx_seq *src, int device);
+/* n replicas at once, out[i] on devices[i]: a DOUBLING TREE over xGMI -- in every round each device that holds the data
+ * feeds one that does not, all copies of a round in flight together (xGMI is point to point: 7 replicas take 3 rounds with
+ * 1, 2, 4 source devices instead of 7 copies through device 0's links).  The assembly travels as its packed planes
+ * (0.375 B/base; mfx_seq_pack builds them on the device); a replica holds the planes and unpacks on demand.  On failure
+ * nothing is left allocated. */
+int        mfx_index_replicate_many(const mfx_index *src, const int *devices, uint32_t n, mfx_index **out);
+int        mfx_seq_replicate_many(const mfx_seq *src, const int *devices, uint32_t n, mfx_seq **out);
+int        mfx_seq_pack(mfx_seq *seq);
 int        mfx_hist_run_multi(mfx_eval *const *evs, const mfx_seq *const *seqs, uint32_t ndev, mfx_hist_result *out);
 
 /* One process per GPU (torchrun / mpirun style launchers): the collective of the path, on RCCL over xGMI.
@@ -295,6 +303,14 @@ int       mfx_comm_barrier(mfx_comm *c, void *stream);      /* all ranks arrived
 int       mfx_hist_allreduce(mfx_comm *c, uint64_t *d_counts, double *d_kover, uint32_t nbins, uint32_t ncontigs, void *stream);
 /* synchronises `stream`; records[] receives the records of all ranks in rank order */
 int       mfx_hist_allgather_overflow(mfx_comm *c, mfx_eval *ev, uint64_t *records, uint64_t cap, uint64_t *n_out, void *stream);
+/* The exchange step of the sharded index (config 5: "allToAllv of the routed k-mers") for the
+ * one-process-per-GPU form: group r of d_send (send_counts[r] elements of elem_bytes, groups back to back in rank order:
+ * what mfx_route_tiles writes) goes to rank r; the groups arrive in source-rank order.  mfx_comm_exchange_counts tells
+ * every rank what it will receive (all-gather of the count rows; synchronises `stream`), mfx_comm_alltoallv moves one
+ * array (one RCCL group of point-to-point sends / receives over xGMI; asynchronous on `stream`). */
+int       mfx_comm_exchange_counts(mfx_comm *c, const uint64_t *send_counts, uint64_t *recv_counts, void *stream);
+int       mfx_comm_alltoallv(mfx_comm *c, const void *d_send, const uint64_t *send_counts, void *d_recv, const uint64_t *recv_counts,
+                             uint32_t elem_bytes, void *stream);
 /* fold overflow records (mfx_hist_take_overflow / mfx_hist_allgather_overflow format) into a result */
 int       mfx_hist_result_add_overflow(mfx_hist_result *r, const uint64_t *records, uint64_t n);
 

@@ -67,7 +67,8 @@ SYMBOLS = [
     "mfx_index_set_fingerprint", "mfx_index_get_origin",
     "mfx_host_alloc", "mfx_host_free", "mfx_seq_create", "mfx_hist_run_streamed",
     "mfx_index_replicate", "mfx_seq_replicate", "mfx_hist_run_multi", "mfx_hist_run_sharded",
-    "mfx_comm_unique_id", "mfx_comm_create", "mfx_comm_free", "mfx_comm_rank", "mfx_comm_size", "mfx_comm_barrier",
+    "mfx_comm_unique_id", "mfx_comm_create", "mfx_comm_free", "mfx_comm_rank", "mfx_comm_size", "mfx_comm_barrier", "mfx_comm_exchange_counts", "mfx_comm_alltoallv",
+    "mfx_index_replicate_many", "mfx_seq_replicate_many", "mfx_seq_pack",
     "mfx_hist_allreduce", "mfx_hist_allgather_overflow", "mfx_hist_result_add_overflow",
     "mfx_index_image_header", "mfx_index_create_from_header", "mfx_index_device_image", "mfx_index_commit",
     "mfx_seq_upload", "mfx_seq_from_device", "mfx_seq_free", "mfx_seq_num_contigs", "mfx_seq_num_bases",
@@ -212,6 +213,11 @@ def load_library():
     L.mfx_comm_rank.argtypes = [vp]
     L.mfx_comm_size.argtypes = [vp]
     L.mfx_comm_barrier.argtypes = [vp, vp]
+    L.mfx_comm_exchange_counts.argtypes = [vp, u64p, u64p, vp]
+    L.mfx_comm_alltoallv.argtypes = [vp, vp, u64p, vp, u64p, C.c_uint32, vp]
+    L.mfx_index_replicate_many.argtypes = [vp, C.POINTER(C.c_int), C.c_uint32, C.POINTER(vp)]
+    L.mfx_seq_replicate_many.argtypes = [vp, C.POINTER(C.c_int), C.c_uint32, C.POINTER(vp)]
+    L.mfx_seq_pack.argtypes = [vp]
     L.mfx_hist_allreduce.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, vp]
     L.mfx_hist_allgather_overflow.argtypes = [vp, vp, u64p, C.c_uint64, u64p, vp]
     L.mfx_hist_result_add_overflow.argtypes = [C.POINTER(_HistResult), u64p, C.c_uint64]
@@ -373,6 +379,19 @@ class Index:
         ix.k = self.k
         return ix
 
+    def replicate_many(self, devices):
+        """copies on several devices at once: a doubling tree over xGMI (every device that holds the table feeds another one
+        in each round, all copies of a round in flight together)"""
+        devs = (C.c_int * len(devices))(*devices)
+        out = (C.c_void_p * len(devices))()
+        _check(load_library().mfx_index_replicate_many(self.h, devs, len(devices), out))
+        res = []
+        for d, h in zip(devices, out):
+            ix = Index(0, 0, device=d, _handle=h)
+            ix.k = self.k
+            res.append(ix)
+        return res
+
     def set_fingerprint(self, fp):
         _check(load_library().mfx_index_set_fingerprint(self.h, int(fp)))
 
@@ -494,6 +513,17 @@ class Sequences:
     def replicate(self, device):
         """a copy of the packed assembly on another device of the node"""
         return Sequences(device=device, names=self.names, _handle=_need(load_library().mfx_seq_replicate(self.h, device)))
+
+    def replicate_many(self, devices):
+        """copies on several devices at once (doubling tree over xGMI); the assembly travels as its packed planes"""
+        devs = (C.c_int * len(devices))(*devices)
+        out = (C.c_void_p * len(devices))()
+        _check(load_library().mfx_seq_replicate_many(self.h, devs, len(devices), out))
+        return [Sequences(device=d, names=self.names, _handle=h) for d, h in zip(devices, out)]
+
+    def pack(self):
+        """build the packed planes (2-bit codes + validity bits) from the resident bases, on the device"""
+        _check(load_library().mfx_seq_pack(self.h))
 
     @property
     def ncontigs(self):
@@ -719,6 +749,23 @@ class Comm:
         _check(load_library().mfx_hist_allgather_overflow(self.h, ev.h, rec.ctypes.data_as(C.POINTER(C.c_uint64)), cap, C.byref(n),
                                                           C.c_void_p(stream or 0)))
         return rec[:n.value]
+
+    def exchange_counts(self, send_counts, stream=None):
+        """what every rank will send to this one (all-gather of the count rows; synchronises `stream`)"""
+        sc = np.ascontiguousarray(send_counts, dtype=np.uint64)
+        assert len(sc) == self.nranks
+        rc = np.zeros(self.nranks, dtype=np.uint64)
+        _check(load_library().mfx_comm_exchange_counts(self.h, sc.ctypes.data_as(C.POINTER(C.c_uint64)), rc.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                       C.c_void_p(stream or 0)))
+        return rc
+
+    def alltoallv(self, d_send, send_counts, d_recv, recv_counts, elem_bytes, stream=None):
+        """group r of d_send -> rank r, received groups in source-rank order (device buffers; async on `stream`)"""
+        p = lambda x: C.c_void_p(x.data_ptr() if hasattr(x, "data_ptr") else int(x))
+        sc = np.ascontiguousarray(send_counts, dtype=np.uint64)
+        rc = np.ascontiguousarray(recv_counts, dtype=np.uint64)
+        _check(load_library().mfx_comm_alltoallv(self.h, p(d_send), sc.ctypes.data_as(C.POINTER(C.c_uint64)), p(d_recv),
+                                                 rc.ctypes.data_as(C.POINTER(C.c_uint64)), elem_bytes, C.c_void_p(stream or 0)))
 
     def close(self):
         if getattr(self, "h", None):

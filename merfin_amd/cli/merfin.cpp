@@ -339,24 +339,41 @@ struct Slots {
     devs = G.devices;
     ixs.assign(N, nullptr); sqs.assign(N, nullptr); evs.assign(N, nullptr);
     ixs[0] = ix; sqs[0] = seq; evs[0] = ev;
+    // the devices that need a copy (a device named twice shares table and sequence): all at once, by a doubling tree
+    std::vector<int> fresh;
+    std::vector<size_t> first(N, 0);
+    for (size_t d = 0; d < N; ++d) {
+      first[d] = d;
+      for (size_t e = 0; e < d; ++e) if (devs[e] == devs[d]) { first[d] = e; break; }
+      if (first[d] == d && d > 0) fresh.push_back(devs[d]);
+    }
+    std::vector<mfx_index *> rix(fresh.size(), nullptr);
+    std::vector<mfx_seq *> rsq(fresh.size(), nullptr);
+    if (!fresh.empty()) {
+      if (mfx_index_replicate_many(ix, fresh.data(), (uint32_t)fresh.size(), rix.data())) return false;
+      if (seq && mfx_seq_replicate_many(seq, fresh.data(), (uint32_t)fresh.size(), rsq.data())) {
+        for (auto *x : rix) mfx_index_free(x);
+        return false;
+      }
+    }
+    for (size_t d = 1, f = 0; d < N; ++d) {
+      if (first[d] == d) { ixs[d] = rix[f]; sqs[d] = rsq[f]; ++f; }
+      else { ixs[d] = ixs[first[d]]; sqs[d] = sqs[first[d]]; }
+    }
     for (size_t d = 1; d < N; ++d) {
-      size_t same = d;
-      for (size_t e = 0; e < d; ++e) if (devs[e] == devs[d]) { same = e; break; }
-      ixs[d] = same < d ? ixs[same] : mfx_index_replicate(ix, devs[d]);
-      sqs[d] = same < d ? sqs[same] : (seq ? mfx_seq_replicate(seq, devs[d]) : nullptr);
-      evs[d] = (ixs[d] && (sqs[d] || !seq)) ? mfx_eval_create(ixs[d], kp, 0) : nullptr;
-      if (!evs[d]) return false;
+      evs[d] = mfx_eval_create(ixs[d], kp, 0);
+      if (!evs[d]) { release(); return false; }
     }
     return true;
   }
   void release() {                       // slot 0 belongs to the caller
-    for (size_t d = 1; d < evs.size(); ++d) {
+    for (size_t d = 1; d < ixs.size(); ++d) {
       if (evs[d]) mfx_eval_free(evs[d]);
       bool shared = false;
       for (size_t e = 0; e < d; ++e) if (devs[e] == devs[d]) shared = true;
       if (!shared) { if (sqs[d]) mfx_seq_free(sqs[d]); if (ixs[d]) mfx_index_free(ixs[d]); }
     }
-    evs.clear();
+    evs.clear(); ixs.clear(); sqs.clear();
   }
 };
 

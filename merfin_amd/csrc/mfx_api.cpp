@@ -1002,7 +1002,7 @@ static int hist_launch(mfx_eval *ev, const mfx_seq *seq, uint64_t tile_begin, ui
   a.t = ev->ix->view();
   a.canonical = canon;
   a.bases = seq->d_bases;
-  if (seq->bases_stale) { a.codes = seq->d_codes; a.valid = seq->d_valid; }      // a packed upload: the planes are the sequence
+  if (seq->planes_ok || seq->bases_stale) { a.codes = seq->d_codes; a.valid = seq->d_valid; }      // packed planes present: the tiles are copied, not encoded
   a.contig_off = seq->d_contig_off;
   a.contig_len = seq->d_contig_len;
   a.tile_start = seq->d_tile_start;
@@ -1137,27 +1137,57 @@ extern "C" int mfx_hist_result_add_overflow(mfx_hist_result *r, const uint64_t *
   return result_add_overflow(r, std::vector<uint64_t>(records, records + n));
 }
 
+// What a whole-assembly run needs besides the evaluator's tables -- a stream, the counts image, its pinned mirror -- belongs
+// to the evaluator and is made once (mfx_eval::sr): creating and releasing it per call costs ~2.5 ms, which is most of an
+// 8-device evaluation (4 ms of kernel per device at 3 Gb).  The device of `ev` must be current.
+static int eval_run_resources(mfx_eval *ev, size_t words) {
+  auto &R = ev->sr;
+  if (R.words < words) {
+    if (R.d_counts) (void)hipFree(R.d_counts);
+    if (R.h_img) (void)hipHostFree(R.h_img);
+    R.d_counts = nullptr; R.h_img = nullptr; R.words = 0;
+    MFX_HIP(hipMalloc((void **)&R.d_counts, words * sizeof(uint64_t)));
+    MFX_HIP(hipHostMalloc((void **)&R.h_img, (words + 1) * sizeof(uint64_t), hipHostMallocDefault));
+    R.words = words;
+  }
+  if (!R.d_kover) MFX_HIP(hipMalloc((void **)&R.d_kover, sizeof(double)));
+  for (auto &k : R.kern) if (!k) MFX_HIP(hipStreamCreateWithFlags(&k, hipStreamNonBlocking));
+  return MFX_OK;
+}
+
+// clears + launch (contiguous tiles, or the block-cyclic share part_rank of part_n) + D2H of image and koverCpy, all
+// asynchronous on the evaluator's own stream; the caller synchronises ev->sr.kern[0] and reads ev->sr.h_img
+static int eval_run_enqueue(mfx_eval *ev, const mfx_seq *seq, uint32_t part_rank, uint32_t part_n) {
+  const size_t words = MFX_HIST_WORDS(ev->nbins, seq->ncontigs);
+  int rc = eval_run_resources(ev, words);
+  if (rc) return rc;
+  auto &R = ev->sr;
+  hipStream_t st = R.kern[0];
+  MFX_HIP(hipMemsetAsync(R.d_counts, 0, words * sizeof(uint64_t), st));
+  MFX_HIP(hipMemsetAsync(R.d_kover, 0, sizeof(double), st));
+  MFX_HIP(hipMemsetAsync(ev->d_ovf, 0, sizeof(uint64_t), st));      // records nobody collected from an earlier launch are not this run's
+  rc = part_n > 1 ? mfx_hist_launch_cyclic(ev, seq, part_rank, part_n, 256, R.d_counts, R.d_kover, st)
+                  : mfx_hist_launch(ev, seq, 0, seq->ntiles, R.d_counts, R.d_kover, st);
+  if (rc) return rc;
+  MFX_HIP(hipMemcpyAsync(R.h_img, R.d_counts, words * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  MFX_HIP(hipMemcpyAsync(R.h_img + words, R.d_kover, sizeof(double), hipMemcpyDeviceToHost, st));
+  return MFX_OK;
+}
+
 extern "C" int mfx_hist_run(mfx_eval *ev, const mfx_seq *seq, mfx_hist_result *out) {
   if (!ev || !seq || !out) return mfx_fail(MFX_E_INVAL, "mfx_hist_run: null argument");
+  if (ev->device != seq->device) return mfx_fail(MFX_E_INVAL, "evaluator and sequence live on different devices");
   DevGuard g(ev->device);
-  MFX_HIP(hipMemset(ev->d_ovf, 0, sizeof(uint64_t)));      // records nobody collected from an earlier launch are not this run's
   const size_t words = MFX_HIST_WORDS(ev->nbins, seq->ncontigs);
-  DevBuf<uint64_t> dc;
-  DevBuf<double> dk;
-  MFX_HIP(dc.alloc(words));
-  MFX_HIP(dk.alloc(1));
-  MFX_HIP(hipMemset(dc.p, 0, words * sizeof(uint64_t)));
-  MFX_HIP(hipMemset(dk.p, 0, sizeof(double)));
-  int rc = mfx_hist_launch(ev, seq, 0, seq->ntiles, dc.p, dk.p, nullptr);
+  int rc = eval_run_enqueue(ev, seq, 0, 1);
   if (rc) return rc;
-  MFX_HIP(hipDeviceSynchronize());
-  std::vector<uint64_t> h(words);
+  MFX_HIP(hipStreamSynchronize(ev->sr.kern[0]));
   double kover = 0;
-  MFX_HIP(hipMemcpy(h.data(), dc.p, words * sizeof(uint64_t), hipMemcpyDeviceToHost));
-  MFX_HIP(hipMemcpy(&kover, dk.p, sizeof(double), hipMemcpyDeviceToHost));
-  rc = mfx_hist_result_from_counts(ev->nbins, h.data(), kover, seq->ncontigs, out);
+  memcpy(&kover, ev->sr.h_img + words, sizeof(double));
+  const uint64_t novf = ev->sr.h_img[2ull * ev->nbins + 2];
+  rc = mfx_hist_result_from_counts(ev->nbins, ev->sr.h_img, kover, seq->ncontigs, out);
   if (rc) return rc;
-  rc = result_take_overflow(ev, h[2ull * ev->nbins + 2], out);
+  rc = result_take_overflow(ev, novf, out);
   if (rc) mfx_hist_result_free(out);
   return rc;
 }
@@ -1300,6 +1330,7 @@ static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *cons
   for (int b = 0; b < NB && b < (int)chunks.size(); ++b)
     if (!ev->h_pack[b]) STREAMED_HIP(hipHostMalloc((void **)&ev->h_pack[b], STAGE_W * 12, hipHostMallocDefault));
   seq->bases_stale = true;
+  seq->planes_ok = true;
 
   // the packers: worker w encodes its share of the words of every chunk, in chunk order
   const unsigned W = std::max(1u, std::min(mfx_host_threads(), 64u));
@@ -1415,6 +1446,7 @@ extern "C" int mfx_hist_run_streamed(mfx_eval *ev, mfx_seq *seq, const char *con
     if (!ev->ix->wide() && !(asc && atoi(asc))) return hist_run_streamed_packed(ev, seq, bases, out);
   }
   seq->bases_stale = false;                                 // this path writes d_bases
+  seq->planes_ok = false;
   DevGuard g(ev->device);
   const size_t words = MFX_HIST_WORDS(ev->nbins, seq->ncontigs);
   const uint64_t T = seq->ntiles;
@@ -1522,59 +1554,148 @@ extern "C" int mfx_hist_run_streamed(mfx_eval *ev, mfx_seq *seq, const char *con
 // a fixed-order fp64 sum, so the result is bit-stable run to run.  K* bins beyond the dense image travel in
 // every evaluator's overflow list and are folded in as well.
 // ---------------------------------------------------------------------------
-extern "C" mfx_index *mfx_index_replicate(const mfx_index *src, int device) {
-  if (!src || device < 0 || device >= mfx_device_count()) {
-    mfx_fail(MFX_E_INVAL, "mfx_index_replicate: bad argument (device %d of %d)", device, mfx_device_count());
-    return nullptr;
+// Doubling tree over the devices of a node: holder 0 has the data; in every round each holder feeds ONE device that does
+// not have it yet, all copies of a round in flight together (xGMI is point to point: 1, 2, 4 source devices work in
+// parallel, 7 replicas of a 97 GB table take 3 rounds instead of 7 copies through device 0's links one after the other).
+// dev[h], ptr[h][s]: device and buffers of holder h; bytes[s]: size of segment s (the same for every holder).
+static int tree_copy(const std::vector<int> &dev, const std::vector<std::vector<void *>> &ptr, const std::vector<size_t> &bytes) {
+  const size_t H = dev.size();
+  std::vector<hipStream_t> st(H, nullptr);
+  int rc = MFX_OK;
+  std::vector<size_t> have(1, 0);
+  size_t next = 1;
+  const size_t CH = 1ull << 30;
+  while (next < H && rc == MFX_OK) {
+    std::vector<size_t> fresh;
+    for (size_t j = 0; j < have.size() && next < H && rc == MFX_OK; ++j, ++next) {
+      const size_t from = have[j], to = next;
+      DevGuard g(dev[to]);
+      if (dev[from] != dev[to]) {
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, dev[to], dev[from]) == hipSuccess && can && hipDeviceEnablePeerAccess(dev[from], 0) != hipSuccess)
+          (void)hipGetLastError();                              // "already enabled" is fine
+      }
+      hipError_t e = st[to] ? hipSuccess : hipStreamCreateWithFlags(&st[to], hipStreamNonBlocking);
+      for (size_t sgi = 0; sgi < bytes.size() && e == hipSuccess; ++sgi)
+        for (size_t o = 0; o < bytes[sgi] && e == hipSuccess; o += CH)
+          e = hipMemcpyPeerAsync((char *)ptr[to][sgi] + o, dev[to], (const char *)ptr[from][sgi] + o, dev[from], std::min(CH, bytes[sgi] - o), st[to]);
+      if (e != hipSuccess) rc = mfx_fail(MFX_E_HIP, "peer copy from device %d to device %d failed: %s", dev[from], dev[to], hipGetErrorString(e));
+      fresh.push_back(to);
+    }
+    for (size_t t : fresh) {
+      DevGuard g(dev[t]);
+      const hipError_t e = st[t] ? hipStreamSynchronize(st[t]) : hipSuccess;
+      if (e != hipSuccess && rc == MFX_OK) rc = mfx_fail(MFX_E_HIP, "peer copy to device %d failed: %s", dev[t], hipGetErrorString(e));
+      have.push_back(t);
+    }
+  }
+  for (size_t h = 0; h < H; ++h)
+    if (st[h]) { DevGuard g(dev[h]); (void)hipStreamDestroy(st[h]); }
+  return rc;
+}
+
+extern "C" int mfx_index_replicate_many(const mfx_index *src, const int *devices, uint32_t n, mfx_index **out) {
+  if (!src || !devices || !out || n == 0) return mfx_fail(MFX_E_INVAL, "mfx_index_replicate_many: null argument");
+  for (uint32_t i = 0; i < n; ++i) {
+    out[i] = nullptr;
+    if (devices[i] < 0 || devices[i] >= mfx_device_count()) return mfx_fail(MFX_E_INVAL, "mfx_index_replicate_many: device %d of %d", devices[i], mfx_device_count());
   }
   uint8_t hdr[MFX_INDEX_HEADER_BYTES];
-  if (mfx_index_image_header(src, hdr) != MFX_OK) return nullptr;
-  mfx_index *dst = mfx_index_create_from_header(hdr, 0.0, device);
-  if (!dst) return nullptr;
-  const uint64_t bytes = src->total_lines() * MFX_ALIGN;
-  hipError_t e = hipSuccess;
-  {
-    DevGuard g(device);
-    if (src->device != device) {
-      int can = 0;
-      if (hipDeviceCanAccessPeer(&can, device, src->device) == hipSuccess && can) {
-        hipError_t pe = hipDeviceEnablePeerAccess(src->device, 0);          // xGMI path; "already enabled" is fine
-        if (pe != hipSuccess) (void)hipGetLastError();
-      }
-    }
-    const uint64_t CH = 1ull << 30;
-    for (uint64_t o = 0; o < bytes && e == hipSuccess; o += CH)
-      e = hipMemcpyPeerAsync((char *)dst->d_slots + o, device, (const char *)src->d_slots + o, src->device, std::min(CH, bytes - o), nullptr);
-    if (e == hipSuccess) e = hipMemcpyPeer(dst->d_meta, device, src->d_meta, src->device, 4 * sizeof(uint64_t));
-    if (e == hipSuccess) e = hipDeviceSynchronize();
+  int rc = mfx_index_image_header(src, hdr);
+  if (rc) return rc;
+  std::vector<int> dev(1, src->device);
+  std::vector<std::vector<void *>> ptr(1, std::vector<void *>{src->d_slots, src->d_meta});
+  for (uint32_t i = 0; i < n && rc == MFX_OK; ++i) {
+    out[i] = mfx_index_create_from_header(hdr, 0.0, devices[i]);
+    if (!out[i]) { rc = mfx_last_error_code() ? mfx_last_error_code() : MFX_E_NOMEM; break; }
+    dev.push_back(devices[i]);
+    ptr.push_back(std::vector<void *>{out[i]->d_slots, out[i]->d_meta});
   }
-  if (e != hipSuccess) {
-    mfx_fail(MFX_E_HIP, "copying the k-mer table from device %d to device %d failed: %s", src->device, device, hipGetErrorString(e));
-    mfx_index_free(dst);
-    return nullptr;
+  if (rc == MFX_OK) {
+    { DevGuard g(src->device); (void)hipDeviceSynchronize(); }          // the source's last inserts are done
+    rc = tree_copy(dev, ptr, std::vector<size_t>{(size_t)(src->total_lines() * MFX_ALIGN), 4 * sizeof(uint64_t)});
   }
-  dst->fingerprint = src->fingerprint;
-  (void)mfx_index_commit(dst);
-  return dst;
+  if (rc != MFX_OK) {
+    const std::string why = mfx_last_error();
+    for (uint32_t i = 0; i < n; ++i) { if (out[i]) mfx_index_free(out[i]); out[i] = nullptr; }
+    return mfx_fail(rc, "copying the k-mer table to %u device(s) failed: %s", n, why.c_str());
+  }
+  for (uint32_t i = 0; i < n; ++i) {
+    out[i]->fingerprint = src->fingerprint;
+    (void)mfx_index_commit(out[i]);
+  }
+  return MFX_OK;
+}
+
+extern "C" mfx_index *mfx_index_replicate(const mfx_index *src, int device) {
+  mfx_index *out = nullptr;
+  return mfx_index_replicate_many(src, &device, 1, &out) == MFX_OK ? out : nullptr;
+}
+
+static uint64_t seq_plane_words(const mfx_seq *s) { return s->buf_bytes / 32 + (MFX_TILE + 64) / 32 + 1; }   // a tile reads 130 words from its first one
+
+static int seq_alloc_planes(mfx_seq *s) {
+  if (s->d_codes) return MFX_OK;
+  const uint64_t pw = seq_plane_words(s);
+  MFX_HIP(hipMalloc((void **)&s->d_codes, pw * sizeof(uint64_t)));
+  MFX_HIP(hipMalloc((void **)&s->d_valid, pw * sizeof(uint32_t)));
+  MFX_HIP(hipMemset(s->d_valid, 0, pw * sizeof(uint32_t)));           // no valid base behind the sequence
+  MFX_HIP(hipMemset(s->d_codes, 0, pw * sizeof(uint64_t)));
+  return MFX_OK;
+}
+
+// the packed planes of a resident sequence (2-bit codes + one validity bit per base, the tile's own form), made on the device
+extern "C" int mfx_seq_pack(mfx_seq *s) {
+  if (!s) return mfx_fail(MFX_E_INVAL, "mfx_seq_pack: null argument");
+  if (s->planes_ok) return MFX_OK;
+  DevGuard g(s->device);
+  int rc = seq_alloc_planes(s);
+  if (rc) return rc;
+  MFX_HIP(mfx_k_pack(s->d_bases, s->d_codes, s->d_valid, s->buf_bytes / 32, nullptr));
+  MFX_HIP(hipDeviceSynchronize());
+  s->planes_ok = true;
+  return MFX_OK;
+}
+
+// The assembly travels between devices as its packed planes (0.375 B per base instead of 1); a replica holds the planes
+// only and unpacks them if a kernel asks for one byte per base (mfx_seq_ensure_ascii).
+extern "C" int mfx_seq_replicate_many(const mfx_seq *csrc, const int *devices, uint32_t n, mfx_seq **out) {
+  if (!csrc || !devices || !out || n == 0) return mfx_fail(MFX_E_INVAL, "mfx_seq_replicate_many: null argument");
+  for (uint32_t i = 0; i < n; ++i) {
+    out[i] = nullptr;
+    if (devices[i] < 0 || devices[i] >= mfx_device_count()) return mfx_fail(MFX_E_INVAL, "mfx_seq_replicate_many: device %d of %d", devices[i], mfx_device_count());
+  }
+  mfx_seq *src = const_cast<mfx_seq *>(csrc);
+  int rc = mfx_seq_pack(src);
+  if (rc) return rc;
+  const uint64_t pw = seq_plane_words(src);
+  std::vector<int> dev(1, src->device);
+  std::vector<std::vector<void *>> ptr(1, std::vector<void *>{src->d_codes, src->d_valid});
+  for (uint32_t i = 0; i < n && rc == MFX_OK; ++i) {
+    out[i] = mfx_seq_create(devices[i], src->len.data(), src->ncontigs);
+    if (!out[i]) { rc = mfx_last_error_code() ? mfx_last_error_code() : MFX_E_NOMEM; break; }
+    DevGuard g(devices[i]);
+    rc = seq_alloc_planes(out[i]);
+    dev.push_back(devices[i]);
+    ptr.push_back(std::vector<void *>{out[i]->d_codes, out[i]->d_valid});
+  }
+  if (rc == MFX_OK) {
+    { DevGuard g(devices[n - 1]); (void)hipDeviceSynchronize(); }       // the memsets of the last replica's planes
+    for (uint32_t i = 0; i + 1 < n; ++i) { DevGuard g(devices[i]); (void)hipDeviceSynchronize(); }
+    rc = tree_copy(dev, ptr, std::vector<size_t>{(size_t)(pw * sizeof(uint64_t)), (size_t)(pw * sizeof(uint32_t))});
+  }
+  if (rc != MFX_OK) {
+    const std::string why = mfx_last_error();
+    for (uint32_t i = 0; i < n; ++i) { if (out[i]) mfx_seq_free(out[i]); out[i] = nullptr; }
+    return mfx_fail(rc, "copying the packed assembly to %u device(s) failed: %s", n, why.c_str());
+  }
+  for (uint32_t i = 0; i < n; ++i) { out[i]->bases_stale = true; out[i]->planes_ok = true; }
+  return MFX_OK;
 }
 
 extern "C" mfx_seq *mfx_seq_replicate(const mfx_seq *src, int device) {
-  if (!src || device < 0 || device >= mfx_device_count()) {
-    mfx_fail(MFX_E_INVAL, "mfx_seq_replicate: bad argument (device %d of %d)", device, mfx_device_count());
-    return nullptr;
-  }
-  if (mfx_seq_ensure_ascii(src)) return nullptr;
-  mfx_seq *s = mfx_seq_create(device, src->len.data(), src->ncontigs);
-  if (!s) return nullptr;
-  DevGuard g(device);
-  hipError_t e = hipMemcpyPeer(s->d_bases, device, src->d_bases, src->device, src->buf_bytes);
-  if (e == hipSuccess) e = hipDeviceSynchronize();
-  if (e != hipSuccess) {
-    mfx_fail(MFX_E_HIP, "copying the packed assembly from device %d to device %d failed: %s", src->device, device, hipGetErrorString(e));
-    mfx_seq_free(s);
-    return nullptr;
-  }
-  return s;
+  mfx_seq *out = nullptr;
+  return mfx_seq_replicate_many(src, &device, 1, &out) == MFX_OK ? out : nullptr;
 }
 
 extern "C" int mfx_hist_run_multi(mfx_eval *const *evs, const mfx_seq *const *seqs, uint32_t ndev, mfx_hist_result *out) {
@@ -1590,54 +1711,49 @@ extern "C" int mfx_hist_run_multi(mfx_eval *const *evs, const mfx_seq *const *se
   if (ndev == 1) return mfx_hist_run(evs[0], seqs[0], out);
   const uint32_t nbins = evs[0]->nbins, ncontigs = seqs[0]->ncontigs;
   const size_t words = MFX_HIST_WORDS(nbins, ncontigs);
-  struct Slot {
-    uint64_t *d_counts = nullptr; double *d_kover = nullptr; uint64_t *h = nullptr; hipStream_t st = nullptr;
-  };
-  std::vector<Slot> sl(ndev);
   int rc = MFX_OK;
-  auto fail_hip = [&](const char *what, hipError_t e) { if (rc == MFX_OK) rc = mfx_fail(MFX_E_HIP, "mfx_hist_run_multi: %s failed: %s", what, hipGetErrorString(e)); };
-  // launch on every device before waiting for any
+  // launch on every device before waiting for any; every slot works on its evaluator's own stream and image (nothing is
+  // created or released per call)
+  const bool timing = getenv("MFX_MULTI_TIMING") && atoi(getenv("MFX_MULTI_TIMING"));
+  auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = now();
+  std::vector<char> launched(ndev, 0);
   for (uint32_t d = 0; d < ndev && rc == MFX_OK; ++d) {
     DevGuard g(evs[d]->device);
-    hipError_t e;
-    if ((e = hipStreamCreateWithFlags(&sl[d].st, hipStreamNonBlocking)) != hipSuccess) { fail_hip("hipStreamCreate", e); break; }
-    if ((e = hipMalloc((void **)&sl[d].d_counts, words * sizeof(uint64_t))) != hipSuccess ||
-        (e = hipMalloc((void **)&sl[d].d_kover, sizeof(double))) != hipSuccess ||
-        (e = hipHostMalloc((void **)&sl[d].h, (words + 1) * sizeof(uint64_t), hipHostMallocDefault)) != hipSuccess ||
-        (e = hipMemsetAsync(sl[d].d_counts, 0, words * sizeof(uint64_t), sl[d].st)) != hipSuccess ||
-        (e = hipMemsetAsync(sl[d].d_kover, 0, sizeof(double), sl[d].st)) != hipSuccess ||
-        (e = hipMemsetAsync(evs[d]->d_ovf, 0, sizeof(uint64_t), sl[d].st)) != hipSuccess) { fail_hip("buffer setup", e); break; }
-    rc = mfx_hist_launch_cyclic(evs[d], seqs[d], d, ndev, 256, sl[d].d_counts, sl[d].d_kover, sl[d].st);
-    if (rc) break;
-    if ((e = hipMemcpyAsync(sl[d].h, sl[d].d_counts, words * sizeof(uint64_t), hipMemcpyDeviceToHost, sl[d].st)) != hipSuccess ||
-        (e = hipMemcpyAsync(sl[d].h + words, sl[d].d_kover, sizeof(double), hipMemcpyDeviceToHost, sl[d].st)) != hipSuccess) fail_hip("D2H of the counts image", e);
+    rc = eval_run_enqueue(evs[d], seqs[d], d, ndev);
+    launched[d] = rc == MFX_OK;
   }
-  std::vector<uint64_t> sum(words, 0);
-  double kover = 0.0;
-  for (uint32_t d = 0; d < ndev; ++d) {
-    if (!sl[d].st) continue;
+  const double t1 = now();
+  for (uint32_t d = 0; d < ndev; ++d) {                      // wait for all: the slots' kernels run side by side
+    if (!launched[d] && !evs[d]->sr.kern[0]) continue;
     DevGuard g(evs[d]->device);
-    hipError_t e = hipStreamSynchronize(sl[d].st);
-    if (e != hipSuccess) fail_hip("hipStreamSynchronize", e);
-    if (rc == MFX_OK) {
-      for (size_t i = 0; i < words; ++i) sum[i] += sl[d].h[i];
-      double kv;
-      memcpy(&kv, sl[d].h + words, sizeof(double));
-      kover = kover + kv;                                   // device order: a fixed-order fp64 sum
-    }
+    hipError_t e = hipStreamSynchronize(evs[d]->sr.kern[0]);
+    if (e != hipSuccess && rc == MFX_OK) rc = mfx_fail(MFX_E_HIP, "mfx_hist_run_multi: slot %u failed: %s", d, hipGetErrorString(e));
   }
-  if (rc == MFX_OK) rc = mfx_hist_result_from_counts(nbins, sum.data(), kover, ncontigs, out);
+  const double t2 = now();
+  // the N images (~1 MB each) are added in slot order: integers exactly, koverCpy as a fixed-order fp64 sum
+  uint64_t *sum = evs[0]->sr.h_img;                          // slot 0's pinned image is the accumulator
+  double kover = 0.0;
+  uint64_t novf0 = 0;
   if (rc == MFX_OK) {
-    for (uint32_t d = 0; d < ndev && rc == MFX_OK; ++d) rc = result_take_overflow(evs[d], sl[d].h[2ull * nbins + 2], out);
+    novf0 = sum[2ull * nbins + 2];
+    memcpy(&kover, sum + words, sizeof(double));
+    for (uint32_t d = 1; d < ndev; ++d) {
+      const uint64_t *h = evs[d]->sr.h_img;
+      for (size_t i = 0; i < words; ++i) sum[i] += h[i];
+      double kv;
+      memcpy(&kv, h + words, sizeof(double));
+      kover = kover + kv;
+    }
+    rc = mfx_hist_result_from_counts(nbins, sum, kover, ncontigs, out);
+  }
+  if (rc == MFX_OK) {
+    rc = result_take_overflow(evs[0], novf0, out);
+    for (uint32_t d = 1; d < ndev && rc == MFX_OK; ++d) rc = result_take_overflow(evs[d], evs[d]->sr.h_img[2ull * nbins + 2], out);
     if (rc) mfx_hist_result_free(out);
   }
-  for (uint32_t d = 0; d < ndev; ++d) {
-    DevGuard g(evs[d]->device);
-    if (sl[d].d_counts) (void)hipFree(sl[d].d_counts);
-    if (sl[d].d_kover) (void)hipFree(sl[d].d_kover);
-    if (sl[d].h) (void)hipHostFree(sl[d].h);
-    if (sl[d].st) (void)hipStreamDestroy(sl[d].st);
-  }
+  if (timing)
+    fprintf(stderr, "[mfx multi] %u slots: enqueue %.3f ms, wait %.3f ms, reduce + result %.3f ms\n", ndev, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (now() - t2) * 1e3);
   return rc;
 }
 

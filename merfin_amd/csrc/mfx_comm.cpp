@@ -25,6 +25,7 @@ struct mfx_comm {
   int rank = 0, nranks = 1, device = 0;
   double   *d_gather = nullptr;      // [nranks] one koverCpy per rank
   uint64_t *d_novf = nullptr;        // [nranks] overflow records per rank
+  uint64_t *d_cnt = nullptr;         // [nranks + nranks * nranks] a rank's send counts, then every rank's (mfx_comm_exchange_counts)
 };
 
 namespace {
@@ -73,7 +74,8 @@ extern "C" mfx_comm *mfx_comm_create(const void *id, int rank, int nranks, int d
     return nullptr;
   }
   if (hipMalloc((void **)&c->d_gather, (size_t)nranks * sizeof(double)) != hipSuccess ||
-      hipMalloc((void **)&c->d_novf, (size_t)nranks * sizeof(uint64_t)) != hipSuccess) {
+      hipMalloc((void **)&c->d_novf, (size_t)nranks * sizeof(uint64_t)) != hipSuccess ||
+      hipMalloc((void **)&c->d_cnt, ((size_t)nranks + (size_t)nranks * nranks) * sizeof(uint64_t)) != hipSuccess) {
     mfx_fail(MFX_E_NOMEM, "mfx_comm_create: device allocation failed");
     mfx_comm_free(c);
     return nullptr;
@@ -86,6 +88,7 @@ extern "C" void mfx_comm_free(mfx_comm *c) {
   DeviceScope ds(c->device);
   if (c->d_gather) (void)hipFree(c->d_gather);
   if (c->d_novf) (void)hipFree(c->d_novf);
+  if (c->d_cnt) (void)hipFree(c->d_cnt);
   if (c->comm) (void)ncclCommDestroy(c->comm);
   delete c;
 }
@@ -156,5 +159,56 @@ extern "C" int mfx_hist_allgather_overflow(mfx_comm *c, mfx_eval *ev, uint64_t *
     for (uint64_t i = 0; i < cnt[rk]; ++i, ++w)
       if (records && w < cap) records[w] = all[(size_t)rk * mx + i];
   if (total > cap) return mfx_fail(MFX_E_OVERFLOW, "overflow list has %lu records, caller buffer %lu", (unsigned long)total, (unsigned long)cap);
+  return MFX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// The exchange of the sharded index (BASELINE config 5; SURVEY 8(e): "allToAllv of 8 B k-mers"): every rank has grouped
+// the k-mers of its tiles by owner (mfx_route_tiles) and sends group r to rank r.  RCCL has no all-to-all-v primitive;
+// it is one group of point-to-point sends and receives, which RCCL runs concurrently over the direct xGMI links.
+//   1. mfx_comm_exchange_counts: recv_counts[s] = what rank s will send to this rank (an all-gather of the count rows;
+//      synchronises `stream` once -- the receive buffer has to be sized on the host);
+//   2. mfx_comm_alltoallv, once per array (keys, contig ids): element r-th group of d_send -> rank r, groups received
+//      in source-rank order (so the owner sees its k-mers source by source, sequence order inside a source: the order
+//      the fp64 koverCpy sum depends on).  Asynchronous on `stream`.
+// ---------------------------------------------------------------------------
+extern "C" int mfx_comm_exchange_counts(mfx_comm *c, const uint64_t *send_counts, uint64_t *recv_counts, void *stream) {
+  if (!c || !send_counts || !recv_counts) return mfx_fail(MFX_E_INVAL, "mfx_comm_exchange_counts: null argument");
+  DeviceScope ds(c->device);
+  if (!ds.ok) return mfx_fail(MFX_E_HIP, "hipSetDevice(%d) failed", c->device);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t n = (size_t)c->nranks;
+  MFX_HIP(hipMemcpyAsync(c->d_cnt, send_counts, n * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+  MFX_NCCL(ncclAllGather(c->d_cnt, c->d_cnt + n, n, ncclUint64, c->comm, st));
+  std::vector<uint64_t> all(n * n);
+  MFX_HIP(hipMemcpyAsync(all.data(), c->d_cnt + n, all.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  MFX_HIP(hipStreamSynchronize(st));
+  for (size_t s2 = 0; s2 < n; ++s2) recv_counts[s2] = all[s2 * n + (size_t)c->rank];
+  return MFX_OK;
+}
+
+extern "C" int mfx_comm_alltoallv(mfx_comm *c, const void *d_send, const uint64_t *send_counts, void *d_recv, const uint64_t *recv_counts,
+                                  uint32_t elem_bytes, void *stream) {
+  if (!c || !send_counts || !recv_counts || !elem_bytes) return mfx_fail(MFX_E_INVAL, "mfx_comm_alltoallv: null argument");
+  DeviceScope ds(c->device);
+  if (!ds.ok) return mfx_fail(MFX_E_HIP, "hipSetDevice(%d) failed", c->device);
+  hipStream_t st = (hipStream_t)stream;
+  uint64_t so = 0, ro = 0;
+  for (int r = 0; r < c->nranks; ++r) { so += send_counts[r]; ro += recv_counts[r]; }
+  if ((so && !d_send) || (ro && !d_recv)) return mfx_fail(MFX_E_INVAL, "mfx_comm_alltoallv: null buffer");
+  so = ro = 0;
+  MFX_NCCL(ncclGroupStart());
+  ncclResult_t bad = ncclSuccess;
+  for (int r = 0; r < c->nranks; ++r) {
+    if (send_counts[r] && bad == ncclSuccess)
+      bad = ncclSend((const char *)d_send + so * elem_bytes, send_counts[r] * elem_bytes, ncclUint8, r, c->comm, st);
+    if (recv_counts[r] && bad == ncclSuccess)
+      bad = ncclRecv((char *)d_recv + ro * elem_bytes, recv_counts[r] * elem_bytes, ncclUint8, r, c->comm, st);
+    so += send_counts[r];
+    ro += recv_counts[r];
+  }
+  const ncclResult_t ge = ncclGroupEnd();
+  if (bad != ncclSuccess) return mfx_fail(MFX_E_HIP, "ncclSend / ncclRecv of the routed k-mers failed: %s", ncclGetErrorString(bad));
+  if (ge != ncclSuccess) return mfx_fail(MFX_E_HIP, "ncclGroupEnd failed: %s", ncclGetErrorString(ge));
   return MFX_OK;
 }

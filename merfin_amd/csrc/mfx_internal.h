@@ -137,6 +137,7 @@ struct mfx_seq {
   uint64_t *d_codes = nullptr;
   uint32_t *d_valid = nullptr;
   bool      bases_stale = false;
+  bool      planes_ok = false;       // the planes hold the current sequence (a packed upload, mfx_seq_pack, a replica)
   uint64_t *d_contig_off = nullptr;  // [ncontigs]   byte offset of each contig
   uint64_t *d_contig_len = nullptr;  // [ncontigs]
   uint64_t *d_tile_start = nullptr;  // [ncontigs+1] first tile of each contig

@@ -1440,6 +1440,21 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_unpack_kernel(const uint64_t *c
   }
 }
 
+// ASCII bases -> packed planes, the whole buffer at once (the device-side twin of the host packer csrc/mfx_pack.cpp; the
+// per-tile form is mfx_tile_fill): one thread per 16 bases
+__global__ __launch_bounds__(MFX_BLOCK) void mfx_pack_kernel(const uint8_t *bases, uint64_t *codes, uint32_t *valid, uint64_t nwords) {
+  const uint64_t stride = (uint64_t)gridDim.x * MFX_BLOCK;
+  uint32_t *c32 = reinterpret_cast<uint32_t *>(codes);
+  uint16_t *v16 = reinterpret_cast<uint16_t *>(valid);
+  for (uint64_t i = (uint64_t)blockIdx.x * MFX_BLOCK + threadIdx.x; i < 2 * nwords; i += stride) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(bases + 16 * i);
+    uint32_t c, ok;
+    mfx_pack16(v, c, ok);
+    c32[i ^ 1] = c;                      // first 16 bases of a 32-base word are its HIGH half
+    v16[i ^ 1] = (uint16_t)ok;
+  }
+}
+
 // dst[i] += src[i]: the value arrays of the shards of one index add up to the whole index's values (every k-mer has
 // exactly one owner; the other shards answer 0)
 __global__ __launch_bounds__(MFX_BLOCK) void mfx_add_u32_kernel(uint32_t *dst, const uint32_t *src, uint64_t n) {
@@ -1652,6 +1667,13 @@ hipError_t mfx_k_unpack(const uint64_t *codes, const uint32_t *valid, uint8_t *b
   uint64_t blocks = (2 * nwords + MFX_BLOCK - 1) / MFX_BLOCK;
   if (blocks > 65536) blocks = 65536;
   mfx_unpack_kernel<<<(unsigned)blocks, MFX_BLOCK, 0, st>>>(codes, valid, bases, nwords);
+  return hipGetLastError();
+}
+hipError_t mfx_k_pack(const uint8_t *bases, uint64_t *codes, uint32_t *valid, uint64_t nwords, hipStream_t st) {
+  if (nwords == 0) return hipSuccess;
+  uint64_t blocks = (2 * nwords + MFX_BLOCK - 1) / MFX_BLOCK;
+  if (blocks > 65536) blocks = 65536;
+  mfx_pack_kernel<<<(unsigned)blocks, MFX_BLOCK, 0, st>>>(bases, codes, valid, nwords);
   return hipGetLastError();
 }
 hipError_t mfx_k_add_u32(uint32_t *dst, const uint32_t *src, uint64_t n, hipStream_t st) {

@@ -100,11 +100,29 @@ def exchange_device(keys, contigs, send_counts):
     return rk, rcg
 
 
-def sharded_hist(ev, router, seqs, rank, world, counts, kover, stream=None, exchange=exchange_device):
+def exchange_comm(comm, stream=None):
+    """the same exchange through the library's own collective (csrc/mfx_comm.cpp: one RCCL group of point-to-point
+    sends / receives over xGMI per array): no torch process group touches the data path"""
+    def ex(keys, contigs, send_counts):
+        import torch
+        rc = comm.exchange_counts(send_counts, stream=stream)
+        n_out = int(rc.sum())
+        rk = torch.empty(n_out, dtype=keys.dtype, device=keys.device)
+        rcg = torch.empty(n_out, dtype=contigs.dtype, device=keys.device)
+        comm.alltoallv(keys, send_counts, rk, rc, 8, stream=stream)
+        comm.alltoallv(contigs, send_counts, rcg, rc, 4, stream=stream)
+        return rk, rcg
+    return ex
+
+
+def sharded_hist(ev, router, seqs, rank, world, counts, kover, stream=None, exchange=exchange_device, comm=None):
     """-hist over a sharded index.  `ev`/`router` are bound to THIS rank's shard of
     the index; `seqs` is the whole assembly (every rank holds it); this rank routes
-    its tile range.  Accumulates into counts/kover (device tensors) and all-reduces."""
+    its tile range.  Accumulates into counts/kover (device tensors) and all-reduces.
+    comm (binding.Comm): exchange and reduction go through the library's RCCL path instead of torch.distributed."""
     import torch
+    if comm is not None:
+        exchange = exchange_comm(comm, stream)
     T = seqs.ntiles
     lo, hi = shard(T, rank, world)
     per = router.max_tiles
@@ -120,6 +138,9 @@ def sharded_hist(ev, router, seqs, rank, world, counts, kover, stream=None, exch
         if rk.numel():
             ev.hist_keys_launch(rk, rc, rk.numel(), seqs.ncontigs, counts, kover, stream=stream)
         torch.cuda.synchronize()                           # rk/rc are released after this round
+    if comm is not None:
+        comm.hist_allreduce(ev, counts, kover, seqs.ncontigs, stream=stream)
+        return counts, kover
     return all_reduce_hist(counts, kover)
 
 

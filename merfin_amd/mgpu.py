@@ -125,6 +125,13 @@ def main(argv=None):
         else:
             dist.init_process_group(backend)
     log = (lambda *x: print(*x, file=sys.stderr, flush=True)) if rank == 0 else (lambda *x: None)
+    # the data-path collectives (all-reduce of the counts image, the all-to-all of a sharded index) are the library's own,
+    # on RCCL (csrc/mfx_comm.cpp); torch.distributed stays the control plane (rendezvous, barriers, object gathers)
+    comm = None
+    if world > 1 and backend == "nccl":
+        uid = [m.Comm.unique_id().tobytes() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        comm = m.Comm(np.frombuffer(uid[0], dtype=np.uint8), rank, world, device=local)
 
     names, seqs = read_sequences(a.sequence) if a.sequence else ([], [])
     rdb = m.db_probe(a.readmers)
@@ -229,7 +236,9 @@ def main(argv=None):
     def reduce_all():
         if world == 1:
             return
-        if backend == "nccl":
+        if comm is not None:
+            comm.hist_allreduce(ev, counts, kover, sq.ncontigs, stream=stream)
+        elif backend == "nccl":
             D.all_reduce_hist(counts, kover)
         else:
             c, kv = counts.cpu(), kover.cpu()
@@ -241,7 +250,7 @@ def main(argv=None):
     if a.sharded and world > 1:
         router = m.Router(ix, world, min(a.chunk_tiles, max(1, sq.ntiles)))
         if backend == "nccl":
-            D.sharded_hist(ev, router, sq, rank, world, counts, kover, stream=stream)
+            D.sharded_hist(ev, router, sq, rank, world, counts, kover, stream=stream, comm=comm)
         else:
             T = sq.ntiles
             lo, hi = D.shard(T, rank, world)

@@ -294,7 +294,11 @@ def test_cli_sequence_read_overlaps_the_index_build(tmp_path):
         f.write(gzip.compress(b">ctg0\n" + contigs[0] + b"\n"))
         f.write(gzip.compress(b">ctg1\n" + contigs[1] + b"\n>ctg2\n" + contigs[2] + b"\n"))
     base = ["-hist", "-readmers", str(tmp_path / "read.mfxk"), "-peak", str(peak)]
-    for i, (fa, env, note) in enumerate([(plain, {"MFX_CLI_OVERLAP": "1"}, False), (plain, {}, False), (gz1, {}, False), (gz1, {"MFX_CLI_OVERLAP": "0"}, False), (gz2, {}, True)]):
+    # (-hist builds a sequence-only index by default, which needs the sequence first: the overlap belongs to the full
+    # tables, MFX_CLI_FULL_INDEX=1; the last case is the default -hist on the two-member .gz)
+    full = {"MFX_CLI_FULL_INDEX": "1"}
+    for i, (fa, env, note) in enumerate([(plain, dict(full, MFX_CLI_OVERLAP="1"), False), (plain, full, False), (gz1, full, False),
+                                         (gz1, dict(full, MFX_CLI_OVERLAP="0"), False), (gz2, full, True), (gz2, {}, False)]):
         out = str(tmp_path / ("g%d.hist" % i))
         r = subprocess.run([EXE] + base + ["-sequence", fa, "-output", out], capture_output=True, text=True, env=dict(os.environ, MFX_CLI_TIMING="1", **env))
         assert r.returncode == 0, r.stderr

@@ -203,6 +203,14 @@ def test_rccl_communicator_world_of_one():
     res = ev.result_from_counts(h, kb, seqs.ncontigs).add_overflow(rec)
     assert_hist_equal(res, g, ka, km, k)
     assert len(ev.take_overflow()) == 0                       # the gather consumed the list
+    # the sharded index's exchange with nranks = 1: everything goes to (and comes from) this rank
+    send = torch.arange(1000, dtype=torch.int64, device="cuda")
+    recv = torch.zeros(1000, dtype=torch.int64, device="cuda")
+    rc = comm.exchange_counts([777], stream=s)
+    assert list(rc) == [777]
+    comm.alltoallv(send, [777], recv, rc, 8, stream=s)
+    torch.cuda.synchronize()
+    assert torch.equal(recv[:777], send[:777]) and int(recv[777:].abs().sum()) == 0
     comm.close()
 
 
