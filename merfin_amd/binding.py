@@ -21,7 +21,8 @@ class MfxError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libmerfin_amd.so")
+    # MFX_LIB: another build of the same sources (kernel A/B experiments: tools/ab_build.sh); never a different ABI
+    return os.environ.get("MFX_LIB") or os.path.join(_HERE, "libmerfin_amd.so")
 
 
 class _KP(C.Structure):

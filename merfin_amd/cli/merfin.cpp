@@ -541,7 +541,9 @@ int main(int argc, char **argv) {
   if (rdb.format == MFX_DB_MERYL || (G.seqDBname && adb.format == MFX_DB_MERYL))
     fprintf(stderr, "-- NOTE: meryl database directories are decoded from a recalled description of the format; it has not been\n"
                     "--       checked against upstream meryl.  The decoder cross-checks every database against its own index\n"
-                    "--       statistics; `meryl print` text is the verified interchange form (tools/meryl_conformance.py).\n");
+                    "--       statistics; `meryl print` text is the verified interchange form.  To validate the decoder on this\n"
+                    "--       database: python tools/meryl_conformance.py <db.meryl> <output of `meryl print db.meryl`>\n"
+                    "--       (= MFX_REAL_MERYL_DB / MFX_REAL_MERYL_PRINT for tests/test_gpu_meryl_conformance.py).\n");
   lap("probe k-mer databases");
   // sequences (load_Sequence, merfin-globals.C:165-197; loadSequence, merfin.C:30-53).  The file is read (and, for
   // .gz/.bz2/.xz, decompressed) by its own thread from here on; with -seqmers nothing needs the sequence before the

@@ -108,6 +108,7 @@ struct mfx_hist_lds {
   double   term[MFX_KLUT * MFX_KLUT];
   uint32_t lut_ok;
   uint64_t next[2];                       // dynamic tile scheduler: the tile fetched for the next iteration
+  uint64_t tot[2];                        // mfx_hist_kernel: valid / missing k-mers of the contigs this block already flushed (thread 0)
   uint64_t red[MFX_BLOCK / 64][3];
   double   dred[MFX_BLOCK];
 };
@@ -136,8 +137,9 @@ __device__ __forceinline__ void mfx_hist_lds_init(mfx_hist_lds &H, const mfx_kst
 
 // One evaluated k-mer: merfin-histogram.C:63-90 after the lookups.  Returns true when the
 // k-mer is "missing" (readK == 0).
+template <class Counter>
 __device__ __forceinline__ bool mfx_hist_eval(mfx_hist_lds &H, const mfx_kstar_args &ka, bool lut_ok, uint32_t readV,
-                                              uint32_t asmV, uint64_t &n_over0, double &kover) {
+                                              uint32_t asmV, Counter &n_over0, double &kover) {
   double readK, prob;
   uint32_t rki = 0xffffffffu;                                  // readK as an integer when the tables apply
   if (lut_ok && readV < MFX_MAXP_LDS) {

@@ -911,7 +911,10 @@ __device__ __forceinline__ bool mfx_tile_kmer(const mfx_tile_lds &L, int k, uint
 // -hist
 // ===========================================================================
 
-constexpr int MFX_BATCH = 4;          // independent probes in flight per lane
+#ifndef MFX_V_BATCH
+#define MFX_V_BATCH 4
+#endif
+constexpr int MFX_BATCH = MFX_V_BATCH;          // queries per lane and cooperative-probe sequence (tools/ab_build.sh -DMFX_V_BATCH=2: A/B)
 
 template <bool CANON, bool COMPACT>
 __global__ __launch_bounds__(MFX_BLOCK, 4) void mfx_hist_kernel(mfx_hist_args a) {
@@ -925,8 +928,10 @@ __global__ __launch_bounds__(MFX_BLOCK, 4) void mfx_hist_kernel(mfx_hist_args a)
   mfx_hist_lds_init(H, ka);
   const bool lut_ok = H.lut_ok != 0u;
 
-  uint64_t n_valid = 0, n_missing = 0, n_over0 = 0;     // per-lane counters
-  uint64_t tot_valid = 0, tot_missing = 0;               // block totals of the contigs already flushed (thread 0)
+  // per-lane counters: 16 positions per tile and lane, so 32 bits hold 2^28 tiles of one block (a terabase); they are
+  // widened when they leave the lane.  The block's running totals live in LDS (only thread 0 touches them).
+  uint32_t n_valid = 0, n_missing = 0, n_over0 = 0;
+  if (tid == 0) H.tot[0] = H.tot[1] = 0;
   uint64_t *c_glob = ka.counts + 2ull * ka.nbins;        // kasm, kmissing, novf
   uint64_t *c_kasm = c_glob + 3, *c_kmis = c_kasm + ka.ncontigs;
 
@@ -952,8 +957,8 @@ __global__ __launch_bounds__(MFX_BLOCK, 4) void mfx_hist_kernel(mfx_hist_args a)
         if (tid == 0 && (x | y)) {
           atomicAdd((unsigned long long *)&c_kasm[c], x);
           atomicAdd((unsigned long long *)&c_kmis[c], y);
-          tot_valid += x;                                // the global totals leave the block once, at its end:
-          tot_missing += y;                              // a fragmented assembly changes contig on every tile
+          H.tot[0] += x;                                 // the global totals leave the block once, at its end:
+          H.tot[1] += y;                                 // a fragmented assembly changes contig on every tile
         }
         n_valid = n_missing = 0;
       }
@@ -1026,8 +1031,8 @@ __global__ __launch_bounds__(MFX_BLOCK, 4) void mfx_hist_kernel(mfx_hist_args a)
         atomicAdd((unsigned long long *)&c_kasm[c], x);
         atomicAdd((unsigned long long *)&c_kmis[c], y);
       }
-      if (tot_valid + x) atomicAdd((unsigned long long *)&c_glob[0], tot_valid + x);
-      if (tot_missing + y) atomicAdd((unsigned long long *)&c_glob[1], tot_missing + y);
+      if (H.tot[0] + x) atomicAdd((unsigned long long *)&c_glob[0], H.tot[0] + x);
+      if (H.tot[1] + y) atomicAdd((unsigned long long *)&c_glob[1], H.tot[1] + y);
       if (z) atomicAdd((unsigned long long *)&ka.counts[ka.nbins], z);
     }
   }

@@ -217,11 +217,19 @@ struct vcfFile {                                         /* vcf.H:89-125 */
   }
 };
 
+/* The lookups of varMer::score, injectable: cb != NULL replaces kmerIterator + getK(fmer, rmer) by a caller-supplied
+ * function of the k-mer's TEXT (k bases, all ACGT) -- the k-agnostic form used to pin the 32 <= k <= 64 path, whose k-mers
+ * do not fit the 64-bit orc_kiter / orc_lookup (tests: a plain-Python getK over arbitrary-precision k-mers,
+ * oracle/plain.py).  The validity rule is kmerIterator's: a k-mer ends at a base iff the k bases up to it are ACGT. */
+typedef void (*orc_getk_text_fn)(void *ctx, const char *kmer, int k, double *readK, double *asmK, double *prob);
+
 struct Globals {
   const orc_params *p;
   const orc_lookup *R, *A;
   int reportType;
   uint32_t comb;
+  orc_getk_text_fn cb = nullptr;
+  void *cb_ctx = nullptr;
 };
 
 struct varMer {                                          /* varMer.H, varMer.C */
@@ -260,11 +268,16 @@ struct varMer {                                          /* varMer.H, varMer.C *
       m_dks.clear();
       idx = 0;
       orc_kiter kiter;
-      orc_kiter_init(&kiter, g->p->k, seq.c_str(), seq.size());
+      orc_kiter_init(&kiter, g->cb ? 1 : g->p->k, seq.c_str(), seq.size());   /* cb: only its per-byte stepping is used */
+      uint64_t run = 0, at = 0;                                                /* cb: valid bases ending at byte `at` */
       while (orc_kiter_next_base(&kiter)) {
         readK = 0;
         asmK = 0;
-        if (orc_kiter_is_valid(&kiter))
+        if (g->cb) {
+          run = orc_base_code((unsigned char)seq[at]) >= 0 ? run + 1 : 0;
+          if (run >= K) g->cb(g->cb_ctx, seq.c_str() + at + 1 - K, (int)K, &readK, &asmK, &prob);
+          at++;
+        } else if (orc_kiter_is_valid(&kiter))
           orc_getK_kmers(g->p, g->R, g->A, kiter.fmer, kiter.rmer, &readK, &asmK, &prob);
         if (readK == 0)
           numM++;
@@ -525,10 +538,31 @@ string traverse(uint32_t idx, vector<uint32_t> &refIdxList, vector<uint32_t> ref
  * (headers + selected records) to out_path; optional debug_path receives the
  * -debug lines (merfin-variants.C:240-276) as plain text; `log` receives the
  * PANIC / WARNING lines.  Returns the number of clusters evaluated, <0 on error. */
+static long variants_run_impl(const orc_params *p, const orc_lookup *R, const orc_lookup *A, orc_getk_text_fn cb, void *cb_ctx, int mode, uint32_t comb,
+                              int nosplit, const char *vcf_path, const char *const *names, const char *const *contigs,
+                              const uint64_t *lens, uint32_t ncontigs, const char *out_path, const char *debug_path,
+                              const char *log_path);
+
 extern "C" long orc_variants_run(const orc_params *p, const orc_lookup *R, const orc_lookup *A, int mode, uint32_t comb,
                                  int nosplit, const char *vcf_path, const char *const *names, const char *const *contigs,
                                  const uint64_t *lens, uint32_t ncontigs, const char *out_path, const char *debug_path,
                                  const char *log_path) {
+  return variants_run_impl(p, R, A, nullptr, nullptr, mode, comb, nosplit, vcf_path, names, contigs, lens, ncontigs, out_path, debug_path, log_path);
+}
+
+/* the same with the lookups supplied by the caller (p->k may exceed 31; p->peak and the -prob table are the callback's business) */
+extern "C" long orc_variants_run_cb(const orc_params *p, orc_getk_text_fn cb, void *cb_ctx, int mode, uint32_t comb,
+                                    int nosplit, const char *vcf_path, const char *const *names, const char *const *contigs,
+                                    const uint64_t *lens, uint32_t ncontigs, const char *out_path, const char *debug_path,
+                                    const char *log_path) {
+  if (!cb) return -3;
+  return variants_run_impl(p, nullptr, nullptr, cb, cb_ctx, mode, comb, nosplit, vcf_path, names, contigs, lens, ncontigs, out_path, debug_path, log_path);
+}
+
+static long variants_run_impl(const orc_params *p, const orc_lookup *R, const orc_lookup *A, orc_getk_text_fn cb, void *cb_ctx, int mode, uint32_t comb,
+                              int nosplit, const char *vcf_path, const char *const *names, const char *const *contigs,
+                              const uint64_t *lens, uint32_t ncontigs, const char *out_path, const char *debug_path,
+                              const char *log_path) {
   vcfFile vcf;
   if (!vcf.loadFile(vcf_path)) return -1;
   vcf.mergeChrPosGT((uint32_t)p->k, comb, nosplit != 0);                     /* merfin-globals.C:216-217 */
@@ -537,7 +571,7 @@ extern "C" long orc_variants_run(const orc_params *p, const orc_lookup *R, const
   FILE *dbg = debug_path ? fopen(debug_path, "w") : nullptr;
   FILE *log = log_path ? fopen(log_path, "w") : nullptr;
   for (auto &h : vcf._headers) fprintf(out, "%s\n", h.c_str());              /* merfin-variants.C:332-333 */
-  Globals G{p, R, A, mode, comb};
+  Globals G{p, R, A, mode, comb, cb, cb_ctx};
   const uint32_t K = (uint32_t)p->k;
   long nclusters = 0;
   uint64_t varMerId = 0;

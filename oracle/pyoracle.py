@@ -103,8 +103,14 @@ def lib():
     L.orc_variants_run.restype = C.c_long
     L.orc_variants_run.argtypes = [C.POINTER(_Params), C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_char_p,
                                    C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), u64p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_char_p]
+    L.orc_variants_run_cb.restype = C.c_long
+    L.orc_variants_run_cb.argtypes = [C.POINTER(_Params), GETK_TEXT_FN, C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_char_p,
+                                      C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), u64p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_char_p]
     _lib = L
     return L
+
+
+GETK_TEXT_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_char), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
 
 
 _libc = C.CDLL(None)
@@ -317,4 +323,27 @@ def variants_run(p, R, A, mode, vcf_path, names, contigs, out_path, comb=15, nos
                                 debug_path.encode() if debug_path else None, log_path.encode() if log_path else None)
     if rc < 0:
         raise RuntimeError("orc_variants_run failed: %d" % rc)
+    return rc
+
+
+def variants_run_text(k, getk, mode, vcf_path, names, contigs, out_path, comb=15, nosplit=False, debug_path=None, log_path=None):
+    """the same with the lookups supplied as a Python function getk(kmer_text) -> (readK, asmK, prob) of the k-mer's text
+    (k bases, ACGT): k-agnostic -- the oracle of the variant modes at 32 <= k <= 64 (oracle/plain.py holds the k-mers as
+    Python integers).  Everything above the lookups is the C++ restatement unchanged."""
+    n = len(contigs)
+    nm = (C.c_char_p * n)(*[x.encode() for x in names])
+    arr = (C.c_char_p * n)(*contigs)
+    lens = np.array([len(c) for c in contigs], dtype=np.uint64)
+
+    def cb(_ctx, text, kk, rk, ak, pr):
+        a, b, c = getk(C.string_at(text, kk).decode())
+        rk[0], ak[0], pr[0] = a, b, c
+
+    fn = GETK_TEXT_FN(cb)
+    p = Params(k, 1.0)                         # only p.k matters on this path
+    rc = lib().orc_variants_run_cb(p.ref(), fn, None, VARIANT_MODES[mode], comb, 1 if nosplit else 0, vcf_path.encode(),
+                                   nm, arr, _u64(lens), n, out_path.encode(),
+                                   debug_path.encode() if debug_path else None, log_path.encode() if log_path else None)
+    if rc < 0:
+        raise RuntimeError("orc_variants_run_cb failed: %d" % rc)
     return rc

@@ -107,7 +107,8 @@ def world(k=21, sizes=(30000, 9000, 4096, 4097, 500, 20, 0, 8191), peak=17.3, se
 # variant worlds: truth genome, an assembly carrying errors, and a VCF that
 # proposes corrections (true ones, decoys and malformed/edge-case records)
 # ---------------------------------------------------------------------------
-def variant_world(k=21, sizes=(12000, 5000, 300), peak=17.3, seed=SEED, burst=0.08, base_rate=0.002, decoys=60):
+def variant_world(k=21, sizes=(12000, 5000, 300), peak=17.3, seed=SEED, burst=0.08, base_rate=0.002, decoys=60, tables=True):
+    """tables=False: (names, asm, vcf, truth contigs) -- the caller counts the k-mers itself (k > 31: oracle/plain.py)"""
     r = rng(seed)
     truth = [random_contig(r, n) for n in sizes]
     names = ["ctg%d" % i for i in range(len(sizes))]
@@ -196,6 +197,8 @@ def variant_world(k=21, sizes=(12000, 5000, 300), peak=17.3, seed=SEED, burst=0.
     vcf.insert(8, "ctg0\t100\t.\tA\tC\t3\tq40\t.\tGT")           # only 9 columns -> excluded
     vcf.insert(12, "ghost\t10\t.\tA\tC\t3\tPASS\t.\tGT\t1/1")      # chromosome absent from the FASTA
     tb = [t.tobytes() for t in truth]
+    if not tables:
+        return names, asm, "\n".join(vcf) + "\n", tb
     rk, rv = read_counts(r, k, tb, peak, err_kmers=500)
     ak, av = po.count_kmers(k, asm)
     return names, asm, "\n".join(vcf) + "\n", (rk, rv), (ak, av)

@@ -242,3 +242,52 @@ def test_randomized_wide_k_against_plain_oracle(seed, monkeypatch):
     seqs = m.Sequences([c.encode() for c in contigs])
     assert_hist(ev.hist(seqs), contigs, k, peak, [], [], R, A)
     assert_hist(ev.hist_streamed(m.Sequences.create([len(c) for c in contigs]), [c.encode() for c in contigs]), contigs, k, peak, [], [], R, A)
+
+
+@pytest.mark.parametrize("mode,k,seed", [("polish", 33, 21), ("filter", 41, 22), ("better", 64, 23), ("strict", 41, 24), ("loose", 33, 25), ("polish", 64, 26)])
+def test_variant_modes_with_128_bit_kmers(mode, k, seed, tmp_path):
+    """-filter / -polish / -better / -strict / -loose at 32 <= k <= 64 (the reference's kmer holds 2k <= 128 bits:
+    varMer.C:108): VCF and -debug text byte-identical to the C++ restatement of merfin-variants.C / varMer.C with its
+    lookups supplied by the k-agnostic plain-Python getK (oracle.pyoracle.variants_run_text; that form equals the 64-bit
+    k-mer-iterator form byte for byte at k <= 31: tests/test_oracle_vs_numpy.py)"""
+    import merfin_amd as m
+    from oracle import pyoracle as po
+    from tests import synth
+    peak = 9.0
+    names, asm, vcf, truth = synth.variant_world(k=k, peak=peak, seed=seed, sizes=(6000, 2500, 300), tables=False)
+    vp = str(tmp_path / "in.vcf")
+    open(vp, "w").write(vcf)
+    r = np.random.default_rng(seed)
+    T = plain.count_kmers(k, [t.decode() for t in truth])
+    R = {}
+    for x, c in T.items():
+        v = int(r.poisson(peak * c))
+        if v:
+            R[x] = v
+    for _ in range(300):                                      # error k-mers
+        w = "".join(r.choice(list("ACGT"), size=k))
+        R.setdefault(min(plain.enc(w), plain.enc(plain.revcomp(w))), int(r.integers(1, 4)))
+    A = plain.count_kmers(k, [a.decode() for a in asm])
+
+    def getk(text):
+        rv, av = plain.values(k, text.upper(), R, A)
+        return plain.getK(peak, [], [], rv, av)
+
+    n_o = po.variants_run_text(k, getk, mode, vp, names, asm, str(tmp_path / "o.vcf"), comb=9, debug_path=str(tmp_path / "o.dbg"),
+                               log_path=str(tmp_path / "o.log"))
+    ev = m.Evaluator(build(m, k, R, A), m.KParams(peak))
+    n_g = ev.variants(mode, vp, names, asm, str(tmp_path / "g.vcf"), comb=9, debug_path=str(tmp_path / "g.dbg"), log_path=str(tmp_path / "g.log"))
+    assert n_g == n_o and n_o > 10
+    assert open(tmp_path / "g.vcf").read() == open(tmp_path / "o.vcf").read()
+    assert open(tmp_path / "g.dbg").read() == open(tmp_path / "o.dbg").read()
+    assert len([l for l in open(tmp_path / "g.vcf") if not l.startswith("#")]) > 10
+
+
+def test_wide_index_is_not_sharded():
+    """a sharded index handles k <= 31 (BASELINE config 5, the sharded one, uses k = 31): the 128-bit path refuses cleanly"""
+    import merfin_amd as m
+    ix = m.Index(41, 1000)
+    with pytest.raises(m.MfxError, match="k <= 31"):
+        ix.set_shard(0, 2)
+    with pytest.raises(m.MfxError, match="k <= 31"):
+        m.Router(ix, 2, 4)

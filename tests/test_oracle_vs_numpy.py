@@ -95,3 +95,31 @@ def test_plain_completeness_and_filter_against_c_oracle():
         assert {i: int(v) for i, v in enumerate(h.undr()) if v} == undr and {i: int(v) for i, v in enumerate(h.over()) if v} == over
     assert plain.count_kmers(k, [c.decode() for c in contigs]) == A
     assert plain.dec(plain.enc("ACGTTGCA"), 8) == "ACGTTGCA"
+
+
+@pytest.mark.parametrize("mode,k,seed", [("polish", 21, 11), ("filter", 15, 12), ("loose", 21, 13), ("strict", 31, 14), ("better", 11, 15)])
+def test_variants_with_injected_text_lookups_equal_the_kmer_iterator_form(mode, k, seed, tmp_path):
+    """orc_variants_run_cb -- varMer::score's lookups supplied as a function of the k-mer TEXT, here the plain-Python getK
+    over dict counts -- must reproduce orc_variants_run (kmerIterator + merylExactLookup restatement) byte for byte: it is
+    the form that pins the variant modes at 32 <= k <= 64, where the C oracle's 64-bit k-mers end"""
+    from oracle import plain
+    from tests import synth
+    peak = 17.3
+    names, asm, vcf, read, amers = synth.variant_world(k=k, peak=peak, seed=seed, sizes=(6000, 2500, 300))
+    vp = str(tmp_path / "in.vcf")
+    open(vp, "w").write(vcf)
+    p = po.Params(k, peak)
+    n0 = po.variants_run(p, po.Lookup(k, *read), po.Lookup(k, *amers), mode, vp, names, asm, str(tmp_path / "a.vcf"), comb=9,
+                         debug_path=str(tmp_path / "a.dbg"), log_path=str(tmp_path / "a.log"))
+    R = dict(zip(read[0].tolist(), read[1].tolist()))
+    A = dict(zip(amers[0].tolist(), amers[1].tolist()))
+
+    def getk(text):
+        rv, av = plain.values(k, text.upper(), R, A)
+        return plain.getK(peak, [], [], rv, av)
+
+    n1 = po.variants_run_text(k, getk, mode, vp, names, asm, str(tmp_path / "b.vcf"), comb=9, debug_path=str(tmp_path / "b.dbg"),
+                              log_path=str(tmp_path / "b.log"))
+    assert n0 == n1 and n0 > 10
+    for ext in ("vcf", "dbg", "log"):
+        assert (tmp_path / ("a." + ext)).read_bytes() == (tmp_path / ("b." + ext)).read_bytes(), ext
