@@ -23,6 +23,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 
 #include <algorithm>
 #include <atomic>
@@ -55,24 +56,76 @@ std::vector<std::string> split_any(const std::string &s, const char *seps) {
 
 
 // ---- VCF model -------------------------------------------------------------
+// Every text field is a VIEW into the VCF file image, which the database keeps (VcfDB::text): a config-4 call set has
+// millions of records, and a std::string per field (ten per record, plus the ALT list) was most of the load time.
+struct SV {                           // a piece of the file image
+  const char *p = nullptr;
+  uint32_t n = 0;
+  size_t size() const { return n; }
+  bool eq(const SV &o) const { return n == o.n && memcmp(p, o.p, n) == 0; }
+  std::string str() const { return std::string(p, n); }
+};
+inline std::string &operator+=(std::string &s, const SV &v) { return s.append(v.p, v.n); }
+
+// word `i` of s split at any char of `seps`, splitToWords semantics (runs of separators collapse); n = 0 and p = nullptr
+// when there is no such word
+inline SV word_at(const SV &s, const char *seps, size_t i) {
+  size_t at = 0, w = 0;
+  while (at < s.n) {
+    while (at < s.n && strchr(seps, s.p[at])) ++at;
+    if (at >= s.n) break;
+    size_t b = at;
+    while (at < s.n && !strchr(seps, s.p[at])) ++at;
+    if (w++ == i) { SV r; r.p = s.p + b; r.n = (uint32_t)(at - b); return r; }
+  }
+  return SV();
+}
+inline size_t count_words(const SV &s, const char *seps) {
+  size_t at = 0, w = 0;
+  while (at < s.n) {
+    while (at < s.n && strchr(seps, s.p[at])) ++at;
+    if (at >= s.n) break;
+    while (at < s.n && !strchr(seps, s.p[at])) ++at;
+    ++w;
+  }
+  return w;
+}
+
 struct Record {                       // vcfRecord
-  std::string chr, id, ref, alts, filter, info, formats, samples;
-  uint32_t pos = 0;
+  SV chr, id, ref, alts, filter, info, formats, samples;
+  SV gt_field;                       // _arr_samples[0]
+  uint32_t pos = 0, n_alts = 0;      // n_alts = words of ALT (_arr_alts)
   double qual = 0;
-  std::vector<std::string> alt_list; // _arr_alts
-  std::string gt_field;              // _arr_samples[0]
+  bool ok = false;                   // false: fewer than 10 columns, "excluded" (vcfRecord.H:53-56)
   std::string line() const {         // vcfRecord::save, vcfRecord.H:96-97
     char q[64];
     snprintf(q, sizeof(q), "%.1f", qual);
-    return chr + "\t" + std::to_string((int)pos) + "\t" + id + "\t" + ref + "\t" + alts + "\t" + q + "\t" + filter + "\t" + info + "\t" + formats + "\t" + samples + "\n";
+    std::string o;
+    o.reserve(chr.n + id.n + ref.n + alts.n + filter.n + info.n + formats.n + samples.n + 40);
+    o += chr; o += '\t'; o += std::to_string((int)pos); o += '\t'; o += id; o += '\t'; o += ref; o += '\t'; o += alts; o += '\t';
+    o += q; o += '\t'; o += filter; o += '\t'; o += info; o += '\t'; o += formats; o += '\t'; o += samples; o += '\n';
+    return o;
   }
 };
 
 struct Variant {                      // gtAllele
-  const Record *rec;
-  uint32_t pos, refLen;
-  double qual;
-  std::vector<const std::string *> alleles;   // [0] = REF; empty for ./. and 0/0 genotypes
+  const Record *rec = nullptr;
+  uint32_t pos = 0, refLen = 0;
+  double qual = 0;
+  // [0] = REF; none for ./. and 0/0 genotypes.  Two or three alleles is the rule: they live in the object.
+  SV few[4];
+  uint32_t n_alleles = 0;
+  std::vector<SV> many;              // only beyond four alleles
+  size_t nalleles() const { return n_alleles; }
+  const SV &allele(size_t i) const { return n_alleles <= 4 ? few[i] : many[i]; }
+  void push(const SV &a) {
+    if (n_alleles < 4) few[n_alleles] = a;
+    else {
+      if (n_alleles == 4) many.assign(few, few + 4);
+      many.push_back(a);
+    }
+    ++n_alleles;
+  }
 };
 
 struct Cluster {                      // posGT
@@ -81,59 +134,80 @@ struct Cluster {                      // posGT
 };
 
 struct VcfDB {
+  std::string text;                   // the file image every SV points into
   std::vector<std::string> headers;
-  std::vector<Record *> records;
-  std::vector<Variant *> variants;
+  std::vector<Record> rec_store;      // one per data line (excluded ones included), file order
+  std::vector<Variant> var_store;
+  size_t n_records = 0;               // records loaded (not excluded)
   std::map<std::string, std::vector<Cluster *>> by_chr;
+  std::map<std::string, std::vector<std::pair<size_t, size_t>>> runs;   // per CHROM: its runs [begin, end) of rec_store, file order
   uint64_t excluded = 0;
   int contig_ids = 0;
   ~VcfDB() {
-    for (auto r : records) delete r;
-    for (auto v : variants) delete v;
     for (auto &kv : by_chr) for (auto c : kv.second) delete c;
   }
 };
 
 // gtAllele::gtAllele, vcf.C:23-87
-Variant *make_variant(const Record *r) {
-  Variant *v = new Variant;
+void make_variant(const Record *r, Variant *v) {
   v->rec = r;
   v->pos = r->pos - 1;
   v->refLen = (uint32_t)r->ref.size();
   v->qual = r->qual;
-  const std::string &g = r->gt_field;
-  if (g.compare(0, 3, "./.") == 0 || g.compare(0, 3, "0/0") == 0)
-    return v;                                            // no alleles at all
-  v->alleles.push_back(&r->ref);
-  std::vector<int> seen_alt;
-  for (const std::string &tok : split_any(g, "|/")) {
-    long altIdx = strtol(tok.c_str(), nullptr, 10);
+  const SV &g = r->gt_field;
+  if (g.n >= 3 && (memcmp(g.p, "./.", 3) == 0 || memcmp(g.p, "0/0", 3) == 0))
+    return;                                              // no alleles at all
+  v->push(r->ref);
+  int seen_alt[8];
+  size_t n_seen = 0;
+  std::vector<int> seen_more;
+  for (size_t ti = 0;; ++ti) {
+    const SV tok = word_at(g, "|/", ti);
+    if (!tok.p) break;
+    char num[24];
+    const size_t nn = std::min<size_t>(tok.n, sizeof(num) - 1);
+    memcpy(num, tok.p, nn);
+    num[nn] = 0;
+    long altIdx = strtol(num, nullptr, 10);
     if ((int32_t)altIdx <= 0) continue;
-    if ((size_t)altIdx > r->alt_list.size()) continue;   // operator[] past the end -> nullptr
+    if ((size_t)altIdx > r->n_alts) continue;            // operator[] past the end -> nullptr
     // the reference compares POINTERS into the ALT list (same ALT index listed twice) ...
-    if (std::find(seen_alt.begin(), seen_alt.end(), (int)altIdx) != seen_alt.end()) continue;
-    const std::string &hap = r->alt_list[altIdx - 1];
-    if (hap == r->ref) continue;                         // ... and the STRING against the reference allele only
-    seen_alt.push_back((int)altIdx);
-    v->alleles.push_back(&hap);
+    bool dup = std::find(seen_alt, seen_alt + n_seen, (int)altIdx) != seen_alt + n_seen ||
+               std::find(seen_more.begin(), seen_more.end(), (int)altIdx) != seen_more.end();
+    if (dup) continue;
+    const SV hap = word_at(r->alts, ",", (size_t)altIdx - 1);
+    if (hap.eq(r->ref)) continue;                        // ... and the STRING against the reference allele only
+    if (n_seen < 8) seen_alt[n_seen++] = (int)altIdx; else seen_more.push_back((int)altIdx);
+    v->push(hap);
   }
-  return v;
 }
 
-// one data line -> record (nullptr: fewer than 10 columns, "excluded", vcfRecord.H:53-56)
-Record *parse_record(const char *L, size_t n) {
-  std::vector<std::string> w = split_any(std::string(L, n), "\t");
-  if (w.size() < 10) return nullptr;
-  Record *r = new Record;
+// one data line -> record (ok = false: fewer than 10 columns, "excluded", vcfRecord.H:53-56)
+void parse_record(const char *L, size_t n, Record *r) {
+  SV line;
+  line.p = L; line.n = (uint32_t)n;
+  SV w[10];
+  for (int i = 0; i < 10; ++i) {
+    w[i] = word_at(line, "\t", (size_t)i);               // (ten short scans of one line: still far cheaper than ten strings)
+    if (!w[i].p) return;
+  }
+  r->ok = true;
   r->chr = w[0];
-  r->pos = (uint32_t)strtoul(w[1].c_str(), nullptr, 10);
+  {
+    char num[32];
+    const size_t nn = std::min<size_t>(w[1].n, sizeof(num) - 1);
+    memcpy(num, w[1].p, nn); num[nn] = 0;
+    r->pos = (uint32_t)strtoul(num, nullptr, 10);
+    char q[64];
+    const size_t nq = std::min<size_t>(w[5].n, sizeof(q) - 1);
+    memcpy(q, w[5].p, nq); q[nq] = 0;
+    r->qual = strtod(q, nullptr);
+  }
   r->id = w[2]; r->ref = w[3]; r->alts = w[4];
-  r->qual = strtod(w[5].c_str(), nullptr);
   r->filter = w[6]; r->info = w[7]; r->formats = w[8]; r->samples = w[9];
-  r->alt_list = split_any(r->alts, ",");
-  std::vector<std::string> smp = split_any(r->samples, ":");
-  r->gt_field = smp.empty() ? std::string() : smp[0];
-  return r;
+  r->n_alts = (uint32_t)count_words(r->alts, ",");
+  r->gt_field = word_at(r->samples, ":", 0);
+  if (!r->gt_field.p) r->gt_field = SV();
 }
 
 template <class F> void parallel_for(size_t n, F &&fn);
@@ -145,8 +219,10 @@ int load_vcf(const char *path, VcfDB &db) {
   mfx_file fh = mfx_open_reader(path);
   FILE *f = fh.f;
   if (!f) return mfx_fail(MFX_E_IO, "cannot open VCF '%s'", path);
-  std::string buf;
+  std::string &buf = db.text;
   {
+    struct stat st;
+    if (!fh.is_pipe() && fstat(fileno(f), &st) == 0 && S_ISREG(st.st_mode)) buf.reserve((size_t)st.st_size + 1);
     std::vector<char> blk(1 << 22);
     size_t n;
     while ((n = fread(blk.data(), 1, blk.size(), f)) > 0) buf.append(blk.data(), n);
@@ -165,36 +241,33 @@ int load_vcf(const char *path, VcfDB &db) {
     }
     o = e + 1;
   }
-  std::vector<Record *> recs(lines.size(), nullptr);
-  std::vector<Variant *> vars(lines.size(), nullptr);
+  db.rec_store.resize(lines.size());
+  db.var_store.resize(lines.size());
   const size_t CH = 4096;                                  // lines per task
   parallel_for((lines.size() + CH - 1) / CH, [&](size_t c) {
     for (size_t i = c * CH, e = std::min(lines.size(), (c + 1) * CH); i < e; ++i) {
-      recs[i] = parse_record(buf.data() + lines[i].first, lines[i].second);
-      if (recs[i]) vars[i] = make_variant(recs[i]);
+      parse_record(buf.data() + lines[i].first, lines[i].second, &db.rec_store[i]);
+      if (db.rec_store[i].ok) make_variant(&db.rec_store[i], &db.var_store[i]);
     }
   });
-  db.records.reserve(lines.size());
-  db.variants.reserve(lines.size());
-  std::vector<Cluster *> *bucket = nullptr;                // records of one CHROM come in runs: one map lookup per run
-  const std::string *bucket_chr = nullptr;
+  // records of one CHROM come in runs: the runs are noted here (one map lookup per run), the clusters themselves are
+  // made per CHROM by the host threads (merge_clusters)
+  std::vector<std::pair<size_t, size_t>> *bucket = nullptr;
+  SV bucket_chr;
   for (size_t i = 0; i < lines.size(); ++i) {
-    Record *r = recs[i];
-    if (!r) { db.excluded++; continue; }
-    db.records.push_back(r);
-    Variant *v = vars[i];
-    db.variants.push_back(v);
-    Cluster *c = new Cluster;
-    c->rStart = v->pos;
-    c->rEnd = v->pos + v->refLen;
-    c->vars.push_back(v);
-    if (!bucket || *bucket_chr != r->chr) {
-      auto it = db.by_chr.find(r->chr);
-      if (it == db.by_chr.end()) it = db.by_chr.emplace(r->chr, std::vector<Cluster *>()).first;
-      bucket = &it->second;
-      bucket_chr = &it->first;
+    const Record *r = &db.rec_store[i];
+    if (!r->ok) { db.excluded++; continue; }
+    db.n_records++;
+    if (!bucket || !bucket_chr.eq(r->chr)) {
+      const std::string chr = r->chr.str();
+      db.by_chr.emplace(chr, std::vector<Cluster *>());
+      bucket = &db.runs[chr];
+      bucket_chr = r->chr;
+      bucket->emplace_back(i, i);
+    } else if (bucket->back().second != i) {
+      bucket->emplace_back(i, i);                          // an excluded line in between: a new run of the same CHROM
     }
-    bucket->push_back(c);
+    bucket->back().second = i + 1;
   }
   return MFX_OK;
 }
@@ -204,8 +277,23 @@ int load_vcf(const char *path, VcfDB &db) {
 // `comb` variants and splitting is allowed.
 void merge_clusters(VcfDB &db, uint32_t k, uint32_t comb, bool nosplit, FILE *log) {
   const uint32_t K_OFFSET = 2 * k;
-  for (auto &kv : db.by_chr) {
-    std::vector<Cluster *> &in = kv.second;
+  // one CHROM per task: its clusters are created (one per record, file order), sorted and merged independently of the
+  // others; the log lines are printed afterwards in map order, as the sequential loop printed them
+  std::vector<std::pair<const std::string *, std::vector<Cluster *> *>> chrs;
+  for (auto &kv : db.by_chr) chrs.emplace_back(&kv.first, &kv.second);
+  std::vector<std::string> logs(chrs.size());
+  parallel_for(chrs.size(), [&](size_t ci) {
+    std::vector<Cluster *> &in = *chrs[ci].second;
+    for (const auto &run : db.runs[*chrs[ci].first])
+      for (size_t i = run.first; i < run.second; ++i) {
+        if (!db.rec_store[i].ok) continue;
+        const Variant *v = &db.var_store[i];
+        Cluster *c = new Cluster;
+        c->rStart = v->pos;
+        c->rEnd = v->pos + v->refLen;
+        c->vars.push_back(v);
+        in.push_back(c);
+      }
     std::vector<Cluster *> out;
     uint32_t split = 0, merged = 0;
     // same algorithm + comparator as the reference so ties on rStart land in the same order
@@ -224,43 +312,77 @@ void merge_clusters(VcfDB &db, uint32_t k, uint32_t comb, bool nosplit, FILE *lo
       merged++;
       delete cur;
     }
-    if (log) {
-      fprintf(log, "%s : Reduced %lu variants down to %lu combinations for evaluation:\n", kv.first.c_str(), in.size(), out.size());
-      if (split > 0) fprintf(log, "%s :   Split   %u complicated combinations.\n", kv.first.c_str(), split);
-      if (merged > 0) fprintf(log, "%s :   Merged  %u variants into combinations.\n", kv.first.c_str(), merged);
-    }
+    const std::string &nm = *chrs[ci].first;
+    logs[ci] = nm + " : Reduced " + std::to_string(in.size()) + " variants down to " + std::to_string(out.size()) + " combinations for evaluation:\n";
+    if (split > 0) logs[ci] += nm + " :   Split   " + std::to_string(split) + " complicated combinations.\n";
+    if (merged > 0) logs[ci] += nm + " :   Merged  " + std::to_string(merged) + " variants into combinations.\n";
     in.swap(out);
-  }
+  });
+  if (log) for (const std::string &l : logs) fputs(l.c_str(), log);
 }
 
 // ---- allele-combination enumeration (traverse) ------------------------------
-struct PathSet {                      // varMer's per-cluster containers
-  std::vector<std::string> seqs;
-  std::vector<std::vector<int>> gt;          // gtPaths
-  std::vector<std::vector<uint32_t>> vidx;   // idxPaths (shifted offsets snapshot)
-  std::vector<std::vector<uint32_t>> vlen;   // lenPaths (post-substitution lengths snapshot)
+// varMer's per-cluster containers (seqs, gtPaths, idxPaths, lenPaths), flat: a config-4 call set makes millions of
+// paths of ~60 bases, and a std::string + three std::vectors per path was most of the host time (allocation, and the
+// page faults of a heap that only grows).  Path p is text[toff[p], toff[p+1] - 1), followed by ONE separator byte ('\n',
+// not ACGT: the whole arena is copied into the packed GPU buffer as it is); its genotype / offset / length snapshots
+// are rows p of gt / vidx / vlen (nv = variants of the cluster columns each).
+struct PathSet {
+  std::string text;
+  std::vector<uint32_t> toff;                // [np + 1]
+  std::vector<int> gt;                       // gtPaths   [np * nv]
+  std::vector<uint32_t> vidx, vlen;          // idxPaths / lenPaths (shifted offsets / post-substitution lengths snapshots) [np * nv]
+  uint32_t nv = 0;
+  std::unordered_map<uint64_t, std::vector<uint32_t>> seen;     // only once a cluster has many paths: hash -> path indices
+  size_t size() const { return toff.empty() ? 0 : toff.size() - 1; }
+  size_t len(size_t p) const { return toff[p + 1] - toff[p] - 1; }
+  const char *seq(size_t p) const { return text.data() + toff[p]; }
+  static uint64_t hash(const std::string &s) {
+    uint64_t h = 0xcbf29ce484222325ULL;
+    for (unsigned char c : s) { h ^= c; h *= 0x100000001b3ULL; }
+    return h;
+  }
+  bool same(size_t p, const std::string &s) const { return len(p) == s.size() && memcmp(seq(p), s.data(), s.size()) == 0; }
   void add(const std::string &s, const std::vector<int> &g, const std::vector<uint32_t> &ix, const std::vector<uint32_t> &ln) {
-    if (std::find(seqs.begin(), seqs.end(), s) != seqs.end()) return;    // varMer.C:39
-    seqs.push_back(s); gt.push_back(g); vidx.push_back(ix); vlen.push_back(ln);
+    const size_t np = size();
+    // varMer.C:39: a sequence already present is not added again.  Few paths: compare them all; many: by hash.
+    if (np < 32) {
+      for (size_t p = 0; p < np; ++p) if (same(p, s)) return;
+    } else {
+      if (seen.empty()) for (size_t p = 0; p < np; ++p) seen[hash(std::string(seq(p), len(p)))].push_back((uint32_t)p);
+      std::vector<uint32_t> &cand = seen[hash(s)];
+      for (uint32_t p : cand) if (same(p, s)) return;
+      cand.push_back((uint32_t)np);
+    }
+    if (toff.empty()) toff.push_back(0);
+    text.append(s);
+    text.push_back('\n');
+    toff.push_back((uint32_t)text.size());
+    gt.insert(gt.end(), g.begin(), g.end());
+    vidx.insert(vidx.end(), ix.begin(), ix.end());
+    vlen.insert(vlen.end(), ln.begin(), ln.end());
   }
 };
 
 // merfin-variants.C:22-126.  `lens` and `cand` are per-call copies, `offs` and
 // `path` are shared -- that asymmetry is part of the observable behaviour
-// (the stored snapshots feed the "new k-mer" test of scoring).
+// (the stored snapshots feed the "new k-mer" test of scoring).  `reps`: one string per recursion depth, reused for
+// every candidate built at that depth (the reference copies the candidate once per allele); the caller sizes it to the
+// cluster's variant count (references into it are held across the recursion: it must not grow here).
 void enumerate(uint32_t idx, std::vector<uint32_t> &offs, std::vector<uint32_t> lens, const Cluster &cl,
-               const std::string &cand, std::vector<int> &path, PathSet &out) {
-  const std::vector<const std::string *> &haps = cl.vars[idx]->alleles;
+               const std::string &cand, std::vector<int> &path, PathSet &out, std::vector<std::string> &reps, size_t depth) {
+  const Variant &var = *cl.vars[idx];
   const uint32_t refLen = lens[idx];
   const uint32_t last = (uint32_t)offs.size() - 1;
-  for (int j = 0; j < (int)haps.size(); ++j) {
+  for (int j = 0; j < (int)var.nalleles(); ++j) {
     path.push_back(j);
-    std::string rep = cand;
+    std::string &rep = reps[depth];
+    rep = cand;
     int skipped = 0, delta = 0;
     if (j > 0) {
-      const std::string &hap = *haps[j];
+      const SV &hap = var.allele(j);
       lens[idx] = refLen;
-      rep.replace(offs[idx], lens[idx], hap);
+      rep.replace(offs[idx], lens[idx], hap.p, hap.n);
       delta = (int)hap.size() - (int)lens[idx];
       const uint32_t affected = offs[idx] + lens[idx];
       lens[idx] = (uint32_t)hap.size();
@@ -275,8 +397,8 @@ void enumerate(uint32_t idx, std::vector<uint32_t> &offs, std::vector<uint32_t> 
       }
       for (uint32_t i = idx + 1; i < offs.size(); ++i) offs[i] += delta;
     }
-    if (idx + 1 < offs.size()) enumerate(idx + 1, offs, lens, cl, rep, path, out);
-    if (idx == last) out.add(rep, path, offs, lens);
+    if (idx + 1 < offs.size()) enumerate(idx + 1, offs, lens, cl, reps[depth], path, out, reps, depth + 1);
+    if (idx == last) out.add(reps[depth], path, offs, lens);
     for (uint32_t i = idx + 1; i < offs.size(); ++i) offs[i] -= delta;
     for (int q = 0; q < skipped; ++q) { path.pop_back(); --idx; }
     path.pop_back();
@@ -286,7 +408,8 @@ void enumerate(uint32_t idx, std::vector<uint32_t> &offs, std::vector<uint32_t> 
 // ---- scoring + selection -----------------------------------------------------
 struct Scored {
   std::vector<uint32_t> numM;
-  std::vector<std::vector<double>> ks, dks;
+  std::vector<double> totdk;                 // getTotdK of every path: the sum of its delta-K values in position order
+  std::vector<std::vector<double>> ks, dks;  // per position; kept for the -debug statistics only
 };
 
 inline int base_ok(unsigned char c) {
@@ -298,9 +421,9 @@ struct Job {                          // one cluster waiting for its GPU values
   uint32_t contig;
   uint32_t rStart, rEnd;
   PathSet ps;
-  std::vector<uint64_t> off;          // offset of each path in the packed buffer
+  uint64_t off = 0;                   // offset of its path arena in the packed buffer
   uint64_t first_id = 0;              // varMerId of its first path (-debug numbering)
-  std::string out, dbg, log;          // produced by a worker thread, written in input order
+  std::string dbg;                    // -debug lines of this cluster (appended to its run's text by the worker)
 };
 
 // dynamic parallel-for over [0, n) on the host threads the library may use
@@ -319,30 +442,30 @@ void parallel_for(size_t n, F &&fn) {
   for (auto &x : th) x.join();
 }
 
-std::string hom_record(const Cluster &cl, const std::vector<int> &g, const char *chr) {     // varMer.C:531-550
+std::string hom_record(const Cluster &cl, const int *g, size_t ng, const char *chr) {     // varMer.C:531-550
   std::string out;
-  for (size_t i = 0; i < g.size(); ++i) {
+  for (size_t i = 0; i < ng; ++i) {
     int a = g[i];
     if (a <= 0) continue;
     const Variant *v = cl.vars[i];
-    out += std::string(chr) + "\t" + std::to_string(v->pos + 1) + "\t.\t" + *v->alleles[0] + "\t" + *v->alleles[a] + "\t" +
-           std::to_string((int)v->qual) + "\tPASS\t.\tGT\t1/1\n";
+    out += chr; out += '\t'; out += std::to_string(v->pos + 1); out += "\t.\t"; out += v->allele(0); out += '\t'; out += v->allele(a); out += '\t';
+    out += std::to_string((int)v->qual); out += "\tPASS\t.\tGT\t1/1\n";
   }
   return out;
 }
 
-std::string het_record(const Cluster &cl, const std::vector<int> &g1, const std::vector<int> &g2, const char *chr) {   // varMer.C:472-529
+std::string het_record(const Cluster &cl, const int *g1, const int *g2, size_t ng, const char *chr) {   // varMer.C:472-529
   std::string out;
-  for (size_t i = 0; i < g1.size(); ++i) {
+  for (size_t i = 0; i < ng; ++i) {
     int a1 = g1[i], a2 = g2[i];
     if (a1 + a2 <= 0) continue;
     const Variant *v = cl.vars[i];
     std::string q = std::to_string((int)v->qual);
-    out += std::string(chr) + "\t" + std::to_string(v->pos + 1) + "\t.\t" + *v->alleles[0] + "\t";
-    if (a1 == a2) out += *v->alleles[a1] + "\t" + q + "\tPASS\t.\tGT\t1/1\n";
-    else if (a1 == 0 && a2 > 0) out += *v->alleles[a2] + "\t" + q + "\tPASS\t.\tGT\t0/1\n";
-    else if (a1 > 0 && a2 > 0) out += *v->alleles[a1] + "," + *v->alleles[a2] + "\t" + q + "\tPASS\t.\tGT\t1/2\n";
-    else if (a1 > 0 && a2 == 0) out += *v->alleles[a1] + "\t" + q + "\tPASS\t.\tGT\t1/0\n";
+    out += chr; out += '\t'; out += std::to_string(v->pos + 1); out += "\t.\t"; out += v->allele(0); out += '\t';
+    if (a1 == a2) { out += v->allele(a1); out += '\t'; out += q; out += "\tPASS\t.\tGT\t1/1\n"; }
+    else if (a1 == 0 && a2 > 0) { out += v->allele(a2); out += '\t'; out += q; out += "\tPASS\t.\tGT\t0/1\n"; }
+    else if (a1 > 0 && a2 > 0) { out += v->allele(a1); out += ','; out += v->allele(a2); out += '\t'; out += q; out += "\tPASS\t.\tGT\t1/2\n"; }
+    else if (a1 > 0 && a2 == 0) { out += v->allele(a1); out += '\t'; out += q; out += "\tPASS\t.\tGT\t1/0\n"; }
   }
   return out;
 }
@@ -354,7 +477,7 @@ std::vector<int> min_missing(const Job &jb, const Scored &sc, uint32_t k, bool f
   uint32_t numMissing = UINT32_MAX;
   std::vector<int> idxs;
   for (int i = 0; i < (int)sc.numM.size(); ++i) {
-    if (sc.numM[i] == jb.ps.seqs[i].size() - k + 1) continue;            // size_t arithmetic, as the reference
+    if (sc.numM[i] == jb.ps.len(i) - k + 1) continue;                    // size_t arithmetic, as the reference
     if (filter_rule && sc.numM[i] == 0) { idxs.push_back(i); numMissing = 0; }
     if (sc.numM[i] < numMissing) { numMissing = sc.numM[i]; idxs.clear(); idxs.push_back(i); }
     else if (sc.numM[i] == numMissing) idxs.push_back(i);
@@ -366,14 +489,16 @@ std::vector<int> min_missing(const Job &jb, const Scored &sc, uint32_t k, bool f
 std::string select_records(const Job &jb, const Scored &sc, int mode, uint32_t k, const char *chr, std::string *log) {
   const PathSet &ps = jb.ps;
   const Cluster &cl = *jb.cl;
+  const size_t nv = ps.nv;
+  auto gt = [&](size_t p) { return ps.gt.data() + p * nv; };
   if (mode == MFX_VAR_FILTER) {                                          // bestFilter, varMer.C:150-199
     uint32_t best;
     std::vector<int> idxs = min_missing(jb, sc, k, true, &best);
     if (idxs.empty()) return "";
     std::list<int> gtIdxs;
     for (int p : idxs)
-      for (int i = 0; i < (int)ps.gt[p].size(); ++i)
-        if (ps.gt[p][i] > 0) gtIdxs.push_back(i);
+      for (int i = 0; i < (int)nv; ++i)
+        if (gt(p)[i] > 0) gtIdxs.push_back(i);
     gtIdxs.sort();
     gtIdxs.unique();
     std::string out;
@@ -384,20 +509,20 @@ std::string select_records(const Job &jb, const Scored &sc, int mode, uint32_t k
     uint32_t best;
     std::vector<int> idxs = min_missing(jb, sc, k, false, &best);
     if (best == UINT32_MAX) return "";
-    if (idxs.size() == 1) return hom_record(cl, ps.gt[idxs[0]], chr);
+    if (idxs.size() == 1) return hom_record(cl, gt(idxs[0]), nv, chr);
     // tie: order by total delta-K through the reference's own container type --
     // multimap<double,int,greater<int>> compares the keys AS INTS, descending (varMer.H:72)
     std::multimap<double, int, std::greater<int>> byDk;
-    for (int p : idxs) byDk.insert(std::make_pair(tot_dk(sc.dks[p]), p));
+    for (int p : idxs) byDk.insert(std::make_pair(sc.totdk[p], p));
     auto it = byDk.begin();
     double d1 = it->first; int p1 = it->second;
     ++it;
     double d2 = it->first; int p2 = it->second;
     if (d1 == d2) {
-      if (ps.seqs[p1].length() >= ps.seqs[p2].length()) return het_record(cl, ps.gt[p1], ps.gt[p2], chr);
-      return het_record(cl, ps.gt[p2], ps.gt[p1], chr);
+      if (ps.len(p1) >= ps.len(p2)) return het_record(cl, gt(p1), gt(p2), nv, chr);
+      return het_record(cl, gt(p2), gt(p1), nv, chr);
     }
-    return hom_record(cl, ps.gt[p1], chr);
+    return hom_record(cl, gt(p1), nv, chr);
   }
   // -better / -strict / -loose start from the reference path (varMer.C:204-395)
   if (sc.numM.empty()) return "";
@@ -410,28 +535,28 @@ std::string select_records(const Job &jb, const Scored &sc, int mode, uint32_t k
     else if (sc.numM[i] == numMissing && (loose ? sc.numM[i] <= refMissing : sc.numM[i] < refMissing)) idxs.push_back(i);
   }
   if (idxs.empty()) return "";
-  if (idxs.size() == 1) return hom_record(cl, ps.gt[idxs[0]], chr);
+  if (idxs.size() == 1) return hom_record(cl, gt(idxs[0]), nv, chr);
   if (!loose) {                                                          // longest path wins (first on ties)
     int idx = idxs[0];
-    uint32_t longest = (uint32_t)ps.seqs[idx].size();
+    uint32_t longest = (uint32_t)ps.len(idx);
     for (size_t i = 1; i < idxs.size(); ++i) {
-      uint32_t L = (uint32_t)ps.seqs[idxs[i]].length();
+      uint32_t L = (uint32_t)ps.len(idxs[i]);
       if (L > longest) { longest = L; idx = idxs[i]; }
     }
-    return hom_record(cl, ps.gt[idx], chr);
+    return hom_record(cl, gt(idx), nv, chr);
   }
-  if (idxs[0] == 0 && idxs.size() == 2) return hom_record(cl, ps.gt[idxs[1]], chr);
+  if (idxs[0] == 0 && idxs.size() == 2) return hom_record(cl, gt(idxs[1]), nv, chr);
   int maxVars = 0, maxIdx = idxs[0];                                     // most ALT alleles wins
   for (size_t i = 1; i < idxs.size(); ++i) {
     int cnt = 0;
-    for (int a : ps.gt[idxs[i]]) if (a > 0) cnt++;
+    for (size_t q = 0; q < nv; ++q) if (gt(idxs[i])[q] > 0) cnt++;
     if (cnt > maxVars) { maxVars = cnt; maxIdx = idxs[i]; }
   }
   if (log) {
     *log += "[ WARNING ] :: Multiple (" + std::to_string(idxs.size()) + ") alternate pathes detected in a path beginning with variant : " + cl.vars[0]->rec->line();
     *log += "[ WARNING ] :: Max. " + std::to_string(maxVars) + " ALT variants selected\n";
   }
-  return hom_record(cl, ps.gt[maxIdx], chr);
+  return hom_record(cl, gt(maxIdx), nv, chr);
 }
 
 // debug statistics (varMer.C:553-624)
@@ -457,7 +582,8 @@ double med_abs_k(std::vector<double> k) {
 // (mfx_dump_values) or the shards of one index (mfx_dump_values_sharded)
 using PathValues = std::function<int(const char *, uint64_t, uint32_t *, uint32_t *)>;
 
-static int variants_impl(const mfx_eval *ev, const PathValues &values, const char *vcf_path, const char *const *names, const char *const *bases,
+// (not static: tools/variants_host_bench.cpp drives the host side with a synthetic `values`, without a device)
+int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const char *vcf_path, const char *const *names, const char *const *bases,
                          const uint64_t *lens, uint32_t ncontigs, const mfx_variant_opts *opts,
                          const char *out_path, const char *log_path, uint64_t *n_clusters) {
   if (!ev || !vcf_path || !opts || !out_path || (ncontigs && (!names || !bases || !lens)))
@@ -482,7 +608,7 @@ static int variants_impl(const mfx_eval *ev, const PathValues &values, const cha
   int rc = load_vcf(vcf_path, db);
   if (rc) { if (log != stderr) fclose(log); return rc; }
   fprintf(log, "   Collected %zu header lines.\n   Loaded %zu records:\n      %-8lu unique contig%s\n      %-8u contig IDs\n   Excluded %lu invalid records\n\n",
-          db.headers.size(), db.records.size(), db.by_chr.size(), db.by_chr.size() == 1 ? "" : "s", (unsigned)db.contig_ids, (unsigned long)db.excluded);
+          db.headers.size(), db.n_records, db.by_chr.size(), db.by_chr.size() == 1 ? "" : "s", (unsigned)db.contig_ids, (unsigned long)db.excluded);
   fprintf(log, "Merge variants within %u-mer bases, splitting combinations greater than %u.\n", K, comb);
   merge_clusters(db, K, comb, opts->nosplit != 0, log);
   lap(0);
@@ -504,7 +630,7 @@ static int variants_impl(const mfx_eval *ev, const PathValues &values, const cha
   std::vector<double> lutK(KLUT), lutP(KLUT);
   for (uint32_t v = 0; v < KLUT; ++v) { double a; mfx_getK(&kp, v, 0, &lutK[v], &a, &lutP[v]); }
   uint64_t clusters = 0, varMerId = 0;
-  const uint64_t BATCH_BYTES = 256ull << 20;                             // packed path text per GPU launch
+  const uint64_t BATCH_BYTES = (getenv("MFX_VAR_BATCH_MB") ? (uint64_t)atoi(getenv("MFX_VAR_BATCH_MB")) : 64ull) << 20;   // packed path text per GPU launch
 
   std::vector<Job> jobs;
   jobs.reserve(65536);
@@ -523,19 +649,24 @@ static int variants_impl(const mfx_eval *ev, const PathValues &values, const cha
       std::vector<uint32_t> offs, vl;
       for (const Variant *v : jb.cl->vars) { offs.push_back(v->pos - jb.rStart); vl.push_back(v->refLen); }
       std::vector<int> path;
-      enumerate(0, offs, vl, *jb.cl, std::string(bases[jb.contig] + jb.rStart, bases[jb.contig] + jb.rEnd), path, jb.ps);
+      static thread_local std::vector<std::string> reps;                 // candidate strings per recursion depth, reused
+      jb.ps.nv = (uint32_t)jb.cl->vars.size();
+      if (reps.size() < jb.cl->vars.size() + 1) reps.resize(jb.cl->vars.size() + 1);
+      enumerate(0, offs, vl, *jb.cl, std::string(bases[jb.contig] + jb.rStart, bases[jb.contig] + jb.rEnd), path, jb.ps, reps, 0);
+      jb.ps.seen.clear();
     });
     lap(1);
     uint64_t total = 0;
     for (Job &jb : jobs) {
       jb.first_id = varMerId;
-      varMerId += jb.ps.seqs.size();
-      for (const std::string &s : jb.ps.seqs) { jb.off.push_back(total); total += s.size() + 1; }
+      varMerId += jb.ps.size();
+      jb.off = total;
+      total += jb.ps.text.size();                                        // every path is followed by its '\n' (not ACGT: k-mers never span two paths)
     }
-    packed.assign(total, '\n');                                          // '\n' is not ACGT: k-mers never span two paths
+    packed.resize(total);
     parallel_for(jobs.size(), [&](size_t i) {
-      Job &jb = jobs[i];
-      for (size_t p = 0; p < jb.ps.seqs.size(); ++p) memcpy(&packed[jb.off[p]], jb.ps.seqs[p].data(), jb.ps.seqs[p].size());
+      const Job &jb = jobs[i];
+      memcpy(&packed[jb.off], jb.ps.text.data(), jb.ps.text.size());
     });
     lap(2);
     if (total) {
@@ -546,22 +677,35 @@ static int variants_impl(const mfx_eval *ev, const PathValues &values, const cha
     }
     lap(3);
     const bool want_dbg = dbg != nullptr;
-    parallel_for(jobs.size(), [&](size_t ji) {
+    // the jobs of a batch are scored in runs of OUT_RUN consecutive ones; a run's records / -debug lines / log lines are
+    // concatenated by the worker that scored it, so that the writer below issues one write per run, not per cluster
+    constexpr size_t OUT_RUN = 256;
+    const size_t nruns = (jobs.size() + OUT_RUN - 1) / OUT_RUN;
+    std::vector<std::string> run_out(nruns), run_dbg(nruns), run_log(nruns);
+    parallel_for(nruns, [&](size_t ri) {
+     for (size_t ji = ri * OUT_RUN, je = std::min(jobs.size(), (ri + 1) * OUT_RUN); ji < je; ++ji) {
       Job &jb = jobs[ji];
       // `prob` is a local of varMer::score (one per cluster) that the reference reads
       // uninitialised until the first valid k-mer writes it; before that it only
       // multiplies |0-0|, so any finite start value is equivalent.  We fix 1.0.
       double prob = 1.0;
       Scored sc;
-      const size_t np = jb.ps.seqs.size();
-      sc.numM.resize(np); sc.ks.resize(np); sc.dks.resize(np);
+      const size_t np = jb.ps.size(), nv = jb.ps.nv;
+      // what the selectors read: numM always; the paths' total delta-K only in -polish (its tie-break); the per-position
+      // K* and delta-K values only in the -debug statistics.  Nothing else is computed or stored.
+      const bool need_dk = mode == MFX_VAR_POLISH || want_dbg, keep = want_dbg && mode != MFX_VAR_FILTER;
+      sc.numM.resize(np); sc.totdk.assign(np, 0.0);
+      if (want_dbg) { sc.ks.resize(np); sc.dks.resize(np); }
       for (size_t p = 0; p < np; ++p) {                                  // varMer::score, varMer.C:66-144
-        const std::string &s = jb.ps.seqs[p];
-        const uint64_t o = jb.off[p];
+        const char *s = jb.ps.seq(p);
+        const uint32_t slen = (uint32_t)jb.ps.len(p);
+        const uint64_t o = jb.off + jb.ps.toff[p];
+        const int *gtp = jb.ps.gt.data() + p * nv;
+        const uint32_t *vip = jb.ps.vidx.data() + p * nv, *vlp = jb.ps.vlen.data() + p * nv;
         uint32_t numM = 0, run = 0;
-        std::vector<double> &ks = sc.ks[p], &dks = sc.dks[p];
-        if (mode != MFX_VAR_FILTER) { ks.reserve(s.size()); dks.reserve(s.size()); }
-        for (uint32_t idx = 0; idx < s.size(); ++idx) {
+        double totdk = 0.0;                                              // summed in position order, as getTotdK does
+        if (keep) { sc.ks[p].reserve(slen); sc.dks[p].reserve(slen); }
+        for (uint32_t idx = 0; idx < slen; ++idx) {
           run = base_ok((unsigned char)s[idx]) ? run + 1 : 0;
           double readK = 0, asmK = 0;
           if (run >= K) {                                                // k-mer ENDING at idx starts at idx-k+1
@@ -571,21 +715,25 @@ static int variants_impl(const mfx_eval *ev, const PathValues &values, const cha
             else mfx_getK(&kp, v, av[sp], &readK, &asmK, &prob);
           }
           if (readK == 0) numM++;
-          if (mode == MFX_VAR_FILTER) continue;                          // :93-96
+          if (mode == MFX_VAR_FILTER || !need_dk) continue;              // :93-96 (and: nobody reads the values below)
           const double oD = fabs(readK - asmK) * prob;                   // :99
-          for (size_t j = 0; j < jb.ps.vidx[p].size(); ++j) {            // :103-112, uint32 wrap included
-            const uint32_t vi = jb.ps.vidx[p][j], vl = jb.ps.vlen[p][j];
-            if (jb.ps.gt[p][j] > 0 && vi + 1 - K <= idx && idx < vi + vl + K) { asmK++; break; }
+          for (size_t j = 0; j < nv; ++j) {                              // :103-112, uint32 wrap included
+            const uint32_t vi = vip[j], vl = vlp[j];
+            if (gtp[j] > 0 && vi + 1 - K <= idx && idx < vi + vl + K) { asmK++; break; }
           }
-          double kM;
-          if (readK == 0) kM = -1;                                       // :116-124
-          else if (readK > asmK) kM = readK / asmK - 1;
-          else kM = asmK / readK - 1;
           const double nD = fabs(readK - asmK) * prob;                   // :126
-          ks.push_back(kM);
-          dks.push_back(oD - nD);
+          totdk += oD - nD;
+          if (keep) {
+            double kM;
+            if (readK == 0) kM = -1;                                     // :116-124
+            else if (readK > asmK) kM = readK / asmK - 1;
+            else kM = asmK / readK - 1;
+            sc.ks[p].push_back(kM);
+            sc.dks[p].push_back(oD - nD);
+          }
         }
         sc.numM[p] = numM;
+        sc.totdk[p] = totdk;
       }
       const char *chr = names[jb.contig];
       if (want_dbg) {                                                    // merfin-variants.C:240-276
@@ -593,30 +741,33 @@ static int variants_impl(const mfx_eval *ev, const PathValues &values, const cha
         for (size_t p = 0; p < np; ++p) {
           snprintf(buf, sizeof(buf), "%lu\t%s:%u-%u\t", (unsigned long)(jb.first_id + p), chr, jb.rStart, jb.rEnd);
           jb.dbg += buf;
-          jb.dbg += jb.ps.seqs[p];
+          jb.dbg.append(jb.ps.seq(p), jb.ps.len(p));
           snprintf(buf, sizeof(buf), "\t%u\t%.5f\t%.5f\t%.5f\t%.5f\t%.5f\t", sc.numM[p], min_abs_k(sc.ks[p]), max_abs_k(sc.ks[p]),
-                   med_abs_k(sc.ks[p]), avg_abs_k(sc.ks[p], sc.numM[p]), tot_dk(sc.dks[p]));
+                   med_abs_k(sc.ks[p]), avg_abs_k(sc.ks[p], sc.numM[p]), sc.totdk[p]);
           jb.dbg += buf;
-          for (size_t i = 0; i < jb.ps.gt[p].size(); ++i) {
-            int a = jb.ps.gt[p][i];
+          for (size_t i = 0; i < nv; ++i) {
+            int a = jb.ps.gt[p * nv + i];
             if (a > 0)
-              jb.dbg += std::string(chr) + " " + std::to_string(jb.cl->vars[i]->pos + 1) + " . " + *jb.cl->vars[i]->alleles[0] + " " +
-                        *jb.cl->vars[i]->alleles[a] + " . PASS . GT 1/1  ";
+            {
+              jb.dbg += chr; jb.dbg += ' '; jb.dbg += std::to_string(jb.cl->vars[i]->pos + 1); jb.dbg += " . "; jb.dbg += jb.cl->vars[i]->allele(0);
+              jb.dbg += ' '; jb.dbg += jb.cl->vars[i]->allele(a); jb.dbg += " . PASS . GT 1/1  ";
+            }
           }
           jb.dbg += "\n";
         }
       }
-      jb.out = select_records(jb, sc, mode, K, chr, &jb.log);
+      run_out[ri] += select_records(jb, sc, mode, K, chr, &run_log[ri]);
+      if (want_dbg) { run_dbg[ri] += jb.dbg; std::string().swap(jb.dbg); }
       jb.ps = PathSet();                                                 // release the per-path containers here, on the worker
-      std::vector<uint64_t>().swap(jb.off);
+     }
     });
     lap(4);
-    for (Job &jb : jobs) {
-      if (!jb.log.empty()) fputs(jb.log.c_str(), log);
-      if (dbg && !jb.dbg.empty()) fputs(jb.dbg.c_str(), dbg);
-      fputs(jb.out.c_str(), out);
-      clusters++;
+    for (size_t ri = 0; ri < nruns; ++ri) {
+      if (!run_log[ri].empty()) fwrite(run_log[ri].data(), 1, run_log[ri].size(), log);
+      if (dbg && !run_dbg[ri].empty()) fwrite(run_dbg[ri].data(), 1, run_dbg[ri].size(), dbg);
+      fwrite(run_out[ri].data(), 1, run_out[ri].size(), out);
     }
+    clusters += jobs.size();
     jobs.clear();
     packed.clear();
     lap(5);
@@ -650,9 +801,9 @@ static int variants_impl(const mfx_eval *ev, const PathValues &values, const cha
       double npaths = 1;
       uint64_t plen = (uint64_t)(rEnd - rStart) + 1;
       for (const Variant *v : cl->vars) {
-        npaths *= (double)std::max<size_t>(v->alleles.size(), 1);
+        npaths *= (double)std::max<size_t>(v->nalleles(), 1);
         size_t longest = 0;
-        for (const std::string *a : v->alleles) longest = std::max(longest, a->size());
+        for (size_t ai = 0; ai < v->nalleles(); ++ai) longest = std::max<size_t>(longest, v->allele(ai).size());
         plen += longest;
       }
       est_bytes += (uint64_t)std::min(npaths, 4194304.0) * plen;
@@ -683,7 +834,7 @@ extern "C" int mfx_variants_run(mfx_eval *ev, const char *vcf_path, const char *
     mfx_seq_free(ps);
     return r;
   };
-  return variants_impl(ev, values, vcf_path, names, bases, lens, ncontigs, opts, out_path, log_path, n_clusters);
+  return mfx_variants_run_values(ev, values, vcf_path, names, bases, lens, ncontigs, opts, out_path, log_path, n_clusters);
 }
 
 // The variant modes over an index sharded across N evaluators (read databases beyond one GPU): the packed path text of
@@ -713,5 +864,5 @@ extern "C" int mfx_variants_run_sharded(mfx_eval *const *evs, uint32_t nslots, c
     }
     return r;
   };
-  return variants_impl(evs[0], values, vcf_path, names, bases, lens, ncontigs, opts, out_path, log_path, n_clusters);
+  return mfx_variants_run_values(evs[0], values, vcf_path, names, bases, lens, ncontigs, opts, out_path, log_path, n_clusters);
 }

@@ -1,0 +1,81 @@
+// Host side of the variant modes without a device: mfx_variants_run_values driven by a synthetic `values` (every path
+// k-mer gets counts derived from a hash of its text), on a config-4-shaped input (one call per ~765 bases).  For profiling
+// the VCF load / clustering / path enumeration / scoring / selection code on any machine:
+//   g++ -O2 -std=c++17 tools/variants_host_bench.cpp -Imerfin_amd/csrc -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ -Lmerfin_amd -lmerfin_amd \
+//       -Wl,-rpath,$PWD/merfin_amd -Wl,-rpath,/opt/rocm/lib -o tools/_build/variants_host_bench && MFX_VAR_TIMING=1 tools/_build/variants_host_bench 300e6
+#include <chrono>
+#include <functional>
+#include <algorithm>
+#include <random>
+
+#include "mfx_internal.h"
+
+using PathValues = std::function<int(const char *, uint64_t, uint32_t *, uint32_t *)>;
+int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const char *vcf_path, const char *const *names, const char *const *bases,
+                            const uint64_t *lens, uint32_t ncontigs, const mfx_variant_opts *opts, const char *out_path, const char *log_path,
+                            uint64_t *n_clusters);
+
+int main(int argc, char **argv) {
+  const uint64_t total = argc > 1 ? (uint64_t)atof(argv[1]) : 100000000ull;
+  const int mode = argc > 2 ? atoi(argv[2]) : MFX_VAR_POLISH;
+  const uint32_t nc = 24;
+  std::mt19937_64 rng(7);
+  std::vector<std::string> contigs(nc), names(nc);
+  std::string vcf = "##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tSAMPLE\n";
+  uint64_t calls = 0;
+  for (uint32_t c = 0; c < nc; ++c) {
+    names[c] = "ctg" + std::to_string(c);
+    std::string &s = contigs[c];
+    s.resize(total / nc);
+    for (size_t i = 0; i < s.size(); i += 32) {
+      uint64_t x = rng();
+      for (size_t j = i; j < std::min(s.size(), i + 32); ++j, x >>= 2) s[j] = "ACGT"[x & 3];
+    }
+    // as tests/test_gpu_cfg4_fullsize.py: half of the calls alone, half in tight groups of 4 within 40 bases (DeepVariant-like)
+    const size_t nv = (size_t)(s.size() / 765.0);
+    std::vector<size_t> pos;
+    for (size_t i = 0; i < nv / 2; ++i) pos.push_back(30 + rng() % (s.size() - 60));
+    for (size_t i = 0; i < nv / 8; ++i) {
+      const size_t p0 = 30 + rng() % (s.size() - 230);
+      for (int q = 0; q < 4; ++q) pos.push_back(p0 + rng() % 40);
+    }
+    std::sort(pos.begin(), pos.end());
+    pos.erase(std::unique(pos.begin(), pos.end()), pos.end());
+    for (size_t p : pos) {
+      char buf[256];
+      const char ref = s[p];
+      const char alt = "ACGT"[(std::string("ACGT").find(ref) + 1 + rng() % 3) % 4];
+      snprintf(buf, sizeof(buf), "%s\t%zu\t.\t%c\t%c\t30\tPASS\t.\tGT\t1/1\n", names[c].c_str(), p + 1, ref, alt);
+      vcf += buf;
+      ++calls;
+    }
+  }
+  const char *vp = "/tmp/mfx_vhb.vcf";
+  FILE *f = fopen(vp, "w");
+  fwrite(vcf.data(), 1, vcf.size(), f);
+  fclose(f);
+  mfx_index ix;
+  ix.k = 21;
+  mfx_eval ev;
+  ev.ix = &ix;
+  ev.peak = 26.0;
+  PathValues values = [](const char *text, uint64_t len, uint32_t *rv, uint32_t *av) -> int {
+    for (uint64_t i = 0; i < len; ++i) {
+      uint64_t h = (i * 0x9E3779B97F4A7C15ull) ^ (uint64_t)(unsigned char)text[i] * 0xD6E8FEB86659FD93ull;
+      h ^= h >> 29;
+      rv[i] = (h % 37 == 0) ? 0u : 20u + (uint32_t)(h % 13);
+      av[i] = 1u + (uint32_t)((h >> 20) % 7 == 0);
+    }
+    return 0;
+  };
+  std::vector<const char *> nm(nc), bs(nc);
+  std::vector<uint64_t> ln(nc);
+  for (uint32_t c = 0; c < nc; ++c) { nm[c] = names[c].c_str(); bs[c] = contigs[c].data(); ln[c] = contigs[c].size(); }
+  mfx_variant_opts vo{mode, 15, 0, nullptr};
+  uint64_t ncl = 0;
+  auto t0 = std::chrono::steady_clock::now();
+  int rc = mfx_variants_run_values(&ev, values, vp, nm.data(), bs.data(), ln.data(), nc, &vo, "/tmp/mfx_vhb.out.vcf", "/tmp/mfx_vhb.log", &ncl);
+  double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  printf("rc %d: %lu bases, %lu calls, %lu clusters in %.2f s = %.0f clusters/s\n", rc, (unsigned long)total, (unsigned long)calls, (unsigned long)ncl, dt, ncl / dt);
+  return rc;
+}
