@@ -25,7 +25,11 @@ if os.path.exists(log):
     shutil.copy(log, os.path.join(dst, name.replace("_final", "") + "_gpu_pytest.log"))
 r, t = b["roofline"], b["roofline"]["traffic_info"]
 old = json.load(open(dst + "/traffic.json"))
-json.dump({"hist_k21_3Gb_synthetic_prob": r["traffic"], "kernel_source_hash": b["config"]["kernel_source_hash"], "_note": old["_note"],
+kind = "seq" if b["config"].get("index", "").startswith("sequence-only") else "full"
+json.dump({b["config"]["workload"] + ":" + kind: r["traffic"], "kernel_source_hash": b["config"]["kernel_source_hash"],
+           "_note": "HBM bytes per launch of the dominant kernel (" + r["kernel"] + "), measured by bench.py's own rocprofv3 PMC passes: 2 x FETCH_SIZE*1024 + WRITE_SIZE*1024; "
+                    "gfx950 correction x2 on FETCH_SIZE (MI355X_MICROARCH section HBM; calibration profiles/r01_fetch_size_calibration.csv). Key = workload:index kind. "
+                    "bench.py uses this file only when rocprofv3 is unavailable AND kernel_source_hash equals the hash of the current kernel sources.",
            "_raw_fetch_bytes": t["raw_fetch_bytes"], "_raw_write_bytes": t["raw_write_bytes"], "_kmers_per_launch": r["kmers_per_launch"],
            "_bytes_per_kmer_corrected": r["bytes_per_kmer"], "_lines_per_kmer": r["lines_per_kmer"], "_index_gb": b["config"]["index_gb"]},
           open(dst + "/traffic.json", "w"), indent=1)
