@@ -342,3 +342,58 @@ def test_randomized_fasta_layouts(tmp_path, seed):
     assert (tmp_path / "g.hist").read_bytes() == (tmp_path / "o.hist").read_bytes()
     named = [l.split("\t")[0] for l in rr.stderr.splitlines() if l.count("\t") == 4 and l.startswith("ctg")]
     assert named == ["ctg%d" % i for i in range(len(contigs))]
+
+
+@pytest.mark.gpu
+def test_cli_hist_falls_back_to_the_full_tables_for_a_non_canonical_database(tmp_path):
+    """`merfin -hist / -dump` build a sequence-only index (one slot per canonical k-mer of -sequence).  A database that holds
+    forward (non-canonical) k-mers cannot be answered from it -- value(fmer) + value(rmer) needs both strands' slots
+    (merfin-globals.C:107-108) -- so the load reports it and the CLI builds the full tables: same result as the oracle."""
+    import merfin_amd as m
+    k, peak = 11, 5.0
+    r = synth.rng(3)
+    contigs = synth.as_bytes(synth.decorate(r, synth.make_truth(r, (6000, 2500))))
+    fw = {}
+    for c in contigs:
+        for _, f, _r in po.kiter(k, c):
+            fw[f] = fw.get(f, 0) + 1
+    ak = np.array(sorted(fw), dtype=np.uint64)
+    av = np.array([fw[x] for x in ak.tolist()], dtype=np.uint32)
+    rv = (av * 5 + (ak % 3).astype(np.uint32)).astype(np.uint32)
+    p = po.Params(k, peak)
+    g, ka, km, _ = po.hist_run(p, po.Lookup(k, ak, rv), po.Lookup(k, ak, av), contigs, threads=2)
+    po.report_histogram(p, g, str(tmp_path / "o.hist"), None)
+    m.db_write_flat(str(tmp_path / "read.mfxk"), k, ak, rv)
+    m.db_write_flat(str(tmp_path / "asm.mfxk"), k, ak, av)
+    fa = str(tmp_path / "a.fasta")
+    _write_fasta(fa, contigs, gz=False)
+    for seqmers in (True, False):
+        args = ["-hist", "-sequence", fa, "-readmers", str(tmp_path / "read.mfxk"), "-peak", str(peak), "-output", str(tmp_path / "g.hist")]
+        if seqmers:
+            args += ["-seqmers", str(tmp_path / "asm.mfxk")]
+        rr = subprocess.run([EXE] + args, capture_output=True, text=True)
+        assert rr.returncode == 0, rr.stderr
+        assert "not canonical; building the full lookup tables" in rr.stderr
+        if seqmers:                     # (without -seqmers the assembly side is the canonical count of the sequence: another world)
+            assert (tmp_path / "g.hist").read_bytes() == (tmp_path / "o.hist").read_bytes()
+
+
+@pytest.mark.gpu
+def test_cli_index_cache_of_a_sequence_only_index(tmp_path, golden_dir):
+    """-index with -hist caches the sequence-only table; -completeness on the same databases must not take it (it needs every
+    read k-mer) and rebuilds the full one"""
+    g = lambda n: os.path.join(golden_dir, n)
+    img = str(tmp_path / "c.mfxi")
+    common = ["-sequence", g("case1.fasta"), "-readmers", g("case1.read.kmers.txt"), "-seqmers", g("case1.asm.kmers.txt"), "-peak", "17.3",
+              "-prob", g("example_lookup_table.txt"), "-index", img]
+    for attempt in (0, 1):
+        r = subprocess.run([EXE, "-hist"] + common + ["-output", str(tmp_path / "h")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert (tmp_path / "h").read_bytes() == open(g("case1.hist"), "rb").read()
+        assert ("Loading the index image" in r.stderr) == (attempt == 1)
+    ref = subprocess.run([EXE, "-completeness"] + common[:-2], capture_output=True, text=True)
+    r = subprocess.run([EXE, "-completeness"] + common, capture_output=True, text=True)
+    assert r.returncode == 0 and ref.returncode == 0, r.stderr
+    assert "rebuilding it" in r.stderr
+    tot = lambda s: [l for l in s.splitlines() if l.startswith(("TOTAL", "COMPLETENESS"))]
+    assert tot(r.stderr) == tot(ref.stderr) and len(tot(r.stderr)) == 3
