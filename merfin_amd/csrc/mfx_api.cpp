@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <memory>
 #include <mutex>
 #include <functional>
 #include <condition_variable>
@@ -423,7 +424,7 @@ static mfx_ingest *ingest_get(mfx_index *ix, uint64_t n) {
 // device over that device's own PCIe link; each table inserts what it keeps (a sharded index skips the k-mers it
 // does not own in the insert kernel).  nix = 1 is the ordinary load.
 template <class Fill>
-static int index_ingest_multi(mfx_index *const *ixs, uint32_t nix, uint64_t n, int side, Fill &&fill) {
+static int index_ingest_multi(mfx_index *const *ixs, uint32_t nix, uint64_t n, int side, Fill &&fill, bool packed = false) {
   std::vector<mfx_ingest *> gs(nix, nullptr);
   for (uint32_t i = 0; i < nix; ++i) {
     DevGuard dg(ixs[i]->device);
@@ -451,9 +452,9 @@ static int index_ingest_multi(mfx_index *const *ixs, uint32_t nix, uint64_t n, i
       mfx_ingest::Lane &l = g->L[cur];
       DevGuard dg(ix->device);
       ok = hipMemcpyAsync(l.dk, src.hk, m * 8 * g->kw, hipMemcpyHostToDevice, g->st) == hipSuccess &&
-           hipMemcpyAsync(l.dv, src.hv, m * 4, hipMemcpyHostToDevice, g->st) == hipSuccess &&
+           (packed || hipMemcpyAsync(l.dv, src.hv, m * 4, hipMemcpyHostToDevice, g->st) == hipSuccess) &&        // packed records carry their counts
            (ix->wide() ? mfx_kw_table_add(ix->view(), l.dk, l.dv, m, side, ix->d_meta, g->st)
-                       : mfx_k_table_add(ix->view(), l.dk, l.dv, m, side, ix->d_meta, g->st)) == hipSuccess &&
+                       : mfx_k_table_add(ix->view(), l.dk, packed ? nullptr : l.dv, m, side, ix->d_meta, g->st)) == hipSuccess &&
            hipEventRecord(l.done, g->st) == hipSuccess;
       l.busy = true;
     }
@@ -509,12 +510,18 @@ int mfx_index_add_multi(mfx_index *const *ixs, uint32_t nix, const uint64_t *kme
 
 // n bytes at file offset `off` into dst, read by several threads (each pread copies straight out of the page cache:
 // no mapping to fault in page by page, which is what made the mmap + memcpy route top out at ~7 GB/s)
-static bool par_pread(int fd, uint8_t *dst, size_t n, uint64_t off) {
+static unsigned pread_threads() {
   // these threads wait on memory, not on the ALUs: more of them than the CPU quota grants still pays (1 Gb ingest on
   // a 16-core quota: 1.9 s with 16 readers, 1.3 s with 32), unless MFX_HOST_THREADS fixes the count
   unsigned nt = std::max(1u, mfx_host_threads());
   if (!getenv("MFX_HOST_THREADS")) nt = std::max(nt, std::min(32u, std::max(1u, std::thread::hardware_concurrency())));
-  nt = std::min(nt, 64u);
+  return std::min(nt, 64u);
+}
+
+// pool: reader threads that live for the whole file (a database is read in ~100 chunks: starting and joining 32 threads for
+// each was a third of the time of a chunk once the records shrank to 8 bytes); nullptr: threads of this call
+static bool par_pread(int fd, uint8_t *dst, size_t n, uint64_t off, WorkerPool *pool = nullptr) {
+  const unsigned nt = pool ? pool->W : pread_threads();
   auto rd = [fd](uint8_t *d, size_t len, uint64_t o) {
     while (len) {
       ssize_t r = pread(fd, d, len, (off_t)o);
@@ -524,9 +531,18 @@ static bool par_pread(int fd, uint8_t *dst, size_t n, uint64_t off) {
     return true;
   };
   if (n < (8u << 20) || nt == 1) return rd(dst, n, off);
-  std::vector<std::thread> th;
   std::vector<char> good(nt, 1);
   const size_t per = ((n + nt - 1) / nt + 4095) & ~(size_t)4095;
+  if (pool) {
+    pool->start([&](unsigned t) {
+      const size_t b = std::min(n, t * per), e = std::min(n, b + per);
+      if (e > b) good[t] = rd(dst + b, e - b, off + b) ? 1 : 0;
+    });
+    pool->wait();
+    for (char c : good) if (!c) return false;
+    return true;
+  }
+  std::vector<std::thread> th;
   for (unsigned t = 0; t < nt; ++t) {
     const size_t b = std::min(n, t * per), e = std::min(n, b + per);
     if (e > b) th.emplace_back([&, t, b, e]() { good[t] = rd(dst + b, e - b, off + b) ? 1 : 0; });
@@ -544,11 +560,15 @@ int mfx_index_add_from_file(mfx_index *const *ixs, uint32_t nix, int fd, const c
   if (fd < 0) return mfx_fail(MFX_E_INVAL, "mfx_index_add_from_file: bad argument");
   if (side == 0) for (uint32_t i = 0; i < nix; ++i) if ((rc = set_read_filter(ixs[i], minV, maxV)) != MFX_OK) return rc;
   const size_t kw = ixs[0]->key_words();
+  const bool packed = vals_off == 0;
+  if (packed && kw != 1) return mfx_fail(MFX_E_INVAL, "mfx_index_add_from_file: packed records hold k-mers of k <= %d", MFX_MAX_K_PACKED);
+  std::unique_ptr<WorkerPool> pool(n * 8 * kw >= (64u << 20) ? new WorkerPool(pread_threads()) : nullptr);
   return index_ingest_multi(ixs, nix, n, side, [&](uint64_t o, uint64_t m, uint64_t *hk, uint32_t *hv) {
-    if (par_pread(fd, (uint8_t *)hk, m * 8 * kw, keys_off + o * 8 * kw) && par_pread(fd, (uint8_t *)hv, m * 4, vals_off + o * 4)) return true;
+    if (par_pread(fd, (uint8_t *)hk, m * 8 * kw, keys_off + o * 8 * kw, pool.get()) &&
+        (packed || par_pread(fd, (uint8_t *)hv, m * 4, vals_off + o * 4, pool.get()))) return true;
     mfx_fail(MFX_E_IO, "reading '%s' failed", path);
     return false;
-  });
+  }, packed);
 }
 
 static int index_add(mfx_index *ix, const uint64_t *kmers, const uint32_t *values, uint64_t n, int side, int on_device) {

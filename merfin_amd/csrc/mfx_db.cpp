@@ -62,10 +62,15 @@ int base_code(unsigned char c) {
 struct FlatHeader {
   char     magic[8];     // "MFXKMER1"
   uint32_t k;
-  uint32_t flags;        // bit 0: canonical
+  uint32_t flags;        // bit 0: canonical; bit 1: PACKED records (k <= 21)
   uint64_t n;
-  uint64_t reserved;
+  uint64_t n_escape;     // packed: records whose count did not fit the record (was: reserved, 0)
 };
+// Payload, plain : n k-mers (8 bytes; 16 for k > 31), then n uint32 counts.
+// Payload, packed: n records {k-mer << 22 | count} (mfx_internal.h MFX_PACKED_*: 8 bytes per k-mer instead of 12 on disk, in
+//                  the staging lanes and over PCIe; a count field of all ones = escape), then the n_escape escaped k-mers
+//                  (uint64) and their counts (uint32).
+constexpr uint32_t FLAT_PACKED = 2u;
 
 // ---- meryl stuffedBits reader (UNVALIDATED) -----------
 // A stuffedBits file image: u64 dataBlockLenMax (bits), u32 dataBlocksLen,
@@ -616,6 +621,24 @@ extern "C" int mfx_index_load_db_multi(mfx_index *const *ixs, uint32_t nix, cons
     }
     if ((int)h.k != ix->k) { close(fdn); return mfx_fail(MFX_E_INVAL, "'%s' holds %u-mers but the index is built for k=%d", path, h.k, ix->k); }
     const uint64_t kw = ix->key_words();                     // k > 31: 16-byte k-mers {low, high}
+    if (h.flags & FLAT_PACKED) {
+      if (h.k > (uint32_t)MFX_MAX_K_PACKED || (uint64_t)st.st_size < sizeof(h) + h.n * 8 + h.n_escape * 12) {
+        close(fdn);
+        return mfx_fail(MFX_E_FORMAT, "'%s': truncated or inconsistent packed payload", path);
+      }
+      if (h.n) rc = mfx_index_add_from_file(ixs, nix, fdn, path, sizeof(h), 0, h.n, side, minV, maxV);
+      if (rc == MFX_OK && h.n_escape) {                      // the few counts beyond the record's field
+        std::vector<uint64_t> ek(h.n_escape);
+        std::vector<uint32_t> ev(h.n_escape);
+        const uint64_t eo = sizeof(h) + h.n * 8;
+        if (pread(fdn, ek.data(), h.n_escape * 8, (off_t)eo) != (ssize_t)(h.n_escape * 8) ||
+            pread(fdn, ev.data(), h.n_escape * 4, (off_t)(eo + h.n_escape * 8)) != (ssize_t)(h.n_escape * 4))
+          rc = mfx_fail(MFX_E_IO, "reading '%s' failed", path);
+        else rc = mfx_index_add_multi(ixs, nix, ek.data(), ev.data(), h.n_escape, side, minV, maxV);
+      }
+      close(fdn);
+      return rc;
+    }
     if ((uint64_t)st.st_size < sizeof(h) + h.n * (8 * kw + 4)) { close(fdn); return mfx_fail(MFX_E_FORMAT, "'%s': truncated payload", path); }
     if (h.n) rc = mfx_index_add_from_file(ixs, nix, fdn, path, sizeof(h), sizeof(h) + h.n * 8 * kw, h.n, side, minV, maxV);
     close(fdn);
@@ -676,7 +699,30 @@ extern "C" int mfx_db_write_flat(const char *path, int k, const uint64_t *kmers,
   h.k = (uint32_t)k;
   h.flags = 0;
   h.n = n;
-  h.reserved = 0;
+  h.n_escape = 0;
+  const char *pe = getenv("MFX_FLAT_PACKED");
+  if (k <= MFX_MAX_K_PACKED && !(pe && atoi(pe) == 0)) {    // packed records: 8 bytes per k-mer
+    h.flags |= FLAT_PACKED;
+    std::vector<uint64_t> ek;
+    std::vector<uint32_t> ev;
+    bool ok = true;
+    {
+      // the escapes first (their number goes into the header), then the records in pieces
+      for (uint64_t i = 0; i < n; ++i) if (values[i] >= MFX_PACKED_VMASK) { ek.push_back(kmers[i]); ev.push_back(values[i]); }
+      h.n_escape = ek.size();
+      ok = fwrite(&h, sizeof(h), 1, f) == 1;
+      std::vector<uint64_t> rec(std::min<uint64_t>(n, 1u << 20));
+      for (uint64_t o = 0; o < n && ok; o += rec.size()) {
+        const uint64_t m = std::min<uint64_t>(rec.size(), n - o);
+        for (uint64_t i = 0; i < m; ++i)
+          rec[i] = (kmers[o + i] << MFX_PACKED_VBITS) | (values[o + i] >= MFX_PACKED_VMASK ? MFX_PACKED_VMASK : values[o + i]);
+        ok = fwrite(rec.data(), 8, m, f) == m;
+      }
+      ok = ok && (ek.empty() || (fwrite(ek.data(), 8, ek.size(), f) == ek.size() && fwrite(ev.data(), 4, ev.size(), f) == ev.size()));
+    }
+    fclose(f);
+    return ok ? MFX_OK : mfx_fail(MFX_E_IO, "short write to '%s'", path);
+  }
   const size_t kw = k > MFX_MAX_K_NARROW ? 2 : 1;           // k > 31: two words per k-mer {low 64 bits, high bits}
   bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && (n == 0 || (fwrite(kmers, 8 * kw, n, f) == n && fwrite(values, 4, n, f) == n));
   fclose(f);

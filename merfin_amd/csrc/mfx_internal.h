@@ -28,6 +28,7 @@ int  mfx_fail(int code, const char *fmt, ...);
   } while (0)
 
 // flat-binary database -> table, read with parallel pread into the index's staging lanes (mfx_api.cpp)
+// vals_off == 0: the records at keys_off are PACKED (MFX_PACKED_VBITS), there is no counts array
 int  mfx_index_add_from_file(struct mfx_index *const *ixs, uint32_t nix, int fd, const char *path, uint64_t keys_off, uint64_t vals_off,
                              uint64_t n, int side, uint64_t minV, uint64_t maxV);
 // host arrays into several tables at once (one staging, one H2D per table; sharded tables keep what they own)
@@ -62,6 +63,14 @@ struct mfx_slot {               // 16 bytes: one dwordx4 load per probe
   uint32_t asmV;                // assembly count
 };
 constexpr uint64_t MFX_EMPTY = ~0ull;
+
+// Packed k-mer records of the flat database form and of its transport (k <= 21: a k-mer has at most 42 bits): one uint64 =
+// {k-mer << 22 | count}; a count field of all ones is an escape -- the record's real count (>= 2^22 - 1) comes in a short
+// side list.  8 bytes per k-mer on disk, through the staging lanes and over PCIe instead of 12; unpacked by the lane that
+// inserts it (mfx_table_add_kernel / mfx_table_update_kernel with values == nullptr).
+constexpr int      MFX_PACKED_VBITS = 22;
+constexpr uint32_t MFX_PACKED_VMASK = (1u << MFX_PACKED_VBITS) - 1u;
+constexpr int      MFX_MAX_K_PACKED = 21;
 
 // 32 <= k <= 64: k-mers of up to 128 bits (mfx_wide.hip).  Four 32-byte slots per 128-byte line.
 struct mfx_wslot {

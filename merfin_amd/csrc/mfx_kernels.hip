@@ -471,7 +471,11 @@ __global__ __launch_bounds__(256) void mfx_table_add_kernel(mfx_table_view t, co
     const uint64_t i = base + threadIdx.x;
     uint64_t key = 0;
     uint32_t v = 0;
-    if (i < n) { key = kmers[i]; v = values[i]; }
+    if (i < n) {
+      key = kmers[i];
+      if (values) v = values[i];
+      else { v = (uint32_t)key & MFX_PACKED_VMASK; key >>= MFX_PACKED_VBITS; if (v == MFX_PACKED_VMASK) v = 0u; }   // packed record; escape: added separately
+    }
     bool ok = v != 0;
     if (ok) {
       const uint64_t krc = mfx_revcomp(key, t.k);
@@ -497,8 +501,10 @@ __global__ __launch_bounds__(256) void mfx_table_update_kernel(mfx_table_view t,
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   uint32_t dropped = 0, noncanon = 0;
   for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += stride) {
-    const uint64_t key = kmers[i];
-    const uint32_t v = values[i];
+    uint64_t key = kmers[i];
+    uint32_t v;
+    if (values) v = values[i];
+    else { v = (uint32_t)key & MFX_PACKED_VMASK; key >>= MFX_PACKED_VBITS; if (v == MFX_PACKED_VMASK) v = 0u; }     // packed record; escape: added separately
     if (v == 0u) continue;
     if (key > mfx_revcomp(key, t.k)) { ++noncanon; continue; }
     if (t.compact) {

@@ -340,3 +340,45 @@ def test_randomized_database_forms_agree(tmp_path, seed, monkeypatch):
         ix.load_db(flat, 0, lo, hi)
         got, _ = ix.value(keys)
         assert got.tolist() == [v if lo <= v <= hi else 0 for v in vals.tolist()]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [21, 15])
+def test_packed_flat_records_equal_plain_ones(tmp_path, k, monkeypatch):
+    """the flat form stores k <= 21 as packed 8-byte records {k-mer << 22 | count} (counts >= 2^22 - 1 escape to a side list);
+    plain (MFX_FLAT_PACKED=0: 8 + 4 bytes) and packed files of one database give the same full table and the same
+    sequence-only table, escapes and zero counts included"""
+    import os
+    import merfin_amd as m
+    from tests import synth
+    contigs, read, asm = synth.world(k=k, peak=9.0, seed=77)
+    rv = read[1].astype(np.uint64)
+    rv[::37] = np.array([2**22 - 2, 2**22 - 1, 2**22, 2**31, 2**32 - 1] * (len(rv[::37]) // 5 + 1), dtype=np.uint64)[:len(rv[::37])]
+    rv[5::41] = 0                                                    # a zero count: never stored
+    read = (read[0], rv.astype(np.uint32))
+    paths = {}
+    for packed in ("0", "1"):
+        monkeypatch.setenv("MFX_FLAT_PACKED", packed)
+        paths[packed] = str(tmp_path / ("r%s.mfxk" % packed))
+        m.db_write_flat(paths[packed], k, *read)
+    n = len(read[0])
+    assert os.path.getsize(paths["0"]) == 32 + 12 * n
+    n_esc = int((read[1] >= 2**22 - 1).sum())
+    assert os.path.getsize(paths["1"]) == 32 + 8 * n + 12 * n_esc and n_esc > 10
+    seqs = m.Sequences(contigs)
+    tables = []
+    for packed in ("0", "1"):
+        assert m.db_probe(paths[packed]) == {"k": k, "format": "flat", "n_kmers": n}
+        full = m.Index(k, n + 16)
+        full.load_db(paths[packed], 0)
+        so = m.Index.for_seq(k, sum(len(c) for c in contigs) + 16)
+        so.count_asm(seqs)
+        so.load_db(paths[packed], 0)
+        tables.append((full.export(), so.export()))
+    for a, b in zip(tables[0], tables[1]):
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
+    ek, er, _ = tables[1][0]
+    keep = read[1] > 0
+    np.testing.assert_array_equal(ek, read[0][keep])
+    np.testing.assert_array_equal(er, read[1][keep])
