@@ -254,16 +254,32 @@ __device__ __forceinline__ uint2 mfx_c_lookup(const mfx_table_view &c, uint64_t 
   return mfx_c_fields(c, key, (uint32_t)w);
 }
 
-// find-or-claim the slot of `key` (mfx_claim for 8-byte slots): slots of a line fill in order, a slot never changes its
-// key once written.  cur = the slot's word as seen (a fresh claim: the key with both counts 0).
+// Where in its line a k-mer goes: the line is eight MINI-BUCKETS of two slots (16 bytes: one dwordx4 of one lane); a
+// k-mer's slots are tried from mini-bucket mfx_c_first(key) on, around the line, then on through the candidate lines.
+// At the load factors this layout is built at (<= 0.5, 0.25 by default) 92 % of the k-mers sit in their first mini-bucket,
+// so a lookup is ONE 16-byte load of one lane for most queries (mfx_lane_lookup8) -- and neighbouring k-mers, which share
+// their minimizer's line, make those loads fall into the same 128-byte lines.  A lookup stops at the key or at the first
+// empty slot of its own order; scanning a WHOLE line (mfx_c_find, the cooperative probe) may stop at any empty slot: the
+// k-mer's order visits every slot of a line before it leaves it.
+__device__ __forceinline__ uint32_t mfx_c_first(uint64_t key) {
+  uint32_t x = (uint32_t)key ^ (uint32_t)(key >> 32);
+  x ^= x >> 15;
+  x ^= x >> 7;
+  return (x ^ (x >> 3)) & 7u;
+}
+
+// find-or-claim the slot of `key` (mfx_claim for 8-byte slots): a k-mer takes the first empty slot of its order, a slot
+// never changes its key once written.  cur = the slot's word as seen (a fresh claim: the key with both counts 0).
 __device__ __forceinline__ unsigned long long *mfx_c_claim(const mfx_table_view &c, uint64_t key, uint64_t *meta, uint32_t &fresh,
                                                            unsigned long long &cur) {
   const mfx_probe pr = mfx_home(c, key);
   unsigned long long *cs = reinterpret_cast<unsigned long long *>(c.slots);
   const unsigned long long mine = (unsigned long long)key << 22;
+  const uint32_t q0 = 2u * mfx_c_first(key);
   for (uint32_t d = 0; d < MFX_MAX_LINES; ++d) {
     unsigned long long *base = cs + mfx_probe_line(c, pr, d) * MFX_CSLOTS_LINE;
-    for (uint32_t q = 0; q < MFX_CSLOTS_LINE; ++q) {
+    for (uint32_t qi = 0; qi < MFX_CSLOTS_LINE; ++qi) {
+      const uint32_t q = (q0 + qi) & (MFX_CSLOTS_LINE - 1u);
       cur = __hip_atomic_load(base + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (cur == MFX_EMPTY) {
         cur = atomicCAS(base + q, (unsigned long long)MFX_EMPTY, mine);
@@ -781,8 +797,10 @@ __device__ __forceinline__ void mfx_group_post8(uint32_t *rec, const mfx_u32x4 (
 }
 template <int S>
 __device__ __forceinline__ uint64_t mfx_group_room8(const mfx_u32x4 (&v)[8]) {
-  const uint64_t m = __ballot(v[S].w == 0xffffffffu);        // the LAST slot of the line is lane 7's second one; a stored high word is < 2^20
-  return ((m >> 7) & 0x0101010101010101ULL) << S;
+  // any empty slot in the line (slots are not filled in line order: mfx_c_first); a stored high word is < 2^20
+  uint64_t m = __ballot(v[S].y == 0xffffffffu || v[S].w == 0xffffffffu);
+  m |= m >> 4; m |= m >> 2; m |= m >> 1;                     // bit 8g: any lane of group g
+  return (m & 0x0101010101010101ULL) << S;
 }
 
 template <int B>
@@ -871,7 +889,7 @@ __device__ __forceinline__ void mfx_group_lookup8(const mfx_table_view &c, mfx_m
     if (live) sl = *reinterpret_cast<const uint4 *>(slots0 + ((uint64_t)ent.z << 7) + sub16);
     uint32_t *rec = reinterpret_cast<uint32_t *>(&M.rec[wbase + e]);
     if (live) {
-      if ((tid & 7u) == 7u && sl.w == 0xffffffffu) rec[3] = 1u;                        // the line's last slot is free: it has room
+      if (sl.y == 0xffffffffu || sl.w == 0xffffffffu) rec[3] = 1u;                     // an empty slot: the line has room
       if (sl.y == ent.y && ((sl.x ^ ent.x) >> 22) == 0u) { rec[0] = sl.x; rec[2] = 0xffffffffu; }    // found (marker: no line has this index)
       else if (sl.w == ent.y && ((sl.z ^ ent.x) >> 22) == 0u) { rec[0] = sl.z; rec[2] = 0xffffffffu; }
     }
@@ -901,6 +919,135 @@ __device__ __forceinline__ void mfx_group_lookup8(const mfx_table_view &c, mfx_m
     rv[j] = x.x; av[j] = x.y;
   }
 }
+
+// ---------------------------------------------------------------------------
+// Per-lane probe of the compact layout.  Every lane looks its own queries up: ONE 16-byte load per query -- the k-mer's
+// first mini-bucket -- and 92 % of the k-mers are there (load factor 0.25).  No hand-offs between lanes, no mailbox,
+// no broadcasts: what the cooperative probe spends on them (~100 VALU / LDS-crossbar instructions per k-mer) is gone, and
+// the memory system sees the same lines: neighbouring lanes hold neighbouring k-mers, which share their minimizer's line,
+// so a wave's 64 loads fall into ~27 distinct 128-byte lines and run at the LINE rate, not at a lane rate
+// (tools/ubench_locality.hip: 119 G 16-byte lane loads/s at 2.4 lanes per line, 50 G distinct lines/s either way).
+// The B queries of a lane are in flight together; queries that did not end in their first mini-bucket go round by round
+// through the next ones (a round = one more load for the lanes that need it, the others wait): 5.8 % need a second
+// load, 1.3 % a third.  A line exhausted without the key or an empty slot is rare enough for the whole-line scan (mfx_c_find).
+// ---------------------------------------------------------------------------
+template <int B>
+__device__ __forceinline__ void mfx_lane_lookup8(const mfx_table_view &c, mfx_mailbox &M, const uint64_t (&key)[B], const uint64_t (&krc)[B],
+                                                 const bool (&ok)[B], uint32_t (&rv)[B], uint32_t (&av)[B]) {
+  const uint32_t tid = threadIdx.x, sub16 = (tid & 7u) << 4, lane = tid & 63u, wbase = tid & ~63u;
+  const uint4 *const slots0 = reinterpret_cast<const uint4 *>(c.slots);
+  uint32_t line[B];
+  uint32_t st[B];               // 0xff done; 1 not in its first mini-bucket; 0xfe a count field is saturated (the slot's low word parked in rv);
+                                // 0xfd / 0xfc whole-line scans from candidate line 1 / 0 (set below)
+  uint4 v[B];
+  // ---- first mini-bucket of every query: one 16-byte load per lane and query, all B in flight
+#pragma unroll
+  for (int j = 0; j < B; ++j) {
+    line[j] = ok[j] ? mfx_first_line(c, key[j], krc[j]) : 0u;  // no k-mer here: a dummy load of line 0, ignored below
+    v[j] = slots0[((uint64_t)line[j] << 3) | mfx_c_first(key[j])];
+  }
+#pragma unroll
+  for (int j = 0; j < B; ++j) {
+    const uint4 s = v[j];
+    // {key 42 | counts 22}: equal high words and low words that differ in the 22 count bits only (the empty word's key is
+    // not a canonical k-mer)
+    const uint64_t ks = key[j] << 22;
+    const uint32_t klo = (uint32_t)ks, khi = (uint32_t)(ks >> 32);
+    const bool ha = s.y == khi && ((s.x ^ klo) >> 22) == 0u, hb = s.w == khi && ((s.z ^ klo) >> 22) == 0u;
+    const bool found = ha || hb, room = s.y == 0xffffffffu || s.w == 0xffffffffu;
+    const uint32_t lo = ha ? s.x : s.z;
+    const uint32_t r_rv = (lo >> 11) & MFX_CSAT, r_av = lo & MFX_CSAT;
+    const bool sat = r_rv == MFX_CSAT || r_av == MFX_CSAT;
+    const uint32_t f_rv = (r_rv < c.minV || r_rv > c.maxV) ? 0u : r_rv;      // -min / -max (merfin.C:199-200)
+    rv[j] = found ? (sat ? lo : f_rv) : 0u;
+    av[j] = (found && !sat) ? r_av : 0u;
+    st[j] = !ok[j] ? 0xffu : (found ? (sat ? 0xfeu : 0xffu) : (room ? 0xffu : 1u));  // an empty slot before the key: absent (value 0, merfin-globals.C:84)
+  }
+  // ---- the queries that were not in their first mini-bucket (8 % at load factor 0.25): compacted into this wave's mailbox
+  // and served 8 per step by the cooperative whole-line probe -- the 8 lanes of a group fetch the query's HOME line with one
+  // coalesced request, so that whichever mini-bucket the k-mer went to, one more round trip finds it
+  uint32_t qpos[B];
+  uint32_t nq = 0;
+#pragma unroll
+  for (int j = 0; j < B; ++j) {
+    const bool p = st[j] == 1u;
+    const uint64_t m = __ballot(p);
+    const uint32_t pos = nq + (uint32_t)__popcll(m & ((1ULL << lane) - 1ULL));
+    qpos[j] = 0xffffffffu;
+    if (p && pos < 64u) {
+      qpos[j] = pos;
+      const uint64_t ks = key[j] << 22;
+      M.rec[wbase + pos] = make_uint4((uint32_t)ks, (uint32_t)(ks >> 32), line[j], 0u);
+    }
+    nq += (uint32_t)__popcll(m);
+  }
+  if (nq) {                                                    // wave-uniform
+    mfx_wave_handoff();
+    if (nq > 64u) nq = 64u;
+    for (uint32_t q0 = 0; q0 < nq; q0 += 8u) {
+      const uint32_t e = q0 + (lane >> 3);
+      const bool live = e < nq;
+      const uint4 ent = M.rec[wbase + (live ? e : 0u)];
+      mfx_wave_handoff();
+      uint4 sl = make_uint4(0u, 0u, 0u, 0u);
+      if (live) sl = *reinterpret_cast<const uint4 *>(reinterpret_cast<uint64_t>(c.slots) + ((uint64_t)ent.z << 7) + sub16);
+      uint32_t *rec = reinterpret_cast<uint32_t *>(&M.rec[wbase + e]);
+      if (live) {
+        if (sl.y == 0xffffffffu || sl.w == 0xffffffffu) rec[3] = 1u;                     // an empty slot: the line has room
+        if (sl.y == ent.y && ((sl.x ^ ent.x) >> 22) == 0u) { rec[0] = sl.x; rec[2] = 0xffffffffu; }    // found (marker: no line has this index)
+        else if (sl.w == ent.y && ((sl.z ^ ent.x) >> 22) == 0u) { rec[0] = sl.z; rec[2] = 0xffffffffu; }
+      }
+    }
+    mfx_wave_handoff();
+#pragma unroll
+    for (int j = 0; j < B; ++j) {
+      if (st[j] != 1u) continue;
+      st[j] = 0xfcu;                                           // not served (more than 64 of them in this wave): whole-line scans from the home line
+      if (qpos[j] != 0xffffffffu) {
+        const uint4 r = M.rec[wbase + qpos[j]];
+        if (r.z == 0xffffffffu) {
+          const uint32_t r_rv = (r.x >> 11) & MFX_CSAT, r_av = r.x & MFX_CSAT;
+          if (r_rv == MFX_CSAT || r_av == MFX_CSAT) { rv[j] = r.x; st[j] = 0xfeu; }
+          else { rv[j] = (r_rv < c.minV || r_rv > c.maxV) ? 0u : r_rv; av[j] = r_av; st[j] = 0xffu; }
+        } else if (r.w == 1u) st[j] = 0xffu;                   // the home line has room and does not hold the key: absent
+        else st[j] = 0xfdu;                                    // the home line is full of other k-mers: the next candidate lines
+      }
+    }
+  }
+  // ---- the rare endings, ONE instance of their code for all B queries of the lane: a saturated count field (the exact
+  // count is in the side table) or whole-line scans of the candidate lines
+  while (true) {
+    int sj = -1;
+    uint64_t skey = 0;
+    uint32_t slo = 0, scode = 0;
+#pragma unroll
+    for (int j = 0; j < B; ++j)
+      if (sj < 0 && st[j] >= 0xfcu && st[j] <= 0xfeu) { sj = j; skey = key[j]; slo = rv[j]; scode = st[j]; }
+    if (!__any(sj >= 0)) break;
+    if (sj >= 0) {
+      uint2 x = make_uint2(0u, 0u);
+      bool have = scode == 0xfeu;
+      if (!have) {
+        unsigned long long w = 0;
+        have = mfx_c_find(c, skey, mfx_home(c, skey), scode == 0xfdu ? 1u : 0u, w) != nullptr;
+        slo = (uint32_t)w;
+      }
+      if (have) x = mfx_c_fields(c, skey, slo);
+#pragma unroll
+      for (int j = 0; j < B; ++j)
+        if (sj == j) { rv[j] = x.x; av[j] = x.y; st[j] = 0xffu; }
+    }
+  }
+}
+
+#ifndef MFX_V_LANEPROBE
+#define MFX_V_LANEPROBE 1             // 1: per-lane probe of the compact layout (mfx_lane_lookup8); 0: the cooperative one (A/B: tools/ab_build.sh)
+#endif
+#if MFX_V_LANEPROBE
+#define MFX_COMPACT_LOOKUP(t, MB, key, krc, ok, rv, av) mfx_lane_lookup8<MFX_BATCH>(t, MB, key, krc, ok, rv, av)
+#else
+#define MFX_COMPACT_LOOKUP(t, MB, key, krc, ok, rv, av) mfx_group_lookup8<MFX_BATCH>(t, MB, key, krc, ok, rv, av)
+#endif
 
 // k-mer starting at tile position p; returns validity (all k bases ACGT)
 __device__ __forceinline__ bool mfx_tile_kmer(const mfx_tile_lds &L, int k, uint32_t p, uint64_t &fwd) {
@@ -1001,12 +1148,12 @@ __global__ __launch_bounds__(MFX_BLOCK, 4) void mfx_hist_kernel(mfx_hist_args a)
           key[j] = f; key2[j] = r;
         }
       }
-      if (COMPACT) mfx_group_lookup8<MFX_BATCH>(a.t, MB, key, key2, ok, rv, av);
+      if (COMPACT) MFX_COMPACT_LOOKUP(a.t, MB, key, key2, ok, rv, av);
       else mfx_group_lookup<MFX_BATCH>(a.t, MB, key, key2, ok, rv, av);
       if (!CANON) {
         // value(fmer) + value(rmer), uint32 arithmetic (merfin-globals.C:107-108)
         uint32_t rv2[MFX_BATCH], av2[MFX_BATCH];
-        if (COMPACT) mfx_group_lookup8<MFX_BATCH>(a.t, MB, key2, key, ok, rv2, av2);
+        if (COMPACT) MFX_COMPACT_LOOKUP(a.t, MB, key2, key, ok, rv2, av2);
         else mfx_group_lookup<MFX_BATCH>(a.t, MB, key2, key, ok, rv2, av2);
 #pragma unroll
         for (int j = 0; j < MFX_BATCH; ++j) { rv[j] += rv2[j]; av[j] += av2[j]; }
@@ -1392,11 +1539,11 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_dump_kernel(mfx_dump_args a) {
 #pragma unroll
       for (int j = 0; j < MFX_BATCH; ++j) rv[j] = ok[j] ? a.readV[pos0 + (b + j) * MFX_BLOCK + tid - a.skip] : 0u;
     } else {
-      if (COMPACT) mfx_group_lookup8<MFX_BATCH>(a.t, MB, key, key2, ok, rv, av);
+      if (COMPACT) MFX_COMPACT_LOOKUP(a.t, MB, key, key2, ok, rv, av);
       else mfx_group_lookup<MFX_BATCH>(a.t, MB, key, key2, ok, rv, av);
       if (!CANON) {
         uint32_t rv2[MFX_BATCH], av2[MFX_BATCH];
-        if (COMPACT) mfx_group_lookup8<MFX_BATCH>(a.t, MB, key2, key, ok, rv2, av2);
+        if (COMPACT) MFX_COMPACT_LOOKUP(a.t, MB, key2, key, ok, rv2, av2);
         else mfx_group_lookup<MFX_BATCH>(a.t, MB, key2, key, ok, rv2, av2);
 #pragma unroll
         for (int j = 0; j < MFX_BATCH; ++j) { rv[j] += rv2[j]; av[j] += av2[j]; }
