@@ -133,10 +133,11 @@ struct DevBuf {   // scoped device scratch
 // second probes (3 Gb -hist, w = 3: 0.7 -> 80, 0.6 -> 85, 0.52 -> 89.8, 0.45 -> 91.5, 0.40 -> 91.2 G k-mers/s: nothing is
 // gained below 0.45), and 288 GB of HBM are there to be used.
 constexpr double MFX_LF_MAX = 0.7, MFX_LF_MIN = 0.45, MFX_LF_HBM_SHARE = 0.75;
-// The compact layout of a sequence-only index (16 slots per line, buckets of w = 4 windows): 3 Gb -hist runs at 85.8 /
-// 95.7 / 98.9 / 101.1 G k-mers/s at load factors 0.40 / 0.30 / 0.25 / 0.20 (profiles/r02_compact_index.txt); 0.25 is
-// 96 GB for a human assembly -- less than half of what the full table of reads + assembly takes at its 0.45.
-constexpr double MFX_CLF_MAX = 0.5, MFX_CLF_MIN = 0.25;
+// The compact layout of a sequence-only index (16 slots per line in 8 mini-buckets, buckets of w = 4 windows): the emptier the
+// table, the more k-mers sit in their first mini-bucket (one 16-byte load) -- 3 Gb -hist: 102.6 / 108.0 / 111.9 G k-mers/s at load
+// factors 0.30 / 0.25 / 0.20 (profiles/r03_kernel_experiments.txt).  0.225 is 105 GB for a human assembly -- half of what the
+// full table of reads + assembly takes at its 0.45.
+constexpr double MFX_CLF_MAX = 0.5, MFX_CLF_MIN = 0.225;
 
 bool load_factor_fixed(double *lf) {
   const char *e = getenv("MFX_LOAD_FACTOR");

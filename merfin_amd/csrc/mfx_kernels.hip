@@ -1069,14 +1069,20 @@ __device__ __forceinline__ bool mfx_tile_kmer(const mfx_tile_lds &L, int k, uint
 #endif
 constexpr int MFX_BATCH = MFX_V_BATCH;          // queries per lane and cooperative-probe sequence (tools/ab_build.sh -DMFX_V_BATCH=2: A/B)
 
-template <bool CANON, bool COMPACT>
+// KF, WF: k-mer size and minimizer windows as COMPILE-TIME constants (0: taken from the table at run time).  Every shift, mask
+// and window count of the extraction, the reverse complement and the placement hash is then an immediate instead of a scalar
+// register -- the generic kernel keeps so many loop-invariant scalars that a third of them live spilled in VGPR lanes and are
+// read back (v_readlane + hazard nops) for every query.  The launcher picks the instance of the k the table holds: k = 21
+// (meryl's default for a human genome, BASELINE configs 1-4) and k = 31 (config 5); any other k runs the generic instance.
+template <bool CANON, bool COMPACT, int KF, int WF>
 __global__ __launch_bounds__(MFX_BLOCK, 4) void mfx_hist_kernel(mfx_hist_args a) {
   __shared__ mfx_tile_lds L;
   __shared__ mfx_mailbox MB;
   __shared__ mfx_hist_lds H;
 
   const uint32_t tid = threadIdx.x;
-  const int k = a.t.k;
+  if (KF) { a.t.k = KF; a.t.mz_w = WF; }                       // (the launcher checked that they are the table's)
+  const int k = KF ? KF : a.t.k;
   const mfx_kstar_args &ka = a.ks;
   mfx_hist_lds_init(H, ka);
   const bool lut_ok = H.lut_ok != 0u;
@@ -1757,10 +1763,14 @@ hipError_t mfx_k_table_export(mfx_table_view t, uint64_t *kmers, uint32_t *readV
 hipError_t mfx_k_hist(const mfx_hist_args &a, int grid, hipStream_t st) {
   // MFX_DEBUG_DYN_LDS: extra dynamic LDS per block, an occupancy knob for experiments only
   static const unsigned dyn = getenv("MFX_DEBUG_DYN_LDS") ? (unsigned)atoi(getenv("MFX_DEBUG_DYN_LDS")) : 0u;
-  if (a.canonical && a.t.compact) mfx_hist_kernel<true, true><<<grid, MFX_BLOCK, dyn, st>>>(a);
-  else if (a.canonical)           mfx_hist_kernel<true, false><<<grid, MFX_BLOCK, dyn, st>>>(a);
-  else if (a.t.compact)           mfx_hist_kernel<false, true><<<grid, MFX_BLOCK, dyn, st>>>(a);
-  else                            mfx_hist_kernel<false, false><<<grid, MFX_BLOCK, dyn, st>>>(a);
+  static const bool generic = getenv("MFX_HIST_GENERIC") && atoi(getenv("MFX_HIST_GENERIC"));     // A/B, tests: never the specialised instances
+  if (a.canonical && a.t.compact && a.t.k == 21 && a.t.mz_w == 4 && !generic)   mfx_hist_kernel<true, true, 21, 4><<<grid, MFX_BLOCK, dyn, st>>>(a);
+  else if (a.canonical && !a.t.compact && a.t.k == 21 && a.t.mz_w == 3 && !generic) mfx_hist_kernel<true, false, 21, 3><<<grid, MFX_BLOCK, dyn, st>>>(a);
+  else if (a.canonical && !a.t.compact && a.t.k == 31 && a.t.mz_w == 3 && !generic) mfx_hist_kernel<true, false, 31, 3><<<grid, MFX_BLOCK, dyn, st>>>(a);
+  else if (a.canonical && a.t.compact) mfx_hist_kernel<true, true, 0, 0><<<grid, MFX_BLOCK, dyn, st>>>(a);
+  else if (a.canonical)                mfx_hist_kernel<true, false, 0, 0><<<grid, MFX_BLOCK, dyn, st>>>(a);
+  else if (a.t.compact)                mfx_hist_kernel<false, true, 0, 0><<<grid, MFX_BLOCK, dyn, st>>>(a);
+  else                                 mfx_hist_kernel<false, false, 0, 0><<<grid, MFX_BLOCK, dyn, st>>>(a);
   return hipGetLastError();
 }
 hipError_t mfx_k_route(const mfx_route_args &a, hipStream_t st) {
@@ -1815,8 +1825,8 @@ hipError_t mfx_k_sum_tile_partials(double *tile_partials, uint64_t ntiles, doubl
 }
 int mfx_k_hist_resident_blocks(int compact) {
   int nb = 0;
-  const hipError_t e = compact ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mfx_hist_kernel<true, true>, MFX_BLOCK, 0)
-                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mfx_hist_kernel<true, false>, MFX_BLOCK, 0);
+  const hipError_t e = compact ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mfx_hist_kernel<true, true, 0, 0>, MFX_BLOCK, 0)
+                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mfx_hist_kernel<true, false, 0, 0>, MFX_BLOCK, 0);
   if (e != hipSuccess || nb < 1) nb = 4;
   return nb;
 }

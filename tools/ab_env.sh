@@ -1,0 +1,13 @@
+#!/bin/bash
+# usage: tools/ab_env.sh "label ENV=VAL ..." ...   -- 3 Gb -hist bench per environment, same box, back to back (twice)
+for rep in 1 2; do
+for spec in "$@"; do
+  read -r label rest <<< "$spec"
+  env $rest python bench.py --steps 10 --warmup 3 --no-pmc --no-cpu-baseline --no-streamed > gpurun_out/abe_$label.json 2> gpurun_out/abe_$label.err
+  python - <<PY
+import json
+d=json.load(open("gpurun_out/abe_$label.json"))
+print("$label rep$rep", "%.2f G k-mers/s" % (d["value"]/1e9), "%.3f ms" % d["ms_per_step"], "kernel %.3f ms" % d["roofline"]["kernel_ms"], d["config"]["kmissing"], d["config"]["koverCpy"], d["config"]["hist_sum_check"])
+PY
+done
+done
