@@ -1072,8 +1072,9 @@ constexpr int MFX_BATCH = MFX_V_BATCH;          // queries per lane and cooperat
 // KF, WF: k-mer size and minimizer windows as COMPILE-TIME constants (0: taken from the table at run time).  Every shift, mask
 // and window count of the extraction, the reverse complement and the placement hash is then an immediate instead of a scalar
 // register -- the generic kernel keeps so many loop-invariant scalars that a third of them live spilled in VGPR lanes and are
-// read back (v_readlane + hazard nops) for every query.  The launcher picks the instance of the k the table holds: k = 21
-// (meryl's default for a human genome, BASELINE configs 1-4) and k = 31 (config 5); any other k runs the generic instance.
+// read back (v_readlane + hazard nops) for every query.  The launcher picks the k = 21 / w = 4 instance for the compact layout
+// (meryl's default k for a human genome, BASELINE configs 1-4: 103.6 -> 108.0 G k-mers/s); any other k, and the full table --
+// whose kernel sits on the HBM line rate either way (91.0 G with and without) -- run the generic instance.
 template <bool CANON, bool COMPACT, int KF, int WF>
 __global__ __launch_bounds__(MFX_BLOCK, 4) void mfx_hist_kernel(mfx_hist_args a) {
   __shared__ mfx_tile_lds L;
@@ -1765,8 +1766,6 @@ hipError_t mfx_k_hist(const mfx_hist_args &a, int grid, hipStream_t st) {
   static const unsigned dyn = getenv("MFX_DEBUG_DYN_LDS") ? (unsigned)atoi(getenv("MFX_DEBUG_DYN_LDS")) : 0u;
   static const bool generic = getenv("MFX_HIST_GENERIC") && atoi(getenv("MFX_HIST_GENERIC"));     // A/B, tests: never the specialised instances
   if (a.canonical && a.t.compact && a.t.k == 21 && a.t.mz_w == 4 && !generic)   mfx_hist_kernel<true, true, 21, 4><<<grid, MFX_BLOCK, dyn, st>>>(a);
-  else if (a.canonical && !a.t.compact && a.t.k == 21 && a.t.mz_w == 3 && !generic) mfx_hist_kernel<true, false, 21, 3><<<grid, MFX_BLOCK, dyn, st>>>(a);
-  else if (a.canonical && !a.t.compact && a.t.k == 31 && a.t.mz_w == 3 && !generic) mfx_hist_kernel<true, false, 31, 3><<<grid, MFX_BLOCK, dyn, st>>>(a);
   else if (a.canonical && a.t.compact) mfx_hist_kernel<true, true, 0, 0><<<grid, MFX_BLOCK, dyn, st>>>(a);
   else if (a.canonical)                mfx_hist_kernel<true, false, 0, 0><<<grid, MFX_BLOCK, dyn, st>>>(a);
   else if (a.t.compact)                mfx_hist_kernel<false, true, 0, 0><<<grid, MFX_BLOCK, dyn, st>>>(a);
