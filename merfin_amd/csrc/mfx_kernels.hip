@@ -984,18 +984,32 @@ __device__ __forceinline__ void mfx_lane_lookup8(const mfx_table_view &c, mfx_ma
   if (nq) {                                                    // wave-uniform
     mfx_wave_handoff();
     if (nq > 64u) nq = 64u;
-    for (uint32_t q0 = 0; q0 < nq; q0 += 8u) {
-      const uint32_t e = q0 + (lane >> 3);
-      const bool live = e < nq;
-      const uint4 ent = M.rec[wbase + (live ? e : 0u)];
-      mfx_wave_handoff();
-      uint4 sl = make_uint4(0u, 0u, 0u, 0u);
-      if (live) sl = *reinterpret_cast<const uint4 *>(reinterpret_cast<uint64_t>(c.slots) + ((uint64_t)ent.z << 7) + sub16);
-      uint32_t *rec = reinterpret_cast<uint32_t *>(&M.rec[wbase + e]);
-      if (live) {
-        if (sl.y == 0xffffffffu || sl.w == 0xffffffffu) rec[3] = 1u;                     // an empty slot: the line has room
-        if (sl.y == ent.y && ((sl.x ^ ent.x) >> 22) == 0u) { rec[0] = sl.x; rec[2] = 0xffffffffu; }    // found (marker: no line has this index)
-        else if (sl.w == ent.y && ((sl.z ^ ent.x) >> 22) == 0u) { rec[0] = sl.z; rec[2] = 0xffffffffu; }
+    // up to MFX_TAIL_STEPS steps (8 queries each) per pass, their line loads in flight TOGETHER: a wave typically has ~20 such
+    // queries among its 256, i.e. three steps -- one round trip instead of three
+    constexpr uint32_t MFX_TAIL_STEPS = 4;
+    for (uint32_t q0 = 0; q0 < nq; q0 += 8u * MFX_TAIL_STEPS) {
+      uint4 ent[MFX_TAIL_STEPS], sl[MFX_TAIL_STEPS];
+#pragma unroll
+      for (uint32_t sp = 0; sp < MFX_TAIL_STEPS; ++sp) {
+        const uint32_t e = q0 + 8u * sp + (lane >> 3);
+        ent[sp] = M.rec[wbase + (e < nq ? e : 0u)];
+      }
+      mfx_wave_handoff();                                        // every lane of a group has its entries before one answers into them
+#pragma unroll
+      for (uint32_t sp = 0; sp < MFX_TAIL_STEPS; ++sp) {
+        const uint32_t e = q0 + 8u * sp + (lane >> 3);
+        sl[sp] = make_uint4(0u, 0u, 0u, 0u);
+        if (e < nq) sl[sp] = *reinterpret_cast<const uint4 *>(reinterpret_cast<uint64_t>(c.slots) + ((uint64_t)ent[sp].z << 7) + sub16);
+      }
+#pragma unroll
+      for (uint32_t sp = 0; sp < MFX_TAIL_STEPS; ++sp) {
+        const uint32_t e = q0 + 8u * sp + (lane >> 3);
+        uint32_t *rec = reinterpret_cast<uint32_t *>(&M.rec[wbase + e]);
+        if (e < nq) {
+          if (sl[sp].y == 0xffffffffu || sl[sp].w == 0xffffffffu) rec[3] = 1u;               // an empty slot: the line has room
+          if (sl[sp].y == ent[sp].y && ((sl[sp].x ^ ent[sp].x) >> 22) == 0u) { rec[0] = sl[sp].x; rec[2] = 0xffffffffu; }    // found (marker: no line has this index)
+          else if (sl[sp].w == ent[sp].y && ((sl[sp].z ^ ent[sp].x) >> 22) == 0u) { rec[0] = sl[sp].z; rec[2] = 0xffffffffu; }
+        }
       }
     }
     mfx_wave_handoff();
