@@ -276,16 +276,25 @@ __device__ __forceinline__ unsigned long long *mfx_c_claim(const mfx_table_view 
   unsigned long long *cs = reinterpret_cast<unsigned long long *>(c.slots);
   const unsigned long long mine = (unsigned long long)key << 22;
   const uint32_t q0 = 2u * mfx_c_first(key);
+  // A mini-bucket is read by ONE plain 16-byte load.  It may come from this CU's L1 and be older than the table: a slot
+  // seen occupied stays what it is (a slot never changes its key once written), a slot seen empty is taken by compare-and-
+  // swap, whose answer is the truth -- the claim, the k-mer itself (another lane claimed it first), or another key (on).
   for (uint32_t d = 0; d < MFX_MAX_LINES; ++d) {
     unsigned long long *base = cs + mfx_probe_line(c, pr, d) * MFX_CSLOTS_LINE;
-    for (uint32_t qi = 0; qi < MFX_CSLOTS_LINE; ++qi) {
+    for (uint32_t qi = 0; qi < MFX_CSLOTS_LINE; qi += 2) {
       const uint32_t q = (q0 + qi) & (MFX_CSLOTS_LINE - 1u);
-      cur = __hip_atomic_load(base + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (cur == MFX_EMPTY) {
-        cur = atomicCAS(base + q, (unsigned long long)MFX_EMPTY, mine);
-        if (cur == MFX_EMPTY) { ++fresh; cur = mine; return base + q; }
+      const uint4 s = *reinterpret_cast<const uint4 *>(base + q);
+      const unsigned long long seen[2] = {(unsigned long long)s.x | ((unsigned long long)s.y << 32),
+                                          (unsigned long long)s.z | ((unsigned long long)s.w << 32)};
+#pragma unroll
+      for (uint32_t e = 0; e < 2; ++e) {
+        cur = seen[e];
+        if (cur == MFX_EMPTY) {
+          cur = atomicCAS(base + q + e, (unsigned long long)MFX_EMPTY, mine);
+          if (cur == MFX_EMPTY) { ++fresh; cur = mine; return base + q + e; }
+        }
+        if ((cur >> 22) == key) return base + q + e;         // cur is not the empty word here
       }
-      if ((cur >> 22) == key) return base + q;               // cur is not the empty word here
     }
   }
   atomicAdd((unsigned long long *)&meta[2], 1ull);
@@ -383,7 +392,10 @@ __device__ __forceinline__ void mfx_ins_announce(mfx_ins_rounds &R, uint64_t key
   R.val[S] = mfx_group_bcast<S>(v);
 }
 
-// one key per lane (v == 0: none); adds v to the key's read (side 0) or assembly (side 1) count
+// one key per lane (v == 0: none); adds v to the key's read (side 0) or assembly (side 1) count.
+// CLAIM = false: update-only (sequence-only index) -- a key that is not in the table is dropped, not inserted, and `fresh`
+// counts those instead of the new k-mers.
+template <bool CLAIM = true>
 __device__ __forceinline__ void mfx_group_insert(const mfx_table_view &t, uint64_t key, uint32_t v, int side, uint64_t *meta,
                                                  uint32_t &fresh) {
   const uint32_t lane = threadIdx.x & 63u, sub = lane & 7u, gsh = lane & ~7u;
@@ -424,6 +436,9 @@ __device__ __forceinline__ void mfx_group_insert(const mfx_table_view &t, uint64
       mfx_slot *sl = t.slots + (uint64_t)R.line[s] * MFX_SLOTS_LINE + sub;
       if (m_match) {
         if (sub == (uint32_t)__ffs((int)m_match) - 1u) atomicAdd(side ? &sl->asmV : &sl->readV, R.val[s]);
+        pending &= ~(1u << s);
+      } else if (m_empty && !CLAIM) {                         // the line that would hold it has room and does not: never claimed
+        if (sub == 0u) ++fresh;
         pending &= ~(1u << s);
       } else if (m_empty) {
         if (sub == (uint32_t)__ffs((int)m_empty) - 1u)       // lowest empty slot
@@ -512,24 +527,60 @@ __global__ __launch_bounds__(256) void mfx_table_add_kernel(mfx_table_view t, co
 // k-mer's slot and updates the count, or drops the k-mer (meta[3] counts those).  Only canonical k-mers were claimed:
 // a non-canonical k-mer of the database is counted in meta[1] and dropped, and the host refuses the load
 // (value(fmer) + value(rmer) of the reference would need the other strand's slot too).
+#ifndef MFX_UPD_BATCH
+#define MFX_UPD_BATCH 4
+#endif
 __global__ __launch_bounds__(256) void mfx_table_update_kernel(mfx_table_view t, const uint64_t *kmers, const uint32_t *values, uint64_t n,
                                                                int side, uint64_t *meta) {
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  // MFX_UPD_BATCH k-mers per lane and pass: their records, then their table loads, are in flight together.  Compact
+  // layout: ONE 16-byte load per k-mer -- its first mini-bucket, where 92 % of the claimed k-mers sit and where an empty
+  // slot proves that the k-mer was never claimed (mfx_c_first); the whole line (mfx_c_find) only for the rest.
+  constexpr int UB = MFX_UPD_BATCH;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * UB;
   uint32_t dropped = 0, noncanon = 0;
-  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += stride) {
-    uint64_t key = kmers[i];
-    uint32_t v;
-    if (values) v = values[i];
-    else { v = (uint32_t)key & MFX_PACKED_VMASK; key >>= MFX_PACKED_VBITS; if (v == MFX_PACKED_VMASK) v = 0u; }     // packed record; escape: added separately
-    if (v == 0u) continue;
-    if (key > mfx_revcomp(key, t.k)) { ++noncanon; continue; }
+  for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x * UB; base < n; base += stride) {
+    uint64_t key[UB];
+    uint32_t v[UB];
+#pragma unroll
+    for (int j = 0; j < UB; ++j) {
+      const uint64_t i = base + (uint64_t)j * blockDim.x + threadIdx.x;
+      key[j] = 0; v[j] = 0u;
+      if (i < n) {
+        key[j] = kmers[i];
+        if (values) v[j] = values[i];
+        else { v[j] = (uint32_t)key[j] & MFX_PACKED_VMASK; key[j] >>= MFX_PACKED_VBITS; if (v[j] == MFX_PACKED_VMASK) v[j] = 0u; }   // packed record; escape: added separately
+      }
+    }
     if (t.compact) {
-      unsigned long long cur = 0;
-      unsigned long long *w = mfx_c_find(t, key, mfx_home(t, key), 0, cur);
-      if (w) mfx_c_add(t, w, cur, key, v, side, meta); else ++dropped;
-    } else {
-      mfx_slot *sl = mfx_find(t, key);
-      if (sl) atomicAdd(side ? &sl->asmV : &sl->readV, v); else ++dropped;
+      unsigned long long *mb[UB];
+      uint4 s[UB];
+#pragma unroll
+      for (int j = 0; j < UB; ++j) {
+        if (v[j] && key[j] > mfx_revcomp(key[j], t.k)) { ++noncanon; v[j] = 0u; }
+        mb[j] = reinterpret_cast<unsigned long long *>(t.slots) + mfx_probe_line(t, mfx_home(t, key[j]), 0) * MFX_CSLOTS_LINE +
+                2u * mfx_c_first(key[j]);
+        s[j] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+        if (v[j]) s[j] = *reinterpret_cast<const uint4 *>(mb[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < UB; ++j) {
+        if (v[j] == 0u) continue;
+        const uint64_t x = (uint64_t)s[j].x | ((uint64_t)s[j].y << 32), y = (uint64_t)s[j].z | ((uint64_t)s[j].w << 32);
+        unsigned long long *w = nullptr;
+        unsigned long long cur = 0;
+        if (x == MFX_EMPTY) { }                                // first slot of its order empty: never claimed
+        else if ((x >> 22) == key[j]) { w = mb[j]; cur = x; }
+        else if (y == MFX_EMPTY) { }
+        else if ((y >> 22) == key[j]) { w = mb[j] + 1; cur = y; }
+        else w = mfx_c_find(t, key[j], mfx_home(t, key[j]), 0, cur);
+        if (w) mfx_c_add(t, w, cur, key[j], v[j], side, meta); else ++dropped;
+      }
+    } else {                                                   // 16-byte slots: the cooperative insert without its claim
+#pragma unroll
+      for (int j = 0; j < UB; ++j) {
+        if (v[j] && key[j] > mfx_revcomp(key[j], t.k)) { ++noncanon; v[j] = 0u; }
+        mfx_group_insert<false>(t, key[j], v[j], side, meta, dropped);      // wave-uniform: every lane takes part
+      }
     }
   }
   uint64_t d = dropped, c = noncanon;
@@ -1753,6 +1804,8 @@ hipError_t mfx_k_table_add(mfx_table_view t, const uint64_t *kmers, const uint32
   uint64_t blocks = (n + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   if (t.seq_only) {
+    blocks = (n + 256 * MFX_UPD_BATCH - 1) / (256 * MFX_UPD_BATCH);
+    if (blocks > 8192) blocks = 8192;
     mfx_table_update_kernel<<<(unsigned)blocks, 256, 0, st>>>(t, kmers, values, n, side, meta);
     return hipGetLastError();
   }
