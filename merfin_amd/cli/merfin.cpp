@@ -559,7 +559,9 @@ int main(int argc, char **argv) {
     fprintf(stderr, "-- Opening sequences in '%s'.\n", G.seqName);
     auto sf = std::make_shared<SeqFile>(G.seqName);
     if (!sf->ok()) { fprintf(stderr, "ERROR: cannot open '%s'.\n", G.seqName); return 1; }
-    seqReader = std::thread([&recs, &seqReadFailed, sf]() {
+    const std::string seqPath = G.seqName;
+    seqReader = std::thread([&recs, &seqReadFailed, sf, seqPath]() {
+      if (read_fasta_parallel(seqPath, recs)) { seqReadFailed = sf->finish() != 0; return; }     // plain FASTA: all host threads
       SeqRecord r;
       while (sf->next(r)) recs.push_back(std::move(r));
       seqReadFailed = sf->finish() != 0;      // a decompressor that died mid-stream: the records read so far are NOT the file
@@ -576,7 +578,7 @@ int main(int argc, char **argv) {
     }
     bases.resize(recs.size());
     lens.resize(recs.size());
-    for (size_t i = 0; i < recs.size(); ++i) { bases[i] = recs[i].bases.data(); lens[i] = recs[i].bases.size(); totalBases += lens[i]; }
+    for (size_t i = 0; i < recs.size(); ++i) { bases[i] = recs[i].data(); lens[i] = recs[i].size(); totalBases += lens[i]; }
     lap("read sequences");
   };
   // ... and without -seqmers whenever the file tells an upper bound of its bases: the table is sized by the bound, the

@@ -371,24 +371,23 @@ struct mfx_ingest {
     uint64_t *hk = nullptr, *dk = nullptr;
     uint32_t *hv = nullptr, *dv = nullptr;
     hipEvent_t done = nullptr;
+    hipStream_t st = nullptr;    // a stream per lane: the transfer of one lane's chunk runs under the insert kernel of the other's
     bool busy = false;
   } L[2];
-  hipStream_t st = nullptr;
   uint64_t cap = 0;            // k-mers per lane
   size_t kw = 1;
 };
 
 static void ingest_free(mfx_ingest *g) {
   if (!g) return;
-  if (g->st) (void)hipStreamSynchronize(g->st);
   for (auto &l : g->L) {
+    if (l.st) { (void)hipStreamSynchronize(l.st); (void)hipStreamDestroy(l.st); }
     if (l.hk) (void)hipHostFree(l.hk);
     if (l.hv) (void)hipHostFree(l.hv);
     if (l.dk) (void)hipFree(l.dk);
     if (l.dv) (void)hipFree(l.dv);
     if (l.done) (void)hipEventDestroy(l.done);
   }
-  if (g->st) (void)hipStreamDestroy(g->st);
   delete g;
 }
 
@@ -400,8 +399,11 @@ void mfx_index_ingest_release(mfx_index *ix) {
 }
 
 static mfx_ingest *ingest_get(mfx_index *ix, uint64_t n) {
-  const uint64_t want = std::min<uint64_t>(std::max<uint64_t>(n, 1), MFX_INGEST_CHUNK);
-  if (ix->ingest && ix->ingest->cap >= want) return ix->ingest;
+  uint64_t chunk = MFX_INGEST_CHUNK;
+  if (const char *e = getenv("MFX_INGEST_CHUNK_LOG2")) { const int lg = atoi(e); if (lg >= 16 && lg <= 28) chunk = 1ull << lg; }
+  const uint64_t want = std::min<uint64_t>(std::max<uint64_t>(n, 1), chunk);
+  // lanes of 4 M k-mers or more serve any load (it goes through them in chunks): re-pinning larger ones costs more than they save
+  if (ix->ingest && (ix->ingest->cap >= want || ix->ingest->cap >= (1ull << 22))) return ix->ingest;
   mfx_index_ingest_release(ix);
   // small loads (tests, single contigs) get small lanes; the first large one gets the full-size lanes
   uint64_t cap = 1ull << 16;
@@ -409,9 +411,9 @@ static mfx_ingest *ingest_get(mfx_index *ix, uint64_t n) {
   mfx_ingest *g = new mfx_ingest;
   g->cap = cap;
   g->kw = ix->key_words();
-  bool ok = hipStreamCreateWithFlags(&g->st, hipStreamNonBlocking) == hipSuccess;
+  bool ok = true;
   for (auto &l : g->L)
-    ok = ok && hipHostMalloc((void **)&l.hk, cap * 8 * g->kw, hipHostMallocPortable) == hipSuccess &&      // DMA source for any device
+    ok = ok && hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking) == hipSuccess && hipHostMalloc((void **)&l.hk, cap * 8 * g->kw, hipHostMallocPortable) == hipSuccess &&      // DMA source for any device
          hipHostMalloc((void **)&l.hv, cap * 4, hipHostMallocPortable) == hipSuccess &&
          hipMalloc((void **)&l.dk, cap * 8 * g->kw) == hipSuccess && hipMalloc((void **)&l.dv, cap * 4) == hipSuccess &&
          hipEventCreateWithFlags(&l.done, hipEventDisableTiming) == hipSuccess;
@@ -420,25 +422,37 @@ static mfx_ingest *ingest_get(mfx_index *ix, uint64_t n) {
   return g;
 }
 
-// fill(o, m, hk, hv): put k-mers [o, o+m) of the source into the pinned lane buffers; false = the source failed.
-// ONE source, nix tables: the chunk is staged once (in the first index's pinned lane) and sent to every index's
-// device over that device's own PCIe link; each table inserts what it keeps (a sharded index skips the k-mers it
-// does not own in the insert kernel).  nix = 1 is the ordinary load.
-template <class Fill>
-static int index_ingest_multi(mfx_index *const *ixs, uint32_t nix, uint64_t n, int side, Fill &&fill, bool packed = false) {
+// The staging loop of every host-side load.  next(cap, hk, hv, d): put the next chunk of the source into the pinned lane
+// buffers (room: cap * 8 * key_words bytes in hk, cap * 4 in hv) and describe it in d -- 1 = a chunk is ready, 0 = the
+// source is done, -1 = it failed.  ONE source, nix tables: the chunk is staged once (in the first index's pinned lane)
+// and sent to every index's device over that device's own PCIe link; each table inserts what it keeps (a sharded index
+// skips the k-mers it does not own in the insert kernel).  nix = 1 is the ordinary load.
+struct IngestChunk {
+  size_t kbytes = 0, vbytes = 0;                             // what goes over the link from hk / hv
+  // enqueue the insert of the chunk (device copies at dk / dv) on st
+  std::function<hipError_t(mfx_index *ix, uint64_t *dk, uint32_t *dv, hipStream_t st)> launch;
+};
+
+template <class Next>
+static int index_ingest_chunks(mfx_index *const *ixs, uint32_t nix, uint64_t n_hint, Next &&next) {
+  const bool timing = getenv("MFX_INGEST_TIMING") != nullptr;
+  auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_begin = now();
+  double t_wait = 0, t_fill = 0;
+  uint64_t nchunks = 0, nbytes = 0;
   std::vector<mfx_ingest *> gs(nix, nullptr);
   for (uint32_t i = 0; i < nix; ++i) {
     DevGuard dg(ixs[i]->device);
     ixs[i]->frozen = true;                                  // a sequence-only index takes no more claims once counts arrive
-    gs[i] = ingest_get(ixs[i], n);
+    gs[i] = ingest_get(ixs[i], n_hint);
     if (!gs[i]) return mfx_fail(MFX_E_NOMEM, "mfx_index_add: staging allocation failed");
   }
+  const double t_lanes = now() - t_begin;
   uint64_t cap = gs[0]->cap;
   for (uint32_t i = 1; i < nix; ++i) cap = std::min(cap, gs[i]->cap);
   bool ok = true, src_ok = true;
-  int cur = 0;
-  for (uint64_t o = 0; o < n && ok; o += cap, cur ^= 1) {
-    const uint64_t m = std::min(cap, n - o);
+  for (int cur = 0; ok; cur ^= 1) {
+    const double t0 = now();
     for (uint32_t i = 0; i < nix && ok; ++i) {               // the lane's previous chunk has left the pinned buffer everywhere
       mfx_ingest::Lane &l = gs[i]->L[cur];
       if (l.busy) { DevGuard dg(ixs[i]->device); if (hipEventSynchronize(l.done) != hipSuccess) ok = false; }
@@ -446,25 +460,31 @@ static int index_ingest_multi(mfx_index *const *ixs, uint32_t nix, uint64_t n, i
     }
     if (!ok) break;
     mfx_ingest::Lane &src = gs[0]->L[cur];
-    if (!fill(o, m, src.hk, src.hv)) { src_ok = false; break; }
+    IngestChunk d;
+    const double t1 = now();
+    const int got = next(cap, src.hk, src.hv, d);
+    t_wait += t1 - t0; t_fill += now() - t1;
+    if (got < 0) src_ok = false;
+    if (got <= 0) break;
+    ++nchunks; nbytes += d.kbytes + d.vbytes;
     for (uint32_t i = 0; i < nix && ok; ++i) {
       mfx_index *ix = ixs[i];
-      mfx_ingest *g = gs[i];
-      mfx_ingest::Lane &l = g->L[cur];
+      mfx_ingest::Lane &l = gs[i]->L[cur];
       DevGuard dg(ix->device);
-      ok = hipMemcpyAsync(l.dk, src.hk, m * 8 * g->kw, hipMemcpyHostToDevice, g->st) == hipSuccess &&
-           (packed || hipMemcpyAsync(l.dv, src.hv, m * 4, hipMemcpyHostToDevice, g->st) == hipSuccess) &&        // packed records carry their counts
-           (ix->wide() ? mfx_kw_table_add(ix->view(), l.dk, l.dv, m, side, ix->d_meta, g->st)
-                       : mfx_k_table_add(ix->view(), l.dk, packed ? nullptr : l.dv, m, side, ix->d_meta, g->st)) == hipSuccess &&
-           hipEventRecord(l.done, g->st) == hipSuccess;
+      ok = (d.kbytes == 0 || hipMemcpyAsync(l.dk, src.hk, d.kbytes, hipMemcpyHostToDevice, l.st) == hipSuccess) &&
+           (d.vbytes == 0 || hipMemcpyAsync(l.dv, src.hv, d.vbytes, hipMemcpyHostToDevice, l.st) == hipSuccess) &&
+           d.launch(ix, l.dk, l.dv, l.st) == hipSuccess && hipEventRecord(l.done, l.st) == hipSuccess;
       l.busy = true;
     }
   }
   for (uint32_t i = 0; i < nix; ++i) {
     DevGuard dg(ixs[i]->device);
-    if (hipStreamSynchronize(gs[i]->st) != hipSuccess) ok = false;
+    for (auto &l : gs[i]->L) if (hipStreamSynchronize(l.st) != hipSuccess) ok = false;
     gs[i]->L[0].busy = gs[i]->L[1].busy = false;
   }
+  if (timing)
+    fprintf(stderr, "-- ingest: %.3f s = lanes %.3f (cap %llu) + fill %.3f + waits for the device %.3f + drain; %llu chunks, %.2f GB over the link\n",
+            now() - t_begin, t_lanes, (unsigned long long)cap, t_fill, t_wait, (unsigned long long)nchunks, nbytes / 1e9);
   if (!ok) return mfx_fail(MFX_E_HIP, "mfx_index_add: transfer / insert failed: %s", hipGetErrorString(hipGetLastError()));
   if (!src_ok) return mfx_last_error_code() ? mfx_last_error_code() : MFX_E_IO;
   for (uint32_t i = 0; i < nix; ++i) {
@@ -473,6 +493,26 @@ static int index_ingest_multi(mfx_index *const *ixs, uint32_t nix, uint64_t n, i
     if (rc) return rc;
   }
   return MFX_OK;
+}
+
+// fill(o, m, hk, hv): put k-mers [o, o+m) of the source into the pinned lane buffers; false = the source failed.
+// packed: the records carry their counts (MFX_PACKED_VBITS), nothing comes through hv.
+template <class Fill>
+static int index_ingest_multi(mfx_index *const *ixs, uint32_t nix, uint64_t n, int side, Fill &&fill, bool packed = false) {
+  uint64_t o = 0;
+  return index_ingest_chunks(ixs, nix, n, [&](uint64_t cap, uint64_t *hk, uint32_t *hv, IngestChunk &d) {
+    if (o >= n) return 0;
+    const uint64_t m = std::min(cap, n - o);
+    if (!fill(o, m, hk, hv)) return -1;
+    o += m;
+    d.kbytes = m * 8 * ixs[0]->key_words();
+    d.vbytes = packed ? 0 : m * 4;
+    d.launch = [m, side, packed](mfx_index *ix, uint64_t *dk, uint32_t *dv, hipStream_t st) {
+      return ix->wide() ? mfx_kw_table_add(ix->view(), dk, dv, m, side, ix->d_meta, st)
+                        : mfx_k_table_add(ix->view(), dk, packed ? nullptr : dv, m, side, ix->d_meta, st);
+    };
+    return 1;
+  });
 }
 
 template <class Fill>
@@ -570,6 +610,39 @@ int mfx_index_add_from_file(mfx_index *const *ixs, uint32_t nix, int fd, const c
     mfx_fail(MFX_E_IO, "reading '%s' failed", path);
     return false;
   }, packed);
+}
+
+// the delta-coded blocks of an open flat database (mfx_db.cpp FLAT_DELTA): dir = (nblocks + 1) x {first k-mer, file offset |
+// kbits << 48 | vbits << 56}, n k-mers in all.  Whole blocks go through the lanes as they lie in the file -- 2.5-3 bytes
+// per k-mer of a 30x read set -- and are decoded by the kernel that inserts them (mfx_table_add_delta_kernel).
+int mfx_index_add_delta_file(mfx_index *const *ixs, uint32_t nix, int fd, const char *path, const uint64_t *dir, uint64_t nblocks, uint64_t n,
+                             int side, uint64_t minV, uint64_t maxV) {
+  int rc = check_same_kind(ixs, nix, "mfx_index_add_delta_file");
+  if (rc) return rc;
+  if (fd < 0 || !dir || ixs[0]->key_words() != 1) return mfx_fail(MFX_E_INVAL, "mfx_index_add_delta_file: bad argument");
+  if (side == 0) for (uint32_t i = 0; i < nix; ++i) if ((rc = set_read_filter(ixs[i], minV, maxV)) != MFX_OK) return rc;
+  auto off = [dir](uint64_t b) { return dir[2 * b + 1] & 0xffffffffffffull; };
+  const uint64_t total = off(nblocks) - off(0);
+  std::unique_ptr<WorkerPool> pool(total >= (64u << 20) ? new WorkerPool(pread_threads()) : nullptr);
+  uint64_t b0 = 0;
+  // lanes sized as for total / 8 records (32 MB at most: ~13 M k-mers a chunk): a chunk is a byte range of the file, not a k-mer count
+  return index_ingest_chunks(ixs, nix, std::min<uint64_t>(std::max<uint64_t>(total / 8 + 1, 2 * MFX_DELTA_BLOCK * 11), 1ull << 22), [&](uint64_t cap, uint64_t *hk, uint32_t *hv, IngestChunk &d) {
+    if (b0 >= nblocks) return 0;
+    uint64_t b1 = b0 + 1;                                    // at least one block (a lane holds the largest possible block)
+    while (b1 < nblocks && off(b1 + 1) - off(b0) <= cap * 8 && (b1 + 2 - b0) * 16 <= cap * 4) ++b1;
+    const uint64_t bytes = off(b1) - off(b0), nb = b1 - b0;
+    if (bytes > cap * 8 || (nb + 1) * 16 > cap * 4) { mfx_fail(MFX_E_FORMAT, "'%s': a block larger than the format allows", path); return -1; }
+    if (!par_pread(fd, (uint8_t *)hk, bytes, off(b0), pool.get())) { mfx_fail(MFX_E_IO, "reading '%s' failed", path); return -1; }
+    memcpy(hv, dir + 2 * b0, (nb + 1) * 16);
+    const uint64_t base = off(b0), m = std::min<uint64_t>(n - b0 * MFX_DELTA_BLOCK, nb * MFX_DELTA_BLOCK);
+    d.kbytes = bytes;
+    d.vbytes = (nb + 1) * 16;
+    d.launch = [nb, m, base, side](mfx_index *ix, uint64_t *dk, uint32_t *dv, hipStream_t st) {
+      return mfx_k_table_add_delta(ix->view(), dk, reinterpret_cast<const uint64_t *>(dv), (uint32_t)nb, m, base, side, ix->d_meta, st);
+    };
+    b0 = b1;
+    return 1;
+  });
 }
 
 static int index_add(mfx_index *ix, const uint64_t *kmers, const uint32_t *values, uint64_t n, int side, int on_device) {

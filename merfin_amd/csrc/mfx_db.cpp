@@ -62,7 +62,7 @@ int base_code(unsigned char c) {
 struct FlatHeader {
   char     magic[8];     // "MFXKMER1"
   uint32_t k;
-  uint32_t flags;        // bit 0: canonical; bit 1: PACKED records (k <= 21)
+  uint32_t flags;        // bit 0: canonical; bit 1: PACKED records (k <= 21); bit 2: DELTA-coded blocks (sorted k-mers, k <= 31)
   uint64_t n;
   uint64_t n_escape;     // packed: records whose count did not fit the record (was: reserved, 0)
 };
@@ -70,7 +70,17 @@ struct FlatHeader {
 // Payload, packed: n records {k-mer << 22 | count} (mfx_internal.h MFX_PACKED_*: 8 bytes per k-mer instead of 12 on disk, in
 //                  the staging lanes and over PCIe; a count field of all ones = escape), then the n_escape escaped k-mers
 //                  (uint64) and their counts (uint32).
+// Payload, delta : what a SORTED database (strictly ascending k-mers: `meryl print` order) is written as -- blocks of
+//                  MFX_DELTA_BLOCK k-mers, each {first k-mer (in the directory); count-1 differences of kbits bits; count values
+//                  of vbits bits, all ones = escape}: uint64 nblocks, the directory (nblocks + 1 entries {first k-mer, file offset
+//                  of the block (48 bits) | kbits << 48 | vbits << 56}; the last entry closes the last block), the blocks (8-byte
+//                  aligned; bit fields LSB-first in little-endian uint64 words, the values start at a word boundary), then
+//                  the n_escape escaped k-mers and counts as in the packed form.  kbits / vbits are chosen per block (vbits: what
+//                  makes block + escapes smallest): 2.5-3 bytes per k-mer of a 30x human read set.  Blocks are decoded by the
+//                  kernel that inserts them (mfx_table_add_delta_kernel): on disk, in the staging lanes and over PCIe the
+//                  database is a third of its packed size.
 constexpr uint32_t FLAT_PACKED = 2u;
+constexpr uint32_t FLAT_DELTA = 4u;
 
 // ---- meryl stuffedBits reader (UNVALIDATED) -----------
 // A stuffedBits file image: u64 dataBlockLenMax (bits), u32 dataBlocksLen,
@@ -540,6 +550,158 @@ int scan_text_parallel(const std::string &path, int *k_out, uint64_t *count, Mak
 
 inline bool text_is_plain(const std::string &path) { return mfx_suffix_tool(path) == nullptr; }
 
+
+// ---- delta-coded flat form ---------------------------------------------------
+struct DeltaBlockPlan { uint8_t kb = 0, vb = 2; uint32_t nesc = 0; uint64_t bytes = 0; };
+
+inline uint32_t bit_length(uint64_t x) { return x ? 64u - (uint32_t)__builtin_clzll(x) : 0u; }
+
+// widths and size of block [b, b + cnt) of a strictly ascending database
+DeltaBlockPlan plan_delta_block(const uint64_t *kmers, const uint32_t *values, uint32_t cnt) {
+  DeltaBlockPlan p;
+  uint64_t maxd = 0;
+  for (uint32_t i = 1; i < cnt; ++i) maxd = std::max(maxd, kmers[i] - kmers[i - 1]);
+  p.kb = (uint8_t)bit_length(maxd);
+  uint32_t hist[34] = {0};                                    // bit length of value + 1: a value fits vb bits iff that is <= vb
+  for (uint32_t i = 0; i < cnt; ++i) ++hist[bit_length((uint64_t)values[i] + 1)];
+  uint64_t best = ~0ull;
+  uint32_t above = 0;                                         // values that need more than vb bits
+  for (int vb = 33; vb >= 2; --vb) {
+    if (vb <= MFX_DELTA_MAX_VBITS) {
+      const uint64_t cost = (uint64_t)cnt * vb + 96ull * above;
+      if (cost <= best) { best = cost; p.vb = (uint8_t)vb; p.nesc = above; }
+    }
+    above += hist[vb];
+  }
+  const uint64_t kwords = ((uint64_t)(cnt - 1) * p.kb + 63) / 64, vwords = ((uint64_t)cnt * p.vb + 63) / 64;
+  p.bytes = (kwords + vwords) * 8;
+  return p;
+}
+
+void put_bits(uint64_t *w, uint64_t bit, uint32_t nbits, uint64_t x) {       // into zeroed words
+  const uint64_t i = bit >> 6;
+  const uint32_t sh = (uint32_t)bit & 63u;
+  w[i] |= x << sh;
+  if (sh + nbits > 64u) w[i + 1] |= x >> (64u - sh);
+}
+
+void pack_delta_block(const uint64_t *kmers, const uint32_t *values, uint32_t cnt, const DeltaBlockPlan &p, uint64_t *out) {
+  memset(out, 0, p.bytes);
+  for (uint32_t i = 1; i < cnt; ++i) if (p.kb) put_bits(out, (uint64_t)(i - 1) * p.kb, p.kb, kmers[i] - kmers[i - 1]);
+  uint64_t *vw = out + ((uint64_t)(cnt - 1) * p.kb + 63) / 64;
+  const uint32_t esc = (1u << p.vb) - 1u;
+  for (uint32_t i = 0; i < cnt; ++i) put_bits(vw, (uint64_t)i * p.vb, p.vb, values[i] >= esc ? esc : values[i]);
+}
+
+template <class F>
+void par_blocks(uint64_t nblocks, F &&fn) {                   // fn(b) for every block, on the library's host threads
+  const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>({(nblocks + 255) / 256, 64, (uint64_t)mfx_host_threads()}));
+  if (nt == 1) { for (uint64_t b = 0; b < nblocks; ++b) fn(b); return; }
+  std::atomic<uint64_t> nextb{0};
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < nt; ++t)
+    th.emplace_back([&]() {
+      for (uint64_t b0 = nextb.fetch_add(256); b0 < nblocks; b0 = nextb.fetch_add(256))
+        for (uint64_t b = b0; b < std::min(nblocks, b0 + 256); ++b) fn(b);
+    });
+  for (auto &x : th) x.join();
+}
+
+// 0 = written; 1 = the k-mers are not strictly ascending (the caller writes another form); < 0: error
+int write_flat_delta(FILE *f, const char *path, FlatHeader h, const uint64_t *kmers, const uint32_t *values, uint64_t n) {
+  const uint64_t nblocks = (n + MFX_DELTA_BLOCK - 1) / MFX_DELTA_BLOCK;
+  auto cnt_of = [&](uint64_t b) { return (uint32_t)std::min<uint64_t>(MFX_DELTA_BLOCK, n - b * MFX_DELTA_BLOCK); };
+  std::vector<DeltaBlockPlan> plan(nblocks);
+  std::atomic<int> unsorted{0};
+  par_blocks(nblocks, [&](uint64_t b) {
+    const uint64_t o = b * MFX_DELTA_BLOCK;
+    const uint32_t cnt = cnt_of(b);
+    for (uint32_t i = (b ? 0 : 1); i < cnt; ++i) if (kmers[o + i] <= kmers[o + i - 1]) { unsorted = 1; return; }
+    plan[b] = plan_delta_block(kmers + o, values + o, cnt);
+  });
+  if (unsorted) return 1;
+  std::vector<uint64_t> dir(2 * (nblocks + 1));
+  uint64_t at = sizeof(FlatHeader) + 8 + dir.size() * 8;
+  h.n_escape = 0;
+  for (uint64_t b = 0; b < nblocks; ++b) {
+    dir[2 * b] = kmers[b * MFX_DELTA_BLOCK];
+    dir[2 * b + 1] = at | ((uint64_t)plan[b].kb << 48) | ((uint64_t)plan[b].vb << 56);
+    at += plan[b].bytes;
+    h.n_escape += plan[b].nesc;
+  }
+  dir[2 * nblocks] = 0;
+  dir[2 * nblocks + 1] = at;
+  if (at >> 48) return mfx_fail(MFX_E_INVAL, "mfx_db_write_flat: the database is too large for the delta form");
+  h.flags |= FLAT_DELTA;
+  bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && fwrite(&nblocks, 8, 1, f) == 1 && fwrite(dir.data(), 8, dir.size(), f) == dir.size();
+  // the blocks, packed by all threads a piece (<= 256 MB) at a time
+  std::vector<uint64_t> buf;
+  for (uint64_t b0 = 0; b0 < nblocks && ok;) {
+    uint64_t b1 = b0, bytes = 0;
+    while (b1 < nblocks && (b1 == b0 || bytes + plan[b1].bytes <= (256ull << 20))) bytes += plan[b1++].bytes;
+    buf.resize(bytes / 8);
+    const uint64_t base = dir[2 * b0 + 1] & 0xffffffffffffull;
+    par_blocks(b1 - b0, [&](uint64_t i) {
+      const uint64_t b = b0 + i;
+      pack_delta_block(kmers + b * MFX_DELTA_BLOCK, values + b * MFX_DELTA_BLOCK, cnt_of(b), plan[b],
+                       buf.data() + ((dir[2 * b + 1] & 0xffffffffffffull) - base) / 8);
+    });
+    ok = fwrite(buf.data(), 8, buf.size(), f) == buf.size();
+    b0 = b1;
+  }
+  // the escapes: the counts that did not fit their block's field
+  std::vector<uint64_t> ek;
+  std::vector<uint32_t> ev;
+  for (uint64_t b = 0; b < nblocks; ++b) {
+    if (!plan[b].nesc) continue;
+    const uint32_t esc = (1u << plan[b].vb) - 1u;
+    for (uint64_t i = b * MFX_DELTA_BLOCK, e = i + cnt_of(b); i < e; ++i) if (values[i] >= esc) { ek.push_back(kmers[i]); ev.push_back(values[i]); }
+  }
+  ok = ok && ek.size() == h.n_escape &&
+       (ek.empty() || (fwrite(ek.data(), 8, ek.size(), f) == ek.size() && fwrite(ev.data(), 4, ev.size(), f) == ev.size()));
+  return ok ? 0 : mfx_fail(MFX_E_IO, "short write to '%s'", path);
+}
+
+int load_flat_delta(mfx_index *const *ixs, uint32_t nix, int fd, const char *path, const FlatHeader &h, uint64_t fsize, int side,
+                    uint64_t minV, uint64_t maxV) {
+  auto bad = [&](const char *what) { return mfx_fail(MFX_E_FORMAT, "'%s': %s", path, what); };
+  uint64_t nblocks = 0;
+  if (h.k > (uint32_t)MFX_MAX_K_NARROW || fsize < sizeof(h) + 8 || pread(fd, &nblocks, 8, sizeof(h)) != 8) return bad("truncated delta-coded payload");
+  if (nblocks != (h.n + MFX_DELTA_BLOCK - 1) / MFX_DELTA_BLOCK) return bad("block count does not match the k-mer count");
+  const uint64_t dir_off = sizeof(h) + 8, dir_bytes = (nblocks + 1) * 16;
+  if (fsize < dir_off + dir_bytes) return bad("truncated block directory");
+  std::vector<uint64_t> dir(2 * (nblocks + 1));
+  for (uint64_t o = 0; o < dir_bytes;) {
+    const ssize_t r = pread(fd, (char *)dir.data() + o, dir_bytes - o, (off_t)(dir_off + o));
+    if (r <= 0) return mfx_fail(MFX_E_IO, "reading '%s' failed", path);
+    o += (uint64_t)r;
+  }
+  // the directory is checked before anything reads by it: offsets ascending, 8-byte aligned, inside the file, and every
+  // block exactly as long as its widths say
+  uint64_t expect = dir_off + dir_bytes;
+  for (uint64_t b = 0; b <= nblocks; ++b) {
+    const uint64_t off = dir[2 * b + 1] & 0xffffffffffffull;
+    if (off != expect) return bad("inconsistent block directory");
+    if (b == nblocks) break;
+    const uint32_t kb = (uint32_t)(dir[2 * b + 1] >> 48) & 0xffu, vb = (uint32_t)(dir[2 * b + 1] >> 56) & 0xffu;
+    const uint64_t cnt = std::min<uint64_t>(MFX_DELTA_BLOCK, h.n - b * MFX_DELTA_BLOCK);
+    if (kb > 2u * h.k || vb < 2u || vb > (uint32_t)MFX_DELTA_MAX_VBITS) return bad("block field widths out of range");
+    expect = off + (((cnt - 1) * kb + 63) / 64 + (cnt * vb + 63) / 64) * 8;
+  }
+  if (fsize < expect + h.n_escape * 12) return bad("truncated delta-coded payload");
+  int rc = MFX_OK;
+  if (h.n) rc = mfx_index_add_delta_file(ixs, nix, fd, path, dir.data(), nblocks, h.n, side, minV, maxV);
+  if (rc == MFX_OK && h.n_escape) {
+    std::vector<uint64_t> ek(h.n_escape);
+    std::vector<uint32_t> ev(h.n_escape);
+    if (pread(fd, ek.data(), h.n_escape * 8, (off_t)expect) != (ssize_t)(h.n_escape * 8) ||
+        pread(fd, ev.data(), h.n_escape * 4, (off_t)(expect + h.n_escape * 8)) != (ssize_t)(h.n_escape * 4))
+      rc = mfx_fail(MFX_E_IO, "reading '%s' failed", path);
+    else rc = mfx_index_add_multi(ixs, nix, ek.data(), ev.data(), h.n_escape, side, minV, maxV);
+  }
+  return rc;
+}
+
 }  // namespace
 
 // merylFileReader(path): opens the DB and reveals k (merfin-globals.C:118-119:
@@ -621,6 +783,11 @@ extern "C" int mfx_index_load_db_multi(mfx_index *const *ixs, uint32_t nix, cons
     }
     if ((int)h.k != ix->k) { close(fdn); return mfx_fail(MFX_E_INVAL, "'%s' holds %u-mers but the index is built for k=%d", path, h.k, ix->k); }
     const uint64_t kw = ix->key_words();                     // k > 31: 16-byte k-mers {low, high}
+    if (h.flags & FLAT_DELTA) {
+      rc = load_flat_delta(ixs, nix, fdn, path, h, (uint64_t)st.st_size, side, minV, maxV);
+      close(fdn);
+      return rc;
+    }
     if (h.flags & FLAT_PACKED) {
       if (h.k > (uint32_t)MFX_MAX_K_PACKED || (uint64_t)st.st_size < sizeof(h) + h.n * 8 + h.n_escape * 12) {
         close(fdn);
@@ -700,6 +867,11 @@ extern "C" int mfx_db_write_flat(const char *path, int k, const uint64_t *kmers,
   h.flags = 0;
   h.n = n;
   h.n_escape = 0;
+  const char *de = getenv("MFX_FLAT_DELTA");
+  if (k <= MFX_MAX_K_NARROW && n && !(de && atoi(de) == 0)) {   // sorted k-mers: delta-coded blocks
+    const int rc = write_flat_delta(f, path, h, kmers, values, n);
+    if (rc <= 0) { fclose(f); return rc; }
+  }
   const char *pe = getenv("MFX_FLAT_PACKED");
   if (k <= MFX_MAX_K_PACKED && !(pe && atoi(pe) == 0)) {    // packed records: 8 bytes per k-mer
     h.flags |= FLAT_PACKED;

@@ -31,6 +31,9 @@ int  mfx_fail(int code, const char *fmt, ...);
 // vals_off == 0: the records at keys_off are PACKED (MFX_PACKED_VBITS), there is no counts array
 int  mfx_index_add_from_file(struct mfx_index *const *ixs, uint32_t nix, int fd, const char *path, uint64_t keys_off, uint64_t vals_off,
                              uint64_t n, int side, uint64_t minV, uint64_t maxV);
+// the delta-coded blocks of a sorted flat database (mfx_db.cpp FLAT_DELTA); dir: (nblocks + 1) x 2 words
+int  mfx_index_add_delta_file(struct mfx_index *const *ixs, uint32_t nix, int fd, const char *path, const uint64_t *dir, uint64_t nblocks,
+                              uint64_t n, int side, uint64_t minV, uint64_t maxV);
 // host arrays into several tables at once (one staging, one H2D per table; sharded tables keep what they own)
 int  mfx_index_add_multi(struct mfx_index *const *ixs, uint32_t nix, const uint64_t *kmers, const uint32_t *values, uint64_t n, int side,
                          uint64_t minV, uint64_t maxV);
@@ -71,6 +74,8 @@ constexpr uint64_t MFX_EMPTY = ~0ull;
 constexpr int      MFX_PACKED_VBITS = 22;
 constexpr uint32_t MFX_PACKED_VMASK = (1u << MFX_PACKED_VBITS) - 1u;
 constexpr int      MFX_MAX_K_PACKED = 21;
+constexpr uint32_t MFX_DELTA_BLOCK = 4096;     // k-mers per delta-coded block of a sorted flat database (mfx_db.cpp FLAT_DELTA)
+constexpr int      MFX_DELTA_MAX_VBITS = 22;   // widest count field of a block; larger counts are escapes
 
 // 32 <= k <= 64: k-mers of up to 128 bits (mfx_wide.hip).  Four 32-byte slots per 128-byte line.
 struct mfx_wslot {

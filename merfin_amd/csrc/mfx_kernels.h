@@ -90,6 +90,10 @@ struct mfx_count_args {
 hipError_t mfx_k_table_init(mfx_slot *slots, uint64_t nslots, hipStream_t st);
 hipError_t mfx_k_table_add(mfx_table_view t, const uint64_t *kmers, const uint32_t *values, uint64_t n, int side,
                            uint64_t *meta, hipStream_t st);
+// delta-coded blocks (mfx_db.cpp FLAT_DELTA): dir = {first k-mer, byte offset | kbits << 48 | vbits << 56} per block + one closing
+// entry; payload_base = the file offset payload[0] holds; n = k-mers of the nblocks blocks
+hipError_t mfx_k_table_add_delta(mfx_table_view t, const uint64_t *payload, const uint64_t *dir, uint32_t nblocks, uint64_t n,
+                                 uint64_t payload_base, int side, uint64_t *meta, hipStream_t st);
 hipError_t mfx_k_table_value(mfx_table_view t, const uint64_t *kmers, uint64_t n, uint32_t *readV, uint32_t *asmV,
                              hipStream_t st);
 hipError_t mfx_k_table_export(mfx_table_view t, uint64_t *kmers, uint32_t *readV, uint32_t *asmV,

@@ -270,11 +270,14 @@ __device__ __forceinline__ uint32_t mfx_c_first(uint64_t key) {
 
 // find-or-claim the slot of `key` (mfx_claim for 8-byte slots): a k-mer takes the first empty slot of its order, a slot
 // never changes its key once written.  cur = the slot's word as seen (a fresh claim: the key with both counts 0).
+// init: the counts a FRESH slot starts with (the assembly counter claims with asmV = 1: one atomic per new k-mer, not two);
+// claimed = this call wrote the slot.
 __device__ __forceinline__ unsigned long long *mfx_c_claim(const mfx_table_view &c, uint64_t key, uint64_t *meta, uint32_t &fresh,
-                                                           unsigned long long &cur) {
+                                                           unsigned long long &cur, uint32_t init, bool &claimed) {
   const mfx_probe pr = mfx_home(c, key);
   unsigned long long *cs = reinterpret_cast<unsigned long long *>(c.slots);
-  const unsigned long long mine = (unsigned long long)key << 22;
+  const unsigned long long mine = ((unsigned long long)key << 22) | init;
+  claimed = false;
   const uint32_t q0 = 2u * mfx_c_first(key);
   // A mini-bucket is read by ONE plain 16-byte load.  It may come from this CU's L1 and be older than the table: a slot
   // seen occupied stays what it is (a slot never changes its key once written), a slot seen empty is taken by compare-and-
@@ -291,7 +294,7 @@ __device__ __forceinline__ unsigned long long *mfx_c_claim(const mfx_table_view 
         cur = seen[e];
         if (cur == MFX_EMPTY) {
           cur = atomicCAS(base + q + e, (unsigned long long)MFX_EMPTY, mine);
-          if (cur == MFX_EMPTY) { ++fresh; cur = mine; return base + q + e; }
+          if (cur == MFX_EMPTY) { ++fresh; cur = mine; claimed = true; return base + q + e; }
         }
         if ((cur >> 22) == key) return base + q + e;         // cur is not the empty word here
       }
@@ -523,22 +526,85 @@ __global__ __launch_bounds__(256) void mfx_table_add_kernel(mfx_table_view t, co
   mfx_meta_flush(meta, fresh, noncanon);
 }
 
-// the same for a SEQUENCE-ONLY index: the key set is frozen (the k-mers claimed from the sequence), an add finds its
-// k-mer's slot and updates the count, or drops the k-mer (meta[3] counts those).  Only canonical k-mers were claimed:
-// a non-canonical k-mer of the database is counted in meta[1] and dropped, and the host refuses the load
-// (value(fmer) + value(rmer) of the reference would need the other strand's slot too).
+// UB k-mers of every lane go into the table (v == 0: none), all lanes of the wave together.
+//  * SEQUENCE-ONLY index: the key set is frozen (the k-mers claimed from the sequence), an add finds its k-mer's slot and
+//    updates the count, or drops the k-mer (T.dropped -> meta[3]).  Only canonical k-mers were claimed: a non-canonical
+//    k-mer of the database is counted (meta[1]) and dropped, and the host refuses the load (value(fmer) + value(rmer) of
+//    the reference would need the other strand's slot too).
+//    Compact layout: ONE 16-byte load per k-mer -- its first mini-bucket, where 92 % of the claimed k-mers sit and where
+//    an empty slot proves that the k-mer was never claimed (mfx_c_first); the whole line (mfx_c_find) only for the rest.
+//    The UB loads of a lane are in flight together.  16-byte slots: the cooperative insert without its claim.
+//  * full tables: the cooperative insert (mfx_group_insert); a sharded table keeps the k-mers it owns.
+struct mfx_tally { uint32_t fresh = 0, dropped = 0, noncanon = 0; };
+
+__device__ __forceinline__ void mfx_tally_flush(uint64_t *meta, const mfx_tally &T) {
+  uint64_t f = T.fresh, d = T.dropped, c = T.noncanon;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { f += __shfl_down(f, o, 64); d += __shfl_down(d, o, 64); c += __shfl_down(c, o, 64); }
+  if ((threadIdx.x & 63u) == 0) {
+    if (f) atomicAdd((unsigned long long *)&meta[0], (unsigned long long)f);
+    if (c) atomicAdd((unsigned long long *)&meta[1], (unsigned long long)c);
+    if (d) atomicAdd((unsigned long long *)&meta[3], (unsigned long long)d);
+  }
+}
+
+template <int UB>
+__device__ __forceinline__ void mfx_apply_batch(const mfx_table_view &t, uint64_t (&key)[UB], uint32_t (&v)[UB], int side, uint64_t *meta,
+                                                mfx_tally &T) {
+  if (t.seq_only && t.compact) {
+    unsigned long long *mb[UB];
+    uint4 s[UB];
+#pragma unroll
+    for (int j = 0; j < UB; ++j) {
+      if (v[j] && key[j] > mfx_revcomp(key[j], t.k)) { ++T.noncanon; v[j] = 0u; }
+      mb[j] = reinterpret_cast<unsigned long long *>(t.slots) + mfx_probe_line(t, mfx_home(t, key[j]), 0) * MFX_CSLOTS_LINE +
+              2u * mfx_c_first(key[j]);
+      s[j] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+      if (v[j]) s[j] = *reinterpret_cast<const uint4 *>(mb[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < UB; ++j) {
+      if (v[j] == 0u) continue;
+      const uint64_t x = (uint64_t)s[j].x | ((uint64_t)s[j].y << 32), y = (uint64_t)s[j].z | ((uint64_t)s[j].w << 32);
+      unsigned long long *w = nullptr;
+      unsigned long long cur = 0;
+      if (x == MFX_EMPTY) { }                                  // first slot of its order empty: never claimed
+      else if ((x >> 22) == key[j]) { w = mb[j]; cur = x; }
+      else if (y == MFX_EMPTY) { }
+      else if ((y >> 22) == key[j]) { w = mb[j] + 1; cur = y; }
+      else w = mfx_c_find(t, key[j], mfx_home(t, key[j]), 0, cur);
+      if (w) mfx_c_add(t, w, cur, key[j], v[j], side, meta); else ++T.dropped;
+    }
+  } else if (t.seq_only) {
+#pragma unroll
+    for (int j = 0; j < UB; ++j) {
+      if (v[j] && key[j] > mfx_revcomp(key[j], t.k)) { ++T.noncanon; v[j] = 0u; }
+      mfx_group_insert<false>(t, key[j], v[j], side, meta, T.dropped);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < UB; ++j) {
+      if (v[j]) {
+        const uint64_t krc = mfx_revcomp(key[j], t.k);
+        if (key[j] > krc) ++T.noncanon;
+        if (t.shard_n > 1 && mfx_owner(t, key[j] < krc ? key[j] : krc, key[j] < krc ? krc : key[j], t.shard_n) != t.shard_rank)
+          v[j] = 0u;                                           // another rank owns this k-mer
+      }
+      mfx_group_insert<true>(t, key[j], v[j], side, meta, T.fresh);
+    }
+  }
+}
+
 #ifndef MFX_UPD_BATCH
 #define MFX_UPD_BATCH 4
 #endif
+// loads into a sequence-only index: MFX_UPD_BATCH k-mers per lane and pass
 __global__ __launch_bounds__(256) void mfx_table_update_kernel(mfx_table_view t, const uint64_t *kmers, const uint32_t *values, uint64_t n,
                                                                int side, uint64_t *meta) {
-  // MFX_UPD_BATCH k-mers per lane and pass: their records, then their table loads, are in flight together.  Compact
-  // layout: ONE 16-byte load per k-mer -- its first mini-bucket, where 92 % of the claimed k-mers sit and where an empty
-  // slot proves that the k-mer was never claimed (mfx_c_first); the whole line (mfx_c_find) only for the rest.
   constexpr int UB = MFX_UPD_BATCH;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * UB;
-  uint32_t dropped = 0, noncanon = 0;
-  for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x * UB; base < n; base += stride) {
+  mfx_tally T;
+  for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x * UB; base < n; base += stride) {     // wave-uniform trip count
     uint64_t key[UB];
     uint32_t v[UB];
 #pragma unroll
@@ -551,45 +617,78 @@ __global__ __launch_bounds__(256) void mfx_table_update_kernel(mfx_table_view t,
         else { v[j] = (uint32_t)key[j] & MFX_PACKED_VMASK; key[j] >>= MFX_PACKED_VBITS; if (v[j] == MFX_PACKED_VMASK) v[j] = 0u; }   // packed record; escape: added separately
       }
     }
-    if (t.compact) {
-      unsigned long long *mb[UB];
-      uint4 s[UB];
+    mfx_apply_batch<UB>(t, key, v, side, meta, T);
+  }
+  mfx_tally_flush(meta, T);
+}
+
+// ---------------------------------------------------------------------------
+// Delta-coded blocks of a sorted database (this repo's flat format, mfx_db.cpp FLAT_DELTA): MFX_DELTA_BLOCK k-mers per
+// block as {first k-mer; (count - 1) differences of kbits bits; count values of vbits bits, all ones = escape} -- 2.5-3
+// bytes per k-mer of a 30x human read set instead of 8 on disk, in the staging lanes and over PCIe.  One workgroup per
+// block: a lane decodes 16 consecutive entries (sum of its differences, workgroup scan, then the entries four at a time)
+// and puts them into the table itself -- the decoded k-mers never exist in memory.
+// dir[b] = {first k-mer, payload byte offset (48 bits) | kbits << 48 | vbits << 56}; dir[nblocks] closes the last block.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mfx_bits_at(const uint64_t *w, uint64_t bit, uint32_t nbits) {     // nbits <= 63
+  const uint64_t i = bit >> 6;
+  const uint32_t sh = (uint32_t)bit & 63u;
+  uint64_t x = w[i] >> sh;
+  if (sh + nbits > 64u) x |= w[i + 1] << (64u - sh);
+  return x & ((1ull << nbits) - 1ull);
+}
+
+__global__ __launch_bounds__(256) void mfx_table_add_delta_kernel(mfx_table_view t, const uint64_t *payload, const uint64_t *dir,
+                                                                  uint32_t nblocks, uint64_t n, uint64_t payload_base, int side,
+                                                                  uint64_t *meta) {
+  constexpr int PER = MFX_DELTA_BLOCK / 256;                   // entries per lane
+  static_assert(PER == 16, "a lane decodes 16 entries, four at a time");
+  __shared__ uint64_t wsum[4];
+  mfx_tally T;
+  const uint32_t tid = threadIdx.x, wv = tid >> 6, ln = tid & 63u;
+  for (uint32_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
+    const uint64_t first = dir[2 * (uint64_t)b], info = dir[2 * (uint64_t)b + 1];
+    const uint32_t kb = (uint32_t)(info >> 48) & 0xffu, vb = (uint32_t)(info >> 56) & 0xffu;
+    const uint64_t left = n - (uint64_t)b * MFX_DELTA_BLOCK;
+    const uint32_t cnt = left < MFX_DELTA_BLOCK ? (uint32_t)left : (uint32_t)MFX_DELTA_BLOCK;
+    const uint64_t *pw = payload + (((info & 0xffffffffffffull) - payload_base) >> 3);
+    const uint64_t vbit0 = (((uint64_t)(cnt - 1u) * kb + 63u) >> 6) << 6;      // the values start at a word boundary
+    const uint32_t e0 = tid * PER;
+    // ---- the sum of this lane's differences (entry e > 0 has difference e - 1; entry 0 is the block's first k-mer)
+    uint64_t mine = 0;
+#pragma unroll 4
+    for (uint32_t i = 0; i < PER; ++i) {
+      const uint32_t e = e0 + i;
+      if (e > 0u && e < cnt && kb) mine += mfx_bits_at(pw, (uint64_t)(e - 1u) * kb, kb);
+    }
+    uint64_t inc = mine;                                       // inclusive scan over the workgroup
 #pragma unroll
-      for (int j = 0; j < UB; ++j) {
-        if (v[j] && key[j] > mfx_revcomp(key[j], t.k)) { ++noncanon; v[j] = 0u; }
-        mb[j] = reinterpret_cast<unsigned long long *>(t.slots) + mfx_probe_line(t, mfx_home(t, key[j]), 0) * MFX_CSLOTS_LINE +
-                2u * mfx_c_first(key[j]);
-        s[j] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
-        if (v[j]) s[j] = *reinterpret_cast<const uint4 *>(mb[j]);
-      }
+    for (int o = 1; o < 64; o <<= 1) { const uint64_t u = __shfl_up(inc, o, 64); if ((int)ln >= o) inc += u; }
+    __syncthreads();                                           // wsum of the previous block is read by now
+    if (ln == 63u) wsum[wv] = inc;
+    __syncthreads();
+    uint64_t run = first + inc - mine;
+    for (uint32_t w2 = 0; w2 < wv; ++w2) run += wsum[w2];
+    // ---- the entries, four at a time
+#pragma unroll 1
+    for (uint32_t g = 0; g < PER; g += 4) {
+      uint64_t key[4];
+      uint32_t v[4];
 #pragma unroll
-      for (int j = 0; j < UB; ++j) {
-        if (v[j] == 0u) continue;
-        const uint64_t x = (uint64_t)s[j].x | ((uint64_t)s[j].y << 32), y = (uint64_t)s[j].z | ((uint64_t)s[j].w << 32);
-        unsigned long long *w = nullptr;
-        unsigned long long cur = 0;
-        if (x == MFX_EMPTY) { }                                // first slot of its order empty: never claimed
-        else if ((x >> 22) == key[j]) { w = mb[j]; cur = x; }
-        else if (y == MFX_EMPTY) { }
-        else if ((y >> 22) == key[j]) { w = mb[j] + 1; cur = y; }
-        else w = mfx_c_find(t, key[j], mfx_home(t, key[j]), 0, cur);
-        if (w) mfx_c_add(t, w, cur, key[j], v[j], side, meta); else ++dropped;
+      for (uint32_t i = 0; i < 4; ++i) {
+        const uint32_t e = e0 + g + i;
+        key[i] = 0; v[i] = 0u;
+        if (e < cnt) {
+          if (e > 0u && kb) run += mfx_bits_at(pw, (uint64_t)(e - 1u) * kb, kb);
+          key[i] = run;
+          v[i] = (uint32_t)mfx_bits_at(pw, vbit0 + (uint64_t)e * vb, vb);
+          if (v[i] == (1u << vb) - 1u) v[i] = 0u;              // escape: added separately (the file's escape list)
+        }
       }
-    } else {                                                   // 16-byte slots: the cooperative insert without its claim
-#pragma unroll
-      for (int j = 0; j < UB; ++j) {
-        if (v[j] && key[j] > mfx_revcomp(key[j], t.k)) { ++noncanon; v[j] = 0u; }
-        mfx_group_insert<false>(t, key[j], v[j], side, meta, dropped);      // wave-uniform: every lane takes part
-      }
+      mfx_apply_batch<4>(t, key, v, side, meta, T);
     }
   }
-  uint64_t d = dropped, c = noncanon;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { d += __shfl_down(d, o, 64); c += __shfl_down(c, o, 64); }
-  if ((threadIdx.x & 63u) == 0) {
-    if (d) atomicAdd((unsigned long long *)&meta[3], (unsigned long long)d);
-    if (c) atomicAdd((unsigned long long *)&meta[1], (unsigned long long)c);
-  }
+  mfx_tally_flush(meta, T);
 }
 
 __global__ void mfx_table_value_kernel(mfx_table_view t, const uint64_t *kmers, uint64_t n, uint32_t *readV, uint32_t *asmV) {
@@ -1732,8 +1831,9 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_count_kernel(mfx_count_args a) 
       if (a.t.compact) {                                      // 8-byte slots (sequence-only index)
         if (ok) {
           unsigned long long cur = 0;
-          unsigned long long *w = mfx_c_claim(a.t, key, a.meta, fresh, cur);
-          if (w && a.count) mfx_c_add(a.t, w, cur, key, 1u, 1, a.meta);
+          bool claimed;
+          unsigned long long *w = mfx_c_claim(a.t, key, a.meta, fresh, cur, a.count ? 1u : 0u, claimed);
+          if (w && a.count && !claimed) mfx_c_add(a.t, w, cur, key, 1u, 1, a.meta);
         }
       } else if (MODE == 1 && a.count) mfx_group_insert(a.t, key, ok ? 1u : 0u, 1, a.meta, fresh);
       else if (ok) {
@@ -1813,6 +1913,12 @@ hipError_t mfx_k_table_add(mfx_table_view t, const uint64_t *kmers, const uint32
   const int mode = me ? atoi(me) : 1;
   if (mode == 0)      mfx_table_add_kernel<0><<<(unsigned)blocks, 256, 0, st>>>(t, kmers, values, n, side, meta);
   else                mfx_table_add_kernel<1><<<(unsigned)blocks, 256, 0, st>>>(t, kmers, values, n, side, meta);
+  return hipGetLastError();
+}
+hipError_t mfx_k_table_add_delta(mfx_table_view t, const uint64_t *payload, const uint64_t *dir, uint32_t nblocks, uint64_t n,
+                                 uint64_t payload_base, int side, uint64_t *meta, hipStream_t st) {
+  if (nblocks == 0) return hipSuccess;
+  mfx_table_add_delta_kernel<<<nblocks < 8192u ? nblocks : 8192u, 256, 0, st>>>(t, payload, dir, nblocks, n, payload_base, side, meta);
   return hipGetLastError();
 }
 hipError_t mfx_k_table_value(mfx_table_view t, const uint64_t *kmers, uint64_t n, uint32_t *readV, uint32_t *asmV,

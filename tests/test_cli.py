@@ -342,6 +342,15 @@ def test_randomized_fasta_layouts(tmp_path, seed):
     assert (tmp_path / "g.hist").read_bytes() == (tmp_path / "o.hist").read_bytes()
     named = [l.split("\t")[0] for l in rr.stderr.splitlines() if l.count("\t") == 4 and l.startswith("ctg")]
     assert named == ["ctg%d" % i for i in range(len(contigs))]
+    if not gz:
+        # plain files of 1 MB and more are read by all host threads (read_fasta_parallel): the same file through that reader
+        # (pieces of 4099 bytes: CR LF pairs and lines straddle them) and through the sequential one
+        for env in ({"MFX_CLI_SEQ_PAR_MIN": "0", "MFX_CLI_SEQ_SLICE": "4099", "MFX_CLI_SEQ_THREADS": "7"}, {"MFX_CLI_SEQ_THREADS": "1"}):
+            r2 = run(["-hist", "-sequence", fa, "-readmers", str(tmp_path / "read.mfxk"), "-peak", str(peak), "-output", str(tmp_path / "g2.hist")],
+                     env=dict(os.environ, **env))
+            assert r2.returncode == 0, r2.stderr
+            assert (tmp_path / "g2.hist").read_bytes() == (tmp_path / "o.hist").read_bytes(), env
+            assert [l.split("\t")[0] for l in r2.stderr.splitlines() if l.count("\t") == 4 and l.startswith("ctg")] == named
 
 
 @pytest.mark.gpu

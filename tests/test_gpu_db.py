@@ -343,11 +343,12 @@ def test_randomized_database_forms_agree(tmp_path, seed, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k", [21, 15])
-def test_packed_flat_records_equal_plain_ones(tmp_path, k, monkeypatch):
-    """the flat form stores k <= 21 as packed 8-byte records {k-mer << 22 | count} (counts >= 2^22 - 1 escape to a side list);
-    plain (MFX_FLAT_PACKED=0: 8 + 4 bytes) and packed files of one database give the same full table and the same
-    sequence-only table, escapes and zero counts included"""
+@pytest.mark.parametrize("k", [21, 15, 31])
+def test_flat_forms_give_the_same_tables(tmp_path, k, monkeypatch):
+    """the flat form of one database in its three encodings -- plain (8 + 4 bytes per k-mer), packed records {k-mer << 22 |
+    count} for k <= 21 (counts >= 2^22 - 1 escape to a side list), delta-coded blocks of the sorted k-mers (decoded by the
+    inserting kernel; counts beyond a block's field escape) -- gives the same full table and the same sequence-only table,
+    escapes and zero counts included"""
     import os
     import merfin_amd as m
     from tests import synth
@@ -356,29 +357,73 @@ def test_packed_flat_records_equal_plain_ones(tmp_path, k, monkeypatch):
     rv[::37] = np.array([2**22 - 2, 2**22 - 1, 2**22, 2**31, 2**32 - 1] * (len(rv[::37]) // 5 + 1), dtype=np.uint64)[:len(rv[::37])]
     rv[5::41] = 0                                                    # a zero count: never stored
     read = (read[0], rv.astype(np.uint32))
-    paths = {}
-    for packed in ("0", "1"):
-        monkeypatch.setenv("MFX_FLAT_PACKED", packed)
-        paths[packed] = str(tmp_path / ("r%s.mfxk" % packed))
-        m.db_write_flat(paths[packed], k, *read)
+    assert (np.diff(read[0].astype(np.uint64)) > 0).all()            # sorted: the writer's condition for the delta form
     n = len(read[0])
-    assert os.path.getsize(paths["0"]) == 32 + 12 * n
+    forms = {"plain": ("0", "0"), "packed": ("0", "1"), "delta": ("1", "1")}
+    if k > 21:
+        del forms["packed"]
+    paths = {}
+    for name, (delta, packed) in forms.items():
+        monkeypatch.setenv("MFX_FLAT_DELTA", delta)
+        monkeypatch.setenv("MFX_FLAT_PACKED", packed)
+        paths[name] = str(tmp_path / ("r_%s.mfxk" % name))
+        m.db_write_flat(paths[name], k, *read)
+    assert os.path.getsize(paths["plain"]) == 32 + 12 * n
     n_esc = int((read[1] >= 2**22 - 1).sum())
-    assert os.path.getsize(paths["1"]) == 32 + 8 * n + 12 * n_esc and n_esc > 10
+    if "packed" in paths:
+        assert os.path.getsize(paths["packed"]) == 32 + 8 * n + 12 * n_esc and n_esc > 10
+    assert os.path.getsize(paths["delta"]) < 0.75 * os.path.getsize(paths["plain"])
     seqs = m.Sequences(contigs)
     tables = []
-    for packed in ("0", "1"):
-        assert m.db_probe(paths[packed]) == {"k": k, "format": "flat", "n_kmers": n}
+    for name in forms:
+        assert m.db_probe(paths[name]) == {"k": k, "format": "flat", "n_kmers": n}
         full = m.Index(k, n + 16)
-        full.load_db(paths[packed], 0)
+        full.load_db(paths[name], 0)
         so = m.Index.for_seq(k, sum(len(c) for c in contigs) + 16)
         so.count_asm(seqs)
-        so.load_db(paths[packed], 0)
+        so.load_db(paths[name], 0)
         tables.append((full.export(), so.export()))
-    for a, b in zip(tables[0], tables[1]):
-        for x, y in zip(a, b):
-            np.testing.assert_array_equal(x, y)
-    ek, er, _ = tables[1][0]
+    for other in tables[1:]:
+        for a, b in zip(tables[0], other):
+            for x, y in zip(a, b):
+                np.testing.assert_array_equal(x, y)
+    ek, er, _ = tables[-1][0]
     keep = read[1] > 0
     np.testing.assert_array_equal(ek, read[0][keep])
     np.testing.assert_array_equal(er, read[1][keep])
+
+
+@pytest.mark.gpu
+def test_delta_form_many_blocks_and_a_sharded_load(tmp_path):
+    """a delta-coded database of many blocks (a partial last block, dense and sparse stretches, blocks whose counts all
+    escape) loads as its arrays do -- into a whole table and, in one pass, into the three shards of one process"""
+    import merfin_amd as m
+    rng = np.random.default_rng(5)
+    k = 21
+    n = 3 * 4096 * 7 + 1234
+    keys = np.unique(rng.integers(0, 1 << 42, size=n + 5000, dtype=np.uint64))[:n]
+    keys[4096:8192] = keys[4096] + np.arange(4096, dtype=np.uint64)          # a block of consecutive k-mers: 1-bit differences
+    keys = np.unique(keys)
+    # canonical only (the tables hold canonical k-mers): fold every k-mer onto min(fwd, rc) and re-sort
+    x, rc = keys.copy(), np.zeros_like(keys)
+    for _ in range(k):                                                        # complement of a 2-bit code: code ^ 2
+        rc = (rc << np.uint64(2)) | ((x & np.uint64(3)) ^ np.uint64(2))
+        x = x >> np.uint64(2)
+    keys = np.unique(np.minimum(keys, rc))
+    n = len(keys)
+    vals = rng.integers(1, 60, size=n).astype(np.uint32)
+    vals[8192:12288] = 2**31 + np.arange(4096, dtype=np.uint32)               # a whole block of escapes
+    vals[::1000] = 2**32 - 1
+    path = str(tmp_path / "d.mfxk")
+    m.db_write_flat(path, k, keys, vals)
+    whole = m.Index(k, n + 16)
+    whole.load_db(path, 0)
+    ek, er, _ = whole.export()
+    np.testing.assert_array_equal(ek, keys)
+    np.testing.assert_array_equal(er, vals)
+    shards = [m.Index(k, n + 16) for _ in range(3)]
+    for r, ix in enumerate(shards):
+        ix.set_shard(r, 3)
+    m.load_db_multi(shards, path, 0)
+    got = sorted((int(a), int(b)) for ix in shards for a, b in zip(*ix.export()[:2]))
+    assert got == list(zip(keys.tolist(), vals.tolist()))

@@ -20,9 +20,19 @@ out = os.environ.get("MFX_TMP", "/tmp/mfx_cfg2")
 os.makedirs(out, exist_ok=True)
 t0 = time.time()
 ix, seqs, asm, info = st.build_world(m, bases, k=21, lam=26.0, ncontigs=1)
-ek, er, ea = ix.export(sort=False)          # a flat database may hold its k-mers in any order
+ek, er, ea = ix.export(sort=False)
+# sorted as `meryl print` lists a database (the delta-coded flat form needs that; any order gives packed records); the sort on the GPU
+order = torch.argsort(torch.from_numpy(ek.view(np.int64)).cuda()).cpu().numpy()
+ek, er, ea = ek[order], er[order], ea[order]
+del order
 m.db_write_flat(out + "/read.mfxk", 21, ek[er > 0], er[er > 0])
 m.db_write_flat(out + "/asm.mfxk", 21, ek[ea > 0], ea[ea > 0])
+if os.environ.get("MFX_TIMING_FORMS", "1") != "0":           # the packed-record form of the same databases, for the comparison below
+    os.environ["MFX_FLAT_DELTA"] = "0"
+    m.db_write_flat(out + "/read_packed.mfxk", 21, ek[er > 0], er[er > 0])
+    del os.environ["MFX_FLAT_DELTA"]
+print("read database: %.2f GB delta-coded%s" % (os.path.getsize(out + "/read.mfxk") / 1e9,
+      ", %.2f GB as packed records" % (os.path.getsize(out + "/read_packed.mfxk") / 1e9) if os.path.exists(out + "/read_packed.mfxk") else ""), flush=True)
 seq = asm[0].cpu().numpy().tobytes()
 with open(out + "/asm.fasta", "wb") as f:
     f.write(b">chr20_like synthetic\n")
@@ -57,3 +67,20 @@ for rep in range(2):
                             "-output", out + "/out3.hist"], capture_output=True, text=True, env=dict(os.environ, MFX_CLI_TIMING="1", **env))
         print("-hist without -seqmers, %s: wall=%.2fs" % (what, time.time() - t))
         print("    " + "\n    ".join(l for l in r.stderr.splitlines() if "timing" in l))
+if os.path.exists(out + "/read_packed.mfxk"):
+    for rep in range(2):
+        for db, what in (("/read.mfxk", "delta-coded blocks"), ("/read_packed.mfxk", "packed records")):
+            t = time.time()
+            r = subprocess.run([exe, "-hist", "-sequence", out + "/asm.fasta", "-readmers", out + db, "-peak", "26", "-prob", prob,
+                                "-output", out + "/out4.hist"], capture_output=True, text=True, env=dict(os.environ, MFX_CLI_TIMING="1"))
+            print("-hist without -seqmers, read database as %s: wall=%.2fs same_hist=%s" % (what, time.time() - t,
+                  open(out + "/out.hist").read() == open(out + "/out4.hist").read()))
+            print("    " + "\n    ".join(l for l in r.stderr.splitlines() if "timing" in l))
+for sweep in [x for x in os.environ.get("MFX_TIMING_SWEEP", "").split(";") if x]:
+    env = dict(kv.split("=", 1) for kv in sweep.split())
+    for rep in range(2):
+        t = time.time()
+        r = subprocess.run([exe, "-hist", "-sequence", out + "/asm.fasta", "-readmers", out + "/read.mfxk", "-peak", "26", "-prob", prob,
+                            "-output", out + "/out5.hist"], capture_output=True, text=True, env=dict(os.environ, MFX_CLI_TIMING="1", MFX_INGEST_TIMING="1", **env))
+        print("-hist without -seqmers, %s: wall=%.2fs same_hist=%s" % (sweep, time.time() - t, open(out + "/out.hist").read() == open(out + "/out5.hist").read()))
+        print("    " + "\n    ".join(l for l in r.stderr.splitlines() if "timing" in l or "ingest:" in l or "read_fasta" in l))
