@@ -150,7 +150,12 @@ inline std::shared_ptr<char> mfx_big_alloc(size_t n) {
   void *p = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
   if (p == MAP_FAILED) return std::shared_ptr<char>();
   (void)madvise(p, len, MADV_HUGEPAGE);
-  return std::shared_ptr<char>((char *)p, [len](char *q) { munmap(q, len); });
+  // released in pieces: unmapping a GB in one call holds the address-space lock for 50 ms, and every other thread of the
+  // process that maps, unmaps or ends (a thread's stack) waits behind it
+  return std::shared_ptr<char>((char *)p, [len](char *q) {
+    const size_t piece = 32u << 20;
+    for (size_t o = 0; o < len; o += piece) munmap(q + o, std::min(piece, len - o));
+  });
 }
 
 // A plain FASTA file read by all host threads (the sequential reader parses ~5 Gb/s on one core: 0.2 s per Gb of a run

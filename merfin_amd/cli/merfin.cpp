@@ -525,6 +525,14 @@ int main(int argc, char **argv) {
     phases.emplace_back(what, std::chrono::duration<double>(t - t_last).count());
     t_last = t;
   };
+  // MFX_CLI_TIMING=2: the steps of the index build as well
+  auto t_sub = t_last;
+  std::vector<std::pair<const char *, double>> steps;
+  auto step = [&](const char *what) {
+    auto t = std::chrono::steady_clock::now();
+    steps.emplace_back(what, std::chrono::duration<double>(t - t_sub).count());
+    t_sub = t;
+  };
 
   if (!load_Kmetric(G)) return 1;
 
@@ -647,27 +655,33 @@ int main(int argc, char **argv) {
     const uint64_t capacity = totalBases + 1024;                  // a sequence has at most one new k-mer per base
     fprintf(stderr, "--\n-- Memory needed: %.3f GB\n-- Memory limit:  %.3f GB%s\n--\n", mfx_index_estimate_gb_for_seq(k, capacity),
             G.maxMemory, G.maxMemory > 0 ? "" : " (none)");
+    step("(before the index)");
     ix = mfx_index_create_for_seq(k, capacity, G.maxMemory, G.device);
     if (!ix) {
       fprintf(stderr, "\n%s\n\n", mfx_last_error());
       return 1;
     }
+    step("create the table");
     int lrc = 0;
     if (G.seqDBname) {
       fprintf(stderr, "-- Claiming the %d-mers of '%s' on the GPU.\n", k, G.seqName);
       if (mfx_index_claim_seq(ix, seq, nullptr)) DIE_MFX("claiming sequence k-mers");
+      step("claim the sequence's k-mers");
       fprintf(stderr, "-- Loading kmers from '%s' into lookup table.\n", G.seqDBname);
       lrc = mfx_index_load_db(ix, G.seqDBname, 1, 0, ~0ull);
       if (lrc && lrc != MFX_E_NONCANON) DIE_MFX("loading -seqmers");
+      step("load -seqmers");
     } else {
       // replaces `meryl count k=.. <seq> output <seq>.meryl` (merfin-globals.C:182-186)
       fprintf(stderr, "-- No -seqmer given. Counting the %d-mers of '%s' on the GPU.\n", k, G.seqName);
       if (mfx_index_count_asm(ix, seq, nullptr)) DIE_MFX("counting sequence k-mers");
+      step("count the sequence's k-mers");
     }
     if (!lrc) {
       fprintf(stderr, "-- Loading kmers from '%s' into lookup table.\n", G.readDBname);
       lrc = mfx_index_load_db(ix, G.readDBname, 0, G.minV, G.maxV);
       if (lrc && lrc != MFX_E_NONCANON) DIE_MFX("loading -readmers");
+      step("load -readmers");
     }
     if (lrc == MFX_E_NONCANON) {
       // one slot per canonical k-mer cannot answer value(fmer) + value(rmer) of a non-canonical database
@@ -971,6 +985,11 @@ int main(int argc, char **argv) {
     fprintf(stderr, "-- timing:");
     for (auto &ph : phases) fprintf(stderr, "  %s %.2fs", ph.first, ph.second);
     fprintf(stderr, "\n");
+    if (atoi(getenv("MFX_CLI_TIMING")) > 1 && !steps.empty()) {
+      fprintf(stderr, "-- timing (index):");
+      for (auto &ph : steps) fprintf(stderr, "  %s %.3fs", ph.first, ph.second);
+      fprintf(stderr, "\n");
+    }
   }
   fprintf(stderr, "Bye!\n");
   return rc;

@@ -825,6 +825,9 @@ int mfx_seq_ensure_ascii(const mfx_seq *cs) {
   return MFX_OK;
 }
 
+static int seq_upload_packed(mfx_seq *seq, const char *const *bases);
+static int seq_alloc_planes(mfx_seq *s);
+
 extern "C" mfx_seq *mfx_seq_upload(int device, const char *const *bases, const uint64_t *lens, uint32_t ncontigs) {
   if ((ncontigs && (!bases || !lens)) || device < 0 || device >= mfx_device_count()) {
     mfx_fail(device < 0 || device >= mfx_device_count() ? MFX_E_NODEVICE : MFX_E_INVAL,
@@ -832,8 +835,23 @@ extern "C" mfx_seq *mfx_seq_upload(int device, const char *const *bases, const u
     return nullptr;
   }
   DevGuard g(device);
+  const double t_up0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
   mfx_seq *s = seq_layout(device, lens, ncontigs);
+  const double t_up1 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
   if (seq_alloc(s) != MFX_OK) { mfx_seq_free(s); return nullptr; }
+  if (getenv("MFX_UPLOAD_TIMING"))
+    fprintf(stderr, "-- upload: layout %.3f s, device buffers %.3f s\n", t_up1 - t_up0,
+            std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_up1);
+  {
+    // default: the sequence crosses the bus as its packed planes (0.375 B per base, encoded by the host threads); one byte per
+    // base is made on the device when a kernel asks for it (mfx_seq_ensure_ascii).  MFX_UPLOAD_ASCII=1: the bytes themselves.
+    const char *asc = getenv("MFX_UPLOAD_ASCII");
+    const char *pm = getenv("MFX_UPLOAD_PACKED_MIN");          // bytes from which the packed transport pays (tests: 0)
+    if (!(asc && atoi(asc)) && s->buf_bytes >= (pm ? strtoull(pm, nullptr, 10) : (uint64_t)(8u << 20))) {
+      if (seq_upload_packed(s, bases) != MFX_OK) { mfx_seq_free(s); return nullptr; }
+      return s;
+    }
+  }
   // The packed image (contigs at their padded offsets, zero filler in between) is assembled in a
   // pinned staging buffer and sent in large pieces: an assembly of a million small contigs must not
   // become a million tiny hipMemcpy calls.
@@ -1529,6 +1547,102 @@ static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *cons
   rc = result_take_overflow(ev, novf, out);
   if (rc) mfx_hist_result_free(out);
   return rc;
+}
+
+// mfx_seq_upload's transport: the same encoder and chunking as the streamed -hist, without the evaluation -- three small
+// pinned buffers (32 M bases = 12 MB each: pinning costs 0.4 ms per MB, the old 2 x 64 MB of bytes cost 50 ms before
+// the first base moved), the host threads encode chunk i+1 and i+2 while chunk i is on the bus.
+static int seq_upload_packed(mfx_seq *seq, const char *const *bases) {
+  const bool timing = getenv("MFX_UPLOAD_TIMING") != nullptr;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double tm[5] = {now(), 0, 0, 0, 0};
+  const uint64_t T = seq->ntiles, CH = 8192;                   // tiles per chunk
+  constexpr int NB = 3;
+  struct Chunk { std::vector<Piece> pieces; uint64_t lo = 0, hi = 0; };
+  std::vector<Chunk> chunks;
+  for (uint64_t t0 = 0; t0 < T; t0 += CH) {
+    Chunk c;
+    chunk_pieces(seq, t0, std::min(T, t0 + CH), c.pieces);
+    if (c.pieces.empty()) continue;
+    c.lo = seq->off[c.pieces.front().contig] + c.pieces.front().pos;                 // a multiple of 128
+    c.hi = (seq->off[c.pieces.back().contig] + c.pieces.back().pos + c.pieces.back().n + 31) / 32 * 32;
+    chunks.push_back(std::move(c));
+  }
+  tm[1] = now();
+  int rc = seq_alloc_planes(seq);
+  if (rc) return rc;
+  seq->bases_stale = true;
+  seq->planes_ok = true;
+  if (chunks.empty()) return MFX_OK;
+  tm[2] = now();
+  size_t STAGE_W = 0;
+  for (const Chunk &c : chunks) STAGE_W = std::max<size_t>(STAGE_W, (c.hi - c.lo) / 32);
+  STAGE_W = (STAGE_W + 2 + 4095) / 4096 * 4096;
+  uint8_t *stage[NB] = {nullptr, nullptr, nullptr};
+  hipEvent_t up[NB] = {nullptr, nullptr, nullptr};
+  hipStream_t cs = nullptr;
+  std::atomic<int64_t> allowed{NB - 1};
+  std::atomic<bool> stop{false};
+  std::vector<std::atomic<uint32_t>> done(chunks.size());
+  for (auto &d : done) d.store(0);
+  const unsigned W = std::max(1u, std::min(mfx_host_threads(), 64u));
+  std::unique_ptr<WorkerPool> pool;
+  bool ok = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) == hipSuccess;
+  for (int b = 0; b < NB && b < (int)chunks.size() && ok; ++b)
+    ok = hipHostMalloc((void **)&stage[b], STAGE_W * 12, hipHostMallocDefault) == hipSuccess &&
+         hipEventCreateWithFlags(&up[b], hipEventDisableTiming) == hipSuccess;
+  auto work = [&, W](unsigned w) {
+    for (size_t ci = 0; ci < chunks.size(); ++ci) {
+      while (allowed.load(std::memory_order_acquire) < (int64_t)ci) {
+        if (stop.load()) return;
+        std::this_thread::yield();
+      }
+      const Chunk &c = chunks[ci];
+      const uint64_t nw = (c.hi - c.lo) / 32, w0 = nw * w / W, w1 = nw * (w + 1) / W;
+      uint64_t *codes = reinterpret_cast<uint64_t *>(stage[ci % NB]);
+      uint32_t *valid = reinterpret_cast<uint32_t *>(stage[ci % NB] + (size_t)STAGE_W * 8);
+      if (w1 > w0) {
+        memset(codes + w0, 0, (w1 - w0) * 8);                // gaps between contigs and the words behind a contig's end
+        memset(valid + w0, 0, (w1 - w0) * 4);
+        const uint64_t my_lo = c.lo + 32 * w0, my_hi = c.lo + 32 * w1;
+        for (const Piece &pc : c.pieces) {
+          const uint64_t at = seq->off[pc.contig] + pc.pos;      // a multiple of 128
+          const uint64_t s = std::max(my_lo, at), e = std::min(my_hi, at + pc.n);
+          if (e > s) mfx_pack_bases(reinterpret_cast<const uint8_t *>(bases[pc.contig]) + pc.pos + (s - at), e - s, codes + (s - c.lo) / 32, valid + (s - c.lo) / 32);
+        }
+      }
+      done[ci].fetch_add(1, std::memory_order_release);
+    }
+  };
+  tm[3] = now();
+  if (ok) {
+    pool.reset(new WorkerPool(W));
+    pool->start(work);
+    for (size_t ci = 0; ci < chunks.size() && ok; ++ci) {
+      const Chunk &c = chunks[ci];
+      const int b = (int)(ci % NB);
+      if (ci >= 1) {                                          // the copy of chunk ci-1 has left its buffer: chunk ci-1+NB may be packed into it
+        ok = hipEventSynchronize(up[(ci - 1) % NB]) == hipSuccess;
+        allowed.store((int64_t)(ci - 1 + NB), std::memory_order_release);
+      }
+      while (done[ci].load(std::memory_order_acquire) < W) std::this_thread::yield();
+      const uint64_t nw = (c.hi - c.lo) / 32;
+      ok = ok && hipMemcpyAsync(seq->d_codes + c.lo / 32, stage[b], nw * 8, hipMemcpyHostToDevice, cs) == hipSuccess &&
+           hipMemcpyAsync(seq->d_valid + c.lo / 32, stage[b] + (size_t)STAGE_W * 8, nw * 4, hipMemcpyHostToDevice, cs) == hipSuccess &&
+           hipEventRecord(up[b], cs) == hipSuccess;
+    }
+    stop.store(!ok);
+    if (!ok) allowed.store((int64_t)chunks.size());
+    pool->wait();
+    if (hipStreamSynchronize(cs) != hipSuccess) ok = false;
+  }
+  tm[4] = now();
+  for (int b = 0; b < NB; ++b) { if (stage[b]) (void)hipHostFree(stage[b]); if (up[b]) (void)hipEventDestroy(up[b]); }
+  if (cs) (void)hipStreamDestroy(cs);
+  if (timing)
+    fprintf(stderr, "-- packed upload: chunk plan %.3f s, planes %.3f, pinned staging + stream %.3f, encode + copy %.3f (%u threads, %zu chunks), release %.3f\n",
+            tm[1] - tm[0], tm[2] - tm[1], tm[3] - tm[2], tm[4] - tm[3], W, chunks.size(), now() - tm[4]);
+  return ok ? MFX_OK : mfx_fail(MFX_E_HIP, "packed upload of the sequence failed: %s", hipGetErrorString(hipGetLastError()));
 }
 
 extern "C" int mfx_hist_run_streamed(mfx_eval *ev, mfx_seq *seq, const char *const *bases, mfx_hist_result *out) {

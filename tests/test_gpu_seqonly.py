@@ -208,3 +208,39 @@ def test_seq_only_multi_slot_and_even_k():
         ix, seqs = seq_index(m, k, contigs, read)
         evs = [m.Evaluator(ix, m.KParams(peak)) for _ in range(3)]
         assert_hist_equal(m.hist_multi(evs, [seqs] * 3), g, ka, km, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [21, 31, 41])
+def test_packed_upload_equals_the_byte_upload(k, monkeypatch):
+    """mfx_seq_upload sends large sequences as their packed planes (2-bit codes + validity bits encoded by the host threads;
+    one byte per base is made on the device on demand).  The same contigs -- N runs, lowercase, IUPAC codes, empty and
+    one-base contigs -- through both transports: counted, evaluated and dumped alike, and as the oracle says"""
+    m = _mfx()
+    peak = 17.3
+    contigs, read, asm = synth.world(k=min(k, 31), peak=peak, seed=911)
+    results = []
+    for pm in ("0", str(1 << 40)):
+        monkeypatch.setenv("MFX_UPLOAD_PACKED_MIN", pm)
+        seqs = m.Sequences(contigs)
+        ix = m.Index(k, sum(len(c) for c in contigs) + 64)
+        ix.count_asm(seqs)
+        ev = m.Evaluator(ix, m.KParams(peak))
+        h = ev.hist(seqs)
+        d = [ev.dump_values(seqs, c, 0, len(contigs[c])) for c in range(len(contigs)) if len(contigs[c])]
+        results.append((ix.export(), h, d))
+    (ea, ha, da), (eb, hb, db) = results
+    for x, y in zip(ea, eb):
+        np.testing.assert_array_equal(x, y)
+    assert ha.kasm == hb.kasm and ha.kmissing == hb.kmissing and ha.koverCpy == hb.koverCpy
+    np.testing.assert_array_equal(ha.undr(), hb.undr())
+    np.testing.assert_array_equal(ha.over(), hb.over())
+    np.testing.assert_array_equal(ha.contig_kasm(), hb.contig_kasm())
+    np.testing.assert_array_equal(ha.contig_kmissing(), hb.contig_kmissing())
+    for x, y in zip(da, db):
+        np.testing.assert_array_equal(x[0], y[0])
+        np.testing.assert_array_equal(x[1], y[1])
+        assert x[2:] == y[2:]
+    if k <= 31:
+        np.testing.assert_array_equal(ea[0], asm[0])
+        np.testing.assert_array_equal(ea[2], asm[1])

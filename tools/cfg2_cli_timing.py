@@ -36,8 +36,15 @@ print("read database: %.2f GB delta-coded%s" % (os.path.getsize(out + "/read.mfx
 seq = asm[0].cpu().numpy().tobytes()
 with open(out + "/asm.fasta", "wb") as f:
     f.write(b">chr20_like synthetic\n")
-    for o in range(0, len(seq), 1 << 20):
-        f.write(seq[o:o + (1 << 20)] + b"\n")
+    a = np.frombuffer(seq, dtype=np.uint8)                    # 80 bases per line, as assemblies come
+    rows = len(a) // 80
+    out_ = np.empty((rows, 81), dtype=np.uint8)
+    out_[:, :80] = a[:rows * 80].reshape(rows, 80)
+    out_[:, 80] = 10
+    f.write(out_.tobytes())
+    if rows * 80 < len(a):
+        f.write(seq[rows * 80:] + b"\n")
+    del a, out_
 del ix, seqs, asm
 torch.cuda.empty_cache()
 print("inputs written in %.1fs: %d read k-mers, %d asm k-mers" % (time.time() - t0, int((er > 0).sum()), int((ea > 0).sum())), flush=True)
@@ -47,7 +54,7 @@ common = ["-sequence", out + "/asm.fasta", "-readmers", out + "/read.mfxk", "-se
 modes = (("-hist", out + "/out.hist"), ("-dump", out + "/out.dump")) if bases <= 128_000_000 else (("-hist", out + "/out.hist"),)
 for mode, o in modes:
     t = time.time()
-    r = subprocess.run([exe, mode] + common + ["-output", o], capture_output=True, text=True, env=dict(os.environ, MFX_CLI_TIMING="1"))
+    r = subprocess.run([exe, mode] + common + ["-output", o], capture_output=True, text=True, env=dict(os.environ, MFX_CLI_TIMING="2"))
     dt = time.time() - t
     tail = [l for l in r.stderr.splitlines() if l and not l.startswith("Copy-number")][-14:]
     print("%s: rc=%d wall=%.2fs output=%.1f MB" % (mode, r.returncode, dt, os.path.getsize(o) / 1e6))
@@ -56,7 +63,7 @@ for mode, o in modes:
 # -hist without -seqmers: assembly k-mers counted on the GPU
 t = time.time()
 r = subprocess.run([exe, "-hist", "-sequence", out + "/asm.fasta", "-readmers", out + "/read.mfxk", "-peak", "26", "-prob", prob,
-                    "-output", out + "/out2.hist"], capture_output=True, text=True, env=dict(os.environ, MFX_CLI_TIMING="1"))
+                    "-output", out + "/out2.hist"], capture_output=True, text=True, env=dict(os.environ, MFX_CLI_TIMING="2"))
 print("-hist (asm counted on GPU): rc=%d wall=%.2fs same_hist=%s" % (r.returncode, time.time() - t,
       open(out + "/out.hist").read() == open(out + "/out2.hist").read()))
 print("    " + "\n    ".join(l for l in r.stderr.splitlines() if "timing" in l))
@@ -64,7 +71,7 @@ for rep in range(2):
     for env, what in (({"MFX_CLI_OVERLAP": "0"}, "sequence read first"), ({"MFX_CLI_OVERLAP": "1"}, "sequence read under the index build")):
         t = time.time()
         r = subprocess.run([exe, "-hist", "-sequence", out + "/asm.fasta", "-readmers", out + "/read.mfxk", "-peak", "26", "-prob", prob,
-                            "-output", out + "/out3.hist"], capture_output=True, text=True, env=dict(os.environ, MFX_CLI_TIMING="1", **env))
+                            "-output", out + "/out3.hist"], capture_output=True, text=True, env=dict(os.environ, MFX_CLI_TIMING="2", **env))
         print("-hist without -seqmers, %s: wall=%.2fs" % (what, time.time() - t))
         print("    " + "\n    ".join(l for l in r.stderr.splitlines() if "timing" in l))
 if os.path.exists(out + "/read_packed.mfxk"):
@@ -72,7 +79,7 @@ if os.path.exists(out + "/read_packed.mfxk"):
         for db, what in (("/read.mfxk", "delta-coded blocks"), ("/read_packed.mfxk", "packed records")):
             t = time.time()
             r = subprocess.run([exe, "-hist", "-sequence", out + "/asm.fasta", "-readmers", out + db, "-peak", "26", "-prob", prob,
-                                "-output", out + "/out4.hist"], capture_output=True, text=True, env=dict(os.environ, MFX_CLI_TIMING="1"))
+                                "-output", out + "/out4.hist"], capture_output=True, text=True, env=dict(os.environ, MFX_CLI_TIMING="2"))
             print("-hist without -seqmers, read database as %s: wall=%.2fs same_hist=%s" % (what, time.time() - t,
                   open(out + "/out.hist").read() == open(out + "/out4.hist").read()))
             print("    " + "\n    ".join(l for l in r.stderr.splitlines() if "timing" in l))
@@ -81,6 +88,6 @@ for sweep in [x for x in os.environ.get("MFX_TIMING_SWEEP", "").split(";") if x]
     for rep in range(2):
         t = time.time()
         r = subprocess.run([exe, "-hist", "-sequence", out + "/asm.fasta", "-readmers", out + "/read.mfxk", "-peak", "26", "-prob", prob,
-                            "-output", out + "/out5.hist"], capture_output=True, text=True, env=dict(os.environ, MFX_CLI_TIMING="1", MFX_INGEST_TIMING="1", **env))
+                            "-output", out + "/out5.hist"], capture_output=True, text=True, env=dict(os.environ, MFX_CLI_TIMING="2", MFX_INGEST_TIMING="1", **env))
         print("-hist without -seqmers, %s: wall=%.2fs same_hist=%s" % (sweep, time.time() - t, open(out + "/out.hist").read() == open(out + "/out5.hist").read()))
         print("    " + "\n    ".join(l for l in r.stderr.splitlines() if "timing" in l or "ingest:" in l or "read_fasta" in l))
