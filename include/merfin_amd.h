@@ -104,6 +104,10 @@ int mfx_index_load_db(mfx_index *ix, const char *path, int side, uint64_t minV, 
 /* the same into several tables with ONE pass over the database: the shards of one process (mfx_index_set_shard), each
  * keeping the k-mers it owns -- the chunk is staged once and sent to every table's device */
 int mfx_index_load_db_multi(mfx_index *const *ixs, uint32_t nix, const char *path, int side, uint64_t minV, uint64_t maxV);
+/* this library's flat binary form of a database (interchange; no reference counterpart).  Strictly ascending k-mers
+ * (the order `meryl print` lists them in, k <= 31) are written as delta-coded blocks -- 2.6 bytes per k-mer of a 30x read
+ * set, decoded by the kernel that inserts them; any other order as 8-byte packed records (k <= 21) or plain arrays.
+ * All forms load into the same tables (csrc/mfx_db.cpp holds the layouts). */
 int mfx_db_write_flat(const char *path, int k, const uint64_t *kmers, const uint32_t *values, uint64_t n);
 
 /* The built table as a device-format image on disk: later runs on the same databases skip the decode +
