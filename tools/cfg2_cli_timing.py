@@ -19,21 +19,43 @@ bases = int(float(sys.argv[1])) if len(sys.argv) > 1 else 64_000_000
 out = os.environ.get("MFX_TMP", "/tmp/mfx_cfg2")
 os.makedirs(out, exist_ok=True)
 t0 = time.time()
-ix, seqs, asm, info = st.build_world(m, bases, k=21, lam=26.0, ncontigs=1)
 big = bases > 1_500_000_000                                # a 3 Gb genome: only the read database is written, only -hist without -seqmers runs
+if big:
+    os.environ["MFX_LOAD_FACTOR"] = "0.85"                  # the world's own table (127 GB) must leave room for its export (96 GB)
+ix, seqs, asm, info = st.build_world(m, bases, k=21, lam=26.0, ncontigs=1)
+os.environ.pop("MFX_LOAD_FACTOR", None)
 ek, er, ea = ix.export(sort=False)
 seq = asm[0].cpu().numpy().tobytes()
 del ix, seqs, asm
 torch.cuda.empty_cache()
 # sorted as `meryl print` lists a database (the delta-coded flat form needs that; any order gives packed records) -- sort, filter
 # and gather on the GPU, so that the host only ever holds the arrays it writes
-kd, order = torch.sort(torch.from_numpy(ek.view(np.int64)).cuda())
+kd = torch.from_numpy(ek.view(np.int64)).cuda()
 del ek
-rd = torch.from_numpy(er.view(np.int32)).cuda()[order]
+
+
+def sorted_db(values):
+    """(k-mers, counts) of the entries with a count, ascending -- eight key ranges, each sorted on its own (torch.sort takes < 2^31 elements)"""
+    vd = torch.from_numpy(values.view(np.int32)).cuda()
+    ks, vs = [], []
+    CH = 1 << 30                                               # (mask selection, like sort, wants < 2^31 elements at a time)
+    for q in range(8):
+        kp, vp = [], []
+        for o in range(0, kd.numel(), CH):
+            kc, vc = kd[o:o + CH], vd[o:o + CH]
+            sel = ((kc >> 39) == q) & (vc != 0)
+            kp.append(kc[sel])
+            vp.append(vc[sel])
+        kq, o = torch.sort(torch.cat(kp))
+        vq = torch.cat(vp)[o]
+        ks.append(kq.cpu().numpy().view(np.uint64))
+        vs.append(vq.cpu().numpy().view(np.uint32))
+        del kp, vp, kq, o, vq, sel
+    return np.concatenate(ks), np.concatenate(vs)
+
+
+rk, rv = sorted_db(er)
 del er
-keep = rd != 0
-rk, rv = kd[keep].cpu().numpy().view(np.uint64), rd[keep].cpu().numpy().view(np.uint32)
-del rd, keep
 m.db_write_flat(out + "/read.mfxk", 21, rk, rv)
 if not big and os.environ.get("MFX_TIMING_FORMS", "1") != "0":   # the packed-record form of the same database, for the comparison below
     os.environ["MFX_FLAT_DELTA"] = "0"
@@ -43,13 +65,11 @@ n_read = len(rk)
 del rk, rv
 n_asm = 0
 if not big:
-    ad = torch.from_numpy(ea.view(np.int32)).cuda()[order]
-    keep = ad != 0
-    ak, av = kd[keep].cpu().numpy().view(np.uint64), ad[keep].cpu().numpy().view(np.uint32)
+    ak, av = sorted_db(ea)
     n_asm = len(ak)
     m.db_write_flat(out + "/asm.mfxk", 21, ak, av)
-    del ak, av, ad, keep
-del ea, kd, order
+    del ak, av
+del ea, kd
 torch.cuda.empty_cache()
 print("read database: %.2f GB delta-coded%s" % (os.path.getsize(out + "/read.mfxk") / 1e9,
       ", %.2f GB as packed records" % (os.path.getsize(out + "/read_packed.mfxk") / 1e9) if os.path.exists(out + "/read_packed.mfxk") else ""), flush=True)
