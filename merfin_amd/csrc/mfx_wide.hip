@@ -8,9 +8,11 @@
 //
 // Slot protocol.  A 128-bit key cannot be claimed with one 64-bit compare-and-swap, and for k = 64 every 128-bit
 // pattern is a legal k-mer, so "empty" lives in a separate word: state 0 = empty, 1 = claimed (key being written),
-// 2 = ready.  An inserter claims with CAS(state, 0 -> 1), stores the key, fences, publishes state = 2; a lane that
-// meets state 1 simply takes another turn of its loop (never an inner spin: the claiming lane may sit in the same
-// wave and must get to its publish).  Slots of a line fill in order, so a lookup stops at the first empty slot.
+// 2 = ready.  An inserter claims with CAS(state, 0 -> 1), stores the key, waits for those stores, publishes state = 2; a
+// lane that meets state 1 simply takes another turn of its loop (never an inner spin: the claiming lane may sit in the same
+// wave and must get to its publish).  A k-mer's slots are tried in ITS order (mfx_w_home: from a hashed slot of the home
+// line around the line, then the next lines), a claim takes the first empty one, so a lookup stops at the first empty slot
+// of that order.
 #include "mfx_device.h"
 
 typedef unsigned __int128 mfx_u128;
@@ -32,8 +34,12 @@ __device__ __forceinline__ mfx_u128 mfx_w_revcomp(mfx_u128 f, int k) {
   return (r ^ comp) & mask;
 }
 
-__device__ __forceinline__ uint32_t mfx_w_home(const mfx_table_view &t, mfx_u128 key) {
+// home line of a k-mer, and the slot of a line its probes start at: a k-mer's slots are tried from q0 on, around the line,
+// then on through the following lines (each from q0 again) -- most lookups end at the first slot they read (32 bytes of one
+// lane), where a walk from slot 0 read half the occupied slots of the line first
+__device__ __forceinline__ uint32_t mfx_w_home(const mfx_table_view &t, mfx_u128 key, uint32_t &q0) {
   const uint64_t h = mfx_hash64((uint64_t)key ^ mfx_hash64((uint64_t)(key >> 64) + 0x9E3779B97F4A7C15ULL));
+  q0 = (uint32_t)((h * 0xD6E8FEB86659FD93ULL) >> 62);
   return mfx_range32(h, t.nlines);
 }
 
@@ -56,14 +62,15 @@ __device__ __forceinline__ bool mfx_w_tile_kmer(const mfx_tile_lds &L, int k, ui
 // value(kmer): stored counts, 0 when absent (merfin-globals.C:84); -min/-max applied to the read count
 __device__ __forceinline__ uint2 mfx_w_lookup(const mfx_table_view &t, mfx_u128 key) {
   const mfx_wslot *S = mfx_w_slots(t);
-  uint64_t line = mfx_w_home(t, key);
+  uint32_t q0;
+  uint64_t line = mfx_w_home(t, key, q0);
   const uint64_t lo = (uint64_t)key, hi = (uint64_t)(key >> 64);
   for (uint32_t d = 0; d < MFX_W_MAX_LINES; ++d) {
     const mfx_wslot *ln = S + line * MFX_WSLOTS_LINE;
 #pragma unroll
-    for (uint32_t q = 0; q < MFX_WSLOTS_LINE; ++q) {
-      const mfx_wslot s = ln[q];
-      if (s.state == 0) return make_uint2(0u, 0u);           // slots fill in order: the key was never inserted
+    for (uint32_t qi = 0; qi < MFX_WSLOTS_LINE; ++qi) {
+      const mfx_wslot s = ln[(q0 + qi) & (MFX_WSLOTS_LINE - 1u)];
+      if (s.state == 0) return make_uint2(0u, 0u);           // the first empty slot of its order: the key was never inserted
       if (s.lo == lo && s.hi == hi) {
         uint32_t rv = s.readV;
         if (rv < t.minV || rv > t.maxV) rv = 0;              // merfin.C:199-200
@@ -78,21 +85,27 @@ __device__ __forceinline__ uint2 mfx_w_lookup(const mfx_table_view &t, mfx_u128 
 // find-or-claim; nullptr when the probe limit is hit
 __device__ __forceinline__ mfx_wslot *mfx_w_claim(const mfx_table_view &t, mfx_u128 key, uint64_t *meta, uint32_t &fresh) {
   mfx_wslot *S = mfx_w_slots(t);
-  uint64_t line = mfx_w_home(t, key);
+  uint32_t q0;
+  uint64_t line = mfx_w_home(t, key, q0);
   const uint64_t lo = (uint64_t)key, hi = (uint64_t)(key >> 64);
-  uint32_t d = 0, q = 0;
+  uint32_t d = 0, q = 0;                                     // q: slots of the current line tried so far
   mfx_wslot *found = nullptr;
   bool done = false;
   while (!done) {                                            // one slot examination per turn; state 1 = take another turn
-    mfx_wslot *sl = S + line * MFX_WSLOTS_LINE + q;
+    mfx_wslot *sl = S + line * MFX_WSLOTS_LINE + ((q0 + q) & (MFX_WSLOTS_LINE - 1u));
     unsigned long long *sp = reinterpret_cast<unsigned long long *>(&sl->state);
-    unsigned long long st = __hip_atomic_load(sp, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long st = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (st == 0ull) {
       st = atomicCAS(sp, 0ull, 1ull);
       if (st == 0ull) {                                      // the slot is ours: write the key, then publish
         __hip_atomic_store(reinterpret_cast<unsigned long long *>(&sl->lo), (unsigned long long)lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(reinterpret_cast<unsigned long long *>(&sl->hi), (unsigned long long)hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(sp, 2ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        // The key words must be performed before the slot is published.  Every access of this protocol is an agent-scope
+        // atomic (performed at the device's coherence point, past the XCD's L2), so waiting for the two stores' acknowledgements
+        // orders them -- a workgroup-scope release fence is exactly that wait.  (An agent-scope release instead writes back the
+        // whole L2 of the XCD on every claim: 0.4 G k-mers/s.)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __hip_atomic_store(sp, 2ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ++fresh;
         found = sl;
         done = true;
