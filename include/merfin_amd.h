@@ -109,6 +109,10 @@ int mfx_index_load_db_multi(mfx_index *const *ixs, uint32_t nix, const char *pat
  * set, decoded by the kernel that inserts them; any other order as 8-byte packed records (k <= 21) or plain arrays.
  * All forms load into the same tables (csrc/mfx_db.cpp holds the layouts). */
 int mfx_db_write_flat(const char *path, int k, const uint64_t *kmers, const uint32_t *values, uint64_t n);
+/* any accepted database (meryl directory, `meryl print` text, flat) -> the flat form, sorted (k <= 31), on the host: no
+ * device is touched.  One pass makes every later load of the database a matter of its bytes over PCIe (a 30x human read
+ * set: a minute of text parsing -> half a second).  CLI: merfin -convert <db> -output <file>.  n_kmers may be null. */
+int mfx_db_convert(const char *in_path, const char *out_path, uint64_t *n_kmers);
 
 /* The built table as a device-format image on disk: later runs on the same databases skip the decode +
  * insert (no reference counterpart; merfin rebuilds its lookup tables on every start, merfin.C:361). */

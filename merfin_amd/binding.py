@@ -64,7 +64,7 @@ SYMBOLS = [
     "mfx_last_error", "mfx_last_error_code", "mfx_version", "mfx_device_count",
     "mfx_index_create", "mfx_index_free", "mfx_index_estimate_gb", "mfx_index_add_read", "mfx_index_add_asm",
     "mfx_index_count_asm", "mfx_index_create_for_seq", "mfx_index_estimate_gb_for_seq", "mfx_index_claim_seq", "mfx_index_value", "mfx_index_get_info", "mfx_index_export",
-    "mfx_db_probe", "mfx_index_load_db", "mfx_index_load_db_multi", "mfx_db_write_flat", "mfx_index_save", "mfx_index_load",
+    "mfx_db_probe", "mfx_index_load_db", "mfx_index_load_db_multi", "mfx_db_write_flat", "mfx_db_convert", "mfx_index_save", "mfx_index_load",
     "mfx_index_set_fingerprint", "mfx_index_get_origin",
     "mfx_host_alloc", "mfx_host_free", "mfx_seq_create", "mfx_hist_run_streamed",
     "mfx_index_replicate", "mfx_seq_replicate", "mfx_hist_run_multi", "mfx_hist_run_sharded",
@@ -134,6 +134,7 @@ def load_library():
     L.mfx_db_probe.argtypes = [C.c_char_p, C.POINTER(_DbInfo)]
     L.mfx_index_load_db.argtypes = [vp, C.c_char_p, C.c_int, C.c_uint64, C.c_uint64]
     L.mfx_db_write_flat.argtypes = [C.c_char_p, C.c_int, u64p, u32p, C.c_uint64]
+    L.mfx_db_convert.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_uint64)]
     L.mfx_index_load_db_multi.argtypes = [C.POINTER(vp), C.c_uint32, C.c_char_p, C.c_int, C.c_uint64, C.c_uint64]
     L.mfx_index_save.argtypes = [vp, C.c_char_p]
     L.mfx_index_load.restype = vp
@@ -296,6 +297,13 @@ def load_db_multi(indexes, path, side, minV=0, maxV=2**64 - 1):
     n = len(indexes)
     arr = (C.c_void_p * n)(*[ix.h for ix in indexes])
     _check(load_library().mfx_index_load_db_multi(arr, n, path.encode(), side, minV, maxV))
+
+
+def db_convert(in_path, out_path):
+    """any accepted database -> the flat form (sorted: delta-coded blocks); returns the number of k-mers (mfx_db_convert, host only)"""
+    n = C.c_uint64(0)
+    _check(load_library().mfx_db_convert(in_path.encode(), out_path.encode(), C.byref(n)))
+    return n.value
 
 
 def db_write_flat(path, k, kmers, values):

@@ -27,7 +27,7 @@ enum { OP_NONE, OP_HIST, OP_COMPL, OP_DUMP, OP_FILTER, OP_POLISH, OP_BETTER, OP_
 
 struct Globals {
   const char *seqName = nullptr, *seqDBname = nullptr, *readDBname = nullptr, *pLookupTable = nullptr;
-  const char *vcfName = nullptr, *outName = nullptr, *indexName = nullptr;
+  const char *vcfName = nullptr, *outName = nullptr, *indexName = nullptr, *convertName = nullptr;
   double peak = 0, maxMemory = 0;
   uint64_t minV = 0, maxV = ~0ull;
   int threads = 0, reportType = OP_NONE, device = 0;
@@ -51,6 +51,8 @@ static void usage(const char *exe) {
           "    -peak m           haploid k-mer coverage peak (required except -filter)\n"
           "    -prob file        readK,prob rows; row n overrides -peak for multiplicity n\n"
           "    -seqmers db       assembly k-mer database; default: counted from -sequence on the GPU\n"
+          "    -convert db       no report: rewrite the k-mer database <db> (any accepted form) as -output <file> in the flat form\n"
+          "                      (sorted k-mers in delta-coded blocks; loads at the speed of the PCIe link)\n"
           "    -device d         HIP device (default 0)\n"
           "    -devices list     several GPUs of this node driven by this one process, e.g. 0-7 or 0,2,5 (-hist: the index is\n"
           "                      built once and copied to the others over xGMI, every GPU evaluates its share of the\n"
@@ -475,6 +477,7 @@ int main(int argc, char **argv) {
     }
     else if (is("-index")) G.indexName = val();
     else if (is("-sharded")) G.sharded = true;
+    else if (is("-convert")) G.convertName = val();
     else if (is("-nosplit")) G.nosplit = true;
     else if (is("-filter")) G.reportType = OP_FILTER;
     else if (is("-better")) G.reportType = OP_BETTER;
@@ -488,6 +491,20 @@ int main(int argc, char **argv) {
     else if (is("-comb")) G.comb = (unsigned)strtoul(val(), nullptr, 10);
     else if (is("-debug")) G.debug = true;
     else err.push_back(std::string("Unknown option '") + argv[arg] + "'.\n");
+  }
+
+  if (G.convertName && err.empty()) {
+    // merfin -convert <db> -output <file>: a database in any accepted form rewritten as this program's flat form (sorted
+    // k-mers in delta-coded blocks), on the host -- no report, no device
+    if (!G.outName) { fprintf(stderr, "No output (-output) supplied.\n"); return 1; }
+    fprintf(stderr, "-- Converting '%s' to '%s'.\n", G.convertName, G.outName);
+    uint64_t n = 0;
+    if (mfx_db_convert(G.convertName, G.outName, &n)) { fprintf(stderr, "ERROR: -convert: %s\n", mfx_last_error()); return 1; }
+    struct stat st;
+    fprintf(stderr, "-- Wrote %lu k-mers", (unsigned long)n);
+    if (stat(G.outName, &st) == 0 && n) fprintf(stderr, " in %.2f GB (%.2f bytes per k-mer)", st.st_size / 1e9, (double)st.st_size / (double)n);
+    fprintf(stderr, ".\nBye!\n");
+    return 0;
   }
 
   // merfin.C:159-181

@@ -29,6 +29,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <string>
@@ -461,13 +462,20 @@ int scan_text(const std::string &path, int *k_out, F &&emit, uint64_t *count) {
 // the thread that draws it and covers the lines that START in it (pread of the piece plus the tail of its last
 // line).  make(t) returns thread t's sink: sink(lo, hi, v) per k-mer, sink.done() once (its return value is the
 // thread's status).  A 6 G-line database (150 GB of text) is minutes of single-threaded fgets otherwise.
+// on_piece(t, pc), if given, tells that thread t starts piece pc (a sink that wants the file's order back collects by piece).
+inline uint64_t text_piece_bytes() {
+  uint64_t PIECE = 32ull << 20;
+  if (const char *e = getenv("MFX_TEXT_PIECE")) { const long v = atol(e); if (v >= 64) PIECE = (uint64_t)v; }   // tests: many pieces of a small file
+  return PIECE;
+}
+
 template <class Make>
-int scan_text_parallel(const std::string &path, int *k_out, uint64_t *count, Make &&make) {
+int scan_text_parallel(const std::string &path, int *k_out, uint64_t *count, Make &&make,
+                       const std::function<void(unsigned, uint64_t)> &on_piece = nullptr) {
   const int fd = open(path.c_str(), O_RDONLY);
   struct stat st;
   if (fd < 0 || fstat(fd, &st) != 0) { if (fd >= 0) close(fd); return mfx_fail(MFX_E_IO, "cannot open '%s'", path.c_str()); }
-  uint64_t PIECE = 32ull << 20;
-  if (const char *e = getenv("MFX_TEXT_PIECE")) { const long v = atol(e); if (v >= 64) PIECE = (uint64_t)v; }   // tests: many pieces of a small file
+  const uint64_t PIECE = text_piece_bytes();
   const uint64_t size = (uint64_t)st.st_size, TAIL = 4096;
   const uint64_t npieces = (size + PIECE - 1) / PIECE;
   const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>({npieces, 64, (uint64_t)mfx_host_threads()}));
@@ -487,6 +495,7 @@ int scan_text_parallel(const std::string &path, int *k_out, uint64_t *count, Mak
     uint64_t mine = 0;
     for (uint64_t pc; (pc = next.fetch_add(1)) < npieces;) {
       { std::lock_guard<std::mutex> g(emu); if (bad_rc != MFX_OK) break; }
+      if (on_piece) on_piece(t, pc);
       const uint64_t b = pc * PIECE, want = std::min(size - (b ? b - 1 : 0), PIECE + TAIL + (b ? 1 : 0));
       // one byte before the piece tells whether a line starts exactly at b
       const uint64_t from = b ? b - 1 : 0;
@@ -611,6 +620,10 @@ void par_blocks(uint64_t nblocks, F &&fn) {                   // fn(b) for every
 int write_flat_delta(FILE *f, const char *path, FlatHeader h, const uint64_t *kmers, const uint32_t *values, uint64_t n) {
   const uint64_t nblocks = (n + MFX_DELTA_BLOCK - 1) / MFX_DELTA_BLOCK;
   auto cnt_of = [&](uint64_t b) { return (uint32_t)std::min<uint64_t>(MFX_DELTA_BLOCK, n - b * MFX_DELTA_BLOCK); };
+  const bool timing = getenv("MFX_DB_TIMING") != nullptr;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double tw0 = now();
+  double t_pack = 0, t_io = 0;
   std::vector<DeltaBlockPlan> plan(nblocks);
   std::atomic<int> unsorted{0};
   par_blocks(nblocks, [&](uint64_t b) {
@@ -620,6 +633,7 @@ int write_flat_delta(FILE *f, const char *path, FlatHeader h, const uint64_t *km
     plan[b] = plan_delta_block(kmers + o, values + o, cnt);
   });
   if (unsorted) return 1;
+  const double tw1 = now();
   std::vector<uint64_t> dir(2 * (nblocks + 1));
   uint64_t at = sizeof(FlatHeader) + 8 + dir.size() * 8;
   h.n_escape = 0;
@@ -641,12 +655,15 @@ int write_flat_delta(FILE *f, const char *path, FlatHeader h, const uint64_t *km
     while (b1 < nblocks && (b1 == b0 || bytes + plan[b1].bytes <= (256ull << 20))) bytes += plan[b1++].bytes;
     buf.resize(bytes / 8);
     const uint64_t base = dir[2 * b0 + 1] & 0xffffffffffffull;
+    const double tp0 = now();
     par_blocks(b1 - b0, [&](uint64_t i) {
       const uint64_t b = b0 + i;
       pack_delta_block(kmers + b * MFX_DELTA_BLOCK, values + b * MFX_DELTA_BLOCK, cnt_of(b), plan[b],
                        buf.data() + ((dir[2 * b + 1] & 0xffffffffffffull) - base) / 8);
     });
+    const double tp1 = now();
     ok = fwrite(buf.data(), 8, buf.size(), f) == buf.size();
+    t_pack += tp1 - tp0; t_io += now() - tp1;
     b0 = b1;
   }
   // the escapes: the counts that did not fit their block's field
@@ -659,6 +676,8 @@ int write_flat_delta(FILE *f, const char *path, FlatHeader h, const uint64_t *km
   }
   ok = ok && ek.size() == h.n_escape &&
        (ek.empty() || (fwrite(ek.data(), 8, ek.size(), f) == ek.size() && fwrite(ev.data(), 4, ev.size(), f) == ev.size()));
+  if (timing) fprintf(stderr, "[mfx db] delta writer: plan %.2f s, pack %.2f s, write %.2f s, all %.2f s (%lu blocks)\n", tw1 - tw0, t_pack, t_io, now() - tw0,
+                      (unsigned long)nblocks);
   return ok ? 0 : mfx_fail(MFX_E_IO, "short write to '%s'", path);
 }
 
@@ -899,6 +918,222 @@ extern "C" int mfx_db_write_flat(const char *path, int k, const uint64_t *kmers,
   bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && (n == 0 || (fwrite(kmers, 8 * kw, n, f) == n && fwrite(values, 4, n, f) == n));
   fclose(f);
   return ok ? MFX_OK : mfx_fail(MFX_E_IO, "short write to '%s'", path);
+}
+
+// ---------------------------------------------------------------------------
+// mfx_db_convert: any accepted database -> this library's flat form, on the host (no device).  The point is the
+// delta-coded form: `meryl print` text of a 30x human read set parses at ~120 M lines/s (a minute per run), the
+// same database as delta-coded blocks loads in half a second.  The k-mers are collected in input order -- which
+// is ascending for `meryl print` text and for meryl directories read file by file -- and sorted (bucket by the top
+// bits, then every bucket on its own) only if they are not; k > 31 keeps its order (plain 16-byte k-mers).
+// ---------------------------------------------------------------------------
+namespace {
+struct Collected { std::vector<uint64_t> k; std::vector<uint32_t> v; };
+
+uint64_t flat_get_bits(const uint64_t *w, uint64_t bit, uint32_t nbits) {
+  const uint64_t i = bit >> 6;
+  const uint32_t sh = (uint32_t)bit & 63u;
+  uint64_t x = w[i] >> sh;
+  if (sh + nbits > 64u) x |= w[i + 1] << (64u - sh);
+  return nbits >= 64 ? x : x & ((1ull << nbits) - 1ull);
+}
+
+// a flat file into host arrays (all three encodings; k > 31: two words per k-mer)
+int read_flat_host(const std::string &path, int *k_out, std::vector<uint64_t> &keys, std::vector<uint32_t> &vals) {
+  FILE *f = fopen(path.c_str(), "rb");
+  if (!f) return mfx_fail(MFX_E_IO, "cannot open '%s'", path.c_str());
+  auto bad = [&](const char *what) { fclose(f); return mfx_fail(MFX_E_FORMAT, "'%s': %s", path.c_str(), what); };
+  FlatHeader h;
+  if (fread(&h, sizeof(h), 1, f) != 1) return bad("truncated header");
+  *k_out = (int)h.k;
+  const size_t kw = h.k > (uint32_t)MFX_MAX_K_NARROW ? 2 : 1;
+  keys.resize(h.n * kw);
+  vals.resize(h.n);
+  auto escapes = [&]() -> bool {                              // the side list of a packed / delta file: counts by k-mer
+    std::vector<uint64_t> ek(h.n_escape);
+    std::vector<uint32_t> ev(h.n_escape);
+    if (h.n_escape && (fread(ek.data(), 8, ek.size(), f) != ek.size() || fread(ev.data(), 4, ev.size(), f) != ev.size())) return false;
+    std::vector<std::pair<uint64_t, uint32_t>> e(h.n_escape);
+    for (size_t i = 0; i < e.size(); ++i) e[i] = {ek[i], ev[i]};
+    std::sort(e.begin(), e.end());
+    for (uint64_t i = 0; i < h.n; ++i)
+      if (vals[i] == 0xffffffffu && !e.empty()) {             // marked below
+        auto it = std::lower_bound(e.begin(), e.end(), std::make_pair(keys[i], 0u));
+        if (it == e.end() || it->first != keys[i]) return false;
+        vals[i] = it->second;
+      }
+    return true;
+  };
+  if (h.flags & FLAT_DELTA) {
+    uint64_t nblocks = 0;
+    if (kw != 1 || fread(&nblocks, 8, 1, f) != 1 || nblocks != (h.n + MFX_DELTA_BLOCK - 1) / MFX_DELTA_BLOCK) return bad("inconsistent delta-coded payload");
+    std::vector<uint64_t> dir(2 * (nblocks + 1));
+    if (fread(dir.data(), 8, dir.size(), f) != dir.size()) return bad("truncated block directory");
+    std::vector<uint64_t> w;
+    for (uint64_t b = 0; b < nblocks; ++b) {
+      const uint64_t off = dir[2 * b + 1] & 0xffffffffffffull, nxt = dir[2 * b + 3] & 0xffffffffffffull;
+      const uint32_t kb = (uint32_t)(dir[2 * b + 1] >> 48) & 0xffu, vb = (uint32_t)(dir[2 * b + 1] >> 56) & 0xffu;
+      const uint64_t cnt = std::min<uint64_t>(MFX_DELTA_BLOCK, h.n - b * MFX_DELTA_BLOCK);
+      if (nxt < off || (nxt - off) != (((cnt - 1) * kb + 63) / 64 + (cnt * vb + 63) / 64) * 8 || vb < 2 || vb > (uint32_t)MFX_DELTA_MAX_VBITS || kb > 62)
+        return bad("inconsistent block directory");
+      w.assign((nxt - off) / 8 + 1, 0);
+      if (fseek(f, (long)off, SEEK_SET) != 0 || fread(w.data(), 8, (nxt - off) / 8, f) != (nxt - off) / 8) return bad("truncated block");
+      const uint64_t *vw = w.data() + ((cnt - 1) * kb + 63) / 64;
+      uint64_t cur = dir[2 * b];
+      for (uint64_t e = 0; e < cnt; ++e) {
+        if (e && kb) cur += flat_get_bits(w.data(), (e - 1) * kb, kb);
+        keys[b * MFX_DELTA_BLOCK + e] = cur;
+        const uint32_t v = (uint32_t)flat_get_bits(vw, e * vb, vb);
+        vals[b * MFX_DELTA_BLOCK + e] = v == (1u << vb) - 1u ? 0xffffffffu : v;
+      }
+    }
+    if (fseek(f, (long)(dir[2 * nblocks + 1] & 0xffffffffffffull), SEEK_SET) != 0 || !escapes()) return bad("inconsistent escape list");
+  } else if (h.flags & FLAT_PACKED) {
+    if (kw != 1 || (h.n && fread(keys.data(), 8, h.n, f) != h.n)) return bad("truncated packed payload");
+    for (uint64_t i = 0; i < h.n; ++i) {
+      const uint32_t v = (uint32_t)keys[i] & MFX_PACKED_VMASK;
+      keys[i] >>= MFX_PACKED_VBITS;
+      vals[i] = v == MFX_PACKED_VMASK ? 0xffffffffu : v;
+    }
+    if (!escapes()) return bad("inconsistent escape list");
+  } else if (h.n && (fread(keys.data(), 8 * kw, h.n, f) != h.n || fread(vals.data(), 4, h.n, f) != h.n)) return bad("truncated payload");
+  fclose(f);
+  return MFX_OK;
+}
+
+// ascending order of (k, v) for one-word k-mers: buckets by the top bits, every bucket sorted on its own, all on the host threads
+void sort_pairs(int k, std::vector<uint64_t> &keys, std::vector<uint32_t> &vals) {
+  const uint64_t n = vals.size();
+  const int shift = std::max(0, 2 * k - 12);
+  const size_t NB = (size_t)1 << std::min(12, 2 * k);
+  // histogram and scatter by slices of the input, one per host thread (a 6 G-k-mer database is two 50 GB passes)
+  const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>({n / (1u << 20) + 1, 64, (uint64_t)mfx_host_threads()}));
+  std::vector<std::vector<uint64_t>> cnt(T, std::vector<uint64_t>(NB, 0));
+  auto slices = [&](auto &&fn) {
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < T; ++t) th.emplace_back([&, t]() { fn(t, n * t / T, n * (t + 1) / T); });
+    for (auto &x : th) x.join();
+  };
+  slices([&](unsigned t, uint64_t b, uint64_t e) { for (uint64_t i = b; i < e; ++i) ++cnt[t][keys[i] >> shift]; });
+  std::vector<uint64_t> start(NB + 1, 0);
+  for (size_t b = 0; b < NB; ++b) {
+    uint64_t at = start[b];
+    for (unsigned t = 0; t < T; ++t) { const uint64_t c = cnt[t][b]; cnt[t][b] = at; at += c; }     // slice t's first destination in bucket b
+    start[b + 1] = at;
+  }
+  std::vector<uint64_t> k2(n);
+  std::vector<uint32_t> v2(n);
+  slices([&](unsigned t, uint64_t b, uint64_t e) {
+    for (uint64_t i = b; i < e; ++i) { const uint64_t d = cnt[t][keys[i] >> shift]++; k2[d] = keys[i]; v2[d] = vals[i]; }
+  });
+  keys.swap(k2); vals.swap(v2);
+  std::vector<uint64_t>().swap(k2); std::vector<uint32_t>().swap(v2);
+  par_blocks(NB, [&](uint64_t b) {
+    const uint64_t lo = start[b], hi = start[b + 1];
+    if (hi - lo < 2 || std::is_sorted(keys.begin() + lo, keys.begin() + hi)) return;
+    std::vector<std::pair<uint64_t, uint32_t>> t(hi - lo);
+    for (uint64_t i = lo; i < hi; ++i) t[i - lo] = {keys[i], vals[i]};
+    std::sort(t.begin(), t.end());
+    for (uint64_t i = lo; i < hi; ++i) { keys[i] = t[i - lo].first; vals[i] = t[i - lo].second; }
+  });
+}
+}  // namespace
+
+extern "C" int mfx_db_convert(const char *in_path, const char *out_path, uint64_t *n_out) {
+  if (!in_path || !out_path) return mfx_fail(MFX_E_INVAL, "mfx_db_convert: null argument");
+  const std::string p(in_path);
+  const int fmt = detect(p);
+  if (!fmt) return mfx_fail(MFX_E_IO, "k-mer database '%s' does not exist", in_path);
+  int k = 0, rc = MFX_OK;
+  std::vector<uint64_t> keys;
+  std::vector<uint32_t> vals;
+  const bool timing = getenv("MFX_DB_TIMING") != nullptr;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = now();
+  auto gather = [&](std::vector<Collected> &parts, size_t kw) {   // parts in input order -> one pair of arrays
+    uint64_t n = 0;
+    for (auto &c : parts) n += c.v.size();
+    keys.resize(n * kw);
+    vals.resize(n);
+    uint64_t at = 0;
+    for (auto &c : parts) {
+      if (!c.v.empty()) { memcpy(keys.data() + at * kw, c.k.data(), c.k.size() * 8); memcpy(vals.data() + at, c.v.data(), c.v.size() * 4); }
+      at += c.v.size();
+      Collected().k.swap(c.k); Collected().v.swap(c.v);
+    }
+  };
+  if (fmt == MFX_DB_FLAT) rc = read_flat_host(p, &k, keys, vals);
+  else if (fmt == MFX_DB_TEXT) {
+    // k first (the first line), then every line; plain files by all host threads, collected PER PIECE of the file so that
+    // the file's order -- ascending for `meryl print` -- survives the threads
+    {
+      mfx_file fh = mfx_open_reader(in_path);
+      char line[512];
+      while (fh.f && k == 0 && fgets(line, sizeof(line), fh.f))
+        for (const char *q = line; base_code((unsigned char)*q) >= 0; ++q) ++k;
+      if (fh.f) (void)mfx_close(fh, true);
+      if (k == 0) return mfx_fail(MFX_E_FORMAT, "'%s': no k-mers found", in_path);
+      if (k > MFX_MAX_K) return mfx_fail(MFX_E_FORMAT, "'%s': k-mers of more than %d bases", in_path, MFX_MAX_K);
+    }
+    const size_t kw = k > MFX_MAX_K_NARROW ? 2 : 1;
+    uint64_t n = 0;
+    int k2 = 0;
+    if (text_is_plain(p)) {
+      struct stat st;
+      if (stat(in_path, &st) != 0) return mfx_fail(MFX_E_IO, "cannot open '%s'", in_path);
+      const uint64_t PIECE = text_piece_bytes(), npieces = ((uint64_t)st.st_size + PIECE - 1) / PIECE;
+      std::vector<Collected> per(npieces ? npieces : 1);
+      std::vector<Collected *> cur(64, nullptr);
+      struct Sink {
+        Collected **c; size_t kw;
+        void operator()(uint64_t lo, uint64_t hi, uint32_t v) { (*c)->k.push_back(lo); if (kw == 2) (*c)->k.push_back(hi); (*c)->v.push_back(v); }
+        int done() { return MFX_OK; }
+      };
+      rc = scan_text_parallel(p, &k2, &n, [&](unsigned t) { return Sink{&cur[t], kw}; },
+                              [&](unsigned t, uint64_t pc) {
+                                cur[t] = &per[pc];
+                                per[pc].v.reserve((size_t)(PIECE / (uint64_t)(k + 3)) + 16);
+                                per[pc].k.reserve(((size_t)(PIECE / (uint64_t)(k + 3)) + 16) * kw);
+                              });
+      if (rc == MFX_OK) gather(per, kw);
+    } else {
+      std::vector<Collected> one(1);
+      rc = scan_text(p, &k2, [&](uint64_t lo, uint64_t hi, uint32_t v) { one[0].k.push_back(lo); if (kw == 2) one[0].k.push_back(hi); one[0].v.push_back(v); }, &n);
+      if (rc == MFX_OK) gather(one, kw);
+    }
+    if (rc == MFX_OK && k2 != k && n) rc = mfx_fail(MFX_E_FORMAT, "'%s': k-mer length %d differs from %d", in_path, k2, k);
+  } else {
+    MerylIndex mi;
+    rc = read_meryl_master(p, mi);
+    if (rc) return rc;
+    k = (int)((mi.prefixSize + mi.suffixSize) / 2);
+    const size_t kw = k > MFX_MAX_K_NARROW ? 2 : 1;
+    std::vector<Collected> per(64);
+    std::vector<MerylFileSums> sums(64);
+    rc = for_each_meryl_file([&](uint32_t fl) {
+      Collected &c = per[fl];
+      return read_meryl_data(meryl_file_name(p, fl, ".merylData"), fl, mi,
+                             [&](uint64_t lo, uint64_t hi, uint32_t v) { c.k.push_back(lo); if (kw == 2) c.k.push_back(hi); c.v.push_back(v); }, &sums[fl]);
+    });
+    if (rc == MFX_OK) rc = check_meryl_sums(p, mi, sums, true);
+    if (rc == MFX_OK) gather(per, kw);
+  }
+  if (rc) return rc;
+  const double t1 = now();
+  if (k <= MFX_MAX_K_NARROW) {
+    bool sorted = true;
+    for (uint64_t i = 1; i < vals.size() && sorted; ++i) sorted = keys[i] > keys[i - 1];
+    if (!sorted) {
+      sort_pairs(k, keys, vals);
+      for (uint64_t i = 1; i < vals.size(); ++i)
+        if (keys[i] == keys[i - 1]) return mfx_fail(MFX_E_FORMAT, "'%s' lists a k-mer twice; a database holds every k-mer once", in_path);
+    }
+  }
+  if (n_out) *n_out = vals.size();
+  const double t2 = now();
+  rc = mfx_db_write_flat(out_path, k, keys.data(), vals.data(), vals.size());
+  if (timing) fprintf(stderr, "[mfx db] convert: read %.2f s, order %.2f s, write %.2f s\n", t1 - t0, t2 - t1, now() - t2);
+  return rc;
 }
 
 // ---------------------------------------------------------------------------
