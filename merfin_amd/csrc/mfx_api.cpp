@@ -1052,9 +1052,9 @@ extern "C" double mfx_histoQV(double kval, double ktot, int k) {
 static int index_canonical(const mfx_index *ix, int *canon) {
   uint64_t meta[4];
   MFX_HIP(hipMemcpy(meta, ix->d_meta, sizeof(meta), hipMemcpyDeviceToHost));
-  // single probe of min(f,r) equals value(f)+value(r) only for a canonical DB
-  // and odd k (no palindromes); otherwise probe both strands (SURVEY A-7).
-  *canon = (meta[1] == 0 && (ix->k & 1)) ? 1 : 0;
+  // single probe of min(f,r) equals value(f)+value(r) for a canonical DB: the other strand is not in it (SURVEY A-7);
+  // for even k the kernels count a palindromic k-mer's slot twice.  A database with non-canonical k-mers: both strands.
+  *canon = meta[1] == 0 ? 1 : 0;
   return MFX_OK;
 }
 
@@ -2103,7 +2103,7 @@ extern "C" int mfx_route_tiles(mfx_router *r, const mfx_seq *seq, uint64_t tile_
   int canon = 0;
   int rc = index_canonical(r->ix, &canon);
   if (rc) return rc;
-  if (!canon) return mfx_fail(MFX_E_INVAL, "a sharded index needs a canonical k-mer database and odd k");
+  if (!canon || !(r->ix->k & 1)) return mfx_fail(MFX_E_INVAL, "a sharded index needs a canonical k-mer database and odd k");
   const uint64_t n = (tile_end - tile_begin) * MFX_TILE;
   if (int erc = mfx_seq_ensure_ascii(seq)) return erc;
   mfx_route_args a;

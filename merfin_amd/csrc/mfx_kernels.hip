@@ -1328,6 +1328,12 @@ __global__ __launch_bounds__(MFX_BLOCK, 4) void mfx_hist_kernel(mfx_hist_args a)
         else mfx_group_lookup<MFX_BATCH>(a.t, MB, key2, key, ok, rv2, av2);
 #pragma unroll
         for (int j = 0; j < MFX_BATCH; ++j) { rv[j] += rv2[j]; av[j] += av2[j]; }
+      } else if (KF ? (KF & 1) == 0 : (k & 1) == 0) {
+        // even k, canonical database: a k-mer that is its own reverse complement is looked up as fmer AND as rmer by the
+        // reference -- the same slot twice (value(fmer) + value(rmer), uint32 arithmetic); every other k-mer has one strand
+        // in the database, the one probed
+#pragma unroll
+        for (int j = 0; j < MFX_BATCH; ++j) if (key[j] == key2[j]) { rv[j] += rv[j]; av[j] += av[j]; }
       }
 #pragma unroll
       for (int j = 0; j < MFX_BATCH; ++j) {
@@ -1718,6 +1724,9 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_dump_kernel(mfx_dump_args a) {
         else mfx_group_lookup<MFX_BATCH>(a.t, MB, key2, key, ok, rv2, av2);
 #pragma unroll
         for (int j = 0; j < MFX_BATCH; ++j) { rv[j] += rv2[j]; av[j] += av2[j]; }
+      } else if ((k & 1) == 0) {                               // even k: a palindromic k-mer is value(fmer) + value(rmer) of ONE slot
+#pragma unroll
+        for (int j = 0; j < MFX_BATCH; ++j) if (key[j] == key2[j]) { rv[j] += rv[j]; av[j] += av[j]; }
       }
     }
 #pragma unroll

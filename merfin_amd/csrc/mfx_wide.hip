@@ -185,11 +185,16 @@ __global__ void mfx_w_export_kernel(mfx_table_view t, uint64_t *kmers, uint32_t 
 }
 
 // getK(kmer,kmer): value(fmer) + value(rmer) in uint32 arithmetic (merfin-globals.C:107-108); with a canonical
-// database and odd k exactly one strand can be present, so one probe of min(f, r) gives the same sum
+// database only the canonical strand can be present, so one probe of min(f, r) gives the same sum (twice the slot for
+// a k-mer that is its own reverse complement: even k)
 template <bool CANON>
 __device__ __forceinline__ uint2 mfx_w_getV(const mfx_table_view &t, mfx_u128 f, int k) {
   const mfx_u128 r = mfx_w_revcomp(f, k);
-  if (CANON) return mfx_w_lookup(t, f < r ? f : r);
+  if (CANON) {
+    uint2 v = mfx_w_lookup(t, f < r ? f : r);
+    if (f == r) { v.x += v.x; v.y += v.y; }                  // even k: a palindrome is looked up as fmer and as rmer -- one slot, twice
+    return v;
+  }
   const uint2 a = mfx_w_lookup(t, f), b = mfx_w_lookup(t, r);
   return make_uint2(a.x + b.x, a.y + b.y);
 }
