@@ -329,29 +329,6 @@ __device__ __forceinline__ void mfx_c_add(const mfx_table_view &c, unsigned long
   if (sl) atomicAdd(side ? &sl->asmV : &sl->readV, amount);
 }
 
-// standard slots, no claim: the slot holding `key`, or nullptr (sequence-only index with 16-byte slots, k > 21)
-__device__ __forceinline__ mfx_slot *mfx_find(const mfx_table_view &t, uint64_t key) {
-  const mfx_probe pr = mfx_home(t, key);
-  for (uint32_t d = 0; d < MFX_MAX_LINES; ++d) {
-    mfx_slot *base = t.slots + mfx_probe_line(t, pr, d) * MFX_SLOTS_LINE;
-    const uint4 *ln = reinterpret_cast<const uint4 *>(base);
-    uint4 s[MFX_SLOTS_LINE];
-#pragma unroll
-    for (uint32_t q = 0; q < MFX_SLOTS_LINE; ++q) s[q] = ln[q];
-    bool any_empty = false;
-    int at = -1;
-#pragma unroll
-    for (uint32_t q = 0; q < MFX_SLOTS_LINE; ++q) {
-      const uint64_t sk = (uint64_t)s[q].x | ((uint64_t)s[q].y << 32);
-      if (sk == key) at = (int)q;
-      any_empty |= (sk == MFX_EMPTY);
-    }
-    if (at >= 0) return base + at;
-    if (any_empty) break;
-  }
-  return nullptr;
-}
-
 // ---------------------------------------------------------------------------
 // Wave-cooperative insert (index build, assembly k-mer counting): the mirror image of the cooperative lookup.
 // Each lane brings one key; the 8 lanes of a lane-group serve their group's 8 keys ("rounds" S = 0..7), and for

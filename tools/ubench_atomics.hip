@@ -69,6 +69,10 @@ int main(int argc, char **argv) {
   CK(hipMalloc(&t, bytes)); CK(hipMalloc(&out, 8));
   CK(hipMemset(t, 0, bytes));
   printf("table %llu GiB\n", (unsigned long long)gib);
+  if (argc > 2) {                                             // only the loads, at the given lanes per line (x 256)
+    for (int i = 2; i < argc; ++i) run<3, 4>(t, bytes, out, (uint32_t)atoi(argv[i]), "16-byte load");
+    return 0;
+  }
   for (uint32_t g : {256u, 614u}) {
     run<3, 1>(t, bytes, out, g, "16-byte load");
     run<3, 4>(t, bytes, out, g, "16-byte load");
