@@ -138,6 +138,10 @@ constexpr double MFX_LF_MAX = 0.7, MFX_LF_MIN = 0.45, MFX_LF_HBM_SHARE = 0.75;
 // factors 0.30 / 0.25 / 0.20 (profiles/r03_kernel_experiments.txt).  0.225 is 105 GB for a human assembly -- half of what the
 // full table of reads + assembly takes at its 0.45.
 constexpr double MFX_CLF_MAX = 0.5, MFX_CLF_MIN = 0.225;
+// A sequence-only index in 16-byte slots (22 <= k <= 31) holds the assembly's k-mers only -- half of what the full tables hold --
+// and gives the memory back as speed: 500 Mb -hist at k = 31: 71.3 / 80.6 / 86.7 G k-mers/s at load factors 0.45 / 0.35 / 0.25
+// (profiles/r03_hist_rates_by_k.txt).  0.30 is 160 GB for a human assembly.
+constexpr double MFX_SLF_MIN = 0.30;
 
 bool load_factor_fixed(double *lf) {
   const char *e = getenv("MFX_LOAD_FACTOR");
@@ -163,8 +167,9 @@ uint64_t lines_for(uint64_t capacity_kmers, uint32_t slots_line = MFX_SLOTS_LINE
 }
 
 // the table actually allocated: budget_bytes = what the table may take (0: unknown, use the smallest)
-uint64_t lines_auto(uint64_t capacity_kmers, double budget_bytes, uint32_t slots_line) {
-  const double lf_max = slots_line == MFX_CSLOTS_LINE ? MFX_CLF_MAX : MFX_LF_MAX, lf_min = slots_line == MFX_CSLOTS_LINE ? MFX_CLF_MIN : MFX_LF_MIN;
+uint64_t lines_auto(uint64_t capacity_kmers, double budget_bytes, uint32_t slots_line, bool seq_only = false) {
+  const double lf_max = slots_line == MFX_CSLOTS_LINE ? MFX_CLF_MAX : MFX_LF_MAX,
+               lf_min = slots_line == MFX_CSLOTS_LINE ? MFX_CLF_MIN : (seq_only && slots_line == MFX_SLOTS_LINE) ? MFX_SLF_MIN : MFX_LF_MIN;
   double lf;
   if (load_factor_fixed(&lf)) return lines_at(capacity_kmers, lf, slots_line);
   lf = lf_max;
@@ -290,7 +295,7 @@ static mfx_index *index_create(int k, uint64_t capacity_kmers, double max_gb, in
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = MFX_LF_HBM_SHARE * (double)free_b;
     if (max_gb > 0) budget = budget > 0 ? std::min(budget, max_gb * 1e9) : max_gb * 1e9;
     if (budget > 0) budget = std::max(1.0, budget - (double)ix->side_nlines * MFX_ALIGN);
-    ix->nlines = lines_auto(capacity_kmers, budget, slots_line);
+    ix->nlines = lines_auto(capacity_kmers, budget, slots_line, seq_only);
   }
   if (ix->nlines >= (1ull << 32)) {        // line numbers are 32-bit on the device (550 GB of table: beyond one GPU anyway)
     mfx_fail(MFX_E_NOMEM, "Not enough memory to load databases.  %lu k-mers need %.0f GB on one GPU; shard the index (mfx_index_set_shard).",
