@@ -31,6 +31,7 @@
 #include <map>
 #include <chrono>
 #include <functional>
+#include <future>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -632,17 +633,28 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
   uint64_t clusters = 0, varMerId = 0;
   const uint64_t BATCH_BYTES = (getenv("MFX_VAR_BATCH_MB") ? (uint64_t)atoi(getenv("MFX_VAR_BATCH_MB")) : 64ull) << 20;   // packed path text per GPU launch
 
-  std::vector<Job> jobs;
-  jobs.reserve(65536);
+  // A batch of clusters goes through three stages: A = its paths are enumerated and packed (host threads), B = every path k-mer
+  // is looked up with ONE GPU launch, C = the selectors run (host threads) and the records are written in input order.  Two
+  // batches are in flight: stage B of a batch runs (on its own thread: upload, kernel, download) under stage C of the batch
+  // before it and under the queueing of the next one.
+  struct Batch {
+    std::vector<Job> jobs;
+    std::string packed;
+    std::vector<uint32_t> rv, av;
+    std::future<int> gpu;
+    std::string err;                  // the error text of stage B (errors are per thread: it is carried back to the caller's)
+    bool live = false;
+  } batches[2];
+  int cur_b = 0;
+  batches[0].jobs.reserve(65536);
+  batches[1].jobs.reserve(65536);
   std::vector<char> out_buf(4u << 20);
   setvbuf(out, out_buf.data(), _IOFBF, out_buf.size());
-  std::string packed;
-  std::vector<uint32_t> rv, av;
 
-  // Enumerates the queued clusters' paths (host threads), scores every path k-mer
-  // with ONE GPU launch, applies the selectors (host threads), writes in input order.
-  auto flush = [&]() -> int {
-    if (jobs.empty()) return MFX_OK;
+  // stage A + the launch of stage B
+  auto stage_ab = [&](Batch &bt) -> int {
+    std::vector<Job> &jobs = bt.jobs;
+    std::string &packed = bt.packed;
     lap(5);
     parallel_for(jobs.size(), [&](size_t i) {
       Job &jb = jobs[i];
@@ -669,11 +681,31 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
       memcpy(&packed[jb.off], jb.ps.text.data(), jb.ps.text.size());
     });
     lap(2);
+    bt.live = true;
     if (total) {
-      rv.resize(packed.size() + 1);
-      av.resize(packed.size() + 1);
-      int r = values(packed.data(), packed.size(), rv.data(), av.data());
-      if (r) return r;
+      bt.rv.resize(packed.size() + 1);
+      bt.av.resize(packed.size() + 1);
+      Batch *bp = &bt;
+      bt.gpu = std::async(std::launch::async, [bp, &values]() {
+        const int r = values(bp->packed.data(), bp->packed.size(), bp->rv.data(), bp->av.data());
+        if (r) bp->err = mfx_last_error();
+        return r;
+      });
+    }
+    return MFX_OK;
+  };
+
+  // the end of stage B (its values are waited for) and stage C
+  auto stage_c = [&](Batch &bt) -> int {
+    if (!bt.live) return MFX_OK;
+    std::vector<Job> &jobs = bt.jobs;
+    std::string &packed = bt.packed;
+    const std::vector<uint32_t> &rv = bt.rv, &av = bt.av;
+    bt.live = false;
+    lap(5);
+    if (bt.gpu.valid()) {
+      const int r = bt.gpu.get();
+      if (r) { jobs.clear(); packed.clear(); return mfx_fail(r, "%s", bt.err.c_str()); }
     }
     lap(3);
     const bool want_dbg = dbg != nullptr;
@@ -774,6 +806,15 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
     return MFX_OK;
   };
 
+  // the queued clusters start their stages A and B; the batch before them finishes (its stage C)
+  auto flush = [&]() -> int {
+    if (batches[cur_b].jobs.empty()) return MFX_OK;
+    int r = stage_ab(batches[cur_b]);
+    const int r2 = stage_c(batches[cur_b ^ 1]);
+    cur_b ^= 1;
+    return r ? r : r2;
+  };
+
   uint64_t est_bytes = 0;
   for (uint32_t c = 0; c < ncontigs && rc == MFX_OK; ++c) {
     auto it = db.by_chr.find(names[c]);
@@ -794,6 +835,7 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
                 names[c], rStart, rEnd, cl->vars.size(), comb);
         continue;
       }
+      std::vector<Job> &jobs = batches[cur_b].jobs;
       jobs.emplace_back();
       Job &jb = jobs.back();
       jb.cl = cl; jb.contig = c; jb.rStart = rStart; jb.rEnd = rEnd;
@@ -812,6 +854,11 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
     }
   }
   if (rc == MFX_OK) rc = flush();
+  {
+    const int r2 = stage_c(batches[cur_b ^ 1]);              // the last batch launched (after an error: its GPU work is waited for, nothing is written twice)
+    if (rc == MFX_OK) rc = r2;
+    for (Batch &bt : batches) if (bt.gpu.valid()) (void)bt.gpu.get();
+  }
   lap(5);
   if (timing)
     fprintf(stderr, "[mfx_variants] load+cluster %.2fs  enumerate %.2fs  pack %.2fs  gpu %.2fs  score+select %.2fs  queue+write %.2fs\n",
