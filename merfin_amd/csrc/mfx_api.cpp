@@ -224,6 +224,7 @@ mfx_table_view mfx_index::view() const {
   v.maxV = maxV > 0xffffffffull ? 0xffffffffu : (uint32_t)maxV;
   v.k = k;
   v.mz_w = mz_w;
+  v.mz_t = mz_t;
   v.shard_rank = shard_rank;
   v.shard_n = shard_n;
   v.wide = wide() ? 1 : 0;
@@ -314,6 +315,12 @@ static mfx_index *index_create(int k, uint64_t capacity_kmers, double max_gb, in
     int w = ws ? atoi(ws) : w_default;
     if (w < 1 || w > 5) w = w_default;
     ix->mz_w = (mz && !ix->wide()) ? std::min(w, k) : 0;    // 128-bit k-mers: plain hashing (mfx_wide.hip)
+    // compact layout: the window is sampled by the k-mer's smallest t-mer (mod-minimizer: 0.30 instead of 0.40 lines per k-mer);
+    // t makes (k - t) % 4 == 3, which makes the choice the same on both strands.  MFX_MZ_MOD=0: the smallest m-mer, as the other layouts.
+    {
+      const char *mm = getenv("MFX_MZ_MOD");
+      ix->mz_t = (compact && ix->mz_w == 4 && k >= 13 && !(mm && atoi(mm) == 0)) ? ((k + 1) & 3) + 4 : 0;
+    }
   }
   hipError_t e = hipMalloc((void **)&ix->d_slots, ix->total_lines() * MFX_ALIGN);
   if (e != hipSuccess && ix->nlines > lines_for(capacity_kmers, slots_line)) {

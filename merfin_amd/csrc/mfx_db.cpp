@@ -1162,7 +1162,7 @@ static int fill_header(const mfx_index *ix, IndexImageHeader &h) {
   if (hipSetDevice(ix->device) != hipSuccess) return mfx_fail(MFX_E_HIP, "hipSetDevice(%d) failed", ix->device);
   memset(&h, 0, sizeof(h));
   memcpy(h.magic, "MFXINDX2", 8);
-  h.k = (uint32_t)ix->k; h.mz_w = (uint32_t)ix->mz_w;
+  h.k = (uint32_t)ix->k; h.mz_w = (uint32_t)ix->mz_w | ((uint32_t)ix->mz_t << 8);   // (the sampling t-mer length rides in the second byte)
   h.shard_rank = ix->shard_rank; h.shard_n = ix->shard_n;
   h.nlines = ix->nlines; h.capacity_kmers = ix->capacity_kmers;
   h.minV = ix->minV; h.maxV = ix->maxV;
@@ -1200,7 +1200,8 @@ static mfx_index *index_from_header(const IndexImageHeader &h, double max_gb, in
   ix->d_slots = nullptr;
   ix->nlines = h.nlines;
   ix->capacity_kmers = h.capacity_kmers;
-  ix->mz_w = (int)h.mz_w;
+  ix->mz_w = (int)(h.mz_w & 0xffu);
+  ix->mz_t = (int)((h.mz_w >> 8) & 0xffu);
   ix->shard_rank = h.shard_rank; ix->shard_n = h.shard_n ? h.shard_n : 1;
   ix->minV = h.minV; ix->maxV = h.maxV; ix->filter_set = h.filter_set != 0;
   ix->fingerprint = h.fingerprint;

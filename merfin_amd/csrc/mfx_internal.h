@@ -55,7 +55,7 @@ constexpr uint32_t MFX_MAXP_LDS   = 1024;       // read counts whose (readK, pro
 constexpr uint32_t MFX_KLUT       = 32;         // (readK, asmK) pairs below this use tabulated bin index / over-copy term
 // placement functions of the table (mfx_kernels.hip: mfx_minimizer, mfx_mz_line, mfx_home); index images
 // written under another version are refused by mfx_index_load
-constexpr uint32_t MFX_LAYOUT_VERSION = 5u;
+constexpr uint32_t MFX_LAYOUT_VERSION = 6u;
 constexpr uint32_t MFX_SPLIT_MAX_RANKS = 16;  // owners the sort-free router handles (a node has 8 GPUs); more: radix sort
 constexpr int      MFX_MZ_W_DEFAULT = 3;        // minimizer windows of the default placement (MFX_MZ_W overrides)
 constexpr uint32_t MFX_OVF_CAP    = 1u << 20;   // histogram overflow records per evaluator
@@ -100,6 +100,7 @@ struct mfx_table_view {
   uint32_t  minV, maxV;         // read-count filter (merfin.C:199-200), clamped to uint32
   int       k;
   int       mz_w;               // minimizer windows (0 = plain k-mer hashing; else m = k - mz_w + 1)
+  int       mz_t;               // > 0: the window is SAMPLED by the k-mer's smallest mz_t-mer (mod-minimizer, mfx_kernels.hip); 0: the smallest m-mer
   uint32_t  shard_rank, shard_n;  // sharded index: this table keeps only the k-mers owned by shard_rank of shard_n
   int       wide;               // k > 31: slots are mfx_wslot (mfx_wide.hip kernels)
   int       seq_only;           // the key set is the k-mers claimed from a sequence: adds update, they never claim
@@ -121,6 +122,7 @@ struct mfx_index {
   uint64_t  minV = 0, maxV = ~0ull;
   bool      filter_set = false;
   int       mz_w = 0;
+  int       mz_t = 0;
   uint32_t  shard_rank = 0, shard_n = 1;
   uint64_t  version = 0;        // bumped by every insert batch; lets evaluators cache index-derived facts
   uint64_t  fingerprint = 0;    // caller-supplied digest of the inputs (travels with the index image)

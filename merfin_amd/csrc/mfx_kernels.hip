@@ -78,12 +78,39 @@ __device__ __forceinline__ uint64_t mfx_minimizer(uint64_t key, uint64_t rc, int
   return best;
 }
 
+// MOD-MINIMIZER (the compact layout): the window is not the one with the smallest m-mer but the one SAMPLED by the k-mer's
+// smallest t-mer (t small: 4..7): of the k-t+1 t-mers of the k-mer the smallest (order hash of the canonical t-mer, ties: the
+// leftmost in `key`) sits at offset x, and the k-mer's minimizer is its m-mer at offset x mod w.  Neighbouring k-mers agree
+// on a t-mer for much longer than on an m-mer (a k-mer has 16 t-mers and 4 m-mers), and x mod w walks through the windows
+// as the t-mer moves through the k-mer: a random sequence changes its minimizer every 3.35 positions instead of every 2.5
+// (density 0.299 against 0.402 for w = 4) -- a quarter fewer table lines per k-mer at the same bucket size.  With
+// (k - t) % w == w - 1 the k-mer and its reverse complement sample the same m-mer (offset x becomes k-t-x, window j becomes
+// w-1-j), so that neighbours of either orientation share buckets; ties are the k-mer's own business (`key` is what the
+// table stores: the canonical k-mer).  The order hash has 9 bits: it is compared together with 7 position bits in 16-bit lanes
+// by the evaluation kernel, which finds the same offsets for a whole wave at once (mfx_wave_mod_lines).
+__device__ __forceinline__ uint32_t mfx_tmer_order(uint32_t canonical_tmer) { return ((canonical_tmer * 0x9E3779B1u) >> 7) & 511u; }
+
+__device__ __forceinline__ uint64_t mfx_minimizer_mod(uint64_t key, uint64_t rc, int k, int w, int t) {
+  const uint32_t tmask = (1u << (2 * t)) - 1u;
+  uint32_t best = 0xffffffffu, x = 0;
+  for (int p = 0; p + t <= k; ++p) {                           // p: offset from the left (the most significant base)
+    const uint32_t a = (uint32_t)(key >> (2 * (k - t - p))) & tmask, b = (uint32_t)(rc >> (2 * p)) & tmask;   // the t-mer and its reverse complement
+    const uint32_t o = mfx_tmer_order(a < b ? a : b);
+    if (o < best) { best = o; x = (uint32_t)p; }
+  }
+  const int m = k - w + 1, j = (int)(x % (uint32_t)w);          // window j from the left
+  const uint64_t mmask = (~0ULL) >> (64 - 2 * m);
+  const uint64_t a = (key >> (2 * (w - 1 - j))) & mmask, b = (rc >> (2 * j)) & mmask;
+  return a < b ? a : b;
+}
+
 // line of a k-mer's minimizer: one odd 64-bit multiplication (the high half of the product
 // depends on every bit of the m-mer), then the multiply-range reduction.  The multiplier must
 // be unrelated to the order hash's: the minimizer is the window with the SMALLEST order hash,
 // so a line hash correlated with it would crowd the low lines.
 __device__ __forceinline__ uint32_t mfx_mz_line(const mfx_table_view &t, uint64_t key, uint64_t krc) {
-  return mfx_range32(mfx_minimizer(key, krc, t.k, t.mz_w) * 0xD6E8FEB86659FD93ULL, t.nlines);
+  const uint64_t mz = t.mz_t ? mfx_minimizer_mod(key, krc, t.k, t.mz_w, t.mz_t) : mfx_minimizer(key, krc, t.k, t.mz_w);
+  return mfx_range32(mz * 0xD6E8FEB86659FD93ULL, t.nlines);
 }
 
 __device__ __forceinline__ mfx_probe mfx_home(const mfx_table_view &t, uint64_t key) {
@@ -204,7 +231,7 @@ __device__ __forceinline__ void mfx_meta_flush(uint64_t *meta, uint32_t fresh, u
 __device__ __forceinline__ mfx_table_view mfx_side_view(const mfx_table_view &c) {
   mfx_table_view s = c;
   s.slots = c.side; s.nlines = c.side_nlines;
-  s.mz_w = 0; s.compact = 0; s.seq_only = 0;
+  s.mz_w = 0; s.mz_t = 0; s.compact = 0; s.seq_only = 0;
   s.minV = 0u; s.maxV = 0xffffffffu;                           // the read filter is applied to the resolved count
   s.shard_rank = 0u; s.shard_n = 1u;
   return s;
@@ -1058,9 +1085,10 @@ __device__ __forceinline__ void mfx_group_lookup8(const mfx_table_view &c, mfx_m
 // through the next ones (a round = one more load for the lanes that need it, the others wait): 5.8 % need a second
 // load, 1.3 % a third.  A line exhausted without the key or an empty slot is rare enough for the whole-line scan (mfx_c_find).
 // ---------------------------------------------------------------------------
+// pre: the queries' home lines if the caller has them already (mfx_wave_mod_lines), else nullptr
 template <int B>
 __device__ __forceinline__ void mfx_lane_lookup8(const mfx_table_view &c, mfx_mailbox &M, const uint64_t (&key)[B], const uint64_t (&krc)[B],
-                                                 const bool (&ok)[B], uint32_t (&rv)[B], uint32_t (&av)[B]) {
+                                                 const bool (&ok)[B], uint32_t (&rv)[B], uint32_t (&av)[B], const uint32_t *pre = nullptr) {
   const uint32_t tid = threadIdx.x, sub16 = (tid & 7u) << 4, lane = tid & 63u, wbase = tid & ~63u;
   const uint4 *const slots0 = reinterpret_cast<const uint4 *>(c.slots);
   uint32_t line[B];
@@ -1070,7 +1098,7 @@ __device__ __forceinline__ void mfx_lane_lookup8(const mfx_table_view &c, mfx_ma
   // ---- first mini-bucket of every query: one 16-byte load per lane and query, all B in flight
 #pragma unroll
   for (int j = 0; j < B; ++j) {
-    line[j] = ok[j] ? mfx_first_line(c, key[j], krc[j]) : 0u;  // no k-mer here: a dummy load of line 0, ignored below
+    line[j] = !ok[j] ? 0u : pre ? pre[j] : mfx_first_line(c, key[j], krc[j]);  // no k-mer here: a dummy load of line 0, ignored below
     v[j] = slots0[((uint64_t)line[j] << 3) | mfx_c_first(key[j])];
   }
 #pragma unroll
@@ -1186,8 +1214,10 @@ __device__ __forceinline__ void mfx_lane_lookup8(const mfx_table_view &c, mfx_ma
 #endif
 #if MFX_V_LANEPROBE
 #define MFX_COMPACT_LOOKUP(t, MB, key, krc, ok, rv, av) mfx_lane_lookup8<MFX_BATCH>(t, MB, key, krc, ok, rv, av)
+#define MFX_COMPACT_LOOKUP_PRE(t, MB, key, krc, ok, rv, av, pre) mfx_lane_lookup8<MFX_BATCH>(t, MB, key, krc, ok, rv, av, pre)
 #else
 #define MFX_COMPACT_LOOKUP(t, MB, key, krc, ok, rv, av) mfx_group_lookup8<MFX_BATCH>(t, MB, key, krc, ok, rv, av)
+#define MFX_COMPACT_LOOKUP_PRE(t, MB, key, krc, ok, rv, av, pre) mfx_group_lookup8<MFX_BATCH>(t, MB, key, krc, ok, rv, av)
 #endif
 
 // k-mer starting at tile position p; returns validity (all k bases ACGT)
@@ -1199,6 +1229,68 @@ __device__ __forceinline__ bool mfx_tile_kmer(const mfx_tile_lds &L, int k, uint
   fwd = hi >> (64 - 2 * k);
   uint64_t vv = (((uint64_t)L.valid[w] << 32) | L.valid[w + 1]) << o;
   return (vv >> (64 - k)) == ((~0ULL) >> (64 - k));
+}
+
+// ---------------------------------------------------------------------------
+// The home lines of a wave's k-mers under the mod-minimizer placement (mfx_minimizer_mod), found for the whole wave at once.
+// The lanes of a wave hold 64 consecutive positions per batch element, and the k-mer at position q samples its window by the
+// smallest of the t-mers at q .. q+npos-1: a SLIDING-WINDOW MINIMUM over values that each lane computes once (the order hash
+// of the t-mer at its own position) instead of npos times.  Values are 16-bit {order: 9 bits | position in the wave: 7 bits}
+// so that the minimum carries its position; two of them ride in one register -- low half: ties to the leftmost (position
+// q), high half: ties to the rightmost (127 - q) -- and v_pk_min_u16 takes both minima at once; a k-mer whose canonical form
+// is the reverse strand reads the high half (the leftmost t-mer of the canonical k-mer is the rightmost of the forward one).
+// The up to 15 positions behind the wave's 64 are computed once for all B batch elements: lane 15 * j + i takes the t-mer at
+// position 64 + i of element j (mfx_wave_mod_halo).
+// f, r: the forward k-mer at the lane's position and its reverse complement (whatever their validity: a valid k-mer only
+// ever looks at t-mers inside itself).  p0: the tile position of the lane's first batch element.  Every lane of the wave
+// takes part (the calls are wave-uniform).
+// ---------------------------------------------------------------------------
+typedef unsigned short mfx_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t mfx_pk_min_u16(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(mfx_us2, a), __builtin_bit_cast(mfx_us2, b)));
+}
+__device__ __forceinline__ uint32_t mfx_mod_pack(uint32_t order, uint32_t q) { return ((order << 7) | q) | (((order << 7) | (127u - q)) << 16); }
+
+// the order values of the positions behind the wave, for all B batch elements (lane 15 * j + i: position 64 + i of element j)
+template <int B>
+__device__ __forceinline__ uint32_t mfx_wave_mod_halo(const mfx_table_view &c, const mfx_tile_lds &L, uint32_t p0) {
+  static_assert(15 * B <= 64, "one lane per position behind the wave and batch element");
+  const int t = c.mz_t;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t jj = lane / 15u, ii = lane - 15u * jj;
+  uint32_t halo = 0xffffffffu;
+  if (jj < (uint32_t)B) {
+    const uint32_t q = p0 - lane + jj * MFX_BLOCK + 64u + ii, wd = q >> 5, o = q & 31u, sh = 2u * o;
+    const uint64_t w0 = L.codes[wd], w1 = L.codes[wd + 1];
+    const uint32_t a = (uint32_t)(((w0 << sh) | ((w1 >> 1) >> (63u - sh))) >> (64 - 2 * t));
+    const uint32_t b = (uint32_t)mfx_revcomp((uint64_t)a, t);
+    halo = mfx_mod_pack(mfx_tmer_order(a < b ? a : b), 64u + ii);
+  }
+  return halo;
+}
+
+// the home line of the lane's k-mer of batch element j (f: forward k-mer, r: its reverse complement).  mw: 80 words of LDS of
+// this wave (the mailbox of the lookup, idle at this point): the wave's values are written side by side and every lane takes
+// the minimum of the npos words from its own on -- 16 plain LDS reads and 15 packed minima; a doubling scheme over cross-lane
+// reads (4 x 2 ds_bpermute, the second for the positions behind the wave) cost twice the instructions.
+__device__ __forceinline__ uint32_t mfx_wave_mod_line(const mfx_table_view &c, uint32_t *mw, uint32_t halo, int j, uint64_t f, uint64_t r) {
+  const int k = c.k, t = c.mz_t, w = c.mz_w, m = k - w + 1, npos = k - t + 1;
+  const uint32_t lane = threadIdx.x & 63u, tmask = (1u << (2 * t)) - 1u;
+  const uint64_t mmask = (~0ULL) >> (64 - 2 * m);
+  const uint32_t a = (uint32_t)(f >> (2 * (k - t))) & tmask, b = (uint32_t)r & tmask;     // the t-mer at this position, and its reverse complement
+  const uint32_t hv = (uint32_t)__shfl((int)halo, (int)(15u * (uint32_t)j + lane), 64);
+  mfx_wave_handoff();                                          // the previous element's reads are done
+  mw[lane] = mfx_mod_pack(mfx_tmer_order(a < b ? a : b), lane);
+  if (lane < 16u) mw[64u + lane] = lane < 15u ? hv : 0xffffffffu;
+  mfx_wave_handoff();
+  uint32_t v = 0xffffffffu;
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    if (i < npos) v = mfx_pk_min_u16(v, mw[lane + (uint32_t)i]);
+  const uint32_t q = f <= r ? (v & 127u) : 127u - ((v >> 16) & 127u);
+  const uint32_t jf = (q - lane) % (uint32_t)w;               // the window, counted on the forward strand
+  const uint64_t ma = (f >> (2 * ((uint32_t)w - 1u - jf))) & mmask, mb = (r >> (2 * jf)) & mmask;
+  return mfx_range32((ma < mb ? ma : mb) * 0xD6E8FEB86659FD93ULL, c.nlines);
 }
 
 // ===========================================================================
@@ -1216,14 +1308,14 @@ constexpr int MFX_BATCH = MFX_V_BATCH;          // queries per lane and cooperat
 // read back (v_readlane + hazard nops) for every query.  The launcher picks the k = 21 / w = 4 instance for the compact layout
 // (meryl's default k for a human genome, BASELINE configs 1-4: 103.6 -> 108.0 G k-mers/s); any other k, and the full table --
 // whose kernel sits on the HBM line rate either way (91.0 G with and without) -- run the generic instance.
-template <bool CANON, bool COMPACT, int KF, int WF>
+template <bool CANON, bool COMPACT, int KF, int WF, int TF>
 __global__ __launch_bounds__(MFX_BLOCK, 4) void mfx_hist_kernel(mfx_hist_args a) {
   __shared__ mfx_tile_lds L;
   __shared__ mfx_mailbox MB;
   __shared__ mfx_hist_lds H;
 
   const uint32_t tid = threadIdx.x;
-  if (KF) { a.t.k = KF; a.t.mz_w = WF; }                       // (the launcher checked that they are the table's)
+  if (KF) { a.t.k = KF; a.t.mz_w = WF; a.t.mz_t = TF; }         // (the launcher checked that they are the table's)
   const int k = KF ? KF : a.t.k;
   const mfx_kstar_args &ka = a.ks;
   mfx_hist_lds_init(H, ka);
@@ -1282,21 +1374,26 @@ __global__ __launch_bounds__(MFX_BLOCK, 4) void mfx_hist_kernel(mfx_hist_args a)
     for (uint32_t b = 0; b < MFX_TILE / MFX_BLOCK; b += MFX_BATCH) {
       if (b * MFX_BLOCK >= n) break;         // short last tile of a contig (block-uniform): nothing starts beyond n
       uint64_t key[MFX_BATCH], key2[MFX_BATCH];
-      uint32_t rv[MFX_BATCH], av[MFX_BATCH];
+      uint32_t rv[MFX_BATCH], av[MFX_BATCH], pre[MFX_BATCH];
       bool     ok[MFX_BATCH];
+      // mod-minimizer placement: the wave finds its home lines together (mfx_wave_mod_line)
+      const bool wave_lines = COMPACT && CANON && (KF ? TF != 0 : a.t.mz_t != 0);
+      const uint32_t halo = wave_lines ? mfx_wave_mod_halo<MFX_BATCH>(a.t, L, b * MFX_BLOCK + tid) : 0u;
 #pragma unroll
       for (int j = 0; j < MFX_BATCH; ++j) {
         uint32_t p = (b + j) * MFX_BLOCK + tid;     // lane-consecutive positions
         uint64_t f;
         ok[j] = mfx_tile_kmer(L, k, p, f) && (p < n);
         uint64_t r = mfx_revcomp(f, k);
+        pre[j] = wave_lines ? mfx_wave_mod_line(a.t, reinterpret_cast<uint32_t *>(&MB.rec[tid & ~63u]), halo, j, f, r) : 0u;
         if (CANON) {
           key[j] = f < r ? f : r; key2[j] = f < r ? r : f;     // canonical k-mer and its reverse complement
         } else {
           key[j] = f; key2[j] = r;
         }
       }
-      if (COMPACT) MFX_COMPACT_LOOKUP(a.t, MB, key, key2, ok, rv, av);
+      if (wave_lines) MFX_COMPACT_LOOKUP_PRE(a.t, MB, key, key2, ok, rv, av, pre);
+      else if (COMPACT) MFX_COMPACT_LOOKUP(a.t, MB, key, key2, ok, rv, av);
       else mfx_group_lookup<MFX_BATCH>(a.t, MB, key, key2, ok, rv, av);
       if (!CANON) {
         // value(fmer) + value(rmer), uint32 arithmetic (merfin-globals.C:107-108)
@@ -1924,11 +2021,11 @@ hipError_t mfx_k_hist(const mfx_hist_args &a, int grid, hipStream_t st) {
   // MFX_DEBUG_DYN_LDS: extra dynamic LDS per block, an occupancy knob for experiments only
   static const unsigned dyn = getenv("MFX_DEBUG_DYN_LDS") ? (unsigned)atoi(getenv("MFX_DEBUG_DYN_LDS")) : 0u;
   static const bool generic = getenv("MFX_HIST_GENERIC") && atoi(getenv("MFX_HIST_GENERIC"));     // A/B, tests: never the specialised instances
-  if (a.canonical && a.t.compact && a.t.k == 21 && a.t.mz_w == 4 && !generic)   mfx_hist_kernel<true, true, 21, 4><<<grid, MFX_BLOCK, dyn, st>>>(a);
-  else if (a.canonical && a.t.compact) mfx_hist_kernel<true, true, 0, 0><<<grid, MFX_BLOCK, dyn, st>>>(a);
-  else if (a.canonical)                mfx_hist_kernel<true, false, 0, 0><<<grid, MFX_BLOCK, dyn, st>>>(a);
-  else if (a.t.compact)                mfx_hist_kernel<false, true, 0, 0><<<grid, MFX_BLOCK, dyn, st>>>(a);
-  else                                 mfx_hist_kernel<false, false, 0, 0><<<grid, MFX_BLOCK, dyn, st>>>(a);
+  if (a.canonical && a.t.compact && a.t.k == 21 && a.t.mz_w == 4 && a.t.mz_t == 6 && !generic) mfx_hist_kernel<true, true, 21, 4, 6><<<grid, MFX_BLOCK, dyn, st>>>(a);
+  else if (a.canonical && a.t.compact) mfx_hist_kernel<true, true, 0, 0, 0><<<grid, MFX_BLOCK, dyn, st>>>(a);
+  else if (a.canonical)                mfx_hist_kernel<true, false, 0, 0, 0><<<grid, MFX_BLOCK, dyn, st>>>(a);
+  else if (a.t.compact)                mfx_hist_kernel<false, true, 0, 0, 0><<<grid, MFX_BLOCK, dyn, st>>>(a);
+  else                                 mfx_hist_kernel<false, false, 0, 0, 0><<<grid, MFX_BLOCK, dyn, st>>>(a);
   return hipGetLastError();
 }
 hipError_t mfx_k_route(const mfx_route_args &a, hipStream_t st) {
@@ -1983,8 +2080,8 @@ hipError_t mfx_k_sum_tile_partials(double *tile_partials, uint64_t ntiles, doubl
 }
 int mfx_k_hist_resident_blocks(int compact) {
   int nb = 0;
-  const hipError_t e = compact ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mfx_hist_kernel<true, true, 0, 0>, MFX_BLOCK, 0)
-                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mfx_hist_kernel<true, false, 0, 0>, MFX_BLOCK, 0);
+  const hipError_t e = compact ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mfx_hist_kernel<true, true, 0, 0, 0>, MFX_BLOCK, 0)
+                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mfx_hist_kernel<true, false, 0, 0, 0>, MFX_BLOCK, 0);
   if (e != hipSuccess || nb < 1) nb = 4;
   return nb;
 }

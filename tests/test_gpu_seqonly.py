@@ -244,3 +244,47 @@ def test_packed_upload_equals_the_byte_upload(k, monkeypatch):
     if k <= 31:
         np.testing.assert_array_equal(ea[0], asm[0])
         np.testing.assert_array_equal(ea[2], asm[1])
+
+
+@pytest.mark.parametrize("k", list(range(13, 22)))
+def test_mod_minimizer_placement_every_k(k, monkeypatch):
+    """the compact layout places a k-mer by the window its smallest t-mer samples (mod-minimizer: t = 4..7 by k, windows of
+    8 / 12 / 16 t-mers).  The evaluation kernel finds those windows for a whole wave at once, the build kernels and the by-key
+    lookups one k-mer at a time: both must agree for every k the layout takes -- sequences with N runs, lowercase, contigs
+    that end inside and at the edges of tiles, low-complexity stretches (every t-mer of a window equal: all ties) -- and the
+    results are the oracle's, with the specialised and the generic kernel, and the same with the placement switched off"""
+    m = _mfx()
+    peak = 11.0
+    r = np.random.default_rng(700 + k)
+    sizes = (30000, 4096, 4097, 4095 + k, 8192 + k - 1, 500, k, k - 1, 0, 12345)
+    contigs, read, asm = synth.world(k=k, peak=peak, seed=800 + k, sizes=sizes)
+    # low-complexity inserts: homopolymers and dinucleotide repeats longer than a k-mer, both strands' worth
+    contigs = list(contigs)
+    c0 = bytearray(contigs[0])
+    for at, unit in ((1000, b"A"), (2000, b"AC"), (3000, b"T"), (4090, b"GA"), (8180, b"ACG"), (12000, b"C")):
+        rep = (unit * 80)[:70]
+        c0[at:at + len(rep)] = rep
+    contigs[0] = bytes(c0)
+    # the assembly's own k-mers, recounted by the plain-Python oracle (the inserts changed them); the reads keep their counts
+    import oracle.plain as plain
+    p = po.Params(k, peak)
+    amer = plain.count_kmers(k, [c.decode() for c in contigs])
+    ks = np.array(sorted(amer), dtype=np.uint64)
+    asm = (ks, np.array([amer[int(x)] for x in ks], dtype=np.uint32))
+    g, ka, km_, _ = po.hist_run(p, po.Lookup(k, *read), po.Lookup(k, *asm), contigs, threads=2)
+    for env in ({}, {"MFX_HIST_GENERIC": "1"}, {"MFX_MZ_MOD": "0"}):
+        for kk, vv in env.items():
+            monkeypatch.setenv(kk, vv)
+        ix, seqs = seq_index(m, k, contigs, read)
+        assert ix.info()["compact"]
+        ev = m.Evaluator(ix, m.KParams(peak))
+        assert_hist_equal(ev.hist(seqs), g, ka, km_, k)
+        ek, er, ea = ix.export()
+        np.testing.assert_array_equal(ek, asm[0])
+        np.testing.assert_array_equal(ea, asm[1])
+        rd = dict(zip(read[0].tolist(), read[1].tolist()))
+        np.testing.assert_array_equal(er, np.array([rd.get(x, 0) for x in ek.tolist()], dtype=np.uint32))
+        rv, av = ix.value(asm[0][::7])                            # by-key lookups walk the same placement
+        np.testing.assert_array_equal(av, asm[1][::7])
+        for kk in env:
+            monkeypatch.delenv(kk)
