@@ -1308,8 +1308,11 @@ constexpr int MFX_BATCH = MFX_V_BATCH;          // queries per lane and cooperat
 // read back (v_readlane + hazard nops) for every query.  The launcher picks the k = 21 / w = 4 instance for the compact layout
 // (meryl's default k for a human genome, BASELINE configs 1-4: 103.6 -> 108.0 G k-mers/s); any other k, and the full table --
 // whose kernel sits on the HBM line rate either way (91.0 G with and without) -- run the generic instance.
+#ifndef MFX_V_MINBLOCKS
+#define MFX_V_MINBLOCKS 4             // blocks per CU the register allocation aims at (tools/ab_build.sh -DMFX_V_MINBLOCKS=3: A/B)
+#endif
 template <bool CANON, bool COMPACT, int KF, int WF, int TF>
-__global__ __launch_bounds__(MFX_BLOCK, 4) void mfx_hist_kernel(mfx_hist_args a) {
+__global__ __launch_bounds__(MFX_BLOCK, MFX_V_MINBLOCKS) void mfx_hist_kernel(mfx_hist_args a) {
   __shared__ mfx_tile_lds L;
   __shared__ mfx_mailbox MB;
   __shared__ mfx_hist_lds H;
