@@ -104,13 +104,25 @@ __device__ __forceinline__ uint64_t mfx_minimizer_mod(uint64_t key, uint64_t rc,
   return a < b ? a : b;
 }
 
+// line of a mod-minimizer (an m-mer of at most 36 bits: the compact layout holds k <= 21): two 32-bit multiplications fold the
+// halves, a third scales into the table -- a third of the instructions of the 64-bit product below, in the kernel that is
+// bound by instruction issue
+__device__ __forceinline__ uint32_t mfx_mod_line_of(uint64_t mz, uint64_t nlines) {
+#ifdef MFX_V_MODHASH64                                         // A/B (tools/ab_build.sh): the 64-bit product of the other layouts
+  return mfx_range32(mz * 0xD6E8FEB86659FD93ULL, nlines);
+#else
+  const uint32_t h = ((uint32_t)mz * 0x9E3779B1u) ^ (((uint32_t)(mz >> 32) + 0x7F4A7C15u) * 0x85EBCA77u);
+  return __umulhi(h ^ (h >> 15), (uint32_t)nlines);
+#endif
+}
+
 // line of a k-mer's minimizer: one odd 64-bit multiplication (the high half of the product
 // depends on every bit of the m-mer), then the multiply-range reduction.  The multiplier must
 // be unrelated to the order hash's: the minimizer is the window with the SMALLEST order hash,
 // so a line hash correlated with it would crowd the low lines.
 __device__ __forceinline__ uint32_t mfx_mz_line(const mfx_table_view &t, uint64_t key, uint64_t krc) {
-  const uint64_t mz = t.mz_t ? mfx_minimizer_mod(key, krc, t.k, t.mz_w, t.mz_t) : mfx_minimizer(key, krc, t.k, t.mz_w);
-  return mfx_range32(mz * 0xD6E8FEB86659FD93ULL, t.nlines);
+  if (t.mz_t) return mfx_mod_line_of(mfx_minimizer_mod(key, krc, t.k, t.mz_w, t.mz_t), t.nlines);
+  return mfx_range32(mfx_minimizer(key, krc, t.k, t.mz_w) * 0xD6E8FEB86659FD93ULL, t.nlines);
 }
 
 __device__ __forceinline__ mfx_probe mfx_home(const mfx_table_view &t, uint64_t key) {
@@ -1290,7 +1302,7 @@ __device__ __forceinline__ uint32_t mfx_wave_mod_line(const mfx_table_view &c, u
   const uint32_t q = f <= r ? (v & 127u) : 127u - ((v >> 16) & 127u);
   const uint32_t jf = (q - lane) % (uint32_t)w;               // the window, counted on the forward strand
   const uint64_t ma = (f >> (2 * ((uint32_t)w - 1u - jf))) & mmask, mb = (r >> (2 * jf)) & mmask;
-  return mfx_range32((ma < mb ? ma : mb) * 0xD6E8FEB86659FD93ULL, c.nlines);
+  return mfx_mod_line_of(ma < mb ? ma : mb, c.nlines);
 }
 
 // ===========================================================================
