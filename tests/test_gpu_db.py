@@ -427,3 +427,49 @@ def test_delta_form_many_blocks_and_a_sharded_load(tmp_path):
     m.load_db_multi(shards, path, 0)
     got = sorted((int(a), int(b)) for ix in shards for a, b in zip(*ix.export()[:2]))
     assert got == list(zip(keys.tolist(), vals.tolist()))
+
+
+@pytest.mark.gpu
+def test_delta_form_with_a_damaged_directory_is_refused(tmp_path):
+    """the block directory of a delta-coded file is checked as a whole before any block is read by it (offsets chained, 8-byte
+    aligned, inside the file; widths in range; every block as long as its widths say): a damaged file is a format error, never
+    a read outside the staging lanes or the device buffers"""
+    import struct
+    import merfin_amd as m
+    rng = np.random.default_rng(12)
+    k = 21
+    keys = np.unique(rng.integers(0, 1 << 42, size=30000, dtype=np.uint64))
+    vals = rng.integers(1, 50, size=len(keys)).astype(np.uint32)
+    good = str(tmp_path / "good.mfxk")
+    m.db_write_flat(good, k, keys, vals)
+    raw = bytearray(open(good, "rb").read())
+    (nblocks,) = struct.unpack_from("<Q", raw, 32)
+    assert nblocks == (len(keys) + 4095) // 4096 and nblocks >= 3
+    d1 = 40 + 16 * 1 + 8                                             # the info word of block 1
+
+    def damaged(name, edit, cut=None):
+        b = bytearray(raw)
+        edit(b)
+        p = str(tmp_path / name)
+        open(p, "wb").write(bytes(b[:cut] if cut else b))
+        ix = m.Index(k, len(keys) + 16)
+        with pytest.raises(m.MfxError) as e:
+            ix.load_db(p, 0)
+        assert e.value.code in (-7, -6), (name, str(e.value))         # FORMAT, IO
+        assert ix.info()["distinct"] == 0                            # nothing was inserted on the way
+
+    def put(off, fmt, v):
+        return lambda b: struct.pack_into(fmt, b, off, v)
+
+    info1 = struct.unpack_from("<Q", raw, d1)[0]
+    damaged("nblocks.mfxk", put(32, "<Q", nblocks + 1))
+    damaged("offset.mfxk", put(d1, "<Q", info1 + 8))                 # block 1 starts 8 bytes late
+    damaged("kbits.mfxk", put(d1, "<Q", (info1 & ~(0xff << 48)) | (63 << 48)))
+    damaged("vbits.mfxk", put(d1, "<Q", (info1 & ~(0xff << 56)) | (1 << 56)))
+    damaged("vbits_wide.mfxk", put(d1, "<Q", (info1 & ~(0xff << 56)) | (23 << 56)))
+    damaged("short.mfxk", lambda b: None, cut=len(raw) - 64)
+    damaged("dir_cut.mfxk", lambda b: None, cut=40 + 16 * 2)
+    damaged("n.mfxk", put(16, "<Q", len(keys) + 5000))               # more k-mers than the blocks hold
+    ix = m.Index(k, len(keys) + 16)
+    ix.load_db(good, 0)
+    assert ix.info()["distinct"] == len(keys)
