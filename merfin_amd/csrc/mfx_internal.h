@@ -51,7 +51,10 @@ constexpr uint32_t MFX_BLOCK      = 256;
 constexpr uint32_t MFX_ALIGN      = 128;
 constexpr uint32_t MFX_SLOTS_LINE = 8;          // 8 x 16-byte slots = one 128-byte HBM line
 constexpr uint32_t MFX_NB_LDS     = 1024;       // K* bins per side privatised in LDS
-constexpr uint32_t MFX_MAXP_LDS   = 1024;       // read counts whose (readK, prob) is tabulated in LDS
+#ifndef MFX_V_MAXP_LDS
+#define MFX_V_MAXP_LDS 1024
+#endif
+constexpr uint32_t MFX_MAXP_LDS   = MFX_V_MAXP_LDS;   // read counts whose (readK, prob) is tabulated in LDS (A/B: tools/ab_build.sh -DMFX_V_MAXP_LDS=256)
 constexpr uint32_t MFX_KLUT       = 32;         // (readK, asmK) pairs below this use tabulated bin index / over-copy term
 // placement functions of the table (mfx_kernels.hip: mfx_minimizer, mfx_mz_line, mfx_home); index images
 // written under another version are refused by mfx_index_load
