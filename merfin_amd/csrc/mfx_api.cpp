@@ -12,6 +12,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
+#include <sched.h>
+#include <pthread.h>
+#include <sys/syscall.h>
 
 #include <algorithm>
 #include <atomic>
@@ -1387,6 +1390,40 @@ void chunk_pieces(const mfx_seq *s, uint64_t t0, uint64_t t1, std::vector<Piece>
 
 extern "C" void mfx_pack_bases(const uint8_t *src, uint64_t n, uint64_t *codes, uint32_t *valid);      // mfx_pack.cpp
 
+// The CPUs of the NUMA node that holds `addr` (two-socket hosts: an encoder thread on the other socket reads the assembly over
+// the inter-socket links).  false: unknown (no such call in this container, one node, too few of its CPUs allowed) -- no binding.
+static bool cpus_near(const void *addr, cpu_set_t *out) {
+  const char *e = getenv("MFX_NUMA_BIND");
+  if (e && atoi(e) == 0) return false;
+  int node = -1;
+  if (syscall(SYS_get_mempolicy, &node, nullptr, 0UL, const_cast<void *>(addr), 3UL /* MPOL_F_NODE | MPOL_F_ADDR */) != 0 || node < 0) return false;
+  char path[96];
+  snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+  FILE *f = fopen(path, "r");
+  if (!f) return false;
+  char buf[4096];
+  const bool got = fgets(buf, sizeof(buf), f) != nullptr;
+  fclose(f);
+  if (!got) return false;
+  cpu_set_t allowed, near;
+  CPU_ZERO(&near);
+  if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return false;
+  for (char *p = buf; *p;) {                                  // "0-63,128-191"
+    char *q;
+    const long a = strtol(p, &q, 10);
+    if (q == p) break;
+    long b = a;
+    if (*q == '-') { p = q + 1; b = strtol(p, &q, 10); }
+    for (long c = a; c <= b && c < CPU_SETSIZE; ++c) if (CPU_ISSET(c, &allowed)) CPU_SET(c, &near);
+    p = *q == ',' ? q + 1 : q;
+    if (*q != ',' ) break;
+  }
+  if ((unsigned)CPU_COUNT(&near) < std::max(1u, mfx_host_threads())) return false;
+  if (CPU_COUNT(&near) == CPU_COUNT(&allowed)) return false;  // one node: nothing to choose
+  *out = near;
+  return true;
+}
+
 // The streamed -hist with the assembly crossing PCIe PACKED (0.375 B per base): host threads encode every chunk into
 // the tile form (2-bit codes + validity bits, csrc/mfx_pack.cpp) while the previous chunk is on the bus and the one
 // before is being evaluated; the kernel reads its tiles from the packed planes (mfx_tile_fill_packed).  One byte per
@@ -1461,7 +1498,10 @@ static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *cons
   if (ev->pool && static_cast<WorkerPool *>(ev->pool)->W != W) { delete static_cast<WorkerPool *>(ev->pool); ev->pool = nullptr; }
   if (!ev->pool) ev->pool = new WorkerPool(W);
   uint8_t *const *stage = ev->h_pack;
+  cpu_set_t near_cpus;
+  const bool bind = seq->ncontigs && bases[0] && cpus_near(bases[0], &near_cpus);      // the encoders run next to the memory they read
   auto work = [&, W](unsigned w) {
+    if (bind) (void)pthread_setaffinity_np(pthread_self(), sizeof(near_cpus), &near_cpus);
     for (size_t ci = 0; ci < chunks.size(); ++ci) {
       while (allowed.load(std::memory_order_acquire) < (int64_t)ci) {
         if (stop.load()) return;
