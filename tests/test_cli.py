@@ -406,3 +406,26 @@ def test_cli_index_cache_of_a_sequence_only_index(tmp_path, golden_dir):
     assert "rebuilding it" in r.stderr
     tot = lambda s: [l for l in s.splitlines() if l.startswith(("TOTAL", "COMPLETENESS"))]
     assert tot(r.stderr) == tot(ref.stderr) and len(tot(r.stderr)) == 3
+
+
+@pytest.mark.gpu
+def test_cli_convert_then_hist_equals_hist_from_the_text(tmp_path):
+    """`merfin -convert` of a `meryl print` text gives a flat database (sorted: delta-coded, decoded by the inserting kernel) that
+    answers -hist and -dump exactly as the text does -- which is what the oracle says"""
+    k, peak = 21, 17.3
+    contigs, read, asm = synth.world(k=k, peak=peak, seed=77, sizes=(20000, 5000, 300))
+    p = po.Params(k, peak)
+    g, ka, km, _ = po.hist_run(p, po.Lookup(k, *read), po.Lookup(k, *asm), contigs, threads=2)
+    po.report_histogram(p, g, str(tmp_path / "o.hist"), None)
+    fa = str(tmp_path / "asm.fasta")
+    _write_fasta(fa, contigs)
+    _write_text_db(str(tmp_path / "read.txt"), k, *read)
+    r = run(["-convert", str(tmp_path / "read.txt"), "-output", str(tmp_path / "read.mfxk")])
+    assert r.returncode == 0 and "Wrote %d k-mers" % len(read[0]) in r.stderr, r.stderr
+    outs = []
+    for db in ("read.txt", "read.mfxk"):
+        o = str(tmp_path / (db + ".hist"))
+        r = run(["-hist", "-sequence", fa, "-readmers", str(tmp_path / db), "-peak", str(peak), "-output", o])
+        assert r.returncode == 0, r.stderr
+        outs.append(open(o, "rb").read())
+    assert outs[0] == outs[1] == (tmp_path / "o.hist").read_bytes()
