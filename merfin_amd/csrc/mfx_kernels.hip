@@ -293,6 +293,58 @@ __device__ __forceinline__ uint2 mfx_c_lookup(const mfx_table_view &c, uint64_t 
   return mfx_c_fields(c, key, (uint32_t)w);
 }
 
+// The same two lookups for the RARE endings of the evaluation kernel's probe (a saturated count; a k-mer beyond the first two of its
+// candidate lines, which the cooperative passes of the probe cover): one slot at a time, a handful of registers.  A kernel's register
+// allocation is set by its hungriest path however rarely it runs; the whole-line forms above hold 32 registers of slots in flight.
+__device__ __forceinline__ uint2 mfx_side_lookup_lean(const mfx_table_view &c, uint64_t key) {
+  const mfx_table_view t = mfx_side_view(c);
+  const mfx_probe pr = mfx_home(t, key);
+  for (uint32_t d = 0; d < MFX_MAX_LINES; ++d) {
+    const uint4 *ln = reinterpret_cast<const uint4 *>(t.slots + mfx_probe_line(t, pr, d) * MFX_SLOTS_LINE);
+    bool any_empty = false;
+#pragma unroll 1
+    for (uint32_t q = 0; q < MFX_SLOTS_LINE; ++q) {
+      const uint4 s = ln[q];
+      const uint64_t sk = (uint64_t)s.x | ((uint64_t)s.y << 32);
+      if (sk == key) return make_uint2(s.z, s.w);
+      any_empty |= sk == MFX_EMPTY;
+    }
+    if (any_empty) break;
+  }
+  return make_uint2(0u, 0u);
+}
+
+// (found, the slot's low word) of `key` from candidate line d0 on
+__device__ __forceinline__ uint2 mfx_c_find_lean(const mfx_table_view &c, uint64_t key, uint32_t d0) {
+  const mfx_probe pr = mfx_home(c, key);
+  for (uint32_t d = d0; d < MFX_MAX_LINES; ++d) {
+    const uint4 *ln = reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned long long *>(c.slots) + mfx_probe_line(c, pr, d) * MFX_CSLOTS_LINE);
+    bool any_empty = false;
+#pragma unroll 1
+    for (uint32_t q = 0; q < MFX_CSLOTS_LINE / 2; ++q) {
+      const uint4 s = ln[q];
+      const uint64_t x = (uint64_t)s.x | ((uint64_t)s.y << 32), y = (uint64_t)s.z | ((uint64_t)s.w << 32);
+      if (x != MFX_EMPTY && (x >> 22) == key) return make_uint2(1u, s.x);
+      if (y != MFX_EMPTY && (y >> 22) == key) return make_uint2(1u, s.z);
+      any_empty |= (x == MFX_EMPTY) || (y == MFX_EMPTY);
+    }
+    if (any_empty) break;
+  }
+  return make_uint2(0u, 0u);
+}
+
+// the pair of a found compact slot from its low word, saturated fields from the side table (mfx_c_fields, lean)
+__device__ __forceinline__ uint2 mfx_c_fields_lean(const mfx_table_view &c, uint64_t key, uint32_t lo) {
+  uint32_t rv = (lo >> 11) & MFX_CSAT, av = lo & MFX_CSAT;
+  if (rv == MFX_CSAT || av == MFX_CSAT) {
+    const uint2 x = mfx_side_lookup_lean(c, key);
+    if (rv == MFX_CSAT) rv = x.x;
+    if (av == MFX_CSAT) av = x.y;
+  }
+  if (rv < c.minV || rv > c.maxV) rv = 0;                      // -min / -max (merfin.C:199-200)
+  return make_uint2(rv, av);
+}
+
 // Where in its line a k-mer goes: the line is eight MINI-BUCKETS of two slots (16 bytes: one dwordx4 of one lane); a
 // k-mer's slots are tried from mini-bucket mfx_c_first(key) on, around the line, then on through the candidate lines.
 // At the load factors this layout is built at (<= 0.5, 0.25 by default) 92 % of the k-mers sit in their first mini-bucket,
@@ -1151,48 +1203,76 @@ __device__ __forceinline__ void mfx_lane_lookup8(const mfx_table_view &c, mfx_ma
   if (nq) {                                                    // wave-uniform
     mfx_wave_handoff();
     if (nq > 64u) nq = 64u;
-    // up to MFX_TAIL_STEPS steps (8 queries each) per pass, their line loads in flight TOGETHER: a wave typically has ~20 such
-    // queries among its 256, i.e. three steps -- one round trip instead of three
+    // One pass over the wave's entries: 8 lanes per entry read its line (rec.z) with one coalesced request and answer into the
+    // record -- found: the slot's low word and the marker; an empty slot seen: "room".  Up to MFX_TAIL_STEPS steps (8 entries
+    // each) have their line loads in flight TOGETHER: a wave typically has ~25 displaced queries among its 256, i.e. four steps
+    // -- one round trip.  second: only the entries an owner flagged for their next candidate line (rec.w == 2).
     constexpr uint32_t MFX_TAIL_STEPS = 4;
-    for (uint32_t q0 = 0; q0 < nq; q0 += 8u * MFX_TAIL_STEPS) {
-      uint4 ent[MFX_TAIL_STEPS], sl[MFX_TAIL_STEPS];
+    auto tail_pass = [&](bool second) {
+      for (uint32_t q0 = 0; q0 < nq; q0 += 8u * MFX_TAIL_STEPS) {
+        uint4 sl[MFX_TAIL_STEPS];
+        bool act[MFX_TAIL_STEPS];
 #pragma unroll
-      for (uint32_t sp = 0; sp < MFX_TAIL_STEPS; ++sp) {
-        const uint32_t e = q0 + 8u * sp + (lane >> 3);
-        ent[sp] = M.rec[wbase + (e < nq ? e : 0u)];
-      }
-      mfx_wave_handoff();                                        // every lane of a group has its entries before one answers into them
+        for (uint32_t sp = 0; sp < MFX_TAIL_STEPS; ++sp) {
+          const uint32_t e = q0 + 8u * sp + (lane >> 3);
+          sl[sp] = make_uint4(0u, 0u, 0u, 0u);
+          act[sp] = false;
+          if (e < nq) {
+            const uint2 lw = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint32_t *>(&M.rec[wbase + e]) + 2);   // {line, flag}
+            act[sp] = !second || lw.y == 2u;
+            if (act[sp]) sl[sp] = *reinterpret_cast<const uint4 *>(reinterpret_cast<uint64_t>(c.slots) + ((uint64_t)lw.x << 7) + sub16);
+          }
+        }
+        mfx_wave_handoff();                                      // every lane has its entries' lines before one answers into a record
 #pragma unroll
-      for (uint32_t sp = 0; sp < MFX_TAIL_STEPS; ++sp) {
-        const uint32_t e = q0 + 8u * sp + (lane >> 3);
-        sl[sp] = make_uint4(0u, 0u, 0u, 0u);
-        if (e < nq) sl[sp] = *reinterpret_cast<const uint4 *>(reinterpret_cast<uint64_t>(c.slots) + ((uint64_t)ent[sp].z << 7) + sub16);
-      }
-#pragma unroll
-      for (uint32_t sp = 0; sp < MFX_TAIL_STEPS; ++sp) {
-        const uint32_t e = q0 + 8u * sp + (lane >> 3);
-        uint32_t *rec = reinterpret_cast<uint32_t *>(&M.rec[wbase + e]);
-        if (e < nq) {
-          if (sl[sp].y == 0xffffffffu || sl[sp].w == 0xffffffffu) rec[3] = 1u;               // an empty slot: the line has room
-          if (sl[sp].y == ent[sp].y && ((sl[sp].x ^ ent[sp].x) >> 22) == 0u) { rec[0] = sl[sp].x; rec[2] = 0xffffffffu; }    // found (marker: no line has this index)
-          else if (sl[sp].w == ent[sp].y && ((sl[sp].z ^ ent[sp].x) >> 22) == 0u) { rec[0] = sl[sp].z; rec[2] = 0xffffffffu; }
+        for (uint32_t sp = 0; sp < MFX_TAIL_STEPS; ++sp) {
+          const uint32_t e = q0 + 8u * sp + (lane >> 3);
+          if (act[sp]) {
+            uint32_t *rec = reinterpret_cast<uint32_t *>(&M.rec[wbase + e]);
+            const uint2 kk = *reinterpret_cast<const uint2 *>(rec);                          // the query's {key << 22} words (a finder of this group may have replaced word 0: same key bits)
+            if (sl[sp].y == 0xffffffffu || sl[sp].w == 0xffffffffu) rec[3] = 1u;               // an empty slot: the line has room
+            if (sl[sp].y == kk.y && ((sl[sp].x ^ kk.x) >> 22) == 0u) { rec[0] = sl[sp].x; rec[2] = 0xffffffffu; }    // found (marker: no line has this index)
+            else if (sl[sp].w == kk.y && ((sl[sp].z ^ kk.x) >> 22) == 0u) { rec[0] = sl[sp].z; rec[2] = 0xffffffffu; }
+          }
         }
       }
-    }
-    mfx_wave_handoff();
+      mfx_wave_handoff();
+    };
+    // what a pass left in the lane's own entries
+    auto collect = [&](uint32_t pending, uint32_t full_code) {
 #pragma unroll
-    for (int j = 0; j < B; ++j) {
-      if (st[j] != 1u) continue;
-      st[j] = 0xfcu;                                           // not served (more than 64 of them in this wave): whole-line scans from the home line
-      if (qpos[j] != 0xffffffffu) {
-        const uint4 r = M.rec[wbase + qpos[j]];
-        if (r.z == 0xffffffffu) {
-          const uint32_t r_rv = (r.x >> 11) & MFX_CSAT, r_av = r.x & MFX_CSAT;
-          if (r_rv == MFX_CSAT || r_av == MFX_CSAT) { rv[j] = r.x; st[j] = 0xfeu; }
-          else { rv[j] = (r_rv < c.minV || r_rv > c.maxV) ? 0u : r_rv; av[j] = r_av; st[j] = 0xffu; }
-        } else if (r.w == 1u) st[j] = 0xffu;                   // the home line has room and does not hold the key: absent
-        else st[j] = 0xfdu;                                    // the home line is full of other k-mers: the next candidate lines
+      for (int j = 0; j < B; ++j) {
+        if (st[j] != pending) continue;
+        st[j] = 0xfcu;                                         // not served (more than 64 of them in this wave): whole-line scans from the home line
+        if (qpos[j] != 0xffffffffu) {
+          const uint4 r = M.rec[wbase + qpos[j]];
+          if (r.z == 0xffffffffu) {
+            const uint32_t r_rv = (r.x >> 11) & MFX_CSAT, r_av = r.x & MFX_CSAT;
+            if (r_rv == MFX_CSAT || r_av == MFX_CSAT) { rv[j] = r.x; st[j] = 0xfeu; }
+            else { rv[j] = (r_rv < c.minV || r_rv > c.maxV) ? 0u : r_rv; av[j] = r_av; st[j] = 0xffu; }
+          } else if (r.w == 1u) st[j] = 0xffu;                 // the line has room and does not hold the key: absent
+          else st[j] = full_code;                              // the line is full of other k-mers
+        }
       }
+    };
+    tail_pass(false);
+    collect(1u, 2u);
+    // ---- the queries whose home line is full of other k-mers: their next candidate line, the same way (most waves have none)
+    bool again = false;
+#pragma unroll
+    for (int j = 0; j < B; ++j)
+      if (st[j] == 2u) {
+        uint32_t *rec = reinterpret_cast<uint32_t *>(&M.rec[wbase + qpos[j]]);
+        mfx_probe pr;
+        pr.lineA = pr.lineB = line[j];
+        rec[2] = (uint32_t)mfx_probe_line(c, pr, 1u);          // (candidate lines 0 .. MFX_MZ_REGION-1 follow the minimizer's line)
+        rec[3] = 2u;
+        again = true;
+      }
+    if (__any(again)) {
+      mfx_wave_handoff();
+      tail_pass(true);
+      collect(2u, 0xfdu);                                      // still not there and no room: whole-line scans from candidate line 2
     }
   }
   // ---- the rare endings, ONE instance of their code for all B queries of the lane: a saturated count field (the exact
@@ -1209,11 +1289,11 @@ __device__ __forceinline__ void mfx_lane_lookup8(const mfx_table_view &c, mfx_ma
       uint2 x = make_uint2(0u, 0u);
       bool have = scode == 0xfeu;
       if (!have) {
-        unsigned long long w = 0;
-        have = mfx_c_find(c, skey, mfx_home(c, skey), scode == 0xfdu ? 1u : 0u, w) != nullptr;
-        slo = (uint32_t)w;
+        const uint2 fd = mfx_c_find_lean(c, skey, scode == 0xfdu ? 2u : 0u);
+        have = fd.x != 0u;
+        slo = fd.y;
       }
-      if (have) x = mfx_c_fields(c, skey, slo);
+      if (have) x = mfx_c_fields_lean(c, skey, slo);
 #pragma unroll
       for (int j = 0; j < B; ++j)
         if (sj == j) { rv[j] = x.x; av[j] = x.y; st[j] = 0xffu; }
