@@ -527,19 +527,13 @@ int main(int argc, char **argv) {
   }
   if (!G.devices.empty()) G.device = G.devices[0];
   else G.devices.push_back(G.device);
-  // The HIP runtime takes 0.2 s to come up (hipInit: driver, topology).  It does so on its own thread while this one loads the
-  // K* table, probes the databases and starts the sequence reader; the devices are checked when that is done (check_devices).
-  std::thread hipUp([]() { (void)mfx_device_count(); });
-  struct HipJoiner { std::thread &t; ~HipJoiner() { if (t.joinable()) t.join(); } } hipJoiner{hipUp};
-  auto check_devices = [&]() -> bool {
-    if (hipUp.joinable()) hipUp.join();
-    for (int d : G.devices)
-      if (mfx_device_count() <= d) {
-        fprintf(stderr, "ERROR: HIP device %d not available (%d visible). This program has no CPU path.\n", d, mfx_device_count());
-        return false;
-      }
-    return true;
-  };
+  // (the device check stays on this thread, before anything else is started: the HIP runtime coming up on a thread of its own
+  // while this one spawns a decompressor for -sequence was seen to come up with no device)
+  for (int d : G.devices)
+    if (mfx_device_count() <= d) {
+      fprintf(stderr, "ERROR: HIP device %d not available (%d visible). This program has no CPU path.\n", d, mfx_device_count());
+      return 1;
+    }
 
   // MFX_CLI_TIMING=1: wall time per phase on stderr at exit (diagnostics; not part of merfin's output)
   const bool timing = getenv("MFX_CLI_TIMING") && atoi(getenv("MFX_CLI_TIMING"));
@@ -600,7 +594,6 @@ int main(int argc, char **argv) {
       seqReadFailed = sf->finish() != 0;      // a decompressor that died mid-stream: the records read so far are NOT the file
     });
   }
-  if (!check_devices()) return 1;
   bool seqDone = false;
   auto finish_seq = [&]() {
     if (seqDone) return;
