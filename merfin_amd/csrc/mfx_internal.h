@@ -58,7 +58,7 @@ constexpr uint32_t MFX_MAXP_LDS   = MFX_V_MAXP_LDS;   // read counts whose (read
 constexpr uint32_t MFX_KLUT       = 32;         // (readK, asmK) pairs below this use tabulated bin index / over-copy term
 // placement functions of the table (mfx_kernels.hip: mfx_minimizer, mfx_mz_line, mfx_home); index images
 // written under another version are refused by mfx_index_load
-constexpr uint32_t MFX_LAYOUT_VERSION = 6u;
+constexpr uint32_t MFX_LAYOUT_VERSION = 7u;
 constexpr uint32_t MFX_SPLIT_MAX_RANKS = 16;  // owners the sort-free router handles (a node has 8 GPUs); more: radix sort
 constexpr int      MFX_MZ_W_DEFAULT = 3;        // minimizer windows of the default placement (MFX_MZ_W overrides)
 constexpr uint32_t MFX_OVF_CAP    = 1u << 20;   // histogram overflow records per evaluator

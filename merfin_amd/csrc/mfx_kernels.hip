@@ -52,6 +52,7 @@ constexpr uint32_t MFX_MAX_LINES = 512;
 
 struct mfx_probe {
   uint32_t lineA, lineB;
+  uint32_t b0;                 // compact layout: the mini-bucket of the line the k-mer's slots are tried from (mfx_home)
 };
 
 // Canonical minimizer of a k-mer: of its w windows of m = k-w+1 bases, the canonical m-mer
@@ -90,9 +91,10 @@ __device__ __forceinline__ uint64_t mfx_minimizer(uint64_t key, uint64_t rc, int
 // by the evaluation kernel, which finds the same offsets for a whole wave at once (mfx_wave_mod_lines).
 __device__ __forceinline__ uint32_t mfx_tmer_order(uint32_t canonical_tmer) { return ((canonical_tmer * 0x9E3779B1u) >> 7) & 511u; }
 
-__device__ __forceinline__ uint64_t mfx_minimizer_mod(uint64_t key, uint64_t rc, int k, int w, int t) {
+__device__ __forceinline__ uint64_t mfx_minimizer_mod(uint64_t key, uint64_t rc, int k, int w, int t, uint32_t &x) {
   const uint32_t tmask = (1u << (2 * t)) - 1u;
-  uint32_t best = 0xffffffffu, x = 0;
+  uint32_t best = 0xffffffffu;
+  x = 0;
   for (int p = 0; p + t <= k; ++p) {                           // p: offset from the left (the most significant base)
     const uint32_t a = (uint32_t)(key >> (2 * (k - t - p))) & tmask, b = (uint32_t)(rc >> (2 * p)) & tmask;   // the t-mer and its reverse complement
     const uint32_t o = mfx_tmer_order(a < b ? a : b);
@@ -104,16 +106,16 @@ __device__ __forceinline__ uint64_t mfx_minimizer_mod(uint64_t key, uint64_t rc,
   return a < b ? a : b;
 }
 
-// line of a mod-minimizer (an m-mer of at most 36 bits: the compact layout holds k <= 21): two 32-bit multiplications fold the
-// halves, a third scales into the table -- a third of the instructions of the 64-bit product below, in the kernel that is
-// bound by instruction issue
-__device__ __forceinline__ uint32_t mfx_mod_line_of(uint64_t mz, uint64_t nlines) {
-#ifdef MFX_V_MODHASH64                                         // A/B (tools/ab_build.sh): the 64-bit product of the other layouts
-  return mfx_range32(mz * 0xD6E8FEB86659FD93ULL, nlines);
-#else
+// Line and first mini-bucket of a mod-minimizer (an m-mer of at most 36 bits: the compact layout holds k <= 21) sampled by the
+// t-mer at offset x of the (canonical) k-mer.  Line: two 32-bit multiplications fold the halves, a third scales into the table -- a
+// third of the instructions of the 64-bit product below.  Mini-bucket: (x + three other bits of the hash) mod 8 -- the k-mers that
+// share a minimizer sit at consecutive positions and see its t-mer at DIFFERENT offsets, so they start at different mini-buckets of
+// their common line instead of colliding at random: 3.1 % of the k-mers of a random sequence end outside their first mini-bucket at load
+// factor 0.225 where a hash of the k-mer left 8.3 %.
+__device__ __forceinline__ void mfx_mod_place(uint64_t mz, uint32_t x, uint64_t nlines, uint32_t &line, uint32_t &b0) {
   const uint32_t h = ((uint32_t)mz * 0x9E3779B1u) ^ (((uint32_t)(mz >> 32) + 0x7F4A7C15u) * 0x85EBCA77u);
-  return __umulhi(h ^ (h >> 15), (uint32_t)nlines);
-#endif
+  line = __umulhi(h ^ (h >> 15), (uint32_t)nlines);
+  b0 = (x + h) & 7u;
 }
 
 // line of a k-mer's minimizer: one odd 64-bit multiplication (the high half of the product
@@ -121,8 +123,21 @@ __device__ __forceinline__ uint32_t mfx_mod_line_of(uint64_t mz, uint64_t nlines
 // be unrelated to the order hash's: the minimizer is the window with the SMALLEST order hash,
 // so a line hash correlated with it would crowd the low lines.
 __device__ __forceinline__ uint32_t mfx_mz_line(const mfx_table_view &t, uint64_t key, uint64_t krc) {
-  if (t.mz_t) return mfx_mod_line_of(mfx_minimizer_mod(key, krc, t.k, t.mz_w, t.mz_t), t.nlines);
+  if (t.mz_t) {
+    uint32_t x, line, b0;
+    const uint64_t mz = mfx_minimizer_mod(key, krc, t.k, t.mz_w, t.mz_t, x);
+    mfx_mod_place(mz, x, t.nlines, line, b0);
+    return line;
+  }
   return mfx_range32(mfx_minimizer(key, krc, t.k, t.mz_w) * 0xD6E8FEB86659FD93ULL, t.nlines);
+}
+
+// first mini-bucket of a compact line by a hash of the k-mer (the compact layout without the mod-minimizer placement)
+__device__ __forceinline__ uint32_t mfx_c_first(uint64_t key) {
+  uint32_t x = (uint32_t)key ^ (uint32_t)(key >> 32);
+  x ^= x >> 15;
+  x ^= x >> 7;
+  return (x ^ (x >> 3)) & 7u;
 }
 
 __device__ __forceinline__ mfx_probe mfx_home(const mfx_table_view &t, uint64_t key) {
@@ -130,8 +145,16 @@ __device__ __forceinline__ mfx_probe mfx_home(const mfx_table_view &t, uint64_t 
   uint64_t h = mfx_hash64(key);
   pr.lineB = mfx_range32(h, t.nlines);
   pr.lineA = pr.lineB;
+  pr.b0 = 0u;
+  if (t.mz_t) {                                                // compact layout, mod-minimizer: line and first mini-bucket together
+    uint32_t x;
+    const uint64_t mz = mfx_minimizer_mod(key, mfx_revcomp(key, t.k), t.k, t.mz_w, t.mz_t, x);
+    mfx_mod_place(mz, x, t.nlines, pr.lineA, pr.b0);
+    return pr;
+  }
   if (t.mz_w > 0)
     pr.lineA = mfx_mz_line(t, key, mfx_revcomp(key, t.k));
+  if (t.compact) pr.b0 = mfx_c_first(key);
   return pr;
 }
 
@@ -352,12 +375,6 @@ __device__ __forceinline__ uint2 mfx_c_fields_lean(const mfx_table_view &c, uint
 // their minimizer's line, make those loads fall into the same 128-byte lines.  A lookup stops at the key or at the first
 // empty slot of its own order; scanning a WHOLE line (mfx_c_find, the cooperative probe) may stop at any empty slot: the
 // k-mer's order visits every slot of a line before it leaves it.
-__device__ __forceinline__ uint32_t mfx_c_first(uint64_t key) {
-  uint32_t x = (uint32_t)key ^ (uint32_t)(key >> 32);
-  x ^= x >> 15;
-  x ^= x >> 7;
-  return (x ^ (x >> 3)) & 7u;
-}
 
 // find-or-claim the slot of `key` (mfx_claim for 8-byte slots): a k-mer takes the first empty slot of its order, a slot
 // never changes its key once written.  cur = the slot's word as seen (a fresh claim: the key with both counts 0).
@@ -369,7 +386,7 @@ __device__ __forceinline__ unsigned long long *mfx_c_claim(const mfx_table_view 
   unsigned long long *cs = reinterpret_cast<unsigned long long *>(c.slots);
   const unsigned long long mine = ((unsigned long long)key << 22) | init;
   claimed = false;
-  const uint32_t q0 = 2u * mfx_c_first(key);
+  const uint32_t q0 = 2u * pr.b0;
   // A mini-bucket is read by ONE plain 16-byte load.  It may come from this CU's L1 and be older than the table: a slot
   // seen occupied stays what it is (a slot never changes its key once written), a slot seen empty is taken by compare-and-
   // swap, whose answer is the truth -- the claim, the k-mer itself (another lane claimed it first), or another key (on).
@@ -625,8 +642,8 @@ __device__ __forceinline__ void mfx_apply_batch(const mfx_table_view &t, uint64_
 #pragma unroll
     for (int j = 0; j < UB; ++j) {
       if (v[j] && key[j] > mfx_revcomp(key[j], t.k)) { ++T.noncanon; v[j] = 0u; }
-      mb[j] = reinterpret_cast<unsigned long long *>(t.slots) + mfx_probe_line(t, mfx_home(t, key[j]), 0) * MFX_CSLOTS_LINE +
-              2u * mfx_c_first(key[j]);
+      const mfx_probe pr = mfx_home(t, key[j]);
+      mb[j] = reinterpret_cast<unsigned long long *>(t.slots) + mfx_probe_line(t, pr, 0) * MFX_CSLOTS_LINE + 2u * pr.b0;
       s[j] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
       if (v[j]) s[j] = *reinterpret_cast<const uint4 *>(mb[j]);
     }
@@ -1152,7 +1169,8 @@ __device__ __forceinline__ void mfx_group_lookup8(const mfx_table_view &c, mfx_m
 // pre: the queries' home lines if the caller has them already (mfx_wave_mod_lines), else nullptr
 template <int B>
 __device__ __forceinline__ void mfx_lane_lookup8(const mfx_table_view &c, mfx_mailbox &M, const uint64_t (&key)[B], const uint64_t (&krc)[B],
-                                                 const bool (&ok)[B], uint32_t (&rv)[B], uint32_t (&av)[B], const uint32_t *pre = nullptr) {
+                                                 const bool (&ok)[B], uint32_t (&rv)[B], uint32_t (&av)[B], const uint32_t *pre = nullptr,
+                                                 const uint32_t *pre_b0 = nullptr) {
   const uint32_t tid = threadIdx.x, sub16 = (tid & 7u) << 4, lane = tid & 63u, wbase = tid & ~63u;
   const uint4 *const slots0 = reinterpret_cast<const uint4 *>(c.slots);
   uint32_t line[B];
@@ -1162,8 +1180,13 @@ __device__ __forceinline__ void mfx_lane_lookup8(const mfx_table_view &c, mfx_ma
   // ---- first mini-bucket of every query: one 16-byte load per lane and query, all B in flight
 #pragma unroll
   for (int j = 0; j < B; ++j) {
-    line[j] = !ok[j] ? 0u : pre ? pre[j] : mfx_first_line(c, key[j], krc[j]);  // no k-mer here: a dummy load of line 0, ignored below
-    v[j] = slots0[((uint64_t)line[j] << 3) | mfx_c_first(key[j])];
+    uint32_t b0 = 0u;
+    line[j] = 0u;                                              // no k-mer here: a dummy load of line 0, ignored below
+    if (ok[j]) {
+      if (pre) { line[j] = pre[j]; b0 = pre_b0[j]; }
+      else { const mfx_probe pr = mfx_home(c, key[j]); line[j] = pr.lineA; b0 = pr.b0; }
+    }
+    v[j] = slots0[((uint64_t)line[j] << 3) | b0];
   }
 #pragma unroll
   for (int j = 0; j < B; ++j) {
@@ -1306,10 +1329,10 @@ __device__ __forceinline__ void mfx_lane_lookup8(const mfx_table_view &c, mfx_ma
 #endif
 #if MFX_V_LANEPROBE
 #define MFX_COMPACT_LOOKUP(t, MB, key, krc, ok, rv, av) mfx_lane_lookup8<MFX_BATCH>(t, MB, key, krc, ok, rv, av)
-#define MFX_COMPACT_LOOKUP_PRE(t, MB, key, krc, ok, rv, av, pre) mfx_lane_lookup8<MFX_BATCH>(t, MB, key, krc, ok, rv, av, pre)
+#define MFX_COMPACT_LOOKUP_PRE(t, MB, key, krc, ok, rv, av, pre, pb0) mfx_lane_lookup8<MFX_BATCH>(t, MB, key, krc, ok, rv, av, pre, pb0)
 #else
 #define MFX_COMPACT_LOOKUP(t, MB, key, krc, ok, rv, av) mfx_group_lookup8<MFX_BATCH>(t, MB, key, krc, ok, rv, av)
-#define MFX_COMPACT_LOOKUP_PRE(t, MB, key, krc, ok, rv, av, pre) mfx_group_lookup8<MFX_BATCH>(t, MB, key, krc, ok, rv, av)
+#define MFX_COMPACT_LOOKUP_PRE(t, MB, key, krc, ok, rv, av, pre, pb0) mfx_group_lookup8<MFX_BATCH>(t, MB, key, krc, ok, rv, av)
 #endif
 
 // k-mer starting at tile position p; returns validity (all k bases ACGT)
@@ -1365,7 +1388,7 @@ __device__ __forceinline__ uint32_t mfx_wave_mod_halo(const mfx_table_view &c, c
 // this wave (the mailbox of the lookup, idle at this point): the wave's values are written side by side and every lane takes
 // the minimum of the npos words from its own on -- 16 plain LDS reads and 15 packed minima; a doubling scheme over cross-lane
 // reads (4 x 2 ds_bpermute, the second for the positions behind the wave) cost twice the instructions.
-__device__ __forceinline__ uint32_t mfx_wave_mod_line(const mfx_table_view &c, uint32_t *mw, uint32_t halo, int j, uint64_t f, uint64_t r) {
+__device__ __forceinline__ uint32_t mfx_wave_mod_line(const mfx_table_view &c, uint32_t *mw, uint32_t halo, int j, uint64_t f, uint64_t r, uint32_t &b0) {
   const int k = c.k, t = c.mz_t, w = c.mz_w, m = k - w + 1, npos = k - t + 1;
   const uint32_t lane = threadIdx.x & 63u, tmask = (1u << (2 * t)) - 1u;
   const uint64_t mmask = (~0ULL) >> (64 - 2 * m);
@@ -1379,10 +1402,13 @@ __device__ __forceinline__ uint32_t mfx_wave_mod_line(const mfx_table_view &c, u
 #pragma unroll
   for (int i = 0; i < 16; ++i)
     if (i < npos) v = mfx_pk_min_u16(v, mw[lane + (uint32_t)i]);
-  const uint32_t q = f <= r ? (v & 127u) : 127u - ((v >> 16) & 127u);
-  const uint32_t jf = (q - lane) % (uint32_t)w;               // the window, counted on the forward strand
+  const bool fwd = f <= r;
+  const uint32_t q = fwd ? (v & 127u) : 127u - ((v >> 16) & 127u);
+  const uint32_t xf = q - lane, jf = xf % (uint32_t)w;        // the t-mer's offset and the window, counted on the forward strand
   const uint64_t ma = (f >> (2 * ((uint32_t)w - 1u - jf))) & mmask, mb = (r >> (2 * jf)) & mmask;
-  return mfx_mod_line_of(ma < mb ? ma : mb, c.nlines);
+  uint32_t line;
+  mfx_mod_place(ma < mb ? ma : mb, fwd ? xf : (uint32_t)(k - t) - xf, c.nlines, line, b0);    // the offset in the canonical k-mer
+  return line;
 }
 
 // ===========================================================================
@@ -1469,7 +1495,7 @@ __global__ __launch_bounds__(MFX_BLOCK, MFX_V_MINBLOCKS) void mfx_hist_kernel(mf
     for (uint32_t b = 0; b < MFX_TILE / MFX_BLOCK; b += MFX_BATCH) {
       if (b * MFX_BLOCK >= n) break;         // short last tile of a contig (block-uniform): nothing starts beyond n
       uint64_t key[MFX_BATCH], key2[MFX_BATCH];
-      uint32_t rv[MFX_BATCH], av[MFX_BATCH], pre[MFX_BATCH];
+      uint32_t rv[MFX_BATCH], av[MFX_BATCH], pre[MFX_BATCH], pb0[MFX_BATCH];
       bool     ok[MFX_BATCH];
       // mod-minimizer placement: the wave finds its home lines together (mfx_wave_mod_line)
       const bool wave_lines = COMPACT && CANON && (KF ? TF != 0 : a.t.mz_t != 0);
@@ -1480,14 +1506,15 @@ __global__ __launch_bounds__(MFX_BLOCK, MFX_V_MINBLOCKS) void mfx_hist_kernel(mf
         uint64_t f;
         ok[j] = mfx_tile_kmer(L, k, p, f) && (p < n);
         uint64_t r = mfx_revcomp(f, k);
-        pre[j] = wave_lines ? mfx_wave_mod_line(a.t, reinterpret_cast<uint32_t *>(&MB.rec[tid & ~63u]), halo, j, f, r) : 0u;
+        pb0[j] = 0u;
+        pre[j] = wave_lines ? mfx_wave_mod_line(a.t, reinterpret_cast<uint32_t *>(&MB.rec[tid & ~63u]), halo, j, f, r, pb0[j]) : 0u;
         if (CANON) {
           key[j] = f < r ? f : r; key2[j] = f < r ? r : f;     // canonical k-mer and its reverse complement
         } else {
           key[j] = f; key2[j] = r;
         }
       }
-      if (wave_lines) MFX_COMPACT_LOOKUP_PRE(a.t, MB, key, key2, ok, rv, av, pre);
+      if (wave_lines) MFX_COMPACT_LOOKUP_PRE(a.t, MB, key, key2, ok, rv, av, pre, pb0);
       else if (COMPACT) MFX_COMPACT_LOOKUP(a.t, MB, key, key2, ok, rv, av);
       else mfx_group_lookup<MFX_BATCH>(a.t, MB, key, key2, ok, rv, av);
       if (!CANON) {
