@@ -650,7 +650,11 @@ int main(int argc, char **argv) {
   };
   if (!deferSeq && !make_seq()) DIE_MFX("uploading sequences");
   FILE *probe = G.indexName ? fopen(G.indexName, "rb") : nullptr;
-  const uint64_t fingerprint = G.indexName ? input_fingerprint(G, seqOnly) : 0;
+  uint64_t fingerprint = G.indexName ? input_fingerprint(G, seqOnly) : 0;
+  // a run that would build the sequence-only index also accepts a FULL image of the same inputs: that is what such a run
+  // saved when a database turned out not to be canonical (the fallback below) -- without this every later run would
+  // build twice again and the cache would never take effect
+  const uint64_t fingerprintFull = (G.indexName && seqOnly) ? input_fingerprint(G, false) : fingerprint;
   if (probe) {
     fclose(probe);
     fprintf(stderr, "-- Loading the index image '%s' (k-mer databases are not read).\n", G.indexName);
@@ -661,7 +665,10 @@ int main(int argc, char **argv) {
     if (info.k != k) { fprintf(stderr, "ERROR: the index image holds %d-mers but -readmers holds %d-mers.\n", info.k, k); return 1; }
     uint64_t fp = 0, imin = 0, imax = 0;
     if (mfx_index_get_origin(ix, &fp, &imin, &imax)) DIE_MFX("reading the index image");
-    if (fp != fingerprint || imin != G.minV || imax != G.maxV || (info.seq_only != 0) != seqOnly) {
+    if (seqOnly && info.seq_only == 0 && fp == fingerprintFull && imin == G.minV && imax == G.maxV) {
+      seqOnly = false;                                              // the full tables of these inputs (a non-canonical database)
+      fingerprint = fingerprintFull;
+    } else if (fp != fingerprint || imin != G.minV || imax != G.maxV || (info.seq_only != 0) != seqOnly) {
       // the image was built from other inputs (a re-polished -sequence, another database, other -min/-max):
       // using it would give wrong asmK / readK with no diagnostic
       fprintf(stderr, "-- The index image '%s' was built from other inputs (%s); rebuilding it.\n", G.indexName,
@@ -708,6 +715,7 @@ int main(int argc, char **argv) {
       mfx_index_free(ix);
       ix = nullptr;
       seqOnly = false;
+      fingerprint = fingerprintFull;                                // what is saved below is the full index of these inputs
     } else if (G.indexName) {
       fprintf(stderr, "-- Writing the index image '%s'.\n", G.indexName);
       if (mfx_index_set_fingerprint(ix, fingerprint) || mfx_index_save(ix, G.indexName)) DIE_MFX("writing the index image");

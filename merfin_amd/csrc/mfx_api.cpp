@@ -337,8 +337,8 @@ static mfx_index *index_create(int k, uint64_t capacity_kmers, double max_gb, in
     delete ix;
     return nullptr;
   }
-  if (hipMalloc((void **)&ix->d_meta, 4 * sizeof(uint64_t)) != hipSuccess ||
-      hipMemset(ix->d_meta, 0, 4 * sizeof(uint64_t)) != hipSuccess ||
+  if (hipMalloc((void **)&ix->d_meta, MFX_META_WORDS * sizeof(uint64_t)) != hipSuccess ||
+      hipMemset(ix->d_meta, 0, MFX_META_WORDS * sizeof(uint64_t)) != hipSuccess ||
       (ix->wide() ? hipMemsetAsync(ix->d_slots, 0, ix->nlines * MFX_ALIGN, nullptr)           // state 0 = empty
        : ix->compact ? hipMemsetAsync(ix->d_slots, 0xff, ix->nlines * MFX_ALIGN, nullptr)      // 8-byte slots: the all-ones word is empty
                      : mfx_k_table_init(ix->d_slots, ix->nlines * MFX_SLOTS_LINE, nullptr)) != hipSuccess ||
@@ -362,8 +362,11 @@ extern "C" void mfx_index_free(mfx_index *ix) {
 
 static int index_check(mfx_index *ix) {
   ix->version++;
-  uint64_t meta[4];
+  uint64_t meta[5];
   MFX_HIP(hipMemcpy(meta, ix->d_meta, sizeof(meta), hipMemcpyDeviceToHost));
+  if (meta[4] != 0)
+    return mfx_fail(MFX_E_FORMAT, "the database holds %lu records wider than 2k = %d bits: damaged or not a %d-mer database (none was inserted)",
+                    (unsigned long)meta[4], 2 * ix->k, ix->k);
   if (meta[2] != 0)
     return mfx_fail(MFX_E_FULL, "k-mer table full: %lu inserts hit the probe limit (capacity %lu k-mers, %lu stored)",
                     (unsigned long)meta[2], (unsigned long)ix->capacity_kmers, (unsigned long)meta[0]);
@@ -715,6 +718,8 @@ static int index_count(mfx_index *ix, const mfx_seq *seq, int count, void *strea
   a.count = count;
   MFX_HIP(ix->wide() ? mfx_kw_count(a, (hipStream_t)stream) : mfx_k_count(a, (hipStream_t)stream));
   MFX_HIP(hipStreamSynchronize((hipStream_t)stream));
+  if (ix->seq_only)                                            // what this table can answer for: the k-mers of THIS sequence
+    if (int drc = mfx_seq_digest32(seq, &ix->seq_digest)) return drc;
   return index_check(ix);
 }
 
@@ -837,6 +842,41 @@ int mfx_seq_ensure_ascii(const mfx_seq *cs) {
   MFX_HIP(mfx_k_unpack(s->d_codes, s->d_valid, s->d_bases, s->buf_bytes / 32, nullptr));
   MFX_HIP(hipDeviceSynchronize());
   s->bases_stale = false;
+  return MFX_OK;
+}
+
+// h: the device's sum over the words (mfx_seq_digest_kernel)
+static void seq_digest_finish(const mfx_seq *s, uint64_t h) {
+  for (uint32_t c = 0; c < s->ncontigs; ++c) h = (h ^ s->len[c]) * 0x100000001B3ULL + c;       // the contig structure
+  const uint32_t f = (uint32_t)(h ^ (h >> 32));
+  s->digest = f ? f : 1u;
+}
+
+int mfx_seq_digest32(const mfx_seq *s, uint32_t *out) {
+  if (s->digest == 0) {
+    DevGuard g(s->device);
+    uint64_t *d = nullptr, h = 0;
+    MFX_HIP(hipMalloc((void **)&d, sizeof(uint64_t)));
+    hipError_t e = hipMemset(d, 0, sizeof(uint64_t));
+    const bool planes = s->planes_ok || s->bases_stale;
+    if (e == hipSuccess) e = mfx_k_seq_digest(s->d_bases, planes ? s->d_codes : nullptr, planes ? s->d_valid : nullptr, s->buf_bytes / 32, d, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(&h, d, sizeof(h), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return mfx_fail(MFX_E_HIP, "sequence digest failed: %s", hipGetErrorString(e));
+    seq_digest_finish(s, h);
+  }
+  *out = s->digest;
+  return MFX_OK;
+}
+
+int mfx_check_seq_of_index(const mfx_index *ix, const mfx_seq *s, const char *who) {
+  if (!ix->seq_only || ix->seq_digest == 0) return MFX_OK;
+  uint32_t d = 0;
+  if (int rc = mfx_seq_digest32(s, &d)) return rc;
+  if (d != ix->seq_digest)
+    return mfx_fail(MFX_E_INVAL, "%s: this sequence-only index holds the k-mers of ANOTHER sequence (content digest %08x, this one %08x): "
+                    "k-mers it never claimed would read as absent; build the index from this sequence (mfx_index_create_for_seq + "
+                    "mfx_index_count_asm / mfx_index_claim_seq) or use a full index", who, ix->seq_digest, d);
   return MFX_OK;
 }
 
@@ -1115,6 +1155,10 @@ static int hist_launch(mfx_eval *ev, const mfx_seq *seq, uint64_t tile_begin, ui
   int canon = 0;
   int rc = eval_canonical(ev, &canon);
   if (rc) return rc;
+  if (!chunk_of_total) {                                     // (a streamed run checks once its upload is complete)
+    rc = mfx_check_seq_of_index(ev->ix, seq, "-hist");
+    if (rc) return rc;
+  }
   const char *force = getenv("MFX_FORCE_TWO_STRAND");
   if (force && atoi(force)) canon = 0;
   if (!chunk_of_total) {
@@ -1274,10 +1318,10 @@ static int eval_run_resources(mfx_eval *ev, size_t words) {
     if (R.h_img) (void)hipHostFree(R.h_img);
     R.d_counts = nullptr; R.h_img = nullptr; R.words = 0;
     MFX_HIP(hipMalloc((void **)&R.d_counts, words * sizeof(uint64_t)));
-    MFX_HIP(hipHostMalloc((void **)&R.h_img, (words + 1) * sizeof(uint64_t), hipHostMallocDefault));
+    MFX_HIP(hipHostMalloc((void **)&R.h_img, (words + 2) * sizeof(uint64_t), hipHostMallocDefault));
     R.words = words;
   }
-  if (!R.d_kover) MFX_HIP(hipMalloc((void **)&R.d_kover, sizeof(double)));
+  if (!R.d_kover) MFX_HIP(hipMalloc((void **)&R.d_kover, 2 * sizeof(double)));          // ([1]: hist_run_streamed_packed's digest word)
   for (auto &k : R.kern) if (!k) MFX_HIP(hipStreamCreateWithFlags(&k, hipStreamNonBlocking));
   return MFX_OK;
 }
@@ -1492,6 +1536,7 @@ static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *cons
     if (!ev->h_pack[b]) STREAMED_HIP(hipHostMalloc((void **)&ev->h_pack[b], STAGE_W * 12, hipHostMallocDefault));
   seq->bases_stale = true;
   seq->planes_ok = true;
+  seq->digest = 0;                                           // new content
 
   // the packers: worker w encodes its share of the words of every chunk, in chunk order
   const unsigned W = std::max(1u, std::min(mfx_host_threads(), 64u));
@@ -1533,10 +1578,10 @@ static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *cons
     if (R.h_img) (void)hipHostFree(R.h_img);
     R.d_counts = nullptr; R.h_img = nullptr; R.words = 0;
     STREAMED_HIP(hipMalloc((void **)&R.d_counts, words * sizeof(uint64_t)));
-    STREAMED_HIP(hipHostMalloc((void **)&R.h_img, (words + 1) * sizeof(uint64_t), hipHostMallocDefault));
+    STREAMED_HIP(hipHostMalloc((void **)&R.h_img, (words + 2) * sizeof(uint64_t), hipHostMallocDefault));
     R.words = words;
   }
-  if (!R.d_kover) STREAMED_HIP(hipMalloc((void **)&R.d_kover, sizeof(double)));
+  if (!R.d_kover) STREAMED_HIP(hipMalloc((void **)&R.d_kover, 2 * sizeof(double)));    // [1]: the uploaded sequence's content digest (a uint64)
   if (!R.copy) STREAMED_HIP(hipStreamCreateWithFlags(&R.copy, hipStreamNonBlocking));
   for (auto &k : R.kern) if (!k) STREAMED_HIP(hipStreamCreateWithFlags(&k, hipStreamNonBlocking));
   for (auto &e : R.up) if (!e) STREAMED_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1576,14 +1621,28 @@ static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *cons
     if (rc) { cleanup(); return rc; }
   }
   t_mark[2] = now();
+  // a sequence-only index answers for the k-mers of ONE sequence: the content digest of what was just uploaded is taken on
+  // the copy stream, behind the last chunk and under the last launches, and compared before the result is handed out
+  const bool want_digest = ev->ix->seq_only && ev->ix->seq_digest != 0;
+  if (want_digest) {
+    uint64_t *d_dig = reinterpret_cast<uint64_t *>(d_kover + 1);
+    STREAMED_HIP(hipMemsetAsync(d_dig, 0, sizeof(uint64_t), cs));
+    STREAMED_HIP(mfx_k_seq_digest(nullptr, seq->d_codes, seq->d_valid, seq->buf_bytes / 32, d_dig, cs));
+    STREAMED_HIP(hipMemcpyAsync(h_img + words + 1, d_dig, sizeof(uint64_t), hipMemcpyDeviceToHost, cs));
+  }
   STREAMED_HIP(hipEventRecord(R.kdone, R.kern[1]));
   STREAMED_HIP(hipStreamWaitEvent(ks, R.kdone, 0));
   if (T) STREAMED_HIP(mfx_k_sum_tile_partials(ev->d_tile_partials, T, d_kover, ev->d_tile_ctr, ks));
   STREAMED_HIP(hipMemcpyAsync(h_img, d_counts, words * sizeof(uint64_t), hipMemcpyDeviceToHost, ks));
   STREAMED_HIP(hipMemcpyAsync(h_img + words, d_kover, sizeof(double), hipMemcpyDeviceToHost, ks));
   STREAMED_HIP(hipStreamSynchronize(ks));
+  if (want_digest) STREAMED_HIP(hipStreamSynchronize(cs));
   t_mark[3] = now();
 #undef STREAMED_HIP
+  if (want_digest) {
+    seq_digest_finish(seq, h_img[words + 1]);
+    if ((rc = mfx_check_seq_of_index(ev->ix, seq, "-hist (streamed)")) != MFX_OK) { cleanup(); return rc; }
+  }
   double kover;
   memcpy(&kover, h_img + words, sizeof(double));
   rc = mfx_hist_result_from_counts(ev->nbins, h_img, kover, seq->ncontigs, out);
@@ -1625,6 +1684,7 @@ static int seq_upload_packed(mfx_seq *seq, const char *const *bases) {
   if (rc) return rc;
   seq->bases_stale = true;
   seq->planes_ok = true;
+  seq->digest = 0;
   if (chunks.empty()) return MFX_OK;
   tm[2] = now();
   size_t STAGE_W = 0;
@@ -1707,6 +1767,7 @@ extern "C" int mfx_hist_run_streamed(mfx_eval *ev, mfx_seq *seq, const char *con
   }
   seq->bases_stale = false;                                 // this path writes d_bases
   seq->planes_ok = false;
+  seq->digest = 0;
   DevGuard g(ev->device);
   const size_t words = MFX_HIST_WORDS(ev->nbins, seq->ncontigs);
   const uint64_t T = seq->ntiles;
@@ -1798,6 +1859,7 @@ extern "C" int mfx_hist_run_streamed(mfx_eval *ev, mfx_seq *seq, const char *con
 #undef STREAMED_HIP
   double kover;
   memcpy(&kover, h_img + words, sizeof(double));
+  if ((rc = mfx_check_seq_of_index(ev->ix, seq, "-hist (streamed)")) != MFX_OK) { cleanup(); return rc; }
   rc = mfx_hist_result_from_counts(ev->nbins, h_img, kover, seq->ncontigs, out);
   const uint64_t novf = h_img[2ull * ev->nbins + 2];
   cleanup();
@@ -1882,6 +1944,7 @@ extern "C" int mfx_index_replicate_many(const mfx_index *src, const int *devices
   }
   for (uint32_t i = 0; i < n; ++i) {
     out[i]->fingerprint = src->fingerprint;
+    out[i]->seq_digest = src->seq_digest;
     (void)mfx_index_commit(out[i]);
   }
   return MFX_OK;
@@ -2367,6 +2430,7 @@ extern "C" int mfx_dump_values(mfx_eval *ev, const mfx_seq *seq, uint32_t contig
   int canon = 0;
   int rc = index_canonical(ev->ix, &canon);
   if (rc) return rc;
+  if ((rc = mfx_check_seq_of_index(ev->ix, seq, "-dump")) != MFX_OK) return rc;
   uint64_t n = pos_end - pos_begin;
   if (kasm) *kasm = 0;
   if (kmissing) *kmissing = 0;

@@ -83,6 +83,33 @@ struct FlatHeader {
 constexpr uint32_t FLAT_PACKED = 2u;
 constexpr uint32_t FLAT_DELTA = 4u;
 
+// The header's counts are bounded by the file's size BEFORE any arithmetic uses them (a damaged or crafted header must end in
+// MFX_E_FORMAT, never in a wrapped size check, a std::length_error through the C ABI or an out-of-bounds scatter): every
+// escape takes 12 bytes; a k-mer takes 8 (16) + 4 bytes plain, 8 packed, and at least 2 bits delta-coded (vbits >= 2).
+// nullptr = acceptable, else what is wrong.
+const char *flat_header_problem(const FlatHeader &h, uint64_t fsize) {
+  if (memcmp(h.magic, "MFXKMER1", 8) != 0) return "bad magic (not a flat k-mer file)";
+  if (h.k < 1 || h.k > (uint32_t)MFX_MAX_K) return "k out of range";
+  if (fsize < sizeof(FlatHeader)) return "truncated header";
+  const uint64_t body = fsize - sizeof(FlatHeader);
+  if (h.n_escape > body / 12) return "escape count beyond the file's size";
+  const uint64_t rest = body - h.n_escape * 12;
+  if (h.flags & FLAT_DELTA) {
+    if (h.k > (uint32_t)MFX_MAX_K_NARROW) return "delta-coded blocks hold k <= 31";
+    if (h.n / 4 > rest) return "k-mer count beyond the file's size";
+  } else if (h.flags & FLAT_PACKED) {
+    if (h.k > (uint32_t)MFX_MAX_K_PACKED) return "packed records hold k <= 21";
+    if (h.n > rest / 8) return "k-mer count beyond the file's size";
+  } else {
+    const uint64_t per = (h.k > (uint32_t)MFX_MAX_K_NARROW ? 16u : 8u) + 4u;
+    if (h.n > rest / per) return "k-mer count beyond the file's size";
+  }
+  if (h.n_escape > h.n) return "more escapes than k-mers";
+  return nullptr;
+}
+// a k-mer of k <= 31 bases has no bit at or above 2k
+inline bool flat_key_fits(uint64_t key, uint32_t k) { return k >= 32 || (key >> (2 * k)) == 0; }
+
 // ---- meryl stuffedBits reader (UNVALIDATED) -----------
 // A stuffedBits file image: u64 dataBlockLenMax (bits), u32 dataBlocksLen,
 // u32 dataBlocksMax, u64 bgn[dataBlocksLen], u64 len[dataBlocksLen] (bits),
@@ -681,6 +708,21 @@ int write_flat_delta(FILE *f, const char *path, FlatHeader h, const uint64_t *km
   return ok ? 0 : mfx_fail(MFX_E_IO, "short write to '%s'", path);
 }
 
+// the escape list of a packed / delta-coded file (n_escape was bounded by the file's size: flat_header_problem)
+int load_flat_escapes(mfx_index *const *ixs, uint32_t nix, int fd, const char *path, const FlatHeader &h, uint64_t at, int side,
+                      uint64_t minV, uint64_t maxV) {
+  std::vector<uint64_t> ek;
+  std::vector<uint32_t> ev;
+  try { ek.resize(h.n_escape); ev.resize(h.n_escape); }
+  catch (const std::exception &) { return mfx_fail(MFX_E_NOMEM, "'%s': no memory for %lu escapes", path, (unsigned long)h.n_escape); }
+  if (pread(fd, ek.data(), h.n_escape * 8, (off_t)at) != (ssize_t)(h.n_escape * 8) ||
+      pread(fd, ev.data(), h.n_escape * 4, (off_t)(at + h.n_escape * 8)) != (ssize_t)(h.n_escape * 4))
+    return mfx_fail(MFX_E_IO, "reading '%s' failed", path);
+  for (uint64_t i = 0; i < h.n_escape; ++i)
+    if (!flat_key_fits(ek[i], h.k)) return mfx_fail(MFX_E_FORMAT, "'%s': an escaped k-mer is wider than 2k bits", path);
+  return mfx_index_add_multi(ixs, nix, ek.data(), ev.data(), h.n_escape, side, minV, maxV);
+}
+
 int load_flat_delta(mfx_index *const *ixs, uint32_t nix, int fd, const char *path, const FlatHeader &h, uint64_t fsize, int side,
                     uint64_t minV, uint64_t maxV) {
   auto bad = [&](const char *what) { return mfx_fail(MFX_E_FORMAT, "'%s': %s", path, what); };
@@ -689,7 +731,8 @@ int load_flat_delta(mfx_index *const *ixs, uint32_t nix, int fd, const char *pat
   if (nblocks != (h.n + MFX_DELTA_BLOCK - 1) / MFX_DELTA_BLOCK) return bad("block count does not match the k-mer count");
   const uint64_t dir_off = sizeof(h) + 8, dir_bytes = (nblocks + 1) * 16;
   if (fsize < dir_off + dir_bytes) return bad("truncated block directory");
-  std::vector<uint64_t> dir(2 * (nblocks + 1));
+  std::vector<uint64_t> dir;
+  try { dir.resize(2 * (nblocks + 1)); } catch (const std::exception &) { return mfx_fail(MFX_E_NOMEM, "'%s': no memory for %lu directory entries", path, (unsigned long)nblocks); }
   for (uint64_t o = 0; o < dir_bytes;) {
     const ssize_t r = pread(fd, (char *)dir.data() + o, dir_bytes - o, (off_t)(dir_off + o));
     if (r <= 0) return mfx_fail(MFX_E_IO, "reading '%s' failed", path);
@@ -705,19 +748,16 @@ int load_flat_delta(mfx_index *const *ixs, uint32_t nix, int fd, const char *pat
     const uint32_t kb = (uint32_t)(dir[2 * b + 1] >> 48) & 0xffu, vb = (uint32_t)(dir[2 * b + 1] >> 56) & 0xffu;
     const uint64_t cnt = std::min<uint64_t>(MFX_DELTA_BLOCK, h.n - b * MFX_DELTA_BLOCK);
     if (kb > 2u * h.k || vb < 2u || vb > (uint32_t)MFX_DELTA_MAX_VBITS) return bad("block field widths out of range");
+    if (!flat_key_fits(dir[2 * b], h.k)) return bad("a block's first k-mer is wider than 2k bits");
+    // (the k-mers inside a block exist only in the kernel that decodes them: it refuses what is wider than 2k bits, index meta[4])
+    if (b + 1 < nblocks && dir[2 * (b + 1)] <= dir[2 * b]) return bad("block directory not ascending");
     expect = off + (((cnt - 1) * kb + 63) / 64 + (cnt * vb + 63) / 64) * 8;
+    if (expect > fsize) return bad("truncated delta-coded payload");
   }
-  if (fsize < expect + h.n_escape * 12) return bad("truncated delta-coded payload");
+  if (expect > fsize || fsize - expect < h.n_escape * 12) return bad("truncated delta-coded payload");
   int rc = MFX_OK;
   if (h.n) rc = mfx_index_add_delta_file(ixs, nix, fd, path, dir.data(), nblocks, h.n, side, minV, maxV);
-  if (rc == MFX_OK && h.n_escape) {
-    std::vector<uint64_t> ek(h.n_escape);
-    std::vector<uint32_t> ev(h.n_escape);
-    if (pread(fd, ek.data(), h.n_escape * 8, (off_t)expect) != (ssize_t)(h.n_escape * 8) ||
-        pread(fd, ev.data(), h.n_escape * 4, (off_t)(expect + h.n_escape * 8)) != (ssize_t)(h.n_escape * 4))
-      rc = mfx_fail(MFX_E_IO, "reading '%s' failed", path);
-    else rc = mfx_index_add_multi(ixs, nix, ek.data(), ev.data(), h.n_escape, side, minV, maxV);
-  }
+  if (rc == MFX_OK && h.n_escape) rc = load_flat_escapes(ixs, nix, fd, path, h, expect, side, minV, maxV);
   return rc;
 }
 
@@ -800,6 +840,7 @@ extern "C" int mfx_index_load_db_multi(mfx_index *const *ixs, uint32_t nix, cons
       close(fdn);
       return mfx_fail(MFX_E_FORMAT, "'%s': truncated header", path);
     }
+    if (const char *why = flat_header_problem(h, (uint64_t)st.st_size)) { close(fdn); return mfx_fail(MFX_E_FORMAT, "'%s': %s", path, why); }
     if ((int)h.k != ix->k) { close(fdn); return mfx_fail(MFX_E_INVAL, "'%s' holds %u-mers but the index is built for k=%d", path, h.k, ix->k); }
     const uint64_t kw = ix->key_words();                     // k > 31: 16-byte k-mers {low, high}
     if (h.flags & FLAT_DELTA) {
@@ -813,15 +854,8 @@ extern "C" int mfx_index_load_db_multi(mfx_index *const *ixs, uint32_t nix, cons
         return mfx_fail(MFX_E_FORMAT, "'%s': truncated or inconsistent packed payload", path);
       }
       if (h.n) rc = mfx_index_add_from_file(ixs, nix, fdn, path, sizeof(h), 0, h.n, side, minV, maxV);
-      if (rc == MFX_OK && h.n_escape) {                      // the few counts beyond the record's field
-        std::vector<uint64_t> ek(h.n_escape);
-        std::vector<uint32_t> ev(h.n_escape);
-        const uint64_t eo = sizeof(h) + h.n * 8;
-        if (pread(fdn, ek.data(), h.n_escape * 8, (off_t)eo) != (ssize_t)(h.n_escape * 8) ||
-            pread(fdn, ev.data(), h.n_escape * 4, (off_t)(eo + h.n_escape * 8)) != (ssize_t)(h.n_escape * 4))
-          rc = mfx_fail(MFX_E_IO, "reading '%s' failed", path);
-        else rc = mfx_index_add_multi(ixs, nix, ek.data(), ev.data(), h.n_escape, side, minV, maxV);
-      }
+      if (rc == MFX_OK && h.n_escape)                        // the few counts beyond the record's field
+        rc = load_flat_escapes(ixs, nix, fdn, path, h, sizeof(h) + h.n * 8, side, minV, maxV);
       close(fdn);
       return rc;
     }
@@ -945,10 +979,13 @@ int read_flat_host(const std::string &path, int *k_out, std::vector<uint64_t> &k
   auto bad = [&](const char *what) { fclose(f); return mfx_fail(MFX_E_FORMAT, "'%s': %s", path.c_str(), what); };
   FlatHeader h;
   if (fread(&h, sizeof(h), 1, f) != 1) return bad("truncated header");
+  struct stat fst;
+  if (fstat(fileno(f), &fst) != 0) { fclose(f); return mfx_fail(MFX_E_IO, "cannot stat '%s'", path.c_str()); }
+  if (const char *why = flat_header_problem(h, (uint64_t)fst.st_size)) return bad(why);
   *k_out = (int)h.k;
   const size_t kw = h.k > (uint32_t)MFX_MAX_K_NARROW ? 2 : 1;
-  keys.resize(h.n * kw);
-  vals.resize(h.n);
+  try { keys.resize(h.n * kw); vals.resize(h.n); }
+  catch (const std::exception &) { fclose(f); return mfx_fail(MFX_E_NOMEM, "'%s': no memory for %lu k-mers", path.c_str(), (unsigned long)h.n); }
   auto escapes = [&]() -> bool {                              // the side list of a packed / delta file: counts by k-mer
     std::vector<uint64_t> ek(h.n_escape);
     std::vector<uint32_t> ev(h.n_escape);
@@ -997,6 +1034,14 @@ int read_flat_host(const std::string &path, int *k_out, std::vector<uint64_t> &k
     }
     if (!escapes()) return bad("inconsistent escape list");
   } else if (h.n && (fread(keys.data(), 8 * kw, h.n, f) != h.n || fread(vals.data(), 4, h.n, f) != h.n)) return bad("truncated payload");
+  // every k-mer inside 2k bits: what follows (sort_pairs' bucket index, the writers' bit widths) relies on it
+  if (kw == 1) {
+    for (uint64_t i = 0; i < h.n; ++i)
+      if (!flat_key_fits(keys[i], h.k)) return bad("a k-mer is wider than 2k bits");
+  } else if (h.k < 64) {
+    for (uint64_t i = 0; i < h.n; ++i)
+      if (keys[2 * i + 1] >> (2 * h.k - 64)) return bad("a k-mer is wider than 2k bits");
+  }
   fclose(f);
   return MFX_OK;
 }
@@ -1153,7 +1198,7 @@ struct IndexImageHeader {
   uint32_t filter_set, layout;   // layout = MFX_LAYOUT_VERSION of the build that wrote the image
   uint64_t fingerprint;          // caller's digest of the inputs the table was built from (mfx_index_set_fingerprint)
   uint64_t side_nlines;          // compact layout: lines of the side table that follow the nlines main lines
-  uint32_t flags, reserved;      // bit 0: sequence-only index, bit 1: compact layout, bit 2: frozen (counts were added)
+  uint32_t flags, seq_digest;    // bit 0: sequence-only index, bit 1: compact layout, bit 2: frozen (counts were added); digest of the claimed sequence (0: none)
 };
 
 static_assert(sizeof(IndexImageHeader) <= MFX_INDEX_HEADER_BYTES, "index image header outgrew its public size");
@@ -1172,6 +1217,7 @@ static int fill_header(const mfx_index *ix, IndexImageHeader &h) {
   h.fingerprint = ix->fingerprint;
   h.side_nlines = ix->side_nlines;
   h.flags = (ix->seq_only ? 1u : 0u) | (ix->compact ? 2u : 0u) | (ix->frozen ? 4u : 0u);
+  h.seq_digest = ix->seq_digest;
   if (hipMemcpy(h.meta, ix->d_meta, sizeof(h.meta), hipMemcpyDeviceToHost) != hipSuccess) return mfx_fail(MFX_E_HIP, "reading index metadata failed");
   return MFX_OK;
 }
@@ -1207,6 +1253,7 @@ static mfx_index *index_from_header(const IndexImageHeader &h, double max_gb, in
   ix->fingerprint = h.fingerprint;
   ix->side_nlines = h.side_nlines;
   ix->seq_only = (h.flags & 1u) != 0; ix->compact = (h.flags & 2u) != 0; ix->frozen = (h.flags & 4u) != 0;
+  ix->seq_digest = ix->seq_only ? h.seq_digest : 0u;
   if (hipMalloc((void **)&ix->d_slots, total_lines * MFX_ALIGN) != hipSuccess ||
       hipMemcpy(ix->d_meta, h.meta, sizeof(h.meta), hipMemcpyHostToDevice) != hipSuccess) {
     mfx_fail(MFX_E_NOMEM, "cannot allocate %.3f GB for the index image on device %d", (double)total_lines * MFX_ALIGN / 1e9, device);

@@ -62,6 +62,7 @@ constexpr uint32_t MFX_LAYOUT_VERSION = 7u;
 constexpr uint32_t MFX_SPLIT_MAX_RANKS = 16;  // owners the sort-free router handles (a node has 8 GPUs); more: radix sort
 constexpr int      MFX_MZ_W_DEFAULT = 3;        // minimizer windows of the default placement (MFX_MZ_W overrides)
 constexpr uint32_t MFX_OVF_CAP    = 1u << 20;   // histogram overflow records per evaluator
+constexpr uint32_t MFX_META_WORDS = 8;          // mfx_index::d_meta
 
 struct mfx_slot {               // 16 bytes: one dwordx4 load per probe
   uint64_t key;                 // 2k-bit k-mer, ~0 = empty
@@ -122,6 +123,7 @@ struct mfx_index {
   uint64_t  nlines = 0;
   mfx_slot *d_slots = nullptr;
   uint64_t *d_meta = nullptr;   // [0] distinct  [1] non-canonical inserts  [2] probe-limit failures  [3] adds dropped by a sequence-only index
+                                // [4] records wider than 2k bits (a damaged database; never inserted).  MFX_META_WORDS allocated; images and replicas carry the first 4
   uint64_t  minV = 0, maxV = ~0ull;
   bool      filter_set = false;
   int       mz_w = 0;
@@ -137,6 +139,8 @@ struct mfx_index {
   bool      compact = false;    // seq_only, k <= 21: 8-byte slots, 16 per line (mfx_table_view)
   bool      frozen = false;     // an add / load happened: no more claims
   uint64_t  side_nlines = 0;    // compact: lines of the side table, which follows the nlines main lines in d_slots
+  uint32_t  seq_digest = 0;     // seq_only: content digest of the sequence the k-mers were claimed from (0: not recorded);
+                                // evaluating another sequence on it is refused (mfx_seq_digest32, mfx_api.cpp)
   uint64_t  total_lines() const { return nlines + side_nlines; }
   bool      wide() const { return k > MFX_MAX_K_NARROW; }
   uint32_t  slots_per_line() const { return wide() ? MFX_WSLOTS_LINE : compact ? MFX_CSLOTS_LINE : MFX_SLOTS_LINE; }
@@ -162,7 +166,13 @@ struct mfx_seq {
   uint64_t *d_tile_start = nullptr;  // [ncontigs+1] first tile of each contig
   uint32_t *d_tile_contig = nullptr; // [ntiles] contig of each tile
   std::vector<uint64_t> off, len, tile_start;
+  mutable uint32_t digest = 0;       // content digest (mfx_seq_digest32), computed on first use; 0: not computed / the content changed
 };
+
+// content digest of a sequence (never 0): contig lengths + the codes and validity of every base, whatever form it is held in
+int mfx_seq_digest32(const mfx_seq *s, uint32_t *out);
+// refuses (MFX_E_INVAL) the evaluation of a sequence other than the one a sequence-only index was claimed from
+int mfx_check_seq_of_index(const mfx_index *ix, const mfx_seq *s, const char *who);
 
 int mfx_seq_ensure_ascii(const mfx_seq *s);      // unpacks the planes into d_bases if a packed upload left them newer (mfx_api.cpp)
 

@@ -120,6 +120,8 @@ hipError_t mfx_kw_count(const mfx_count_args &a, hipStream_t st);
 hipError_t mfx_kw_completeness(mfx_table_view t, double peak, uint32_t n_prob, const uint32_t *probK, const double *probP, double *partials,
                                int grid, hipStream_t st);
 hipError_t mfx_k_dump(const mfx_dump_args &a, hipStream_t st);
+// *out += the content digest of nwords 32-base words (codes != nullptr: from the packed planes, else from the bytes)
+hipError_t mfx_k_seq_digest(const uint8_t *bases, const uint64_t *codes, const uint32_t *valid, uint64_t nwords, uint64_t *out, hipStream_t st);
 hipError_t mfx_k_add_u32(uint32_t *dst, const uint32_t *src, uint64_t n, hipStream_t st);
 hipError_t mfx_k_pack(const uint8_t *bases, uint64_t *codes, uint32_t *valid, uint64_t nwords, hipStream_t st);
 hipError_t mfx_k_unpack(const uint64_t *codes, const uint32_t *valid, uint8_t *bases, uint64_t nwords, hipStream_t st);

@@ -596,6 +596,7 @@ __global__ __launch_bounds__(256) void mfx_table_add_kernel(mfx_table_view t, co
       else { v = (uint32_t)key & MFX_PACKED_VMASK; key >>= MFX_PACKED_VBITS; if (v == MFX_PACKED_VMASK) v = 0u; }   // packed record; escape: added separately
     }
     bool ok = v != 0;
+    if (ok && (key >> (2 * t.k))) { ok = false; atomicAdd((unsigned long long *)&meta[4], 1ull); }   // wider than 2k bits: a damaged record, refused by the host
     if (ok) {
       const uint64_t krc = mfx_revcomp(key, t.k);
       if (key > krc) ++noncanon;
@@ -620,7 +621,7 @@ __global__ __launch_bounds__(256) void mfx_table_add_kernel(mfx_table_view t, co
 //    an empty slot proves that the k-mer was never claimed (mfx_c_first); the whole line (mfx_c_find) only for the rest.
 //    The UB loads of a lane are in flight together.  16-byte slots: the cooperative insert without its claim.
 //  * full tables: the cooperative insert (mfx_group_insert); a sharded table keeps the k-mers it owns.
-struct mfx_tally { uint32_t fresh = 0, dropped = 0, noncanon = 0; };
+struct mfx_tally { uint32_t fresh = 0, dropped = 0, noncanon = 0, wide = 0; };
 
 __device__ __forceinline__ void mfx_tally_flush(uint64_t *meta, const mfx_tally &T) {
   uint64_t f = T.fresh, d = T.dropped, c = T.noncanon;
@@ -631,11 +632,17 @@ __device__ __forceinline__ void mfx_tally_flush(uint64_t *meta, const mfx_tally 
     if (c) atomicAdd((unsigned long long *)&meta[1], (unsigned long long)c);
     if (d) atomicAdd((unsigned long long *)&meta[3], (unsigned long long)d);
   }
+  if (T.wide) atomicAdd((unsigned long long *)&meta[4], (unsigned long long)T.wide);    // a damaged database only: the host refuses the load
 }
 
 template <int UB>
 __device__ __forceinline__ void mfx_apply_batch(const mfx_table_view &t, uint64_t (&key)[UB], uint32_t (&v)[UB], int side, uint64_t *meta,
                                                 mfx_tally &T) {
+  // a k-mer has 2k bits: anything wider is a damaged record (mfx_db.cpp checks what it can see on the host; the k-mers of a
+  // delta-coded block only exist here) -- never inserted, counted in meta[4], the host refuses the load (index_check)
+#pragma unroll
+  for (int j = 0; j < UB; ++j)
+    if (v[j] && (key[j] >> (2 * t.k))) { ++T.wide; v[j] = 0u; }
   if (t.seq_only && t.compact) {
     unsigned long long *mb[UB];
     uint4 s[UB];
@@ -1989,6 +1996,41 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_pack_kernel(const uint8_t *base
   }
 }
 
+// Digest of a sequence's CONTENT in the library's own terms -- the 2-bit codes of the valid bases and the validity bits of
+// every 32-base word of the padded buffer -- so that it does not depend on how the sequence is held (one byte per base or
+// packed planes), on letter case or on what the invalid bytes were.  A wrapping sum of per-word hashes: any launch shape
+// and any chunking give the same value.  A sequence-only index records the digest of the sequence it was claimed from and
+// evaluations of another sequence are refused (mfx_api.cpp: seq_digest32).
+__device__ __forceinline__ uint64_t mfx_double_bits(uint32_t v) {       // bit b of v -> bits 2b and 2b+1
+  uint64_t x = v;
+  x = (x | (x << 16)) & 0x0000FFFF0000FFFFULL;
+  x = (x | (x << 8)) & 0x00FF00FF00FF00FFULL;
+  x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0FULL;
+  x = (x | (x << 2)) & 0x3333333333333333ULL;
+  x = (x | (x << 1)) & 0x5555555555555555ULL;
+  return x | (x << 1);
+}
+__global__ __launch_bounds__(MFX_BLOCK) void mfx_seq_digest_kernel(const uint8_t *bases, const uint64_t *codes, const uint32_t *valid,
+                                                                   uint64_t nwords, unsigned long long *out) {
+  const uint64_t stride = (uint64_t)gridDim.x * MFX_BLOCK;
+  uint64_t acc = 0;
+  for (uint64_t w = (uint64_t)blockIdx.x * MFX_BLOCK + threadIdx.x; w < nwords; w += stride) {
+    uint64_t c;
+    uint32_t v;
+    if (codes) { c = codes[w]; v = valid[w]; }
+    else {
+      uint32_t c0, v0, c1, v1;
+      mfx_pack16(*reinterpret_cast<const uint4 *>(bases + 32 * w), c0, v0);
+      mfx_pack16(*reinterpret_cast<const uint4 *>(bases + 32 * w + 16), c1, v1);
+      c = ((uint64_t)c0 << 32) | c1;                         // first 16 bases of a 32-base word are its HIGH half
+      v = (v0 << 16) | v1;
+    }
+    if (v) acc += mfx_hash64((c & mfx_double_bits(v)) ^ (w * 0x9E3779B97F4A7C15ULL)) + mfx_hash64((uint64_t)v + w * 0xD6E8FEB86659FD93ULL + 1ULL);
+  }
+  acc = mfx_wave_sum(acc);
+  if ((threadIdx.x & 63u) == 0 && acc) atomicAdd(out, (unsigned long long)acc);
+}
+
 // dst[i] += src[i]: the value arrays of the shards of one index add up to the whole index's values (every k-mer has
 // exactly one owner; the other shards answer 0)
 __global__ __launch_bounds__(MFX_BLOCK) void mfx_add_u32_kernel(uint32_t *dst, const uint32_t *src, uint64_t n) {
@@ -2219,6 +2261,13 @@ hipError_t mfx_k_pack(const uint8_t *bases, uint64_t *codes, uint32_t *valid, ui
   uint64_t blocks = (2 * nwords + MFX_BLOCK - 1) / MFX_BLOCK;
   if (blocks > 65536) blocks = 65536;
   mfx_pack_kernel<<<(unsigned)blocks, MFX_BLOCK, 0, st>>>(bases, codes, valid, nwords);
+  return hipGetLastError();
+}
+hipError_t mfx_k_seq_digest(const uint8_t *bases, const uint64_t *codes, const uint32_t *valid, uint64_t nwords, uint64_t *out, hipStream_t st) {
+  if (nwords == 0) return hipSuccess;
+  uint64_t blocks = (nwords + MFX_BLOCK - 1) / MFX_BLOCK;
+  if (blocks > 4096) blocks = 4096;
+  mfx_seq_digest_kernel<<<(unsigned)blocks, MFX_BLOCK, 0, st>>>(bases, codes, valid, nwords, reinterpret_cast<unsigned long long *>(out));
   return hipGetLastError();
 }
 hipError_t mfx_k_add_u32(uint32_t *dst, const uint32_t *src, uint64_t n, hipStream_t st) {

@@ -641,7 +641,7 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
     std::vector<Job> jobs;
     std::string packed;
     std::vector<uint32_t> rv, av;
-    std::future<int> gpu;
+    std::shared_future<int> gpu;      // stage B of this batch (shared: the next batch's stage B waits for it too)
     std::string err;                  // the error text of stage B (errors are per thread: it is carried back to the caller's)
     bool live = false;
   } batches[2];
@@ -682,11 +682,17 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
     });
     lap(2);
     bt.live = true;
+    bt.gpu = std::shared_future<int>();                                  // (a shared future stays valid after get(): this batch has none yet)
     if (total) {
       bt.rv.resize(packed.size() + 1);
       bt.av.resize(packed.size() + 1);
       Batch *bp = &bt;
-      bt.gpu = std::async(std::launch::async, [bp, &values]() {
+      // one stage B at a time on the evaluator(s): it still runs under stages A and C of its neighbours on the host, but two
+      // values() calls never hold their device buffers (path text + two value arrays each) at once, and the sharded form
+      // (mfx_dump_values_sharded: per-slot scratch, peer copies) is never entered twice
+      std::shared_future<int> prev = batches[&bt == &batches[0] ? 1 : 0].gpu;
+      bt.gpu = std::async(std::launch::async, [bp, prev, &values]() {
+        if (prev.valid()) prev.wait();
         const int r = values(bp->packed.data(), bp->packed.size(), bp->rv.data(), bp->av.data());
         if (r) bp->err = mfx_last_error();
         return r;

@@ -385,6 +385,16 @@ def test_cli_hist_falls_back_to_the_full_tables_for_a_non_canonical_database(tmp
         assert "not canonical; building the full lookup tables" in rr.stderr
         if seqmers:                     # (without -seqmers the assembly side is the canonical count of the sequence: another world)
             assert (tmp_path / "g.hist").read_bytes() == (tmp_path / "o.hist").read_bytes()
+            # -index: the fallback saves the FULL tables under the full-index digest, and the next run takes that image instead
+            # of building twice again (advisor, round 3: it used to be saved under the sequence-only digest and never matched)
+            img = str(tmp_path / "nc.mfxi")
+            for attempt in (0, 1):
+                (tmp_path / "g.hist").unlink()
+                rr = subprocess.run([EXE] + args + ["-index", img], capture_output=True, text=True)
+                assert rr.returncode == 0, rr.stderr
+                assert ("Loading the index image" in rr.stderr) == (attempt == 1), rr.stderr
+                assert ("building the full lookup tables" in rr.stderr) == (attempt == 0) and "rebuilding it" not in rr.stderr
+                assert (tmp_path / "g.hist").read_bytes() == (tmp_path / "o.hist").read_bytes()
 
 
 @pytest.mark.gpu

@@ -116,3 +116,40 @@ def test_cli_convert_needs_no_device(tmp_path):
     assert m.db_probe(out) == {"k": k, "format": "flat", "n_kmers": len(keys)}
     r = subprocess.run([EXE, "-convert", p], capture_output=True, text=True)
     assert r.returncode == 1 and "No output (-output) supplied." in r.stderr
+
+
+def _write_plain(path, k, keys, vals, n=None, n_escape=0, flags=1):
+    import struct
+    keys = np.asarray(keys, dtype="<u8")
+    vals = np.asarray(vals, dtype="<u4")
+    with open(path, "wb") as f:
+        f.write(b"MFXKMER1" + struct.pack("<IIQQ", k, flags, len(keys) if n is None else n, n_escape))
+        f.write(keys.tobytes())
+        f.write(vals.tobytes())
+
+
+def test_a_flat_file_with_a_k_mer_wider_than_2k_bits_is_refused(tmp_path):
+    """a k-mer with bits at or above 2k once indexed past sort_pairs' bucket histogram (advisor, round 3): now MFX_E_FORMAT"""
+    import merfin_amd as m
+    k = 9
+    keys = [5, 3, (1 << 18) | 7, 1 << 40, 2]           # not ascending (so the converter sorts) and two keys beyond 18 bits
+    p = str(tmp_path / "wide.mfxk")
+    _write_plain(p, k, keys, [1] * len(keys))
+    with pytest.raises(m.MfxError) as e:
+        m.db_convert(p, str(tmp_path / "o.mfxk"))
+    assert "wider than 2k bits" in str(e.value)
+    _write_plain(p, k, [5, 3, 2], [1, 2, 3])            # the same file without them converts
+    assert m.db_convert(p, str(tmp_path / "o.mfxk")) == 3
+
+
+@pytest.mark.parametrize("n, n_escape, flags", [(1 << 62, 0, 1), (3, 1 << 62, 3), (3, 1 << 61, 5), ((1 << 64) - 1, (1 << 64) - 1, 1),
+                                                (1 << 40, 0, 3), (1 << 50, 0, 5), (3, 4, 3)])
+def test_damaged_flat_headers_are_format_errors_not_aborts(tmp_path, n, n_escape, flags):
+    """header counts that wrap the size checks (n_escape = 2^62: 12 * n_escape == 0 mod 2^64) used to reach std::vector's
+    length_error through the C ABI (advisor, round 3)"""
+    import merfin_amd as m
+    p = str(tmp_path / "bad.mfxk")
+    _write_plain(p, 21, [1, 2, 3], [1, 1, 1], n=n, n_escape=n_escape, flags=flags)
+    with pytest.raises(m.MfxError) as e:
+        m.db_convert(p, str(tmp_path / "o.mfxk"))
+    assert "beyond the file's size" in str(e.value) or "more escapes" in str(e.value)

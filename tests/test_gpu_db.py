@@ -473,3 +473,79 @@ def test_delta_form_with_a_damaged_directory_is_refused(tmp_path):
     ix = m.Index(k, len(keys) + 16)
     ix.load_db(good, 0)
     assert ix.info()["distinct"] == len(keys)
+
+
+@pytest.mark.gpu
+def test_records_wider_than_2k_bits_are_refused_by_the_device_loaders(tmp_path, monkeypatch):
+    """a k-mer has 2k bits.  Every flat encoding with one wider record is a format error of the load (plain and packed: the
+    kernels that unpack the records count them, index meta[4]; delta-coded: the k-mers of a block only ever exist in the kernel
+    that decodes it) and none of the wide records reaches the table.  Damaged header counts are format errors, not aborts."""
+    import struct
+    import merfin_amd as m
+    from tests.test_db_convert import _write_plain
+    k = 15
+    rng = np.random.default_rng(3)
+    keys = np.unique(rng.integers(0, 1 << 30, size=9000, dtype=np.uint64))
+    x, rc = keys.copy(), np.zeros_like(keys)
+    for _ in range(k):
+        rc = (rc << np.uint64(2)) | ((x & np.uint64(3)) ^ np.uint64(2))
+        x = x >> np.uint64(2)
+    keys = np.unique(np.minimum(keys, rc))
+    vals = rng.integers(1, 50, size=len(keys)).astype(np.uint32)
+    # plain: one key with a bit above 2k
+    bad = keys.copy()
+    bad[1234] |= np.uint64(1 << 33)
+    p = str(tmp_path / "plain.mfxk")
+    _write_plain(p, k, bad, vals)
+    for make in (lambda: m.Index(k, len(keys) + 16), ):
+        ix = make()
+        with pytest.raises(m.MfxError) as e:
+            ix.load_db(p, 0)
+        assert e.value.code == -7 and "wider than 2k" in str(e.value)
+        assert ix.info()["distinct"] == len(keys) - 1
+    # packed records {k-mer << 22 | count}
+    p = str(tmp_path / "packed.mfxk")
+    with open(p, "wb") as f:
+        f.write(b"MFXKMER1" + struct.pack("<IIQQ", k, 3, len(keys), 0))
+        f.write(((bad << np.uint64(22)) | vals.astype(np.uint64)).astype("<u8").tobytes())
+    ix = m.Index(k, len(keys) + 16)
+    with pytest.raises(m.MfxError) as e:
+        ix.load_db(p, 0)
+    assert e.value.code == -7 and ix.info()["distinct"] == len(keys) - 1
+    # delta-coded: widen the last difference of the last block until the last k-mer leaves 2k bits
+    good = str(tmp_path / "good.mfxk")
+    m.db_write_flat(good, k, keys, vals)
+    raw = bytearray(open(good, "rb").read())
+    assert struct.unpack_from("<I", raw, 12)[0] & 4
+    (nblocks,) = struct.unpack_from("<Q", raw, 32)
+    first, info = struct.unpack_from("<QQ", raw, 40 + 16 * (nblocks - 1))
+    struct.pack_into("<Q", raw, 40 + 16 * (nblocks - 1), first | (1 << 31))       # the block's first k-mer: 32 bits > 2k = 30
+    p = str(tmp_path / "delta.mfxk")
+    open(p, "wb").write(bytes(raw))
+    ix = m.Index(k, len(keys) + 16)
+    with pytest.raises(m.MfxError) as e:
+        ix.load_db(p, 0)
+    assert e.value.code == -7                                                     # seen by the host's directory check
+    # ... and a hand-made block whose DIFFERENCES leave 2k bits: only the decoding kernel can see that
+    kb, vb = 30, 2
+    d = [1, (1 << 30) - 1]
+    blk = struct.pack("<QQ", d[0] | (d[1] << kb), 1 | (1 << vb) | (1 << 2 * vb))
+    off = 32 + 8 + 2 * 16
+    p = str(tmp_path / "delta2.mfxk")
+    with open(p, "wb") as f:
+        f.write(b"MFXKMER1" + struct.pack("<IIQQ", k, 5, 3, 0) + struct.pack("<Q", 1))
+        f.write(struct.pack("<QQ", 1 << 29, off | (kb << 48) | (vb << 56)) + struct.pack("<QQ", 0, off + 16))
+        f.write(blk)
+    ix = m.Index(k, 64)
+    with pytest.raises(m.MfxError) as e:
+        ix.load_db(p, 0)
+    assert e.value.code == -7 and "wider than 2k" in str(e.value)
+    assert ix.info()["distinct"] == 2                                             # the two k-mers inside 2k bits
+    # header counts that would wrap the size arithmetic
+    for n, nesc, flags in ((1 << 62, 0, 1), (3, 1 << 62, 3), (3, 1 << 61, 5)):
+        p = str(tmp_path / "hdr.mfxk")
+        _write_plain(p, k, keys[:3], vals[:3], n=n, n_escape=nesc, flags=flags)
+        ix = m.Index(k, 64)
+        with pytest.raises(m.MfxError) as e:
+            ix.load_db(p, 0)
+        assert e.value.code == -7, str(e.value)

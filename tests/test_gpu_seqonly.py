@@ -180,6 +180,53 @@ def test_seq_only_rules():
     assert ei.value.code == m.E_NONCANON
 
 
+def test_seq_only_index_refuses_another_sequence(tmp_path):
+    """a sequence-only index answers for the k-mers of the sequence it was claimed from: k-mers it never claimed would read as
+    absent (a full table would answer their read count), so evaluating ANOTHER or an edited sequence on it is an error, for
+    -hist (resident, launch by launch, streamed), -dump, an image and a replica alike; the same content in another form
+    (another object, lower case, other invalid bytes, packed planes or bytes) is the same sequence (advisor, round 3)."""
+    m = _mfx()
+    k, peak = 21, 9.0
+    contigs, read, asm = synth.world(k=k, peak=peak, seed=11)
+    ix, seqs = seq_index(m, k, contigs, read)
+    ev = m.Evaluator(ix, m.KParams(peak))
+    ref = ev.hist(seqs)
+    # the same content, held differently
+    low = [bytes(c).lower().replace(b"n", b"x") for c in contigs]
+    for same in (m.Sequences(contigs), m.Sequences(low)):
+        r = ev.hist(same)
+        assert (r.kasm, r.kmissing) == (ref.kasm, ref.kmissing) and r.koverCpy == ref.koverCpy
+    r = ev.hist_streamed(m.Sequences.create([len(c) for c in contigs]), low)
+    assert (r.kasm, r.kmissing) == (ref.kasm, ref.kmissing)
+    # one substituted base; one contig fewer; the contigs in another order
+    edited = [bytearray(c) for c in contigs]
+    big = max(range(len(edited)), key=lambda i: len(edited[i]))
+    pos = next(i for i in range(100, len(edited[big])) if edited[big][i:i + 1] in (b"A", b"C", b"G", b"T"))
+    edited[big][pos:pos + 1] = b"C" if edited[big][pos:pos + 1] != b"C" else b"G"
+    edited = [bytes(c) for c in edited]
+    others = [edited, [c for c in contigs if len(c)][:-1], list(reversed(contigs))]
+    img = str(tmp_path / "img")
+    ix.save(img)
+    for holder in (ix, m.Index.load(img), ix.replicate(0)):
+        e2 = m.Evaluator(holder, m.KParams(peak))
+        for o in others:
+            if [bytes(x) for x in o] == [bytes(x) for x in contigs]:
+                continue
+            so = m.Sequences(o)
+            with pytest.raises(m.MfxError, match="ANOTHER sequence") as ei:
+                e2.hist(so)
+            assert ei.value.code == -1
+            with pytest.raises(m.MfxError, match="ANOTHER sequence"):
+                e2.hist_streamed(m.Sequences.create([len(c) for c in o]), o)
+            with pytest.raises(m.MfxError, match="ANOTHER sequence"):
+                e2.dump_values(so, 0, 0, len(o[0]))
+        r = e2.hist(seqs)
+        assert (r.kasm, r.kmissing) == (ref.kasm, ref.kmissing)
+    # a full index has no such tie
+    full = m.Evaluator(build_index(m, k, read, asm), m.KParams(peak))
+    full.hist(m.Sequences(edited))
+
+
 @pytest.mark.parametrize("k", [21, 27])
 def test_seq_only_image_roundtrip_and_replica(k, tmp_path):
     """the device-format image (-index cache) and the replica made for another slot carry the compact layout, its side
