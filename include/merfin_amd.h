@@ -222,6 +222,12 @@ typedef struct mfx_eval mfx_eval;
 mfx_eval *mfx_eval_create(const mfx_index *ix, const mfx_kparams *kp, uint32_t nbins);
 void      mfx_eval_free(mfx_eval *ev);
 uint32_t  mfx_eval_nbins(const mfx_eval *ev);
+/* Test hook (no reference counterpart): -hist launches of this evaluator run the DEBUG instance of the kernel where one
+ * exists (compact layout, k = 21) and count how its probe's queries ended: out8[0] not in the first mini-bucket (first
+ * cooperative pass), [1] home line full (second cooperative pass), [2] saturated count (side table), [3] per-lane
+ * whole-line scans.  mfx_eval_debug_counters reads and clears them.  Never the measured configuration. */
+int       mfx_eval_debug_enable(mfx_eval *ev, int on);
+int       mfx_eval_debug_counters(mfx_eval *ev, uint64_t *out8);
 
 /* merfinGlobal::getK(kmvalu,kmvalu,...) + getKmetric on the host, bit-exact
  * with the device code (merfin-globals.C:66-98, merfin-globals.H:248-261). */

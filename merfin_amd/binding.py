@@ -74,7 +74,7 @@ SYMBOLS = [
     "mfx_index_image_header", "mfx_index_create_from_header", "mfx_index_device_image", "mfx_index_commit",
     "mfx_seq_upload", "mfx_seq_from_device", "mfx_seq_free", "mfx_seq_num_contigs", "mfx_seq_num_bases",
     "mfx_seq_num_tiles",
-    "mfx_eval_create", "mfx_eval_free", "mfx_eval_nbins", "mfx_getK", "mfx_getKmetric", "mfx_histoQV",
+    "mfx_eval_create", "mfx_eval_free", "mfx_eval_nbins", "mfx_eval_debug_enable", "mfx_eval_debug_counters", "mfx_getK", "mfx_getKmetric", "mfx_histoQV",
     "mfx_hist_run", "mfx_hist_result_free", "mfx_hist_launch", "mfx_hist_launch_cyclic", "mfx_hist_result_from_counts",
     "mfx_hist_take_overflow", "mfx_hist_report",
     "mfx_pack_bases", "mfx_host_threads_share", "mfx_dump_values", "mfx_dump_contig", "mfx_dump_values_sharded", "mfx_dump_contig_sharded", "mfx_variants_run_sharded", "mfx_completeness", "mfx_completeness_pieces", "mfx_variants_run",
@@ -160,6 +160,8 @@ def load_library():
     L.mfx_eval_free.argtypes = [vp]
     L.mfx_eval_nbins.restype = C.c_uint32
     L.mfx_eval_nbins.argtypes = [vp]
+    L.mfx_eval_debug_enable.argtypes = [vp, C.c_int]
+    L.mfx_eval_debug_counters.argtypes = [vp, u64p]
     L.mfx_getK.argtypes = [C.POINTER(_KP), C.c_uint32, C.c_uint32, f64p, f64p, f64p]
     L.mfx_getKmetric.restype = C.c_double
     L.mfx_getKmetric.argtypes = [C.c_double, C.c_double]
@@ -796,6 +798,16 @@ class Evaluator:
     @property
     def nbins(self):
         return load_library().mfx_eval_nbins(self.h)
+
+    def debug(self, on=True):
+        """test hook: -hist launches run the DEBUG instance of the kernel (probe path counters) where one exists"""
+        _check(load_library().mfx_eval_debug_enable(self.h, 1 if on else 0))
+
+    def debug_counters(self):
+        """{first_pass, second_pass, side_table, line_scans}: how the probe's queries that left the one-load path ended; cleared"""
+        out = np.zeros(8, dtype=np.uint64)
+        _check(load_library().mfx_eval_debug_counters(self.h, out.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return {"first_pass": int(out[0]), "second_pass": int(out[1]), "side_table": int(out[2]), "line_scans": int(out[3])}
 
     def hist(self, seqs):
         r = HistResult()

@@ -1068,6 +1068,7 @@ extern "C" void mfx_eval_free(mfx_eval *ev) {
   if (ev->d_tile_ctr) (void)hipFree(ev->d_tile_ctr);
   if (ev->d_tile_partials) (void)hipFree(ev->d_tile_partials);
   if (ev->d_ovf) (void)hipFree(ev->d_ovf);
+  if (ev->d_dbg) (void)hipFree(ev->d_dbg);
   for (auto &p : ev->h_stage) if (p) (void)hipHostFree(p);
   for (auto &p : ev->h_pack) if (p) (void)hipHostFree(p);
   if (ev->pool) delete static_cast<WorkerPool *>(ev->pool);
@@ -1082,6 +1083,34 @@ extern "C" void mfx_eval_free(mfx_eval *ev) {
 }
 
 extern "C" uint32_t mfx_eval_nbins(const mfx_eval *ev) { return ev ? ev->nbins : 0; }
+
+// Test hook: from now on -hist launches of this evaluator run the DEBUG instance of the kernel where one exists (the compact
+// layout's specialised k = 21 kernel: same code with four counters in its probe) -- never what bench.py measures.
+extern "C" int mfx_eval_debug_enable(mfx_eval *ev, int on) {
+  if (!ev) return mfx_fail(MFX_E_INVAL, "mfx_eval_debug_enable: null argument");
+  DevGuard g(ev->device);
+  if (on && !ev->d_dbg) {
+    MFX_HIP(hipMalloc((void **)&ev->d_dbg, 8 * sizeof(uint64_t)));
+    MFX_HIP(hipMemset(ev->d_dbg, 0, 8 * sizeof(uint64_t)));
+  } else if (!on && ev->d_dbg) {
+    MFX_HIP(hipDeviceSynchronize());
+    (void)hipFree(ev->d_dbg);
+    ev->d_dbg = nullptr;
+  }
+  return MFX_OK;
+}
+
+// out[0] queries that were not in their first mini-bucket (first cooperative pass), [1] home line full of other k-mers (second
+// cooperative pass), [2] a saturated count (side table), [3] per-lane whole-line scans; the counters are read and cleared
+extern "C" int mfx_eval_debug_counters(mfx_eval *ev, uint64_t *out8) {
+  if (!ev || !out8) return mfx_fail(MFX_E_INVAL, "mfx_eval_debug_counters: null argument");
+  if (!ev->d_dbg) return mfx_fail(MFX_E_INVAL, "mfx_eval_debug_counters: not enabled (mfx_eval_debug_enable)");
+  DevGuard g(ev->device);
+  MFX_HIP(hipDeviceSynchronize());
+  MFX_HIP(hipMemcpy(out8, ev->d_dbg, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  MFX_HIP(hipMemset(ev->d_dbg, 0, 8 * sizeof(uint64_t)));
+  return MFX_OK;
+}
 
 extern "C" void mfx_getK(const mfx_kparams *kp, uint32_t readV, uint32_t asmV, double *readK, double *asmK, double *prob) {
   double rk, pr;
@@ -1196,6 +1225,7 @@ static int hist_launch(mfx_eval *ev, const mfx_seq *seq, uint64_t tile_begin, ui
   a.ks.counts = d_counts;
   a.ks.partials = ev->d_partials;
   a.ks.ovf = ev->d_ovf;
+  a.dbg = ev->d_dbg;
   MFX_HIP(ev->ix->wide() ? mfx_kw_hist(a, (int)std::min<uint64_t>((uint64_t)ev->grid, ntl), (hipStream_t)stream)
                           : mfx_k_hist(a, (int)std::min<uint64_t>((uint64_t)ev->grid, ntl), (hipStream_t)stream));
   if (chunk_of_total) MFX_HIP(hipMemsetAsync(ev->d_tile_ctr + ctr_slot, 0, sizeof(uint64_t), (hipStream_t)stream));   // re-arm the tile scheduler
@@ -1474,10 +1504,15 @@ static bool cpus_near(const void *addr, cpu_set_t *out) {
 // base never reaches the device (seq->bases_stale; unpacked on demand by mfx_seq_ensure_ascii).
 static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *const *bases, mfx_hist_result *out) {
   DevGuard g(ev->device);
-  const bool timing = getenv("MFX_STREAM_TIMING") && atoi(getenv("MFX_STREAM_TIMING"));
+  const int timing = getenv("MFX_STREAM_TIMING") ? atoi(getenv("MFX_STREAM_TIMING")) : 0;
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t_begin = now();
   double t_mark[6] = {0, 0, 0, 0, 0, 0};
+  // MFX_STREAM_TIMING=2: the timeline of every chunk (host clocks of the packers and of the enqueue loop, device events around
+  // its copy and behind its launch) -- what tools/stream_phases.py prints; costs a few events, never on by default
+  struct ChunkTimes { double pack_first = 0, pack_last = 0, wait_buf = 0, enq = 0; hipEvent_t c0 = nullptr, c1 = nullptr, k1 = nullptr; };
+  std::vector<ChunkTimes> ct;
+  hipEvent_t ev_base = nullptr;
   const size_t words = MFX_HIST_WORDS(ev->nbins, seq->ncontigs);
   const uint64_t T = seq->ntiles;
   // chunks grow from 8 MB to 128 MB of bases: the first tile reaches the kernel after ~0.2 ms, and the bulk runs in few,
@@ -1510,6 +1545,12 @@ static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *cons
   for (auto &d : done) d.store(0);
   int rc = MFX_OK;
   auto &R = ev->sr;
+  std::mutex ct_mu;
+  if (timing >= 2) {
+    ct.resize(chunks.size());
+    (void)hipEventCreate(&ev_base);
+    for (auto &x : ct) { (void)hipEventCreate(&x.c0); (void)hipEventCreate(&x.c1); (void)hipEventCreate(&x.k1); }
+  }
   auto cleanup = [&]() {
     stop.store(true);
     if (ev->pool) static_cast<WorkerPool *>(ev->pool)->wait();
@@ -1556,6 +1597,7 @@ static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *cons
       const uint64_t nw = (c.hi - c.lo) / 32, w0 = nw * w / W, w1 = nw * (w + 1) / W;
       uint64_t *codes = reinterpret_cast<uint64_t *>(stage[ci % NB]);
       uint32_t *valid = reinterpret_cast<uint32_t *>(stage[ci % NB] + (size_t)STAGE_W * 8);
+      const double t_p0 = timing >= 2 ? now() : 0.0;
       if (w1 > w0) {
         memset(codes + w0, 0, (w1 - w0) * 8);                // gaps between contigs and the words behind a contig's end
         memset(valid + w0, 0, (w1 - w0) * 4);
@@ -1565,6 +1607,12 @@ static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *cons
           const uint64_t s = std::max(my_lo, at), e = std::min(my_hi, at + pc.n);
           if (e > s) mfx_pack_bases(reinterpret_cast<const uint8_t *>(bases[pc.contig]) + pc.pos + (s - at), e - s, codes + (s - c.lo) / 32, valid + (s - c.lo) / 32);
         }
+      }
+      if (timing >= 2) {
+        const double t_p1 = now();
+        std::lock_guard<std::mutex> lk(ct_mu);
+        if (ct[ci].pack_first == 0 || t_p0 < ct[ci].pack_first) ct[ci].pack_first = t_p0;
+        if (t_p1 > ct[ci].pack_last) ct[ci].pack_last = t_p1;
       }
       done[ci].fetch_add(1, std::memory_order_release);
     }
@@ -1597,6 +1645,8 @@ static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *cons
   STREAMED_HIP(hipEventRecord(R.kdone, ks));
   STREAMED_HIP(hipStreamWaitEvent(R.kern[1], R.kdone, 0));          // the second kernel stream starts behind the clears
   if ((rc = ensure_tile_partials(ev, T)) != MFX_OK) { cleanup(); return rc; }
+  double t_base_host = 0;
+  if (timing >= 2) { (void)hipEventRecord(ev_base, cs); (void)hipEventSynchronize(ev_base); t_base_host = now(); }
 
   for (size_t ci = 0; ci < chunks.size(); ++ci) {
     const Chunk &c = chunks[ci];
@@ -1606,12 +1656,15 @@ static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *cons
       STREAMED_HIP(hipEventSynchronize(up[(ci - 1) % NB]));
       allowed.store((int64_t)(ci - 1 + NB), std::memory_order_release);
     }
+    if (timing >= 2) ct[ci].wait_buf = now();
     while (done[ci].load(std::memory_order_acquire) < W) std::this_thread::yield();
+    if (timing >= 2) { ct[ci].enq = now(); (void)hipEventRecord(ct[ci].c0, cs); }
     if (c.hi > c.lo) {
       const uint64_t nw = (c.hi - c.lo) / 32;
       STREAMED_HIP(hipMemcpyAsync(seq->d_codes + c.lo / 32, stage[b], nw * 8, hipMemcpyHostToDevice, cs));
       STREAMED_HIP(hipMemcpyAsync(seq->d_valid + c.lo / 32, stage[b] + (size_t)STAGE_W * 8, nw * 4, hipMemcpyHostToDevice, cs));
     }
+    if (timing >= 2) (void)hipEventRecord(ct[ci].c1, cs);
     STREAMED_HIP(hipEventRecord(up[b], cs));
     // two kernel streams (and tile counters) alternate: the first blocks of a launch fill the CUs the previous launch's
     // last blocks leave behind, instead of waiting for its tail
@@ -1619,6 +1672,7 @@ static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *cons
     STREAMED_HIP(hipStreamWaitEvent(kst, up[b], 0));
     rc = hist_launch(ev, seq, c.t0, c.t1, 0, 1, 0, d_counts, d_kover, kst, T, (int)(ci & 1));
     if (rc) { cleanup(); return rc; }
+    if (timing >= 2) (void)hipEventRecord(ct[ci].k1, kst);
   }
   t_mark[2] = now();
   // a sequence-only index answers for the k-mers of ONE sequence: the content digest of what was just uploaded is taken on
@@ -1651,9 +1705,25 @@ static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *cons
   cleanup();
   t_mark[5] = now();
   if (timing)
-    fprintf(stderr, "[mfx stream] %zu chunks: setup %.2f ms, spawn %.2f, enqueue loop %.2f, drain %.2f, result %.2f, cleanup %.2f\n", chunks.size(),
+    fprintf(stderr, "[mfx stream] %zu chunks: setup %.2f ms, spawn %.2f, enqueue loop %.2f, drain %.2f, result %.2f, cleanup %.2f; total %.2f ms%s\n", chunks.size(),
             (t_mark[0] - t_begin) * 1e3, (t_mark[1] - t_mark[0]) * 1e3, (t_mark[2] - t_mark[1]) * 1e3, (t_mark[3] - t_mark[2]) * 1e3,
-            (t_mark[4] - t_mark[3]) * 1e3, (t_mark[5] - t_mark[4]) * 1e3);
+            (t_mark[4] - t_mark[3]) * 1e3, (t_mark[5] - t_mark[4]) * 1e3, (t_mark[5] - t_begin) * 1e3, bind ? "; encoders bound to the source's NUMA node" : "");
+  if (timing >= 2) {
+    // all times in ms since the function was entered; device times are placed on the host clock through ev_base
+    fprintf(stderr, "[mfx stream] chunk   Mbases  pack:first..last   buf-wait   enqueue   copy:start..end   kernel-end   (ms since entry; %u packer threads)\n", W);
+    for (size_t ci = 0; ci < chunks.size(); ++ci) {
+      float a = 0, b2 = 0, k2 = 0;
+      (void)hipEventElapsedTime(&a, ev_base, ct[ci].c0);
+      (void)hipEventElapsedTime(&b2, ev_base, ct[ci].c1);
+      (void)hipEventElapsedTime(&k2, ev_base, ct[ci].k1);
+      const double off = (t_base_host - t_begin) * 1e3;
+      fprintf(stderr, "[mfx stream] %5zu %8.1f %8.2f %8.2f %10.2f %9.2f %9.2f %8.2f %11.2f\n", ci, (chunks[ci].hi - chunks[ci].lo) / 1e6,
+              (ct[ci].pack_first - t_begin) * 1e3, (ct[ci].pack_last - t_begin) * 1e3, (ct[ci].wait_buf - t_begin) * 1e3, (ct[ci].enq - t_begin) * 1e3,
+              off + a, off + b2, off + k2);
+    }
+    for (auto &x : ct) { (void)hipEventDestroy(x.c0); (void)hipEventDestroy(x.c1); (void)hipEventDestroy(x.k1); }
+    (void)hipEventDestroy(ev_base);
+  }
   if (rc) return rc;
   rc = result_take_overflow(ev, novf, out);
   if (rc) mfx_hist_result_free(out);

@@ -194,6 +194,7 @@ struct mfx_eval {
   double   *d_tile_partials = nullptr; // per-(tile,wave) koverCpy of the last launch + the chunk sums behind them
   uint64_t  tile_partials_cap = 0;   // doubles allocated
   uint64_t *d_ovf = nullptr;         // [0] count, [1..] records
+  uint64_t *d_dbg = nullptr;         // [8] probe path counters of the DEBUG instance of the -hist kernel (mfx_eval_debug_enable); null: the measured instance runs
   uint8_t  *h_stage[2] = {nullptr, nullptr};   // pinned staging of the streamed upload (pageable sources), kept between calls
   size_t    h_stage_bytes = 0;
   void     *pool = nullptr;                             // host threads parked between streamed runs (mfx_api.cpp: WorkerPool)

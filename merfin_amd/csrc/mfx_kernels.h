@@ -32,6 +32,7 @@ struct mfx_hist_args {
   //   part_n  > 1 : block-cyclic share of rank part_rank: tile = ((li >> part_shift) * part_n + part_rank << part_shift) + (li & mask)
   uint64_t        n_logical;
   uint32_t        part_rank, part_n, part_shift;
+  uint64_t       *dbg = nullptr;      // non-null: the debug instance of the kernel counts the probe's endings here (mfx_eval_debug_counters)
   mfx_kstar_args  ks;
 };
 

@@ -1177,7 +1177,10 @@ __device__ __forceinline__ void mfx_group_lookup8(const mfx_table_view &c, mfx_m
 template <int B>
 __device__ __forceinline__ void mfx_lane_lookup8(const mfx_table_view &c, mfx_mailbox &M, const uint64_t (&key)[B], const uint64_t (&krc)[B],
                                                  const bool (&ok)[B], uint32_t (&rv)[B], uint32_t (&av)[B], const uint32_t *pre = nullptr,
-                                                 const uint32_t *pre_b0 = nullptr) {
+                                                 const uint32_t *pre_b0 = nullptr, unsigned long long *dbg = nullptr) {
+  // dbg (the DEBUG instance of the -hist kernel only, mfx_hist_args::dbg): how many queries left the one-load fast path, and how --
+  // [0] not in their first mini-bucket (first cooperative pass), [1] home line full of other k-mers (second cooperative pass),
+  // [2] a saturated count (side table), [3] per-lane whole-line scans; tests assert that a world exercises every ending
   const uint32_t tid = threadIdx.x, sub16 = (tid & 7u) << 4, lane = tid & 63u, wbase = tid & ~63u;
   const uint4 *const slots0 = reinterpret_cast<const uint4 *>(c.slots);
   uint32_t line[B];
@@ -1230,6 +1233,7 @@ __device__ __forceinline__ void mfx_lane_lookup8(const mfx_table_view &c, mfx_ma
     }
     nq += (uint32_t)__popcll(m);
   }
+  if (dbg && nq && lane == 0u) atomicAdd(&dbg[0], (unsigned long long)nq);
   if (nq) {                                                    // wave-uniform
     mfx_wave_handoff();
     if (nq > 64u) nq = 64u;
@@ -1298,6 +1302,7 @@ __device__ __forceinline__ void mfx_lane_lookup8(const mfx_table_view &c, mfx_ma
         rec[2] = (uint32_t)mfx_probe_line(c, pr, 1u);          // (candidate lines 0 .. MFX_MZ_REGION-1 follow the minimizer's line)
         rec[3] = 2u;
         again = true;
+        if (dbg) atomicAdd(&dbg[1], 1ull);
       }
     if (__any(again)) {
       mfx_wave_handoff();
@@ -1318,6 +1323,7 @@ __device__ __forceinline__ void mfx_lane_lookup8(const mfx_table_view &c, mfx_ma
     if (sj >= 0) {
       uint2 x = make_uint2(0u, 0u);
       bool have = scode == 0xfeu;
+      if (dbg) atomicAdd(&dbg[have ? 2 : 3], 1ull);
       if (!have) {
         const uint2 fd = mfx_c_find_lean(c, skey, scode == 0xfdu ? 2u : 0u);
         have = fd.x != 0u;
@@ -1337,9 +1343,11 @@ __device__ __forceinline__ void mfx_lane_lookup8(const mfx_table_view &c, mfx_ma
 #if MFX_V_LANEPROBE
 #define MFX_COMPACT_LOOKUP(t, MB, key, krc, ok, rv, av) mfx_lane_lookup8<MFX_BATCH>(t, MB, key, krc, ok, rv, av)
 #define MFX_COMPACT_LOOKUP_PRE(t, MB, key, krc, ok, rv, av, pre, pb0) mfx_lane_lookup8<MFX_BATCH>(t, MB, key, krc, ok, rv, av, pre, pb0)
+#define MFX_COMPACT_LOOKUP_DBG(t, MB, key, krc, ok, rv, av, pre, pb0, dbg) mfx_lane_lookup8<MFX_BATCH>(t, MB, key, krc, ok, rv, av, pre, pb0, dbg)
 #else
 #define MFX_COMPACT_LOOKUP(t, MB, key, krc, ok, rv, av) mfx_group_lookup8<MFX_BATCH>(t, MB, key, krc, ok, rv, av)
 #define MFX_COMPACT_LOOKUP_PRE(t, MB, key, krc, ok, rv, av, pre, pb0) mfx_group_lookup8<MFX_BATCH>(t, MB, key, krc, ok, rv, av)
+#define MFX_COMPACT_LOOKUP_DBG(t, MB, key, krc, ok, rv, av, pre, pb0, dbg) mfx_group_lookup8<MFX_BATCH>(t, MB, key, krc, ok, rv, av)
 #endif
 
 // k-mer starting at tile position p; returns validity (all k bases ACGT)
@@ -1436,7 +1444,8 @@ constexpr int MFX_BATCH = MFX_V_BATCH;          // queries per lane and cooperat
 #ifndef MFX_V_MINBLOCKS
 #define MFX_V_MINBLOCKS 4             // blocks per CU the register allocation aims at (tools/ab_build.sh -DMFX_V_MINBLOCKS=3: A/B)
 #endif
-template <bool CANON, bool COMPACT, int KF, int WF, int TF>
+// DBG: the same kernel with the probe's path counters (mfx_hist_args::dbg, mfx_lane_lookup8); never the measured instance
+template <bool CANON, bool COMPACT, int KF, int WF, int TF, bool DBG = false>
 __global__ __launch_bounds__(MFX_BLOCK, MFX_V_MINBLOCKS) void mfx_hist_kernel(mfx_hist_args a) {
   __shared__ mfx_tile_lds L;
   __shared__ mfx_mailbox MB;
@@ -1521,7 +1530,8 @@ __global__ __launch_bounds__(MFX_BLOCK, MFX_V_MINBLOCKS) void mfx_hist_kernel(mf
           key[j] = f; key2[j] = r;
         }
       }
-      if (wave_lines) MFX_COMPACT_LOOKUP_PRE(a.t, MB, key, key2, ok, rv, av, pre, pb0);
+      if (wave_lines && DBG) MFX_COMPACT_LOOKUP_DBG(a.t, MB, key, key2, ok, rv, av, pre, pb0, reinterpret_cast<unsigned long long *>(a.dbg));
+      else if (wave_lines) MFX_COMPACT_LOOKUP_PRE(a.t, MB, key, key2, ok, rv, av, pre, pb0);
       else if (COMPACT) MFX_COMPACT_LOOKUP(a.t, MB, key, key2, ok, rv, av);
       else mfx_group_lookup<MFX_BATCH>(a.t, MB, key, key2, ok, rv, av);
       if (!CANON) {
@@ -2185,7 +2195,8 @@ hipError_t mfx_k_hist(const mfx_hist_args &a, int grid, hipStream_t st) {
   // MFX_DEBUG_DYN_LDS: extra dynamic LDS per block, an occupancy knob for experiments only
   static const unsigned dyn = getenv("MFX_DEBUG_DYN_LDS") ? (unsigned)atoi(getenv("MFX_DEBUG_DYN_LDS")) : 0u;
   static const bool generic = getenv("MFX_HIST_GENERIC") && atoi(getenv("MFX_HIST_GENERIC"));     // A/B, tests: never the specialised instances
-  if (a.canonical && a.t.compact && a.t.k == 21 && a.t.mz_w == 4 && a.t.mz_t == 6 && !generic) mfx_hist_kernel<true, true, 21, 4, 6><<<grid, MFX_BLOCK, dyn, st>>>(a);
+  if (a.dbg && a.canonical && a.t.compact && a.t.k == 21 && a.t.mz_w == 4 && a.t.mz_t == 6 && !generic) mfx_hist_kernel<true, true, 21, 4, 6, true><<<grid, MFX_BLOCK, dyn, st>>>(a);
+  else if (a.canonical && a.t.compact && a.t.k == 21 && a.t.mz_w == 4 && a.t.mz_t == 6 && !generic) mfx_hist_kernel<true, true, 21, 4, 6><<<grid, MFX_BLOCK, dyn, st>>>(a);
   else if (a.canonical && a.t.compact) mfx_hist_kernel<true, true, 0, 0, 0><<<grid, MFX_BLOCK, dyn, st>>>(a);
   else if (a.canonical)                mfx_hist_kernel<true, false, 0, 0, 0><<<grid, MFX_BLOCK, dyn, st>>>(a);
   else if (a.t.compact)                mfx_hist_kernel<false, true, 0, 0, 0><<<grid, MFX_BLOCK, dyn, st>>>(a);

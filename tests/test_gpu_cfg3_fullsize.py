@@ -116,3 +116,67 @@ def test_cfg3_hist_kernel_equals_dump_kernel_plus_host_kstar(world, golden_dir):
     assert ru[len(undr):].sum() == 0 and ro[len(over):].sum() == 0
     kover = float(((1.0 - rK[under] / aK[under]) * pr[under]).sum())
     assert res.koverCpy == pytest.approx(kover, rel=1e-9)
+
+
+def test_cfg3_sequence_only_compact_index_equals_the_full_table(world, golden_dir):
+    """THE BENCHMARKED PATH AT THE BENCHMARKED SIZE.  bench.py (and `merfin -hist`) evaluate on the sequence-only COMPACT index
+    (mfx_index_create_for_seq: 8-byte slots, mod-minimizer placement, load factor 0.225, kernel instance <true, true, 21, 4, 6>),
+    the tests above on the full table (kernel <true, false, 0, 0, 0>).  Both answer value() of the sequence's k-mers identically
+    (merfin-histogram.C:54-91 asks for nothing else), so on the same 3 Gb world: bins, kasm, kmissing and the per-contig counters
+    bit-equal, koverCpy to 1e-12; then on the compact index the 8-way block-cyclic shard sum (what bench.py --gpus 8 deals) and the
+    streamed evaluation (value_8d's path: packed upload under the kernel) equal the resident single launch.  The workload is a pure
+    function of the seed: kmissing and koverCpy are pinned to the numbers every bench.py run of either index kind prints.
+    Runs LAST in this module: it releases the module's full table (two 100-200 GB tables do not fit one GPU)."""
+    m, st, torch, ix, seqs, asm, info = world
+    import gc
+    kp = m.KParams.from_file(26.0, os.path.join(golden_dir, "example_lookup_table.txt"))
+    ev = m.Evaluator(ix, kp)
+    full = ev.hist(seqs)
+    ref = dict(kasm=full.kasm, kmissing=full.kmissing, undr=full.undr().copy(), over=full.over().copy(), ckasm=full.contig_kasm().copy(),
+               ckmis=full.contig_kmissing().copy(), kover=full.koverCpy)
+    if BASES == 3_000_000_000:
+        assert ref["kmissing"] == 15444757
+        assert ref["kover"] == pytest.approx(18263623.1582698, rel=1e-12)
+    host = [a.cpu().numpy() for a in asm]                       # the streamed leg hands over host buffers
+    del full, ev
+    # release the full table: the fixture's tuple keeps references, so the device memory is freed through the handle
+    ix.close()
+    seqs.close() if hasattr(seqs, "close") else None
+    del seqs
+    gc.collect()
+    torch.cuda.empty_cache()
+
+    ix2, seqs2, asm2, info2 = st.build_world(m, BASES, k=21, lam=26.0, ncontigs=24, seq_only=True)
+    assert info2["seq_only"] and info2["compact"]
+    for a, b in zip(asm, asm2):
+        assert a.numel() == b.numel()
+    ev2 = m.Evaluator(ix2, kp)
+
+    def same(r, what):
+        assert (r.kasm, r.kmissing) == (ref["kasm"], ref["kmissing"]), what
+        np.testing.assert_array_equal(r.undr(), ref["undr"], err_msg=what)
+        np.testing.assert_array_equal(r.over(), ref["over"], err_msg=what)
+        np.testing.assert_array_equal(r.contig_kasm(), ref["ckasm"], err_msg=what)
+        np.testing.assert_array_equal(r.contig_kmissing(), ref["ckmis"], err_msg=what)
+        assert r.koverCpy == pytest.approx(ref["kover"], rel=1e-12), what
+
+    whole = ev2.hist(seqs2)
+    same(whole, "sequence-only compact index, one launch")
+    # the 8-way block-cyclic shards of the compact index, one after the other on this GPU
+    words = m.hist_words(ev2.nbins, seqs2.ncontigs)
+    s = torch.cuda.current_stream().cuda_stream
+    counts = torch.zeros(words, dtype=torch.int64, device="cuda")
+    kover = torch.zeros(1, dtype=torch.float64, device="cuda")
+    for r in range(8):
+        ev2.hist_launch_cyclic(seqs2, r, 8, counts, kover, block_tiles=256, stream=s)
+    torch.cuda.synchronize()
+    same(_image_result(m, ev2, seqs2, counts, kover), "8-way block-cyclic shards of the compact index")
+    del counts, kover
+    # value_8d's path: the assembly handed over as host buffers, packed by the host threads, uploaded under the kernel
+    s2 = m.Sequences.create([int(a.numel()) for a in asm], device=0)
+    streamed = ev2.hist_streamed(s2, host)
+    same(streamed, "streamed evaluation on the compact index")
+    assert streamed.koverCpy == whole.koverCpy                  # bit-identical however the upload was cut
+    del ev2, ix2, seqs2, asm2, s2
+    gc.collect()
+    torch.cuda.empty_cache()
