@@ -226,6 +226,10 @@ uint32_t  mfx_eval_nbins(const mfx_eval *ev);
  * exists (compact layout, k = 21) and count how its probe's queries ended: out8[0] not in the first mini-bucket (first
  * cooperative pass), [1] home line full (second cooperative pass), [2] saturated count (side table), [3] per-lane
  * whole-line scans.  mfx_eval_debug_counters reads and clears them.  Never the measured configuration. */
+/* Diagnostic (no reference counterpart): random 128-byte lines per second this device's HBM delivers to independent
+ * 16-byte loads over a table of table_bytes (allocated and released by the call): the roof of the index probe on this
+ * box; bench.py reports the -hist kernel's line rate against it (roofline.gather_ceiling). */
+int       mfx_diag_gather_rate(int device, uint64_t table_bytes, double *lines_per_s);
 int       mfx_eval_debug_enable(mfx_eval *ev, int on);
 int       mfx_eval_debug_counters(mfx_eval *ev, uint64_t *out8);
 

@@ -74,6 +74,7 @@ SYMBOLS = [
     "mfx_index_image_header", "mfx_index_create_from_header", "mfx_index_device_image", "mfx_index_commit",
     "mfx_seq_upload", "mfx_seq_from_device", "mfx_seq_free", "mfx_seq_num_contigs", "mfx_seq_num_bases",
     "mfx_seq_num_tiles",
+    "mfx_diag_gather_rate",
     "mfx_eval_create", "mfx_eval_free", "mfx_eval_nbins", "mfx_eval_debug_enable", "mfx_eval_debug_counters", "mfx_getK", "mfx_getKmetric", "mfx_histoQV",
     "mfx_hist_run", "mfx_hist_result_free", "mfx_hist_launch", "mfx_hist_launch_cyclic", "mfx_hist_result_from_counts",
     "mfx_hist_take_overflow", "mfx_hist_report",
@@ -160,6 +161,7 @@ def load_library():
     L.mfx_eval_free.argtypes = [vp]
     L.mfx_eval_nbins.restype = C.c_uint32
     L.mfx_eval_nbins.argtypes = [vp]
+    L.mfx_diag_gather_rate.argtypes = [C.c_int, C.c_uint64, C.POINTER(C.c_double)]
     L.mfx_eval_debug_enable.argtypes = [vp, C.c_int]
     L.mfx_eval_debug_counters.argtypes = [vp, u64p]
     L.mfx_getK.argtypes = [C.POINTER(_KP), C.c_uint32, C.c_uint32, f64p, f64p, f64p]
@@ -785,6 +787,13 @@ class Comm:
 
     def __del__(self):
         self.close()
+
+
+def gather_rate(table_bytes, device=0):
+    """diagnostic: random 128-byte lines per second the device's HBM delivers over a table of that size (mfx_diag_gather_rate)"""
+    out = C.c_double(0.0)
+    _check(load_library().mfx_diag_gather_rate(device, int(table_bytes), C.byref(out)))
+    return out.value
 
 
 class Evaluator:

@@ -20,6 +20,7 @@
 #include <atomic>
 #include <chrono>
 #include <memory>
+#include <map>
 #include <mutex>
 #include <functional>
 #include <condition_variable>
@@ -53,6 +54,27 @@ int mfx_fail(int code, const char *fmt, ...) {
 extern "C" const char *mfx_last_error(void) { return g_err; }
 extern "C" int mfx_last_error_code(void) { return g_err_code; }
 extern "C" const char *mfx_version(void) { return "merfin_amd 0.2 (gfx950)"; }
+
+// Diagnostic (no reference counterpart): random 128-byte lines per second this device's HBM delivers to independent
+// 16-byte loads over a table of `table_bytes` (allocated and released here) -- the roof of the index probe on THIS box.
+extern "C" int mfx_diag_gather_rate(int device, uint64_t table_bytes, double *lines_per_s) {
+  if (!lines_per_s || table_bytes < (1ull << 20)) return mfx_fail(MFX_E_INVAL, "mfx_diag_gather_rate: bad argument");
+  if (device < 0 || device >= mfx_device_count()) return mfx_fail(MFX_E_NODEVICE, "HIP device %d not available", device);
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  MFX_HIP(hipSetDevice(device));
+  void *t = nullptr;
+  uint64_t *scratch = nullptr;
+  hipError_t e = hipMalloc(&t, table_bytes);
+  if (e == hipSuccess) e = hipMalloc((void **)&scratch, 8);
+  if (e == hipSuccess) e = hipMemset(t, 0x5a, table_bytes);
+  if (e == hipSuccess) e = mfx_k_gather_rate(t, table_bytes / MFX_ALIGN, scratch, lines_per_s, nullptr);
+  if (t) (void)hipFree(t);
+  if (scratch) (void)hipFree(scratch);
+  if (prev >= 0) (void)hipSetDevice(prev);
+  if (e != hipSuccess) { (void)hipGetLastError(); return mfx_fail(e == hipErrorOutOfMemory ? MFX_E_NOMEM : MFX_E_HIP, "mfx_diag_gather_rate: %s", hipGetErrorString(e)); }
+  return MFX_OK;
+}
 
 extern "C" int mfx_device_count(void) {
   int n = 0;
@@ -186,11 +208,20 @@ uint64_t lines_auto(uint64_t capacity_kmers, double budget_bytes, uint32_t slots
 }
 
 // does a sequence-only index of k-mers of this size take the compact layout?  (MFX_SEQ_COMPACT=0: never -- A/B, tests)
+// k <= 21: the slot holds the k-mer; 22 <= k <= 31: its quotient (mfx_kernels.hip: mfx_q_place), which needs the default
+// placement (4 windows, mod-minimizer) and the per-lane probe
 bool seq_compact(int k) {
   const char *e = getenv("MFX_SEQ_COMPACT");
   const char *hm = getenv("MFX_HOME_MODE");
-  return k <= MFX_MAX_K_COMPACT && !(e && atoi(e) == 0) && !(hm && strcmp(hm, "plain") == 0);
+  if (k > MFX_MAX_K_COMPACT || (e && atoi(e) == 0) || (hm && strcmp(hm, "plain") == 0)) return false;
+  if (k > MFX_MAX_K_DIRECT) {
+    const char *ws = getenv("MFX_MZ_W"), *mm = getenv("MFX_MZ_MOD"), *q = getenv("MFX_SEQ_QUOT");
+    if ((ws && atoi(ws) != MFX_MZ_W_COMPACT) || (mm && atoi(mm) == 0) || (q && atoi(q) == 0) || !mfx_k_quot_supported()) return false;
+  }
+  return true;
 }
+// the fewest lines a quotient table may have: the key field keeps 2m - floor(log2(nlines)) + 9 bits of a k-mer (m = k - 3) in 40
+uint64_t quot_min_lines(int k) { return k > MFX_MAX_K_DIRECT ? 1ull << (2 * (k - 3) - 31) : 0; }
 
 // Side table of a compact index (exact counts of the saturated fields, 16-byte slots at load factor <= 0.5): room for
 // 1/64 of the capacity -- a count saturates at 2047, i.e. beyond ~70 copies at 30x coverage -- and never fewer than
@@ -233,6 +264,9 @@ mfx_table_view mfx_index::view() const {
   v.wide = wide() ? 1 : 0;
   v.seq_only = seq_only ? 1 : 0;
   v.compact = compact ? 1 : 0;
+  v.quot = quot ? 1 : 0;
+  v.qshift = 0;
+  for (uint64_t x = nlines; x > 1; x >>= 1) ++v.qshift;      // floor(log2(nlines))
   v.side = compact ? d_slots + nlines * MFX_SLOTS_LINE : nullptr;      // the side table follows the main lines
   v.side_nlines = side_nlines;
   return v;
@@ -245,7 +279,7 @@ extern "C" double mfx_index_estimate_gb(int k, uint64_t capacity_kmers) {
 extern "C" double mfx_index_estimate_gb_for_seq(int k, uint64_t capacity_kmers) {
   if (k > MFX_MAX_K_NARROW) return mfx_index_estimate_gb(k, capacity_kmers);
   if (!seq_compact(k)) return (double)lines_for(capacity_kmers, MFX_SLOTS_LINE) * MFX_ALIGN / 1e9;
-  return (double)(lines_for(capacity_kmers, MFX_CSLOTS_LINE) + side_lines_for(capacity_kmers)) * MFX_ALIGN / 1e9;
+  return (double)(std::max(lines_for(capacity_kmers, MFX_CSLOTS_LINE), quot_min_lines(k)) + side_lines_for(capacity_kmers)) * MFX_ALIGN / 1e9;
 }
 
 static mfx_index *index_create(int k, uint64_t capacity_kmers, double max_gb, int device, bool seq_only);
@@ -292,6 +326,7 @@ static mfx_index *index_create(int k, uint64_t capacity_kmers, double max_gb, in
   ix->capacity_kmers = capacity_kmers;
   ix->seq_only = seq_only;
   ix->compact = compact;
+  ix->quot = compact && k > MFX_MAX_K_DIRECT;
   ix->side_nlines = compact ? side_lines_for(capacity_kmers) : 0;
   {
     size_t free_b = 0, total_b = 0;
@@ -300,6 +335,7 @@ static mfx_index *index_create(int k, uint64_t capacity_kmers, double max_gb, in
     if (max_gb > 0) budget = budget > 0 ? std::min(budget, max_gb * 1e9) : max_gb * 1e9;
     if (budget > 0) budget = std::max(1.0, budget - (double)ix->side_nlines * MFX_ALIGN);
     ix->nlines = lines_auto(capacity_kmers, budget, slots_line, seq_only);
+    if (ix->quot) ix->nlines = std::max(ix->nlines, quot_min_lines(k));     // (k = 31: 4 GB of table at least; a small genome's table is mostly air)
   }
   if (ix->nlines >= (1ull << 32)) {        // line numbers are 32-bit on the device (550 GB of table: beyond one GPU anyway)
     mfx_fail(MFX_E_NOMEM, "Not enough memory to load databases.  %lu k-mers need %.0f GB on one GPU; shard the index (mfx_index_set_shard).",
@@ -326,10 +362,10 @@ static mfx_index *index_create(int k, uint64_t capacity_kmers, double max_gb, in
     }
   }
   hipError_t e = hipMalloc((void **)&ix->d_slots, ix->total_lines() * MFX_ALIGN);
-  if (e != hipSuccess && ix->nlines > lines_for(capacity_kmers, slots_line)) {
+  if (e != hipSuccess && ix->nlines > std::max(lines_for(capacity_kmers, slots_line), quot_min_lines(ix->quot ? k : 0))) {
     // the roomier table did not fit after all (fragmentation, another process): fall back to the smallest one
     (void)hipGetLastError();
-    ix->nlines = lines_for(capacity_kmers, slots_line);
+    ix->nlines = std::max(lines_for(capacity_kmers, slots_line), quot_min_lines(ix->quot ? k : 0));
     e = hipMalloc((void **)&ix->d_slots, ix->total_lines() * MFX_ALIGN);
   }
   if (e != hipSuccess) {
@@ -1466,7 +1502,7 @@ extern "C" void mfx_pack_bases(const uint8_t *src, uint64_t n, uint64_t *codes, 
 
 // The CPUs of the NUMA node that holds `addr` (two-socket hosts: an encoder thread on the other socket reads the assembly over
 // the inter-socket links).  false: unknown (no such call in this container, one node, too few of its CPUs allowed) -- no binding.
-static bool cpus_near(const void *addr, cpu_set_t *out) {
+static bool cpus_near(const void *addr, cpu_set_t *out, int *node_out = nullptr) {
   const char *e = getenv("MFX_NUMA_BIND");
   if (e && atoi(e) == 0) return false;
   int node = -1;
@@ -1492,10 +1528,64 @@ static bool cpus_near(const void *addr, cpu_set_t *out) {
     p = *q == ',' ? q + 1 : q;
     if (*q != ',' ) break;
   }
+  if (node_out) *node_out = node;
   if ((unsigned)CPU_COUNT(&near) < std::max(1u, mfx_host_threads())) return false;
   if (CPU_COUNT(&near) == CPU_COUNT(&allowed)) return false;  // one node: nothing to choose
   *out = near;
   return true;
+}
+
+// Where the W encoder threads of a streamed run go.  A core reads memory through its CCD's link to the I/O die, and a few
+// threads saturate one link (EPYC 9575F, tools/native/pack_bench.cpp: 8 threads in one CCD encode 55 GB/s of bases, 8 threads in 8
+// CCDs 130-147 GB/s), so WHERE the scheduler happens to put the threads decides the rate of the whole pipeline: 16 threads that
+// share two CCDs encode 99 GB/s, spread over the CCDs 145-193 GB/s.  MFX_PACK_PLACE:
+//   spread (default) worker w is pinned to L3 domain w mod n of the source's NUMA node (every node if that is unknown), on the
+//                    first hardware thread of its cores;   node  the CPUs of the source's node (the round-3 behaviour);
+//   all              L3 domains of every node;   os  no binding
+struct PackTopology {
+  std::vector<std::vector<int>> l3_of_node[8];        // [node][domain] -> primary hardware threads
+  cpu_set_t allowed;
+  bool ok = false;
+  PackTopology() {
+    CPU_ZERO(&allowed);
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return;
+    auto read_int = [](const char *p) { int v = -1; if (FILE *f = fopen(p, "r")) { if (fscanf(f, "%d", &v) != 1) v = -1; fclose(f); } return v; };
+    std::map<std::pair<int, int>, std::vector<int>> dom;
+    for (int c = 0; c < CPU_SETSIZE; ++c) {
+      if (!CPU_ISSET(c, &allowed)) continue;
+      char p[160];
+      snprintf(p, sizeof(p), "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", c);
+      if (read_int(p) != c) continue;                  // a second hardware thread of its core
+      snprintf(p, sizeof(p), "/sys/devices/system/cpu/cpu%d/cache/index3/id", c);
+      const int l3 = read_int(p);
+      int node = -1;
+      for (int nd = 0; nd < 8 && node < 0; ++nd) {
+        snprintf(p, sizeof(p), "/sys/devices/system/cpu/cpu%d/node%d", c, nd);
+        if (access(p, F_OK) == 0) node = nd;
+      }
+      if (l3 < 0) continue;
+      dom[{node < 0 ? 0 : node, l3}].push_back(c);
+    }
+    for (auto &kv : dom) l3_of_node[kv.first.first].push_back(kv.second);
+    size_t n = 0;
+    for (auto &v : l3_of_node) n += v.size();
+    ok = n > 1;
+  }
+};
+static const PackTopology &pack_topology() { static PackTopology t; return t; }
+
+// the CPU set worker w of W runs on under `mode` (0 os, 1 node, 2 spread, 3 all); false: leave the thread where it is allowed
+static bool pack_cpus(int mode, int node, const cpu_set_t *near, unsigned w, cpu_set_t *out) {
+  const PackTopology &T = pack_topology();
+  if (mode == 0) { *out = T.allowed; return CPU_COUNT(&T.allowed) > 0; }
+  if (mode == 1) { if (near) { *out = *near; return true; } *out = T.allowed; return CPU_COUNT(&T.allowed) > 0; }
+  if (!T.ok) { *out = T.allowed; return CPU_COUNT(&T.allowed) > 0; }
+  std::vector<const std::vector<int> *> doms;
+  if (mode == 2 && node >= 0 && node < 8) for (auto &d : T.l3_of_node[node]) doms.push_back(&d);
+  if (doms.empty()) for (auto &nd : T.l3_of_node) for (auto &d : nd) doms.push_back(&d);
+  CPU_ZERO(out);
+  for (int c : *doms[w % doms.size()]) CPU_SET(c, out);
+  return CPU_COUNT(out) > 0;
 }
 
 // The streamed -hist with the assembly crossing PCIe PACKED (0.375 B per base): host threads encode every chunk into
@@ -1523,11 +1613,26 @@ static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *cons
   const uint64_t plane_words = seq->buf_bytes / 32 + (MFX_TILE + 64) / 32 + 1;   // a tile reads 130 words from its first one
   struct Chunk { std::vector<Piece> pieces; uint64_t lo = 0, hi = 0, t0 = 0, t1 = 0; };
   std::vector<Chunk> chunks;
-  for (uint64_t t0 = 0, sz = CH0; t0 < T; sz = std::min(CH, sz * 2)) {
+  // ... and shrink again at the end (64, 32, 16 MB): what follows the last upload is the evaluation of the last chunk alone
+  std::vector<uint64_t> cuts;                                 // chunk boundaries, ascending
+  {
+    std::vector<uint64_t> tail;                               // sizes of the closing chunks, last first
+    uint64_t back = 0;
+    for (uint64_t sz = 2 * CH0; sz < CH && back + sz + CH <= T / 2; sz *= 2) { tail.push_back(sz); back += sz; }
+    const uint64_t front_end = T - back;
+    uint64_t t0 = 0;
+    for (uint64_t sz = CH0; t0 < front_end; sz = std::min(CH, sz * 2)) {
+      uint64_t t1 = std::min(front_end, t0 + sz);
+      if (front_end - t1 < sz / 2) t1 = front_end;            // no short launch in the middle (at most 1.5 x CH tiles)
+      cuts.push_back(t1);
+      t0 = t1;
+    }
+    for (size_t i = tail.size(); i-- > 0;) { t0 += tail[i]; cuts.push_back(t0); }
+  }
+  for (uint64_t t0 = 0, ci = 0; ci < cuts.size(); ++ci) {
     Chunk c;
     c.t0 = t0;
-    c.t1 = std::min(T, t0 + sz);
-    if (T - c.t1 < sz / 2) c.t1 = T;                          // no short last launch (at most 1.5 x CH tiles)
+    c.t1 = cuts[ci];
     t0 = c.t1;
     chunk_pieces(seq, c.t0, c.t1, c.pieces);
     if (!c.pieces.empty()) {
@@ -1585,9 +1690,14 @@ static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *cons
   if (!ev->pool) ev->pool = new WorkerPool(W);
   uint8_t *const *stage = ev->h_pack;
   cpu_set_t near_cpus;
-  const bool bind = seq->ncontigs && bases[0] && cpus_near(bases[0], &near_cpus);      // the encoders run next to the memory they read
+  int src_node = -1;
+  const bool bind = seq->ncontigs && bases[0] && cpus_near(bases[0], &near_cpus, &src_node);      // the encoders run next to the memory they read
+  int place = 2;
+  if (const char *pp = getenv("MFX_PACK_PLACE")) place = !strcmp(pp, "os") ? 0 : !strcmp(pp, "node") ? 1 : !strcmp(pp, "all") ? 3 : 2;
+  if (const char *nb = getenv("MFX_NUMA_BIND")) if (atoi(nb) == 0) place = 0;
   auto work = [&, W](unsigned w) {
-    if (bind) (void)pthread_setaffinity_np(pthread_self(), sizeof(near_cpus), &near_cpus);
+    cpu_set_t mine;
+    if (pack_cpus(place, src_node, bind ? &near_cpus : nullptr, w, &mine)) (void)pthread_setaffinity_np(pthread_self(), sizeof(mine), &mine);
     for (size_t ci = 0; ci < chunks.size(); ++ci) {
       while (allowed.load(std::memory_order_acquire) < (int64_t)ci) {
         if (stop.load()) return;
@@ -1707,7 +1817,7 @@ static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *cons
   if (timing)
     fprintf(stderr, "[mfx stream] %zu chunks: setup %.2f ms, spawn %.2f, enqueue loop %.2f, drain %.2f, result %.2f, cleanup %.2f; total %.2f ms%s\n", chunks.size(),
             (t_mark[0] - t_begin) * 1e3, (t_mark[1] - t_mark[0]) * 1e3, (t_mark[2] - t_mark[1]) * 1e3, (t_mark[3] - t_mark[2]) * 1e3,
-            (t_mark[4] - t_mark[3]) * 1e3, (t_mark[5] - t_mark[4]) * 1e3, (t_mark[5] - t_begin) * 1e3, bind ? "; encoders bound to the source's NUMA node" : "");
+            (t_mark[4] - t_mark[3]) * 1e3, (t_mark[5] - t_mark[4]) * 1e3, (t_mark[5] - t_begin) * 1e3, place == 0 ? "; encoders unbound" : place == 1 ? "; encoders on the source's NUMA node" : place == 2 ? "; encoders spread over the L3 domains of the source's node" : "; encoders spread over all L3 domains");
   if (timing >= 2) {
     // all times in ms since the function was entered; device times are placed on the host clock through ev_base
     fprintf(stderr, "[mfx stream] chunk   Mbases  pack:first..last   buf-wait   enqueue   copy:start..end   kernel-end   (ms since entry; %u packer threads)\n", W);

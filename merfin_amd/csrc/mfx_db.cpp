@@ -1198,7 +1198,7 @@ struct IndexImageHeader {
   uint32_t filter_set, layout;   // layout = MFX_LAYOUT_VERSION of the build that wrote the image
   uint64_t fingerprint;          // caller's digest of the inputs the table was built from (mfx_index_set_fingerprint)
   uint64_t side_nlines;          // compact layout: lines of the side table that follow the nlines main lines
-  uint32_t flags, seq_digest;    // bit 0: sequence-only index, bit 1: compact layout, bit 2: frozen (counts were added); digest of the claimed sequence (0: none)
+  uint32_t flags, seq_digest;    // bit 0: sequence-only index, bit 1: compact layout, bit 2: frozen (counts were added), bit 3: quotient key fields; digest of the claimed sequence (0: none)
 };
 
 static_assert(sizeof(IndexImageHeader) <= MFX_INDEX_HEADER_BYTES, "index image header outgrew its public size");
@@ -1216,7 +1216,7 @@ static int fill_header(const mfx_index *ix, IndexImageHeader &h) {
   h.layout = MFX_LAYOUT_VERSION;
   h.fingerprint = ix->fingerprint;
   h.side_nlines = ix->side_nlines;
-  h.flags = (ix->seq_only ? 1u : 0u) | (ix->compact ? 2u : 0u) | (ix->frozen ? 4u : 0u);
+  h.flags = (ix->seq_only ? 1u : 0u) | (ix->compact ? 2u : 0u) | (ix->frozen ? 4u : 0u) | (ix->quot ? 8u : 0u);
   h.seq_digest = ix->seq_digest;
   if (hipMemcpy(h.meta, ix->d_meta, sizeof(h.meta), hipMemcpyDeviceToHost) != hipSuccess) return mfx_fail(MFX_E_HIP, "reading index metadata failed");
   return MFX_OK;
@@ -1225,6 +1225,8 @@ static int fill_header(const mfx_index *ix, IndexImageHeader &h) {
 static bool header_ok(const IndexImageHeader &h) {
   const bool wide = h.k > (uint32_t)MFX_MAX_K_NARROW, compact = (h.flags & 2u) != 0;
   if (compact && (!(h.flags & 1u) || wide || h.k > (uint32_t)MFX_MAX_K_COMPACT || h.side_nlines == 0)) return false;
+  if (((h.flags & 8u) != 0) != (compact && h.k > (uint32_t)MFX_MAX_K_DIRECT)) return false;      // the quotient form is the compact layout of k > 21
+  if ((h.flags & 8u) && h.nlines < (1ull << (2 * ((int)h.k - 3) - 31))) return false;
   if (!compact && h.side_nlines != 0) return false;
   const uint32_t line_slots = wide ? MFX_WSLOTS_LINE : compact ? MFX_CSLOTS_LINE : MFX_SLOTS_LINE;
   return memcmp(h.magic, "MFXINDX2", 8) == 0 && h.slot_bytes == MFX_ALIGN / line_slots && h.line_slots == line_slots && h.k >= 1 &&
@@ -1252,7 +1254,7 @@ static mfx_index *index_from_header(const IndexImageHeader &h, double max_gb, in
   ix->minV = h.minV; ix->maxV = h.maxV; ix->filter_set = h.filter_set != 0;
   ix->fingerprint = h.fingerprint;
   ix->side_nlines = h.side_nlines;
-  ix->seq_only = (h.flags & 1u) != 0; ix->compact = (h.flags & 2u) != 0; ix->frozen = (h.flags & 4u) != 0;
+  ix->seq_only = (h.flags & 1u) != 0; ix->compact = (h.flags & 2u) != 0; ix->frozen = (h.flags & 4u) != 0; ix->quot = (h.flags & 8u) != 0;
   ix->seq_digest = ix->seq_only ? h.seq_digest : 0u;
   if (hipMalloc((void **)&ix->d_slots, total_lines * MFX_ALIGN) != hipSuccess ||
       hipMemcpy(ix->d_meta, h.meta, sizeof(h.meta), hipMemcpyHostToDevice) != hipSuccess) {

@@ -58,7 +58,7 @@ constexpr uint32_t MFX_MAXP_LDS   = MFX_V_MAXP_LDS;   // read counts whose (read
 constexpr uint32_t MFX_KLUT       = 32;         // (readK, asmK) pairs below this use tabulated bin index / over-copy term
 // placement functions of the table (mfx_kernels.hip: mfx_minimizer, mfx_mz_line, mfx_home); index images
 // written under another version are refused by mfx_index_load
-constexpr uint32_t MFX_LAYOUT_VERSION = 7u;
+constexpr uint32_t MFX_LAYOUT_VERSION = 8u;
 constexpr uint32_t MFX_SPLIT_MAX_RANKS = 16;  // owners the sort-free router handles (a node has 8 GPUs); more: radix sort
 constexpr int      MFX_MZ_W_DEFAULT = 3;        // minimizer windows of the default placement (MFX_MZ_W overrides)
 constexpr uint32_t MFX_OVF_CAP    = 1u << 20;   // histogram overflow records per evaluator
@@ -95,7 +95,8 @@ constexpr int      MFX_MAX_K_NARROW = 31, MFX_MAX_K = 64;
 // the side table" (standard 16-byte slots, plain hashing, right behind the main lines in the same allocation).
 constexpr uint32_t MFX_CSLOTS_LINE = 16;
 constexpr uint32_t MFX_CSAT = 2047u;
-constexpr int      MFX_MAX_K_COMPACT = 21;
+constexpr int      MFX_MAX_K_COMPACT = 31;        // compact layout: k <= MFX_MAX_K_DIRECT holds the k-mer in the slot, above that its quotient (mfx_q_place)
+constexpr int      MFX_MAX_K_DIRECT = 21;
 constexpr int      MFX_MZ_W_COMPACT = 4;          // minimizer windows of the compact layout (MFX_MZ_W overrides)
 
 struct mfx_table_view {
@@ -109,6 +110,8 @@ struct mfx_table_view {
   int       wide;               // k > 31: slots are mfx_wslot (mfx_wide.hip kernels)
   int       seq_only;           // the key set is the k-mers claimed from a sequence: adds update, they never claim
   int       compact;            // 8-byte slots (above); implies seq_only
+  int       quot;               // compact, k > MFX_MAX_K_DIRECT: the slot's key field holds the k-mer's QUOTIENT (mfx_kernels.hip: mfx_q_place)
+  int       qshift;             // ... floor(log2(nlines))
   mfx_slot *side;               // compact: the side table of saturated counts
   uint64_t  side_nlines;
 };
@@ -136,7 +139,8 @@ struct mfx_index {
   // that was not claimed is dropped.  What -hist and -dump ask the lookup tables is the k-mers of -sequence and nothing
   // else (merfin-histogram.C:54-64, merfin-dump.C:44-61), so their answers are those of the full tables.
   bool      seq_only = false;
-  bool      compact = false;    // seq_only, k <= 21: 8-byte slots, 16 per line (mfx_table_view)
+  bool      compact = false;    // seq_only, k <= 31: 8-byte slots, 16 per line (mfx_table_view)
+  bool      quot = false;       // compact, k > 21: quotient form of the key field
   bool      frozen = false;     // an add / load happened: no more claims
   uint64_t  side_nlines = 0;    // compact: lines of the side table, which follows the nlines main lines in d_slots
   uint32_t  seq_digest = 0;     // seq_only: content digest of the sequence the k-mers were claimed from (0: not recorded);

@@ -111,6 +111,8 @@ hipError_t mfx_k_ordered_sum(const double *v, uint32_t n, double *out, hipStream
 uint64_t mfx_k_tile_partials_words(uint64_t ntiles);
 hipError_t mfx_k_sum_tile_partials(double *tile_partials, uint64_t ntiles, double *out, uint64_t *ctr_reset, hipStream_t st);
 int mfx_k_hist_resident_blocks(int compact);
+int mfx_k_quot_supported();
+hipError_t mfx_k_gather_rate(const void *table, uint64_t nlines, uint64_t *scratch, double *lines_per_s, hipStream_t st);
 // 32 <= k <= 64 (mfx_wide.hip); kmers: two uint64 words per k-mer {low 64 bits, high bits}
 hipError_t mfx_kw_table_add(mfx_table_view t, const uint64_t *kmers, const uint32_t *values, uint64_t n, int side, uint64_t *meta, hipStream_t st);
 hipError_t mfx_kw_table_value(mfx_table_view t, const uint64_t *kmers, uint64_t n, uint32_t *readV, uint32_t *asmV, hipStream_t st);

@@ -53,6 +53,8 @@ constexpr uint32_t MFX_MAX_LINES = 512;
 struct mfx_probe {
   uint32_t lineA, lineB;
   uint32_t b0;                 // compact layout: the mini-bucket of the line the k-mer's slots are tried from (mfx_home)
+  uint64_t fkey;               // compact layout: what the key field of the k-mer's slot holds in candidate line 0 -- the k-mer itself
+                               // (k <= 21), its QUOTIENT (22 <= k <= 31, mfx_q_place); candidate line d: mfx_c_keyat
 };
 
 // Canonical minimizer of a k-mer: of its w windows of m = k-w+1 bases, the canonical m-mer
@@ -91,7 +93,8 @@ __device__ __forceinline__ uint64_t mfx_minimizer(uint64_t key, uint64_t rc, int
 // by the evaluation kernel, which finds the same offsets for a whole wave at once (mfx_wave_mod_lines).
 __device__ __forceinline__ uint32_t mfx_tmer_order(uint32_t canonical_tmer) { return ((canonical_tmer * 0x9E3779B1u) >> 7) & 511u; }
 
-__device__ __forceinline__ uint64_t mfx_minimizer_mod(uint64_t key, uint64_t rc, int k, int w, int t, uint32_t &x) {
+// x: offset of the sampling t-mer; wa / wb: the m-mer of the sampled window as it stands in `key`, and its reverse complement
+__device__ __forceinline__ void mfx_mod_window(uint64_t key, uint64_t rc, int k, int w, int t, uint32_t &x, uint64_t &wa, uint64_t &wb) {
   const uint32_t tmask = (1u << (2 * t)) - 1u;
   uint32_t best = 0xffffffffu;
   x = 0;
@@ -102,7 +105,12 @@ __device__ __forceinline__ uint64_t mfx_minimizer_mod(uint64_t key, uint64_t rc,
   }
   const int m = k - w + 1, j = (int)(x % (uint32_t)w);          // window j from the left
   const uint64_t mmask = (~0ULL) >> (64 - 2 * m);
-  const uint64_t a = (key >> (2 * (w - 1 - j))) & mmask, b = (rc >> (2 * j)) & mmask;
+  wa = (key >> (2 * (w - 1 - j))) & mmask;
+  wb = (rc >> (2 * j)) & mmask;
+}
+__device__ __forceinline__ uint64_t mfx_minimizer_mod(uint64_t key, uint64_t rc, int k, int w, int t, uint32_t &x) {
+  uint64_t a, b;
+  mfx_mod_window(key, rc, k, w, t, x, a, b);
   return a < b ? a : b;
 }
 
@@ -118,11 +126,88 @@ __device__ __forceinline__ void mfx_mod_place(uint64_t mz, uint32_t x, uint64_t 
   b0 = (x + h) & 7u;
 }
 
+// ---------------------------------------------------------------------------
+// QUOTIENT form of the compact layout (22 <= k <= 31; w = 4, mod-minimizer).  A k-mer of up to 62 bits does not fit the 42-bit
+// key field of an 8-byte slot -- but most of it is implied by WHERE the slot is.  The k-mer is (its minimizer: an m-mer of
+// m = k - 3 bases in canonical form, the strand it stands in, the window j it occupies, the 3 bases around it); the line of the
+// bucket is taken from the high bits of a BIJECTION of the minimizer, so the slot only has to keep what the line does not say:
+//   top   = mix(low 32 bits of the minimizer) ^ (high bits * C)          -- invertible given the high bits, which are stored as they are
+//   line  = (top * nlines) >> 32,   f = low 32 bits of top * nlines      -- two `top` of one line differ in f by >= nlines >= 2^qshift,
+//   fq    = f >> qshift,  qshift = floor(log2(nlines))                      so fq tells them apart in 32 - qshift bits
+//   F0    = {high bits of the minimizer : 2m - 32 | fq : 32 - qshift | strand : 1 | j : 2 | outer bases : 6}   <= 40 bits
+// (the host makes the table large enough for that: nlines >= 2^(2m - 31), mfx_api.cpp).  A slot in candidate line d of its k-mer
+// holds F0 | d << 40 with d <= 2: (line, key field) <-> k-mer is one to one (mfx_q_invert is the way back, used by the export),
+// so a 42-bit compare is an exact match, and the all-ones word (d = 3) stays the empty slot.  A k-mer whose three candidate
+// lines are full lives in the side table under its full key (mfx_c_claim).  Everything else of the layout -- 16 slots per line,
+// mini-buckets, counts of 11 bits with the side table behind them, the probe -- is that of k <= 21: -hist at k = 31 reads one
+// 16-byte mini-bucket per k-mer from a table half the size of the 16-byte-slot form.
+// ---------------------------------------------------------------------------
+constexpr uint32_t MFX_Q_LINES = 3;            // candidate lines of the quotient form (d = 0 .. 2)
+constexpr int      MFX_Q_DSHIFT = 40;          // d sits above the 40 bits of F0
+
+__device__ __forceinline__ uint32_t mfx_q_mix(uint32_t lo, uint32_t hi) {
+  uint32_t u = lo * 0x9E3779B1u;
+  u ^= u >> 15; u *= 0x85EBCA77u; u ^= u >> 13;
+  return u ^ (hi * 0xC2B2AE3Du);
+}
+__device__ __forceinline__ uint32_t mfx_q_unmix(uint32_t top, uint32_t hi) {
+  uint32_t u = top ^ (hi * 0xC2B2AE3Du);
+  u ^= u >> 13; u ^= u >> 26; u *= 0xB6C92F47u;              // the inverses of the steps above, last first
+  u ^= u >> 15; u ^= u >> 30;
+  return u * 0x0E8B2F51u;
+}
+
+// c: canonical minimizer; sbit: it stands reversed in the (canonical) k-mer; j: its window from the left; e: the j bases left and
+// 3 - j bases right of it; x: offset of the sampling t-mer (first mini-bucket, as mfx_mod_place)
+__device__ __forceinline__ void mfx_q_place(const mfx_table_view &t, uint64_t c, uint32_t sbit, uint32_t j, uint32_t e, uint32_t x,
+                                            uint32_t &line, uint32_t &b0, uint64_t &f0) {
+  const uint32_t hi = (uint32_t)(c >> 32), top = mfx_q_mix((uint32_t)c, hi), nl = (uint32_t)t.nlines;
+  line = __umulhi(top, nl);
+  const uint32_t fq = (top * nl) >> t.qshift;
+  b0 = (x + (top >> 3)) & 7u;
+  const int R = 2 * (t.k - 3) - 32, Q = 32 - t.qshift;
+  f0 = (uint64_t)hi | ((uint64_t)fq << R) | ((uint64_t)(sbit | (j << 1) | (e << 3)) << (R + Q));
+}
+
+// the pieces of a canonical k-mer `key` (rc: its reverse complement) that mfx_q_place takes
+__device__ __forceinline__ void mfx_q_parts(const mfx_table_view &t, uint64_t key, uint64_t rc, uint32_t &x, uint64_t &c, uint32_t &sbit,
+                                            uint32_t &j, uint32_t &e) {
+  uint64_t a, b;
+  mfx_mod_window(key, rc, t.k, 4, t.mz_t, x, a, b);
+  j = x & 3u;
+  c = a < b ? a : b;
+  sbit = b < a ? 1u : 0u;
+  const int m = t.k - 3;
+  e = (uint32_t)(((key >> (2 * (m + 3 - (int)j))) << (2 * (3 - (int)j))) | (key & ((1ull << (2 * (3 - (int)j))) - 1ull)));
+}
+
+// (home line, F0) -> the k-mer (export, tests): the inverse of mfx_q_parts + mfx_q_place
+__device__ __forceinline__ uint64_t mfx_q_invert(const mfx_table_view &t, uint32_t home, uint64_t f0) {
+  const int m = t.k - 3, R = 2 * m - 32, Q = 32 - t.qshift;
+  const uint32_t hi = (uint32_t)(f0 & ((1ull << R) - 1ull)), fq = (uint32_t)(f0 >> R) & (uint32_t)((1ull << Q) - 1ull);
+  const uint32_t meta = (uint32_t)(f0 >> (R + Q)), sbit = meta & 1u, j = (meta >> 1) & 3u, e = (meta >> 3) & 63u;
+  const uint32_t nl = (uint32_t)t.nlines;
+  uint32_t top = (uint32_t)((((uint64_t)home << 32) + nl - 1u) / nl);          // the smallest `top` of this line
+  const uint32_t f_first = top * nl, want = fq << t.qshift;                    // f grows by nl from one `top` of the line to the next, without wrapping
+  if (want > f_first) top += (uint32_t)(((uint64_t)(want - f_first) + nl - 1u) / nl);
+  const uint64_t c = ((uint64_t)hi << 32) | mfx_q_unmix(top, hi);
+  const uint64_t mmer = sbit ? mfx_revcomp(c, m) : c;
+  const uint64_t left = e >> (2 * (3 - j)), right = e & ((1u << (2 * (3 - j))) - 1u);
+  return (left << (2 * (m + 3 - (int)j))) | (mmer << (2 * (3 - j))) | right;
+}
+
 // line of a k-mer's minimizer: one odd 64-bit multiplication (the high half of the product
 // depends on every bit of the m-mer), then the multiply-range reduction.  The multiplier must
 // be unrelated to the order hash's: the minimizer is the window with the SMALLEST order hash,
 // so a line hash correlated with it would crowd the low lines.
 __device__ __forceinline__ uint32_t mfx_mz_line(const mfx_table_view &t, uint64_t key, uint64_t krc) {
+  if (t.quot) {
+    uint32_t x, sbit, j, e, line, b0;
+    uint64_t c, f0;
+    mfx_q_parts(t, key, krc, x, c, sbit, j, e);
+    mfx_q_place(t, c, sbit, j, e, x, line, b0, f0);
+    return line;
+  }
   if (t.mz_t) {
     uint32_t x, line, b0;
     const uint64_t mz = mfx_minimizer_mod(key, krc, t.k, t.mz_w, t.mz_t, x);
@@ -146,6 +231,14 @@ __device__ __forceinline__ mfx_probe mfx_home(const mfx_table_view &t, uint64_t 
   pr.lineB = mfx_range32(h, t.nlines);
   pr.lineA = pr.lineB;
   pr.b0 = 0u;
+  pr.fkey = key;
+  if (t.quot) {                                                // compact layout, quotient form (mfx_q_place)
+    uint32_t x, sbit, j, e;
+    uint64_t c;
+    mfx_q_parts(t, key, mfx_revcomp(key, t.k), x, c, sbit, j, e);
+    mfx_q_place(t, c, sbit, j, e, x, pr.lineA, pr.b0, pr.fkey);
+    return pr;
+  }
   if (t.mz_t) {                                                // compact layout, mod-minimizer: line and first mini-bucket together
     uint32_t x;
     const uint64_t mz = mfx_minimizer_mod(key, mfx_revcomp(key, t.k), t.k, t.mz_w, t.mz_t, x);
@@ -272,6 +365,30 @@ __device__ __forceinline__ mfx_table_view mfx_side_view(const mfx_table_view &c)
   return s;
 }
 
+// what the key field of a k-mer's slot holds in candidate line d (quotient form: d rides above F0; else the k-mer, whatever d)
+__device__ __forceinline__ uint64_t mfx_c_keyat(const mfx_table_view &c, uint64_t fkey, uint32_t d) {
+  return c.quot ? fkey | ((uint64_t)d << MFX_Q_DSHIFT) : fkey;
+}
+// candidate lines a compact k-mer may live in (beyond them, quotient form: the side table)
+__device__ __forceinline__ uint32_t mfx_c_maxlines(const mfx_table_view &c) { return c.quot ? MFX_Q_LINES : MFX_MAX_LINES; }
+
+// the slot of `key` in a 16-byte-slot table (the side table of a compact index), or nullptr
+__device__ __forceinline__ mfx_slot *mfx_find_slot(const mfx_table_view &t, uint64_t key) {
+  const mfx_probe pr = mfx_home(t, key);
+  for (uint32_t d = 0; d < MFX_MAX_LINES; ++d) {
+    mfx_slot *ln = t.slots + mfx_probe_line(t, pr, d) * MFX_SLOTS_LINE;
+    bool any_empty = false;
+#pragma unroll 1
+    for (uint32_t q = 0; q < MFX_SLOTS_LINE; ++q) {
+      const unsigned long long sk = __hip_atomic_load(reinterpret_cast<unsigned long long *>(&ln[q].key), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (sk == key) return ln + q;
+      any_empty |= sk == MFX_EMPTY;
+    }
+    if (any_empty) break;
+  }
+  return nullptr;
+}
+
 // the pair of a found compact slot from its low word (a saturated field: the side table has the exact count)
 __device__ __forceinline__ uint2 mfx_c_fields(const mfx_table_view &c, uint64_t key, uint32_t lo) {
   uint32_t rv = (lo >> 11) & MFX_CSAT, av = lo & MFX_CSAT;
@@ -284,13 +401,17 @@ __device__ __forceinline__ uint2 mfx_c_fields(const mfx_table_view &c, uint64_t 
   return make_uint2(rv, av);
 }
 
-// per-lane scan of candidate lines d0, d0+1, ...: the slot holding `key` (its word in `word`), or nullptr when the
+// per-lane scan of candidate lines d0, d0+1, ...: the slot holding the k-mer (its word in `word`), or nullptr when the
 // first line with room does not hold it (never claimed).  The whole line is requested at once (8 x 16 bytes).
-__device__ __forceinline__ unsigned long long *mfx_c_find(const mfx_table_view &c, uint64_t key, const mfx_probe &pr, uint32_t d0,
-                                                          unsigned long long &word) {
+// beyond (quotient form): every candidate line is full of other k-mers -- if the k-mer was claimed, it is in the side table.
+__device__ __forceinline__ unsigned long long *mfx_c_find(const mfx_table_view &c, const mfx_probe &pr, uint32_t d0,
+                                                          unsigned long long &word, bool &beyond) {
   unsigned long long *cs = reinterpret_cast<unsigned long long *>(c.slots);
-  for (uint32_t d = d0; d < MFX_MAX_LINES; ++d) {
+  beyond = false;
+  const uint32_t dmax = mfx_c_maxlines(c);
+  for (uint32_t d = d0; d < dmax; ++d) {
     unsigned long long *base = cs + mfx_probe_line(c, pr, d) * MFX_CSLOTS_LINE;
+    const uint64_t key = mfx_c_keyat(c, pr.fkey, d);
     const uint4 *ln = reinterpret_cast<const uint4 *>(base);
     uint4 s[8];
 #pragma unroll
@@ -305,14 +426,21 @@ __device__ __forceinline__ unsigned long long *mfx_c_find(const mfx_table_view &
       any_empty |= (x == MFX_EMPTY) || (y == MFX_EMPTY);
     }
     if (at >= 0) return base + at;
-    if (any_empty) break;
+    if (any_empty) return nullptr;
   }
+  beyond = c.quot != 0;
   return nullptr;
 }
 
 __device__ __forceinline__ uint2 mfx_c_lookup(const mfx_table_view &c, uint64_t key) {
   unsigned long long w = 0;
-  if (!mfx_c_find(c, key, mfx_home(c, key), 0, w)) return make_uint2(0u, 0u);      // absent -> value 0 (merfin-globals.C:84)
+  bool beyond;
+  if (!mfx_c_find(c, mfx_home(c, key), 0, w, beyond)) {
+    if (!beyond) return make_uint2(0u, 0u);                     // absent -> value 0 (merfin-globals.C:84)
+    uint2 x = mfx_lookup(mfx_side_view(c), key);                // beyond its candidate lines: under its full key in the side table
+    if (x.x < c.minV || x.x > c.maxV) x.x = 0;                  // -min / -max (merfin.C:199-200)
+    return x;
+  }
   return mfx_c_fields(c, key, (uint32_t)w);
 }
 
@@ -337,11 +465,18 @@ __device__ __forceinline__ uint2 mfx_side_lookup_lean(const mfx_table_view &c, u
   return make_uint2(0u, 0u);
 }
 
-// (found, the slot's low word) of `key` from candidate line d0 on
-__device__ __forceinline__ uint2 mfx_c_find_lean(const mfx_table_view &c, uint64_t key, uint32_t d0) {
-  const mfx_probe pr = mfx_home(c, key);
-  for (uint32_t d = d0; d < MFX_MAX_LINES; ++d) {
+// (found, the slot's low word) of the k-mer with key field `fkey` and home line `lineA`, from candidate line d0 on
+__device__ __forceinline__ uint2 mfx_c_find_lean(const mfx_table_view &c, uint64_t fkey, uint32_t lineA, uint32_t d0, bool &beyond) {
+  mfx_probe pr;
+  pr.lineA = lineA;
+  pr.lineB = c.quot ? 0u : mfx_range32(mfx_hash64(fkey), c.nlines);    // (k <= 21: fkey is the k-mer; candidate lines >= MFX_MZ_REGION follow its own hash)
+  pr.b0 = 0u;
+  pr.fkey = fkey;
+  beyond = false;
+  const uint32_t dmax = mfx_c_maxlines(c);
+  for (uint32_t d = d0; d < dmax; ++d) {
     const uint4 *ln = reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned long long *>(c.slots) + mfx_probe_line(c, pr, d) * MFX_CSLOTS_LINE);
+    const uint64_t key = mfx_c_keyat(c, fkey, d);
     bool any_empty = false;
 #pragma unroll 1
     for (uint32_t q = 0; q < MFX_CSLOTS_LINE / 2; ++q) {
@@ -351,8 +486,9 @@ __device__ __forceinline__ uint2 mfx_c_find_lean(const mfx_table_view &c, uint64
       if (y != MFX_EMPTY && (y >> 22) == key) return make_uint2(1u, s.z);
       any_empty |= (x == MFX_EMPTY) || (y == MFX_EMPTY);
     }
-    if (any_empty) break;
+    if (any_empty) return make_uint2(0u, 0u);
   }
+  beyond = c.quot != 0;
   return make_uint2(0u, 0u);
 }
 
@@ -381,17 +517,20 @@ __device__ __forceinline__ uint2 mfx_c_fields_lean(const mfx_table_view &c, uint
 // init: the counts a FRESH slot starts with (the assembly counter claims with asmV = 1: one atomic per new k-mer, not two);
 // claimed = this call wrote the slot.
 __device__ __forceinline__ unsigned long long *mfx_c_claim(const mfx_table_view &c, uint64_t key, uint64_t *meta, uint32_t &fresh,
-                                                           unsigned long long &cur, uint32_t init, bool &claimed) {
+                                                           unsigned long long &cur, uint32_t init, bool &claimed, mfx_slot *&side_slot) {
   const mfx_probe pr = mfx_home(c, key);
   unsigned long long *cs = reinterpret_cast<unsigned long long *>(c.slots);
-  const unsigned long long mine = ((unsigned long long)key << 22) | init;
   claimed = false;
+  side_slot = nullptr;
   const uint32_t q0 = 2u * pr.b0;
+  const uint32_t dmax = mfx_c_maxlines(c);
   // A mini-bucket is read by ONE plain 16-byte load.  It may come from this CU's L1 and be older than the table: a slot
   // seen occupied stays what it is (a slot never changes its key once written), a slot seen empty is taken by compare-and-
   // swap, whose answer is the truth -- the claim, the k-mer itself (another lane claimed it first), or another key (on).
-  for (uint32_t d = 0; d < MFX_MAX_LINES; ++d) {
+  for (uint32_t d = 0; d < dmax; ++d) {
     unsigned long long *base = cs + mfx_probe_line(c, pr, d) * MFX_CSLOTS_LINE;
+    const uint64_t kf = mfx_c_keyat(c, pr.fkey, d);
+    const unsigned long long mine = ((unsigned long long)kf << 22) | init;
     for (uint32_t qi = 0; qi < MFX_CSLOTS_LINE; qi += 2) {
       const uint32_t q = (q0 + qi) & (MFX_CSLOTS_LINE - 1u);
       const uint4 s = *reinterpret_cast<const uint4 *>(base + q);
@@ -404,9 +543,15 @@ __device__ __forceinline__ unsigned long long *mfx_c_claim(const mfx_table_view 
           cur = atomicCAS(base + q + e, (unsigned long long)MFX_EMPTY, mine);
           if (cur == MFX_EMPTY) { ++fresh; cur = mine; claimed = true; return base + q + e; }
         }
-        if ((cur >> 22) == key) return base + q + e;         // cur is not the empty word here
+        if ((cur >> 22) == kf) return base + q + e;          // cur is not the empty word here
       }
     }
+  }
+  if (c.quot) {
+    // quotient form: the three candidate lines are full of other k-mers (and stay full: slots never empty again) -- the k-mer
+    // lives in the side table under its full key, with its counts (zero at the claim: the caller adds there)
+    side_slot = mfx_claim(mfx_side_view(c), key, meta, fresh);
+    return nullptr;
   }
   atomicAdd((unsigned long long *)&meta[2], 1ull);
   return nullptr;
@@ -646,11 +791,12 @@ __device__ __forceinline__ void mfx_apply_batch(const mfx_table_view &t, uint64_
   if (t.seq_only && t.compact) {
     unsigned long long *mb[UB];
     uint4 s[UB];
+    mfx_probe pr[UB];
 #pragma unroll
     for (int j = 0; j < UB; ++j) {
       if (v[j] && key[j] > mfx_revcomp(key[j], t.k)) { ++T.noncanon; v[j] = 0u; }
-      const mfx_probe pr = mfx_home(t, key[j]);
-      mb[j] = reinterpret_cast<unsigned long long *>(t.slots) + mfx_probe_line(t, pr, 0) * MFX_CSLOTS_LINE + 2u * pr.b0;
+      pr[j] = mfx_home(t, key[j]);
+      mb[j] = reinterpret_cast<unsigned long long *>(t.slots) + mfx_probe_line(t, pr[j], 0) * MFX_CSLOTS_LINE + 2u * pr[j].b0;
       s[j] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
       if (v[j]) s[j] = *reinterpret_cast<const uint4 *>(mb[j]);
     }
@@ -660,12 +806,17 @@ __device__ __forceinline__ void mfx_apply_batch(const mfx_table_view &t, uint64_
       const uint64_t x = (uint64_t)s[j].x | ((uint64_t)s[j].y << 32), y = (uint64_t)s[j].z | ((uint64_t)s[j].w << 32);
       unsigned long long *w = nullptr;
       unsigned long long cur = 0;
+      bool beyond = false;
       if (x == MFX_EMPTY) { }                                  // first slot of its order empty: never claimed
-      else if ((x >> 22) == key[j]) { w = mb[j]; cur = x; }
+      else if ((x >> 22) == pr[j].fkey) { w = mb[j]; cur = x; }
       else if (y == MFX_EMPTY) { }
-      else if ((y >> 22) == key[j]) { w = mb[j] + 1; cur = y; }
-      else w = mfx_c_find(t, key[j], mfx_home(t, key[j]), 0, cur);
-      if (w) mfx_c_add(t, w, cur, key[j], v[j], side, meta); else ++T.dropped;
+      else if ((y >> 22) == pr[j].fkey) { w = mb[j] + 1; cur = y; }
+      else w = mfx_c_find(t, pr[j], 0, cur, beyond);
+      if (w) mfx_c_add(t, w, cur, key[j], v[j], side, meta);
+      else {
+        mfx_slot *ss = beyond ? mfx_find_slot(mfx_side_view(t), key[j]) : nullptr;     // quotient form: beyond its candidate lines
+        if (ss) atomicAdd(side ? &ss->asmV : &ss->readV, v[j]); else ++T.dropped;
+      }
     }
   } else if (t.seq_only) {
 #pragma unroll
@@ -804,11 +955,33 @@ __global__ void mfx_table_export_kernel(mfx_table_view t, uint64_t *kmers, uint3
     for (; i < t.nlines * MFX_CSLOTS_LINE; i += stride) {
       const uint64_t x = cs[i];
       if (x == MFX_EMPTY) continue;
-      const uint2 v = mfx_c_fields(raw, x >> 22, (uint32_t)x);
+      uint64_t km = x >> 22;
+      if (t.quot) {                                              // (line, key field) -> k-mer: the slot sits in candidate line d of its home
+        const uint32_t d = (uint32_t)(km >> MFX_Q_DSHIFT), line = (uint32_t)(i / MFX_CSLOTS_LINE);
+        const uint32_t home = line >= d ? line - d : line + (uint32_t)t.nlines - d;
+        km = mfx_q_invert(t, home, km & ((1ull << MFX_Q_DSHIFT) - 1ull));
+      }
+      const uint2 v = mfx_c_fields(raw, km, (uint32_t)x);
       unsigned long long w = atomicAdd(count, 1ull);
-      kmers[w] = x >> 22;
+      kmers[w] = km;
       readV[w] = v.x;
       asmV[w] = v.y;
+    }
+    if (t.quot) {
+      // quotient form: the k-mers beyond their candidate lines live in the side table only (its other entries are the exact
+      // counts of saturated fields, whose k-mers were listed above)
+      const mfx_table_view sv = mfx_side_view(t);
+      for (i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < sv.nlines * MFX_SLOTS_LINE; i += stride) {
+        const mfx_slot sl = sv.slots[i];
+        if (sl.key == MFX_EMPTY) continue;
+        unsigned long long word = 0;
+        bool beyond;
+        if (mfx_c_find(t, mfx_home(t, sl.key), 0, word, beyond) || !beyond) continue;
+        unsigned long long w = atomicAdd(count, 1ull);
+        kmers[w] = sl.key;
+        readV[w] = sl.readV;
+        asmV[w] = sl.asmV;
+      }
     }
     return;
   }
@@ -1153,7 +1326,8 @@ __device__ __forceinline__ void mfx_group_lookup8(const mfx_table_view &c, mfx_m
       }
       if (!have) {
         unsigned long long w = 0;
-        if (!mfx_c_find(c, key[j], mfx_home(c, key[j]), from, w)) continue;   // exact per-lane path (rare)
+        bool beyond;                                                          // (this probe serves k <= 21 only: mfx_k_quot_supported)
+        if (!mfx_c_find(c, mfx_home(c, key[j]), from, w, beyond)) continue;   // exact per-lane path (rare)
         lo = (uint32_t)w;
       }
     }
@@ -1173,37 +1347,32 @@ __device__ __forceinline__ void mfx_group_lookup8(const mfx_table_view &c, mfx_m
 // through the next ones (a round = one more load for the lanes that need it, the others wait): 5.8 % need a second
 // load, 1.3 % a third.  A line exhausted without the key or an empty slot is rare enough for the whole-line scan (mfx_c_find).
 // ---------------------------------------------------------------------------
-// pre: the queries' home lines if the caller has them already (mfx_wave_mod_lines), else nullptr
-template <int B>
-__device__ __forceinline__ void mfx_lane_lookup8(const mfx_table_view &c, mfx_mailbox &M, const uint64_t (&key)[B], const uint64_t (&krc)[B],
-                                                 const bool (&ok)[B], uint32_t (&rv)[B], uint32_t (&av)[B], const uint32_t *pre = nullptr,
-                                                 const uint32_t *pre_b0 = nullptr, unsigned long long *dbg = nullptr) {
+// fkey: what the key field of each query's slot holds in its home line (mfx_probe::fkey: the k-mer, or its quotient for k > 21);
+// line / b0: its home line and first mini-bucket (mfx_home, or mfx_wave_mod_line for a whole wave at once); a query that is not
+// ok must come with line 0 / b0 0 (a dummy load, ignored).  keyof(j): the canonical k-mer of query j -- asked for on the rare
+// endings only (a saturated count; quotient form: a k-mer beyond its candidate lines), so that the quotient form keeps no
+// k-mer alive across the loads: the -hist and -dump kernels re-extract it from the tile.
+template <int B, class KeyOf>
+__device__ __forceinline__ void mfx_lane_lookup8(const mfx_table_view &c, mfx_mailbox &M, const uint64_t (&fkey)[B], const bool (&ok)[B],
+                                                 uint32_t (&rv)[B], uint32_t (&av)[B], const uint32_t (&line)[B], const uint32_t (&b0)[B],
+                                                 KeyOf keyof, unsigned long long *dbg = nullptr) {
   // dbg (the DEBUG instance of the -hist kernel only, mfx_hist_args::dbg): how many queries left the one-load fast path, and how --
   // [0] not in their first mini-bucket (first cooperative pass), [1] home line full of other k-mers (second cooperative pass),
   // [2] a saturated count (side table), [3] per-lane whole-line scans; tests assert that a world exercises every ending
   const uint32_t tid = threadIdx.x, sub16 = (tid & 7u) << 4, lane = tid & 63u, wbase = tid & ~63u;
   const uint4 *const slots0 = reinterpret_cast<const uint4 *>(c.slots);
-  uint32_t line[B];
   uint32_t st[B];               // 0xff done; 1 not in its first mini-bucket; 0xfe a count field is saturated (the slot's low word parked in rv);
-                                // 0xfd / 0xfc whole-line scans from candidate line 1 / 0 (set below)
+                                // 0xfd / 0xfc whole-line scans from candidate line 2 / 0 (set below)
   uint4 v[B];
   // ---- first mini-bucket of every query: one 16-byte load per lane and query, all B in flight
 #pragma unroll
-  for (int j = 0; j < B; ++j) {
-    uint32_t b0 = 0u;
-    line[j] = 0u;                                              // no k-mer here: a dummy load of line 0, ignored below
-    if (ok[j]) {
-      if (pre) { line[j] = pre[j]; b0 = pre_b0[j]; }
-      else { const mfx_probe pr = mfx_home(c, key[j]); line[j] = pr.lineA; b0 = pr.b0; }
-    }
-    v[j] = slots0[((uint64_t)line[j] << 3) | b0];
-  }
+  for (int j = 0; j < B; ++j) v[j] = slots0[((uint64_t)line[j] << 3) | b0[j]];
 #pragma unroll
   for (int j = 0; j < B; ++j) {
     const uint4 s = v[j];
-    // {key 42 | counts 22}: equal high words and low words that differ in the 22 count bits only (the empty word's key is
-    // not a canonical k-mer)
-    const uint64_t ks = key[j] << 22;
+    // {key 42 | counts 22}: equal high words and low words that differ in the 22 count bits only (the empty word's key field is
+    // no k-mer's: poly-G is not canonical, and a quotient never has d = 3)
+    const uint64_t ks = fkey[j] << 22;
     const uint32_t klo = (uint32_t)ks, khi = (uint32_t)(ks >> 32);
     const bool ha = s.y == khi && ((s.x ^ klo) >> 22) == 0u, hb = s.w == khi && ((s.z ^ klo) >> 22) == 0u;
     const bool found = ha || hb, room = s.y == 0xffffffffu || s.w == 0xffffffffu;
@@ -1215,7 +1384,7 @@ __device__ __forceinline__ void mfx_lane_lookup8(const mfx_table_view &c, mfx_ma
     av[j] = (found && !sat) ? r_av : 0u;
     st[j] = !ok[j] ? 0xffu : (found ? (sat ? 0xfeu : 0xffu) : (room ? 0xffu : 1u));  // an empty slot before the key: absent (value 0, merfin-globals.C:84)
   }
-  // ---- the queries that were not in their first mini-bucket (8 % at load factor 0.25): compacted into this wave's mailbox
+  // ---- the queries that were not in their first mini-bucket (3 % at load factor 0.225): compacted into this wave's mailbox
   // and served 8 per step by the cooperative whole-line probe -- the 8 lanes of a group fetch the query's HOME line with one
   // coalesced request, so that whichever mini-bucket the k-mer went to, one more round trip finds it
   uint32_t qpos[B];
@@ -1228,7 +1397,7 @@ __device__ __forceinline__ void mfx_lane_lookup8(const mfx_table_view &c, mfx_ma
     qpos[j] = 0xffffffffu;
     if (p && pos < 64u) {
       qpos[j] = pos;
-      const uint64_t ks = key[j] << 22;
+      const uint64_t ks = fkey[j] << 22;
       M.rec[wbase + pos] = make_uint4((uint32_t)ks, (uint32_t)(ks >> 32), line[j], 0u);
     }
     nq += (uint32_t)__popcll(m);
@@ -1263,7 +1432,7 @@ __device__ __forceinline__ void mfx_lane_lookup8(const mfx_table_view &c, mfx_ma
           const uint32_t e = q0 + 8u * sp + (lane >> 3);
           if (act[sp]) {
             uint32_t *rec = reinterpret_cast<uint32_t *>(&M.rec[wbase + e]);
-            const uint2 kk = *reinterpret_cast<const uint2 *>(rec);                          // the query's {key << 22} words (a finder of this group may have replaced word 0: same key bits)
+            const uint2 kk = *reinterpret_cast<const uint2 *>(rec);                          // the query's {key field << 22} words (a finder of this group may have replaced word 0: same key bits)
             if (sl[sp].y == 0xffffffffu || sl[sp].w == 0xffffffffu) rec[3] = 1u;               // an empty slot: the line has room
             if (sl[sp].y == kk.y && ((sl[sp].x ^ kk.x) >> 22) == 0u) { rec[0] = sl[sp].x; rec[2] = 0xffffffffu; }    // found (marker: no line has this index)
             else if (sl[sp].w == kk.y && ((sl[sp].z ^ kk.x) >> 22) == 0u) { rec[0] = sl[sp].z; rec[2] = 0xffffffffu; }
@@ -1301,6 +1470,7 @@ __device__ __forceinline__ void mfx_lane_lookup8(const mfx_table_view &c, mfx_ma
         pr.lineA = pr.lineB = line[j];
         rec[2] = (uint32_t)mfx_probe_line(c, pr, 1u);          // (candidate lines 0 .. MFX_MZ_REGION-1 follow the minimizer's line)
         rec[3] = 2u;
+        if (c.quot) rec[1] |= 1u << (MFX_Q_DSHIFT + 22 - 32);  // quotient form: the key field of candidate line 1 (d = 1 above F0; the finder left word 1 alone)
         again = true;
         if (dbg) atomicAdd(&dbg[1], 1ull);
       }
@@ -1311,25 +1481,32 @@ __device__ __forceinline__ void mfx_lane_lookup8(const mfx_table_view &c, mfx_ma
     }
   }
   // ---- the rare endings, ONE instance of their code for all B queries of the lane: a saturated count field (the exact
-  // count is in the side table) or whole-line scans of the candidate lines
+  // count is in the side table), whole-line scans of the further candidate lines, and (quotient form) a k-mer beyond them
   while (true) {
     int sj = -1;
-    uint64_t skey = 0;
-    uint32_t slo = 0, scode = 0;
+    uint64_t sfkey = 0;
+    uint32_t slo = 0, scode = 0, sline = 0;
 #pragma unroll
     for (int j = 0; j < B; ++j)
-      if (sj < 0 && st[j] >= 0xfcu && st[j] <= 0xfeu) { sj = j; skey = key[j]; slo = rv[j]; scode = st[j]; }
+      if (sj < 0 && st[j] >= 0xfcu && st[j] <= 0xfeu) { sj = j; sfkey = fkey[j]; slo = rv[j]; scode = st[j]; sline = line[j]; }
     if (!__any(sj >= 0)) break;
     if (sj >= 0) {
       uint2 x = make_uint2(0u, 0u);
-      bool have = scode == 0xfeu;
+      bool have = scode == 0xfeu, beyond = false;
       if (dbg) atomicAdd(&dbg[have ? 2 : 3], 1ull);
       if (!have) {
-        const uint2 fd = mfx_c_find_lean(c, skey, scode == 0xfdu ? 2u : 0u);
+        const uint2 fd = mfx_c_find_lean(c, sfkey, sline, scode == 0xfdu ? 2u : 0u, beyond);
         have = fd.x != 0u;
         slo = fd.y;
       }
-      if (have) x = mfx_c_fields_lean(c, skey, slo);
+      uint32_t r_rv = (slo >> 11) & MFX_CSAT, r_av = slo & MFX_CSAT;
+      const bool sat = have && (r_rv == MFX_CSAT || r_av == MFX_CSAT);
+      if (sat || beyond) {                                     // the side table is keyed by the k-mer itself
+        const uint2 sx = mfx_side_lookup_lean(c, keyof(sj));
+        if (beyond) { r_rv = sx.x; r_av = sx.y; have = true; }
+        else { if (r_rv == MFX_CSAT) r_rv = sx.x; if (r_av == MFX_CSAT) r_av = sx.y; }
+      }
+      if (have) x = make_uint2((r_rv < c.minV || r_rv > c.maxV) ? 0u : r_rv, r_av);      // -min / -max (merfin.C:199-200)
 #pragma unroll
       for (int j = 0; j < B; ++j)
         if (sj == j) { rv[j] = x.x; av[j] = x.y; st[j] = 0xffu; }
@@ -1337,18 +1514,40 @@ __device__ __forceinline__ void mfx_lane_lookup8(const mfx_table_view &c, mfx_ma
   }
 }
 
+// the k-mer of query j from an array (the callers that hold their k-mers anyway): a select chain, never an indexed register array
+template <int B>
+struct mfx_key_from_array {
+  const uint64_t (&key)[B];
+  __device__ __forceinline__ uint64_t operator()(int sj) const {
+    uint64_t k = 0;
+#pragma unroll
+    for (int j = 0; j < B; ++j) if (j == sj) k = key[j];
+    return k;
+  }
+};
+
 #ifndef MFX_V_LANEPROBE
-#define MFX_V_LANEPROBE 1             // 1: per-lane probe of the compact layout (mfx_lane_lookup8); 0: the cooperative one (A/B: tools/ab_build.sh)
+#define MFX_V_LANEPROBE 1             // 1: per-lane probe of the compact layout (mfx_lane_lookup8); 0: the cooperative one (A/B: tools/ab_build.sh; k <= 21 only)
 #endif
+
+// the compact lookup of the kernels that hold their k-mers: home line, first mini-bucket and key field by mfx_home
+template <int B>
+__device__ __forceinline__ void mfx_compact_lookup(const mfx_table_view &t, mfx_mailbox &M, const uint64_t (&key)[B], const uint64_t (&krc)[B],
+                                                   const bool (&ok)[B], uint32_t (&rv)[B], uint32_t (&av)[B]) {
 #if MFX_V_LANEPROBE
-#define MFX_COMPACT_LOOKUP(t, MB, key, krc, ok, rv, av) mfx_lane_lookup8<MFX_BATCH>(t, MB, key, krc, ok, rv, av)
-#define MFX_COMPACT_LOOKUP_PRE(t, MB, key, krc, ok, rv, av, pre, pb0) mfx_lane_lookup8<MFX_BATCH>(t, MB, key, krc, ok, rv, av, pre, pb0)
-#define MFX_COMPACT_LOOKUP_DBG(t, MB, key, krc, ok, rv, av, pre, pb0, dbg) mfx_lane_lookup8<MFX_BATCH>(t, MB, key, krc, ok, rv, av, pre, pb0, dbg)
+  uint64_t fkey[B];
+  uint32_t line[B], b0[B];
+#pragma unroll
+  for (int j = 0; j < B; ++j) {
+    fkey[j] = key[j]; line[j] = 0u; b0[j] = 0u;
+    if (ok[j]) { const mfx_probe pr = mfx_home(t, key[j]); fkey[j] = pr.fkey; line[j] = pr.lineA; b0[j] = pr.b0; }
+  }
+  mfx_lane_lookup8<B>(t, M, fkey, ok, rv, av, line, b0, mfx_key_from_array<B>{key});
 #else
-#define MFX_COMPACT_LOOKUP(t, MB, key, krc, ok, rv, av) mfx_group_lookup8<MFX_BATCH>(t, MB, key, krc, ok, rv, av)
-#define MFX_COMPACT_LOOKUP_PRE(t, MB, key, krc, ok, rv, av, pre, pb0) mfx_group_lookup8<MFX_BATCH>(t, MB, key, krc, ok, rv, av)
-#define MFX_COMPACT_LOOKUP_DBG(t, MB, key, krc, ok, rv, av, pre, pb0, dbg) mfx_group_lookup8<MFX_BATCH>(t, MB, key, krc, ok, rv, av)
+  mfx_group_lookup8<B>(t, M, key, krc, ok, rv, av);
 #endif
+}
+#define MFX_COMPACT_LOOKUP(t, MB, key, krc, ok, rv, av) mfx_compact_lookup<MFX_BATCH>(t, MB, key, krc, ok, rv, av)
 
 // k-mer starting at tile position p; returns validity (all k bases ACGT)
 __device__ __forceinline__ bool mfx_tile_kmer(const mfx_tile_lds &L, int k, uint32_t p, uint64_t &fwd) {
@@ -1381,48 +1580,67 @@ __device__ __forceinline__ uint32_t mfx_pk_min_u16(uint32_t a, uint32_t b) {
 }
 __device__ __forceinline__ uint32_t mfx_mod_pack(uint32_t order, uint32_t q) { return ((order << 7) | q) | (((order << 7) | (127u - q)) << 16); }
 
-// the order values of the positions behind the wave, for all B batch elements (lane 15 * j + i: position 64 + i of element j)
+// the order values of the H = npos - 1 positions behind the wave (H <= 27), for all B batch elements: lane H * jj + i takes the
+// t-mer at position 64 + i of element jj; 64 / H elements fit one pass (all four for k = 21: H = 15), the rest a second one
 template <int B>
-__device__ __forceinline__ uint32_t mfx_wave_mod_halo(const mfx_table_view &c, const mfx_tile_lds &L, uint32_t p0) {
-  static_assert(15 * B <= 64, "one lane per position behind the wave and batch element");
+__device__ __forceinline__ void mfx_wave_mod_halo(const mfx_table_view &c, const mfx_tile_lds &L, uint32_t p0, uint32_t (&halo)[2]) {
   const int t = c.mz_t;
+  const uint32_t H = (uint32_t)(c.k - t), per = 64u / H;
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t jj = lane / 15u, ii = lane - 15u * jj;
-  uint32_t halo = 0xffffffffu;
-  if (jj < (uint32_t)B) {
-    const uint32_t q = p0 - lane + jj * MFX_BLOCK + 64u + ii, wd = q >> 5, o = q & 31u, sh = 2u * o;
-    const uint64_t w0 = L.codes[wd], w1 = L.codes[wd + 1];
-    const uint32_t a = (uint32_t)(((w0 << sh) | ((w1 >> 1) >> (63u - sh))) >> (64 - 2 * t));
-    const uint32_t b = (uint32_t)mfx_revcomp((uint64_t)a, t);
-    halo = mfx_mod_pack(mfx_tmer_order(a < b ? a : b), 64u + ii);
+  const uint32_t jj = lane / H, ii = lane - H * jj;
+#pragma unroll
+  for (uint32_t ps = 0; ps < 2u; ++ps) {
+    halo[ps] = 0xffffffffu;
+    const uint32_t el = ps * per + jj;
+    if (ps * per < (uint32_t)B && jj < per && el < (uint32_t)B) {     // (wave-uniform first test: no second pass when one holds all B)
+      const uint32_t q = p0 - lane + el * MFX_BLOCK + 64u + ii, wd = q >> 5, o = q & 31u, sh = 2u * o;
+      const uint64_t w0 = L.codes[wd], w1 = L.codes[wd + 1];
+      const uint32_t a = (uint32_t)(((w0 << sh) | ((w1 >> 1) >> (63u - sh))) >> (64 - 2 * t));
+      const uint32_t b = (uint32_t)mfx_revcomp((uint64_t)a, t);
+      halo[ps] = mfx_mod_pack(mfx_tmer_order(a < b ? a : b), 64u + ii);
+    }
   }
-  return halo;
 }
 
-// the home line of the lane's k-mer of batch element j (f: forward k-mer, r: its reverse complement).  mw: 80 words of LDS of
-// this wave (the mailbox of the lookup, idle at this point): the wave's values are written side by side and every lane takes
-// the minimum of the npos words from its own on -- 16 plain LDS reads and 15 packed minima; a doubling scheme over cross-lane
-// reads (4 x 2 ds_bpermute, the second for the positions behind the wave) cost twice the instructions.
-__device__ __forceinline__ uint32_t mfx_wave_mod_line(const mfx_table_view &c, uint32_t *mw, uint32_t halo, int j, uint64_t f, uint64_t r, uint32_t &b0) {
+// the home line of the lane's k-mer of batch element j (f: forward k-mer, r: its reverse complement).  mw: 64 + npos words of LDS
+// of this wave (the mailbox of the lookup, idle at this point): the wave's values are written side by side and every lane takes
+// the minimum of the npos words from its own on -- npos plain LDS reads and npos - 1 packed minima (16 for k = 21); a doubling
+// scheme over cross-lane reads (4 x 2 ds_bpermute, the second for the positions behind the wave) cost twice the instructions.
+// fkey: what the key field of the k-mer's slot holds (the canonical k-mer; quotient form: mfx_q_place).
+__device__ __forceinline__ uint32_t mfx_wave_mod_line(const mfx_table_view &c, uint32_t *mw, const uint32_t (&halo)[2], int j, uint64_t f, uint64_t r,
+                                                      uint32_t &b0, uint64_t &fkey) {
   const int k = c.k, t = c.mz_t, w = c.mz_w, m = k - w + 1, npos = k - t + 1;
   const uint32_t lane = threadIdx.x & 63u, tmask = (1u << (2 * t)) - 1u;
+  const uint32_t H = (uint32_t)(k - t), per = 64u / H;
   const uint64_t mmask = (~0ULL) >> (64 - 2 * m);
   const uint32_t a = (uint32_t)(f >> (2 * (k - t))) & tmask, b = (uint32_t)r & tmask;     // the t-mer at this position, and its reverse complement
-  const uint32_t hv = (uint32_t)__shfl((int)halo, (int)(15u * (uint32_t)j + lane), 64);
+  const uint32_t hsrc = (uint32_t)j < per ? halo[0] : halo[1];
+  const uint32_t hv = (uint32_t)__shfl((int)hsrc, (int)(H * ((uint32_t)j < per ? (uint32_t)j : (uint32_t)j - per) + lane), 64);
   mfx_wave_handoff();                                          // the previous element's reads are done
   mw[lane] = mfx_mod_pack(mfx_tmer_order(a < b ? a : b), lane);
-  if (lane < 16u) mw[64u + lane] = lane < 15u ? hv : 0xffffffffu;
+  if (lane <= H) mw[64u + lane] = lane < H ? hv : 0xffffffffu;
   mfx_wave_handoff();
   uint32_t v = 0xffffffffu;
 #pragma unroll
-  for (int i = 0; i < 16; ++i)
+  for (int i = 0; i < 28; ++i)
     if (i < npos) v = mfx_pk_min_u16(v, mw[lane + (uint32_t)i]);
   const bool fwd = f <= r;
   const uint32_t q = fwd ? (v & 127u) : 127u - ((v >> 16) & 127u);
   const uint32_t xf = q - lane, jf = xf % (uint32_t)w;        // the t-mer's offset and the window, counted on the forward strand
   const uint64_t ma = (f >> (2 * ((uint32_t)w - 1u - jf))) & mmask, mb = (r >> (2 * jf)) & mmask;
+  const uint32_t xc = fwd ? xf : (uint32_t)(k - t) - xf;     // the offset in the canonical k-mer
   uint32_t line;
-  mfx_mod_place(ma < mb ? ma : mb, fwd ? xf : (uint32_t)(k - t) - xf, c.nlines, line, b0);    // the offset in the canonical k-mer
+  fkey = fwd ? f : r;
+  if (c.quot) {
+    // the pieces mfx_q_parts finds from the canonical k-mer, read off the forward-strand ones ((k - t) % 4 == 3: window jf of the
+    // forward k-mer is window 3 - jf of its reverse complement)
+    const uint32_t jc = fwd ? jf : 3u - jf;
+    const uint64_t ac = fwd ? ma : mb, bc = fwd ? mb : ma;
+    const uint32_t e = (uint32_t)(((fkey >> (2 * (m + 3 - (int)jc))) << (2 * (3 - (int)jc))) | (fkey & ((1ull << (2 * (3 - (int)jc))) - 1ull)));
+    mfx_q_place(c, ac < bc ? ac : bc, bc < ac ? 1u : 0u, jc, e, xc, line, b0, fkey);
+  } else {
+    mfx_mod_place(ma < mb ? ma : mb, xc, c.nlines, line, b0);
+  }
   return line;
 }
 
@@ -1452,7 +1670,7 @@ __global__ __launch_bounds__(MFX_BLOCK, MFX_V_MINBLOCKS) void mfx_hist_kernel(mf
   __shared__ mfx_hist_lds H;
 
   const uint32_t tid = threadIdx.x;
-  if (KF) { a.t.k = KF; a.t.mz_w = WF; a.t.mz_t = TF; }         // (the launcher checked that they are the table's)
+  if (KF) { a.t.k = KF; a.t.mz_w = WF; a.t.mz_t = TF; a.t.quot = KF > MFX_MAX_K_DIRECT ? 1 : 0; }   // (the launcher checked that they are the table's)
   const int k = KF ? KF : a.t.k;
   const mfx_kstar_args &ka = a.ks;
   mfx_hist_lds_init(H, ka);
@@ -1510,43 +1728,77 @@ __global__ __launch_bounds__(MFX_BLOCK, MFX_V_MINBLOCKS) void mfx_hist_kernel(mf
     double kover = 0.0;                      // this lane's koverCpy terms of this tile
     for (uint32_t b = 0; b < MFX_TILE / MFX_BLOCK; b += MFX_BATCH) {
       if (b * MFX_BLOCK >= n) break;         // short last tile of a contig (block-uniform): nothing starts beyond n
-      uint64_t key[MFX_BATCH], key2[MFX_BATCH];
-      uint32_t rv[MFX_BATCH], av[MFX_BATCH], pre[MFX_BATCH], pb0[MFX_BATCH];
+      uint32_t rv[MFX_BATCH], av[MFX_BATCH];
       bool     ok[MFX_BATCH];
       // mod-minimizer placement: the wave finds its home lines together (mfx_wave_mod_line)
       const bool wave_lines = COMPACT && CANON && (KF ? TF != 0 : a.t.mz_t != 0);
-      const uint32_t halo = wave_lines ? mfx_wave_mod_halo<MFX_BATCH>(a.t, L, b * MFX_BLOCK + tid) : 0u;
+      const bool even_k = KF ? (KF & 1) == 0 : (k & 1) == 0;
+      if (wave_lines) {
+        uint64_t fkey[MFX_BATCH];
+        uint32_t line[MFX_BATCH], b0[MFX_BATCH];
+        uint32_t halo[2], pal = 0u;
+        mfx_wave_mod_halo<MFX_BATCH>(a.t, L, b * MFX_BLOCK + tid, halo);
 #pragma unroll
-      for (int j = 0; j < MFX_BATCH; ++j) {
-        uint32_t p = (b + j) * MFX_BLOCK + tid;     // lane-consecutive positions
-        uint64_t f;
-        ok[j] = mfx_tile_kmer(L, k, p, f) && (p < n);
-        uint64_t r = mfx_revcomp(f, k);
-        pb0[j] = 0u;
-        pre[j] = wave_lines ? mfx_wave_mod_line(a.t, reinterpret_cast<uint32_t *>(&MB.rec[tid & ~63u]), halo, j, f, r, pb0[j]) : 0u;
-        if (CANON) {
-          key[j] = f < r ? f : r; key2[j] = f < r ? r : f;     // canonical k-mer and its reverse complement
-        } else {
-          key[j] = f; key2[j] = r;
+        for (int j = 0; j < MFX_BATCH; ++j) {
+          const uint32_t p = (b + j) * MFX_BLOCK + tid;     // lane-consecutive positions
+          uint64_t f;
+          ok[j] = mfx_tile_kmer(L, k, p, f) && (p < n);
+          const uint64_t r = mfx_revcomp(f, k);
+          line[j] = mfx_wave_mod_line(a.t, reinterpret_cast<uint32_t *>(&MB.rec[tid & ~63u]), halo, j, f, r, b0[j], fkey[j]);
+          if (!ok[j]) { line[j] = 0u; b0[j] = 0u; }            // no k-mer here: a dummy load of line 0, ignored
+          if (even_k && f == r) pal |= 1u << j;
         }
-      }
-      if (wave_lines && DBG) MFX_COMPACT_LOOKUP_DBG(a.t, MB, key, key2, ok, rv, av, pre, pb0, reinterpret_cast<unsigned long long *>(a.dbg));
-      else if (wave_lines) MFX_COMPACT_LOOKUP_PRE(a.t, MB, key, key2, ok, rv, av, pre, pb0);
-      else if (COMPACT) MFX_COMPACT_LOOKUP(a.t, MB, key, key2, ok, rv, av);
-      else mfx_group_lookup<MFX_BATCH>(a.t, MB, key, key2, ok, rv, av);
-      if (!CANON) {
-        // value(fmer) + value(rmer), uint32 arithmetic (merfin-globals.C:107-108)
-        uint32_t rv2[MFX_BATCH], av2[MFX_BATCH];
-        if (COMPACT) MFX_COMPACT_LOOKUP(a.t, MB, key2, key, ok, rv2, av2);
-        else mfx_group_lookup<MFX_BATCH>(a.t, MB, key2, key, ok, rv2, av2);
+        // the k-mer of query sj, for the rare endings of the probe: the key field itself (k <= 21), or again from the tile
+        const bool quot = KF ? KF > MFX_MAX_K_DIRECT : a.t.quot != 0;
+        auto keyof = [&](int sj) -> uint64_t {
+          uint64_t kk = 0;
+          if (!quot) {
 #pragma unroll
-        for (int j = 0; j < MFX_BATCH; ++j) { rv[j] += rv2[j]; av[j] += av2[j]; }
-      } else if (KF ? (KF & 1) == 0 : (k & 1) == 0) {
-        // even k, canonical database: a k-mer that is its own reverse complement is looked up as fmer AND as rmer by the
-        // reference -- the same slot twice (value(fmer) + value(rmer), uint32 arithmetic); every other k-mer has one strand
-        // in the database, the one probed
+            for (int j = 0; j < MFX_BATCH; ++j) if (j == sj) kk = fkey[j];
+          } else {
+            uint64_t f;
+            (void)mfx_tile_kmer(L, k, (b + (uint32_t)sj) * MFX_BLOCK + tid, f);
+            const uint64_t r = mfx_revcomp(f, k);
+            kk = f < r ? f : r;
+          }
+          return kk;
+        };
+        mfx_lane_lookup8<MFX_BATCH>(a.t, MB, fkey, ok, rv, av, line, b0, keyof, DBG ? reinterpret_cast<unsigned long long *>(a.dbg) : nullptr);
+        if (even_k) {
+          // even k, canonical database: a k-mer that is its own reverse complement is looked up as fmer AND as rmer by the
+          // reference -- the same slot twice (value(fmer) + value(rmer), uint32 arithmetic); every other k-mer has one strand
+          // in the database, the one probed
 #pragma unroll
-        for (int j = 0; j < MFX_BATCH; ++j) if (key[j] == key2[j]) { rv[j] += rv[j]; av[j] += av[j]; }
+          for (int j = 0; j < MFX_BATCH; ++j) if ((pal >> j) & 1u) { rv[j] += rv[j]; av[j] += av[j]; }
+        }
+      } else {
+        uint64_t key[MFX_BATCH], key2[MFX_BATCH];
+#pragma unroll
+        for (int j = 0; j < MFX_BATCH; ++j) {
+          const uint32_t p = (b + j) * MFX_BLOCK + tid;     // lane-consecutive positions
+          uint64_t f;
+          ok[j] = mfx_tile_kmer(L, k, p, f) && (p < n);
+          const uint64_t r = mfx_revcomp(f, k);
+          if (CANON) {
+            key[j] = f < r ? f : r; key2[j] = f < r ? r : f;     // canonical k-mer and its reverse complement
+          } else {
+            key[j] = f; key2[j] = r;
+          }
+        }
+        if (COMPACT) MFX_COMPACT_LOOKUP(a.t, MB, key, key2, ok, rv, av);
+        else mfx_group_lookup<MFX_BATCH>(a.t, MB, key, key2, ok, rv, av);
+        if (!CANON) {
+          // value(fmer) + value(rmer), uint32 arithmetic (merfin-globals.C:107-108)
+          uint32_t rv2[MFX_BATCH], av2[MFX_BATCH];
+          if (COMPACT) MFX_COMPACT_LOOKUP(a.t, MB, key2, key, ok, rv2, av2);
+          else mfx_group_lookup<MFX_BATCH>(a.t, MB, key2, key, ok, rv2, av2);
+#pragma unroll
+          for (int j = 0; j < MFX_BATCH; ++j) { rv[j] += rv2[j]; av[j] += av2[j]; }
+        } else if (even_k) {
+          // (the same slot twice for a k-mer that is its own reverse complement: see above)
+#pragma unroll
+          for (int j = 0; j < MFX_BATCH; ++j) if (key[j] == key2[j]) { rv[j] += rv[j]; av[j] += av[j]; }
+        }
       }
 #pragma unroll
       for (int j = 0; j < MFX_BATCH; ++j) {
@@ -2089,8 +2341,10 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_count_kernel(mfx_count_args a) 
         if (ok) {
           unsigned long long cur = 0;
           bool claimed;
-          unsigned long long *w = mfx_c_claim(a.t, key, a.meta, fresh, cur, a.count ? 1u : 0u, claimed);
+          mfx_slot *ss;
+          unsigned long long *w = mfx_c_claim(a.t, key, a.meta, fresh, cur, a.count ? 1u : 0u, claimed, ss);
           if (w && a.count && !claimed) mfx_c_add(a.t, w, cur, key, 1u, 1, a.meta);
+          else if (ss && a.count) atomicAdd(&ss->asmV, 1u);      // beyond its candidate lines (quotient form): counted in the side table
         }
       } else if (MODE == 1 && a.count) mfx_group_insert(a.t, key, ok ? 1u : 0u, 1, a.meta, fresh);
       else if (ok) {
@@ -2149,6 +2403,46 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_completeness_kernel(mfx_table_v
 }
 
 // ===========================================================================
+// Diagnostic: the random-access LINE rate of this device's HBM -- independent 16-byte loads at uniformly random 128-byte
+// lines of a table far beyond the caches, four in flight per lane (tools/ubench_gather.hip found the rate the same for
+// 8 .. 16 bytes per lane, 1 .. 8 loads in flight and 4 .. 16 blocks per CU, for tables of 8 .. 160 GiB).  It is the roof
+// of the index probe: bench.py runs it on the box of the measurement and reports the kernel's line rate against it.
+// ===========================================================================
+__global__ __launch_bounds__(256) void mfx_gather_rate_kernel(const uint4 *__restrict__ t, uint64_t nlines, int iters, uint64_t seed, uint64_t *out) {
+  const uint64_t tid = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  uint64_t acc = 0, ctr = seed + tid * 0x9e3779b97f4a7c15ULL;
+  for (int it = 0; it < iters; ++it) {
+    uint4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ctr += 0xD1B54A32D192ED03ULL;
+      v[j] = t[__umul64hi(mfx_hash64(ctr), nlines) * 8];      // the first 16 bytes of a random line
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc += v[j].x ^ v[j].w;
+  }
+  if (acc == 0x1234567ULL) out[0] = acc;                       // (keeps the loads)
+}
+hipError_t mfx_k_gather_rate(const void *table, uint64_t nlines, uint64_t *scratch, double *lines_per_s, hipStream_t st) {
+  const int grid = 256 * 8, iters = 256;                       // 2^21 lanes x 4 x 256 = 2.1 G line reads
+  hipEvent_t e0, e1;
+  hipError_t e = hipEventCreate(&e0);
+  if (e != hipSuccess) return e;
+  e = hipEventCreate(&e1);
+  if (e != hipSuccess) { (void)hipEventDestroy(e0); return e; }
+  mfx_gather_rate_kernel<<<grid, 256, 0, st>>>(reinterpret_cast<const uint4 *>(table), nlines, 2, 1, scratch);       // warm
+  (void)hipEventRecord(e0, st);
+  mfx_gather_rate_kernel<<<grid, 256, 0, st>>>(reinterpret_cast<const uint4 *>(table), nlines, iters, 77, scratch);
+  (void)hipEventRecord(e1, st);
+  e = hipEventSynchronize(e1);
+  float ms = 0;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (e == hipSuccess) *lines_per_s = (double)grid * 256.0 * 4.0 * iters / (ms * 1e-3);
+  return e;
+}
+
+// ===========================================================================
 // launch wrappers (called from mfx_api.cpp, which is compiled as plain C++)
 // ===========================================================================
 hipError_t mfx_k_table_init(mfx_slot *slots, uint64_t nslots, hipStream_t st) {
@@ -2194,9 +2488,11 @@ hipError_t mfx_k_table_export(mfx_table_view t, uint64_t *kmers, uint32_t *readV
 hipError_t mfx_k_hist(const mfx_hist_args &a, int grid, hipStream_t st) {
   // MFX_DEBUG_DYN_LDS: extra dynamic LDS per block, an occupancy knob for experiments only
   static const unsigned dyn = getenv("MFX_DEBUG_DYN_LDS") ? (unsigned)atoi(getenv("MFX_DEBUG_DYN_LDS")) : 0u;
-  static const bool generic = getenv("MFX_HIST_GENERIC") && atoi(getenv("MFX_HIST_GENERIC"));     // A/B, tests: never the specialised instances
+  const char *ge = getenv("MFX_HIST_GENERIC");                                                    // A/B, tests: never the specialised instances (read per launch: tests switch it)
+  const bool generic = ge && atoi(ge);
   if (a.dbg && a.canonical && a.t.compact && a.t.k == 21 && a.t.mz_w == 4 && a.t.mz_t == 6 && !generic) mfx_hist_kernel<true, true, 21, 4, 6, true><<<grid, MFX_BLOCK, dyn, st>>>(a);
   else if (a.canonical && a.t.compact && a.t.k == 21 && a.t.mz_w == 4 && a.t.mz_t == 6 && !generic) mfx_hist_kernel<true, true, 21, 4, 6><<<grid, MFX_BLOCK, dyn, st>>>(a);
+  else if (a.canonical && a.t.compact && a.t.quot && a.t.k == 31 && a.t.mz_w == 4 && a.t.mz_t == 4 && !generic) mfx_hist_kernel<true, true, 31, 4, 4><<<grid, MFX_BLOCK, dyn, st>>>(a);
   else if (a.canonical && a.t.compact) mfx_hist_kernel<true, true, 0, 0, 0><<<grid, MFX_BLOCK, dyn, st>>>(a);
   else if (a.canonical)                mfx_hist_kernel<true, false, 0, 0, 0><<<grid, MFX_BLOCK, dyn, st>>>(a);
   else if (a.t.compact)                mfx_hist_kernel<false, true, 0, 0, 0><<<grid, MFX_BLOCK, dyn, st>>>(a);
@@ -2253,6 +2549,9 @@ hipError_t mfx_k_sum_tile_partials(double *tile_partials, uint64_t ntiles, doubl
   mfx_sum_partials_kernel<<<1, MFX_BLOCK, 0, st>>>(tile_partials + n, (uint32_t)nch, out, ctr_reset);
   return hipGetLastError();
 }
+// the quotient form of the compact layout (22 <= k <= 31) is served by the per-lane probe only (an A/B build with
+// -DMFX_V_LANEPROBE=0 keeps those k in 16-byte slots)
+int mfx_k_quot_supported() { return MFX_V_LANEPROBE ? 1 : 0; }
 int mfx_k_hist_resident_blocks(int compact) {
   int nb = 0;
   const hipError_t e = compact ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mfx_hist_kernel<true, true, 0, 0, 0>, MFX_BLOCK, 0)

@@ -1,7 +1,7 @@
 """The SEQUENCE-ONLY index (mfx_index_create_for_seq): the lookup object of -hist and -dump, which only ever ask for the
 k-mers of -sequence (merfin-histogram.C:54-64, merfin-dump.C:44-61).  It holds the k-mers claimed from the sequence;
-loads only update.  For k <= 21 it takes the compact layout (8-byte slots, 16 per line, saturated counts in a side
-table).  Everything it answers must equal what the full index -- and the oracle -- answer."""
+loads only update.  For k <= 31 it takes the compact layout (8-byte slots, 16 per line, saturated counts in a side
+table; 22 <= k <= 31: the slot's key field holds the k-mer's QUOTIENT -- what its line does not already say).  Everything it answers must equal what the full index -- and the oracle -- answer."""
 import os
 
 import numpy as np
@@ -35,7 +35,9 @@ def seq_index(m, k, contigs, read, asm=None, lo=0, hi=2**64 - 1, seqs=None):
 
 
 @pytest.mark.parametrize("k,peak,use_prob,compact", [(21, 17.3, False, "1"), (21, 26.0, True, "1"), (21, 26.0, True, "0"), (31, 17.3, False, "1"),
-                                                     (15, 9.0, False, "1"), (8, 9.0, False, "1"), (12, 3.0, True, "0")])
+                                                     (15, 9.0, False, "1"), (8, 9.0, False, "1"), (12, 3.0, True, "0"),
+                                                     (31, 17.3, False, "0"), (22, 9.0, False, "1"), (24, 26.0, True, "1"), (27, 17.3, False, "1"),
+                                                     (30, 9.0, False, "1")])
 def test_seq_only_hist_and_dump_match_oracle(k, peak, use_prob, compact, golden_dir, monkeypatch):
     m = _mfx()
     monkeypatch.setenv("MFX_SEQ_COMPACT", compact)
@@ -47,7 +49,7 @@ def test_seq_only_hist_and_dump_match_oracle(k, peak, use_prob, compact, golden_
     for from_db in (False, True):
         ix, seqs = seq_index(m, k, contigs, read, asm if from_db else None)
         info = ix.info()
-        assert info["seq_only"] and info["compact"] == (compact == "1" and k <= 21)
+        assert info["seq_only"] and info["compact"] == (compact == "1" and k <= 31)
         assert info["distinct"] == len(asm[0])                    # one slot per distinct canonical k-mer of the sequence
         # every read k-mer that is not a k-mer of the sequence was dropped, nothing else
         assert info["dropped"] == int(np.count_nonzero(~np.isin(read[0], asm[0]) & (read[1] > 0)))
@@ -120,6 +122,59 @@ def test_seq_only_saturated_counts_and_crowded_lines(seed, monkeypatch):
     true_asm = po.count_kmers(k, contigs)
     _, ga2 = cx.value(true_asm[0])
     np.testing.assert_array_equal(ga2, true_asm[1])
+
+
+@pytest.mark.parametrize("k,lf,seed", [(22, "0.5", 1), (22, "0.85", 2), (23, "0.85", 3), (24, "0.7", 4), (24, "0.85", 5), (25, None, 6), (28, None, 7)])
+def test_quotient_form_crowded_tables_and_the_side_table(k, lf, seed, monkeypatch):
+    """22 <= k <= 31: the slot keeps the k-mer's quotient (mfx_q_place), a k-mer has THREE candidate lines (d rides in the key
+    field) and lives in the side table under its full key beyond them.  Tables so full that all of that happens (the smallest
+    table of a k grows with k -- k = 22..24 can be crowded by a test-sized world): claims, counts by unit steps, loads in
+    instalments with saturating fields, -hist (wave path and the generic kernel), value(), the export (quotient -> k-mer) and
+    -dump must all be the oracle's"""
+    m = _mfx()
+    if lf:
+        monkeypatch.setenv("MFX_LOAD_FACTOR", lf)
+    r = np.random.default_rng(9000 + seed)
+    peak = float(r.choice([2.5, 9.0, 26.0]))
+    contigs, read, asm = synth.world(k=k, peak=peak, seed=9100 + seed, sizes=(60000, 20000, 4097, 30, 0), err_kmers=1500)
+    rv = read[1].astype(np.uint64)
+    big = r.random(len(rv)) < 0.03
+    rv[big] = r.choice([2046, 2047, 2048, 5000, 200000], size=int(big.sum()))
+    read = (read[0], rv.astype(np.uint32))
+    p, g, ka, km = oracle_hist(k, peak, contigs, read, asm)
+    seqs = m.Sequences(contigs)
+    ix = m.Index.for_seq(k, sum(len(c) for c in contigs) + 16)
+    ix.count_asm(seqs)                                            # every occurrence counted one by one
+    info = ix.info()
+    assert info["compact"] and info["distinct"] == len(asm[0])
+    parts = [read[1] // 2, read[1] - read[1] // 2]
+    for part in parts:
+        ix.add_read(read[0], part)
+    ek, er, ea = ix.export()
+    np.testing.assert_array_equal(ek, asm[0])
+    np.testing.assert_array_equal(ea, asm[1])
+    rd = dict(zip(read[0].tolist(), read[1].tolist()))
+    want = np.array([rd.get(x, 0) for x in asm[0].tolist()], dtype=np.uint32)
+    np.testing.assert_array_equal(er, want)
+    gr, ga = ix.value(asm[0])
+    np.testing.assert_array_equal(ga, asm[1])
+    np.testing.assert_array_equal(gr, want)
+    foreign = read[0][~np.isin(read[0], asm[0])][:2000]
+    fr, fa = ix.value(foreign)
+    assert not fr.any() and not fa.any()
+    ev = m.Evaluator(ix, m.KParams(peak))
+    assert_hist_equal(ev.hist(seqs), g, ka, km, k)
+    assert_hist_equal(ev.hist_streamed(m.Sequences.create([len(c) for c in contigs]), contigs), g, ka, km, k)
+    monkeypatch.setenv("MFX_HIST_GENERIC", "1")
+    assert_hist_equal(m.Evaluator(ix, m.KParams(peak)).hist(seqs), g, ka, km, k)
+    monkeypatch.delenv("MFX_HIST_GENERIC")
+    full = m.Evaluator(build_index(m, k, read, asm), m.KParams(peak))
+    for c in range(2):
+        a = ev.dump_values(seqs, c, 0, len(contigs[c]))
+        b = full.dump_values(seqs, c, 0, len(contigs[c]))
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[1], b[1])
+        assert a[2:] == b[2:]
 
 
 def test_seq_only_counts_accumulate_beyond_the_field_by_unit_steps():
@@ -240,7 +295,7 @@ def test_seq_only_image_roundtrip_and_replica(k, tmp_path):
     ix.save(str(tmp_path / "img"))
     for other in (m.Index.load(str(tmp_path / "img")), ix.replicate(0)):
         info = other.info()
-        assert info["seq_only"] and info["compact"] == (k <= 21) and info["distinct"] == len(asm[0])
+        assert info["seq_only"] and info["compact"] == (k <= 31) and info["distinct"] == len(asm[0])
         assert_hist_equal(m.Evaluator(other, m.KParams(peak)).hist(seqs), g, ka, km, k)
         with pytest.raises(m.MfxError, match="claimed before"):
             other.claim_seq(seqs)
@@ -293,7 +348,7 @@ def test_packed_upload_equals_the_byte_upload(k, monkeypatch):
         np.testing.assert_array_equal(ea[2], asm[1])
 
 
-@pytest.mark.parametrize("k", list(range(13, 22)))
+@pytest.mark.parametrize("k", list(range(13, 32)))
 def test_mod_minimizer_placement_every_k(k, monkeypatch):
     """the compact layout places a k-mer by the window its smallest t-mer samples (mod-minimizer: t = 4..7 by k, windows of
     8 / 12 / 16 t-mers).  The evaluation kernel finds those windows for a whole wave at once, the build kernels and the by-key
@@ -323,7 +378,7 @@ def test_mod_minimizer_placement_every_k(k, monkeypatch):
         for kk, vv in env.items():
             monkeypatch.setenv(kk, vv)
         ix, seqs = seq_index(m, k, contigs, read)
-        assert ix.info()["compact"]
+        assert ix.info()["compact"] == (k <= 21 or "MFX_MZ_MOD" not in env)     # the quotient form (k > 21) needs the mod-minimizer
         ev = m.Evaluator(ix, m.KParams(peak))
         assert_hist_equal(ev.hist(seqs), g, ka, km_, k)
         ek, er, ea = ix.export()

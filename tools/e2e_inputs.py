@@ -1,0 +1,97 @@
+"""Inputs of an end-to-end `merfin -hist` run made from the synthetic world of bench.py: the assembly as a FASTA
+file (80 bases per line) and the read database -- every read k-mer of the FULL tables, sorted as `meryl print` lists them --
+as this repo's delta-coded flat file (mfx_db_write_flat; what `merfin -convert` makes of a meryl database once).
+Bench / profiling infrastructure: used by bench.py's `e2e` leg and tools/cfg2_cli_timing.py-style timings."""
+import os
+import time
+
+import numpy as np
+
+
+def write_inputs(m, st, torch, bases, outdir, ncontigs=24, k=21, lam=26.0, seed=None, log=lambda *a: None):
+    """returns {"fasta": path, "readdb": path, "read_kmers": n, "db_bytes": b, "fasta_bytes": b, "lens": [...], "write_s": s}"""
+    t0 = time.time()
+    os.makedirs(outdir, exist_ok=True)
+    # the world's own full table only has to leave room for its export: a crowded table is fine here
+    os.environ["MFX_LOAD_FACTOR"] = "0.85"
+    try:
+        kw = {} if seed is None else {"seed": seed}
+        ix, seqs, asm, info = st.build_world(m, bases, k=k, lam=lam, ncontigs=ncontigs, **kw)
+    finally:
+        os.environ.pop("MFX_LOAD_FACTOR", None)
+    ek, er, _ea = ix.export(sort=False)
+    del _ea
+    contigs = [a.cpu().numpy() for a in asm]
+    ix.close()
+    seqs.close()
+    del ix, seqs, asm
+    torch.cuda.empty_cache()
+    log("world built and exported: %.1fs" % (time.time() - t0))
+    # sorted, entries with a read count only -- on the GPU, in key ranges (torch.sort takes < 2^31 elements)
+    kd = torch.from_numpy(ek.view(np.int64)).cuda()
+    vd = torch.from_numpy(er.view(np.int32)).cuda()
+    del ek, er
+    nq = max(1, int(np.ceil(kd.numel() / 7e8)))
+    shift = 2 * k
+    ks, vs = [], []
+    CH = 1 << 30
+    for q in range(nq):
+        lo, hi = (q << shift) // nq, ((q + 1) << shift) // nq
+        kp, vp = [], []
+        for o in range(0, kd.numel(), CH):
+            kc, vc = kd[o:o + CH], vd[o:o + CH]
+            sel = (kc >= lo) & (kc < hi) & (vc != 0)
+            kp.append(kc[sel])
+            vp.append(vc[sel])
+        kq, o = torch.sort(torch.cat(kp))
+        vq = torch.cat(vp)[o]
+        ks.append(kq.cpu().numpy().view(np.uint64))
+        vs.append(vq.cpu().numpy().view(np.uint32))
+        del kp, vp, kq, o, vq, sel
+    del kd, vd
+    torch.cuda.empty_cache()
+    rk, rv = np.concatenate(ks), np.concatenate(vs)
+    del ks, vs
+    readdb = os.path.join(outdir, "read.mfxk")
+    m.db_write_flat(readdb, k, rk, rv)
+    n_read = len(rk)
+    del rk, rv
+    log("read database written: %.1fs" % (time.time() - t0))
+    fasta = os.path.join(outdir, "asm.fasta")
+    with open(fasta, "wb") as f:
+        for ci, a in enumerate(contigs):
+            f.write(b">contig_%d synthetic\n" % (ci + 1))
+            rows = len(a) // 80
+            out_ = np.empty((rows, 81), dtype=np.uint8)
+            out_[:, :80] = a[:rows * 80].reshape(rows, 80)
+            out_[:, 80] = 10
+            f.write(out_.tobytes())
+            if rows * 80 < len(a):
+                f.write(a[rows * 80:].tobytes() + b"\n")
+            del out_
+    return {"fasta": fasta, "readdb": readdb, "read_kmers": n_read, "db_bytes": os.path.getsize(readdb), "fasta_bytes": os.path.getsize(fasta),
+            "lens": [len(a) for a in contigs], "write_s": time.time() - t0}
+
+
+def run_cli_hist(root, inp, peak=26.0, prob=None, out_hist=None, env=None):
+    """one `merfin -hist` process on the inputs; returns (returncode, wall seconds, {phase: seconds}, stderr)"""
+    import subprocess
+    exe = os.path.join(root, "merfin_amd", "bin", "merfin")
+    cmd = [exe, "-hist", "-sequence", inp["fasta"], "-readmers", inp["readdb"], "-peak", str(peak), "-output", out_hist or os.path.join(os.path.dirname(inp["fasta"]), "out.hist")]
+    if prob:
+        cmd += ["-prob", prob]
+    t = time.time()
+    r = subprocess.run(cmd, stdin=subprocess.DEVNULL, capture_output=True, text=True, env=dict(os.environ, MFX_CLI_TIMING="2", **(env or {})))
+    wall = time.time() - t
+    phases = {}
+    for line in r.stderr.splitlines():
+        if line.startswith("-- timing"):                        # "-- timing:  name 0.12s  other name 3.40s ..."
+            for tok in line.split(":", 1)[1].split("  "):
+                tok = tok.strip()
+                if tok.endswith("s") and " " in tok:
+                    name, sec = tok.rsplit(" ", 1)
+                    try:
+                        phases[name.strip()] = float(sec[:-1])
+                    except ValueError:
+                        pass
+    return r.returncode, wall, phases, r.stderr
