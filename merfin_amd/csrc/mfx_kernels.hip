@@ -16,6 +16,7 @@
 #include "mfx_device.h"
 
 #include <stdlib.h>
+#include <algorithm>
 
 // ===========================================================================
 // joint k-mer table: 128-byte lines of 8 x {key, readV, asmV}
@@ -257,10 +258,14 @@ __device__ __forceinline__ uint32_t mfx_first_line(const mfx_table_view &t, uint
   return mfx_range32(mfx_hash64(key), t.nlines);
 }
 
-// owner rank of a k-mer in a sharded index (independent of the line hash bits)
+// owner rank of a k-mer in a sharded index: a hash of its minimizer (of the k-mer under plain hashing) on multipliers the line
+// hash does not use, so that the owner is independent of the line inside the owner's table; 32-bit arithmetic -- the router
+// evaluates it for every position of the assembly (layout version 8: before, a 64-bit finaliser and a 64-bit high product)
 __device__ __forceinline__ uint32_t mfx_owner(const mfx_table_view &t, uint64_t key, uint64_t krc, uint32_t nranks) {
-  uint64_t h = t.mz_w > 0 ? mfx_minimizer(key, krc, t.k, t.mz_w) : key * 0xA24BAED4963EE407ULL;
-  return (uint32_t)__umul64hi(mfx_hash64(h ^ 0x5851F42D4C957F2DULL), (uint64_t)nranks);
+  const uint64_t x = t.mz_w > 0 ? mfx_minimizer(key, krc, t.k, t.mz_w) : key;
+  uint32_t h = ((uint32_t)x * 0xCC9E2D51u) ^ (((uint32_t)(x >> 32) + 0x1B873593u) * 0xE6546B64u);
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13;
+  return __umulhi(h, nranks);
 }
 
 // d-th candidate line
@@ -2020,6 +2025,91 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_route_scatter_kernel(mfx_route_
   }
 }
 
+// ---------------------------------------------------------------------------
+// ONE-PASS router of the one-process sharded -hist (mfx_hist_run_sharded): count, scan and scatter above read and decode every
+// tile twice and need the per-tile prefix in between -- all to keep the k-mers of an owner in sequence order, which only the
+// ordered fp64 koverCpy sum of the owner needs.  Here the owner sums koverCpy in FIXED POINT (mfx_hist_keys_kernel<true>: integer
+// adds commute), so order is free: a block decodes a tile once, keeps its k-mers in registers, reserves room for them in every
+// owner's REGION of the output with one atomic per (tile, owner), and writes them.  regions: owner d's k-mers start at
+// d * region_cap; cursors[d] counts them; cursors[nranks] is raised when a region would overflow (the host then routes the round
+// again with the exact, packed path -- a round so unbalanced needs a pathological sequence).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(MFX_BLOCK) void mfx_route_fused_kernel(mfx_route_args a, uint64_t *keys_out, uint32_t *contig_out,
+                                                                    unsigned long long *cursors, uint64_t region_cap) {
+  __shared__ mfx_tile_lds L;
+  __shared__ uint32_t s_wtot[MFX_BLOCK / 64][MFX_SPLIT_MAX_RANKS];
+  __shared__ uint64_t s_base[MFX_SPLIT_MAX_RANKS];
+  __shared__ uint64_t s_red[MFX_BLOCK / 64][3];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const int k = a.t.k;
+  constexpr uint32_t ROUNDS = MFX_TILE / MFX_BLOCK;               // 16 rounds of 64 positions per wave
+  constexpr uint32_t WSPAN = MFX_TILE / (MFX_BLOCK / 64);         // 1024 positions per wave
+  for (uint64_t tile = a.tile_begin + blockIdx.x; tile < a.tile_end; tile += gridDim.x) {
+    const uint32_t c = a.tile_contig[tile];
+    const uint64_t pos0 = (tile - a.tile_start[c]) * MFX_TILE;
+    const uint64_t clen = a.contig_len[c];
+    const uint32_t n = (clen - pos0 < MFX_TILE) ? (uint32_t)(clen - pos0) : MFX_TILE;
+    __syncthreads();                                              // previous tile consumed (L, s_wtot, s_base)
+    mfx_tile_fill(L, a.bases + a.contig_off[c] + pos0);
+    __syncthreads();
+    uint64_t key[ROUNDS];
+    uint32_t own[ROUNDS];
+    uint64_t n_valid = 0, z1 = 0, z2 = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < ROUNDS; ++r) {
+      const uint32_t p = wave * WSPAN + r * 64u + lane;
+      uint64_t f;
+      own[r] = 0xffu;
+      key[r] = 0;
+      if (mfx_tile_kmer(L, k, p, f) && p < n) {
+        const uint64_t rc = mfx_revcomp(f, k);
+        key[r] = f < rc ? f : rc;
+        own[r] = mfx_owner(a.t, key[r], f < rc ? rc : f, a.nranks);
+        n_valid++;
+      }
+    }
+    for (uint32_t d = 0; d < a.nranks; ++d) {                      // this wave's k-mers per owner
+      uint32_t cnt = 0;
+#pragma unroll
+      for (uint32_t r = 0; r < ROUNDS; ++r) cnt += (uint32_t)__popcll(__ballot(own[r] == d));
+      if (lane == 0) s_wtot[wave][d] = cnt;
+    }
+    mfx_block_sum3(n_valid, z1, z2, s_red);                       // (barriers inside: s_wtot is complete after it)
+    if (tid == 0 && n_valid) {                                    // merfin-histogram.C:58, counted where the sequence lives
+      atomicAdd((unsigned long long *)&a.counts[2ull * a.nbins + 0], n_valid);
+      atomicAdd((unsigned long long *)&a.counts[2ull * a.nbins + 3 + c], n_valid);
+    }
+    if (tid < a.nranks) {                                         // room for this tile's k-mers in every owner's region
+      uint32_t tot = 0;
+      for (uint32_t w = 0; w < MFX_BLOCK / 64; ++w) tot += s_wtot[w][tid];
+      uint64_t base = ~0ull;
+      if (tot) {
+        base = atomicAdd(&cursors[tid], (unsigned long long)tot);
+        if (base + tot > region_cap) { atomicAdd(&cursors[a.nranks], 1ull); base = ~0ull; }    // would overflow: nothing is written, the host re-routes
+      }
+      s_base[tid] = base;
+    }
+    __syncthreads();
+    for (uint32_t d = 0; d < a.nranks; ++d) {
+      uint64_t run = s_base[d];
+      if (run == ~0ull) continue;                                  // (block-uniform)
+      run += (uint64_t)d * region_cap;
+      for (uint32_t w = 0; w < wave; ++w) run += s_wtot[w][d];
+#pragma unroll
+      for (uint32_t r = 0; r < ROUNDS; ++r) {
+        const bool mine = own[r] == d;
+        const uint64_t m = __ballot(mine);
+        if (mine) {
+          const uint64_t o = run + (uint64_t)__popcll(m & ((1ULL << lane) - 1ULL));
+          keys_out[o] = key[r];
+          contig_out[o] = c;
+        }
+        run += (uint64_t)__popcll(m);
+      }
+    }
+  }
+}
+
 // gathers the routed k-mers into owner order (idx = stable-sorted positions) and attaches the contig id
 __global__ void mfx_route_gather_kernel(mfx_route_args a, const uint32_t *idx, uint64_t nvalid, uint64_t *keys_out, uint32_t *contig_out) {
   uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
@@ -2408,37 +2498,44 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_completeness_kernel(mfx_table_v
 // 8 .. 16 bytes per lane, 1 .. 8 loads in flight and 4 .. 16 blocks per CU, for tables of 8 .. 160 GiB).  It is the roof
 // of the index probe: bench.py runs it on the box of the measurement and reports the kernel's line rate against it.
 // ===========================================================================
+template <int ILP>
 __global__ __launch_bounds__(256) void mfx_gather_rate_kernel(const uint4 *__restrict__ t, uint64_t nlines, int iters, uint64_t seed, uint64_t *out) {
   const uint64_t tid = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
   uint64_t acc = 0, ctr = seed + tid * 0x9e3779b97f4a7c15ULL;
   for (int it = 0; it < iters; ++it) {
-    uint4 v[4];
+    uint4 v[ILP];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < ILP; ++j) {
       ctr += 0xD1B54A32D192ED03ULL;
       v[j] = t[__umul64hi(mfx_hash64(ctr), nlines) * 8];      // the first 16 bytes of a random line
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc += v[j].x ^ v[j].w;
+    for (int j = 0; j < ILP; ++j) acc += v[j].x ^ v[j].w;
   }
   if (acc == 0x1234567ULL) out[0] = acc;                       // (keeps the loads)
 }
 hipError_t mfx_k_gather_rate(const void *table, uint64_t nlines, uint64_t *scratch, double *lines_per_s, hipStream_t st) {
-  const int grid = 256 * 8, iters = 256;                       // 2^21 lanes x 4 x 256 = 2.1 G line reads
+  const int grid = 256 * 8;                                    // 2^19 lanes x 2^12 loads = 2.1 G line reads per timed launch
   hipEvent_t e0, e1;
   hipError_t e = hipEventCreate(&e0);
   if (e != hipSuccess) return e;
   e = hipEventCreate(&e1);
   if (e != hipSuccess) { (void)hipEventDestroy(e0); return e; }
-  mfx_gather_rate_kernel<<<grid, 256, 0, st>>>(reinterpret_cast<const uint4 *>(table), nlines, 2, 1, scratch);       // warm
-  (void)hipEventRecord(e0, st);
-  mfx_gather_rate_kernel<<<grid, 256, 0, st>>>(reinterpret_cast<const uint4 *>(table), nlines, iters, 77, scratch);
-  (void)hipEventRecord(e1, st);
-  e = hipEventSynchronize(e1);
-  float ms = 0;
-  if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  const uint4 *t = reinterpret_cast<const uint4 *>(table);
+  mfx_gather_rate_kernel<4><<<grid, 256, 0, st>>>(t, nlines, 64, 1, scratch);       // warm: the table's pages have been touched
+  double best = 0;
+  for (int v = 0; v < 4 && e == hipSuccess; ++v) {              // 4 and 8 loads in flight per lane, twice each: the best is the roof
+    (void)hipEventRecord(e0, st);
+    if (v & 1) mfx_gather_rate_kernel<8><<<grid, 256, 0, st>>>(t, nlines, 512, 77 + v, scratch);
+    else       mfx_gather_rate_kernel<4><<<grid, 256, 0, st>>>(t, nlines, 1024, 77 + v, scratch);
+    (void)hipEventRecord(e1, st);
+    e = hipEventSynchronize(e1);
+    float ms = 0;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e == hipSuccess && ms > 0) best = std::max(best, (double)grid * 256.0 * 4096.0 / (ms * 1e-3));
+  }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  if (e == hipSuccess) *lines_per_s = (double)grid * 256.0 * 4.0 * iters / (ms * 1e-3);
+  if (e == hipSuccess) *lines_per_s = best;
   return e;
 }
 

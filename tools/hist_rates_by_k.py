@@ -20,6 +20,8 @@ def main():
     sq = m.Sequences.from_device([seq.data_ptr()], [bases])
     for k in ks:
         kinds = ("seq", "full") if k <= 31 else ("full",)
+        if os.environ.get("MFX_RATES_KINDS"):                      # e.g. MFX_RATES_KINDS=seq: one index kind only (PMC passes)
+            kinds = tuple(x for x in kinds if x in os.environ["MFX_RATES_KINDS"].split(","))
         for kind in kinds:
             ix = m.Index.for_seq(k, bases + 1024) if kind == "seq" else m.Index(k, bases + 1024)
             t = time.perf_counter()
