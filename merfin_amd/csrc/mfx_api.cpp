@@ -82,6 +82,8 @@ extern "C" int mfx_device_count(void) {
   return n;
 }
 
+void mfx_pin_spread(unsigned w);          // pins the calling thread to L3 domain w mod n (all NUMA nodes); defined with the encoder placement below
+
 // Host threads that stay parked between the streamed runs of an evaluator: starting 16 threads costs ~0.45 ms, 1.3 % of a
 // 3 Gb run, waking them ~0.05 ms.
 namespace {
@@ -94,9 +96,12 @@ struct WorkerPool {
   uint64_t gen = 0;
   unsigned running = 0;
   bool quit = false;
-  explicit WorkerPool(unsigned w) : W(w) {
+  // spread: thread i is pinned to L3 domain i mod n of the machine (pack_spread_cpus, below) -- threads that move memory
+  // share their CCD's link to it, and threads started by one parent tend to land next to each other
+  explicit WorkerPool(unsigned w, bool spread = false) : W(w) {
     for (unsigned i = 0; i < W; ++i)
-      th.emplace_back([this, i]() {
+      th.emplace_back([this, i, spread]() {
+        if (spread) mfx_pin_spread(i);
         uint64_t seen = 0;
         for (;;) {
           std::function<void(unsigned)> f;
@@ -420,6 +425,7 @@ static int index_check(mfx_index *ix) {
 // (pinning memory costs ~0.4 ms per MB: allocating them per call was 3.5 s of a 5.1 s ingest at 1 Gb); they are
 // released with the index (or by mfx_index_ingest_release once the loading is over).
 constexpr uint64_t MFX_INGEST_CHUNK = 1ull << 24;           // k-mers per lane: 128 MB of keys + 64 MB of counts
+constexpr int MFX_INGEST_MAX_LANES = 4;
 struct mfx_ingest {
   struct Lane {
     uint64_t *hk = nullptr, *dk = nullptr;
@@ -427,7 +433,8 @@ struct mfx_ingest {
     hipEvent_t done = nullptr;
     hipStream_t st = nullptr;    // a stream per lane: the transfer of one lane's chunk runs under the insert kernel of the other's
     bool busy = false;
-  } L[2];
+  } L[MFX_INGEST_MAX_LANES];
+  int nl = 2;                  // lanes in use: fill | H2D | insert of three chunks overlap with >= 3 (MFX_INGEST_LANES)
   uint64_t cap = 0;            // k-mers per lane
   size_t kw = 1;
 };
@@ -465,12 +472,19 @@ static mfx_ingest *ingest_get(mfx_index *ix, uint64_t n) {
   mfx_ingest *g = new mfx_ingest;
   g->cap = cap;
   g->kw = ix->key_words();
+  // three lanes let the fill of a chunk, the transfer of the one before and the insert of the one before that overlap (two
+  // lanes: a lane's transfer and insert run one behind the other while only ONE other chunk is filled); small loads keep two
+  // (pinning costs 0.4 ms per MB)
+  g->nl = cap >= (1ull << 20) ? 3 : 2;
+  if (const char *e = getenv("MFX_INGEST_LANES")) { const int v = atoi(e); if (v >= 2 && v <= MFX_INGEST_MAX_LANES) g->nl = v; }
   bool ok = true;
-  for (auto &l : g->L)
+  for (int li = 0; li < g->nl; ++li) {
+    auto &l = g->L[li];
     ok = ok && hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking) == hipSuccess && hipHostMalloc((void **)&l.hk, cap * 8 * g->kw, hipHostMallocPortable) == hipSuccess &&      // DMA source for any device
          hipHostMalloc((void **)&l.hv, cap * 4, hipHostMallocPortable) == hipSuccess &&
          hipMalloc((void **)&l.dk, cap * 8 * g->kw) == hipSuccess && hipMalloc((void **)&l.dv, cap * 4) == hipSuccess &&
          hipEventCreateWithFlags(&l.done, hipEventDisableTiming) == hipSuccess;
+  }
   if (!ok) { (void)hipGetLastError(); ingest_free(g); return nullptr; }
   ix->ingest = g;
   return g;
@@ -505,7 +519,9 @@ static int index_ingest_chunks(mfx_index *const *ixs, uint32_t nix, uint64_t n_h
   uint64_t cap = gs[0]->cap;
   for (uint32_t i = 1; i < nix; ++i) cap = std::min(cap, gs[i]->cap);
   bool ok = true, src_ok = true;
-  for (int cur = 0; ok; cur ^= 1) {
+  int nl = gs[0]->nl;
+  for (uint32_t i = 1; i < nix; ++i) nl = std::min(nl, gs[i]->nl);
+  for (int cur = 0; ok; cur = (cur + 1) % nl) {
     const double t0 = now();
     for (uint32_t i = 0; i < nix && ok; ++i) {               // the lane's previous chunk has left the pinned buffer everywhere
       mfx_ingest::Lane &l = gs[i]->L[cur];
@@ -533,8 +549,7 @@ static int index_ingest_chunks(mfx_index *const *ixs, uint32_t nix, uint64_t n_h
   }
   for (uint32_t i = 0; i < nix; ++i) {
     DevGuard dg(ixs[i]->device);
-    for (auto &l : gs[i]->L) if (hipStreamSynchronize(l.st) != hipSuccess) ok = false;
-    gs[i]->L[0].busy = gs[i]->L[1].busy = false;
+    for (int li = 0; li < gs[i]->nl; ++li) { if (hipStreamSynchronize(gs[i]->L[li].st) != hipSuccess) ok = false; gs[i]->L[li].busy = false; }
   }
   if (timing)
     fprintf(stderr, "-- ingest: %.3f s = lanes %.3f (cap %llu) + fill %.3f + waits for the device %.3f + drain; %llu chunks, %.2f GB over the link\n",
@@ -657,7 +672,7 @@ int mfx_index_add_from_file(mfx_index *const *ixs, uint32_t nix, int fd, const c
   const size_t kw = ixs[0]->key_words();
   const bool packed = vals_off == 0;
   if (packed && kw != 1) return mfx_fail(MFX_E_INVAL, "mfx_index_add_from_file: packed records hold k-mers of k <= %d", MFX_MAX_K_PACKED);
-  std::unique_ptr<WorkerPool> pool(n * 8 * kw >= (64u << 20) ? new WorkerPool(pread_threads()) : nullptr);
+  std::unique_ptr<WorkerPool> pool(n * 8 * kw >= (64u << 20) ? new WorkerPool(pread_threads(), true) : nullptr);
   return index_ingest_multi(ixs, nix, n, side, [&](uint64_t o, uint64_t m, uint64_t *hk, uint32_t *hv) {
     if (par_pread(fd, (uint8_t *)hk, m * 8 * kw, keys_off + o * 8 * kw, pool.get()) &&
         (packed || par_pread(fd, (uint8_t *)hv, m * 4, vals_off + o * 4, pool.get()))) return true;
@@ -677,7 +692,7 @@ int mfx_index_add_delta_file(mfx_index *const *ixs, uint32_t nix, int fd, const 
   if (side == 0) for (uint32_t i = 0; i < nix; ++i) if ((rc = set_read_filter(ixs[i], minV, maxV)) != MFX_OK) return rc;
   auto off = [dir](uint64_t b) { return dir[2 * b + 1] & 0xffffffffffffull; };
   const uint64_t total = off(nblocks) - off(0);
-  std::unique_ptr<WorkerPool> pool(total >= (64u << 20) ? new WorkerPool(pread_threads()) : nullptr);
+  std::unique_ptr<WorkerPool> pool(total >= (64u << 20) ? new WorkerPool(pread_threads(), true) : nullptr);
   uint64_t b0 = 0;
   // lanes sized as for total / 8 records (32 MB at most: ~13 M k-mers a chunk): a chunk is a byte range of the file, not a k-mer count
   return index_ingest_chunks(ixs, nix, std::min<uint64_t>(std::max<uint64_t>(total / 8 + 1, 2 * MFX_DELTA_BLOCK * 11), 1ull << 22), [&](uint64_t cap, uint64_t *hk, uint32_t *hv, IngestChunk &d) {
@@ -1573,6 +1588,20 @@ struct PackTopology {
   }
 };
 static const PackTopology &pack_topology() { static PackTopology t; return t; }
+
+void mfx_pin_spread(unsigned w) {
+  const char *e = getenv("MFX_POOL_SPREAD");
+  if (e && atoi(e) == 0) return;
+  cpu_set_t mine;
+  const PackTopology &T = pack_topology();
+  if (!T.ok) return;
+  std::vector<const std::vector<int> *> doms;
+  for (auto &nd : T.l3_of_node) for (auto &d : nd) doms.push_back(&d);
+  if (doms.empty()) return;
+  CPU_ZERO(&mine);
+  for (int c : *doms[w % doms.size()]) CPU_SET(c, &mine);
+  if (CPU_COUNT(&mine) > 0) (void)pthread_setaffinity_np(pthread_self(), sizeof(mine), &mine);
+}
 
 // the CPU set worker w of W runs on under `mode` (0 os, 1 node, 2 spread, 3 all); false: leave the thread where it is allowed
 static bool pack_cpus(int mode, int node, const cpu_set_t *near, unsigned w, cpu_set_t *out) {
@@ -2476,7 +2505,7 @@ extern "C" int mfx_hist_keys_launch(mfx_eval *ev, const uint64_t *d_keys, const 
 // one-process-per-GPU form (merfin_amd/distributed.py::sharded_hist) -- and every owner probes / computes K* / bins
 // what it received, source by source in slot order (so koverCpy is a fixed-order sum).  The N counts images are added
 // on the host; kasm was counted at the sources, kmissing / bins / koverCpy at the owners.
-extern "C" int mfx_hist_run_sharded(mfx_eval *const *evs, mfx_router *const *routers, const mfx_seq *const *seqs, uint32_t ndev,
+static int hist_run_sharded_ordered(mfx_eval *const *evs, mfx_router *const *routers, const mfx_seq *const *seqs, uint32_t ndev,
                                     mfx_hist_result *out) {
   if (!evs || !routers || !seqs || !out || ndev == 0) return mfx_fail(MFX_E_INVAL, "mfx_hist_run_sharded: null argument");
   for (uint32_t d = 0; d < ndev; ++d) {
@@ -2589,6 +2618,231 @@ extern "C" int mfx_hist_run_sharded(mfx_eval *const *evs, mfx_router *const *rou
   if (rc == MFX_OK) rc = mfx_hist_result_from_counts(nbins, sum.data(), kover, ncontigs, out);
   if (rc == MFX_OK) {
     for (uint32_t d = 0; d < ndev && rc == MFX_OK; ++d) rc = result_take_overflow(evs[d], sl[d].dest[0], out);
+    if (rc) mfx_hist_result_free(out);
+  }
+  release();
+  return rc;
+}
+
+
+// The same run with the ONE-PASS router (mfx_route_fused_kernel) and owners that evaluate the groups WHERE THEY LIE
+// (mfx_hist_keys_kernel<true>: up to 16 segments per launch): a tile is decoded once instead of twice, no per-tile prefix, a
+// group whose source shares the owner's device is not copied at all, and the routing of round r + 1 runs under the owners'
+// evaluation of round r (two sets of group buffers).  The price is the ORDER of an owner's k-mers, which only the fp64 sum of
+// koverCpy ever needed: the owners sum it in fixed point (units of 2^-52, 128-bit integers -- adds commute), so the result is
+// still bit-identical run to run, whatever the devices and the scheduling.  Taken when every slot is one of <= 16 ranks and
+// every prob of the K* table lies in [0, 4096) (the fixed-point range); else hist_run_sharded_ordered.  A round so unbalanced
+// that an owner's region overflows (a megabase of one repeated minimizer) is routed again by the exact counting split.
+extern "C" int mfx_hist_run_sharded(mfx_eval *const *evs, mfx_router *const *routers, const mfx_seq *const *seqs, uint32_t ndev,
+                                    mfx_hist_result *out) {
+  if (!evs || !routers || !seqs || !out || ndev == 0) return mfx_fail(MFX_E_INVAL, "mfx_hist_run_sharded: null argument");
+  for (uint32_t d = 0; d < ndev; ++d) {
+    if (!evs[d] || !routers[d] || !seqs[d]) return mfx_fail(MFX_E_INVAL, "mfx_hist_run_sharded: null object for slot %u", d);
+    const mfx_index *ix = evs[d]->ix;
+    if (ix->shard_n != ndev || ix->shard_rank != d || routers[d]->ix != ix || routers[d]->nranks != ndev)
+      return mfx_fail(MFX_E_INVAL, "slot %u: its index must be shard %u of %u (mfx_index_set_shard) and its router built on it for %u ranks", d, d, ndev, ndev);
+    if (evs[d]->device != seqs[d]->device || evs[d]->nbins != evs[0]->nbins || seqs[d]->ntiles != seqs[0]->ntiles ||
+        seqs[d]->ncontigs != seqs[0]->ncontigs || routers[d]->max_tiles != routers[0]->max_tiles)
+      return mfx_fail(MFX_E_INVAL, "slot %u: evaluators / sequences / routers of one run must match each other", d);
+  }
+  bool fused = ndev <= MFX_KEYS_MAX_SEGS && ndev <= MFX_SPLIT_MAX_RANKS;
+  for (uint32_t d = 0; d < ndev && fused; ++d) {
+    if (!routers[d]->split || evs[d]->ix->wide() || evs[d]->ix->seq_only) fused = false;
+    for (double p : evs[d]->probP) if (!(p >= 0.0 && p < 4096.0)) fused = false;
+  }
+  if (const char *e = getenv("MFX_SHARDED_ORDERED")) if (atoi(e)) fused = false;      // A/B, tests: the ordered form
+  if (!fused) return hist_run_sharded_ordered(evs, routers, seqs, ndev, out);
+
+  const uint32_t nbins = evs[0]->nbins, ncontigs = seqs[0]->ncontigs, per = routers[0]->max_tiles;
+  const uint64_t T = seqs[0]->ntiles;
+  const size_t words = MFX_HIST_WORDS(nbins, ncontigs), cap = (size_t)per * MFX_TILE;
+  const size_t region_cap = cap / ndev + cap / (4 * ndev) + 2 * MFX_TILE;     // an owner's share of a round: 1/N of it + 25 % + two tiles
+  bool any_remote = false;
+  for (uint32_t d = 1; d < ndev; ++d) if (evs[d]->device != evs[0]->device) any_remote = true;
+  const size_t rcap = any_remote ? cap + cap / 2 + 4096 : 0;                 // receive side of the groups that come from other devices
+  struct Slot {
+    uint64_t *d_counts = nullptr, *d_keys[2] = {nullptr, nullptr}, *d_rkeys = nullptr, *d_cursors = nullptr, *d_kfix = nullptr, *d_pkeys = nullptr;
+    uint32_t *d_ctg[2] = {nullptr, nullptr}, *d_rctg = nullptr, *d_pctg = nullptr;
+    uint64_t *h_cursors = nullptr;                               // pinned: [2][ndev + 1]
+    double   *d_kover = nullptr;                                 // (the exact fallback's ordered partial sums land here)
+    hipStream_t rst = nullptr, ost = nullptr;
+    // the groups this slot routed in a round: [set][owner] -> where and how many
+    std::vector<const uint64_t *> gkeys[2];
+    std::vector<const uint32_t *> gctg[2];
+    std::vector<uint64_t> gn[2];
+    int rc = MFX_OK;
+    std::string err;
+  };
+  std::vector<Slot> sl(ndev);
+  int rc = MFX_OK;
+  auto release = [&]() {
+    for (uint32_t d = 0; d < ndev; ++d) {
+      DevGuard g(evs[d]->device);
+      if (sl[d].rst) (void)hipStreamSynchronize(sl[d].rst);
+      if (sl[d].ost) (void)hipStreamSynchronize(sl[d].ost);
+      void *p[] = {sl[d].d_counts, sl[d].d_keys[0], sl[d].d_keys[1], sl[d].d_rkeys, sl[d].d_cursors, sl[d].d_kfix, sl[d].d_pkeys, sl[d].d_ctg[0], sl[d].d_ctg[1],
+                   sl[d].d_rctg, sl[d].d_pctg, sl[d].d_kover};
+      for (void *x : p) if (x) (void)hipFree(x);
+      if (sl[d].h_cursors) (void)hipHostFree(sl[d].h_cursors);
+      if (sl[d].rst) (void)hipStreamDestroy(sl[d].rst);
+      if (sl[d].ost) (void)hipStreamDestroy(sl[d].ost);
+    }
+  };
+  for (uint32_t d = 0; d < ndev && rc == MFX_OK; ++d) {
+    DevGuard g(evs[d]->device);
+    Slot &S = sl[d];
+    for (int b2 = 0; b2 < 2; ++b2) { S.gkeys[b2].assign(ndev, nullptr); S.gctg[b2].assign(ndev, nullptr); S.gn[b2].assign(ndev, 0); }
+    bool ok = hipStreamCreateWithFlags(&S.rst, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&S.ost, hipStreamNonBlocking) == hipSuccess &&
+              hipMalloc((void **)&S.d_counts, words * sizeof(uint64_t)) == hipSuccess && hipMalloc((void **)&S.d_kover, sizeof(double)) == hipSuccess &&
+              hipMalloc((void **)&S.d_kfix, 2 * sizeof(uint64_t)) == hipSuccess && hipMalloc((void **)&S.d_cursors, 2 * (ndev + 1) * sizeof(uint64_t)) == hipSuccess &&
+              hipHostMalloc((void **)&S.h_cursors, 2 * (ndev + 1) * sizeof(uint64_t), hipHostMallocDefault) == hipSuccess;
+    for (int b2 = 0; b2 < 2 && ok; ++b2)
+      ok = hipMalloc((void **)&S.d_keys[b2], (size_t)ndev * region_cap * 8) == hipSuccess && hipMalloc((void **)&S.d_ctg[b2], (size_t)ndev * region_cap * 4) == hipSuccess;
+    if (ok && rcap) ok = hipMalloc((void **)&S.d_rkeys, rcap * 8) == hipSuccess && hipMalloc((void **)&S.d_rctg, rcap * 4) == hipSuccess;
+    ok = ok && hipMemsetAsync(S.d_counts, 0, words * sizeof(uint64_t), S.ost) == hipSuccess && hipMemsetAsync(S.d_kover, 0, sizeof(double), S.ost) == hipSuccess &&
+         hipMemsetAsync(S.d_kfix, 0, 2 * sizeof(uint64_t), S.ost) == hipSuccess && hipMemsetAsync(evs[d]->d_ovf, 0, sizeof(uint64_t), S.ost) == hipSuccess &&
+         hipStreamSynchronize(S.ost) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); rc = mfx_fail(MFX_E_NOMEM, "mfx_hist_run_sharded: buffers for slot %u (%zu k-mers per round) could not be set up", d, cap); }
+    for (uint32_t e = 0; e < d && rc == MFX_OK; ++e)
+      if (evs[e]->device != evs[d]->device) {
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, evs[d]->device, evs[e]->device) == hipSuccess && can && hipDeviceEnablePeerAccess(evs[e]->device, 0) != hipSuccess)
+          (void)hipGetLastError();                            // already enabled
+        if (hipDeviceCanAccessPeer(&can, evs[e]->device, evs[d]->device) == hipSuccess && can) {
+          DevGuard g2(evs[e]->device);
+          if (hipDeviceEnablePeerAccess(evs[d]->device, 0) != hipSuccess) (void)hipGetLastError();
+        }
+      }
+  }
+  const uint64_t rounds = ((T + ndev - 1) / ndev + per - 1) / per;
+  // ---- route round r of every slot into buffer set b2 (one host thread per slot; returns when the group sizes are on the host)
+  auto route_round = [&](uint64_t r, int b2) {
+    std::vector<std::thread> th;
+    for (uint32_t d = 0; d < ndev; ++d)
+      th.emplace_back([&, d]() {
+        Slot &S = sl[d];
+        S.rc = MFX_OK;
+        const uint64_t lo = T * d / ndev, hi = T * (d + 1) / ndev;
+        const uint64_t tb = std::min(hi, lo + r * per), te = std::min(hi, tb + per);
+        for (uint32_t o = 0; o < ndev; ++o) { S.gn[b2][o] = 0; S.gkeys[b2][o] = nullptr; S.gctg[b2][o] = nullptr; }
+        if (te <= tb) return;
+        DevGuard g(evs[d]->device);
+        mfx_router *R = routers[d];
+        const mfx_seq *seq = seqs[d];
+        auto fail = [&](int code, const char *what, hipError_t e) { S.rc = code; S.err = std::string(what) + ": " + hipGetErrorString(e); (void)hipGetLastError(); };
+        int canon = 0;
+        if (int erc = index_canonical(R->ix, &canon)) { S.rc = erc; S.err = mfx_last_error(); return; }
+        if (!canon || !(R->ix->k & 1)) { S.rc = MFX_E_INVAL; S.err = "a sharded index needs a canonical k-mer database and odd k"; return; }
+        if (int erc = mfx_seq_ensure_ascii(seq)) { S.rc = erc; S.err = mfx_last_error(); return; }
+        mfx_route_args a;
+        a.t = R->ix->view();
+        a.bases = seq->d_bases;
+        a.contig_off = seq->d_contig_off; a.contig_len = seq->d_contig_len; a.tile_start = seq->d_tile_start;
+        a.ncontigs = seq->ncontigs;
+        a.tile_begin = tb; a.tile_end = te;
+        a.nranks = ndev;
+        a.keys = nullptr; a.owner = nullptr; a.dest_counts = R->d_dest;
+        a.counts = S.d_counts;
+        a.nbins = nbins;
+        a.tile_contig = seq->d_tile_contig;
+        a.tile_cnt = R->d_tile_cnt;
+        uint64_t *cur = S.d_cursors + (size_t)b2 * (ndev + 1), *hcur = S.h_cursors + (size_t)b2 * (ndev + 1);
+        hipError_t e = hipMemsetAsync(cur, 0, (ndev + 1) * sizeof(uint64_t), S.rst);
+        if (e == hipSuccess) e = mfx_k_route_fused(a, S.d_keys[b2], S.d_ctg[b2], cur, region_cap, S.rst);
+        if (e == hipSuccess) e = hipMemcpyAsync(hcur, cur, (ndev + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, S.rst);
+        if (e == hipSuccess) e = hipStreamSynchronize(S.rst);
+        if (e != hipSuccess) { fail(MFX_E_HIP, "routing failed", e); return; }
+        if (hcur[ndev] == 0) {
+          for (uint32_t o = 0; o < ndev; ++o) { S.gn[b2][o] = hcur[o]; S.gkeys[b2][o] = S.d_keys[b2] + (size_t)o * region_cap; S.gctg[b2][o] = S.d_ctg[b2] + (size_t)o * region_cap; }
+          return;
+        }
+        // an owner's region overflowed: this round of this slot again, by the exact counting split into a packed buffer.  (The one-pass
+        // kernel counted the round's k-mers into kasm already: the split's own count is taken back out below.)
+        if (!S.d_pkeys) {
+          e = hipMalloc((void **)&S.d_pkeys, 2 * cap * 8);
+          if (e == hipSuccess) e = hipMalloc((void **)&S.d_pctg, 2 * cap * 4);
+          if (e != hipSuccess) { fail(MFX_E_NOMEM, "no memory for the exact re-routing of an unbalanced round", e); return; }
+        }
+        // kasm (global + per contig) would be counted twice: the exact split counts into a scratch image instead
+        uint64_t *scratch = nullptr;
+        e = hipMalloc((void **)&scratch, words * sizeof(uint64_t));
+        if (e == hipSuccess) e = hipMemsetAsync(scratch, 0, words * sizeof(uint64_t), S.rst);
+        a.counts = scratch;
+        uint64_t *pk = S.d_pkeys + (size_t)b2 * cap;
+        uint32_t *pc = S.d_pctg + (size_t)b2 * cap;
+        if (e == hipSuccess) e = mfx_k_route_split(a, pk, pc, S.rst);
+        uint64_t hd[MFX_SPLIT_MAX_RANKS] = {0};
+        if (e == hipSuccess) e = hipMemcpyAsync(hd, R->d_dest, ndev * 8, hipMemcpyDeviceToHost, S.rst);
+        if (e == hipSuccess) e = hipStreamSynchronize(S.rst);
+        if (scratch) (void)hipFree(scratch);
+        if (e != hipSuccess) { fail(MFX_E_HIP, "exact re-routing failed", e); return; }
+        uint64_t at = 0;
+        for (uint32_t o = 0; o < ndev; ++o) { S.gn[b2][o] = hd[o]; S.gkeys[b2][o] = pk + at; S.gctg[b2][o] = pc + at; at += hd[o]; }
+      });
+    for (auto &x : th) x.join();
+    for (uint32_t d = 0; d < ndev && rc == MFX_OK; ++d)
+      if (sl[d].rc) rc = mfx_fail(sl[d].rc, "slot %u: %s", d, sl[d].err.c_str());
+  };
+  if (rounds && rc == MFX_OK) route_round(0, 0);
+  for (uint64_t r = 0; r < rounds && rc == MFX_OK; ++r) {
+    const int b2 = (int)(r & 1);
+    // ---- owners: one launch over the groups of all sources; a group on another device travels by peer copy first
+    for (uint32_t o = 0; o < ndev && rc == MFX_OK; ++o) {
+      DevGuard g(evs[o]->device);
+      Slot &O = sl[o];
+      mfx_hist_keys_args a;
+      a.t = evs[o]->ix->view();
+      a.ks.peak = evs[o]->peak; a.ks.n_prob = evs[o]->n_prob; a.ks.probK = evs[o]->d_probK; a.ks.probP = evs[o]->d_probP;
+      a.ks.nbins = nbins; a.ks.ncontigs = ncontigs; a.ks.counts = O.d_counts; a.ks.partials = evs[o]->d_partials; a.ks.ovf = evs[o]->d_ovf;
+      a.kfix = O.d_kfix;
+      uint64_t at = 0, total = 0;
+      for (uint32_t s2 = 0; s2 < ndev && rc == MFX_OK; ++s2) {
+        const uint64_t n = sl[s2].gn[b2][o];
+        if (!n) continue;
+        const uint64_t *kp = sl[s2].gkeys[b2][o];
+        const uint32_t *cp = sl[s2].gctg[b2][o];
+        if (evs[s2]->device != evs[o]->device) {
+          if (at + n > rcap) { rc = mfx_fail(MFX_E_FULL, "mfx_hist_run_sharded: owner %u receives more than %zu k-mers in one round", o, rcap); break; }
+          hipError_t e = hipMemcpyPeerAsync(O.d_rkeys + at, evs[o]->device, kp, evs[s2]->device, n * 8, O.ost);
+          if (e == hipSuccess) e = hipMemcpyPeerAsync(O.d_rctg + at, evs[o]->device, cp, evs[s2]->device, n * 4, O.ost);
+          if (e != hipSuccess) { rc = mfx_fail(MFX_E_HIP, "peer copy of %lu routed k-mers from slot %u to slot %u failed: %s", (unsigned long)n, s2, o, hipGetErrorString(e)); break; }
+          kp = O.d_rkeys + at; cp = O.d_rctg + at;
+          at += n;
+        }
+        a.seg_keys[a.nseg] = kp; a.seg_contig[a.nseg] = cp; a.seg_n[a.nseg] = n;
+        ++a.nseg;
+        total += n;
+      }
+      a.n = total;
+      if (rc == MFX_OK && total) {
+        hipError_t e = mfx_k_hist_keys(a, evs[o]->grid, O.ost);
+        if (e != hipSuccess) rc = mfx_fail(MFX_E_HIP, "mfx_hist_run_sharded: owner launch of slot %u failed: %s", o, hipGetErrorString(e));
+      }
+    }
+    // ---- the next round is routed (into the other buffer set) while the owners evaluate this one
+    if (r + 1 < rounds && rc == MFX_OK) route_round(r + 1, b2 ^ 1);
+    // this round's groups are consumed before the round after the next overwrites their buffers
+    for (uint32_t d = 0; d < ndev; ++d) {
+      DevGuard g(evs[d]->device);
+      if (hipStreamSynchronize(sl[d].ost) != hipSuccess && rc == MFX_OK) rc = mfx_fail(MFX_E_HIP, "mfx_hist_run_sharded: slot %u failed: %s", d, hipGetErrorString(hipGetLastError()));
+    }
+  }
+  std::vector<uint64_t> sum(words, 0), h(words);
+  unsigned __int128 kfix = 0;
+  for (uint32_t d = 0; d < ndev && rc == MFX_OK; ++d) {
+    DevGuard g(evs[d]->device);
+    uint64_t kf[2] = {0, 0};
+    if (hipMemcpy(h.data(), sl[d].d_counts, words * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(kf, sl[d].d_kfix, sizeof(kf), hipMemcpyDeviceToHost) != hipSuccess) { rc = mfx_fail(MFX_E_HIP, "mfx_hist_run_sharded: D2H of slot %u failed", d); break; }
+    for (size_t i = 0; i < words; ++i) sum[i] += h[i];
+    kfix += ((unsigned __int128)kf[1] << 64) | kf[0];           // integers: the order of the slots does not matter either
+    sl[d].gn[0].assign(1, h[2ull * nbins + 2]);               // this slot's overflow count
+  }
+  // koverCpy = kfix * 2^-52 (the same three roundings whatever the run: deterministic)
+  const double kover = ((double)(uint64_t)(kfix >> 64) * 18446744073709551616.0 + (double)(uint64_t)kfix) / 4503599627370496.0;
+  if (rc == MFX_OK) rc = mfx_hist_result_from_counts(nbins, sum.data(), kover, ncontigs, out);
+  if (rc == MFX_OK) {
+    for (uint32_t d = 0; d < ndev && rc == MFX_OK; ++d) rc = result_take_overflow(evs[d], sl[d].gn[0][0], out);
     if (rc) mfx_hist_result_free(out);
   }
   release();

@@ -97,15 +97,22 @@ __device__ __forceinline__ void mfx_block_sum3(uint64_t &a, uint64_t &b, uint64_
 
 // LDS state of the K* / histogram stage, shared by the sequence-driven kernel
 // (mfx_hist_kernel) and the key-driven one (mfx_hist_keys_kernel, sharded index).
+#ifndef MFX_V_LDS_DIET
+#define MFX_V_LDS_DIET 0              // 1: no prob / over-copy tables in LDS (16 KB less per block: they serve the `asmK > readK` branch only) -- A/B: tools/ab_build.sh
+#endif
 struct mfx_hist_lds {
   uint32_t hist[2 * MFX_NB_LDS];
   // Exact lookup tables, filled with the SAME fp64 routines the generic path uses:
   //   rk/pr[v]     readK and prob of read count v < MFX_MAXP_LDS (prob table and peak rule merged)
   //   bin[h][l]    bin index of the ratio h/l, term[h][l] = 1 - l/h     (h, l < MFX_KLUT)
   uint32_t rk[MFX_MAXP_LDS];
+#if !MFX_V_LDS_DIET
   double   pr[MFX_MAXP_LDS];
+#endif
   uint16_t bin[MFX_KLUT * MFX_KLUT];
+#if !MFX_V_LDS_DIET
   double   term[MFX_KLUT * MFX_KLUT];
+#endif
   uint32_t lut_ok;
   uint64_t next[2];                       // dynamic tile scheduler: the tile fetched for the next iteration
   uint64_t tot[2];                        // mfx_hist_kernel: valid / missing k-mers of the contigs this block already flushed (thread 0)
@@ -124,13 +131,17 @@ __device__ __forceinline__ void mfx_hist_lds_init(mfx_hist_lds &H, const mfx_kst
     // the table holds readK as an integer; anything else disables the fast path for this launch
     if (!(rk >= 0.0 && rk < 4294967296.0 && rk == (double)(uint32_t)rk)) H.lut_ok = 0u;
     H.rk[v] = (uint32_t)rk;
+#if !MFX_V_LDS_DIET
     H.pr[v] = pr;
+#endif
   }
   for (uint32_t i = tid; i < MFX_KLUT * MFX_KLUT; i += MFX_BLOCK) {
     uint32_t h = i / MFX_KLUT, l = i % MFX_KLUT;
     uint32_t b = (h >= 1 && l >= 1 && h >= l) ? mfx_bin_index((double)h, (double)l) : 0u;
     H.bin[i] = (uint16_t)b;
+#if !MFX_V_LDS_DIET
     H.term[i] = (h >= 1 && l >= 1 && h > l) ? mfx_overcopy_term((double)l, (double)h, 1.0) : 0.0;
+#endif
   }
   __syncthreads();
 }
@@ -143,7 +154,13 @@ __device__ __forceinline__ bool mfx_hist_eval(mfx_hist_lds &H, const mfx_kstar_a
   double readK, prob;
   uint32_t rki = 0xffffffffu;                                  // readK as an integer when the tables apply
   if (lut_ok && readV < MFX_MAXP_LDS) {
+#if MFX_V_LDS_DIET
+    // prob is read by the `asmK > readK` branch alone: taken from the table itself there (merfin-globals.C:93-97: the table's
+    // row for 1 <= readV <= rows, else 1)
+    rki = H.rk[readV]; prob = 1.0; readK = (double)rki;
+#else
     rki = H.rk[readV]; prob = H.pr[readV]; readK = (double)rki;
+#endif
   } else {
     mfx_getK_core(ka.peak, ka.n_prob, ka.probK, ka.probP, readV, readK, prob);
   }
@@ -154,9 +171,19 @@ __device__ __forceinline__ bool mfx_hist_eval(mfx_hist_lds &H, const mfx_kstar_a
   if (rki < MFX_KLUT && asmV < MFX_KLUT && asmV >= 1) {        // exact tables (same fp64 code, evaluated once)
     const uint32_t hi = under ? asmV : rki, lo = under ? rki : asmV;
     idx = H.bin[hi * MFX_KLUT + lo];
+#if MFX_V_LDS_DIET
+    if (under) {
+      if (readV > 0 && readV <= ka.n_prob) prob = ka.probP[readV - 1];
+      kover += mfx_overcopy_term(readK, asmK, prob);           // :81  (1 - readK/asmK) * prob
+    }
+#else
     if (under) kover += H.term[hi * MFX_KLUT + lo] * prob;     // :81  (1 - readK/asmK) * prob
+#endif
   } else {
     idx = under ? mfx_bin_index(asmK, readK) : mfx_bin_index(readK, asmK);
+#if MFX_V_LDS_DIET
+    if (under && rki != 0xffffffffu && readV > 0 && readV <= ka.n_prob) prob = ka.probP[readV - 1];   // (readK came from the LDS table: prob was not looked up yet)
+#endif
     if (under) kover += mfx_overcopy_term(readK, asmK, prob);  // :81
   }
   if (!under && idx == 0) { n_over0++; return false; }         // the dominant bin stays in a register

@@ -54,11 +54,18 @@ struct mfx_route_args {
                                       //   their exclusive prefix over the tiles (per owner)
 };
 
+constexpr uint32_t MFX_KEYS_MAX_SEGS = 16;
 struct mfx_hist_keys_args {
   mfx_table_view  t;
-  const uint64_t *keys;
-  const uint32_t *contig;
-  uint64_t        n;
+  const uint64_t *keys = nullptr;     // nseg == 0: one array of n k-mers with their contigs; koverCpy as ordered fp64 partials (ks.partials)
+  const uint32_t *contig = nullptr;
+  uint64_t        n = 0;              // k-mers in all (nseg > 0: the sum of seg_n)
+  // nseg > 0: the k-mers as segments, evaluated where they lie; koverCpy in fixed point (units of 2^-52) into kfix[0..1] (low, high word)
+  uint32_t        nseg = 0;
+  const uint64_t *seg_keys[MFX_KEYS_MAX_SEGS] = {};
+  const uint32_t *seg_contig[MFX_KEYS_MAX_SEGS] = {};
+  uint64_t        seg_n[MFX_KEYS_MAX_SEGS] = {};
+  uint64_t       *kfix = nullptr;
   mfx_kstar_args  ks;
 };
 
@@ -106,6 +113,8 @@ hipError_t mfx_k_route_gather(const mfx_route_args &a, const uint32_t *idx, uint
                               uint32_t *contig_out, hipStream_t st);
 hipError_t mfx_k_iota(uint32_t *v, uint64_t n, hipStream_t st);
 hipError_t mfx_k_hist_keys(const mfx_hist_keys_args &a, int grid, hipStream_t st);
+// one-pass router (atomic reservation per tile and owner): owner d's k-mers at keys_out[d * region_cap ...), cursors[d] of them; cursors[nranks] != 0: a region overflowed
+hipError_t mfx_k_route_fused(const mfx_route_args &a, uint64_t *keys_out, uint32_t *contig_out, uint64_t *cursors, uint64_t region_cap, hipStream_t st);
 hipError_t mfx_k_sum_partials(const double *partials, uint32_t n, double *out, hipStream_t st);
 hipError_t mfx_k_ordered_sum(const double *v, uint32_t n, double *out, hipStream_t st);
 uint64_t mfx_k_tile_partials_words(uint64_t ntiles);

@@ -2034,78 +2034,73 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_route_scatter_kernel(mfx_route_
 // d * region_cap; cursors[d] counts them; cursors[nranks] is raised when a region would overflow (the host then routes the round
 // again with the exact, packed path -- a round so unbalanced needs a pathological sequence).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(MFX_BLOCK) void mfx_route_fused_kernel(mfx_route_args a, uint64_t *keys_out, uint32_t *contig_out,
+__global__ __launch_bounds__(MFX_BLOCK, 6) void mfx_route_fused_kernel(mfx_route_args a, uint64_t *keys_out, uint32_t *contig_out,
                                                                     unsigned long long *cursors, uint64_t region_cap) {
   __shared__ mfx_tile_lds L;
-  __shared__ uint32_t s_wtot[MFX_BLOCK / 64][MFX_SPLIT_MAX_RANKS];
+  __shared__ uint32_t s_cnt[MFX_SPLIT_MAX_RANKS];
   __shared__ uint64_t s_base[MFX_SPLIT_MAX_RANKS];
   __shared__ uint64_t s_red[MFX_BLOCK / 64][3];
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t tid = threadIdx.x;
   const int k = a.t.k;
-  constexpr uint32_t ROUNDS = MFX_TILE / MFX_BLOCK;               // 16 rounds of 64 positions per wave
-  constexpr uint32_t WSPAN = MFX_TILE / (MFX_BLOCK / 64);         // 1024 positions per wave
+  constexpr uint32_t ROUNDS = MFX_TILE / MFX_BLOCK;               // 16 positions per lane and tile
+  constexpr uint32_t MFX_ROUTE_PART = 4;
   for (uint64_t tile = a.tile_begin + blockIdx.x; tile < a.tile_end; tile += gridDim.x) {
     const uint32_t c = a.tile_contig[tile];
     const uint64_t pos0 = (tile - a.tile_start[c]) * MFX_TILE;
     const uint64_t clen = a.contig_len[c];
     const uint32_t n = (clen - pos0 < MFX_TILE) ? (uint32_t)(clen - pos0) : MFX_TILE;
-    __syncthreads();                                              // previous tile consumed (L, s_wtot, s_base)
+    __syncthreads();                                              // previous tile consumed (L)
     mfx_tile_fill(L, a.bases + a.contig_off[c] + pos0);
-    __syncthreads();
-    uint64_t key[ROUNDS];
-    uint32_t own[ROUNDS];
     uint64_t n_valid = 0, z1 = 0, z2 = 0;
+    // order inside an owner's group is free (the owners sum koverCpy in fixed point), so a k-mer's place in its tile's share of
+    // the group is simply what an LDS atomic hands out: no ballots, no per-wave prefixes.  A tile goes in PARTS of MFX_ROUTE_PART
+    // positions per lane: the k-mers wait in registers between the count and the write, and 16 of them cost the occupancy
+    for (uint32_t part = 0; part < ROUNDS; part += MFX_ROUTE_PART) {
+      __syncthreads();                                            // tile filled / the previous part's s_cnt and s_base consumed
+      if (tid < MFX_SPLIT_MAX_RANKS) s_cnt[tid] = 0u;
+      __syncthreads();
+      uint64_t key[MFX_ROUTE_PART];
+      uint32_t where[MFX_ROUTE_PART];                             // owner << 16 | place in the part's share (0xffffffff: no k-mer)
 #pragma unroll
-    for (uint32_t r = 0; r < ROUNDS; ++r) {
-      const uint32_t p = wave * WSPAN + r * 64u + lane;
-      uint64_t f;
-      own[r] = 0xffu;
-      key[r] = 0;
-      if (mfx_tile_kmer(L, k, p, f) && p < n) {
-        const uint64_t rc = mfx_revcomp(f, k);
-        key[r] = f < rc ? f : rc;
-        own[r] = mfx_owner(a.t, key[r], f < rc ? rc : f, a.nranks);
-        n_valid++;
+      for (uint32_t r = 0; r < MFX_ROUTE_PART; ++r) {
+        const uint32_t p = (part + r) * MFX_BLOCK + tid;           // lane-consecutive positions: neighbours (one minimizer, one owner) stay neighbours
+        uint64_t f;
+        where[r] = 0xffffffffu;
+        key[r] = 0;
+        if (mfx_tile_kmer(L, k, p, f) && p < n) {
+          const uint64_t rc = mfx_revcomp(f, k);
+          key[r] = f < rc ? f : rc;
+          const uint32_t own = mfx_owner(a.t, key[r], f < rc ? rc : f, a.nranks);
+          where[r] = (own << 16) | atomicAdd(&s_cnt[own], 1u);     // (at most 4096 per tile)
+          n_valid++;
+        }
+      }
+      __syncthreads();                                            // s_cnt complete
+      if (tid < a.nranks) {                                       // room for this part's k-mers in every owner's region
+        const uint32_t tot = s_cnt[tid];
+        uint64_t base = ~0ull;
+        if (tot) {
+          base = atomicAdd(&cursors[tid], (unsigned long long)tot);
+          if (base + tot > region_cap) { atomicAdd(&cursors[a.nranks], 1ull); base = ~0ull; }    // would overflow: nothing is written, the host re-routes
+          else base += (uint64_t)tid * region_cap;
+        }
+        s_base[tid] = base;
+      }
+      __syncthreads();
+#pragma unroll
+      for (uint32_t r = 0; r < MFX_ROUTE_PART; ++r) {
+        if (where[r] == 0xffffffffu) continue;
+        const uint64_t base = s_base[where[r] >> 16];
+        if (base == ~0ull) continue;
+        const uint64_t o = base + (where[r] & 0xffffu);
+        keys_out[o] = key[r];
+        contig_out[o] = c;
       }
     }
-    for (uint32_t d = 0; d < a.nranks; ++d) {                      // this wave's k-mers per owner
-      uint32_t cnt = 0;
-#pragma unroll
-      for (uint32_t r = 0; r < ROUNDS; ++r) cnt += (uint32_t)__popcll(__ballot(own[r] == d));
-      if (lane == 0) s_wtot[wave][d] = cnt;
-    }
-    mfx_block_sum3(n_valid, z1, z2, s_red);                       // (barriers inside: s_wtot is complete after it)
+    mfx_block_sum3(n_valid, z1, z2, s_red);
     if (tid == 0 && n_valid) {                                    // merfin-histogram.C:58, counted where the sequence lives
       atomicAdd((unsigned long long *)&a.counts[2ull * a.nbins + 0], n_valid);
       atomicAdd((unsigned long long *)&a.counts[2ull * a.nbins + 3 + c], n_valid);
-    }
-    if (tid < a.nranks) {                                         // room for this tile's k-mers in every owner's region
-      uint32_t tot = 0;
-      for (uint32_t w = 0; w < MFX_BLOCK / 64; ++w) tot += s_wtot[w][tid];
-      uint64_t base = ~0ull;
-      if (tot) {
-        base = atomicAdd(&cursors[tid], (unsigned long long)tot);
-        if (base + tot > region_cap) { atomicAdd(&cursors[a.nranks], 1ull); base = ~0ull; }    // would overflow: nothing is written, the host re-routes
-      }
-      s_base[tid] = base;
-    }
-    __syncthreads();
-    for (uint32_t d = 0; d < a.nranks; ++d) {
-      uint64_t run = s_base[d];
-      if (run == ~0ull) continue;                                  // (block-uniform)
-      run += (uint64_t)d * region_cap;
-      for (uint32_t w = 0; w < wave; ++w) run += s_wtot[w][d];
-#pragma unroll
-      for (uint32_t r = 0; r < ROUNDS; ++r) {
-        const bool mine = own[r] == d;
-        const uint64_t m = __ballot(mine);
-        if (mine) {
-          const uint64_t o = run + (uint64_t)__popcll(m & ((1ULL << lane) - 1ULL));
-          keys_out[o] = key[r];
-          contig_out[o] = c;
-        }
-        run += (uint64_t)__popcll(m);
-      }
     }
   }
 }
@@ -2135,6 +2130,12 @@ __global__ void mfx_iota_kernel(uint32_t *v, uint64_t n) {
 
 // owner side: canonical k-mers (grouped by source order) -> lookup -> K* -> bins.
 // kasm was counted by the source; this adds kmissing (global + per contig), bins, koverCpy.
+// SEGS: the k-mers come as up to MFX_KEYS_MAX_SEGS segments (the groups of the sources of a sharded run, evaluated where
+// they lie: a group of the owner's own device is not copied first) and koverCpy is summed in FIXED POINT (every term
+// truncated to a multiple of 2^-52, 128-bit integer accumulator a.kfix): integer adds commute, so the sum does not depend on
+// the order the router's atomics left the k-mers in, nor on how the blocks cut them.  The host takes this form only when
+// every prob is in [0, 4096) (terms stay below 2^64 * 2^-52); |sum - fp64 sum| <= terms * 2^-53.
+template <bool SEGS>
 __global__ __launch_bounds__(MFX_BLOCK, 4) void mfx_hist_keys_kernel(mfx_hist_keys_args a) {
   __shared__ mfx_mailbox MB;
   __shared__ mfx_hist_lds H;
@@ -2147,6 +2148,7 @@ __global__ __launch_bounds__(MFX_BLOCK, 4) void mfx_hist_keys_kernel(mfx_hist_ke
   const uint64_t i0 = blockIdx.x * per, i1 = i0 + per < a.n ? i0 + per : a.n;
   uint64_t n_missing = 0, n_over0 = 0, zz = 0;
   double kover = 0.0;
+  uint64_t fx_lo = 0, fx_hi = 0;                                   // SEGS: this lane's koverCpy terms, units of 2^-52
   uint64_t *c_glob = ka.counts + 2ull * ka.nbins;
   uint64_t *c_kmis = c_glob + 3 + ka.ncontigs;
   // Per-contig kmissing: the k-mers arrive in sequence order per source, so a block's slice is almost always
@@ -2154,31 +2156,52 @@ __global__ __launch_bounds__(MFX_BLOCK, 4) void mfx_hist_keys_kernel(mfx_hist_ke
   // only a slice that straddles contigs sends the others straight to the global counters.  (One global atomic
   // per missing k-mer made every block queue on the same few addresses: 5x the kernel time.)
   __shared__ uint32_t s_kmis;
-  const uint32_t bctg = i0 < i1 ? a.contig[i0] : 0u;               // block-uniform
   if (tid == 0) s_kmis = 0u;
-  __syncthreads();
-  for (uint64_t base = i0; base < i1; base += MFX_BLOCK * MFX_BATCH) {       // block-uniform trip count
-    uint64_t key[MFX_BATCH], krc[MFX_BATCH];
-    uint32_t rv[MFX_BATCH], av[MFX_BATCH];
-    bool ok[MFX_BATCH];
-#pragma unroll
-    for (int j = 0; j < MFX_BATCH; ++j) {
-      const uint64_t i = base + (uint64_t)j * MFX_BLOCK + tid;
-      ok[j] = i < i1;
-      key[j] = ok[j] ? a.keys[i] : 0ULL;
-      krc[j] = mfx_revcomp(key[j], k);
+  // the block's slice [i0, i1) of the concatenated segments, one segment piece after the other
+  uint64_t seg_lo = 0;                                             // global index of the current segment's first k-mer
+  bool have_bctg = false;
+  uint32_t bctg = 0u;
+  for (uint32_t sg = 0; sg < (SEGS ? a.nseg : 1u); ++sg) {
+    const uint64_t seg_n = SEGS ? a.seg_n[sg] : a.n;
+    const uint64_t *skeys = SEGS ? a.seg_keys[sg] : a.keys;
+    const uint32_t *sctg = SEGS ? a.seg_contig[sg] : a.contig;
+    const uint64_t lo = i0 > seg_lo ? i0 - seg_lo : 0, hi = i1 > seg_lo ? (i1 - seg_lo < seg_n ? i1 - seg_lo : seg_n) : 0;   // within the segment
+    seg_lo += seg_n;
+    if (hi <= lo) continue;                                        // (block-uniform)
+    if (!have_bctg) {
+      have_bctg = true;
+      bctg = sctg[lo];                                             // block-uniform
+      __syncthreads();
     }
-    mfx_group_lookup<MFX_BATCH>(a.t, MB, key, krc, ok, rv, av);
+    for (uint64_t base = lo; base < hi; base += MFX_BLOCK * MFX_BATCH) {       // block-uniform trip count
+      uint64_t key[MFX_BATCH], krc[MFX_BATCH];
+      uint32_t rv[MFX_BATCH], av[MFX_BATCH];
+      bool ok[MFX_BATCH];
 #pragma unroll
-    for (int j = 0; j < MFX_BATCH; ++j) {
-      const bool miss = ok[j] && mfx_hist_eval(H, ka, lut_ok, rv[j], av[j], n_over0, kover);
-      const uint32_t cg = miss ? a.contig[base + (uint64_t)j * MFX_BLOCK + tid] : bctg;
-      const bool here = miss && cg == bctg;
-      const uint64_t m = __ballot(here);                                      // wave-uniform control flow up to here
-      if (m != 0ull && (tid & 63u) == (uint32_t)__ffsll((long long)m) - 1u) atomicAdd(&s_kmis, (uint32_t)__popcll(m));
-      if (miss) {
-        n_missing++;
-        if (!here) atomicAdd((unsigned long long *)&c_kmis[cg], 1ull);
+      for (int j = 0; j < MFX_BATCH; ++j) {
+        const uint64_t i = base + (uint64_t)j * MFX_BLOCK + tid;
+        ok[j] = i < hi;
+        key[j] = ok[j] ? skeys[i] : 0ULL;
+        krc[j] = mfx_revcomp(key[j], k);
+      }
+      mfx_group_lookup<MFX_BATCH>(a.t, MB, key, krc, ok, rv, av);
+#pragma unroll
+      for (int j = 0; j < MFX_BATCH; ++j) {
+        double term = 0.0;
+        const bool miss = ok[j] && mfx_hist_eval(H, ka, lut_ok, rv[j], av[j], n_over0, SEGS ? term : kover);
+        if (SEGS && term > 0.0) {                                  // 0 + x == x exactly: `term` is this k-mer's own (1 - readK/asmK) * prob
+          const uint64_t q = (uint64_t)(term * 4503599627370496.0);    // * 2^52, truncated
+          fx_lo += q;
+          fx_hi += fx_lo < q ? 1ull : 0ull;
+        }
+        const uint32_t cg = miss ? sctg[base + (uint64_t)j * MFX_BLOCK + tid] : bctg;
+        const bool here = miss && cg == bctg;
+        const uint64_t m = __ballot(here);                                      // wave-uniform control flow up to here
+        if (m != 0ull && (tid & 63u) == (uint32_t)__ffsll((long long)m) - 1u) atomicAdd(&s_kmis, (uint32_t)__popcll(m));
+        if (miss) {
+          n_missing++;
+          if (!here) atomicAdd((unsigned long long *)&c_kmis[cg], 1ull);
+        }
       }
     }
   }
@@ -2188,7 +2211,31 @@ __global__ __launch_bounds__(MFX_BLOCK, 4) void mfx_hist_keys_kernel(mfx_hist_ke
     if (n_over0) atomicAdd((unsigned long long *)&ka.counts[ka.nbins], n_over0);
     if (s_kmis) atomicAdd((unsigned long long *)&c_kmis[bctg], (unsigned long long)s_kmis);
   }
-  mfx_hist_lds_flush(H, ka, kover);
+  if (SEGS) {
+    // 128-bit sum over the block, then into the launch's accumulator: the low word's wrap-arounds are carried into the high one
+    // (each add of the low word reports the value it met)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint64_t ol = __shfl_down(fx_lo, o, 64), oh = __shfl_down(fx_hi, o, 64);
+      fx_lo += ol;
+      fx_hi += oh + (fx_lo < ol ? 1ull : 0ull);
+    }
+    __syncthreads();
+    if ((tid & 63u) == 0) { H.red[tid >> 6][0] = fx_lo; H.red[tid >> 6][1] = fx_hi; }
+    __syncthreads();
+    if (tid == 0) {
+      uint64_t lo = 0, hi = 0;
+      for (uint32_t w = 0; w < MFX_BLOCK / 64; ++w) { lo += H.red[w][0]; hi += H.red[w][1] + (lo < H.red[w][0] ? 1ull : 0ull); }
+      if (lo | hi) {
+        const unsigned long long old = atomicAdd((unsigned long long *)&a.kfix[0], (unsigned long long)lo);
+        hi += (old + lo < old) ? 1ull : 0ull;
+        if (hi) atomicAdd((unsigned long long *)&a.kfix[1], (unsigned long long)hi);
+      }
+    }
+    mfx_hist_lds_flush_bins(H, ka);
+  } else {
+    mfx_hist_lds_flush(H, ka, kover);
+  }
 }
 
 // sums the partials in a fixed order and adds the result to *out; re-arms the tile scheduler counter
@@ -2623,7 +2670,14 @@ hipError_t mfx_k_iota(uint32_t *v, uint64_t n, hipStream_t st) {
   return hipGetLastError();
 }
 hipError_t mfx_k_hist_keys(const mfx_hist_keys_args &a, int grid, hipStream_t st) {
-  mfx_hist_keys_kernel<<<grid, MFX_BLOCK, 0, st>>>(a);
+  if (a.nseg) mfx_hist_keys_kernel<true><<<grid, MFX_BLOCK, 0, st>>>(a);
+  else        mfx_hist_keys_kernel<false><<<grid, MFX_BLOCK, 0, st>>>(a);
+  return hipGetLastError();
+}
+hipError_t mfx_k_route_fused(const mfx_route_args &a, uint64_t *keys_out, uint32_t *contig_out, uint64_t *cursors, uint64_t region_cap, hipStream_t st) {
+  const uint64_t nt = a.tile_end - a.tile_begin;
+  if (nt == 0) return hipSuccess;
+  mfx_route_fused_kernel<<<(unsigned)(nt < 4096 ? nt : 4096), MFX_BLOCK, 0, st>>>(a, keys_out, contig_out, reinterpret_cast<unsigned long long *>(cursors), region_cap);
   return hipGetLastError();
 }
 hipError_t mfx_k_sum_partials(const double *partials, uint32_t n, double *out, hipStream_t st) {

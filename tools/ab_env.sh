@@ -3,7 +3,7 @@
 for rep in 1 2; do
 for spec in "$@"; do
   read -r label rest <<< "$spec"
-  env $rest python bench.py --steps 10 --warmup 3 --no-pmc --no-cpu-baseline --no-streamed > gpurun_out/abe_$label.json 2> gpurun_out/abe_$label.err
+  env $rest python bench.py --steps 10 --warmup 3 --no-pmc --no-cpu-baseline --no-streamed --no-e2e --no-full-index > gpurun_out/abe_$label.json 2> gpurun_out/abe_$label.err
   python - <<PY
 import json
 d=json.load(open("gpurun_out/abe_$label.json"))

@@ -4,7 +4,7 @@ for rep in 1 2; do
 for spec in "$@"; do
   label=${spec%%=*}; lib=${spec#*=}
   if [ "$lib" = "default" ]; then unset MFX_LIB; else export MFX_LIB=$PWD/$lib; fi
-  python bench.py --steps 10 --warmup 3 --no-pmc --no-cpu-baseline --no-streamed > gpurun_out/ab_$label.json 2> gpurun_out/ab_$label.err
+  python bench.py --steps 10 --warmup 3 --no-pmc --no-cpu-baseline --no-streamed --no-e2e --no-full-index > gpurun_out/ab_$label.json 2> gpurun_out/ab_$label.err
   python - <<PY
 import json
 d=json.load(open("gpurun_out/ab_$label.json"))
