@@ -401,6 +401,8 @@ extern "C" void mfx_index_free(mfx_index *ix) {
   delete ix;
 }
 
+static mfx_ingest *ingest_get(mfx_index *ix, uint64_t n);
+
 static int index_check(mfx_index *ix) {
   ix->version++;
   uint64_t meta[5];
@@ -472,10 +474,10 @@ static mfx_ingest *ingest_get(mfx_index *ix, uint64_t n) {
   mfx_ingest *g = new mfx_ingest;
   g->cap = cap;
   g->kw = ix->key_words();
-  // three lanes let the fill of a chunk, the transfer of the one before and the insert of the one before that overlap (two
+  // three or more lanes let the fill of a chunk, the transfer of the one before and the insert of the one before that overlap (two
   // lanes: a lane's transfer and insert run one behind the other while only ONE other chunk is filled); small loads keep two
   // (pinning costs 0.4 ms per MB)
-  g->nl = cap >= (1ull << 20) ? 3 : 2;
+  g->nl = cap >= (1ull << 20) ? 4 : 2;
   if (const char *e = getenv("MFX_INGEST_LANES")) { const int v = atoi(e); if (v >= 2 && v <= MFX_INGEST_MAX_LANES) g->nl = v; }
   bool ok = true;
   for (int li = 0; li < g->nl; ++li) {
@@ -767,10 +769,13 @@ static int index_count(mfx_index *ix, const mfx_seq *seq, int count, void *strea
   a.ntiles = seq->ntiles;
   a.meta = ix->d_meta;
   a.count = count;
-  MFX_HIP(ix->wide() ? mfx_kw_count(a, (hipStream_t)stream) : mfx_k_count(a, (hipStream_t)stream));
-  MFX_HIP(hipStreamSynchronize((hipStream_t)stream));
   if (ix->seq_only)                                            // what this table can answer for: the k-mers of THIS sequence
     if (int drc = mfx_seq_digest32(seq, &ix->seq_digest)) return drc;
+  MFX_HIP(ix->wide() ? mfx_kw_count(a, (hipStream_t)stream) : mfx_k_count(a, (hipStream_t)stream));
+  // While the kernel claims / counts a large sequence's k-mers (0.11 s for 3 Gb), the host pins the staging lanes the database
+  // load that follows will want (0.06 s): the lanes belong to the index and are reused by every load.
+  if (ix->seq_only && seq->total_bases >= (256ull << 20)) (void)ingest_get(ix, 1ull << 22);
+  MFX_HIP(hipStreamSynchronize((hipStream_t)stream));
   return index_check(ix);
 }
 
@@ -1090,7 +1095,7 @@ extern "C" mfx_eval *mfx_eval_create(const mfx_index *ix, const mfx_kparams *kp,
     return nullptr;
   }
   const char *e = getenv("MFX_BLOCKS_PER_CU");
-  int bpc = e ? atoi(e) : mfx_k_hist_resident_blocks(ix->compact ? 1 : 0);   // persistent blocks: as many as are resident at once
+  int bpc = e ? atoi(e) : mfx_k_hist_resident_blocks(ix->compact ? 1 : 0, ix->k);   // persistent blocks: as many as are resident at once
   if (bpc < 1) bpc = 1;
   ev->grid = prop.multiProcessorCount * bpc;
   size_t np = ev->n_prob ? ev->n_prob : 1;
@@ -2358,6 +2363,14 @@ struct mfx_router {
   size_t    tmp_bytes = 0;
   uint32_t *d_tile_cnt = nullptr;    // [max_tiles * nranks] sort-free path (nranks <= MFX_SPLIT_MAX_RANKS)
   bool      split = false;
+  // buffers of the one-pass routing of mfx_hist_run_sharded, made by its first run and kept for the next ones (allocating
+  // gigabytes next to tables that fill the device took up to 0.3 s of a 0.08 s run)
+  struct Fused {
+    uint64_t *d_keys[2] = {nullptr, nullptr}, *d_rkeys = nullptr, *d_cursors = nullptr, *h_cursors = nullptr;
+    uint32_t *d_ctg[2] = {nullptr, nullptr}, *d_rctg = nullptr;
+    size_t region_cap = 0, rcap = 0;
+    uint32_t ndev = 0;
+  } fused;
 };
 
 int mfx_sort_by_owner(void *tmp, size_t &tmp_bytes, const uint8_t *kin, uint8_t *kout, const uint32_t *vin, uint32_t *vout,
@@ -2406,11 +2419,20 @@ extern "C" mfx_router *mfx_router_create(const mfx_index *ix, uint32_t nranks, u
   return r;
 }
 
+static void router_fused_free(mfx_router *r) {
+  auto &F = r->fused;
+  void *p[] = {F.d_keys[0], F.d_keys[1], F.d_rkeys, F.d_cursors, F.d_ctg[0], F.d_ctg[1], F.d_rctg};
+  for (void *x : p) if (x) (void)hipFree(x);
+  if (F.h_cursors) (void)hipHostFree(F.h_cursors);
+  F = mfx_router::Fused();
+}
+
 extern "C" void mfx_router_free(mfx_router *r) {
   if (!r) return;
   DevGuard g(r->device);
   void *p[] = {r->d_keys, r->d_owner, r->d_owner2, r->d_idx, r->d_idx2, r->d_dest, r->d_tmp, r->d_tile_cnt};
   for (void *x : p) if (x) (void)hipFree(x);
+  router_fused_free(r);
   delete r;
 }
 
@@ -2680,10 +2702,8 @@ extern "C" int mfx_hist_run_sharded(mfx_eval *const *evs, mfx_router *const *rou
       DevGuard g(evs[d]->device);
       if (sl[d].rst) (void)hipStreamSynchronize(sl[d].rst);
       if (sl[d].ost) (void)hipStreamSynchronize(sl[d].ost);
-      void *p[] = {sl[d].d_counts, sl[d].d_keys[0], sl[d].d_keys[1], sl[d].d_rkeys, sl[d].d_cursors, sl[d].d_kfix, sl[d].d_pkeys, sl[d].d_ctg[0], sl[d].d_ctg[1],
-                   sl[d].d_rctg, sl[d].d_pctg, sl[d].d_kover};
+      void *p[] = {sl[d].d_counts, sl[d].d_kfix, sl[d].d_pkeys, sl[d].d_pctg, sl[d].d_kover};      // (the group buffers stay with the router)
       for (void *x : p) if (x) (void)hipFree(x);
-      if (sl[d].h_cursors) (void)hipHostFree(sl[d].h_cursors);
       if (sl[d].rst) (void)hipStreamDestroy(sl[d].rst);
       if (sl[d].ost) (void)hipStreamDestroy(sl[d].ost);
     }
@@ -2694,11 +2714,23 @@ extern "C" int mfx_hist_run_sharded(mfx_eval *const *evs, mfx_router *const *rou
     for (int b2 = 0; b2 < 2; ++b2) { S.gkeys[b2].assign(ndev, nullptr); S.gctg[b2].assign(ndev, nullptr); S.gn[b2].assign(ndev, 0); }
     bool ok = hipStreamCreateWithFlags(&S.rst, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&S.ost, hipStreamNonBlocking) == hipSuccess &&
               hipMalloc((void **)&S.d_counts, words * sizeof(uint64_t)) == hipSuccess && hipMalloc((void **)&S.d_kover, sizeof(double)) == hipSuccess &&
-              hipMalloc((void **)&S.d_kfix, 2 * sizeof(uint64_t)) == hipSuccess && hipMalloc((void **)&S.d_cursors, 2 * (ndev + 1) * sizeof(uint64_t)) == hipSuccess &&
-              hipHostMalloc((void **)&S.h_cursors, 2 * (ndev + 1) * sizeof(uint64_t), hipHostMallocDefault) == hipSuccess;
-    for (int b2 = 0; b2 < 2 && ok; ++b2)
-      ok = hipMalloc((void **)&S.d_keys[b2], (size_t)ndev * region_cap * 8) == hipSuccess && hipMalloc((void **)&S.d_ctg[b2], (size_t)ndev * region_cap * 4) == hipSuccess;
-    if (ok && rcap) ok = hipMalloc((void **)&S.d_rkeys, rcap * 8) == hipSuccess && hipMalloc((void **)&S.d_rctg, rcap * 4) == hipSuccess;
+              hipMalloc((void **)&S.d_kfix, 2 * sizeof(uint64_t)) == hipSuccess;
+    // the group buffers live in the router (made by the first run on it)
+    auto &F = routers[d]->fused;
+    if (ok && (F.region_cap != region_cap || F.rcap != rcap || F.ndev != ndev)) {
+      router_fused_free(routers[d]);
+      F.region_cap = region_cap; F.rcap = rcap; F.ndev = ndev;
+      ok = hipMalloc((void **)&F.d_cursors, 2 * (ndev + 1) * sizeof(uint64_t)) == hipSuccess &&
+           hipHostMalloc((void **)&F.h_cursors, 2 * (ndev + 1) * sizeof(uint64_t), hipHostMallocDefault) == hipSuccess;
+      for (int b2 = 0; b2 < 2 && ok; ++b2)
+        ok = hipMalloc((void **)&F.d_keys[b2], (size_t)ndev * region_cap * 8) == hipSuccess && hipMalloc((void **)&F.d_ctg[b2], (size_t)ndev * region_cap * 4) == hipSuccess;
+      if (ok && rcap) ok = hipMalloc((void **)&F.d_rkeys, rcap * 8) == hipSuccess && hipMalloc((void **)&F.d_rctg, rcap * 4) == hipSuccess;
+      if (!ok) router_fused_free(routers[d]);
+    }
+    if (ok) {
+      S.d_keys[0] = F.d_keys[0]; S.d_keys[1] = F.d_keys[1]; S.d_ctg[0] = F.d_ctg[0]; S.d_ctg[1] = F.d_ctg[1];
+      S.d_rkeys = F.d_rkeys; S.d_rctg = F.d_rctg; S.d_cursors = F.d_cursors; S.h_cursors = F.h_cursors;
+    }
     ok = ok && hipMemsetAsync(S.d_counts, 0, words * sizeof(uint64_t), S.ost) == hipSuccess && hipMemsetAsync(S.d_kover, 0, sizeof(double), S.ost) == hipSuccess &&
          hipMemsetAsync(S.d_kfix, 0, 2 * sizeof(uint64_t), S.ost) == hipSuccess && hipMemsetAsync(evs[d]->d_ovf, 0, sizeof(uint64_t), S.ost) == hipSuccess &&
          hipStreamSynchronize(S.ost) == hipSuccess;

@@ -98,7 +98,7 @@ __device__ __forceinline__ void mfx_block_sum3(uint64_t &a, uint64_t &b, uint64_
 // LDS state of the K* / histogram stage, shared by the sequence-driven kernel
 // (mfx_hist_kernel) and the key-driven one (mfx_hist_keys_kernel, sharded index).
 #ifndef MFX_V_LDS_DIET
-#define MFX_V_LDS_DIET 0              // 1: no prob / over-copy tables in LDS (16 KB less per block: they serve the `asmK > readK` branch only) -- A/B: tools/ab_build.sh
+#define MFX_V_LDS_DIET 1              // 1 (default since round 4): no prob / over-copy tables in LDS (16 KB less per block: they serve the `asmK > readK` branch only; 22.5 KB per block lets 7 blocks share a CU) -- A/B: tools/ab_build.sh -DMFX_V_LDS_DIET=0
 #endif
 struct mfx_hist_lds {
   uint32_t hist[2 * MFX_NB_LDS];

@@ -119,7 +119,7 @@ hipError_t mfx_k_sum_partials(const double *partials, uint32_t n, double *out, h
 hipError_t mfx_k_ordered_sum(const double *v, uint32_t n, double *out, hipStream_t st);
 uint64_t mfx_k_tile_partials_words(uint64_t ntiles);
 hipError_t mfx_k_sum_tile_partials(double *tile_partials, uint64_t ntiles, double *out, uint64_t *ctr_reset, hipStream_t st);
-int mfx_k_hist_resident_blocks(int compact);
+int mfx_k_hist_resident_blocks(int compact, int k);
 int mfx_k_quot_supported();
 hipError_t mfx_k_gather_rate(const void *table, uint64_t nlines, uint64_t *scratch, double *lines_per_s, hipStream_t st);
 // 32 <= k <= 64 (mfx_wide.hip); kmers: two uint64 words per k-mer {low 64 bits, high bits}

@@ -1352,6 +1352,9 @@ __device__ __forceinline__ void mfx_group_lookup8(const mfx_table_view &c, mfx_m
 // through the next ones (a round = one more load for the lanes that need it, the others wait): 5.8 % need a second
 // load, 1.3 % a third.  A line exhausted without the key or an empty slot is rare enough for the whole-line scan (mfx_c_find).
 // ---------------------------------------------------------------------------
+#ifndef MFX_V_TAIL_STEPS
+#define MFX_V_TAIL_STEPS 0            // cooperative steps of the probe's tail whose line loads are in flight together; 0: by the batch size (A/B: tools/ab_build.sh)
+#endif
 // fkey: what the key field of each query's slot holds in its home line (mfx_probe::fkey: the k-mer, or its quotient for k > 21);
 // line / b0: its home line and first mini-bucket (mfx_home, or mfx_wave_mod_line for a whole wave at once); a query that is not
 // ok must come with line 0 / b0 0 (a dummy load, ignored).  keyof(j): the canonical k-mer of query j -- asked for on the rare
@@ -1415,7 +1418,7 @@ __device__ __forceinline__ void mfx_lane_lookup8(const mfx_table_view &c, mfx_ma
     // record -- found: the slot's low word and the marker; an empty slot seen: "room".  Up to MFX_TAIL_STEPS steps (8 entries
     // each) have their line loads in flight TOGETHER: a wave typically has ~25 displaced queries among its 256, i.e. four steps
     // -- one round trip.  second: only the entries an owner flagged for their next candidate line (rec.w == 2).
-    constexpr uint32_t MFX_TAIL_STEPS = 4;
+    constexpr uint32_t MFX_TAIL_STEPS = MFX_V_TAIL_STEPS ? MFX_V_TAIL_STEPS : (B <= 2 ? 2 : 4);   // ~6 displaced queries per batch element and wave
     auto tail_pass = [&](bool second) {
       for (uint32_t q0 = 0; q0 < nq; q0 += 8u * MFX_TAIL_STEPS) {
         uint4 sl[MFX_TAIL_STEPS];
@@ -1667,9 +1670,36 @@ constexpr int MFX_BATCH = MFX_V_BATCH;          // queries per lane and cooperat
 #ifndef MFX_V_MINBLOCKS
 #define MFX_V_MINBLOCKS 4             // blocks per CU the register allocation aims at (tools/ab_build.sh -DMFX_V_MINBLOCKS=3: A/B)
 #endif
-// DBG: the same kernel with the probe's path counters (mfx_hist_args::dbg, mfx_lane_lookup8); never the measured instance
+// Occupancy target (blocks per CU = waves per SIMD) and queries per lane of the -hist instances.  The per-lane probe of the
+// compact layout is bound by round trips: throughput follows (waves x queries in flight) / latency, and what a wave holds per query
+// decides how many waves fit.  Round 4 (profiles/r04_kernel_waves.txt, 3 Gb, same box, back to back): 4 waves x 4 queries 134.1 G,
+// 5 x 4 142.1, 6 x 2 144.4, 7 x 2 147.6 (72 VGPRs, 22.5 KB of LDS per block: the prob / over-copy tables left LDS for that),
+// 6 x 3 138.5, 6 x 4 107.8, 8 x 2 101.9 (spills), 8 x 1 135.6.  The cooperative probe of the full table keeps 4 x 4.
+#ifndef MFX_V_MINBLOCKS_K21
+#define MFX_V_MINBLOCKS_K21 7
+#endif
+#ifndef MFX_V_BATCH_K21
+#define MFX_V_BATCH_K21 2
+#endif
+#ifndef MFX_V_MINBLOCKS_K31
+#define MFX_V_MINBLOCKS_K31 4
+#endif
+#ifndef MFX_V_BATCH_K31
+#define MFX_V_BATCH_K31 4
+#endif
+#ifndef MFX_V_MINBLOCKS_GEN
+#define MFX_V_MINBLOCKS_GEN 4
+#endif
+#ifndef MFX_V_BATCH_GEN
+#define MFX_V_BATCH_GEN 4
+#endif
+template <bool CANON, bool COMPACT, int KF> struct mfx_hist_tune { static constexpr int blocks = MFX_V_MINBLOCKS, batch = MFX_V_BATCH; };
+template <> struct mfx_hist_tune<true, true, 21> { static constexpr int blocks = MFX_V_MINBLOCKS_K21, batch = MFX_V_BATCH_K21; };
+template <> struct mfx_hist_tune<true, true, 31> { static constexpr int blocks = MFX_V_MINBLOCKS_K31, batch = MFX_V_BATCH_K31; };
+template <> struct mfx_hist_tune<true, true, 0> { static constexpr int blocks = MFX_V_MINBLOCKS_GEN, batch = MFX_V_BATCH_GEN; };
 template <bool CANON, bool COMPACT, int KF, int WF, int TF, bool DBG = false>
-__global__ __launch_bounds__(MFX_BLOCK, MFX_V_MINBLOCKS) void mfx_hist_kernel(mfx_hist_args a) {
+__global__ __launch_bounds__(MFX_BLOCK, (mfx_hist_tune<CANON, COMPACT, KF>::blocks)) void mfx_hist_kernel(mfx_hist_args a) {
+  constexpr int BT = mfx_hist_tune<CANON, COMPACT, KF>::batch;                  // queries per lane and probe sequence of this instance
   __shared__ mfx_tile_lds L;
   __shared__ mfx_mailbox MB;
   __shared__ mfx_hist_lds H;
@@ -1731,20 +1761,20 @@ __global__ __launch_bounds__(MFX_BLOCK, MFX_V_MINBLOCKS) void mfx_hist_kernel(mf
     __syncthreads();
 
     double kover = 0.0;                      // this lane's koverCpy terms of this tile
-    for (uint32_t b = 0; b < MFX_TILE / MFX_BLOCK; b += MFX_BATCH) {
+    for (uint32_t b = 0; b < MFX_TILE / MFX_BLOCK; b += BT) {
       if (b * MFX_BLOCK >= n) break;         // short last tile of a contig (block-uniform): nothing starts beyond n
-      uint32_t rv[MFX_BATCH], av[MFX_BATCH];
-      bool     ok[MFX_BATCH];
+      uint32_t rv[BT], av[BT];
+      bool     ok[BT];
       // mod-minimizer placement: the wave finds its home lines together (mfx_wave_mod_line)
       const bool wave_lines = COMPACT && CANON && (KF ? TF != 0 : a.t.mz_t != 0);
       const bool even_k = KF ? (KF & 1) == 0 : (k & 1) == 0;
       if (wave_lines) {
-        uint64_t fkey[MFX_BATCH];
-        uint32_t line[MFX_BATCH], b0[MFX_BATCH];
+        uint64_t fkey[BT];
+        uint32_t line[BT], b0[BT];
         uint32_t halo[2], pal = 0u;
-        mfx_wave_mod_halo<MFX_BATCH>(a.t, L, b * MFX_BLOCK + tid, halo);
+        mfx_wave_mod_halo<BT>(a.t, L, b * MFX_BLOCK + tid, halo);
 #pragma unroll
-        for (int j = 0; j < MFX_BATCH; ++j) {
+        for (int j = 0; j < BT; ++j) {
           const uint32_t p = (b + j) * MFX_BLOCK + tid;     // lane-consecutive positions
           uint64_t f;
           ok[j] = mfx_tile_kmer(L, k, p, f) && (p < n);
@@ -1759,7 +1789,7 @@ __global__ __launch_bounds__(MFX_BLOCK, MFX_V_MINBLOCKS) void mfx_hist_kernel(mf
           uint64_t kk = 0;
           if (!quot) {
 #pragma unroll
-            for (int j = 0; j < MFX_BATCH; ++j) if (j == sj) kk = fkey[j];
+            for (int j = 0; j < BT; ++j) if (j == sj) kk = fkey[j];
           } else {
             uint64_t f;
             (void)mfx_tile_kmer(L, k, (b + (uint32_t)sj) * MFX_BLOCK + tid, f);
@@ -1768,18 +1798,18 @@ __global__ __launch_bounds__(MFX_BLOCK, MFX_V_MINBLOCKS) void mfx_hist_kernel(mf
           }
           return kk;
         };
-        mfx_lane_lookup8<MFX_BATCH>(a.t, MB, fkey, ok, rv, av, line, b0, keyof, DBG ? reinterpret_cast<unsigned long long *>(a.dbg) : nullptr);
+        mfx_lane_lookup8<BT>(a.t, MB, fkey, ok, rv, av, line, b0, keyof, DBG ? reinterpret_cast<unsigned long long *>(a.dbg) : nullptr);
         if (even_k) {
           // even k, canonical database: a k-mer that is its own reverse complement is looked up as fmer AND as rmer by the
           // reference -- the same slot twice (value(fmer) + value(rmer), uint32 arithmetic); every other k-mer has one strand
           // in the database, the one probed
 #pragma unroll
-          for (int j = 0; j < MFX_BATCH; ++j) if ((pal >> j) & 1u) { rv[j] += rv[j]; av[j] += av[j]; }
+          for (int j = 0; j < BT; ++j) if ((pal >> j) & 1u) { rv[j] += rv[j]; av[j] += av[j]; }
         }
       } else {
-        uint64_t key[MFX_BATCH], key2[MFX_BATCH];
+        uint64_t key[BT], key2[BT];
 #pragma unroll
-        for (int j = 0; j < MFX_BATCH; ++j) {
+        for (int j = 0; j < BT; ++j) {
           const uint32_t p = (b + j) * MFX_BLOCK + tid;     // lane-consecutive positions
           uint64_t f;
           ok[j] = mfx_tile_kmer(L, k, p, f) && (p < n);
@@ -1790,23 +1820,23 @@ __global__ __launch_bounds__(MFX_BLOCK, MFX_V_MINBLOCKS) void mfx_hist_kernel(mf
             key[j] = f; key2[j] = r;
           }
         }
-        if (COMPACT) MFX_COMPACT_LOOKUP(a.t, MB, key, key2, ok, rv, av);
-        else mfx_group_lookup<MFX_BATCH>(a.t, MB, key, key2, ok, rv, av);
+        if (COMPACT) mfx_compact_lookup<BT>(a.t, MB, key, key2, ok, rv, av);
+        else mfx_group_lookup<BT>(a.t, MB, key, key2, ok, rv, av);
         if (!CANON) {
           // value(fmer) + value(rmer), uint32 arithmetic (merfin-globals.C:107-108)
-          uint32_t rv2[MFX_BATCH], av2[MFX_BATCH];
-          if (COMPACT) MFX_COMPACT_LOOKUP(a.t, MB, key2, key, ok, rv2, av2);
-          else mfx_group_lookup<MFX_BATCH>(a.t, MB, key2, key, ok, rv2, av2);
+          uint32_t rv2[BT], av2[BT];
+          if (COMPACT) mfx_compact_lookup<BT>(a.t, MB, key2, key, ok, rv2, av2);
+          else mfx_group_lookup<BT>(a.t, MB, key2, key, ok, rv2, av2);
 #pragma unroll
-          for (int j = 0; j < MFX_BATCH; ++j) { rv[j] += rv2[j]; av[j] += av2[j]; }
+          for (int j = 0; j < BT; ++j) { rv[j] += rv2[j]; av[j] += av2[j]; }
         } else if (even_k) {
           // (the same slot twice for a k-mer that is its own reverse complement: see above)
 #pragma unroll
-          for (int j = 0; j < MFX_BATCH; ++j) if (key[j] == key2[j]) { rv[j] += rv[j]; av[j] += av[j]; }
+          for (int j = 0; j < BT; ++j) if (key[j] == key2[j]) { rv[j] += rv[j]; av[j] += av[j]; }
         }
       }
 #pragma unroll
-      for (int j = 0; j < MFX_BATCH; ++j) {
+      for (int j = 0; j < BT; ++j) {
         if (!ok[j]) continue;
         n_valid++;                                                   // merfin-histogram.C:58
         if (mfx_hist_eval(H, ka, lut_ok, rv[j], av[j], n_over0, kover)) n_missing++;
@@ -2703,10 +2733,13 @@ hipError_t mfx_k_sum_tile_partials(double *tile_partials, uint64_t ntiles, doubl
 // the quotient form of the compact layout (22 <= k <= 31) is served by the per-lane probe only (an A/B build with
 // -DMFX_V_LANEPROBE=0 keeps those k in 16-byte slots)
 int mfx_k_quot_supported() { return MFX_V_LANEPROBE ? 1 : 0; }
-int mfx_k_hist_resident_blocks(int compact) {
+// blocks of the -hist instance this table's evaluation launches that are resident per CU (the persistent grid's size)
+int mfx_k_hist_resident_blocks(int compact, int k) {
   int nb = 0;
-  const hipError_t e = compact ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mfx_hist_kernel<true, true, 0, 0, 0>, MFX_BLOCK, 0)
-                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mfx_hist_kernel<true, false, 0, 0, 0>, MFX_BLOCK, 0);
+  const hipError_t e = !compact ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mfx_hist_kernel<true, false, 0, 0, 0>, MFX_BLOCK, 0)
+                       : k == 21 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mfx_hist_kernel<true, true, 21, 4, 6>, MFX_BLOCK, 0)
+                       : k == 31 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mfx_hist_kernel<true, true, 31, 4, 4>, MFX_BLOCK, 0)
+                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mfx_hist_kernel<true, true, 0, 0, 0>, MFX_BLOCK, 0);
   if (e != hipSuccess || nb < 1) nb = 4;
   return nb;
 }

@@ -24,6 +24,7 @@ try:
           (bases, inp["fasta_bytes"] / 1e9, inp["read_kmers"], inp["db_bytes"] / 1e9, inp["db_bytes"] / inp["read_kmers"], inp["write_s"]), flush=True)
     prob = os.path.join(ROOT, "tests", "golden", "example_lookup_table.txt")
     ref = None
+    time.sleep(3)                                               # let the writer's threads and the driver settle: the first run is the figure of a quiet box
     for rep in range(2):
         for env in envs:
             rc, wall, ph, err = e2e_inputs.run_cli_hist(ROOT, inp, prob=prob, out_hist=os.path.join(tmp, "o.hist"), env=dict(env, MFX_INGEST_TIMING="1"))
