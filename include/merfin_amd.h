@@ -159,6 +159,14 @@ typedef struct mfx_seq mfx_seq;
 mfx_index *mfx_index_create_for_seq(int k, uint64_t capacity_kmers, double max_gb, int device);
 double     mfx_index_estimate_gb_for_seq(int k, uint64_t capacity_kmers);
 int        mfx_index_claim_seq(mfx_index *ix, const mfx_seq *seq, void *stream);
+/* PART of an assembly per device (round 4; config 5's -hist / -dump without any exchange): a device that evaluates some
+ * contigs claims THEIR k-mers (mfx_index_claim_seq on a sequence object of those contigs), takes their assembly counts
+ * from the WHOLE assembly -- asmV += 1 per occurrence of a claimed k-mer in `seq`, nothing is claimed --
+ *   mfx_index_count_claimed(ix, whole_assembly, 0)
+ * and loads the read database update-only as above.  value() of its contigs' k-mers is then what the full tables of the
+ * whole run answer (`meryl count` of -sequence counts every contig, merfin-globals.C:182-186), the device evaluates its
+ * contigs alone, and mfx_hist_run_parts adds the devices' results. */
+int        mfx_index_count_claimed(mfx_index *ix, const mfx_seq *seq, void *stream);
 
 /* Native replacement of the `meryl count k=.. <seq> output <seq>.meryl` child
  * process (merfin-globals.C:182-186): counts the canonical k-mers of every
@@ -301,6 +309,14 @@ int        mfx_index_replicate_many(const mfx_index *src, const int *devices, ui
 int        mfx_seq_replicate_many(const mfx_seq *src, const int *devices, uint32_t n, mfx_seq **out);
 int        mfx_seq_pack(mfx_seq *seq);
 int        mfx_hist_run_multi(mfx_eval *const *evs, const mfx_seq *const *seqs, uint32_t ndev, mfx_hist_result *out);
+/* PARTS of one assembly, one per slot: slot d evaluates ITS contigs (seqs[d]) on its own sequence-only index (their k-mers
+ * claimed, assembly counts from the whole assembly by mfx_index_count_claimed, the read database update-only) -- no k-mer
+ * ever leaves its device, whatever the size of the read database.  contig_ids[d][i] = number of slot d's contig i in the
+ * whole assembly (ncontigs_total of them); bins and counters are added, the per-contig counters placed by those numbers,
+ * koverCpy summed in slot order.  The reference's own way to spread a large run -- contigs over processes,
+ * scripts/parallel1/merfin.sh:68-85 -- inside one process, with the lookup object cut to each part. */
+int        mfx_hist_run_parts(mfx_eval *const *evs, const mfx_seq *const *seqs, const uint32_t *const *contig_ids, uint32_t ndev,
+                              uint32_t ncontigs_total, mfx_hist_result *out);
 
 /* One process per GPU (torchrun / mpirun style launchers): the collective of the path, on RCCL over xGMI.
  * Rank 0 makes an id (mfx_comm_unique_id), the launcher hands its MFX_COMM_ID_BYTES to every rank by any

@@ -63,7 +63,7 @@ _lib = None
 SYMBOLS = [
     "mfx_last_error", "mfx_last_error_code", "mfx_version", "mfx_device_count",
     "mfx_index_create", "mfx_index_free", "mfx_index_estimate_gb", "mfx_index_add_read", "mfx_index_add_asm",
-    "mfx_index_count_asm", "mfx_index_create_for_seq", "mfx_index_estimate_gb_for_seq", "mfx_index_claim_seq", "mfx_index_value", "mfx_index_get_info", "mfx_index_export",
+    "mfx_index_count_asm", "mfx_index_count_claimed", "mfx_hist_run_parts", "mfx_index_create_for_seq", "mfx_index_estimate_gb_for_seq", "mfx_index_claim_seq", "mfx_index_value", "mfx_index_get_info", "mfx_index_export",
     "mfx_db_probe", "mfx_index_load_db", "mfx_index_load_db_multi", "mfx_db_write_flat", "mfx_db_convert", "mfx_index_save", "mfx_index_load",
     "mfx_index_set_fingerprint", "mfx_index_get_origin",
     "mfx_host_alloc", "mfx_host_free", "mfx_seq_create", "mfx_hist_run_streamed",
@@ -124,6 +124,8 @@ def load_library():
     L.mfx_index_add_read.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int]
     L.mfx_index_add_asm.argtypes = [vp, vp, vp, C.c_uint64, C.c_int]
     L.mfx_index_count_asm.argtypes = [vp, vp, vp]
+    L.mfx_index_count_claimed.argtypes = [vp, vp, vp]
+    L.mfx_hist_run_parts.argtypes = [C.POINTER(vp), C.POINTER(vp), C.POINTER(C.POINTER(C.c_uint32)), C.c_uint32, C.c_uint32, vp]
     L.mfx_index_create_for_seq.restype = vp
     L.mfx_index_create_for_seq.argtypes = [C.c_int, C.c_uint64, C.c_double, C.c_int]
     L.mfx_index_estimate_gb_for_seq.restype = C.c_double
@@ -345,6 +347,10 @@ class Index:
         """a SEQUENCE-ONLY index (mfx_index_create_for_seq): claim the k-mers of the sequence first (count_asm or
         claim_seq), then add / load -- those only update the claimed k-mers.  For -hist and -dump."""
         return Index(k, capacity_kmers, max_gb=max_gb, device=device, seq_only=True)
+
+    def count_claimed(self, seqs, stream=None):
+        """asmV += 1 per occurrence, in `seqs`, of a k-mer claimed before (claim_seq); nothing is claimed"""
+        _check(load_library().mfx_index_count_claimed(self.h, seqs.h, C.c_void_p(stream or 0)))
 
     def claim_seq(self, seqs, stream=None):
         _check(load_library().mfx_index_claim_seq(self.h, seqs.h, C.c_void_p(stream or 0)))
@@ -787,6 +793,18 @@ class Comm:
 
     def __del__(self):
         self.close()
+
+
+def hist_parts(evaluators, sequences, contig_ids, ncontigs_total):
+    """mfx_hist_run_parts: slot d evaluates its contigs (sequences[d], numbered contig_ids[d] in the whole assembly) on its own index"""
+    n = len(evaluators)
+    evs = (C.c_void_p * n)(*[e.h for e in evaluators])
+    sqs = (C.c_void_p * n)(*[s.h for s in sequences])
+    keep = [np.ascontiguousarray(ids, dtype=np.uint32) for ids in contig_ids]
+    idp = (C.POINTER(C.c_uint32) * n)(*[k.ctypes.data_as(C.POINTER(C.c_uint32)) for k in keep])
+    r = HistResult()
+    _check(load_library().mfx_hist_run_parts(evs, sqs, idp, n, int(ncontigs_total), C.byref(r.c)))
+    return r
 
 
 def gather_rate(table_bytes, device=0):

@@ -209,6 +209,135 @@ static uint64_t bases_upper_bound(const char *path) {
   return best;
 }
 
+// -hist and -dump with -sharded: PARTS of the assembly, one per slot (round 4).  They only ever ask the lookup tables for the
+// k-mers of -sequence (merfin-histogram.C:54-64, merfin-dump.C:44-61), so a slot needs the k-mers of the contigs IT evaluates
+// and nothing else: the contigs are dealt to the slots (balanced by bases), slot d claims its contigs' k-mers into a
+// sequence-only index, counts them over the whole assembly (or takes them from -seqmers), the databases -- decoded once, sent
+// to every slot -- update them, and every slot evaluates its contigs on its own device: no k-mer is ever exchanged, whatever
+// the size of the read database (config 5: each of the 8 GPUs keeps the 1/8 of a 2 x 10^10-k-mer database that its contigs hit).
+// Returns -1 when a database is not canonical (the caller falls back to the hash-sharded full tables).
+static int run_parts(const Globals &G, int k, const std::vector<SeqRecord> &recs, const std::vector<const char *> &bases,
+                     const std::vector<uint64_t> &lens) {
+  const uint32_t N = (uint32_t)G.devices.size();
+  const uint32_t NC = (uint32_t)recs.size();
+  // the contigs of every slot: largest first to the least loaded slot; ascending numbers inside a slot
+  std::vector<std::vector<uint32_t>> ids(N);
+  {
+    std::vector<uint32_t> order(NC);
+    for (uint32_t c = 0; c < NC; ++c) order[c] = c;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return lens[a] > lens[b]; });
+    std::vector<uint64_t> load(N, 0);
+    for (uint32_t c : order) {
+      const uint32_t d = (uint32_t)(std::min_element(load.begin(), load.end()) - load.begin());
+      ids[d].push_back(c);
+      load[d] += lens[c] + 1;
+    }
+    for (auto &v : ids) std::sort(v.begin(), v.end());
+  }
+  std::vector<mfx_index *> ixs(N, nullptr);
+  std::vector<mfx_seq *> own(N, nullptr), whole(N, nullptr);
+  std::vector<mfx_eval *> evs(N, nullptr);
+  mfx_kparams kp{G.peak, (uint32_t)G.copyKmerK.size(), G.copyKmerK.data(), G.copyKmerP.data()};
+  int rc = 0;
+  auto fail = [&](const char *what) { fprintf(stderr, "ERROR: %s: %s\n", what, mfx_last_error()); rc = 1; };
+  auto release = [&]() {
+    for (uint32_t d = 0; d < N; ++d) {
+      if (evs[d]) mfx_eval_free(evs[d]);
+      if (ixs[d]) mfx_index_free(ixs[d]);
+      if (own[d]) mfx_seq_free(own[d]);
+      bool shared = false;
+      for (uint32_t e = 0; e < d; ++e) if (whole[e] == whole[d]) shared = true;
+      if (whole[d] && !shared) mfx_seq_free(whole[d]);
+      evs[d] = nullptr; ixs[d] = nullptr; own[d] = nullptr; whole[d] = nullptr;
+    }
+  };
+  for (uint32_t d = 0; d < N && !rc; ++d) {
+    std::vector<const char *> b2;
+    std::vector<uint64_t> l2;
+    uint64_t nb = 0;
+    for (uint32_t c : ids[d]) { b2.push_back(bases[c]); l2.push_back(lens[c]); nb += lens[c]; }
+    fprintf(stderr, "-- Part %u of %u on device %d: %zu sequences, %lu bases.\n", d, N, G.devices[d], ids[d].size(), (unsigned long)nb);
+    own[d] = mfx_seq_upload(G.devices[d], b2.data(), l2.data(), (uint32_t)b2.size());
+    if (!own[d]) { fail("uploading sequences"); break; }
+    ixs[d] = mfx_index_create_for_seq(k, nb + 1024, G.maxMemory, G.devices[d]);
+    if (!ixs[d]) { fprintf(stderr, "\n%s\n\n", mfx_last_error()); rc = 1; break; }
+    if (mfx_index_claim_seq(ixs[d], own[d], nullptr)) { fail("claiming sequence k-mers"); break; }
+    if (!G.seqDBname) {
+      // replaces `meryl count k=.. <seq> output <seq>.meryl` (merfin-globals.C:182-186): every contig of the assembly counts
+      for (uint32_t e = 0; e < d; ++e) if (G.devices[e] == G.devices[d]) { whole[d] = whole[e]; break; }
+      if (!whole[d]) whole[d] = mfx_seq_upload(G.devices[d], bases.data(), lens.data(), NC);
+      if (!whole[d]) { fail("uploading sequences"); break; }
+      if (mfx_index_count_claimed(ixs[d], whole[d], nullptr)) { fail("counting sequence k-mers"); break; }
+    }
+  }
+  for (uint32_t d = 0; d < N; ++d) {                              // the whole assembly was only needed for the counts
+    bool shared = false;
+    for (uint32_t e = 0; e < d; ++e) if (whole[e] == whole[d]) shared = true;
+    if (whole[d] && !shared) mfx_seq_free(whole[d]);
+  }
+  std::fill(whole.begin(), whole.end(), nullptr);
+  int lrc = 0;
+  if (!rc && G.seqDBname) {
+    fprintf(stderr, "-- Loading kmers from '%s' into the %u parts.\n", G.seqDBname, N);
+    lrc = mfx_index_load_db_multi(ixs.data(), N, G.seqDBname, 1, 0, ~0ull);
+    if (lrc && lrc != MFX_E_NONCANON) fail("loading -seqmers");
+  }
+  if (!rc && !lrc) {
+    fprintf(stderr, "-- Loading kmers from '%s' into the %u parts.\n", G.readDBname, N);
+    lrc = mfx_index_load_db_multi(ixs.data(), N, G.readDBname, 0, G.minV, G.maxV);
+    if (lrc && lrc != MFX_E_NONCANON) fail("loading -readmers");
+  }
+  if (!rc && lrc == MFX_E_NONCANON) {
+    fprintf(stderr, "-- A k-mer database is not canonical; building the sharded full tables instead.\n");
+    release();
+    return -1;
+  }
+  for (uint32_t d = 0; d < N && !rc; ++d) {
+    evs[d] = mfx_eval_create(ixs[d], &kp, 0);
+    if (!evs[d]) { fail("creating evaluator"); break; }
+  }
+  std::vector<const uint32_t *> idp(N);
+  for (uint32_t d = 0; d < N; ++d) idp[d] = ids[d].data();
+  if (!rc && (G.reportType == OP_HIST || G.skipMissing)) {
+    mfx_hist_result r;
+    if (G.reportType == OP_HIST) fprintf(stderr, "-- Generate histogram of the k* metric to '%s' on %u devices (one part of the sequences each).\n", G.outName, N);
+    else fprintf(stderr, "-- Dump per-base k* metric to '%s' on %u devices (one part of the sequences each).\n", G.outName, N);
+    if (mfx_hist_run_parts(evs.data(), own.data(), idp.data(), N, NC, &r)) fail("-hist over the parts");
+    else if (G.reportType == OP_HIST) {
+      bool ok = true;
+      print_hist(recs, r, k, G.outName, &ok);
+      if (!ok) fail("writing histogram");
+      mfx_hist_result_free(&r);
+    } else {                               // -dump -skipMissing (merfin-dump.C:34,81-87): no dump file, only the per-contig counts
+      uint64_t cumMissing = 0, cumAsm = 0;
+      for (size_t c = 0; c < recs.size(); ++c) {
+        cumMissing += r.contig_kmissing[c];
+        cumAsm += r.contig_kasm[c];
+        fprintf(stderr, "%s\t%lu\t%lu\t%lu\n", recs[c].name.c_str(), (unsigned long)r.contig_kmissing[c], (unsigned long)cumMissing, (unsigned long)cumAsm);
+      }
+      mfx_hist_result_free(&r);
+    }
+  } else if (!rc) {
+    fprintf(stderr, "-- Dump per-base k* metric to '%s' on %u devices (one part of the sequences each).\n", G.outName, N);
+    // every contig by the slot that holds it, in input order (merfin.C:384: -dump writes in order)
+    std::vector<std::pair<uint32_t, uint32_t>> where(NC);           // contig -> (slot, number inside the slot)
+    for (uint32_t d = 0; d < N; ++d) for (uint32_t i = 0; i < ids[d].size(); ++i) where[ids[d][i]] = {d, i};
+    uint64_t cumMissing = 0, cumAsm = 0;
+    for (uint32_t c = 0; c < NC && !rc; ++c) {
+      uint64_t ka = 0, km = 0;
+      const uint32_t d = where[c].first;
+      if (mfx_dump_contig(evs[d], own[d], where[c].second, recs[c].name.c_str(), G.outName, c > 0, &ka, &km)) { fail("-dump over the parts"); break; }
+      cumMissing += km;
+      cumAsm += ka;
+      fprintf(stderr, "%s\t%lu\t%lu\t%lu\n", recs[c].name.c_str(), (unsigned long)km, (unsigned long)cumMissing, (unsigned long)cumAsm);
+    }
+    if (recs.empty()) { FILE *f = fopen(G.outName, "w"); if (f) fclose(f); }
+  }
+  release();
+  if (!rc) fprintf(stderr, "Bye!\n");
+  return rc;
+}
+
 // Every report over an index SHARDED across the devices of -devices (read databases beyond one GPU, BASELINE
 // config 5): slot d keeps the k-mers it owns (mfx_index_set_shard), loads skip foreign k-mers, -hist routes every k-mer
 // to its owner (mfx_hist_run_sharded), -completeness adds the per-piece sums of the shards in piece order
@@ -631,6 +760,13 @@ int main(int argc, char **argv) {
       return 1;
     }
     if (G.indexName) { fprintf(stderr, "ERROR: -index caches a whole table; it cannot be combined with -sharded.\n"); return 1; }
+    // -hist / -dump: a part of the sequences per device, each on the sequence-only index of ITS k-mers (no exchange);
+    // everything else -- and a non-canonical database -- takes the hash-sharded full tables (MFX_CLI_FULL_INDEX=1: always)
+    const char *fi = getenv("MFX_CLI_FULL_INDEX");
+    if ((G.reportType == OP_HIST || G.reportType == OP_DUMP) && k <= 31 && !(fi && atoi(fi))) {
+      const int prc = run_parts(G, k, recs, bases, lens);
+      if (prc >= 0) return prc;
+    }
     return run_sharded(G, k, rdb, adb, recs, bases, lens, totalBases);
   }
   mfx_index *ix = nullptr;

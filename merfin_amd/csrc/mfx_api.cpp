@@ -754,9 +754,10 @@ extern "C" int mfx_index_add_asm(mfx_index *ix, const uint64_t *kmers, const uin
 static int index_count(mfx_index *ix, const mfx_seq *seq, int count, void *stream, const char *who) {
   if (!ix || !seq) return mfx_fail(MFX_E_INVAL, "%s: null argument", who);
   if (ix->device != seq->device) return mfx_fail(MFX_E_INVAL, "index and sequence live on different devices");
-  if (ix->seq_only && ix->frozen)
+  if (ix->seq_only && ix->frozen && count != 2)
     return mfx_fail(MFX_E_INVAL, "%s: this sequence-only index already took counts; its k-mers must all be claimed before the first add / load "
                     "(a k-mer claimed now would have missed them)", who);
+  if (count == 2 && (!ix->seq_only || ix->wide())) return mfx_fail(MFX_E_INVAL, "%s: counting claimed k-mers needs a sequence-only index (mfx_index_create_for_seq)", who);
   if (int erc = mfx_seq_ensure_ascii(seq)) return erc;
   DevGuard g(ix->device);
   mfx_count_args a;
@@ -769,8 +770,9 @@ static int index_count(mfx_index *ix, const mfx_seq *seq, int count, void *strea
   a.ntiles = seq->ntiles;
   a.meta = ix->d_meta;
   a.count = count;
-  if (ix->seq_only)                                            // what this table can answer for: the k-mers of THIS sequence
+  if (ix->seq_only && count != 2)                              // what this table can answer for: the k-mers of THIS sequence
     if (int drc = mfx_seq_digest32(seq, &ix->seq_digest)) return drc;
+  if (count == 2) ix->frozen = true;                           // counts arrived: no more claims
   MFX_HIP(ix->wide() ? mfx_kw_count(a, (hipStream_t)stream) : mfx_k_count(a, (hipStream_t)stream));
   // While the kernel claims / counts a large sequence's k-mers (0.11 s for 3 Gb), the host pins the staging lanes the database
   // load that follows will want (0.06 s): the lanes belong to the index and are reused by every load.
@@ -781,6 +783,14 @@ static int index_count(mfx_index *ix, const mfx_seq *seq, int count, void *strea
 
 extern "C" int mfx_index_count_asm(mfx_index *ix, const mfx_seq *seq, void *stream) {
   return index_count(ix, seq, 1, stream, "mfx_index_count_asm");
+}
+
+// The assembly counts of the k-mers claimed BEFORE (mfx_index_claim_seq), taken from another -- usually larger -- sequence:
+// asmV += 1 per occurrence of a claimed k-mer, nothing is claimed.  This is how a device that evaluates PART of an assembly
+// (some contigs) gets value() right for its k-mers: they are claimed from its contigs and counted over the whole assembly
+// (`meryl count` of -sequence counts every contig, merfin-globals.C:182-186), and the read database then updates them.
+extern "C" int mfx_index_count_claimed(mfx_index *ix, const mfx_seq *seq, void *stream) {
+  return index_count(ix, seq, 2, stream, "mfx_index_count_claimed");
 }
 
 extern "C" int mfx_index_claim_seq(mfx_index *ix, const mfx_seq *seq, void *stream) {
@@ -2291,6 +2301,68 @@ extern "C" int mfx_hist_run_multi(mfx_eval *const *evs, const mfx_seq *const *se
   if (timing)
     fprintf(stderr, "[mfx multi] %u slots: enqueue %.3f ms, wait + add %.3f ms (of which adding the images %.3f), result %.3f ms\n", ndev, (t1 - t0) * 1e3,
             (t2 - t1) * 1e3, t_add * 1e3, (now() - t2) * 1e3);
+  return rc;
+}
+
+// PARTS of one assembly, one per slot, each on its own sequence-only index (mfx_index_claim_seq on the slot's contigs,
+// mfx_index_count_claimed over the whole assembly, the read database update-only): every slot evaluates ITS contigs on its
+// device -- no exchange of k-mers at all, whatever the size of the read database -- and the results are put together: bins and
+// counters added, the per-contig counters placed at the contigs' numbers in the whole assembly (contig_ids[d][i] = number of
+// slot d's contig i), koverCpy a fixed-order sum over the slots.  What config 5's -hist (15 Gb, a read database beyond one GPU)
+// runs on the 8-GPU node: each device holds the slots of its contigs' k-mers only.  Slots may share a device.
+extern "C" int mfx_hist_run_parts(mfx_eval *const *evs, const mfx_seq *const *seqs, const uint32_t *const *contig_ids, uint32_t ndev,
+                                  uint32_t ncontigs_total, mfx_hist_result *out) {
+  if (!evs || !seqs || !contig_ids || !out || ndev == 0) return mfx_fail(MFX_E_INVAL, "mfx_hist_run_parts: null argument");
+  std::vector<char> seen(ncontigs_total, 0);
+  for (uint32_t d = 0; d < ndev; ++d) {
+    if (!evs[d] || !seqs[d] || (seqs[d]->ncontigs && !contig_ids[d])) return mfx_fail(MFX_E_INVAL, "mfx_hist_run_parts: null object for slot %u", d);
+    if (evs[d]->device != seqs[d]->device) return mfx_fail(MFX_E_INVAL, "slot %u: evaluator and sequence live on different devices", d);
+    if (evs[d]->nbins != evs[0]->nbins) return mfx_fail(MFX_E_INVAL, "slot %u: the evaluators of one run must have the same bins", d);
+    for (uint32_t e = 0; e < d; ++e)
+      if (evs[e] == evs[d]) return mfx_fail(MFX_E_INVAL, "slots %u and %u share one evaluator (each slot launches concurrently)", e, d);
+    for (uint32_t i = 0; i < seqs[d]->ncontigs; ++i) {
+      const uint32_t c = contig_ids[d][i];
+      if (c >= ncontigs_total || seen[c]) return mfx_fail(MFX_E_INVAL, "slot %u: contig number %u is out of range or belongs to two slots", d, c);
+      seen[c] = 1;
+    }
+  }
+  const uint32_t nbins = evs[0]->nbins;
+  int rc = MFX_OK;
+  std::vector<char> launched(ndev, 0);
+  for (uint32_t d = 0; d < ndev && rc == MFX_OK; ++d) {
+    if (seqs[d]->ntiles == 0) continue;
+    DevGuard g(evs[d]->device);
+    rc = eval_run_enqueue(evs[d], seqs[d], 0, 1);
+    launched[d] = rc == MFX_OK;
+  }
+  const size_t words = MFX_HIST_WORDS(nbins, ncontigs_total);
+  std::vector<uint64_t> sum(words, 0);
+  double kover = 0.0;
+  std::vector<uint64_t> novf(ndev, 0);
+  for (uint32_t d = 0; d < ndev; ++d) {
+    if (!launched[d]) continue;
+    DevGuard g(evs[d]->device);
+    hipError_t e = hipStreamSynchronize(evs[d]->sr.kern[0]);
+    if (e != hipSuccess && rc == MFX_OK) rc = mfx_fail(MFX_E_HIP, "mfx_hist_run_parts: slot %u failed: %s", d, hipGetErrorString(e));
+    if (rc != MFX_OK) continue;
+    const uint32_t nc = seqs[d]->ncontigs;
+    const uint64_t *h = evs[d]->sr.h_img;
+    const size_t w = MFX_HIST_WORDS(nbins, nc);
+    for (size_t i = 0; i < 2ull * nbins + 3; ++i) sum[i] += h[i];
+    novf[d] = h[2ull * nbins + 2];
+    for (uint32_t i = 0; i < nc; ++i) {
+      sum[2ull * nbins + 3 + contig_ids[d][i]] += h[2ull * nbins + 3 + i];
+      sum[2ull * nbins + 3 + ncontigs_total + contig_ids[d][i]] += h[2ull * nbins + 3 + nc + i];
+    }
+    double kv;
+    memcpy(&kv, h + w, sizeof(double));
+    kover = kover + kv;                                       // slot order: a fixed-order fp64 sum
+  }
+  if (rc == MFX_OK) rc = mfx_hist_result_from_counts(nbins, sum.data(), kover, ncontigs_total, out);
+  if (rc == MFX_OK) {
+    for (uint32_t d = 0; d < ndev && rc == MFX_OK; ++d) if (launched[d]) rc = result_take_overflow(evs[d], novf[d], out);
+    if (rc) mfx_hist_result_free(out);
+  }
   return rc;
 }
 

@@ -92,7 +92,7 @@ struct mfx_count_args {
   uint32_t        ncontigs;
   uint64_t        ntiles;
   uint64_t       *meta;
-  int             count = 1;          // 1: asmV += 1 per occurrence (`meryl count`); 0: claim the k-mers only (sequence-only index)
+  int             count = 1;          // 1: asmV += 1 per occurrence (`meryl count`); 0: claim the k-mers only (sequence-only index); 2: asmV += 1 for the k-mers claimed BEFORE, no claims
 };
 
 hipError_t mfx_k_table_init(mfx_slot *slots, uint64_t nslots, hipStream_t st);

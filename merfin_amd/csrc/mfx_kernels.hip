@@ -1674,7 +1674,9 @@ constexpr int MFX_BATCH = MFX_V_BATCH;          // queries per lane and cooperat
 // compact layout is bound by round trips: throughput follows (waves x queries in flight) / latency, and what a wave holds per query
 // decides how many waves fit.  Round 4 (profiles/r04_kernel_waves.txt, 3 Gb, same box, back to back): 4 waves x 4 queries 134.1 G,
 // 5 x 4 142.1, 6 x 2 144.4, 7 x 2 147.6 (72 VGPRs, 22.5 KB of LDS per block: the prob / over-copy tables left LDS for that),
-// 6 x 3 138.5, 6 x 4 107.8, 8 x 2 101.9 (spills), 8 x 1 135.6.  The cooperative probe of the full table keeps 4 x 4.
+// 6 x 3 138.5, 6 x 4 107.8, 8 x 2 101.9 (spills), 8 x 1 135.6.  k = 31 (quotient form; profiles/r04_ab_k31.txt): 4 x 4 115.7 G, 5 x 4 85.8, 5 x 2 117.6,
+// 6 x 2 = 7 x 2 125.7.  The generic compact instance (other k: run-time shifts) is best at 4 x 4 (k = 22 / 25 / 27 at 1 Gb: 91 / 83 / 86 G; 6 x 2: 82 / 79 / 80),
+// and so is the cooperative probe of the full table.
 #ifndef MFX_V_MINBLOCKS_K21
 #define MFX_V_MINBLOCKS_K21 7
 #endif
@@ -1682,10 +1684,10 @@ constexpr int MFX_BATCH = MFX_V_BATCH;          // queries per lane and cooperat
 #define MFX_V_BATCH_K21 2
 #endif
 #ifndef MFX_V_MINBLOCKS_K31
-#define MFX_V_MINBLOCKS_K31 4
+#define MFX_V_MINBLOCKS_K31 6
 #endif
 #ifndef MFX_V_BATCH_K31
-#define MFX_V_BATCH_K31 4
+#define MFX_V_BATCH_K31 2
 #endif
 #ifndef MFX_V_MINBLOCKS_GEN
 #define MFX_V_MINBLOCKS_GEN 4
@@ -2504,7 +2506,32 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_count_kernel(mfx_count_args a) 
       const uint64_t r = mfx_revcomp(f, k);
       const uint64_t key = f < r ? f : r;
       if (ok && a.t.shard_n > 1 && mfx_owner(a.t, key, f < r ? r : f, a.t.shard_n) != a.t.shard_rank) ok = false;
-      if (a.t.compact) {                                      // 8-byte slots (sequence-only index)
+      if (a.count == 2) {
+        // count ONLY what was claimed before (a sequence-only index whose k-mers come from PART of the assembly -- the contigs one
+        // device evaluates -- takes the assembly counts of those k-mers from the WHOLE assembly): find, add, never claim
+        if (a.t.compact) {
+          if (ok) {
+            // the first mini-bucket of the k-mer's order answers for most: the k-mer, or an empty slot before it (never claimed)
+            const mfx_probe pr = mfx_home(a.t, key);
+            unsigned long long *mb = reinterpret_cast<unsigned long long *>(a.t.slots) + mfx_probe_line(a.t, pr, 0) * MFX_CSLOTS_LINE + 2u * pr.b0;
+            const uint4 s4 = *reinterpret_cast<const uint4 *>(mb);
+            const uint64_t x = (uint64_t)s4.x | ((uint64_t)s4.y << 32), y = (uint64_t)s4.z | ((uint64_t)s4.w << 32);
+            unsigned long long *w = nullptr;
+            unsigned long long cur = 0;
+            bool beyond = false;
+            if (x == MFX_EMPTY) { }
+            else if ((x >> 22) == pr.fkey) { w = mb; cur = x; }
+            else if (y == MFX_EMPTY) { }
+            else if ((y >> 22) == pr.fkey) { w = mb + 1; cur = y; }
+            else w = mfx_c_find(a.t, pr, 0, cur, beyond);
+            if (w) mfx_c_add(a.t, w, cur, key, 1u, 1, a.meta);
+            else if (beyond) { mfx_slot *ss = mfx_find_slot(mfx_side_view(a.t), key); if (ss) atomicAdd(&ss->asmV, 1u); }
+          }
+        } else {
+          uint32_t dropped = 0;
+          mfx_group_insert<false>(a.t, key, ok ? 1u : 0u, 1, a.meta, dropped);
+        }
+      } else if (a.t.compact) {                               // 8-byte slots (sequence-only index)
         if (ok) {
           unsigned long long cur = 0;
           bool claimed;

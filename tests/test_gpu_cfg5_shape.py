@@ -100,6 +100,56 @@ def test_cfg5_sharded_equals_whole_at_scale(monkeypatch):
         st_ += t
         su_ += u
     assert np.array_equal(st_, wt) and np.array_equal(su_, wu)
-    print("\nconfig-5 shape: %d bases, k=%d, %d k-mers in %d shards (%.1f-%.1f M each); whole build+hist %.1f s, sharded build %.1f s, "
+    # ---- the same -hist by PARTS (what `merfin -hist -devices 0-7 -sharded` runs since round 4): every slot holds a part of the
+    # contigs and the sequence-only index of THEIR k-mers (claimed from its contigs, counted over the whole assembly, the read
+    # database update-only) -- no routing, no exchange; the hash-sharded tables above stay what -completeness runs on
+    for e in evs:
+        e.close()
+    for r_ in routers:
+        r_.close() if hasattr(r_, "close") else None
+    for s_ in shards:
+        s_.close()
+    del evs, routers, shards, fan
+    gc.collect()
+    torch.cuda.empty_cache()
+    monkeypatch.delenv("MFX_LOAD_FACTOR")
+    from tests.test_gpu_parts import split_contigs
+    t0p = time.time()
+    lens = [int(a.numel()) for a in asm]
+    ids = split_contigs([range(n) for n in lens], WORLD)
+    pix, pseq = [], []
+    for mine in ids:
+        own = m.Sequences.from_device([asm[i].data_ptr() for i in mine], [lens[i] for i in mine])
+        ix = m.Index.for_seq(K, sum(lens[i] for i in mine) + 1024)
+        ix.claim_seq(own)
+        ix.count_claimed(seqs)
+        pix.append(ix)
+        pseq.append(own)
+
+    class _Parts:
+        def add_read(self, k_, v_):
+            for ix in pix:
+                ix.add_read(k_, v_)
+    truth, layout = st.make_truth(st.contig_sizes(BASES, 24), st.SEED, "cuda:0")
+    st.add_reads_from_truth(_Parts(), truth, K, LAM, st.SEED)
+    del truth
+    st.add_error_kmers(_Parts(), int(BASES * 1.0), K, st.SEED)
+    torch.cuda.synchronize()
+    t_pbuild = time.time() - t0p
+    pevs = [m.Evaluator(ix, kp) for ix in pix]
+    pres = m.hist_parts(pevs, pseq, ids, len(lens))
+    tp = []
+    for _ in range(3):
+        t3 = time.time()
+        pres = m.hist_parts(pevs, pseq, ids, len(lens))
+        tp.append(time.time() - t3)
+    assert np.array_equal(pres.undr(), W["undr"]) and np.array_equal(pres.over(), W["over"])
+    assert (pres.kasm, pres.kmissing) == (W["kasm"], W["kmissing"])
+    assert np.array_equal(pres.contig_kasm(), W["ckasm"]) and np.array_equal(pres.contig_kmissing(), W["ckmis"])
+    assert abs(pres.koverCpy - W["kover"]) <= 1e-12 * max(abs(W["kover"]), 1.0)
+    psz = [ix.info() for ix in pix]
+    print("\nconfig-5 shape by PARTS: %d slots on one GPU, tables %.1f GB in all (%d k-mers claimed), build %.1f s; -hist %.3f s = %.1f G k-mers/s, no exchange"
+          % (WORLD, sum(i["bytes"] for i in psz) / 1e9, sum(i["distinct"] for i in psz), t_pbuild, min(tp), pres.kasm / min(tp) / 1e9))
+    print("config-5 shape: %d bases, k=%d, %d k-mers in %d shards (%.1f-%.1f M each); whole build+hist %.1f s, sharded build %.1f s, "
           "sharded -hist %.3f s = %.1f G k-mers/s through the route->owner loop on one GPU (first run, which makes the group buffers: %.3f s)"
           % (BASES, K, W["distinct"], WORLD, min(sizes) / 1e6, max(sizes) / 1e6, t_whole, t1 - t0, t_hist, res.kasm / t_hist / 1e9, t_first))

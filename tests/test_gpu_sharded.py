@@ -238,6 +238,13 @@ def test_cli_sharded_hist_and_completeness(tmp_path, golden_dir):
     r = subprocess.run([exe, "-hist"] + common + ["-output", str(tmp_path / "s.hist"), "-devices", "0,0,0", "-sharded"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert (tmp_path / "s.hist").read_bytes() == open(g("case1.hist"), "rb").read()
+    # -hist asks for the k-mers of -sequence only: every slot holds a PART of the sequences and the sequence-only index of its k-mers
+    assert open(g("case1.summary")).read() in r.stderr and "Part 2 of 3" in r.stderr
+    # ... and the hash-sharded full tables with the routed -hist (what -completeness and the variant modes run on) when asked for
+    r = subprocess.run([exe, "-hist"] + common + ["-output", str(tmp_path / "s2.hist"), "-devices", "0,0,0", "-sharded"], capture_output=True, text=True,
+                       env=dict(os.environ, MFX_CLI_FULL_INDEX="1"))
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "s2.hist").read_bytes() == open(g("case1.hist"), "rb").read()
     assert open(g("case1.summary")).read() in r.stderr and "Shard 2 of 3" in r.stderr
     cargs = ["-completeness", "-readmers", g("case1.read.kmers.txt"), "-seqmers", g("case1.asm.kmers.txt"), "-peak", "17.3"]
     a = subprocess.run([exe] + cargs, capture_output=True, text=True)
@@ -375,6 +382,10 @@ def test_cli_sharded_dump_and_variants(tmp_path, golden_dir):
     counts = lambda t: [l for l in t.splitlines() if l.count("\t") == 3 and not l.startswith("--")]
     assert counts(r2.stderr) == counts(one.stderr) and len(counts(one.stderr)) > 1
     assert counts(r.stderr) == counts(one.stderr)                        # the per-contig missing / cumulative columns of -dump
+    assert "one part of the sequences each" in r.stderr
+    rf = subprocess.run([exe, "-dump"] + common + ["-output", str(tmp_path / "sf.dump")], capture_output=True, text=True, env=dict(os.environ, MFX_CLI_FULL_INDEX="1"))
+    assert rf.returncode == 0 and "sharded index" in rf.stderr, rf.stderr     # the same from the hash-sharded full tables
+    assert (tmp_path / "sf.dump").read_bytes() == open(g("case1.dump"), "rb").read()
     for mode, suffix in (("polish", ".polish.vcf"), ("filter", ".filter.vcf"), ("loose", ".filter.vcf")):
         out = str(tmp_path / ("v_" + mode))
         rv = subprocess.run([exe, "-" + mode] + common + ["-vcf", g("case1.vcf"), "-comb", "8", "-output", out], capture_output=True, text=True)
