@@ -186,3 +186,32 @@ def test_cli_devices_every_report_type_vs_golden(tmp_path):
         assert r.returncode == 0, r.stderr
         tot.append([l for l in r.stderr.splitlines() if l.startswith(("TOTAL", "COMPLETENESS"))])
     assert tot[0] == tot[1] and len(tot[0]) == 3
+
+
+@pytest.mark.parametrize("k,from_db", [(21, False), (31, True)])
+def test_parts_of_an_assembly_over_distinct_devices(k, from_db):
+    """config 5's -hist on the node: every GPU holds the sequence-only index of ITS contigs' k-mers (claimed there, counted over the
+    whole assembly), evaluates alone, mfx_hist_run_parts adds the images -- the twin of tests/test_gpu_parts.py over distinct devices"""
+    import merfin_amd as m
+    from tests.test_gpu_parts import build_parts
+    devs = _devices()
+    peak = 17.3
+    contigs, read, asm = synth.world(k=k, peak=peak, seed=640 + k, sizes=(300000, 90000, 4097, 30, 0, 250000, 120000, 7000))
+    p, g, ka, km = oracle_hist(k, peak, contigs, read, asm)
+    nslots = len(devs) + 1                                         # (one device carries two slots)
+    ixs, seqs, ids = build_parts(m, k, contigs, read, nslots, asm_db=asm if from_db else None, device_of=lambda d: devs[d % len(devs)])
+    evs = [m.Evaluator(ix, m.KParams(peak)) for ix in ixs]
+    assert_hist_equal(m.hist_parts(evs, seqs, ids, len(contigs)), g, ka, km, k)
+
+
+def test_cli_parts_on_distinct_devices(tmp_path):
+    """`merfin -hist|-dump -devices 0-(N-1) -sharded`: a part of the sequences per GPU, the committed golden outputs"""
+    devs = _devices()
+    common = ["-sequence", os.path.join(G, "case1.fasta"), "-readmers", os.path.join(G, "case1.read.kmers.txt"), "-peak", str(PEAK),
+              "-prob", os.path.join(G, "example_lookup_table.txt"), "-devices", ",".join(str(d) for d in devs), "-sharded"]
+    r = subprocess.run([EXE, "-hist"] + common + ["-output", str(tmp_path / "p.hist")], capture_output=True, text=True)
+    assert r.returncode == 0 and "one part of the sequences each" in r.stderr, r.stderr
+    assert (tmp_path / "p.hist").read_bytes() == open(os.path.join(G, "case1.hist"), "rb").read()
+    r = subprocess.run([EXE, "-dump"] + common + ["-output", str(tmp_path / "p.dump")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "p.dump").read_bytes() == open(os.path.join(G, "case1.dump"), "rb").read()
