@@ -3008,6 +3008,70 @@ extern "C" int mfx_dump_values(mfx_eval *ev, const mfx_seq *seq, uint32_t contig
 // other shards answer 0, so each slot runs the lookup kernel over its copy of the sequence against its own shard and
 // the N value arrays are ADDED on slot 0's device (peer copies, 8 B per position and slot).  kmissing is then
 // counted from the summed values (readK == 0 is not additive over shards).
+int mfx_score_paths(mfx_eval *ev, const char *text, uint64_t len, const mfx_path_table *pt, int need_dk, uint32_t *numM, double *totdk) {
+  if (!ev || !pt || (len && !text) || (pt->npaths && (!numM || !pt->cfirst || (need_dk && !totdk)))) return mfx_fail(MFX_E_INVAL, "mfx_score_paths: null argument");
+  if (pt->npaths == 0 || len == 0) return MFX_OK;
+  mfx_seq *seq = mfx_seq_upload(ev->device, &text, &len, 1);
+  if (!seq) return mfx_last_error_code() ? mfx_last_error_code() : MFX_E_HIP;
+  struct Free { mfx_seq *s; ~Free() { mfx_seq_free(s); } } fr{seq};
+  if (int erc = mfx_seq_ensure_ascii(seq)) return erc;
+  DevGuard g(ev->device);
+  int canon = 0;
+  int rc = index_canonical(ev->ix, &canon);
+  if (rc) return rc;
+  if (ev->ix->seq_only) return mfx_fail(MFX_E_INVAL, "mfx_score_paths: a sequence-only index holds the k-mers of one sequence; alternative paths need the full index");
+  DevBuf<uint32_t> dr, da, dlen, dnv, dvidx, dvlen, dnum;
+  DevBuf<int32_t> dgt;
+  DevBuf<uint64_t> ds, doff, dvoff, dcf;
+  DevBuf<double> ddk;
+  const uint64_t np = pt->npaths, nvl = pt->nvals ? pt->nvals : 1;
+  MFX_HIP(dr.alloc(len)); MFX_HIP(da.alloc(len)); MFX_HIP(ds.alloc(2));
+  MFX_HIP(doff.alloc(np)); MFX_HIP(dlen.alloc(np)); MFX_HIP(dnv.alloc(np)); MFX_HIP(dvoff.alloc(np)); MFX_HIP(dcf.alloc(np));
+  MFX_HIP(dgt.alloc(nvl)); MFX_HIP(dvidx.alloc(nvl)); MFX_HIP(dvlen.alloc(nvl));
+  MFX_HIP(dnum.alloc(np)); MFX_HIP(ddk.alloc(need_dk ? np : 1));
+  hipStream_t st = nullptr;
+  MFX_HIP(hipMemsetAsync(ds.p, 0, 2 * sizeof(uint64_t), st));
+  MFX_HIP(hipMemcpyAsync(doff.p, pt->off, np * 8, hipMemcpyHostToDevice, st));
+  MFX_HIP(hipMemcpyAsync(dlen.p, pt->len, np * 4, hipMemcpyHostToDevice, st));
+  MFX_HIP(hipMemcpyAsync(dnv.p, pt->nv, np * 4, hipMemcpyHostToDevice, st));
+  MFX_HIP(hipMemcpyAsync(dvoff.p, pt->voff, np * 8, hipMemcpyHostToDevice, st));
+  MFX_HIP(hipMemcpyAsync(dcf.p, pt->cfirst, np * 8, hipMemcpyHostToDevice, st));
+  if (pt->nvals) {
+    MFX_HIP(hipMemcpyAsync(dgt.p, pt->gt, pt->nvals * 4, hipMemcpyHostToDevice, st));
+    MFX_HIP(hipMemcpyAsync(dvidx.p, pt->vidx, pt->nvals * 4, hipMemcpyHostToDevice, st));
+    MFX_HIP(hipMemcpyAsync(dvlen.p, pt->vlen, pt->nvals * 4, hipMemcpyHostToDevice, st));
+  }
+  mfx_dump_args a;
+  a.t = ev->ix->view();
+  a.canonical = canon;
+  a.src = seq->d_bases + seq->off[0];
+  a.npos = len;
+  a.skip = 0;
+  a.clen_left = len;
+  a.readV = dr.p;
+  a.asmV = da.p;
+  a.peak = ev->peak;
+  a.n_prob = ev->n_prob;
+  a.probK = ev->d_probK;
+  a.probP = ev->d_probP;
+  a.stats = ds.p;
+  MFX_HIP(ev->ix->wide() ? mfx_kw_dump(a, st) : mfx_k_dump(a, st));
+  mfx_var_score_args sa;
+  sa.text = seq->d_bases + seq->off[0];
+  sa.readV = dr.p; sa.asmV = da.p;
+  sa.npaths = np;
+  sa.off = doff.p; sa.len = dlen.p; sa.nv = dnv.p; sa.voff = dvoff.p; sa.cfirst = dcf.p;
+  sa.gt = dgt.p; sa.vidx = dvidx.p; sa.vlen = dvlen.p;
+  sa.k = (uint32_t)ev->ix->k;
+  sa.need_dk = need_dk ? 1 : 0;
+  sa.peak = ev->peak; sa.n_prob = ev->n_prob; sa.probK = ev->d_probK; sa.probP = ev->d_probP;
+  sa.numM = dnum.p; sa.totdk = ddk.p;
+  MFX_HIP(mfx_k_var_score(sa, st));
+  MFX_HIP(hipMemcpy(numM, dnum.p, np * 4, hipMemcpyDeviceToHost));
+  if (need_dk) MFX_HIP(hipMemcpy(totdk, ddk.p, np * 8, hipMemcpyDeviceToHost));
+  return MFX_OK;
+}
+
 extern "C" int mfx_dump_values_sharded(mfx_eval *const *evs, const mfx_seq *const *seqs, uint32_t nslots, uint32_t contig,
                                        uint64_t pos_begin, uint64_t pos_end, uint32_t *readV, uint32_t *asmV,
                                        uint64_t *kasm, uint64_t *kmissing) {

@@ -178,6 +178,22 @@ int mfx_seq_digest32(const mfx_seq *s, uint32_t *out);
 // refuses (MFX_E_INVAL) the evaluation of a sequence other than the one a sequence-only index was claimed from
 int mfx_check_seq_of_index(const mfx_index *ix, const mfx_seq *s, const char *who);
 
+// The paths of a batch of variant clusters inside their packed text, for the device-side varMer::score (mfx_api.cpp:
+// mfx_score_paths; kernel mfx_var_score_kernel): host arrays
+struct mfx_path_table {
+  uint64_t        npaths = 0, nvals = 0;
+  const uint64_t *off = nullptr;      // [npaths] first base of the path in the text
+  const uint32_t *len = nullptr;      // [npaths] its bases
+  const uint32_t *nv = nullptr;       // [npaths] variants of its cluster
+  const uint64_t *voff = nullptr;     // [npaths] first of its nv entries below
+  const uint64_t *cfirst = nullptr;   // [npaths] number of the first path of its cluster (`prob` carries from path to path inside a cluster)
+  const int32_t  *gt = nullptr;       // [nvals] allele of each variant on the path
+  const uint32_t *vidx = nullptr, *vlen = nullptr;   // [nvals] offset / length snapshots of the variants on the path
+};
+// looks every k-mer of `text` up (as mfx_dump_values) and scores every path on the device: numM[p] (missing k-mers, lead-in
+// included) and, need_dk, totdk[p] (sum of the delta-K terms in position order) -- the values varMer::score computes
+int mfx_score_paths(mfx_eval *ev, const char *text, uint64_t len, const mfx_path_table *pt, int need_dk, uint32_t *numM, double *totdk);
+
 int mfx_seq_ensure_ascii(const mfx_seq *s);      // unpacks the planes into d_bases if a packed upload left them newer (mfx_api.cpp)
 
 struct mfx_eval {

@@ -95,6 +95,27 @@ struct mfx_count_args {
   int             count = 1;          // 1: asmV += 1 per occurrence (`meryl count`); 0: claim the k-mers only (sequence-only index); 2: asmV += 1 for the k-mers claimed BEFORE, no claims
 };
 
+// varMer::score of the paths of a batch (mfx_var_score_kernel): everything device memory
+struct mfx_var_score_args {
+  const uint8_t  *text;               // the packed path text (every path followed by '\n')
+  const uint32_t *readV, *asmV;       // per start position of the text (mfx_dump_kernel)
+  uint64_t        npaths;
+  const uint64_t *off;                // [npaths] first base of the path in `text`
+  const uint32_t *len, *nv;           // [npaths] bases; variants of its cluster
+  const uint64_t *voff;               // [npaths] first of its nv entries in gt / vidx / vlen
+  const uint64_t *cfirst;             // [npaths] number of the first path of its cluster
+  const int32_t  *gt;
+  const uint32_t *vidx, *vlen;
+  uint32_t        k;
+  int             need_dk;            // 0: numM only (-filter / -better / -strict / -loose), 1: + totdk (-polish)
+  double          peak;
+  uint32_t        n_prob;
+  const uint32_t *probK;
+  const double   *probP;
+  uint32_t       *numM;               // [npaths] out
+  double         *totdk;              // [npaths] out (need_dk)
+};
+hipError_t mfx_k_var_score(const mfx_var_score_args &a, hipStream_t st);
 hipError_t mfx_k_table_init(mfx_slot *slots, uint64_t nslots, hipStream_t st);
 hipError_t mfx_k_table_add(mfx_table_view t, const uint64_t *kmers, const uint32_t *values, uint64_t n, int side,
                            uint64_t *meta, hipStream_t st);

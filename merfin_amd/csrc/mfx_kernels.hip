@@ -2386,6 +2386,76 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_dump_kernel(mfx_dump_args a) {
   }
 }
 
+// ===========================================================================
+// varMer::score on the device (varMer.C:66-144): one lane per alternative PATH of a batch of variant clusters.  The paths'
+// k-mers have been looked up by mfx_dump_kernel over the packed path text (readV / asmV per start position); this walks a
+// path's bases in order exactly as the reference does -- run length of valid bases, the k-mer ENDING at idx, readK / prob by
+// mfx_getK_core (prob keeps its previous value where no k-mer ends: varMer.C:77-90), missing count, and for -polish the
+// delta-K terms |readK - asmK| * prob before / after the "new k-mer" bump of asmK (varMer.C:99-132, uint32 wrap of
+// idxPath + 1 - k included) summed IN POSITION ORDER in fp64 -- so numM and totdk are the host's values bit for bit, and only
+// 12 bytes per path come back instead of 8 bytes per base.
+// ===========================================================================
+__global__ __launch_bounds__(MFX_BLOCK) void mfx_var_score_kernel(mfx_var_score_args a) {
+  const uint64_t p = (uint64_t)blockIdx.x * MFX_BLOCK + threadIdx.x;
+  if (p >= a.npaths) return;
+  const uint64_t o = a.off[p];
+  const uint32_t slen = a.len[p], nv = a.nv[p], K = a.k;
+  const int32_t *gtp = a.gt + a.voff[p];
+  const uint32_t *vip = a.vidx + a.voff[p], *vlp = a.vlen + a.voff[p];
+  const uint8_t *s = a.text + o;
+  double prob = 1.0, totdk = 0.0;
+  uint32_t numM = 0, run = 0;
+  // `prob` is ONE variable per cluster in the reference (a local of varMer::score, which loops over the cluster's paths): a path
+  // starts with what the last k-mer of the paths before it left there (1.0 before the first).  The lanes of a cluster's paths
+  // run side by side, so each finds that value itself: the last valid k-mer of the nearest earlier path that has one.
+  if (a.need_dk) {
+    for (uint64_t q = p; q-- > a.cfirst[p];) {
+      const uint8_t *sq = a.text + a.off[q];
+      const uint32_t lq = a.len[q];
+      uint32_t rq = 0, last = 0xffffffffu;
+      for (uint32_t idx = 0; idx < lq; ++idx) {
+        const uint32_t u = (uint32_t)(sq[idx] & 0xDFu) - 0x41u;
+        rq = (u < 32u && ((0x00080045u >> u) & 1u)) ? rq + 1u : 0u;
+        if (rq >= K) last = idx;
+      }
+      if (last != 0xffffffffu) {
+        double rk;
+        mfx_getK_core(a.peak, a.n_prob, a.probK, a.probP, a.readV[a.off[q] + last - (K - 1u)], rk, prob);
+        break;
+      }
+    }
+  }
+  for (uint32_t idx = 0; idx < slen; ++idx) {
+    const uint32_t u = (uint32_t)(s[idx] & 0xDFu) - 0x41u;                       // 'A' -> 0, 'C' -> 2, 'G' -> 6, 'T' -> 19, either case
+    run = (u < 32u && ((0x00080045u >> u) & 1u)) ? run + 1u : 0u;
+    double readK = 0.0, asmK = 0.0;
+    if (run >= K) {                                                              // the k-mer ENDING at idx starts at idx - k + 1
+      const uint64_t sp = o + idx - (K - 1u);
+      mfx_getK_core(a.peak, a.n_prob, a.probK, a.probP, a.readV[sp], readK, prob);
+      asmK = (double)a.asmV[sp];
+    }
+    if (readK == 0) numM++;
+    if (!a.need_dk) continue;
+    const double d0 = readK - asmK;
+    const double oD = fabs(d0) * prob;                                           // varMer.C:99
+    for (uint32_t j = 0; j < nv; ++j) {                                          // :103-112
+      const uint32_t vi = vip[j], vl = vlp[j];
+      if (gtp[j] > 0 && vi + 1u - K <= idx && idx < vi + vl + K) { asmK = asmK + 1.0; break; }
+    }
+    const double d1 = readK - asmK;
+    const double nD = fabs(d1) * prob;                                           // :126
+    const double dk = oD - nD;
+    totdk = totdk + dk;
+  }
+  a.numM[p] = numM;
+  if (a.need_dk) a.totdk[p] = totdk;
+}
+hipError_t mfx_k_var_score(const mfx_var_score_args &a, hipStream_t st) {
+  if (a.npaths == 0) return hipSuccess;
+  mfx_var_score_kernel<<<(unsigned)((a.npaths + MFX_BLOCK - 1) / MFX_BLOCK), MFX_BLOCK, 0, st>>>(a);
+  return hipGetLastError();
+}
+
 // packed planes -> ASCII bases (for the kernels that read mfx_seq::d_bases after a packed upload): one thread per 16
 // bases; invalid positions become 'N'
 __global__ __launch_bounds__(MFX_BLOCK) void mfx_unpack_kernel(const uint64_t *codes, const uint32_t *valid, uint8_t *bases, uint64_t nwords) {

@@ -30,6 +30,8 @@
 #include <list>
 #include <map>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <functional>
 #include <future>
 #include <string>
@@ -582,11 +584,15 @@ double med_abs_k(std::vector<double> k) {
 // values(text, len, rv, av): the (readV, asmV) pair of every k-mer start of the packed path text -- one evaluator
 // (mfx_dump_values) or the shards of one index (mfx_dump_values_sharded)
 using PathValues = std::function<int(const char *, uint64_t, uint32_t *, uint32_t *)>;
+// scores(text, len, paths, need_dk, numM, totdk): varMer::score of every path of the batch on the device (mfx_score_paths):
+// what the selectors read comes back -- 12 bytes per path instead of 8 bytes per base --, the host's scoring loop does not run.
+// Empty: the host scores from values() (the sharded index, -debug, tools/variants_host_bench.cpp).
+using PathScores = std::function<int(const char *, uint64_t, const mfx_path_table &, int, uint32_t *, double *)>;
 
 // (not static: tools/variants_host_bench.cpp drives the host side with a synthetic `values`, without a device)
 int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const char *vcf_path, const char *const *names, const char *const *bases,
                          const uint64_t *lens, uint32_t ncontigs, const mfx_variant_opts *opts,
-                         const char *out_path, const char *log_path, uint64_t *n_clusters) {
+                         const char *out_path, const char *log_path, uint64_t *n_clusters, const PathScores &scores = PathScores()) {
   if (!ev || !vcf_path || !opts || !out_path || (ncontigs && (!names || !bases || !lens)))
     return mfx_fail(MFX_E_INVAL, "mfx_variants_run: null argument");
   const int mode = opts->mode;
@@ -600,7 +606,7 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
 
   // MFX_VAR_TIMING=1: per-phase wall time on stderr (diagnostics only)
   const bool timing = getenv("MFX_VAR_TIMING") && atoi(getenv("MFX_VAR_TIMING"));
-  double t_phase[6] = {0, 0, 0, 0, 0, 0};                                // load+cluster, enumerate, pack, gpu, score+select, write
+  double t_phase[7] = {0, 0, 0, 0, 0, 0, 0};                             // load+cluster, enumerate, pack, gpu, score+select, write, queue
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t_mark = now();
   auto lap = [&](int i) { double t = now(); t_phase[i] += t - t_mark; t_mark = t; };
@@ -641,6 +647,12 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
     std::vector<Job> jobs;
     std::string packed;
     std::vector<uint32_t> rv, av;
+    // device-side scoring (`scores`): the batch's paths, one entry per path, and what came back
+    std::vector<uint64_t> p_off, p_voff, p_cfirst;
+    std::vector<uint32_t> p_len, p_nv, p_vidx, p_vlen, numM;
+    std::vector<int32_t> p_gt;
+    std::vector<double> totdk;
+    std::vector<uint64_t> job_p0;     // first path of every job in the arrays above
     std::shared_future<int> gpu;      // stage B of this batch (shared: the next batch's stage B waits for it too)
     std::string err;                  // the error text of stage B (errors are per thread: it is carried back to the caller's)
     bool live = false;
@@ -650,12 +662,40 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
   batches[1].jobs.reserve(65536);
   std::vector<char> out_buf(4u << 20);
   setvbuf(out, out_buf.data(), _IOFBF, out_buf.size());
+  // The records of a batch (a few hundred MB for a human call set) are written by their own thread, batch by batch in order,
+  // under the stages of the next batches: config 4 spent 0.6 s of its 2.5 s inside fwrite on the thread that drives the stages.
+  struct Writer {
+    FILE *f;
+    std::mutex m;
+    std::condition_variable cv;
+    std::list<std::vector<std::string>> q;
+    bool done = false, failed = false;
+    std::thread th;
+    explicit Writer(FILE *file) : f(file) {
+      th = std::thread([this]() {
+        for (;;) {
+          std::vector<std::string> b;
+          {
+            std::unique_lock<std::mutex> lk(m);
+            cv.wait(lk, [&] { return done || !q.empty(); });
+            if (q.empty()) return;
+            b = std::move(q.front());
+            q.pop_front();
+          }
+          for (const std::string &x : b) if (!x.empty() && fwrite(x.data(), 1, x.size(), f) != x.size()) failed = true;
+        }
+      });
+    }
+    void push(std::vector<std::string> &&b) { { std::lock_guard<std::mutex> lk(m); q.push_back(std::move(b)); } cv.notify_one(); }
+    bool finish() { { std::lock_guard<std::mutex> lk(m); done = true; } cv.notify_one(); if (th.joinable()) th.join(); return !failed; }
+    ~Writer() { finish(); }
+  } writer(out);
 
   // stage A + the launch of stage B
   auto stage_ab = [&](Batch &bt) -> int {
     std::vector<Job> &jobs = bt.jobs;
     std::string &packed = bt.packed;
-    lap(5);
+    lap(6);                                                              // (the clusters were queued since the last lap)
     parallel_for(jobs.size(), [&](size_t i) {
       Job &jb = jobs[i];
       std::vector<uint32_t> offs, vl;
@@ -683,7 +723,50 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
     lap(2);
     bt.live = true;
     bt.gpu = std::shared_future<int>();                                  // (a shared future stays valid after get(): this batch has none yet)
-    if (total) {
+    const bool on_device = (bool)scores && dbg == nullptr;               // -debug wants the per-position values: scored on the host
+    if (total && on_device) {
+      // the path table of the batch: one entry per path, the variants' rows concatenated
+      bt.job_p0.resize(jobs.size() + 1);
+      std::vector<uint64_t> v0(jobs.size() + 1);
+      uint64_t np = 0, nvals = 0;
+      for (size_t i = 0; i < jobs.size(); ++i) { bt.job_p0[i] = np; v0[i] = nvals; np += jobs[i].ps.size(); nvals += jobs[i].ps.size() * jobs[i].ps.nv; }
+      bt.job_p0[jobs.size()] = np;
+      bt.p_off.resize(np); bt.p_voff.resize(np); bt.p_cfirst.resize(np); bt.p_len.resize(np); bt.p_nv.resize(np);
+      bt.p_gt.resize(nvals); bt.p_vidx.resize(nvals); bt.p_vlen.resize(nvals);
+      bt.numM.resize(np); bt.totdk.resize(np);
+      parallel_for(jobs.size(), [&](size_t i) {
+        const Job &jb = jobs[i];
+        const size_t n = jb.ps.size(), nv = jb.ps.nv;
+        for (size_t p = 0; p < n; ++p) {
+          const uint64_t q = bt.job_p0[i] + p;
+          bt.p_off[q] = jb.off + jb.ps.toff[p];
+          bt.p_len[q] = (uint32_t)jb.ps.len(p);
+          bt.p_nv[q] = (uint32_t)nv;
+          bt.p_voff[q] = v0[i] + p * nv;
+          bt.p_cfirst[q] = bt.job_p0[i];
+        }
+        if (n * nv) {
+          memcpy(&bt.p_gt[v0[i]], jb.ps.gt.data(), n * nv * sizeof(int32_t));
+          memcpy(&bt.p_vidx[v0[i]], jb.ps.vidx.data(), n * nv * sizeof(uint32_t));
+          memcpy(&bt.p_vlen[v0[i]], jb.ps.vlen.data(), n * nv * sizeof(uint32_t));
+        }
+      });
+      lap(2);
+      Batch *bp = &bt;
+      const int need_dk = mode == MFX_VAR_POLISH ? 1 : 0;
+      std::shared_future<int> prev = batches[&bt == &batches[0] ? 1 : 0].gpu;
+      bt.gpu = std::async(std::launch::async, [bp, prev, need_dk, nvals, &scores]() {
+        if (prev.valid()) prev.wait();                                   // one stage B at a time on the evaluator
+        mfx_path_table pt;
+        pt.npaths = bp->p_off.size(); pt.nvals = nvals;
+        pt.off = bp->p_off.data(); pt.len = bp->p_len.data(); pt.nv = bp->p_nv.data(); pt.voff = bp->p_voff.data(); pt.cfirst = bp->p_cfirst.data();
+        pt.gt = bp->p_gt.data(); pt.vidx = bp->p_vidx.data(); pt.vlen = bp->p_vlen.data();
+        const int r = scores(bp->packed.data(), bp->packed.size(), pt, need_dk, bp->numM.data(), bp->totdk.data());
+        if (r) bp->err = mfx_last_error();
+        return r;
+      });
+    } else if (total) {
+      bt.job_p0.clear();
       bt.rv.resize(packed.size() + 1);
       bt.av.resize(packed.size() + 1);
       Batch *bp = &bt;
@@ -697,7 +780,7 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
         if (r) bp->err = mfx_last_error();
         return r;
       });
-    }
+    } else bt.job_p0.clear();
     return MFX_OK;
   };
 
@@ -734,7 +817,12 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
       const bool need_dk = mode == MFX_VAR_POLISH || want_dbg, keep = want_dbg && mode != MFX_VAR_FILTER;
       sc.numM.resize(np); sc.totdk.assign(np, 0.0);
       if (want_dbg) { sc.ks.resize(np); sc.dks.resize(np); }
-      for (size_t p = 0; p < np; ++p) {                                  // varMer::score, varMer.C:66-144
+      const bool scored = !bt.job_p0.empty();                            // varMer::score ran on the device (mfx_score_paths)
+      if (scored) {
+        const uint64_t q0 = bt.job_p0[ji];
+        for (size_t p = 0; p < np; ++p) { sc.numM[p] = bt.numM[q0 + p]; if (need_dk) sc.totdk[p] = bt.totdk[q0 + p]; }
+      }
+      for (size_t p = 0; p < np && !scored; ++p) {                       // varMer::score, varMer.C:66-144
         const char *s = jb.ps.seq(p);
         const uint32_t slen = (uint32_t)jb.ps.len(p);
         const uint64_t o = jb.off + jb.ps.toff[p];
@@ -803,8 +891,8 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
     for (size_t ri = 0; ri < nruns; ++ri) {
       if (!run_log[ri].empty()) fwrite(run_log[ri].data(), 1, run_log[ri].size(), log);
       if (dbg && !run_dbg[ri].empty()) fwrite(run_dbg[ri].data(), 1, run_dbg[ri].size(), dbg);
-      fwrite(run_out[ri].data(), 1, run_out[ri].size(), out);
     }
+    writer.push(std::move(run_out));                                     // the records, in order, by the writer thread
     clusters += jobs.size();
     jobs.clear();
     packed.clear();
@@ -867,9 +955,10 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
   }
   lap(5);
   if (timing)
-    fprintf(stderr, "[mfx_variants] load+cluster %.2fs  enumerate %.2fs  pack %.2fs  gpu %.2fs  score+select %.2fs  queue+write %.2fs\n",
-            t_phase[0], t_phase[1], t_phase[2], t_phase[3], t_phase[4], t_phase[5]);
-  fclose(out);
+    fprintf(stderr, "[mfx_variants] load+cluster %.2fs  enumerate %.2fs  pack %.2fs  gpu %.2fs  score+select %.2fs  queue %.2fs  write %.2fs\n",
+            t_phase[0], t_phase[1], t_phase[2], t_phase[3], t_phase[4], t_phase[6], t_phase[5]);
+  if (!writer.finish() && rc == MFX_OK) rc = mfx_fail(MFX_E_IO, "writing '%s' failed", out_path);
+  if (fclose(out) != 0 && rc == MFX_OK) rc = mfx_fail(MFX_E_IO, "writing '%s' failed", out_path);
   if (dbg && mfx_close(dbgh) && rc == MFX_OK) rc = mfx_fail(MFX_E_IO, "writing '%s' failed", opts->debug_path);
   if (log != stderr) fclose(log);
   if (n_clusters) *n_clusters = clusters;
@@ -887,7 +976,15 @@ extern "C" int mfx_variants_run(mfx_eval *ev, const char *vcf_path, const char *
     mfx_seq_free(ps);
     return r;
   };
-  return mfx_variants_run_values(ev, values, vcf_path, names, bases, lens, ncontigs, opts, out_path, log_path, n_clusters);
+  // varMer::score of every path on the device (MFX_VAR_HOST_SCORE=1: on the host threads from the per-base values, as -debug
+  // and the sharded index do)
+  PathScores scores;
+  const char *hs = getenv("MFX_VAR_HOST_SCORE");
+  if (!(hs && atoi(hs)))
+    scores = [ev](const char *text, uint64_t len, const mfx_path_table &pt, int need_dk, uint32_t *numM, double *totdk) -> int {
+      return mfx_score_paths(ev, text, len, &pt, need_dk, numM, totdk);
+    };
+  return mfx_variants_run_values(ev, values, vcf_path, names, bases, lens, ncontigs, opts, out_path, log_path, n_clusters, scores);
 }
 
 // The variant modes over an index sharded across N evaluators (read databases beyond one GPU): the packed path text of
