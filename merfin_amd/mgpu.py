@@ -84,6 +84,9 @@ def main(argv=None):
     ap.add_argument("-min", type=int, default=0)
     ap.add_argument("-max", type=int, default=2**64 - 1)
     ap.add_argument("-sharded", action="store_true")
+    ap.add_argument("-parts", action="store_true",
+                    help="-hist / -dump: every rank indexes and evaluates its own run of contigs on a sequence-only index; "
+                         "no k-mer is exchanged, each rank keeps the 1/N of the read database its contigs hit")
     ap.add_argument("-broadcast-index", dest="broadcast_index", action="store_true",
                     help="replicated index: rank 0 reads the k-mer databases and builds, the table is broadcast to the other GPUs")
     ap.add_argument("-completeness", action="store_true")
@@ -107,6 +110,8 @@ def main(argv=None):
         ap.error("No variant call input (-vcf) supplied.")
     if (vmode or a.dump) and a.sharded:
         ap.error("-sharded applies to -hist and -completeness")
+    if a.parts and (vmode or a.completeness or a.sharded or a.broadcast_index or not a.sequence):
+        ap.error("-parts applies to -hist and -dump over -sequence")
 
     import torch
     import torch.distributed as dist
@@ -143,7 +148,29 @@ def main(argv=None):
     sq = m.Sequences(seqs, device=local, names=names)
     bcast = a.broadcast_index and world > 1 and not a.sharded
     ix = None
-    if not bcast or rank == 0:
+    own_lo = own_hi = 0
+    sq_own = None
+    if a.parts:
+        # the one-process-per-GPU form of the CLI's run_parts (cli/merfin.cpp): a contiguous run of contigs per rank, a
+        # sequence-only index of exactly their k-mers (claim), the assembly count of those k-mers over EVERY contig
+        # (merfin-globals.C:182-186 counts the whole assembly), the read database update-only.  Nothing is exchanged but
+        # the counts image at the end.
+        if k > 31:
+            ap.error("-parts needs k <= 31 (the sequence-only index)")
+        own_lo, own_hi = D.contig_partition([len(s) for s in seqs], world)[rank]
+        nb = sum(len(s) for s in seqs[own_lo:own_hi])
+        print("-- Part %d of %d: contigs [%d,%d), %d bases." % (rank, world, own_lo, own_hi, nb), file=sys.stderr, flush=True)
+        ix = m.Index.for_seq(k, nb + 1024, device=local)
+        if own_hi > own_lo:
+            sq_own = m.Sequences(seqs[own_lo:own_hi], device=local, names=names[own_lo:own_hi])
+            ix.claim_seq(sq_own)
+            if a.seqmers:
+                ix.load_db(a.seqmers, 1)
+            else:
+                ix.count_claimed(sq)
+            log("-- Loading kmers from '%s' into lookup table." % a.readmers)
+            ix.load_db(a.readmers, 0, a.min, a.max)
+    elif not bcast or rank == 0:
         ix = m.Index(k, cap, device=local)
         if a.sharded and world > 1:
             ix.set_shard(rank, world)
@@ -193,13 +220,15 @@ def main(argv=None):
             weights = [len(s) for s in seqs]
             out = a.output
         lo, hi = D.contig_partition(weights, world)[rank]
+        assert not a.parts or (lo, hi) == (own_lo, own_hi)
         part = "%s.part%04d" % (out, rank) if world > 1 else out
         log("-- %s on %d GPU(s): rank 0 takes contigs [%d,%d) of %d." % ("-dump" if a.dump else "-" + vmode[0], world, lo, hi, len(names)))
         if a.dump:
             open(part, "wb").close()
             tot_a = tot_m = 0
             for c in range(lo, hi):
-                ka, km = ev.dump_contig(sq, c, names[c], part, append=True)
+                ka, km = (ev.dump_contig(sq_own, c - lo, names[c], part, append=True) if a.parts else
+                          ev.dump_contig(sq, c, names[c], part, append=True))
                 tot_a += ka
                 tot_m += km
             cnt = torch.tensor([tot_a, tot_m], dtype=torch.int64)
@@ -247,7 +276,20 @@ def main(argv=None):
             kover.copy_(kv)
 
     log("-- Generate histogram of the k* metric to '%s' on %d GPU(s)%s." % (a.output, world, " (sharded index)" if a.sharded else ""))
-    if a.sharded and world > 1:
+    if a.parts:
+        n_own = own_hi - own_lo
+        if n_own:
+            mine = torch.zeros(m.hist_words(ev.nbins, n_own), dtype=torch.int64, device="cuda")
+            ev.hist_launch(sq_own, 0, sq_own.ntiles, mine, kover, stream=stream)
+            torch.cuda.synchronize()
+            # this rank's image into the image of the whole assembly: the bins and totals as they are, the per-contig
+            # words at the contigs' numbers in the input
+            fixed = 2 * ev.nbins + 3
+            counts[:fixed] = mine[:fixed]
+            counts[fixed + own_lo:fixed + own_hi] = mine[fixed:fixed + n_own]
+            counts[fixed + sq.ncontigs + own_lo:fixed + sq.ncontigs + own_hi] = mine[fixed + n_own:fixed + 2 * n_own]
+        reduce_all()
+    elif a.sharded and world > 1:
         router = m.Router(ix, world, min(a.chunk_tiles, max(1, sq.ntiles)))
         if backend == "nccl":
             D.sharded_hist(ev, router, sq, rank, world, counts, kover, stream=stream, comm=comm)

@@ -76,6 +76,34 @@ def test_launcher_dump_parts_concatenate_to_golden(tmp_path, nproc):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nproc,with_seqmers", [(2, True), (2, False), (3, False), (5, True)])
+def test_launcher_parts_hist_matches_golden(tmp_path, nproc, with_seqmers):
+    """-parts: every rank indexes (sequence-only) and evaluates its own run of contigs, the assembly counts come from the
+    whole assembly (merfin-globals.C:182-186), the images meet in one all-reduce; 5 ranks over 4 contigs leaves one empty"""
+    out = str(tmp_path / "out.hist")
+    args = ["-parts", "-sequence", G + "/case1.fasta", "-readmers", G + "/case1.read.kmers.txt", "-peak", "17.3",
+            "-prob", G + "/example_lookup_table.txt", "-output", out]
+    if with_seqmers:
+        args += ["-seqmers", G + "/case1.asm.kmers.txt"]
+    r = _launch(nproc, args, 29 * nproc + with_seqmers)
+    assert open(out, "rb").read() == open(G + "/case1.hist", "rb").read()
+    assert open(G + "/case1.summary").read() in r.stderr
+    assert "-- Part 1 of %d" % nproc in r.stderr
+    want = subprocess.run([os.path.join(ROOT, "merfin_amd", "bin", "merfin"), "-hist"] + args[1:], capture_output=True, text=True, timeout=600)
+    assert want.returncode == 0, want.stderr[-2000:]
+    per = lambda txt: [l for l in txt.splitlines() if l.startswith("ctg")]
+    assert per(want.stderr) and per(r.stderr) == per(want.stderr)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc", [2, 3])
+def test_launcher_parts_dump_matches_golden(tmp_path, nproc):
+    out = str(tmp_path / "out.dump")
+    _launch(nproc, ["-dump", "-parts"] + COMMON + ["-output", out], 31 * nproc)
+    assert open(out, "rb").read() == open(G + "/case1.dump", "rb").read()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode,nproc", [("polish", 2), ("filter", 2), ("loose", 2), ("polish", 3)])
 def test_launcher_variant_modes_match_golden(tmp_path, mode, nproc):
     """-polish/-filter/-loose over contigs split across ranks: one header, records in contig order, byte-identical"""

@@ -69,13 +69,24 @@ int main(int argc, char **argv) {
     }
     return 0;
   };
+  // argv[3] = 1: the device-scoring form of the pipeline (what the product runs), with a stand-in for mfx_score_paths
+  const bool dev = argc > 3 && atoi(argv[3]);
+  PathScores scores = [](const char *text, uint64_t, const mfx_path_table &pt, int need_dk, uint32_t *numM, double *totdk) -> int {
+    for (uint64_t p = 0; p < pt.npaths; ++p) {
+      uint64_t h = (pt.off[p] * 0x9E3779B97F4A7C15ull) ^ (uint64_t)(unsigned char)text[pt.off[p]] * 0xD6E8FEB86659FD93ull;
+      h ^= h >> 29;
+      numM[p] = (uint32_t)(h % 3);
+      totdk[p] = need_dk ? (double)(int)(h % 17) - 8.0 : 0.0;
+    }
+    return 0;
+  };
   std::vector<const char *> nm(nc), bs(nc);
   std::vector<uint64_t> ln(nc);
   for (uint32_t c = 0; c < nc; ++c) { nm[c] = names[c].c_str(); bs[c] = contigs[c].data(); ln[c] = contigs[c].size(); }
-  mfx_variant_opts vo{mode, 15, 0, nullptr};
+  mfx_variant_opts vo{mode, argc > 5 ? (uint32_t)atoi(argv[5]) : 15u, 0, argc > 4 && argv[4][0] ? argv[4] : nullptr};   // argv[4] = -debug file, argv[5] = -comb
   uint64_t ncl = 0;
   auto t0 = std::chrono::steady_clock::now();
-  int rc = mfx_variants_run_values(&ev, values, vp, nm.data(), bs.data(), ln.data(), nc, &vo, "/tmp/mfx_vhb.out.vcf", "/tmp/mfx_vhb.log", &ncl, PathScores());
+  int rc = mfx_variants_run_values(&ev, values, vp, nm.data(), bs.data(), ln.data(), nc, &vo, "/tmp/mfx_vhb.out.vcf", "/tmp/mfx_vhb.log", &ncl, dev ? scores : PathScores());
   double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   printf("rc %d: %lu bases, %lu calls, %lu clusters in %.2f s = %.0f clusters/s\n", rc, (unsigned long)total, (unsigned long)calls, (unsigned long)ncl, dt, ncl / dt);
   return rc;
