@@ -100,14 +100,12 @@ struct Record {                       // vcfRecord
   uint32_t pos = 0, n_alts = 0;      // n_alts = words of ALT (_arr_alts)
   double qual = 0;
   bool ok = false;                   // false: fewer than 10 columns, "excluded" (vcfRecord.H:53-56)
-  std::string line() const {         // vcfRecord::save, vcfRecord.H:96-97
+  std::string line() const { std::string o; line_to(o); return o; }
+  void line_to(std::string &o) const {    // vcfRecord::save, vcfRecord.H:96-97
     char q[64];
     snprintf(q, sizeof(q), "%.1f", qual);
-    std::string o;
-    o.reserve(chr.n + id.n + ref.n + alts.n + filter.n + info.n + formats.n + samples.n + 40);
     o += chr; o += '\t'; o += std::to_string((int)pos); o += '\t'; o += id; o += '\t'; o += ref; o += '\t'; o += alts; o += '\t';
     o += q; o += '\t'; o += filter; o += '\t'; o += info; o += '\t'; o += formats; o += '\t'; o += samples; o += '\n';
-    return o;
   }
 };
 
@@ -131,9 +129,28 @@ struct Variant {                      // gtAllele
   }
 };
 
+// the variants of a cluster: one to three is the rule (no heap block then)
+struct VarList {
+  const Variant *few[3] = {nullptr, nullptr, nullptr};
+  std::vector<const Variant *> many;                     // all of them, once there are more than three
+  uint32_t n = 0;
+  size_t size() const { return n; }
+  const Variant *const *begin() const { return n <= 3 ? few : many.data(); }
+  const Variant *const *end() const { return begin() + n; }
+  const Variant *operator[](size_t i) const { return begin()[i]; }
+  void push_back(const Variant *v) {
+    if (n < 3) few[n] = v;
+    else {
+      if (n == 3) many.assign(few, few + 3);
+      many.push_back(v);
+    }
+    ++n;
+  }
+};
+
 struct Cluster {                      // posGT
   uint32_t rStart, rEnd;
-  std::vector<const Variant *> vars;
+  VarList vars;
 };
 
 struct VcfDB {
@@ -143,12 +160,10 @@ struct VcfDB {
   std::vector<Variant> var_store;
   size_t n_records = 0;               // records loaded (not excluded)
   std::map<std::string, std::vector<Cluster *>> by_chr;
+  std::map<std::string, std::vector<Cluster>> cluster_store;   // per CHROM: one Cluster per record (the merged-away ones stay unused); by_chr points into it
   std::map<std::string, std::vector<std::pair<size_t, size_t>>> runs;   // per CHROM: its runs [begin, end) of rec_store, file order
   uint64_t excluded = 0;
   int contig_ids = 0;
-  ~VcfDB() {
-    for (auto &kv : by_chr) for (auto c : kv.second) delete c;
-  }
 };
 
 // gtAllele::gtAllele, vcf.C:23-87
@@ -190,9 +205,20 @@ void parse_record(const char *L, size_t n, Record *r) {
   SV line;
   line.p = L; line.n = (uint32_t)n;
   SV w[10];
-  for (int i = 0; i < 10; ++i) {
-    w[i] = word_at(line, "\t", (size_t)i);               // (ten short scans of one line: still far cheaper than ten strings)
-    if (!w[i].p) return;
+  {
+    // the first ten words of the line split at tabs, splitToWords semantics (runs of tabs collapse), in one pass
+    size_t at = 0;
+    int nw = 0;
+    while (nw < 10) {
+      while (at < n && L[at] == '\t') ++at;
+      if (at >= n) break;
+      const char *e = (const char *)memchr(L + at, '\t', n - at);
+      const size_t end = e ? (size_t)(e - L) : n;
+      w[nw].p = L + at; w[nw].n = (uint32_t)(end - at);
+      ++nw;
+      at = end;
+    }
+    if (nw < 10) return;
   }
   r->ok = true;
   r->chr = w[0];
@@ -218,7 +244,10 @@ template <class F> void parallel_for(size_t n, F &&fn);
 // vcfFile::loadFile, vcf.C:93-149.  The file is read whole, its data lines are parsed by the host threads (a
 // config-4-sized VCF has millions of records, and the per-record string work is most of the load time), and the
 // records enter the database in FILE ORDER, exactly as a sequential read would put them.
-int load_vcf(const char *path, VcfDB &db) {
+int load_vcf(const char *path, VcfDB &db, double *t_sub = nullptr) {   // t_sub[4]: read, line scan, parse, runs (seconds; diagnostics)
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t0 = now();
+  auto sub = [&](int i) { const double t = now(); if (t_sub) t_sub[i] += t - t0; t0 = t; };
   mfx_file fh = mfx_open_reader(path);
   FILE *f = fh.f;
   if (!f) return mfx_fail(MFX_E_IO, "cannot open VCF '%s'", path);
@@ -231,7 +260,9 @@ int load_vcf(const char *path, VcfDB &db) {
     while ((n = fread(blk.data(), 1, blk.size(), f)) > 0) buf.append(blk.data(), n);
   }
   if (mfx_close(fh)) return mfx_fail(MFX_E_IO, "reading VCF '%s' failed (stream error or the decompressor exited with an error)", path);
+  sub(0);
   std::vector<std::pair<size_t, size_t>> lines;           // (offset, length) of every data line
+  lines.reserve(buf.size() / 48 + 16);
   for (size_t o = 0; o < buf.size();) {
     const char *nl = (const char *)memchr(buf.data() + o, '\n', buf.size() - o);
     size_t e = nl ? (size_t)(nl - buf.data()) : buf.size(), n = e - o;
@@ -244,8 +275,13 @@ int load_vcf(const char *path, VcfDB &db) {
     }
     o = e + 1;
   }
-  db.rec_store.resize(lines.size());
-  db.var_store.resize(lines.size());
+  sub(1);
+  {
+    // (a config-4 call set: 1.1 GB of records and variants; the two arrays are made side by side)
+    std::thread other([&]() { db.var_store.resize(lines.size()); });
+    db.rec_store.resize(lines.size());
+    other.join();
+  }
   const size_t CH = 4096;                                  // lines per task
   parallel_for((lines.size() + CH - 1) / CH, [&](size_t c) {
     for (size_t i = c * CH, e = std::min(lines.size(), (c + 1) * CH); i < e; ++i) {
@@ -253,6 +289,7 @@ int load_vcf(const char *path, VcfDB &db) {
       if (db.rec_store[i].ok) make_variant(&db.rec_store[i], &db.var_store[i]);
     }
   });
+  sub(2);
   // records of one CHROM come in runs: the runs are noted here (one map lookup per run), the clusters themselves are
   // made per CHROM by the host threads (merge_clusters)
   std::vector<std::pair<size_t, size_t>> *bucket = nullptr;
@@ -272,6 +309,7 @@ int load_vcf(const char *path, VcfDB &db) {
     }
     bucket->back().second = i + 1;
   }
+  sub(3);
   return MFX_OK;
 }
 
@@ -283,15 +321,23 @@ void merge_clusters(VcfDB &db, uint32_t k, uint32_t comb, bool nosplit, FILE *lo
   // one CHROM per task: its clusters are created (one per record, file order), sorted and merged independently of the
   // others; the log lines are printed afterwards in map order, as the sequential loop printed them
   std::vector<std::pair<const std::string *, std::vector<Cluster *> *>> chrs;
-  for (auto &kv : db.by_chr) chrs.emplace_back(&kv.first, &kv.second);
+  std::vector<std::vector<Cluster> *> stores;
+  for (auto &kv : db.by_chr) { chrs.emplace_back(&kv.first, &kv.second); stores.push_back(&db.cluster_store[kv.first]); }
   std::vector<std::string> logs(chrs.size());
   parallel_for(chrs.size(), [&](size_t ci) {
     std::vector<Cluster *> &in = *chrs[ci].second;
-    for (const auto &run : db.runs[*chrs[ci].first])
+    std::vector<Cluster> &store = *stores[ci];
+    const auto &runs = db.runs[*chrs[ci].first];
+    size_t nrec = 0;
+    for (const auto &run : runs) nrec += run.second - run.first;
+    store.reserve(nrec);                                   // (never grows below: the pointers into it stay valid)
+    in.reserve(nrec);
+    for (const auto &run : runs)
       for (size_t i = run.first; i < run.second; ++i) {
         if (!db.rec_store[i].ok) continue;
         const Variant *v = &db.var_store[i];
-        Cluster *c = new Cluster;
+        store.emplace_back();
+        Cluster *c = &store.back();
         c->rStart = v->pos;
         c->rEnd = v->pos + v->refLen;
         c->vars.push_back(v);
@@ -313,7 +359,6 @@ void merge_clusters(VcfDB &db, uint32_t k, uint32_t comb, bool nosplit, FILE *lo
       last->rStart = std::min(last->rStart, v->pos);
       last->rEnd = std::max(last->rEnd, v->pos + v->refLen);
       merged++;
-      delete cur;
     }
     const std::string &nm = *chrs[ci].first;
     logs[ci] = nm + " : Reduced " + std::to_string(in.size()) + " variants down to " + std::to_string(out.size()) + " combinations for evaluation:\n";
@@ -330,40 +375,57 @@ void merge_clusters(VcfDB &db, uint32_t k, uint32_t comb, bool nosplit, FILE *lo
 // page faults of a heap that only grows).  Path p is text[toff[p], toff[p+1] - 1), followed by ONE separator byte ('\n',
 // not ACGT: the whole arena is copied into the packed GPU buffer as it is); its genotype / offset / length snapshots
 // are rows p of gt / vidx / vlen (nv = variants of the cluster columns each).
-struct PathSet {
+struct PathArena {                           // the paths of a RUN of consecutive clusters: one worker fills it (stage A), one reads it (stage C)
   std::string text;
-  std::vector<uint32_t> toff;                // [np + 1]
-  std::vector<int> gt;                       // gtPaths   [np * nv]
-  std::vector<uint32_t> vidx, vlen;          // idxPaths / lenPaths (shifted offsets / post-substitution lengths snapshots) [np * nv]
-  uint32_t nv = 0;
-  std::unordered_map<uint64_t, std::vector<uint32_t>> seen;     // only once a cluster has many paths: hash -> path indices
-  size_t size() const { return toff.empty() ? 0 : toff.size() - 1; }
-  size_t len(size_t p) const { return toff[p + 1] - toff[p] - 1; }
-  const char *seq(size_t p) const { return text.data() + toff[p]; }
-  static uint64_t hash(const std::string &s) {
+  std::vector<uint64_t> toff;                // [paths + 1]: path q is text[toff[q], toff[q + 1] - 1)
+  std::vector<int> gt;                       // gtPaths rows, cluster after cluster (a cluster's rows have its nv columns)
+  std::vector<uint32_t> vidx, vlen;          // idxPaths / lenPaths rows (shifted offsets / post-substitution lengths snapshots)
+  uint64_t off = 0;                          // where the run's text lies in the batch's packed buffer
+  uint64_t p0 = 0, v0 = 0;                   // the run's first path / first row entry in the batch's path table
+  uint64_t first_id = 0;                     // varMerId of the run's first path (-debug numbering)
+  void reset() { text.clear(); toff.clear(); toff.push_back(0); gt.clear(); vidx.clear(); vlen.clear(); }
+};
+
+// One cluster's paths: a window of its run's arena.  (Round 3 kept a string + four vectors per cluster: their ~12 heap blocks
+// per cluster -- allocated by one thread, freed by another -- were most of the host time of a config-4 call set.)
+struct PathSet {
+  PathArena *ar = nullptr;
+  uint64_t p0 = 0, v0 = 0;                   // first path / first row entry inside the arena
+  uint32_t np = 0, nv = 0;
+  size_t size() const { return np; }
+  size_t len(size_t p) const { return (size_t)(ar->toff[p0 + p + 1] - ar->toff[p0 + p] - 1); }
+  const char *seq(size_t p) const { return ar->text.data() + ar->toff[p0 + p]; }
+  uint64_t packed_off(size_t p) const { return ar->off + ar->toff[p0 + p]; }       // of path p in the batch's packed buffer
+  uint64_t table_p0() const { return ar->p0 + p0; }                                  // of path 0 in the batch's path table
+  uint64_t first_id() const { return ar->first_id + p0; }
+  const int *gt(size_t p) const { return ar->gt.data() + v0 + p * nv; }
+  const uint32_t *vidx(size_t p) const { return ar->vidx.data() + v0 + p * nv; }
+  const uint32_t *vlen(size_t p) const { return ar->vlen.data() + v0 + p * nv; }
+  static uint64_t hash(const char *s, size_t n) {
     uint64_t h = 0xcbf29ce484222325ULL;
-    for (unsigned char c : s) { h ^= c; h *= 0x100000001b3ULL; }
+    for (size_t i = 0; i < n; ++i) { h ^= (unsigned char)s[i]; h *= 0x100000001b3ULL; }
     return h;
   }
   bool same(size_t p, const std::string &s) const { return len(p) == s.size() && memcmp(seq(p), s.data(), s.size()) == 0; }
-  void add(const std::string &s, const std::vector<int> &g, const std::vector<uint32_t> &ix, const std::vector<uint32_t> &ln) {
-    const size_t np = size();
+  // `seen`: hash -> path indices, used once a cluster has many paths; the caller's scratch, empty at the cluster's start
+  void add(const std::string &s, const std::vector<int> &g, const std::vector<uint32_t> &ix, const std::vector<uint32_t> &ln,
+           std::unordered_map<uint64_t, std::vector<uint32_t>> &seen) {
     // varMer.C:39: a sequence already present is not added again.  Few paths: compare them all; many: by hash.
     if (np < 32) {
       for (size_t p = 0; p < np; ++p) if (same(p, s)) return;
     } else {
-      if (seen.empty()) for (size_t p = 0; p < np; ++p) seen[hash(std::string(seq(p), len(p)))].push_back((uint32_t)p);
-      std::vector<uint32_t> &cand = seen[hash(s)];
+      if (seen.empty()) for (size_t p = 0; p < np; ++p) seen[hash(seq(p), len(p))].push_back((uint32_t)p);
+      std::vector<uint32_t> &cand = seen[hash(s.data(), s.size())];
       for (uint32_t p : cand) if (same(p, s)) return;
-      cand.push_back((uint32_t)np);
+      cand.push_back(np);
     }
-    if (toff.empty()) toff.push_back(0);
-    text.append(s);
-    text.push_back('\n');
-    toff.push_back((uint32_t)text.size());
-    gt.insert(gt.end(), g.begin(), g.end());
-    vidx.insert(vidx.end(), ix.begin(), ix.end());
-    vlen.insert(vlen.end(), ln.begin(), ln.end());
+    ar->text.append(s);
+    ar->text.push_back('\n');
+    ar->toff.push_back(ar->text.size());
+    ar->gt.insert(ar->gt.end(), g.begin(), g.end());
+    ar->vidx.insert(ar->vidx.end(), ix.begin(), ix.end());
+    ar->vlen.insert(ar->vlen.end(), ln.begin(), ln.end());
+    ++np;
   }
 };
 
@@ -372,8 +434,9 @@ struct PathSet {
 // (the stored snapshots feed the "new k-mer" test of scoring).  `reps`: one string per recursion depth, reused for
 // every candidate built at that depth (the reference copies the candidate once per allele); the caller sizes it to the
 // cluster's variant count (references into it are held across the recursion: it must not grow here).
+using SeenMap = std::unordered_map<uint64_t, std::vector<uint32_t>>;
 void enumerate(uint32_t idx, std::vector<uint32_t> &offs, std::vector<uint32_t> lens, const Cluster &cl,
-               const std::string &cand, std::vector<int> &path, PathSet &out, std::vector<std::string> &reps, size_t depth) {
+               const std::string &cand, std::vector<int> &path, PathSet &out, std::vector<std::string> &reps, size_t depth, SeenMap &seen) {
   const Variant &var = *cl.vars[idx];
   const uint32_t refLen = lens[idx];
   const uint32_t last = (uint32_t)offs.size() - 1;
@@ -393,15 +456,15 @@ void enumerate(uint32_t idx, std::vector<uint32_t> &offs, std::vector<uint32_t> 
         ++idx; path.push_back(0); ++skipped;
       }
       if (skipped > 0 && idx == last) {
-        out.add(rep, path, offs, lens);
+        out.add(rep, path, offs, lens, seen);
         for (int q = 0; q < skipped; ++q) { path.pop_back(); --idx; }
         path.pop_back();
         continue;
       }
       for (uint32_t i = idx + 1; i < offs.size(); ++i) offs[i] += delta;
     }
-    if (idx + 1 < offs.size()) enumerate(idx + 1, offs, lens, cl, reps[depth], path, out, reps, depth + 1);
-    if (idx == last) out.add(reps[depth], path, offs, lens);
+    if (idx + 1 < offs.size()) enumerate(idx + 1, offs, lens, cl, reps[depth], path, out, reps, depth + 1, seen);
+    if (idx == last) out.add(reps[depth], path, offs, lens, seen);
     for (uint32_t i = idx + 1; i < offs.size(); ++i) offs[i] -= delta;
     for (int q = 0; q < skipped; ++q) { path.pop_back(); --idx; }
     path.pop_back();
@@ -423,9 +486,7 @@ struct Job {                          // one cluster waiting for its GPU values
   const Cluster *cl;
   uint32_t contig;
   uint32_t rStart, rEnd;
-  PathSet ps;
-  uint64_t off = 0;                   // offset of its path arena in the packed buffer
-  uint64_t first_id = 0;              // varMerId of its first path (-debug numbering)
+  PathSet ps;                         // its paths, inside the arena of its run of clusters
   std::string dbg;                    // -debug lines of this cluster (appended to its run's text by the worker)
 };
 
@@ -445,40 +506,48 @@ void parallel_for(size_t n, F &&fn) {
   for (auto &x : th) x.join();
 }
 
-std::string hom_record(const Cluster &cl, const int *g, size_t ng, const char *chr) {     // varMer.C:531-550
-  std::string out;
+// decimal text of an integer appended to `o` (what std::to_string gives, without the temporary)
+inline void put_int(std::string &o, long long v) {
+  char b[24];
+  int n = 0;
+  unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+  do { b[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+  if (v < 0) o += '-';
+  while (n) o += b[--n];
+}
+
+// the records are appended to `out` (the text of a run of clusters: one write per run)
+void hom_record(std::string &out, const Cluster &cl, const int *g, size_t ng, const char *chr) {     // varMer.C:531-550
   for (size_t i = 0; i < ng; ++i) {
     int a = g[i];
     if (a <= 0) continue;
     const Variant *v = cl.vars[i];
-    out += chr; out += '\t'; out += std::to_string(v->pos + 1); out += "\t.\t"; out += v->allele(0); out += '\t'; out += v->allele(a); out += '\t';
-    out += std::to_string((int)v->qual); out += "\tPASS\t.\tGT\t1/1\n";
+    out += chr; out += '\t'; put_int(out, (long long)(uint32_t)(v->pos + 1)); out += "\t.\t"; out += v->allele(0); out += '\t'; out += v->allele(a); out += '\t';
+    put_int(out, (int)v->qual); out += "\tPASS\t.\tGT\t1/1\n";
   }
-  return out;
 }
 
-std::string het_record(const Cluster &cl, const int *g1, const int *g2, size_t ng, const char *chr) {   // varMer.C:472-529
-  std::string out;
+void het_record(std::string &out, const Cluster &cl, const int *g1, const int *g2, size_t ng, const char *chr) {   // varMer.C:472-529
   for (size_t i = 0; i < ng; ++i) {
     int a1 = g1[i], a2 = g2[i];
     if (a1 + a2 <= 0) continue;
     const Variant *v = cl.vars[i];
-    std::string q = std::to_string((int)v->qual);
-    out += chr; out += '\t'; out += std::to_string(v->pos + 1); out += "\t.\t"; out += v->allele(0); out += '\t';
-    if (a1 == a2) { out += v->allele(a1); out += '\t'; out += q; out += "\tPASS\t.\tGT\t1/1\n"; }
-    else if (a1 == 0 && a2 > 0) { out += v->allele(a2); out += '\t'; out += q; out += "\tPASS\t.\tGT\t0/1\n"; }
-    else if (a1 > 0 && a2 > 0) { out += v->allele(a1); out += ','; out += v->allele(a2); out += '\t'; out += q; out += "\tPASS\t.\tGT\t1/2\n"; }
-    else if (a1 > 0 && a2 == 0) { out += v->allele(a1); out += '\t'; out += q; out += "\tPASS\t.\tGT\t1/0\n"; }
+    const int q = (int)v->qual;
+    out += chr; out += '\t'; put_int(out, (long long)(uint32_t)(v->pos + 1)); out += "\t.\t"; out += v->allele(0); out += '\t';
+    if (a1 == a2) { out += v->allele(a1); out += '\t'; put_int(out, q); out += "\tPASS\t.\tGT\t1/1\n"; }
+    else if (a1 == 0 && a2 > 0) { out += v->allele(a2); out += '\t'; put_int(out, q); out += "\tPASS\t.\tGT\t0/1\n"; }
+    else if (a1 > 0 && a2 > 0) { out += v->allele(a1); out += ','; out += v->allele(a2); out += '\t'; put_int(out, q); out += "\tPASS\t.\tGT\t1/2\n"; }
+    else if (a1 > 0 && a2 == 0) { out += v->allele(a1); out += '\t'; put_int(out, q); out += "\tPASS\t.\tGT\t1/0\n"; }
   }
-  return out;
 }
 
 double tot_dk(const std::vector<double> &d) { double s = 0; for (double x : d) s += x; return s; }   // getTotdK
 
-// paths with the fewest missing k-mers, optionally ignoring all-missing paths (varMer.C:156-178, 406-421)
-std::vector<int> min_missing(const Job &jb, const Scored &sc, uint32_t k, bool filter_rule, uint32_t *best) {
+// paths with the fewest missing k-mers, optionally ignoring all-missing paths (varMer.C:156-178, 406-421); `idxs`: the
+// caller's scratch
+void min_missing(const Job &jb, const Scored &sc, uint32_t k, bool filter_rule, uint32_t *best, std::vector<int> &idxs) {
   uint32_t numMissing = UINT32_MAX;
-  std::vector<int> idxs;
+  idxs.clear();
   for (int i = 0; i < (int)sc.numM.size(); ++i) {
     if (sc.numM[i] == jb.ps.len(i) - k + 1) continue;                    // size_t arithmetic, as the reference
     if (filter_rule && sc.numM[i] == 0) { idxs.push_back(i); numMissing = 0; }
@@ -486,33 +555,34 @@ std::vector<int> min_missing(const Job &jb, const Scored &sc, uint32_t k, bool f
     else if (sc.numM[i] == numMissing) idxs.push_back(i);
   }
   *best = numMissing;
-  return idxs;
 }
 
-std::string select_records(const Job &jb, const Scored &sc, int mode, uint32_t k, const char *chr, std::string *log) {
+// the records one cluster contributes, appended to `out`
+void select_records(std::string &out, const Job &jb, const Scored &sc, int mode, uint32_t k, const char *chr, std::string *log) {
   const PathSet &ps = jb.ps;
   const Cluster &cl = *jb.cl;
   const size_t nv = ps.nv;
-  auto gt = [&](size_t p) { return ps.gt.data() + p * nv; };
+  auto gt = [&](size_t p) { return ps.gt(p); };
+  static thread_local std::vector<int> idxs;
   if (mode == MFX_VAR_FILTER) {                                          // bestFilter, varMer.C:150-199
     uint32_t best;
-    std::vector<int> idxs = min_missing(jb, sc, k, true, &best);
-    if (idxs.empty()) return "";
-    std::list<int> gtIdxs;
+    min_missing(jb, sc, k, true, &best, idxs);
+    if (idxs.empty()) return;
+    static thread_local std::vector<int> gtIdxs;                         // the reference's list: sorted, duplicates dropped
+    gtIdxs.clear();
     for (int p : idxs)
       for (int i = 0; i < (int)nv; ++i)
         if (gt(p)[i] > 0) gtIdxs.push_back(i);
-    gtIdxs.sort();
-    gtIdxs.unique();
-    std::string out;
-    for (int i : gtIdxs) out += cl.vars[i]->rec->line();
-    return out;
+    std::sort(gtIdxs.begin(), gtIdxs.end());
+    gtIdxs.erase(std::unique(gtIdxs.begin(), gtIdxs.end()), gtIdxs.end());
+    for (int i : gtIdxs) cl.vars[i]->rec->line_to(out);
+    return;
   }
   if (mode == MFX_VAR_POLISH) {                                          // bestVariant, varMer.C:400-467
     uint32_t best;
-    std::vector<int> idxs = min_missing(jb, sc, k, false, &best);
-    if (best == UINT32_MAX) return "";
-    if (idxs.size() == 1) return hom_record(cl, gt(idxs[0]), nv, chr);
+    min_missing(jb, sc, k, false, &best, idxs);
+    if (best == UINT32_MAX) return;
+    if (idxs.size() == 1) { hom_record(out, cl, gt(idxs[0]), nv, chr); return; }
     // tie: order by total delta-K through the reference's own container type --
     // multimap<double,int,greater<int>> compares the keys AS INTS, descending (varMer.H:72)
     std::multimap<double, int, std::greater<int>> byDk;
@@ -522,23 +592,25 @@ std::string select_records(const Job &jb, const Scored &sc, int mode, uint32_t k
     ++it;
     double d2 = it->first; int p2 = it->second;
     if (d1 == d2) {
-      if (ps.len(p1) >= ps.len(p2)) return het_record(cl, gt(p1), gt(p2), nv, chr);
-      return het_record(cl, gt(p2), gt(p1), nv, chr);
+      if (ps.len(p1) >= ps.len(p2)) het_record(out, cl, gt(p1), gt(p2), nv, chr);
+      else het_record(out, cl, gt(p2), gt(p1), nv, chr);
+      return;
     }
-    return hom_record(cl, gt(p1), nv, chr);
+    hom_record(out, cl, gt(p1), nv, chr);
+    return;
   }
   // -better / -strict / -loose start from the reference path (varMer.C:204-395)
-  if (sc.numM.empty()) return "";
+  if (sc.numM.empty()) return;
   const uint32_t refMissing = sc.numM[0];
   uint32_t numMissing = refMissing;
-  std::vector<int> idxs;
+  idxs.clear();
   const bool loose = mode == MFX_VAR_LOOSE;
   for (int i = 0; i < (int)sc.numM.size(); ++i) {
     if (sc.numM[i] < numMissing) { numMissing = sc.numM[i]; idxs.clear(); idxs.push_back(i); }
     else if (sc.numM[i] == numMissing && (loose ? sc.numM[i] <= refMissing : sc.numM[i] < refMissing)) idxs.push_back(i);
   }
-  if (idxs.empty()) return "";
-  if (idxs.size() == 1) return hom_record(cl, gt(idxs[0]), nv, chr);
+  if (idxs.empty()) return;
+  if (idxs.size() == 1) { hom_record(out, cl, gt(idxs[0]), nv, chr); return; }
   if (!loose) {                                                          // longest path wins (first on ties)
     int idx = idxs[0];
     uint32_t longest = (uint32_t)ps.len(idx);
@@ -546,9 +618,10 @@ std::string select_records(const Job &jb, const Scored &sc, int mode, uint32_t k
       uint32_t L = (uint32_t)ps.len(idxs[i]);
       if (L > longest) { longest = L; idx = idxs[i]; }
     }
-    return hom_record(cl, gt(idx), nv, chr);
+    hom_record(out, cl, gt(idx), nv, chr);
+    return;
   }
-  if (idxs[0] == 0 && idxs.size() == 2) return hom_record(cl, gt(idxs[1]), nv, chr);
+  if (idxs[0] == 0 && idxs.size() == 2) { hom_record(out, cl, gt(idxs[1]), nv, chr); return; }
   int maxVars = 0, maxIdx = idxs[0];                                     // most ALT alleles wins
   for (size_t i = 1; i < idxs.size(); ++i) {
     int cnt = 0;
@@ -559,7 +632,7 @@ std::string select_records(const Job &jb, const Scored &sc, int mode, uint32_t k
     *log += "[ WARNING ] :: Multiple (" + std::to_string(idxs.size()) + ") alternate pathes detected in a path beginning with variant : " + cl.vars[0]->rec->line();
     *log += "[ WARNING ] :: Max. " + std::to_string(maxVars) + " ALT variants selected\n";
   }
-  return hom_record(cl, gt(maxIdx), nv, chr);
+  hom_record(out, cl, gt(maxIdx), nv, chr);
 }
 
 // debug statistics (varMer.C:553-624)
@@ -606,13 +679,14 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
 
   // MFX_VAR_TIMING=1: per-phase wall time on stderr (diagnostics only)
   const bool timing = getenv("MFX_VAR_TIMING") && atoi(getenv("MFX_VAR_TIMING"));
-  double t_phase[7] = {0, 0, 0, 0, 0, 0, 0};                             // load+cluster, enumerate, pack, gpu, score+select, write, queue
+  double t_phase[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                             // load+cluster, enumerate, pack, gpu, score+select, write, queue
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t_mark = now();
   auto lap = [&](int i) { double t = now(); t_phase[i] += t - t_mark; t_mark = t; };
 
   VcfDB db;
-  int rc = load_vcf(vcf_path, db);
+  double t_load[4] = {0, 0, 0, 0};
+  int rc = load_vcf(vcf_path, db, t_load);
   if (rc) { if (log != stderr) fclose(log); return rc; }
   fprintf(log, "   Collected %zu header lines.\n   Loaded %zu records:\n      %-8lu unique contig%s\n      %-8u contig IDs\n   Excluded %lu invalid records\n\n",
           db.headers.size(), db.n_records, db.by_chr.size(), db.by_chr.size() == 1 ? "" : "s", (unsigned)db.contig_ids, (unsigned long)db.excluded);
@@ -652,7 +726,9 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
     std::vector<uint32_t> p_len, p_nv, p_vidx, p_vlen, numM;
     std::vector<int32_t> p_gt;
     std::vector<double> totdk;
-    std::vector<uint64_t> job_p0;     // first path of every job in the arrays above
+    std::vector<PathArena> arenas;    // one per run of RUN consecutive jobs; their capacity is kept from batch to batch
+    size_t nruns = 0;
+    bool scored = false;              // varMer::score of this batch runs on the device (numM / totdk above)
     std::shared_future<int> gpu;      // stage B of this batch (shared: the next batch's stage B waits for it too)
     std::string err;                  // the error text of stage B (errors are per thread: it is carried back to the caller's)
     bool live = false;
@@ -692,63 +768,89 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
   } writer(out);
 
   // stage A + the launch of stage B
+  // the jobs of a batch are worked on in runs of RUN consecutive ones: a run's paths share one arena (stage A), and its
+  // records / -debug lines / log lines are concatenated by the worker that scores it (stage C), so that the writer issues
+  // one write per run, not per cluster
+  constexpr size_t RUN = 256;
   auto stage_ab = [&](Batch &bt) -> int {
     std::vector<Job> &jobs = bt.jobs;
     std::string &packed = bt.packed;
     lap(6);                                                              // (the clusters were queued since the last lap)
-    parallel_for(jobs.size(), [&](size_t i) {
-      Job &jb = jobs[i];
-      std::vector<uint32_t> offs, vl;
-      for (const Variant *v : jb.cl->vars) { offs.push_back(v->pos - jb.rStart); vl.push_back(v->refLen); }
-      std::vector<int> path;
-      static thread_local std::vector<std::string> reps;                 // candidate strings per recursion depth, reused
-      jb.ps.nv = (uint32_t)jb.cl->vars.size();
-      if (reps.size() < jb.cl->vars.size() + 1) reps.resize(jb.cl->vars.size() + 1);
-      enumerate(0, offs, vl, *jb.cl, std::string(bases[jb.contig] + jb.rStart, bases[jb.contig] + jb.rEnd), path, jb.ps, reps, 0);
-      jb.ps.seen.clear();
+    const size_t nruns = (jobs.size() + RUN - 1) / RUN;
+    bt.nruns = nruns;
+    if (bt.arenas.size() < nruns) bt.arenas.resize(nruns);
+    parallel_for(nruns, [&](size_t ri) {
+      PathArena &ar = bt.arenas[ri];
+      ar.reset();
+      // per-thread scratch, reused from cluster to cluster
+      static thread_local std::vector<uint32_t> offs, vl;
+      static thread_local std::vector<int> path;
+      static thread_local std::vector<std::string> reps;                 // candidate strings per recursion depth
+      static thread_local std::string window;
+      static thread_local SeenMap seen;
+      for (size_t i = ri * RUN, e = std::min(jobs.size(), (ri + 1) * RUN); i < e; ++i) {
+        Job &jb = jobs[i];
+        offs.clear(); vl.clear(); path.clear();
+        for (const Variant *v : jb.cl->vars) { offs.push_back(v->pos - jb.rStart); vl.push_back(v->refLen); }
+        jb.ps = PathSet();
+        jb.ps.ar = &ar;
+        jb.ps.p0 = ar.toff.size() - 1;
+        jb.ps.v0 = ar.gt.size();
+        jb.ps.nv = (uint32_t)jb.cl->vars.size();
+        if (reps.size() < jb.cl->vars.size() + 1) reps.resize(jb.cl->vars.size() + 1);
+        window.assign(bases[jb.contig] + jb.rStart, bases[jb.contig] + jb.rEnd);
+        if (!seen.empty()) seen.clear();
+        enumerate(0, offs, vl, *jb.cl, window, path, jb.ps, reps, 0, seen);
+      }
+      if (!seen.empty()) seen.clear();
     });
     lap(1);
-    uint64_t total = 0;
-    for (Job &jb : jobs) {
-      jb.first_id = varMerId;
-      varMerId += jb.ps.size();
-      jb.off = total;
-      total += jb.ps.text.size();                                        // every path is followed by its '\n' (not ACGT: k-mers never span two paths)
+    uint64_t total = 0, np = 0, nvals = 0;
+    for (size_t ri = 0; ri < nruns; ++ri) {
+      PathArena &ar = bt.arenas[ri];
+      ar.first_id = varMerId;
+      varMerId += ar.toff.size() - 1;
+      ar.off = total;
+      total += ar.text.size();                                           // every path is followed by its '\n' (not ACGT: k-mers never span two paths)
+      ar.p0 = np;
+      np += ar.toff.size() - 1;
+      ar.v0 = nvals;
+      nvals += ar.gt.size();
     }
     packed.resize(total);
-    parallel_for(jobs.size(), [&](size_t i) {
-      const Job &jb = jobs[i];
-      memcpy(&packed[jb.off], jb.ps.text.data(), jb.ps.text.size());
+    parallel_for(nruns, [&](size_t ri) {
+      const PathArena &ar = bt.arenas[ri];
+      if (!ar.text.empty()) memcpy(&packed[ar.off], ar.text.data(), ar.text.size());
     });
     lap(2);
     bt.live = true;
+    bt.scored = false;
     bt.gpu = std::shared_future<int>();                                  // (a shared future stays valid after get(): this batch has none yet)
     const bool on_device = (bool)scores && dbg == nullptr;               // -debug wants the per-position values: scored on the host
     if (total && on_device) {
       // the path table of the batch: one entry per path, the variants' rows concatenated
-      bt.job_p0.resize(jobs.size() + 1);
-      std::vector<uint64_t> v0(jobs.size() + 1);
-      uint64_t np = 0, nvals = 0;
-      for (size_t i = 0; i < jobs.size(); ++i) { bt.job_p0[i] = np; v0[i] = nvals; np += jobs[i].ps.size(); nvals += jobs[i].ps.size() * jobs[i].ps.nv; }
-      bt.job_p0[jobs.size()] = np;
+      bt.scored = true;
       bt.p_off.resize(np); bt.p_voff.resize(np); bt.p_cfirst.resize(np); bt.p_len.resize(np); bt.p_nv.resize(np);
       bt.p_gt.resize(nvals); bt.p_vidx.resize(nvals); bt.p_vlen.resize(nvals);
       bt.numM.resize(np); bt.totdk.resize(np);
-      parallel_for(jobs.size(), [&](size_t i) {
-        const Job &jb = jobs[i];
-        const size_t n = jb.ps.size(), nv = jb.ps.nv;
-        for (size_t p = 0; p < n; ++p) {
-          const uint64_t q = bt.job_p0[i] + p;
-          bt.p_off[q] = jb.off + jb.ps.toff[p];
-          bt.p_len[q] = (uint32_t)jb.ps.len(p);
-          bt.p_nv[q] = (uint32_t)nv;
-          bt.p_voff[q] = v0[i] + p * nv;
-          bt.p_cfirst[q] = bt.job_p0[i];
+      parallel_for(nruns, [&](size_t ri) {
+        const PathArena &ar = bt.arenas[ri];
+        for (size_t i = ri * RUN, e = std::min(jobs.size(), (ri + 1) * RUN); i < e; ++i) {
+          const PathSet &ps = jobs[i].ps;
+          const uint64_t q0 = ps.table_p0();
+          for (size_t p = 0; p < ps.np; ++p) {
+            const uint64_t q = q0 + p;
+            bt.p_off[q] = ps.packed_off(p);
+            bt.p_len[q] = (uint32_t)ps.len(p);
+            bt.p_nv[q] = ps.nv;
+            bt.p_voff[q] = ar.v0 + ps.v0 + p * ps.nv;
+            bt.p_cfirst[q] = q0;
+          }
         }
-        if (n * nv) {
-          memcpy(&bt.p_gt[v0[i]], jb.ps.gt.data(), n * nv * sizeof(int32_t));
-          memcpy(&bt.p_vidx[v0[i]], jb.ps.vidx.data(), n * nv * sizeof(uint32_t));
-          memcpy(&bt.p_vlen[v0[i]], jb.ps.vlen.data(), n * nv * sizeof(uint32_t));
+        if (!ar.gt.empty()) {
+          memcpy(&bt.p_gt[ar.v0], ar.gt.data(), ar.gt.size() * sizeof(int32_t));
+          memcpy(&bt.p_vidx[ar.v0], ar.vidx.data(), ar.vidx.size() * sizeof(uint32_t));
+          memcpy(&bt.p_vlen[ar.v0], ar.vlen.data(), ar.vlen.size() * sizeof(uint32_t));
         }
       });
       lap(2);
@@ -766,7 +868,6 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
         return r;
       });
     } else if (total) {
-      bt.job_p0.clear();
       bt.rv.resize(packed.size() + 1);
       bt.av.resize(packed.size() + 1);
       Batch *bp = &bt;
@@ -780,7 +881,7 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
         if (r) bp->err = mfx_last_error();
         return r;
       });
-    } else bt.job_p0.clear();
+    }
     return MFX_OK;
   };
 
@@ -791,43 +892,41 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
     std::string &packed = bt.packed;
     const std::vector<uint32_t> &rv = bt.rv, &av = bt.av;
     bt.live = false;
-    lap(5);
+    lap(7);
     if (bt.gpu.valid()) {
       const int r = bt.gpu.get();
       if (r) { jobs.clear(); packed.clear(); return mfx_fail(r, "%s", bt.err.c_str()); }
     }
     lap(3);
     const bool want_dbg = dbg != nullptr;
-    // the jobs of a batch are scored in runs of OUT_RUN consecutive ones; a run's records / -debug lines / log lines are
-    // concatenated by the worker that scored it, so that the writer below issues one write per run, not per cluster
-    constexpr size_t OUT_RUN = 256;
-    const size_t nruns = (jobs.size() + OUT_RUN - 1) / OUT_RUN;
+    const size_t nruns = bt.nruns;                                       // the runs of stage A (one arena each)
     std::vector<std::string> run_out(nruns), run_dbg(nruns), run_log(nruns);
     parallel_for(nruns, [&](size_t ri) {
-     for (size_t ji = ri * OUT_RUN, je = std::min(jobs.size(), (ri + 1) * OUT_RUN); ji < je; ++ji) {
+     static thread_local Scored sc;                                      // per-thread scratch, reused from cluster to cluster
+     run_out[ri].reserve(RUN * 96);
+     for (size_t ji = ri * RUN, je = std::min(jobs.size(), (ri + 1) * RUN); ji < je; ++ji) {
       Job &jb = jobs[ji];
       // `prob` is a local of varMer::score (one per cluster) that the reference reads
       // uninitialised until the first valid k-mer writes it; before that it only
       // multiplies |0-0|, so any finite start value is equivalent.  We fix 1.0.
       double prob = 1.0;
-      Scored sc;
       const size_t np = jb.ps.size(), nv = jb.ps.nv;
       // what the selectors read: numM always; the paths' total delta-K only in -polish (its tie-break); the per-position
       // K* and delta-K values only in the -debug statistics.  Nothing else is computed or stored.
       const bool need_dk = mode == MFX_VAR_POLISH || want_dbg, keep = want_dbg && mode != MFX_VAR_FILTER;
       sc.numM.resize(np); sc.totdk.assign(np, 0.0);
-      if (want_dbg) { sc.ks.resize(np); sc.dks.resize(np); }
-      const bool scored = !bt.job_p0.empty();                            // varMer::score ran on the device (mfx_score_paths)
+      if (want_dbg) { sc.ks.assign(np, std::vector<double>()); sc.dks.assign(np, std::vector<double>()); }
+      const bool scored = bt.scored;                                     // varMer::score ran on the device (mfx_score_paths)
       if (scored) {
-        const uint64_t q0 = bt.job_p0[ji];
+        const uint64_t q0 = jb.ps.table_p0();
         for (size_t p = 0; p < np; ++p) { sc.numM[p] = bt.numM[q0 + p]; if (need_dk) sc.totdk[p] = bt.totdk[q0 + p]; }
       }
       for (size_t p = 0; p < np && !scored; ++p) {                       // varMer::score, varMer.C:66-144
         const char *s = jb.ps.seq(p);
         const uint32_t slen = (uint32_t)jb.ps.len(p);
-        const uint64_t o = jb.off + jb.ps.toff[p];
-        const int *gtp = jb.ps.gt.data() + p * nv;
-        const uint32_t *vip = jb.ps.vidx.data() + p * nv, *vlp = jb.ps.vlen.data() + p * nv;
+        const uint64_t o = jb.ps.packed_off(p);
+        const int *gtp = jb.ps.gt(p);
+        const uint32_t *vip = jb.ps.vidx(p), *vlp = jb.ps.vlen(p);
         uint32_t numM = 0, run = 0;
         double totdk = 0.0;                                              // summed in position order, as getTotdK does
         if (keep) { sc.ks[p].reserve(slen); sc.dks[p].reserve(slen); }
@@ -865,14 +964,14 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
       if (want_dbg) {                                                    // merfin-variants.C:240-276
         char buf[512];
         for (size_t p = 0; p < np; ++p) {
-          snprintf(buf, sizeof(buf), "%lu\t%s:%u-%u\t", (unsigned long)(jb.first_id + p), chr, jb.rStart, jb.rEnd);
+          snprintf(buf, sizeof(buf), "%lu\t%s:%u-%u\t", (unsigned long)(jb.ps.first_id() + p), chr, jb.rStart, jb.rEnd);
           jb.dbg += buf;
           jb.dbg.append(jb.ps.seq(p), jb.ps.len(p));
           snprintf(buf, sizeof(buf), "\t%u\t%.5f\t%.5f\t%.5f\t%.5f\t%.5f\t", sc.numM[p], min_abs_k(sc.ks[p]), max_abs_k(sc.ks[p]),
                    med_abs_k(sc.ks[p]), avg_abs_k(sc.ks[p], sc.numM[p]), sc.totdk[p]);
           jb.dbg += buf;
           for (size_t i = 0; i < nv; ++i) {
-            int a = jb.ps.gt[p * nv + i];
+            int a = jb.ps.gt(p)[i];
             if (a > 0)
             {
               jb.dbg += chr; jb.dbg += ' '; jb.dbg += std::to_string(jb.cl->vars[i]->pos + 1); jb.dbg += " . "; jb.dbg += jb.cl->vars[i]->allele(0);
@@ -882,9 +981,8 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
           jb.dbg += "\n";
         }
       }
-      run_out[ri] += select_records(jb, sc, mode, K, chr, &run_log[ri]);
+      select_records(run_out[ri], jb, sc, mode, K, chr, &run_log[ri]);
       if (want_dbg) { run_dbg[ri] += jb.dbg; std::string().swap(jb.dbg); }
-      jb.ps = PathSet();                                                 // release the per-path containers here, on the worker
      }
     });
     lap(4);
@@ -892,9 +990,12 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
       if (!run_log[ri].empty()) fwrite(run_log[ri].data(), 1, run_log[ri].size(), log);
       if (dbg && !run_dbg[ri].empty()) fwrite(run_dbg[ri].data(), 1, run_dbg[ri].size(), dbg);
     }
+    lap(8);
     writer.push(std::move(run_out));                                     // the records, in order, by the writer thread
+    lap(9);
     clusters += jobs.size();
     jobs.clear();
+    lap(10);
     packed.clear();
     lap(5);
     return MFX_OK;
@@ -957,6 +1058,8 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
   if (timing)
     fprintf(stderr, "[mfx_variants] load+cluster %.2fs  enumerate %.2fs  pack %.2fs  gpu %.2fs  score+select %.2fs  queue %.2fs  write %.2fs\n",
             t_phase[0], t_phase[1], t_phase[2], t_phase[3], t_phase[4], t_phase[6], t_phase[5]);
+  if (timing) fprintf(stderr, "[mfx_variants]   load: read %.3f  lines %.3f  parse %.3f  runs %.3f  (the rest: clustering) | stage C: before %.3f  logs %.3f  hand-over %.3f  clear %.3f\n",
+                      t_load[0], t_load[1], t_load[2], t_load[3], t_phase[7], t_phase[8], t_phase[9], t_phase[10]);
   if (!writer.finish() && rc == MFX_OK) rc = mfx_fail(MFX_E_IO, "writing '%s' failed", out_path);
   if (fclose(out) != 0 && rc == MFX_OK) rc = mfx_fail(MFX_E_IO, "writing '%s' failed", out_path);
   if (dbg && mfx_close(dbgh) && rc == MFX_OK) rc = mfx_fail(MFX_E_IO, "writing '%s' failed", opts->debug_path);

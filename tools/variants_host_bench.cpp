@@ -20,6 +20,7 @@ int main(int argc, char **argv) {
   const uint64_t total = argc > 1 ? (uint64_t)atof(argv[1]) : 100000000ull;
   const int mode = argc > 2 ? atoi(argv[2]) : MFX_VAR_POLISH;
   const uint32_t nc = 24;
+  const bool varied = argc > 6 && atoi(argv[6]);
   std::mt19937_64 rng(7);
   std::vector<std::string> contigs(nc), names(nc);
   std::string vcf = "##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tSAMPLE\n";
@@ -43,10 +44,24 @@ int main(int argc, char **argv) {
     std::sort(pos.begin(), pos.end());
     pos.erase(std::unique(pos.begin(), pos.end()), pos.end());
     for (size_t p : pos) {
-      char buf[256];
+      char buf[512];
       const char ref = s[p];
       const char alt = "ACGT"[(std::string("ACGT").find(ref) + 1 + rng() % 3) % 4];
-      snprintf(buf, sizeof(buf), "%s\t%zu\t.\t%c\t%c\t30\tPASS\t.\tGT\t1/1\n", names[c].c_str(), p + 1, ref, alt);
+      const unsigned kind = varied ? (unsigned)(rng() % 20) : 0u;        // argv[6] = 1: indels, two ALTs, every genotype form
+      static const char *gts[] = {"1/1", "0/1", "1|0", "1/2", "./.", "0/0", "1/1:30:12", "2/1"};
+      const char *gt = varied ? gts[rng() % 8] : "1/1";
+      if (kind < 12) snprintf(buf, sizeof(buf), "%s\t%zu\t.\t%c\t%c\t30\tPASS\t.\tGT\t%s\n", names[c].c_str(), p + 1, ref, alt, gt);
+      else if (kind < 15) {                                              // deletion of 1..6 bases
+        const size_t L = 2 + rng() % 6;
+        snprintf(buf, sizeof(buf), "%s\t%zu\t.\t%s\t%c\t%.1f\tPASS\t.\tGT:DP\t%s\n", names[c].c_str(), p + 1, s.substr(p, L).c_str(), ref, 10.0 + (double)(rng() % 400) / 10, gt);
+      } else if (kind < 18) {                                            // insertion
+        std::string ins(1, ref);
+        for (size_t q = 0, L = 1 + rng() % 5; q < L; ++q) ins += "ACGT"[rng() % 4];
+        snprintf(buf, sizeof(buf), "%s\t%zu\tid%zu\t%c\t%s\t50\t.\tDP=3\tGT\t%s\n", names[c].c_str(), p + 1, p, ref, ins.c_str(), gt);
+      } else {                                                           // two ALTs, one of them equal to REF now and then
+        const char alt2 = (rng() % 4 == 0) ? ref : "ACGT"[rng() % 4];
+        snprintf(buf, sizeof(buf), "%s\t%zu\t.\t%c\t%c,%c%c\t30\tPASS\t.\tGT\t%s\n", names[c].c_str(), p + 1, ref, alt, alt2, "ACGT"[rng() % 4], gt);
+      }
       vcf += buf;
       ++calls;
     }
