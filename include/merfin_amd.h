@@ -55,6 +55,9 @@ const char *mfx_last_error(void);
 int         mfx_last_error_code(void);   /* code of the last failing call on this thread */
 const char *mfx_version(void);
 int         mfx_device_count(void);
+/* Optional (no reference counterpart): bring the device's context, this library's code object and the pinned-memory path up
+ * now -- what the first upload would otherwise pay (~0.07 s) -- e.g. on a helper thread while the caller reads its FASTA. */
+int         mfx_device_warm(int device);
 
 /* ------------------------------------------------------------------------ */
 /* Index: replaces the two merylExactLookup objects readLookup / asmLookup  */

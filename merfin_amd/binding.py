@@ -61,7 +61,7 @@ _lib = None
 
 # every symbol include/merfin_amd.h declares (tests check the .so exports all of them)
 SYMBOLS = [
-    "mfx_last_error", "mfx_last_error_code", "mfx_version", "mfx_device_count",
+    "mfx_last_error", "mfx_last_error_code", "mfx_version", "mfx_device_count", "mfx_device_warm",
     "mfx_index_create", "mfx_index_free", "mfx_index_estimate_gb", "mfx_index_add_read", "mfx_index_add_asm",
     "mfx_index_count_asm", "mfx_index_count_claimed", "mfx_hist_run_parts", "mfx_index_create_for_seq", "mfx_index_estimate_gb_for_seq", "mfx_index_claim_seq", "mfx_index_value", "mfx_index_get_info", "mfx_index_export",
     "mfx_db_probe", "mfx_index_load_db", "mfx_index_load_db_multi", "mfx_db_write_flat", "mfx_db_convert", "mfx_index_save", "mfx_index_load",
@@ -116,6 +116,7 @@ def load_library():
     L.mfx_version.restype = C.c_char_p
     L.mfx_last_error_code.restype = C.c_int
     L.mfx_device_count.restype = C.c_int
+    L.mfx_device_warm.argtypes = [C.c_int]
     L.mfx_index_create.restype = vp
     L.mfx_index_create.argtypes = [C.c_int, C.c_uint64, C.c_double, C.c_int]
     L.mfx_index_free.argtypes = [vp]
@@ -247,6 +248,11 @@ def _need(ptr):
 
 def device_count():
     return load_library().mfx_device_count()
+
+
+def device_warm(device=0):
+    """context, code object and pinned-memory path of the device brought up now (mfx_device_warm)"""
+    _check(load_library().mfx_device_warm(device))
 
 
 def hist_words(nbins, ncontigs):

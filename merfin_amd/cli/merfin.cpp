@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <unistd.h>
 #include <thread>
 #include <memory>
 #include <string>
@@ -567,6 +568,10 @@ static bool concat_parts(const std::string &out, const std::vector<std::string> 
   } while (0)
 
 int main(int argc, char **argv) {
+  // MFX_CLI_TIMING=3: wall-clock stamps (seconds since the epoch) at main / after the device check / at the end, so that a
+  // caller who timed the whole process can tell start-up and tear-down from the phases (diagnostics)
+  auto epoch = [] { return std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count(); };
+  const double stamp_main = epoch();
   Globals G;
   std::vector<std::string> err;
   for (int arg = 1; arg < argc; arg++) {
@@ -664,6 +669,7 @@ int main(int argc, char **argv) {
       return 1;
     }
 
+  const double stamp_devices = epoch();
   // MFX_CLI_TIMING=1: wall time per phase on stderr at exit (diagnostics; not part of merfin's output)
   const bool timing = getenv("MFX_CLI_TIMING") && atoi(getenv("MFX_CLI_TIMING"));
   auto t_last = std::chrono::steady_clock::now();
@@ -753,6 +759,10 @@ int main(int argc, char **argv) {
   const bool wantOverlap = ov ? atoi(ov) != 0 : compressed;
   const uint64_t basesBound = (G.seqName && !G.seqDBname && wantOverlap && !seqOnly) ? bases_upper_bound(G.seqName) : 0;
   const bool deferSeq = G.seqName && !G.sharded && !seqOnly && wantOverlap && (G.seqDBname || basesBound > 0);
+  // while the reader thread is on the file: the device's context, the library's code object and the pinned-memory path come
+  // up here instead of inside the first upload (~0.07 s; an error here is left to that upload to report).  Not with a
+  // decompressor child around (see the device check above) and not for several devices (their slots come up in parallel).
+  if (G.seqName && !compressed && G.devices.size() == 1 && !(getenv("MFX_CLI_WARM") && !atoi(getenv("MFX_CLI_WARM")))) (void)mfx_device_warm(G.device);
   if (!deferSeq) finish_seq();
   if (G.sharded) {
     if (G.devices.size() < 2) {
@@ -1153,7 +1163,12 @@ int main(int argc, char **argv) {
       for (auto &ph : steps) fprintf(stderr, "  %s %.3fs", ph.first, ph.second);
       fprintf(stderr, "\n");
     }
+    if (atoi(getenv("MFX_CLI_TIMING")) > 2)
+      fprintf(stderr, "-- stamps: main %.6f devices %.6f end %.6f\n", stamp_main, stamp_devices, epoch());
   }
   fprintf(stderr, "Bye!\n");
+  // MFX_CLI_QUICK_EXIT=1: every output is written and closed by now; leave without the tear-down of the HIP runtime's statics
+  // (not under a profiler: its tool library writes its files from an exit handler)
+  if (const char *qe = getenv("MFX_CLI_QUICK_EXIT")) if (atoi(qe)) { fflush(nullptr); _exit(rc); }
   return rc;
 }

@@ -76,6 +76,31 @@ extern "C" int mfx_diag_gather_rate(int device, uint64_t table_bytes, double *li
   return MFX_OK;
 }
 
+extern "C" int mfx_device_warm(int device) {
+  if (device < 0 || device >= mfx_device_count()) return mfx_fail(MFX_E_NODEVICE, "HIP device %d not available", device);
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  MFX_HIP(hipSetDevice(device));
+  // a device allocation + memset (the runtime's own kernels), one kernel of this library (its code object), a pinned
+  // allocation and a stream: everything the first upload would otherwise bring up on the caller's time
+  void *d = nullptr, *h = nullptr;
+  hipStream_t st = nullptr;
+  hipError_t e = hipMalloc(&d, 1 << 20);
+  if (e == hipSuccess) e = hipMemset(d, 0, 1 << 20);
+  if (e == hipSuccess) e = mfx_k_table_init(reinterpret_cast<mfx_slot *>(d), (1 << 20) / sizeof(mfx_slot), nullptr);
+  if (e == hipSuccess) e = hipHostMalloc(&h, 1 << 20, hipHostMallocDefault);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMemcpyAsync(d, h, 1 << 20, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (st) (void)hipStreamDestroy(st);
+  if (h) (void)hipHostFree(h);
+  if (d) (void)hipFree(d);
+  if (prev >= 0) (void)hipSetDevice(prev);
+  if (e != hipSuccess) { (void)hipGetLastError(); return mfx_fail(MFX_E_HIP, "mfx_device_warm: %s", hipGetErrorString(e)); }
+  return MFX_OK;
+}
+
 extern "C" int mfx_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -165,9 +190,11 @@ struct DevBuf {   // scoped device scratch
 constexpr double MFX_LF_MAX = 0.7, MFX_LF_MIN = 0.45, MFX_LF_HBM_SHARE = 0.75;
 // The compact layout of a sequence-only index (16 slots per line in 8 mini-buckets, buckets of w = 4 windows): the emptier the
 // table, the more k-mers sit in their first mini-bucket (one 16-byte load) -- 3 Gb -hist: 102.6 / 108.0 / 111.9 G k-mers/s at load
-// factors 0.30 / 0.25 / 0.20 (profiles/r03_kernel_experiments.txt).  0.225 is 105 GB for a human assembly -- half of what the
-// full table of reads + assembly takes at its 0.45.
-constexpr double MFX_CLF_MAX = 0.5, MFX_CLF_MIN = 0.225;
+// factors 0.30 / 0.25 / 0.20 (profiles/r03_kernel_experiments.txt).  Round 4's kernel runs at the HBM's random-line rate, so every
+// line not fetched is time: 148.1 / 151.8 / 152.7 / 153.6 / 154.3 G at 0.225 / 0.18 / 0.15 / 0.125 / 0.10
+// (profiles/r04_ab_load_factor.txt).  0.18 is 135 GB for a human assembly -- under two thirds of what the full table of reads +
+// assembly takes at its 0.45 -- and still chosen only when that much HBM is free (lines_auto).
+constexpr double MFX_CLF_MAX = 0.5, MFX_CLF_MIN = 0.18;
 // A sequence-only index in 16-byte slots (22 <= k <= 31) holds the assembly's k-mers only -- half of what the full tables hold --
 // and gives the memory back as speed: 500 Mb -hist at k = 31: 71.3 / 80.6 / 86.7 G k-mers/s at load factors 0.45 / 0.35 / 0.25
 // (profiles/r03_hist_rates_by_k.txt).  0.30 is 160 GB for a human assembly.

@@ -1,6 +1,6 @@
 """The path bench.py measures -- `-hist` on the SEQUENCE-ONLY COMPACT index of a k = 21 world built by the bench's own
 generator (tools/synth_torch.py: the SURVEY 8(d) recipe) -- against the ORACLE at a size where the regimes of the 3 Gb run
-exist: a 256 Mb world at the default load factor (0.225 floor) has hundreds of thousands of queries that leave the one-load
+exist: a 256 Mb world at the default load factor (0.18 floor) has hundreds of thousands of queries that leave the one-load
 fast path of the probe (mfx_lane_lookup8) -- displaced from their first mini-bucket (first cooperative pass), in a home line
 full of other k-mers (second cooperative pass), behind a saturated count field (the side table: the 1000-copy tandem repeats
 carry read counts of ~26,000) -- which the ~56 kb worlds of tests/synth.py never produce.  The DEBUG instance of the kernel
@@ -92,7 +92,7 @@ def test_bench_path_equals_the_oracle_where_every_probe_ending_occurs(sample, lo
     assert info["seq_only"] and info["compact"]
     slots = info["bytes"] / 8.0
     lf = info["distinct"] / slots
-    assert (0.2 < lf < 0.26) if not load_factor else (0.4 < lf < 0.55), lf
+    assert (0.15 < lf < 0.26) if not load_factor else (0.4 < lf < 0.55), lf
     kp = m.KParams(LAM, probK, probP)
     ev = m.Evaluator(ix, kp)
     fast = ev.hist(seqs)                                       # the measured instance <true, true, 21, 4, 6>

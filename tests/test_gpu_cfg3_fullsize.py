@@ -120,7 +120,7 @@ def test_cfg3_hist_kernel_equals_dump_kernel_plus_host_kstar(world, golden_dir):
 
 def test_cfg3_sequence_only_compact_index_equals_the_full_table(world, golden_dir):
     """THE BENCHMARKED PATH AT THE BENCHMARKED SIZE.  bench.py (and `merfin -hist`) evaluate on the sequence-only COMPACT index
-    (mfx_index_create_for_seq: 8-byte slots, mod-minimizer placement, load factor 0.225, kernel instance <true, true, 21, 4, 6>),
+    (mfx_index_create_for_seq: 8-byte slots, mod-minimizer placement, load factor 0.18 when the HBM is free, kernel instance <true, true, 21, 4, 6>),
     the tests above on the full table (kernel <true, false, 0, 0, 0>).  Both answer value() of the sequence's k-mers identically
     (merfin-histogram.C:54-91 asks for nothing else), so on the same 3 Gb world: bins, kasm, kmissing and the per-contig counters
     bit-equal, koverCpy to 1e-12; then on the compact index the 8-way block-cyclic shard sum (what bench.py --gpus 8 deals) and the
