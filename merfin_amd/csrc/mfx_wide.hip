@@ -59,16 +59,14 @@ __device__ __forceinline__ bool mfx_w_tile_kmer(const mfx_tile_lds &L, int k, ui
   return top == want;
 }
 
-// value(kmer): stored counts, 0 when absent (merfin-globals.C:84); -min/-max applied to the read count
-__device__ __forceinline__ uint2 mfx_w_lookup(const mfx_table_view &t, mfx_u128 key) {
+// value(kmer): stored counts, 0 when absent (merfin-globals.C:84); -min/-max applied to the read count.
+// mfx_w_lookup_from: the walk over the k-mer's slot order from slot qi0 of its home line on (qi0 = 1: the caller has looked
+// at the first slot itself -- the batched -hist below, whose first-slot loads of several k-mers are in flight together).
+__device__ __forceinline__ uint2 mfx_w_lookup_from(const mfx_table_view &t, uint64_t lo, uint64_t hi, uint64_t line, uint32_t q0, uint32_t qi0) {
   const mfx_wslot *S = mfx_w_slots(t);
-  uint32_t q0;
-  uint64_t line = mfx_w_home(t, key, q0);
-  const uint64_t lo = (uint64_t)key, hi = (uint64_t)(key >> 64);
   for (uint32_t d = 0; d < MFX_W_MAX_LINES; ++d) {
     const mfx_wslot *ln = S + line * MFX_WSLOTS_LINE;
-#pragma unroll
-    for (uint32_t qi = 0; qi < MFX_WSLOTS_LINE; ++qi) {
+    for (uint32_t qi = d ? 0u : qi0; qi < MFX_WSLOTS_LINE; ++qi) {
       const mfx_wslot s = ln[(q0 + qi) & (MFX_WSLOTS_LINE - 1u)];
       if (s.state == 0) return make_uint2(0u, 0u);           // the first empty slot of its order: the key was never inserted
       if (s.lo == lo && s.hi == hi) {
@@ -80,6 +78,12 @@ __device__ __forceinline__ uint2 mfx_w_lookup(const mfx_table_view &t, mfx_u128 
     if (++line >= t.nlines) line = 0;
   }
   return make_uint2(0u, 0u);
+}
+
+__device__ __forceinline__ uint2 mfx_w_lookup(const mfx_table_view &t, mfx_u128 key) {
+  uint32_t q0;
+  const uint64_t line = mfx_w_home(t, key, q0);
+  return mfx_w_lookup_from(t, (uint64_t)key, (uint64_t)(key >> 64), line, q0, 0u);
 }
 
 // find-or-claim; nullptr when the probe limit is hit
@@ -200,8 +204,14 @@ __device__ __forceinline__ uint2 mfx_w_getV(const mfx_table_view &t, mfx_u128 f,
 }
 
 // -hist (merfin-histogram.C:54-91): tile li of the launch is evaluated by block li % gridDim.x
+#ifndef MFX_W_BATCH
+#define MFX_W_BATCH 2          // positions of a lane whose first-slot loads are in flight together (1, 2, 4 measure alike: profiles/r04_wide_hist.txt)
+#endif
+#ifndef MFX_W_MINBLOCKS
+#define MFX_W_MINBLOCKS 1
+#endif
 template <bool CANON>
-__global__ __launch_bounds__(MFX_BLOCK) void mfx_w_hist_kernel(mfx_hist_args a) {
+__global__ __launch_bounds__(MFX_BLOCK, MFX_W_MINBLOCKS) void mfx_w_hist_kernel(mfx_hist_args a) {
   __shared__ mfx_tile_lds L;
   __shared__ mfx_hist_lds H;
   const uint32_t tid = threadIdx.x;
@@ -224,14 +234,57 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_w_hist_kernel(mfx_hist_args a) 
     __syncthreads();
     uint64_t n_valid = 0, n_missing = 0, zz = 0;
     double kover = 0.0;
-    for (uint32_t b = 0; b < MFX_TILE / MFX_BLOCK; ++b) {
-      if (b * MFX_BLOCK >= n) break;
-      const uint32_t p = b * MFX_BLOCK + tid;
-      mfx_u128 f;
-      if (!(mfx_w_tile_kmer(L, k, p, f) && p < n)) continue;
-      const uint2 v = mfx_w_getV<CANON>(a.t, f, k);
-      n_valid++;                                             // merfin-histogram.C:58
-      if (mfx_hist_eval(H, ka, lut_ok, v.x, v.y, n_over0, kover)) n_missing++;
+    if (CANON) {
+      // WB positions of a lane per pass: the first slot of each k-mer's order (32 bytes: where ~3 of 4 lookups end) is loaded
+      // for all of them before any is looked at -- WB independent line fetches in flight per lane instead of one; the positions
+      // are evaluated in the order the one-at-a-time loop took them (the lane's koverCpy terms add up in the same order)
+      constexpr uint32_t WB = MFX_W_BATCH;
+      const mfx_wslot *S = mfx_w_slots(a.t);
+      for (uint32_t b0 = 0; b0 < MFX_TILE / MFX_BLOCK; b0 += WB) {
+        if (b0 * MFX_BLOCK >= n) break;
+        uint64_t lo[WB], hi[WB], line[WB];
+        uint32_t q0[WB];
+        bool ok[WB], pal[WB];
+        mfx_wslot s0[WB];
+#pragma unroll
+        for (uint32_t j = 0; j < WB; ++j) {
+          const uint32_t p = (b0 + j) * MFX_BLOCK + tid;
+          mfx_u128 f;
+          ok[j] = mfx_w_tile_kmer(L, k, p, f) && p < n;
+          const mfx_u128 r = mfx_w_revcomp(f, k);
+          const mfx_u128 key = f < r ? f : r;
+          pal[j] = f == r;                                   // even k: a palindrome is looked up as fmer and as rmer -- one slot, twice
+          lo[j] = (uint64_t)key; hi[j] = (uint64_t)(key >> 64);
+          line[j] = mfx_w_home(a.t, key, q0[j]);
+          s0[j].state = 0;
+          if (ok[j]) s0[j] = S[line[j] * MFX_WSLOTS_LINE + q0[j]];
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < WB; ++j) {
+          if (!ok[j]) continue;
+          uint2 v = make_uint2(0u, 0u);
+          if (s0[j].state != 0) {
+            if (s0[j].lo == lo[j] && s0[j].hi == hi[j]) {
+              uint32_t rv = s0[j].readV;
+              if (rv < a.t.minV || rv > a.t.maxV) rv = 0;    // merfin.C:199-200
+              v = make_uint2(rv, s0[j].asmV);
+            } else v = mfx_w_lookup_from(a.t, lo[j], hi[j], line[j], q0[j], 1u);
+          }
+          if (pal[j]) { v.x += v.x; v.y += v.y; }
+          n_valid++;                                         // merfin-histogram.C:58
+          if (mfx_hist_eval(H, ka, lut_ok, v.x, v.y, n_over0, kover)) n_missing++;
+        }
+      }
+    } else {
+      for (uint32_t b = 0; b < MFX_TILE / MFX_BLOCK; ++b) {
+        if (b * MFX_BLOCK >= n) break;
+        const uint32_t p = b * MFX_BLOCK + tid;
+        mfx_u128 f;
+        if (!(mfx_w_tile_kmer(L, k, p, f) && p < n)) continue;
+        const uint2 v = mfx_w_getV<CANON>(a.t, f, k);
+        n_valid++;                                           // merfin-histogram.C:58
+        if (mfx_hist_eval(H, ka, lut_ok, v.x, v.y, n_over0, kover)) n_missing++;
+      }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) kover = kover + __shfl_down(kover, off, 64);

@@ -6,11 +6,13 @@ set -u
 BASES=$1; K=$2; OUT=$(realpath -m $3)
 cd "$(dirname "$0")/.."
 ROOT=$PWD
-export TMPDIR=/tmp MFX_RATES_KINDS=seq
+export TMPDIR=/tmp
+if [ "$K" -le 31 ]; then export MFX_RATES_KINDS=seq; fi
+RE=${PMC_KERNEL_RE:-hist_kernel}                 # k > 31: the 128-bit kernels are mfx_w_hist_kernel
 mkdir -p "$(dirname "$OUT")"
 for CTR in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES; do
   D=/tmp/pmc_$$_$CTR
-  ( cd /tmp && timeout 900 rocprofv3 --pmc $CTR --kernel-include-regex mfx_hist_kernel --output-format csv -d $D -o pmc -- python $ROOT/tools/hist_rates_by_k.py $BASES $K ) > ${OUT}_pmc_$CTR.log 2>&1 || true
+  ( cd /tmp && timeout 900 rocprofv3 --pmc $CTR --kernel-include-regex $RE --output-format csv -d $D -o pmc -- python $ROOT/tools/hist_rates_by_k.py $BASES $K ) > ${OUT}_pmc_$CTR.log 2>&1 || true
   F=$(find $D -name '*counter_collection.csv' | head -1)
   if [ -n "$F" ]; then cp "$F" ${OUT}_pmc_$CTR.csv; fi
   rm -rf $D
@@ -26,7 +28,7 @@ out, bases, k = sys.argv[1], float(sys.argv[2]), int(sys.argv[3])
 vals = {}
 for f in glob.glob(out + "_pmc_*.csv"):
     for row in csv.DictReader(open(f)):
-        if "mfx_hist_kernel" in row.get("Kernel_Name", ""):
+        if "hist_kernel" in row.get("Kernel_Name", ""):
             vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
 n = bases - k + 1
 for c, v in sorted(vals.items()):
