@@ -3391,15 +3391,20 @@ static int dump_contig_impl(const mfx_eval *ev, const mfx_seq *seq, uint32_t con
     const uint64_t cnt = e - o, per = (cnt + nthr - 1) / nthr;
     const uint32_t *rv = rvb[b].data(), *av = avb[b].data();
     t0 = now();
+    std::atomic<bool> fmt_ok{true};
     {
       std::vector<std::thread> th;
       for (unsigned t = 0; t < nthr; ++t) {
         const uint64_t bb = std::min(cnt, t * per), n = std::min(cnt, bb + per) - bb;
-        th.emplace_back([&, t, bb, n]() { dump_format_range(kp, name, name_len, o + bb, n, rv + bb, av + bb, parts[t], used[t]); });
+        th.emplace_back([&, t, bb, n]() {
+          try { dump_format_range(kp, name, name_len, o + bb, n, rv + bb, av + bb, parts[t], used[t]); }
+          catch (const std::bad_alloc &) { used[t] = 0; fmt_ok = false; }
+        });
       }
       for (auto &x : th) x.join();
     }
     t_format += now() - t0;
+    if (!fmt_ok) { rc = mfx_fail(MFX_E_NOMEM, "out of host memory while formatting the dump of '%s'", name); break; }
     t0 = now();
     if (plain) {
       std::vector<uint64_t> at(nthr + 1, file_off);
@@ -3414,6 +3419,7 @@ static int dump_contig_impl(const mfx_eval *ev, const mfx_seq *seq, uint32_t con
           uint64_t off = at[t];
           while (left) {
             const ssize_t r = pwrite(fd, p, std::min<size_t>(left, 64u << 20), (off_t)off);
+            if (r < 0 && errno == EINTR) continue;
             if (r <= 0) { wok = false; return; }
             p += r; left -= (size_t)r; off += (uint64_t)r;
           }
