@@ -175,6 +175,10 @@ int        mfx_index_count_claimed(mfx_index *ix, const mfx_seq *seq, void *stre
  * process (merfin-globals.C:182-186): counts the canonical k-mers of every
  * contig of `seq` into the assembly side of the index, on the GPU. */
 int mfx_index_count_asm(mfx_index *ix, const mfx_seq *seq, void *stream);
+/* mfx_index_count_asm(ix, seq, 0) followed by mfx_index_load_db(ix, read_db_path, 0, minV, maxV) as one call: the database's
+ * bytes cross PCIe while the sequence's k-mers are still being claimed and counted (the inserts wait for that kernel on the
+ * device).  Same table as the two calls.  Replaces load_Kmers + the `meryl count` of -sequence, merfin-globals.C:114-163,182-186. */
+int mfx_index_build_for_hist(mfx_index *ix, const mfx_seq *seq, const char *read_db_path, uint64_t minV, uint64_t maxV);
 
 /* merylExactLookup::value(kmer), merfin-globals.C:107-108, batched: for each
  * query returns the stored read and asm counts (0 when absent).  Queries are

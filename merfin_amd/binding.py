@@ -63,7 +63,7 @@ _lib = None
 SYMBOLS = [
     "mfx_last_error", "mfx_last_error_code", "mfx_version", "mfx_device_count", "mfx_device_warm",
     "mfx_index_create", "mfx_index_free", "mfx_index_estimate_gb", "mfx_index_add_read", "mfx_index_add_asm",
-    "mfx_index_count_asm", "mfx_index_count_claimed", "mfx_hist_run_parts", "mfx_index_create_for_seq", "mfx_index_estimate_gb_for_seq", "mfx_index_claim_seq", "mfx_index_value", "mfx_index_get_info", "mfx_index_export",
+    "mfx_index_count_asm", "mfx_index_build_for_hist", "mfx_index_count_claimed", "mfx_hist_run_parts", "mfx_index_create_for_seq", "mfx_index_estimate_gb_for_seq", "mfx_index_claim_seq", "mfx_index_value", "mfx_index_get_info", "mfx_index_export",
     "mfx_db_probe", "mfx_index_load_db", "mfx_index_load_db_multi", "mfx_db_write_flat", "mfx_db_convert", "mfx_index_save", "mfx_index_load",
     "mfx_index_set_fingerprint", "mfx_index_get_origin",
     "mfx_host_alloc", "mfx_host_free", "mfx_seq_create", "mfx_hist_run_streamed",
@@ -126,6 +126,7 @@ def load_library():
     L.mfx_index_add_asm.argtypes = [vp, vp, vp, C.c_uint64, C.c_int]
     L.mfx_index_count_asm.argtypes = [vp, vp, vp]
     L.mfx_index_count_claimed.argtypes = [vp, vp, vp]
+    L.mfx_index_build_for_hist.argtypes = [vp, vp, C.c_char_p, C.c_uint64, C.c_uint64]
     L.mfx_hist_run_parts.argtypes = [C.POINTER(vp), C.POINTER(vp), C.POINTER(C.POINTER(C.c_uint32)), C.c_uint32, C.c_uint32, vp]
     L.mfx_index_create_for_seq.restype = vp
     L.mfx_index_create_for_seq.argtypes = [C.c_int, C.c_uint64, C.c_double, C.c_int]
@@ -357,6 +358,10 @@ class Index:
     def count_claimed(self, seqs, stream=None):
         """asmV += 1 per occurrence, in `seqs`, of a k-mer claimed before (claim_seq); nothing is claimed"""
         _check(load_library().mfx_index_count_claimed(self.h, seqs.h, C.c_void_p(stream or 0)))
+
+    def build_for_hist(self, seqs, read_db_path, minV=0, maxV=2**64 - 1):
+        """count_asm(seqs) + load_db(read_db_path, 0, minV, maxV) in one call: the database crosses PCIe while the sequence's k-mers are claimed"""
+        _check(load_library().mfx_index_build_for_hist(self.h, seqs.h, read_db_path.encode(), minV, maxV))
 
     def claim_seq(self, seqs, stream=None):
         _check(load_library().mfx_index_claim_seq(self.h, seqs.h, C.c_void_p(stream or 0)))

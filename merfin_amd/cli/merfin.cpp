@@ -835,6 +835,7 @@ int main(int argc, char **argv) {
     }
     step("create the table");
     int lrc = 0;
+    bool fused = false;
     if (G.seqDBname) {
       fprintf(stderr, "-- Claiming the %d-mers of '%s' on the GPU.\n", k, G.seqName);
       if (mfx_index_claim_seq(ix, seq, nullptr)) DIE_MFX("claiming sequence k-mers");
@@ -846,10 +847,14 @@ int main(int argc, char **argv) {
     } else {
       // replaces `meryl count k=.. <seq> output <seq>.meryl` (merfin-globals.C:182-186)
       fprintf(stderr, "-- No -seqmer given. Counting the %d-mers of '%s' on the GPU.\n", k, G.seqName);
-      if (mfx_index_count_asm(ix, seq, nullptr)) DIE_MFX("counting sequence k-mers");
-      step("count the sequence's k-mers");
+      // (one call for the counting and the load of -readmers: the database crosses PCIe while the k-mers are claimed)
+      fprintf(stderr, "-- Loading kmers from '%s' into lookup table.\n", G.readDBname);
+      lrc = mfx_index_build_for_hist(ix, seq, G.readDBname, G.minV, G.maxV);
+      if (lrc && lrc != MFX_E_NONCANON) DIE_MFX("counting sequence k-mers / loading -readmers");
+      step("count the sequence's k-mers + load -readmers");
+      fused = true;
     }
-    if (!lrc) {
+    if (!lrc && !fused) {
       fprintf(stderr, "-- Loading kmers from '%s' into lookup table.\n", G.readDBname);
       lrc = mfx_index_load_db(ix, G.readDBname, 0, G.minV, G.maxV);
       if (lrc && lrc != MFX_E_NONCANON) DIE_MFX("loading -readmers");

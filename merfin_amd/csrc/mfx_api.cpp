@@ -449,34 +449,52 @@ static int index_check(mfx_index *ix) {
   return MFX_OK;
 }
 
-// Host -> table pipeline.  Two lanes of pinned staging + device buffers alternate: while lane A's chunk travels over
-// PCIe and is inserted, host threads fill lane B.  The lanes belong to the index and are REUSED by every load call
-// (pinning memory costs ~0.4 ms per MB: allocating them per call was 3.5 s of a 5.1 s ingest at 1 Gb); they are
-// released with the index (or by mfx_index_ingest_release once the loading is over).
+// Host -> table pipeline.  LANES of pinned staging are filled by the host and emptied over PCIe into a RING of device
+// buffers; the insert kernel of a chunk runs on the device buffer.  The two are decoupled (round 4): a lane is free again
+// as soon as its chunk has crossed the link, a device buffer once its chunk is inserted -- so the transfers run ahead of
+// the inserts by the depth of the ring (up to MFX_INGEST_RING_BYTES, 3 GB), e.g. while the kernel that claims the
+// sequence's k-mers is still running (mfx_index_build_for_hist: the inserts wait for it, the link does not).
+// Lanes and ring belong to the index and are REUSED by every load call (pinning memory costs ~0.4 ms per MB: allocating
+// them per call was 3.5 s of a 5.1 s ingest at 1 Gb); they are released with the index (or by mfx_index_ingest_release).
 constexpr uint64_t MFX_INGEST_CHUNK = 1ull << 24;           // k-mers per lane: 128 MB of keys + 64 MB of counts
-constexpr int MFX_INGEST_MAX_LANES = 4;
+constexpr int MFX_INGEST_MAX_LANES = 4, MFX_INGEST_MAX_RING = 64, MFX_INGEST_STREAMS = 4;
 struct mfx_ingest {
   struct Lane {
-    uint64_t *hk = nullptr, *dk = nullptr;
-    uint32_t *hv = nullptr, *dv = nullptr;
-    hipEvent_t done = nullptr;
-    hipStream_t st = nullptr;    // a stream per lane: the transfer of one lane's chunk runs under the insert kernel of the other's
+    uint64_t *hk = nullptr;
+    uint32_t *hv = nullptr;
+    hipEvent_t copied = nullptr;   // the lane's chunk has left the pinned buffer (recorded on the copy stream)
     bool busy = false;
   } L[MFX_INGEST_MAX_LANES];
-  int nl = 2;                  // lanes in use: fill | H2D | insert of three chunks overlap with >= 3 (MFX_INGEST_LANES)
+  struct Dev {
+    uint64_t *dk = nullptr;
+    uint32_t *dv = nullptr;
+    hipEvent_t done = nullptr;     // the buffer's chunk is inserted
+    bool busy = false;
+  } D[MFX_INGEST_MAX_RING];
+  hipStream_t cs = nullptr;                                  // the copy stream
+  hipStream_t is[MFX_INGEST_STREAMS] = {nullptr, nullptr, nullptr, nullptr};   // insert streams, ring buffer r uses is[r % 4]
+  hipEvent_t after = nullptr;  // inserts wait for this event (the claim / count kernel of mfx_index_build_for_hist); owned here
+  int nl = 2;                  // lanes in use (MFX_INGEST_LANES)
+  int nd = 2;                  // ring buffers in use
   uint64_t cap = 0;            // k-mers per lane
   size_t kw = 1;
 };
 
 static void ingest_free(mfx_ingest *g) {
   if (!g) return;
+  if (g->cs) { (void)hipStreamSynchronize(g->cs); }
+  for (auto &st : g->is) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+  if (g->cs) (void)hipStreamDestroy(g->cs);
+  if (g->after) { (void)hipEventSynchronize(g->after); (void)hipEventDestroy(g->after); }
   for (auto &l : g->L) {
-    if (l.st) { (void)hipStreamSynchronize(l.st); (void)hipStreamDestroy(l.st); }
     if (l.hk) (void)hipHostFree(l.hk);
     if (l.hv) (void)hipHostFree(l.hv);
-    if (l.dk) (void)hipFree(l.dk);
-    if (l.dv) (void)hipFree(l.dv);
-    if (l.done) (void)hipEventDestroy(l.done);
+    if (l.copied) (void)hipEventDestroy(l.copied);
+  }
+  for (auto &d : g->D) {
+    if (d.dk) (void)hipFree(d.dk);
+    if (d.dv) (void)hipFree(d.dv);
+    if (d.done) (void)hipEventDestroy(d.done);
   }
   delete g;
 }
@@ -494,25 +512,45 @@ static mfx_ingest *ingest_get(mfx_index *ix, uint64_t n) {
   const uint64_t want = std::min<uint64_t>(std::max<uint64_t>(n, 1), chunk);
   // lanes of 4 M k-mers or more serve any load (it goes through them in chunks): re-pinning larger ones costs more than they save
   if (ix->ingest && (ix->ingest->cap >= want || ix->ingest->cap >= (1ull << 22))) return ix->ingest;
+  hipEvent_t keep_after = nullptr;                          // (an event the inserts must wait for survives a re-sizing of the lanes)
+  if (ix->ingest) { keep_after = ix->ingest->after; ix->ingest->after = nullptr; }
   mfx_index_ingest_release(ix);
   // small loads (tests, single contigs) get small lanes; the first large one gets the full-size lanes
   uint64_t cap = 1ull << 16;
   while (cap < want) cap <<= 1;
   mfx_ingest *g = new mfx_ingest;
+  g->after = keep_after;
   g->cap = cap;
   g->kw = ix->key_words();
-  // three or more lanes let the fill of a chunk, the transfer of the one before and the insert of the one before that overlap (two
-  // lanes: a lane's transfer and insert run one behind the other while only ONE other chunk is filled); small loads keep two
-  // (pinning costs 0.4 ms per MB)
+  // three or more lanes let the fill of a chunk, the transfer of the one before and the insert of the one before that overlap;
+  // small loads keep two (pinning costs 0.4 ms per MB)
   g->nl = cap >= (1ull << 20) ? 4 : 2;
   if (const char *e = getenv("MFX_INGEST_LANES")) { const int v = atoi(e); if (v >= 2 && v <= MFX_INGEST_MAX_LANES) g->nl = v; }
-  bool ok = true;
-  for (int li = 0; li < g->nl; ++li) {
+  // the ring: as many device buffers as MFX_INGEST_RING_BYTES hold (large loads), never fewer than the lanes
+  const uint64_t buf_bytes = cap * 8 * g->kw + cap * 4;
+  uint64_t ring_bytes = cap >= (1ull << 20) ? (3ull << 30) : 0;
+  if (const char *e = getenv("MFX_INGEST_RING_MB")) ring_bytes = (uint64_t)std::max(0, atoi(e)) << 20;
+  g->nd = (int)std::min<uint64_t>(MFX_INGEST_MAX_RING, std::max<uint64_t>((uint64_t)g->nl, ring_bytes / buf_bytes));
+  bool ok = hipStreamCreateWithFlags(&g->cs, hipStreamNonBlocking) == hipSuccess;
+  for (int si = 0; si < MFX_INGEST_STREAMS && ok; ++si) ok = hipStreamCreateWithFlags(&g->is[si], hipStreamNonBlocking) == hipSuccess;
+  for (int li = 0; li < g->nl && ok; ++li) {
     auto &l = g->L[li];
-    ok = ok && hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking) == hipSuccess && hipHostMalloc((void **)&l.hk, cap * 8 * g->kw, hipHostMallocPortable) == hipSuccess &&      // DMA source for any device
+    ok = hipHostMalloc((void **)&l.hk, cap * 8 * g->kw, hipHostMallocPortable) == hipSuccess &&      // DMA source for any device
          hipHostMalloc((void **)&l.hv, cap * 4, hipHostMallocPortable) == hipSuccess &&
-         hipMalloc((void **)&l.dk, cap * 8 * g->kw) == hipSuccess && hipMalloc((void **)&l.dv, cap * 4) == hipSuccess &&
-         hipEventCreateWithFlags(&l.done, hipEventDisableTiming) == hipSuccess;
+         hipEventCreateWithFlags(&l.copied, hipEventDisableTiming) == hipSuccess;
+  }
+  for (int di = 0; di < g->nd && ok; ++di) {
+    auto &d = g->D[di];
+    const bool got = hipMalloc((void **)&d.dk, cap * 8 * g->kw) == hipSuccess && hipMalloc((void **)&d.dv, cap * 4) == hipSuccess &&
+                     hipEventCreateWithFlags(&d.done, hipEventDisableTiming) == hipSuccess;
+    if (!got) {
+      (void)hipGetLastError();
+      if (d.dk) { (void)hipFree(d.dk); d.dk = nullptr; }
+      if (d.dv) { (void)hipFree(d.dv); d.dv = nullptr; }
+      if (d.done) { (void)hipEventDestroy(d.done); d.done = nullptr; }
+      if (di >= g->nl) { g->nd = di; break; }                // a shorter ring will do (the HBM is full of table)
+      ok = false;
+    }
   }
   if (!ok) { (void)hipGetLastError(); ingest_free(g); return nullptr; }
   ix->ingest = g;
@@ -550,11 +588,18 @@ static int index_ingest_chunks(mfx_index *const *ixs, uint32_t nix, uint64_t n_h
   bool ok = true, src_ok = true;
   int nl = gs[0]->nl;
   for (uint32_t i = 1; i < nix; ++i) nl = std::min(nl, gs[i]->nl);
+  // the inserts of a table wait for whatever still claims its k-mers (mfx_index_build_for_hist); the transfers do not
+  for (uint32_t i = 0; i < nix && ok; ++i)
+    if (gs[i]->after) {
+      DevGuard dg(ixs[i]->device);
+      for (auto &st : gs[i]->is) if (hipStreamWaitEvent(st, gs[i]->after, 0) != hipSuccess) ok = false;
+    }
+  std::vector<uint64_t> ring_at(nix, 0);                     // chunks sent to table i so far: chunk c lands in ring buffer c % nd
   for (int cur = 0; ok; cur = (cur + 1) % nl) {
     const double t0 = now();
     for (uint32_t i = 0; i < nix && ok; ++i) {               // the lane's previous chunk has left the pinned buffer everywhere
       mfx_ingest::Lane &l = gs[i]->L[cur];
-      if (l.busy) { DevGuard dg(ixs[i]->device); if (hipEventSynchronize(l.done) != hipSuccess) ok = false; }
+      if (l.busy) { DevGuard dg(ixs[i]->device); if (hipEventSynchronize(l.copied) != hipSuccess) ok = false; }
       l.busy = false;
     }
     if (!ok) break;
@@ -568,21 +613,37 @@ static int index_ingest_chunks(mfx_index *const *ixs, uint32_t nix, uint64_t n_h
     ++nchunks; nbytes += d.kbytes + d.vbytes;
     for (uint32_t i = 0; i < nix && ok; ++i) {
       mfx_index *ix = ixs[i];
-      mfx_ingest::Lane &l = gs[i]->L[cur];
+      mfx_ingest *g = gs[i];
+      const int r = (int)(ring_at[i]++ % (uint64_t)g->nd);
+      mfx_ingest::Dev &dv = g->D[r];
+      hipStream_t ist = g->is[r % MFX_INGEST_STREAMS];
       DevGuard dg(ix->device);
-      ok = (d.kbytes == 0 || hipMemcpyAsync(l.dk, src.hk, d.kbytes, hipMemcpyHostToDevice, l.st) == hipSuccess) &&
-           (d.vbytes == 0 || hipMemcpyAsync(l.dv, src.hv, d.vbytes, hipMemcpyHostToDevice, l.st) == hipSuccess) &&
-           d.launch(ix, l.dk, l.dv, l.st) == hipSuccess && hipEventRecord(l.done, l.st) == hipSuccess;
-      l.busy = true;
+      // the ring buffer is free once its previous chunk is inserted: the COPY STREAM waits for that, not the host
+      ok = (!dv.busy || hipStreamWaitEvent(g->cs, dv.done, 0) == hipSuccess) &&
+           (d.kbytes == 0 || hipMemcpyAsync(dv.dk, src.hk, d.kbytes, hipMemcpyHostToDevice, g->cs) == hipSuccess) &&
+           (d.vbytes == 0 || hipMemcpyAsync(dv.dv, src.hv, d.vbytes, hipMemcpyHostToDevice, g->cs) == hipSuccess) &&
+           hipEventRecord(g->L[cur].copied, g->cs) == hipSuccess &&
+           hipStreamWaitEvent(ist, g->L[cur].copied, 0) == hipSuccess &&
+           d.launch(ix, dv.dk, dv.dv, ist) == hipSuccess && hipEventRecord(dv.done, ist) == hipSuccess;
+      g->L[cur].busy = true;
+      dv.busy = true;
     }
   }
   for (uint32_t i = 0; i < nix; ++i) {
     DevGuard dg(ixs[i]->device);
-    for (int li = 0; li < gs[i]->nl; ++li) { if (hipStreamSynchronize(gs[i]->L[li].st) != hipSuccess) ok = false; gs[i]->L[li].busy = false; }
+    if (hipStreamSynchronize(gs[i]->cs) != hipSuccess) ok = false;
+    for (auto &st : gs[i]->is) if (hipStreamSynchronize(st) != hipSuccess) ok = false;
+    for (int li = 0; li < gs[i]->nl; ++li) gs[i]->L[li].busy = false;
+    for (int di = 0; di < gs[i]->nd; ++di) gs[i]->D[di].busy = false;
+    if (gs[i]->after) {                                      // what the inserts waited for is over as well: its errors are in meta
+      if (hipEventSynchronize(gs[i]->after) != hipSuccess) ok = false;
+      (void)hipEventDestroy(gs[i]->after);
+      gs[i]->after = nullptr;
+    }
   }
   if (timing)
-    fprintf(stderr, "-- ingest: %.3f s = lanes %.3f (cap %llu) + fill %.3f + waits for the device %.3f + drain; %llu chunks, %.2f GB over the link\n",
-            now() - t_begin, t_lanes, (unsigned long long)cap, t_fill, t_wait, (unsigned long long)nchunks, nbytes / 1e9);
+    fprintf(stderr, "-- ingest: %.3f s = lanes %.3f (cap %llu, ring %d) + fill %.3f + waits for the link %.3f + drain; %llu chunks, %.2f GB over the link\n",
+            now() - t_begin, t_lanes, (unsigned long long)cap, gs[0]->nd, t_fill, t_wait, (unsigned long long)nchunks, nbytes / 1e9);
   if (!ok) return mfx_fail(MFX_E_HIP, "mfx_index_add: transfer / insert failed: %s", hipGetErrorString(hipGetLastError()));
   if (!src_ok) return mfx_last_error_code() ? mfx_last_error_code() : MFX_E_IO;
   for (uint32_t i = 0; i < nix; ++i) {
@@ -778,7 +839,10 @@ extern "C" int mfx_index_add_asm(mfx_index *ix, const uint64_t *kmers, const uin
   return index_add(ix, kmers, values, n, 1, on_device);
 }
 
-static int index_count(mfx_index *ix, const mfx_seq *seq, int count, void *stream, const char *who) {
+// defer: the kernel is launched and NOT waited for -- an event recorded behind it is left in the index's staging state
+// (mfx_ingest::after), the inserts of the load that follows wait for it on the device, and that load's final check reads what
+// both left in meta (mfx_index_build_for_hist)
+static int index_count(mfx_index *ix, const mfx_seq *seq, int count, void *stream, const char *who, bool defer = false) {
   if (!ix || !seq) return mfx_fail(MFX_E_INVAL, "%s: null argument", who);
   if (ix->device != seq->device) return mfx_fail(MFX_E_INVAL, "index and sequence live on different devices");
   if (ix->seq_only && ix->frozen && count != 2)
@@ -803,9 +867,30 @@ static int index_count(mfx_index *ix, const mfx_seq *seq, int count, void *strea
   MFX_HIP(ix->wide() ? mfx_kw_count(a, (hipStream_t)stream) : mfx_k_count(a, (hipStream_t)stream));
   // While the kernel claims / counts a large sequence's k-mers (0.11 s for 3 Gb), the host pins the staging lanes the database
   // load that follows will want (0.06 s): the lanes belong to the index and are reused by every load.
-  if (ix->seq_only && seq->total_bases >= (256ull << 20)) (void)ingest_get(ix, 1ull << 22);
+  if (defer) {
+    hipEvent_t ev = nullptr;
+    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(ev, (hipStream_t)stream);
+    mfx_ingest *g = e == hipSuccess ? ingest_get(ix, 1ull << 22) : nullptr;      // (pins the lanes while the kernel runs)
+    if (g) {
+      if (g->after) { (void)hipEventSynchronize(g->after); (void)hipEventDestroy(g->after); }
+      g->after = ev;
+      return MFX_OK;
+    }
+    if (ev) (void)hipEventDestroy(ev);
+    (void)hipGetLastError();                                  // no staging state: fall through to the waited form
+  } else if (ix->seq_only && seq->total_bases >= (256ull << 20)) (void)ingest_get(ix, 1ull << 22);
   MFX_HIP(hipStreamSynchronize((hipStream_t)stream));
   return index_check(ix);
+}
+
+// an event the inserts were to wait for is waited for here and dropped (error paths of mfx_index_build_for_hist)
+static void ingest_settle_after(mfx_index *ix) {
+  if (!ix || !ix->ingest || !ix->ingest->after) return;
+  DevGuard g(ix->device);
+  (void)hipEventSynchronize(ix->ingest->after);
+  (void)hipEventDestroy(ix->ingest->after);
+  ix->ingest->after = nullptr;
 }
 
 extern "C" int mfx_index_count_asm(mfx_index *ix, const mfx_seq *seq, void *stream) {
@@ -818,6 +903,20 @@ extern "C" int mfx_index_count_asm(mfx_index *ix, const mfx_seq *seq, void *stre
 // (`meryl count` of -sequence counts every contig, merfin-globals.C:182-186), and the read database then updates them.
 extern "C" int mfx_index_count_claimed(mfx_index *ix, const mfx_seq *seq, void *stream) {
   return index_count(ix, seq, 2, stream, "mfx_index_count_claimed");
+}
+
+// mfx_index_count_asm + mfx_index_load_db(side 0) as ONE call -- what `merfin -hist -sequence s -readmers db` needs
+// (load_Kmers, merfin-globals.C:114-163 + the `meryl count` of -sequence, :182-186) -- with the database's bytes crossing
+// PCIe while the sequence's k-mers are still being claimed and counted: the inserts wait for that kernel on the device,
+// the transfers fill the staging ring meanwhile.  Same table as the two calls one after the other.
+extern "C" int mfx_index_build_for_hist(mfx_index *ix, const mfx_seq *seq, const char *read_db_path, uint64_t minV, uint64_t maxV) {
+  if (!ix || !seq || !read_db_path) return mfx_fail(MFX_E_INVAL, "mfx_index_build_for_hist: null argument");
+  const char *ov = getenv("MFX_BUILD_OVERLAP");              // 0: the two calls one after the other (A/B, tests)
+  const bool defer = !(ov && atoi(ov) == 0);
+  int rc = index_count(ix, seq, 1, nullptr, "mfx_index_build_for_hist", defer);
+  if (rc == MFX_OK) rc = mfx_index_load_db(ix, read_db_path, 0, minV, maxV);
+  ingest_settle_after(ix);                                   // (a load that failed before its staging loop leaves the event behind)
+  return rc;
 }
 
 extern "C" int mfx_index_claim_seq(mfx_index *ix, const mfx_seq *seq, void *stream) {

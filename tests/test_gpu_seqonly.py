@@ -390,3 +390,87 @@ def test_mod_minimizer_placement_every_k(k, monkeypatch):
         np.testing.assert_array_equal(av, asm[1][::7])
         for kk in env:
             monkeypatch.delenv(kk)
+
+
+def _export_sorted(ix):
+    k_, r_, a_ = ix.export()
+    o = np.argsort(k_, kind="stable") if k_.ndim == 1 else np.lexsort((k_[:, 0], k_[:, 1]))
+    return k_[o], r_[o], a_[o]
+
+
+@pytest.mark.parametrize("k,form,env", [(21, "flat", {}), (31, "flat", {}), (21, "text", {}),
+                                        (21, "flat", {"MFX_INGEST_CHUNK_LOG2": "16", "MFX_INGEST_RING_MB": "1"}),      # many chunks through a two-buffer ring
+                                        (21, "flat", {"MFX_INGEST_CHUNK_LOG2": "16", "MFX_INGEST_RING_MB": "64"}),     # ... and through a ring deeper than the load
+                                        (41, "flat", {})])
+def test_build_for_hist_equals_count_then_load(k, form, env, tmp_path, monkeypatch):
+    """mfx_index_build_for_hist (the claim / count kernel still running while the database's chunks cross the link; the inserts
+    wait for it on the device) builds the table mfx_index_count_asm + mfx_index_load_db build, -min / -max included; the staging
+    ring smaller and larger than the load; the 128-bit tables through the same call"""
+    from oracle import plain
+    m = _mfx()
+    peak = 17.3
+    if k > 31:
+        from tests.test_gpu_wide import small_world, to_rows
+        wc, R, _A = small_world(k, 77, n=7000)
+        contigs = [c.encode() for c in wc]
+        rk = sorted(R)
+        read = (to_rows(rk), np.array([R[x] for x in rk], dtype=np.uint32))
+        asm = None
+    else:
+        contigs, read, asm = synth.world(k=k, peak=peak, seed=21 + k)
+    if k <= 31:
+        # enough k-mers for several chunks of 2^16: the read database repeated with other counts would change nothing (update-only
+        # of the same k-mers), so pad it with k-mers that are NOT in the sequence (dropped by the index, still staged and decoded)
+        rng = np.random.default_rng(5)
+        extra = np.unique(rng.integers(0, 1 << (2 * k - 1), 300000, dtype=np.uint64))
+        x, r = extra.copy(), np.zeros_like(extra)
+        for _ in range(k):                                        # reverse complement: base order reversed, code ^ 2
+            r = (r << np.uint64(2)) | ((x & np.uint64(3)) ^ np.uint64(2))
+            x >>= np.uint64(2)
+        canon = np.minimum(extra, r)
+        canon = np.setdiff1d(np.unique(canon), read[0])
+        keys = np.concatenate([read[0], canon])
+        vals = np.concatenate([read[1], np.full(len(canon), 3, dtype=np.uint32)])
+        o = np.argsort(keys, kind="stable")
+        keys, vals = keys[o], vals[o]
+    else:
+        keys, vals = read
+    path = str(tmp_path / ("r.mfxk" if form == "flat" else "r.txt"))
+    if form == "flat":
+        m.db_write_flat(path, k, keys, vals)
+    else:
+        with open(path, "w") as f:
+            for kk, vv in zip(keys.tolist(), vals.tolist()):
+                f.write("%s\t%d\n" % (plain.dec(kk, k), vv))
+    for name, value in env.items():
+        monkeypatch.setenv(name, value)
+    seqs = m.Sequences(contigs)
+    lo, hi = 2, 1000
+
+    def two_calls():
+        ix = m.Index.for_seq(k, sum(len(c) for c in contigs) + 16) if k <= 31 else m.Index(k, len(keys) + sum(len(c) for c in contigs) + 16)
+        ix.count_asm(seqs)
+        ix.load_db(path, 0, lo, hi)
+        return ix
+
+    def one_call(overlap):
+        monkeypatch.setenv("MFX_BUILD_OVERLAP", overlap)
+        ix = m.Index.for_seq(k, sum(len(c) for c in contigs) + 16) if k <= 31 else m.Index(k, len(keys) + sum(len(c) for c in contigs) + 16)
+        ix.build_for_hist(seqs, path, lo, hi)
+        monkeypatch.delenv("MFX_BUILD_OVERLAP")
+        return ix
+    want = _export_sorted(two_calls())
+    for overlap in ("1", "0", "1"):
+        ix = one_call(overlap)
+        got = _export_sorted(ix)
+        for a_, b_ in zip(got, want):
+            np.testing.assert_array_equal(a_, b_)
+        # the index stays usable: a second load through the same lanes adds the same counts again
+        ix.load_db(path, 0, lo, hi)
+        again = _export_sorted(ix)
+        np.testing.assert_array_equal(again[0], want[0])
+        rv2 = want[1].astype(np.uint64) * 2
+        np.testing.assert_array_equal(again[1].astype(np.uint64), rv2)
+    if k <= 31:
+        p, g, ka, km = oracle_hist(k, peak, contigs, (read[0], np.where((read[1] >= lo) & (read[1] <= hi), read[1], 0).astype(np.uint32)), asm)
+        assert_hist_equal(m.Evaluator(one_call("1"), m.KParams(peak)).hist(seqs), g, ka, km, k)

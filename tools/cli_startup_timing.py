@@ -24,10 +24,13 @@ def main():
         exe = os.path.join(ROOT, "merfin_amd", "bin", "merfin")
         prob = os.path.join(ROOT, "tests", "golden", "example_lookup_table.txt")
         cmd = [exe, "-hist", "-sequence", inp["fasta"], "-readmers", inp["readdb"], "-peak", "26", "-prob", prob, "-output", os.path.join(tmp, "o.hist")]
-        for variant in ({}, {}, {}, {"MFX_CLI_WARM": "0"}, {"MFX_CLI_WARM": "0"}, {}, {"MFX_CLI_WARM": "0"}):
+        variants = ({}, {}, {}, {"MFX_CLI_WARM": "0"}, {"MFX_CLI_WARM": "0"}, {}, {"MFX_CLI_WARM": "0"})
+        if os.environ.get("MFX_CST_VARIANTS") == "overlap":
+            variants = ({}, {"MFX_BUILD_OVERLAP": "0"}, {}, {"MFX_BUILD_OVERLAP": "0"}, {"MFX_INGEST_RING_MB": "0"}, {}, {"MFX_BUILD_OVERLAP": "0"}, {"MFX_INGEST_RING_MB": "0"})
+        for variant in variants:
             time.sleep(3)
             t0 = time.time()
-            r = subprocess.run(cmd, stdin=subprocess.DEVNULL, capture_output=True, text=True, env=dict(os.environ, MFX_CLI_TIMING="3", MFX_UPLOAD_TIMING="1", MFX_CLI_SEQ_TIMING="1", **variant))
+            r = subprocess.run(cmd, stdin=subprocess.DEVNULL, capture_output=True, text=True, env=dict(os.environ, MFX_CLI_TIMING="3", MFX_UPLOAD_TIMING="1", MFX_CLI_SEQ_TIMING="1", MFX_INGEST_TIMING="1", **variant))
             t1 = time.time()
             st_ = [l for l in r.stderr.splitlines() if l.startswith("-- stamps:")]
             ph = [l for l in r.stderr.splitlines() if l.startswith("-- timing:")]
@@ -40,7 +43,7 @@ def main():
                   (variant or "(default)", t1 - t0, t_main - t0, t_dev - t_main, t_end - t_dev, t1 - t_end), flush=True)
             print("     " + (ph[0] if ph else ""), flush=True)
             for l in r.stderr.splitlines():
-                if l.startswith(("-- upload", "-- read_fasta_parallel", "-- timing (index)")):
+                if l.startswith(("-- upload", "-- read_fasta_parallel", "-- timing (index)", "-- ingest")):
                     print("     " + l, flush=True)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

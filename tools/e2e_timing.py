@@ -27,6 +27,7 @@ try:
     time.sleep(3)                                               # let the writer's threads and the driver settle: the first run is the figure of a quiet box
     for rep in range(2):
         for env in envs:
+            time.sleep(3)
             rc, wall, ph, err = e2e_inputs.run_cli_hist(ROOT, inp, prob=prob, out_hist=os.path.join(tmp, "o.hist"), env=dict(env, MFX_INGEST_TIMING="1"))
             h = open(os.path.join(tmp, "o.hist")).read() if rc == 0 else None
             ref = ref or h
