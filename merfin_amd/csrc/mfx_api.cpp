@@ -2078,6 +2078,8 @@ static int seq_upload_packed(mfx_seq *seq, const char *const *bases) {
   };
   tm[3] = now();
   if (ok) {
+    // (not spread over the L3 domains: 3 Gb are encoded + copied in 0.024-0.034 s as the threads fall, 0.034-0.070 s pinned; what an upload costs
+    // is its device buffers -- 0.05-0.15 s for 3 GB: profiles/r04_cli_startup_1gb.txt)
     pool.reset(new WorkerPool(W));
     pool->start(work);
     for (size_t ci = 0; ci < chunks.size() && ok; ++ci) {

@@ -25,6 +25,8 @@ def main():
         prob = os.path.join(ROOT, "tests", "golden", "example_lookup_table.txt")
         cmd = [exe, "-hist", "-sequence", inp["fasta"], "-readmers", inp["readdb"], "-peak", "26", "-prob", prob, "-output", os.path.join(tmp, "o.hist")]
         variants = ({}, {}, {}, {"MFX_CLI_WARM": "0"}, {"MFX_CLI_WARM": "0"}, {}, {"MFX_CLI_WARM": "0"})
+        if os.environ.get("MFX_CST_VARIANTS") == "upload":
+            variants = ({}, {"MFX_POOL_SPREAD": "0"}, {}, {"MFX_POOL_SPREAD": "0"})
         if os.environ.get("MFX_CST_VARIANTS") == "overlap":
             variants = ({}, {"MFX_BUILD_OVERLAP": "0"}, {}, {"MFX_BUILD_OVERLAP": "0"}, {"MFX_INGEST_RING_MB": "0"}, {}, {"MFX_BUILD_OVERLAP": "0"}, {"MFX_INGEST_RING_MB": "0"})
         for variant in variants:
@@ -43,7 +45,7 @@ def main():
                   (variant or "(default)", t1 - t0, t_main - t0, t_dev - t_main, t_end - t_dev, t1 - t_end), flush=True)
             print("     " + (ph[0] if ph else ""), flush=True)
             for l in r.stderr.splitlines():
-                if l.startswith(("-- upload", "-- read_fasta_parallel", "-- timing (index)", "-- ingest")):
+                if l.startswith(("-- upload", "-- packed upload", "-- read_fasta_parallel", "-- timing (index)", "-- ingest")):
                     print("     " + l, flush=True)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
