@@ -849,11 +849,14 @@ static int index_count(mfx_index *ix, const mfx_seq *seq, int count, void *strea
     return mfx_fail(MFX_E_INVAL, "%s: this sequence-only index already took counts; its k-mers must all be claimed before the first add / load "
                     "(a k-mer claimed now would have missed them)", who);
   if (count == 2 && (!ix->seq_only || ix->wide())) return mfx_fail(MFX_E_INVAL, "%s: counting claimed k-mers needs a sequence-only index (mfx_index_create_for_seq)", who);
-  if (int erc = mfx_seq_ensure_ascii(seq)) return erc;
+  // the k <= 31 kernel reads the packed planes when the sequence has them (a packed upload never makes the bytes)
+  const bool from_planes = !ix->wide() && (seq->planes_ok || seq->bases_stale) && !(getenv("MFX_COUNT_ASCII") && atoi(getenv("MFX_COUNT_ASCII")));
+  if (!from_planes) if (int erc = mfx_seq_ensure_ascii(seq)) return erc;
   DevGuard g(ix->device);
   mfx_count_args a;
   a.t = ix->view();
   a.bases = seq->d_bases;
+  if (from_planes) { a.codes = seq->d_codes; a.valid = seq->d_valid; }
   a.contig_off = seq->d_contig_off;
   a.contig_len = seq->d_contig_len;
   a.tile_start = seq->d_tile_start;
@@ -1003,9 +1006,18 @@ static mfx_seq *seq_layout(int device, const uint64_t *lens, uint32_t ncontigs) 
   return s;
 }
 
-static int seq_alloc(mfx_seq *s) {
+// One byte per base (mfx_seq::d_bases) is what the 128-bit kernels, -dump, the router and the variant modes read; a sequence
+// that arrives packed and is only ever counted and evaluated by the k <= 31 -hist kernels never needs it (3 GB for a human assembly,
+// 0.05-0.15 s of its upload): it is made on first use (mfx_seq_ensure_ascii).
+static int seq_need_bases(mfx_seq *s) {
+  if (s->d_bases) return MFX_OK;
   MFX_HIP(hipMalloc((void **)&s->d_bases, s->buf_bytes));
   MFX_HIP(hipMemset(s->d_bases, 0, s->buf_bytes));                    // byte 0 is not ACGT: separators + padding
+  return MFX_OK;
+}
+
+static int seq_alloc(mfx_seq *s, bool with_bases = true) {
+  if (with_bases) if (int rc = seq_need_bases(s)) return rc;
   size_t nc = s->ncontigs ? s->ncontigs : 1;
   MFX_HIP(hipMalloc((void **)&s->d_contig_off, nc * sizeof(uint64_t)));
   MFX_HIP(hipMalloc((void **)&s->d_contig_len, nc * sizeof(uint64_t)));
@@ -1028,9 +1040,11 @@ static int seq_alloc(mfx_seq *s) {
 // A packed upload (mfx_hist_run_streamed) leaves the sequence in its packed planes only; the kernels that read one byte
 // per base get them unpacked here, once, on first use.
 int mfx_seq_ensure_ascii(const mfx_seq *cs) {
-  if (!cs->bases_stale) return MFX_OK;
+  if (!cs->bases_stale && cs->d_bases) return MFX_OK;
   mfx_seq *s = const_cast<mfx_seq *>(cs);
   DevGuard g(s->device);
+  if (int rc = seq_need_bases(s)) return rc;
+  if (!s->bases_stale) return MFX_OK;                       // (a sequence that holds nothing yet: all bytes 0)
   MFX_HIP(mfx_k_unpack(s->d_codes, s->d_valid, s->d_bases, s->buf_bytes / 32, nullptr));
   MFX_HIP(hipDeviceSynchronize());
   s->bases_stale = false;
@@ -1051,6 +1065,7 @@ int mfx_seq_digest32(const mfx_seq *s, uint32_t *out) {
     MFX_HIP(hipMalloc((void **)&d, sizeof(uint64_t)));
     hipError_t e = hipMemset(d, 0, sizeof(uint64_t));
     const bool planes = s->planes_ok || s->bases_stale;
+    if (!planes && !s->d_bases) { (void)hipFree(d); if (int rc = seq_need_bases(const_cast<mfx_seq *>(s))) return rc; MFX_HIP(hipMalloc((void **)&d, sizeof(uint64_t))); e = hipMemset(d, 0, sizeof(uint64_t)); }
     if (e == hipSuccess) e = mfx_k_seq_digest(s->d_bases, planes ? s->d_codes : nullptr, planes ? s->d_valid : nullptr, s->buf_bytes / 32, d, nullptr);
     if (e == hipSuccess) e = hipMemcpy(&h, d, sizeof(h), hipMemcpyDeviceToHost);
     (void)hipFree(d);
@@ -1085,16 +1100,20 @@ extern "C" mfx_seq *mfx_seq_upload(int device, const char *const *bases, const u
   const double t_up0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
   mfx_seq *s = seq_layout(device, lens, ncontigs);
   const double t_up1 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
-  if (seq_alloc(s) != MFX_OK) { mfx_seq_free(s); return nullptr; }
+  bool packed_transport = false;
+  {
+    const char *asc = getenv("MFX_UPLOAD_ASCII");
+    const char *pm = getenv("MFX_UPLOAD_PACKED_MIN");          // bytes from which the packed transport pays (tests: 0)
+    packed_transport = !(asc && atoi(asc)) && s->buf_bytes >= (pm ? strtoull(pm, nullptr, 10) : (uint64_t)(8u << 20));
+  }
+  if (seq_alloc(s, !packed_transport) != MFX_OK) { mfx_seq_free(s); return nullptr; }
   if (getenv("MFX_UPLOAD_TIMING"))
     fprintf(stderr, "-- upload: layout %.3f s, device buffers %.3f s\n", t_up1 - t_up0,
             std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_up1);
   {
     // default: the sequence crosses the bus as its packed planes (0.375 B per base, encoded by the host threads); one byte per
     // base is made on the device when a kernel asks for it (mfx_seq_ensure_ascii).  MFX_UPLOAD_ASCII=1: the bytes themselves.
-    const char *asc = getenv("MFX_UPLOAD_ASCII");
-    const char *pm = getenv("MFX_UPLOAD_PACKED_MIN");          // bytes from which the packed transport pays (tests: 0)
-    if (!(asc && atoi(asc)) && s->buf_bytes >= (pm ? strtoull(pm, nullptr, 10) : (uint64_t)(8u << 20))) {
+    if (packed_transport) {
       if (seq_upload_packed(s, bases) != MFX_OK) { mfx_seq_free(s); return nullptr; }
       return s;
     }
@@ -1390,6 +1409,10 @@ static int hist_launch(mfx_eval *ev, const mfx_seq *seq, uint64_t tile_begin, ui
     rc = mfx_seq_ensure_ascii(seq);
     if (rc) return rc;
   }
+  if (!(seq->planes_ok || seq->bases_stale) && !seq->d_bases) {   // (a sequence nothing was put into: every byte 0)
+    rc = mfx_seq_ensure_ascii(seq);
+    if (rc) return rc;
+  }
   mfx_hist_args a;
   a.t = ev->ix->view();
   a.canonical = canon;
@@ -1626,7 +1649,7 @@ extern "C" mfx_seq *mfx_seq_create(int device, const uint64_t *lens, uint32_t nc
   }
   DevGuard g(device);
   mfx_seq *s = seq_layout(device, lens, ncontigs);
-  if (seq_alloc(s) != MFX_OK) { mfx_seq_free(s); return nullptr; }
+  if (seq_alloc(s, false) != MFX_OK) { mfx_seq_free(s); return nullptr; }      // what fills it decides which form it holds
   return s;
 }
 
@@ -2117,10 +2140,11 @@ extern "C" int mfx_hist_run_streamed(mfx_eval *ev, mfx_seq *seq, const char *con
     const char *asc = getenv("MFX_STREAM_ASCII");
     if (!ev->ix->wide() && !(asc && atoi(asc))) return hist_run_streamed_packed(ev, seq, bases, out);
   }
+  DevGuard g(ev->device);
+  if (int brc = seq_need_bases(seq)) return brc;
   seq->bases_stale = false;                                 // this path writes d_bases
   seq->planes_ok = false;
   seq->digest = 0;
-  DevGuard g(ev->device);
   const size_t words = MFX_HIST_WORDS(ev->nbins, seq->ncontigs);
   const uint64_t T = seq->ntiles;
   const uint64_t CH = 16384;                                // tiles per chunk: 64 MB of bases
@@ -2326,6 +2350,7 @@ extern "C" int mfx_seq_pack(mfx_seq *s) {
   DevGuard g(s->device);
   int rc = seq_alloc_planes(s);
   if (rc) return rc;
+  if ((rc = seq_need_bases(s)) != MFX_OK) return rc;
   MFX_HIP(mfx_k_pack(s->d_bases, s->d_codes, s->d_valid, s->buf_bytes / 32, nullptr));
   MFX_HIP(hipDeviceSynchronize());
   s->planes_ok = true;

@@ -88,6 +88,8 @@ struct mfx_dump_args {
 struct mfx_count_args {
   mfx_table_view  t;
   const uint8_t  *bases;
+  const uint64_t *codes = nullptr;    // the sequence's packed planes (2-bit codes, validity bits): read instead of `bases` when given
+  const uint32_t *valid = nullptr;
   const uint64_t *contig_off, *contig_len, *tile_start;
   uint32_t        ncontigs;
   uint64_t        ntiles;

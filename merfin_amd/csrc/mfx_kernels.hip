@@ -2566,7 +2566,12 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_count_kernel(mfx_count_args a) 
     const uint64_t clen = a.contig_len[c];
     const uint32_t n = (clen - pos0 < MFX_TILE) ? (uint32_t)(clen - pos0) : MFX_TILE;
     __syncthreads();
-    mfx_tile_fill(L, a.bases + a.contig_off[c] + pos0);
+    if (a.codes) {                                           // block-uniform: the sequence is there as its packed planes
+      const uint64_t w0 = (a.contig_off[c] + pos0) >> 5;
+      mfx_tile_fill_packed(L, a.codes + w0, a.valid + w0);
+    } else {
+      mfx_tile_fill(L, a.bases + a.contig_off[c] + pos0);
+    }
     __syncthreads();
     for (uint32_t b = 0; b < MFX_TILE / MFX_BLOCK; ++b) {
       if (b * MFX_BLOCK >= n) break;                         // short last tile (block-uniform)
