@@ -1288,6 +1288,7 @@ extern "C" void mfx_eval_free(mfx_eval *ev) {
   if (ev->sr.h_img) (void)hipHostFree(ev->sr.h_img);
   for (auto &e : ev->sr.up) if (e) (void)hipEventDestroy(e);
   if (ev->sr.kdone) (void)hipEventDestroy(ev->sr.kdone);
+  for (auto &x : ev->sr.d_exc) if (x) (void)hipFree(x);
   if (ev->sr.copy) (void)hipStreamDestroy(ev->sr.copy);
   for (auto &k : ev->sr.kern) if (k) (void)hipStreamDestroy(k);
   delete ev;
@@ -1871,8 +1872,23 @@ static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *cons
     for (auto &p : ev->h_pack) { if (p) (void)hipHostFree(p); p = nullptr; }
     ev->h_pack_words = STAGE_W;
   }
+  // The validity plane crosses the link SPARSE: a word of it is all ones wherever 32 consecutive bases are ACGT, so a chunk sends
+  // its code words and the few validity words that are not (contig ends, gaps, N runs); the plane's range is filled with ones on the
+  // device and those are put in (mfx_k_valid_scatter): 0.25 instead of 0.375 bytes per base over PCIe, the bound of the streamed run.
+  // Every packer lists the exceptional words of its share behind the staging buffer (room for 1/8 of its words: a chunk with more goes whole).
+  const char *spv = getenv("MFX_STREAM_SPARSE_VALID");
+  const bool sparse_valid = !(spv && atoi(spv) == 0);
+  const size_t EXC_TOTAL = STAGE_W / 8 + 64 * 64;               // entries behind a staging buffer (up to 64 packers)
   for (int b = 0; b < NB && b < (int)chunks.size(); ++b)
-    if (!ev->h_pack[b]) STREAMED_HIP(hipHostMalloc((void **)&ev->h_pack[b], STAGE_W * 12, hipHostMallocDefault));
+    if (!ev->h_pack[b]) STREAMED_HIP(hipHostMalloc((void **)&ev->h_pack[b], STAGE_W * 12 + EXC_TOTAL * 8, hipHostMallocDefault));
+  if (sparse_valid && R.exc_cap < EXC_TOTAL) {
+    for (auto &x : R.d_exc) { if (x) (void)hipFree(x); x = nullptr; }
+    for (auto &x : R.d_exc) STREAMED_HIP(hipMalloc((void **)&x, EXC_TOTAL * 8));
+    R.exc_cap = EXC_TOTAL;
+  }
+  std::vector<uint32_t> nexc(chunks.size() * 64, 0);           // exceptional words listed by packer w of chunk ci: nexc[ci * 64 + w]
+  std::vector<std::atomic<uint32_t>> dense(chunks.size());     // a packer ran out of room: the chunk's validity words go whole
+  for (auto &d : dense) d.store(0);
   seq->bases_stale = true;
   seq->planes_ok = true;
   seq->digest = 0;                                           // new content
@@ -1909,6 +1925,18 @@ static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *cons
           const uint64_t at = seq->off[pc.contig] + pc.pos;      // a multiple of 128
           const uint64_t s = std::max(my_lo, at), e = std::min(my_hi, at + pc.n);
           if (e > s) mfx_pack_bases(reinterpret_cast<const uint8_t *>(bases[pc.contig]) + pc.pos + (s - at), e - s, codes + (s - c.lo) / 32, valid + (s - c.lo) / 32);
+        }
+        if (sparse_valid) {
+          const size_t cap_w = STAGE_W / (8 * (size_t)W) + 64;
+          uint64_t *mine_exc = reinterpret_cast<uint64_t *>(stage[ci % NB] + (size_t)STAGE_W * 12) + (size_t)w * cap_w;
+          uint32_t cnt = 0;
+          for (uint64_t i = w0; i < w1; ++i) {
+            const uint32_t vw = valid[i];
+            if (vw == 0xffffffffu) continue;
+            if (cnt == cap_w) { dense[ci].store(1, std::memory_order_relaxed); break; }
+            mine_exc[cnt++] = (uint64_t)i | ((uint64_t)vw << 32);
+          }
+          nexc[ci * 64 + w] = cnt;
         }
       }
       if (timing >= 2) {
@@ -1965,7 +1993,25 @@ static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *cons
     if (c.hi > c.lo) {
       const uint64_t nw = (c.hi - c.lo) / 32;
       STREAMED_HIP(hipMemcpyAsync(seq->d_codes + c.lo / 32, stage[b], nw * 8, hipMemcpyHostToDevice, cs));
-      STREAMED_HIP(hipMemcpyAsync(seq->d_valid + c.lo / 32, stage[b] + (size_t)STAGE_W * 8, nw * 4, hipMemcpyHostToDevice, cs));
+      if (sparse_valid && !dense[ci].load(std::memory_order_relaxed)) {
+        // the packers' lists, one behind the other, at the head of the (now free) validity words of the staging buffer
+        const size_t cap_w = STAGE_W / (8 * (size_t)W) + 64;
+        uint64_t *all = reinterpret_cast<uint64_t *>(stage[b] + (size_t)STAGE_W * 8);
+        const uint64_t *lists = reinterpret_cast<const uint64_t *>(stage[b] + (size_t)STAGE_W * 12);
+        size_t n = 0;
+        for (unsigned w = 0; w < W; ++w) {
+          const uint32_t m_ = nexc[ci * 64 + w];
+          if (m_) memcpy(all + n, lists + (size_t)w * cap_w, (size_t)m_ * 8);
+          n += m_;
+        }
+        STREAMED_HIP(hipMemsetAsync(seq->d_valid + c.lo / 32, 0xff, nw * 4, cs));
+        if (n) {
+          STREAMED_HIP(hipMemcpyAsync(R.d_exc[b], all, n * 8, hipMemcpyHostToDevice, cs));
+          STREAMED_HIP(mfx_k_valid_scatter(seq->d_valid + c.lo / 32, R.d_exc[b], (uint32_t)n, cs));
+        }
+      } else {
+        STREAMED_HIP(hipMemcpyAsync(seq->d_valid + c.lo / 32, stage[b] + (size_t)STAGE_W * 8, nw * 4, hipMemcpyHostToDevice, cs));
+      }
     }
     if (timing >= 2) (void)hipEventRecord(ct[ci].c1, cs);
     STREAMED_HIP(hipEventRecord(up[b], cs));

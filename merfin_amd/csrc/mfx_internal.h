@@ -228,5 +228,7 @@ struct mfx_eval {
     uint64_t  *h_img = nullptr;                         // pinned: image + koverCpy
     hipStream_t copy = nullptr, kern[2] = {nullptr, nullptr};
     hipEvent_t up[3] = {nullptr, nullptr, nullptr}, kdone = nullptr;
+    uint64_t  *d_exc[3] = {nullptr, nullptr, nullptr};  // per staging buffer: the validity words of a chunk that are not all ones
+    size_t     exc_cap = 0;                             // entries each
   } sr;
 };

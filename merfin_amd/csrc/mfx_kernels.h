@@ -160,6 +160,7 @@ hipError_t mfx_k_seq_digest(const uint8_t *bases, const uint64_t *codes, const u
 hipError_t mfx_k_add_u32(uint32_t *dst, const uint32_t *src, uint64_t n, hipStream_t st);
 hipError_t mfx_k_pack(const uint8_t *bases, uint64_t *codes, uint32_t *valid, uint64_t nwords, hipStream_t st);
 hipError_t mfx_k_unpack(const uint64_t *codes, const uint32_t *valid, uint8_t *bases, uint64_t nwords, hipStream_t st);
+hipError_t mfx_k_valid_scatter(uint32_t *valid, const uint64_t *exc, uint32_t n, hipStream_t st);     // exc[i] = word index | word << 32
 hipError_t mfx_k_count(const mfx_count_args &a, hipStream_t st);
 hipError_t mfx_k_completeness(mfx_table_view t, double peak, uint32_t n_prob, const uint32_t *probK, const double *probP,
                               double *partials, int grid, hipStream_t st);

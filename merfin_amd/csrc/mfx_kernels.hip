@@ -2456,6 +2456,19 @@ hipError_t mfx_k_var_score(const mfx_var_score_args &a, hipStream_t st) {
   return hipGetLastError();
 }
 
+// The streamed upload sends the 2-bit codes and, of the validity plane, only the words that are not all ones (gaps between
+// contigs, the words behind a contig's end, N runs): the plane's range is filled with ones on the device and these are put in.
+// exc[i] = {word index inside the range, word}
+__global__ void mfx_valid_scatter_kernel(uint32_t *valid, const uint2 *exc, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) valid[exc[i].x] = exc[i].y;
+}
+hipError_t mfx_k_valid_scatter(uint32_t *valid, const uint64_t *exc, uint32_t n, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  mfx_valid_scatter_kernel<<<(n + 255u) / 256u, 256, 0, st>>>(valid, reinterpret_cast<const uint2 *>(exc), n);
+  return hipGetLastError();
+}
+
 // packed planes -> ASCII bases (for the kernels that read mfx_seq::d_bases after a packed upload): one thread per 16
 // bases; invalid positions become 'N'
 __global__ __launch_bounds__(MFX_BLOCK) void mfx_unpack_kernel(const uint64_t *codes, const uint32_t *valid, uint8_t *bases, uint64_t nwords) {
