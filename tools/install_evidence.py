@@ -34,10 +34,10 @@ json.dump({b["config"]["workload"] + ":" + kind: r["traffic"], "kernel_source_ha
            "_bytes_per_kmer_corrected": r["bytes_per_kmer"], "_lines_per_kmer": r["lines_per_kmer"], "_index_gb": b["config"]["index_gb"]},
           open(dst + "/traffic.json", "w"), indent=1)
 c, cb = b["config"], b["cpu_baseline"]
-print("value %.2f G k-mers/s  ms/step %.2f  kernel_ms %.2f  value_8d %.2f G (%.1f ms)  pageable %.2f G  frac %.3f  traffic %.2f GB  %.2f B/k-mer  %.4f lines/k-mer  overfetch %.2f  alg_frac_8d %.3f  index %.1f GB"
+print("value %.2f G k-mers/s  ms/step %.2f  kernel_ms %.2f  value_8d %.2f G (%.1f ms)  pageable %.2f G  frac %.3f  traffic %.2f GB  %.2f B/k-mer  %.4f lines/k-mer  overfetch %.2f  frac_of_gather_ceiling %.3f  index %.1f GB"
       % (b["value"] / 1e9, b["ms_per_step"], r["kernel_ms"], b["value_8d"] / 1e9, min(c["h2d_inclusive"]["pinned_source_s"], c["h2d_inclusive"]["pageable_source_s"]) * 1e3,
          c["kmers_per_s_h2d_inclusive_pageable"] / 1e9, r["frac"], r["traffic"] / 1e9, r["bytes_per_kmer"], r["lines_per_kmer"],
-         r["overfetch_vs_useful"], r["alg_frac_8d"], c["index_gb"]))
+         r["overfetch_vs_useful"], r.get("frac_of_gather_ceiling") or 0.0, c["index_gb"]))
 print("cpu_baseline %.1f M contig-scheduled / %.1f M tiled; under rocprof: %.2f G, kernel_ms %.2f; raw FETCH %.2fe6 KB"
       % (cb["value"] / 1e6, cb["value_position_tiled"] / 1e6, u["value"] / 1e9, u["roofline"]["kernel_ms"], t["raw_fetch_bytes"] / 1024 / 1e6))
 for l in open(src + "/trace/bench_kernel_stats.csv"):
