@@ -1993,7 +1993,11 @@ static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *cons
     if (c.hi > c.lo) {
       const uint64_t nw = (c.hi - c.lo) / 32;
       STREAMED_HIP(hipMemcpyAsync(seq->d_codes + c.lo / 32, stage[b], nw * 8, hipMemcpyHostToDevice, cs));
-      if (sparse_valid && !dense[ci].load(std::memory_order_relaxed)) {
+      // the sparse form pays (8 bytes per listed word against 4 per word sent whole) only while fewer than half of the chunk's
+      // validity words are exceptional; a chunk of short or gappy contigs goes whole
+      size_t n_exc = 0;
+      for (unsigned w = 0; w < W; ++w) n_exc += nexc[ci * 64 + w];
+      if (sparse_valid && !dense[ci].load(std::memory_order_relaxed) && 2 * n_exc < nw) {
         // the packers' lists, one behind the other, at the head of the (now free) validity words of the staging buffer
         const size_t cap_w = STAGE_W / (8 * (size_t)W) + 64;
         uint64_t *all = reinterpret_cast<uint64_t *>(stage[b] + (size_t)STAGE_W * 8);
