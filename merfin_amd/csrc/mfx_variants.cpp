@@ -29,6 +29,8 @@
 #include <atomic>
 #include <list>
 #include <map>
+#include <new>
+#include <type_traits>
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
@@ -153,11 +155,30 @@ struct Cluster {                      // posGT
   VarList vars;
 };
 
+// n objects whose memory is touched first by the thread that CONSTRUCTS them (placement new in the parsing loop): a config-4
+// call set makes 1.1 GB of records and variants, and a std::vector's resize would zero and fault all of it in on one thread
+// before the 16 parsers start.  Every element must be constructed by the owner before the array is destroyed.
+template <class T> struct RawArray {
+  T *p = nullptr;
+  size_t n = 0;
+  RawArray() = default;
+  RawArray(const RawArray &) = delete;
+  RawArray &operator=(const RawArray &) = delete;
+  bool alloc(size_t n_) { p = n_ ? static_cast<T *>(malloc(n_ * sizeof(T))) : nullptr; n = p ? n_ : 0; return p || !n_; }
+  T &operator[](size_t i) { return p[i]; }
+  const T &operator[](size_t i) const { return p[i]; }
+  size_t size() const { return n; }
+  ~RawArray() {
+    if (!std::is_trivially_destructible<T>::value) for (size_t i = 0; i < n; ++i) p[i].~T();
+    free(p);
+  }
+};
+
 struct VcfDB {
   std::string text;                   // the file image every SV points into
   std::vector<std::string> headers;
-  std::vector<Record> rec_store;      // one per data line (excluded ones included), file order
-  std::vector<Variant> var_store;
+  RawArray<Record> rec_store;         // one per data line (excluded ones included), file order
+  RawArray<Variant> var_store;
   size_t n_records = 0;               // records loaded (not excluded)
   std::map<std::string, std::vector<Cluster *>> by_chr;
   std::map<std::string, std::vector<Cluster>> cluster_store;   // per CHROM: one Cluster per record (the merged-away ones stay unused); by_chr points into it
@@ -182,11 +203,20 @@ void make_variant(const Record *r, Variant *v) {
   for (size_t ti = 0;; ++ti) {
     const SV tok = word_at(g, "|/", ti);
     if (!tok.p) break;
-    char num[24];
-    const size_t nn = std::min<size_t>(tok.n, sizeof(num) - 1);
-    memcpy(num, tok.p, nn);
-    num[nn] = 0;
-    long altIdx = strtol(num, nullptr, 10);
+    long altIdx = 0;
+    bool plain = tok.n >= 1 && tok.n <= 9;                 // plain digits (the rule) are read here, anything else by strtol
+    for (uint32_t i = 0; i < tok.n && plain; ++i) {
+      const unsigned d = (unsigned char)tok.p[i] - (unsigned)'0';
+      if (d > 9) plain = false;
+      altIdx = altIdx * 10 + (long)d;
+    }
+    if (!plain) {
+      char num[24];
+      const size_t nn = std::min<size_t>(tok.n, sizeof(num) - 1);
+      memcpy(num, tok.p, nn);
+      num[nn] = 0;
+      altIdx = strtol(num, nullptr, 10);
+    }
     if ((int32_t)altIdx <= 0) continue;
     if ((size_t)altIdx > r->n_alts) continue;            // operator[] past the end -> nullptr
     // the reference compares POINTERS into the ALT list (same ALT index listed twice) ...
@@ -223,14 +253,44 @@ void parse_record(const char *L, size_t n, Record *r) {
   r->ok = true;
   r->chr = w[0];
   {
-    char num[32];
-    const size_t nn = std::min<size_t>(w[1].n, sizeof(num) - 1);
-    memcpy(num, w[1].p, nn); num[nn] = 0;
-    r->pos = (uint32_t)strtoul(num, nullptr, 10);
-    char q[64];
-    const size_t nq = std::min<size_t>(w[5].n, sizeof(q) - 1);
-    memcpy(q, w[5].p, nq); q[nq] = 0;
-    r->qual = strtod(q, nullptr);
+    // POS: plain digits that fit 32 bits are read here, anything else by strtoul as before
+    bool plain = w[1].n >= 1 && w[1].n <= 9;
+    uint32_t pv = 0;
+    for (uint32_t i = 0; i < w[1].n && plain; ++i) {
+      const unsigned d = (unsigned char)w[1].p[i] - (unsigned)'0';
+      if (d > 9) plain = false;
+      pv = pv * 10 + d;
+    }
+    if (plain) r->pos = pv;
+    else {
+      char num[32];
+      const size_t nn = std::min<size_t>(w[1].n, sizeof(num) - 1);
+      memcpy(num, w[1].p, nn); num[nn] = 0;
+      r->pos = (uint32_t)strtoul(num, nullptr, 10);
+    }
+    // QUAL: digits[.digits] with at most 15 significant digits is an integer below 2^53 over an exact power of ten -- one
+    // correctly rounded division, which is what strtod returns for it; every other spelling (sign, exponent, '.', inf, nan,
+    // longer mantissas) goes to strtod
+    static const double P10[16] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15};
+    uint64_t mant = 0;
+    uint32_t nd = 0, frac = 0;
+    bool fast = w[5].n >= 1 && w[5].n <= 16, dot = false;
+    for (uint32_t i = 0; i < w[5].n && fast; ++i) {
+      const char ch = w[5].p[i];
+      if (ch == '.') { if (dot || i == 0 || i + 1 == w[5].n) fast = false; dot = true; continue; }
+      const unsigned d = (unsigned char)ch - (unsigned)'0';
+      if (d > 9) { fast = false; break; }
+      mant = mant * 10 + d;
+      ++nd;
+      if (dot) ++frac;
+    }
+    if (fast && nd >= 1 && nd <= 15) r->qual = (double)mant / P10[frac];
+    else {
+      char q[64];
+      const size_t nq = std::min<size_t>(w[5].n, sizeof(q) - 1);
+      memcpy(q, w[5].p, nq); q[nq] = 0;
+      r->qual = strtod(q, nullptr);
+    }
   }
   r->id = w[2]; r->ref = w[3]; r->alts = w[4];
   r->filter = w[6]; r->info = w[7]; r->formats = w[8]; r->samples = w[9];
@@ -276,17 +336,15 @@ int load_vcf(const char *path, VcfDB &db, double *t_sub = nullptr) {   // t_sub[
     o = e + 1;
   }
   sub(1);
-  {
-    // (a config-4 call set: 1.1 GB of records and variants; the two arrays are made side by side)
-    std::thread other([&]() { db.var_store.resize(lines.size()); });
-    db.rec_store.resize(lines.size());
-    other.join();
-  }
+  // (a config-4 call set: 1.1 GB of records and variants, constructed -- and so first touched -- by the thread that parses them)
+  if (!db.rec_store.alloc(lines.size()) || !db.var_store.alloc(lines.size())) return mfx_fail(MFX_E_NOMEM, "VCF '%s': no memory for %zu records", path, lines.size());
   const size_t CH = 4096;                                  // lines per task
   parallel_for((lines.size() + CH - 1) / CH, [&](size_t c) {
     for (size_t i = c * CH, e = std::min(lines.size(), (c + 1) * CH); i < e; ++i) {
-      parse_record(buf.data() + lines[i].first, lines[i].second, &db.rec_store[i]);
-      if (db.rec_store[i].ok) make_variant(&db.rec_store[i], &db.var_store[i]);
+      Record *r = new (&db.rec_store[i]) Record();
+      Variant *v = new (&db.var_store[i]) Variant();
+      parse_record(buf.data() + lines[i].first, lines[i].second, r);
+      if (r->ok) make_variant(r, v);
     }
   });
   sub(2);
