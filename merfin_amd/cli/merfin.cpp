@@ -1026,15 +1026,16 @@ int main(int argc, char **argv) {
     vo.nosplit = G.nosplit ? 1 : 0;
     vo.debug_path = G.debug ? dbgName.c_str() : nullptr;
     uint64_t ncl = 0;
-    // These modes are bound by the host (VCF parsing, path enumeration, selectors), whose phases alternate between
-    // parallel and serial stretches: several slots side by side fill one another's serial stretches (1 Gb, 1.3 M calls:
-    // 2.0 s in 8 slots vs 2.7 s in one).  So one device is also run as 4 slots sharing its table -- unless -debug asks
-    // for the single statistics file, or there is only one contig to hand out.  MFX_VARIANT_SLOTS overrides.
+    // One device is run as ONE slot.  (Rounds 2-3 ran it as 4 slots sharing its table: the host phases of these modes then
+    // alternated between parallel and serial stretches and several slots filled one another's gaps -- 1 Gb: 2.0 s in 8 slots
+    // against 2.7 s in one.  With the host side of round 4 -- arenas per run of clusters, parallel VCF load, device scoring --
+    // one slot on all host threads is at least as fast and needs neither the per-slot VCF files nor the evaluator replicas:
+    // config 4 at 3 Gb, evaluate + write 1.11-1.14 s in one slot, 1.16-1.19 s in four + 0.13-0.15 s to set the slots up,
+    // profiles/r04_cfg4_fullsize.txt.)  MFX_VARIANT_SLOTS overrides; several -devices are one slot each.
     {
       size_t want = G.devices.size();
       const char *vs = getenv("MFX_VARIANT_SLOTS");
       if (vs && atoi(vs) > 0) want = (size_t)atoi(vs);
-      else if (want < 4 && !G.debug && recs.size() >= 2) want = 4;
       const std::vector<int> real = G.devices;
       while (G.devices.size() < want) G.devices.push_back(real[G.devices.size() % real.size()]);
     }

@@ -75,6 +75,7 @@ if len(sys.argv) > 3 and sys.argv[3] == "cli":
     del ev, ix
     torch.cuda.empty_cache()
     for devs in ("0", "0,0,0,0,0,0,0,0"):
+        time.sleep(float(os.environ.get("MFX_CFG4_SLEEP", "0")))
         t0 = time.time()
         r = subprocess.run([exe, "-polish", "-sequence", out + "/asm.fasta", "-readmers", out + "/read.mfxk", "-seqmers", out + "/asm.mfxk", "-peak", str(lam),
                             "-vcf", vcf, "-output", out + "/cli_" + str(len(devs)), "-devices", devs], capture_output=True, text=True,
@@ -84,3 +85,13 @@ if len(sys.argv) > 3 and sys.argv[3] == "cli":
         print("    " + "\n    ".join(l for l in r.stderr.splitlines() if "timing" in l or "ERROR" in l))
     a_, b_ = open(out + "/cli_1.polish.vcf").read(), open(out + "/cli_15.polish.vcf").read()
     print("8 slots == 1 device:", a_ == b_, len(a_))
+    # one device run as 1 / 2 / 4 (the default) slots sharing its table: which fills the host best
+    for slots in (os.environ.get("MFX_CFG4_SLOTS", "1,2,4,1,4")).split(","):
+        time.sleep(float(os.environ.get("MFX_CFG4_SLEEP", "0")))        # (the driver scrubs what the run before freed: a table allocated at once waits for it)
+        t0 = time.time()
+        r = subprocess.run([exe, "-polish", "-sequence", out + "/asm.fasta", "-readmers", out + "/read.mfxk", "-seqmers", out + "/asm.mfxk", "-peak", str(lam),
+                            "-vcf", vcf, "-output", out + "/cli_s" + slots], capture_output=True, text=True,
+                           env=dict(os.environ, MFX_CLI_TIMING="2", MFX_VARIANT_SLOTS=slots, MFX_VAR_TIMING="1", MFX_INGEST_TIMING="1"))
+        dt = time.time() - t0
+        print("merfin -polish MFX_VARIANT_SLOTS=%s: rc=%d wall=%.2fs same=%s" % (slots, r.returncode, dt, open(out + "/cli_s" + slots + ".polish.vcf").read() == a_))
+        print("    " + "\n    ".join(l for l in r.stderr.splitlines() if "timing" in l or "ERROR" in l or "ingest" in l or "mfx_variants]" in l and "load:" not in l))
