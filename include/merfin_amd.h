@@ -474,6 +474,16 @@ typedef struct {
 int mfx_variants_run(mfx_eval *ev, const char *vcf_path, const char *const *names, const char *const *bases,
                      const uint64_t *lens, uint32_t ncontigs, const mfx_variant_opts *opts,
                      const char *out_path, const char *log_path, uint64_t *n_clusters);
+/* The VCF of a run read and parsed ahead of it (vcfFile::loadFile, vcf.C:93-149): host work only -- no device, no index --
+ * so a caller runs it on a thread of its own under the index build (merfin opens the VCF after load_Kmers,
+ * merfin-globals.C:201-219).  A handle serves ONE mfx_variants_run_vcf (clustering rearranges it); NULL on error.
+ * mfx_variants_run_vcf = mfx_variants_run on the loaded records: same outputs, byte for byte. */
+typedef struct mfx_vcf mfx_vcf;
+mfx_vcf *mfx_vcf_load(const char *vcf_path);
+void     mfx_vcf_free(mfx_vcf *vcf);
+int mfx_variants_run_vcf(mfx_eval *ev, mfx_vcf *vcf, const char *const *names, const char *const *bases,
+                         const uint64_t *lens, uint32_t ncontigs, const mfx_variant_opts *opts,
+                         const char *out_path, const char *log_path, uint64_t *n_clusters);
 /* The same over an index sharded across nslots evaluators (slot d = shard d of nslots): every batch of path text is
  * scored by mfx_dump_values_sharded; clustering, enumeration, selectors and output are the code above. */
 int mfx_variants_run_sharded(mfx_eval *const *evs, uint32_t nslots, const char *vcf_path, const char *const *names,

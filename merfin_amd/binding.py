@@ -78,7 +78,7 @@ SYMBOLS = [
     "mfx_eval_create", "mfx_eval_free", "mfx_eval_nbins", "mfx_eval_debug_enable", "mfx_eval_debug_counters", "mfx_getK", "mfx_getKmetric", "mfx_histoQV",
     "mfx_hist_run", "mfx_hist_result_free", "mfx_hist_launch", "mfx_hist_launch_cyclic", "mfx_hist_result_from_counts",
     "mfx_hist_take_overflow", "mfx_hist_report",
-    "mfx_pack_bases", "mfx_host_threads_share", "mfx_dump_values", "mfx_dump_contig", "mfx_dump_values_sharded", "mfx_dump_contig_sharded", "mfx_variants_run_sharded", "mfx_completeness", "mfx_completeness_pieces", "mfx_variants_run",
+    "mfx_pack_bases", "mfx_host_threads_share", "mfx_dump_values", "mfx_dump_contig", "mfx_dump_values_sharded", "mfx_dump_contig_sharded", "mfx_variants_run_sharded", "mfx_vcf_load", "mfx_vcf_free", "mfx_variants_run_vcf", "mfx_completeness", "mfx_completeness_pieces", "mfx_variants_run",
     "mfx_index_set_shard", "mfx_router_create", "mfx_router_free", "mfx_route_tiles", "mfx_hist_keys_launch",
 ]
 
@@ -196,6 +196,12 @@ def load_library():
     L.mfx_hist_keys_launch.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp]
     L.mfx_variants_run.argtypes = [vp, C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), u64p, C.c_uint32,
                                    C.POINTER(_VarOpts), C.c_char_p, C.c_char_p, u64p]
+    L.mfx_vcf_load.restype = vp
+    L.mfx_vcf_load.argtypes = [C.c_char_p]
+    L.mfx_vcf_free.restype = None
+    L.mfx_vcf_free.argtypes = [vp]
+    L.mfx_variants_run_vcf.argtypes = [vp, vp, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), u64p, C.c_uint32,
+                                       C.POINTER(_VarOpts), C.c_char_p, C.c_char_p, u64p]
     L.mfx_index_set_fingerprint.argtypes = [vp, C.c_uint64]
     L.mfx_index_get_origin.argtypes = [vp, u64p, u64p, u64p]
     L.mfx_host_threads_share.restype = None
@@ -825,6 +831,24 @@ def gather_rate(table_bytes, device=0):
     return out.value
 
 
+class LoadedVcf:
+    """a VCF read and parsed ahead of its run (mfx_vcf_load): no device involved"""
+
+    def __init__(self, path):
+        self.h = _need(load_library().mfx_vcf_load(path.encode()))
+
+    def close(self):
+        if self.h:
+            load_library().mfx_vcf_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Evaluator:
     """K* parameters bound to an Index; runs -hist / -dump / -completeness."""
 
@@ -925,6 +949,18 @@ class Evaluator:
         ncl = C.c_uint64(0)
         _check(load_library().mfx_variants_run(self.h, vcf_path.encode(), nm, arr, lens.ctypes.data_as(C.POINTER(C.c_uint64)), n,
                                                C.byref(o), out_path.encode(), log_path.encode() if log_path else None, C.byref(ncl)))
+        return ncl.value
+
+    def variants_loaded(self, mode, vcf, names, contigs, out_path, comb=15, nosplit=False, debug_path=None, log_path=None):
+        """the same on a VCF read ahead of the run (LoadedVcf: mfx_vcf_load, host work only); the handle serves one run"""
+        n = len(contigs)
+        nm = (C.c_char_p * n)(*[x.encode() for x in names])
+        arr = (C.c_char_p * n)(*contigs)
+        lens = np.array([len(c) for c in contigs], dtype=np.uint64)
+        o = _VarOpts(VARIANT_MODES[mode], comb, 1 if nosplit else 0, debug_path.encode() if debug_path else None)
+        ncl = C.c_uint64(0)
+        _check(load_library().mfx_variants_run_vcf(self.h, vcf.h, nm, arr, lens.ctypes.data_as(C.POINTER(C.c_uint64)), n,
+                                                   C.byref(o), out_path.encode(), log_path.encode() if log_path else None, C.byref(ncl)))
         return ncl.value
 
     def completeness_pieces(self):

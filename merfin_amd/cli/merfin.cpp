@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <chrono>
 #include <unistd.h>
+#include <future>
 #include <thread>
 #include <memory>
 #include <string>
@@ -795,6 +796,23 @@ int main(int argc, char **argv) {
     return true;
   };
   if (!deferSeq && !make_seq()) DIE_MFX("uploading sequences");
+  // variant modes on one slot: the VCF is read and parsed (host work only) on a thread of its own while the index is built
+  // (merfin opens it after load_Kmers, merfin-globals.C:201-219; 0.15 s of a 4 M-call set).  An error is reported where the
+  // VCF is opened below.  Several slots split the file per slot instead.
+  std::future<mfx_vcf *> vcfAhead;
+  std::string vcfAheadError;
+  {
+    const char *vs = getenv("MFX_VARIANT_SLOTS");
+    const size_t slots = (vs && atoi(vs) > 0) ? (size_t)atoi(vs) : G.devices.size();
+    const char *pa = getenv("MFX_CLI_VCF_AHEAD");
+    if (variantMode && G.vcfName && slots == 1 && !G.sharded && !(pa && atoi(pa) == 0))
+      vcfAhead = std::async(std::launch::async, [&G, &vcfAheadError]() {
+        mfx_vcf *v = mfx_vcf_load(G.vcfName);
+        if (!v) vcfAheadError = mfx_last_error();                  // (errors are per thread: carried to the caller's)
+        return v;
+      });
+  }
+  struct VcfAheadGuard { std::future<mfx_vcf *> &f; ~VcfAheadGuard() { if (f.valid()) mfx_vcf_free(f.get()); } } vcfAheadGuard{vcfAhead};
   FILE *probe = G.indexName ? fopen(G.indexName, "rb") : nullptr;
   uint64_t fingerprint = G.indexName ? input_fingerprint(G, seqOnly) : 0;
   // a run that would build the sequence-only index also accepts a FULL image of the same inputs: that is what such a run
@@ -1146,6 +1164,12 @@ int main(int argc, char **argv) {
       for (size_t d = 0; d < N; ++d) if (!errs[d].empty()) { fprintf(stderr, "ERROR: variant scoring (slot %zu): %s\n", d, errs[d].c_str()); drop_parts(); return 1; }
       if (!concat_parts(outName, parts, true)) { fprintf(stderr, "ERROR: cannot write '%s'.\n", outName.c_str()); drop_parts(); return 1; }
       for (uint64_t x : ncls) ncl += x;
+    } else if (vcfAhead.valid()) {
+      mfx_vcf *vcf = vcfAhead.get();
+      if (!vcf) { fprintf(stderr, "ERROR: variant scoring: %s\n", vcfAheadError.c_str()); return 1; }
+      const int vrc = mfx_variants_run_vcf(ev, vcf, names.data(), bases.data(), lens.data(), (uint32_t)recs.size(), &vo, outName.c_str(), nullptr, &ncl);
+      mfx_vcf_free(vcf);
+      if (vrc) DIE_MFX("variant scoring");
     } else if (mfx_variants_run(ev, G.vcfName, names.data(), bases.data(), lens.data(), (uint32_t)recs.size(), &vo, outName.c_str(), nullptr, &ncl))
       DIE_MFX("variant scoring");
   } else if (G.reportType == OP_COMPL) {

@@ -413,6 +413,17 @@ int load_vcf(const char *path, VcfDB &db, double *t_sub = nullptr) {   // t_sub[
   return MFX_OK;
 }
 
+}  // namespace
+
+// a VCF read and parsed ahead of its run (mfx_vcf_load): host work only, so it can run under the index build
+struct mfx_vcf {
+  VcfDB db;
+  double t_load[4] = {0, 0, 0, 0};
+  bool used = false;
+};
+
+namespace {
+
 // vcfFile::mergeChrPosGT, vcf.C:156-246: clusters whose start lies within 2k of
 // the previous cluster's end are merged, unless that cluster already holds
 // `comb` variants and splitting is allowed.
@@ -765,8 +776,9 @@ using PathScores = std::function<int(const char *, uint64_t, const mfx_path_tabl
 // (not static: tools/variants_host_bench.cpp drives the host side with a synthetic `values`, without a device)
 int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const char *vcf_path, const char *const *names, const char *const *bases,
                          const uint64_t *lens, uint32_t ncontigs, const mfx_variant_opts *opts,
-                         const char *out_path, const char *log_path, uint64_t *n_clusters, const PathScores &scores = PathScores()) {
-  if (!ev || !vcf_path || !opts || !out_path || (ncontigs && (!names || !bases || !lens)))
+                         const char *out_path, const char *log_path, uint64_t *n_clusters, const PathScores &scores = PathScores(),
+                         mfx_vcf *loaded = nullptr) {
+  if (!ev || (!vcf_path && !loaded) || !opts || !out_path || (ncontigs && (!names || !bases || !lens)))
     return mfx_fail(MFX_E_INVAL, "mfx_variants_run: null argument");
   const int mode = opts->mode;
   if (mode < MFX_VAR_FILTER || mode > MFX_VAR_LOOSE) return mfx_fail(MFX_E_INVAL, "mfx_variants_run: unknown mode %d", mode);
@@ -784,9 +796,14 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
   double t_mark = now();
   auto lap = [&](int i) { double t = now(); t_phase[i] += t - t_mark; t_mark = t; };
 
-  VcfDB db;
+  // the records: read and parsed here, or handed in by mfx_vcf_load (then that work ran under the caller's index build)
+  VcfDB own_db;
+  if (loaded && loaded->used) { if (log != stderr) fclose(log); return mfx_fail(MFX_E_INVAL, "mfx_variants_run_vcf: a loaded VCF serves one run (clustering rearranges it); load it again"); }
+  VcfDB &db = loaded ? loaded->db : own_db;
   double t_load[4] = {0, 0, 0, 0};
-  int rc = load_vcf(vcf_path, db, t_load);
+  int rc = MFX_OK;
+  if (loaded) { loaded->used = true; memcpy(t_load, loaded->t_load, sizeof(t_load)); }
+  else rc = load_vcf(vcf_path, db, t_load);
   if (rc) { if (log != stderr) fclose(log); return rc; }
   fprintf(log, "   Collected %zu header lines.\n   Loaded %zu records:\n      %-8lu unique contig%s\n      %-8u contig IDs\n   Excluded %lu invalid records\n\n",
           db.headers.size(), db.n_records, db.by_chr.size(), db.by_chr.size() == 1 ? "" : "s", (unsigned)db.contig_ids, (unsigned long)db.excluded);
@@ -1188,6 +1205,39 @@ extern "C" int mfx_variants_run(mfx_eval *ev, const char *vcf_path, const char *
       return mfx_score_paths(ev, text, len, &pt, need_dk, numM, totdk);
     };
   return mfx_variants_run_values(ev, values, vcf_path, names, bases, lens, ncontigs, opts, out_path, log_path, n_clusters, scores);
+}
+
+// The VCF read and parsed AHEAD of its run: host work only (no device, no index), so a caller starts it on a thread of its own while
+// the index is built -- merfin opens the VCF after load_Kmers (merfin-globals.C:201-219), here the 0.15 s of a 4 M-call set run
+// under the build.  The handle serves one mfx_variants_run_vcf and is freed by the caller.
+extern "C" mfx_vcf *mfx_vcf_load(const char *vcf_path) {
+  if (!vcf_path) { mfx_fail(MFX_E_INVAL, "mfx_vcf_load: null argument"); return nullptr; }
+  mfx_vcf *v = new (std::nothrow) mfx_vcf;
+  if (!v) { mfx_fail(MFX_E_NOMEM, "mfx_vcf_load: no memory"); return nullptr; }
+  if (load_vcf(vcf_path, v->db, v->t_load) != MFX_OK) { delete v; return nullptr; }
+  return v;
+}
+
+extern "C" void mfx_vcf_free(mfx_vcf *v) { delete v; }
+
+extern "C" int mfx_variants_run_vcf(mfx_eval *ev, mfx_vcf *vcf, const char *const *names, const char *const *bases,
+                                    const uint64_t *lens, uint32_t ncontigs, const mfx_variant_opts *opts,
+                                    const char *out_path, const char *log_path, uint64_t *n_clusters) {
+  if (!ev || !vcf) return mfx_fail(MFX_E_INVAL, "mfx_variants_run_vcf: null argument");
+  PathValues values = [ev](const char *text, uint64_t len, uint32_t *rv, uint32_t *av) -> int {
+    mfx_seq *ps = mfx_seq_upload(ev->device, &text, &len, 1);
+    if (!ps) return mfx_last_error_code();
+    int r = mfx_dump_values(ev, ps, 0, 0, len, rv, av, nullptr, nullptr);
+    mfx_seq_free(ps);
+    return r;
+  };
+  PathScores scores;
+  const char *hs = getenv("MFX_VAR_HOST_SCORE");
+  if (!(hs && atoi(hs)))
+    scores = [ev](const char *text, uint64_t len, const mfx_path_table &pt, int need_dk, uint32_t *numM, double *totdk) -> int {
+      return mfx_score_paths(ev, text, len, &pt, need_dk, numM, totdk);
+    };
+  return mfx_variants_run_values(ev, values, nullptr, names, bases, lens, ncontigs, opts, out_path, log_path, n_clusters, scores, vcf);
 }
 
 // The variant modes over an index sharded across N evaluators (read databases beyond one GPU): the packed path text of

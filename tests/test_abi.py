@@ -171,3 +171,15 @@ def test_text_database_probe_needs_no_gpu(tmp_path, piece, monkeypatch):
         with pytest.raises(m.MfxError) as e:
             m.db_probe(bp)
         assert what in str(e.value) and ("at byte %d" % off) in str(e.value)
+
+
+def test_vcf_loads_without_a_device(tmp_path):
+    """mfx_vcf_load is host work only (vcfFile::loadFile, vcf.C:93-149): it succeeds with no GPU in the machine, fails with a
+    message on a missing file, and the handle is released without ever meeting an evaluator"""
+    import merfin_amd as m
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "case1.vcf")
+    v = m.LoadedVcf(g)
+    assert v.h
+    v.close()
+    with pytest.raises(m.MfxError):
+        m.LoadedVcf(str(tmp_path / "missing.vcf"))

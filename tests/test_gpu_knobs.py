@@ -87,7 +87,7 @@ def test_library_knob_answers_as_the_oracle(k, knob, value, tmp_path, monkeypatc
 
 
 CLI_KNOBS = [
-    ("MFX_DUMP_SERIAL", "1"), ("MFX_CLI_WARM", "0"), ("MFX_CLI_QUICK_EXIT", "1"), ("MFX_CLI_FULL_INDEX", "1"), ("MFX_CLI_OVERLAP", "1"),
+    ("MFX_DUMP_SERIAL", "1"), ("MFX_CLI_WARM", "0"), ("MFX_CLI_QUICK_EXIT", "1"), ("MFX_CLI_FULL_INDEX", "1"), ("MFX_CLI_OVERLAP", "1"), ("MFX_CLI_VCF_AHEAD", "0"),
     ("MFX_CLI_SEQ_THREADS", "1"), ("MFX_VARIANT_SLOTS", "3"), ("MFX_VAR_BATCH_MB", "1"), ("MFX_VAR_HOST_SCORE", "1"),
     ("MFX_HOST_THREADS", "1"), ("MFX_HOST_THREADS", "5"), ("MFX_CLI_TIMING", "3"), ("MFX_DUMP_TIMING", "1"), ("MFX_VAR_TIMING", "1"),
     ("MFX_INGEST_TIMING", "1"), ("MFX_UPLOAD_TIMING", "1"), ("MFX_CLI_SEQ_TIMING", "1"),

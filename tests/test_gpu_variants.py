@@ -121,6 +121,10 @@ def test_randomized_vcf_records_parse_like_the_oracle(tmp_path, seed):
             w[4] = str(r.choice([".", "*", "<DEL>", w[4].lower(), w[4] + ",*", w[3]]))
         elif roll < 0.20:
             w[5] = "."
+        elif roll < 0.30:                                             # QUAL spellings: the exact fast path (digits[.digits]) and everything else strtod takes
+                                                                      # (within int range: the reference prints (int)QUAL, varMer.C:486)
+            w[5] = str(r.choice(["30", "12.5", "1e2", "+5", "007.50", "1234567890.12345678", ".5", "5.", "-3.2", "0.30000000000000004",
+                                 "99999999999999.9", "0.05", "2.25", "1.15", "33.35", "1234567.85", "0", "00", "4.450000000000001", "1E-3", "0x10", "12abc"]))
         elif roll < 0.22:
             w[0] = "chrUnknown"
         elif roll < 0.24:
@@ -148,3 +152,28 @@ def test_randomized_vcf_records_parse_like_the_oracle(tmp_path, seed):
     assert open(tmp_path / "g.vcf").read() == open(tmp_path / "o.vcf").read()
     assert open(tmp_path / "g.dbg").read() == open(tmp_path / "o.dbg").read()
     assert _special(str(tmp_path / "g.log")) == _special(str(tmp_path / "o.log"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", MODES)
+def test_variants_on_a_vcf_loaded_ahead(tmp_path, mode):
+    """mfx_vcf_load + mfx_variants_run_vcf (the VCF read and parsed ahead of the run: what the CLI does under the index build,
+    merfin-globals.C:201-219 opens it afterwards) == mfx_variants_run, byte for byte; a handle serves one run"""
+    import merfin_amd as m
+    k, peak = 21, 17.3
+    names, asm, vcf, read, amers = synth.variant_world(k=k, peak=peak, seed=77)
+    vp = str(tmp_path / "in.vcf")
+    open(vp, "w").write(vcf)
+    loaded = m.LoadedVcf(vp)                                   # before any index exists: host work only
+    ix = m.Index(k, len(read[0]) + len(amers[0]) + 16)
+    ix.add_read(*read)
+    ix.add_asm(*amers)
+    ev = m.Evaluator(ix, m.KParams(peak))
+    n_a = ev.variants(mode, vp, names, asm, str(tmp_path / "a.vcf"), log_path=str(tmp_path / "a.log"))
+    n_b = ev.variants_loaded(mode, loaded, names, asm, str(tmp_path / "b.vcf"), log_path=str(tmp_path / "b.log"))
+    assert n_a == n_b and n_a > 0
+    assert open(tmp_path / "a.vcf", "rb").read() == open(tmp_path / "b.vcf", "rb").read()
+    assert open(tmp_path / "a.log", "rb").read() == open(tmp_path / "b.log", "rb").read()
+    with pytest.raises(m.MfxError):                            # clustering rearranged it: one run per load
+        ev.variants_loaded(mode, loaded, names, asm, str(tmp_path / "c.vcf"), log_path=str(tmp_path / "c.log"))
+    loaded.close()
