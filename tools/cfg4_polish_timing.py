@@ -95,3 +95,22 @@ if len(sys.argv) > 3 and sys.argv[3] == "cli":
         dt = time.time() - t0
         print("merfin -polish MFX_VARIANT_SLOTS=%s: rc=%d wall=%.2fs same=%s" % (slots, r.returncode, dt, open(out + "/cli_s" + slots + ".polish.vcf").read() == a_))
         print("    " + "\n    ".join(l for l in r.stderr.splitlines() if "timing" in l or "ERROR" in l or "ingest" in l or "mfx_variants]" in l and "load:" not in l))
+
+    if os.environ.get("MFX_CFG4_DIFF"):
+        # the VCF loaded ahead (default) against MFX_CLI_VCF_AHEAD=0: the outputs, and where they differ
+        outs = {}
+        for ah in ("1", "0", "1"):
+            time.sleep(float(os.environ.get("MFX_CFG4_SLEEP", "0")))
+            r = subprocess.run([exe, "-polish", "-sequence", out + "/asm.fasta", "-readmers", out + "/read.mfxk", "-seqmers", out + "/asm.mfxk", "-peak", str(lam),
+                                "-vcf", vcf, "-output", out + "/cli_ah" + ah], capture_output=True, text=True, env=dict(os.environ, MFX_CLI_VCF_AHEAD=ah))
+            t = open(out + "/cli_ah" + ah + ".polish.vcf").read().splitlines()
+            print("MFX_CLI_VCF_AHEAD=%s rc=%d: %d lines; == 8 slots: %s; == first ahead run: %s" % (ah, r.returncode, len(t), "\n".join(t) + "\n" == b_, outs.get("1") == t if "1" in outs else None))
+            outs[ah] = t
+        A, B = outs["1"], outs["0"]
+        nd = 0
+        for i, (x, y) in enumerate(zip(A, B)):
+            if x != y:
+                nd += 1
+                if nd <= 8:
+                    print("line %d:\n  ahead: %s\n  plain: %s" % (i, x[:160], y[:160]))
+        print("differing lines: %d of %d / %d; same multiset: %s" % (nd, len(A), len(B), sorted(A) == sorted(B)))

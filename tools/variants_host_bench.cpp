@@ -15,6 +15,8 @@ using PathScores = std::function<int(const char *, uint64_t, const mfx_path_tabl
 int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const char *vcf_path, const char *const *names, const char *const *bases,
                             const uint64_t *lens, uint32_t ncontigs, const mfx_variant_opts *opts, const char *out_path, const char *log_path,
                             uint64_t *n_clusters, const PathScores &scores, struct mfx_vcf *loaded);
+extern "C" struct mfx_vcf *mfx_vcf_load(const char *vcf_path);
+extern "C" void mfx_vcf_free(struct mfx_vcf *);
 
 int main(int argc, char **argv) {
   const uint64_t total = argc > 1 ? (uint64_t)atof(argv[1]) : 100000000ull;
@@ -101,7 +103,10 @@ int main(int argc, char **argv) {
   mfx_variant_opts vo{mode, argc > 5 ? (uint32_t)atoi(argv[5]) : 15u, 0, argc > 4 && argv[4][0] ? argv[4] : nullptr};   // argv[4] = -debug file, argv[5] = -comb
   uint64_t ncl = 0;
   auto t0 = std::chrono::steady_clock::now();
-  int rc = mfx_variants_run_values(&ev, values, vp, nm.data(), bs.data(), ln.data(), nc, &vo, "/tmp/mfx_vhb.out.vcf", "/tmp/mfx_vhb.log", &ncl, dev ? scores : PathScores(), nullptr);
+  // argv[7] = 1: the VCF loaded ahead of the run (mfx_vcf_load), as the CLI does under its index build
+  struct mfx_vcf *ahead = (argc > 7 && atoi(argv[7])) ? mfx_vcf_load(vp) : nullptr;
+  int rc = mfx_variants_run_values(&ev, values, ahead ? nullptr : vp, nm.data(), bs.data(), ln.data(), nc, &vo, "/tmp/mfx_vhb.out.vcf", "/tmp/mfx_vhb.log", &ncl, dev ? scores : PathScores(), ahead);
+  if (ahead) mfx_vcf_free(ahead);
   double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   printf("rc %d: %lu bases, %lu calls, %lu clusters in %.2f s = %.0f clusters/s\n", rc, (unsigned long)total, (unsigned long)calls, (unsigned long)ncl, dt, ncl / dt);
   return rc;
