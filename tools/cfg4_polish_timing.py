@@ -85,6 +85,24 @@ if len(sys.argv) > 3 and sys.argv[3] == "cli":
         print("    " + "\n    ".join(l for l in r.stderr.splitlines() if "timing" in l or "ERROR" in l))
     a_, b_ = open(out + "/cli_1.polish.vcf").read(), open(out + "/cli_15.polish.vcf").read()
     print("8 slots == 1 device:", a_ == b_, len(a_))
+    try:
+        print("host: %d cpus in the affinity mask, cpu.max %s" % (len(os.sched_getaffinity(0)), open("/sys/fs/cgroup/cpu.max").read().strip()))
+    except Exception:
+        pass
+    if a_ != b_:
+        A, B = a_.splitlines(), b_.splitlines()
+        nd = 0
+        for i, (x, y) in enumerate(zip(A, B)):
+            if x != y:
+                nd += 1
+                if nd <= 12:
+                    print("line %d:\n  1 slot : %s\n  8 slots: %s" % (i, x[:200], y[:200]))
+        print("differing lines: %d of %d / %d; same multiset: %s" % (nd, len(A), len(B), sorted(A) == sorted(B)))
+        import shutil
+        os.makedirs(os.path.join(ROOT, "gpurun_out", "cfg4_diff"), exist_ok=True)
+        open(os.path.join(ROOT, "gpurun_out", "cfg4_diff", "api.polish.head"), "w").write("".join(open(out + "/out.polish.vcf").readlines()[:20]))
+        api = open(out + "/out.polish.vcf").read()
+        print("API -polish == 1 slot: %s, == 8 slots: %s" % (api == a_, api == b_))
     # one device run as 1 / 2 / 4 (the default) slots sharing its table: which fills the host best
     for slots in (os.environ.get("MFX_CFG4_SLOTS", "1,2,4,1,4")).split(","):
         time.sleep(float(os.environ.get("MFX_CFG4_SLEEP", "0")))        # (the driver scrubs what the run before freed: a table allocated at once waits for it)
