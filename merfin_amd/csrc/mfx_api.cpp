@@ -67,7 +67,7 @@ extern "C" int mfx_diag_gather_rate(int device, uint64_t table_bytes, double *li
   uint64_t *scratch = nullptr;
   hipError_t e = hipMalloc(&t, table_bytes);
   if (e == hipSuccess) e = hipMalloc((void **)&scratch, 8);
-  if (e == hipSuccess) e = hipMemset(t, 0x5a, table_bytes);
+  if (e == hipSuccess) e = mfx_memset_now(t, 0x5a, table_bytes);
   if (e == hipSuccess) e = mfx_k_gather_rate(t, table_bytes / MFX_ALIGN, scratch, lines_per_s, nullptr);
   if (t) (void)hipFree(t);
   if (scratch) (void)hipFree(scratch);
@@ -86,7 +86,7 @@ extern "C" int mfx_device_warm(int device) {
   void *d = nullptr, *h = nullptr;
   hipStream_t st = nullptr;
   hipError_t e = hipMalloc(&d, 1 << 20);
-  if (e == hipSuccess) e = hipMemset(d, 0, 1 << 20);
+  if (e == hipSuccess) e = mfx_memset_now(d, 0, 1 << 20);
   if (e == hipSuccess) e = mfx_k_table_init(reinterpret_cast<mfx_slot *>(d), (1 << 20) / sizeof(mfx_slot), nullptr);
   if (e == hipSuccess) e = hipHostMalloc(&h, 1 << 20, hipHostMallocDefault);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
@@ -406,7 +406,7 @@ static mfx_index *index_create(int k, uint64_t capacity_kmers, double max_gb, in
     return nullptr;
   }
   if (hipMalloc((void **)&ix->d_meta, MFX_META_WORDS * sizeof(uint64_t)) != hipSuccess ||
-      hipMemset(ix->d_meta, 0, MFX_META_WORDS * sizeof(uint64_t)) != hipSuccess ||
+      mfx_memset_now(ix->d_meta, 0, MFX_META_WORDS * sizeof(uint64_t)) != hipSuccess ||
       (ix->wide() ? hipMemsetAsync(ix->d_slots, 0, ix->nlines * MFX_ALIGN, nullptr)           // state 0 = empty
        : ix->compact ? hipMemsetAsync(ix->d_slots, 0xff, ix->nlines * MFX_ALIGN, nullptr)      // 8-byte slots: the all-ones word is empty
                      : mfx_k_table_init(ix->d_slots, ix->nlines * MFX_SLOTS_LINE, nullptr)) != hipSuccess ||
@@ -971,7 +971,7 @@ extern "C" int mfx_index_export(const mfx_index *ix, uint64_t *kmers, uint32_t *
   MFX_HIP(dr.alloc(info.distinct));
   MFX_HIP(da.alloc(info.distinct));
   MFX_HIP(dc.alloc(1));
-  MFX_HIP(hipMemset(dc.p, 0, sizeof(unsigned long long)));
+  MFX_HIP(mfx_memset_now(dc.p, 0, sizeof(unsigned long long)));
   MFX_HIP(ix->wide() ? mfx_kw_table_export(ix->view(), dk.p, dr.p, da.p, dc.p, nullptr) : mfx_k_table_export(ix->view(), dk.p, dr.p, da.p, dc.p, nullptr));
   unsigned long long cnt = 0;
   MFX_HIP(hipMemcpy(&cnt, dc.p, sizeof(cnt), hipMemcpyDeviceToHost));
@@ -1012,7 +1012,7 @@ static mfx_seq *seq_layout(int device, const uint64_t *lens, uint32_t ncontigs) 
 static int seq_need_bases(mfx_seq *s) {
   if (s->d_bases) return MFX_OK;
   MFX_HIP(hipMalloc((void **)&s->d_bases, s->buf_bytes));
-  MFX_HIP(hipMemset(s->d_bases, 0, s->buf_bytes));                    // byte 0 is not ACGT: separators + padding
+  MFX_HIP(mfx_memset_now(s->d_bases, 0, s->buf_bytes));                    // byte 0 is not ACGT: separators + padding
   return MFX_OK;
 }
 
@@ -1063,9 +1063,9 @@ int mfx_seq_digest32(const mfx_seq *s, uint32_t *out) {
     DevGuard g(s->device);
     uint64_t *d = nullptr, h = 0;
     MFX_HIP(hipMalloc((void **)&d, sizeof(uint64_t)));
-    hipError_t e = hipMemset(d, 0, sizeof(uint64_t));
+    hipError_t e = mfx_memset_now(d, 0, sizeof(uint64_t));
     const bool planes = s->planes_ok || s->bases_stale;
-    if (!planes && !s->d_bases) { (void)hipFree(d); if (int rc = seq_need_bases(const_cast<mfx_seq *>(s))) return rc; MFX_HIP(hipMalloc((void **)&d, sizeof(uint64_t))); e = hipMemset(d, 0, sizeof(uint64_t)); }
+    if (!planes && !s->d_bases) { (void)hipFree(d); if (int rc = seq_need_bases(const_cast<mfx_seq *>(s))) return rc; MFX_HIP(hipMalloc((void **)&d, sizeof(uint64_t))); e = mfx_memset_now(d, 0, sizeof(uint64_t)); }
     if (e == hipSuccess) e = mfx_k_seq_digest(s->d_bases, planes ? s->d_codes : nullptr, planes ? s->d_valid : nullptr, s->buf_bytes / 32, d, nullptr);
     if (e == hipSuccess) e = hipMemcpy(&h, d, sizeof(h), hipMemcpyDeviceToHost);
     (void)hipFree(d);
@@ -1258,9 +1258,9 @@ extern "C" mfx_eval *mfx_eval_create(const mfx_index *ix, const mfx_kparams *kp,
       hipMalloc((void **)&ev->d_probP, np * sizeof(double)) != hipSuccess ||
       hipMalloc((void **)&ev->d_partials, 2 * (size_t)ev->grid * sizeof(double)) != hipSuccess ||
       hipMalloc((void **)&ev->d_tile_ctr, 2 * sizeof(uint64_t)) != hipSuccess ||
-      hipMemset(ev->d_tile_ctr, 0, 2 * sizeof(uint64_t)) != hipSuccess ||
+      mfx_memset_now(ev->d_tile_ctr, 0, 2 * sizeof(uint64_t)) != hipSuccess ||
       hipMalloc((void **)&ev->d_ovf, (1 + (size_t)MFX_OVF_CAP) * sizeof(uint64_t)) != hipSuccess ||
-      hipMemset(ev->d_ovf, 0, sizeof(uint64_t)) != hipSuccess ||
+      mfx_memset_now(ev->d_ovf, 0, sizeof(uint64_t)) != hipSuccess ||
       (ev->n_prob && hipMemcpy(ev->d_probK, ev->probK.data(), ev->n_prob * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) ||
       (ev->n_prob && hipMemcpy(ev->d_probP, ev->probP.data(), ev->n_prob * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)) {
     mfx_fail(MFX_E_HIP, "mfx_eval_create: device setup failed: %s", hipGetErrorString(hipGetLastError()));
@@ -1303,7 +1303,7 @@ extern "C" int mfx_eval_debug_enable(mfx_eval *ev, int on) {
   DevGuard g(ev->device);
   if (on && !ev->d_dbg) {
     MFX_HIP(hipMalloc((void **)&ev->d_dbg, 8 * sizeof(uint64_t)));
-    MFX_HIP(hipMemset(ev->d_dbg, 0, 8 * sizeof(uint64_t)));
+    MFX_HIP(mfx_memset_now(ev->d_dbg, 0, 8 * sizeof(uint64_t)));
   } else if (!on && ev->d_dbg) {
     MFX_HIP(hipDeviceSynchronize());
     (void)hipFree(ev->d_dbg);
@@ -1320,7 +1320,7 @@ extern "C" int mfx_eval_debug_counters(mfx_eval *ev, uint64_t *out8) {
   DevGuard g(ev->device);
   MFX_HIP(hipDeviceSynchronize());
   MFX_HIP(hipMemcpy(out8, ev->d_dbg, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-  MFX_HIP(hipMemset(ev->d_dbg, 0, 8 * sizeof(uint64_t)));
+  MFX_HIP(mfx_memset_now(ev->d_dbg, 0, 8 * sizeof(uint64_t)));
   return MFX_OK;
 }
 
@@ -1480,7 +1480,7 @@ extern "C" int mfx_hist_take_overflow(mfx_eval *ev, uint64_t *records, uint64_t 
                     "create the evaluator with a larger nbins", (unsigned long)n, ev->nbins, MFX_OVF_CAP);
   uint64_t m = std::min(n, cap);
   if (m && records) MFX_HIP(hipMemcpy(records, ev->d_ovf + 1, m * sizeof(uint64_t), hipMemcpyDeviceToHost));
-  MFX_HIP(hipMemset(ev->d_ovf, 0, sizeof(uint64_t)));
+  MFX_HIP(mfx_memset_now(ev->d_ovf, 0, sizeof(uint64_t)));
   *n_out = n;
   return (n > cap) ? mfx_fail(MFX_E_OVERFLOW, "overflow list has %lu records, caller buffer %lu", (unsigned long)n, (unsigned long)cap) : MFX_OK;
 }
@@ -1864,8 +1864,8 @@ static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *cons
   if (!seq->d_codes) {
     STREAMED_HIP(hipMalloc((void **)&seq->d_codes, plane_words * sizeof(uint64_t)));
     STREAMED_HIP(hipMalloc((void **)&seq->d_valid, plane_words * sizeof(uint32_t)));
-    STREAMED_HIP(hipMemset(seq->d_valid, 0, plane_words * sizeof(uint32_t)));           // no valid base outside the uploads
-    STREAMED_HIP(hipMemset(seq->d_codes, 0, plane_words * sizeof(uint64_t)));
+    STREAMED_HIP(mfx_memset_now(seq->d_valid, 0, plane_words * sizeof(uint32_t)));           // no valid base outside the uploads
+    STREAMED_HIP(mfx_memset_now(seq->d_codes, 0, plane_words * sizeof(uint64_t)));
   }
   // pinned staging (codes words, then validity words) belongs to the evaluator: pinning costs more than the evaluation
   if (ev->h_pack_words != STAGE_W) {
@@ -2388,8 +2388,8 @@ static int seq_alloc_planes(mfx_seq *s) {
   const uint64_t pw = seq_plane_words(s);
   MFX_HIP(hipMalloc((void **)&s->d_codes, pw * sizeof(uint64_t)));
   MFX_HIP(hipMalloc((void **)&s->d_valid, pw * sizeof(uint32_t)));
-  MFX_HIP(hipMemset(s->d_valid, 0, pw * sizeof(uint32_t)));           // no valid base behind the sequence
-  MFX_HIP(hipMemset(s->d_codes, 0, pw * sizeof(uint64_t)));
+  MFX_HIP(mfx_memset_now(s->d_valid, 0, pw * sizeof(uint32_t)));           // no valid base behind the sequence
+  MFX_HIP(mfx_memset_now(s->d_codes, 0, pw * sizeof(uint64_t)));
   return MFX_OK;
 }
 
@@ -3182,7 +3182,7 @@ extern "C" int mfx_dump_values(mfx_eval *ev, const mfx_seq *seq, uint32_t contig
   MFX_HIP(dr.alloc(n));
   MFX_HIP(da.alloc(n));
   MFX_HIP(ds.alloc(2));
-  MFX_HIP(hipMemset(ds.p, 0, 2 * sizeof(uint64_t)));
+  MFX_HIP(mfx_memset_now(ds.p, 0, 2 * sizeof(uint64_t)));
   mfx_dump_args a;
   a.t = ev->ix->view();
   a.canonical = canon;
@@ -3653,7 +3653,7 @@ extern "C" int mfx_completeness_pieces(mfx_eval *ev, double *total64, double *un
   DevGuard g(ev->device);
   DevBuf<double> dp;
   MFX_HIP(dp.alloc(128));
-  MFX_HIP(hipMemset(dp.p, 0, 128 * sizeof(double)));
+  MFX_HIP(mfx_memset_now(dp.p, 0, 128 * sizeof(double)));
   MFX_HIP(ev->ix->wide() ? mfx_kw_completeness(ev->ix->view(), ev->peak, ev->n_prob, ev->d_probK, ev->d_probP, dp.p, ev->grid, nullptr)
                           : mfx_k_completeness(ev->ix->view(), ev->peak, ev->n_prob, ev->d_probK, ev->d_probP, dp.p, ev->grid, nullptr));
   double h[128];

@@ -27,6 +27,21 @@ int  mfx_fail(int code, const char *fmt, ...);
     }                                                                                         \
   } while (0)
 
+// A fill of device memory that is COMPLETE when the call returns.  hipMemset is not: it only queues the fill on the null stream
+// (tools/native/memset_probe.hip on the MI355X: it returns after 10 us while a 0.2 s kernel holds that stream, a copy issued next on
+// a non-blocking stream lands first -- and is then wiped by the late fill).  Every buffer here is filled on one stream and next
+// touched on another (the non-blocking copy / compute streams), so every fill is waited for.  That was how eight variant slots on
+// one device lost the records of a batch now and then: slot A's path text, uploaded on its copy stream, was zeroed by its own
+// plane fill, which had queued behind slot B's kernels on the null stream.
+static inline hipError_t mfx_memset_now(void *p, int v, size_t n) {
+#ifdef MFX_V_QUEUED_FILLS                                     // A/B build only: the behaviour before (tests/test_gpu_null_stream.py must FAIL on it)
+  return hipMemset(p, v, n);
+#else
+  const hipError_t e = hipMemsetAsync(p, v, n, nullptr);
+  return e == hipSuccess ? hipStreamSynchronize(nullptr) : e;
+#endif
+}
+
 // flat-binary database -> table, read with parallel pread into the index's staging lanes (mfx_api.cpp)
 // vals_off == 0: the records at keys_off are PACKED (MFX_PACKED_VBITS), there is no counts array
 int  mfx_index_add_from_file(struct mfx_index *const *ixs, uint32_t nix, int fd, const char *path, uint64_t keys_off, uint64_t vals_off,
