@@ -13,11 +13,39 @@ from tests.test_gpu_parity import assert_hist_equal, build_index, oracle_hist
 pytestmark = pytest.mark.gpu
 
 
-def _busy(torch, a, n=40):
-    for _ in range(n):                                       # ~0.2-0.4 s of fp32 GEMMs queued on the null stream
-        a = a @ a
-        a = a / a.abs().max()
-    return a
+class _BusyNullStream:
+    """a thread that keeps a few fp32 GEMMs queued on the null stream (torch's default stream) until it is stopped"""
+
+    def __init__(self, torch):
+        import threading
+        self.torch, self.stop, self.launched = torch, False, 0
+        self.a = torch.randn(4096, 4096, device="cuda")
+        self.t = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        torch, x, evs = self.torch, self.a, []
+        while not self.stop:
+            for _ in range(4):
+                x = x @ self.a
+                x = x / x.abs().max()
+            e = torch.cuda.Event()
+            e.record()
+            evs.append(e)
+            self.launched += 4
+            if len(evs) > 3:
+                evs.pop(0).synchronize()                     # at most ~16 GEMMs in the queue: the stream is never idle, never far ahead
+        torch.cuda.synchronize()
+        self.ok = bool(torch.isfinite(x).all())
+
+    def __enter__(self):
+        self.t.start()
+        while self.launched < 8:
+            pass
+        return self
+
+    def __exit__(self, *exc):
+        self.stop = True
+        self.t.join()
 
 
 def test_fills_are_waited_for_while_the_null_stream_is_busy(monkeypatch):
@@ -30,20 +58,15 @@ def test_fills_are_waited_for_while_the_null_stream_is_busy(monkeypatch):
     ix = build_index(m, k, read, asm)
     ev = m.Evaluator(ix, m.KParams(peak))
     idle = ev.dump_values(m.Sequences(contigs), 0, 0, len(contigs[0]))
-    a = torch.randn(6144, 6144, device="cuda")
-    for rep in range(3):
-        x = _busy(torch, a)
-        seqs = m.Sequences(contigs)                          # planes filled + uploaded under the GEMMs
-        got = ev.dump_values(seqs, 0, 0, len(contigs[0]))    # one byte per base made from the planes, then the lookup kernel
-        np.testing.assert_array_equal(got[0], idle[0])
-        np.testing.assert_array_equal(got[1], idle[1])
-        assert got[2:] == idle[2:]
-        x = _busy(torch, x)
-        assert_hist_equal(ev.hist(m.Sequences(contigs)), g, ka, km, k)
-        x = _busy(torch, x)
-        assert_hist_equal(ev.hist_streamed(m.Sequences.create([len(c) for c in contigs]), contigs), g, ka, km, k)
-        x = _busy(torch, x)
-        ev2 = m.Evaluator(ix, m.KParams(peak))               # an evaluator's counters are filled at its creation
-        assert_hist_equal(ev2.hist(seqs), g, ka, km, k)
-        torch.cuda.synchronize()
-        assert bool(torch.isfinite(x).all())
+    with _BusyNullStream(torch) as busy:
+        for rep in range(6):
+            seqs = m.Sequences(contigs)                          # planes filled + uploaded under the GEMMs
+            got = ev.dump_values(seqs, 0, 0, len(contigs[0]))    # one byte per base made from the planes, then the lookup kernel
+            np.testing.assert_array_equal(got[0], idle[0])
+            np.testing.assert_array_equal(got[1], idle[1])
+            assert got[2:] == idle[2:]
+            assert_hist_equal(ev.hist(m.Sequences(contigs)), g, ka, km, k)
+            assert_hist_equal(ev.hist_streamed(m.Sequences.create([len(c) for c in contigs]), contigs), g, ka, km, k)
+            ev2 = m.Evaluator(ix, m.KParams(peak))               # an evaluator's counters are filled at its creation
+            assert_hist_equal(ev2.hist(seqs), g, ka, km, k)
+    assert busy.ok and busy.launched >= 8
