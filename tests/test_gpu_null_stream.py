@@ -70,3 +70,59 @@ def test_fills_are_waited_for_while_the_null_stream_is_busy(monkeypatch):
             ev2 = m.Evaluator(ix, m.KParams(peak))               # an evaluator's counters are filled at its creation
             assert_hist_equal(ev2.hist(seqs), g, ka, km, k)
     assert busy.ok and busy.launched >= 8
+
+
+def test_builds_and_multi_slot_runs_while_the_null_stream_is_busy(tmp_path):
+    """the same for everything else that hands buffers from one stream to another: index builds through the staging lanes (host
+    arrays, a database file), the sequence-only build, replicas and N slots on one device, the sharded route -> owner loop,
+    -completeness and a variant mode with device scoring -- each compared with its own result on the idle device"""
+    torch = pytest.importorskip("torch")
+    import merfin_amd as m
+    k, peak = 21, 17.3
+    contigs, read, asm = synth.world(k=k, peak=peak, seed=4712, sizes=(70000, 20000, 4097, 33))
+    p, g, ka, km = oracle_hist(k, peak, contigs, read, asm)
+    names, vasm, vcf, vread, vamers = synth.variant_world(k=k, peak=peak, seed=4713)
+    vp = str(tmp_path / "in.vcf")
+    open(vp, "w").write(vcf)
+    db = str(tmp_path / "read.mfxk")
+    m.db_write_flat(db, k, read[0], read[1])
+
+    def everything(tag):
+        out = {}
+        ix = build_index(m, k, read, asm)                                     # host arrays through the staging lanes
+        ev = m.Evaluator(ix, m.KParams(peak))
+        seqs = m.Sequences(contigs)
+        assert_hist_equal(ev.hist(seqs), g, ka, km, k)
+        out["compl"] = ev.completeness()
+        six = m.Index.for_seq(k, sum(len(c) for c in contigs) + 16)           # claim + count under the database's transfer
+        six.build_for_hist(seqs, db)
+        assert_hist_equal(m.Evaluator(six, m.KParams(peak)).hist(seqs), g, ka, km, k)
+        n = 3                                                                 # replicas + N slots on this device
+        ixs = [ix] + [ix.replicate(0) for _ in range(n - 1)]
+        sqs = [seqs] + [seqs.replicate(0) for _ in range(n - 1)]
+        assert_hist_equal(m.hist_multi([m.Evaluator(x, m.KParams(peak)) for x in ixs], sqs), g, ka, km, k)
+        shards = []
+        for r in range(n):                                                    # the sharded route -> owner loop
+            sx = m.Index(k, len(read[0]) + len(asm[0]) + 16)
+            sx.set_shard(r, n)
+            sx.add_read(*read)
+            sx.add_asm(*asm)
+            shards.append(sx)
+        sev = [m.Evaluator(x, m.KParams(peak)) for x in shards]
+        routers = [m.Router(x, n, min(2, seqs.ntiles)) for x in shards]
+        assert_hist_equal(m.hist_sharded(sev, routers, [seqs] * n), g, ka, km, k)
+        vix = m.Index(k, len(vread[0]) + len(vamers[0]) + 16)                 # a variant mode, scored on the device
+        vix.add_read(*vread)
+        vix.add_asm(*vamers)
+        o = str(tmp_path / ("polish_%s.vcf" % tag))
+        m.Evaluator(vix, m.KParams(peak)).variants("polish", vp, names, vasm, o, log_path=str(tmp_path / "log"))
+        out["polish"] = open(o, "rb").read()
+        return out
+
+    idle = everything("idle")
+    with _BusyNullStream(torch) as busy:
+        for rep in range(2):
+            got = everything("busy%d" % rep)
+            assert got["compl"] == idle["compl"]
+            assert got["polish"] == idle["polish"] and len(got["polish"]) > 1000
+    assert busy.ok
