@@ -9,7 +9,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-MFX_BENCH_KEEP_PMC=$OUT/pmc python $REPO/bench.py --gpus 1 --steps 10 --warmup 3 > $OUT/bench.json 2> $OUT/bench.log
+B0=$SECONDS; MFX_BENCH_KEEP_PMC=$OUT/pmc python $REPO/bench.py --gpus 1 --steps 10 --warmup 3 > $OUT/bench.json 2> $OUT/bench.log; echo "default bench run: $((SECONDS - B0)) s wall" | tee $OUT/bench_wall.txt
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python $REPO/bench.py --gpus 1 --steps 10 --warmup 3 --no-pmc --no-streamed --no-e2e --no-full-index > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.log
 find $OUT -name "*.csv" | head -50
 # keep the merged-back payload small: drop per-launch traces
