@@ -132,3 +132,22 @@ if len(sys.argv) > 3 and sys.argv[3] == "cli":
                 if nd <= 8:
                     print("line %d:\n  ahead: %s\n  plain: %s" % (i, x[:160], y[:160]))
         print("differing lines: %d of %d / %d; same multiset: %s" % (nd, len(A), len(B), sorted(A) == sorted(B)))
+
+    if os.environ.get("MFX_CFG4_SOAK"):
+        # every report type in 1 / 4 / 8 slots on this device, several times: the outputs must be the single slot's, byte for byte
+        # (slots on one device share its null stream: what a fill, a copy or a kernel of one slot may do to another shows here)
+        reps = int(os.environ["MFX_CFG4_SOAK"])
+        common = ["-sequence", out + "/asm.fasta", "-readmers", out + "/read.mfxk", "-seqmers", out + "/asm.mfxk", "-peak", str(lam)]
+        ref = {}
+        for op, extra, suffix in (("-hist", [], ""), ("-dump", [], ""), ("-polish", ["-vcf", vcf], ".polish.vcf"), ("-filter", ["-vcf", vcf], ".filter.vcf")):
+            for devs in ("0", "0,0,0,0", "0,0,0,0,0,0,0,0"):
+                for rep in range(1 if devs == "0" else reps):
+                    o = out + "/soak" + op
+                    t0 = time.time()
+                    r = subprocess.run([exe, op] + common + extra + ["-output", o, "-devices", devs], capture_output=True, text=True)
+                    data = open(o + suffix, "rb").read() if r.returncode == 0 else b""
+                    if devs == "0":
+                        ref[op] = data
+                    print("soak %s -devices %-15s rep %d: rc=%d %.2fs %d bytes same=%s" % (op, devs, rep, r.returncode, time.time() - t0, len(data), data == ref[op]), flush=True)
+                    if r.returncode:
+                        print(r.stderr[-400:])
