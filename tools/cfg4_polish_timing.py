@@ -139,7 +139,10 @@ if len(sys.argv) > 3 and sys.argv[3] == "cli":
         reps = int(os.environ["MFX_CFG4_SOAK"])
         common = ["-sequence", out + "/asm.fasta", "-readmers", out + "/read.mfxk", "-seqmers", out + "/asm.mfxk", "-peak", str(lam)]
         ref = {}
+        ops = os.environ.get("MFX_CFG4_SOAK_OPS", "-hist,-dump,-polish,-filter").split(",")
         for op, extra, suffix in (("-hist", [], ""), ("-dump", [], ""), ("-polish", ["-vcf", vcf], ".polish.vcf"), ("-filter", ["-vcf", vcf], ".filter.vcf")):
+            if op not in ops:
+                continue
             for devs in ("0", "0,0,0,0", "0,0,0,0,0,0,0,0"):
                 for rep in range(1 if devs == "0" else reps):
                     o = out + "/soak" + op
