@@ -152,5 +152,6 @@ if len(sys.argv) > 3 and sys.argv[3] == "cli":
                     if devs == "0":
                         ref[op] = data
                     print("soak %s -devices %-15s rep %d: rc=%d %.2fs %d bytes same=%s" % (op, devs, rep, r.returncode, time.time() - t0, len(data), data == ref[op]), flush=True)
-                    if r.returncode:
-                        print(r.stderr[-400:])
+                    if r.returncode or data != ref[op]:
+                        print("    " + "\n    ".join(r.stderr.splitlines()[-25:]))
+                        print("    files:", sorted(f for f in os.listdir(out) if f.startswith("soak")))
