@@ -1039,7 +1039,13 @@ static int seq_alloc(mfx_seq *s, bool with_bases = true) {
 
 // A packed upload (mfx_hist_run_streamed) leaves the sequence in its packed planes only; the kernels that read one byte
 // per base get them unpacked here, once, on first use.
+// What a sequence makes on first use -- its bytes per base, its packed planes, its content digest -- is made under this lock:
+// N slots that share a device share its mfx_seq (merfin -dump -devices 0,0,0,0: four threads ask one sequence for its bytes at
+// once; unguarded, one thread's fill of the fresh buffer wiped what another had just unpacked and that slot dumped empty contigs).
+static std::mutex &seq_lazy_mutex() { static std::mutex m; return m; }
+
 int mfx_seq_ensure_ascii(const mfx_seq *cs) {
+  std::lock_guard<std::mutex> lazy(seq_lazy_mutex());
   if (!cs->bases_stale && cs->d_bases) return MFX_OK;
   mfx_seq *s = const_cast<mfx_seq *>(cs);
   DevGuard g(s->device);
@@ -1059,6 +1065,7 @@ static void seq_digest_finish(const mfx_seq *s, uint64_t h) {
 }
 
 int mfx_seq_digest32(const mfx_seq *s, uint32_t *out) {
+  std::lock_guard<std::mutex> lazy(seq_lazy_mutex());
   if (s->digest == 0) {
     DevGuard g(s->device);
     uint64_t *d = nullptr, h = 0;
@@ -2396,6 +2403,7 @@ static int seq_alloc_planes(mfx_seq *s) {
 // the packed planes of a resident sequence (2-bit codes + one validity bit per base, the tile's own form), made on the device
 extern "C" int mfx_seq_pack(mfx_seq *s) {
   if (!s) return mfx_fail(MFX_E_INVAL, "mfx_seq_pack: null argument");
+  std::lock_guard<std::mutex> lazy(seq_lazy_mutex());
   if (s->planes_ok) return MFX_OK;
   DevGuard g(s->device);
   int rc = seq_alloc_planes(s);

@@ -126,3 +126,44 @@ def test_builds_and_multi_slot_runs_while_the_null_stream_is_busy(tmp_path):
             assert got["compl"] == idle["compl"]
             assert got["polish"] == idle["polish"] and len(got["polish"]) > 1000
     assert busy.ok
+
+
+def test_slots_sharing_one_sequence_ask_for_its_bytes_at_once(monkeypatch):
+    """N slots on one device share its mfx_seq (merfin -dump -devices 0,0,0,0).  A sequence uploaded packed makes its bytes per
+    base on first use: four threads asking at once must all see them complete (unguarded, one thread's fill of the fresh buffer
+    wiped what another had just unpacked: that slot dumped contigs without a single valid k-mer, exit code 0)"""
+    import threading
+    import merfin_amd as m
+    k, peak = 21, 17.3
+    contigs, read, asm = synth.world(k=k, peak=peak, seed=4714, sizes=(60000, 50000, 40000, 30000, 20000, 10000, 5000, 4097))
+    monkeypatch.setenv("MFX_UPLOAD_PACKED_MIN", "1")
+    ix = build_index(m, k, read, asm)
+    ref_ev = m.Evaluator(ix, m.KParams(peak))
+    ref_seqs = m.Sequences(contigs)
+    ref = [ref_ev.dump_values(ref_seqs, c, 0, len(contigs[c])) for c in range(len(contigs))]
+    assert sum(r[2] for r in ref) > 100000
+    for rep in range(8):
+        seqs = m.Sequences(contigs)                              # packed planes only: nobody has asked for the bytes yet
+        n = 4
+        evs = [m.Evaluator(ix, m.KParams(peak)) for _ in range(n)]
+        got, errs = {}, []
+        gate = threading.Barrier(n)
+
+        def slot(d):
+            try:
+                gate.wait()
+                for c in range(d, len(contigs), n):
+                    got[c] = evs[d].dump_values(seqs, c, 0, len(contigs[c]))
+            except Exception as e:                               # noqa: BLE001
+                errs.append(repr(e))
+
+        th = [threading.Thread(target=slot, args=(d,)) for d in range(n)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+        for c in range(len(contigs)):
+            np.testing.assert_array_equal(got[c][0], ref[c][0])
+            np.testing.assert_array_equal(got[c][1], ref[c][1])
+            assert got[c][2:] == ref[c][2:]
