@@ -140,10 +140,13 @@ if len(sys.argv) > 3 and sys.argv[3] == "cli":
         common = ["-sequence", out + "/asm.fasta", "-readmers", out + "/read.mfxk", "-seqmers", out + "/asm.mfxk", "-peak", str(lam)]
         ref = {}
         ops = os.environ.get("MFX_CFG4_SOAK_OPS", "-hist,-dump,-polish,-filter").split(",")
-        for op, extra, suffix in (("-hist", [], ""), ("-dump", [], ""), ("-polish", ["-vcf", vcf], ".polish.vcf"), ("-filter", ["-vcf", vcf], ".filter.vcf")):
-            if op not in ops:
+        for op, extra, suffix in (("-hist", [], ""), ("-dump", [], ""), ("-polish", ["-vcf", vcf], ".polish.vcf"), ("-filter", ["-vcf", vcf], ".filter.vcf"),
+                                  ("-hist", ["-sharded"], ""), ("-dump", ["-sharded"], ""), ("-polish", ["-sharded", "-vcf", vcf], ".polish.vcf")):
+            if op not in ops or ("-sharded" in extra and not os.environ.get("MFX_CFG4_SOAK_SHARDED")):
                 continue
             for devs in ("0", "0,0,0,0", "0,0,0,0,0,0,0,0"):
+                if devs == "0" and "-sharded" in extra:
+                    continue                                        # (the reference is the unsharded single slot's, above)
                 for rep in range(1 if devs == "0" else reps):
                     o = out + "/soak" + op
                     t0 = time.time()
@@ -151,7 +154,7 @@ if len(sys.argv) > 3 and sys.argv[3] == "cli":
                     data = open(o + suffix, "rb").read() if r.returncode == 0 else b""
                     if devs == "0":
                         ref[op] = data
-                    print("soak %s -devices %-15s rep %d: rc=%d %.2fs %d bytes same=%s" % (op, devs, rep, r.returncode, time.time() - t0, len(data), data == ref[op]), flush=True)
+                    print("soak %s %s-devices %-15s rep %d: rc=%d %.2fs %d bytes same=%s" % (op, "-sharded " if "-sharded" in extra else "", devs, rep, r.returncode, time.time() - t0, len(data), data == ref[op]), flush=True)
                     if r.returncode or data != ref[op]:
                         print("    " + "\n    ".join(r.stderr.splitlines()[-25:]))
                         print("    files:", sorted(f for f in os.listdir(out) if f.startswith("soak")))
