@@ -19,9 +19,15 @@
  *     code; mfx_last_error() then returns a thread-local description.  The
  *     library never calls exit() (the reference does: merfin-globals.C:31,152).
  *   - objects are bound to the HIP device they were created on; calls may come
- *     from any host thread; one object must not be used from two threads at
- *     once.  `stream` arguments are hipStream_t passed as void* (NULL = the
- *     device's default stream).
+ *     from any host thread.  An mfx_eval is used by one thread at a time.  An
+ *     mfx_seq and an mfx_index that are only READ (evaluations, lookups, dumps,
+ *     variant runs) may be shared by several evaluators driven from several
+ *     threads -- the slots of one device (`merfin -devices 0,0,0,0`): what a
+ *     sequence makes on first use is made under a lock, and no result depends
+ *     on what other threads have queued on the device.  Calls that CHANGE an
+ *     object (uploads into a sequence, adds / loads into an index) need it to
+ *     themselves.  `stream` arguments are hipStream_t passed as void* (NULL =
+ *     the device's default stream).
  *   - k-mers are 2k-bit integers, A=0 C=1 T=2 G=3, first base most significant
  *     (meryl's kmerTiny encoding), 1 <= k <= 64 as in the reference (its kmer type holds
  *     2k <= 128 bits).  For k <= 31 a k-mer is ONE uint64_t in every array of this ABI; for
