@@ -344,6 +344,12 @@ int read_meryl_data(const std::string &path, uint32_t file, const MerylIndex &mi
       break;
     }
     sums->blocks++;
+    // a k-mer of the block takes at least one bit of unary code, its binary part and its count: a header that claims more
+    // k-mers than the block has bits for is damaged (and must not size an allocation)
+    if (nk > (br.nbits - br.pos) / (1ull + bbits + (ccode == 1 ? 32u : 64u))) {
+      rc = mfx_fail(MFX_E_FORMAT, "'%s': a data block of %lu bits claims %lu k-mers", path.c_str(), (unsigned long)br.nbits, (unsigned long)nk);
+      break;
+    }
     if (count_only) { sums->kmers += nk; continue; }
     std::vector<u128> sfx(nk);
     u128 hi = 0;
@@ -388,7 +394,10 @@ int for_each_meryl_file(F &&fn) {
   std::string bad_msg;
   auto work = [&]() {
     for (uint32_t fl; (fl = next.fetch_add(1)) < 64;) {
-      int rc = fn(fl);
+      int rc;
+      try { rc = fn(fl); }                                     // (nothing may leave a worker thread -- or the C ABI -- as an exception)
+      catch (const std::bad_alloc &) { rc = mfx_fail(MFX_E_NOMEM, "meryl data file %u: out of memory", fl); }
+      catch (const std::exception &e) { rc = mfx_fail(MFX_E_FORMAT, "meryl data file %u: %s", fl, e.what()); }
       if (rc != MFX_OK) {
         std::lock_guard<std::mutex> g(emu);
         if (fl < bad_file) { bad_file = fl; bad_rc = rc; bad_msg = mfx_last_error(); }

@@ -153,3 +153,36 @@ def test_damaged_flat_headers_are_format_errors_not_aborts(tmp_path, n, n_escape
     with pytest.raises(m.MfxError) as e:
         m.db_convert(p, str(tmp_path / "o.mfxk"))
     assert "beyond the file's size" in str(e.value) or "more escapes" in str(e.value)
+
+
+def test_damaged_meryl_blocks_are_errors_not_aborts(tmp_path):
+    """every byte of the head of a data file (chunk framing, block header: prefix, number of k-mers, code widths) damaged in turn,
+    then truncations: the decoder answers with an error or -- where the damage is a valid database -- a result, never with an
+    exception through the C ABI (a block header claiming 2^60 k-mers used to size a vector: std::length_error, terminate)"""
+    import merfin_amd as m
+    k = 21
+    keys, vals = database(k, 3000, 99)
+    d = str(tmp_path / "db.meryl")
+    meryl_layout.write_db(d, k, keys, vals)
+    assert m.db_convert(d, str(tmp_path / "ok.mfxk")) == len(keys)
+    files = sorted(f for f in os.listdir(d) if f.endswith(".merylData"))
+    target = next(os.path.join(d, f) for f in files if os.path.getsize(os.path.join(d, f)) > 400)
+    img = open(target, "rb").read()
+    refused = accepted = 0
+    for at in range(0, 200):
+        for mask in (0x80, 0x01, 0xff):
+            dmg = bytearray(img)
+            dmg[at] ^= mask
+            open(target, "wb").write(bytes(dmg))
+            try:
+                m.db_convert(d, str(tmp_path / "o.mfxk"))
+                accepted += 1
+            except m.MfxError:
+                refused += 1
+    for cut in (0, 1, 8, 63, 64, 65, 200, len(img) // 2, len(img) - 1):
+        open(target, "wb").write(img[:cut])
+        with pytest.raises(m.MfxError):
+            m.db_convert(d, str(tmp_path / "o.mfxk"))
+    open(target, "wb").write(img)
+    assert m.db_convert(d, str(tmp_path / "ok2.mfxk")) == len(keys)
+    assert refused > 300                                      # (most damage is caught: framing, magic, monotony, the index's statistics)
