@@ -627,6 +627,11 @@ inline void put_int(std::string &o, long long v) {
   while (n) o += b[--n];
 }
 
+// to_string((int)qual) of the reference (varMer.C:486,537).  A QUAL outside the int range (or NaN) makes that conversion undefined
+// in C++; what the reference's binary does on x86-64 is the hardware's truncating conversion, whose answer for every such
+// value is INT_MIN -- said here in defined terms.
+inline int qual_as_int(double q) { return (q > -2147483649.0 && q < 2147483648.0) ? (int)q : (-2147483647 - 1); }
+
 // the records are appended to `out` (the text of a run of clusters: one write per run)
 void hom_record(std::string &out, const Cluster &cl, const int *g, size_t ng, const char *chr) {     // varMer.C:531-550
   for (size_t i = 0; i < ng; ++i) {
@@ -634,7 +639,7 @@ void hom_record(std::string &out, const Cluster &cl, const int *g, size_t ng, co
     if (a <= 0) continue;
     const Variant *v = cl.vars[i];
     out += chr; out += '\t'; put_int(out, (long long)(uint32_t)(v->pos + 1)); out += "\t.\t"; out += v->allele(0); out += '\t'; out += v->allele(a); out += '\t';
-    put_int(out, (int)v->qual); out += "\tPASS\t.\tGT\t1/1\n";
+    put_int(out, qual_as_int(v->qual)); out += "\tPASS\t.\tGT\t1/1\n";
   }
 }
 
@@ -643,7 +648,7 @@ void het_record(std::string &out, const Cluster &cl, const int *g1, const int *g
     int a1 = g1[i], a2 = g2[i];
     if (a1 + a2 <= 0) continue;
     const Variant *v = cl.vars[i];
-    const int q = (int)v->qual;
+    const int q = qual_as_int(v->qual);
     out += chr; out += '\t'; put_int(out, (long long)(uint32_t)(v->pos + 1)); out += "\t.\t"; out += v->allele(0); out += '\t';
     if (a1 == a2) { out += v->allele(a1); out += '\t'; put_int(out, q); out += "\tPASS\t.\tGT\t1/1\n"; }
     else if (a1 == 0 && a2 > 0) { out += v->allele(a2); out += '\t'; put_int(out, q); out += "\tPASS\t.\tGT\t0/1\n"; }

@@ -68,6 +68,20 @@ int main(int argc, char **argv) {
       ++calls;
     }
   }
+  if (const char *dm = getenv("MFX_VHB_DAMAGE")) {               // sanitizer drives: bytes of the VCF damaged (seed = the value)
+    std::mt19937_64 dr((uint64_t)atoll(dm));
+    const size_t nd = 20 + dr() % 200;
+    for (size_t q = 0; q < nd && !vcf.empty(); ++q) {
+      const size_t at = dr() % vcf.size();
+      switch (dr() % 5) {
+        case 0: vcf[at] = "\t\n,/|.:0#-"[dr() % 10]; break;
+        case 1: vcf[at] = (char)(dr() & 0x7f); break;
+        case 2: vcf.erase(at, dr() % 40); break;
+        case 3: vcf.insert(at, std::string(1 + dr() % 60, "ACGT9"[dr() % 5])); break;
+        default: vcf.insert(at, "9999999999"); break;           // positions / allele indices far outside
+      }
+    }
+  }
   const char *vp = "/tmp/mfx_vhb.vcf";
   FILE *f = fopen(vp, "w");
   fwrite(vcf.data(), 1, vcf.size(), f);
