@@ -439,3 +439,36 @@ def test_cli_convert_then_hist_equals_hist_from_the_text(tmp_path):
         assert r.returncode == 0, r.stderr
         outs.append(open(o, "rb").read())
     assert outs[0] == outs[1] == (tmp_path / "o.hist").read_bytes()
+
+
+@pytest.mark.gpu
+def test_cli_slots_of_one_device_with_the_packed_transport(tmp_path):
+    """-dump, -hist and -polish in 4 and 8 slots on one device, the assembly uploaded PACKED (what an assembly of 8 MB or more
+    takes; forced here): the slots share one mfx_seq and one null stream -- the outputs must be the single slot's, byte for
+    byte, run after run (at 64 Mb the -dump of several slots came out empty in 5 of 6 runs before what a sequence makes on
+    first use was made under a lock: profiles/r04_slots_soak.txt)"""
+    import merfin_amd as m
+    k, peak = 21, 17.3
+    names, asm, vcf, read, amers = synth.variant_world(k=k, peak=peak, seed=67, sizes=(40000, 30000, 20000, 12000, 9000, 5000, 4097, 300))
+    vp = str(tmp_path / "in.vcf")
+    open(vp, "w").write(vcf)
+    fa = str(tmp_path / "asm.fasta")
+    with open(fa, "wb") as f:
+        for n, c in zip(names, asm):
+            f.write(b">" + n.encode() + b"\n" + c + b"\n")
+    m.db_write_flat(str(tmp_path / "read.mfxk"), k, *read)
+    m.db_write_flat(str(tmp_path / "asm.mfxk"), k, *amers)
+    common = ["-sequence", fa, "-readmers", str(tmp_path / "read.mfxk"), "-seqmers", str(tmp_path / "asm.mfxk"), "-peak", str(peak)]
+    env = dict(os.environ, MFX_UPLOAD_PACKED_MIN="1")
+    for op, extra, suffix in (("-dump", [], ""), ("-hist", [], ""), ("-polish", ["-vcf", vp], ".polish.vcf")):
+        ref = None
+        for devices in ("0", "0,0,0,0", "0,0,0,0,0,0,0,0"):
+            for rep in range(1 if devices == "0" else 4):
+                out = str(tmp_path / ("o%s_%d_%d" % (op, len(devices), rep)))
+                r = run([op] + common + extra + ["-devices", devices, "-output", out], env=env)
+                assert r.returncode == 0, r.stderr
+                data = open(out + suffix, "rb").read()
+                if ref is None:
+                    ref = data
+                    assert len(ref) > (1000 if op != "-hist" else 10)
+                assert data == ref, "%s -devices %s, repetition %d differs from the single slot" % (op, devices, rep)
