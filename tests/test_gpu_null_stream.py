@@ -167,3 +167,49 @@ def test_slots_sharing_one_sequence_ask_for_its_bytes_at_once(monkeypatch):
             np.testing.assert_array_equal(got[c][0], ref[c][0])
             np.testing.assert_array_equal(got[c][1], ref[c][1])
             assert got[c][2:] == ref[c][2:]
+
+
+def test_two_threads_each_with_their_own_objects_on_one_device(tmp_path):
+    """two host threads, each with its own index (built from a database file through its own staging lanes), evaluator and
+    sequences on the same device, running builds, streamed and resident evaluations and dumps at the same time: every result
+    is the oracle's (objects are per thread; the device, its null stream and the library's globals are shared)"""
+    import threading
+    import merfin_amd as m
+    worlds = []
+    for i, k in enumerate((21, 27)):
+        peak = 17.3
+        contigs, read, asm = synth.world(k=k, peak=peak, seed=4720 + i, sizes=(80000, 30000, 4097, 50))
+        p, g, ka, km = oracle_hist(k, peak, contigs, read, asm)
+        db = str(tmp_path / ("read%d.mfxk" % k))
+        m.db_write_flat(db, k, read[0], read[1])
+        worlds.append((k, peak, contigs, read, asm, g, ka, km, db))
+    errs = []
+    gate = threading.Barrier(2)
+
+    def work(w):
+        k, peak, contigs, read, asm, g, ka, km, db = w
+        try:
+            gate.wait()
+            for rep in range(4):
+                seqs = m.Sequences(contigs)
+                six = m.Index.for_seq(k, sum(len(c) for c in contigs) + 16)
+                six.build_for_hist(seqs, db)
+                ev = m.Evaluator(six, m.KParams(peak))
+                assert_hist_equal(ev.hist(seqs), g, ka, km, k)
+                assert_hist_equal(ev.hist_streamed(m.Sequences.create([len(c) for c in contigs]), contigs), g, ka, km, k)
+                full = m.Evaluator(build_index(m, k, read, asm), m.KParams(peak))
+                a = ev.dump_values(seqs, 0, 0, len(contigs[0]))
+                b = full.dump_values(seqs, 0, 0, len(contigs[0]))
+                np.testing.assert_array_equal(a[0], b[0])
+                np.testing.assert_array_equal(a[1], b[1])
+                assert a[2:] == b[2:]
+        except BaseException as e:                             # noqa: BLE001
+            import traceback
+            errs.append(traceback.format_exc()[-1500:])
+
+    th = [threading.Thread(target=work, args=(w,)) for w in worlds]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, "\n".join(errs)
