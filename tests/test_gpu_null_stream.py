@@ -10,7 +10,7 @@ import pytest
 from tests import synth
 from tests.test_gpu_parity import assert_hist_equal, build_index, oracle_hist
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]     # (threads: a hang must not take the whole GPU tier with it)
 
 
 class _BusyNullStream:
@@ -18,11 +18,17 @@ class _BusyNullStream:
 
     def __init__(self, torch):
         import threading
-        self.torch, self.stop, self.launched = torch, False, 0
+        self.torch, self.stop, self.launched, self.ok, self.error = torch, False, 0, False, None
         self.a = torch.randn(4096, 4096, device="cuda")
         self.t = threading.Thread(target=self._run, daemon=True)
 
     def _run(self):
+        try:
+            self._loop()
+        except BaseException as e:                               # noqa: BLE001  (seen by __enter__ / the test, not lost in the thread)
+            self.error = repr(e)
+
+    def _loop(self):
         torch, x, evs = self.torch, self.a, []
         while not self.stop:
             for _ in range(4):
@@ -38,9 +44,12 @@ class _BusyNullStream:
         self.ok = bool(torch.isfinite(x).all())
 
     def __enter__(self):
+        import time
         self.t.start()
-        while self.launched < 8:
-            pass
+        t0 = time.time()
+        while self.launched < 8 and self.t.is_alive() and time.time() - t0 < 120:
+            time.sleep(0.001)
+        assert self.launched >= 8, "the thread that keeps the null stream busy did not start: %s" % self.error
         return self
 
     def __exit__(self, *exc):
