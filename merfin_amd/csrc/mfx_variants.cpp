@@ -34,6 +34,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
+#include <exception>
 #include <functional>
 #include <future>
 #include <string>
@@ -609,12 +610,21 @@ void parallel_for(size_t n, F &&fn) {
   const size_t chunk = std::max<size_t>(1, std::min<size_t>(64, n / (nt * 8)));
   std::atomic<size_t> next(0);
   std::vector<std::thread> th;
+  std::exception_ptr thrown;                                   // what a worker throws (an allocation failure) is rethrown by the caller
+  std::mutex thrown_mu;
   for (unsigned t = 0; t < nt; ++t)
     th.emplace_back([&]() {
-      for (size_t b; (b = next.fetch_add(chunk)) < n;)
-        for (size_t i = b, e = std::min(n, b + chunk); i < e; ++i) fn(i);
+      try {
+        for (size_t b; (b = next.fetch_add(chunk)) < n;)
+          for (size_t i = b, e = std::min(n, b + chunk); i < e; ++i) fn(i);
+      } catch (...) {
+        std::lock_guard<std::mutex> lk(thrown_mu);
+        if (!thrown) thrown = std::current_exception();
+        next.store(n);                                         // the others stop at their next draw
+      }
     });
   for (auto &x : th) x.join();
+  if (thrown) std::rethrow_exception(thrown);
 }
 
 // decimal text of an integer appended to `o` (what std::to_string gives, without the temporary)
@@ -1190,6 +1200,13 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
   return rc;
 }
 
+// the host pipeline allocates throughout (records, paths, batches): what it throws becomes an error code at the C ABI
+template <class F> static int variants_guarded(const char *who, F &&body) {
+  try { return body(); }
+  catch (const std::bad_alloc &) { return mfx_fail(MFX_E_NOMEM, "%s: out of memory", who); }
+  catch (const std::exception &e) { return mfx_fail(MFX_E_HIP, "%s: %s", who, e.what()); }
+}
+
 extern "C" int mfx_variants_run(mfx_eval *ev, const char *vcf_path, const char *const *names, const char *const *bases,
                                 const uint64_t *lens, uint32_t ncontigs, const mfx_variant_opts *opts,
                                 const char *out_path, const char *log_path, uint64_t *n_clusters) {
@@ -1209,7 +1226,7 @@ extern "C" int mfx_variants_run(mfx_eval *ev, const char *vcf_path, const char *
     scores = [ev](const char *text, uint64_t len, const mfx_path_table &pt, int need_dk, uint32_t *numM, double *totdk) -> int {
       return mfx_score_paths(ev, text, len, &pt, need_dk, numM, totdk);
     };
-  return mfx_variants_run_values(ev, values, vcf_path, names, bases, lens, ncontigs, opts, out_path, log_path, n_clusters, scores);
+  return variants_guarded("mfx_variants_run", [&] { return mfx_variants_run_values(ev, values, vcf_path, names, bases, lens, ncontigs, opts, out_path, log_path, n_clusters, scores); });
 }
 
 // The VCF read and parsed AHEAD of its run: host work only (no device, no index), so a caller starts it on a thread of its own while
@@ -1219,7 +1236,11 @@ extern "C" mfx_vcf *mfx_vcf_load(const char *vcf_path) {
   if (!vcf_path) { mfx_fail(MFX_E_INVAL, "mfx_vcf_load: null argument"); return nullptr; }
   mfx_vcf *v = new (std::nothrow) mfx_vcf;
   if (!v) { mfx_fail(MFX_E_NOMEM, "mfx_vcf_load: no memory"); return nullptr; }
-  if (load_vcf(vcf_path, v->db, v->t_load) != MFX_OK) { delete v; return nullptr; }
+  int rc;
+  try { rc = load_vcf(vcf_path, v->db, v->t_load); }          // (nothing leaves the C ABI as an exception)
+  catch (const std::bad_alloc &) { rc = mfx_fail(MFX_E_NOMEM, "loading VCF '%s': out of memory", vcf_path); }
+  catch (const std::exception &e) { rc = mfx_fail(MFX_E_IO, "loading VCF '%s': %s", vcf_path, e.what()); }
+  if (rc != MFX_OK) { delete v; return nullptr; }
   return v;
 }
 
@@ -1242,7 +1263,7 @@ extern "C" int mfx_variants_run_vcf(mfx_eval *ev, mfx_vcf *vcf, const char *cons
     scores = [ev](const char *text, uint64_t len, const mfx_path_table &pt, int need_dk, uint32_t *numM, double *totdk) -> int {
       return mfx_score_paths(ev, text, len, &pt, need_dk, numM, totdk);
     };
-  return mfx_variants_run_values(ev, values, nullptr, names, bases, lens, ncontigs, opts, out_path, log_path, n_clusters, scores, vcf);
+  return variants_guarded("mfx_variants_run_vcf", [&] { return mfx_variants_run_values(ev, values, nullptr, names, bases, lens, ncontigs, opts, out_path, log_path, n_clusters, scores, vcf); });
 }
 
 // The variant modes over an index sharded across N evaluators (read databases beyond one GPU): the packed path text of
@@ -1272,5 +1293,5 @@ extern "C" int mfx_variants_run_sharded(mfx_eval *const *evs, uint32_t nslots, c
     }
     return r;
   };
-  return mfx_variants_run_values(evs[0], values, vcf_path, names, bases, lens, ncontigs, opts, out_path, log_path, n_clusters);
+  return variants_guarded("mfx_variants_run_sharded", [&] { return mfx_variants_run_values(evs[0], values, vcf_path, names, bases, lens, ncontigs, opts, out_path, log_path, n_clusters); });
 }
