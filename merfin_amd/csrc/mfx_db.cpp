@@ -774,7 +774,7 @@ int load_flat_delta(mfx_index *const *ixs, uint32_t nix, int fd, const char *pat
 
 // merylFileReader(path): opens the DB and reveals k (merfin-globals.C:118-119:
 // "Make readDB first so we know the k size").
-extern "C" int mfx_db_probe(const char *path, mfx_db_info *out) {
+static int mfx_db_probe_impl(const char *path, mfx_db_info *out) {
   if (!path || !out) return mfx_fail(MFX_E_INVAL, "mfx_db_probe: null argument");
   memset(out, 0, sizeof(*out));
   std::string p(path);
@@ -818,6 +818,13 @@ extern "C" int mfx_db_probe(const char *path, mfx_db_info *out) {
   return rc;
 }
 
+extern "C" int mfx_db_probe(const char *path, mfx_db_info *out) {
+  try { return mfx_db_probe_impl(path, out); }                       // (nothing leaves the C ABI as an exception)
+  catch (const std::bad_alloc &) { return mfx_fail(MFX_E_NOMEM, "mfx_db_probe: out of memory"); }
+  catch (const std::exception &e) { return mfx_fail(MFX_E_IO, "mfx_db_probe: %s", e.what()); }
+}
+
+
 // merylExactLookup::load (merfin-globals.C:156,159): side 0 = read DB with the
 // -min/-max filter, side 1 = assembly DB.
 extern "C" int mfx_index_load_db(mfx_index *ix, const char *path, int side, uint64_t minV, uint64_t maxV) {
@@ -827,7 +834,7 @@ extern "C" int mfx_index_load_db(mfx_index *ix, const char *path, int side, uint
 
 // One pass over the database feeds nix tables: the shards of one process each keep the k-mers they own
 // (mfx_index_set_shard), so a config-5-sized read database is decoded ONCE, not once per GPU.
-extern "C" int mfx_index_load_db_multi(mfx_index *const *ixs, uint32_t nix, const char *path, int side, uint64_t minV, uint64_t maxV) {
+static int mfx_index_load_db_multi_impl(mfx_index *const *ixs, uint32_t nix, const char *path, int side, uint64_t minV, uint64_t maxV) {
   if (!ixs || nix == 0 || !path) return mfx_fail(MFX_E_INVAL, "mfx_index_load_db: null argument");
   for (uint32_t i = 0; i < nix; ++i)
     if (!ixs[i] || ixs[i]->k != ixs[0]->k) return mfx_fail(MFX_E_INVAL, "mfx_index_load_db_multi: the indexes of one load must hold the same k");
@@ -918,8 +925,15 @@ extern "C" int mfx_index_load_db_multi(mfx_index *const *ixs, uint32_t nix, cons
   return rc ? rc : fd.rc;
 }
 
+extern "C" int mfx_index_load_db_multi(mfx_index *const *ixs, uint32_t nix, const char *path, int side, uint64_t minV, uint64_t maxV) {
+  try { return mfx_index_load_db_multi_impl(ixs, nix, path, side, minV, maxV); }                       // (nothing leaves the C ABI as an exception)
+  catch (const std::bad_alloc &) { return mfx_fail(MFX_E_NOMEM, "mfx_index_load_db_multi: out of memory"); }
+  catch (const std::exception &e) { return mfx_fail(MFX_E_IO, "mfx_index_load_db_multi: %s", e.what()); }
+}
+
+
 // writes this repo's flat binary form (fixtures, interchange)
-extern "C" int mfx_db_write_flat(const char *path, int k, const uint64_t *kmers, const uint32_t *values, uint64_t n) {
+static int mfx_db_write_flat_impl(const char *path, int k, const uint64_t *kmers, const uint32_t *values, uint64_t n) {
   if (!path || (n && (!kmers || !values))) return mfx_fail(MFX_E_INVAL, "mfx_db_write_flat: null argument");
   FILE *f = fopen(path, "wb");
   if (!f) return mfx_fail(MFX_E_IO, "cannot open '%s' for writing", path);
@@ -962,6 +976,13 @@ extern "C" int mfx_db_write_flat(const char *path, int k, const uint64_t *kmers,
   fclose(f);
   return ok ? MFX_OK : mfx_fail(MFX_E_IO, "short write to '%s'", path);
 }
+
+extern "C" int mfx_db_write_flat(const char *path, int k, const uint64_t *kmers, const uint32_t *values, uint64_t n) {
+  try { return mfx_db_write_flat_impl(path, k, kmers, values, n); }                       // (nothing leaves the C ABI as an exception)
+  catch (const std::bad_alloc &) { return mfx_fail(MFX_E_NOMEM, "mfx_db_write_flat: out of memory"); }
+  catch (const std::exception &e) { return mfx_fail(MFX_E_IO, "mfx_db_write_flat: %s", e.what()); }
+}
+
 
 // ---------------------------------------------------------------------------
 // mfx_db_convert: any accepted database -> this library's flat form, on the host (no device).  The point is the
@@ -1093,7 +1114,7 @@ void sort_pairs(int k, std::vector<uint64_t> &keys, std::vector<uint32_t> &vals)
 }
 }  // namespace
 
-extern "C" int mfx_db_convert(const char *in_path, const char *out_path, uint64_t *n_out) {
+static int mfx_db_convert_impl(const char *in_path, const char *out_path, uint64_t *n_out) {
   if (!in_path || !out_path) return mfx_fail(MFX_E_INVAL, "mfx_db_convert: null argument");
   const std::string p(in_path);
   const int fmt = detect(p);
@@ -1189,6 +1210,13 @@ extern "C" int mfx_db_convert(const char *in_path, const char *out_path, uint64_
   if (timing) fprintf(stderr, "[mfx db] convert: read %.2f s, order %.2f s, write %.2f s\n", t1 - t0, t2 - t1, now() - t2);
   return rc;
 }
+
+extern "C" int mfx_db_convert(const char *in_path, const char *out_path, uint64_t *n_out) {
+  try { return mfx_db_convert_impl(in_path, out_path, n_out); }                       // (nothing leaves the C ABI as an exception)
+  catch (const std::bad_alloc &) { return mfx_fail(MFX_E_NOMEM, "mfx_db_convert: out of memory"); }
+  catch (const std::exception &e) { return mfx_fail(MFX_E_IO, "mfx_db_convert: %s", e.what()); }
+}
+
 
 // ---------------------------------------------------------------------------
 // Device-format index image: the built table written to / read from disk as is,
