@@ -2015,7 +2015,12 @@ static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *cons
           if (m_) memcpy(all + n, lists + (size_t)w * cap_w, (size_t)m_ * 8);
           n += m_;
         }
-        STREAMED_HIP(hipMemsetAsync(seq->d_valid + c.lo / 32, 0xff, nw * 4, cs));
+        // A chunk that starts inside a contig begins with the MFX_ALIGN bases the previous chunk already sent as the halo of its last
+        // tile, and that chunk's kernel may still be reading them (the copy stream does not wait for it): those words are left out of
+        // the fill -- they hold their final values, and the listed ones among them are only rewritten with the same value.  Filling
+        // them with ones first would let the running kernel see an N or a contig end behind the cut as valid bases for a moment.
+        const uint64_t keep = c.pieces.front().pos ? std::min<uint64_t>(nw, MFX_ALIGN / 32) : 0;
+        if (nw > keep) STREAMED_HIP(hipMemsetAsync(seq->d_valid + c.lo / 32 + keep, 0xff, (nw - keep) * 4, cs));
         if (n) {
           STREAMED_HIP(hipMemcpyAsync(R.d_exc[b], all, n * 8, hipMemcpyHostToDevice, cs));
           STREAMED_HIP(mfx_k_valid_scatter(seq->d_valid + c.lo / 32, R.d_exc[b], (uint32_t)n, cs));

@@ -4,6 +4,7 @@ single-process oracle result.  Each rank fabricates its partial image with the
 ORACLE over its tile shard (the HIP kernel needs a GPU; the decomposition,
 image layout, collective and result assembly are what is under test here)."""
 import os
+import subprocess
 import sys
 
 import numpy as np
@@ -157,3 +158,26 @@ def test_bench_launcher_channel_three_ranks(tmp_path):
     port = 29300 + os.getpid() % 500
     mp.spawn(_oob_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
     assert all((tmp_path / ("ok%d" % r)).exists() for r in range(3))
+
+
+def _bench(args, env=None, timeout=300):
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, capture_output=True, text=True, env=e, timeout=timeout)
+
+
+def test_bench_refuses_to_mislabel_its_gpu_count():
+    """`python bench.py --gpus N` owns its ranks (as merfin.C:366-414 owns its workers): without a launcher it starts N of them
+    itself, and where it cannot -- fewer than N devices (none here), or a launcher whose WORLD_SIZE disagrees -- it prints ONE JSON line
+    with value null and exits non-zero instead of measuring another GPU count than the one it reports."""
+    import json
+    r = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], env={"HIP_VISIBLE_DEVICES": "", "ROCR_VISIBLE_DEVICES": ""})
+    assert r.returncode != 0
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["n_gpus"] == 2 and "HIP device(s) visible" in d["error"]
+    r = _bench(["--gpus", "2"], env={"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["value"] is None and "WORLD_SIZE=4" in d["error"]

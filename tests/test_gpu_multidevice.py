@@ -123,17 +123,26 @@ def _torchrun(n, args, env=None, timeout=900):
 
 
 def test_bench_over_rccl_with_more_than_one_rank():
-    """bench.py as the driver launches it for N > 1: the reduction must be the library's RCCL all-reduce (not the
+    """bench.py for N > 1, under torchrun and as the plain `python bench.py --gpus N` (it then starts its own ranks): the reduction must be the library's RCCL all-reduce (not the
     host-memory fallback), the reduced histogram must account for every k-mer, and rank 0 prints ONE line"""
     devs = _devices()
     n = len(devs)
-    r = _torchrun(n, ["bench.py", "--gpus", str(n), "--steps", "3", "--warmup", "1", "--bases", "64e6", "--no-pmc", "--no-cpu-baseline"])
+    bargs = ["bench.py", "--gpus", str(n), "--steps", "3", "--warmup", "1", "--bases", "64e6", "--no-pmc", "--no-cpu-baseline"]
+    r = _torchrun(n, bargs)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == n and d["config"]["hist_sum_check"] is True
     assert "RCCL via libmerfin_amd" in d["config"]["parallelism"], d["config"]["parallelism"]
+    assert d["config"]["collective"] == "RCCL" and d["config"]["rccl_ranks"] == n and len(d["config"]["rank_kernel_ms"]["all"]) == n
+    # ... and the plain command, no launcher around it: bench.py starts its own N ranks (README: `python bench.py --gpus N`)
+    e = {k_: v for k_, v in os.environ.items() if k_ not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    rp = subprocess.run([sys.executable] + bargs, cwd=ROOT, capture_output=True, text=True, env=e, timeout=900)
+    assert rp.returncode == 0, rp.stderr[-3000:]
+    dp = json.loads([l for l in rp.stdout.splitlines() if l.startswith("{")][0])
+    assert dp["n_gpus"] == n and dp["config"]["collective"] == "RCCL" and dp["config"]["rccl_ranks"] == n
+    assert dp["config"]["kmissing"] == d["config"]["kmissing"] and dp["config"]["valid_kmers"] == d["config"]["valid_kmers"]
     # the same workload on one GPU: identical counters
     r1 = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "1", "--warmup", "0", "--bases", "64e6", "--no-pmc", "--no-cpu-baseline",
                          "--no-streamed"], cwd=ROOT, capture_output=True, text=True, timeout=900)

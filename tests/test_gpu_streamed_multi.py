@@ -109,6 +109,35 @@ def test_streamed_spans_several_chunks():
     _same(ev.hist_streamed(m.Sequences.create(list(sizes)), [pb.array for pb in pins]), resident)
 
 
+def test_streamed_invalid_bases_just_behind_a_chunk_cut():
+    """An N, a lower-case run and a contig end 1..k-1 bases behind the cut between two chunks of the streamed run: the k-mers of the
+    earlier chunk's last tile run over them, and that chunk's kernel may still be reading the validity words of its halo while the next
+    chunk's upload arrives (the sparse validity transport fills a chunk's range with ones before it scatters the exceptions: the halo
+    words are left out of that fill).  Chunks are cut at 2048, 6144, 14336 tiles (8, 16, 32 MB of bases: CH0 doubling)."""
+    import merfin_amd as m
+    k, peak = 21, 9.0
+    r = synth.rng(317)
+    T0, T1, T2 = 2048, 6144, 14336
+    sizes = (T1 * 4096 + 5, (T2 - T1 - 1) * 4096 + 4096 * 700 + 11)   # contig 0 ends 5 bases behind the second cut
+    contigs = [synth.random_contig(r, n) for n in sizes]
+    contigs[0][T0 * 4096 + 1] = ord("N")                      # 1 base behind the first cut
+    at2 = (T2 - T1 - 1) * 4096                                # the third cut, in contig 1's coordinates
+    contigs[1][at2 + 19] = ord("n")                           # k-2 bases behind it
+    contigs[1][at2 + 4096 * 300 + 7:at2 + 4096 * 300 + 9] = ord("-")
+    seqs = m.Sequences([c.tobytes() for c in contigs])
+    ix = m.Index(k, sum(sizes) + 1024)
+    ix.count_asm(seqs)
+    spots = [contigs[0][T0 * 4096 - 5000:T0 * 4096 + 5000], contigs[0][-5000:], contigs[1][:5000], contigs[1][at2 - 5000:at2 + 5000]]
+    rk = po.count_kmers(k, [x.tobytes() for x in spots])[0]
+    ix.add_read(rk, (1 + (rk % 50)).astype(np.uint32))
+    ev = m.Evaluator(ix, m.KParams(peak))
+    resident = ev.hist(seqs)
+    assert resident.kasm == sum(n - 20 for n in sizes) - 21 - 21 - 22
+    s = m.Sequences.create(list(sizes))
+    for _ in range(6):                                        # the race this guards against was a matter of timing
+        _same(ev.hist_streamed(s, contigs), resident)
+
+
 @pytest.fixture(scope="module")
 def five_mb_world():
     k, peak = 21, 17.3
