@@ -298,6 +298,22 @@ void    *mfx_host_alloc(size_t bytes);
 void     mfx_host_free(void *p);
 mfx_seq *mfx_seq_create(int device, const uint64_t *lens, uint32_t ncontigs);
 int      mfx_hist_run_streamed(mfx_eval *ev, mfx_seq *seq, const char *const *bases, mfx_hist_result *out);
+/* The same over N devices driven by one process (the reference is one binary driving its workers, merfin.C:366-414; SURVEY 8(d) asks
+ * for the evaluate phase "at 1/2/4/8 GPUs"): device d receives only the packed planes of ITS share of the tiles -- the contiguous
+ * stretch [T d / N, T (d + 1) / N), cut at multiples of 1024 tiles, plus the k - 1 bases of halo behind it -- over its own copy
+ * stream from its own encoder threads, and evaluates the chunks as they land; the images are added on the host in slot order.  The
+ * result is bit-identical to mfx_hist_run_streamed / mfx_hist_run on one device, koverCpy included (the first-level sums of the
+ * (tile, wave) values are the single launch's own, and the host adds them in the device's order).  Every slot needs its own
+ * evaluator and its own sequence object (mfx_seq_create on the slot's device; evaluators on replicas of one index); afterwards a
+ * slot's sequence object holds its part only and refuses whole-sequence calls (MFX_E_INVAL) until something is uploaded whole. */
+int      mfx_hist_run_streamed_multi(mfx_eval *const *evs, mfx_seq *const *seqs, uint32_t ndev, const char *const *bases, mfx_hist_result *out);
+/* One rank's share of it for the one-process-per-GPU launcher (bench.py, merfin_amd.mgpu): the tiles [tile_begin, tile_end) are
+ * encoded, uploaded and evaluated, counts and koverCpy are ADDED to the caller's device image (MFX_HIST_WORDS(nbins, ncontigs) words
+ * and one double, cleared by the caller), which the launcher then all-reduces (mfx_hist_allreduce).  Returns when the device is
+ * done.  mfx_hist_stream_share: the bounds rank r of n takes (the same cut as the one-process run). */
+int      mfx_hist_run_streamed_range(mfx_eval *ev, mfx_seq *seq, const char *const *bases, uint64_t tile_begin, uint64_t tile_end,
+                                     uint64_t *d_counts, double *d_kover);
+int      mfx_hist_stream_share(uint64_t ntiles, uint32_t rank, uint32_t nranks, uint64_t *tile_begin, uint64_t *tile_end);
 /* The host-side encoder of that transport (AVX-512 / AVX2 / scalar, chosen at run time; ~28 GB/s per core of an EPYC
  * 9575F): n bases -> ceil(n/32) words.  codes[w] holds bases 32w..32w+31, the first in the two HIGHEST bits,
  * code = (c >> 1) & 3 (A 0, C 1, T 2, G 3, either case); valid[w] holds one bit per base, the first in the highest

@@ -67,6 +67,7 @@ SYMBOLS = [
     "mfx_db_probe", "mfx_index_load_db", "mfx_index_load_db_multi", "mfx_db_write_flat", "mfx_db_convert", "mfx_index_save", "mfx_index_load",
     "mfx_index_set_fingerprint", "mfx_index_get_origin",
     "mfx_host_alloc", "mfx_host_free", "mfx_seq_create", "mfx_hist_run_streamed",
+    "mfx_hist_run_streamed_multi", "mfx_hist_run_streamed_range", "mfx_hist_stream_share",
     "mfx_index_replicate", "mfx_seq_replicate", "mfx_hist_run_multi", "mfx_hist_run_sharded",
     "mfx_comm_unique_id", "mfx_comm_create", "mfx_comm_free", "mfx_comm_rank", "mfx_comm_size", "mfx_comm_barrier", "mfx_comm_exchange_counts", "mfx_comm_alltoallv",
     "mfx_index_replicate_many", "mfx_seq_replicate_many", "mfx_seq_pack",
@@ -220,6 +221,9 @@ def load_library():
     L.mfx_seq_replicate.restype = vp
     L.mfx_seq_replicate.argtypes = [vp, C.c_int]
     L.mfx_hist_run_multi.argtypes = [C.POINTER(vp), C.POINTER(vp), C.c_uint32, C.POINTER(_HistResult)]
+    L.mfx_hist_run_streamed_multi.argtypes = [C.POINTER(vp), C.POINTER(vp), C.c_uint32, C.POINTER(vp), C.POINTER(_HistResult)]
+    L.mfx_hist_run_streamed_range.argtypes = [vp, vp, C.POINTER(vp), C.c_uint64, C.c_uint64, vp, vp]
+    L.mfx_hist_stream_share.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.mfx_hist_run_sharded.argtypes = [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.c_uint32, C.POINTER(_HistResult)]
     L.mfx_comm_unique_id.argtypes = [vp]
     L.mfx_comm_create.restype = vp
@@ -688,6 +692,44 @@ def hist_multi(evaluators, sequences):
     return r
 
 
+def _host_ptrs(host_contigs):
+    """(ctypes void* array, objects to keep alive) of bytes / numpy uint8 arrays / PinnedBuffer views, one per contig"""
+    n = len(host_contigs)
+    keep = []
+    ptrs = (C.c_void_p * max(n, 1))()
+    for i, c in enumerate(host_contigs):
+        if isinstance(c, (bytes, bytearray)):
+            b = C.c_char_p(bytes(c))
+            keep.append(b)
+            ptrs[i] = C.cast(b, C.c_void_p).value
+        else:
+            a = np.ascontiguousarray(c, dtype=np.uint8)
+            keep.append(a)
+            ptrs[i] = a.ctypes.data
+    return ptrs, keep
+
+
+def hist_streamed_multi(evaluators, sequences, host_contigs):
+    """SURVEY 8(d)'s evaluate phase over several devices driven by this one process (mfx_hist_run_streamed_multi): slot d gets,
+    through its own copy stream, only the packed planes of its contiguous share of the tiles and evaluates them as they land.
+    sequences[d] = Sequences.create(lens, device=d): one object per slot (it holds the slot's part afterwards)."""
+    n = len(evaluators)
+    assert n == len(sequences) and n >= 1
+    ev = (C.c_void_p * n)(*[e.h for e in evaluators])
+    sq = (C.c_void_p * n)(*[s.h for s in sequences])
+    ptrs, keep = _host_ptrs(host_contigs)
+    r = HistResult()
+    _check(load_library().mfx_hist_run_streamed_multi(ev, sq, n, ptrs, C.byref(r.c)))
+    return r
+
+
+def stream_share(ntiles, rank, nranks):
+    """the tiles [begin, end) rank `rank` of `nranks` streams (mfx_hist_stream_share)"""
+    a, b = C.c_uint64(0), C.c_uint64(0)
+    _check(load_library().mfx_hist_stream_share(ntiles, rank, nranks, C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
 def hist_sharded(evaluators, routers, sequences):
     """-hist over an index sharded across the slots of ONE process (mfx_hist_run_sharded): slot d = evaluator + router on
     shard d of N, plus the packed assembly on that shard's device"""
@@ -879,21 +921,18 @@ class Evaluator:
     def hist_streamed(self, seqs, host_contigs):
         """-hist with the upload inside (SURVEY 8d's evaluate phase): `seqs` = Sequences.create(lens); host_contigs =
         bytes / numpy uint8 arrays / PinnedBuffer views, one per contig.  Chunked H2D overlapped with the kernel."""
-        n = len(host_contigs)
-        keep = []
-        ptrs = (C.c_void_p * max(n, 1))()
-        for i, c in enumerate(host_contigs):
-            if isinstance(c, (bytes, bytearray)):
-                b = C.c_char_p(bytes(c))
-                keep.append(b)
-                ptrs[i] = C.cast(b, C.c_void_p).value
-            else:
-                a = np.ascontiguousarray(c, dtype=np.uint8)
-                keep.append(a)
-                ptrs[i] = a.ctypes.data
+        ptrs, keep = _host_ptrs(host_contigs)
         r = HistResult()
         _check(load_library().mfx_hist_run_streamed(self.h, seqs.h, ptrs, C.byref(r.c)))
         return r
+
+    def hist_streamed_range(self, seqs, host_contigs, tile_begin, tile_end, d_counts, d_kover):
+        """one rank's share of a streamed -hist (mfx_hist_run_streamed_range): tiles [tile_begin, tile_end) encoded, uploaded and
+        evaluated, ADDED to the caller's device image / koverCpy; returns when the device is done"""
+        ptrs, keep = _host_ptrs(host_contigs)
+        pc = d_counts.data_ptr() if hasattr(d_counts, "data_ptr") else int(d_counts)
+        pk = d_kover.data_ptr() if hasattr(d_kover, "data_ptr") else int(d_kover)
+        _check(load_library().mfx_hist_run_streamed_range(self.h, seqs.h, ptrs, tile_begin, tile_end, C.c_void_p(pc), C.c_void_p(pk)))
 
     def hist_launch(self, seqs, tile_begin, tile_end, d_counts, d_kover, stream=None):
         """Asynchronous accumulate into caller-owned device buffers (torch tensors or raw pointers)."""

@@ -850,6 +850,7 @@ static int index_count(mfx_index *ix, const mfx_seq *seq, int count, void *strea
                     "(a k-mer claimed now would have missed them)", who);
   if (count == 2 && (!ix->seq_only || ix->wide())) return mfx_fail(MFX_E_INVAL, "%s: counting claimed k-mers needs a sequence-only index (mfx_index_create_for_seq)", who);
   // the k <= 31 kernel reads the packed planes when the sequence has them (a packed upload never makes the bytes)
+  if (seq->partial) return mfx_seq_partial_error(seq, who);
   const bool from_planes = !ix->wide() && (seq->planes_ok || seq->bases_stale) && !(getenv("MFX_COUNT_ASCII") && atoi(getenv("MFX_COUNT_ASCII")));
   if (!from_planes) if (int erc = mfx_seq_ensure_ascii(seq)) return erc;
   DevGuard g(ix->device);
@@ -1044,7 +1045,13 @@ static int seq_alloc(mfx_seq *s, bool with_bases = true) {
 // once; unguarded, one thread's fill of the fresh buffer wiped what another had just unpacked and that slot dumped empty contigs).
 static std::mutex &seq_lazy_mutex() { static std::mutex m; return m; }
 
+int mfx_seq_partial_error(const mfx_seq *s, const char *who) {
+  return mfx_fail(MFX_E_INVAL, "%s: the sequence object holds only the tiles [%lu, %lu) of its %lu (the part one device evaluated in a streamed run over "
+                  "several); upload the sequence whole", who, (unsigned long)s->part_lo, (unsigned long)s->part_hi, (unsigned long)s->ntiles);
+}
+
 int mfx_seq_ensure_ascii(const mfx_seq *cs) {
+  if (cs && cs->partial) return mfx_seq_partial_error(cs, "unpacking the sequence");
   std::lock_guard<std::mutex> lazy(seq_lazy_mutex());
   if (!cs->bases_stale && cs->d_bases) return MFX_OK;
   mfx_seq *s = const_cast<mfx_seq *>(cs);
@@ -1065,6 +1072,7 @@ static void seq_digest_finish(const mfx_seq *s, uint64_t h) {
 }
 
 int mfx_seq_digest32(const mfx_seq *s, uint32_t *out) {
+  if (s->partial) return mfx_seq_partial_error(s, "the sequence's content digest");
   std::lock_guard<std::mutex> lazy(seq_lazy_mutex());
   if (s->digest == 0) {
     DevGuard g(s->device);
@@ -1391,7 +1399,8 @@ static int ensure_tile_partials(mfx_eval *ev, uint64_t ntiles) {
 // their tile's place in ev->d_tile_partials (sized by the caller) and are summed ONCE after the last chunk, so
 // koverCpy is bit-identical to a single launch over the whole range, however the upload was cut.
 static int hist_launch(mfx_eval *ev, const mfx_seq *seq, uint64_t tile_begin, uint64_t tile_end, uint32_t part_rank, uint32_t part_n,
-                       uint32_t part_shift, uint64_t *d_counts, double *d_kover, void *stream, uint64_t chunk_of_total = 0, int ctr_slot = 0) {
+                       uint32_t part_shift, uint64_t *d_counts, double *d_kover, void *stream, uint64_t chunk_of_total = 0, int ctr_slot = 0,
+                       uint64_t partials_tile0 = 0) {
   uint64_t ntl = tile_end - tile_begin;
   if (part_n > 1) {
     const uint64_t blk = 1ull << part_shift, nblk = (seq->ntiles + blk - 1) / blk;
@@ -1404,6 +1413,7 @@ static int hist_launch(mfx_eval *ev, const mfx_seq *seq, uint64_t tile_begin, ui
   int rc = eval_canonical(ev, &canon);
   if (rc) return rc;
   if (!chunk_of_total) {                                     // (a streamed run checks once its upload is complete)
+    if (seq->partial) return mfx_seq_partial_error(seq, "-hist");
     rc = mfx_check_seq_of_index(ev->ix, seq, "-hist");
     if (rc) return rc;
   }
@@ -1434,7 +1444,7 @@ static int hist_launch(mfx_eval *ev, const mfx_seq *seq, uint64_t tile_begin, ui
   a.tile_end = tile_end;
   a.tile_contig = seq->d_tile_contig;
   a.tile_ctr = ev->d_tile_ctr + ctr_slot;
-  a.tile_partials = ev->d_tile_partials + (chunk_of_total ? tile_begin * (MFX_BLOCK / 64) : 0);
+  a.tile_partials = ev->d_tile_partials + (chunk_of_total ? (tile_begin - partials_tile0) * (MFX_BLOCK / 64) : 0);   // partials_tile0: first tile of a streamed PART
   a.n_logical = ntl;
   a.part_rank = part_rank;
   a.part_n = part_n;
@@ -1793,7 +1803,16 @@ static bool pack_cpus(int mode, int node, const cpu_set_t *near, unsigned w, cpu
 // the tile form (2-bit codes + validity bits, csrc/mfx_pack.cpp) while the previous chunk is on the bus and the one
 // before is being evaluated; the kernel reads its tiles from the packed planes (mfx_tile_fill_packed).  One byte per
 // base never reaches the device (seq->bases_stale; unpacked on demand by mfx_seq_ensure_ascii).
-static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *const *bases, mfx_hist_result *out) {
+// part != nullptr: only the tiles [part->tl, part->th) are encoded, uploaded and evaluated (one device's share of a run over several:
+// mfx_hist_run_streamed_multi / mfx_hist_run_streamed_range); the sequence object then holds that part only (mfx_seq::partial).
+struct StreamPart {
+  uint64_t tl = 0, th = 0;
+  uint64_t *d_counts = nullptr;          // caller's device image / koverCpy to accumulate into (cleared by the caller); null: the evaluator's own, returned on the host
+  double   *d_kover = nullptr;
+  std::vector<double> *chunk_sums = nullptr;   // the first-level koverCpy sums of the part (4096 (tile, wave) values each), for a bit-stable sum over the parts
+  bool      want_result = true;          // false: the image stays in ev->sr.h_img (or on the device), no mfx_hist_result is made
+};
+static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *const *bases, mfx_hist_result *out, const StreamPart *part = nullptr) {
   DevGuard g(ev->device);
   const int timing = getenv("MFX_STREAM_TIMING") ? atoi(getenv("MFX_STREAM_TIMING")) : 0;
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -1805,7 +1824,9 @@ static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *cons
   std::vector<ChunkTimes> ct;
   hipEvent_t ev_base = nullptr;
   const size_t words = MFX_HIST_WORDS(ev->nbins, seq->ncontigs);
-  const uint64_t T = seq->ntiles;
+  const uint64_t TL = part ? part->tl : 0, TH = part ? part->th : seq->ntiles;
+  const uint64_t T = TH - TL;                                 // tiles of this run
+  const bool whole = TL == 0 && TH == seq->ntiles;
   // chunks grow from 8 MB to 128 MB of bases: the first tile reaches the kernel after ~0.2 ms, and the bulk runs in few,
   // long launches (every launch pays a ramp-up and a tail of its persistent blocks: 47 launches of 64 MB cost 38 ms of
   // kernel time for 3 Gb, one launch 33.4 ms)
@@ -1832,9 +1853,9 @@ static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *cons
   }
   for (uint64_t t0 = 0, ci = 0; ci < cuts.size(); ++ci) {
     Chunk c;
-    c.t0 = t0;
-    c.t1 = cuts[ci];
-    t0 = c.t1;
+    c.t0 = TL + t0;
+    c.t1 = TL + cuts[ci];
+    t0 = cuts[ci];
     chunk_pieces(seq, c.t0, c.t1, c.pieces);
     if (!c.pieces.empty()) {
       c.lo = seq->off[c.pieces.front().contig] + c.pieces.front().pos;                 // a multiple of 128
@@ -1899,6 +1920,9 @@ static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *cons
   seq->bases_stale = true;
   seq->planes_ok = true;
   seq->digest = 0;                                           // new content
+  seq->partial = !whole;
+  seq->part_lo = TL;
+  seq->part_hi = TH;
 
   // the packers: worker w encodes its share of the words of every chunk, in chunk order
   const unsigned W = std::max(1u, std::min(mfx_host_threads(), 64u));
@@ -1973,11 +1997,14 @@ static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *cons
   for (auto &e : R.up) if (!e) STREAMED_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   if (!R.kdone) STREAMED_HIP(hipEventCreateWithFlags(&R.kdone, hipEventDisableTiming));
   hipStream_t cs = R.copy, ks = R.kern[0];
-  uint64_t *const d_counts = R.d_counts, *const h_img = R.h_img;
-  double *const d_kover = R.d_kover;
+  const bool own_image = !(part && part->d_counts);
+  uint64_t *const d_counts = own_image ? R.d_counts : part->d_counts, *const h_img = R.h_img;
+  double *const d_kover = own_image ? R.d_kover : part->d_kover;
   hipEvent_t *const up = R.up;
-  STREAMED_HIP(hipMemsetAsync(d_counts, 0, words * sizeof(uint64_t), ks));
-  STREAMED_HIP(hipMemsetAsync(d_kover, 0, sizeof(double), ks));
+  if (own_image) {
+    STREAMED_HIP(hipMemsetAsync(d_counts, 0, words * sizeof(uint64_t), ks));
+    STREAMED_HIP(hipMemsetAsync(d_kover, 0, sizeof(double), ks));
+  }
   STREAMED_HIP(hipMemsetAsync(ev->d_tile_ctr, 0, 2 * sizeof(uint64_t), ks));
   STREAMED_HIP(hipMemsetAsync(ev->d_ovf, 0, sizeof(uint64_t), ks));
   STREAMED_HIP(hipEventRecord(R.kdone, ks));
@@ -2019,7 +2046,7 @@ static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *cons
         // tile, and that chunk's kernel may still be reading them (the copy stream does not wait for it): those words are left out of
         // the fill -- they hold their final values, and the listed ones among them are only rewritten with the same value.  Filling
         // them with ones first would let the running kernel see an N or a contig end behind the cut as valid bases for a moment.
-        const uint64_t keep = c.pieces.front().pos ? std::min<uint64_t>(nw, MFX_ALIGN / 32) : 0;
+        const uint64_t keep = (ci > 0 && c.pieces.front().pos) ? std::min<uint64_t>(nw, MFX_ALIGN / 32) : 0;   // (the first chunk of a part has nobody before it)
         if (nw > keep) STREAMED_HIP(hipMemsetAsync(seq->d_valid + c.lo / 32 + keep, 0xff, (nw - keep) * 4, cs));
         if (n) {
           STREAMED_HIP(hipMemcpyAsync(R.d_exc[b], all, n * 8, hipMemcpyHostToDevice, cs));
@@ -2035,14 +2062,15 @@ static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *cons
     // last blocks leave behind, instead of waiting for its tail
     hipStream_t kst = R.kern[ci & 1];
     STREAMED_HIP(hipStreamWaitEvent(kst, up[b], 0));
-    rc = hist_launch(ev, seq, c.t0, c.t1, 0, 1, 0, d_counts, d_kover, kst, T, (int)(ci & 1));
+    rc = hist_launch(ev, seq, c.t0, c.t1, 0, 1, 0, d_counts, d_kover, kst, T, (int)(ci & 1), TL);
     if (rc) { cleanup(); return rc; }
     if (timing >= 2) (void)hipEventRecord(ct[ci].k1, kst);
   }
   t_mark[2] = now();
   // a sequence-only index answers for the k-mers of ONE sequence: the content digest of what was just uploaded is taken on
   // the copy stream, behind the last chunk and under the last launches, and compared before the result is handed out
-  const bool want_digest = ev->ix->seq_only && ev->ix->seq_digest != 0;
+  // (a part cannot be checked: its digest is not the sequence's; the caller of the parts vouches for the sequence)
+  const bool want_digest = whole && ev->ix->seq_only && ev->ix->seq_digest != 0;
   if (want_digest) {
     uint64_t *d_dig = reinterpret_cast<uint64_t *>(d_kover + 1);
     STREAMED_HIP(hipMemsetAsync(d_dig, 0, sizeof(uint64_t), cs));
@@ -2052,10 +2080,18 @@ static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *cons
   STREAMED_HIP(hipEventRecord(R.kdone, R.kern[1]));
   STREAMED_HIP(hipStreamWaitEvent(ks, R.kdone, 0));
   if (T) STREAMED_HIP(mfx_k_sum_tile_partials(ev->d_tile_partials, T, d_kover, ev->d_tile_ctr, ks));
-  STREAMED_HIP(hipMemcpyAsync(h_img, d_counts, words * sizeof(uint64_t), hipMemcpyDeviceToHost, ks));
-  STREAMED_HIP(hipMemcpyAsync(h_img + words, d_kover, sizeof(double), hipMemcpyDeviceToHost, ks));
+  if (own_image) {
+    STREAMED_HIP(hipMemcpyAsync(h_img, d_counts, words * sizeof(uint64_t), hipMemcpyDeviceToHost, ks));
+    STREAMED_HIP(hipMemcpyAsync(h_img + words, d_kover, sizeof(double), hipMemcpyDeviceToHost, ks));
+  }
   STREAMED_HIP(hipStreamSynchronize(ks));
   if (want_digest) STREAMED_HIP(hipStreamSynchronize(cs));
+  if (part && part->chunk_sums) {
+    // the first-level sums behind the (tile, wave) values: what mfx_sum_partials_kernel added up; the caller adds the parts' in the same order
+    const uint64_t nv = T * (MFX_BLOCK / 64), nch = (nv + 4095) / 4096;
+    part->chunk_sums->assign(nch, 0.0);
+    if (nch) STREAMED_HIP(hipMemcpy(part->chunk_sums->data(), ev->d_tile_partials + nv, nch * sizeof(double), hipMemcpyDeviceToHost));
+  }
   t_mark[3] = now();
 #undef STREAMED_HIP
   if (want_digest) {
@@ -2064,8 +2100,9 @@ static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *cons
   }
   double kover;
   memcpy(&kover, h_img + words, sizeof(double));
-  rc = mfx_hist_result_from_counts(ev->nbins, h_img, kover, seq->ncontigs, out);
-  const uint64_t novf = h_img[2ull * ev->nbins + 2];
+  const bool want_result = !part || (part->want_result && own_image);
+  if (want_result) rc = mfx_hist_result_from_counts(ev->nbins, h_img, kover, seq->ncontigs, out);
+  const uint64_t novf = own_image ? h_img[2ull * ev->nbins + 2] : 0;
   t_mark[4] = now();
   cleanup();
   t_mark[5] = now();
@@ -2089,7 +2126,7 @@ static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *cons
     for (auto &x : ct) { (void)hipEventDestroy(x.c0); (void)hipEventDestroy(x.c1); (void)hipEventDestroy(x.k1); }
     (void)hipEventDestroy(ev_base);
   }
-  if (rc) return rc;
+  if (rc || !want_result) return rc;
   rc = result_take_overflow(ev, novf, out);
   if (rc) mfx_hist_result_free(out);
   return rc;
@@ -2120,6 +2157,7 @@ static int seq_upload_packed(mfx_seq *seq, const char *const *bases) {
   seq->bases_stale = true;
   seq->planes_ok = true;
   seq->digest = 0;
+  seq->partial = false;
   if (chunks.empty()) return MFX_OK;
   tm[2] = now();
   size_t STAGE_W = 0;
@@ -2207,6 +2245,7 @@ extern "C" int mfx_hist_run_streamed(mfx_eval *ev, mfx_seq *seq, const char *con
   seq->bases_stale = false;                                 // this path writes d_bases
   seq->planes_ok = false;
   seq->digest = 0;
+  seq->partial = false;
   const size_t words = MFX_HIST_WORDS(ev->nbins, seq->ncontigs);
   const uint64_t T = seq->ntiles;
   const uint64_t CH = 16384;                                // tiles per chunk: 64 MB of bases
@@ -2429,6 +2468,7 @@ extern "C" int mfx_seq_replicate_many(const mfx_seq *csrc, const int *devices, u
     if (devices[i] < 0 || devices[i] >= mfx_device_count()) return mfx_fail(MFX_E_INVAL, "mfx_seq_replicate_many: device %d of %d", devices[i], mfx_device_count());
   }
   mfx_seq *src = const_cast<mfx_seq *>(csrc);
+  if (src->partial) return mfx_seq_partial_error(src, "mfx_seq_replicate");
   int rc = mfx_seq_pack(src);
   if (rc) return rc;
   const uint64_t pw = seq_plane_words(src);
@@ -2518,6 +2558,117 @@ extern "C" int mfx_hist_run_multi(mfx_eval *const *evs, const mfx_seq *const *se
     fprintf(stderr, "[mfx multi] %u slots: enqueue %.3f ms, wait + add %.3f ms (of which adding the images %.3f), result %.3f ms\n", ndev, (t1 - t0) * 1e3,
             (t2 - t1) * 1e3, t_add * 1e3, (now() - t2) * 1e3);
   return rc;
+}
+
+// SURVEY 8(d)'s evaluate phase over N devices driven by one process: "first tile H2D start -> final reduced histogram on host" with the
+// assembly in host memory.  Device d receives ONLY the packed planes of its share -- the tiles [T d / N, T (d + 1) / N), cut at
+// multiples of 1024 tiles, plus the k - 1 bases of halo behind it -- through its own copy stream, from its own encoder threads (the
+// host's threads are dealt to the slots), and evaluates the chunks as they land, exactly as the single-device run does
+// (hist_run_streamed_packed).  The images are added on the host in slot order; koverCpy is bit-identical to the single launch: the
+// first-level sums of the (tile, wave) values (4096 values = 1024 tiles each: the parts are cut there) are the single launch's own,
+// and the host adds them in the order of mfx_sum_partials_kernel.  Contiguous shares, not the block-cyclic deal of the resident
+// run: a device's share must be one stretch of the upload.  Every slot needs its own evaluator AND its own sequence object
+// (mfx_seq_create on its device; they hold different parts afterwards and refuse whole-sequence calls: mfx_seq::partial).
+static unsigned t_sharers_get();
+static double sum_like_partials_kernel(const std::vector<double> &p) {
+  double s[MFX_BLOCK];
+  for (uint32_t t = 0; t < MFX_BLOCK; ++t) {
+    double v = 0.0;
+    for (size_t i = t; i < p.size(); i += MFX_BLOCK) v = v + p[i];
+    s[t] = v;
+  }
+  for (uint32_t st = MFX_BLOCK / 2; st > 0; st >>= 1)
+    for (uint32_t t = 0; t < st; ++t) s[t] = s[t] + s[t + st];
+  return 0.0 + s[0];
+}
+
+static void stream_part_bounds(uint64_t T, uint32_t n, std::vector<uint64_t> &b) {
+  b.assign(n + 1, 0);
+  for (uint32_t d = 1; d < n; ++d) {
+    uint64_t x = (uint64_t)((__uint128_t)T * d / n);
+    x = (x + 512) / 1024 * 1024;
+    b[d] = std::min(T, std::max(b[d - 1], x));
+  }
+  b[n] = T;
+}
+
+extern "C" int mfx_hist_run_streamed_multi(mfx_eval *const *evs, mfx_seq *const *seqs, uint32_t ndev, const char *const *bases, mfx_hist_result *out) {
+  if (!evs || !seqs || !out || ndev == 0) return mfx_fail(MFX_E_INVAL, "mfx_hist_run_streamed_multi: null argument");
+  for (uint32_t d = 0; d < ndev; ++d) {
+    if (!evs[d] || !seqs[d]) return mfx_fail(MFX_E_INVAL, "mfx_hist_run_streamed_multi: null evaluator / sequence for slot %u", d);
+    if (evs[d]->device != seqs[d]->device) return mfx_fail(MFX_E_INVAL, "slot %u: evaluator and sequence live on different devices", d);
+    if (evs[d]->nbins != evs[0]->nbins || seqs[d]->ntiles != seqs[0]->ntiles || seqs[d]->ncontigs != seqs[0]->ncontigs || seqs[d]->len != seqs[0]->len)
+      return mfx_fail(MFX_E_INVAL, "slot %u: the sequence objects of one run must have the same contig lengths, the evaluators the same bins", d);
+    if (evs[d]->ix->wide()) return mfx_fail(MFX_E_INVAL, "mfx_hist_run_streamed_multi: k > 31 is not supported (the 128-bit kernels read one byte per base)");
+    for (uint32_t e = 0; e < d; ++e)
+      if (evs[e] == evs[d] || seqs[e] == seqs[d]) return mfx_fail(MFX_E_INVAL, "slots %u and %u share an evaluator or a sequence object (every slot streams its own part)", e, d);
+  }
+  if (seqs[0]->ncontigs && !bases) return mfx_fail(MFX_E_INVAL, "mfx_hist_run_streamed_multi: null argument");
+  if (ndev == 1) return mfx_hist_run_streamed(evs[0], seqs[0], bases, out);
+  const uint32_t nbins = evs[0]->nbins, ncontigs = seqs[0]->ncontigs;
+  const size_t words = MFX_HIST_WORDS(nbins, ncontigs);
+  std::vector<uint64_t> bound;
+  stream_part_bounds(seqs[0]->ntiles, ndev, bound);
+  std::vector<std::vector<double>> sums(ndev);
+  std::vector<int> rcs(ndev, MFX_OK);
+  std::vector<std::string> errs(ndev);
+  const unsigned sharers = t_sharers_get() * ndev;
+  {
+    std::vector<std::thread> th;
+    for (uint32_t d = 0; d < ndev; ++d)
+      th.emplace_back([&, d] {
+        mfx_host_threads_share(sharers);                      // the host's encoder threads are dealt to the slots
+        StreamPart p;
+        p.tl = bound[d]; p.th = bound[d + 1];
+        p.chunk_sums = &sums[d];
+        p.want_result = false;
+        rcs[d] = hist_run_streamed_packed(evs[d], seqs[d], bases, nullptr, &p);
+        if (rcs[d]) errs[d] = mfx_last_error();
+      });
+    for (auto &t : th) t.join();
+  }
+  for (uint32_t d = 0; d < ndev; ++d)
+    if (rcs[d]) return mfx_fail(rcs[d], "mfx_hist_run_streamed_multi: slot %u: %s", d, errs[d].c_str());
+  uint64_t *sum = evs[0]->sr.h_img;                           // slot 0's pinned image is the accumulator
+  std::vector<uint64_t> novf(ndev, 0);
+  std::vector<double> all;
+  for (uint32_t d = 0; d < ndev; ++d) {
+    const uint64_t *h = evs[d]->sr.h_img;
+    novf[d] = h[2ull * nbins + 2];
+    if (d) for (size_t i = 0; i < words; ++i) sum[i] += h[i];
+    all.insert(all.end(), sums[d].begin(), sums[d].end());
+  }
+  int rc = mfx_hist_result_from_counts(nbins, sum, sum_like_partials_kernel(all), ncontigs, out);
+  for (uint32_t d = 0; d < ndev && rc == MFX_OK; ++d) rc = result_take_overflow(evs[d], novf[d], out);
+  if (rc && out->undr) mfx_hist_result_free(out);
+  return rc;
+}
+
+// One rank's share of the same, for the one-process-per-GPU launcher: the tiles [tile_begin, tile_end) of the assembly in host memory
+// are encoded, uploaded and evaluated; counts and koverCpy are ADDED to the caller's device image (cleared by the caller; the
+// launcher all-reduces it over the ranks, mfx_hist_allreduce).  Returns when the device is done.  mfx_hist_stream_share gives rank
+// r of n the bounds the one-process run uses.
+extern "C" int mfx_hist_run_streamed_range(mfx_eval *ev, mfx_seq *seq, const char *const *bases, uint64_t tile_begin, uint64_t tile_end,
+                                           uint64_t *d_counts, double *d_kover) {
+  if (!ev || !seq || !d_counts || !d_kover || (seq->ncontigs && !bases)) return mfx_fail(MFX_E_INVAL, "mfx_hist_run_streamed_range: null argument");
+  if (ev->device != seq->device) return mfx_fail(MFX_E_INVAL, "evaluator and sequence live on different devices");
+  if (tile_begin > tile_end || tile_end > seq->ntiles) return mfx_fail(MFX_E_INVAL, "tile range [%lu,%lu) outside [0,%lu)",
+                                                                      (unsigned long)tile_begin, (unsigned long)tile_end, (unsigned long)seq->ntiles);
+  if (ev->ix->wide()) return mfx_fail(MFX_E_INVAL, "mfx_hist_run_streamed_range: k > 31 is not supported");
+  StreamPart p;
+  p.tl = tile_begin; p.th = tile_end;
+  p.d_counts = d_counts; p.d_kover = d_kover;
+  p.want_result = false;
+  return hist_run_streamed_packed(ev, seq, bases, nullptr, &p);
+}
+
+extern "C" int mfx_hist_stream_share(uint64_t ntiles, uint32_t rank, uint32_t nranks, uint64_t *tile_begin, uint64_t *tile_end) {
+  if (!nranks || rank >= nranks || !tile_begin || !tile_end) return mfx_fail(MFX_E_INVAL, "mfx_hist_stream_share: rank %u of %u", rank, nranks);
+  std::vector<uint64_t> b;
+  stream_part_bounds(ntiles, nranks, b);
+  *tile_begin = b[rank];
+  *tile_end = b[rank + 1];
+  return MFX_OK;
 }
 
 // PARTS of one assembly, one per slot, each on its own sequence-only index (mfx_index_claim_seq on the slot's contigs,
@@ -3402,6 +3553,7 @@ extern "C" int mfx_dump_values_sharded(mfx_eval *const *evs, const mfx_seq *cons
 // host threads the library may use for text formatting: min(hardware, cgroup quota, 64)
 static thread_local unsigned t_sharers = 1;
 extern "C" void mfx_host_threads_share(unsigned nsharers) { t_sharers = nsharers ? nsharers : 1; }
+static unsigned t_sharers_get() { return t_sharers; }
 
 static unsigned host_threads_total();
 unsigned mfx_host_threads() { return std::max(1u, host_threads_total() / t_sharers); }

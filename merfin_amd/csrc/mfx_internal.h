@@ -185,6 +185,8 @@ struct mfx_seq {
   uint64_t *d_tile_start = nullptr;  // [ncontigs+1] first tile of each contig
   uint32_t *d_tile_contig = nullptr; // [ntiles] contig of each tile
   std::vector<uint64_t> off, len, tile_start;
+  bool      partial = false;         // a streamed PART was the last thing put in: only the tiles [part_lo, part_hi) are there (mfx_hist_run_streamed_multi / _range)
+  uint64_t  part_lo = 0, part_hi = 0;
   mutable uint32_t digest = 0;       // content digest (mfx_seq_digest32), computed on first use; 0: not computed / the content changed
 };
 
@@ -209,6 +211,7 @@ struct mfx_path_table {
 // included) and, need_dk, totdk[p] (sum of the delta-K terms in position order) -- the values varMer::score computes
 int mfx_score_paths(mfx_eval *ev, const char *text, uint64_t len, const mfx_path_table *pt, int need_dk, uint32_t *numM, double *totdk);
 
+int mfx_seq_partial_error(const mfx_seq *s, const char *who);     // MFX_E_INVAL: the sequence object holds a part only
 int mfx_seq_ensure_ascii(const mfx_seq *s);      // unpacks the planes into d_bases if a packed upload left them newer (mfx_api.cpp)
 
 struct mfx_eval {

@@ -31,6 +31,8 @@ def test_plain_command_starts_its_own_ranks():
     assert len(d["config"]["rank_kernel_ms"]["all"]) == 2
     assert "bench.py started its own ranks" in d["config"]["launcher"]
     assert d["config"]["collective"].startswith("host memory")          # the rehearsal never claims RCCL
+    # SURVEY 8(d)'s metric at N > 1: every rank streamed its share from host memory, same histogram
+    assert d["value_8d"] and d["value_8d"] > 0 and d["config"]["h2d_inclusive_multi"]["equals_resident_result"] is True
     r1 = _bench(["--gpus", "1", "--no-streamed"] + common)
     assert r1.returncode == 0, r1.stderr[-3000:]
     d1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])

@@ -114,6 +114,27 @@ def test_sharded_index_across_devices(k, tmp_path):
         assert (tmp_path / ("s_" + mode)).read_bytes() == (tmp_path / ("w_" + mode)).read_bytes()
 
 
+def test_streamed_hist_over_distinct_devices():
+    """SURVEY 8(d)'s evaluate phase at N GPUs (mfx_hist_run_streamed_multi): every device receives and evaluates its own stretch of
+    the assembly; equal to the oracle and, bit for bit, to the resident single-device run"""
+    import merfin_amd as m
+    devs = _devices()
+    k, peak = 21, 17.3
+    contigs, read, asm = synth.world(k=k, peak=peak, seed=509, sizes=(4200000 * len(devs) // 2, 1100000, 4097, 500, 0, 8191), err_kmers=3000)
+    p, g, ka, km = oracle_hist(k, peak, contigs, read, asm)
+    ix0 = build_index(m, k, read, asm)
+    ixs = [ix0] + ix0.replicate_many(devs[1:])
+    evs = [m.Evaluator(ix, m.KParams(peak)) for ix in ixs]
+    lens = [len(c) for c in contigs]
+    sqs = [m.Sequences.create(lens, device=d) for d in devs]
+    res = m.hist_streamed_multi(evs, sqs, contigs)
+    assert_hist_equal(res, g, ka, km, k)
+    one = evs[0].hist(m.Sequences(contigs, device=devs[0]))
+    assert (res.kasm, res.kmissing, res.koverCpy) == (one.kasm, one.kmissing, one.koverCpy)
+    np.testing.assert_array_equal(res.undr(), one.undr())
+    np.testing.assert_array_equal(res.over(), one.over())
+
+
 def _torchrun(n, args, env=None, timeout=900):
     port = 29500 + os.getpid() % 400
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",

@@ -146,6 +146,72 @@ def five_mb_world():
     return k, peak, contigs, read, asm, g, ka, km
 
 
+@pytest.mark.parametrize("nslots", [2, 3, 8])
+def test_streamed_over_several_slots_equals_resident_bit_for_bit(nslots):
+    """SURVEY 8(d)'s evaluate phase over N devices (mfx_hist_run_streamed_multi; the slots are N contexts on device 0 here, distinct
+    devices in tests/test_gpu_multidevice.py): every slot uploads and evaluates only its contiguous share of the tiles; bins, counters,
+    per-contig counters AND koverCpy equal the single resident launch to the last bit (shares are cut at multiples of 1024 tiles, the
+    host adds the first-level sums in the device's order)."""
+    import merfin_amd as m
+    k, peak = 21, 9.0
+    r = synth.rng(331)
+    sizes = (2300 * 4096 + 77, 5, 700 * 4096 + 4095, 0, 260 * 4096)      # 3263 tiles: cuts at 1024 / 2048 / 3072 for 3 slots
+    contigs = [synth.random_contig(r, n) for n in sizes]
+    contigs[0][1024 * 4096 + 3] = ord("N")                    # just behind a cut between two slots
+    contigs[0][2048 * 4096 - 2:2048 * 4096 + 30] |= 0x20
+    contigs[2][100] = ord("N")
+    for c in contigs:                                          # duplicated stretches: asmK > readK somewhere, so koverCpy is a real sum
+        if len(c) > 300000:
+            c[200000:260000] = c[100000:160000]
+    seqs = m.Sequences([c.tobytes() for c in contigs])
+    ix = m.Index(k, sum(sizes) + 1024)
+    ix.count_asm(seqs)
+    spots = [contigs[0][:400000], contigs[0][1024 * 4096 - 50000:1024 * 4096 + 50000], contigs[0][2048 * 4096 - 50000:2048 * 4096 + 50000],
+             contigs[0][-50000:], contigs[1], contigs[2][:300000], contigs[4][-100000:]]
+    rk = po.count_kmers(k, [x.tobytes() for x in spots])[0]
+    ix.add_read(rk, (1 + (rk % 7)).astype(np.uint32))
+    ev = m.Evaluator(ix, m.KParams(peak))
+    resident = ev.hist(seqs)
+    assert resident.koverCpy > 0 and 0 < resident.kmissing < resident.kasm
+    evs = [m.Evaluator(ix, m.KParams(peak)) for _ in range(nslots)]
+    sqs = [m.Sequences.create(list(sizes)) for _ in range(nslots)]
+    for rep in range(2):                                       # the second run re-arms every slot's buffers
+        _same(m.hist_streamed_multi(evs, sqs, contigs), resident)
+    # a slot's sequence object holds its part only: whole-sequence calls are refused until something is uploaded whole
+    with pytest.raises(m.MfxError, match="holds only the tiles"):
+        evs[0].hist(sqs[0])
+    with pytest.raises(m.MfxError, match="share an evaluator or a sequence"):
+        m.hist_streamed_multi(evs[:2], [sqs[0], sqs[0]], contigs)
+    _same(evs[0].hist_streamed(sqs[0], contigs), resident)    # whole again
+    _same(evs[0].hist(sqs[0]), resident)
+    # one rank's share, added into the caller's device image (what bench.py's ranks do before their all-reduce)
+    import torch
+    words = m.hist_words(ev.nbins, seqs.ncontigs)
+    counts = torch.zeros(words, dtype=torch.int64, device="cuda")
+    kover = torch.zeros(1, dtype=torch.float64, device="cuda")
+    for rank in range(nslots):
+        lo, hi = m.stream_share(seqs.ntiles, rank, nslots)
+        evs[rank].hist_streamed_range(sqs[rank], contigs, lo, hi, counts, kover)
+    torch.cuda.synchronize()
+    got = ev.result_from_counts(counts.cpu().numpy().view(np.uint64), float(kover.item()), seqs.ncontigs)
+    assert (got.kasm, got.kmissing) == (resident.kasm, resident.kmissing)
+    np.testing.assert_array_equal(got.undr(), resident.undr())
+    np.testing.assert_array_equal(got.over(), resident.over())
+    np.testing.assert_array_equal(got.contig_kasm(), resident.contig_kasm())
+    assert abs(got.koverCpy - resident.koverCpy) <= 1e-12 * abs(resident.koverCpy)
+
+
+def test_streamed_over_several_slots_matches_oracle(five_mb_world):
+    import merfin_amd as m
+    k, peak, contigs, read, asm, g, ka, km = five_mb_world
+    ix = build_index(m, k, read, asm)
+    lens = [len(c) for c in contigs]
+    for n in (2, 4):
+        evs = [m.Evaluator(ix, m.KParams(peak)) for _ in range(n)]
+        res = m.hist_streamed_multi(evs, [m.Sequences.create(lens) for _ in range(n)], contigs)
+        assert_hist_equal(res, g, ka, km, k)
+
+
 @pytest.mark.parametrize("nslots", [2, 3, 5])
 def test_one_process_several_slots_matches_oracle(nslots, five_mb_world):
     import merfin_amd as m
