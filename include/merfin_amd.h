@@ -166,6 +166,11 @@ typedef struct mfx_seq mfx_seq;
  * (one slot per canonical k-mer cannot answer value(fmer) + value(rmer) of a non-canonical one): a load that meets a
  * non-canonical k-mer fails with MFX_E_NONCANON and the caller builds the full index instead. */
 mfx_index *mfx_index_create_for_seq(int k, uint64_t capacity_kmers, double max_gb, int device);
+/* ... with the table's load factor chosen by the caller (0: by the free memory, as above; MFX_LOAD_FACTOR overrides both).  The
+ * emptiest table probes fastest, but a short-lived process pays for the memory it asks for: one started behind another waits in
+ * hipMalloc while the driver clears what the earlier one freed.  The `merfin` CLI asks for 0.4 (61 GB for a human assembly), a
+ * resident evaluator for the default (0.18, 135 GB): profiles/r05_e2e_lf_ab.txt. */
+mfx_index *mfx_index_create_for_seq_lf(int k, uint64_t capacity_kmers, double max_gb, int device, double load_factor);
 double     mfx_index_estimate_gb_for_seq(int k, uint64_t capacity_kmers);
 int        mfx_index_claim_seq(mfx_index *ix, const mfx_seq *seq, void *stream);
 /* PART of an assembly per device (round 4; config 5's -hist / -dump without any exchange): a device that evaluates some
@@ -185,6 +190,18 @@ int mfx_index_count_asm(mfx_index *ix, const mfx_seq *seq, void *stream);
  * bytes cross PCIe while the sequence's k-mers are still being claimed and counted (the inserts wait for that kernel on the
  * device).  Same table as the two calls.  Replaces load_Kmers + the `meryl count` of -sequence, merfin-globals.C:114-163,182-186. */
 int mfx_index_build_for_hist(mfx_index *ix, const mfx_seq *seq, const char *read_db_path, uint64_t minV, uint64_t maxV);
+/* The same with the database's bytes moving from the moment the process starts (what the reference pays per run, load_Kmers,
+ * merfin-globals.C:114-163, 155-159): mfx_db_stage_begin opens a delta-coded flat database (`merfin -convert`), takes device memory
+ * for all of its blocks and lets a thread of its own read the file into it over PCIe -- under the FASTA read, the sequence upload, the
+ * table's allocation and the claim / count kernel; mfx_index_build_for_hist_staged launches that kernel and, behind it, the
+ * decode + update kernel over the staged blocks as their copies complete.  Same table as mfx_index_build_for_hist.  _begin returns
+ * NULL (mfx_last_error says why) for any other database form, when the blocks would take more than a fifth of the free device
+ * memory, or with MFX_DB_STAGE=0: the caller then takes the unstaged call.  The stage is released with mfx_db_stage_free (also
+ * before it was used). */
+typedef struct mfx_db_stage mfx_db_stage;
+mfx_db_stage *mfx_db_stage_begin(const char *read_db_path, int device);
+int           mfx_index_build_for_hist_staged(mfx_index *ix, const mfx_seq *seq, mfx_db_stage *stage, uint64_t minV, uint64_t maxV);
+void          mfx_db_stage_free(mfx_db_stage *stage);
 
 /* merylExactLookup::value(kmer), merfin-globals.C:107-108, batched: for each
  * query returns the stored read and asm counts (0 when absent).  Queries are

@@ -63,7 +63,7 @@ _lib = None
 SYMBOLS = [
     "mfx_last_error", "mfx_last_error_code", "mfx_version", "mfx_device_count", "mfx_device_warm",
     "mfx_index_create", "mfx_index_free", "mfx_index_estimate_gb", "mfx_index_add_read", "mfx_index_add_asm",
-    "mfx_index_count_asm", "mfx_index_build_for_hist", "mfx_index_count_claimed", "mfx_hist_run_parts", "mfx_index_create_for_seq", "mfx_index_estimate_gb_for_seq", "mfx_index_claim_seq", "mfx_index_value", "mfx_index_get_info", "mfx_index_export",
+    "mfx_index_count_asm", "mfx_index_build_for_hist", "mfx_index_count_claimed", "mfx_hist_run_parts", "mfx_index_create_for_seq", "mfx_index_create_for_seq_lf", "mfx_db_stage_begin", "mfx_index_build_for_hist_staged", "mfx_db_stage_free", "mfx_index_estimate_gb_for_seq", "mfx_index_claim_seq", "mfx_index_value", "mfx_index_get_info", "mfx_index_export",
     "mfx_db_probe", "mfx_index_load_db", "mfx_index_load_db_multi", "mfx_db_write_flat", "mfx_db_convert", "mfx_index_save", "mfx_index_load",
     "mfx_index_set_fingerprint", "mfx_index_get_origin",
     "mfx_host_alloc", "mfx_host_free", "mfx_seq_create", "mfx_hist_run_streamed",
@@ -131,6 +131,13 @@ def load_library():
     L.mfx_hist_run_parts.argtypes = [C.POINTER(vp), C.POINTER(vp), C.POINTER(C.POINTER(C.c_uint32)), C.c_uint32, C.c_uint32, vp]
     L.mfx_index_create_for_seq.restype = vp
     L.mfx_index_create_for_seq.argtypes = [C.c_int, C.c_uint64, C.c_double, C.c_int]
+    L.mfx_index_create_for_seq_lf.restype = vp
+    L.mfx_index_create_for_seq_lf.argtypes = [C.c_int, C.c_uint64, C.c_double, C.c_int, C.c_double]
+    L.mfx_db_stage_begin.restype = vp
+    L.mfx_db_stage_begin.argtypes = [C.c_char_p, C.c_int]
+    L.mfx_index_build_for_hist_staged.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64]
+    L.mfx_db_stage_free.restype = None
+    L.mfx_db_stage_free.argtypes = [vp]
     L.mfx_index_estimate_gb_for_seq.restype = C.c_double
     L.mfx_index_estimate_gb_for_seq.argtypes = [C.c_int, C.c_uint64]
     L.mfx_index_claim_seq.argtypes = [vp, vp, vp]
@@ -345,25 +352,47 @@ def _ptr(x):
     return C.c_void_p(int(x)), 1, None
 
 
+class DbStage:
+    """A delta-coded flat database on its way into device memory (mfx_db_stage_begin); None-like (ok == False) when it cannot be staged."""
+
+    def __init__(self, path, device=0):
+        self.h = load_library().mfx_db_stage_begin(path.encode(), device)
+        self.ok = bool(self.h)
+        self.why = None if self.ok else load_library().mfx_last_error().decode()
+
+    def close(self):
+        if self.h:
+            load_library().mfx_db_stage_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Index:
     """Joint read+assembly k-mer count table resident in HBM."""
 
-    def __init__(self, k, capacity_kmers, max_gb=0.0, device=0, _handle=None, seq_only=False):
+    def __init__(self, k, capacity_kmers, max_gb=0.0, device=0, _handle=None, seq_only=False, load_factor=0.0):
         L = load_library()
         self.k = k
         self.device = device
         if _handle is not None:
             self.h = _handle
+        elif seq_only and load_factor:
+            self.h = _need(L.mfx_index_create_for_seq_lf(k, int(capacity_kmers), float(max_gb), device, float(load_factor)))
         elif seq_only:
             self.h = _need(L.mfx_index_create_for_seq(k, int(capacity_kmers), float(max_gb), device))
         else:
             self.h = _need(L.mfx_index_create(k, int(capacity_kmers), float(max_gb), device))
 
     @staticmethod
-    def for_seq(k, capacity_kmers, max_gb=0.0, device=0):
+    def for_seq(k, capacity_kmers, max_gb=0.0, device=0, load_factor=0.0):
         """a SEQUENCE-ONLY index (mfx_index_create_for_seq): claim the k-mers of the sequence first (count_asm or
         claim_seq), then add / load -- those only update the claimed k-mers.  For -hist and -dump."""
-        return Index(k, capacity_kmers, max_gb=max_gb, device=device, seq_only=True)
+        return Index(k, capacity_kmers, max_gb=max_gb, device=device, seq_only=True, load_factor=load_factor)
 
     def count_claimed(self, seqs, stream=None):
         """asmV += 1 per occurrence, in `seqs`, of a k-mer claimed before (claim_seq); nothing is claimed"""
@@ -372,6 +401,10 @@ class Index:
     def build_for_hist(self, seqs, read_db_path, minV=0, maxV=2**64 - 1):
         """count_asm(seqs) + load_db(read_db_path, 0, minV, maxV) in one call: the database crosses PCIe while the sequence's k-mers are claimed"""
         _check(load_library().mfx_index_build_for_hist(self.h, seqs.h, read_db_path.encode(), minV, maxV))
+
+    def build_for_hist_staged(self, seqs, stage, minV=0, maxV=2**64 - 1):
+        """the same from a DbStage (mfx_db_stage_begin): the database has been on its way into device memory since the stage was made"""
+        _check(load_library().mfx_index_build_for_hist_staged(self.h, seqs.h, stage.h, minV, maxV))
 
     def claim_seq(self, seqs, stream=None):
         _check(load_library().mfx_index_claim_seq(self.h, seqs.h, C.c_void_p(stream or 0)))

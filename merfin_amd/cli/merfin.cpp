@@ -707,6 +707,17 @@ int main(int argc, char **argv) {
                     "--       statistics; `meryl print` text is the verified interchange form.  To validate the decoder on this\n"
                     "--       database: python tools/meryl_conformance.py <db.meryl> <output of `meryl print db.meryl`>\n"
                     "--       (= MFX_REAL_MERYL_DB / MFX_REAL_MERYL_PRINT for tests/test_gpu_meryl_conformance.py).\n");
+  // `merfin -hist / -dump -sequence s -readmers db` on one device with a delta-coded database and no -seqmers: the database's bytes start
+  // moving into device memory NOW, on a thread of their own (mfx_db_stage_begin) -- under the FASTA read, the sequence upload, the
+  // table's allocation and the kernel that claims the sequence's k-mers.  Any other database form, too little free memory,
+  // MFX_DB_STAGE=0: no stage, the build reads the database when it gets there.
+  mfx_db_stage *stage = nullptr;
+  struct StageGuard { mfx_db_stage *&s; ~StageGuard() { if (s) mfx_db_stage_free(s); s = nullptr; } } stageGuard{stage};
+  {
+    const bool histLike = (G.reportType == OP_HIST || G.reportType == OP_DUMP) && !G.sharded && k <= 31 && G.seqName && !G.seqDBname && !G.indexName &&
+                          G.devices.size() == 1 && !(getenv("MFX_CLI_FULL_INDEX") && atoi(getenv("MFX_CLI_FULL_INDEX")));
+    if (histLike && rdb.format == MFX_DB_FLAT) stage = mfx_db_stage_begin(G.readDBname, G.device);
+  }
   lap("probe k-mer databases");
   // sequences (load_Sequence, merfin-globals.C:165-197; loadSequence, merfin.C:30-53).  The file is read (and, for
   // .gz/.bz2/.xz, decompressed) by its own thread from here on; with -seqmers nothing needs the sequence before the
@@ -850,7 +861,15 @@ int main(int argc, char **argv) {
     fprintf(stderr, "--\n-- Memory needed: %.3f GB\n-- Memory limit:  %.3f GB%s\n--\n", mfx_index_estimate_gb_for_seq(k, capacity),
             G.maxMemory, G.maxMemory > 0 ? "" : " (none)");
     step("(before the index)");
-    ix = mfx_index_create_for_seq(k, capacity, G.maxMemory, G.device);
+    // load factor of the table: 0.4 unless the user says otherwise (MFX_LOAD_FACTOR) -- the emptier tables the library would pick probe
+    // faster (3 Gb: 20 instead of 23 ms of -hist kernel) but a run that starts behind another waits seconds in hipMalloc for the driver
+    // to clear what that one freed, the longer the more of the HBM both ask for (profiles/r05_e2e_lf_ab.txt)
+    ix = mfx_index_create_for_seq_lf(k, capacity, G.maxMemory, G.device, 0.4);
+    if (!ix && stage) {                                             // (the staged database may be what the table lacks)
+      mfx_db_stage_free(stage);
+      stage = nullptr;
+      ix = mfx_index_create_for_seq_lf(k, capacity, G.maxMemory, G.device, 0.4);
+    }
     if (!ix) {
       fprintf(stderr, "\n%s\n\n", mfx_last_error());
       return 1;
@@ -871,7 +890,8 @@ int main(int argc, char **argv) {
       fprintf(stderr, "-- No -seqmer given. Counting the %d-mers of '%s' on the GPU.\n", k, G.seqName);
       // (one call for the counting and the load of -readmers: the database crosses PCIe while the k-mers are claimed)
       fprintf(stderr, "-- Loading kmers from '%s' into lookup table.\n", G.readDBname);
-      lrc = mfx_index_build_for_hist(ix, seq, G.readDBname, G.minV, G.maxV);
+      lrc = stage ? mfx_index_build_for_hist_staged(ix, seq, stage, G.minV, G.maxV) : mfx_index_build_for_hist(ix, seq, G.readDBname, G.minV, G.maxV);
+      if (stage) { mfx_db_stage_free(stage); stage = nullptr; }     // its device memory is not needed by the evaluation
       if (lrc && lrc != MFX_E_NONCANON) DIE_MFX("counting sequence k-mers / loading -readmers");
       step("count the sequence's k-mers + load -readmers");
       fused = true;

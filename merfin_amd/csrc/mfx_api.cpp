@@ -200,8 +200,10 @@ constexpr double MFX_CLF_MAX = 0.5, MFX_CLF_MIN = 0.18;
 // (profiles/r03_hist_rates_by_k.txt).  0.30 is 160 GB for a human assembly.
 constexpr double MFX_SLF_MIN = 0.30;
 
+thread_local double t_lf_request = 0;      // mfx_index_create_for_seq_lf: the caller's load factor for the table being created (0: none)
 bool load_factor_fixed(double *lf) {
   const char *e = getenv("MFX_LOAD_FACTOR");
+  if (!e && t_lf_request > 0) { *lf = std::min(0.9, std::max(0.05, t_lf_request)); return true; }
   if (!e) return false;
   double v = atof(e);
   if (!(v > 0.05 && v <= 0.9)) v = MFX_LF_MAX;
@@ -326,6 +328,18 @@ extern "C" mfx_index *mfx_index_create_for_seq(int k, uint64_t capacity_kmers, d
     return nullptr;
   }
   return index_create(k, capacity_kmers, max_gb, device, true);
+}
+
+// The table's load factor chosen by the caller instead of by the free memory (0: as mfx_index_create_for_seq; MFX_LOAD_FACTOR still
+// overrides).  The emptiest table is the fastest to probe (3 Gb, k = 21: 151.8 G k-mers/s at 0.18 = 135 GB against 136 G at 0.4 = 61 GB)
+// but not the fastest RUN: a process that starts behind another one waits in hipMalloc while the driver clears what that one freed,
+// and how long depends on how much of the HBM both want (profiles/r05_e2e_lf_ab.txt: `merfin -hist` at 3 Gb back to back 4.5-4.9 s at
+// 0.18, 1.2-1.3 s at 0.4) -- the CLI asks for 0.4, a resident service for 0.18.
+extern "C" mfx_index *mfx_index_create_for_seq_lf(int k, uint64_t capacity_kmers, double max_gb, int device, double load_factor) {
+  t_lf_request = load_factor > 0 ? load_factor : 0;
+  mfx_index *ix = mfx_index_create_for_seq(k, capacity_kmers, max_gb, device);
+  t_lf_request = 0;
+  return ix;
 }
 
 static mfx_index *index_create(int k, uint64_t capacity_kmers, double max_gb, int device, bool seq_only) {
@@ -842,7 +856,8 @@ extern "C" int mfx_index_add_asm(mfx_index *ix, const uint64_t *kmers, const uin
 // defer: the kernel is launched and NOT waited for -- an event recorded behind it is left in the index's staging state
 // (mfx_ingest::after), the inserts of the load that follows wait for it on the device, and that load's final check reads what
 // both left in meta (mfx_index_build_for_hist)
-static int index_count(mfx_index *ix, const mfx_seq *seq, int count, void *stream, const char *who, bool defer = false) {
+// no_wait: the kernel is launched on `stream` and neither waited for nor checked -- the caller orders what follows behind it and checks
+static int index_count(mfx_index *ix, const mfx_seq *seq, int count, void *stream, const char *who, bool defer = false, bool no_wait = false) {
   if (!ix || !seq) return mfx_fail(MFX_E_INVAL, "%s: null argument", who);
   if (ix->device != seq->device) return mfx_fail(MFX_E_INVAL, "index and sequence live on different devices");
   if (ix->seq_only && ix->frozen && count != 2)
@@ -869,6 +884,7 @@ static int index_count(mfx_index *ix, const mfx_seq *seq, int count, void *strea
     if (int drc = mfx_seq_digest32(seq, &ix->seq_digest)) return drc;
   if (count == 2) ix->frozen = true;                           // counts arrived: no more claims
   MFX_HIP(ix->wide() ? mfx_kw_count(a, (hipStream_t)stream) : mfx_k_count(a, (hipStream_t)stream));
+  if (no_wait) return MFX_OK;
   // While the kernel claims / counts a large sequence's k-mers (0.11 s for 3 Gb), the host pins the staging lanes the database
   // load that follows will want (0.06 s): the lanes belong to the index and are reused by every load.
   if (defer) {
@@ -920,6 +936,191 @@ extern "C" int mfx_index_build_for_hist(mfx_index *ix, const mfx_seq *seq, const
   int rc = index_count(ix, seq, 1, nullptr, "mfx_index_build_for_hist", defer);
   if (rc == MFX_OK) rc = mfx_index_load_db(ix, read_db_path, 0, minV, maxV);
   ingest_settle_after(ix);                                   // (a load that failed before its staging loop leaves the event behind)
+  return rc;
+}
+
+// ---------------------------------------------------------------------------
+// STAGED load of the read database (load_Kmers, merfin-globals.C:114-163, as `merfin -hist` pays it per run).  The database's bytes do
+// not depend on anything else of the run, so they start moving when the process starts: mfx_db_stage_begin opens a delta-coded flat
+// database, takes device memory for ALL of its blocks + directory, and a thread of its own reads the file through three pinned
+// lanes into that memory (one copy stream) -- under the FASTA read, the sequence upload, the table's allocation and the kernel that
+// claims and counts the sequence's k-mers.  mfx_index_build_for_hist_staged then launches that kernel and, behind it, the decode +
+// update kernel over the staged blocks, chunk by chunk as their copies complete (the kernels wait for the copy events on the device).
+// The link is busy from the first 0.1 s of the process instead of from the moment the table exists; same table as
+// mfx_index_build_for_hist.  nullptr from _begin (another database form, too little free HBM): the caller takes the unstaged call.
+// ---------------------------------------------------------------------------
+struct mfx_db_stage {
+  int device = 0, fd = -1;
+  std::string path;
+  mfx_flat_delta_info info;
+  std::vector<uint64_t> dir;                                  // (nblocks + 1) x {first k-mer, file offset | kbits << 48 | vbits << 56}
+  uint64_t off0 = 0, payload_bytes = 0;
+  uint8_t *d_payload = nullptr;
+  uint64_t *d_dir = nullptr;
+  struct Chunk { uint64_t b0, b1; hipEvent_t copied = nullptr; };
+  std::vector<Chunk> chunks;
+  std::atomic<int64_t> enqueued{0};                           // chunks whose copy is enqueued and whose event is recorded
+  std::atomic<int> failed{0};
+  std::string error;
+  std::thread worker;
+  double t_begin = 0, t_first_copy = 0, t_last_enqueued = 0;
+  uint64_t file_off(uint64_t b) const { return dir[2 * b + 1] & 0xffffffffffffull; }
+};
+
+static double stage_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+static void stage_worker(mfx_db_stage *S) {
+  constexpr int NL = 3;
+  const size_t LANE = 32u << 20;
+  uint8_t *lane[NL] = {nullptr, nullptr, nullptr};
+  hipEvent_t left[NL] = {nullptr, nullptr, nullptr};
+  hipStream_t cs = nullptr;
+  bool busy[NL] = {false, false, false};
+  auto fail = [&](const char *what, hipError_t e) {
+    S->error = std::string(what) + (e != hipSuccess ? std::string(": ") + hipGetErrorString(e) : std::string());
+    S->failed.store(1);
+  };
+  hipError_t e = hipSetDevice(S->device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+  for (int i = 0; i < NL && e == hipSuccess; ++i) {
+    e = hipHostMalloc((void **)&lane[i], LANE, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&left[i], hipEventDisableTiming);
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(S->d_dir, S->dir.data(), S->dir.size() * 8, hipMemcpyHostToDevice, cs);
+  if (e != hipSuccess) fail("staging set-up failed", e);
+  {
+    std::unique_ptr<WorkerPool> pool(new WorkerPool(pread_threads(), true));
+    for (size_t c = 0; c < S->chunks.size() && !S->failed.load(); ++c) {
+      const int li = (int)(c % NL);
+      if (busy[li] && (e = hipEventSynchronize(left[li])) != hipSuccess) { fail("staging copy failed", e); break; }
+      const uint64_t o = S->file_off(S->chunks[c].b0), bytes = S->file_off(S->chunks[c].b1) - o;
+      if (!par_pread(S->fd, lane[li], bytes, o, pool.get())) { fail("reading the database failed", hipSuccess); break; }
+      if (c == 0) S->t_first_copy = stage_now();
+      e = hipMemcpyAsync(S->d_payload + (o - S->off0), lane[li], bytes, hipMemcpyHostToDevice, cs);
+      if (e == hipSuccess) e = hipEventRecord(left[li], cs);
+      if (e == hipSuccess) e = hipEventRecord(S->chunks[c].copied, cs);
+      if (e != hipSuccess) { fail("staging copy failed", e); break; }
+      busy[li] = true;
+      S->enqueued.store((int64_t)c + 1, std::memory_order_release);
+    }
+  }
+  S->t_last_enqueued = stage_now();
+  if (cs) (void)hipStreamSynchronize(cs);
+  for (int i = 0; i < NL; ++i) { if (lane[i]) (void)hipHostFree(lane[i]); if (left[i]) (void)hipEventDestroy(left[i]); }
+  if (cs) (void)hipStreamDestroy(cs);
+}
+
+extern "C" void mfx_db_stage_free(mfx_db_stage *S) {
+  if (!S) return;
+  S->failed.store(1);                                          // (a worker still on the file stops at its next chunk)
+  if (S->worker.joinable()) S->worker.join();
+  DevGuard g(S->device);
+  for (auto &c : S->chunks) if (c.copied) (void)hipEventDestroy(c.copied);
+  if (S->d_payload) (void)hipFree(S->d_payload);
+  if (S->d_dir) (void)hipFree(S->d_dir);
+  if (S->fd >= 0) close(S->fd);
+  delete S;
+}
+
+extern "C" mfx_db_stage *mfx_db_stage_begin(const char *path, int device) {
+  if (!path) { mfx_fail(MFX_E_INVAL, "mfx_db_stage_begin: null argument"); return nullptr; }
+  if (const char *e = getenv("MFX_DB_STAGE")) if (atoi(e) == 0) { mfx_fail(MFX_E_INVAL, "staged load disabled (MFX_DB_STAGE=0)"); return nullptr; }
+  std::unique_ptr<mfx_db_stage> S(new mfx_db_stage);
+  S->t_begin = stage_now();
+  S->device = device;
+  S->path = path;
+  if (mfx_flat_delta_open(path, &S->fd, &S->info, S->dir)) return nullptr;
+  auto drop = [&](mfx_db_stage *x) { mfx_db_stage_free(x); return (mfx_db_stage *)nullptr; };
+  if (S->info.n == 0 || S->info.k > MFX_MAX_K_NARROW) { mfx_fail(MFX_E_INVAL, "'%s': nothing to stage", path); return drop(S.release()); }
+  S->off0 = S->file_off(0);
+  S->payload_bytes = S->file_off(S->info.nblocks) - S->off0;
+  DevGuard g(device);
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); mfx_fail(MFX_E_HIP, "hipMemGetInfo failed"); return drop(S.release()); }
+  // a fifth of the free HBM at most: the table is sized by what is left (a read database beyond that goes through the ring)
+  if ((double)(S->payload_bytes + S->dir.size() * 8) > 0.2 * (double)free_b) {
+    mfx_fail(MFX_E_NOMEM, "'%s': %.1f GB of blocks against %.1f GB of free device memory: not staged", path, S->payload_bytes / 1e9, free_b / 1e9);
+    return drop(S.release());
+  }
+  if (hipMalloc((void **)&S->d_payload, S->payload_bytes + 64) != hipSuccess || hipMalloc((void **)&S->d_dir, S->dir.size() * 8) != hipSuccess) {
+    (void)hipGetLastError();
+    mfx_fail(MFX_E_NOMEM, "'%s': no device memory for the staged database", path);
+    return drop(S.release());
+  }
+  // chunks: whole blocks, at most 32 MB of file each
+  const uint64_t LANE = 32u << 20;
+  for (uint64_t b0 = 0; b0 < S->info.nblocks;) {
+    uint64_t b1 = b0 + 1;
+    while (b1 < S->info.nblocks && S->file_off(b1 + 1) - S->file_off(b0) <= LANE) ++b1;
+    if (S->file_off(b1) - S->file_off(b0) > LANE) { mfx_fail(MFX_E_FORMAT, "'%s': a block larger than the format allows", path); return drop(S.release()); }
+    mfx_db_stage::Chunk c;
+    c.b0 = b0; c.b1 = b1;
+    if (hipEventCreateWithFlags(&c.copied, hipEventDisableTiming) != hipSuccess) { mfx_fail(MFX_E_HIP, "event creation failed"); return drop(S.release()); }
+    S->chunks.push_back(c);
+    b0 = b1;
+  }
+  mfx_db_stage *raw = S.release();
+  raw->worker = std::thread(stage_worker, raw);
+  return raw;
+}
+
+extern "C" int mfx_index_build_for_hist_staged(mfx_index *ix, const mfx_seq *seq, mfx_db_stage *S, uint64_t minV, uint64_t maxV) {
+  if (!ix || !seq || !S) return mfx_fail(MFX_E_INVAL, "mfx_index_build_for_hist_staged: null argument");
+  if (ix->device != S->device) return mfx_fail(MFX_E_INVAL, "mfx_index_build_for_hist_staged: index and staged database live on different devices");
+  if (S->info.k != ix->k) return mfx_fail(MFX_E_INVAL, "'%s' holds %d-mers but the index is built for k=%d", S->path.c_str(), S->info.k, ix->k);
+  if (ix->wide()) return mfx_fail(MFX_E_INVAL, "mfx_index_build_for_hist_staged: k <= 31 only");
+  const bool timing = getenv("MFX_INGEST_TIMING") != nullptr;
+  const double t0 = stage_now();
+  int rc = set_read_filter(ix, minV, maxV);
+  if (rc) return rc;
+  DevGuard g(ix->device);
+  hipStream_t is[MFX_INGEST_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t counted = nullptr;
+  auto release = [&]() {
+    for (auto &st : is) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    if (counted) (void)hipEventDestroy(counted);
+  };
+#define STAGED_HIP(call)                                                                                          \
+  do {                                                                                                            \
+    hipError_t e_ = (call);                                                                                       \
+    if (e_ != hipSuccess) { rc = mfx_fail(MFX_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); release(); return rc; } \
+  } while (0)
+  for (auto &st : is) STAGED_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  STAGED_HIP(hipEventCreateWithFlags(&counted, hipEventDisableTiming));
+  // the claim / count kernel on the first insert stream; every insert stream waits for it
+  rc = index_count(ix, seq, 1, is[0], "mfx_index_build_for_hist_staged", false, /*no_wait=*/true);
+  if (rc) { release(); return rc; }
+  STAGED_HIP(hipEventRecord(counted, is[0]));
+  for (int i = 1; i < MFX_INGEST_STREAMS; ++i) STAGED_HIP(hipStreamWaitEvent(is[i], counted, 0));
+  ix->frozen = true;
+  const double t1 = stage_now();
+  double t_wait = 0;
+  for (size_t c = 0; c < S->chunks.size(); ++c) {
+    const double tw = stage_now();
+    while (S->enqueued.load(std::memory_order_acquire) <= (int64_t)c) {
+      if (S->failed.load()) { release(); return mfx_fail(MFX_E_IO, "'%s': %s", S->path.c_str(), S->error.c_str()); }
+      std::this_thread::yield();
+    }
+    t_wait += stage_now() - tw;
+    const mfx_db_stage::Chunk &ch = S->chunks[c];
+    hipStream_t st = is[c % MFX_INGEST_STREAMS];
+    STAGED_HIP(hipStreamWaitEvent(st, ch.copied, 0));
+    const uint64_t nb = ch.b1 - ch.b0, m = std::min<uint64_t>(S->info.n - ch.b0 * MFX_DELTA_BLOCK, nb * MFX_DELTA_BLOCK);
+    STAGED_HIP(mfx_k_table_add_delta(ix->view(), reinterpret_cast<const uint64_t *>(S->d_payload), S->d_dir + 2 * ch.b0, (uint32_t)nb, m, S->off0, 0, ix->d_meta, st));
+  }
+  const double t2 = stage_now();
+  for (auto &st : is) STAGED_HIP(hipStreamSynchronize(st));
+#undef STAGED_HIP
+  const double t3 = stage_now();
+  release();
+  if (S->failed.load()) return mfx_fail(MFX_E_IO, "'%s': %s", S->path.c_str(), S->error.c_str());
+  rc = mfx_flat_delta_escapes(ix, S->fd, S->path.c_str(), &S->info, 0, minV, maxV);
+  if (rc == MFX_OK) rc = index_check(ix);
+  if (timing)
+    fprintf(stderr, "-- staged build: %.3f s = count launched %.3f + %zu update launches %.3f (of which waiting for the stager %.3f) + drain %.3f + escapes / check %.3f; "
+            "stager: first copy %.3f s after its start, last copy enqueued after %.3f s (%.2f GB); the build began %.3f s after the stager\n",
+            stage_now() - t0, t1 - t0, S->chunks.size(), t2 - t1, t_wait, t3 - t2, stage_now() - t3, S->t_first_copy - S->t_begin, S->t_last_enqueued - S->t_begin,
+            S->payload_bytes / 1e9, t0 - S->t_begin);
   return rc;
 }
 

@@ -732,15 +732,15 @@ int load_flat_escapes(mfx_index *const *ixs, uint32_t nix, int fd, const char *p
   return mfx_index_add_multi(ixs, nix, ek.data(), ev.data(), h.n_escape, side, minV, maxV);
 }
 
-int load_flat_delta(mfx_index *const *ixs, uint32_t nix, int fd, const char *path, const FlatHeader &h, uint64_t fsize, int side,
-                    uint64_t minV, uint64_t maxV) {
+// the block directory of a delta-coded file, read and checked; *expect_out: where the blocks end (the escape list follows)
+int read_delta_directory(int fd, const char *path, const FlatHeader &h, uint64_t fsize, std::vector<uint64_t> &dir, uint64_t *nblocks_out,
+                         uint64_t *expect_out) {
   auto bad = [&](const char *what) { return mfx_fail(MFX_E_FORMAT, "'%s': %s", path, what); };
   uint64_t nblocks = 0;
   if (h.k > (uint32_t)MFX_MAX_K_NARROW || fsize < sizeof(h) + 8 || pread(fd, &nblocks, 8, sizeof(h)) != 8) return bad("truncated delta-coded payload");
   if (nblocks != (h.n + MFX_DELTA_BLOCK - 1) / MFX_DELTA_BLOCK) return bad("block count does not match the k-mer count");
   const uint64_t dir_off = sizeof(h) + 8, dir_bytes = (nblocks + 1) * 16;
   if (fsize < dir_off + dir_bytes) return bad("truncated block directory");
-  std::vector<uint64_t> dir;
   try { dir.resize(2 * (nblocks + 1)); } catch (const std::exception &) { return mfx_fail(MFX_E_NOMEM, "'%s': no memory for %lu directory entries", path, (unsigned long)nblocks); }
   for (uint64_t o = 0; o < dir_bytes;) {
     const ssize_t r = pread(fd, (char *)dir.data() + o, dir_bytes - o, (off_t)(dir_off + o));
@@ -764,13 +764,58 @@ int load_flat_delta(mfx_index *const *ixs, uint32_t nix, int fd, const char *pat
     if (expect > fsize) return bad("truncated delta-coded payload");
   }
   if (expect > fsize || fsize - expect < h.n_escape * 12) return bad("truncated delta-coded payload");
-  int rc = MFX_OK;
+  *nblocks_out = nblocks;
+  *expect_out = expect;
+  return MFX_OK;
+}
+
+int load_flat_delta(mfx_index *const *ixs, uint32_t nix, int fd, const char *path, const FlatHeader &h, uint64_t fsize, int side,
+                    uint64_t minV, uint64_t maxV) {
+  std::vector<uint64_t> dir;
+  uint64_t nblocks = 0, expect = 0;
+  int rc = read_delta_directory(fd, path, h, fsize, dir, &nblocks, &expect);
+  if (rc) return rc;
   if (h.n) rc = mfx_index_add_delta_file(ixs, nix, fd, path, dir.data(), nblocks, h.n, side, minV, maxV);
   if (rc == MFX_OK && h.n_escape) rc = load_flat_escapes(ixs, nix, fd, path, h, expect, side, minV, maxV);
   return rc;
 }
 
 }  // namespace
+
+// ---- for the staged load (mfx_api.cpp: mfx_db_stage) ----------------------------------------------------------------------
+// opens `path` if it is a delta-coded flat database and reads + checks its directory; MFX_E_FORMAT with *fd_out = -1 when it is
+// another kind of database (the caller then takes the ordinary load)
+int mfx_flat_delta_open(const char *path, int *fd_out, mfx_flat_delta_info *info, std::vector<uint64_t> &dir) {
+  *fd_out = -1;
+  if (detect(std::string(path)) != MFX_DB_FLAT) return mfx_fail(MFX_E_FORMAT, "'%s' is not a flat k-mer file", path);
+  int fd = open(path, O_RDONLY);
+  struct stat st;
+  if (fd < 0 || fstat(fd, &st) != 0) { if (fd >= 0) close(fd); return mfx_fail(MFX_E_IO, "cannot open '%s'", path); }
+  FlatHeader h;
+  if ((uint64_t)st.st_size < sizeof(h) || pread(fd, &h, sizeof(h), 0) != (ssize_t)sizeof(h)) { close(fd); return mfx_fail(MFX_E_FORMAT, "'%s': truncated header", path); }
+  if (const char *why = flat_header_problem(h, (uint64_t)st.st_size)) { close(fd); return mfx_fail(MFX_E_FORMAT, "'%s': %s", path, why); }
+  if (!(h.flags & FLAT_DELTA)) { close(fd); return mfx_fail(MFX_E_FORMAT, "'%s' is not delta-coded", path); }
+  uint64_t nblocks = 0, expect = 0;
+  if (int rc = read_delta_directory(fd, path, h, (uint64_t)st.st_size, dir, &nblocks, &expect)) { close(fd); return rc; }
+  info->k = (int)h.k;
+  info->n = h.n;
+  info->n_escape = h.n_escape;
+  info->nblocks = nblocks;
+  info->escapes_off = expect;
+  info->fsize = (uint64_t)st.st_size;
+  *fd_out = fd;
+  return MFX_OK;
+}
+
+int mfx_flat_delta_escapes(mfx_index *ix, int fd, const char *path, const mfx_flat_delta_info *info, int side, uint64_t minV, uint64_t maxV) {
+  if (!info->n_escape) return MFX_OK;
+  FlatHeader h;
+  memset(&h, 0, sizeof(h));
+  h.k = (uint32_t)info->k;
+  h.n = info->n;
+  h.n_escape = info->n_escape;
+  return load_flat_escapes(&ix, 1, fd, path, h, info->escapes_off, side, minV, maxV);
+}
 
 // merylFileReader(path): opens the DB and reveals k (merfin-globals.C:118-119:
 // "Make readDB first so we know the k size").

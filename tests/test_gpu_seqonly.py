@@ -474,3 +474,20 @@ def test_build_for_hist_equals_count_then_load(k, form, env, tmp_path, monkeypat
     if k <= 31:
         p, g, ka, km = oracle_hist(k, peak, contigs, (read[0], np.where((read[1] >= lo) & (read[1] <= hi), read[1], 0).astype(np.uint32)), asm)
         assert_hist_equal(m.Evaluator(one_call("1"), m.KParams(peak)).hist(seqs), g, ka, km, k)
+    # the STAGED form (mfx_db_stage_begin + mfx_index_build_for_hist_staged: the database moves into device memory on a thread of its own from
+    # the moment the stage exists): same table, for the delta-coded flat form; every other form is not staged and says so
+    stage = m.DbStage(path)
+    if form == "flat" and k <= 31:
+        assert stage.ok, stage.why
+        for load_factor in (0.0, 0.4):
+            st = stage if load_factor == 0.0 else m.DbStage(path)
+            ix = m.Index.for_seq(k, sum(len(c) for c in contigs) + 16, load_factor=load_factor)
+            ix.build_for_hist_staged(seqs, st, lo, hi)
+            st.close()
+            for a_, b_ in zip(_export_sorted(ix), want):
+                np.testing.assert_array_equal(a_, b_)
+            assert_hist_equal(m.Evaluator(ix, m.KParams(peak)).hist(seqs), g, ka, km, k)
+        # a stage that is never used is released cleanly (its worker may still be on the file)
+        m.DbStage(path).close()
+    else:
+        assert not stage.ok and stage.why
