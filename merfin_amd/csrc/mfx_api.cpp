@@ -404,7 +404,9 @@ static mfx_index *index_create(int k, uint64_t capacity_kmers, double max_gb, in
     // t makes (k - t) % 4 == 3, which makes the choice the same on both strands.  MFX_MZ_MOD=0: the smallest m-mer, as the other layouts.
     {
       const char *mm = getenv("MFX_MZ_MOD");
-      ix->mz_t = (compact && ix->mz_w == 4 && k >= 13 && !(mm && atoi(mm) == 0)) ? ((k + 1) & 3) + 4 : 0;
+      // (w = 5, MFX_MZ_W=5, direct form only: t = 4 .. 8 with (k - t) % 5 == 4)
+      const bool modw = ix->mz_w == 4 || (ix->mz_w == 5 && !ix->quot);
+      ix->mz_t = (compact && modw && k >= 13 && !(mm && atoi(mm) == 0)) ? (ix->mz_w == 4 ? ((k + 1) & 3) + 4 : 4 + ((k - 8) % 5)) : 0;
     }
   }
   hipError_t e = hipMalloc((void **)&ix->d_slots, ix->total_lines() * MFX_ALIGN);

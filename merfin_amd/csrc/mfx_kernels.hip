@@ -2781,6 +2781,7 @@ hipError_t mfx_k_hist(const mfx_hist_args &a, int grid, hipStream_t st) {
   const bool generic = ge && atoi(ge);
   if (a.dbg && a.canonical && a.t.compact && a.t.k == 21 && a.t.mz_w == 4 && a.t.mz_t == 6 && !generic) mfx_hist_kernel<true, true, 21, 4, 6, true><<<grid, MFX_BLOCK, dyn, st>>>(a);
   else if (a.canonical && a.t.compact && a.t.k == 21 && a.t.mz_w == 4 && a.t.mz_t == 6 && !generic) mfx_hist_kernel<true, true, 21, 4, 6><<<grid, MFX_BLOCK, dyn, st>>>(a);
+  else if (a.canonical && a.t.compact && a.t.k == 21 && a.t.mz_w == 5 && a.t.mz_t == 7 && !generic) mfx_hist_kernel<true, true, 21, 5, 7><<<grid, MFX_BLOCK, dyn, st>>>(a);
   else if (a.canonical && a.t.compact && a.t.quot && a.t.k == 31 && a.t.mz_w == 4 && a.t.mz_t == 4 && !generic) mfx_hist_kernel<true, true, 31, 4, 4><<<grid, MFX_BLOCK, dyn, st>>>(a);
   else if (a.canonical && a.t.compact) mfx_hist_kernel<true, true, 0, 0, 0><<<grid, MFX_BLOCK, dyn, st>>>(a);
   else if (a.canonical)                mfx_hist_kernel<true, false, 0, 0, 0><<<grid, MFX_BLOCK, dyn, st>>>(a);

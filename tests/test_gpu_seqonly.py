@@ -374,11 +374,14 @@ def test_mod_minimizer_placement_every_k(k, monkeypatch):
     ks = np.array(sorted(amer), dtype=np.uint64)
     asm = (ks, np.array([amer[int(x)] for x in ks], dtype=np.uint32))
     g, ka, km_, _ = po.hist_run(p, po.Lookup(k, *read), po.Lookup(k, *asm), contigs, threads=2)
-    for env in ({}, {"MFX_HIST_GENERIC": "1"}, {"MFX_MZ_MOD": "0"}):
+    # (MFX_MZ_W=5: five windows of k - 4 bases sampled by a t-mer with (k - t) % 5 == 4 -- the direct form (k <= 21) takes it, the
+    # quotient form is built on four windows and falls back to 16-byte slots)
+    envs = ({}, {"MFX_HIST_GENERIC": "1"}, {"MFX_MZ_MOD": "0"}, {"MFX_MZ_W": "5"}, {"MFX_MZ_W": "5", "MFX_HIST_GENERIC": "1"})
+    for env in envs:
         for kk, vv in env.items():
             monkeypatch.setenv(kk, vv)
         ix, seqs = seq_index(m, k, contigs, read)
-        assert ix.info()["compact"] == (k <= 21 or "MFX_MZ_MOD" not in env)     # the quotient form (k > 21) needs the mod-minimizer
+        assert ix.info()["compact"] == (k <= 21 or ("MFX_MZ_MOD" not in env and "MFX_MZ_W" not in env))     # the quotient form (k > 21) needs the mod-minimizer on four windows
         ev = m.Evaluator(ix, m.KParams(peak))
         assert_hist_equal(ev.hist(seqs), g, ka, km_, k)
         ek, er, ea = ix.export()
