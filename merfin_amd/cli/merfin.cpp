@@ -804,6 +804,7 @@ int main(int argc, char **argv) {
       if (!seq) return false;
     }
     lap("upload sequences");
+    if (stage) mfx_db_stage_boost(stage);                         // the host's threads are free: the database's readers may have them all
     return true;
   };
   // The variant modes never evaluate the assembly itself on the device -- the paths around the variants go up batch by batch

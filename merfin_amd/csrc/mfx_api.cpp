@@ -959,6 +959,11 @@ struct mfx_db_stage {
   uint64_t off0 = 0, payload_bytes = 0;
   uint8_t *d_payload = nullptr;
   uint64_t *d_dir = nullptr;
+  uint64_t *d_esc_k = nullptr;                                // the escape list (k-mers whose count did not fit their block's field), staged like the blocks
+  uint32_t *d_esc_v = nullptr;
+  hipEvent_t esc_copied = nullptr;
+  std::atomic<int> esc_ready{0};                              // the escape copies are enqueued and esc_copied is recorded
+  std::atomic<int> boost{0};                                  // 0: a few reader threads (the FASTA reader has the host); 1: all of them (mfx_db_stage_boost)
   struct Chunk { uint64_t b0, b1; hipEvent_t copied = nullptr; };
   std::vector<Chunk> chunks;
   std::atomic<int64_t> enqueued{0};                           // chunks whose copy is enqueued and whose event is recorded
@@ -991,12 +996,22 @@ static void stage_worker(mfx_db_stage *S) {
   if (e == hipSuccess) e = hipMemcpyAsync(S->d_dir, S->dir.data(), S->dir.size() * 8, hipMemcpyHostToDevice, cs);
   if (e != hipSuccess) fail("staging set-up failed", e);
   {
-    std::unique_ptr<WorkerPool> pool(new WorkerPool(pread_threads(), true));
+    // While the FASTA file is being read and encoded the host's threads are busy with that (a full pool here slowed the sequence
+    // down by more than the database gained: profiles/r05_e2e_staged.txt); until the caller says the sequence is in
+    // (mfx_db_stage_boost) a few readers keep the link fed, then all of them.
+    unsigned few = 4;
+    if (const char *fe = getenv("MFX_DB_STAGE_THREADS")) few = (unsigned)std::max(1, atoi(fe));
+    std::unique_ptr<WorkerPool> pool_few(new WorkerPool(std::min(few, pread_threads()), true)), pool_all;
+    auto pool_now = [&]() -> WorkerPool * {
+      if (!S->boost.load(std::memory_order_relaxed)) return pool_few.get();
+      if (!pool_all) pool_all.reset(new WorkerPool(pread_threads(), true));
+      return pool_all.get();
+    };
     for (size_t c = 0; c < S->chunks.size() && !S->failed.load(); ++c) {
       const int li = (int)(c % NL);
       if (busy[li] && (e = hipEventSynchronize(left[li])) != hipSuccess) { fail("staging copy failed", e); break; }
       const uint64_t o = S->file_off(S->chunks[c].b0), bytes = S->file_off(S->chunks[c].b1) - o;
-      if (!par_pread(S->fd, lane[li], bytes, o, pool.get())) { fail("reading the database failed", hipSuccess); break; }
+      if (!par_pread(S->fd, lane[li], bytes, o, pool_now())) { fail("reading the database failed", hipSuccess); break; }
       if (c == 0) S->t_first_copy = stage_now();
       e = hipMemcpyAsync(S->d_payload + (o - S->off0), lane[li], bytes, hipMemcpyHostToDevice, cs);
       if (e == hipSuccess) e = hipEventRecord(left[li], cs);
@@ -1004,6 +1019,33 @@ static void stage_worker(mfx_db_stage *S) {
       if (e != hipSuccess) { fail("staging copy failed", e); break; }
       busy[li] = true;
       S->enqueued.store((int64_t)c + 1, std::memory_order_release);
+    }
+    // the escape list behind the blocks: k-mers (8 bytes each), then their counts (4 bytes each)
+    const uint64_t ne = S->info.n_escape;
+    for (int part = 0; part < 2 && ne && !S->failed.load(); ++part) {
+      const uint64_t width = part == 0 ? 8 : 4, total = ne * width, at = S->info.escapes_off + (part == 0 ? 0 : ne * 8);
+      uint8_t *dst = part == 0 ? reinterpret_cast<uint8_t *>(S->d_esc_k) : reinterpret_cast<uint8_t *>(S->d_esc_v);
+      for (uint64_t o = 0, c = S->chunks.size(); o < total && !S->failed.load(); o += LANE, ++c) {
+        const int li = (int)(c % NL);
+        const uint64_t bytes = std::min<uint64_t>(LANE, total - o);
+        if (busy[li] && (e = hipEventSynchronize(left[li])) != hipSuccess) { fail("staging copy failed", e); break; }
+        if (!par_pread(S->fd, lane[li], bytes, at + o, pool_now())) { fail("reading the database failed", hipSuccess); break; }
+        if (part == 0) {                                      // a k-mer of k bases has no bit at or above 2k (a damaged file)
+          const uint64_t *kk = reinterpret_cast<const uint64_t *>(lane[li]);
+          bool wide = false;
+          if (S->info.k < 32) for (uint64_t i = 0; i < bytes / 8; ++i) wide |= (kk[i] >> (2 * S->info.k)) != 0;
+          if (wide) { fail("an escaped k-mer is wider than 2k bits", hipSuccess); break; }
+        }
+        e = hipMemcpyAsync(dst + o, lane[li], bytes, hipMemcpyHostToDevice, cs);
+        if (e == hipSuccess) e = hipEventRecord(left[li], cs);
+        if (e != hipSuccess) { fail("staging copy failed", e); break; }
+        busy[li] = true;
+      }
+    }
+    if (!S->failed.load()) {
+      e = hipEventRecord(S->esc_copied, cs);
+      if (e != hipSuccess) fail("staging copy failed", e);
+      else S->esc_ready.store(1, std::memory_order_release);
     }
   }
   S->t_last_enqueued = stage_now();
@@ -1020,8 +1062,16 @@ extern "C" void mfx_db_stage_free(mfx_db_stage *S) {
   for (auto &c : S->chunks) if (c.copied) (void)hipEventDestroy(c.copied);
   if (S->d_payload) (void)hipFree(S->d_payload);
   if (S->d_dir) (void)hipFree(S->d_dir);
+  if (S->d_esc_k) (void)hipFree(S->d_esc_k);
+  if (S->d_esc_v) (void)hipFree(S->d_esc_v);
+  if (S->esc_copied) (void)hipEventDestroy(S->esc_copied);
   if (S->fd >= 0) close(S->fd);
   delete S;
+}
+
+// the sequence is read and uploaded: the stager may use every reader thread from here on
+extern "C" void mfx_db_stage_boost(mfx_db_stage *S) {
+  if (S) S->boost.store(1, std::memory_order_relaxed);
 }
 
 extern "C" mfx_db_stage *mfx_db_stage_begin(const char *path, int device) {
@@ -1040,11 +1090,13 @@ extern "C" mfx_db_stage *mfx_db_stage_begin(const char *path, int device) {
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); mfx_fail(MFX_E_HIP, "hipMemGetInfo failed"); return drop(S.release()); }
   // a fifth of the free HBM at most: the table is sized by what is left (a read database beyond that goes through the ring)
-  if ((double)(S->payload_bytes + S->dir.size() * 8) > 0.2 * (double)free_b) {
+  if ((double)(S->payload_bytes + S->dir.size() * 8 + S->info.n_escape * 12) > 0.2 * (double)free_b) {
     mfx_fail(MFX_E_NOMEM, "'%s': %.1f GB of blocks against %.1f GB of free device memory: not staged", path, S->payload_bytes / 1e9, free_b / 1e9);
     return drop(S.release());
   }
-  if (hipMalloc((void **)&S->d_payload, S->payload_bytes + 64) != hipSuccess || hipMalloc((void **)&S->d_dir, S->dir.size() * 8) != hipSuccess) {
+  if (hipMalloc((void **)&S->d_payload, S->payload_bytes + 64) != hipSuccess || hipMalloc((void **)&S->d_dir, S->dir.size() * 8) != hipSuccess ||
+      hipEventCreateWithFlags(&S->esc_copied, hipEventDisableTiming) != hipSuccess ||
+      (S->info.n_escape && (hipMalloc((void **)&S->d_esc_k, S->info.n_escape * 8) != hipSuccess || hipMalloc((void **)&S->d_esc_v, S->info.n_escape * 4) != hipSuccess))) {
     (void)hipGetLastError();
     mfx_fail(MFX_E_NOMEM, "'%s': no device memory for the staged database", path);
     return drop(S.release());
@@ -1110,16 +1162,24 @@ extern "C" int mfx_index_build_for_hist_staged(mfx_index *ix, const mfx_seq *seq
     const uint64_t nb = ch.b1 - ch.b0, m = std::min<uint64_t>(S->info.n - ch.b0 * MFX_DELTA_BLOCK, nb * MFX_DELTA_BLOCK);
     STAGED_HIP(mfx_k_table_add_delta(ix->view(), reinterpret_cast<const uint64_t *>(S->d_payload), S->d_dir + 2 * ch.b0, (uint32_t)nb, m, S->off0, 0, ix->d_meta, st));
   }
+  // the escapes, from the staged copy: an ordinary update of (k-mer, count) arrays that are already on the device
+  while (!S->esc_ready.load(std::memory_order_acquire)) {
+    if (S->failed.load()) { release(); return mfx_fail(MFX_E_IO, "'%s': %s", S->path.c_str(), S->error.c_str()); }
+    std::this_thread::yield();
+  }
+  if (S->info.n_escape) {
+    STAGED_HIP(hipStreamWaitEvent(is[0], S->esc_copied, 0));
+    STAGED_HIP(mfx_k_table_add(ix->view(), S->d_esc_k, S->d_esc_v, S->info.n_escape, 0, ix->d_meta, is[0]));
+  }
   const double t2 = stage_now();
   for (auto &st : is) STAGED_HIP(hipStreamSynchronize(st));
 #undef STAGED_HIP
   const double t3 = stage_now();
   release();
   if (S->failed.load()) return mfx_fail(MFX_E_IO, "'%s': %s", S->path.c_str(), S->error.c_str());
-  rc = mfx_flat_delta_escapes(ix, S->fd, S->path.c_str(), &S->info, 0, minV, maxV);
-  if (rc == MFX_OK) rc = index_check(ix);
+  rc = index_check(ix);
   if (timing)
-    fprintf(stderr, "-- staged build: %.3f s = count launched %.3f + %zu update launches %.3f (of which waiting for the stager %.3f) + drain %.3f + escapes / check %.3f; "
+    fprintf(stderr, "-- staged build: %.3f s = count launched %.3f + %zu update launches + escapes %.3f (of which waiting for the stager %.3f) + drain %.3f + check %.3f; "
             "stager: first copy %.3f s after its start, last copy enqueued after %.3f s (%.2f GB); the build began %.3f s after the stager\n",
             stage_now() - t0, t1 - t0, S->chunks.size(), t2 - t1, t_wait, t3 - t2, stage_now() - t3, S->t_first_copy - S->t_begin, S->t_last_enqueued - S->t_begin,
             S->payload_bytes / 1e9, t0 - S->t_begin);

@@ -807,16 +807,6 @@ int mfx_flat_delta_open(const char *path, int *fd_out, mfx_flat_delta_info *info
   return MFX_OK;
 }
 
-int mfx_flat_delta_escapes(mfx_index *ix, int fd, const char *path, const mfx_flat_delta_info *info, int side, uint64_t minV, uint64_t maxV) {
-  if (!info->n_escape) return MFX_OK;
-  FlatHeader h;
-  memset(&h, 0, sizeof(h));
-  h.k = (uint32_t)info->k;
-  h.n = info->n;
-  h.n_escape = info->n_escape;
-  return load_flat_escapes(&ix, 1, fd, path, h, info->escapes_off, side, minV, maxV);
-}
-
 // merylFileReader(path): opens the DB and reveals k (merfin-globals.C:118-119:
 // "Make readDB first so we know the k size").
 static int mfx_db_probe_impl(const char *path, mfx_db_info *out) {

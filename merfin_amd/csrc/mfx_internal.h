@@ -56,7 +56,6 @@ void mfx_index_ingest_release(struct mfx_index *ix);
 // a delta-coded flat database opened for the staged load (mfx_db.cpp; mfx_api.cpp: mfx_db_stage)
 struct mfx_flat_delta_info { int k = 0; uint64_t n = 0, n_escape = 0, nblocks = 0, escapes_off = 0, fsize = 0; };
 int  mfx_flat_delta_open(const char *path, int *fd_out, mfx_flat_delta_info *info, std::vector<uint64_t> &dir);
-int  mfx_flat_delta_escapes(struct mfx_index *ix, int fd, const char *path, const mfx_flat_delta_info *info, int side, uint64_t minV, uint64_t maxV);
 
 // host threads the library may use: min(hardware, cgroup CPU quota, 64), or MFX_HOST_THREADS
 unsigned mfx_host_threads();

@@ -1522,6 +1522,199 @@ __device__ __forceinline__ void mfx_lane_lookup8(const mfx_table_view &c, mfx_ma
   }
 }
 
+// ---------------------------------------------------------------------------
+// The same probe with its tail DEFERRED (the -hist kernel; MFX_V_DEFER).  mfx_lane_lookup8 ends every batch with the cooperative
+// pass over the few queries that were not in their first mini-bucket (~4 of a wave's 128 at load factor 0.18) -- two hand-offs, a
+// ballot prefix, the line loads, the answers, the collection: ~150 wave instructions that cost the same for 4 entries as for 64,
+// a quarter of what the wave issues per batch.  Here a batch only PARKS such a query in the wave's mailbox -- {key field << 22,
+// home line, tile position} -- and goes on; the mailbox is worked off when it holds MFX_DEFER_FLUSH entries or the tile ends
+// (mfx_lane_flush): one cooperative pass over up to 64 entries (8 lanes read an entry's line with one request, four steps in
+// flight), then LANE e CONSUMES ENTRY e -- second candidate line, side table, further lines as before -- and evaluates it (K*, bin,
+// counters) itself, all lanes busy.  Whose lane a k-mer's result lands in does not matter: the counters are integers summed over
+// the block, and koverCpy of a (tile, wave) is an integer sum as well (units of 2^-52, mfx_hist_kernel), so the result does not
+// depend on which queries happened to be displaced -- that is decided by the races of the table's build.
+// ---------------------------------------------------------------------------
+#ifndef MFX_V_DEFER
+#define MFX_V_DEFER 1
+#endif
+#ifndef MFX_V_DEFER_FLUSH
+#define MFX_V_DEFER_FLUSH 32          // entries in the wave's mailbox (of 64) from which on the next batch boundary flushes it
+#endif
+constexpr uint32_t MFX_DEFER_FLUSH = MFX_V_DEFER_FLUSH;
+constexpr uint32_t MFX_REC_FOUND = 0xffffffffu;                // rec.z of an answered entry (no line has this index)
+
+// phase A: the batch's loads and the one-load answers.  defer: bit j set = query j was parked (its rv / av come at the flush).
+template <int B, class KeyOf>
+__device__ __forceinline__ uint32_t mfx_lane_probe_defer(const mfx_table_view &c, mfx_mailbox &M, uint32_t &nq, const uint64_t (&fkey)[B], const bool (&ok)[B],
+                                                         uint32_t (&rv)[B], uint32_t (&av)[B], const uint32_t (&line)[B], const uint32_t (&b0)[B],
+                                                         const uint32_t (&pos)[B], KeyOf keyof, unsigned long long *dbg = nullptr) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wbase = tid & ~63u;
+  const uint4 *const slots0 = reinterpret_cast<const uint4 *>(c.slots);
+  uint32_t st[B];               // 0xff done; 1 parked; 0xfe a count field is saturated (the slot's low word in rv); 0xfc whole-line scans from the home line
+  uint4 v[B];
+#pragma unroll
+  for (int j = 0; j < B; ++j) v[j] = slots0[((uint64_t)line[j] << 3) | b0[j]];
+#pragma unroll
+  for (int j = 0; j < B; ++j) {
+    const uint4 s = v[j];
+    const uint64_t ks = fkey[j] << 22;
+    const uint32_t klo = (uint32_t)ks, khi = (uint32_t)(ks >> 32);
+    const bool ha = s.y == khi && ((s.x ^ klo) >> 22) == 0u, hb = s.w == khi && ((s.z ^ klo) >> 22) == 0u;
+    const bool found = ha || hb, room = s.y == 0xffffffffu || s.w == 0xffffffffu;
+    const uint32_t lo = ha ? s.x : s.z;
+    const uint32_t r_rv = (lo >> 11) & MFX_CSAT, r_av = lo & MFX_CSAT;
+    const bool sat = r_rv == MFX_CSAT || r_av == MFX_CSAT;
+    const uint32_t f_rv = (r_rv < c.minV || r_rv > c.maxV) ? 0u : r_rv;      // -min / -max (merfin.C:199-200)
+    rv[j] = found ? (sat ? lo : f_rv) : 0u;
+    av[j] = (found && !sat) ? r_av : 0u;
+    st[j] = !ok[j] ? 0xffu : (found ? (sat ? 0xfeu : 0xffu) : (room ? 0xffu : 1u));  // an empty slot before the key: absent (value 0, merfin-globals.C:84)
+  }
+  uint32_t defer = 0u;
+#pragma unroll
+  for (int j = 0; j < B; ++j) {
+    const bool p = st[j] == 1u;
+    const uint64_t m = __ballot(p);
+    if (m) {                                                    // wave-uniform
+      const uint32_t at = nq + (uint32_t)__popcll(m & ((1ULL << lane) - 1ULL));
+      if (p) {
+        if (at < 64u) {
+          const uint64_t ks = fkey[j] << 22;
+          M.rec[wbase + at] = make_uint4((uint32_t)ks, (uint32_t)(ks >> 32), line[j], pos[j] << 4);
+          defer |= 1u << j;
+        } else st[j] = 0xfcu;                                   // no room in the mailbox (more than 64 parked queries in this wave): scanned here and now
+      }
+      const uint32_t cnt = (uint32_t)__popcll(m);
+      if (dbg && lane == 0u) atomicAdd(&dbg[0], (unsigned long long)cnt);
+      nq = nq + cnt < 64u ? nq + cnt : 64u;
+    }
+  }
+  // the rare endings that cannot wait (the k-mer itself is at hand only here): a saturated count, a query the mailbox had no room for
+  while (true) {
+    int sj = -1;
+    uint64_t sfkey = 0;
+    uint32_t slo = 0, scode = 0, sline = 0;
+#pragma unroll
+    for (int j = 0; j < B; ++j)
+      if (sj < 0 && (st[j] == 0xfcu || st[j] == 0xfeu)) { sj = j; sfkey = fkey[j]; slo = rv[j]; scode = st[j]; sline = line[j]; }
+    if (!__any(sj >= 0)) break;
+    if (sj >= 0) {
+      uint2 x = make_uint2(0u, 0u);
+      bool have = scode == 0xfeu, beyond = false;
+      if (dbg) atomicAdd(&dbg[have ? 2 : 3], 1ull);
+      if (!have) {
+        const uint2 fd = mfx_c_find_lean(c, sfkey, sline, 0u, beyond);
+        have = fd.x != 0u;
+        slo = fd.y;
+      }
+      uint32_t r_rv = (slo >> 11) & MFX_CSAT, r_av = slo & MFX_CSAT;
+      const bool sat = have && (r_rv == MFX_CSAT || r_av == MFX_CSAT);
+      if (sat || beyond) {
+        const uint2 sx = mfx_side_lookup_lean(c, keyof(sj));
+        if (beyond) { r_rv = sx.x; r_av = sx.y; have = true; }
+        else { if (r_rv == MFX_CSAT) r_rv = sx.x; if (r_av == MFX_CSAT) r_av = sx.y; }
+      }
+      if (have) x = make_uint2((r_rv < c.minV || r_rv > c.maxV) ? 0u : r_rv, r_av);
+#pragma unroll
+      for (int j = 0; j < B; ++j)
+        if (sj == j) { rv[j] = x.x; av[j] = x.y; st[j] = 0xffu; }
+    }
+  }
+  return defer;
+}
+
+// phase B: the wave's parked queries (nq <= 64 of them) answered and handed to eval(readV, asmV), one entry per lane.
+// kmer_at(p): the canonical k-mer at tile position p (quotient form: the side table is keyed by the k-mer itself).
+template <class KmerAt, class Eval>
+__device__ __forceinline__ void mfx_lane_flush(const mfx_table_view &c, mfx_mailbox &M, uint32_t &nq, KmerAt kmer_at, Eval eval, unsigned long long *dbg = nullptr) {
+  const uint32_t tid = threadIdx.x, sub16 = (tid & 7u) << 4, lane = tid & 63u, wbase = tid & ~63u;
+  const uint32_t n = nq;
+  nq = 0u;
+  if (n == 0u) return;                                           // wave-uniform
+  mfx_wave_handoff();
+  constexpr uint32_t STEPS = 4;
+  auto tail_pass = [&](bool second) {
+    for (uint32_t q0 = 0; q0 < n; q0 += 8u * STEPS) {
+      uint4 sl[STEPS];
+      uint32_t fl[STEPS];
+      bool act[STEPS];
+#pragma unroll
+      for (uint32_t sp = 0; sp < STEPS; ++sp) {
+        const uint32_t e = q0 + 8u * sp + (lane >> 3);
+        sl[sp] = make_uint4(0u, 0u, 0u, 0u);
+        act[sp] = false;
+        fl[sp] = 0u;
+        if (e < n) {
+          const uint2 lw = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint32_t *>(&M.rec[wbase + e]) + 2);   // {line, position << 4 | flag}
+          fl[sp] = lw.y;
+          act[sp] = lw.x != MFX_REC_FOUND && (!second || (lw.y & 3u) == 2u);
+          if (act[sp]) sl[sp] = *reinterpret_cast<const uint4 *>(reinterpret_cast<uint64_t>(c.slots) + ((uint64_t)lw.x << 7) + sub16);
+        }
+      }
+      mfx_wave_handoff();                                        // every lane has its entries' lines before one answers into a record
+#pragma unroll
+      for (uint32_t sp = 0; sp < STEPS; ++sp) {
+        const uint32_t e = q0 + 8u * sp + (lane >> 3);
+        if (act[sp]) {
+          uint32_t *rec = reinterpret_cast<uint32_t *>(&M.rec[wbase + e]);
+          const uint2 kk = *reinterpret_cast<const uint2 *>(rec);                            // {key field << 22} (a finder of this group may have replaced word 0: same key bits)
+          if (sl[sp].y == 0xffffffffu || sl[sp].w == 0xffffffffu) rec[3] = (fl[sp] & ~3u) | 1u;  // an empty slot: the line has room
+          if (sl[sp].y == kk.y && ((sl[sp].x ^ kk.x) >> 22) == 0u) { rec[0] = sl[sp].x; rec[2] = MFX_REC_FOUND; }
+          else if (sl[sp].w == kk.y && ((sl[sp].z ^ kk.x) >> 22) == 0u) { rec[0] = sl[sp].z; rec[2] = MFX_REC_FOUND; }
+        }
+      }
+    }
+    mfx_wave_handoff();
+  };
+  tail_pass(false);
+  // lane e consumes entry e
+  const bool mine = lane < n;
+  uint4 r = make_uint4(0u, 0u, MFX_REC_FOUND, 0u);
+  if (mine) r = M.rec[wbase + lane];
+  const bool full = mine && r.z != MFX_REC_FOUND && (r.w & 3u) != 1u;          // its home line is full of other k-mers: the next candidate line
+  if (__any(full)) {
+    if (full) {
+      uint32_t *rec = reinterpret_cast<uint32_t *>(&M.rec[wbase + lane]);
+      mfx_probe pr;
+      pr.lineA = pr.lineB = r.z;
+      rec[2] = (uint32_t)mfx_probe_line(c, pr, 1u);              // (candidate lines 0 .. MFX_MZ_REGION-1 follow the minimizer's line)
+      rec[3] = (r.w & ~3u) | 2u;
+      if (c.quot) rec[1] = r.y | (1u << (MFX_Q_DSHIFT + 22 - 32));   // quotient form: the key field of candidate line 1 (d = 1 above F0)
+      if (dbg) atomicAdd(&dbg[1], 1ull);
+    }
+    mfx_wave_handoff();
+    tail_pass(true);
+    if (full) {
+      const uint4 r2 = M.rec[wbase + lane];
+      r.x = r2.x; r.w = r2.w;
+      if (r2.z == MFX_REC_FOUND) r.z = MFX_REC_FOUND;           // (else r.z stays the HOME line)
+    }
+  }
+  if (mine) {
+    bool have = r.z == MFX_REC_FOUND, beyond = false;
+    uint32_t lo = r.x;
+    uint64_t fk = (((uint64_t)r.y << 32) | r.x) >> 22;           // the key field (quotient form: F0, without the candidate line's mark)
+    if (c.quot) fk &= (1ull << MFX_Q_DSHIFT) - 1ull;
+    if (!have && (r.w & 3u) == 2u) {                             // neither in its home line nor in the next, both full: whole-line scans from candidate line 2
+      if (dbg) atomicAdd(&dbg[3], 1ull);
+      const uint2 fd = mfx_c_find_lean(c, fk, r.z, 2u, beyond);
+      have = fd.x != 0u;
+      lo = fd.y;
+    }
+    uint32_t r_rv = (lo >> 11) & MFX_CSAT, r_av = lo & MFX_CSAT;
+    const bool sat = have && (r_rv == MFX_CSAT || r_av == MFX_CSAT);
+    if (sat || beyond) {                                         // the side table is keyed by the k-mer itself
+      if (dbg && sat) atomicAdd(&dbg[2], 1ull);
+      const uint2 sx = mfx_side_lookup_lean(c, c.quot ? kmer_at(r.w >> 4) : fk);
+      if (beyond) { r_rv = sx.x; r_av = sx.y; have = true; }
+      else { if (r_rv == MFX_CSAT) r_rv = sx.x; if (r_av == MFX_CSAT) r_av = sx.y; }
+    }
+    uint32_t o_rv = 0u, o_av = 0u;
+    if (have) { o_rv = (r_rv < c.minV || r_rv > c.maxV) ? 0u : r_rv; o_av = r_av; }      // -min / -max (merfin.C:199-200)
+    eval(o_rv, o_av);
+  }
+  mfx_wave_handoff();                                            // the mailbox is free again
+}
+
 // the k-mer of query j from an array (the callers that hold their k-mers anyway): a select chain, never an indexed register array
 template <int B>
 struct mfx_key_from_array {
@@ -1762,13 +1955,39 @@ __global__ __launch_bounds__(MFX_BLOCK, (mfx_hist_tune<CANON, COMPACT, KF>::bloc
     }
     __syncthreads();
 
-    double kover = 0.0;                      // this lane's koverCpy terms of this tile
-    for (uint32_t b = 0; b < MFX_TILE / MFX_BLOCK; b += BT) {
-      if (b * MFX_BLOCK >= n) break;         // short last tile of a contig (block-uniform): nothing starts beyond n
+    // This lane's koverCpy terms of this tile, in units of 2^-52 (a term is (1 - readK/asmK) * prob in [0, 1]: at most 16 of them per lane
+    // and tile).  An INTEGER sum: the value of a (tile, wave) does not depend on the order its terms were added in, nor on which lane
+    // evaluated which k-mer (the deferred tail of the probe hands parked queries to other lanes of the wave, mfx_lane_flush).
+    uint64_t kfx = 0;
+    auto eval1 = [&](uint32_t rvv, uint32_t avv) {
+      double term = 0.0;                       // 0 + x == x exactly: this k-mer's own term
+      if (mfx_hist_eval(H, ka, lut_ok, rvv, avv, n_over0, term)) n_missing++;
+      if (term > 0.0) kfx += (uint64_t)(term * 4503599627370496.0);     // * 2^52, truncated
+    };
+    // mod-minimizer placement: the wave finds its home lines together (mfx_wave_mod_line)
+    const bool wave_lines = COMPACT && CANON && (KF ? TF != 0 : a.t.mz_t != 0);
+    // the specialised instances: the probe's tail is deferred (mfx_lane_flush).  Odd k only: a parked query's counts are not seen by the
+    // palindrome doubling below (an even k takes the undeferred probe)
+    const bool defer_tail = MFX_V_DEFER != 0 && COMPACT && CANON && KF != 0 && TF != 0 && (KF & 1) != 0;
+    const bool quotf = KF ? KF > MFX_MAX_K_DIRECT : a.t.quot != 0;
+    uint32_t nq = 0;                         // queries parked in this wave's mailbox (wave-uniform)
+    uint32_t *const mwave = reinterpret_cast<uint32_t *>(H.dred) + (tid >> 6) * 128u;        // the wave's 64 + npos words of mfx_wave_mod_line (H.dred is idle in this kernel)
+    for (uint32_t b = 0;; b += BT) {
+      const bool last = b >= MFX_TILE / MFX_BLOCK || b * MFX_BLOCK >= n;    // (short last tile of a contig, block-uniform: nothing starts beyond n)
+      nq = (uint32_t)__builtin_amdgcn_readfirstlane((int)nq);
+      if (defer_tail && (last || nq >= MFX_DEFER_FLUSH)) {
+        auto kmer_at = [&](uint32_t p) -> uint64_t {
+          uint64_t f;
+          (void)mfx_tile_kmer(L, k, p, f);
+          const uint64_t r = mfx_revcomp(f, k);
+          return f < r ? f : r;
+        };
+        mfx_lane_flush(a.t, MB, nq, kmer_at, eval1, DBG ? reinterpret_cast<unsigned long long *>(a.dbg) : nullptr);
+      }
+      if (last) break;
       uint32_t rv[BT], av[BT];
       bool     ok[BT];
-      // mod-minimizer placement: the wave finds its home lines together (mfx_wave_mod_line)
-      const bool wave_lines = COMPACT && CANON && (KF ? TF != 0 : a.t.mz_t != 0);
+      uint32_t parked = 0u;
       const bool even_k = KF ? (KF & 1) == 0 : (k & 1) == 0;
       if (wave_lines) {
         uint64_t fkey[BT];
@@ -1781,12 +2000,12 @@ __global__ __launch_bounds__(MFX_BLOCK, (mfx_hist_tune<CANON, COMPACT, KF>::bloc
           uint64_t f;
           ok[j] = mfx_tile_kmer(L, k, p, f) && (p < n);
           const uint64_t r = mfx_revcomp(f, k);
-          line[j] = mfx_wave_mod_line(a.t, reinterpret_cast<uint32_t *>(&MB.rec[tid & ~63u]), halo, j, f, r, b0[j], fkey[j]);
+          line[j] = mfx_wave_mod_line(a.t, mwave, halo, j, f, r, b0[j], fkey[j]);
           if (!ok[j]) { line[j] = 0u; b0[j] = 0u; }            // no k-mer here: a dummy load of line 0, ignored
           if (even_k && f == r) pal |= 1u << j;
         }
         // the k-mer of query sj, for the rare endings of the probe: the key field itself (k <= 21), or again from the tile
-        const bool quot = KF ? KF > MFX_MAX_K_DIRECT : a.t.quot != 0;
+        const bool quot = quotf;
         auto keyof = [&](int sj) -> uint64_t {
           uint64_t kk = 0;
           if (!quot) {
@@ -1800,7 +2019,14 @@ __global__ __launch_bounds__(MFX_BLOCK, (mfx_hist_tune<CANON, COMPACT, KF>::bloc
           }
           return kk;
         };
-        mfx_lane_lookup8<BT>(a.t, MB, fkey, ok, rv, av, line, b0, keyof, DBG ? reinterpret_cast<unsigned long long *>(a.dbg) : nullptr);
+        if (defer_tail) {
+          uint32_t posn[BT];
+#pragma unroll
+          for (int j = 0; j < BT; ++j) posn[j] = (b + (uint32_t)j) * MFX_BLOCK + tid;
+          parked = mfx_lane_probe_defer<BT>(a.t, MB, nq, fkey, ok, rv, av, line, b0, posn, keyof, DBG ? reinterpret_cast<unsigned long long *>(a.dbg) : nullptr);
+        } else {
+          mfx_lane_lookup8<BT>(a.t, MB, fkey, ok, rv, av, line, b0, keyof, DBG ? reinterpret_cast<unsigned long long *>(a.dbg) : nullptr);
+        }
         if (even_k) {
           // even k, canonical database: a k-mer that is its own reverse complement is looked up as fmer AND as rmer by the
           // reference -- the same slot twice (value(fmer) + value(rmer), uint32 arithmetic); every other k-mer has one strand
@@ -1841,13 +2067,13 @@ __global__ __launch_bounds__(MFX_BLOCK, (mfx_hist_tune<CANON, COMPACT, KF>::bloc
       for (int j = 0; j < BT; ++j) {
         if (!ok[j]) continue;
         n_valid++;                                                   // merfin-histogram.C:58
-        if (mfx_hist_eval(H, ka, lut_ok, rv[j], av[j], n_over0, kover)) n_missing++;
+        if (!((parked >> j) & 1u)) eval1(rv[j], av[j]);             // (a parked query is evaluated when the mailbox is flushed)
       }
     }
-    // koverCpy of this (tile, wave): fixed-order tree over the 64 lanes
+    // koverCpy of this (tile, wave): the integer sum over the 64 lanes (< 2^62), as a double
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) kover = kover + __shfl_down(kover, off, 64);
-    if ((tid & 63u) == 0) a.tile_partials[li * (MFX_BLOCK / 64) + (tid >> 6)] = kover;
+    for (int off = 32; off > 0; off >>= 1) kfx += __shfl_down(kfx, off, 64);
+    if ((tid & 63u) == 0) a.tile_partials[li * (MFX_BLOCK / 64) + (tid >> 6)] = (double)kfx * 2.220446049250313e-16;   // * 2^-52
 
     __syncthreads();                         // tile consumed; H.next[it & 1] written
     const uint64_t nx = H.next[it & 1];

@@ -34,43 +34,48 @@ def main():
         body = lines[i:j + 1]
         i = j + 1
         demangled = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip() or name
-        # the first depth-2 loop header inside the depth-1 tile loop
-        hdr = None
+        # Blocks and the loops they belong to, from the compiler's own annotations ("in Loop: Header=BBf_n Depth=d", "Parent Loop BBf_n
+        # Depth=d", "This Loop Header: Depth=d").  The per-batch loop is the depth-2 loop with the most instructions; a block is inside it
+        # if it is its header, names it as its header, or names it as a parent loop.
+        isn = lambda l: l.startswith("\t") and not l.lstrip().startswith((";", "."))
+        blocks, cur = [], None
         for n, l in enumerate(body):
-            if re.match(r"^\.LBB\d+_\d+:", l) and n + 1 < len(body) and "This Loop Header: Depth=2" in body[n + 1]:
-                hdr = (n, l.split(":")[0])
-                break
-        if hdr is None:
-            for n, l in enumerate(body):
-                if re.match(r"^\.LBB\d+_\d+:", l) and "Loop Header: Depth=2" in "".join(body[n:n + 3]):
-                    hdr = (n, l.split(":")[0])
-                    break
-        if hdr is None:
+            if re.match(r"^(\.LBB\d+_\d+:|; %bb\.\d+:)", l):
+                cur = {"label": l.split(":")[0].replace("; %", ""), "note": l, "lines": []}
+                blocks.append(cur)
+            elif cur is not None and l.lstrip().startswith(";") and not isn(l) and not cur["lines"]:
+                cur["note"] += l
+            elif cur is not None:
+                cur["lines"].append(l)
+        heads = [b_ for b_ in blocks if "Loop Header: Depth=2" in b_["note"]]
+        if not heads:
             print("%s: no depth-2 loop found" % demangled)
             continue
-        last = max(n for n, l in enumerate(body) if re.search(r"s_c?branch\S*\s+%s\b" % re.escape(hdr[1]), l))
+
+        def members(h):
+            name = h["label"].lstrip(".L")
+            return [b_ for b_ in blocks if b_ is h or re.search(r"(Header=|Parent Loop )%s\b" % re.escape(name), b_["note"])]
+        hd = max(heads, key=lambda h: sum(sum(map(isn, b_["lines"])) for b_ in members(h)))
+        mem = members(hd)
+        inside = [l for b_ in mem for l in b_["lines"]]
+        outside = [l for b_ in blocks if b_ not in mem for l in b_["lines"]] + body[:body.index(blocks[0]["note"].split("\n")[0]) if blocks else 0]
+        hdr, last = (0, hd["label"]), len(mem)
 
         def count(rng, pat):
             return sum(1 for l in rng if re.search(pat, l) and not l.lstrip().startswith(";"))
-        inside, outside = body[hdr[0]:last + 1], body[:hdr[0]] + body[last + 1:]
-        isn = lambda l: l.startswith("\t") and not l.lstrip().startswith((";", "."))
         print("%s" % demangled)
-        print("   instructions %5d   per-batch loop %s .. line %d: %5d" % (sum(map(isn, body)), hdr[1], last, sum(map(isn, inside))))
+        print("   instructions %5d   per-batch loop %s (%d blocks): %5d" % (sum(map(isn, body)), hdr[1], last, sum(map(isn, inside))))
         for what, pat in (("scratch_load / scratch_store", r"\bscratch_"), ("v_readlane / v_writelane (SGPR spills)", r"\bv_(read|write)lane"),
                           ("global_load", r"\bglobal_load"), ("global_atomic", r"\bglobal_atomic"), ("ds_ (LDS)", r"\bds_")):
             print("   %-40s inside the batch loop %4d   outside %4d" % (what, count(inside, pat), count(outside, pat)))
         # the straight-line blocks of the loop that hold its global loads of 16 bytes (the probe): lane spills there are on the hot path
-        blocks, cur = [], None
-        for l in inside:
-            if re.match(r"^\.LBB\d+_\d+:", l) or cur is None:
-                cur = {"label": l.split(":")[0], "n": 0, "lanes": 0, "x4": 0, "scratch": 0}
-                blocks.append(cur)
-            if isn(l):
-                cur["n"] += 1
-                cur["lanes"] += bool(re.search(r"\bv_(read|write)lane", l))
-                cur["x4"] += "global_load_dwordx4" in l
-                cur["scratch"] += "scratch_" in l
-        hot = [b for b in blocks if b["x4"] and b["n"] > 100]
+        hot = []
+        for b_ in mem:
+            ins = [l for l in b_["lines"] if isn(l)]
+            x4 = sum("global_load_dwordx4" in l for l in ins)
+            if x4 and len(ins) > 100:
+                hot.append({"label": b_["label"], "n": len(ins), "x4": x4, "lanes": sum(bool(re.search(r"\bv_(read|write)lane", l)) for l in ins),
+                            "scratch": sum("scratch_" in l for l in ins)})
         for b in hot:
             print("   block %-12s %4d instructions, %d x global_load_dwordx4 (the probe), lane spills %d, scratch %d" % (b["label"], b["n"], b["x4"], b["lanes"], b["scratch"]))
 
