@@ -310,10 +310,25 @@ extern "C" double mfx_index_estimate_gb(int k, uint64_t capacity_kmers) {
   return (double)lines_for(capacity_kmers, k > MFX_MAX_K_NARROW ? MFX_WSLOTS_LINE : MFX_SLOTS_LINE) * MFX_ALIGN / 1e9;
 }
 
+// bytes of the smallest 16-byte-slot / compact sequence-only table for this capacity
+static double seq_plain_bytes(uint64_t capacity_kmers) { return (double)lines_for(capacity_kmers, MFX_SLOTS_LINE) * MFX_ALIGN; }
+static double seq_compact_bytes(int k, uint64_t capacity_kmers) {
+  return (double)(std::max(lines_for(capacity_kmers, MFX_CSLOTS_LINE), quot_min_lines(k)) + side_lines_for(capacity_kmers)) * MFX_ALIGN;
+}
+// The quotient form needs a table of at least 2^(2(k-3)-31) lines (4 GB at k = 31) whatever the genome's size: a small genome under a
+// small -memory limit (or on a nearly full device) takes the 16-byte slots, sized by the genome, instead (budget_bytes 0: no limit known).
+static bool seq_compact_fits(int k, uint64_t capacity_kmers, double budget_bytes) {
+  if (!seq_compact(k)) return false;
+  if (k <= MFX_MAX_K_DIRECT || budget_bytes <= 0) return true;
+  const double cb = seq_compact_bytes(k, capacity_kmers);
+  return cb <= budget_bytes || cb <= seq_plain_bytes(capacity_kmers);
+}
+
 extern "C" double mfx_index_estimate_gb_for_seq(int k, uint64_t capacity_kmers) {
   if (k > MFX_MAX_K_NARROW) return mfx_index_estimate_gb(k, capacity_kmers);
-  if (!seq_compact(k)) return (double)lines_for(capacity_kmers, MFX_SLOTS_LINE) * MFX_ALIGN / 1e9;
-  return (double)(std::max(lines_for(capacity_kmers, MFX_CSLOTS_LINE), quot_min_lines(k)) + side_lines_for(capacity_kmers)) * MFX_ALIGN / 1e9;
+  if (!seq_compact(k)) return seq_plain_bytes(capacity_kmers) / 1e9;
+  // (the smaller of the two layouts a run may take: index_create falls back to the 16-byte slots when the quotient form's floor does not fit)
+  return std::min(seq_compact_bytes(k, capacity_kmers), k > MFX_MAX_K_DIRECT ? seq_plain_bytes(capacity_kmers) : 1e300) / 1e9;
 }
 
 static mfx_index *index_create(int k, uint64_t capacity_kmers, double max_gb, int device, bool seq_only);
@@ -347,18 +362,27 @@ static mfx_index *index_create(int k, uint64_t capacity_kmers, double max_gb, in
     mfx_fail(MFX_E_INVAL, "k=%d unsupported: k-mers hold 2k <= 128 bits, 1 <= k <= 64", k);
     return nullptr;
   }
-  const bool compact = seq_only && seq_compact(k);
-  const uint32_t slots_line = k > MFX_MAX_K_NARROW ? MFX_WSLOTS_LINE : compact ? MFX_CSLOTS_LINE : MFX_SLOTS_LINE;
   if (mfx_device_count() <= device || device < 0) {
     mfx_fail(MFX_E_NODEVICE, "HIP device %d not available (%d visible); merfin_amd has no CPU path", device, mfx_device_count());
     return nullptr;
   }
+  bool compact = seq_only && seq_compact(k);
+  if (compact && k > MFX_MAX_K_DIRECT) {                      // the quotient form's floor against -memory and the free device memory
+    double budget = max_gb > 0 ? max_gb * 1e9 : 0;
+    DevGuard bg(device);
+    size_t free_b = 0, total_b = 0;
+    if (bg.ok && hipMemGetInfo(&free_b, &total_b) == hipSuccess) { const double fb = MFX_LF_HBM_SHARE * (double)free_b; budget = budget > 0 ? std::min(budget, fb) : fb; }
+    else (void)hipGetLastError();
+    compact = seq_compact_fits(k, capacity_kmers, budget);
+  }
+  const uint32_t slots_line = k > MFX_MAX_K_NARROW ? MFX_WSLOTS_LINE : compact ? MFX_CSLOTS_LINE : MFX_SLOTS_LINE;
   if (lines_for(capacity_kmers, slots_line) >= 0xfffffff0ull) {
     mfx_fail(MFX_E_INVAL, "capacity of %lu k-mers needs more than 2^32 table lines (512 GB); shard the index instead",
              (unsigned long)capacity_kmers);
     return nullptr;
   }
-  double need = seq_only ? mfx_index_estimate_gb_for_seq(k, capacity_kmers) : mfx_index_estimate_gb(k, capacity_kmers);
+  double need = !seq_only ? mfx_index_estimate_gb(k, capacity_kmers) : k > MFX_MAX_K_NARROW ? mfx_index_estimate_gb(k, capacity_kmers)
+                : compact ? seq_compact_bytes(k, capacity_kmers) / 1e9 : seq_plain_bytes(capacity_kmers) / 1e9;
   if (max_gb > 0 && need > max_gb) {
     // merfin-globals.C:148-153
     mfx_fail(MFX_E_NOMEM, "Not enough memory to load databases.  Increase -memory. (need %.3f GB, limit %.3f GB)", need, max_gb);
@@ -882,8 +906,16 @@ static int index_count(mfx_index *ix, const mfx_seq *seq, int count, void *strea
   a.ntiles = seq->ntiles;
   a.meta = ix->d_meta;
   a.count = count;
-  if (ix->seq_only && count != 2)                              // what this table can answer for: the k-mers of THIS sequence
-    if (int drc = mfx_seq_digest32(seq, &ix->seq_digest)) return drc;
+  if (ix->seq_only && count != 2) {                            // what this table can answer for: the k-mers of THIS sequence
+    uint32_t d = 0;
+    if (int drc = mfx_seq_digest32(seq, &d)) return drc;
+    // one sequence per sequence-only index: a second claim from ANOTHER sequence would leave the index bound to the last one and the
+    // evaluation of the first refused ("holds the k-mers of another sequence") -- say so here, where the mistake is made
+    if (ix->seq_digest != 0 && ix->seq_digest != d)
+      return mfx_fail(MFX_E_INVAL, "%s: this sequence-only index already claimed the k-mers of another sequence (content digest %08x, this one %08x); "
+                      "one such index answers for ONE sequence object -- put the contigs into one mfx_seq", who, ix->seq_digest, d);
+    ix->seq_digest = d;
+  }
   if (count == 2) ix->frozen = true;                           // counts arrived: no more claims
   MFX_HIP(ix->wide() ? mfx_kw_count(a, (hipStream_t)stream) : mfx_k_count(a, (hipStream_t)stream));
   if (no_wait) return MFX_OK;
@@ -1306,7 +1338,6 @@ static int seq_alloc(mfx_seq *s, bool with_bases = true) {
 // What a sequence makes on first use -- its bytes per base, its packed planes, its content digest -- is made under this lock:
 // N slots that share a device share its mfx_seq (merfin -dump -devices 0,0,0,0: four threads ask one sequence for its bytes at
 // once; unguarded, one thread's fill of the fresh buffer wiped what another had just unpacked and that slot dumped empty contigs).
-static std::mutex &seq_lazy_mutex() { static std::mutex m; return m; }
 
 int mfx_seq_partial_error(const mfx_seq *s, const char *who) {
   return mfx_fail(MFX_E_INVAL, "%s: the sequence object holds only the tiles [%lu, %lu) of its %lu (the part one device evaluated in a streamed run over "
@@ -1315,7 +1346,7 @@ int mfx_seq_partial_error(const mfx_seq *s, const char *who) {
 
 int mfx_seq_ensure_ascii(const mfx_seq *cs) {
   if (cs && cs->partial) return mfx_seq_partial_error(cs, "unpacking the sequence");
-  std::lock_guard<std::mutex> lazy(seq_lazy_mutex());
+  std::lock_guard<std::mutex> lazy(cs->lazy_mu);
   if (!cs->bases_stale && cs->d_bases) return MFX_OK;
   mfx_seq *s = const_cast<mfx_seq *>(cs);
   DevGuard g(s->device);
@@ -1336,7 +1367,7 @@ static void seq_digest_finish(const mfx_seq *s, uint64_t h) {
 
 int mfx_seq_digest32(const mfx_seq *s, uint32_t *out) {
   if (s->partial) return mfx_seq_partial_error(s, "the sequence's content digest");
-  std::lock_guard<std::mutex> lazy(seq_lazy_mutex());
+  std::lock_guard<std::mutex> lazy(s->lazy_mu);
   if (s->digest == 0) {
     DevGuard g(s->device);
     uint64_t *d = nullptr, h = 0;
@@ -2710,7 +2741,7 @@ static int seq_alloc_planes(mfx_seq *s) {
 // the packed planes of a resident sequence (2-bit codes + one validity bit per base, the tile's own form), made on the device
 extern "C" int mfx_seq_pack(mfx_seq *s) {
   if (!s) return mfx_fail(MFX_E_INVAL, "mfx_seq_pack: null argument");
-  std::lock_guard<std::mutex> lazy(seq_lazy_mutex());
+  std::lock_guard<std::mutex> lazy(s->lazy_mu);
   if (s->planes_ok) return MFX_OK;
   DevGuard g(s->device);
   int rc = seq_alloc_planes(s);

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -190,6 +191,7 @@ struct mfx_seq {
   std::vector<uint64_t> off, len, tile_start;
   bool      partial = false;         // a streamed PART was the last thing put in: only the tiles [part_lo, part_hi) are there (mfx_hist_run_streamed_multi / _range)
   uint64_t  part_lo = 0, part_hi = 0;
+  mutable std::mutex lazy_mu;        // what a sequence makes on first use (bytes per base, planes, digest) is made under it; per object: slots of other sequences / devices do not queue here
   mutable uint32_t digest = 0;       // content digest (mfx_seq_digest32), computed on first use; 0: not computed / the content changed
 };
 

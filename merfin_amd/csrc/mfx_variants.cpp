@@ -165,12 +165,28 @@ template <class T> struct RawArray {
   RawArray() = default;
   RawArray(const RawArray &) = delete;
   RawArray &operator=(const RawArray &) = delete;
-  bool alloc(size_t n_) { p = n_ ? static_cast<T *>(malloc(n_ * sizeof(T))) : nullptr; n = p ? n_ : 0; return p || !n_; }
+  // Elements are placement-constructed by the threads that parse them (make(i)), and a worker that throws -- or a load that returns
+  // early -- leaves some unconstructed: one flag byte per element (calloc: untouched pages cost nothing) says which ones the
+  // destructor may destroy.
+  uint8_t *made = nullptr;
+  bool alloc(size_t n_) {
+    p = n_ ? static_cast<T *>(malloc(n_ * sizeof(T))) : nullptr;
+    made = (p && !std::is_trivially_destructible<T>::value) ? static_cast<uint8_t *>(calloc(n_, 1)) : nullptr;
+    if (p && !std::is_trivially_destructible<T>::value && !made) { free(p); p = nullptr; }
+    n = p ? n_ : 0;
+    return p || !n_;
+  }
+  T *make(size_t i) {                 // constructs element i (once, by one thread)
+    T *x = new (&p[i]) T();
+    if (made) made[i] = 1;
+    return x;
+  }
   T &operator[](size_t i) { return p[i]; }
   const T &operator[](size_t i) const { return p[i]; }
   size_t size() const { return n; }
   ~RawArray() {
-    if (!std::is_trivially_destructible<T>::value) for (size_t i = 0; i < n; ++i) p[i].~T();
+    if (made) for (size_t i = 0; i < n; ++i) if (made[i]) p[i].~T();
+    free(made);
     free(p);
   }
 };
@@ -368,8 +384,8 @@ int load_vcf(const char *path, VcfDB &db, double *t_sub = nullptr) {   // t_sub[
   const size_t CH = 4096;                                  // lines per task
   parallel_for((lines.size() + CH - 1) / CH, [&](size_t c) {
     for (size_t i = c * CH, e = std::min(lines.size(), (c + 1) * CH); i < e; ++i) {
-      Record *r = new (&db.rec_store[i]) Record();
-      Variant *v = new (&db.var_store[i]) Variant();
+      Record *r = db.rec_store.make(i);
+      Variant *v = db.var_store.make(i);
       parse_record(buf.data() + lines[i].first, lines[i].second, r);
       if (r->ok) make_variant(r, v);
     }
@@ -803,6 +819,18 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
   const uint32_t comb = opts->comb ? opts->comb : 15;
   FILE *log = log_path ? fopen(log_path, "w") : stderr;
   if (!log) return mfx_fail(MFX_E_IO, "cannot open '%s'", log_path);
+  // whatever way this function is left (an exception of the host pipeline included: variants_guarded turns it into an error code),
+  // the files are closed: the normal path closes them itself, checks the result and disarms the guard
+  struct Files {
+    FILE *log = nullptr, *out = nullptr;
+    mfx_file *dbgh = nullptr;
+    ~Files() {
+      if (out) fclose(out);
+      if (dbgh && dbgh->f) (void)mfx_close(*dbgh);
+      if (log && log != stderr) fclose(log);
+    }
+  } files;
+  files.log = log;
 
   // MFX_VAR_TIMING=1: per-phase wall time on stderr (diagnostics only)
   const bool timing = getenv("MFX_VAR_TIMING") && atoi(getenv("MFX_VAR_TIMING"));
@@ -813,13 +841,13 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
 
   // the records: read and parsed here, or handed in by mfx_vcf_load (then that work ran under the caller's index build)
   VcfDB own_db;
-  if (loaded && loaded->used) { if (log != stderr) fclose(log); return mfx_fail(MFX_E_INVAL, "mfx_variants_run_vcf: a loaded VCF serves one run (clustering rearranges it); load it again"); }
+  if (loaded && loaded->used) { return mfx_fail(MFX_E_INVAL, "mfx_variants_run_vcf: a loaded VCF serves one run (clustering rearranges it); load it again"); }
   VcfDB &db = loaded ? loaded->db : own_db;
   double t_load[4] = {0, 0, 0, 0};
   int rc = MFX_OK;
   if (loaded) { loaded->used = true; memcpy(t_load, loaded->t_load, sizeof(t_load)); }
   else rc = load_vcf(vcf_path, db, t_load);
-  if (rc) { if (log != stderr) fclose(log); return rc; }
+  if (rc) return rc;
   fprintf(log, "   Collected %zu header lines.\n   Loaded %zu records:\n      %-8lu unique contig%s\n      %-8u contig IDs\n   Excluded %lu invalid records\n\n",
           db.headers.size(), db.n_records, db.by_chr.size(), db.by_chr.size() == 1 ? "" : "s", (unsigned)db.contig_ids, (unsigned long)db.excluded);
   fprintf(log, "Merge variants within %u-mer bases, splitting combinations greater than %u.\n", K, comb);
@@ -827,13 +855,15 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
   lap(0);
 
   FILE *out = fopen(out_path, "w");
-  if (!out) { if (log != stderr) fclose(log); return mfx_fail(MFX_E_IO, "cannot open '%s' for writing", out_path); }
+  if (!out) return mfx_fail(MFX_E_IO, "cannot open '%s' for writing", out_path);
+  files.out = out;
   for (auto &h : db.headers) fprintf(out, "%s\n", h.c_str());              // merfin-variants.C:332-333
   mfx_file dbgh;
   FILE *dbg = nullptr;
   if (opts->debug_path) {
     dbgh = mfx_open_writer(opts->debug_path, false);                       // compressedFileWriter, merfin-variants.C:149
     dbg = dbgh.f;
+    files.dbgh = &dbgh;
   }
 
   mfx_kparams kp{ev->peak, ev->n_prob, ev->probK.data(), ev->probP.data()};
@@ -861,10 +891,14 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
     std::vector<PathArena> arenas;    // one per run of RUN consecutive jobs; their capacity is kept from batch to batch
     size_t nruns = 0;
     bool scored = false;              // varMer::score of this batch runs on the device (numM / totdk above)
-    std::shared_future<int> gpu;      // stage B of this batch (shared: the next batch's stage B waits for it too)
     std::string err;                  // the error text of stage B (errors are per thread: it is carried back to the caller's)
     bool live = false;
+    // stage B of this batch (shared: the next batch's stage B waits for it too).  Declared LAST: a batch that is destroyed while its
+    // stage B still runs (an exception unwinding this function) blocks in the future's destructor before anything the task writes
+    // (err, the value arrays) is gone -- and the guard below waits for both batches before either is destroyed.
+    std::shared_future<int> gpu;
   } batches[2];
+  struct StageBGuard { Batch (&b)[2]; ~StageBGuard() { for (Batch &x : b) if (x.gpu.valid()) x.gpu.wait(); } } stageBGuard{batches};
   int cur_b = 0;
   batches[0].jobs.reserve(65536);
   batches[1].jobs.reserve(65536);
@@ -989,8 +1023,9 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
       Batch *bp = &bt;
       const int need_dk = mode == MFX_VAR_POLISH ? 1 : 0;
       std::shared_future<int> prev = batches[&bt == &batches[0] ? 1 : 0].gpu;
-      bt.gpu = std::async(std::launch::async, [bp, prev, need_dk, nvals, &scores]() {
+      bt.gpu = std::async(std::launch::async, [bp, prev, need_dk, nvals, &scores]() mutable {
         if (prev.valid()) prev.wait();                                   // one stage B at a time on the evaluator
+        prev = std::shared_future<int>();                                // (let go of the earlier batch's state: no chain of all batches so far)
         mfx_path_table pt;
         pt.npaths = bp->p_off.size(); pt.nvals = nvals;
         pt.off = bp->p_off.data(); pt.len = bp->p_len.data(); pt.nv = bp->p_nv.data(); pt.voff = bp->p_voff.data(); pt.cfirst = bp->p_cfirst.data();
@@ -1007,8 +1042,9 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
       // values() calls never hold their device buffers (path text + two value arrays each) at once, and the sharded form
       // (mfx_dump_values_sharded: per-slot scratch, peer copies) is never entered twice
       std::shared_future<int> prev = batches[&bt == &batches[0] ? 1 : 0].gpu;
-      bt.gpu = std::async(std::launch::async, [bp, prev, &values]() {
+      bt.gpu = std::async(std::launch::async, [bp, prev, &values]() mutable {
         if (prev.valid()) prev.wait();
+        prev = std::shared_future<int>();
         const int r = values(bp->packed.data(), bp->packed.size(), bp->rv.data(), bp->av.data());
         if (r) bp->err = mfx_last_error();
         return r;
@@ -1193,8 +1229,11 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
   if (timing) fprintf(stderr, "[mfx_variants]   load: read %.3f  lines %.3f  parse %.3f  runs %.3f  (the rest: clustering) | stage C: before %.3f  logs %.3f  hand-over %.3f  clear %.3f\n",
                       t_load[0], t_load[1], t_load[2], t_load[3], t_phase[7], t_phase[8], t_phase[9], t_phase[10]);
   if (!writer.finish() && rc == MFX_OK) rc = mfx_fail(MFX_E_IO, "writing '%s' failed", out_path);
+  files.out = nullptr;
   if (fclose(out) != 0 && rc == MFX_OK) rc = mfx_fail(MFX_E_IO, "writing '%s' failed", out_path);
+  files.dbgh = nullptr;
   if (dbg && mfx_close(dbgh) && rc == MFX_OK) rc = mfx_fail(MFX_E_IO, "writing '%s' failed", opts->debug_path);
+  files.log = nullptr;
   if (log != stderr) fclose(log);
   if (n_clusters) *n_clusters = clusters;
   return rc;

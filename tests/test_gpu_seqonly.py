@@ -207,6 +207,13 @@ def test_seq_only_rules():
         ix.count_asm(seqs)
     with pytest.raises(m.MfxError, match="claimed before"):
         ix.claim_seq(seqs)
+    # one sequence-only index answers for ONE sequence object: a claim from a second, different one is refused where it is made
+    # (it would leave the index bound to the last sequence and the evaluation of the first refused); the same content again is fine
+    two = m.Index.for_seq(k, sum(len(c) for c in contigs) + 16)
+    two.claim_seq(m.Sequences(contigs[:2]))
+    two.claim_seq(m.Sequences(contigs[:2]))
+    with pytest.raises(m.MfxError, match="already claimed the k-mers of another sequence"):
+        two.claim_seq(m.Sequences(contigs[2:]))
     ev = m.Evaluator(ix, m.KParams(9.0))
     with pytest.raises(m.MfxError, match="sequence-only"):
         ev.completeness()
@@ -494,3 +501,23 @@ def test_build_for_hist_equals_count_then_load(k, form, env, tmp_path, monkeypat
         m.DbStage(path).close()
     else:
         assert not stage.ok and stage.why
+
+
+def test_small_genome_at_k31_under_a_memory_limit():
+    """the quotient form of the compact layout needs 2^(2(k-3)-31) table lines whatever the genome (4 GB at k = 31): a small genome
+    under a -memory limit below that takes the 16-byte slots sized by the genome instead of failing (advisor, round 4), same results"""
+    m = _mfx()
+    k, peak = 31, 11.0
+    contigs, read, asm = synth.world(k=k, peak=peak, seed=4242, sizes=(30000, 4097, 500))
+    nb = sum(len(c) for c in contigs)
+    assert m.load_library().mfx_index_estimate_gb_for_seq(k, nb + 16) < 0.1
+    p, g, ka, km = oracle_hist(k, peak, contigs, read, asm)
+    for max_gb, compact in ((1.0, False), (0.0, True)):
+        ix = m.Index.for_seq(k, nb + 16, max_gb=max_gb)
+        assert bool(ix.info()["compact"]) == compact
+        seqs = m.Sequences(contigs)
+        ix.count_asm(seqs)
+        ix.add_read(*read)
+        assert_hist_equal(m.Evaluator(ix, m.KParams(peak)).hist(seqs), g, ka, km, k)
+    with pytest.raises(m.MfxError, match="Not enough memory"):
+        m.Index.for_seq(k, nb + 16, max_gb=1e-5)
