@@ -66,13 +66,26 @@ if len(sys.argv) > 3 and sys.argv[3] == "cli":
     import subprocess
     exe = os.path.join(ROOT, "merfin_amd", "bin", "merfin")
     ek, er, ea = ix.export(sort=False)
-    m.db_write_flat(out + "/read.mfxk", k, ek[er > 0], er[er > 0])
-    m.db_write_flat(out + "/asm.mfxk", k, ek[ea > 0], ea[ea > 0])
+    del ev, ix
+    torch.cuda.empty_cache()
+    if os.environ.get("MFX_CFG4_UNSORTED"):
+        # (round 4's inputs: unsorted flat files of 8-byte packed records -- 2 x 24 GB at 3 Gb, a link-bound load of 1.2-1.4 s)
+        m.db_write_flat(out + "/read.mfxk", k, ek[er > 0], er[er > 0])
+        m.db_write_flat(out + "/asm.mfxk", k, ek[ea > 0], ea[ea > 0])
+    else:
+        # the databases as `merfin -convert` makes them of a meryl database: sorted, delta-coded blocks (2.4-3 bytes per k-mer), decoded by
+        # the kernel that inserts them -- the full table of the variant modes is fed from the same form as the -hist index
+        from tools import e2e_inputs
+        for name, vals in (("read", er), ("asm", ea)):
+            sk, sv = e2e_inputs.sorted_nonzero(torch, ek, vals, k)
+            m.db_write_flat(out + "/%s.mfxk" % name, k, sk, sv)
+            print("%s database: %d k-mers, %.2f GB (%.2f bytes per k-mer)" % (name, len(sk), os.path.getsize(out + "/%s.mfxk" % name) / 1e9,
+                                                                            os.path.getsize(out + "/%s.mfxk" % name) / max(len(sk), 1)), flush=True)
+            del sk, sv
     del ek, er, ea
     with open(out + "/asm.fasta", "wb") as f:
         for nm, a in zip(names, asm):
             f.write(b">" + nm.encode() + b"\n" + a + b"\n")
-    del ev, ix
     torch.cuda.empty_cache()
     for devs in ("0", "0,0,0,0,0,0,0,0"):
         time.sleep(float(os.environ.get("MFX_CFG4_SLEEP", "0")))

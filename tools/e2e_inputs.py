@@ -8,29 +8,11 @@ import time
 import numpy as np
 
 
-def write_inputs(m, st, torch, bases, outdir, ncontigs=24, k=21, lam=26.0, seed=None, log=lambda *a: None):
-    """returns {"fasta": path, "readdb": path, "read_kmers": n, "db_bytes": b, "fasta_bytes": b, "lens": [...], "write_s": s}"""
-    t0 = time.time()
-    os.makedirs(outdir, exist_ok=True)
-    # the world's own full table only has to leave room for its export: a crowded table is fine here
-    os.environ["MFX_LOAD_FACTOR"] = "0.85"
-    try:
-        kw = {} if seed is None else {"seed": seed}
-        ix, seqs, asm, info = st.build_world(m, bases, k=k, lam=lam, ncontigs=ncontigs, **kw)
-    finally:
-        os.environ.pop("MFX_LOAD_FACTOR", None)
-    ek, er, _ea = ix.export(sort=False)
-    del _ea
-    contigs = [a.cpu().numpy() for a in asm]
-    ix.close()
-    seqs.close()
-    del ix, seqs, asm
-    torch.cuda.empty_cache()
-    log("world built and exported: %.1fs" % (time.time() - t0))
-    # sorted, entries with a read count only -- on the GPU, in key ranges (torch.sort takes < 2^31 elements)
-    kd = torch.from_numpy(ek.view(np.int64)).cuda()
-    vd = torch.from_numpy(er.view(np.int32)).cuda()
-    del ek, er
+def sorted_nonzero(torch, ek, ev, k):
+    """the entries of an (unsorted) index export that have a count, sorted by k-mer as `meryl print` lists them (what mfx_db_write_flat
+    delta-codes) -- on the GPU, in key ranges (torch.sort takes < 2^31 elements); k <= 31"""
+    kd = torch.from_numpy(np.ascontiguousarray(ek).view(np.int64)).cuda()
+    vd = torch.from_numpy(np.ascontiguousarray(ev).view(np.int32)).cuda()
     nq = max(1, int(np.ceil(kd.numel() / 7e8)))
     shift = 2 * k
     ks, vs = [], []
@@ -50,8 +32,30 @@ def write_inputs(m, st, torch, bases, outdir, ncontigs=24, k=21, lam=26.0, seed=
         del kp, vp, kq, o, vq, sel
     del kd, vd
     torch.cuda.empty_cache()
-    rk, rv = np.concatenate(ks), np.concatenate(vs)
-    del ks, vs
+    return np.concatenate(ks), np.concatenate(vs)
+
+
+def write_inputs(m, st, torch, bases, outdir, ncontigs=24, k=21, lam=26.0, seed=None, log=lambda *a: None):
+    """returns {"fasta": path, "readdb": path, "read_kmers": n, "db_bytes": b, "fasta_bytes": b, "lens": [...], "write_s": s}"""
+    t0 = time.time()
+    os.makedirs(outdir, exist_ok=True)
+    # the world's own full table only has to leave room for its export: a crowded table is fine here
+    os.environ["MFX_LOAD_FACTOR"] = "0.85"
+    try:
+        kw = {} if seed is None else {"seed": seed}
+        ix, seqs, asm, info = st.build_world(m, bases, k=k, lam=lam, ncontigs=ncontigs, **kw)
+    finally:
+        os.environ.pop("MFX_LOAD_FACTOR", None)
+    ek, er, _ea = ix.export(sort=False)
+    del _ea
+    contigs = [a.cpu().numpy() for a in asm]
+    ix.close()
+    seqs.close()
+    del ix, seqs, asm
+    torch.cuda.empty_cache()
+    log("world built and exported: %.1fs" % (time.time() - t0))
+    rk, rv = sorted_nonzero(torch, ek, er, k)
+    del ek, er
     readdb = os.path.join(outdir, "read.mfxk")
     m.db_write_flat(readdb, k, rk, rv)
     n_read = len(rk)
