@@ -171,6 +171,7 @@ mfx_index *mfx_index_create_for_seq(int k, uint64_t capacity_kmers, double max_g
  * hipMalloc while the driver clears what the earlier one freed.  The `merfin` CLI asks for 0.4 (61 GB for a human assembly), a
  * resident evaluator for the default (0.18, 135 GB): profiles/r05_e2e_lf_ab.txt. */
 mfx_index *mfx_index_create_for_seq_lf(int k, uint64_t capacity_kmers, double max_gb, int device, double load_factor);
+mfx_index *mfx_index_create_lf(int k, uint64_t capacity_kmers, double max_gb, int device, double load_factor);     /* the full table, likewise (the CLI: 0.7) */
 double     mfx_index_estimate_gb_for_seq(int k, uint64_t capacity_kmers);
 int        mfx_index_claim_seq(mfx_index *ix, const mfx_seq *seq, void *stream);
 /* PART of an assembly per device (round 4; config 5's -hist / -dump without any exchange): a device that evaluates some

@@ -63,7 +63,7 @@ _lib = None
 SYMBOLS = [
     "mfx_last_error", "mfx_last_error_code", "mfx_version", "mfx_device_count", "mfx_device_warm",
     "mfx_index_create", "mfx_index_free", "mfx_index_estimate_gb", "mfx_index_add_read", "mfx_index_add_asm",
-    "mfx_index_count_asm", "mfx_index_build_for_hist", "mfx_index_count_claimed", "mfx_hist_run_parts", "mfx_index_create_for_seq", "mfx_index_create_for_seq_lf", "mfx_db_stage_begin", "mfx_index_build_for_hist_staged", "mfx_db_stage_free", "mfx_db_stage_boost", "mfx_index_estimate_gb_for_seq", "mfx_index_claim_seq", "mfx_index_value", "mfx_index_get_info", "mfx_index_export",
+    "mfx_index_count_asm", "mfx_index_build_for_hist", "mfx_index_count_claimed", "mfx_hist_run_parts", "mfx_index_create_for_seq", "mfx_index_create_for_seq_lf", "mfx_index_create_lf", "mfx_db_stage_begin", "mfx_index_build_for_hist_staged", "mfx_db_stage_free", "mfx_db_stage_boost", "mfx_index_estimate_gb_for_seq", "mfx_index_claim_seq", "mfx_index_value", "mfx_index_get_info", "mfx_index_export",
     "mfx_db_probe", "mfx_index_load_db", "mfx_index_load_db_multi", "mfx_db_write_flat", "mfx_db_convert", "mfx_index_save", "mfx_index_load",
     "mfx_index_set_fingerprint", "mfx_index_get_origin",
     "mfx_host_alloc", "mfx_host_free", "mfx_seq_create", "mfx_hist_run_streamed",
@@ -131,6 +131,8 @@ def load_library():
     L.mfx_hist_run_parts.argtypes = [C.POINTER(vp), C.POINTER(vp), C.POINTER(C.POINTER(C.c_uint32)), C.c_uint32, C.c_uint32, vp]
     L.mfx_index_create_for_seq.restype = vp
     L.mfx_index_create_for_seq.argtypes = [C.c_int, C.c_uint64, C.c_double, C.c_int]
+    L.mfx_index_create_lf.restype = vp
+    L.mfx_index_create_lf.argtypes = [C.c_int, C.c_uint64, C.c_double, C.c_int, C.c_double]
     L.mfx_index_create_for_seq_lf.restype = vp
     L.mfx_index_create_for_seq_lf.argtypes = [C.c_int, C.c_uint64, C.c_double, C.c_int, C.c_double]
     L.mfx_db_stage_begin.restype = vp
@@ -391,6 +393,8 @@ class Index:
             self.h = _need(L.mfx_index_create_for_seq_lf(k, int(capacity_kmers), float(max_gb), device, float(load_factor)))
         elif seq_only:
             self.h = _need(L.mfx_index_create_for_seq(k, int(capacity_kmers), float(max_gb), device))
+        elif load_factor:
+            self.h = _need(L.mfx_index_create_lf(k, int(capacity_kmers), float(max_gb), device, float(load_factor)))
         else:
             self.h = _need(L.mfx_index_create(k, int(capacity_kmers), float(max_gb), device))
 

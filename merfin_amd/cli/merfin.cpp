@@ -922,7 +922,9 @@ int main(int argc, char **argv) {
       const uint64_t capacity = rdb.n_kmers + (G.seqDBname ? adb.n_kmers : (seqDone ? totalBases : basesBound)) + 1024;
       fprintf(stderr, "--\n-- Memory needed: %.3f GB\n-- Memory limit:  %.3f GB%s\n--\n", mfx_index_estimate_gb(k, capacity),
               G.maxMemory, G.maxMemory > 0 ? "" : " (none)");
-      ix = mfx_index_create(k, capacity, G.maxMemory, G.device);
+      // (the smallest table the library makes, load factor 0.7: the device stage of these report types is a hundredth of the run, and a
+      // table allocated behind another process waits for the driver to clear what that one freed -- the longer, the larger both are)
+      ix = mfx_index_create_lf(k, capacity, G.maxMemory, G.device, 0.7);
       if (!ix && !G.seqDBname && !seqDone && basesBound > 0) {
         // the capacity came from the file's BOUND on its bases (a .gz of a human assembly sits near the 4 GiB step of that
         // bound): read the file to the end, as the reference does before anything else, and size the table by the truth

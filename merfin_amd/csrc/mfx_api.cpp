@@ -357,6 +357,15 @@ extern "C" mfx_index *mfx_index_create_for_seq_lf(int k, uint64_t capacity_kmers
   return ix;
 }
 
+// (the full table likewise: the variant modes and -completeness of the CLI ask for the smallest table, 0.7 -- their device stage is a
+// hundredth of the run, the table's allocation behind another process is seconds)
+extern "C" mfx_index *mfx_index_create_lf(int k, uint64_t capacity_kmers, double max_gb, int device, double load_factor) {
+  t_lf_request = load_factor > 0 ? load_factor : 0;
+  mfx_index *ix = mfx_index_create(k, capacity_kmers, max_gb, device);
+  t_lf_request = 0;
+  return ix;
+}
+
 static mfx_index *index_create(int k, uint64_t capacity_kmers, double max_gb, int device, bool seq_only) {
   if (k < 1 || k > MFX_MAX_K) {
     mfx_fail(MFX_E_INVAL, "k=%d unsupported: k-mers hold 2k <= 128 bits, 1 <= k <= 64", k);
