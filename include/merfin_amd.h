@@ -204,7 +204,7 @@ mfx_db_stage *mfx_db_stage_begin(const char *read_db_path, int device);
 int           mfx_index_build_for_hist_staged(mfx_index *ix, const mfx_seq *seq, mfx_db_stage *stage, uint64_t minV, uint64_t maxV);
 void          mfx_db_stage_free(mfx_db_stage *stage);
 /* Until this call the stage reads the file with a few threads only (the host is busy reading and encoding the sequence; MFX_DB_STAGE_THREADS,
- * default 4); call it when the sequence is uploaded. */
+ * default 8); call it when the sequence is uploaded. */
 void          mfx_db_stage_boost(mfx_db_stage *stage);
 
 /* merylExactLookup::value(kmer), merfin-globals.C:107-108, batched: for each

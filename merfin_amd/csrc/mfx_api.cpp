@@ -1040,7 +1040,7 @@ static void stage_worker(mfx_db_stage *S) {
     // While the FASTA file is being read and encoded the host's threads are busy with that (a full pool here slowed the sequence
     // down by more than the database gained: profiles/r05_e2e_staged.txt); until the caller says the sequence is in
     // (mfx_db_stage_boost) a few readers keep the link fed, then all of them.
-    unsigned few = 4;
+    unsigned few = 8;                                          // (2 / 4 / 8: 3 Gb wall 1.23-1.25 / 1.20-1.23 / 1.18-1.19 s spaced, profiles/r05_e2e_staged.txt)
     if (const char *fe = getenv("MFX_DB_STAGE_THREADS")) few = (unsigned)std::max(1, atoi(fe));
     std::unique_ptr<WorkerPool> pool_few(new WorkerPool(std::min(few, pread_threads()), true)), pool_all;
     auto pool_now = [&]() -> WorkerPool * {
@@ -1585,6 +1585,24 @@ extern "C" mfx_eval *mfx_eval_create(const mfx_index *ix, const mfx_kparams *kp,
     mfx_eval_free(ev);
     return nullptr;
   }
+  // (1 - readK/asmK) * prob of every (read count < MFX_MAXP_LDS, asmV < MFX_KLUT) pair the kernel's exact tables cover, as the integer
+  // the tile-driven kernel adds up (mfx_kfix): the same fp64 routines the kernel's generic path runs (mfx_kstar.h, no contraction)
+  {
+    std::vector<uint64_t> uq((size_t)MFX_MAXP_LDS * MFX_KLUT, 0);
+    for (uint32_t rv = 0; rv < MFX_MAXP_LDS; ++rv) {
+      double rk, pr;
+      mfx_getK_core(ev->peak, ev->n_prob, ev->probK.data(), ev->probP.data(), rv, rk, pr);
+      if (!(rk >= 1.0 && rk < (double)MFX_KLUT && rk == (double)(uint32_t)rk)) continue;
+      for (uint32_t av = 1; av < MFX_KLUT; ++av)
+        if ((double)av > rk) uq[(size_t)rv * MFX_KLUT + av] = mfx_kfix(mfx_overcopy_term(rk, (double)av, pr));
+    }
+    if (hipMalloc((void **)&ev->d_underq, uq.size() * sizeof(uint64_t)) != hipSuccess ||
+        hipMemcpy(ev->d_underq, uq.data(), uq.size() * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess) {
+      mfx_fail(MFX_E_HIP, "mfx_eval_create: device setup failed: %s", hipGetErrorString(hipGetLastError()));
+      mfx_eval_free(ev);
+      return nullptr;
+    }
+  }
   return ev;
 }
 
@@ -1593,6 +1611,7 @@ extern "C" void mfx_eval_free(mfx_eval *ev) {
   DevGuard g(ev->device);
   if (ev->d_probK) (void)hipFree(ev->d_probK);
   if (ev->d_probP) (void)hipFree(ev->d_probP);
+  if (ev->d_underq) (void)hipFree(ev->d_underq);
   if (ev->d_partials) (void)hipFree(ev->d_partials);
   if (ev->d_tile_ctr) (void)hipFree(ev->d_tile_ctr);
   if (ev->d_tile_partials) (void)hipFree(ev->d_tile_partials);
@@ -1756,6 +1775,7 @@ static int hist_launch(mfx_eval *ev, const mfx_seq *seq, uint64_t tile_begin, ui
   a.ks.n_prob = ev->n_prob;
   a.ks.probK = ev->d_probK;
   a.ks.probP = ev->d_probP;
+  a.ks.underq = ev->d_underq;
   a.ks.nbins = ev->nbins;
   a.ks.ncontigs = seq->ncontigs;
   a.ks.counts = d_counts;

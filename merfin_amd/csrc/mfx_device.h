@@ -198,6 +198,45 @@ __device__ __forceinline__ bool mfx_hist_eval(mfx_hist_lds &H, const mfx_kstar_a
   return false;
 }
 
+// The same for the tile-driven kernel, whose koverCpy is an integer sum (mfx_kfix): the over-copy term of the (read count, asmV) pairs
+// the exact tables cover comes from ka.underq -- filled once per evaluator by the SAME fp64 routines (mfx_eval_create) -- instead of a
+// probability load, an fp64 division and a conversion in a branch that some lane of most waves takes (1-2 % of the k-mers have
+// asmK > readK: 60 % of the waves' evaluations had to walk through it).
+template <class Counter>
+__device__ __forceinline__ bool mfx_hist_eval_fx(mfx_hist_lds &H, const mfx_kstar_args &ka, bool lut_ok, uint32_t readV,
+                                                 uint32_t asmV, Counter &n_over0, uint64_t &kfx) {
+  double readK, prob;
+  uint32_t rki = 0xffffffffu;                                  // readK as an integer when the tables apply
+  if (lut_ok && readV < MFX_MAXP_LDS) {
+    rki = H.rk[readV]; prob = 1.0; readK = (double)rki;
+  } else {
+    mfx_getK_core(ka.peak, ka.n_prob, ka.probK, ka.probP, readV, readK, prob);
+  }
+  const double asmK = (double)asmV;
+  if (readK == 0) return true;                                 // :66-69
+  const bool under = asmK > readK;                             // :71
+  uint32_t idx;
+  if (rki < MFX_KLUT && asmV < MFX_KLUT && asmV >= 1) {        // exact tables (same fp64 code, evaluated once)
+    const uint32_t hi = under ? asmV : rki, lo = under ? rki : asmV;
+    idx = H.bin[hi * MFX_KLUT + lo];
+    if (under) kfx += ka.underq[readV * MFX_KLUT + asmV];      // :81  (1 - readK/asmK) * prob
+  } else {
+    idx = under ? mfx_bin_index(asmK, readK) : mfx_bin_index(readK, asmK);
+    if (under && rki != 0xffffffffu && readV > 0 && readV <= ka.n_prob) prob = ka.probP[readV - 1];   // (readK came from the LDS table: prob was not looked up yet)
+    if (under) kfx += mfx_kfix(mfx_overcopy_term(readK, asmK, prob));  // :81
+  }
+  if (!under && idx == 0) { n_over0++; return false; }         // the dominant bin stays in a register
+  uint64_t *c_undr = ka.counts, *c_over = ka.counts + ka.nbins;
+  if (idx < MFX_NB_LDS) atomicAdd(&H.hist[(under ? 0 : MFX_NB_LDS) + idx], 1u);
+  else if (idx < ka.nbins) atomicAdd((unsigned long long *)&(under ? c_undr : c_over)[idx], 1ull);
+  else {
+    unsigned long long w = atomicAdd((unsigned long long *)&ka.ovf[0], 1ull);
+    if (w < MFX_OVF_CAP) ka.ovf[1 + w] = (under ? 0ull : (1ull << 63)) | idx;
+    atomicAdd((unsigned long long *)&ka.counts[2ull * ka.nbins + 2], 1ull);
+  }
+  return false;
+}
+
 // LDS bins -> global (non-zero only)
 __device__ __forceinline__ void mfx_hist_lds_flush_bins(mfx_hist_lds &H, const mfx_kstar_args &ka) {
   const uint32_t tid = threadIdx.x;

@@ -228,6 +228,7 @@ struct mfx_eval {
   std::vector<double>   probP;
   uint32_t *d_probK = nullptr;
   double   *d_probP = nullptr;
+  uint64_t *d_underq = nullptr;      // [MFX_MAXP_LDS * MFX_KLUT] the over-copy terms of the tabulated (read count, asmV) pairs as integers (mfx_kfix; mfx_hist_eval_fx)
   uint32_t  nbins = 65536;
   int       grid = 0;
   uint64_t  canon_version = ~0ull;   // index version the cached `canon` flag belongs to

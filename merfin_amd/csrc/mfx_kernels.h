@@ -13,6 +13,7 @@ struct mfx_kstar_args {
   uint64_t       *counts;             // layout: include/merfin_amd.h MFX_HIST_WORDS
   double         *partials;           // [gridDim.x]
   uint64_t       *ovf;                // [0] count, [1..MFX_OVF_CAP] records
+  const uint64_t *underq = nullptr;   // [MFX_MAXP_LDS * MFX_KLUT] mfx_kfix of the over-copy term of (read count, asmV) where the exact tables apply, else 0 (mfx_eval_create)
 };
 
 struct mfx_hist_args {

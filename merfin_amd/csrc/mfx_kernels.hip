@@ -1775,6 +1775,9 @@ __device__ __forceinline__ bool mfx_tile_kmer(const mfx_tile_lds &L, int k, uint
 // ever looks at t-mers inside itself).  p0: the tile position of the lane's first batch element.  Every lane of the wave
 // takes part (the calls are wave-uniform).
 // ---------------------------------------------------------------------------
+#ifndef MFX_V_MIN2LEVEL
+#define MFX_V_MIN2LEVEL 1             // the sliding-window minimum of mfx_wave_mod_line in two levels (A/B: tools/ab_build.sh -DMFX_V_MIN2LEVEL=0)
+#endif
 typedef unsigned short mfx_us2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t mfx_pk_min_u16(uint32_t a, uint32_t b) {
   return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(mfx_us2, a), __builtin_bit_cast(mfx_us2, b)));
@@ -1822,9 +1825,30 @@ __device__ __forceinline__ uint32_t mfx_wave_mod_line(const mfx_table_view &c, u
   if (lane <= H) mw[64u + lane] = lane < H ? hv : 0xffffffffu;
   mfx_wave_handoff();
   uint32_t v = 0xffffffffu;
+#if MFX_V_MIN2LEVEL
+  // The minimum over npos consecutive words in two levels: A[p] = min of the g1 words from p on -- every lane takes A[lane], the
+  // first npos - g1 + 1 lanes also A[64 + lane] (the positions behind the wave) --, written back over the words, then the minimum
+  // of g2 = ceil(npos / g1) values A[lane + j g1] (the last one moved back to end at the window's end: overlapping blocks do not
+  // change a minimum).  k = 21: 12 reads and 9 packed minima instead of 16 and 15; k = 31 (28 t-mers): 17 and 14 instead of 28 and 27.
+  {
+    const int g1 = npos >= 26 ? 6 : npos >= 10 ? 4 : npos >= 5 ? 3 : 2, g2 = (npos + g1 - 1) / g1;
+    uint32_t a0 = 0xffffffffu, a1 = 0xffffffffu;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      if (i < g1) { a0 = mfx_pk_min_u16(a0, mw[lane + (uint32_t)i]); a1 = mfx_pk_min_u16(a1, mw[(lane <= (uint32_t)(npos - g1) ? 64u + lane : lane) + (uint32_t)i]); }
+    mfx_wave_handoff();                                        // every lane has read its words
+    mw[lane] = a0;
+    if (lane <= (uint32_t)(npos - g1)) mw[64u + lane] = a1;
+    mfx_wave_handoff();
+#pragma unroll
+    for (int j = 0; j < 7; ++j)
+      if (j < g2) v = mfx_pk_min_u16(v, mw[lane + (uint32_t)(j * g1 < npos - g1 ? j * g1 : npos - g1)]);
+  }
+#else
 #pragma unroll
   for (int i = 0; i < 28; ++i)
     if (i < npos) v = mfx_pk_min_u16(v, mw[lane + (uint32_t)i]);
+#endif
   const bool fwd = f <= r;
   const uint32_t q = fwd ? (v & 127u) : 127u - ((v >> 16) & 127u);
   const uint32_t xf = q - lane, jf = xf % (uint32_t)w;        // the t-mer's offset and the window, counted on the forward strand
@@ -1960,9 +1984,7 @@ __global__ __launch_bounds__(MFX_BLOCK, (mfx_hist_tune<CANON, COMPACT, KF>::bloc
     // evaluated which k-mer (the deferred tail of the probe hands parked queries to other lanes of the wave, mfx_lane_flush).
     uint64_t kfx = 0;
     auto eval1 = [&](uint32_t rvv, uint32_t avv) {
-      double term = 0.0;                       // 0 + x == x exactly: this k-mer's own term
-      if (mfx_hist_eval(H, ka, lut_ok, rvv, avv, n_over0, term)) n_missing++;
-      if (term > 0.0) kfx += (uint64_t)(term * 4503599627370496.0);     // * 2^52, truncated
+      if (mfx_hist_eval_fx(H, ka, lut_ok, rvv, avv, n_over0, kfx)) n_missing++;
     };
     // mod-minimizer placement: the wave finds its home lines together (mfx_wave_mod_line)
     const bool wave_lines = COMPACT && CANON && (KF ? TF != 0 : a.t.mz_t != 0);

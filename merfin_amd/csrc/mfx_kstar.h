@@ -82,3 +82,14 @@ MFX_HD double mfx_overcopy_term(double readK, double asmK, double prob) {
   double d = 1.0 - q;
   return d * prob;
 }
+
+// koverCpy as an INTEGER sum (the tile-driven -hist kernel): a term (1 - readK/asmK) * prob lies in [0, 1) -- readK >= 1, asmK <= 2^32
+// -- and is counted in units of 2^-52, rounded to nearest: term + 1.0 lies in [1, 2], where a double's last bit is 2^-52, so the
+// mantissa of the sum IS the rounded multiple (a term that rounds up to 1.0 gives 2.0, i.e. 2^52 units, by the same subtraction).
+// Order-free, therefore: which lane of a wave evaluated a k-mer, and when, does not change the sum.
+MFX_HD uint64_t mfx_kfix(double term) {
+  const double y = term + 1.0;
+  uint64_t b;
+  __builtin_memcpy(&b, &y, sizeof(b));
+  return b - 0x3FF0000000000000ull;
+}
