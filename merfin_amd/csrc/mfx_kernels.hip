@@ -1912,10 +1912,20 @@ constexpr int MFX_BATCH = MFX_V_BATCH;          // queries per lane and cooperat
 #ifndef MFX_V_BATCH_GEN
 #define MFX_V_BATCH_GEN 4
 #endif
-template <bool CANON, bool COMPACT, int KF> struct mfx_hist_tune { static constexpr int blocks = MFX_V_MINBLOCKS, batch = MFX_V_BATCH; };
-template <> struct mfx_hist_tune<true, true, 21> { static constexpr int blocks = MFX_V_MINBLOCKS_K21, batch = MFX_V_BATCH_K21; };
-template <> struct mfx_hist_tune<true, true, 31> { static constexpr int blocks = MFX_V_MINBLOCKS_K31, batch = MFX_V_BATCH_K31; };
-template <> struct mfx_hist_tune<true, true, 0> { static constexpr int blocks = MFX_V_MINBLOCKS_GEN, batch = MFX_V_BATCH_GEN; };
+// defer: the probe's tail deferred (mfx_lane_probe_defer / mfx_lane_flush).  It saves instructions (k = 21: 209 -> 200 wave-VALU per
+// k-mer, k = 31: 238 -> 234) and costs table lines (a parked query's home line is fetched again when the mailbox is worked off: 0.321 ->
+// 0.335 lines per k-mer) -- a gain for the instance the ALUs bound (k = 31, quotient form: 135.7 -> 139.0 G k-mers/s), a loss for the one on
+// the HBM's random-line rate (k = 21: 150.4 -> 143.4 G; profiles/r05_kernel_ab.txt).
+#ifndef MFX_V_DEFER_K21
+#define MFX_V_DEFER_K21 0
+#endif
+#ifndef MFX_V_DEFER_K31
+#define MFX_V_DEFER_K31 1
+#endif
+template <bool CANON, bool COMPACT, int KF> struct mfx_hist_tune { static constexpr int blocks = MFX_V_MINBLOCKS, batch = MFX_V_BATCH, defer = 0; };
+template <> struct mfx_hist_tune<true, true, 21> { static constexpr int blocks = MFX_V_MINBLOCKS_K21, batch = MFX_V_BATCH_K21, defer = MFX_V_DEFER_K21; };
+template <> struct mfx_hist_tune<true, true, 31> { static constexpr int blocks = MFX_V_MINBLOCKS_K31, batch = MFX_V_BATCH_K31, defer = MFX_V_DEFER_K31; };
+template <> struct mfx_hist_tune<true, true, 0> { static constexpr int blocks = MFX_V_MINBLOCKS_GEN, batch = MFX_V_BATCH_GEN, defer = 0; };
 template <bool CANON, bool COMPACT, int KF, int WF, int TF, bool DBG = false>
 __global__ __launch_bounds__(MFX_BLOCK, (mfx_hist_tune<CANON, COMPACT, KF>::blocks)) void mfx_hist_kernel(mfx_hist_args a) {
   constexpr int BT = mfx_hist_tune<CANON, COMPACT, KF>::batch;                  // queries per lane and probe sequence of this instance
@@ -1990,7 +2000,7 @@ __global__ __launch_bounds__(MFX_BLOCK, (mfx_hist_tune<CANON, COMPACT, KF>::bloc
     const bool wave_lines = COMPACT && CANON && (KF ? TF != 0 : a.t.mz_t != 0);
     // the specialised instances: the probe's tail is deferred (mfx_lane_flush).  Odd k only: a parked query's counts are not seen by the
     // palindrome doubling below (an even k takes the undeferred probe)
-    const bool defer_tail = MFX_V_DEFER != 0 && COMPACT && CANON && KF != 0 && TF != 0 && (KF & 1) != 0;
+    const bool defer_tail = MFX_V_DEFER != 0 && mfx_hist_tune<CANON, COMPACT, KF>::defer != 0 && COMPACT && CANON && KF != 0 && TF != 0 && (KF & 1) != 0;
     const bool quotf = KF ? KF > MFX_MAX_K_DIRECT : a.t.quot != 0;
     uint32_t nq = 0;                         // queries parked in this wave's mailbox (wave-uniform)
     uint32_t *const mwave = reinterpret_cast<uint32_t *>(H.dred) + (tid >> 6) * 128u;        // the wave's 64 + npos words of mfx_wave_mod_line (H.dred is idle in this kernel)
