@@ -37,7 +37,7 @@ class _Info(C.Structure):
 
 
 class _DbInfo(C.Structure):
-    _fields_ = [("k", C.c_int), ("format", C.c_int), ("n_kmers", C.c_uint64)]
+    _fields_ = [("k", C.c_int), ("format", C.c_int), ("n_kmers", C.c_uint64), ("placed", C.c_int)]
 
 
 class _VarOpts(C.Structure):
@@ -64,7 +64,7 @@ SYMBOLS = [
     "mfx_last_error", "mfx_last_error_code", "mfx_version", "mfx_device_count", "mfx_device_warm",
     "mfx_index_create", "mfx_index_free", "mfx_index_estimate_gb", "mfx_index_add_read", "mfx_index_add_asm",
     "mfx_index_count_asm", "mfx_index_build_for_hist", "mfx_index_count_claimed", "mfx_hist_run_parts", "mfx_index_create_for_seq", "mfx_index_create_for_seq_lf", "mfx_index_create_lf", "mfx_db_stage_begin", "mfx_index_build_for_hist_staged", "mfx_db_stage_free", "mfx_db_stage_boost", "mfx_index_estimate_gb_for_seq", "mfx_index_claim_seq", "mfx_index_value", "mfx_index_get_info", "mfx_index_export",
-    "mfx_db_probe", "mfx_index_load_db", "mfx_index_load_db_multi", "mfx_db_write_flat", "mfx_db_convert", "mfx_index_save", "mfx_index_load",
+    "mfx_db_probe", "mfx_index_load_db", "mfx_index_load_db_multi", "mfx_db_write_flat", "mfx_db_convert", "mfx_db_convert_placed", "mfx_db_write_flat_placed", "mfx_db_place_keys", "mfx_index_save", "mfx_index_load",
     "mfx_index_set_fingerprint", "mfx_index_get_origin",
     "mfx_host_alloc", "mfx_host_free", "mfx_seq_create", "mfx_hist_run_streamed",
     "mfx_hist_run_streamed_multi", "mfx_hist_run_streamed_range", "mfx_hist_stream_share",
@@ -152,6 +152,9 @@ def load_library():
     L.mfx_index_load_db.argtypes = [vp, C.c_char_p, C.c_int, C.c_uint64, C.c_uint64]
     L.mfx_db_write_flat.argtypes = [C.c_char_p, C.c_int, u64p, u32p, C.c_uint64]
     L.mfx_db_convert.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_uint64)]
+    L.mfx_db_convert_placed.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_uint64)]
+    L.mfx_db_write_flat_placed.argtypes = [C.c_char_p, C.c_int, u64p, u32p, C.c_uint64]
+    L.mfx_db_place_keys.argtypes = [C.c_int, vp, C.c_uint64, vp, C.c_int, C.c_int]
     L.mfx_index_load_db_multi.argtypes = [C.POINTER(vp), C.c_uint32, C.c_char_p, C.c_int, C.c_uint64, C.c_uint64]
     L.mfx_index_save.argtypes = [vp, C.c_char_p]
     L.mfx_index_load.restype = vp
@@ -323,7 +326,7 @@ def db_probe(path):
     """merylFileReader(path): (k, format, n_kmers) of a k-mer database on disk"""
     i = _DbInfo()
     _check(load_library().mfx_db_probe(path.encode(), C.byref(i)))
-    return {"k": i.k, "format": {1: "meryl", 2: "text", 3: "flat"}.get(i.format), "n_kmers": i.n_kmers}
+    return {"k": i.k, "format": {1: "meryl", 2: "text", 3: "flat"}.get(i.format), "n_kmers": i.n_kmers, "placed": bool(i.placed)}
 
 
 def load_db_multi(indexes, path, side, minV=0, maxV=2**64 - 1):
@@ -338,6 +341,35 @@ def db_convert(in_path, out_path):
     n = C.c_uint64(0)
     _check(load_library().mfx_db_convert(in_path.encode(), out_path.encode(), C.byref(n)))
     return n.value
+
+
+def db_convert_placed(in_path, out_path):
+    """any accepted canonical database (13 <= k <= 30) -> the PLACED flat form: records sorted by their place in the compact table
+    (mfx_db_convert_placed, host only); returns the number of k-mers"""
+    n = C.c_uint64(0)
+    _check(load_library().mfx_db_convert_placed(in_path.encode(), out_path.encode(), C.byref(n)))
+    return n.value
+
+
+def db_place_keys(k, kmers, out=None, device=0):
+    """the placement numbers P (csrc/mfx_place.h) of k-mers: numpy uint64 arrays on the host, or torch int64 CUDA tensors on the device"""
+    if isinstance(kmers, np.ndarray):
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
+        out = np.empty_like(kmers) if out is None else out
+        _check(load_library().mfx_db_place_keys(k, C.c_void_p(kmers.ctypes.data), len(kmers), C.c_void_p(out.ctypes.data), 0, device))
+        return out
+    import torch
+    out = torch.empty_like(kmers) if out is None else out
+    _check(load_library().mfx_db_place_keys(k, C.c_void_p(kmers.data_ptr()), kmers.numel(), C.c_void_p(out.data_ptr()), 1, device))
+    return out
+
+
+def db_write_flat_placed(path, k, pkeys, values):
+    """ascending placement numbers (db_place_keys of the k-mers, sorted) and their counts -> a placed flat file"""
+    pkeys = np.ascontiguousarray(pkeys, dtype=np.uint64)
+    values = np.ascontiguousarray(values, dtype=np.uint32)
+    _check(load_library().mfx_db_write_flat_placed(path.encode(), k, pkeys.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                   values.ctypes.data_as(C.POINTER(C.c_uint32)), len(pkeys)))
 
 
 def db_write_flat(path, k, kmers, values):

@@ -30,6 +30,7 @@ enum { OP_NONE, OP_HIST, OP_COMPL, OP_DUMP, OP_FILTER, OP_POLISH, OP_BETTER, OP_
 struct Globals {
   const char *seqName = nullptr, *seqDBname = nullptr, *readDBname = nullptr, *pLookupTable = nullptr;
   const char *vcfName = nullptr, *outName = nullptr, *indexName = nullptr, *convertName = nullptr;
+  bool placed = false;                 // -convert -placed: the records sorted by their place in the -hist table (mfx_db_convert_placed)
   double peak = 0, maxMemory = 0;
   uint64_t minV = 0, maxV = ~0ull;
   int threads = 0, reportType = OP_NONE, device = 0;
@@ -55,6 +56,8 @@ static void usage(const char *exe) {
           "    -seqmers db       assembly k-mer database; default: counted from -sequence on the GPU\n"
           "    -convert db       no report: rewrite the k-mer database <db> (any accepted form) as -output <file> in the flat form\n"
           "                      (sorted k-mers in delta-coded blocks; loads at the speed of the PCIe link)\n"
+          "    -placed           with -convert: the records sorted by their PLACE in the table -hist / -dump build (13 <= k <= 30,\n"
+          "                      canonical databases): such a database is applied to the table line after line\n"
           "    -device d         HIP device (default 0)\n"
           "    -devices list     several GPUs of this node driven by this one process, e.g. 0-7 or 0,2,5 (-hist: the index is\n"
           "                      built once and copied to the others over xGMI, every GPU evaluates its share of the\n"
@@ -613,6 +616,7 @@ int main(int argc, char **argv) {
     else if (is("-index")) G.indexName = val();
     else if (is("-sharded")) G.sharded = true;
     else if (is("-convert")) G.convertName = val();
+    else if (is("-placed")) G.placed = true;
     else if (is("-nosplit")) G.nosplit = true;
     else if (is("-filter")) G.reportType = OP_FILTER;
     else if (is("-better")) G.reportType = OP_BETTER;
@@ -634,7 +638,10 @@ int main(int argc, char **argv) {
     if (!G.outName) { fprintf(stderr, "No output (-output) supplied.\n"); return 1; }
     fprintf(stderr, "-- Converting '%s' to '%s'.\n", G.convertName, G.outName);
     uint64_t n = 0;
-    if (mfx_db_convert(G.convertName, G.outName, &n)) { fprintf(stderr, "ERROR: -convert: %s\n", mfx_last_error()); return 1; }
+    if (G.placed ? mfx_db_convert_placed(G.convertName, G.outName, &n) : mfx_db_convert(G.convertName, G.outName, &n)) {
+      fprintf(stderr, "ERROR: -convert: %s\n", mfx_last_error());
+      return 1;
+    }
     struct stat st;
     fprintf(stderr, "-- Wrote %lu k-mers", (unsigned long)n);
     if (stat(G.outName, &st) == 0 && n) fprintf(stderr, " in %.2f GB (%.2f bytes per k-mer)", st.st_size / 1e9, (double)st.st_size / (double)n);

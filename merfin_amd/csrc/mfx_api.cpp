@@ -3,6 +3,7 @@
 // kernels in mfx_kernels.hip.  There is deliberately NO CPU fallback: without
 // a usable HIP device every entry point fails with MFX_E_NODEVICE / MFX_E_HIP.
 #include "mfx_internal.h"
+#include "mfx_place.h"
 #include "mfx_kernels.h"
 #include "mfx_pipe.h"
 
@@ -824,7 +825,7 @@ int mfx_index_add_from_file(mfx_index *const *ixs, uint32_t nix, int fd, const c
 // kbits << 48 | vbits << 56}, n k-mers in all.  Whole blocks go through the lanes as they lie in the file -- 2.5-3 bytes
 // per k-mer of a 30x read set -- and are decoded by the kernel that inserts them (mfx_table_add_delta_kernel).
 int mfx_index_add_delta_file(mfx_index *const *ixs, uint32_t nix, int fd, const char *path, const uint64_t *dir, uint64_t nblocks, uint64_t n,
-                             int side, uint64_t minV, uint64_t maxV) {
+                             int side, uint64_t minV, uint64_t maxV, int placed) {
   int rc = check_same_kind(ixs, nix, "mfx_index_add_delta_file");
   if (rc) return rc;
   if (fd < 0 || !dir || ixs[0]->key_words() != 1) return mfx_fail(MFX_E_INVAL, "mfx_index_add_delta_file: bad argument");
@@ -845,8 +846,9 @@ int mfx_index_add_delta_file(mfx_index *const *ixs, uint32_t nix, int fd, const 
     const uint64_t base = off(b0), m = std::min<uint64_t>(n - b0 * MFX_DELTA_BLOCK, nb * MFX_DELTA_BLOCK);
     d.kbytes = bytes;
     d.vbytes = (nb + 1) * 16;
-    d.launch = [nb, m, base, side](mfx_index *ix, uint64_t *dk, uint32_t *dv, hipStream_t st) {
-      return mfx_k_table_add_delta(ix->view(), dk, reinterpret_cast<const uint64_t *>(dv), (uint32_t)nb, m, base, side, ix->d_meta, st);
+    d.launch = [nb, m, base, side, placed](mfx_index *ix, uint64_t *dk, uint32_t *dv, hipStream_t st) {
+      return placed ? mfx_k_table_add_placed(ix->view(), dk, reinterpret_cast<const uint64_t *>(dv), (uint32_t)nb, m, base, side, ix->d_meta, st)
+                    : mfx_k_table_add_delta(ix->view(), dk, reinterpret_cast<const uint64_t *>(dv), (uint32_t)nb, m, base, side, ix->d_meta, st);
     };
     b0 = b1;
     return 1;
@@ -1201,7 +1203,8 @@ extern "C" int mfx_index_build_for_hist_staged(mfx_index *ix, const mfx_seq *seq
     hipStream_t st = is[c % MFX_INGEST_STREAMS];
     STAGED_HIP(hipStreamWaitEvent(st, ch.copied, 0));
     const uint64_t nb = ch.b1 - ch.b0, m = std::min<uint64_t>(S->info.n - ch.b0 * MFX_DELTA_BLOCK, nb * MFX_DELTA_BLOCK);
-    STAGED_HIP(mfx_k_table_add_delta(ix->view(), reinterpret_cast<const uint64_t *>(S->d_payload), S->d_dir + 2 * ch.b0, (uint32_t)nb, m, S->off0, 0, ix->d_meta, st));
+    STAGED_HIP(S->info.placed ? mfx_k_table_add_placed(ix->view(), reinterpret_cast<const uint64_t *>(S->d_payload), S->d_dir + 2 * ch.b0, (uint32_t)nb, m, S->off0, 0, ix->d_meta, st)
+                              : mfx_k_table_add_delta(ix->view(), reinterpret_cast<const uint64_t *>(S->d_payload), S->d_dir + 2 * ch.b0, (uint32_t)nb, m, S->off0, 0, ix->d_meta, st));
   }
   // the escapes, from the staged copy: an ordinary update of (k-mer, count) arrays that are already on the device
   while (!S->esc_ready.load(std::memory_order_acquire)) {
@@ -1225,6 +1228,18 @@ extern "C" int mfx_index_build_for_hist_staged(mfx_index *ix, const mfx_seq *seq
             stage_now() - t0, t1 - t0, S->chunks.size(), t2 - t1, t_wait, t3 - t2, stage_now() - t3, S->t_first_copy - S->t_begin, S->t_last_enqueued - S->t_begin,
             S->payload_bytes / 1e9, t0 - S->t_begin);
   return rc;
+}
+
+// P (mfx_place.h) of n k-mers -- canonicalised first --: on_device != 0: both arrays are device pointers on `device` (tools that sort a
+// database on the GPU); else host arrays, host threads
+extern "C" int mfx_db_place_keys(int k, const uint64_t *kmers, uint64_t n, uint64_t *out, int on_device, int device) {
+  if (n && (!kmers || !out)) return mfx_fail(MFX_E_INVAL, "mfx_db_place_keys: null argument");
+  if (k < MFX_PLACE_MIN_K || k > MFX_PLACE_MAX_K) return mfx_fail(MFX_E_INVAL, "mfx_db_place_keys: %d <= k <= %d (k = %d)", MFX_PLACE_MIN_K, MFX_PLACE_MAX_K, k);
+  if (!on_device) { mfx_place_keys_host(k, kmers, n, out); return MFX_OK; }
+  DevGuard g(device);
+  MFX_HIP(mfx_k_place_keys(k, kmers, n, out, nullptr));
+  MFX_HIP(hipStreamSynchronize(nullptr));
+  return MFX_OK;
 }
 
 extern "C" int mfx_index_claim_seq(mfx_index *ix, const mfx_seq *seq, void *stream) {

@@ -16,6 +16,7 @@
 //                 rather than guessing.
 #include "mfx_internal.h"
 #include "mfx_pipe.h"
+#include "mfx_place.h"
 
 #include <dirent.h>
 #include <stdio.h>
@@ -82,6 +83,14 @@ struct FlatHeader {
 //                  database is a third of its packed size.
 constexpr uint32_t FLAT_PACKED = 2u;
 constexpr uint32_t FLAT_DELTA = 4u;
+// Payload, placed: a delta-coded file whose records are not the k-mers but the numbers P of mfx_place.h -- one to one with the canonical
+//                  k-mers, ascending P = ascending LINE of the compact table, for a table of any size (13 <= k <= 30) -- in ascending
+//                  order: what `merfin -convert -placed` makes.  The table's update kernel then walks the table line after line instead
+//                  of reading a random line per record (mfx_table_add_placed_kernel).  Directory and blocks as in the delta form with P
+//                  in the k-mer's place (2k + 3 bits); the escape list holds k-mers.  Bits 8-15 of `flags`: MFX_PLACE_VERSION of the
+//                  functions that made P (another version is refused: convert again).
+constexpr uint32_t FLAT_PLACED = 8u;
+inline uint32_t flat_place_version(const FlatHeader &h) { return (h.flags >> 8) & 0xffu; }
 
 // The header's counts are bounded by the file's size BEFORE any arithmetic uses them (a damaged or crafted header must end in
 // MFX_E_FORMAT, never in a wrapped size check, a std::length_error through the C ABI or an out-of-bounds scatter): every
@@ -94,6 +103,11 @@ const char *flat_header_problem(const FlatHeader &h, uint64_t fsize) {
   const uint64_t body = fsize - sizeof(FlatHeader);
   if (h.n_escape > body / 12) return "escape count beyond the file's size";
   const uint64_t rest = body - h.n_escape * 12;
+  if (h.flags & FLAT_PLACED) {
+    if (!(h.flags & FLAT_DELTA)) return "a placed database is delta-coded";
+    if (h.k < (uint32_t)MFX_PLACE_MIN_K || h.k > (uint32_t)MFX_PLACE_MAX_K) return "placed records hold 13 <= k <= 30";
+    if (flat_place_version(h) != MFX_PLACE_VERSION) return "placed by another version of the placement functions (convert the database again)";
+  }
   if (h.flags & FLAT_DELTA) {
     if (h.k > (uint32_t)MFX_MAX_K_NARROW) return "delta-coded blocks hold k <= 31";
     if (h.n / 4 > rest) return "k-mer count beyond the file's size";
@@ -109,6 +123,9 @@ const char *flat_header_problem(const FlatHeader &h, uint64_t fsize) {
 }
 // a k-mer of k <= 31 bases has no bit at or above 2k
 inline bool flat_key_fits(uint64_t key, uint32_t k) { return k >= 32 || (key >> (2 * k)) == 0; }
+// bits of a record's key: the k-mer's 2k, or the 2k + 3 of a placed record
+inline uint32_t flat_rec_bits(const FlatHeader &h) { return (h.flags & FLAT_PLACED) ? (uint32_t)mfx_p_bits((int)h.k) : 2u * h.k; }
+inline bool flat_rec_fits(uint64_t key, const FlatHeader &h) { const uint32_t b = flat_rec_bits(h); return b >= 64 || (key >> b) == 0; }
 
 // ---- meryl stuffedBits reader (UNVALIDATED) -----------
 // A stuffedBits file image: u64 dataBlockLenMax (bits), u32 dataBlocksLen,
@@ -653,7 +670,8 @@ void par_blocks(uint64_t nblocks, F &&fn) {                   // fn(b) for every
 }
 
 // 0 = written; 1 = the k-mers are not strictly ascending (the caller writes another form); < 0: error
-int write_flat_delta(FILE *f, const char *path, FlatHeader h, const uint64_t *kmers, const uint32_t *values, uint64_t n) {
+// placed: `kmers` are the numbers P of mfx_place.h (ascending); the escape list then holds the k-mers they decode to
+int write_flat_delta(FILE *f, const char *path, FlatHeader h, const uint64_t *kmers, const uint32_t *values, uint64_t n, bool placed = false) {
   const uint64_t nblocks = (n + MFX_DELTA_BLOCK - 1) / MFX_DELTA_BLOCK;
   auto cnt_of = [&](uint64_t b) { return (uint32_t)std::min<uint64_t>(MFX_DELTA_BLOCK, n - b * MFX_DELTA_BLOCK); };
   const bool timing = getenv("MFX_DB_TIMING") != nullptr;
@@ -683,6 +701,7 @@ int write_flat_delta(FILE *f, const char *path, FlatHeader h, const uint64_t *km
   dir[2 * nblocks + 1] = at;
   if (at >> 48) return mfx_fail(MFX_E_INVAL, "mfx_db_write_flat: the database is too large for the delta form");
   h.flags |= FLAT_DELTA;
+  if (placed) h.flags |= FLAT_PLACED | (MFX_PLACE_VERSION << 8);
   bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && fwrite(&nblocks, 8, 1, f) == 1 && fwrite(dir.data(), 8, dir.size(), f) == dir.size();
   // the blocks, packed by all threads a piece (<= 256 MB) at a time
   std::vector<uint64_t> buf;
@@ -708,7 +727,12 @@ int write_flat_delta(FILE *f, const char *path, FlatHeader h, const uint64_t *km
   for (uint64_t b = 0; b < nblocks; ++b) {
     if (!plan[b].nesc) continue;
     const uint32_t esc = (1u << plan[b].vb) - 1u;
-    for (uint64_t i = b * MFX_DELTA_BLOCK, e = i + cnt_of(b); i < e; ++i) if (values[i] >= esc) { ek.push_back(kmers[i]); ev.push_back(values[i]); }
+    for (uint64_t i = b * MFX_DELTA_BLOCK, e = i + cnt_of(b); i < e; ++i)
+      if (values[i] >= esc) {
+        uint32_t top, hi, pm;
+        ek.push_back(placed ? mfx_p_decode((int)h.k, kmers[i], top, hi, pm) : kmers[i]);
+        ev.push_back(values[i]);
+      }
   }
   ok = ok && ek.size() == h.n_escape &&
        (ek.empty() || (fwrite(ek.data(), 8, ek.size(), f) == ek.size() && fwrite(ev.data(), 4, ev.size(), f) == ev.size()));
@@ -756,8 +780,8 @@ int read_delta_directory(int fd, const char *path, const FlatHeader &h, uint64_t
     if (b == nblocks) break;
     const uint32_t kb = (uint32_t)(dir[2 * b + 1] >> 48) & 0xffu, vb = (uint32_t)(dir[2 * b + 1] >> 56) & 0xffu;
     const uint64_t cnt = std::min<uint64_t>(MFX_DELTA_BLOCK, h.n - b * MFX_DELTA_BLOCK);
-    if (kb > 2u * h.k || vb < 2u || vb > (uint32_t)MFX_DELTA_MAX_VBITS) return bad("block field widths out of range");
-    if (!flat_key_fits(dir[2 * b], h.k)) return bad("a block's first k-mer is wider than 2k bits");
+    if (kb > flat_rec_bits(h) || vb < 2u || vb > (uint32_t)MFX_DELTA_MAX_VBITS) return bad("block field widths out of range");
+    if (!flat_rec_fits(dir[2 * b], h)) return bad("a block's first k-mer is wider than 2k bits");
     // (the k-mers inside a block exist only in the kernel that decodes them: it refuses what is wider than 2k bits, index meta[4])
     if (b + 1 < nblocks && dir[2 * (b + 1)] <= dir[2 * b]) return bad("block directory not ascending");
     expect = off + (((cnt - 1) * kb + 63) / 64 + (cnt * vb + 63) / 64) * 8;
@@ -775,7 +799,7 @@ int load_flat_delta(mfx_index *const *ixs, uint32_t nix, int fd, const char *pat
   uint64_t nblocks = 0, expect = 0;
   int rc = read_delta_directory(fd, path, h, fsize, dir, &nblocks, &expect);
   if (rc) return rc;
-  if (h.n) rc = mfx_index_add_delta_file(ixs, nix, fd, path, dir.data(), nblocks, h.n, side, minV, maxV);
+  if (h.n) rc = mfx_index_add_delta_file(ixs, nix, fd, path, dir.data(), nblocks, h.n, side, minV, maxV, (h.flags & FLAT_PLACED) ? 1 : 0);
   if (rc == MFX_OK && h.n_escape) rc = load_flat_escapes(ixs, nix, fd, path, h, expect, side, minV, maxV);
   return rc;
 }
@@ -798,6 +822,7 @@ int mfx_flat_delta_open(const char *path, int *fd_out, mfx_flat_delta_info *info
   uint64_t nblocks = 0, expect = 0;
   if (int rc = read_delta_directory(fd, path, h, (uint64_t)st.st_size, dir, &nblocks, &expect)) { close(fd); return rc; }
   info->k = (int)h.k;
+  info->placed = (h.flags & FLAT_PLACED) ? 1 : 0;
   info->n = h.n;
   info->n_escape = h.n_escape;
   info->nblocks = nblocks;
@@ -823,6 +848,7 @@ static int mfx_db_probe_impl(const char *path, mfx_db_info *out) {
     fclose(f);
     out->k = (int)h.k;
     out->n_kmers = h.n;
+    out->placed = (memcmp(h.magic, "MFXKMER1", 8) == 0 && (h.flags & FLAT_PLACED)) ? 1 : 0;
     return MFX_OK;
   }
   if (fmt == MFX_DB_TEXT) {
@@ -1076,7 +1102,7 @@ int read_flat_host(const std::string &path, int *k_out, std::vector<uint64_t> &k
       const uint64_t off = dir[2 * b + 1] & 0xffffffffffffull, nxt = dir[2 * b + 3] & 0xffffffffffffull;
       const uint32_t kb = (uint32_t)(dir[2 * b + 1] >> 48) & 0xffu, vb = (uint32_t)(dir[2 * b + 1] >> 56) & 0xffu;
       const uint64_t cnt = std::min<uint64_t>(MFX_DELTA_BLOCK, h.n - b * MFX_DELTA_BLOCK);
-      if (nxt < off || (nxt - off) != (((cnt - 1) * kb + 63) / 64 + (cnt * vb + 63) / 64) * 8 || vb < 2 || vb > (uint32_t)MFX_DELTA_MAX_VBITS || kb > 62)
+      if (nxt < off || (nxt - off) != (((cnt - 1) * kb + 63) / 64 + (cnt * vb + 63) / 64) * 8 || vb < 2 || vb > (uint32_t)MFX_DELTA_MAX_VBITS || kb > 63)
         return bad("inconsistent block directory");
       w.assign((nxt - off) / 8 + 1, 0);
       if (fseek(f, (long)off, SEEK_SET) != 0 || fread(w.data(), 8, (nxt - off) / 8, f) != (nxt - off) / 8) return bad("truncated block");
@@ -1088,6 +1114,12 @@ int read_flat_host(const std::string &path, int *k_out, std::vector<uint64_t> &k
         const uint32_t v = (uint32_t)flat_get_bits(vw, e * vb, vb);
         vals[b * MFX_DELTA_BLOCK + e] = v == (1u << vb) - 1u ? 0xffffffffu : v;
       }
+    }
+    if (h.flags & FLAT_PLACED) {                              // the records are placement numbers: back to k-mers (in the file's order)
+      for (uint64_t i = 0; i < h.n; ++i) if (!flat_rec_fits(keys[i], h)) return bad("a placed record is wider than 2k + 3 bits");
+      par_blocks((h.n + 65535) / 65536, [&](uint64_t b) {
+        for (uint64_t i = b * 65536, e = std::min<uint64_t>(h.n, i + 65536); i < e; ++i) { uint32_t top, hi, pm; keys[i] = mfx_p_decode((int)h.k, keys[i], top, hi, pm); }
+      });
     }
     if (fseek(f, (long)(dir[2 * nblocks + 1] & 0xffffffffffffull), SEEK_SET) != 0 || !escapes()) return bad("inconsistent escape list");
   } else if (h.flags & FLAT_PACKED) {
@@ -1112,10 +1144,11 @@ int read_flat_host(const std::string &path, int *k_out, std::vector<uint64_t> &k
 }
 
 // ascending order of (k, v) for one-word k-mers: buckets by the top bits, every bucket sorted on its own, all on the host threads
-void sort_pairs(int k, std::vector<uint64_t> &keys, std::vector<uint32_t> &vals) {
+void sort_pairs(int k, std::vector<uint64_t> &keys, std::vector<uint32_t> &vals, int bits = 0) {      // bits: width of the keys (0: the k-mer's 2k)
   const uint64_t n = vals.size();
-  const int shift = std::max(0, 2 * k - 12);
-  const size_t NB = (size_t)1 << std::min(12, 2 * k);
+  if (!bits) bits = 2 * k;
+  const int shift = std::max(0, bits - 12);
+  const size_t NB = (size_t)1 << std::min(12, bits);
   // histogram and scatter by slices of the input, one per host thread (a 6 G-k-mer database is two 50 GB passes)
   const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>({n / (1u << 20) + 1, 64, (uint64_t)mfx_host_threads()}));
   std::vector<std::vector<uint64_t>> cnt(T, std::vector<uint64_t>(NB, 0));
@@ -1244,6 +1277,75 @@ static int mfx_db_convert_impl(const char *in_path, const char *out_path, uint64
   rc = mfx_db_write_flat(out_path, k, keys.data(), vals.data(), vals.size());
   if (timing) fprintf(stderr, "[mfx db] convert: read %.2f s, order %.2f s, write %.2f s\n", t1 - t0, t2 - t1, now() - t2);
   return rc;
+}
+
+// the flat form of ascending placement numbers P (mfx_place.h) and their counts
+static int mfx_db_write_flat_placed_impl(const char *path, int k, const uint64_t *pkeys, const uint32_t *values, uint64_t n) {
+  if (!path || (n && (!pkeys || !values))) return mfx_fail(MFX_E_INVAL, "mfx_db_write_flat_placed: null argument");
+  if (k < MFX_PLACE_MIN_K || k > MFX_PLACE_MAX_K) return mfx_fail(MFX_E_INVAL, "a placed database holds %d <= k <= %d (k = %d)", MFX_PLACE_MIN_K, MFX_PLACE_MAX_K, k);
+  if (!n) return mfx_fail(MFX_E_INVAL, "mfx_db_write_flat_placed: no k-mers");
+  for (uint64_t i = 0; i < n; ++i)
+    if (pkeys[i] >> mfx_p_bits(k)) return mfx_fail(MFX_E_INVAL, "mfx_db_write_flat_placed: record %lu is wider than a placement number of this k", (unsigned long)i);
+  FILE *f = fopen(path, "wb");
+  if (!f) return mfx_fail(MFX_E_IO, "cannot open '%s' for writing", path);
+  FlatHeader h;
+  memcpy(h.magic, "MFXKMER1", 8);
+  h.k = (uint32_t)k;
+  h.flags = 0;
+  h.n = n;
+  h.n_escape = 0;
+  int rc = write_flat_delta(f, path, h, pkeys, values, n, true);
+  if (fclose(f) != 0 && rc == 0) rc = mfx_fail(MFX_E_IO, "short write to '%s'", path);
+  if (rc == 1) rc = mfx_fail(MFX_E_INVAL, "mfx_db_write_flat_placed: the records are not strictly ascending");
+  return rc;
+}
+extern "C" int mfx_db_write_flat_placed(const char *path, int k, const uint64_t *pkeys, const uint32_t *values, uint64_t n) {
+  try { return mfx_db_write_flat_placed_impl(path, k, pkeys, values, n); }
+  catch (const std::bad_alloc &) { return mfx_fail(MFX_E_NOMEM, "mfx_db_write_flat_placed: out of memory"); }
+  catch (const std::exception &e) { return mfx_fail(MFX_E_IO, "mfx_db_write_flat_placed: %s", e.what()); }
+}
+
+// P of n canonical k-mers, on the host (mfx_place.h; the device form: mfx_db_place_keys in mfx_api.cpp)
+void mfx_place_keys_host(int k, const uint64_t *kmers, uint64_t n, uint64_t *out) {
+  par_blocks((n + 65535) / 65536, [&](uint64_t b) {
+    for (uint64_t i = b * 65536, e = std::min<uint64_t>(n, i + 65536); i < e; ++i) {
+      const uint64_t key = kmers[i], rc = mfx_p_revcomp(key, k);
+      out[i] = mfx_p_encode(k, key < rc ? key : rc);
+    }
+  });
+}
+
+// any accepted database -> the PLACED flat form: the records sorted by where the compact table puts them
+static int mfx_db_convert_placed_impl(const char *in_path, const char *out_path, uint64_t *n_out) {
+  if (!in_path || !out_path) return mfx_fail(MFX_E_INVAL, "mfx_db_convert_placed: null argument");
+  // through the sorted flat form in memory: read (any form), then re-key
+  std::string tmp = std::string(out_path) + ".tmp-sorted";
+  uint64_t n = 0;
+  int rc = mfx_db_convert(in_path, tmp.c_str(), &n);
+  if (rc) { unlink(tmp.c_str()); return rc; }
+  int k = 0;
+  std::vector<uint64_t> keys;
+  std::vector<uint32_t> vals;
+  rc = read_flat_host(tmp, &k, keys, vals);
+  unlink(tmp.c_str());
+  if (rc) return rc;
+  if (k < MFX_PLACE_MIN_K || k > MFX_PLACE_MAX_K)
+    return mfx_fail(MFX_E_INVAL, "'%s' holds %d-mers: a placed database holds %d <= k <= %d (use -convert without -placed)", in_path, k, MFX_PLACE_MIN_K, MFX_PLACE_MAX_K);
+  std::atomic<int> noncanon{0};
+  par_blocks((vals.size() + 65535) / 65536, [&](uint64_t b) {
+    for (uint64_t i = b * 65536, e = std::min<uint64_t>(vals.size(), i + 65536); i < e; ++i)
+      if (keys[i] > mfx_p_revcomp(keys[i], k)) { noncanon = 1; return; }
+  });
+  if (noncanon) return mfx_fail(MFX_E_NONCANON, "'%s' is not canonical: a placed database holds canonical k-mers (the sequence-only index it feeds does)", in_path);
+  mfx_place_keys_host(k, keys.data(), vals.size(), keys.data());
+  sort_pairs(k, keys, vals, mfx_p_bits(k));
+  if (n_out) *n_out = vals.size();
+  return mfx_db_write_flat_placed(out_path, k, keys.data(), vals.data(), vals.size());
+}
+extern "C" int mfx_db_convert_placed(const char *in_path, const char *out_path, uint64_t *n_out) {
+  try { return mfx_db_convert_placed_impl(in_path, out_path, n_out); }
+  catch (const std::bad_alloc &) { return mfx_fail(MFX_E_NOMEM, "mfx_db_convert_placed: out of memory"); }
+  catch (const std::exception &e) { return mfx_fail(MFX_E_IO, "mfx_db_convert_placed: %s", e.what()); }
 }
 
 extern "C" int mfx_db_convert(const char *in_path, const char *out_path, uint64_t *n_out) {

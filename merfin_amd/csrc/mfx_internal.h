@@ -49,13 +49,14 @@ int  mfx_index_add_from_file(struct mfx_index *const *ixs, uint32_t nix, int fd,
                              uint64_t n, int side, uint64_t minV, uint64_t maxV);
 // the delta-coded blocks of a sorted flat database (mfx_db.cpp FLAT_DELTA); dir: (nblocks + 1) x 2 words
 int  mfx_index_add_delta_file(struct mfx_index *const *ixs, uint32_t nix, int fd, const char *path, const uint64_t *dir, uint64_t nblocks,
-                              uint64_t n, int side, uint64_t minV, uint64_t maxV);
+                              uint64_t n, int side, uint64_t minV, uint64_t maxV, int placed = 0);     // placed: the records are placement numbers (mfx_place.h)
 // host arrays into several tables at once (one staging, one H2D per table; sharded tables keep what they own)
 int  mfx_index_add_multi(struct mfx_index *const *ixs, uint32_t nix, const uint64_t *kmers, const uint32_t *values, uint64_t n, int side,
                          uint64_t minV, uint64_t maxV);
 void mfx_index_ingest_release(struct mfx_index *ix);
 // a delta-coded flat database opened for the staged load (mfx_db.cpp; mfx_api.cpp: mfx_db_stage)
-struct mfx_flat_delta_info { int k = 0; uint64_t n = 0, n_escape = 0, nblocks = 0, escapes_off = 0, fsize = 0; };
+struct mfx_flat_delta_info { int k = 0, placed = 0; uint64_t n = 0, n_escape = 0, nblocks = 0, escapes_off = 0, fsize = 0; };
+void mfx_place_keys_host(int k, const uint64_t *kmers, uint64_t n, uint64_t *out);      // mfx_db.cpp: P (mfx_place.h) of canonical k-mers, host threads
 int  mfx_flat_delta_open(const char *path, int *fd_out, mfx_flat_delta_info *info, std::vector<uint64_t> &dir);
 
 // host threads the library may use: min(hardware, cgroup CPU quota, 64), or MFX_HOST_THREADS
@@ -77,7 +78,7 @@ constexpr uint32_t MFX_MAXP_LDS   = MFX_V_MAXP_LDS;   // read counts whose (read
 constexpr uint32_t MFX_KLUT       = 32;         // (readK, asmK) pairs below this use tabulated bin index / over-copy term
 // placement functions of the table (mfx_kernels.hip: mfx_minimizer, mfx_mz_line, mfx_home); index images
 // written under another version are refused by mfx_index_load
-constexpr uint32_t MFX_LAYOUT_VERSION = 8u;
+constexpr uint32_t MFX_LAYOUT_VERSION = 9u;     // 9: the compact layout's line from the bijective mix of the minimizer, its first mini-bucket from the window (mfx_place.h)
 constexpr uint32_t MFX_SPLIT_MAX_RANKS = 16;  // owners the sort-free router handles (a node has 8 GPUs); more: radix sort
 constexpr int      MFX_MZ_W_DEFAULT = 3;        // minimizer windows of the default placement (MFX_MZ_W overrides)
 constexpr uint32_t MFX_OVF_CAP    = 1u << 20;   // histogram overflow records per evaluator

@@ -126,6 +126,11 @@ hipError_t mfx_k_table_add(mfx_table_view t, const uint64_t *kmers, const uint32
 // entry; payload_base = the file offset payload[0] holds; n = k-mers of the nblocks blocks
 hipError_t mfx_k_table_add_delta(mfx_table_view t, const uint64_t *payload, const uint64_t *dir, uint32_t nblocks, uint64_t n,
                                  uint64_t payload_base, int side, uint64_t *meta, hipStream_t st);
+// a PLACED database's blocks (records = the numbers P of mfx_place.h, ascending: the order of the table's lines)
+hipError_t mfx_k_table_add_placed(mfx_table_view t, const uint64_t *payload, const uint64_t *dir, uint32_t nblocks, uint64_t n,
+                                  uint64_t payload_base, int side, uint64_t *meta, hipStream_t st);
+int        mfx_k_table_takes_placed(const mfx_table_view &t);
+hipError_t mfx_k_place_keys(int k, const uint64_t *kmers, uint64_t n, uint64_t *out, hipStream_t st);
 hipError_t mfx_k_table_value(mfx_table_view t, const uint64_t *kmers, uint64_t n, uint32_t *readV, uint32_t *asmV,
                              hipStream_t st);
 hipError_t mfx_k_table_export(mfx_table_view t, uint64_t *kmers, uint32_t *readV, uint32_t *asmV,

@@ -14,6 +14,7 @@
 #include "mfx_internal.h"
 #include "mfx_kernels.h"
 #include "mfx_device.h"
+#include "mfx_place.h"
 
 #include <stdlib.h>
 #include <algorithm>
@@ -115,16 +116,17 @@ __device__ __forceinline__ uint64_t mfx_minimizer_mod(uint64_t key, uint64_t rc,
   return a < b ? a : b;
 }
 
-// Line and first mini-bucket of a mod-minimizer (an m-mer of at most 36 bits: the compact layout holds k <= 21) sampled by the
-// t-mer at offset x of the (canonical) k-mer.  Line: two 32-bit multiplications fold the halves, a third scales into the table -- a
-// third of the instructions of the 64-bit product below.  Mini-bucket: (x + three other bits of the hash) mod 8 -- the k-mers that
-// share a minimizer sit at consecutive positions and see its t-mer at DIFFERENT offsets, so they start at different mini-buckets of
-// their common line instead of colliding at random: 3.1 % of the k-mers of a random sequence end outside their first mini-bucket at load
-// factor 0.225 where a hash of the k-mer left 8.3 %.
-__device__ __forceinline__ void mfx_mod_place(uint64_t mz, uint32_t x, uint64_t nlines, uint32_t &line, uint32_t &b0) {
-  const uint32_t h = ((uint32_t)mz * 0x9E3779B1u) ^ (((uint32_t)(mz >> 32) + 0x7F4A7C15u) * 0x85EBCA77u);
-  line = __umulhi(h ^ (h >> 15), (uint32_t)nlines);
-  b0 = (x + h) & 7u;
+// Line and first mini-bucket of a mod-minimizer (an m-mer of at most 36 bits: the compact layout holds k <= 21 in this form) that stands
+// in window jw of the (canonical) k-mer.  Line: the high bits of a BIJECTION of the minimizer (mfx_place.h: mfx_p_mix -- the quotient
+// form's, so that a database sorted by it walks the table line after line: mfx_p_encode) scaled into the table.  Mini-bucket:
+// (2 jw + three other bits of the hash) mod 8 -- the k-mers that share a minimizer occurrence hold it in DIFFERENT windows, so they
+// start at different mini-buckets of their common line instead of colliding at random: 3 % of the k-mers of a random sequence end
+// outside their first mini-bucket at load factor 0.225 where a hash of the k-mer left 8.3 %.  (Layout version 9; before: a 32-bit
+// fold of the minimizer and the sampling t-mer's offset x, of which jw is the low bits.)
+__device__ __forceinline__ void mfx_mod_place(uint64_t mz, uint32_t jw, uint64_t nlines, uint32_t &line, uint32_t &b0) {
+  const uint32_t top = mfx_p_mix((uint32_t)mz, (uint32_t)(mz >> 32));
+  line = __umulhi(top, (uint32_t)nlines);
+  b0 = mfx_p_bucket(top, jw);
 }
 
 // ---------------------------------------------------------------------------
@@ -146,17 +148,8 @@ __device__ __forceinline__ void mfx_mod_place(uint64_t mz, uint32_t x, uint64_t 
 constexpr uint32_t MFX_Q_LINES = 3;            // candidate lines of the quotient form (d = 0 .. 2)
 constexpr int      MFX_Q_DSHIFT = 40;          // d sits above the 40 bits of F0
 
-__device__ __forceinline__ uint32_t mfx_q_mix(uint32_t lo, uint32_t hi) {
-  uint32_t u = lo * 0x9E3779B1u;
-  u ^= u >> 15; u *= 0x85EBCA77u; u ^= u >> 13;
-  return u ^ (hi * 0xC2B2AE3Du);
-}
-__device__ __forceinline__ uint32_t mfx_q_unmix(uint32_t top, uint32_t hi) {
-  uint32_t u = top ^ (hi * 0xC2B2AE3Du);
-  u ^= u >> 13; u ^= u >> 26; u *= 0xB6C92F47u;              // the inverses of the steps above, last first
-  u ^= u >> 15; u ^= u >> 30;
-  return u * 0x0E8B2F51u;
-}
+__device__ __forceinline__ uint32_t mfx_q_mix(uint32_t lo, uint32_t hi) { return mfx_p_mix(lo, hi); }          // (mfx_place.h: shared with the host)
+__device__ __forceinline__ uint32_t mfx_q_unmix(uint32_t top, uint32_t hi) { return mfx_p_unmix(top, hi); }
 
 // c: canonical minimizer; sbit: it stands reversed in the (canonical) k-mer; j: its window from the left; e: the j bases left and
 // 3 - j bases right of it; x: offset of the sampling t-mer (first mini-bucket, as mfx_mod_place)
@@ -165,7 +158,8 @@ __device__ __forceinline__ void mfx_q_place(const mfx_table_view &t, uint64_t c,
   const uint32_t hi = (uint32_t)(c >> 32), top = mfx_q_mix((uint32_t)c, hi), nl = (uint32_t)t.nlines;
   line = __umulhi(top, nl);
   const uint32_t fq = (top * nl) >> t.qshift;
-  b0 = (x + (top >> 3)) & 7u;
+  (void)x;
+  b0 = mfx_p_bucket(top, j);
   const int R = 2 * (t.k - 3) - 32, Q = 32 - t.qshift;
   f0 = (uint64_t)hi | ((uint64_t)fq << R) | ((uint64_t)(sbit | (j << 1) | (e << 3)) << (R + Q));
 }
@@ -212,7 +206,7 @@ __device__ __forceinline__ uint32_t mfx_mz_line(const mfx_table_view &t, uint64_
   if (t.mz_t) {
     uint32_t x, line, b0;
     const uint64_t mz = mfx_minimizer_mod(key, krc, t.k, t.mz_w, t.mz_t, x);
-    mfx_mod_place(mz, x, t.nlines, line, b0);
+    mfx_mod_place(mz, x % (uint32_t)t.mz_w, t.nlines, line, b0);
     return line;
   }
   return mfx_range32(mfx_minimizer(key, krc, t.k, t.mz_w) * 0xD6E8FEB86659FD93ULL, t.nlines);
@@ -243,7 +237,7 @@ __device__ __forceinline__ mfx_probe mfx_home(const mfx_table_view &t, uint64_t 
   if (t.mz_t) {                                                // compact layout, mod-minimizer: line and first mini-bucket together
     uint32_t x;
     const uint64_t mz = mfx_minimizer_mod(key, mfx_revcomp(key, t.k), t.k, t.mz_w, t.mz_t, x);
-    mfx_mod_place(mz, x, t.nlines, pr.lineA, pr.b0);
+    mfx_mod_place(mz, x % (uint32_t)t.mz_w, t.nlines, pr.lineA, pr.b0);
     return pr;
   }
   if (t.mz_w > 0)
@@ -785,9 +779,11 @@ __device__ __forceinline__ void mfx_tally_flush(uint64_t *meta, const mfx_tally 
   if (T.wide) atomicAdd((unsigned long long *)&meta[4], (unsigned long long)T.wide);    // a damaged database only: the host refuses the load
 }
 
+// prp: the probes of the keys when the caller knows them without the minimizer scan (a PLACED database's records carry their
+// minimizer: mfx_home_placed), else nullptr
 template <int UB>
 __device__ __forceinline__ void mfx_apply_batch(const mfx_table_view &t, uint64_t (&key)[UB], uint32_t (&v)[UB], int side, uint64_t *meta,
-                                                mfx_tally &T) {
+                                                mfx_tally &T, const mfx_probe *prp = nullptr) {
   // a k-mer has 2k bits: anything wider is a damaged record (mfx_db.cpp checks what it can see on the host; the k-mers of a
   // delta-coded block only exist here) -- never inserted, counted in meta[4], the host refuses the load (index_check)
 #pragma unroll
@@ -800,7 +796,7 @@ __device__ __forceinline__ void mfx_apply_batch(const mfx_table_view &t, uint64_
 #pragma unroll
     for (int j = 0; j < UB; ++j) {
       if (v[j] && key[j] > mfx_revcomp(key[j], t.k)) { ++T.noncanon; v[j] = 0u; }
-      pr[j] = mfx_home(t, key[j]);
+      pr[j] = prp ? prp[j] : mfx_home(t, key[j]);
       mb[j] = reinterpret_cast<unsigned long long *>(t.slots) + mfx_probe_line(t, pr[j], 0) * MFX_CSLOTS_LINE + 2u * pr[j].b0;
       s[j] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
       if (v[j]) s[j] = *reinterpret_cast<const uint4 *>(mb[j]);
@@ -937,6 +933,96 @@ __global__ __launch_bounds__(256) void mfx_table_add_delta_kernel(mfx_table_view
     }
   }
   mfx_tally_flush(meta, T);
+}
+
+// The probe of a k-mer whose placement pieces are known (a record of a PLACED database: mfx_place.h) -- no t-mer scan, no window
+// choice: the line and the first mini-bucket come from `top` and the window, the quotient form's key field from the same pieces.
+// Valid for the compact layout under its default placement (four windows, the mod-minimizer of mfx_p_tlen).
+__device__ __forceinline__ mfx_probe mfx_home_placed(const mfx_table_view &t, uint64_t key, uint32_t top, uint32_t hi, uint32_t meta) {
+  mfx_probe pr;
+  const uint32_t nl = (uint32_t)t.nlines, j = (meta >> 1) & 3u;
+  pr.lineA = pr.lineB = __umulhi(top, nl);
+  pr.b0 = mfx_p_bucket(top, j);
+  pr.fkey = key;
+  if (t.quot) {
+    const int R = 2 * (t.k - 3) - 32, Q = 32 - t.qshift;
+    const uint32_t fq = (top * nl) >> t.qshift;
+    pr.fkey = (uint64_t)hi | ((uint64_t)fq << R) | ((uint64_t)meta << (R + Q));
+  } else {
+    pr.lineB = mfx_range32(mfx_hash64(key), t.nlines);       // (candidate lines beyond the minimizer's region follow the k-mer's own hash)
+  }
+  return pr;
+}
+
+// The delta-coded blocks of a PLACED database (mfx_db.cpp FLAT_PLACED): the records are the numbers P of mfx_place.h in ascending
+// order, i.e. in the order of the table's lines -- a block of 4096 records touches a few hundred CONSECUTIVE lines, each of which is
+// read from HBM once, updated in the L2 and written back once, where a k-mer-sorted database reads a random line per record
+// (1.09 line reads + 0.245 write-backs per record, profiles/r05_build_kernels_pmc.txt).  Same decode as mfx_table_add_delta_kernel;
+// placed != 0: the table takes the records' own placement (compact layout, default placement); else the k-mer is placed anew.
+__global__ __launch_bounds__(256) void mfx_table_add_placed_kernel(mfx_table_view t, const uint64_t *payload, const uint64_t *dir,
+                                                                   uint32_t nblocks, uint64_t n, uint64_t payload_base, int side,
+                                                                   uint64_t *meta, int placed) {
+  constexpr int PER = MFX_DELTA_BLOCK / 256;
+  static_assert(PER == 16, "a lane decodes 16 entries, four at a time");
+  __shared__ uint64_t wsum[4];
+  mfx_tally T;
+  const uint32_t tid = threadIdx.x, wv = tid >> 6, ln = tid & 63u;
+  for (uint32_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
+    const uint64_t first = dir[2 * (uint64_t)b], info = dir[2 * (uint64_t)b + 1];
+    const uint32_t kb = (uint32_t)(info >> 48) & 0xffu, vb = (uint32_t)(info >> 56) & 0xffu;
+    const uint64_t left = n - (uint64_t)b * MFX_DELTA_BLOCK;
+    const uint32_t cnt = left < MFX_DELTA_BLOCK ? (uint32_t)left : (uint32_t)MFX_DELTA_BLOCK;
+    const uint64_t *pw = payload + (((info & 0xffffffffffffull) - payload_base) >> 3);
+    const uint64_t vbit0 = (((uint64_t)(cnt - 1u) * kb + 63u) >> 6) << 6;
+    const uint32_t e0 = tid * PER;
+    uint64_t mine = 0;
+#pragma unroll 4
+    for (uint32_t i = 0; i < PER; ++i) {
+      const uint32_t e = e0 + i;
+      if (e > 0u && e < cnt && kb) mine += mfx_bits_at(pw, (uint64_t)(e - 1u) * kb, kb);
+    }
+    uint64_t inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint64_t u = __shfl_up(inc, o, 64); if ((int)ln >= o) inc += u; }
+    __syncthreads();
+    if (ln == 63u) wsum[wv] = inc;
+    __syncthreads();
+    uint64_t run = first + inc - mine;
+    for (uint32_t w2 = 0; w2 < wv; ++w2) run += wsum[w2];
+#pragma unroll 1
+    for (uint32_t g = 0; g < PER; g += 4) {
+      uint64_t key[4];
+      uint32_t v[4];
+      mfx_probe pr[4];
+#pragma unroll
+      for (uint32_t i = 0; i < 4; ++i) {
+        const uint32_t e = e0 + g + i;
+        key[i] = 0; v[i] = 0u;
+        pr[i].lineA = pr[i].lineB = 0u; pr[i].b0 = 0u; pr[i].fkey = 0;
+        if (e < cnt) {
+          if (e > 0u && kb) run += mfx_bits_at(pw, (uint64_t)(e - 1u) * kb, kb);
+          uint32_t top, hi, pm;
+          key[i] = mfx_p_decode(t.k, run, top, hi, pm);
+          v[i] = (uint32_t)mfx_bits_at(pw, vbit0 + (uint64_t)e * vb, vb);
+          if (v[i] == (1u << vb) - 1u) v[i] = 0u;              // escape: added separately (the file's escape list)
+          if (run >> mfx_p_bits(t.k)) { if (v[i]) ++T.wide; v[i] = 0u; }      // (a damaged record: wider than any P of this k)
+          if (placed) pr[i] = mfx_home_placed(t, key[i], top, hi, pm);
+        }
+      }
+      mfx_apply_batch<4>(t, key, v, side, meta, T, placed ? pr : nullptr);
+    }
+  }
+  mfx_tally_flush(meta, T);
+}
+
+// P of every k-mer of an array (the converter of this repo's tools sorts a database by it on the device; mfx_db.cpp does the same on the host)
+__global__ void mfx_place_keys_kernel(int k, const uint64_t *kmers, uint64_t n, uint64_t *out) {
+  uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const uint64_t key = kmers[i], rc = mfx_p_revcomp(key, k);
+    out[i] = mfx_p_encode(k, key < rc ? key : rc);
+  }
 }
 
 __global__ void mfx_table_value_kernel(mfx_table_view t, const uint64_t *kmers, uint64_t n, uint32_t *readV, uint32_t *asmV) {
@@ -1864,7 +1950,7 @@ __device__ __forceinline__ uint32_t mfx_wave_mod_line(const mfx_table_view &c, u
     const uint32_t e = (uint32_t)(((fkey >> (2 * (m + 3 - (int)jc))) << (2 * (3 - (int)jc))) | (fkey & ((1ull << (2 * (3 - (int)jc))) - 1ull)));
     mfx_q_place(c, ac < bc ? ac : bc, bc < ac ? 1u : 0u, jc, e, xc, line, b0, fkey);
   } else {
-    mfx_mod_place(ma < mb ? ma : mb, xc, c.nlines, line, b0);
+    mfx_mod_place(ma < mb ? ma : mb, fwd ? jf : (uint32_t)w - 1u - jf, c.nlines, line, b0);     // (the window counted in the canonical k-mer)
   }
   return line;
 }
@@ -3017,6 +3103,23 @@ hipError_t mfx_k_table_add_delta(mfx_table_view t, const uint64_t *payload, cons
                                  uint64_t payload_base, int side, uint64_t *meta, hipStream_t st) {
   if (nblocks == 0) return hipSuccess;
   mfx_table_add_delta_kernel<<<nblocks < 8192u ? nblocks : 8192u, 256, 0, st>>>(t, payload, dir, nblocks, n, payload_base, side, meta);
+  return hipGetLastError();
+}
+// does this table take a placed database's records by their own placement?  (the compact layout under its default placement)
+int mfx_k_table_takes_placed(const mfx_table_view &t) {
+  return t.compact && t.seq_only && t.k >= MFX_PLACE_MIN_K && t.k <= MFX_PLACE_MAX_K && t.mz_w == MFX_PLACE_W && t.mz_t == mfx_p_tlen(t.k) && t.shard_n <= 1;
+}
+hipError_t mfx_k_table_add_placed(mfx_table_view t, const uint64_t *payload, const uint64_t *dir, uint32_t nblocks, uint64_t n,
+                                  uint64_t payload_base, int side, uint64_t *meta, hipStream_t st) {
+  if (nblocks == 0) return hipSuccess;
+  mfx_table_add_placed_kernel<<<nblocks < 8192u ? nblocks : 8192u, 256, 0, st>>>(t, payload, dir, nblocks, n, payload_base, side, meta, mfx_k_table_takes_placed(t));
+  return hipGetLastError();
+}
+hipError_t mfx_k_place_keys(int k, const uint64_t *kmers, uint64_t n, uint64_t *out, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  uint64_t blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  mfx_place_keys_kernel<<<(unsigned)blocks, 256, 0, st>>>(k, kmers, n, out);
   return hipGetLastError();
 }
 hipError_t mfx_k_table_value(mfx_table_view t, const uint64_t *kmers, uint64_t n, uint32_t *readV, uint32_t *asmV,

@@ -8,13 +8,19 @@ import time
 import numpy as np
 
 
-def sorted_nonzero(torch, ek, ev, k):
+def sorted_nonzero(torch, ek, ev, k, placed_with=None):
     """the entries of an (unsorted) index export that have a count, sorted by k-mer as `meryl print` lists them (what mfx_db_write_flat
-    delta-codes) -- on the GPU, in key ranges (torch.sort takes < 2^31 elements); k <= 31"""
+    delta-codes) -- on the GPU, in key ranges (torch.sort takes < 2^31 elements); k <= 31.  placed_with = the merfin_amd module: the keys
+    are replaced by their placement numbers (mfx_db_place_keys, csrc/mfx_place.h) first -- the order of a PLACED database"""
     kd = torch.from_numpy(np.ascontiguousarray(ek).view(np.int64)).cuda()
     vd = torch.from_numpy(np.ascontiguousarray(ev).view(np.int32)).cuda()
     nq = max(1, int(np.ceil(kd.numel() / 7e8)))
     shift = 2 * k
+    if placed_with is not None:
+        CHP = 1 << 28
+        for o in range(0, kd.numel(), CHP):
+            placed_with.db_place_keys(k, kd[o:o + CHP], out=kd[o:o + CHP])
+        shift = max(2 * k + 3, 41)
     ks, vs = [], []
     CH = 1 << 30
     for q in range(nq):
@@ -35,7 +41,7 @@ def sorted_nonzero(torch, ek, ev, k):
     return np.concatenate(ks), np.concatenate(vs)
 
 
-def write_inputs(m, st, torch, bases, outdir, ncontigs=24, k=21, lam=26.0, seed=None, log=lambda *a: None):
+def write_inputs(m, st, torch, bases, outdir, ncontigs=24, k=21, lam=26.0, seed=None, log=lambda *a: None, placed=False):
     """returns {"fasta": path, "readdb": path, "read_kmers": n, "db_bytes": b, "fasta_bytes": b, "lens": [...], "write_s": s}"""
     t0 = time.time()
     os.makedirs(outdir, exist_ok=True)
@@ -55,9 +61,15 @@ def write_inputs(m, st, torch, bases, outdir, ncontigs=24, k=21, lam=26.0, seed=
     torch.cuda.empty_cache()
     log("world built and exported: %.1fs" % (time.time() - t0))
     rk, rv = sorted_nonzero(torch, ek, er, k)
-    del ek, er
     readdb = os.path.join(outdir, "read.mfxk")
     m.db_write_flat(readdb, k, rk, rv)
+    placeddb = None
+    if placed:                                                 # the same database in the PLACED form (what `merfin -convert -placed` makes), next to it
+        del rk, rv
+        rk, rv = sorted_nonzero(torch, ek, er, k, placed_with=m)
+        placeddb = os.path.join(outdir, "read.placed.mfxk")
+        m.db_write_flat_placed(placeddb, k, rk, rv)
+    del ek, er
     n_read = len(rk)
     del rk, rv
     log("read database written: %.1fs" % (time.time() - t0))
@@ -73,7 +85,7 @@ def write_inputs(m, st, torch, bases, outdir, ncontigs=24, k=21, lam=26.0, seed=
             if rows * 80 < len(a):
                 f.write(a[rows * 80:].tobytes() + b"\n")
             del out_
-    return {"fasta": fasta, "readdb": readdb, "read_kmers": n_read, "db_bytes": os.path.getsize(readdb), "fasta_bytes": os.path.getsize(fasta),
+    return {"fasta": fasta, "readdb": readdb, "placeddb": placeddb, "placed_db_bytes": os.path.getsize(placeddb) if placeddb else None, "read_kmers": n_read, "db_bytes": os.path.getsize(readdb), "fasta_bytes": os.path.getsize(fasta),
             "lens": [len(a) for a in contigs], "write_s": time.time() - t0}
 
 
