@@ -326,7 +326,10 @@ def db_probe(path):
     """merylFileReader(path): (k, format, n_kmers) of a k-mer database on disk"""
     i = _DbInfo()
     _check(load_library().mfx_db_probe(path.encode(), C.byref(i)))
-    return {"k": i.k, "format": {1: "meryl", 2: "text", 3: "flat"}.get(i.format), "n_kmers": i.n_kmers, "placed": bool(i.placed)}
+    d = {"k": i.k, "format": {1: "meryl", 2: "text", 3: "flat"}.get(i.format), "n_kmers": i.n_kmers}
+    if i.placed:
+        d["placed"] = True                                      # (only a placed flat file says so: mfx_db_convert_placed)
+    return d
 
 
 def load_db_multi(indexes, path, side, minV=0, maxV=2**64 - 1):

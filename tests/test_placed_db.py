@@ -103,10 +103,10 @@ def test_placement_number_matches_the_model_and_inverts(k, tmp_path):
     placed = str(tmp_path / "p.mfxk")
     m.db_write_flat_placed(placed, k, P[o], vals[o])
     info = m.db_probe(placed)
-    assert info["placed"] and info["k"] == k and info["n_kmers"] == len(km)
+    assert info.get("placed") and info["k"] == k and info["n_kmers"] == len(km)
     back = str(tmp_path / "back.mfxk")
     assert m.db_convert(placed, back) == len(km)
-    assert not m.db_probe(back)["placed"]
+    assert not m.db_probe(back).get("placed")
     flat = str(tmp_path / "flat.mfxk")
     m.db_write_flat(flat, k, km, vals)
     assert open(back, "rb").read() == open(flat, "rb").read()
@@ -159,7 +159,7 @@ def test_cli_convert_placed(tmp_path):
     out = str(tmp_path / "out.mfxk")
     r = subprocess.run([exe, "-convert", flat, "-placed", "-output", out], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    assert m.db_probe(out)["placed"]
+    assert m.db_probe(out).get("placed")
     back = str(tmp_path / "back.mfxk")
     m.db_convert(out, back)
     assert open(back, "rb").read() == open(flat, "rb").read()
