@@ -962,9 +962,13 @@ __device__ __forceinline__ mfx_probe mfx_home_placed(const mfx_table_view &t, ui
 __global__ __launch_bounds__(256) void mfx_table_add_placed_kernel(mfx_table_view t, const uint64_t *payload, const uint64_t *dir,
                                                                    uint32_t nblocks, uint64_t n, uint64_t payload_base, int side,
                                                                    uint64_t *meta, int placed) {
-  constexpr int PER = MFX_DELTA_BLOCK / 256;
-  static_assert(PER == 16, "a lane decodes 16 entries, four at a time");
+  // Records in the order of the table's lines only pay if a line's records are applied TOGETHER: a round takes 1024 consecutive
+  // records (four per lane, lane after lane), i.e. ~100 consecutive lines, and never comes back to them -- with sixteen consecutive
+  // records per lane (the k-mer-sorted kernel's split) every line of the block was touched in four rounds, and left the L2 in between
+  // (measured: every table line written back 4.7 times, profiles/r05_e2e_placed.txt).
+  constexpr uint32_t ROUND = 256u * 4u;
   __shared__ uint64_t wsum[4];
+  __shared__ uint64_t s_base;
   mfx_tally T;
   const uint32_t tid = threadIdx.x, wv = tid >> 6, ln = tid & 63u;
   for (uint32_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
@@ -974,33 +978,37 @@ __global__ __launch_bounds__(256) void mfx_table_add_placed_kernel(mfx_table_vie
     const uint32_t cnt = left < MFX_DELTA_BLOCK ? (uint32_t)left : (uint32_t)MFX_DELTA_BLOCK;
     const uint64_t *pw = payload + (((info & 0xffffffffffffull) - payload_base) >> 3);
     const uint64_t vbit0 = (((uint64_t)(cnt - 1u) * kb + 63u) >> 6) << 6;
-    const uint32_t e0 = tid * PER;
-    uint64_t mine = 0;
-#pragma unroll 4
-    for (uint32_t i = 0; i < PER; ++i) {
-      const uint32_t e = e0 + i;
-      if (e > 0u && e < cnt && kb) mine += mfx_bits_at(pw, (uint64_t)(e - 1u) * kb, kb);
-    }
-    uint64_t inc = mine;
+    __syncthreads();                                           // the previous block's rounds are over
+    if (tid == 0) s_base = first;
+    for (uint32_t r0 = 0; r0 < cnt; r0 += ROUND) {             // block-uniform
+      const uint32_t e0 = r0 + tid * 4u;
+      uint64_t d[4], mine = 0;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const uint64_t u = __shfl_up(inc, o, 64); if ((int)ln >= o) inc += u; }
-    __syncthreads();
-    if (ln == 63u) wsum[wv] = inc;
-    __syncthreads();
-    uint64_t run = first + inc - mine;
-    for (uint32_t w2 = 0; w2 < wv; ++w2) run += wsum[w2];
-#pragma unroll 1
-    for (uint32_t g = 0; g < PER; g += 4) {
+      for (uint32_t i = 0; i < 4; ++i) {
+        const uint32_t e = e0 + i;
+        d[i] = (e > 0u && e < cnt && kb) ? mfx_bits_at(pw, (uint64_t)(e - 1u) * kb, kb) : 0ull;     // entry e > 0 has difference e - 1
+        mine += d[i];
+      }
+      uint64_t inc = mine;                                     // inclusive scan over the workgroup
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const uint64_t u = __shfl_up(inc, o, 64); if ((int)ln >= o) inc += u; }
+      __syncthreads();                                         // s_base and wsum of the round before are read by now
+      if (ln == 63u) wsum[wv] = inc;
+      __syncthreads();
+      uint64_t run = s_base + inc - mine;
+      for (uint32_t w2 = 0; w2 < wv; ++w2) run += wsum[w2];
+      __syncthreads();
+      if (tid == 255u) s_base = run + mine;                    // the value of the round's last entry: where the next round starts
       uint64_t key[4];
       uint32_t v[4];
       mfx_probe pr[4];
 #pragma unroll
       for (uint32_t i = 0; i < 4; ++i) {
-        const uint32_t e = e0 + g + i;
+        const uint32_t e = e0 + i;
         key[i] = 0; v[i] = 0u;
         pr[i].lineA = pr[i].lineB = 0u; pr[i].b0 = 0u; pr[i].fkey = 0;
+        run += d[i];
         if (e < cnt) {
-          if (e > 0u && kb) run += mfx_bits_at(pw, (uint64_t)(e - 1u) * kb, kb);
           uint32_t top, hi, pm;
           key[i] = mfx_p_decode(t.k, run, top, hi, pm);
           v[i] = (uint32_t)mfx_bits_at(pw, vbit0 + (uint64_t)e * vb, vb);

@@ -29,15 +29,15 @@ def _export_sorted(ix):
     return k_[o], r_[o], a_[o]
 
 
-def _padded(k, read, n_extra=200000, seed=5):
-    """the read database + k-mers the sequence does not hold (dropped by a sequence-only index, still decoded), sorted"""
+def _padded(k, read, asm, n_extra=200000, seed=5):
+    """the read database + k-mers neither it nor the sequence holds (dropped by a sequence-only index, still decoded), sorted"""
     rng = np.random.default_rng(seed)
     extra = np.unique(rng.integers(0, 1 << (2 * k - 1), n_extra, dtype=np.uint64))
     x, r = extra.copy(), np.zeros_like(extra)
     for _ in range(k):
         r = (r << np.uint64(2)) | ((x & np.uint64(3)) ^ np.uint64(2))
         x >>= np.uint64(2)
-    canon = np.setdiff1d(np.unique(np.minimum(extra, r)), read[0])
+    canon = np.setdiff1d(np.setdiff1d(np.unique(np.minimum(extra, r)), read[0]), asm[0])
     keys = np.concatenate([read[0], canon])
     vals = np.concatenate([read[1], np.full(len(canon), 3, dtype=np.uint32)])
     o = np.argsort(keys, kind="stable")
@@ -50,7 +50,7 @@ def test_placed_database_builds_the_same_table(k, tmp_path, monkeypatch):
     m = _mfx()
     peak = 11.0
     contigs, read, asm = synth.world(k=k, peak=peak, seed=70 + k)
-    keys, vals = _padded(k, read)
+    keys, vals = _padded(k, read, asm)
     vals[::501] = 5000 + (np.arange(len(vals[::501])) % 7).astype(np.uint32) * 100000      # counts beyond any block's field: the escape list
     truth = dict(zip(keys.tolist(), vals.tolist()))
     flat, placed = str(tmp_path / "r.mfxk"), str(tmp_path / "p.mfxk")
