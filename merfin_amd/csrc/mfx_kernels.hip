@@ -813,6 +813,16 @@ __device__ __forceinline__ void mfx_apply_batch(const mfx_table_view &t, uint64_
       else if (y == MFX_EMPTY) { }
       else if ((y >> 22) == pr[j].fkey) { w = mb[j] + 1; cur = y; }
       else w = mfx_c_find(t, pr[j], 0, cur, beyond);
+      if (w && prp) {
+        // A PLACED database's update writes the slot with a plain store.  A slot has ONE writer while a database is applied -- a
+        // database holds every k-mer once, the loads of an index do not overlap, the claim kernel is ordered before them -- and an
+        // atomic on this device is a 64-byte transaction at the memory side whatever the L2 holds (WRITE_SIZE: 64 B per updated
+        // k-mer, sorted or placed), while a line whose slots are stored to one after the other is written back once.  A count that
+        // would saturate its field takes the compare-and-swap path (it moves to the side table with it).
+        const int sh = side ? 0 : 11;
+        const uint32_t f = (uint32_t)(cur >> sh) & MFX_CSAT;
+        if (f != MFX_CSAT && (uint64_t)f + v[j] < MFX_CSAT) { *w = cur + ((unsigned long long)v[j] << sh); continue; }
+      }
       if (w) mfx_c_add(t, w, cur, key[j], v[j], side, meta);
       else {
         mfx_slot *ss = beyond ? mfx_find_slot(mfx_side_view(t), key[j]) : nullptr;     // quotient form: beyond its candidate lines
