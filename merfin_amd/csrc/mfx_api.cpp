@@ -1032,11 +1032,14 @@ static void stage_worker(mfx_db_stage *S) {
   };
   hipError_t e = hipSetDevice(S->device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
-  for (int i = 0; i < NL && e == hipSuccess; ++i) {
-    e = hipHostMalloc((void **)&lane[i], LANE, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&left[i], hipEventDisableTiming);
-  }
-  if (e == hipSuccess) e = hipMemcpyAsync(S->d_dir, S->dir.data(), S->dir.size() * 8, hipMemcpyHostToDevice, cs);
+  // (a lane is pinned when its first chunk comes up -- 13 ms each -- and the directory goes over behind the first chunk: the first
+  // bytes of the database are on the link as early as the runtime allows)
+  auto lane_up = [&](int i) -> hipError_t {
+    if (lane[i]) return hipSuccess;
+    hipError_t le = hipHostMalloc((void **)&lane[i], LANE, hipHostMallocDefault);
+    if (le == hipSuccess) le = hipEventCreateWithFlags(&left[i], hipEventDisableTiming);
+    return le;
+  };
   if (e != hipSuccess) fail("staging set-up failed", e);
   {
     // While the FASTA file is being read and encoded the host's threads are busy with that (a full pool here slowed the sequence
@@ -1052,11 +1055,13 @@ static void stage_worker(mfx_db_stage *S) {
     };
     for (size_t c = 0; c < S->chunks.size() && !S->failed.load(); ++c) {
       const int li = (int)(c % NL);
+      if ((e = lane_up(li)) != hipSuccess) { fail("staging set-up failed", e); break; }
       if (busy[li] && (e = hipEventSynchronize(left[li])) != hipSuccess) { fail("staging copy failed", e); break; }
       const uint64_t o = S->file_off(S->chunks[c].b0), bytes = S->file_off(S->chunks[c].b1) - o;
       if (!par_pread(S->fd, lane[li], bytes, o, pool_now())) { fail("reading the database failed", hipSuccess); break; }
       if (c == 0) S->t_first_copy = stage_now();
       e = hipMemcpyAsync(S->d_payload + (o - S->off0), lane[li], bytes, hipMemcpyHostToDevice, cs);
+      if (e == hipSuccess && c == 0) e = hipMemcpyAsync(S->d_dir, S->dir.data(), S->dir.size() * 8, hipMemcpyHostToDevice, cs);     // (ahead of every chunk's `copied` event but the first's, which the next line records behind it)
       if (e == hipSuccess) e = hipEventRecord(left[li], cs);
       if (e == hipSuccess) e = hipEventRecord(S->chunks[c].copied, cs);
       if (e != hipSuccess) { fail("staging copy failed", e); break; }
@@ -1071,6 +1076,7 @@ static void stage_worker(mfx_db_stage *S) {
       for (uint64_t o = 0, c = S->chunks.size(); o < total && !S->failed.load(); o += LANE, ++c) {
         const int li = (int)(c % NL);
         const uint64_t bytes = std::min<uint64_t>(LANE, total - o);
+        if ((e = lane_up(li)) != hipSuccess) { fail("staging set-up failed", e); break; }
         if (busy[li] && (e = hipEventSynchronize(left[li])) != hipSuccess) { fail("staging copy failed", e); break; }
         if (!par_pread(S->fd, lane[li], bytes, at + o, pool_now())) { fail("reading the database failed", hipSuccess); break; }
         if (part == 0) {                                      // a k-mer of k bases has no bit at or above 2k (a damaged file)
