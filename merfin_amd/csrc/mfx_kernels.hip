@@ -123,10 +123,28 @@ __device__ __forceinline__ uint64_t mfx_minimizer_mod(uint64_t key, uint64_t rc,
 // start at different mini-buckets of their common line instead of colliding at random: 3 % of the k-mers of a random sequence end
 // outside their first mini-bucket at load factor 0.225 where a hash of the k-mer left 8.3 %.  (Layout version 9; before: a 32-bit
 // fold of the minimizer and the sampling t-mer's offset x, of which jw is the low bits.)
-__device__ __forceinline__ void mfx_mod_place(uint64_t mz, uint32_t jw, uint64_t nlines, uint32_t &line, uint32_t &b0) {
+#ifndef MFX_V_PLACE_OLDLINE
+#define MFX_V_PLACE_OLDLINE 0         // A/B only (tools/ab_build.sh): the layout-8 line hash / mini-bucket by the t-mer's offset; such a table does not take placed databases
+#endif
+#ifndef MFX_V_PLACE_XBUCKET
+#define MFX_V_PLACE_XBUCKET 0
+#endif
+__device__ __forceinline__ void mfx_mod_place(uint64_t mz, uint32_t jw, uint32_t sbit, uint64_t nlines, uint32_t &line, uint32_t &b0, uint32_t x = 0) {
+#if MFX_V_PLACE_OLDLINE
+  const uint32_t h = ((uint32_t)mz * 0x9E3779B1u) ^ (((uint32_t)(mz >> 32) + 0x7F4A7C15u) * 0x85EBCA77u);
+  line = __umulhi(h ^ (h >> 15), (uint32_t)nlines);
+  const uint32_t top = h << 3;
+#else
   const uint32_t top = mfx_p_mix((uint32_t)mz, (uint32_t)(mz >> 32));
   line = __umulhi(top, (uint32_t)nlines);
-  b0 = mfx_p_bucket(top, jw);
+#endif
+#if MFX_V_PLACE_XBUCKET
+  b0 = (x + (top >> 3)) & 7u;
+  (void)jw;
+#else
+  b0 = mfx_p_bucket(top, jw, sbit);
+  (void)x;
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -159,7 +177,7 @@ __device__ __forceinline__ void mfx_q_place(const mfx_table_view &t, uint64_t c,
   line = __umulhi(top, nl);
   const uint32_t fq = (top * nl) >> t.qshift;
   (void)x;
-  b0 = mfx_p_bucket(top, j);
+  b0 = mfx_p_bucket(top, j, sbit);
   const int R = 2 * (t.k - 3) - 32, Q = 32 - t.qshift;
   f0 = (uint64_t)hi | ((uint64_t)fq << R) | ((uint64_t)(sbit | (j << 1) | (e << 3)) << (R + Q));
 }
@@ -205,8 +223,9 @@ __device__ __forceinline__ uint32_t mfx_mz_line(const mfx_table_view &t, uint64_
   }
   if (t.mz_t) {
     uint32_t x, line, b0;
-    const uint64_t mz = mfx_minimizer_mod(key, krc, t.k, t.mz_w, t.mz_t, x);
-    mfx_mod_place(mz, x % (uint32_t)t.mz_w, t.nlines, line, b0);
+    uint64_t wa, wb;
+    mfx_mod_window(key, krc, t.k, t.mz_w, t.mz_t, x, wa, wb);
+    mfx_mod_place(wa < wb ? wa : wb, x % (uint32_t)t.mz_w, wb < wa ? 1u : 0u, t.nlines, line, b0, x);
     return line;
   }
   return mfx_range32(mfx_minimizer(key, krc, t.k, t.mz_w) * 0xD6E8FEB86659FD93ULL, t.nlines);
@@ -236,8 +255,9 @@ __device__ __forceinline__ mfx_probe mfx_home(const mfx_table_view &t, uint64_t 
   }
   if (t.mz_t) {                                                // compact layout, mod-minimizer: line and first mini-bucket together
     uint32_t x;
-    const uint64_t mz = mfx_minimizer_mod(key, mfx_revcomp(key, t.k), t.k, t.mz_w, t.mz_t, x);
-    mfx_mod_place(mz, x % (uint32_t)t.mz_w, t.nlines, pr.lineA, pr.b0);
+    uint64_t wa, wb;
+    mfx_mod_window(key, mfx_revcomp(key, t.k), t.k, t.mz_w, t.mz_t, x, wa, wb);
+    mfx_mod_place(wa < wb ? wa : wb, x % (uint32_t)t.mz_w, wb < wa ? 1u : 0u, t.nlines, pr.lineA, pr.b0, x);
     return pr;
   }
   if (t.mz_w > 0)
@@ -952,7 +972,7 @@ __device__ __forceinline__ mfx_probe mfx_home_placed(const mfx_table_view &t, ui
   mfx_probe pr;
   const uint32_t nl = (uint32_t)t.nlines, j = (meta >> 1) & 3u;
   pr.lineA = pr.lineB = __umulhi(top, nl);
-  pr.b0 = mfx_p_bucket(top, j);
+  pr.b0 = mfx_p_bucket(top, j, meta & 1u);
   pr.fkey = key;
   if (t.quot) {
     const int R = 2 * (t.k - 3) - 32, Q = 32 - t.qshift;
@@ -1968,7 +1988,8 @@ __device__ __forceinline__ uint32_t mfx_wave_mod_line(const mfx_table_view &c, u
     const uint32_t e = (uint32_t)(((fkey >> (2 * (m + 3 - (int)jc))) << (2 * (3 - (int)jc))) | (fkey & ((1ull << (2 * (3 - (int)jc))) - 1ull)));
     mfx_q_place(c, ac < bc ? ac : bc, bc < ac ? 1u : 0u, jc, e, xc, line, b0, fkey);
   } else {
-    mfx_mod_place(ma < mb ? ma : mb, fwd ? jf : (uint32_t)w - 1u - jf, c.nlines, line, b0);     // (the window counted in the canonical k-mer)
+    // (window and strand of the minimizer counted in the canonical k-mer, as the per-k-mer form has them: mfx_p_parts)
+    mfx_mod_place(ma < mb ? ma : mb, fwd ? jf : (uint32_t)w - 1u - jf, (fwd ? mb < ma : ma < mb) ? 1u : 0u, c.nlines, line, b0, xc);
   }
   return line;
 }

@@ -80,10 +80,13 @@ MFX_PHD uint32_t mfx_p_unmix(uint32_t top, uint32_t hi) {
   return u * 0x0E8B2F51u;
 }
 
-// line and first mini-bucket of a minimizer's `top`, window j (the k-mers of one minimizer occurrence have different j: they start
-// at different mini-buckets of their common line)
+// Line and first mini-bucket of a minimizer's `top`.  The mini-bucket comes from WHERE the minimizer stands -- the window counted in
+// the orientation in which the minimizer reads canonical: j if it stands as it is in the (canonical) k-mer, 3 - j if it stands reversed.
+// The up to four k-mers around one occurrence of a minimizer see it at four different such places whatever strand each of THEM is
+// canonical on (with j alone a k-mer at window 3 and a reverse-canonical one at window 0 meet in one mini-bucket: measured, +25 wave
+// instructions per k-mer in the -hist kernel for the displaced queries that makes), so they start at four different mini-buckets.
 MFX_PHD uint32_t mfx_p_line(uint32_t top, uint32_t nlines) { return (uint32_t)(((uint64_t)top * nlines) >> 32); }
-MFX_PHD uint32_t mfx_p_bucket(uint32_t top, uint32_t j) { return (2u * j + (top >> 3)) & 7u; }
+MFX_PHD uint32_t mfx_p_bucket(uint32_t top, uint32_t j, uint32_t sbit) { return (2u * (sbit ? 3u - j : j) + (top >> 3)) & 7u; }
 
 // the pieces of a CANONICAL k-mer `key` (rc: its reverse complement): c, s, j, e as above; k >= 13 (the mod-minimizer of the layout)
 MFX_PHD void mfx_p_parts(int k, uint64_t key, uint64_t rc, uint64_t &c, uint32_t &sbit, uint32_t &j, uint32_t &e) {

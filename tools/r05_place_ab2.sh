@@ -1,0 +1,43 @@
+#!/bin/bash
+set -u
+cd "$(dirname "$0")/.."
+ROOT=$PWD
+OUT=$ROOT/gpurun_out
+mkdir -p $OUT
+export TMPDIR=/tmp
+echo skip-tests > $OUT/r05_place_ab2_tests.txt
+grep -h "passed\|failed" $OUT/r05_place_ab2_tests.txt
+one() {
+  local label=$1 lib=$2; shift 2
+  if [ "$lib" = "default" ]; then unset MFX_LIB; else export MFX_LIB=$ROOT/$lib; fi
+  python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-e2e --no-k31 --no-full-index --no-streamed "$@" 2>>$OUT/r05_place_ab_err.txt | python -c "
+import json,sys
+d=json.load(sys.stdin); r=d['roofline']
+print('%-56s' % '$label', '%.2f G k-mers/s' % (d['value']/1e9), '%.3f ms' % d['ms_per_step'], 'lines/k-mer %.4f' % (r.get('lines_per_kmer') or 0), 'VALU/k-mer %.1f' % ((r.get('issue') or {}).get('valu_insts_per_kmer') or 0), 'kmissing', d['config']['kmissing'], 'koverCpy %.7f' % d['config']['koverCpy'])
+"
+  unset MFX_LIB
+}
+{
+one "layout 9: mix line, bucket by the window in the orientation of the minimizer" default
+one "layout-8 line, offset bucket (= layout 8)" tools/_build/ab/lib_oldboth.so
+one "layout 9: mix line, bucket by the window in the orientation of the minimizer" default --no-pmc
+one "layout-8 line, offset bucket (= layout 8)" tools/_build/ab/lib_oldboth.so --no-pmc
+} > $OUT/r05_place_ab2.txt 2>&1
+cat $OUT/r05_place_ab2.txt
+python - <<'PY' 2>/dev/null | tail -4
+import os, sys
+sys.path.insert(0, os.getcwd())
+import torch, numpy as np
+import merfin_amd as m
+from tools import synth_torch as st
+import bench
+ix, seqs, asm, info = st.build_world(m, 1_000_000_000, k=21, lam=26.0, ncontigs=24, seq_only=True)
+ev = m.Evaluator(ix, m.KParams.from_file(26.0, "tests/golden/example_lookup_table.txt"))
+ev.debug(True); r = ev.hist(seqs); c = ev.debug_counters(); ev.debug(False)
+print("1 Gb debug counters (layout 9, new bucket):", c, "kasm", r.kasm)
+del ev, ix, seqs, asm
+torch.cuda.empty_cache()
+kp = m.KParams.from_file(26.0, os.path.join("tests", "golden", "example_lookup_table.txt"))
+r = bench.k31_leg(m, st, torch, 3_000_000_000, 26.0, kp, 0, False, 10)
+print("k = 31: %.2f G k-mers/s  %.3f ms  kmissing %d" % (r["value"] / 1e9, r["ms_per_step"], r["kmissing"]))
+PY
