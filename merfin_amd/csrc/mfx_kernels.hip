@@ -129,7 +129,8 @@ __device__ __forceinline__ uint64_t mfx_minimizer_mod(uint64_t key, uint64_t rc,
 #ifndef MFX_V_PLACE_XBUCKET
 #define MFX_V_PLACE_XBUCKET 0
 #endif
-__device__ __forceinline__ void mfx_mod_place(uint64_t mz, uint32_t jw, uint32_t sbit, uint64_t nlines, uint32_t &line, uint32_t &b0, uint32_t x = 0) {
+// jo: the minimizer's window counted in the orientation in which it reads canonical (mfx_p_bucket: j, or 3 - j if it stands reversed)
+__device__ __forceinline__ void mfx_mod_place(uint64_t mz, uint32_t jo, uint64_t nlines, uint32_t &line, uint32_t &b0, uint32_t x = 0) {
 #if MFX_V_PLACE_OLDLINE
   const uint32_t h = ((uint32_t)mz * 0x9E3779B1u) ^ (((uint32_t)(mz >> 32) + 0x7F4A7C15u) * 0x85EBCA77u);
   line = __umulhi(h ^ (h >> 15), (uint32_t)nlines);
@@ -142,7 +143,7 @@ __device__ __forceinline__ void mfx_mod_place(uint64_t mz, uint32_t jw, uint32_t
   b0 = (x + (top >> 3)) & 7u;
   (void)jw;
 #else
-  b0 = mfx_p_bucket(top, jw, sbit);
+  b0 = (2u * jo + (top >> 3)) & 7u;                            // = mfx_p_bucket(top, j, sbit)
   (void)x;
 #endif
 }
@@ -225,7 +226,7 @@ __device__ __forceinline__ uint32_t mfx_mz_line(const mfx_table_view &t, uint64_
     uint32_t x, line, b0;
     uint64_t wa, wb;
     mfx_mod_window(key, krc, t.k, t.mz_w, t.mz_t, x, wa, wb);
-    mfx_mod_place(wa < wb ? wa : wb, x % (uint32_t)t.mz_w, wb < wa ? 1u : 0u, t.nlines, line, b0, x);
+    { const uint32_t jw = x % (uint32_t)t.mz_w; mfx_mod_place(wa < wb ? wa : wb, wb < wa ? (uint32_t)t.mz_w - 1u - jw : jw, t.nlines, line, b0, x); }
     return line;
   }
   return mfx_range32(mfx_minimizer(key, krc, t.k, t.mz_w) * 0xD6E8FEB86659FD93ULL, t.nlines);
@@ -257,7 +258,7 @@ __device__ __forceinline__ mfx_probe mfx_home(const mfx_table_view &t, uint64_t 
     uint32_t x;
     uint64_t wa, wb;
     mfx_mod_window(key, mfx_revcomp(key, t.k), t.k, t.mz_w, t.mz_t, x, wa, wb);
-    mfx_mod_place(wa < wb ? wa : wb, x % (uint32_t)t.mz_w, wb < wa ? 1u : 0u, t.nlines, pr.lineA, pr.b0, x);
+    { const uint32_t jw = x % (uint32_t)t.mz_w; mfx_mod_place(wa < wb ? wa : wb, wb < wa ? (uint32_t)t.mz_w - 1u - jw : jw, t.nlines, pr.lineA, pr.b0, x); }
     return pr;
   }
   if (t.mz_w > 0)
@@ -1988,8 +1989,11 @@ __device__ __forceinline__ uint32_t mfx_wave_mod_line(const mfx_table_view &c, u
     const uint32_t e = (uint32_t)(((fkey >> (2 * (m + 3 - (int)jc))) << (2 * (3 - (int)jc))) | (fkey & ((1ull << (2 * (3 - (int)jc))) - 1ull)));
     mfx_q_place(c, ac < bc ? ac : bc, bc < ac ? 1u : 0u, jc, e, xc, line, b0, fkey);
   } else {
-    // (window and strand of the minimizer counted in the canonical k-mer, as the per-k-mer form has them: mfx_p_parts)
-    mfx_mod_place(ma < mb ? ma : mb, fwd ? jf : (uint32_t)w - 1u - jf, (fwd ? mb < ma : ma < mb) ? 1u : 0u, c.nlines, line, b0, xc);
+    // The oriented window, read off the forward strand: the per-k-mer form (mfx_p_parts on the canonical k-mer: window jc, reversed iff
+    // b < a) gives jf where the minimizer reads canonical on the forward strand and 3 - jf where it does not, whatever strand the K-MER is
+    // canonical on; a palindromic minimizer (ma == mb) counts as standing as it is in the canonical k-mer.
+    const bool lt = ma < mb, keep = lt || (fwd && ma == mb);
+    mfx_mod_place(lt ? ma : mb, keep ? jf : (uint32_t)w - 1u - jf, c.nlines, line, b0, xc);
   }
   return line;
 }

@@ -5,7 +5,7 @@ ROOT=$PWD
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-echo skip-tests > $OUT/r05_place_ab2_tests.txt
+( timeout 2400 python -m pytest tests/test_gpu_placed_db.py tests/test_gpu_seqonly.py tests/test_gpu_parity.py tests/test_gpu_bench_path.py tests/test_golden.py -x -q 2>&1 | tail -6 ) > $OUT/r05_place_ab2_tests.txt
 grep -h "passed\|failed" $OUT/r05_place_ab2_tests.txt
 one() {
   local label=$1 lib=$2; shift 2
