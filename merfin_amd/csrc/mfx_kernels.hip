@@ -116,21 +116,24 @@ __device__ __forceinline__ uint64_t mfx_minimizer_mod(uint64_t key, uint64_t rc,
   return a < b ? a : b;
 }
 
-// Line and first mini-bucket of a mod-minimizer (an m-mer of at most 36 bits: the compact layout holds k <= 21 in this form) that stands
-// in window jw of the (canonical) k-mer.  Line: the high bits of a BIJECTION of the minimizer (mfx_place.h: mfx_p_mix -- the quotient
-// form's, so that a database sorted by it walks the table line after line: mfx_p_encode) scaled into the table.  Mini-bucket:
-// (2 jw + three other bits of the hash) mod 8 -- the k-mers that share a minimizer occurrence hold it in DIFFERENT windows, so they
-// start at different mini-buckets of their common line instead of colliding at random: 3 % of the k-mers of a random sequence end
-// outside their first mini-bucket at load factor 0.225 where a hash of the k-mer left 8.3 %.  (Layout version 9; before: a 32-bit
-// fold of the minimizer and the sampling t-mer's offset x, of which jw is the low bits.)
+// Line and first mini-bucket of a mod-minimizer (an m-mer of at most 36 bits: the compact layout holds k <= 21 in this form) sampled by
+// the t-mer at offset x of the (canonical) k-mer.  Line: the high bits of a BIJECTION of the minimizer (mfx_place.h: mfx_p_mix -- the
+// quotient form's; layout version 9; before: a 32-bit fold) scaled into the table, so that a database sorted by that mix walks the table
+// line after line (the PLACED form, mfx_p_encode; +2 wave-VALU per k-mer in the -hist kernel against the fold).  Mini-bucket: (x + three
+// other bits of the mix) mod 8 -- the k-mers that share a minimizer sit at consecutive positions and see its t-mer at DIFFERENT offsets,
+// so they start at different mini-buckets of their common line instead of colliding at random: 3 % of the k-mers of a random sequence end
+// outside their first mini-bucket at load factor 0.225 where a hash of the k-mer left 8.3 %.  x falls out of the -hist kernel's
+// sliding-window minimum for free; a mini-bucket from the minimizer's WINDOW (which a placed record carries, unlike x) was tried
+// for this form and costs the -hist kernel 12-25 wave-VALU per k-mer (profiles/r05_place_ab.txt): the placed update runs the t-mer
+// scan on its decoded k-mers instead (it is bound by latency, not by its ALUs).  jo: that window, counted in the orientation in which the
+// minimizer reads canonical -- used by the A/B build -DMFX_V_PLACE_WBUCKET=1 only.
 #ifndef MFX_V_PLACE_OLDLINE
-#define MFX_V_PLACE_OLDLINE 0         // A/B only (tools/ab_build.sh): the layout-8 line hash / mini-bucket by the t-mer's offset; such a table does not take placed databases
+#define MFX_V_PLACE_OLDLINE 0         // A/B only (tools/ab_build.sh): the layout-8 line hash; such a table does not take placed databases in their order
 #endif
-#ifndef MFX_V_PLACE_XBUCKET
-#define MFX_V_PLACE_XBUCKET 0
+#ifndef MFX_V_PLACE_WBUCKET
+#define MFX_V_PLACE_WBUCKET 0         // A/B only: the mini-bucket from the oriented window instead of the t-mer's offset
 #endif
-// jo: the minimizer's window counted in the orientation in which it reads canonical (mfx_p_bucket: j, or 3 - j if it stands reversed)
-__device__ __forceinline__ void mfx_mod_place(uint64_t mz, uint32_t jo, uint64_t nlines, uint32_t &line, uint32_t &b0, uint32_t x = 0) {
+__device__ __forceinline__ void mfx_mod_place(uint64_t mz, uint32_t jo, uint64_t nlines, uint32_t &line, uint32_t &b0, uint32_t x) {
 #if MFX_V_PLACE_OLDLINE
   const uint32_t h = ((uint32_t)mz * 0x9E3779B1u) ^ (((uint32_t)(mz >> 32) + 0x7F4A7C15u) * 0x85EBCA77u);
   line = __umulhi(h ^ (h >> 15), (uint32_t)nlines);
@@ -139,12 +142,12 @@ __device__ __forceinline__ void mfx_mod_place(uint64_t mz, uint32_t jo, uint64_t
   const uint32_t top = mfx_p_mix((uint32_t)mz, (uint32_t)(mz >> 32));
   line = __umulhi(top, (uint32_t)nlines);
 #endif
-#if MFX_V_PLACE_XBUCKET
-  b0 = (x + (top >> 3)) & 7u;
-  (void)jw;
-#else
-  b0 = (2u * jo + (top >> 3)) & 7u;                            // = mfx_p_bucket(top, j, sbit)
+#if MFX_V_PLACE_WBUCKET
+  b0 = (2u * jo + (top >> 3)) & 7u;
   (void)x;
+#else
+  b0 = (x + (top >> 3)) & 7u;
+  (void)jo;
 #endif
 }
 
@@ -800,11 +803,11 @@ __device__ __forceinline__ void mfx_tally_flush(uint64_t *meta, const mfx_tally 
   if (T.wide) atomicAdd((unsigned long long *)&meta[4], (unsigned long long)T.wide);    // a damaged database only: the host refuses the load
 }
 
-// prp: the probes of the keys when the caller knows them without the minimizer scan (a PLACED database's records carry their
-// minimizer: mfx_home_placed), else nullptr
+// prp: the probes of the keys when the caller knows them without the minimizer scan (the quotient form's pieces are all in a PLACED
+// database's record: mfx_home_placed), else nullptr.  plain: the counts are written with plain stores (the placed update, see below).
 template <int UB>
 __device__ __forceinline__ void mfx_apply_batch(const mfx_table_view &t, uint64_t (&key)[UB], uint32_t (&v)[UB], int side, uint64_t *meta,
-                                                mfx_tally &T, const mfx_probe *prp = nullptr) {
+                                                mfx_tally &T, const mfx_probe *prp = nullptr, bool plain = false) {
   // a k-mer has 2k bits: anything wider is a damaged record (mfx_db.cpp checks what it can see on the host; the k-mers of a
   // delta-coded block only exist here) -- never inserted, counted in meta[4], the host refuses the load (index_check)
 #pragma unroll
@@ -834,7 +837,7 @@ __device__ __forceinline__ void mfx_apply_batch(const mfx_table_view &t, uint64_
       else if (y == MFX_EMPTY) { }
       else if ((y >> 22) == pr[j].fkey) { w = mb[j] + 1; cur = y; }
       else w = mfx_c_find(t, pr[j], 0, cur, beyond);
-      if (w && prp) {
+      if (w && plain) {
         // A PLACED database's update writes the slot with a plain store.  A slot has ONE writer while a database is applied -- a
         // database holds every k-mer once, the loads of an index do not overlap, the claim kernel is ordered before them -- and an
         // atomic on this device is a 64-byte transaction at the memory side whatever the L2 holds (WRITE_SIZE: 64 B per updated
@@ -967,8 +970,9 @@ __global__ __launch_bounds__(256) void mfx_table_add_delta_kernel(mfx_table_view
 }
 
 // The probe of a k-mer whose placement pieces are known (a record of a PLACED database: mfx_place.h) -- no t-mer scan, no window
-// choice: the line and the first mini-bucket come from `top` and the window, the quotient form's key field from the same pieces.
-// Valid for the compact layout under its default placement (four windows, the mod-minimizer of mfx_p_tlen).
+// choice: the line and the first mini-bucket come from `top`, window and strand, the quotient form's key field from the same pieces.
+// Valid for the QUOTIENT form of the compact layout (22 <= k <= 30) under its default placement; the direct form (k <= 21) takes its
+// first mini-bucket from the t-mer's offset, which a record does not carry (mfx_mod_place).
 __device__ __forceinline__ mfx_probe mfx_home_placed(const mfx_table_view &t, uint64_t key, uint32_t top, uint32_t hi, uint32_t meta) {
   mfx_probe pr;
   const uint32_t nl = (uint32_t)t.nlines, j = (meta >> 1) & 3u;
@@ -979,8 +983,6 @@ __device__ __forceinline__ mfx_probe mfx_home_placed(const mfx_table_view &t, ui
     const int R = 2 * (t.k - 3) - 32, Q = 32 - t.qshift;
     const uint32_t fq = (top * nl) >> t.qshift;
     pr.fkey = (uint64_t)hi | ((uint64_t)fq << R) | ((uint64_t)meta << (R + Q));
-  } else {
-    pr.lineB = mfx_range32(mfx_hash64(key), t.nlines);       // (candidate lines beyond the minimizer's region follow the k-mer's own hash)
   }
   return pr;
 }
@@ -1045,10 +1047,10 @@ __global__ __launch_bounds__(256) void mfx_table_add_placed_kernel(mfx_table_vie
           v[i] = (uint32_t)mfx_bits_at(pw, vbit0 + (uint64_t)e * vb, vb);
           if (v[i] == (1u << vb) - 1u) v[i] = 0u;              // escape: added separately (the file's escape list)
           if (run >> mfx_p_bits(t.k)) { if (v[i]) ++T.wide; v[i] = 0u; }      // (a damaged record: wider than any P of this k)
-          if (placed) pr[i] = mfx_home_placed(t, key[i], top, hi, pm);
+          if (placed && t.quot) pr[i] = mfx_home_placed(t, key[i], top, hi, pm);     // (k <= 21: the first mini-bucket needs the t-mer's offset: mfx_home scans for it)
         }
       }
-      mfx_apply_batch<4>(t, key, v, side, meta, T, placed ? pr : nullptr);
+      mfx_apply_batch<4>(t, key, v, side, meta, T, (placed && t.quot) ? pr : nullptr, placed != 0);
     }
   }
   mfx_tally_flush(meta, T);

@@ -3,7 +3,8 @@
 // The compact layout of a sequence-only index (mfx_kernels.hip) puts a canonical k-mer into the 128-byte line of its
 // MOD-MINIMIZER: of its four windows of m = k - 3 bases the one sampled by the k-mer's smallest t-mer (mfx_mod_window), as a
 // canonical m-mer c.  The line is taken from the high bits of a BIJECTION of c -- top = mix(low 32 bits of c) ^ (high bits * C),
-// line = (top * nlines) >> 32 -- and the first mini-bucket from the window j and three more bits of top.  So the pieces
+// line = (top * nlines) >> 32 -- and the first mini-bucket from where in the k-mer the minimizer stands and three more bits of top
+// (quotient form: its window and strand, mfx_p_bucket; direct form: the sampling t-mer's offset, mfx_mod_place).  So the pieces
 //     c (2m bits), s (c stands reversed in the k-mer), j (its window, 0..3), e (the 3 bases around it)
 // ARE the k-mer, one to one, and the 64-bit number
 //     P = top : 32 | high bits of c : 2m - 32 | s : 1 | j : 2 | e : 6                      (2k + 3 bits for k >= 19: k <= 30)
@@ -80,11 +81,12 @@ MFX_PHD uint32_t mfx_p_unmix(uint32_t top, uint32_t hi) {
   return u * 0x0E8B2F51u;
 }
 
-// Line and first mini-bucket of a minimizer's `top`.  The mini-bucket comes from WHERE the minimizer stands -- the window counted in
-// the orientation in which the minimizer reads canonical: j if it stands as it is in the (canonical) k-mer, 3 - j if it stands reversed.
-// The up to four k-mers around one occurrence of a minimizer see it at four different such places whatever strand each of THEM is
-// canonical on (with j alone a k-mer at window 3 and a reverse-canonical one at window 0 meet in one mini-bucket: measured, +25 wave
-// instructions per k-mer in the -hist kernel for the displaced queries that makes), so they start at four different mini-buckets.
+// Line of a minimizer's `top`, and the first mini-bucket of the QUOTIENT form (22 <= k <= 31; the direct form takes the sampling
+// t-mer's offset instead: mfx_kernels.hip, mfx_mod_place).  The mini-bucket comes from WHERE the minimizer stands -- the window counted
+// in the orientation in which the minimizer reads canonical: j if it stands as it is in the (canonical) k-mer, 3 - j if it stands
+// reversed.  The up to four k-mers around one occurrence of a minimizer see it at four different such places whatever strand each of
+// THEM is canonical on (with j alone a k-mer at window 3 and a reverse-canonical one at window 0 meet in one mini-bucket), so they start
+// at four different mini-buckets.
 MFX_PHD uint32_t mfx_p_line(uint32_t top, uint32_t nlines) { return (uint32_t)(((uint64_t)top * nlines) >> 32); }
 MFX_PHD uint32_t mfx_p_bucket(uint32_t top, uint32_t j, uint32_t sbit) { return (2u * (sbit ? 3u - j : j) + (top >> 3)) & 7u; }
 
