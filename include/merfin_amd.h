@@ -539,6 +539,14 @@ void     mfx_vcf_free(mfx_vcf *vcf);
 int mfx_variants_run_vcf(mfx_eval *ev, mfx_vcf *vcf, const char *const *names, const char *const *bases,
                          const uint64_t *lens, uint32_t ncontigs, const mfx_variant_opts *opts,
                          const char *out_path, const char *log_path, uint64_t *n_clusters);
+/* Stage A of the variant modes ahead of the run, on a loaded VCF: the clusters merged for k (vcfFile::mergeChrPosGT, vcf.C:156-246) and
+ * their allele combinations enumerated and packed batch by batch (merfin-variants.C:22-126, varMer.C:39) -- host work that needs the VCF
+ * and the sequences but neither the index nor a device (merfin does it after load_Kmers, merfin-variants.C:131-230; here a caller runs it
+ * under its index build).  The run -- mfx_variants_run_vcf on the same handle with the same sequences, k (the index's), opts->comb and
+ * opts->nosplit: anything else is refused -- then starts at the lookups; its outputs are the unprepared run's byte for byte.  The
+ * sequences must stay where they are until the run is over.  Once per handle. */
+int mfx_vcf_prepare(mfx_vcf *vcf, int k, const char *const *names, const char *const *bases, const uint64_t *lens,
+                    uint32_t ncontigs, const mfx_variant_opts *opts);
 /* The same over an index sharded across nslots evaluators (slot d = shard d of nslots): every batch of path text is
  * scored by mfx_dump_values_sharded; clustering, enumeration, selectors and output are the code above. */
 int mfx_variants_run_sharded(mfx_eval *const *evs, uint32_t nslots, const char *vcf_path, const char *const *names,

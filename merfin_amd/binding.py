@@ -79,7 +79,7 @@ SYMBOLS = [
     "mfx_eval_create", "mfx_eval_free", "mfx_eval_nbins", "mfx_eval_debug_enable", "mfx_eval_debug_counters", "mfx_getK", "mfx_getKmetric", "mfx_histoQV",
     "mfx_hist_run", "mfx_hist_result_free", "mfx_hist_launch", "mfx_hist_launch_cyclic", "mfx_hist_result_from_counts",
     "mfx_hist_take_overflow", "mfx_hist_report",
-    "mfx_pack_bases", "mfx_host_threads_share", "mfx_dump_values", "mfx_dump_contig", "mfx_dump_values_sharded", "mfx_dump_contig_sharded", "mfx_variants_run_sharded", "mfx_vcf_load", "mfx_vcf_free", "mfx_variants_run_vcf", "mfx_completeness", "mfx_completeness_pieces", "mfx_variants_run",
+    "mfx_pack_bases", "mfx_host_threads_share", "mfx_dump_values", "mfx_dump_contig", "mfx_dump_values_sharded", "mfx_dump_contig_sharded", "mfx_variants_run_sharded", "mfx_vcf_load", "mfx_vcf_free", "mfx_variants_run_vcf", "mfx_vcf_prepare", "mfx_completeness", "mfx_completeness_pieces", "mfx_variants_run",
     "mfx_index_set_shard", "mfx_router_create", "mfx_router_free", "mfx_route_tiles", "mfx_hist_keys_launch",
 ]
 
@@ -217,6 +217,7 @@ def load_library():
     L.mfx_vcf_free.argtypes = [vp]
     L.mfx_variants_run_vcf.argtypes = [vp, vp, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), u64p, C.c_uint32,
                                        C.POINTER(_VarOpts), C.c_char_p, C.c_char_p, u64p]
+    L.mfx_vcf_prepare.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), u64p, C.c_uint32, C.POINTER(_VarOpts)]
     L.mfx_index_set_fingerprint.argtypes = [vp, C.c_uint64]
     L.mfx_index_get_origin.argtypes = [vp, u64p, u64p, u64p]
     L.mfx_host_threads_share.restype = None
@@ -956,6 +957,16 @@ class LoadedVcf:
 
     def __init__(self, path):
         self.h = _need(load_library().mfx_vcf_load(path.encode()))
+
+    def prepare(self, k, mode, names, contigs, comb=15, nosplit=False, debug_path=None):
+        """the clusters merged and their allele combinations enumerated and packed ahead of the run (mfx_vcf_prepare: host work, no
+        index, no device); Evaluator.variants_loaded on this handle with the same k / comb / nosplit / contigs then starts at the lookups"""
+        n = len(contigs)
+        nm = (C.c_char_p * n)(*[x.encode() for x in names])
+        arr = (C.c_char_p * n)(*contigs)
+        lens = np.array([len(c) for c in contigs], dtype=np.uint64)
+        o = _VarOpts(VARIANT_MODES[mode], comb, 1 if nosplit else 0, debug_path.encode() if debug_path else None)
+        _check(load_library().mfx_vcf_prepare(self.h, int(k), nm, arr, lens.ctypes.data_as(C.POINTER(C.c_uint64)), n, C.byref(o)))
 
     def close(self):
         if self.h:

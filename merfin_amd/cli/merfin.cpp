@@ -828,10 +828,27 @@ int main(int argc, char **argv) {
     const char *vs = getenv("MFX_VARIANT_SLOTS");
     const size_t slots = (vs && atoi(vs) > 0) ? (size_t)atoi(vs) : G.devices.size();
     const char *pa = getenv("MFX_CLI_VCF_AHEAD");
+    const bool dbgAhead = G.debug;
     if (variantMode && G.vcfName && slots == 1 && !G.sharded && !(pa && atoi(pa) == 0))
-      vcfAhead = std::async(std::launch::async, [&G, &vcfAheadError]() {
+      vcfAhead = std::async(std::launch::async, [&G, &vcfAheadError, &recs, &bases, &lens, k, dbgAhead]() {
         mfx_vcf *v = mfx_vcf_load(G.vcfName);
-        if (!v) vcfAheadError = mfx_last_error();                  // (errors are per thread: carried to the caller's)
+        if (!v) { vcfAheadError = mfx_last_error(); return v; }    // (errors are per thread: carried to the caller's)
+        // ... and its clusters merged, their allele combinations enumerated and packed (stage A of the run: it needs the sequences,
+        // not the index; MFX_CLI_VCF_AHEAD=1: the load alone)
+        const char *pa2 = getenv("MFX_CLI_VCF_AHEAD");
+        if (pa2 && atoi(pa2) == 1) return v;
+        std::vector<const char *> nm(recs.size());
+        for (size_t c = 0; c < recs.size(); ++c) nm[c] = recs[c].name.c_str();
+        mfx_variant_opts o;
+        o.mode = G.reportType;
+        o.comb = G.comb;
+        o.nosplit = G.nosplit ? 1 : 0;
+        o.debug_path = dbgAhead ? "-" : nullptr;                   // (only whether it is set matters here)
+        if (mfx_vcf_prepare(v, k, nm.data(), bases.data(), lens.data(), (uint32_t)recs.size(), &o)) {
+          vcfAheadError = mfx_last_error();
+          mfx_vcf_free(v);
+          v = nullptr;
+        }
         return v;
       });
   }

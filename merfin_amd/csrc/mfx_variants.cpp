@@ -33,6 +33,7 @@
 #include <type_traits>
 #include <chrono>
 #include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <exception>
 #include <functional>
@@ -433,10 +434,13 @@ int load_vcf(const char *path, VcfDB &db, double *t_sub = nullptr) {   // t_sub[
 }  // namespace
 
 // a VCF read and parsed ahead of its run (mfx_vcf_load): host work only, so it can run under the index build
+namespace { struct VarPrepared; }
 struct mfx_vcf {
   VcfDB db;
   double t_load[4] = {0, 0, 0, 0};
   bool used = false;
+  VarPrepared *prep = nullptr;            // mfx_vcf_prepare: the clusters merged, their paths enumerated and packed batch by batch
+  ~mfx_vcf();
 };
 
 namespace {
@@ -616,6 +620,45 @@ struct Job {                          // one cluster waiting for its GPU values
   uint32_t rStart, rEnd;
   PathSet ps;                         // its paths, inside the arena of its run of clusters
   std::string dbg;                    // -debug lines of this cluster (appended to its run's text by the worker)
+};
+
+// A batch of clusters goes through three stages: A = its paths are enumerated and packed (host threads), B = every path k-mer
+// is looked up with ONE GPU launch, C = the selectors run (host threads) and the records are written in input order.  Two
+// batches are in flight: stage B of a batch runs (on its own thread: upload, kernel, download) under stage C of the batch
+// before it and under the queueing of the next one.
+struct VarBatch {
+  std::vector<Job> jobs;
+  std::string packed;
+  std::vector<uint32_t> rv, av;
+  // device-side scoring (`scores`): the batch's paths, one entry per path, and what came back
+  std::vector<uint64_t> p_off, p_voff, p_cfirst;
+  std::vector<uint32_t> p_len, p_nv, p_vidx, p_vlen, numM;
+  std::vector<int32_t> p_gt;
+  std::vector<double> totdk;
+  std::vector<PathArena> arenas;    // one per run of RUN consecutive jobs; their capacity is kept from batch to batch
+  size_t nruns = 0;
+  uint64_t total = 0, npaths = 0, nvals = 0;     // of stage A: packed bytes, paths, row entries
+  bool tables = false;              // stage A made the path table (p_*)
+  bool scored = false;              // varMer::score of this batch runs on the device (numM / totdk above)
+  std::string err;                  // the error text of stage B (errors are per thread: it is carried back to the caller's)
+  std::string prelude;              // (a prepared batch) what the log received while its clusters were queued
+  bool live = false;
+  // stage B of this batch (shared: the next batch's stage B waits for it too).  Declared LAST: a batch that is destroyed while its
+  // stage B still runs (an exception unwinding the run) blocks in the future's destructor before anything the task writes
+  // (err, the value arrays) is gone -- and the run's guard waits for every batch before any is destroyed.
+  std::shared_future<int> gpu;
+};
+
+// What mfx_vcf_prepare leaves for the run: stage A of EVERY batch (host work that needs the VCF and the sequences but not the
+// index: it runs under the index build), and the log text in the order the run would have produced it.
+struct VarPrepared {
+  uint32_t k = 0, comb = 0, ncontigs = 0;
+  int nosplit = 0;
+  bool with_tables = false;
+  std::vector<uint64_t> lens;
+  std::string head_log, tail_log;   // clustering's lines; what was logged after the last batch was queued
+  std::deque<VarBatch> batches;
+  double t_phase[3] = {0, 0, 0};    // cluster, enumerate, pack (seconds; diagnostics)
 };
 
 // dynamic parallel-for over [0, n) on the host threads the library may use
@@ -808,17 +851,38 @@ using PathScores = std::function<int(const char *, uint64_t, const mfx_path_tabl
 int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const char *vcf_path, const char *const *names, const char *const *bases,
                          const uint64_t *lens, uint32_t ncontigs, const mfx_variant_opts *opts,
                          const char *out_path, const char *log_path, uint64_t *n_clusters, const PathScores &scores = PathScores(),
-                         mfx_vcf *loaded = nullptr) {
-  if (!ev || (!vcf_path && !loaded) || !opts || !out_path || (ncontigs && (!names || !bases || !lens)))
+                         mfx_vcf *loaded = nullptr, uint32_t prepK = 0) {
+  // prepK != 0: PREPARE only (mfx_vcf_prepare) -- the clusters of `loaded` are merged for k = prepK and stage A of every batch is run and
+  // kept in loaded->prep; no evaluator, no output.  A later run on `loaded` starts from there.
+  const bool prepare_only = prepK != 0;
+  if (prepare_only ? (!loaded || !opts || (ncontigs && (!names || !bases || !lens)))
+                   : (!ev || (!vcf_path && !loaded) || !opts || !out_path || (ncontigs && (!names || !bases || !lens))))
     return mfx_fail(MFX_E_INVAL, "mfx_variants_run: null argument");
   const int mode = opts->mode;
   if (mode < MFX_VAR_FILTER || mode > MFX_VAR_LOOSE) return mfx_fail(MFX_E_INVAL, "mfx_variants_run: unknown mode %d", mode);
-  if (ev->ix->seq_only)      // the alternative paths ask for k-mers the sequence does not hold (varMer.C:76-84)
+  if (!prepare_only && ev->ix->seq_only)      // the alternative paths ask for k-mers the sequence does not hold (varMer.C:76-84)
     return mfx_fail(MFX_E_INVAL, "mfx_variants_run: a sequence-only index holds the k-mers of one sequence; the variant modes need a full index (mfx_index_create)");
-  const uint32_t K = (uint32_t)ev->ix->k;
+  const uint32_t K = prepare_only ? prepK : (uint32_t)ev->ix->k;
   const uint32_t comb = opts->comb ? opts->comb : 15;
-  FILE *log = log_path ? fopen(log_path, "w") : stderr;
-  if (!log) return mfx_fail(MFX_E_IO, "cannot open '%s'", log_path);
+  // a prepared VCF: its stage A was run for one k / -comb / -nosplit and one set of sequences
+  VarPrepared *const prep = (!prepare_only && loaded) ? loaded->prep : nullptr;
+  if (prep) {
+    bool same = prep->k == K && prep->comb == comb && prep->nosplit == (opts->nosplit != 0) && prep->ncontigs == ncontigs;
+    for (uint32_t c = 0; c < ncontigs && same; ++c) same = prep->lens[c] == lens[c];
+    if (!same) return mfx_fail(MFX_E_INVAL, "mfx_variants_run_vcf: the VCF was prepared for another k, -comb, -nosplit or set of sequences");
+  }
+  char *mem_log = nullptr;
+  size_t mem_log_n = 0;
+  FILE *log = prepare_only ? open_memstream(&mem_log, &mem_log_n) : (log_path ? fopen(log_path, "w") : stderr);
+  if (!log) return mfx_fail(MFX_E_IO, "cannot open '%s'", log_path ? log_path : "(memory)");
+  struct MemLog { char *&p; ~MemLog() { free(p); } } memLogGuard{mem_log};       // (destroyed after `files` below closed the stream)
+  size_t mem_taken = 0;
+  auto take_log = [&]() -> std::string {                                          // what the memory log received since the last call
+    fflush(log);
+    std::string t(mem_log + mem_taken, mem_log_n - mem_taken);
+    mem_taken = mem_log_n;
+    return t;
+  };
   // whatever way this function is left (an exception of the host pipeline included: variants_guarded turns it into an error code),
   // the files are closed: the normal path closes them itself, checks the result and disarms the guard
   struct Files {
@@ -842,68 +906,67 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
   // the records: read and parsed here, or handed in by mfx_vcf_load (then that work ran under the caller's index build)
   VcfDB own_db;
   if (loaded && loaded->used) { return mfx_fail(MFX_E_INVAL, "mfx_variants_run_vcf: a loaded VCF serves one run (clustering rearranges it); load it again"); }
+  if (prepare_only && loaded->prep) return mfx_fail(MFX_E_INVAL, "mfx_vcf_prepare: the VCF is prepared already");
   VcfDB &db = loaded ? loaded->db : own_db;
   double t_load[4] = {0, 0, 0, 0};
   int rc = MFX_OK;
-  if (loaded) { loaded->used = true; memcpy(t_load, loaded->t_load, sizeof(t_load)); }
+  if (loaded) { loaded->used = !prepare_only; memcpy(t_load, loaded->t_load, sizeof(t_load)); }
   else rc = load_vcf(vcf_path, db, t_load);
   if (rc) return rc;
-  fprintf(log, "   Collected %zu header lines.\n   Loaded %zu records:\n      %-8lu unique contig%s\n      %-8u contig IDs\n   Excluded %lu invalid records\n\n",
-          db.headers.size(), db.n_records, db.by_chr.size(), db.by_chr.size() == 1 ? "" : "s", (unsigned)db.contig_ids, (unsigned long)db.excluded);
-  fprintf(log, "Merge variants within %u-mer bases, splitting combinations greater than %u.\n", K, comb);
-  merge_clusters(db, K, comb, opts->nosplit != 0, log);
+  if (prep) fwrite(prep->head_log.data(), 1, prep->head_log.size(), log);   // (the same lines, written when they were made)
+  else {
+    fprintf(log, "   Collected %zu header lines.\n   Loaded %zu records:\n      %-8lu unique contig%s\n      %-8u contig IDs\n   Excluded %lu invalid records\n\n",
+            db.headers.size(), db.n_records, db.by_chr.size(), db.by_chr.size() == 1 ? "" : "s", (unsigned)db.contig_ids, (unsigned long)db.excluded);
+    fprintf(log, "Merge variants within %u-mer bases, splitting combinations greater than %u.\n", K, comb);
+    merge_clusters(db, K, comb, opts->nosplit != 0, log);
+  }
   lap(0);
-
-  FILE *out = fopen(out_path, "w");
-  if (!out) return mfx_fail(MFX_E_IO, "cannot open '%s' for writing", out_path);
-  files.out = out;
-  for (auto &h : db.headers) fprintf(out, "%s\n", h.c_str());              // merfin-variants.C:332-333
-  mfx_file dbgh;
-  FILE *dbg = nullptr;
-  if (opts->debug_path) {
-    dbgh = mfx_open_writer(opts->debug_path, false);                       // compressedFileWriter, merfin-variants.C:149
-    dbg = dbgh.f;
-    files.dbgh = &dbgh;
+  VarPrepared *making = nullptr;                                           // (prepare) what this call fills
+  if (prepare_only) {
+    making = loaded->prep = new VarPrepared;
+    making->k = K; making->comb = comb; making->nosplit = opts->nosplit != 0; making->ncontigs = ncontigs;
+    making->lens.assign(lens, lens + ncontigs);
+    making->with_tables = opts->debug_path == nullptr;
+    making->head_log = take_log();
   }
 
-  mfx_kparams kp{ev->peak, ev->n_prob, ev->probK.data(), ev->probP.data()};
+  FILE *out = nullptr;
+  mfx_file dbgh;
+  FILE *dbg = nullptr;
+  if (!prepare_only) {
+    out = fopen(out_path, "w");
+    if (!out) return mfx_fail(MFX_E_IO, "cannot open '%s' for writing", out_path);
+    files.out = out;
+    for (auto &h : db.headers) fprintf(out, "%s\n", h.c_str());            // merfin-variants.C:332-333
+    if (opts->debug_path) {
+      dbgh = mfx_open_writer(opts->debug_path, false);                     // compressedFileWriter, merfin-variants.C:149
+      dbg = dbgh.f;
+      files.dbgh = &dbgh;
+    }
+  }
+
+  mfx_kparams kp{0.0, 0, nullptr, nullptr};
   // readK and prob depend on the read count alone (merfin-globals.C:80-97): evaluated once for the counts that occur all
   // the time, by the same routine the scoring loop would call (identical doubles)
   constexpr uint32_t KLUT = 4096;
-  std::vector<double> lutK(KLUT), lutP(KLUT);
-  for (uint32_t v = 0; v < KLUT; ++v) { double a; mfx_getK(&kp, v, 0, &lutK[v], &a, &lutP[v]); }
+  std::vector<double> lutK, lutP;
+  if (!prepare_only) {
+    kp = mfx_kparams{ev->peak, ev->n_prob, ev->probK.data(), ev->probP.data()};
+    lutK.resize(KLUT); lutP.resize(KLUT);
+    for (uint32_t v = 0; v < KLUT; ++v) { double a; mfx_getK(&kp, v, 0, &lutK[v], &a, &lutP[v]); }
+  }
   uint64_t clusters = 0, varMerId = 0;
   const uint64_t BATCH_BYTES = (getenv("MFX_VAR_BATCH_MB") ? (uint64_t)atoi(getenv("MFX_VAR_BATCH_MB")) : 64ull) << 20;   // packed path text per GPU launch
 
-  // A batch of clusters goes through three stages: A = its paths are enumerated and packed (host threads), B = every path k-mer
-  // is looked up with ONE GPU launch, C = the selectors run (host threads) and the records are written in input order.  Two
-  // batches are in flight: stage B of a batch runs (on its own thread: upload, kernel, download) under stage C of the batch
-  // before it and under the queueing of the next one.
-  struct Batch {
-    std::vector<Job> jobs;
-    std::string packed;
-    std::vector<uint32_t> rv, av;
-    // device-side scoring (`scores`): the batch's paths, one entry per path, and what came back
-    std::vector<uint64_t> p_off, p_voff, p_cfirst;
-    std::vector<uint32_t> p_len, p_nv, p_vidx, p_vlen, numM;
-    std::vector<int32_t> p_gt;
-    std::vector<double> totdk;
-    std::vector<PathArena> arenas;    // one per run of RUN consecutive jobs; their capacity is kept from batch to batch
-    size_t nruns = 0;
-    bool scored = false;              // varMer::score of this batch runs on the device (numM / totdk above)
-    std::string err;                  // the error text of stage B (errors are per thread: it is carried back to the caller's)
-    bool live = false;
-    // stage B of this batch (shared: the next batch's stage B waits for it too).  Declared LAST: a batch that is destroyed while its
-    // stage B still runs (an exception unwinding this function) blocks in the future's destructor before anything the task writes
-    // (err, the value arrays) is gone -- and the guard below waits for both batches before either is destroyed.
-    std::shared_future<int> gpu;
-  } batches[2];
-  struct StageBGuard { Batch (&b)[2]; ~StageBGuard() { for (Batch &x : b) if (x.gpu.valid()) x.gpu.wait(); } } stageBGuard{batches};
-  int cur_b = 0;
-  batches[0].jobs.reserve(65536);
-  batches[1].jobs.reserve(65536);
+  // the batches (VarBatch): two that take turns, or -- preparing / prepared -- one per batch of the whole call set
+  std::deque<VarBatch> own_batches;
+  std::deque<VarBatch> &batches = making ? making->batches : prep ? prep->batches : own_batches;
+  if (!prep) { batches.resize(making ? 1 : 2); for (VarBatch &b : batches) b.jobs.reserve(65536); }
+  struct StageBGuard { std::deque<VarBatch> &b; ~StageBGuard() { for (VarBatch &x : b) if (x.gpu.valid()) x.gpu.wait(); } } stageBGuard{batches};
+  using Batch = VarBatch;
+  size_t cur_b = 0;
   std::vector<char> out_buf(4u << 20);
-  setvbuf(out, out_buf.data(), _IOFBF, out_buf.size());
+  if (out) setvbuf(out, out_buf.data(), _IOFBF, out_buf.size());
   // The records of a batch (a few hundred MB for a human call set) are written by their own thread, batch by batch in order,
   // under the stages of the next batches: config 4 spent 0.6 s of its 2.5 s inside fwrite on the thread that drives the stages.
   struct Writer {
@@ -938,7 +1001,7 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
   // records / -debug lines / log lines are concatenated by the worker that scores it (stage C), so that the writer issues
   // one write per run, not per cluster
   constexpr size_t RUN = 256;
-  auto stage_ab = [&](Batch &bt) -> int {
+  auto stage_a = [&](Batch &bt, bool want_tables) {
     std::vector<Job> &jobs = bt.jobs;
     std::string &packed = bt.packed;
     lap(6);                                                              // (the clusters were queued since the last lap)
@@ -989,13 +1052,11 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
       if (!ar.text.empty()) memcpy(&packed[ar.off], ar.text.data(), ar.text.size());
     });
     lap(2);
-    bt.live = true;
-    bt.scored = false;
-    bt.gpu = std::shared_future<int>();                                  // (a shared future stays valid after get(): this batch has none yet)
-    const bool on_device = (bool)scores && dbg == nullptr;               // -debug wants the per-position values: scored on the host
-    if (total && on_device) {
+    bt.total = total; bt.npaths = np; bt.nvals = nvals;
+    bt.tables = false;
+    if (total && want_tables) {
       // the path table of the batch: one entry per path, the variants' rows concatenated
-      bt.scored = true;
+      bt.tables = true;
       bt.p_off.resize(np); bt.p_voff.resize(np); bt.p_cfirst.resize(np); bt.p_len.resize(np); bt.p_nv.resize(np);
       bt.p_gt.resize(nvals); bt.p_vidx.resize(nvals); bt.p_vlen.resize(nvals);
       bt.numM.resize(np); bt.totdk.resize(np);
@@ -1020,9 +1081,21 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
         }
       });
       lap(2);
+    }
+  };
+  // the launch of stage B; prevb: the batch whose stage B runs before this one's (nullptr: none)
+  auto stage_b = [&](Batch &bt, Batch *prevb) -> int {
+    const std::string &packed = bt.packed;
+    const uint64_t total = bt.total, nvals = bt.nvals;
+    bt.live = true;
+    bt.scored = false;
+    bt.gpu = std::shared_future<int>();                                  // (a shared future stays valid after get(): this batch has none yet)
+    const bool on_device = (bool)scores && dbg == nullptr && bt.tables;  // -debug wants the per-position values: scored on the host
+    if (total && on_device) {
+      bt.scored = true;
       Batch *bp = &bt;
       const int need_dk = mode == MFX_VAR_POLISH ? 1 : 0;
-      std::shared_future<int> prev = batches[&bt == &batches[0] ? 1 : 0].gpu;
+      std::shared_future<int> prev = prevb ? prevb->gpu : std::shared_future<int>();
       bt.gpu = std::async(std::launch::async, [bp, prev, need_dk, nvals, &scores]() mutable {
         if (prev.valid()) prev.wait();                                   // one stage B at a time on the evaluator
         prev = std::shared_future<int>();                                // (let go of the earlier batch's state: no chain of all batches so far)
@@ -1041,7 +1114,7 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
       // one stage B at a time on the evaluator(s): it still runs under stages A and C of its neighbours on the host, but two
       // values() calls never hold their device buffers (path text + two value arrays each) at once, and the sharded form
       // (mfx_dump_values_sharded: per-slot scratch, peer copies) is never entered twice
-      std::shared_future<int> prev = batches[&bt == &batches[0] ? 1 : 0].gpu;
+      std::shared_future<int> prev = prevb ? prevb->gpu : std::shared_future<int>();
       bt.gpu = std::async(std::launch::async, [bp, prev, &values]() mutable {
         if (prev.valid()) prev.wait();
         prev = std::shared_future<int>();
@@ -1169,15 +1242,42 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
     return MFX_OK;
   };
 
-  // the queued clusters start their stages A and B; the batch before them finishes (its stage C)
+  // the queued clusters start their stages A and B; the batch before them finishes (its stage C).  Preparing: stage A only, and the
+  // next batch gets a structure of its own.
   auto flush = [&]() -> int {
     if (batches[cur_b].jobs.empty()) return MFX_OK;
-    int r = stage_ab(batches[cur_b]);
+    if (making) {
+      batches[cur_b].prelude = take_log();
+      stage_a(batches[cur_b], making->with_tables);
+      batches.emplace_back();
+      cur_b = batches.size() - 1;
+      batches[cur_b].jobs.reserve(65536);
+      return MFX_OK;
+    }
+    stage_a(batches[cur_b], (bool)scores && dbg == nullptr);
+    int r = stage_b(batches[cur_b], &batches[cur_b ^ 1]);
     const int r2 = stage_c(batches[cur_b ^ 1]);
     cur_b ^= 1;
     return r ? r : r2;
   };
 
+  if (prep) {
+    // stage A was run ahead (mfx_vcf_prepare): every batch's stage B is launched behind the one before it, under that one's stage C
+    // -- the log receives what it would have, in the same order
+    t_mark = now();
+    for (size_t i = 0; i < batches.size() && rc == MFX_OK; ++i) {
+      if (batches[i].jobs.empty()) continue;                            // (the structure made for a batch that never came)
+      fwrite(batches[i].prelude.data(), 1, batches[i].prelude.size(), log);
+      rc = stage_b(batches[i], i ? &batches[i - 1] : nullptr);
+      if (i) { const int r2 = stage_c(batches[i - 1]); if (rc == MFX_OK) rc = r2; }
+      cur_b = i;
+    }
+    if (rc == MFX_OK) fwrite(prep->tail_log.data(), 1, prep->tail_log.size(), log);
+    const int r2 = stage_c(batches[cur_b]);
+    if (rc == MFX_OK) rc = r2;
+    for (Batch &bt : batches) if (bt.gpu.valid()) (void)bt.gpu.get();
+    t_phase[0] += prep->t_phase[0]; t_phase[1] += prep->t_phase[1]; t_phase[2] += prep->t_phase[2];
+  } else {
   uint64_t est_bytes = 0;
   for (uint32_t c = 0; c < ncontigs && rc == MFX_OK; ++c) {
     auto it = db.by_chr.find(names[c]);
@@ -1217,10 +1317,21 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
     }
   }
   if (rc == MFX_OK) rc = flush();
+  if (making) {
+    making->tail_log = take_log();
+    making->t_phase[0] = t_phase[0]; making->t_phase[1] = t_phase[1]; making->t_phase[2] = t_phase[2];
+    if (timing) fprintf(stderr, "[mfx_variants] prepared ahead: cluster %.2fs  enumerate %.2fs  pack %.2fs  (%zu batches)\n", t_phase[0], t_phase[1], t_phase[2],
+                        batches.size() - 1);
+    files.log = nullptr;
+    fclose(log);
+    if (n_clusters) *n_clusters = 0;
+    return rc;
+  }
   {
     const int r2 = stage_c(batches[cur_b ^ 1]);              // the last batch launched (after an error: its GPU work is waited for, nothing is written twice)
     if (rc == MFX_OK) rc = r2;
     for (Batch &bt : batches) if (bt.gpu.valid()) (void)bt.gpu.get();
+  }
   }
   lap(5);
   if (timing)
@@ -1283,7 +1394,23 @@ extern "C" mfx_vcf *mfx_vcf_load(const char *vcf_path) {
   return v;
 }
 
+mfx_vcf::~mfx_vcf() { delete prep; }
+
 extern "C" void mfx_vcf_free(mfx_vcf *v) { delete v; }
+
+// Stage A of the variant modes AHEAD of the run, on a loaded VCF: the clusters merged for k, their allele combinations enumerated
+// (merfin-variants.C:22-126, varMer.C:39) and packed batch by batch -- host work that needs the VCF and the sequences but neither the
+// index nor the device, so a caller runs it next to mfx_vcf_load under its index build (config 4 at 3 Gb: 0.3 s of the 0.8 s behind the
+// build).  The run (mfx_variants_run_vcf on the same handle, the same sequences, k, -comb, -nosplit: checked) starts at stage B; its
+// outputs are the unprepared run's byte for byte.  opts->debug_path set: the path tables of the device scoring are not made (-debug is
+// scored on the host).
+extern "C" int mfx_vcf_prepare(mfx_vcf *vcf, int k, const char *const *names, const char *const *bases, const uint64_t *lens,
+                               uint32_t ncontigs, const mfx_variant_opts *opts) {
+  if (!vcf || !opts || k < 1 || k > MFX_MAX_K) return mfx_fail(MFX_E_INVAL, "mfx_vcf_prepare: null argument or k out of range");
+  return variants_guarded("mfx_vcf_prepare", [&] {
+    return mfx_variants_run_values(nullptr, PathValues(), nullptr, names, bases, lens, ncontigs, opts, nullptr, nullptr, nullptr, PathScores(), vcf, (uint32_t)k);
+  });
+}
 
 extern "C" int mfx_variants_run_vcf(mfx_eval *ev, mfx_vcf *vcf, const char *const *names, const char *const *bases,
                                     const uint64_t *lens, uint32_t ncontigs, const mfx_variant_opts *opts,

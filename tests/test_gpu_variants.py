@@ -177,3 +177,71 @@ def test_variants_on_a_vcf_loaded_ahead(tmp_path, mode):
     with pytest.raises(m.MfxError):                            # clustering rearranged it: one run per load
         ev.variants_loaded(mode, loaded, names, asm, str(tmp_path / "c.vcf"), log_path=str(tmp_path / "c.log"))
     loaded.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("batch_mb", [None, "0"])
+def test_variants_prepared_ahead(tmp_path, monkeypatch, mode, batch_mb):
+    """mfx_vcf_prepare (clusters merged, combinations enumerated and packed before any index exists: what the CLI runs under its index
+    build; merfin does it after load_Kmers, merfin-variants.C:131-230) + mfx_variants_run_vcf == mfx_variants_run, records and log byte
+    for byte -- with the default batches and with one cluster per batch (MFX_VAR_BATCH_MB=0: the order of the log's lines across batches)"""
+    import merfin_amd as m
+    if batch_mb is not None:
+        monkeypatch.setenv("MFX_VAR_BATCH_MB", batch_mb)
+    k, peak = 21, 17.3
+    names, asm, vcf, read, amers = synth.variant_world(k=k, peak=peak, seed=78)
+    vp = str(tmp_path / "in.vcf")
+    open(vp, "w").write(vcf)
+    loaded = m.LoadedVcf(vp)
+    loaded.prepare(k, mode, names, asm)                        # no index, no device
+    with pytest.raises(m.MfxError):
+        loaded.prepare(k, mode, names, asm)                    # once per handle
+    ix = m.Index(k, len(read[0]) + len(amers[0]) + 16)
+    ix.add_read(*read)
+    ix.add_asm(*amers)
+    ev = m.Evaluator(ix, m.KParams(peak))
+    n_a = ev.variants(mode, vp, names, asm, str(tmp_path / "a.vcf"), log_path=str(tmp_path / "a.log"))
+    with pytest.raises(m.MfxError):                            # prepared for -comb 15: another one is refused, the handle stays usable
+        ev.variants_loaded(mode, loaded, names, asm, str(tmp_path / "x.vcf"), comb=3, log_path=str(tmp_path / "x.log"))
+    n_b = ev.variants_loaded(mode, loaded, names, asm, str(tmp_path / "b.vcf"), log_path=str(tmp_path / "b.log"))
+    assert n_a == n_b and n_a > 0
+    assert open(tmp_path / "a.vcf", "rb").read() == open(tmp_path / "b.vcf", "rb").read()
+    assert open(tmp_path / "a.log", "rb").read() == open(tmp_path / "b.log", "rb").read()
+    loaded.close()
+
+
+@pytest.mark.gpu
+def test_variants_prepared_ahead_debug_and_odd_records(tmp_path):
+    """the prepared run with -debug (scored on the host from the per-base values) and a call set with clusters beyond -comb, records of
+    unknown contigs and regions past a contig's end: same records, -debug lines and log as the unprepared run"""
+    import merfin_amd as m
+    k, peak = 21, 17.3
+    names, asm, vcf, read, amers = synth.variant_world(k=k, peak=peak, seed=79, burst=0.3)
+    vp = str(tmp_path / "in.vcf")
+    lines = vcf.rstrip("\n").split("\n")
+    body = [x for x in lines if not x.startswith("#")]
+    extra = []
+    for x in body[:5]:
+        w = x.split("\t")
+        w[0] = "chrUnknown"
+        extra.append("\t".join(w))
+    w = body[-1].split("\t")
+    w[1] = str(len(asm[names.index(w[0])]) + 5)                  # past the contig's end
+    extra.append("\t".join(w))
+    open(vp, "w").write("\n".join(lines + extra) + "\n")
+    ix = m.Index(k, len(read[0]) + len(amers[0]) + 16)
+    ix.add_read(*read)
+    ix.add_asm(*amers)
+    ev = m.Evaluator(ix, m.KParams(peak))
+    for tag, comb in (("d", 15), ("c", 2)):
+        loaded = m.LoadedVcf(vp)
+        loaded.prepare(k, "polish", names, asm, comb=comb, debug_path=str(tmp_path / "unused"))
+        n_a = ev.variants("polish", vp, names, asm, str(tmp_path / (tag + "a.vcf")), comb=comb, debug_path=str(tmp_path / (tag + "a.dbg")),
+                          log_path=str(tmp_path / (tag + "a.log")))
+        n_b = ev.variants_loaded("polish", loaded, names, asm, str(tmp_path / (tag + "b.vcf")), comb=comb, debug_path=str(tmp_path / (tag + "b.dbg")),
+                                 log_path=str(tmp_path / (tag + "b.log")))
+        assert n_a == n_b
+        for ext in ("vcf", "dbg", "log"):
+            assert open(tmp_path / (tag + "a." + ext), "rb").read() == open(tmp_path / (tag + "b." + ext), "rb").read(), (tag, ext)
+        loaded.close()

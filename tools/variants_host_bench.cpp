@@ -14,7 +14,9 @@ using PathValues = std::function<int(const char *, uint64_t, uint32_t *, uint32_
 using PathScores = std::function<int(const char *, uint64_t, const mfx_path_table &, int, uint32_t *, double *)>;
 int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const char *vcf_path, const char *const *names, const char *const *bases,
                             const uint64_t *lens, uint32_t ncontigs, const mfx_variant_opts *opts, const char *out_path, const char *log_path,
-                            uint64_t *n_clusters, const PathScores &scores, struct mfx_vcf *loaded);
+                            uint64_t *n_clusters, const PathScores &scores, struct mfx_vcf *loaded, uint32_t prepK = 0);
+extern "C" int mfx_vcf_prepare(struct mfx_vcf *vcf, int k, const char *const *names, const char *const *bases, const uint64_t *lens, uint32_t ncontigs,
+                               const mfx_variant_opts *opts);
 extern "C" struct mfx_vcf *mfx_vcf_load(const char *vcf_path);
 extern "C" void mfx_vcf_free(struct mfx_vcf *);
 
@@ -118,8 +120,16 @@ int main(int argc, char **argv) {
   uint64_t ncl = 0;
   auto t0 = std::chrono::steady_clock::now();
   // argv[7] = 1: the VCF loaded ahead of the run (mfx_vcf_load), as the CLI does under its index build
+  // argv[7] = 2: ... and prepared (mfx_vcf_prepare: clusters merged, paths enumerated and packed ahead); argv[8]: tag of the output files
   struct mfx_vcf *ahead = (argc > 7 && atoi(argv[7])) ? mfx_vcf_load(vp) : nullptr;
-  int rc = mfx_variants_run_values(&ev, values, ahead ? nullptr : vp, nm.data(), bs.data(), ln.data(), nc, &vo, "/tmp/mfx_vhb.out.vcf", "/tmp/mfx_vhb.log", &ncl, dev ? scores : PathScores(), ahead);
+  if (ahead && atoi(argv[7]) == 2) {
+    if (mfx_vcf_prepare(ahead, ix.k, nm.data(), bs.data(), ln.data(), nc, &vo)) { fprintf(stderr, "prepare: %s\n", mfx_last_error()); return 1; }
+    printf("prepared in %.2f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    t0 = std::chrono::steady_clock::now();
+  }
+  const std::string tag = argc > 8 ? argv[8] : "";
+  const std::string outp = "/tmp/mfx_vhb" + tag + ".out.vcf", logp = "/tmp/mfx_vhb" + tag + ".log";
+  int rc = mfx_variants_run_values(&ev, values, ahead ? nullptr : vp, nm.data(), bs.data(), ln.data(), nc, &vo, outp.c_str(), logp.c_str(), &ncl, dev ? scores : PathScores(), ahead);
   if (ahead) mfx_vcf_free(ahead);
   double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   printf("rc %d: %lu bases, %lu calls, %lu clusters in %.2f s = %.0f clusters/s\n", rc, (unsigned long)total, (unsigned long)calls, (unsigned long)ncl, dt, ncl / dt);
