@@ -72,6 +72,7 @@ def write_inputs(m, st, torch, bases, outdir, ncontigs=24, k=21, lam=26.0, seed=
     del ek, er
     n_read = len(rk)
     del rk, rv
+    torch.cuda.empty_cache()                                   # (the caller measures OTHER processes next: nothing of this one's stays cached in HBM)
     log("read database written: %.1fs" % (time.time() - t0))
     fasta = os.path.join(outdir, "asm.fasta")
     with open(fasta, "wb") as f:
