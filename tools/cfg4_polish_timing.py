@@ -127,6 +127,19 @@ if len(sys.argv) > 3 and sys.argv[3] == "cli":
         print("merfin -polish MFX_VARIANT_SLOTS=%s: rc=%d wall=%.2fs same=%s" % (slots, r.returncode, dt, open(out + "/cli_s" + slots + ".polish.vcf").read() == a_))
         print("    " + "\n    ".join(l for l in r.stderr.splitlines() if "timing" in l or "ERROR" in l or "ingest" in l or "mfx_variants]" in l and "load:" not in l))
 
+    if os.environ.get("MFX_CFG4_AHEAD_AB"):
+        # stage A of the run prepared under the index build (the default) against the VCF load alone (MFX_CLI_VCF_AHEAD=1)
+        for ah in ("1", "2", "1", "2", "2"):
+            time.sleep(float(os.environ.get("MFX_CFG4_SLEEP", "0")))
+            t0 = time.time()
+            r = subprocess.run([exe, "-polish", "-sequence", out + "/asm.fasta", "-readmers", out + "/read.mfxk", "-seqmers", out + "/asm.mfxk", "-peak", str(lam),
+                                "-vcf", vcf, "-output", out + "/cli_ab" + ah], capture_output=True, text=True,
+                               env=dict(os.environ, MFX_CLI_TIMING="2", MFX_VARIANT_SLOTS="1", MFX_VAR_TIMING="1", MFX_CLI_VCF_AHEAD=ah))
+            dt = time.time() - t0
+            print("merfin -polish MFX_CLI_VCF_AHEAD=%s (%s): rc=%d wall=%.2fs same=%s" % (ah, "load + stage A ahead" if ah == "2" else "load ahead", r.returncode, dt,
+                                                                                       open(out + "/cli_ab" + ah + ".polish.vcf").read() == a_))
+            print("    " + "\n    ".join(l for l in r.stderr.splitlines() if "-- timing" in l or "ERROR" in l or "mfx_variants]" in l and "load:" not in l))
+
     if os.environ.get("MFX_CFG4_DIFF"):
         # the VCF loaded ahead (default) against MFX_CLI_VCF_AHEAD=0: the outputs, and where they differ
         outs = {}
