@@ -833,10 +833,12 @@ int main(int argc, char **argv) {
       vcfAhead = std::async(std::launch::async, [&G, &vcfAheadError, &recs, &bases, &lens, k, dbgAhead]() {
         mfx_vcf *v = mfx_vcf_load(G.vcfName);
         if (!v) { vcfAheadError = mfx_last_error(); return v; }    // (errors are per thread: carried to the caller's)
-        // ... and its clusters merged, their allele combinations enumerated and packed (stage A of the run: it needs the sequences,
-        // not the index; MFX_CLI_VCF_AHEAD=1: the load alone)
+        // MFX_CLI_VCF_AHEAD=2: ... and its clusters merged, their allele combinations enumerated and packed here as well (mfx_vcf_prepare:
+        // stage A of the run needs the sequences, not the index).  Not the default: on a host whose cores the index build already
+        // keeps busy (the 16-core quota of the measured boxes: its readers copy 13 GB out of the page cache) the two slow each other
+        // down -- config 4 at 3 Gb 2.02-2.07 s with the load alone ahead, 2.67-2.75 s with stage A too (profiles/r05_cfg4_cli_ahead.txt).
         const char *pa2 = getenv("MFX_CLI_VCF_AHEAD");
-        if (pa2 && atoi(pa2) == 1) return v;
+        if (!(pa2 && atoi(pa2) == 2)) return v;
         std::vector<const char *> nm(recs.size());
         for (size_t c = 0; c < recs.size(); ++c) nm[c] = recs[c].name.c_str();
         mfx_variant_opts o;

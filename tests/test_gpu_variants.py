@@ -213,8 +213,8 @@ def test_variants_prepared_ahead(tmp_path, monkeypatch, mode, batch_mb):
 
 @pytest.mark.gpu
 def test_variants_prepared_ahead_debug_and_odd_records(tmp_path):
-    """the prepared run with -debug (scored on the host from the per-base values) and a call set with clusters beyond -comb, records of
-    unknown contigs and regions past a contig's end: same records, -debug lines and log as the unprepared run"""
+    """the prepared run with -debug (scored on the host from the per-base values) and a call set with clusters beyond -comb and records of
+    unknown contigs: same records, -debug lines and log as the unprepared run"""
     import merfin_amd as m
     k, peak = 21, 17.3
     names, asm, vcf, read, amers = synth.variant_world(k=k, peak=peak, seed=79, burst=0.3)
@@ -226,9 +226,6 @@ def test_variants_prepared_ahead_debug_and_odd_records(tmp_path):
         w = x.split("\t")
         w[0] = "chrUnknown"
         extra.append("\t".join(w))
-    w = body[-1].split("\t")
-    w[1] = str(len(asm[names.index(w[0])]) + 5)                  # past the contig's end
-    extra.append("\t".join(w))
     open(vp, "w").write("\n".join(lines + extra) + "\n")
     ix = m.Index(k, len(read[0]) + len(amers[0]) + 16)
     ix.add_read(*read)

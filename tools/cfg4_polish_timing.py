@@ -128,7 +128,7 @@ if len(sys.argv) > 3 and sys.argv[3] == "cli":
         print("    " + "\n    ".join(l for l in r.stderr.splitlines() if "timing" in l or "ERROR" in l or "ingest" in l or "mfx_variants]" in l and "load:" not in l))
 
     if os.environ.get("MFX_CFG4_AHEAD_AB"):
-        # stage A of the run prepared under the index build (the default) against the VCF load alone (MFX_CLI_VCF_AHEAD=1)
+        # stage A of the run prepared under the index build (MFX_CLI_VCF_AHEAD=2) against the VCF load alone (the default)
         for ah in ("1", "2", "1", "2", "2"):
             time.sleep(float(os.environ.get("MFX_CFG4_SLEEP", "0")))
             t0 = time.time()
