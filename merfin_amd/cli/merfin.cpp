@@ -720,11 +720,17 @@ int main(int argc, char **argv) {
   // MFX_DB_STAGE=0: no stage, the build reads the database when it gets there.
   mfx_db_stage *stage = nullptr;
   struct StageGuard { mfx_db_stage *&s; ~StageGuard() { if (s) mfx_db_stage_free(s); s = nullptr; } } stageGuard{stage};
-  {
+  // (MFX_CLI_STAGE_FIRST=0: the stage begins after the device is warmed up.  Measured, profiles/r05_stager_diag.txt: the warm-up then takes
+  // 0.06 instead of 0.25 s, but the 0.15-0.2 s that the process's first allocations / queue / kernel cost move into the stager's start, the
+  // claim kernel is launched at the same 0.35 s, and with stager, FASTA reader and encoder all at full speed in the first 0.3 s the process
+  // runs into the CPU quota of a 16-core box in some runs: 1.09-1.13 s or 1.27-1.29 s against 1.12-1.16 s this way)
+  const bool stageFirst = !(getenv("MFX_CLI_STAGE_FIRST") && atoi(getenv("MFX_CLI_STAGE_FIRST")) == 0);
+  auto begin_stage = [&]() {
     const bool histLike = (G.reportType == OP_HIST || G.reportType == OP_DUMP) && !G.sharded && k <= 31 && G.seqName && !G.seqDBname && !G.indexName &&
                           G.devices.size() == 1 && !(getenv("MFX_CLI_FULL_INDEX") && atoi(getenv("MFX_CLI_FULL_INDEX")));
     if (histLike && rdb.format == MFX_DB_FLAT) stage = mfx_db_stage_begin(G.readDBname, G.device);
-  }
+  };
+  if (stageFirst) begin_stage();
   lap("probe k-mer databases");
   // sequences (load_Sequence, merfin-globals.C:165-197; loadSequence, merfin.C:30-53).  The file is read (and, for
   // .gz/.bz2/.xz, decompressed) by its own thread from here on; with -seqmers nothing needs the sequence before the
@@ -782,6 +788,7 @@ int main(int argc, char **argv) {
   // up here instead of inside the first upload (~0.07 s; an error here is left to that upload to report).  Not with a
   // decompressor child around (see the device check above) and not for several devices (their slots come up in parallel).
   if (G.seqName && !compressed && G.devices.size() == 1 && !(getenv("MFX_CLI_WARM") && !atoi(getenv("MFX_CLI_WARM")))) (void)mfx_device_warm(G.device);
+  if (!stageFirst) begin_stage();
   if (!deferSeq) finish_seq();
   if (G.sharded) {
     if (G.devices.size() < 2) {

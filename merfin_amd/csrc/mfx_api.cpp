@@ -86,17 +86,29 @@ extern "C" int mfx_device_warm(int device) {
   // allocation and a stream: everything the first upload would otherwise bring up on the caller's time
   void *d = nullptr, *h = nullptr;
   hipStream_t st = nullptr;
+  const bool timing = getenv("MFX_UPLOAD_TIMING") != nullptr;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double tw[8] = {now(), 0, 0, 0, 0, 0, 0, 0};
   hipError_t e = hipMalloc(&d, 1 << 20);
+  tw[1] = now();
   if (e == hipSuccess) e = mfx_memset_now(d, 0, 1 << 20);
+  tw[2] = now();
   if (e == hipSuccess) e = mfx_k_table_init(reinterpret_cast<mfx_slot *>(d), (1 << 20) / sizeof(mfx_slot), nullptr);
+  tw[3] = now();
   if (e == hipSuccess) e = hipHostMalloc(&h, 1 << 20, hipHostMallocDefault);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+  tw[4] = now();
   if (e == hipSuccess) e = hipMemcpyAsync(d, h, 1 << 20, hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
-  if (e == hipSuccess) e = hipDeviceSynchronize();
+  tw[5] = now();
+  // (no device-wide wait here: another thread's stream -- the database's stager -- may be busy for the whole run)
   if (st) (void)hipStreamDestroy(st);
   if (h) (void)hipHostFree(h);
   if (d) (void)hipFree(d);
+  tw[6] = now();
+  if (timing)
+    fprintf(stderr, "-- device warm: %.3f s = first allocation %.3f + fill %.3f + first kernel of the library %.3f + pinned memory and a stream %.3f + a copy %.3f + release %.3f\n",
+            tw[6] - tw[0], tw[1] - tw[0], tw[2] - tw[1], tw[3] - tw[2], tw[4] - tw[3], tw[5] - tw[4], tw[6] - tw[5]);
   if (prev >= 0) (void)hipSetDevice(prev);
   if (e != hipSuccess) { (void)hipGetLastError(); return mfx_fail(MFX_E_HIP, "mfx_device_warm: %s", hipGetErrorString(e)); }
   return MFX_OK;
@@ -763,6 +775,7 @@ int mfx_index_add_multi(mfx_index *const *ixs, uint32_t nix, const uint64_t *kme
 static unsigned pread_threads() {
   // these threads wait on memory, not on the ALUs: more of them than the CPU quota grants still pays (1 Gb ingest on
   // a 16-core quota: 1.9 s with 16 readers, 1.3 s with 32), unless MFX_HOST_THREADS fixes the count
+  if (const char *pe = getenv("MFX_PREAD_THREADS")) if (atoi(pe) > 0) return std::min((unsigned)atoi(pe), 64u);   // (A/B)
   unsigned nt = std::max(1u, mfx_host_threads());
   if (!getenv("MFX_HOST_THREADS")) nt = std::max(nt, std::min(32u, std::max(1u, std::thread::hardware_concurrency())));
   return std::min(nt, 64u);
@@ -1013,19 +1026,23 @@ struct mfx_db_stage {
   std::atomic<int> failed{0};
   std::string error;
   std::thread worker;
-  double t_begin = 0, t_first_copy = 0, t_last_enqueued = 0;
+  double t_begin = 0, t_first_copy = 0, t_last_enqueued = 0, t_all_copied = 0;
+  double t_part[2][3] = {{0, 0, 0}, {0, 0, 0}};              // [before / after the boost][lane wait, file read, enqueue] seconds of the worker (diagnostics)
+  uint64_t n_part[2] = {0, 0}, b_part[2] = {0, 0};
   uint64_t file_off(uint64_t b) const { return dir[2 * b + 1] & 0xffffffffffffull; }
 };
 
 static double stage_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 static void stage_worker(mfx_db_stage *S) {
-  constexpr int NL = 3;
+  constexpr int NLMAX = 8;
+  int NL = 3;
+  if (const char *le = getenv("MFX_DB_STAGE_LANES")) NL = std::min(NLMAX, std::max(2, atoi(le)));
   const size_t LANE = 32u << 20;
-  uint8_t *lane[NL] = {nullptr, nullptr, nullptr};
-  hipEvent_t left[NL] = {nullptr, nullptr, nullptr};
+  uint8_t *lane[NLMAX] = {nullptr};
+  hipEvent_t left[NLMAX] = {nullptr};
   hipStream_t cs = nullptr;
-  bool busy[NL] = {false, false, false};
+  bool busy[NLMAX] = {false};
   auto fail = [&](const char *what, hipError_t e) {
     S->error = std::string(what) + (e != hipSuccess ? std::string(": ") + hipGetErrorString(e) : std::string());
     S->failed.store(1);
@@ -1055,10 +1072,18 @@ static void stage_worker(mfx_db_stage *S) {
     };
     for (size_t c = 0; c < S->chunks.size() && !S->failed.load(); ++c) {
       const int li = (int)(c % NL);
+      const int ph = S->boost.load(std::memory_order_relaxed) ? 1 : 0;              // (diagnostics: before / after mfx_db_stage_boost)
+      double tq = stage_now();
       if ((e = lane_up(li)) != hipSuccess) { fail("staging set-up failed", e); break; }
       if (busy[li] && (e = hipEventSynchronize(left[li])) != hipSuccess) { fail("staging copy failed", e); break; }
       const uint64_t o = S->file_off(S->chunks[c].b0), bytes = S->file_off(S->chunks[c].b1) - o;
+      double tr = stage_now();
+      S->t_part[ph][0] += tr - tq;
       if (!par_pread(S->fd, lane[li], bytes, o, pool_now())) { fail("reading the database failed", hipSuccess); break; }
+      tq = stage_now();
+      S->t_part[ph][1] += tq - tr;
+      S->n_part[ph] += 1;
+      S->b_part[ph] += bytes;
       if (c == 0) S->t_first_copy = stage_now();
       e = hipMemcpyAsync(S->d_payload + (o - S->off0), lane[li], bytes, hipMemcpyHostToDevice, cs);
       if (e == hipSuccess && c == 0) e = hipMemcpyAsync(S->d_dir, S->dir.data(), S->dir.size() * 8, hipMemcpyHostToDevice, cs);     // (ahead of every chunk's `copied` event but the first's, which the next line records behind it)
@@ -1067,6 +1092,7 @@ static void stage_worker(mfx_db_stage *S) {
       if (e != hipSuccess) { fail("staging copy failed", e); break; }
       busy[li] = true;
       S->enqueued.store((int64_t)c + 1, std::memory_order_release);
+      S->t_part[ph][2] += stage_now() - tq;
     }
     // the escape list behind the blocks: k-mers (8 bytes each), then their counts (4 bytes each)
     const uint64_t ne = S->info.n_escape;
@@ -1099,6 +1125,7 @@ static void stage_worker(mfx_db_stage *S) {
   }
   S->t_last_enqueued = stage_now();
   if (cs) (void)hipStreamSynchronize(cs);
+  S->t_all_copied = stage_now();
   for (int i = 0; i < NL; ++i) { if (lane[i]) (void)hipHostFree(lane[i]); if (left[i]) (void)hipEventDestroy(left[i]); }
   if (cs) (void)hipStreamDestroy(cs);
 }
@@ -1233,6 +1260,11 @@ extern "C" int mfx_index_build_for_hist_staged(mfx_index *ix, const mfx_seq *seq
             "stager: first copy %.3f s after its start, last copy enqueued after %.3f s (%.2f GB); the build began %.3f s after the stager\n",
             stage_now() - t0, t1 - t0, S->chunks.size(), t2 - t1, t_wait, t3 - t2, stage_now() - t3, S->t_first_copy - S->t_begin, S->t_last_enqueued - S->t_begin,
             S->payload_bytes / 1e9, t0 - S->t_begin);
+  if (timing)
+    for (int ph = 0; ph < 2; ++ph)
+      fprintf(stderr, "-- stager %s the sequence was in: %lu chunks, %.2f GB; the worker waited for a lane %.3f s, read the file %.3f s (%.1f GB/s), enqueued copies %.3f s\n",
+              ph ? "after" : "before", (unsigned long)S->n_part[ph], S->b_part[ph] / 1e9, S->t_part[ph][0], S->t_part[ph][1],
+              S->t_part[ph][1] > 0 ? S->b_part[ph] / 1e9 / S->t_part[ph][1] : 0.0, S->t_part[ph][2]);
   return rc;
 }
 
