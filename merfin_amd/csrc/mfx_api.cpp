@@ -1027,6 +1027,7 @@ struct mfx_db_stage {
   std::string error;
   std::thread worker;
   double t_begin = 0, t_first_copy = 0, t_last_enqueued = 0, t_all_copied = 0;
+  double t_setup[8] = {0, 0, 0, 0, 0, 0, 0, 0};              // begin: file + directory, memory info, device memory, events; worker: device + stream, first lane, first read, first enqueue
   double t_part[2][3] = {{0, 0, 0}, {0, 0, 0}};              // [before / after the boost][lane wait, file read, enqueue] seconds of the worker (diagnostics)
   uint64_t n_part[2] = {0, 0}, b_part[2] = {0, 0};
   uint64_t file_off(uint64_t b) const { return dir[2 * b + 1] & 0xffffffffffffull; }
@@ -1047,8 +1048,10 @@ static void stage_worker(mfx_db_stage *S) {
     S->error = std::string(what) + (e != hipSuccess ? std::string(": ") + hipGetErrorString(e) : std::string());
     S->failed.store(1);
   };
+  double tw0 = stage_now();
   hipError_t e = hipSetDevice(S->device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+  S->t_setup[4] = stage_now() - tw0;
   // (a lane is pinned when its first chunk comes up -- 13 ms each -- and the directory goes over behind the first chunk: the first
   // bytes of the database are on the link as early as the runtime allows)
   auto lane_up = [&](int i) -> hipError_t {
@@ -1075,6 +1078,7 @@ static void stage_worker(mfx_db_stage *S) {
       const int ph = S->boost.load(std::memory_order_relaxed) ? 1 : 0;              // (diagnostics: before / after mfx_db_stage_boost)
       double tq = stage_now();
       if ((e = lane_up(li)) != hipSuccess) { fail("staging set-up failed", e); break; }
+      if (c == 0) S->t_setup[5] = stage_now() - tq;
       if (busy[li] && (e = hipEventSynchronize(left[li])) != hipSuccess) { fail("staging copy failed", e); break; }
       const uint64_t o = S->file_off(S->chunks[c].b0), bytes = S->file_off(S->chunks[c].b1) - o;
       double tr = stage_now();
@@ -1082,6 +1086,7 @@ static void stage_worker(mfx_db_stage *S) {
       if (!par_pread(S->fd, lane[li], bytes, o, pool_now())) { fail("reading the database failed", hipSuccess); break; }
       tq = stage_now();
       S->t_part[ph][1] += tq - tr;
+      if (c == 0) S->t_setup[6] = tq - tr;
       S->n_part[ph] += 1;
       S->b_part[ph] += bytes;
       if (c == 0) S->t_first_copy = stage_now();
@@ -1093,6 +1098,7 @@ static void stage_worker(mfx_db_stage *S) {
       busy[li] = true;
       S->enqueued.store((int64_t)c + 1, std::memory_order_release);
       S->t_part[ph][2] += stage_now() - tq;
+      if (c == 0) S->t_setup[7] = stage_now() - tq;
     }
     // the escape list behind the blocks: k-mers (8 bytes each), then their counts (4 bytes each)
     const uint64_t ne = S->info.n_escape;
@@ -1158,13 +1164,16 @@ extern "C" mfx_db_stage *mfx_db_stage_begin(const char *path, int device) {
   S->device = device;
   S->path = path;
   if (mfx_flat_delta_open(path, &S->fd, &S->info, S->dir)) return nullptr;
+  S->t_setup[0] = stage_now() - S->t_begin;
   auto drop = [&](mfx_db_stage *x) { mfx_db_stage_free(x); return (mfx_db_stage *)nullptr; };
   if (S->info.n == 0 || S->info.k > MFX_MAX_K_NARROW) { mfx_fail(MFX_E_INVAL, "'%s': nothing to stage", path); return drop(S.release()); }
   S->off0 = S->file_off(0);
   S->payload_bytes = S->file_off(S->info.nblocks) - S->off0;
   DevGuard g(device);
   size_t free_b = 0, total_b = 0;
+  double tq = stage_now();
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); mfx_fail(MFX_E_HIP, "hipMemGetInfo failed"); return drop(S.release()); }
+  S->t_setup[1] = stage_now() - tq; tq = stage_now();
   // a fifth of the free HBM at most: the table is sized by what is left (a read database beyond that goes through the ring)
   if ((double)(S->payload_bytes + S->dir.size() * 8 + S->info.n_escape * 12) > 0.2 * (double)free_b) {
     mfx_fail(MFX_E_NOMEM, "'%s': %.1f GB of blocks against %.1f GB of free device memory: not staged", path, S->payload_bytes / 1e9, free_b / 1e9);
@@ -1177,6 +1186,7 @@ extern "C" mfx_db_stage *mfx_db_stage_begin(const char *path, int device) {
     mfx_fail(MFX_E_NOMEM, "'%s': no device memory for the staged database", path);
     return drop(S.release());
   }
+  S->t_setup[2] = stage_now() - tq; tq = stage_now();
   // chunks: whole blocks, at most 32 MB of file each
   const uint64_t LANE = 32u << 20;
   for (uint64_t b0 = 0; b0 < S->info.nblocks;) {
@@ -1189,6 +1199,7 @@ extern "C" mfx_db_stage *mfx_db_stage_begin(const char *path, int device) {
     S->chunks.push_back(c);
     b0 = b1;
   }
+  S->t_setup[3] = stage_now() - tq;
   mfx_db_stage *raw = S.release();
   raw->worker = std::thread(stage_worker, raw);
   return raw;
@@ -1260,6 +1271,9 @@ extern "C" int mfx_index_build_for_hist_staged(mfx_index *ix, const mfx_seq *seq
             "stager: first copy %.3f s after its start, last copy enqueued after %.3f s (%.2f GB); the build began %.3f s after the stager\n",
             stage_now() - t0, t1 - t0, S->chunks.size(), t2 - t1, t_wait, t3 - t2, stage_now() - t3, S->t_first_copy - S->t_begin, S->t_last_enqueued - S->t_begin,
             S->payload_bytes / 1e9, t0 - S->t_begin);
+  if (timing)
+    fprintf(stderr, "-- stager set-up: begin = file + directory %.3f, memory info %.3f, device memory %.3f, events %.3f; worker = device + stream %.3f, first lane %.3f, first read %.3f, "
+            "first enqueue %.3f s\n", S->t_setup[0], S->t_setup[1], S->t_setup[2], S->t_setup[3], S->t_setup[4], S->t_setup[5], S->t_setup[6], S->t_setup[7]);
   if (timing)
     for (int ph = 0; ph < 2; ++ph)
       fprintf(stderr, "-- stager %s the sequence was in: %lu chunks, %.2f GB; the worker waited for a lane %.3f s, read the file %.3f s (%.1f GB/s), enqueued copies %.3f s\n",

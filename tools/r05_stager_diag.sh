@@ -23,7 +23,7 @@ sleep 10
 {
 echo "# cpu.max: $(cat /sys/fs/cgroup/cpu.max)   columns after the wall: usage_usec / nr_throttled / throttled_usec of the cgroup, differences over the run"
 tail -1 $OUT/r05_inputs10.log
-for spec in "MFX_X=1" "MFX_CLI_STAGE_FIRST=1" "MFX_X=2" "MFX_DB_STAGE_THREADS=32"; do
+for spec in "MFX_X=1" "MFX_CLI_STAGE_FIRST=0"; do
   for rep in 1 2 3; do
     sleep 4
     a=$(stat_)
