@@ -130,8 +130,8 @@ int main(int argc, char **argv) {
   const std::string tag = argc > 8 ? argv[8] : "";
   const std::string outp = "/tmp/mfx_vhb" + tag + ".out.vcf", logp = "/tmp/mfx_vhb" + tag + ".log";
   int rc = mfx_variants_run_values(&ev, values, ahead ? nullptr : vp, nm.data(), bs.data(), ln.data(), nc, &vo, outp.c_str(), logp.c_str(), &ncl, dev ? scores : PathScores(), ahead);
-  if (ahead) mfx_vcf_free(ahead);
   double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (ahead) { auto tf = std::chrono::steady_clock::now(); mfx_vcf_free(ahead); printf("mfx_vcf_free: %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - tf).count()); }
   printf("rc %d: %lu bases, %lu calls, %lu clusters in %.2f s = %.0f clusters/s\n", rc, (unsigned long)total, (unsigned long)calls, (unsigned long)ncl, dt, ncl / dt);
   return rc;
 }
