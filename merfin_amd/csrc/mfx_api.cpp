@@ -3829,6 +3829,100 @@ int mfx_score_paths(mfx_eval *ev, const char *text, uint64_t len, const mfx_path
   return MFX_OK;
 }
 
+int mfx_score_paths_trv(mfx_eval *ev, const char *text, uint64_t len, const mfx_path_table *pt, const mfx_trv_batch *tb, int need_dk, uint32_t *numM, double *totdk) {
+  if (!ev || !pt || !tb || (len && !text) || !numM || (need_dk && !totdk) || (tb->ncl && (!tb->cl || !tb->var || !tb->al || !tb->np || !tb->status || !tb->p_len || !tb->gt)))
+    return mfx_fail(MFX_E_INVAL, "mfx_score_paths_trv: null argument");
+  if (ev->ix->seq_only) return mfx_fail(MFX_E_INVAL, "mfx_score_paths: a sequence-only index holds the k-mers of one sequence; alternative paths need the full index");
+  const uint64_t hp = pt->npaths, hv = pt->nvals, NP = hp + tb->path_cap, NV = hv + tb->row_cap;
+  const uint64_t total = std::max<uint64_t>(tb->text_end, len);
+  if (NP == 0 || total == 0) return MFX_OK;
+  DevGuard g(ev->device);
+  int canon = 0;
+  int rc = index_canonical(ev->ix, &canon);
+  if (rc) return rc;
+  // the batch's text on the device: the host's paths copied in, the rest '\n' (no k-mer) until the traverse kernel writes its paths; the
+  // tile loads of the lookup kernel reach a tile past the end
+  const uint64_t text_bytes = ((total + MFX_TILE - 1) / MFX_TILE + 2) * MFX_TILE + 256;
+  DevBuf<uint8_t> dtext, dwin, dal;
+  DevBuf<mfx_trv_cluster> dcl;
+  DevBuf<mfx_trv_variant> dvar;
+  DevBuf<mfx_trv_allele> dall;
+  DevBuf<uint32_t> dr, da, dlen, dnv, dvidx, dvlen, dnum, dnp, dst;
+  DevBuf<int32_t> dgt;
+  DevBuf<uint64_t> ds, doff, dvoff, dcf;
+  DevBuf<double> ddk;
+  MFX_HIP(dtext.alloc(text_bytes)); MFX_HIP(dr.alloc(total)); MFX_HIP(da.alloc(total)); MFX_HIP(ds.alloc(2));
+  MFX_HIP(doff.alloc(NP)); MFX_HIP(dlen.alloc(NP)); MFX_HIP(dnv.alloc(NP)); MFX_HIP(dvoff.alloc(NP)); MFX_HIP(dcf.alloc(NP));
+  MFX_HIP(dgt.alloc(NV ? NV : 1)); MFX_HIP(dvidx.alloc(NV ? NV : 1)); MFX_HIP(dvlen.alloc(NV ? NV : 1));
+  MFX_HIP(dnum.alloc(NP)); MFX_HIP(ddk.alloc(need_dk ? NP : 1));
+  hipStream_t st = nullptr;
+  MFX_HIP(mfx_memset_now(dtext.p, '\n', text_bytes));
+  MFX_HIP(hipMemsetAsync(ds.p, 0, 2 * sizeof(uint64_t), st));
+  if (len) MFX_HIP(hipMemcpyAsync(dtext.p, text, len, hipMemcpyHostToDevice, st));
+  if (hp) {
+    MFX_HIP(hipMemcpyAsync(doff.p, pt->off, hp * 8, hipMemcpyHostToDevice, st));
+    MFX_HIP(hipMemcpyAsync(dlen.p, pt->len, hp * 4, hipMemcpyHostToDevice, st));
+    MFX_HIP(hipMemcpyAsync(dnv.p, pt->nv, hp * 4, hipMemcpyHostToDevice, st));
+    MFX_HIP(hipMemcpyAsync(dvoff.p, pt->voff, hp * 8, hipMemcpyHostToDevice, st));
+    MFX_HIP(hipMemcpyAsync(dcf.p, pt->cfirst, hp * 8, hipMemcpyHostToDevice, st));
+  }
+  if (hv) {
+    MFX_HIP(hipMemcpyAsync(dgt.p, pt->gt, hv * 4, hipMemcpyHostToDevice, st));
+    MFX_HIP(hipMemcpyAsync(dvidx.p, pt->vidx, hv * 4, hipMemcpyHostToDevice, st));
+    MFX_HIP(hipMemcpyAsync(dvlen.p, pt->vlen, hv * 4, hipMemcpyHostToDevice, st));
+  }
+  if (tb->ncl) {
+    MFX_HIP(dcl.alloc(tb->ncl)); MFX_HIP(dvar.alloc(tb->nvar)); MFX_HIP(dall.alloc(tb->nal));
+    MFX_HIP(dwin.alloc(tb->win_bytes)); MFX_HIP(dal.alloc(tb->al_bytes)); MFX_HIP(dnp.alloc(tb->ncl)); MFX_HIP(dst.alloc(tb->ncl));
+    MFX_HIP(hipMemcpyAsync(dcl.p, tb->cl, tb->ncl * sizeof(mfx_trv_cluster), hipMemcpyHostToDevice, st));
+    MFX_HIP(hipMemcpyAsync(dvar.p, tb->var, tb->nvar * sizeof(mfx_trv_variant), hipMemcpyHostToDevice, st));
+    if (tb->nal) MFX_HIP(hipMemcpyAsync(dall.p, tb->al, tb->nal * sizeof(mfx_trv_allele), hipMemcpyHostToDevice, st));
+    if (tb->win_bytes) MFX_HIP(hipMemcpyAsync(dwin.p, tb->win_text, tb->win_bytes, hipMemcpyHostToDevice, st));
+    if (tb->al_bytes) MFX_HIP(hipMemcpyAsync(dal.p, tb->al_text, tb->al_bytes, hipMemcpyHostToDevice, st));
+    mfx_trv_out o;
+    o.text = reinterpret_cast<char *>(dtext.p);
+    o.p_off = doff.p + hp; o.p_voff = dvoff.p + hp; o.p_cfirst = dcf.p + hp; o.p_len = dlen.p + hp; o.p_nv = dnv.p + hp;
+    o.gt = dgt.p + hv; o.vidx = dvidx.p + hv; o.vlen = dvlen.p + hv;
+    o.table_base = hp; o.row_base = hv;
+    MFX_HIP(mfx_k_var_traverse(dcl.p, tb->ncl, dvar.p, dall.p, reinterpret_cast<const char *>(dwin.p), reinterpret_cast<const char *>(dal.p), o, dnp.p, dst.p, st));
+  }
+  mfx_dump_args a;
+  a.t = ev->ix->view();
+  a.canonical = canon;
+  a.src = dtext.p;
+  a.npos = total;
+  a.skip = 0;
+  a.clen_left = total;
+  a.readV = dr.p;
+  a.asmV = da.p;
+  a.peak = ev->peak;
+  a.n_prob = ev->n_prob;
+  a.probK = ev->d_probK;
+  a.probP = ev->d_probP;
+  a.stats = ds.p;
+  MFX_HIP(ev->ix->wide() ? mfx_kw_dump(a, st) : mfx_k_dump(a, st));
+  mfx_var_score_args sa;
+  sa.text = dtext.p;
+  sa.readV = dr.p; sa.asmV = da.p;
+  sa.npaths = NP;
+  sa.off = doff.p; sa.len = dlen.p; sa.nv = dnv.p; sa.voff = dvoff.p; sa.cfirst = dcf.p;
+  sa.gt = dgt.p; sa.vidx = dvidx.p; sa.vlen = dvlen.p;
+  sa.k = (uint32_t)ev->ix->k;
+  sa.need_dk = need_dk ? 1 : 0;
+  sa.peak = ev->peak; sa.n_prob = ev->n_prob; sa.probK = ev->d_probK; sa.probP = ev->d_probP;
+  sa.numM = dnum.p; sa.totdk = ddk.p;
+  MFX_HIP(mfx_k_var_score(sa, st));
+  MFX_HIP(hipMemcpy(numM, dnum.p, NP * 4, hipMemcpyDeviceToHost));
+  if (need_dk) MFX_HIP(hipMemcpy(totdk, ddk.p, NP * 8, hipMemcpyDeviceToHost));
+  if (tb->ncl) {
+    MFX_HIP(hipMemcpy(tb->np, dnp.p, tb->ncl * 4, hipMemcpyDeviceToHost));
+    MFX_HIP(hipMemcpy(tb->status, dst.p, tb->ncl * 4, hipMemcpyDeviceToHost));
+    if (tb->path_cap) MFX_HIP(hipMemcpy(tb->p_len, dlen.p + hp, tb->path_cap * 4, hipMemcpyDeviceToHost));
+    if (tb->row_cap) MFX_HIP(hipMemcpy(tb->gt, dgt.p + hv, tb->row_cap * 4, hipMemcpyDeviceToHost));
+  }
+  return MFX_OK;
+}
+
 extern "C" int mfx_dump_values_sharded(mfx_eval *const *evs, const mfx_seq *const *seqs, uint32_t nslots, uint32_t contig,
                                        uint64_t pos_begin, uint64_t pos_end, uint32_t *readV, uint32_t *asmV,
                                        uint64_t *kasm, uint64_t *kmissing) {

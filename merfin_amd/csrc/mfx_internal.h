@@ -1,5 +1,6 @@
 // mfx_internal.h -- shared declarations of the merfin_amd library (host side).
 #pragma once
+#include "mfx_traverse.h"
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -216,6 +217,26 @@ struct mfx_path_table {
 // looks every k-mer of `text` up (as mfx_dump_values) and scores every path on the device: numM[p] (missing k-mers, lead-in
 // included) and, need_dk, totdk[p] (sum of the delta-K terms in position order) -- the values varMer::score computes
 int mfx_score_paths(mfx_eval *ev, const char *text, uint64_t len, const mfx_path_table *pt, int need_dk, uint32_t *numM, double *totdk);
+
+// ... with part of the batch's clusters ENUMERATED ON THE DEVICE (mfx_traverse.h; merfin-variants.C:22-126): `text` / `pt` hold the paths the
+// host enumerated (clusters beyond the device's limits; may be empty), `tb` the other clusters as tables -- window bases, variants, alleles --
+// and the room reserved for their paths: text behind the host's (cl[].text0 absolute in the batch's text, >= len), path slots and rows
+// behind the host's (numbered from 0 in cl[].path0 / row0).  numM / totdk: [pt->npaths + tb->path_cap], the device part behind the host's;
+// a slot beyond a cluster's np is an empty path.  Comes back with every cluster's status: a caller that finds one != MFX_TRV_OK discards the
+// device part's results and enumerates on the host.
+struct mfx_trv_batch {
+  uint64_t ncl = 0, nvar = 0, nal = 0, win_bytes = 0, al_bytes = 0;
+  const mfx_trv_cluster *cl = nullptr;
+  const mfx_trv_variant *var = nullptr;
+  const mfx_trv_allele *al = nullptr;
+  const char *win_text = nullptr, *al_text = nullptr;
+  uint64_t text_end = 0;              // the batch's text: [0, len) the host's, up to text_end the device's room
+  uint64_t path_cap = 0, row_cap = 0;
+  uint32_t *np = nullptr, *status = nullptr;     // [ncl] out
+  uint32_t *p_len = nullptr;                     // [path_cap] out: the length of every path slot
+  int32_t *gt = nullptr;                         // [row_cap] out: the genotype rows
+};
+int mfx_score_paths_trv(mfx_eval *ev, const char *text, uint64_t len, const mfx_path_table *pt, const mfx_trv_batch *tb, int need_dk, uint32_t *numM, double *totdk);
 
 int mfx_seq_partial_error(const mfx_seq *s, const char *who);     // MFX_E_INVAL: the sequence object holds a part only
 int mfx_seq_ensure_ascii(const mfx_seq *s);      // unpacks the planes into d_bases if a packed upload left them newer (mfx_api.cpp)

@@ -119,6 +119,8 @@ struct mfx_var_score_args {
   double         *totdk;              // [npaths] out (need_dk)
 };
 hipError_t mfx_k_var_score(const mfx_var_score_args &a, hipStream_t st);
+hipError_t mfx_k_var_traverse(const mfx_trv_cluster *cl, uint64_t ncl, const mfx_trv_variant *vars, const mfx_trv_allele *alleles, const char *win_text,
+                              const char *allele_text, const mfx_trv_out &o, uint32_t *np, uint32_t *status, hipStream_t st);
 hipError_t mfx_k_table_init(mfx_slot *slots, uint64_t nslots, hipStream_t st);
 hipError_t mfx_k_table_add(mfx_table_view t, const uint64_t *kmers, const uint32_t *values, uint64_t n, int side,
                            uint64_t *meta, hipStream_t st);

@@ -2839,6 +2839,44 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_var_score_kernel(mfx_var_score_
   a.numM[p] = numM;
   if (a.need_dk) a.totdk[p] = totdk;
 }
+// `traverse` (merfin-variants.C:22-126) of a batch's clusters on the device: one cluster per WAVE runs mfx_traverse_cluster_t
+// (mfx_traverse.h: the host's recursion as a loop; one thread per cluster with its strings in scratch took 13 ms per 65 K clusters,
+// profiles/r05_cfg4_trv.txt) and writes its paths -- text, path-table entries, genotype / offset / length rows --
+// into the room the host reserved (the product of the allele counts), then closes the slots it did not use (zero-length paths that
+// belong to no cluster).  A few hundred bytes of work per cluster: what it saves is the host's enumeration and the upload of the path text.
+struct mfx_trv_wave {                  // one wave per cluster: every lane runs the control flow, the byte loops are strided over the lanes
+  static __device__ __forceinline__ uint32_t lane() { return threadIdx.x & 63u; }
+  static __device__ __forceinline__ uint32_t lanes() { return 64u; }
+  static __device__ __forceinline__ void sync() { __syncthreads(); }              // (the block IS the wave)
+  static __device__ __forceinline__ bool all(bool p) { return __all((int)p) != 0; }
+};
+__global__ __launch_bounds__(64) void mfx_var_traverse_kernel(const mfx_trv_cluster *cl, uint64_t ncl, const mfx_trv_variant *vars, const mfx_trv_allele *alleles,
+                                                              const char *win_text, const char *allele_text, mfx_trv_out o, uint32_t *np, uint32_t *status) {
+  __shared__ char rep[MFX_TRV_MAX_NV][MFX_TRV_MAX_LEN];
+  for (uint64_t c = blockIdx.x; c < ncl; c += gridDim.x) {
+    const mfx_trv_cluster C = cl[c];
+    uint32_t n = 0;
+    const uint32_t st = mfx_traverse_cluster_t<mfx_trv_wave>(C, vars, alleles, win_text, allele_text, o, &n, rep);
+    if (threadIdx.x == 0) { np[c] = n; status[c] = st; }
+    for (uint32_t q = n + threadIdx.x; q < C.path_cap; q += 64u) {
+      const uint64_t e = C.path0 + q;
+      o.p_off[e] = C.text0;
+      o.p_len[e] = 0u;
+      o.p_nv[e] = 0u;
+      o.p_voff[e] = 0u;
+      o.p_cfirst[e] = o.table_base + e;
+    }
+    __syncthreads();                                                             // (the next cluster's strings reuse the LDS)
+  }
+}
+hipError_t mfx_k_var_traverse(const mfx_trv_cluster *cl, uint64_t ncl, const mfx_trv_variant *vars, const mfx_trv_allele *alleles, const char *win_text,
+                              const char *allele_text, const mfx_trv_out &o, uint32_t *np, uint32_t *status, hipStream_t st) {
+  if (ncl == 0) return hipSuccess;
+  const uint64_t blocks = ncl < 65536u ? ncl : 65536u;
+  mfx_var_traverse_kernel<<<(unsigned)blocks, 64, 0, st>>>(cl, ncl, vars, alleles, win_text, allele_text, o, np, status);
+  return hipGetLastError();
+}
+
 hipError_t mfx_k_var_score(const mfx_var_score_args &a, hipStream_t st) {
   if (a.npaths == 0) return hipSuccess;
   mfx_var_score_kernel<<<(unsigned)((a.npaths + MFX_BLOCK - 1) / MFX_BLOCK), MFX_BLOCK, 0, st>>>(a);

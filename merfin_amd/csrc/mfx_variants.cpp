@@ -38,6 +38,7 @@
 #include <exception>
 #include <functional>
 #include <future>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -515,7 +516,17 @@ struct PathArena {                           // the paths of a RUN of consecutiv
   uint64_t off = 0;                          // where the run's text lies in the batch's packed buffer
   uint64_t p0 = 0, v0 = 0;                   // the run's first path / first row entry in the batch's path table
   uint64_t first_id = 0;                     // varMerId of the run's first path (-debug numbering)
-  void reset() { text.clear(); toff.clear(); toff.push_back(0); gt.clear(); vidx.clear(); vlen.clear(); }
+  // the run's clusters that are enumerated ON THE DEVICE (mfx_traverse.h): their tables, and the room reserved for their paths
+  std::vector<mfx_trv_cluster> tcl;
+  std::vector<mfx_trv_variant> tvar;
+  std::vector<mfx_trv_allele> tal;
+  std::string twin, talt;                    // window bases / allele bases of those clusters
+  uint64_t t_text = 0, t_paths = 0, t_rows = 0;
+  uint64_t b_cl = 0, b_var = 0, b_al = 0, b_win = 0, b_alt = 0, b_text = 0, b_path = 0, b_row = 0;   // where the run's entries lie in the batch's
+  void reset() {
+    text.clear(); toff.clear(); toff.push_back(0); gt.clear(); vidx.clear(); vlen.clear();
+    tcl.clear(); tvar.clear(); tal.clear(); twin.clear(); talt.clear(); t_text = t_paths = t_rows = 0;
+  }
 };
 
 // One cluster's paths: a window of its run's arena.  (Round 3 kept a string + four vectors per cluster: their ~12 heap blocks
@@ -524,13 +535,17 @@ struct PathSet {
   PathArena *ar = nullptr;
   uint64_t p0 = 0, v0 = 0;                   // first path / first row entry inside the arena
   uint32_t np = 0, nv = 0;
+  // a cluster enumerated on the device: what came back of its paths (lengths, genotype rows) and where they stand in the batch's path table
+  const uint32_t *dlen = nullptr;
+  const int32_t *dgt = nullptr;
+  uint64_t dq0 = 0;
   size_t size() const { return np; }
-  size_t len(size_t p) const { return (size_t)(ar->toff[p0 + p + 1] - ar->toff[p0 + p] - 1); }
+  size_t len(size_t p) const { return dlen ? (size_t)dlen[p] : (size_t)(ar->toff[p0 + p + 1] - ar->toff[p0 + p] - 1); }
   const char *seq(size_t p) const { return ar->text.data() + ar->toff[p0 + p]; }
   uint64_t packed_off(size_t p) const { return ar->off + ar->toff[p0 + p]; }       // of path p in the batch's packed buffer
-  uint64_t table_p0() const { return ar->p0 + p0; }                                  // of path 0 in the batch's path table
+  uint64_t table_p0() const { return dlen ? dq0 : ar->p0 + p0; }                     // of path 0 in the batch's path table
   uint64_t first_id() const { return ar->first_id + p0; }
-  const int *gt(size_t p) const { return ar->gt.data() + v0 + p * nv; }
+  const int *gt(size_t p) const { return dlen ? dgt + p * nv : ar->gt.data() + v0 + p * nv; }
   const uint32_t *vidx(size_t p) const { return ar->vidx.data() + v0 + p * nv; }
   const uint32_t *vlen(size_t p) const { return ar->vlen.data() + v0 + p * nv; }
   static uint64_t hash(const char *s, size_t n) {
@@ -619,8 +634,62 @@ struct Job {                          // one cluster waiting for its GPU values
   uint32_t contig;
   uint32_t rStart, rEnd;
   PathSet ps;                         // its paths, inside the arena of its run of clusters
+  int64_t trv = -1;                   // >= 0: enumerated on the device -- its entry among the run's (then the batch's) traverse clusters
   std::string dbg;                    // -debug lines of this cluster (appended to its run's text by the worker)
 };
+
+// A cluster goes to the device's traverse (mfx_traverse.h) if it stays inside its limits; its tables are appended to the run's.  The
+// room reserved: the product of the allele counts in paths, each as long as the window plus every variant's longest allele.
+bool trv_pack(const Cluster &cl, uint32_t rStart, uint32_t rEnd, const char *contig_bases, PathArena &ar) {
+  const size_t nv = cl.vars.size();
+  if (nv == 0 || nv > MFX_TRV_MAX_NV) return false;
+  uint64_t prod = 1, extra = 0;
+  for (const Variant *v : cl.vars) {
+    const size_t na = v->nalleles();
+    if (na == 0) return false;
+    prod *= na;
+    if (prod > MFX_TRV_MAX_PATHS) return false;
+    size_t longest = 0;
+    for (size_t a = 1; a < na; ++a) longest = std::max<size_t>(longest, v->allele(a).size());
+    extra += longest;
+  }
+  const uint64_t win_len = rEnd - rStart, bound = win_len + extra;
+  if (bound > MFX_TRV_MAX_LEN) return false;
+  mfx_trv_cluster c;
+  c.win_off = ar.twin.size();
+  c.win_len = (uint32_t)win_len;
+  c.nv = (uint32_t)nv;
+  c.var0 = (uint32_t)ar.tvar.size();
+  c.path_cap = (uint32_t)prod;
+  c.text0 = ar.t_text;
+  c.path0 = ar.t_paths;
+  c.row0 = ar.t_rows;
+  c.text_cap = (uint32_t)(prod * (bound + 1));
+  c.pad = 0;
+  ar.twin.append(contig_bases + rStart, contig_bases + rEnd);
+  for (const Variant *v : cl.vars) {
+    mfx_trv_variant tv;
+    tv.off = v->pos - rStart;                                  // (uint32 arithmetic, as the host's offs)
+    tv.reflen = v->refLen;
+    tv.na = (uint32_t)v->nalleles();
+    tv.al0 = (uint32_t)ar.tal.size();
+    ar.tvar.push_back(tv);
+    for (size_t a = 0; a < v->nalleles(); ++a) {
+      const SV &h = v->allele(a);
+      mfx_trv_allele ta;
+      ta.off = ar.talt.size();
+      ta.len = (uint32_t)h.size();
+      ta.pad = 0;
+      ar.tal.push_back(ta);
+      ar.talt.append(h.p, h.n);
+    }
+  }
+  ar.t_text += c.text_cap;
+  ar.t_paths += prod;
+  ar.t_rows += prod * nv;
+  ar.tcl.push_back(c);
+  return true;
+}
 
 // A batch of clusters goes through three stages: A = its paths are enumerated and packed (host threads), B = every path k-mer
 // is looked up with ONE GPU launch, C = the selectors run (host threads) and the records are written in input order.  Two
@@ -639,6 +708,14 @@ struct VarBatch {
   size_t nruns = 0;
   uint64_t total = 0, npaths = 0, nvals = 0;     // of stage A: packed bytes, paths, row entries
   bool tables = false;              // stage A made the path table (p_*)
+  // the clusters enumerated on the device (mfx_traverse.h): the runs' tables one behind the other, and what came back
+  std::vector<mfx_trv_cluster> t_cl;
+  std::vector<mfx_trv_variant> t_var;
+  std::vector<mfx_trv_allele> t_al;
+  std::string t_win, t_alt;
+  uint64_t t_text_end = 0, t_path_cap = 0, t_row_cap = 0;
+  std::vector<uint32_t> t_np, t_status, t_plen;
+  std::vector<int32_t> t_gt;
   bool scored = false;              // varMer::score of this batch runs on the device (numM / totdk above)
   std::string err;                  // the error text of stage B (errors are per thread: it is carried back to the caller's)
   std::string prelude;              // (a prepared batch) what the log received while its clusters were queued
@@ -845,7 +922,8 @@ using PathValues = std::function<int(const char *, uint64_t, uint32_t *, uint32_
 // scores(text, len, paths, need_dk, numM, totdk): varMer::score of every path of the batch on the device (mfx_score_paths):
 // what the selectors read comes back -- 12 bytes per path instead of 8 bytes per base --, the host's scoring loop does not run.
 // Empty: the host scores from values() (the sharded index, -debug, tools/variants_host_bench.cpp).
-using PathScores = std::function<int(const char *, uint64_t, const mfx_path_table &, int, uint32_t *, double *)>;
+// tb != nullptr: part of the batch's clusters are enumerated on the device from their tables (mfx_score_paths_trv)
+using PathScores = std::function<int(const char *, uint64_t, const mfx_path_table &, const mfx_trv_batch *, int, uint32_t *, double *)>;
 
 // (not static: tools/variants_host_bench.cpp drives the host side with a synthetic `values`, without a device)
 int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const char *vcf_path, const char *const *names, const char *const *bases,
@@ -1001,7 +1079,12 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
   // records / -debug lines / log lines are concatenated by the worker that scores it (stage C), so that the writer issues
   // one write per run, not per cluster
   constexpr size_t RUN = 256;
-  auto stage_a = [&](Batch &bt, bool want_tables) {
+  // MFX_VAR_DEVICE_TRAVERSE=0: every cluster is enumerated on the host (A/B, tests)
+  const bool trv_on = !(getenv("MFX_VAR_DEVICE_TRAVERSE") && atoi(getenv("MFX_VAR_DEVICE_TRAVERSE")) == 0);
+  const bool trv_check = getenv("MFX_VAR_TRAVERSE_CHECK") && atoi(getenv("MFX_VAR_TRAVERSE_CHECK"));
+  std::atomic<uint64_t> trv_checked{0};
+  auto stage_a = [&](Batch &bt, bool want_tables, bool host_only = false) {
+    const bool use_trv = trv_on && want_tables && !host_only;
     std::vector<Job> &jobs = bt.jobs;
     std::string &packed = bt.packed;
     lap(6);                                                              // (the clusters were queued since the last lap)
@@ -1026,6 +1109,44 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
         jb.ps.p0 = ar.toff.size() - 1;
         jb.ps.v0 = ar.gt.size();
         jb.ps.nv = (uint32_t)jb.cl->vars.size();
+        jb.trv = -1;
+        if (use_trv && trv_pack(*jb.cl, jb.rStart, jb.rEnd, bases[jb.contig], ar)) {      // (its paths are made on the device)
+          jb.trv = (int64_t)ar.tcl.size() - 1;
+          if (trv_check) {
+            // MFX_VAR_TRAVERSE_CHECK=1 (tests): the shared traverse, run here on the host, against the recursion -- every path's bases,
+            // genotype, offset and length rows
+            PathArena tmp;
+            tmp.reset();
+            PathSet ps;
+            ps.ar = &tmp; ps.p0 = 0; ps.v0 = 0; ps.nv = (uint32_t)jb.cl->vars.size();
+            if (reps.size() < jb.cl->vars.size() + 1) reps.resize(jb.cl->vars.size() + 1);
+            window.assign(bases[jb.contig] + jb.rStart, bases[jb.contig] + jb.rEnd);
+            if (!seen.empty()) seen.clear();
+            enumerate(0, offs, vl, *jb.cl, window, path, ps, reps, 0, seen);
+            mfx_trv_cluster c = ar.tcl.back();
+            c.text0 = 0; c.path0 = 0; c.row0 = 0;
+            std::vector<char> T((size_t)c.text_cap + 1, '\n');
+            std::vector<uint64_t> o_off(c.path_cap), o_voff(c.path_cap), o_cf(c.path_cap);
+            std::vector<uint32_t> o_len(c.path_cap), o_nv(c.path_cap), o_vidx((size_t)c.path_cap * c.nv), o_vlen((size_t)c.path_cap * c.nv);
+            std::vector<int32_t> o_gt((size_t)c.path_cap * c.nv);
+            mfx_trv_out o;
+            o.text = T.data(); o.p_off = o_off.data(); o.p_voff = o_voff.data(); o.p_cfirst = o_cf.data(); o.p_len = o_len.data(); o.p_nv = o_nv.data();
+            o.gt = o_gt.data(); o.vidx = o_vidx.data(); o.vlen = o_vlen.data(); o.table_base = 0; o.row_base = 0;
+            uint32_t np2 = 0;
+            const uint32_t st = mfx_traverse_cluster(c, ar.tvar.data(), ar.tal.data(), ar.twin.data(), ar.talt.data(), o, &np2);
+            bool same = st == MFX_TRV_OK && np2 == ps.np;
+            for (uint32_t q = 0; q < np2 && same; ++q) {
+              same = o_len[q] == ps.len(q) && memcmp(T.data() + o_off[q], ps.seq(q), ps.len(q)) == 0 && T[o_off[q] + o_len[q]] == '\n';
+              for (uint32_t i = 0; i < c.nv && same; ++i)
+                same = o_gt[(size_t)q * c.nv + i] == ps.gt(q)[i] && o_vidx[(size_t)q * c.nv + i] == ps.vidx(q)[i] && o_vlen[(size_t)q * c.nv + i] == ps.vlen(q)[i];
+            }
+            if (!same) throw std::runtime_error("the shared traverse and the host's recursion disagree on a cluster (status " + std::to_string(st) + ", paths " +
+                                                std::to_string(np2) + " / " + std::to_string(ps.np) + ") at " + std::string(names[jb.contig]) + ":" + std::to_string(jb.rStart));
+            trv_checked.fetch_add(1, std::memory_order_relaxed);
+            offs.clear(); vl.clear(); path.clear();
+          }
+          continue;
+        }
         if (reps.size() < jb.cl->vars.size() + 1) reps.resize(jb.cl->vars.size() + 1);
         window.assign(bases[jb.contig] + jb.rStart, bases[jb.contig] + jb.rEnd);
         if (!seen.empty()) seen.clear();
@@ -1051,15 +1172,47 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
       const PathArena &ar = bt.arenas[ri];
       if (!ar.text.empty()) memcpy(&packed[ar.off], ar.text.data(), ar.text.size());
     });
+    // the clusters that go to the device's traverse: the runs' tables one behind the other; their paths' text behind the host's, their
+    // path slots and rows numbered from 0 (mfx_score_paths_trv puts them behind the host's)
+    {
+      uint64_t ncl = 0, nvar = 0, nal = 0, nwin = 0, nalt = 0, ntext = 0, npath = 0, nrow = 0;
+      for (size_t ri = 0; ri < nruns; ++ri) {
+        PathArena &ar = bt.arenas[ri];
+        ar.b_cl = ncl; ncl += ar.tcl.size();
+        ar.b_var = nvar; nvar += ar.tvar.size();
+        ar.b_al = nal; nal += ar.tal.size();
+        ar.b_win = nwin; nwin += ar.twin.size();
+        ar.b_alt = nalt; nalt += ar.talt.size();
+        ar.b_text = ntext; ntext += ar.t_text;
+        ar.b_path = npath; npath += ar.t_paths;
+        ar.b_row = nrow; nrow += ar.t_rows;
+      }
+      bt.t_cl.resize(ncl); bt.t_var.resize(nvar); bt.t_al.resize(nal); bt.t_win.resize(nwin); bt.t_alt.resize(nalt);
+      bt.t_text_end = total + ntext; bt.t_path_cap = npath; bt.t_row_cap = nrow;
+      bt.t_np.assign(ncl, 0); bt.t_status.assign(ncl, 0); bt.t_plen.resize(npath); bt.t_gt.resize(nrow);
+      if (ncl)
+        parallel_for(nruns, [&](size_t ri) {
+          const PathArena &ar = bt.arenas[ri];
+          for (size_t i = 0; i < ar.tcl.size(); ++i) {
+            mfx_trv_cluster c = ar.tcl[i];
+            c.win_off += ar.b_win; c.var0 += (uint32_t)ar.b_var; c.text0 += total + ar.b_text; c.path0 += ar.b_path; c.row0 += ar.b_row;
+            bt.t_cl[ar.b_cl + i] = c;
+          }
+          for (size_t i = 0; i < ar.tvar.size(); ++i) { mfx_trv_variant v = ar.tvar[i]; v.al0 += (uint32_t)ar.b_al; bt.t_var[ar.b_var + i] = v; }
+          for (size_t i = 0; i < ar.tal.size(); ++i) { mfx_trv_allele a = ar.tal[i]; a.off += ar.b_alt; bt.t_al[ar.b_al + i] = a; }
+          if (!ar.twin.empty()) memcpy(&bt.t_win[ar.b_win], ar.twin.data(), ar.twin.size());
+          if (!ar.talt.empty()) memcpy(&bt.t_alt[ar.b_alt], ar.talt.data(), ar.talt.size());
+        });
+    }
     lap(2);
     bt.total = total; bt.npaths = np; bt.nvals = nvals;
     bt.tables = false;
-    if (total && want_tables) {
+    if ((total || !bt.t_cl.empty()) && want_tables) {
       // the path table of the batch: one entry per path, the variants' rows concatenated
       bt.tables = true;
       bt.p_off.resize(np); bt.p_voff.resize(np); bt.p_cfirst.resize(np); bt.p_len.resize(np); bt.p_nv.resize(np);
       bt.p_gt.resize(nvals); bt.p_vidx.resize(nvals); bt.p_vlen.resize(nvals);
-      bt.numM.resize(np); bt.totdk.resize(np);
+      bt.numM.resize(np + bt.t_path_cap); bt.totdk.resize(np + bt.t_path_cap);
       parallel_for(nruns, [&](size_t ri) {
         const PathArena &ar = bt.arenas[ri];
         for (size_t i = ri * RUN, e = std::min(jobs.size(), (ri + 1) * RUN); i < e; ++i) {
@@ -1085,13 +1238,15 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
   };
   // the launch of stage B; prevb: the batch whose stage B runs before this one's (nullptr: none)
   auto stage_b = [&](Batch &bt, Batch *prevb) -> int {
+    // (a batch prepared for the device's traverse but scored on the host after all -- -debug, MFX_VAR_HOST_SCORE --: enumerated on the host now)
+    if (!((bool)scores && dbg == nullptr && bt.tables) && !bt.t_cl.empty()) stage_a(bt, false, true);
     const std::string &packed = bt.packed;
     const uint64_t total = bt.total, nvals = bt.nvals;
     bt.live = true;
     bt.scored = false;
     bt.gpu = std::shared_future<int>();                                  // (a shared future stays valid after get(): this batch has none yet)
     const bool on_device = (bool)scores && dbg == nullptr && bt.tables;  // -debug wants the per-position values: scored on the host
-    if (total && on_device) {
+    if ((total || !bt.t_cl.empty()) && on_device) {
       bt.scored = true;
       Batch *bp = &bt;
       const int need_dk = mode == MFX_VAR_POLISH ? 1 : 0;
@@ -1103,7 +1258,14 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
         pt.npaths = bp->p_off.size(); pt.nvals = nvals;
         pt.off = bp->p_off.data(); pt.len = bp->p_len.data(); pt.nv = bp->p_nv.data(); pt.voff = bp->p_voff.data(); pt.cfirst = bp->p_cfirst.data();
         pt.gt = bp->p_gt.data(); pt.vidx = bp->p_vidx.data(); pt.vlen = bp->p_vlen.data();
-        const int r = scores(bp->packed.data(), bp->packed.size(), pt, need_dk, bp->numM.data(), bp->totdk.data());
+        mfx_trv_batch tb;
+        if (!bp->t_cl.empty()) {
+          tb.ncl = bp->t_cl.size(); tb.nvar = bp->t_var.size(); tb.nal = bp->t_al.size(); tb.win_bytes = bp->t_win.size(); tb.al_bytes = bp->t_alt.size();
+          tb.cl = bp->t_cl.data(); tb.var = bp->t_var.data(); tb.al = bp->t_al.data(); tb.win_text = bp->t_win.data(); tb.al_text = bp->t_alt.data();
+          tb.text_end = bp->t_text_end; tb.path_cap = bp->t_path_cap; tb.row_cap = bp->t_row_cap;
+          tb.np = bp->t_np.data(); tb.status = bp->t_status.data(); tb.p_len = bp->t_plen.data(); tb.gt = bp->t_gt.data();
+        }
+        const int r = scores(bp->packed.data(), bp->packed.size(), pt, bp->t_cl.empty() ? nullptr : &tb, need_dk, bp->numM.data(), bp->totdk.data());
         if (r) bp->err = mfx_last_error();
         return r;
       });
@@ -1138,6 +1300,19 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
       const int r = bt.gpu.get();
       if (r) { jobs.clear(); packed.clear(); return mfx_fail(r, "%s", bt.err.c_str()); }
     }
+    if (bt.scored && !bt.t_cl.empty()) {
+      // a cluster the device could not enumerate (a replacement past the end of its string -- the host's std::string throws there --,
+      // or more than the room reserved): the whole batch is enumerated on the host, as without the device's traverse
+      bool redo = false;
+      for (uint32_t st : bt.t_status) redo = redo || st != MFX_TRV_OK;
+      if (redo) {
+        stage_a(bt, true, true);
+        int r = stage_b(bt, nullptr);
+        if (r == MFX_OK && bt.gpu.valid()) r = bt.gpu.get();
+        if (r) { jobs.clear(); packed.clear(); return mfx_fail(r, "%s", bt.err.c_str()); }
+        bt.live = false;
+      }
+    }
     lap(3);
     const bool want_dbg = dbg != nullptr;
     const size_t nruns = bt.nruns;                                       // the runs of stage A (one arena each)
@@ -1151,6 +1326,13 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
       // uninitialised until the first valid k-mer writes it; before that it only
       // multiplies |0-0|, so any finite start value is equivalent.  We fix 1.0.
       double prob = 1.0;
+      if (jb.trv >= 0) {                                                 // enumerated on the device: what came back of its paths
+        const mfx_trv_cluster &C = bt.t_cl[jb.ps.ar->b_cl + (uint64_t)jb.trv];
+        jb.ps.np = bt.t_np[jb.ps.ar->b_cl + (uint64_t)jb.trv];
+        jb.ps.dlen = bt.t_plen.data() + C.path0;
+        jb.ps.dgt = bt.t_gt.data() + C.row0;
+        jb.ps.dq0 = bt.npaths + C.path0;
+      }
       const size_t np = jb.ps.size(), nv = jb.ps.nv;
       // what the selectors read: numM always; the paths' total delta-K only in -polish (its tie-break); the per-position
       // K* and delta-K values only in the -debug statistics.  Nothing else is computed or stored.
@@ -1334,6 +1516,7 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
   }
   }
   lap(5);
+  if (trv_check) fprintf(stderr, "[mfx_variants] traverse check: %lu clusters enumerated both ways, all equal\n", (unsigned long)trv_checked.load());
   if (timing)
     fprintf(stderr, "[mfx_variants] load+cluster %.2fs  enumerate %.2fs  pack %.2fs  gpu %.2fs  score+select %.2fs  queue %.2fs  write %.2fs\n",
             t_phase[0], t_phase[1], t_phase[2], t_phase[3], t_phase[4], t_phase[6], t_phase[5]);
@@ -1373,8 +1556,8 @@ extern "C" int mfx_variants_run(mfx_eval *ev, const char *vcf_path, const char *
   PathScores scores;
   const char *hs = getenv("MFX_VAR_HOST_SCORE");
   if (!(hs && atoi(hs)))
-    scores = [ev](const char *text, uint64_t len, const mfx_path_table &pt, int need_dk, uint32_t *numM, double *totdk) -> int {
-      return mfx_score_paths(ev, text, len, &pt, need_dk, numM, totdk);
+    scores = [ev](const char *text, uint64_t len, const mfx_path_table &pt, const mfx_trv_batch *tb, int need_dk, uint32_t *numM, double *totdk) -> int {
+      return tb ? mfx_score_paths_trv(ev, text, len, &pt, tb, need_dk, numM, totdk) : mfx_score_paths(ev, text, len, &pt, need_dk, numM, totdk);
     };
   return variants_guarded("mfx_variants_run", [&] { return mfx_variants_run_values(ev, values, vcf_path, names, bases, lens, ncontigs, opts, out_path, log_path, n_clusters, scores); });
 }
@@ -1426,8 +1609,8 @@ extern "C" int mfx_variants_run_vcf(mfx_eval *ev, mfx_vcf *vcf, const char *cons
   PathScores scores;
   const char *hs = getenv("MFX_VAR_HOST_SCORE");
   if (!(hs && atoi(hs)))
-    scores = [ev](const char *text, uint64_t len, const mfx_path_table &pt, int need_dk, uint32_t *numM, double *totdk) -> int {
-      return mfx_score_paths(ev, text, len, &pt, need_dk, numM, totdk);
+    scores = [ev](const char *text, uint64_t len, const mfx_path_table &pt, const mfx_trv_batch *tb, int need_dk, uint32_t *numM, double *totdk) -> int {
+      return tb ? mfx_score_paths_trv(ev, text, len, &pt, tb, need_dk, numM, totdk) : mfx_score_paths(ev, text, len, &pt, need_dk, numM, totdk);
     };
   return variants_guarded("mfx_variants_run_vcf", [&] { return mfx_variants_run_values(ev, values, nullptr, names, bases, lens, ncontigs, opts, out_path, log_path, n_clusters, scores, vcf); });
 }

@@ -242,3 +242,35 @@ def test_variants_prepared_ahead_debug_and_odd_records(tmp_path):
         for ext in ("vcf", "dbg", "log"):
             assert open(tmp_path / (tag + "a." + ext), "rb").read() == open(tmp_path / (tag + "b." + ext), "rb").read(), (tag, ext)
         loaded.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", MODES)
+def test_variants_device_traverse_equals_host_enumeration(tmp_path, monkeypatch, mode):
+    """the clusters enumerated on the device (mfx_var_traverse_kernel: merfin's traverse, merfin-variants.C:22-126, one cluster per thread,
+    the default) == enumerated on the host (MFX_VAR_DEVICE_TRAVERSE=0) == the oracle: records and log byte for byte; with bursts of
+    variants (clusters beyond the device's limits go to the host inside the same batch) and one cluster per batch as well"""
+    import merfin_amd as m
+    k, peak = 21, 17.3
+    names, asm, vcf, read, amers = synth.variant_world(k=k, peak=peak, seed=81, burst=0.25)
+    vp = str(tmp_path / "in.vcf")
+    open(vp, "w").write(vcf)
+    p = po.Params(k, peak)
+    R, A = po.Lookup(k, *read), po.Lookup(k, *amers)
+    n_o = po.variants_run(p, R, A, mode, vp, names, asm, str(tmp_path / "o.vcf"), log_path=str(tmp_path / "o.log"))
+    ix = m.Index(k, len(read[0]) + len(amers[0]) + 16)
+    ix.add_read(*read)
+    ix.add_asm(*amers)
+    ev = m.Evaluator(ix, m.KParams(peak))
+    outs = {}
+    for tag, env in (("dev", {}), ("host", {"MFX_VAR_DEVICE_TRAVERSE": "0"}), ("dev1", {"MFX_VAR_BATCH_MB": "0"}), ("chk", {"MFX_VAR_TRAVERSE_CHECK": "1"})):
+        for kk in ("MFX_VAR_DEVICE_TRAVERSE", "MFX_VAR_BATCH_MB", "MFX_VAR_TRAVERSE_CHECK"):
+            monkeypatch.delenv(kk, raising=False)
+        for kk, vv in env.items():
+            monkeypatch.setenv(kk, vv)
+        n = ev.variants(mode, vp, names, asm, str(tmp_path / (tag + ".vcf")), log_path=str(tmp_path / (tag + ".log")))
+        assert n == n_o
+        outs[tag] = open(tmp_path / (tag + ".vcf"), "rb").read()
+        assert outs[tag] == open(tmp_path / "o.vcf", "rb").read(), tag
+        assert _special(str(tmp_path / (tag + ".log"))) == _special(str(tmp_path / "o.log")), tag
+    assert outs["dev"] == outs["host"] == outs["dev1"]

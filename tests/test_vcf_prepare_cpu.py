@@ -58,3 +58,42 @@ def test_prepared_run_equals_the_unprepared_one_on_stand_in_values(tmp_path):
                         os.remove("/tmp/mfx_vhb" + t + ext)
             if os.path.exists("/tmp/mfx_vhb.vcf"):
                 os.remove("/tmp/mfx_vhb.vcf")
+
+
+def test_shared_traverse_equals_the_host_recursion(tmp_path):
+    """mfx_traverse_cluster (csrc/mfx_traverse.h: what the device's traverse kernel runs per cluster) against the host's recursion
+    (merfin-variants.C:22-126 restated in mfx_variants.cpp): every eligible cluster of synthetic call sets -- plain, with multi-allelic and
+    odd records, damaged -- enumerated both ways (bases, genotype, offset and length rows of every path: MFX_VAR_TRAVERSE_CHECK), and the whole
+    run's records and log with the clusters enumerated through the tables == with the recursion"""
+    import filecmp
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not shutil.which("g++") or not os.path.exists("/opt/rocm/include"):
+        pytest.skip("no g++ / ROCm headers")
+    exe = str(tmp_path / "vhb")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(root, "tools", "variants_host_bench.cpp"), "-I" + os.path.join(root, "merfin_amd", "csrc"),
+                           "-I" + os.path.join(root, "include"), "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-L" + os.path.join(root, "merfin_amd"),
+                           "-lmerfin_amd", "-Wl,-rpath," + os.path.join(root, "merfin_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    try:
+        for mode, comb, varied, damage in (("5", "15", "0", None), ("4", "3", "1", None), ("5", "15", "1", "1"), ("6", "15", "1", None)):
+            env = dict(os.environ)
+            if damage:
+                env["MFX_VHB_DAMAGE"] = damage
+            r = subprocess.run([exe, "8e6", mode, "1", "", comb, varied, "0", ".u_c"], env=dict(env, MFX_VAR_TRAVERSE_CHECK="1"), capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr[-400:]
+            checked = [l for l in r.stderr.splitlines() if "traverse check" in l]
+            assert checked and int(checked[0].split(":")[1].split()[0]) > 1000, r.stderr[-400:]
+            subprocess.check_call([exe, "8e6", mode, "1", "", comb, varied, "0", ".u_a"], env=dict(env, MFX_VAR_DEVICE_TRAVERSE="0"), stdout=subprocess.DEVNULL)
+            subprocess.check_call([exe, "8e6", mode, "1", "", comb, varied, "0", ".u_b"], env=dict(env, MFX_VAR_DEVICE_TRAVERSE="1"), stdout=subprocess.DEVNULL)
+            assert filecmp.cmp("/tmp/mfx_vhb.u_a.out.vcf", "/tmp/mfx_vhb.u_b.out.vcf", shallow=False)
+            assert filecmp.cmp("/tmp/mfx_vhb.u_a.log", "/tmp/mfx_vhb.u_b.log", shallow=False)
+            assert os.path.getsize("/tmp/mfx_vhb.u_a.out.vcf") > 1000
+    finally:
+        for t in (".u_a", ".u_b", ".u_c"):
+            for ext in (".out.vcf", ".log"):
+                if os.path.exists("/tmp/mfx_vhb" + t + ext):
+                    os.remove("/tmp/mfx_vhb" + t + ext)
+        if os.path.exists("/tmp/mfx_vhb.vcf"):
+            os.remove("/tmp/mfx_vhb.vcf")

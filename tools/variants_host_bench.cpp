@@ -11,7 +11,7 @@
 #include "mfx_internal.h"
 
 using PathValues = std::function<int(const char *, uint64_t, uint32_t *, uint32_t *)>;
-using PathScores = std::function<int(const char *, uint64_t, const mfx_path_table &, int, uint32_t *, double *)>;
+using PathScores = std::function<int(const char *, uint64_t, const mfx_path_table &, const mfx_trv_batch *, int, uint32_t *, double *)>;
 int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const char *vcf_path, const char *const *names, const char *const *bases,
                             const uint64_t *lens, uint32_t ncontigs, const mfx_variant_opts *opts, const char *out_path, const char *log_path,
                             uint64_t *n_clusters, const PathScores &scores, struct mfx_vcf *loaded, uint32_t prepK = 0);
@@ -104,12 +104,29 @@ int main(int argc, char **argv) {
   };
   // argv[3] = 1: the device-scoring form of the pipeline (what the product runs), with a stand-in for mfx_score_paths
   const bool dev = argc > 3 && atoi(argv[3]);
-  PathScores scores = [](const char *text, uint64_t, const mfx_path_table &pt, int need_dk, uint32_t *numM, double *totdk) -> int {
-    for (uint64_t p = 0; p < pt.npaths; ++p) {
-      uint64_t h = (pt.off[p] * 0x9E3779B97F4A7C15ull) ^ (uint64_t)(unsigned char)text[pt.off[p]] * 0xD6E8FEB86659FD93ull;
+  // (the stand-in depends on a path's bases alone -- not on where it lies in the batch -- so that runs with the clusters enumerated by
+  // mfx_traverse_cluster (MFX_VAR_DEVICE_TRAVERSE, here run on the host in the device's place) and by the host's recursion can be compared)
+  PathScores scores = [](const char *text, uint64_t, const mfx_path_table &pt, const mfx_trv_batch *tb, int need_dk, uint32_t *numM, double *totdk) -> int {
+    auto score1 = [&](const char *sq, uint32_t n, uint64_t q) {
+      uint64_t h = 0xcbf29ce484222325ULL;
+      for (uint32_t i = 0; i < n; ++i) { h ^= (unsigned char)sq[i]; h *= 0x100000001b3ULL; }
       h ^= h >> 29;
-      numM[p] = (uint32_t)(h % 3);
-      totdk[p] = need_dk ? (double)(int)(h % 17) - 8.0 : 0.0;
+      numM[q] = n ? (uint32_t)(h % 3) : 0u;
+      totdk[q] = need_dk && n ? (double)(int)(h % 17) - 8.0 : 0.0;
+    };
+    for (uint64_t p = 0; p < pt.npaths; ++p) score1(text + pt.off[p], pt.len[p], p);
+    if (tb && tb->ncl) {
+      std::vector<char> T(tb->text_end + 1, '\n');
+      std::vector<uint64_t> off(tb->path_cap), voff(tb->path_cap), cfirst(tb->path_cap);
+      std::vector<uint32_t> len(tb->path_cap, 0), nv(tb->path_cap), vidx(tb->row_cap), vlen(tb->row_cap);
+      mfx_trv_out o;
+      o.text = T.data(); o.p_off = off.data(); o.p_voff = voff.data(); o.p_cfirst = cfirst.data(); o.p_len = len.data(); o.p_nv = nv.data();
+      o.gt = tb->gt; o.vidx = vidx.data(); o.vlen = vlen.data(); o.table_base = pt.npaths; o.row_base = pt.nvals;
+      for (uint64_t c = 0; c < tb->ncl; ++c) {
+        tb->status[c] = mfx_traverse_cluster(tb->cl[c], tb->var, tb->al, tb->win_text, tb->al_text, o, &tb->np[c]);
+        for (uint32_t q = tb->np[c]; q < tb->cl[c].path_cap; ++q) len[tb->cl[c].path0 + q] = 0;
+      }
+      for (uint64_t q = 0; q < tb->path_cap; ++q) { tb->p_len[q] = len[q]; score1(T.data() + off[q], len[q], pt.npaths + q); }
     }
     return 0;
   };
