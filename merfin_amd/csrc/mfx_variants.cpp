@@ -7,14 +7,14 @@
 //   per-cluster driver        src/merfin/merfin-variants.C:131-345
 //   scoring + selectors       src/merfin/varMer.C:37-659
 //
-// Shape of this implementation (not the reference's): the host enumerates the
-// allele-combination paths of MANY clusters first, packs all path strings into
-// one buffer separated by a non-ACGT byte, and scores them with ONE launch of
-// the same lookup kernel -dump uses (mfx_dump_values): every k-mer of every
-// path is extracted, canonicalised and probed on the GPU.  The host then turns
-// the raw (readV, asmV) per base into numM / K* / delta-K per path and applies
-// the selector of the chosen mode.  merfin scores cluster by cluster with four
-// CPU probes per base (varMer.C:76-84).
+// Shape of this implementation (not the reference's): MANY clusters go through the device at once.  A batch's clusters are handed over as
+// TABLES (window bases, variants, alleles) and every cluster's allele combinations are enumerated there by one wave (mfx_traverse.h,
+// mfx_var_traverse_kernel: the traverse recursion as a loop) straight into the batch's path text; every k-mer of every path is extracted,
+// canonicalised and probed by ONE launch of the lookup kernel -dump uses, and varMer::score runs per path on the device (mfx_score_paths_trv).
+// What comes back is per path: its length, its genotype row, numM and the total delta-K -- the host applies the selector of the chosen mode
+// and writes the records.  Clusters beyond the device's limits (more than 8 variants or 64 combinations, strings beyond 640 bytes), -debug
+// (per-position values) and the sharded index keep the host's enumeration (the same recursion, packed path text) inside the same batches.
+// merfin scores cluster by cluster with four CPU probes per base (varMer.C:76-84).
 #include "mfx_internal.h"
 #include "mfx_pipe.h"
 
