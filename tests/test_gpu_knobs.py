@@ -91,6 +91,8 @@ CLI_KNOBS = [
     ("MFX_CLI_SEQ_THREADS", "1"), ("MFX_VARIANT_SLOTS", "3"), ("MFX_VAR_BATCH_MB", "1"), ("MFX_VAR_HOST_SCORE", "1"),
     ("MFX_HOST_THREADS", "1"), ("MFX_HOST_THREADS", "5"), ("MFX_CLI_TIMING", "3"), ("MFX_DUMP_TIMING", "1"), ("MFX_VAR_TIMING", "1"),
     ("MFX_INGEST_TIMING", "1"), ("MFX_UPLOAD_TIMING", "1"), ("MFX_CLI_SEQ_TIMING", "1"),
+    ("MFX_VAR_DEVICE_TRAVERSE", "0"), ("MFX_VAR_TRAVERSE_CHECK", "1"), ("MFX_CLI_VCF_AHEAD", "2"), ("MFX_CLI_VCF_AHEAD", "1"), ("MFX_CLI_STAGE_FIRST", "0"),
+    ("MFX_DB_STAGE_THREADS", "2"), ("MFX_DB_STAGE_LANES", "6"), ("MFX_PREAD_THREADS", "3"),
 ]
 
 

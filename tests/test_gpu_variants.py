@@ -274,3 +274,33 @@ def test_variants_device_traverse_equals_host_enumeration(tmp_path, monkeypatch,
         assert outs[tag] == open(tmp_path / "o.vcf", "rb").read(), tag
         assert _special(str(tmp_path / (tag + ".log"))) == _special(str(tmp_path / "o.log")), tag
     assert outs["dev"] == outs["host"] == outs["dev1"]
+
+
+@pytest.mark.gpu
+def test_variants_record_past_its_window_fails_the_same_way_with_and_without_the_device_traverse(tmp_path, monkeypatch):
+    """a record whose position lies past the end of its contig makes the reference's std::string::replace throw (merfin-variants.C:60); the
+    host's enumeration reports that as an error -- and so does the run whose clusters are enumerated on the device: the kernel flags the
+    cluster, the batch goes back to the host, the host throws"""
+    import merfin_amd as m
+    k, peak = 21, 17.3
+    names, asm, vcf, read, amers = synth.variant_world(k=k, peak=peak, seed=79, burst=0.3)
+    lines = vcf.rstrip("\n").split("\n")
+    body = [x for x in lines if not x.startswith("#")]
+    w = body[-1].split("\t")
+    w[1] = str(len(asm[names.index(w[0])]) + 5)
+    vp = str(tmp_path / "in.vcf")
+    open(vp, "w").write("\n".join(lines + ["\t".join(w)]) + "\n")
+    ix = m.Index(k, len(read[0]) + len(amers[0]) + 16)
+    ix.add_read(*read)
+    ix.add_asm(*amers)
+    ev = m.Evaluator(ix, m.KParams(peak))
+    for env in ({}, {"MFX_VAR_DEVICE_TRAVERSE": "0"}):
+        monkeypatch.delenv("MFX_VAR_DEVICE_TRAVERSE", raising=False)
+        for kk, vv in env.items():
+            monkeypatch.setenv(kk, vv)
+        with pytest.raises(m.MfxError):
+            ev.variants("polish", vp, names, asm, str(tmp_path / "x.vcf"), comb=2, log_path=str(tmp_path / "x.log"))
+    # ... and the evaluator is fine afterwards
+    monkeypatch.delenv("MFX_VAR_DEVICE_TRAVERSE", raising=False)
+    open(vp, "w").write(vcf)
+    assert ev.variants("polish", vp, names, asm, str(tmp_path / "y.vcf"), log_path=str(tmp_path / "y.log")) > 0
