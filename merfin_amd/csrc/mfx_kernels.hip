@@ -987,6 +987,27 @@ __device__ __forceinline__ mfx_probe mfx_home_placed(const mfx_table_view &t, ui
   return pr;
 }
 
+// ... of the DIRECT form (k <= 21): the line is `top`'s, the first mini-bucket wants the sampling t-mer's offset x, which the record does not
+// carry -- but it carries the window j = x mod 4, and the smallest t-mer of the k-mer (ties: the leftmost) is then the smallest among the
+// offsets j, j + 4, j + 8, ...: four order hashes instead of the sixteen of the whole scan (mfx_mod_window).
+__device__ __forceinline__ mfx_probe mfx_home_placed_direct(const mfx_table_view &t, uint64_t key, uint32_t top, uint32_t meta) {
+  mfx_probe pr;
+  const int k = t.k, tl = t.mz_t;
+  const uint64_t rc = mfx_revcomp(key, k);
+  const uint32_t tmask = (1u << (2 * tl)) - 1u, j = (meta >> 1) & 3u;
+  uint32_t best = 0xffffffffu, x = j;
+  for (int p = (int)j; p + tl <= k; p += MFX_PLACE_W) {
+    const uint32_t a = (uint32_t)(key >> (2 * (k - tl - p))) & tmask, b = (uint32_t)(rc >> (2 * p)) & tmask;
+    const uint32_t o = mfx_p_tmer_order(a < b ? a : b);
+    if (o < best) { best = o; x = (uint32_t)p; }
+  }
+  pr.lineA = __umulhi(top, (uint32_t)t.nlines);
+  pr.lineB = mfx_range32(mfx_hash64(key), t.nlines);          // (candidate lines beyond the minimizer's region follow the k-mer's own hash, as mfx_home's)
+  pr.b0 = (x + (top >> 3)) & 7u;
+  pr.fkey = key;
+  return pr;
+}
+
 // The delta-coded blocks of a PLACED database (mfx_db.cpp FLAT_PLACED): the records are the numbers P of mfx_place.h in ascending
 // order, i.e. in the order of the table's lines -- a block of 4096 records touches a few hundred CONSECUTIVE lines, each of which is
 // read from HBM once, updated in the L2 and written back once, where a k-mer-sorted database reads a random line per record
@@ -1047,10 +1068,10 @@ __global__ __launch_bounds__(256) void mfx_table_add_placed_kernel(mfx_table_vie
           v[i] = (uint32_t)mfx_bits_at(pw, vbit0 + (uint64_t)e * vb, vb);
           if (v[i] == (1u << vb) - 1u) v[i] = 0u;              // escape: added separately (the file's escape list)
           if (run >> mfx_p_bits(t.k)) { if (v[i]) ++T.wide; v[i] = 0u; }      // (a damaged record: wider than any P of this k)
-          if (placed && t.quot) pr[i] = mfx_home_placed(t, key[i], top, hi, pm);     // (k <= 21: the first mini-bucket needs the t-mer's offset: mfx_home scans for it)
+          if (placed) pr[i] = t.quot ? mfx_home_placed(t, key[i], top, hi, pm) : mfx_home_placed_direct(t, key[i], top, pm);
         }
       }
-      mfx_apply_batch<4>(t, key, v, side, meta, T, (placed && t.quot) ? pr : nullptr, placed != 0);
+      mfx_apply_batch<4>(t, key, v, side, meta, T, placed ? pr : nullptr, placed != 0);
     }
   }
   mfx_tally_flush(meta, T);
@@ -3190,6 +3211,9 @@ hipError_t mfx_k_table_add_delta(mfx_table_view t, const uint64_t *payload, cons
 }
 // does this table take a placed database's records by their own placement?  (the compact layout under its default placement)
 int mfx_k_table_takes_placed(const mfx_table_view &t) {
+#if MFX_V_PLACE_OLDLINE || MFX_V_PLACE_WBUCKET
+  if (!t.quot) return 0;                                       // (A/B builds of the direct form's placement: the records are placed anew)
+#endif
   return t.compact && t.seq_only && t.k >= MFX_PLACE_MIN_K && t.k <= MFX_PLACE_MAX_K && t.mz_w == MFX_PLACE_W && t.mz_t == mfx_p_tlen(t.k) && t.shard_n <= 1;
 }
 hipError_t mfx_k_table_add_placed(mfx_table_view t, const uint64_t *payload, const uint64_t *dir, uint32_t nblocks, uint64_t n,
