@@ -739,27 +739,85 @@ struct VarPrepared {
 };
 
 // dynamic parallel-for over [0, n) on the host threads the library may use
+// Host threads that live for a whole run of the variant modes: a batch goes through five parallel loops and a config-4 call set through
+// ~40 batches -- starting and joining 16 threads for each loop was 0.8 ms of its 1-3 ms (and the loops' per-thread scratch was made anew
+// every time).  The run's driving thread installs its pool (t_var_pool); parallel_for on that thread hands its loop to it.
+struct VarPool {
+  unsigned W;
+  std::vector<std::thread> th;
+  std::mutex m;
+  std::condition_variable wake, idle;
+  const std::function<void()> *job = nullptr;
+  uint64_t gen = 0;
+  unsigned running = 0;
+  bool quit = false;
+  explicit VarPool(unsigned w) : W(w) {
+    for (unsigned i = 0; i < W; ++i)
+      th.emplace_back([this]() {
+        uint64_t seen = 0;
+        for (;;) {
+          const std::function<void()> *f;
+          {
+            std::unique_lock<std::mutex> lk(m);
+            wake.wait(lk, [&] { return quit || gen != seen; });
+            if (quit) return;
+            seen = gen;
+            f = job;
+          }
+          (*f)();                                              // (never throws: parallel_for's body catches)
+          std::lock_guard<std::mutex> lk(m);
+          if (--running == 0) idle.notify_all();
+        }
+      });
+  }
+  void run(const std::function<void()> &f) {                   // f on every thread of the pool; returns when all are through
+    {
+      std::lock_guard<std::mutex> lk(m);
+      job = &f;
+      running = W;
+      ++gen;
+    }
+    wake.notify_all();
+    std::unique_lock<std::mutex> lk(m);
+    idle.wait(lk, [&] { return running == 0; });
+  }
+  ~VarPool() {
+    { std::lock_guard<std::mutex> lk(m); quit = true; }
+    wake.notify_all();
+    for (auto &t : th) t.join();
+  }
+};
+thread_local VarPool *t_var_pool = nullptr;
+
 template <class F>
 void parallel_for(size_t n, F &&fn) {
-  unsigned nt = std::min<size_t>(mfx_host_threads(), n);
+  VarPool *pool = t_var_pool;
+  unsigned nt = std::min<size_t>(pool ? pool->W : mfx_host_threads(), n);
   if (nt <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
   const size_t chunk = std::max<size_t>(1, std::min<size_t>(64, n / (nt * 8)));
   std::atomic<size_t> next(0);
-  std::vector<std::thread> th;
   std::exception_ptr thrown;                                   // what a worker throws (an allocation failure) is rethrown by the caller
   std::mutex thrown_mu;
-  for (unsigned t = 0; t < nt; ++t)
-    th.emplace_back([&]() {
-      try {
-        for (size_t b; (b = next.fetch_add(chunk)) < n;)
-          for (size_t i = b, e = std::min(n, b + chunk); i < e; ++i) fn(i);
-      } catch (...) {
-        std::lock_guard<std::mutex> lk(thrown_mu);
-        if (!thrown) thrown = std::current_exception();
-        next.store(n);                                         // the others stop at their next draw
-      }
-    });
-  for (auto &x : th) x.join();
+  auto body = [&]() {
+    try {
+      for (size_t b; (b = next.fetch_add(chunk)) < n;)
+        for (size_t i = b, e = std::min(n, b + chunk); i < e; ++i) fn(i);
+    } catch (...) {
+      std::lock_guard<std::mutex> lk(thrown_mu);
+      if (!thrown) thrown = std::current_exception();
+      next.store(n);                                           // the others stop at their next draw
+    }
+  };
+  if (pool) {
+    t_var_pool = nullptr;                                      // (a loop inside the loop -- there is none -- would start its own threads)
+    const std::function<void()> job = body;
+    pool->run(job);
+    t_var_pool = pool;
+  } else {
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t) th.emplace_back(body);
+    for (auto &x : th) x.join();
+  }
   if (thrown) std::rethrow_exception(thrown);
 }
 
@@ -973,6 +1031,10 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
     }
   } files;
   files.log = log;
+
+  // this thread drives the stages: its parallel loops run on threads that live as long as the run
+  VarPool run_pool(std::max(1u, mfx_host_threads()));
+  struct PoolScope { VarPool *prev; explicit PoolScope(VarPool *p) : prev(t_var_pool) { t_var_pool = p; } ~PoolScope() { t_var_pool = prev; } } poolScope(&run_pool);
 
   // MFX_VAR_TIMING=1: per-phase wall time on stderr (diagnostics only)
   const bool timing = getenv("MFX_VAR_TIMING") && atoi(getenv("MFX_VAR_TIMING"));
@@ -1252,7 +1314,8 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
       const int need_dk = mode == MFX_VAR_POLISH ? 1 : 0;
       std::shared_future<int> prev = prevb ? prevb->gpu : std::shared_future<int>();
       bt.gpu = std::async(std::launch::async, [bp, prev, need_dk, nvals, &scores]() mutable {
-        if (prev.valid()) prev.wait();                                   // one stage B at a time on the evaluator
+        if (prev.valid()) prev.wait();                                   // one stage B at a time on the evaluator (two at once were measured: their
+                                                                         // allocations and frees stall each other -- config 4: 0.68 -> 0.84 s)
         prev = std::shared_future<int>();                                // (let go of the earlier batch's state: no chain of all batches so far)
         mfx_path_table pt;
         pt.npaths = bp->p_off.size(); pt.nvals = nvals;
