@@ -1687,6 +1687,7 @@ extern "C" void mfx_eval_free(mfx_eval *ev) {
   for (auto &p : ev->h_stage) if (p) (void)hipHostFree(p);
   for (auto &p : ev->h_pack) if (p) (void)hipHostFree(p);
   if (ev->pool) delete static_cast<WorkerPool *>(ev->pool);
+  if (ev->d_var_scratch) (void)hipFree(ev->d_var_scratch);
   if (ev->sr.d_counts) (void)hipFree(ev->sr.d_counts);
   if (ev->sr.d_kover) (void)hipFree(ev->sr.d_kover);
   if (ev->sr.h_img) (void)hipHostFree(ev->sr.h_img);
@@ -3841,22 +3842,37 @@ int mfx_score_paths_trv(mfx_eval *ev, const char *text, uint64_t len, const mfx_
   int rc = index_canonical(ev->ix, &canon);
   if (rc) return rc;
   // the batch's text on the device: the host's paths copied in, the rest '\n' (no k-mer) until the traverse kernel writes its paths; the
-  // tile loads of the lookup kernel reach a tile past the end
+  // tile loads of the lookup kernel reach a tile past the end.  Every array of this call is a piece of ONE allocation that the evaluator
+  // keeps from batch to batch (a run scores ~40 batches of the same size: ~20 allocations and as many frees -- each a device-wide wait --
+  // per batch were a third of a batch's 7 ms).
   const uint64_t text_bytes = ((total + MFX_TILE - 1) / MFX_TILE + 2) * MFX_TILE + 256;
-  DevBuf<uint8_t> dtext, dwin, dal;
-  DevBuf<mfx_trv_cluster> dcl;
-  DevBuf<mfx_trv_variant> dvar;
-  DevBuf<mfx_trv_allele> dall;
-  DevBuf<uint32_t> dr, da, dlen, dnv, dvidx, dvlen, dnum, dnp, dst;
-  DevBuf<int32_t> dgt;
-  DevBuf<uint64_t> ds, doff, dvoff, dcf;
-  DevBuf<double> ddk;
-  MFX_HIP(dtext.alloc(text_bytes)); MFX_HIP(dr.alloc(total)); MFX_HIP(da.alloc(total)); MFX_HIP(ds.alloc(2));
-  MFX_HIP(doff.alloc(NP)); MFX_HIP(dlen.alloc(NP)); MFX_HIP(dnv.alloc(NP)); MFX_HIP(dvoff.alloc(NP)); MFX_HIP(dcf.alloc(NP));
-  MFX_HIP(dgt.alloc(NV ? NV : 1)); MFX_HIP(dvidx.alloc(NV ? NV : 1)); MFX_HIP(dvlen.alloc(NV ? NV : 1));
-  MFX_HIP(dnum.alloc(NP)); MFX_HIP(ddk.alloc(need_dk ? NP : 1));
+  std::lock_guard<std::mutex> scratch_lock(ev->var_scratch_mu);
+  uint64_t need = 0;
+  auto piece = [&](uint64_t bytes) { const uint64_t at = need; need += (bytes + 255) & ~255ull; return at; };
+  const uint64_t o_text = piece(text_bytes), o_r = piece(total * 4), o_a = piece(total * 4), o_s = piece(16), o_off = piece(NP * 8), o_len = piece(NP * 4), o_nv = piece(NP * 4),
+                 o_voff = piece(NP * 8), o_cf = piece(NP * 8), o_gt = piece((NV ? NV : 1) * 4), o_vidx = piece((NV ? NV : 1) * 4), o_vlen = piece((NV ? NV : 1) * 4),
+                 o_num = piece(NP * 4), o_dk = piece((need_dk ? NP : 1) * 8), o_cl = piece(tb->ncl * sizeof(mfx_trv_cluster)), o_var = piece(tb->nvar * sizeof(mfx_trv_variant)),
+                 o_all = piece(tb->nal * sizeof(mfx_trv_allele)), o_win = piece(tb->win_bytes), o_alt = piece(tb->al_bytes), o_np = piece(tb->ncl * 4), o_st = piece(tb->ncl * 4);
+  if (need > ev->var_scratch_bytes) {
+    if (ev->d_var_scratch) { (void)hipFree(ev->d_var_scratch); ev->d_var_scratch = nullptr; ev->var_scratch_bytes = 0; }
+    const uint64_t want = need + need / 4;
+    if (hipMalloc((void **)&ev->d_var_scratch, want) != hipSuccess) { (void)hipGetLastError(); return mfx_fail(MFX_E_NOMEM, "mfx_score_paths: no device memory for a batch of paths (%.1f GB)", want / 1e9); }
+    ev->var_scratch_bytes = want;
+  }
+  uint8_t *const B = ev->d_var_scratch;
+  struct P8 { uint8_t *p; } dtext{B + o_text}, dwin{B + o_win}, dal{B + o_alt};
+  struct PC { mfx_trv_cluster *p; } dcl{reinterpret_cast<mfx_trv_cluster *>(B + o_cl)};
+  struct PV { mfx_trv_variant *p; } dvar{reinterpret_cast<mfx_trv_variant *>(B + o_var)};
+  struct PA { mfx_trv_allele *p; } dall{reinterpret_cast<mfx_trv_allele *>(B + o_all)};
+  struct P32 { uint32_t *p; } dr{reinterpret_cast<uint32_t *>(B + o_r)}, da{reinterpret_cast<uint32_t *>(B + o_a)}, dlen{reinterpret_cast<uint32_t *>(B + o_len)},
+      dnv{reinterpret_cast<uint32_t *>(B + o_nv)}, dvidx{reinterpret_cast<uint32_t *>(B + o_vidx)}, dvlen{reinterpret_cast<uint32_t *>(B + o_vlen)},
+      dnum{reinterpret_cast<uint32_t *>(B + o_num)}, dnp{reinterpret_cast<uint32_t *>(B + o_np)}, dst{reinterpret_cast<uint32_t *>(B + o_st)};
+  struct PI { int32_t *p; } dgt{reinterpret_cast<int32_t *>(B + o_gt)};
+  struct P64 { uint64_t *p; } ds{reinterpret_cast<uint64_t *>(B + o_s)}, doff{reinterpret_cast<uint64_t *>(B + o_off)}, dvoff{reinterpret_cast<uint64_t *>(B + o_voff)},
+      dcf{reinterpret_cast<uint64_t *>(B + o_cf)};
+  struct PD { double *p; } ddk{reinterpret_cast<double *>(B + o_dk)};
   hipStream_t st = nullptr;
-  MFX_HIP(mfx_memset_now(dtext.p, '\n', text_bytes));
+  MFX_HIP(mfx_memset_now(dtext.p + len, '\n', text_bytes - len));
   MFX_HIP(hipMemsetAsync(ds.p, 0, 2 * sizeof(uint64_t), st));
   if (len) MFX_HIP(hipMemcpyAsync(dtext.p, text, len, hipMemcpyHostToDevice, st));
   if (hp) {
@@ -3872,8 +3888,6 @@ int mfx_score_paths_trv(mfx_eval *ev, const char *text, uint64_t len, const mfx_
     MFX_HIP(hipMemcpyAsync(dvlen.p, pt->vlen, hv * 4, hipMemcpyHostToDevice, st));
   }
   if (tb->ncl) {
-    MFX_HIP(dcl.alloc(tb->ncl)); MFX_HIP(dvar.alloc(tb->nvar)); MFX_HIP(dall.alloc(tb->nal));
-    MFX_HIP(dwin.alloc(tb->win_bytes)); MFX_HIP(dal.alloc(tb->al_bytes)); MFX_HIP(dnp.alloc(tb->ncl)); MFX_HIP(dst.alloc(tb->ncl));
     MFX_HIP(hipMemcpyAsync(dcl.p, tb->cl, tb->ncl * sizeof(mfx_trv_cluster), hipMemcpyHostToDevice, st));
     MFX_HIP(hipMemcpyAsync(dvar.p, tb->var, tb->nvar * sizeof(mfx_trv_variant), hipMemcpyHostToDevice, st));
     if (tb->nal) MFX_HIP(hipMemcpyAsync(dall.p, tb->al, tb->nal * sizeof(mfx_trv_allele), hipMemcpyHostToDevice, st));

@@ -264,6 +264,11 @@ struct mfx_eval {
   uint8_t  *h_stage[2] = {nullptr, nullptr};   // pinned staging of the streamed upload (pageable sources), kept between calls
   size_t    h_stage_bytes = 0;
   void     *pool = nullptr;                             // host threads parked between streamed runs (mfx_api.cpp: WorkerPool)
+  // device scratch of mfx_score_paths_trv (the variant modes score ~40 batches per run, one at a time: their ~20 arrays are carved out of one
+  // allocation that is kept from batch to batch)
+  uint8_t  *d_var_scratch = nullptr;
+  uint64_t  var_scratch_bytes = 0;
+  std::mutex var_scratch_mu;
   uint8_t  *h_pack[3] = {nullptr, nullptr, nullptr};   // pinned staging of the PACKED streamed upload (codes then validity words)
   size_t    h_pack_words = 0;
   // what a streamed run needs besides, kept between calls (creating and releasing it costs ~2.5 ms, 7 % of a 3 Gb run)
