@@ -107,6 +107,116 @@ def make_truth(sizes, seed=SEED, device="cuda", unit=10000):
     return contigs, layout
 
 
+# ---------------------------------------------------------------------------
+# The `repeats` world: what a real (T2T-style human) assembly adds to the i.i.d. genome of SURVEY 8(d) -- repeat families whose
+# k-mers have copy numbers in the hundreds to hundreds of thousands, i.e. read counts far beyond the 11-bit count fields of the
+# compact index (readV >= 2047 <=> copy number >~ 79 at 26x) and assembly counts beyond them as well:
+#   alu      : dispersed families, 300 bp consensus x 100 000 copies, every copy diverged from the consensus by its own 5-15 %
+#   sat      : tandem arrays of a 171 bp monomer x 10 000 copies, the array's divergence one of 2 / 5 / 10 / 20 %
+#   tandem5  : an EXACT 5-mer tandem array (>= 2 Mb: five distinct 21-mers, 400 000 copies each)
+#   rdna     : a 45 kb unit x 400 copies (five arrays of 80), 0.1 % diverged
+# `level` (percent of positions meant to carry a saturated read count: 1, 3, 10) picks how many of each; the copy numbers are
+# scaled with the genome (x total / 3 Gb, never below `min_copies`) so that a small sample of the world still saturates.
+# Everything is a pure function of (seed, level, sizes).
+# ---------------------------------------------------------------------------
+REPEAT_LEVELS = {
+    #        alu families, satellite arrays, tandem5 arrays, rdna copies per array (x5 arrays)
+    1:  dict(alu=1,  sat=4,   tandem5=1, rdna=80),
+    3:  dict(alu=5,  sat=24,  tandem5=2, rdna=160),
+    10: dict(alu=18, sat=100, tandem5=4, rdna=480),
+}
+
+
+def _mutated_copies(cons_codes, ncopies, div, seed, device):
+    """[ncopies, L] uint8 ASCII: the consensus (codes 0..3) with i.i.d. substitutions at rate div[copy] (a tensor or a float)"""
+    L = cons_codes.numel()
+    h = _hash_range(seed, 0, ncopies * L, device).view(ncopies, L)
+    u = _lsr(h, 11).double() * (1.0 / (1 << 53))
+    d = div.view(-1, 1) if torch.is_tensor(div) else div
+    hit = u < d
+    code = cons_codes.view(1, L).expand(ncopies, L).long()
+    code = torch.where(hit, (code + 1 + (_lsr(h, 3) % 3)) & 3, code)
+    return torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)[code]
+
+
+def inject_repeats(contigs, level, seed=SEED, min_copies=400):
+    """writes the repeat families of REPEAT_LEVELS[level] into the truth contigs (in place); returns a description"""
+    spec = REPEAT_LEVELS[level]
+    total = sum(int(c.numel()) for c in contigs)
+    scale = min(1.0, total / 3e9)
+    dev = contigs[0].device
+    big = [i for i, c in enumerate(contigs) if c.numel() >= 200000]
+    if not big:
+        return {"level": level, "bases": 0}
+    r = _Rng(seed * 131 + level)
+    placed = {"alu": 0, "sat": 0, "tandem5": 0, "rdna": 0}
+
+    def rand_codes(n, s):
+        return (_lsr(_hash_range(s, 0, n, dev), 61) & 3).to(torch.uint8)
+
+    # tandem arrays first (the dispersed copies then fall into them here and there, as they do in a genome)
+    for a in range(spec["tandem5"]):
+        ci = big[r.below(len(big))]
+        c = contigs[ci]
+        n = min(int(2_000_000 * max(scale, 0.05)), c.numel() // 8) // 5 * 5
+        p = r.below(c.numel() - n)
+        unit = torch.tensor(list(b"GGAAT" if a % 2 == 0 else b"CTTAC"), dtype=torch.uint8, device=dev)
+        if a >= 2:
+            unit = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)[rand_codes(5, seed + 17 * a).long()]
+        c[p:p + n] = unit.repeat(n // 5)
+        placed["tandem5"] += n
+    for a in range(5):
+        ci = big[r.below(len(big))]
+        c = contigs[ci]
+        ncop = max(int(spec["rdna"] * max(scale, 0.1)), 8)
+        L = 45000
+        while ncop * L > c.numel() // 4 and L > 2000:
+            L //= 2
+        cons = rand_codes(L, seed + 0x4D4A)                      # ONE unit for the five arrays
+        cp = _mutated_copies(cons, ncop, 0.001, seed + 911 * (a + 1), dev)
+        p = r.below(c.numel() - ncop * L)
+        c[p:p + ncop * L] = cp.view(-1)
+        placed["rdna"] += ncop * L
+    for a in range(spec["sat"]):
+        ci = big[r.below(len(big))]
+        c = contigs[ci]
+        ncop = max(int(10000 * scale), min_copies)
+        while ncop * 171 > c.numel() // 8:
+            ncop //= 2
+        cons = rand_codes(171, seed + 0x5A7 + 31 * a)
+        div = (0.02, 0.05, 0.10, 0.20)[a % 4]
+        cp = _mutated_copies(cons, ncop, div, seed + 7717 * (a + 1), dev)
+        p = r.below(c.numel() - ncop * 171)
+        c[p:p + ncop * 171] = cp.view(-1)
+        placed["sat"] += ncop * 171
+    # dispersed families: the copies of one family are dealt to the contigs by size, on a grid of 512-base cells picked by hash
+    L = 300
+    for a in range(spec["alu"]):
+        ncop_total = max(int(100000 * scale), min_copies)
+        cons = rand_codes(L, seed + 0xA1 + 53 * a)
+        for ci in big:
+            c = contigs[ci]
+            n = c.numel()
+            ncells = n // 512 - 1
+            want = ncop_total * n / float(sum(contigs[i].numel() for i in big))
+            if ncells < 4 or want < 0.5:
+                continue
+            hc = _hash_range(seed + 0xCE11 + 97 * a + 1009 * ci, 0, ncells, dev)
+            pick = (_lsr(hc, 11).double() * (1.0 / (1 << 53))) < min(0.5, want / ncells)
+            cells = pick.nonzero().squeeze(1)
+            if cells.numel() == 0:
+                continue
+            ncop = int(cells.numel())
+            pos = cells * 512 + (_lsr(hc[cells], 3) % (512 - L))
+            dv = 0.05 + 0.10 * (_lsr(_hash_range(seed + 0xD1 + a + 13 * ci, 0, ncop, dev), 11).double() * (1.0 / (1 << 53)))
+            cp = _mutated_copies(cons, ncop, dv, seed + 333 * (a + 1) + 7 * ci, dev)
+            idx = (pos.view(-1, 1) + torch.arange(L, device=dev).view(1, L)).view(-1)
+            c[idx] = cp.view(-1)
+            placed["alu"] += ncop * L
+    placed.update(level=level, bases=sum(placed.values()), scale=scale)
+    return placed
+
+
 def make_assembly(truth, layout, seed=SEED, sub_rate=1e-4, unit=10000):
     """assembly = truth + substitutions (1e-4/base) + some 2-copy repeats collapsed
     (second copy replaced by novel sequence) + some unique segments duplicated,
@@ -283,12 +393,13 @@ def add_neighbor_error_kmers(ix, truth, k, seed=SEED, per_position=1.0, chunk=1 
 
 
 def build_world(m, total_bases, k=21, lam=26.0, ncontigs=24, seed=SEED, device=0, err_factor=1.0, verbose=None,
-                err_mode="random", index_factory=None, seq_only=False):
+                err_mode="random", index_factory=None, seq_only=False, repeats=0):
     """Full synthetic -hist workload resident on `device`: returns (index, sequences, info).
     index_factory(k, capacity, device=) may supply the index (e.g. a fan-out over the shards of a sharded index).
     seq_only: the SEQUENCE-ONLY index the CLI builds for -hist / -dump (mfx_index_create_for_seq): the assembly's k-mers
     are claimed and counted first, the read database -- the very same k-mers and counts as for the full index -- then
-    only updates them."""
+    only updates them.
+    repeats: 0 = SURVEY 8(d)'s i.i.d. genome; 1 / 3 / 10 = the `repeats` world at that level (inject_repeats): info["repeats"]."""
     import time
     torch.cuda.set_device(device)
     dev = "cuda:%d" % device
@@ -296,9 +407,10 @@ def build_world(m, total_bases, k=21, lam=26.0, ncontigs=24, seed=SEED, device=0
     t0 = time.time()
     sizes = contig_sizes(total_bases, ncontigs)
     truth, layout = make_truth(sizes, seed, dev)
+    rep_info = inject_repeats(truth, repeats, seed) if repeats else None
     asm = make_assembly(truth, layout, seed)
     torch.cuda.synchronize()
-    say("genome+assembly generated: %.1fs" % (time.time() - t0))
+    say("genome+assembly generated: %.1fs%s" % (time.time() - t0, (" (repeat families: %r)" % (rep_info,)) if rep_info else ""))
     n_err = int(total_bases * err_factor)
     if seq_only:
         seqs = m.Sequences.from_device([a.data_ptr() for a in asm], [a.numel() for a in asm], device=device)
@@ -313,6 +425,7 @@ def build_world(m, total_bases, k=21, lam=26.0, ncontigs=24, seed=SEED, device=0
         info = ix.info()
         info["build_s"] = time.time() - t0
         info["sizes"] = sizes
+        info["repeats"] = rep_info
         return ix, seqs, asm, info
     cap = int(total_bases * 1.03) + n_err + 1024
     ix = (index_factory or m.Index)(k, cap, device=device)
@@ -332,4 +445,5 @@ def build_world(m, total_bases, k=21, lam=26.0, ncontigs=24, seed=SEED, device=0
     info = ix.info()
     info["build_s"] = time.time() - t0
     info["sizes"] = sizes
+    info["repeats"] = rep_info
     return ix, seqs, asm, info
