@@ -51,7 +51,7 @@ extern "C" {
 #define MFX_E_NOMEM      -2   /* host or device allocation failed              */
 #define MFX_E_HIP        -3   /* a HIP runtime call failed                     */
 #define MFX_E_FULL       -4   /* index capacity exceeded                       */
-#define MFX_E_OVERFLOW   -5   /* histogram overflow list exhausted             */
+#define MFX_E_OVERFLOW   -5   /* more DISTINCT far K* bins than an evaluator holds */
 #define MFX_E_IO         -6   /* file could not be read / parsed               */
 #define MFX_E_FORMAT     -7   /* file magic / version / layout not recognised  */
 #define MFX_E_NODEVICE   -8   /* no usable HIP device                          */
@@ -272,7 +272,8 @@ typedef struct {
 typedef struct mfx_eval mfx_eval;
 
 /* nbins: dense K* bins kept per side on the device (0 = default 65536); bins
- * beyond go through an overflow list, so results do not depend on it. */
+ * beyond are aggregated in a table of far bins (mfx_hist_take_overflow), so
+ * results do not depend on it. */
 mfx_eval *mfx_eval_create(const mfx_index *ix, const mfx_kparams *kp, uint32_t nbins);
 void      mfx_eval_free(mfx_eval *ev);
 uint32_t  mfx_eval_nbins(const mfx_eval *ev);
@@ -397,7 +398,7 @@ int       mfx_comm_rank(const mfx_comm *c);
 int       mfx_comm_size(const mfx_comm *c);
 int       mfx_comm_barrier(mfx_comm *c, void *stream);      /* all ranks arrived and `stream` drained (synchronous) */
 int       mfx_hist_allreduce(mfx_comm *c, uint64_t *d_counts, double *d_kover, uint32_t nbins, uint32_t ncontigs, void *stream);
-/* synchronises `stream`; records[] receives the records of all ranks in rank order */
+/* synchronises `stream`; records[] (2 * cap words) receives the two-word records of all ranks in rank order; *n_out = records */
 int       mfx_hist_allgather_overflow(mfx_comm *c, mfx_eval *ev, uint64_t *records, uint64_t cap, uint64_t *n_out, void *stream);
 /* The exchange step of the sharded index (config 5: "allToAllv of the routed k-mers") for the
  * one-process-per-GPU form: group r of d_send (send_counts[r] elements of elem_bytes, groups back to back in rank order:
@@ -407,7 +408,7 @@ int       mfx_hist_allgather_overflow(mfx_comm *c, mfx_eval *ev, uint64_t *recor
 int       mfx_comm_exchange_counts(mfx_comm *c, const uint64_t *send_counts, uint64_t *recv_counts, void *stream);
 int       mfx_comm_alltoallv(mfx_comm *c, const void *d_send, const uint64_t *send_counts, void *d_recv, const uint64_t *recv_counts,
                              uint32_t elem_bytes, void *stream);
-/* fold overflow records (mfx_hist_take_overflow / mfx_hist_allgather_overflow format) into a result */
+/* fold n overflow records (two words each: mfx_hist_take_overflow / mfx_hist_allgather_overflow format) into a result */
 int       mfx_hist_result_add_overflow(mfx_hist_result *r, const uint64_t *records, uint64_t n);
 
 /* Device-side accumulate for sharded runs.  d_counts: uint64[MFX_HIST_WORDS]
@@ -430,8 +431,12 @@ int mfx_hist_launch_cyclic(mfx_eval *ev, const mfx_seq *seq, uint32_t rank, uint
  * (pure host code: usable without a device, e.g. on the reducing rank) */
 int mfx_hist_result_from_counts(uint32_t nbins, const uint64_t *h_counts, double kover,
                                 uint32_t ncontigs, mfx_hist_result *out);
-/* K* bins >= nbins seen by launches on this evaluator since the last call:
- * copies up to `cap` records (bit 63 = 1 for `over`, low bits = bin index). */
+/* K* bins >= nbins seen by launches on this evaluator since the last call.  The reference's histogram arrays grow without a
+ * bound (increaseArray, merfin-histogram.C:74,87); here the far bins are AGGREGATED on the device, {bin -> occurrences}, so any
+ * number of k-mers may fall there (an assembly's satellite array the reads under-represent puts millions of positions into a
+ * few far bins); only the number of DISTINCT far bins per evaluator is bounded (2^20; beyond: MFX_E_OVERFLOW, create the
+ * evaluator with a larger nbins).  Copies up to `cap` records of TWO words each -- {bit 63 = 1 for `over` | bin index,
+ * occurrences} --, sorted by the first word; *n_out = records; the evaluator's table is emptied. */
 int mfx_hist_take_overflow(mfx_eval *ev, uint64_t *records, uint64_t cap, uint64_t *n_out);
 
 /* reportHistogram (merfin-histogram.C:140-176): the histogram file text and

@@ -688,10 +688,10 @@ class HistResult:
         return np.ctypeslib.as_array(self.c.contig_kmissing, shape=(max(self.c.ncontigs, 1),))[:self.c.ncontigs].copy()
 
     def add_overflow(self, records):
-        """fold K* bins >= nbins (Evaluator.take_overflow / Comm.allgather_overflow records) into this result"""
-        rec = np.ascontiguousarray(records, dtype=np.uint64)
+        """fold K* bins >= nbins (Evaluator.take_overflow / Comm.allgather_overflow: {key, occurrences} pairs, shape (n, 2)) into this result"""
+        rec = np.ascontiguousarray(records, dtype=np.uint64).reshape(-1)
         if len(rec):
-            _check(load_library().mfx_hist_result_add_overflow(C.byref(self.c), rec.ctypes.data_as(C.POINTER(C.c_uint64)), len(rec)))
+            _check(load_library().mfx_hist_result_add_overflow(C.byref(self.c), rec.ctypes.data_as(C.POINTER(C.c_uint64)), len(rec) // 2))
         return self
 
     def report(self, k, hist_path=None, summary_path=None):
@@ -900,12 +900,13 @@ class Comm:
         _check(load_library().mfx_comm_barrier(self.h, C.c_void_p(stream or 0)))
 
     def allgather_overflow(self, ev, cap=1 << 20, stream=None):
-        """records of ALL ranks (collective; call on every rank when the reduced image's novf word is non-zero)"""
-        rec = np.zeros(cap, dtype=np.uint64)
+        """the far K* bins of ALL ranks as {key, occurrences} pairs, shape (n, 2) (collective; call on every rank when the reduced
+        image's novf word is non-zero)"""
+        rec = np.zeros(2 * cap, dtype=np.uint64)
         n = C.c_uint64(0)
         _check(load_library().mfx_hist_allgather_overflow(self.h, ev.h, rec.ctypes.data_as(C.POINTER(C.c_uint64)), cap, C.byref(n),
                                                           C.c_void_p(stream or 0)))
-        return rec[:n.value]
+        return rec[:2 * n.value].reshape(-1, 2)
 
     def exchange_counts(self, send_counts, stream=None):
         """what every rank will send to this one (all-gather of the count rows; synchronises `stream`)"""
@@ -1040,10 +1041,12 @@ class Evaluator:
         return result_from_counts(self.nbins, h_counts, kover, ncontigs)
 
     def take_overflow(self, cap=1 << 20):
-        rec = np.zeros(cap, dtype=np.uint64)
+        """the K* bins beyond the dense image seen by this evaluator's launches since the last call, as {key (bit 63: `over`; low
+        bits: bin index), occurrences} pairs, shape (n, 2), sorted by key; the evaluator's table is emptied"""
+        rec = np.zeros(2 * cap, dtype=np.uint64)
         n = C.c_uint64(0)
         _check(load_library().mfx_hist_take_overflow(self.h, rec.ctypes.data_as(C.POINTER(C.c_uint64)), cap, C.byref(n)))
-        return rec[:n.value]
+        return rec[:2 * n.value].reshape(-1, 2)
 
     def hist_keys_launch(self, d_keys, d_contigs, n, ncontigs, d_counts, d_kover, stream=None):
         """Owner side of the sharded -hist: probe/K*/bin n received canonical k-mers (device buffers)."""

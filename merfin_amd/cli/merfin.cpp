@@ -83,7 +83,9 @@ static void usage(const char *exe) {
 static bool load_Kmetric(Globals &G) {
   if (!G.pLookupTable) return true;
   fprintf(stderr, "-- Loading probability table '%s'.\n\n", G.pLookupTable);
-  FILE *f = fopen(G.pLookupTable, "r");
+  // compressedFileReader (merfin-globals.C:34): a table named *.gz / *.bz2 / *.xz is read through its decompressor
+  mfx_file pf = mfx_open_reader(G.pLookupTable);
+  FILE *f = pf.f;
   if (!f) {
     fprintf(stderr, "ERROR: Probability table (-prob) file '%s' doesn't exist!\n", G.pLookupTable);
     return false;
@@ -112,7 +114,10 @@ static bool load_Kmetric(Globals &G) {
       fprintf(stderr, "Copy-number: invalid line %u:  '%s'\n", lineNum, keep.c_str());
     }
   }
-  fclose(f);
+  if (mfx_close(pf) != 0) {
+    fprintf(stderr, "ERROR: reading the probability table (-prob) '%s' failed (decompressor or read error).\n", G.pLookupTable);
+    return false;
+  }
   return true;
 }
 
@@ -837,7 +842,7 @@ int main(int argc, char **argv) {
     const char *pa = getenv("MFX_CLI_VCF_AHEAD");
     const bool dbgAhead = G.debug;
     if (variantMode && G.vcfName && slots == 1 && !G.sharded && !(pa && atoi(pa) == 0))
-      vcfAhead = std::async(std::launch::async, [&G, &vcfAheadError, &recs, &bases, &lens, k, dbgAhead]() {
+      vcfAhead = std::async(std::launch::async, [&G, &vcfAheadError, &recs, &bases, &lens, k, dbgAhead, deferSeq]() {
         mfx_vcf *v = mfx_vcf_load(G.vcfName);
         if (!v) { vcfAheadError = mfx_last_error(); return v; }    // (errors are per thread: carried to the caller's)
         // MFX_CLI_VCF_AHEAD=2: ... and its clusters merged, their allele combinations enumerated and packed here as well (mfx_vcf_prepare:
@@ -845,7 +850,8 @@ int main(int argc, char **argv) {
         // keeps busy (the 16-core quota of the measured boxes: its readers copy 13 GB out of the page cache) the two slow each other
         // down -- config 4 at 3 Gb 2.02-2.07 s with the load alone ahead, 2.67-2.75 s with stage A too (profiles/r05_cfg4_cli_ahead.txt).
         const char *pa2 = getenv("MFX_CLI_VCF_AHEAD");
-        if (!(pa2 && atoi(pa2) == 2)) return v;
+        // (never while the sequences are still being read -- deferSeq: finish_seq() fills recs / bases / lens on the main thread later)
+        if (!(pa2 && atoi(pa2) == 2) || deferSeq) return v;
         std::vector<const char *> nm(recs.size());
         for (size_t c = 0; c < recs.size(); ++c) nm[c] = recs[c].name.c_str();
         mfx_variant_opts o;

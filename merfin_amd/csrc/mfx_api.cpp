@@ -1644,8 +1644,9 @@ extern "C" mfx_eval *mfx_eval_create(const mfx_index *ix, const mfx_kparams *kp,
       hipMalloc((void **)&ev->d_partials, 2 * (size_t)ev->grid * sizeof(double)) != hipSuccess ||
       hipMalloc((void **)&ev->d_tile_ctr, 2 * sizeof(uint64_t)) != hipSuccess ||
       mfx_memset_now(ev->d_tile_ctr, 0, 2 * sizeof(uint64_t)) != hipSuccess ||
-      hipMalloc((void **)&ev->d_ovf, (1 + (size_t)MFX_OVF_CAP) * sizeof(uint64_t)) != hipSuccess ||
-      mfx_memset_now(ev->d_ovf, 0, sizeof(uint64_t)) != hipSuccess ||
+      hipMalloc((void **)&ev->d_ovf, MFX_OVF_WORDS * sizeof(uint64_t)) != hipSuccess ||
+      hipMemsetAsync(ev->d_ovf + 2 + MFX_OVF_SLOTS, 0xff, (size_t)MFX_OVF_SLOTS * sizeof(uint64_t), nullptr) != hipSuccess ||      // keys: all ones = empty
+      mfx_memset_now(ev->d_ovf, 0, (2 + (size_t)MFX_OVF_SLOTS) * sizeof(uint64_t)) != hipSuccess ||
       (ev->n_prob && hipMemcpy(ev->d_probK, ev->probK.data(), ev->n_prob * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) ||
       (ev->n_prob && hipMemcpy(ev->d_probP, ev->probP.data(), ev->n_prob * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)) {
     mfx_fail(MFX_E_HIP, "mfx_eval_create: device setup failed: %s", hipGetErrorString(hipGetLastError()));
@@ -1682,6 +1683,7 @@ extern "C" void mfx_eval_free(mfx_eval *ev) {
   if (ev->d_partials) (void)hipFree(ev->d_partials);
   if (ev->d_tile_ctr) (void)hipFree(ev->d_tile_ctr);
   if (ev->d_tile_partials) (void)hipFree(ev->d_tile_partials);
+  for (auto &w : ev->d_wl) if (w) (void)hipFree(w);
   if (ev->d_ovf) (void)hipFree(ev->d_ovf);
   if (ev->d_dbg) (void)hipFree(ev->d_dbg);
   for (auto &p : ev->h_stage) if (p) (void)hipHostFree(p);
@@ -1775,11 +1777,31 @@ static int ensure_tile_partials(mfx_eval *ev, uint64_t ntiles) {
   const uint64_t need = mfx_k_tile_partials_words(ntiles);
   if (need > ev->tile_partials_cap) {
     if (ev->d_tile_partials) (void)hipFree(ev->d_tile_partials);
+  for (auto &w : ev->d_wl) if (w) (void)hipFree(w);
     ev->d_tile_partials = nullptr;
     ev->tile_partials_cap = 0;
     MFX_HIP(hipMalloc((void **)&ev->d_tile_partials, need * sizeof(double)));
     ev->tile_partials_cap = need;
   }
+  return MFX_OK;
+}
+
+// The worklist of a launch over ntl tiles (mfx_hist_rest_kernel): room for one position in 32 -- a genome with human-like repeat
+// families lists 1-2 % of its positions (profiles/r06_repeats_ab.txt); a launch that lists more ends the rest per lane, as every
+// launch did before round 6.  0.5 bytes per position of the largest launch so far; MFX_HIST_WORKLIST=0: no lists.
+static int ensure_worklist(mfx_eval *ev, int slot, uint64_t ntl) {
+  static const bool off = [] { const char *e = getenv("MFX_HIST_WORKLIST"); return e && atoi(e) == 0; }();
+  if (off) return MFX_OK;
+  const uint64_t want = std::min<uint64_t>(std::max<uint64_t>(1u << 16, ntl * MFX_TILE / 32), 0xffffffffull);
+  if (ev->d_wl[slot] && ev->wl_cap[slot] >= want) return MFX_OK;
+  if (ev->d_wl[slot]) { MFX_HIP(hipDeviceSynchronize()); (void)hipFree(ev->d_wl[slot]); ev->d_wl[slot] = nullptr; ev->wl_cap[slot] = 0; }
+  if (hipMalloc((void **)&ev->d_wl[slot], (MFX_WL_HEADER + 2 * want) * sizeof(uint64_t)) != hipSuccess) {
+    (void)hipGetLastError();                                  // no memory for a list: the launches scan per lane
+    ev->d_wl[slot] = nullptr;
+    return MFX_OK;
+  }
+  MFX_HIP(mfx_memset_now(ev->d_wl[slot], 0, MFX_WL_HEADER * sizeof(uint64_t)));
+  ev->wl_cap[slot] = want;
   return MFX_OK;
 }
 
@@ -1850,10 +1872,21 @@ static int hist_launch(mfx_eval *ev, const mfx_seq *seq, uint64_t tile_begin, ui
   a.ks.partials = ev->d_partials;
   a.ks.ovf = ev->d_ovf;
   a.dbg = ev->d_dbg;
+  if (a.t.compact && canon && ntl < (1ull << 29)) {          // the probe's rare endings are listed and ended by mfx_hist_rest_kernel (mfx_kernels.hip)
+    rc = ensure_worklist(ev, ctr_slot, ntl);
+    if (rc) return rc;
+    const uint64_t segs = std::min<uint64_t>((uint64_t)ev->grid, ntl);     // the main kernel's grid: one segment per block
+    if (ev->d_wl[ctr_slot] && segs <= MFX_WL_HEADER - 2) {
+      a.wl = ev->d_wl[ctr_slot];
+      a.wl_segs = (uint32_t)segs;
+      a.wl_segcap = (uint32_t)(ev->wl_cap[ctr_slot] / segs);
+    }
+  }
   MFX_HIP(ev->ix->wide() ? mfx_kw_hist(a, (int)std::min<uint64_t>((uint64_t)ev->grid, ntl), (hipStream_t)stream)
                           : mfx_k_hist(a, (int)std::min<uint64_t>((uint64_t)ev->grid, ntl), (hipStream_t)stream));
+  if (a.wl) MFX_HIP(mfx_k_hist_rest(a, (int)std::min<uint64_t>(1024, (uint64_t)ev->grid), (hipStream_t)stream));
   if (chunk_of_total) MFX_HIP(hipMemsetAsync(ev->d_tile_ctr + ctr_slot, 0, sizeof(uint64_t), (hipStream_t)stream));   // re-arm the tile scheduler
-  else MFX_HIP(mfx_k_sum_tile_partials(ev->d_tile_partials, ntl, d_kover, ev->d_tile_ctr, (hipStream_t)stream));
+  else MFX_HIP(mfx_k_sum_tile_partials(ev->d_tile_partials, ntl, d_kover, ev->d_tile_ctr, (hipStream_t)stream, ev->ix->wide() ? 0 : 1));
   return MFX_OK;
 }
 
@@ -1878,19 +1911,57 @@ extern "C" int mfx_hist_launch_cyclic(mfx_eval *ev, const mfx_seq *seq, uint32_t
   return hist_launch(ev, seq, 0, seq->ntiles, rank, nranks, shift, d_counts, d_kover, stream);
 }
 
+// The evaluator's table of far K* bins emptied for the next launches, asynchronously on `st`: what an earlier launch left there
+// and nobody collected is not the next run's.  16 MB of fills: ~10 us of device time.
+static hipError_t ovf_reset_hip(mfx_eval *ev, hipStream_t st) {
+  const hipError_t e = hipMemsetAsync(ev->d_ovf, 0, (2 + (size_t)MFX_OVF_SLOTS) * sizeof(uint64_t), st);
+  return e != hipSuccess ? e : hipMemsetAsync(ev->d_ovf + 2 + MFX_OVF_SLOTS, 0xff, (size_t)MFX_OVF_SLOTS * sizeof(uint64_t), st);
+}
+int mfx_ovf_reset_async(mfx_eval *ev, hipStream_t st) {
+  MFX_HIP(ovf_reset_hip(ev, st));
+  return MFX_OK;
+}
+
+// the table's occupied slots as {key, occurrences} pairs in `pairs` (room for 2 * n words); the table is emptied.  Synchronises `st`.
+int mfx_ovf_collect(mfx_eval *ev, uint64_t *header2, std::vector<uint64_t> *pairs, hipStream_t st) {
+  uint64_t hd[2] = {0, 0};
+  MFX_HIP(hipMemcpyAsync(hd, ev->d_ovf, sizeof(hd), hipMemcpyDeviceToHost, st));
+  MFX_HIP(hipStreamSynchronize(st));
+  if (header2) { header2[0] = hd[0]; header2[1] = hd[1]; }
+  if (pairs) pairs->clear();
+  if (hd[0] == 0 && hd[1] == 0) return MFX_OK;
+  if (pairs && hd[0]) {
+    // rare: the whole table comes over (16 MB) and is scanned here
+    std::vector<uint64_t> tab(2 * (size_t)MFX_OVF_SLOTS);
+    MFX_HIP(hipMemcpyAsync(tab.data(), ev->d_ovf + 2, tab.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    MFX_HIP(hipStreamSynchronize(st));
+    pairs->reserve(2 * hd[0]);
+    for (size_t i = 0; i < MFX_OVF_SLOTS; ++i)
+      if (tab[MFX_OVF_SLOTS + i] != ~0ull) { pairs->push_back(tab[MFX_OVF_SLOTS + i]); pairs->push_back(tab[i]); }
+    std::vector<std::pair<uint64_t, uint64_t>> srt(pairs->size() / 2);          // by key: the same list whatever the races of the inserts were
+    for (size_t i = 0; i < srt.size(); ++i) srt[i] = {(*pairs)[2 * i], (*pairs)[2 * i + 1]};
+    std::sort(srt.begin(), srt.end());
+    for (size_t i = 0; i < srt.size(); ++i) { (*pairs)[2 * i] = srt[i].first; (*pairs)[2 * i + 1] = srt[i].second; }
+  }
+  if (int rc = mfx_ovf_reset_async(ev, st)) return rc;
+  MFX_HIP(hipStreamSynchronize(st));
+  if (hd[1])
+    return mfx_fail(MFX_E_OVERFLOW, "%lu k-mers fell into more distinct K* bins beyond the %u dense ones than the evaluator's table of far bins "
+                    "holds (%u); create the evaluator with a larger nbins", (unsigned long)hd[1], ev->nbins, MFX_OVF_SLOTS);
+  return MFX_OK;
+}
+
 extern "C" int mfx_hist_take_overflow(mfx_eval *ev, uint64_t *records, uint64_t cap, uint64_t *n_out) {
   if (!ev || !n_out) return mfx_fail(MFX_E_INVAL, "mfx_hist_take_overflow: null argument");
   DevGuard g(ev->device);
-  uint64_t n = 0;
-  MFX_HIP(hipMemcpy(&n, ev->d_ovf, sizeof(n), hipMemcpyDeviceToHost));
-  if (n > MFX_OVF_CAP)
-    return mfx_fail(MFX_E_OVERFLOW, "%lu k-mers fell beyond the %u dense K* bins but the overflow list holds %u; "
-                    "create the evaluator with a larger nbins", (unsigned long)n, ev->nbins, MFX_OVF_CAP);
-  uint64_t m = std::min(n, cap);
-  if (m && records) MFX_HIP(hipMemcpy(records, ev->d_ovf + 1, m * sizeof(uint64_t), hipMemcpyDeviceToHost));
-  MFX_HIP(mfx_memset_now(ev->d_ovf, 0, sizeof(uint64_t)));
-  *n_out = n;
-  return (n > cap) ? mfx_fail(MFX_E_OVERFLOW, "overflow list has %lu records, caller buffer %lu", (unsigned long)n, (unsigned long)cap) : MFX_OK;
+  std::vector<uint64_t> pairs;
+  uint64_t hd[2];
+  int rc = mfx_ovf_collect(ev, hd, &pairs, nullptr);
+  *n_out = pairs.size() / 2;
+  if (rc) return rc;
+  const uint64_t m = std::min<uint64_t>(pairs.size() / 2, cap);
+  if (m && records) memcpy(records, pairs.data(), 2 * m * sizeof(uint64_t));
+  return (pairs.size() / 2 > cap) ? mfx_fail(MFX_E_OVERFLOW, "%lu distinct far K* bins, caller buffer holds %lu", (unsigned long)(pairs.size() / 2), (unsigned long)cap) : MFX_OK;
 }
 
 // The reference's arrays grow in steps of 1024 under a uint32 bound (increaseArray(..., histOverMax, 1024),
@@ -1940,17 +2011,18 @@ extern "C" int mfx_hist_result_from_counts(uint32_t nbins, const uint64_t *h, do
   return MFX_OK;
 }
 
+// rec: {key, occurrences} pairs (mfx_hist_take_overflow's format)
 static int result_add_overflow(mfx_hist_result *r, const std::vector<uint64_t> &rec) {
   uint64_t mu = 0, mo = 0;                                   // grow once, to the largest index of the batch
-  for (uint64_t x : rec) {
-    const uint64_t idx = x & ~(1ull << 63);
+  for (size_t i = 0; i + 1 < rec.size(); i += 2) {
+    const uint64_t x = rec[i], idx = x & ~(1ull << 63);
     if (x >> 63) mo = std::max(mo, idx + 1); else mu = std::max(mu, idx + 1);
   }
   if (int rc = result_grow(r->over, r->overMax, mo)) return rc;
   if (int rc = result_grow(r->undr, r->undrMax, mu)) return rc;
-  for (uint64_t x : rec) {
-    const uint64_t idx = x & ~(1ull << 63);
-    if (x >> 63) r->over[idx]++; else r->undr[idx]++;
+  for (size_t i = 0; i + 1 < rec.size(); i += 2) {
+    const uint64_t x = rec[i], idx = x & ~(1ull << 63);
+    if (x >> 63) r->over[idx] += rec[i + 1]; else r->undr[idx] += rec[i + 1];
   }
   return MFX_OK;
 }
@@ -1959,7 +2031,7 @@ static int result_take_overflow(mfx_eval *ev, uint64_t novf, mfx_hist_result *ou
 
 extern "C" int mfx_hist_result_add_overflow(mfx_hist_result *r, const uint64_t *records, uint64_t n) {
   if (!r || !r->undr || !r->over || (n && !records)) return mfx_fail(MFX_E_INVAL, "mfx_hist_result_add_overflow: null argument");
-  return result_add_overflow(r, std::vector<uint64_t>(records, records + n));
+  return result_add_overflow(r, std::vector<uint64_t>(records, records + 2 * n));
 }
 
 // What a whole-assembly run needs besides the evaluator's tables -- a stream, the counts image, its pinned mirror -- belongs
@@ -1990,7 +2062,7 @@ static int eval_run_enqueue(mfx_eval *ev, const mfx_seq *seq, uint32_t part_rank
   hipStream_t st = R.kern[0];
   MFX_HIP(hipMemsetAsync(R.d_counts, 0, words * sizeof(uint64_t), st));
   MFX_HIP(hipMemsetAsync(R.d_kover, 0, sizeof(double), st));
-  MFX_HIP(hipMemsetAsync(ev->d_ovf, 0, sizeof(uint64_t), st));      // records nobody collected from an earlier launch are not this run's
+  if (int rc0 = mfx_ovf_reset_async(ev, st)) return rc0;             // far bins nobody collected from an earlier launch are not this run's
   rc = part_n > 1 ? mfx_hist_launch_cyclic(ev, seq, part_rank, part_n, 256, R.d_counts, R.d_kover, st)
                   : mfx_hist_launch(ev, seq, 0, seq->ntiles, R.d_counts, R.d_kover, st);
   if (rc) return rc;
@@ -2020,12 +2092,9 @@ extern "C" int mfx_hist_run(mfx_eval *ev, const mfx_seq *seq, mfx_hist_result *o
 // fold the overflow list of `ev` (K* bins >= nbins) into a result
 static int result_take_overflow(mfx_eval *ev, uint64_t novf, mfx_hist_result *out) {
   if (!novf) return MFX_OK;
-  std::vector<uint64_t> rec(novf);
-  uint64_t n = 0;
-  int rc = mfx_hist_take_overflow(ev, rec.data(), novf, &n);
-  if (rc) return rc;
-  rec.resize(std::min(n, novf));
-  return result_add_overflow(out, rec);
+  std::vector<uint64_t> pairs;
+  if (int rc = mfx_ovf_collect(ev, nullptr, &pairs, nullptr)) return rc;
+  return result_add_overflow(out, pairs);
 }
 
 // ---------------------------------------------------------------------------
@@ -2397,7 +2466,7 @@ static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *cons
     STREAMED_HIP(hipMemsetAsync(d_kover, 0, sizeof(double), ks));
   }
   STREAMED_HIP(hipMemsetAsync(ev->d_tile_ctr, 0, 2 * sizeof(uint64_t), ks));
-  STREAMED_HIP(hipMemsetAsync(ev->d_ovf, 0, sizeof(uint64_t), ks));
+  STREAMED_HIP(ovf_reset_hip(ev, ks));
   STREAMED_HIP(hipEventRecord(R.kdone, ks));
   STREAMED_HIP(hipStreamWaitEvent(R.kern[1], R.kdone, 0));          // the second kernel stream starts behind the clears
   if ((rc = ensure_tile_partials(ev, T)) != MFX_OK) { cleanup(); return rc; }
@@ -2463,14 +2532,14 @@ static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *cons
   // (a part cannot be checked: its digest is not the sequence's; the caller of the parts vouches for the sequence)
   const bool want_digest = whole && ev->ix->seq_only && ev->ix->seq_digest != 0;
   if (want_digest) {
-    uint64_t *d_dig = reinterpret_cast<uint64_t *>(d_kover + 1);
+    uint64_t *d_dig = reinterpret_cast<uint64_t *>(R.d_kover + 1);      // the evaluator's own word (eval_run_resources), never the caller's one-double buffer of a range run
     STREAMED_HIP(hipMemsetAsync(d_dig, 0, sizeof(uint64_t), cs));
     STREAMED_HIP(mfx_k_seq_digest(nullptr, seq->d_codes, seq->d_valid, seq->buf_bytes / 32, d_dig, cs));
     STREAMED_HIP(hipMemcpyAsync(h_img + words + 1, d_dig, sizeof(uint64_t), hipMemcpyDeviceToHost, cs));
   }
   STREAMED_HIP(hipEventRecord(R.kdone, R.kern[1]));
   STREAMED_HIP(hipStreamWaitEvent(ks, R.kdone, 0));
-  if (T) STREAMED_HIP(mfx_k_sum_tile_partials(ev->d_tile_partials, T, d_kover, ev->d_tile_ctr, ks));
+  if (T) STREAMED_HIP(mfx_k_sum_tile_partials(ev->d_tile_partials, T, d_kover, ev->d_tile_ctr, ks, ev->ix->wide() ? 0 : 1));
   if (own_image) {
     STREAMED_HIP(hipMemcpyAsync(h_img, d_counts, words * sizeof(uint64_t), hipMemcpyDeviceToHost, ks));
     STREAMED_HIP(hipMemcpyAsync(h_img + words, d_kover, sizeof(double), hipMemcpyDeviceToHost, ks));
@@ -2682,7 +2751,7 @@ extern "C" int mfx_hist_run_streamed(mfx_eval *ev, mfx_seq *seq, const char *con
   STREAMED_HIP(hipMemsetAsync(dc.p, 0, words * sizeof(uint64_t), ks));
   STREAMED_HIP(hipMemsetAsync(dk.p, 0, sizeof(double), ks));
   STREAMED_HIP(hipMemsetAsync(ev->d_tile_ctr, 0, sizeof(uint64_t), ks));
-  STREAMED_HIP(hipMemsetAsync(ev->d_ovf, 0, sizeof(uint64_t), ks));
+  STREAMED_HIP(ovf_reset_hip(ev, ks));
   if ((rc = ensure_tile_partials(ev, T)) != MFX_OK) { cleanup(); return rc; }
   std::vector<char> pinned(seq->ncontigs);
   for (uint32_t c = 0; c < seq->ncontigs; ++c) pinned[c] = seq->len[c] && host_ptr_is_pinned(bases[c]);
@@ -2720,7 +2789,7 @@ extern "C" int mfx_hist_run_streamed(mfx_eval *ev, mfx_seq *seq, const char *con
     rc = hist_launch(ev, seq, t0, t1, 0, 1, 0, dc.p, dk.p, ks, T);
     if (rc) { cleanup(); return rc; }
   }
-  if (T) STREAMED_HIP(mfx_k_sum_tile_partials(ev->d_tile_partials, T, dk.p, ev->d_tile_ctr, ks));
+  if (T) STREAMED_HIP(mfx_k_sum_tile_partials(ev->d_tile_partials, T, dk.p, ev->d_tile_ctr, ks, ev->ix->wide() ? 0 : 1));
   STREAMED_HIP(hipMemcpyAsync(h_img, dc.p, words * sizeof(uint64_t), hipMemcpyDeviceToHost, ks));
   STREAMED_HIP(hipMemcpyAsync(h_img + words, dk.p, sizeof(double), hipMemcpyDeviceToHost, ks));
   STREAMED_HIP(hipStreamSynchronize(ks));
@@ -3402,7 +3471,7 @@ static int hist_run_sharded_ordered(mfx_eval *const *evs, mfx_router *const *rou
         hipMalloc((void **)&sl[d].d_ctg, cap * 4) != hipSuccess || hipMalloc((void **)&sl[d].d_rctg, rcap * 4) != hipSuccess ||
         hipMemsetAsync(sl[d].d_counts, 0, words * sizeof(uint64_t), sl[d].st) != hipSuccess ||
         hipMemsetAsync(sl[d].d_kover, 0, sizeof(double), sl[d].st) != hipSuccess ||
-        hipMemsetAsync(evs[d]->d_ovf, 0, sizeof(uint64_t), sl[d].st) != hipSuccess)
+        ovf_reset_hip(evs[d], sl[d].st) != hipSuccess)
       rc = mfx_fail(MFX_E_NOMEM, "mfx_hist_run_sharded: buffers for slot %u (%zu k-mers per round) could not be set up", d, cap);
     for (uint32_t e = 0; e < d && rc == MFX_OK; ++e)
       if (evs[e]->device != evs[d]->device) {
@@ -3562,7 +3631,7 @@ extern "C" int mfx_hist_run_sharded(mfx_eval *const *evs, mfx_router *const *rou
       S.d_rkeys = F.d_rkeys; S.d_rctg = F.d_rctg; S.d_cursors = F.d_cursors; S.h_cursors = F.h_cursors;
     }
     ok = ok && hipMemsetAsync(S.d_counts, 0, words * sizeof(uint64_t), S.ost) == hipSuccess && hipMemsetAsync(S.d_kover, 0, sizeof(double), S.ost) == hipSuccess &&
-         hipMemsetAsync(S.d_kfix, 0, 2 * sizeof(uint64_t), S.ost) == hipSuccess && hipMemsetAsync(evs[d]->d_ovf, 0, sizeof(uint64_t), S.ost) == hipSuccess &&
+         hipMemsetAsync(S.d_kfix, 0, 2 * sizeof(uint64_t), S.ost) == hipSuccess && ovf_reset_hip(evs[d], S.ost) == hipSuccess &&
          hipStreamSynchronize(S.ost) == hipSuccess;
     if (!ok) { (void)hipGetLastError(); rc = mfx_fail(MFX_E_NOMEM, "mfx_hist_run_sharded: buffers for slot %u (%zu k-mers per round) could not be set up", d, cap); }
     for (uint32_t e = 0; e < d && rc == MFX_OK; ++e)

@@ -123,42 +123,59 @@ extern "C" int mfx_hist_allreduce(mfx_comm *c, uint64_t *d_counts, double *d_kov
   return MFX_OK;
 }
 
-// Every rank ends with the records of ALL ranks (rank order).  Collective: all ranks must call it when the
-// reduced image's novf word (counts[2*nbins + 2]) is non-zero -- it is the same on every rank after the all-reduce.
+// Every rank ends with the far K* bins of ALL ranks as {key, occurrences} pairs (rank order; a key may come from several ranks:
+// mfx_hist_result_add_overflow adds).  Collective: all ranks must call it when the reduced image's novf word
+// (counts[2*nbins + 2]) is non-zero -- it is the same on every rank after the all-reduce.  Every rank collects its own table on
+// the host (mfx_ovf_collect: rare, small), the pair lists travel through one fixed-size all-gather.
 extern "C" int mfx_hist_allgather_overflow(mfx_comm *c, mfx_eval *ev, uint64_t *records, uint64_t cap, uint64_t *n_out, void *stream) {
   if (!c || !ev || !n_out) return mfx_fail(MFX_E_INVAL, "mfx_hist_allgather_overflow: null argument");
   DeviceScope ds(c->device);
   if (!ds.ok) return mfx_fail(MFX_E_HIP, "hipSetDevice(%d) failed", c->device);
   hipStream_t st = (hipStream_t)stream;
-  // ev->d_ovf: [0] = this rank's count, [1..] = its records
-  MFX_NCCL(ncclAllGather(ev->d_ovf, c->d_novf, 1, ncclUint64, c->comm, st));
-  std::vector<uint64_t> cnt((size_t)c->nranks);
-  MFX_HIP(hipMemcpyAsync(cnt.data(), c->d_novf, cnt.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-  MFX_HIP(hipStreamSynchronize(st));
-  uint64_t mx = 0, total = 0;
-  for (uint64_t x : cnt) { mx = std::max(mx, x); total += x; }
-  *n_out = total;
-  if (mx > MFX_OVF_CAP)
-    return mfx_fail(MFX_E_OVERFLOW, "a rank saw %lu k-mers beyond the dense K* bins but its overflow list holds %u; create the evaluators with a larger nbins",
-                    (unsigned long)mx, MFX_OVF_CAP);
-  if (total == 0) return MFX_OK;
-  // fixed-size exchange: every rank contributes `mx` slots (its own records, then filler)
-  uint64_t *d_all = nullptr;
-  MFX_HIP(hipMalloc((void **)&d_all, (size_t)c->nranks * mx * sizeof(uint64_t)));
-  ncclResult_t r = ncclAllGather(ev->d_ovf + 1, d_all, mx, ncclUint64, c->comm, st);
-  std::vector<uint64_t> all((size_t)c->nranks * mx);
-  hipError_t e = hipSuccess;
-  if (r == ncclSuccess) e = hipMemcpyAsync(all.data(), d_all, all.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, st);
-  if (r == ncclSuccess && e == hipSuccess) e = hipStreamSynchronize(st);
-  (void)hipFree(d_all);
-  if (r != ncclSuccess) return mfx_fail(MFX_E_HIP, "ncclAllGather of the overflow records failed: %s", ncclGetErrorString(r));
+  std::vector<uint64_t> mine;
+  uint64_t hd[2] = {0, 0};
+  const int rc_mine = mfx_ovf_collect(ev, hd, &mine, st);      // (an error here must not keep this rank out of the collectives below)
+  const uint64_t lost = rc_mine ? 1ull : 0ull;
+  uint64_t *d_cnt = nullptr;
+  MFX_HIP(hipMalloc((void **)&d_cnt, 2 * sizeof(uint64_t)));
+  const uint64_t h2[2] = {mine.size() / 2, lost};
+  hipError_t e = hipMemcpyAsync(d_cnt, h2, sizeof(h2), hipMemcpyHostToDevice, st);
+  uint64_t *d_cnts = nullptr;
+  if (e == hipSuccess) e = hipMalloc((void **)&d_cnts, 2 * (size_t)c->nranks * sizeof(uint64_t));
+  ncclResult_t r = ncclSuccess;
+  std::vector<uint64_t> cnt(2 * (size_t)c->nranks, 0);
+  if (e == hipSuccess) r = ncclAllGather(d_cnt, d_cnts, 2, ncclUint64, c->comm, st);
+  if (e == hipSuccess && r == ncclSuccess) e = hipMemcpyAsync(cnt.data(), d_cnts, cnt.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess && r == ncclSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(d_cnt);
+  if (d_cnts) (void)hipFree(d_cnts);
+  if (r != ncclSuccess) return mfx_fail(MFX_E_HIP, "ncclAllGather of the far-bin counts failed: %s", ncclGetErrorString(r));
   MFX_HIP(e);
-  MFX_HIP(hipMemsetAsync(ev->d_ovf, 0, sizeof(uint64_t), st));
+  uint64_t mx = 0, total = 0, any_lost = 0;
+  for (int rk = 0; rk < c->nranks; ++rk) { mx = std::max(mx, cnt[2 * rk]); total += cnt[2 * rk]; any_lost += cnt[2 * rk + 1]; }
+  *n_out = total;
+  if (any_lost)
+    return rc_mine ? rc_mine : mfx_fail(MFX_E_OVERFLOW, "a rank saw more distinct K* bins beyond the dense ones than its table of far bins holds (%u); create the evaluators with a larger nbins", MFX_OVF_SLOTS);
+  if (total == 0) return MFX_OK;
+  // fixed-size exchange: every rank contributes `mx` pairs (its own, then filler)
+  uint64_t *d_mine = nullptr, *d_all = nullptr;
+  mine.resize(2 * mx, 0);
+  MFX_HIP(hipMalloc((void **)&d_mine, 2 * mx * sizeof(uint64_t)));
+  e = hipMalloc((void **)&d_all, 2 * (size_t)c->nranks * mx * sizeof(uint64_t));
+  if (e == hipSuccess) e = hipMemcpyAsync(d_mine, mine.data(), 2 * mx * sizeof(uint64_t), hipMemcpyHostToDevice, st);
+  std::vector<uint64_t> all(2 * (size_t)c->nranks * mx);
+  if (e == hipSuccess) r = ncclAllGather(d_mine, d_all, 2 * mx, ncclUint64, c->comm, st);
+  if (e == hipSuccess && r == ncclSuccess) e = hipMemcpyAsync(all.data(), d_all, all.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess && r == ncclSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(d_mine);
+  if (d_all) (void)hipFree(d_all);
+  if (r != ncclSuccess) return mfx_fail(MFX_E_HIP, "ncclAllGather of the far bins failed: %s", ncclGetErrorString(r));
+  MFX_HIP(e);
   uint64_t w = 0;
   for (int rk = 0; rk < c->nranks; ++rk)
-    for (uint64_t i = 0; i < cnt[rk]; ++i, ++w)
-      if (records && w < cap) records[w] = all[(size_t)rk * mx + i];
-  if (total > cap) return mfx_fail(MFX_E_OVERFLOW, "overflow list has %lu records, caller buffer %lu", (unsigned long)total, (unsigned long)cap);
+    for (uint64_t i = 0; i < cnt[2 * rk]; ++i, ++w)
+      if (records && w < cap) { records[2 * w] = all[2 * ((size_t)rk * mx + i)]; records[2 * w + 1] = all[2 * ((size_t)rk * mx + i) + 1]; }
+  if (total > cap) return mfx_fail(MFX_E_OVERFLOW, "%lu far K* bins over all ranks, caller buffer holds %lu", (unsigned long)total, (unsigned long)cap);
   return MFX_OK;
 }
 

@@ -114,6 +114,7 @@ struct mfx_hist_lds {
   double   term[MFX_KLUT * MFX_KLUT];
 #endif
   uint32_t lut_ok;
+  uint32_t wl_n;                          // mfx_hist_kernel: entries this block has put on its segment of the worklist
   uint64_t next[2];                       // dynamic tile scheduler: the tile fetched for the next iteration
   uint64_t tot[2];                        // mfx_hist_kernel: valid / missing k-mers of the contigs this block already flushed (thread 0)
   uint64_t red[MFX_BLOCK / 64][3];
@@ -144,6 +145,54 @@ __device__ __forceinline__ void mfx_hist_lds_init(mfx_hist_lds &H, const mfx_kst
 #endif
   }
   __syncthreads();
+}
+
+// K* bins beyond the dense image (idx >= nbins).  The reference's arrays simply grow (increaseArray, merfin-histogram.C:74,87), so
+// any NUMBER of k-mers may fall there -- an assembly's satellite array that the reads under-represent puts millions of positions
+// into a handful of far bins.  They are therefore AGGREGATED on the device: an open-addressed table {bin key -> occurrences} of
+// MFX_OVF_SLOTS entries per evaluator (key: bit 63 = `over`, low bits = the bin index), so that only the number of DISTINCT far bins
+// is bounded.  The lanes of a wave that hold the same key combine first (one atomic per distinct key and wave: the positions
+// of a tandem array hit the same bin from every lane).  ovf: [0] distinct keys, [1] occurrences that found no slot (the host
+// reports MFX_E_OVERFLOW), [2, 2 + S) occurrences per slot, [2 + S, 2 + 2 S) keys (all ones = empty).
+__device__ __forceinline__ void mfx_ovf_add(uint64_t *ovf, uint64_t key, uint64_t amount) {
+  unsigned long long *cnt = reinterpret_cast<unsigned long long *>(ovf) + 2, *keys = cnt + MFX_OVF_SLOTS;
+  uint64_t x = key * 0x9E3779B97F4A7C15ull;
+  uint32_t h = (uint32_t)(x >> 40) & (MFX_OVF_SLOTS - 1u);
+  for (uint32_t probe = 0; probe < MFX_OVF_PROBES; ++probe) {
+    unsigned long long cur = __hip_atomic_load(&keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == ~0ull) {
+      cur = atomicCAS(&keys[h], ~0ull, (unsigned long long)key);
+      if (cur == ~0ull) { atomicAdd(reinterpret_cast<unsigned long long *>(ovf), 1ull); cur = key; }
+    }
+    if (cur == key) { atomicAdd(&cnt[h], (unsigned long long)amount); return; }
+    h = (h + 1u) & (MFX_OVF_SLOTS - 1u);
+  }
+  atomicAdd(reinterpret_cast<unsigned long long *>(ovf) + 1, (unsigned long long)amount);
+}
+
+// called by the lanes of a wave that evaluated a k-mer into a far bin (any subset of the wave: a divergent branch)
+#ifndef MFX_V_OVF_SIMPLE
+#define MFX_V_OVF_SIMPLE 0            // DIAGNOSTIC builds only
+#endif
+__device__ __forceinline__ void mfx_ovf_record(const mfx_kstar_args &ka, bool under, uint32_t idx) {
+  const uint64_t key = (under ? 0ull : (1ull << 63)) | idx;
+#if MFX_V_OVF_SIMPLE
+  atomicAdd((unsigned long long *)&ka.counts[2ull * ka.nbins + 2], 1ull + (key & 0ull));
+  return;
+#endif
+  const uint32_t lane = threadIdx.x & 63u;
+  uint64_t todo = __ballot(1);                                 // the lanes that are here
+  while (todo) {
+    const int leader = __ffsll((unsigned long long)todo) - 1;
+    const uint64_t lk = ((uint64_t)(uint32_t)__shfl((int)(key >> 32), leader, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)key, leader, 64);
+    const uint64_t same = __ballot(key == lk) & todo;
+    if ((int)lane == leader) {
+      const uint64_t n = (uint64_t)__popcll(same);
+      mfx_ovf_add(ka.ovf, key, n);
+      atomicAdd((unsigned long long *)&ka.counts[2ull * ka.nbins + 2], (unsigned long long)n);
+    }
+    todo &= ~same;                                             // (wave-uniform among the lanes here: all of them leave together)
+  }
 }
 
 // One evaluated k-mer: merfin-histogram.C:63-90 after the lookups.  Returns true when the
@@ -190,11 +239,7 @@ __device__ __forceinline__ bool mfx_hist_eval(mfx_hist_lds &H, const mfx_kstar_a
   uint64_t *c_undr = ka.counts, *c_over = ka.counts + ka.nbins;
   if (idx < MFX_NB_LDS) atomicAdd(&H.hist[(under ? 0 : MFX_NB_LDS) + idx], 1u);
   else if (idx < ka.nbins) atomicAdd((unsigned long long *)&(under ? c_undr : c_over)[idx], 1ull);
-  else {
-    unsigned long long w = atomicAdd((unsigned long long *)&ka.ovf[0], 1ull);
-    if (w < MFX_OVF_CAP) ka.ovf[1 + w] = (under ? 0ull : (1ull << 63)) | idx;
-    atomicAdd((unsigned long long *)&ka.counts[2ull * ka.nbins + 2], 1ull);
-  }
+  else mfx_ovf_record(ka, under, idx);
   return false;
 }
 
@@ -229,11 +274,7 @@ __device__ __forceinline__ bool mfx_hist_eval_fx(mfx_hist_lds &H, const mfx_ksta
   uint64_t *c_undr = ka.counts, *c_over = ka.counts + ka.nbins;
   if (idx < MFX_NB_LDS) atomicAdd(&H.hist[(under ? 0 : MFX_NB_LDS) + idx], 1u);
   else if (idx < ka.nbins) atomicAdd((unsigned long long *)&(under ? c_undr : c_over)[idx], 1ull);
-  else {
-    unsigned long long w = atomicAdd((unsigned long long *)&ka.ovf[0], 1ull);
-    if (w < MFX_OVF_CAP) ka.ovf[1 + w] = (under ? 0ull : (1ull << 63)) | idx;
-    atomicAdd((unsigned long long *)&ka.counts[2ull * ka.nbins + 2], 1ull);
-  }
+  else mfx_ovf_record(ka, under, idx);
   return false;
 }
 

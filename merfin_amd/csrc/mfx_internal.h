@@ -82,7 +82,9 @@ constexpr uint32_t MFX_KLUT       = 32;         // (readK, asmK) pairs below thi
 constexpr uint32_t MFX_LAYOUT_VERSION = 9u;     // 9: the compact layout's line from the bijective mix of the minimizer, its first mini-bucket from the window (mfx_place.h)
 constexpr uint32_t MFX_SPLIT_MAX_RANKS = 16;  // owners the sort-free router handles (a node has 8 GPUs); more: radix sort
 constexpr int      MFX_MZ_W_DEFAULT = 3;        // minimizer windows of the default placement (MFX_MZ_W overrides)
-constexpr uint32_t MFX_OVF_CAP    = 1u << 20;   // histogram overflow records per evaluator
+constexpr uint32_t MFX_OVF_SLOTS  = 1u << 20;   // DISTINCT K* bins beyond the dense image an evaluator can hold (occurrences are unbounded: mfx_device.h, mfx_ovf_add)
+constexpr uint32_t MFX_OVF_PROBES = 256;        // ... linear probes before an occurrence counts as lost (MFX_E_OVERFLOW)
+constexpr size_t   MFX_OVF_WORDS  = 2 + 2 * (size_t)MFX_OVF_SLOTS;
 constexpr uint32_t MFX_META_WORDS = 8;          // mfx_index::d_meta
 
 struct mfx_slot {               // 16 bytes: one dwordx4 load per probe
@@ -259,7 +261,9 @@ struct mfx_eval {
   uint64_t *d_tile_ctr = nullptr;    // [2] dynamic tile scheduler counters of mfx_hist_kernel (0 between launches); the second serves launches that overlap the first's
   double   *d_tile_partials = nullptr; // per-(tile,wave) koverCpy of the last launch + the chunk sums behind them
   uint64_t  tile_partials_cap = 0;   // doubles allocated
-  uint64_t *d_ovf = nullptr;         // [0] count, [1..] records
+  uint64_t *d_wl[2] = {nullptr, nullptr};   // the worklists of mfx_hist_rest_kernel (mfx_kernels.h: mfx_hist_args::wl), one per launch slot (a streamed run's launches alternate between two streams)
+  uint64_t  wl_cap[2] = {0, 0};      // entries each holds
+  uint64_t *d_ovf = nullptr;         // the table of far K* bins: [0] distinct keys, [1] lost occurrences, [2, 2+S) occurrences, [2+S, 2+2S) keys (mfx_device.h)
   uint64_t *d_dbg = nullptr;         // [8] probe path counters of the DEBUG instance of the -hist kernel (mfx_eval_debug_enable); null: the measured instance runs
   uint8_t  *h_stage[2] = {nullptr, nullptr};   // pinned staging of the streamed upload (pageable sources), kept between calls
   size_t    h_stage_bytes = 0;
@@ -283,3 +287,8 @@ struct mfx_eval {
     size_t     exc_cap = 0;                             // entries each
   } sr;
 };
+
+// the evaluator's table of far K* bins (mfx_api.cpp): emptied asynchronously on a stream; collected as sorted {key, occurrences}
+// pairs (header2: {distinct keys, lost occurrences} as read; MFX_E_OVERFLOW when occurrences were lost) and emptied
+int mfx_ovf_reset_async(mfx_eval *ev, hipStream_t st);
+int mfx_ovf_collect(mfx_eval *ev, uint64_t *header2, std::vector<uint64_t> *pairs, hipStream_t st);

@@ -12,10 +12,11 @@ struct mfx_kstar_args {
   uint32_t        ncontigs;
   uint64_t       *counts;             // layout: include/merfin_amd.h MFX_HIST_WORDS
   double         *partials;           // [gridDim.x]
-  uint64_t       *ovf;                // [0] count, [1..MFX_OVF_CAP] records
+  uint64_t       *ovf;                // the evaluator's table of far K* bins (mfx_eval::d_ovf)
   const uint64_t *underq = nullptr;   // [MFX_MAXP_LDS * MFX_KLUT] mfx_kfix of the over-copy term of (read count, asmV) where the exact tables apply, else 0 (mfx_eval_create)
 };
 
+constexpr uint32_t MFX_WL_HEADER = 4096 + 2;    // words in front of the worklist's entries (<= 4096 segments)
 struct mfx_hist_args {
   mfx_table_view  t;                  // t.compact: the 8-byte-slot layout of a sequence-only index (mfx_kernels.hip)
   int             canonical;          // 1: single probe of min(f,r); 0: probe both strands and sum
@@ -34,6 +35,10 @@ struct mfx_hist_args {
   uint64_t        n_logical;
   uint32_t        part_rank, part_n, part_shift;
   uint64_t       *dbg = nullptr;      // non-null: the debug instance of the kernel counts the probe's endings here (mfx_eval_debug_counters)
+  // the worklist of mfx_hist_rest_kernel (compact layout, canonical database; else null): words [2, 2 + wl_segs) = entries in each segment (one
+  // per block of the main kernel's grid), from word MFX_WL_HEADER: 16-byte entries {k-mer, contig, slot | dbl << 31}, segment g at g * wl_segcap
+  uint64_t       *wl = nullptr;
+  uint32_t        wl_segs = 0, wl_segcap = 0;
   mfx_kstar_args  ks;
 };
 
@@ -149,7 +154,8 @@ hipError_t mfx_k_route_fused(const mfx_route_args &a, uint64_t *keys_out, uint32
 hipError_t mfx_k_sum_partials(const double *partials, uint32_t n, double *out, hipStream_t st);
 hipError_t mfx_k_ordered_sum(const double *v, uint32_t n, double *out, hipStream_t st);
 uint64_t mfx_k_tile_partials_words(uint64_t ntiles);
-hipError_t mfx_k_sum_tile_partials(double *tile_partials, uint64_t ntiles, double *out, uint64_t *ctr_reset, hipStream_t st);
+hipError_t mfx_k_sum_tile_partials(double *tile_partials, uint64_t ntiles, double *out, uint64_t *ctr_reset, hipStream_t st, int fixed);   // fixed: the values are integers, units of 2^-52 (k <= 31)
+hipError_t mfx_k_hist_rest(const mfx_hist_args &a, int grid, hipStream_t st);
 int mfx_k_hist_resident_blocks(int compact, int k);
 int mfx_k_quot_supported();
 hipError_t mfx_k_gather_rate(const void *table, uint64_t nlines, uint64_t *scratch, double *lines_per_s, hipStream_t st);

@@ -1500,6 +1500,82 @@ __device__ __forceinline__ void mfx_group_lookup8(const mfx_table_view &c, mfx_m
 // through the next ones (a round = one more load for the lanes that need it, the others wait): 5.8 % need a second
 // load, 1.3 % a third.  A line exhausted without the key or an empty slot is rare enough for the whole-line scan (mfx_c_find).
 // ---------------------------------------------------------------------------
+// the pair of a slot's low word with its saturated fields taken from (xr, xa)
+__device__ __forceinline__ uint2 mfx_sat_fill(uint32_t lo, uint32_t xr, uint32_t xa) {
+  const uint32_t f_rv = (lo >> 11) & MFX_CSAT, f_av = lo & MFX_CSAT;
+  return make_uint2(f_rv == MFX_CSAT ? xr : f_rv, f_av == MFX_CSAT ? xa : f_av);
+}
+
+// The saturated queries of a batch (st == 0xfe, the found slot's low word in rv: the k-mers of repeat families -- a read count >= 2047
+// means copy number >~ 79 at 26x): slot 0 of the k-mer's line of the side table, one 16-byte load per lane and query, all in flight --
+// inside a satellite array or an rDNA unit EVERY lane of the wave has one.  A line of the side table fills from slot 0 on and holds
+// 0.3 k-mers on average, so the k-mer is there (done: st = 0xff), the slot is empty (no exact count was ever moved: 0), or another
+// k-mer is: st stays 0xfe and the query ends like the other rare ones (the worklist of mfx_hist_rest_kernel, or the per-lane scan).
+template <int B, class KeyOf>
+__device__ __forceinline__ void mfx_side_direct(const mfx_table_view &c, uint32_t (&st)[B], uint32_t (&rv)[B], uint32_t (&av)[B], KeyOf keyof, unsigned long long *dbg) {
+  bool anysat = false;
+#pragma unroll
+  for (int j = 0; j < B; ++j) anysat |= st[j] == 0xfeu;
+  if (!__any(anysat)) return;                                  // wave-uniform
+  uint4 sv[B];
+  uint64_t km[B];
+#pragma unroll
+  for (int j = 0; j < B; ++j) {
+    km[j] = 0;
+    sv[j] = make_uint4(0u, 0u, 0u, 0u);
+    if (st[j] == 0xfeu) {
+      km[j] = keyof(j);
+      sv[j] = *reinterpret_cast<const uint4 *>(c.side + (uint64_t)mfx_range32(mfx_hash64(km[j]), c.side_nlines) * MFX_SLOTS_LINE);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < B; ++j) {
+    if (st[j] != 0xfeu) continue;
+    if (dbg) atomicAdd(&dbg[2], 1ull);
+    const uint64_t sk = (uint64_t)sv[j].x | ((uint64_t)sv[j].y << 32);
+    if (sk == km[j] || sk == MFX_EMPTY) {
+      const bool hit = sk == km[j];
+      const uint2 x = mfx_sat_fill(rv[j], hit ? sv[j].z : 0u, hit ? sv[j].w : 0u);
+      rv[j] = (x.x < c.minV || x.x > c.maxV) ? 0u : x.x;       // -min / -max (merfin.C:199-200)
+      av[j] = x.y;
+      st[j] = 0xffu;
+    }
+  }
+  // another k-mer in slot 0: slot 1 the same way (a k-mer of a tandem array is asked for by millions of positions: what is
+  // left after two slots -- 0.4 % of the side table's k-mers at its load -- takes the rare endings' way)
+  bool more = false;
+#pragma unroll
+  for (int j = 0; j < B; ++j) more |= st[j] == 0xfeu;
+  if (!__any(more)) return;                                    // wave-uniform
+#pragma unroll
+  for (int j = 0; j < B; ++j)
+    if (st[j] == 0xfeu) sv[j] = *reinterpret_cast<const uint4 *>(c.side + (uint64_t)mfx_range32(mfx_hash64(km[j]), c.side_nlines) * MFX_SLOTS_LINE + 1);
+#pragma unroll
+  for (int j = 0; j < B; ++j) {
+    if (st[j] != 0xfeu) continue;
+    const uint64_t sk = (uint64_t)sv[j].x | ((uint64_t)sv[j].y << 32);
+    if (sk == km[j] || sk == MFX_EMPTY) {
+      const bool hit = sk == km[j];
+      const uint2 x = mfx_sat_fill(rv[j], hit ? sv[j].z : 0u, hit ? sv[j].w : 0u);
+      rv[j] = (x.x < c.minV || x.x > c.maxV) ? 0u : x.x;       // -min / -max (merfin.C:199-200)
+      av[j] = x.y;
+      st[j] = 0xffu;
+    }
+  }
+}
+
+// "no worklist": the probe's rare endings are per-lane scans (every kernel but -hist)
+template <class F>
+struct mfx_push_fn {
+  static constexpr bool enabled = true;
+  F f;
+  __device__ __forceinline__ bool operator()(int j, bool want, uint64_t kmer) const { return f(j, want, kmer); }
+};
+struct mfx_no_push {
+  static constexpr bool enabled = false;
+  __device__ __forceinline__ bool operator()(int, bool, uint64_t) const { return false; }
+};
+
 #ifndef MFX_V_TAIL_STEPS
 #define MFX_V_TAIL_STEPS 0            // cooperative steps of the probe's tail whose line loads are in flight together; 0: by the batch size (A/B: tools/ab_build.sh)
 #endif
@@ -1508,10 +1584,14 @@ __device__ __forceinline__ void mfx_group_lookup8(const mfx_table_view &c, mfx_m
 // ok must come with line 0 / b0 0 (a dummy load, ignored).  keyof(j): the canonical k-mer of query j -- asked for on the rare
 // endings only (a saturated count; quotient form: a k-mer beyond its candidate lines), so that the quotient form keeps no
 // k-mer alive across the loads: the -hist and -dump kernels re-extract it from the tile.
-template <int B, class KeyOf>
-__device__ __forceinline__ void mfx_lane_lookup8(const mfx_table_view &c, mfx_mailbox &M, const uint64_t (&fkey)[B], const bool (&ok)[B],
-                                                 uint32_t (&rv)[B], uint32_t (&av)[B], const uint32_t (&line)[B], const uint32_t (&b0)[B],
-                                                 KeyOf keyof, unsigned long long *dbg = nullptr) {
+// push(j, want, kmer): the -hist kernel's worklist (mfx_hist_push) -- called by the whole wave; a lane that wants its query j
+// ended by mfx_hist_rest_kernel gets true when the query is on the list (the caller then must not evaluate it: bit j of the
+// result); mfx_no_push: there is no worklist, the rare endings are per-lane scans here and now.
+// CAP: the mailbox entries (of the wave's 64) the passes may use; the queries of a batch beyond them take the rare endings' way
+template <int B, class KeyOf, class Push = mfx_no_push, uint32_t CAP = 64u>
+__device__ __forceinline__ uint32_t mfx_lane_lookup8(const mfx_table_view &c, mfx_mailbox &M, const uint64_t (&fkey)[B], const bool (&ok)[B],
+                                                     uint32_t (&rv)[B], uint32_t (&av)[B], const uint32_t (&line)[B], const uint32_t (&b0)[B],
+                                                     KeyOf keyof, unsigned long long *dbg = nullptr, Push push = Push()) {
   // dbg (the DEBUG instance of the -hist kernel only, mfx_hist_args::dbg): how many queries left the one-load fast path, and how --
   // [0] not in their first mini-bucket (first cooperative pass), [1] home line full of other k-mers (second cooperative pass),
   // [2] a saturated count (side table), [3] per-lane whole-line scans; tests assert that a world exercises every ending
@@ -1540,6 +1620,8 @@ __device__ __forceinline__ void mfx_lane_lookup8(const mfx_table_view &c, mfx_ma
     av[j] = (found && !sat) ? r_av : 0u;
     st[j] = !ok[j] ? 0xffu : (found ? (sat ? 0xfeu : 0xffu) : (room ? 0xffu : 1u));  // an empty slot before the key: absent (value 0, merfin-globals.C:84)
   }
+  // ---- saturated count fields: slot 0 of the side table's line, per lane (what is not there stays 0xfe)
+  mfx_side_direct<B>(c, st, rv, av, keyof, dbg);
   // ---- the queries that were not in their first mini-bucket (3 % at load factor 0.225): compacted into this wave's mailbox
   // and served 8 per step by the cooperative whole-line probe -- the 8 lanes of a group fetch the query's HOME line with one
   // coalesced request, so that whichever mini-bucket the k-mer went to, one more round trip finds it
@@ -1551,7 +1633,7 @@ __device__ __forceinline__ void mfx_lane_lookup8(const mfx_table_view &c, mfx_ma
     const uint64_t m = __ballot(p);
     const uint32_t pos = nq + (uint32_t)__popcll(m & ((1ULL << lane) - 1ULL));
     qpos[j] = 0xffffffffu;
-    if (p && pos < 64u) {
+    if (p && pos < CAP) {
       qpos[j] = pos;
       const uint64_t ks = fkey[j] << 22;
       M.rec[wbase + pos] = make_uint4((uint32_t)ks, (uint32_t)(ks >> 32), line[j], 0u);
@@ -1561,7 +1643,7 @@ __device__ __forceinline__ void mfx_lane_lookup8(const mfx_table_view &c, mfx_ma
   if (dbg && nq && lane == 0u) atomicAdd(&dbg[0], (unsigned long long)nq);
   if (nq) {                                                    // wave-uniform
     mfx_wave_handoff();
-    if (nq > 64u) nq = 64u;
+    if (nq > CAP) nq = CAP;
     // One pass over the wave's entries: 8 lanes per entry read its line (rec.z) with one coalesced request and answer into the
     // record -- found: the slot's low word and the marker; an empty slot seen: "room".  Up to MFX_TAIL_STEPS steps (8 entries
     // each) have their line loads in flight TOGETHER: a wave typically has ~25 displaced queries among its 256, i.e. four steps
@@ -1607,7 +1689,7 @@ __device__ __forceinline__ void mfx_lane_lookup8(const mfx_table_view &c, mfx_ma
           const uint4 r = M.rec[wbase + qpos[j]];
           if (r.z == 0xffffffffu) {
             const uint32_t r_rv = (r.x >> 11) & MFX_CSAT, r_av = r.x & MFX_CSAT;
-            if (r_rv == MFX_CSAT || r_av == MFX_CSAT) { rv[j] = r.x; st[j] = 0xfeu; }
+            if (r_rv == MFX_CSAT || r_av == MFX_CSAT) { rv[j] = r.x; st[j] = 0xfeu; if (dbg) atomicAdd(&dbg[2], 1ull); }
             else { rv[j] = (r_rv < c.minV || r_rv > c.maxV) ? 0u : r_rv; av[j] = r_av; st[j] = 0xffu; }
           } else if (r.w == 1u) st[j] = 0xffu;                 // the line has room and does not hold the key: absent
           else st[j] = full_code;                              // the line is full of other k-mers
@@ -1636,8 +1718,26 @@ __device__ __forceinline__ void mfx_lane_lookup8(const mfx_table_view &c, mfx_ma
       collect(2u, 0xfdu);                                      // still not there and no room: whole-line scans from candidate line 2
     }
   }
-  // ---- the rare endings, ONE instance of their code for all B queries of the lane: a saturated count field (the exact
-  // count is in the side table), whole-line scans of the further candidate lines, and (quotient form) a k-mer beyond them
+  // ---- the rare endings: a saturated count field whose exact count is not in slot 0 of its side-table line, further candidate
+  // lines, (quotient form) a k-mer beyond them.  A lane that scans lines here holds its whole wave for up to eight dependent loads
+  // per line -- 0.2 % of the queries of a genome with human-like repeat families, a fifth of the kernel's time (profiles/r06_repeats_ab.txt)
+  // -- so the -hist kernel only LISTS such a query (push) and mfx_hist_rest_kernel ends it, every lane on an entry of its own.
+  uint32_t pushed = 0u;
+  if (Push::enabled) {
+    bool rare = false;
+#pragma unroll
+    for (int j = 0; j < B; ++j) rare |= st[j] >= 0xfcu && st[j] <= 0xfeu;
+    if (__any(rare)) {                                         // wave-uniform
+#pragma unroll
+      for (int j = 0; j < B; ++j) {
+        const bool want = st[j] >= 0xfcu && st[j] <= 0xfeu;
+        if (!__any(want)) continue;
+        if (dbg && want) atomicAdd(&dbg[st[j] == 0xfeu ? 4 : 3], 1ull);
+        if (push(j, want, want ? keyof(j) : 0ull) && want) { pushed |= 1u << j; st[j] = 0xffu; rv[j] = av[j] = 0u; }
+      }
+    }
+  }
+  // ... or (no list, or the list is full) ONE instance of the scans' code for all B queries of the lane
   while (true) {
     int sj = -1;
     uint64_t sfkey = 0;
@@ -1649,7 +1749,7 @@ __device__ __forceinline__ void mfx_lane_lookup8(const mfx_table_view &c, mfx_ma
     if (sj >= 0) {
       uint2 x = make_uint2(0u, 0u);
       bool have = scode == 0xfeu, beyond = false;
-      if (dbg) atomicAdd(&dbg[have ? 2 : 3], 1ull);
+      if (dbg) atomicAdd(&dbg[Push::enabled ? 5 : (have ? 4 : 3)], 1ull);
       if (!have) {
         const uint2 fd = mfx_c_find_lean(c, sfkey, sline, scode == 0xfdu ? 2u : 0u, beyond);
         have = fd.x != 0u;
@@ -1668,6 +1768,7 @@ __device__ __forceinline__ void mfx_lane_lookup8(const mfx_table_view &c, mfx_ma
         if (sj == j) { rv[j] = x.x; av[j] = x.y; st[j] = 0xffu; }
     }
   }
+  return pushed;
 }
 
 // ---------------------------------------------------------------------------
@@ -1692,10 +1793,10 @@ constexpr uint32_t MFX_DEFER_FLUSH = MFX_V_DEFER_FLUSH;
 constexpr uint32_t MFX_REC_FOUND = 0xffffffffu;                // rec.z of an answered entry (no line has this index)
 
 // phase A: the batch's loads and the one-load answers.  defer: bit j set = query j was parked (its rv / av come at the flush).
-template <int B, class KeyOf>
+template <int B, class KeyOf, class Push = mfx_no_push>
 __device__ __forceinline__ uint32_t mfx_lane_probe_defer(const mfx_table_view &c, mfx_mailbox &M, uint32_t &nq, const uint64_t (&fkey)[B], const bool (&ok)[B],
                                                          uint32_t (&rv)[B], uint32_t (&av)[B], const uint32_t (&line)[B], const uint32_t (&b0)[B],
-                                                         const uint32_t (&pos)[B], KeyOf keyof, unsigned long long *dbg = nullptr) {
+                                                         const uint32_t (&pos)[B], KeyOf keyof, unsigned long long *dbg = nullptr, Push push = Push()) {
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wbase = tid & ~63u;
   const uint4 *const slots0 = reinterpret_cast<const uint4 *>(c.slots);
   uint32_t st[B];               // 0xff done; 1 parked; 0xfe a count field is saturated (the slot's low word in rv); 0xfc whole-line scans from the home line
@@ -1717,6 +1818,7 @@ __device__ __forceinline__ uint32_t mfx_lane_probe_defer(const mfx_table_view &c
     av[j] = (found && !sat) ? r_av : 0u;
     st[j] = !ok[j] ? 0xffu : (found ? (sat ? 0xfeu : 0xffu) : (room ? 0xffu : 1u));  // an empty slot before the key: absent (value 0, merfin-globals.C:84)
   }
+  mfx_side_direct<B>(c, st, rv, av, keyof, dbg);               // saturated count fields: slot 0 of the side table's line, per lane
   uint32_t defer = 0u;
 #pragma unroll
   for (int j = 0; j < B; ++j) {
@@ -1736,7 +1838,22 @@ __device__ __forceinline__ uint32_t mfx_lane_probe_defer(const mfx_table_view &c
       nq = nq + cnt < 64u ? nq + cnt : 64u;
     }
   }
-  // the rare endings that cannot wait (the k-mer itself is at hand only here): a saturated count, a query the mailbox had no room for
+  // the rare endings that cannot wait (the k-mer itself is at hand only here): a saturated count whose exact value is not in slot 0
+  // of its side-table line, a query the mailbox had no room for -- onto the -hist kernel's worklist (mfx_lane_lookup8), else per lane
+  if (Push::enabled) {
+    bool rare = false;
+#pragma unroll
+    for (int j = 0; j < B; ++j) rare |= st[j] == 0xfcu || st[j] == 0xfeu;
+    if (__any(rare)) {                                         // wave-uniform
+#pragma unroll
+      for (int j = 0; j < B; ++j) {
+        const bool want = st[j] == 0xfcu || st[j] == 0xfeu;
+        if (!__any(want)) continue;
+        if (dbg && want) atomicAdd(&dbg[st[j] == 0xfeu ? 4 : 3], 1ull);
+        if (push(j, want, want ? keyof(j) : 0ull) && want) { defer |= 1u << j; st[j] = 0xffu; rv[j] = av[j] = 0u; }
+      }
+    }
+  }
   while (true) {
     int sj = -1;
     uint64_t sfkey = 0;
@@ -1748,7 +1865,7 @@ __device__ __forceinline__ uint32_t mfx_lane_probe_defer(const mfx_table_view &c
     if (sj >= 0) {
       uint2 x = make_uint2(0u, 0u);
       bool have = scode == 0xfeu, beyond = false;
-      if (dbg) atomicAdd(&dbg[have ? 2 : 3], 1ull);
+      if (dbg) atomicAdd(&dbg[Push::enabled ? 5 : (have ? 4 : 3)], 1ull);
       if (!have) {
         const uint2 fd = mfx_c_find_lean(c, sfkey, sline, 0u, beyond);
         have = fd.x != 0u;
@@ -1772,8 +1889,9 @@ __device__ __forceinline__ uint32_t mfx_lane_probe_defer(const mfx_table_view &c
 
 // phase B: the wave's parked queries (nq <= 64 of them) answered and handed to eval(readV, asmV), one entry per lane.
 // kmer_at(p): the canonical k-mer at tile position p (quotient form: the side table is keyed by the k-mer itself).
-template <class KmerAt, class Eval>
-__device__ __forceinline__ void mfx_lane_flush(const mfx_table_view &c, mfx_mailbox &M, uint32_t &nq, KmerAt kmer_at, Eval eval, unsigned long long *dbg = nullptr) {
+// push1(want, kmer): the worklist again (one query per lane here)
+template <class KmerAt, class Eval, class Push1>
+__device__ __forceinline__ void mfx_lane_flush(const mfx_table_view &c, mfx_mailbox &M, uint32_t &nq, KmerAt kmer_at, Eval eval, Push1 push1, unsigned long long *dbg = nullptr) {
   const uint32_t tid = threadIdx.x, sub16 = (tid & 7u) << 4, lane = tid & 63u, wbase = tid & ~63u;
   const uint32_t n = nq;
   nq = 0u;
@@ -1837,13 +1955,23 @@ __device__ __forceinline__ void mfx_lane_flush(const mfx_table_view &c, mfx_mail
       if (r2.z == MFX_REC_FOUND) r.z = MFX_REC_FOUND;           // (else r.z stays the HOME line)
     }
   }
-  if (mine) {
-    bool have = r.z == MFX_REC_FOUND, beyond = false;
-    uint32_t lo = r.x;
-    uint64_t fk = (((uint64_t)r.y << 32) | r.x) >> 22;           // the key field (quotient form: F0, without the candidate line's mark)
-    if (c.quot) fk &= (1ull << MFX_Q_DSHIFT) - 1ull;
-    if (!have && (r.w & 3u) == 2u) {                             // neither in its home line nor in the next, both full: whole-line scans from candidate line 2
-      if (dbg) atomicAdd(&dbg[3], 1ull);
+  // lane e's entry after the passes: closed (found with exact counts, or absent), or RARE -- a saturated count field (the exact
+  // count is in the side table), both candidate lines full of other k-mers: listed for mfx_hist_rest_kernel, else ended per lane
+  bool have = r.z == MFX_REC_FOUND;
+  uint32_t lo = r.x;
+  uint64_t fk = (((uint64_t)r.y << 32) | r.x) >> 22;             // the key field (quotient form: F0, without the candidate line's mark)
+  if (c.quot) fk &= (1ull << MFX_Q_DSHIFT) - 1ull;
+  const bool scan = mine && !have && (r.w & 3u) == 2u;           // neither in its home line nor in the next, both full
+  const bool satd = mine && have && (((lo >> 11) & MFX_CSAT) == MFX_CSAT || (lo & MFX_CSAT) == MFX_CSAT);
+  bool listed = false;
+  if (__any(scan || satd)) {                                     // wave-uniform
+    if (dbg && (scan || satd)) atomicAdd(&dbg[scan ? 3 : 2], 1ull);
+    listed = push1(scan || satd, (scan || satd) ? (c.quot ? kmer_at(r.w >> 4) : fk) : 0ull) && (scan || satd);
+  }
+  if (mine && !listed) {
+    bool beyond = false;
+    if (scan) {                                                  // whole-line scans from candidate line 2
+      if (dbg) atomicAdd(&dbg[5], 1ull);
       const uint2 fd = mfx_c_find_lean(c, fk, r.z, 2u, beyond);
       have = fd.x != 0u;
       lo = fd.y;
@@ -1851,7 +1979,6 @@ __device__ __forceinline__ void mfx_lane_flush(const mfx_table_view &c, mfx_mail
     uint32_t r_rv = (lo >> 11) & MFX_CSAT, r_av = lo & MFX_CSAT;
     const bool sat = have && (r_rv == MFX_CSAT || r_av == MFX_CSAT);
     if (sat || beyond) {                                         // the side table is keyed by the k-mer itself
-      if (dbg && sat) atomicAdd(&dbg[2], 1ull);
       const uint2 sx = mfx_side_lookup_lean(c, c.quot ? kmer_at(r.w >> 4) : fk);
       if (beyond) { r_rv = sx.x; r_av = sx.y; have = true; }
       else { if (r_rv == MFX_CSAT) r_rv = sx.x; if (r_av == MFX_CSAT) r_av = sx.y; }
@@ -1891,7 +2018,7 @@ __device__ __forceinline__ void mfx_compact_lookup(const mfx_table_view &t, mfx_
     fkey[j] = key[j]; line[j] = 0u; b0[j] = 0u;
     if (ok[j]) { const mfx_probe pr = mfx_home(t, key[j]); fkey[j] = pr.fkey; line[j] = pr.lineA; b0[j] = pr.b0; }
   }
-  mfx_lane_lookup8<B>(t, M, fkey, ok, rv, av, line, b0, mfx_key_from_array<B>{key});
+  (void)mfx_lane_lookup8<B>(t, M, fkey, ok, rv, av, line, b0, mfx_key_from_array<B>{key});
 #else
   mfx_group_lookup8<B>(t, M, key, krc, ok, rv, av);
 #endif
@@ -2074,10 +2201,19 @@ constexpr int MFX_BATCH = MFX_V_BATCH;          // queries per lane and cooperat
 #ifndef MFX_V_DEFER_K31
 #define MFX_V_DEFER_K31 1
 #endif
-template <bool CANON, bool COMPACT, int KF> struct mfx_hist_tune { static constexpr int blocks = MFX_V_MINBLOCKS, batch = MFX_V_BATCH, defer = 0; };
-template <> struct mfx_hist_tune<true, true, 21> { static constexpr int blocks = MFX_V_MINBLOCKS_K21, batch = MFX_V_BATCH_K21, defer = MFX_V_DEFER_K21; };
-template <> struct mfx_hist_tune<true, true, 31> { static constexpr int blocks = MFX_V_MINBLOCKS_K31, batch = MFX_V_BATCH_K31, defer = MFX_V_DEFER_K31; };
-template <> struct mfx_hist_tune<true, true, 0> { static constexpr int blocks = MFX_V_MINBLOCKS_GEN, batch = MFX_V_BATCH_GEN, defer = 0; };
+// kfxlds: the lane's koverCpy sum of the tile lives in LDS -- the upper half of the wave's mailbox, whose passes then have 32 entries
+// (MFX_KFX_BASE) -- instead of a register pair: at 72 VGPRs the allocator kept that pair, live across the whole tile and touched by
+// one k-mer in fifty, in SCRATCH, and every evaluation that met an `asmK > readK` k-mer paid a scratch load and store behind a
+// full vmcnt wait (107 G k-mers/s against 150 G; profiles/r06_pmc_compare.txt: 16 M scratch stores per 10^9 k-mers).  A ds_add_u64
+// without return costs one issue slot and nothing waits for it.
+#ifndef MFX_V_KFXLDS_K21
+#define MFX_V_KFXLDS_K21 1
+#endif
+constexpr uint32_t MFX_KFX_BASE = 32u;
+template <bool CANON, bool COMPACT, int KF> struct mfx_hist_tune { static constexpr int blocks = MFX_V_MINBLOCKS, batch = MFX_V_BATCH, defer = 0, kfxlds = 0; };
+template <> struct mfx_hist_tune<true, true, 21> { static constexpr int blocks = MFX_V_MINBLOCKS_K21, batch = MFX_V_BATCH_K21, defer = MFX_V_DEFER_K21, kfxlds = MFX_V_KFXLDS_K21; };
+template <> struct mfx_hist_tune<true, true, 31> { static constexpr int blocks = MFX_V_MINBLOCKS_K31, batch = MFX_V_BATCH_K31, defer = MFX_V_DEFER_K31, kfxlds = 0; };
+template <> struct mfx_hist_tune<true, true, 0> { static constexpr int blocks = MFX_V_MINBLOCKS_GEN, batch = MFX_V_BATCH_GEN, defer = 0, kfxlds = 0; };
 template <bool CANON, bool COMPACT, int KF, int WF, int TF, bool DBG = false>
 __global__ __launch_bounds__(MFX_BLOCK, (mfx_hist_tune<CANON, COMPACT, KF>::blocks)) void mfx_hist_kernel(mfx_hist_args a) {
   constexpr int BT = mfx_hist_tune<CANON, COMPACT, KF>::batch;                  // queries per lane and probe sequence of this instance
@@ -2095,7 +2231,7 @@ __global__ __launch_bounds__(MFX_BLOCK, (mfx_hist_tune<CANON, COMPACT, KF>::bloc
   // per-lane counters: 16 positions per tile and lane, so 32 bits hold 2^28 tiles of one block (a terabase); they are
   // widened when they leave the lane.  The block's running totals live in LDS (only thread 0 touches them).
   uint32_t n_valid = 0, n_missing = 0, n_over0 = 0;
-  if (tid == 0) H.tot[0] = H.tot[1] = 0;
+  if (tid == 0) { H.tot[0] = H.tot[1] = 0; H.wl_n = 0u; }
   uint64_t *c_glob = ka.counts + 2ull * ka.nbins;        // kasm, kmissing, novf
   uint64_t *c_kasm = c_glob + 3, *c_kmis = c_kasm + ka.ncontigs;
 
@@ -2145,8 +2281,20 @@ __global__ __launch_bounds__(MFX_BLOCK, (mfx_hist_tune<CANON, COMPACT, KF>::bloc
     // and tile).  An INTEGER sum: the value of a (tile, wave) does not depend on the order its terms were added in, nor on which lane
     // evaluated which k-mer (the deferred tail of the probe hands parked queries to other lanes of the wave, mfx_lane_flush).
     uint64_t kfx = 0;
+    constexpr bool kfx_lds = mfx_hist_tune<CANON, COMPACT, KF>::kfxlds != 0 && !(MFX_V_DEFER != 0 && mfx_hist_tune<CANON, COMPACT, KF>::defer != 0) && COMPACT && CANON && KF != 0 && TF != 0;
+    unsigned long long *const kfxw = reinterpret_cast<unsigned long long *>(&MB.rec[(tid & ~63u) + MFX_KFX_BASE]) + (tid & 63u);   // (kfx_lds) this lane's word
+    if (kfx_lds) *kfxw = 0ull;                                   // (the mailbox was handed back at the end of the tile before)
+    // ... and so does the count of the dominant bin (`over` 0: nine k-mers in ten), in the same word above the 56 bits of the sum (a lane
+    // evaluates at most 16 k-mers of a tile: 16 terms below 2^52 each, a count of at most 16)
+    // (a 32-bit add to the word's high half: the 64-bit constant 1 << 56 was hoisted out of the loop as a register pair -- and spilled)
+    struct lds_bump { unsigned long long *w; __device__ __forceinline__ void operator++(int) { (void)__hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(w) + 1, 1u << 24, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } };
     auto eval1 = [&](uint32_t rvv, uint32_t avv) {
-      if (mfx_hist_eval_fx(H, ka, lut_ok, rvv, avv, n_over0, kfx)) n_missing++;
+      if (kfx_lds) {
+        uint64_t t = 0;
+        lds_bump bump{kfxw};
+        if (mfx_hist_eval_fx(H, ka, lut_ok, rvv, avv, bump, t)) n_missing++;
+        if (t) (void)__hip_atomic_fetch_add(kfxw, (unsigned long long)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else if (mfx_hist_eval_fx(H, ka, lut_ok, rvv, avv, n_over0, kfx)) n_missing++;
     };
     // mod-minimizer placement: the wave finds its home lines together (mfx_wave_mod_line)
     const bool wave_lines = COMPACT && CANON && (KF ? TF != 0 : a.t.mz_t != 0);
@@ -2154,6 +2302,25 @@ __global__ __launch_bounds__(MFX_BLOCK, (mfx_hist_tune<CANON, COMPACT, KF>::bloc
     // palindrome doubling below (an even k takes the undeferred probe)
     const bool defer_tail = MFX_V_DEFER != 0 && mfx_hist_tune<CANON, COMPACT, KF>::defer != 0 && COMPACT && CANON && KF != 0 && TF != 0 && (KF & 1) != 0;
     const bool quotf = KF ? KF > MFX_MAX_K_DIRECT : a.t.quot != 0;
+    // The worklist of mfx_hist_rest_kernel: a query whose probe did not end in its two cooperative passes is LISTED -- {canonical
+    // k-mer, contig, the (tile, wave) slot its koverCpy term belongs to, "an even-k palindrome: both counts twice"} -- instead of
+    // being scanned for by its lane while 63 others wait.  The whole wave calls; the lanes that want are given consecutive entries
+    // of this BLOCK's segment of the list (one LDS atomic per call); false: no list (a.wl == nullptr) or no room left in the segment,
+    // the lane then scans.  kasm is counted here either way.
+    auto push_wave = [&](bool want, uint64_t kmer, bool dbl) -> bool {
+      if (!a.wl) return false;                                     // (kernel-uniform)
+      const uint64_t m = __ballot(want);
+      if (!m) return false;
+      const uint32_t ln = tid & 63u, leader = (uint32_t)__ffsll((unsigned long long)m) - 1u;
+      uint32_t base = 0;
+      if (ln == leader) base = atomicAdd(&H.wl_n, (uint32_t)__popcll(m));       // this block's own segment of the list: an LDS counter, no global atomic
+      base = (uint32_t)__shfl((int)base, (int)leader, 64);
+      const uint32_t at = base + (uint32_t)__popcll(m & ((1ULL << ln) - 1ULL));
+      const bool fits = want && at < a.wl_segcap;
+      if (fits) reinterpret_cast<uint4 *>(a.wl + MFX_WL_HEADER)[(uint64_t)blockIdx.x * a.wl_segcap + at] =
+                  make_uint4((uint32_t)kmer, (uint32_t)(kmer >> 32), c, ((uint32_t)li * (MFX_BLOCK / 64) + (tid >> 6)) | (dbl ? 0x80000000u : 0u));
+      return fits;
+    };
     uint32_t nq = 0;                         // queries parked in this wave's mailbox (wave-uniform)
     uint32_t *const mwave = reinterpret_cast<uint32_t *>(H.dred) + (tid >> 6) * 128u;        // the wave's 64 + npos words of mfx_wave_mod_line (H.dred is idle in this kernel)
     for (uint32_t b = 0;; b += BT) {
@@ -2166,7 +2333,7 @@ __global__ __launch_bounds__(MFX_BLOCK, (mfx_hist_tune<CANON, COMPACT, KF>::bloc
           const uint64_t r = mfx_revcomp(f, k);
           return f < r ? f : r;
         };
-        mfx_lane_flush(a.t, MB, nq, kmer_at, eval1, DBG ? reinterpret_cast<unsigned long long *>(a.dbg) : nullptr);
+        mfx_lane_flush(a.t, MB, nq, kmer_at, eval1, [&](bool want, uint64_t km) { return push_wave(want, km, false); }, DBG ? reinterpret_cast<unsigned long long *>(a.dbg) : nullptr);
       }
       if (last) break;
       uint32_t rv[BT], av[BT];
@@ -2207,9 +2374,13 @@ __global__ __launch_bounds__(MFX_BLOCK, (mfx_hist_tune<CANON, COMPACT, KF>::bloc
           uint32_t posn[BT];
 #pragma unroll
           for (int j = 0; j < BT; ++j) posn[j] = (b + (uint32_t)j) * MFX_BLOCK + tid;
-          parked = mfx_lane_probe_defer<BT>(a.t, MB, nq, fkey, ok, rv, av, line, b0, posn, keyof, DBG ? reinterpret_cast<unsigned long long *>(a.dbg) : nullptr);
+          auto pj = [&](int jj, bool want, uint64_t km) { (void)jj; return push_wave(want, km, false); };     // (odd k: no palindromes)
+          parked = mfx_lane_probe_defer<BT>(a.t, MB, nq, fkey, ok, rv, av, line, b0, posn, keyof, DBG ? reinterpret_cast<unsigned long long *>(a.dbg) : nullptr,
+                                            mfx_push_fn<decltype(pj)>{pj});
         } else {
-          mfx_lane_lookup8<BT>(a.t, MB, fkey, ok, rv, av, line, b0, keyof, DBG ? reinterpret_cast<unsigned long long *>(a.dbg) : nullptr);
+          auto pj = [&](int jj, bool want, uint64_t km) { return push_wave(want, km, ((pal >> jj) & 1u) != 0u); };
+          parked = mfx_lane_lookup8<BT, decltype(keyof), mfx_push_fn<decltype(pj)>, (kfx_lds ? MFX_KFX_BASE : 64u)>(
+                       a.t, MB, fkey, ok, rv, av, line, b0, keyof, DBG ? reinterpret_cast<unsigned long long *>(a.dbg) : nullptr, mfx_push_fn<decltype(pj)>{pj});
         }
         if (even_k) {
           // even k, canonical database: a k-mer that is its own reverse complement is looked up as fmer AND as rmer by the
@@ -2254,10 +2425,13 @@ __global__ __launch_bounds__(MFX_BLOCK, (mfx_hist_tune<CANON, COMPACT, KF>::bloc
         if (!((parked >> j) & 1u)) eval1(rv[j], av[j]);             // (a parked query is evaluated when the mailbox is flushed)
       }
     }
-    // koverCpy of this (tile, wave): the integer sum over the 64 lanes (< 2^62), as a double
+    // koverCpy of this (tile, wave): the integer sum over the 64 lanes (< 2^62)
+    if (kfx_lds) { mfx_wave_handoff(); const unsigned long long w = *kfxw; kfx = w & ((1ull << 56) - 1ull); n_over0 += (uint32_t)(w >> 56); }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) kfx += __shfl_down(kfx, off, 64);
-    if ((tid & 63u) == 0) a.tile_partials[li * (MFX_BLOCK / 64) + (tid >> 6)] = (double)kfx * 2.220446049250313e-16;   // * 2^-52
+    // (stored as the INTEGER: mfx_hist_rest_kernel adds the terms of the k-mers it ends to the same word; the summing kernels
+    // convert, mfx_sum_chunks_kernel<true>)
+    if ((tid & 63u) == 0) reinterpret_cast<uint64_t *>(a.tile_partials)[li * (MFX_BLOCK / 64) + (tid >> 6)] = kfx;
 
     __syncthreads();                         // tile consumed; H.next[it & 1] written
     const uint64_t nx = H.next[it & 1];
@@ -2268,6 +2442,7 @@ __global__ __launch_bounds__(MFX_BLOCK, (mfx_hist_tune<CANON, COMPACT, KF>::bloc
   {
     uint64_t x = n_valid, y = n_missing, z = n_over0;
     mfx_block_sum3(x, y, z, H.red);
+    if (tid == 0 && a.wl && H.wl_n) a.wl[2 + blockIdx.x] = H.wl_n < a.wl_segcap ? H.wl_n : a.wl_segcap;      // this block's segment of the worklist (mfx_hist_rest_kernel)
     if (tid == 0) {
       if (c != none && (x | y)) {
         atomicAdd((unsigned long long *)&c_kasm[c], x);
@@ -2276,6 +2451,69 @@ __global__ __launch_bounds__(MFX_BLOCK, (mfx_hist_tune<CANON, COMPACT, KF>::bloc
       if (H.tot[0] + x) atomicAdd((unsigned long long *)&c_glob[0], H.tot[0] + x);
       if (H.tot[1] + y) atomicAdd((unsigned long long *)&c_glob[1], H.tot[1] + y);
       if (z) atomicAdd((unsigned long long *)&ka.counts[ka.nbins], z);
+    }
+  }
+  mfx_hist_lds_flush_bins(H, ka);
+}
+
+// ---------------------------------------------------------------------------
+// The queries mfx_hist_kernel listed instead of ending them (push_wave): a wave there serves 128 positions at a time, and one lane
+// scanning further candidate lines or the side table holds the other 63 -- here EVERY lane has an entry of its own, so the plain
+// per-lane lookup (mfx_c_lookup: whole lines, all candidate lines, the side table, the read filter) runs with the wave full.
+// Each entry is evaluated like a position of the sequence (merfin-histogram.C:63-90): bins and counters into the same image, the
+// koverCpy term -- an integer, units of 2^-52 -- added to the word of its own (tile, wave), so that the launch's result is the one
+// the main kernel alone would have produced, bit for bit, whatever was listed.  kasm was counted where the position was seen.
+// Launched behind every launch of the main kernel on the same stream.  The list is cut into one segment per block of the main kernel
+// (a block appends to its own segment through a counter in LDS: one shared counter would be a single-address atomic per listed wave,
+// ~90 M/s -- 80 ms of a launch that lists 7 M of them); block b here takes the segments b, b + gridDim.x, ... and empties them.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(MFX_BLOCK) void mfx_hist_rest_kernel(mfx_hist_args a) {
+  __shared__ mfx_hist_lds H;
+  const uint32_t tid = threadIdx.x;
+  const mfx_kstar_args &ka = a.ks;
+  uint64_t *c_glob = ka.counts + 2ull * ka.nbins, *c_kmis = c_glob + 3 + ka.ncontigs;
+  uint64_t *kfx_words = reinterpret_cast<uint64_t *>(a.tile_partials);
+  uint32_t n_missing = 0, n_over0 = 0;
+  bool ready = false, lut_ok = false;                          // the K* tables of this block are made when it meets its first entry
+  for (uint32_t seg = blockIdx.x; seg < a.wl_segs; seg += gridDim.x) {
+    const uint32_t n = (uint32_t)__hip_atomic_load(reinterpret_cast<unsigned long long *>(&a.wl[2 + seg]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (n == 0u) continue;                                     // block-uniform
+    if (!ready) { mfx_hist_lds_init(H, ka); lut_ok = H.lut_ok != 0u; ready = true; }
+    const uint4 *ent = reinterpret_cast<const uint4 *>(a.wl + MFX_WL_HEADER) + (uint64_t)seg * a.wl_segcap;
+    for (uint32_t i0 = 0; i0 < n; i0 += MFX_BLOCK) {           // block-uniform trip count
+      const uint32_t i = i0 + tid;
+      const bool live = i < n;
+      uint4 e = make_uint4(0u, 0u, 0u, 0u);
+      if (live) e = ent[i];
+      bool missing = false;
+      if (live) {
+        uint2 x = mfx_c_lookup(a.t, ((uint64_t)e.y << 32) | e.x);
+        if (e.w >> 31) { x.x += x.x; x.y += x.y; }             // an even-k palindrome: value(fmer) + value(rmer) is the same slot twice (mfx_hist_kernel)
+        uint64_t kfx = 0;
+        missing = mfx_hist_eval_fx(H, ka, lut_ok, x.x, x.y, n_over0, kfx);
+        if (kfx) atomicAdd(reinterpret_cast<unsigned long long *>(&kfx_words[e.w & 0x7fffffffu]), (unsigned long long)kfx);
+      }
+      // the missing k-mers of a contig: the lanes of a wave that hold the same contig add together (a list runs along the sequence)
+      uint64_t todo = __ballot(missing);
+      while (todo) {
+        const int leader = __ffsll((unsigned long long)todo) - 1;
+        const uint32_t lc = (uint32_t)__shfl((int)e.z, leader, 64);
+        const uint64_t same = __ballot(missing && e.z == lc) & todo;
+        if ((int)(tid & 63u) == leader) atomicAdd(reinterpret_cast<unsigned long long *>(&c_kmis[lc]), (unsigned long long)__popcll(same));
+        todo &= ~same;
+      }
+      if (missing) n_missing++;
+    }
+    __syncthreads();
+    if (tid == 0) a.wl[2 + seg] = 0;                           // the segment is empty again for the next launch
+  }
+  if (!ready) return;                                          // (block-uniform)
+  {
+    uint64_t x = 0, y = n_missing, z = n_over0;
+    mfx_block_sum3(x, y, z, H.red);
+    if (tid == 0) {
+      if (y) atomicAdd(reinterpret_cast<unsigned long long *>(&c_glob[1]), (unsigned long long)y);
+      if (z) atomicAdd(reinterpret_cast<unsigned long long *>(&ka.counts[ka.nbins]), (unsigned long long)z);
     }
   }
   mfx_hist_lds_flush_bins(H, ka);
@@ -2709,12 +2947,14 @@ __global__ void mfx_ordered_sum_kernel(const double *v, uint32_t n, double *out)
 
 // first level over the per-(tile, wave) values: block b sums in[b*MFX_SUM_CHUNK ...) in a fixed order
 #define MFX_SUM_CHUNK 4096u
+// FIXED: the values are integers in units of 2^-52 (mfx_hist_kernel / mfx_hist_rest_kernel), converted as they are read
+template <bool FIXED>
 __global__ __launch_bounds__(MFX_BLOCK) void mfx_sum_chunks_kernel(const double *in, uint64_t n, double *out) {
   __shared__ double s[MFX_BLOCK];
   const uint64_t base = (uint64_t)blockIdx.x * MFX_SUM_CHUNK;
   double v = 0.0;
   for (uint32_t i = threadIdx.x; i < MFX_SUM_CHUNK; i += MFX_BLOCK)
-    if (base + i < n) v = v + in[base + i];
+    if (base + i < n) v = v + (FIXED ? (double)reinterpret_cast<const uint64_t *>(in)[base + i] * 2.220446049250313e-16 : in[base + i]);
   s[threadIdx.x] = v;
   __syncthreads();
   for (uint32_t st = MFX_BLOCK / 2; st > 0; st >>= 1) {
@@ -3257,6 +3497,11 @@ hipError_t mfx_k_hist(const mfx_hist_args &a, int grid, hipStream_t st) {
   else                                 mfx_hist_kernel<false, false, 0, 0, 0><<<grid, MFX_BLOCK, dyn, st>>>(a);
   return hipGetLastError();
 }
+hipError_t mfx_k_hist_rest(const mfx_hist_args &a, int grid, hipStream_t st) {
+  if (!a.wl) return hipSuccess;
+  mfx_hist_rest_kernel<<<grid, MFX_BLOCK, 0, st>>>(a);
+  return hipGetLastError();
+}
 hipError_t mfx_k_route(const mfx_route_args &a, hipStream_t st) {
   uint64_t nt = a.tile_end - a.tile_begin;
   if (nt == 0) return hipSuccess;
@@ -3307,10 +3552,11 @@ uint64_t mfx_k_tile_partials_words(uint64_t ntiles) {
   return n + (n + MFX_SUM_CHUNK - 1) / MFX_SUM_CHUNK;
 }
 // koverCpy of a tile-driven launch: two fixed-order levels over the per-(tile, wave) values, then += *out
-hipError_t mfx_k_sum_tile_partials(double *tile_partials, uint64_t ntiles, double *out, uint64_t *ctr_reset, hipStream_t st) {
+hipError_t mfx_k_sum_tile_partials(double *tile_partials, uint64_t ntiles, double *out, uint64_t *ctr_reset, hipStream_t st, int fixed) {
   const uint64_t n = ntiles * (MFX_BLOCK / 64);
   const uint64_t nch = (n + MFX_SUM_CHUNK - 1) / MFX_SUM_CHUNK;
-  if (nch) mfx_sum_chunks_kernel<<<(unsigned)nch, MFX_BLOCK, 0, st>>>(tile_partials, n, tile_partials + n);
+  if (nch && fixed) mfx_sum_chunks_kernel<true><<<(unsigned)nch, MFX_BLOCK, 0, st>>>(tile_partials, n, tile_partials + n);
+  else if (nch) mfx_sum_chunks_kernel<false><<<(unsigned)nch, MFX_BLOCK, 0, st>>>(tile_partials, n, tile_partials + n);
   mfx_sum_partials_kernel<<<1, MFX_BLOCK, 0, st>>>(tile_partials + n, (uint32_t)nch, out, ctr_reset);
   return hipGetLastError();
 }

@@ -34,6 +34,28 @@ def test_cli_validation_messages():
     assert r.returncode == 1 and "No variant call input (-vcf)" in r.stderr
 
 
+def test_cli_prob_table_through_the_compressed_reader(tmp_path, golden_dir):
+    """load_Kmetric reads -prob through compressedFileReader (merfin-globals.C:34): a .gz table parses like the plain one (the rows
+    are echoed on stderr before the databases are opened, :55), a damaged .gz is an error, a missing file keeps the reference's text"""
+    prob = os.path.join(golden_dir, "example_lookup_table.txt")
+    gzp = str(tmp_path / "table.txt.gz")
+    with open(prob, "rb") as f, gzip.open(gzp, "wb") as g:
+        g.write(f.read())
+    base = ["-hist", "-sequence", str(tmp_path / "none.fasta"), "-readmers", str(tmp_path / "none.meryl"), "-peak", "26", "-output", str(tmp_path / "o")]
+    plain = run(base + ["-prob", prob])
+    zipped = run(base + ["-prob", gzp])
+    rows = lambda r: [l for l in r.stderr.splitlines() if l.startswith("Copy-number:")]
+    assert len(rows(plain)) == 184 and rows(zipped) == rows(plain)
+    assert "Copy-number: 1\t\tReadK: 0\tProbability: " in zipped.stderr
+    bad = str(tmp_path / "bad.txt.gz")
+    with open(bad, "wb") as f:
+        f.write(open(gzp, "rb").read()[:200])
+    r = run(base + ["-prob", bad])
+    assert r.returncode == 1 and "reading the probability table (-prob)" in r.stderr
+    r = run(base + ["-prob", str(tmp_path / "missing.txt.gz")])
+    assert r.returncode == 1 and "Probability table (-prob) file" in r.stderr and "doesn't exist!" in r.stderr
+
+
 def _write_fasta(path, contigs, width=60, gz=False):
     op = gzip.open if gz else open
     with op(path, "wb") as f:
@@ -84,7 +106,9 @@ def test_cli_hist_dump_completeness_end_to_end(tmp_path, golden_dir):
     assert r.stderr.rstrip().endswith("Bye!")
 
     # -hist without -seqmers: the assembly k-mers are counted on the GPU (replaces `meryl count`)
-    r2 = run(["-hist", "-sequence", fa, "-readmers", str(tmp_path / "read.mfxk"), "-peak", str(peak), "-prob", prob,
+    with open(prob, "rb") as f, gzip.open(str(tmp_path / "prob.gz"), "wb") as gzf:
+        gzf.write(f.read())                                    # -prob through the compressed reader (merfin-globals.C:34)
+    r2 = run(["-hist", "-sequence", fa, "-readmers", str(tmp_path / "read.mfxk"), "-peak", str(peak), "-prob", str(tmp_path / "prob.gz"),
               "-output", str(tmp_path / "g2.hist")])
     assert r2.returncode == 0, r2.stderr
     assert (tmp_path / "g2.hist").read_bytes() == (tmp_path / "o.hist").read_bytes()
