@@ -998,10 +998,14 @@ class Evaluator:
         _check(load_library().mfx_eval_debug_enable(self.h, 1 if on else 0))
 
     def debug_counters(self):
-        """{first_pass, second_pass, side_table, line_scans}: how the probe's queries that left the one-load path ended; cleared"""
+        """how the probe's queries that left the one-load path ended (cleared): first_pass / second_pass (cooperative passes over the home
+        line / the next candidate line), side_table (a saturated count field), line_scans (further candidate lines: listed for
+        mfx_hist_rest_kernel), side_not_in_two_slots (saturated, not in slot 0 / 1 of its side-table line: listed), ended_per_lane (no
+        list, or the list was full: scanned for by the lane itself)"""
         out = np.zeros(8, dtype=np.uint64)
         _check(load_library().mfx_eval_debug_counters(self.h, out.ctypes.data_as(C.POINTER(C.c_uint64))))
-        return {"first_pass": int(out[0]), "second_pass": int(out[1]), "side_table": int(out[2]), "line_scans": int(out[3])}
+        return {"first_pass": int(out[0]), "second_pass": int(out[1]), "side_table": int(out[2]), "line_scans": int(out[3]),
+                "side_not_in_two_slots": int(out[4]), "ended_per_lane": int(out[5])}
 
     def hist(self, seqs):
         r = HistResult()

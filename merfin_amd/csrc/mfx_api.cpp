@@ -1872,7 +1872,7 @@ static int hist_launch(mfx_eval *ev, const mfx_seq *seq, uint64_t tile_begin, ui
   a.ks.partials = ev->d_partials;
   a.ks.ovf = ev->d_ovf;
   a.dbg = ev->d_dbg;
-  if (a.t.compact && canon && ntl < (1ull << 29)) {          // the probe's rare endings are listed and ended by mfx_hist_rest_kernel (mfx_kernels.hip)
+  if (a.t.compact && canon && ntl < (1ull << 27)) {          // the probe's rare endings are listed and ended by mfx_hist_rest_kernel (mfx_kernels.hip)
     rc = ensure_worklist(ev, ctr_slot, ntl);
     if (rc) return rc;
     const uint64_t segs = std::min<uint64_t>((uint64_t)ev->grid, ntl);     // the main kernel's grid: one segment per block
@@ -1884,7 +1884,7 @@ static int hist_launch(mfx_eval *ev, const mfx_seq *seq, uint64_t tile_begin, ui
   }
   MFX_HIP(ev->ix->wide() ? mfx_kw_hist(a, (int)std::min<uint64_t>((uint64_t)ev->grid, ntl), (hipStream_t)stream)
                           : mfx_k_hist(a, (int)std::min<uint64_t>((uint64_t)ev->grid, ntl), (hipStream_t)stream));
-  if (a.wl) MFX_HIP(mfx_k_hist_rest(a, (int)std::min<uint64_t>(1024, (uint64_t)ev->grid), (hipStream_t)stream));
+  if (a.wl) MFX_HIP(mfx_k_hist_rest(a, (int)(a.wl_segs * 4u), (hipStream_t)stream));                 // (MFX_REST_SPLIT blocks per segment)
   if (chunk_of_total) MFX_HIP(hipMemsetAsync(ev->d_tile_ctr + ctr_slot, 0, sizeof(uint64_t), (hipStream_t)stream));   // re-arm the tile scheduler
   else MFX_HIP(mfx_k_sum_tile_partials(ev->d_tile_partials, ntl, d_kover, ev->d_tile_ctr, (hipStream_t)stream, ev->ix->wide() ? 0 : 1));
   return MFX_OK;

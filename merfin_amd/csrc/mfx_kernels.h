@@ -36,7 +36,7 @@ struct mfx_hist_args {
   uint32_t        part_rank, part_n, part_shift;
   uint64_t       *dbg = nullptr;      // non-null: the debug instance of the kernel counts the probe's endings here (mfx_eval_debug_counters)
   // the worklist of mfx_hist_rest_kernel (compact layout, canonical database; else null): words [2, 2 + wl_segs) = entries in each segment (one
-  // per block of the main kernel's grid), from word MFX_WL_HEADER: 16-byte entries {k-mer, contig, slot | dbl << 31}, segment g at g * wl_segcap
+  // per block of the main kernel's grid), from word MFX_WL_HEADER: 16-byte entries {k-mer, aux, slot | mode << 29 | dbl << 31}, segment g at g * wl_segcap
   uint64_t       *wl = nullptr;
   uint32_t        wl_segs = 0, wl_segcap = 0;
   mfx_kstar_args  ks;

@@ -1511,12 +1511,23 @@ __device__ __forceinline__ uint2 mfx_sat_fill(uint32_t lo, uint32_t xr, uint32_t
 // inside a satellite array or an rDNA unit EVERY lane of the wave has one.  A line of the side table fills from slot 0 on and holds
 // 0.3 k-mers on average, so the k-mer is there (done: st = 0xff), the slot is empty (no exact count was ever moved: 0), or another
 // k-mer is: st stays 0xfe and the query ends like the other rare ones (the worklist of mfx_hist_rest_kernel, or the per-lane scan).
+#ifndef MFX_V_DIAG_NOSIDE
+#define MFX_V_DIAG_NOSIDE 0           // DIAGNOSTIC builds only (wrong results): saturated fields taken as counts / rare endings dropped
+#endif
+#ifndef MFX_V_DIAG_NOPUSH
+#define MFX_V_DIAG_NOPUSH 0
+#endif
 template <int B, class KeyOf>
 __device__ __forceinline__ void mfx_side_direct(const mfx_table_view &c, uint32_t (&st)[B], uint32_t (&rv)[B], uint32_t (&av)[B], KeyOf keyof, unsigned long long *dbg) {
   bool anysat = false;
 #pragma unroll
   for (int j = 0; j < B; ++j) anysat |= st[j] == 0xfeu;
   if (!__any(anysat)) return;                                  // wave-uniform
+#if MFX_V_DIAG_NOSIDE
+#pragma unroll
+  for (int j = 0; j < B; ++j) if (st[j] == 0xfeu) { st[j] = 0xffu; av[j] = rv[j] & MFX_CSAT; rv[j] = (rv[j] >> 11) & MFX_CSAT; }
+  return;
+#endif
   uint4 sv[B];
   uint64_t km[B];
 #pragma unroll
@@ -1569,11 +1580,11 @@ template <class F>
 struct mfx_push_fn {
   static constexpr bool enabled = true;
   F f;
-  __device__ __forceinline__ bool operator()(int j, bool want, uint64_t kmer) const { return f(j, want, kmer); }
+  __device__ __forceinline__ bool operator()(int j, bool want, uint64_t kmer, uint32_t aux, uint32_t mode) const { return f(j, want, kmer, aux, mode); }
 };
 struct mfx_no_push {
   static constexpr bool enabled = false;
-  __device__ __forceinline__ bool operator()(int, bool, uint64_t) const { return false; }
+  __device__ __forceinline__ bool operator()(int, bool, uint64_t, uint32_t, uint32_t) const { return false; }
 };
 
 #ifndef MFX_V_TAIL_STEPS
@@ -1620,7 +1631,8 @@ __device__ __forceinline__ uint32_t mfx_lane_lookup8(const mfx_table_view &c, mf
     av[j] = (found && !sat) ? r_av : 0u;
     st[j] = !ok[j] ? 0xffu : (found ? (sat ? 0xfeu : 0xffu) : (room ? 0xffu : 1u));  // an empty slot before the key: absent (value 0, merfin-globals.C:84)
   }
-  // ---- saturated count fields: slot 0 of the side table's line, per lane (what is not there stays 0xfe)
+  // ---- saturated count fields: slots 0 and 1 of the side table's line, per lane (what is not there stays 0xfe; a saturated field
+  // met by a PASS below is listed with the rare endings: a second instance of this code behind the passes cost the i.i.d. genome 3 %)
   mfx_side_direct<B>(c, st, rv, av, keyof, dbg);
   // ---- the queries that were not in their first mini-bucket (3 % at load factor 0.225): compacted into this wave's mailbox
   // and served 8 per step by the cooperative whole-line probe -- the 8 lanes of a group fetch the query's HOME line with one
@@ -1733,7 +1745,12 @@ __device__ __forceinline__ uint32_t mfx_lane_lookup8(const mfx_table_view &c, mf
         const bool want = st[j] >= 0xfcu && st[j] <= 0xfeu;
         if (!__any(want)) continue;
         if (dbg && want) atomicAdd(&dbg[st[j] == 0xfeu ? 4 : 3], 1ull);
-        if (push(j, want, want ? keyof(j) : 0ull) && want) { pushed |= 1u << j; st[j] = 0xffu; rv[j] = av[j] = 0u; }
+#if MFX_V_DIAG_NOPUSH
+        if (want) { st[j] = 0xffu; rv[j] = av[j] = 0u; }
+        continue;
+#endif
+        // (a saturated one: the main slot is known -- its low word rides in the entry, the side table's line is all that is left to read)
+        if (push(j, want, want ? keyof(j) : 0ull, st[j] == 0xfeu ? rv[j] : line[j], st[j] == 0xfdu ? 1u : st[j] == 0xfeu ? 2u : 0u) && want) { pushed |= 1u << j; st[j] = 0xffu; rv[j] = av[j] = 0u; }
       }
     }
   }
@@ -1793,7 +1810,7 @@ constexpr uint32_t MFX_DEFER_FLUSH = MFX_V_DEFER_FLUSH;
 constexpr uint32_t MFX_REC_FOUND = 0xffffffffu;                // rec.z of an answered entry (no line has this index)
 
 // phase A: the batch's loads and the one-load answers.  defer: bit j set = query j was parked (its rv / av come at the flush).
-template <int B, class KeyOf, class Push = mfx_no_push>
+template <int B, class KeyOf, class Push = mfx_no_push, uint32_t CAP = 64u>
 __device__ __forceinline__ uint32_t mfx_lane_probe_defer(const mfx_table_view &c, mfx_mailbox &M, uint32_t &nq, const uint64_t (&fkey)[B], const bool (&ok)[B],
                                                          uint32_t (&rv)[B], uint32_t (&av)[B], const uint32_t (&line)[B], const uint32_t (&b0)[B],
                                                          const uint32_t (&pos)[B], KeyOf keyof, unsigned long long *dbg = nullptr, Push push = Push()) {
@@ -1827,7 +1844,7 @@ __device__ __forceinline__ uint32_t mfx_lane_probe_defer(const mfx_table_view &c
     if (m) {                                                    // wave-uniform
       const uint32_t at = nq + (uint32_t)__popcll(m & ((1ULL << lane) - 1ULL));
       if (p) {
-        if (at < 64u) {
+        if (at < CAP) {
           const uint64_t ks = fkey[j] << 22;
           M.rec[wbase + at] = make_uint4((uint32_t)ks, (uint32_t)(ks >> 32), line[j], pos[j] << 4);
           defer |= 1u << j;
@@ -1835,7 +1852,7 @@ __device__ __forceinline__ uint32_t mfx_lane_probe_defer(const mfx_table_view &c
       }
       const uint32_t cnt = (uint32_t)__popcll(m);
       if (dbg && lane == 0u) atomicAdd(&dbg[0], (unsigned long long)cnt);
-      nq = nq + cnt < 64u ? nq + cnt : 64u;
+      nq = nq + cnt < CAP ? nq + cnt : CAP;
     }
   }
   // the rare endings that cannot wait (the k-mer itself is at hand only here): a saturated count whose exact value is not in slot 0
@@ -1850,7 +1867,7 @@ __device__ __forceinline__ uint32_t mfx_lane_probe_defer(const mfx_table_view &c
         const bool want = st[j] == 0xfcu || st[j] == 0xfeu;
         if (!__any(want)) continue;
         if (dbg && want) atomicAdd(&dbg[st[j] == 0xfeu ? 4 : 3], 1ull);
-        if (push(j, want, want ? keyof(j) : 0ull) && want) { defer |= 1u << j; st[j] = 0xffu; rv[j] = av[j] = 0u; }
+        if (push(j, want, want ? keyof(j) : 0ull, st[j] == 0xfeu ? rv[j] : line[j], st[j] == 0xfeu ? 2u : 0u) && want) { defer |= 1u << j; st[j] = 0xffu; rv[j] = av[j] = 0u; }
       }
     }
   }
@@ -1966,7 +1983,7 @@ __device__ __forceinline__ void mfx_lane_flush(const mfx_table_view &c, mfx_mail
   bool listed = false;
   if (__any(scan || satd)) {                                     // wave-uniform
     if (dbg && (scan || satd)) atomicAdd(&dbg[scan ? 3 : 2], 1ull);
-    listed = push1(scan || satd, (scan || satd) ? (c.quot ? kmer_at(r.w >> 4) : fk) : 0ull) && (scan || satd);
+    listed = push1(scan || satd, (scan || satd) ? (c.quot ? kmer_at(r.w >> 4) : fk) : 0ull, scan ? r.z : lo, scan ? 1u : 2u) && (scan || satd);      // (scan: r.z is still the HOME line)
   }
   if (mine && !listed) {
     bool beyond = false;
@@ -2212,7 +2229,10 @@ constexpr int MFX_BATCH = MFX_V_BATCH;          // queries per lane and cooperat
 constexpr uint32_t MFX_KFX_BASE = 32u;
 template <bool CANON, bool COMPACT, int KF> struct mfx_hist_tune { static constexpr int blocks = MFX_V_MINBLOCKS, batch = MFX_V_BATCH, defer = 0, kfxlds = 0; };
 template <> struct mfx_hist_tune<true, true, 21> { static constexpr int blocks = MFX_V_MINBLOCKS_K21, batch = MFX_V_BATCH_K21, defer = MFX_V_DEFER_K21, kfxlds = MFX_V_KFXLDS_K21; };
-template <> struct mfx_hist_tune<true, true, 31> { static constexpr int blocks = MFX_V_MINBLOCKS_K31, batch = MFX_V_BATCH_K31, defer = MFX_V_DEFER_K31, kfxlds = 0; };
+#ifndef MFX_V_KFXLDS_K31
+#define MFX_V_KFXLDS_K31 0
+#endif
+template <> struct mfx_hist_tune<true, true, 31> { static constexpr int blocks = MFX_V_MINBLOCKS_K31, batch = MFX_V_BATCH_K31, defer = MFX_V_DEFER_K31, kfxlds = MFX_V_KFXLDS_K31; };
 template <> struct mfx_hist_tune<true, true, 0> { static constexpr int blocks = MFX_V_MINBLOCKS_GEN, batch = MFX_V_BATCH_GEN, defer = 0, kfxlds = 0; };
 template <bool CANON, bool COMPACT, int KF, int WF, int TF, bool DBG = false>
 __global__ __launch_bounds__(MFX_BLOCK, (mfx_hist_tune<CANON, COMPACT, KF>::blocks)) void mfx_hist_kernel(mfx_hist_args a) {
@@ -2281,7 +2301,8 @@ __global__ __launch_bounds__(MFX_BLOCK, (mfx_hist_tune<CANON, COMPACT, KF>::bloc
     // and tile).  An INTEGER sum: the value of a (tile, wave) does not depend on the order its terms were added in, nor on which lane
     // evaluated which k-mer (the deferred tail of the probe hands parked queries to other lanes of the wave, mfx_lane_flush).
     uint64_t kfx = 0;
-    constexpr bool kfx_lds = mfx_hist_tune<CANON, COMPACT, KF>::kfxlds != 0 && !(MFX_V_DEFER != 0 && mfx_hist_tune<CANON, COMPACT, KF>::defer != 0) && COMPACT && CANON && KF != 0 && TF != 0;
+    constexpr bool kfx_lds = mfx_hist_tune<CANON, COMPACT, KF>::kfxlds != 0 && COMPACT && CANON && KF != 0 && TF != 0;
+    constexpr uint32_t mb_cap = kfx_lds ? MFX_KFX_BASE : 64u;      // mailbox entries the probe has
     unsigned long long *const kfxw = reinterpret_cast<unsigned long long *>(&MB.rec[(tid & ~63u) + MFX_KFX_BASE]) + (tid & 63u);   // (kfx_lds) this lane's word
     if (kfx_lds) *kfxw = 0ull;                                   // (the mailbox was handed back at the end of the tile before)
     // ... and so does the count of the dominant bin (`over` 0: nine k-mers in ten), in the same word above the 56 bits of the sum (a lane
@@ -2303,11 +2324,12 @@ __global__ __launch_bounds__(MFX_BLOCK, (mfx_hist_tune<CANON, COMPACT, KF>::bloc
     const bool defer_tail = MFX_V_DEFER != 0 && mfx_hist_tune<CANON, COMPACT, KF>::defer != 0 && COMPACT && CANON && KF != 0 && TF != 0 && (KF & 1) != 0;
     const bool quotf = KF ? KF > MFX_MAX_K_DIRECT : a.t.quot != 0;
     // The worklist of mfx_hist_rest_kernel: a query whose probe did not end in its two cooperative passes is LISTED -- {canonical
-    // k-mer, contig, the (tile, wave) slot its koverCpy term belongs to, "an even-k palindrome: both counts twice"} -- instead of
-    // being scanned for by its lane while 63 others wait.  The whole wave calls; the lanes that want are given consecutive entries
+    // k-mer, aux, the (tile, wave) slot its koverCpy term belongs to, mode, "an even-k palindrome: both counts twice"} -- instead of
+    // being scanned for by its lane while 63 others wait.  mode 0: aux = its home line; 1 (deep): ... and that line and the next are
+    // known to be full of other k-mers; 2 (saturated): aux = the low word of its slot, only the side table is left to read.  The whole wave calls; the lanes that want are given consecutive entries
     // of this BLOCK's segment of the list (one LDS atomic per call); false: no list (a.wl == nullptr) or no room left in the segment,
     // the lane then scans.  kasm is counted here either way.
-    auto push_wave = [&](bool want, uint64_t kmer, bool dbl) -> bool {
+    auto push_wave = [&](bool want, uint64_t kmer, uint32_t aux, uint32_t mode, bool dbl) -> bool {
       if (!a.wl) return false;                                     // (kernel-uniform)
       const uint64_t m = __ballot(want);
       if (!m) return false;
@@ -2318,7 +2340,7 @@ __global__ __launch_bounds__(MFX_BLOCK, (mfx_hist_tune<CANON, COMPACT, KF>::bloc
       const uint32_t at = base + (uint32_t)__popcll(m & ((1ULL << ln) - 1ULL));
       const bool fits = want && at < a.wl_segcap;
       if (fits) reinterpret_cast<uint4 *>(a.wl + MFX_WL_HEADER)[(uint64_t)blockIdx.x * a.wl_segcap + at] =
-                  make_uint4((uint32_t)kmer, (uint32_t)(kmer >> 32), c, ((uint32_t)li * (MFX_BLOCK / 64) + (tid >> 6)) | (dbl ? 0x80000000u : 0u));
+                  make_uint4((uint32_t)kmer, (uint32_t)(kmer >> 32), aux, ((uint32_t)li * (MFX_BLOCK / 64) + (tid >> 6)) | (dbl ? 0x80000000u : 0u) | (mode << 29));
       return fits;
     };
     uint32_t nq = 0;                         // queries parked in this wave's mailbox (wave-uniform)
@@ -2326,14 +2348,14 @@ __global__ __launch_bounds__(MFX_BLOCK, (mfx_hist_tune<CANON, COMPACT, KF>::bloc
     for (uint32_t b = 0;; b += BT) {
       const bool last = b >= MFX_TILE / MFX_BLOCK || b * MFX_BLOCK >= n;    // (short last tile of a contig, block-uniform: nothing starts beyond n)
       nq = (uint32_t)__builtin_amdgcn_readfirstlane((int)nq);
-      if (defer_tail && (last || nq >= MFX_DEFER_FLUSH)) {
+      if (defer_tail && (last || nq >= (MFX_DEFER_FLUSH < mb_cap ? MFX_DEFER_FLUSH : mb_cap / 2u))) {
         auto kmer_at = [&](uint32_t p) -> uint64_t {
           uint64_t f;
           (void)mfx_tile_kmer(L, k, p, f);
           const uint64_t r = mfx_revcomp(f, k);
           return f < r ? f : r;
         };
-        mfx_lane_flush(a.t, MB, nq, kmer_at, eval1, [&](bool want, uint64_t km) { return push_wave(want, km, false); }, DBG ? reinterpret_cast<unsigned long long *>(a.dbg) : nullptr);
+        mfx_lane_flush(a.t, MB, nq, kmer_at, eval1, [&](bool want, uint64_t km, uint32_t aux, uint32_t mode) { return push_wave(want, km, aux, mode, false); }, DBG ? reinterpret_cast<unsigned long long *>(a.dbg) : nullptr);
       }
       if (last) break;
       uint32_t rv[BT], av[BT];
@@ -2374,12 +2396,12 @@ __global__ __launch_bounds__(MFX_BLOCK, (mfx_hist_tune<CANON, COMPACT, KF>::bloc
           uint32_t posn[BT];
 #pragma unroll
           for (int j = 0; j < BT; ++j) posn[j] = (b + (uint32_t)j) * MFX_BLOCK + tid;
-          auto pj = [&](int jj, bool want, uint64_t km) { (void)jj; return push_wave(want, km, false); };     // (odd k: no palindromes)
-          parked = mfx_lane_probe_defer<BT>(a.t, MB, nq, fkey, ok, rv, av, line, b0, posn, keyof, DBG ? reinterpret_cast<unsigned long long *>(a.dbg) : nullptr,
-                                            mfx_push_fn<decltype(pj)>{pj});
+          auto pj = [&](int jj, bool want, uint64_t km, uint32_t aux, uint32_t mode) { (void)jj; return push_wave(want, km, aux, mode, false); };     // (odd k: no palindromes)
+          parked = mfx_lane_probe_defer<BT, decltype(keyof), mfx_push_fn<decltype(pj)>, mb_cap>(
+                       a.t, MB, nq, fkey, ok, rv, av, line, b0, posn, keyof, DBG ? reinterpret_cast<unsigned long long *>(a.dbg) : nullptr, mfx_push_fn<decltype(pj)>{pj});
         } else {
-          auto pj = [&](int jj, bool want, uint64_t km) { return push_wave(want, km, ((pal >> jj) & 1u) != 0u); };
-          parked = mfx_lane_lookup8<BT, decltype(keyof), mfx_push_fn<decltype(pj)>, (kfx_lds ? MFX_KFX_BASE : 64u)>(
+          auto pj = [&](int jj, bool want, uint64_t km, uint32_t aux, uint32_t mode) { return push_wave(want, km, aux, mode, ((pal >> jj) & 1u) != 0u); };
+          parked = mfx_lane_lookup8<BT, decltype(keyof), mfx_push_fn<decltype(pj)>, mb_cap>(
                        a.t, MB, fkey, ok, rv, av, line, b0, keyof, DBG ? reinterpret_cast<unsigned long long *>(a.dbg) : nullptr, mfx_push_fn<decltype(pj)>{pj});
         }
         if (even_k) {
@@ -2442,7 +2464,7 @@ __global__ __launch_bounds__(MFX_BLOCK, (mfx_hist_tune<CANON, COMPACT, KF>::bloc
   {
     uint64_t x = n_valid, y = n_missing, z = n_over0;
     mfx_block_sum3(x, y, z, H.red);
-    if (tid == 0 && a.wl && H.wl_n) a.wl[2 + blockIdx.x] = H.wl_n < a.wl_segcap ? H.wl_n : a.wl_segcap;      // this block's segment of the worklist (mfx_hist_rest_kernel)
+    if (tid == 0 && a.wl) a.wl[2 + blockIdx.x] = H.wl_n < a.wl_segcap ? H.wl_n : a.wl_segcap;      // this block's segment of the worklist, written by every block of every launch (mfx_hist_rest_kernel)
     if (tid == 0) {
       if (c != none && (x | y)) {
         atomicAdd((unsigned long long *)&c_kasm[c], x);
@@ -2465,8 +2487,9 @@ __global__ __launch_bounds__(MFX_BLOCK, (mfx_hist_tune<CANON, COMPACT, KF>::bloc
 // the main kernel alone would have produced, bit for bit, whatever was listed.  kasm was counted where the position was seen.
 // Launched behind every launch of the main kernel on the same stream.  The list is cut into one segment per block of the main kernel
 // (a block appends to its own segment through a counter in LDS: one shared counter would be a single-address atomic per listed wave,
-// ~90 M/s -- 80 ms of a launch that lists 7 M of them); block b here takes the segments b, b + gridDim.x, ... and empties them.
+// ~90 M/s -- 80 ms of a launch that lists 7 M of them) and writes its count when it ends; MFX_REST_SPLIT blocks here share a segment.
 // ---------------------------------------------------------------------------
+constexpr uint32_t MFX_REST_SPLIT = 4;
 __global__ __launch_bounds__(MFX_BLOCK) void mfx_hist_rest_kernel(mfx_hist_args a) {
   __shared__ mfx_hist_lds H;
   const uint32_t tid = threadIdx.x;
@@ -2475,37 +2498,55 @@ __global__ __launch_bounds__(MFX_BLOCK) void mfx_hist_rest_kernel(mfx_hist_args 
   uint64_t *kfx_words = reinterpret_cast<uint64_t *>(a.tile_partials);
   uint32_t n_missing = 0, n_over0 = 0;
   bool ready = false, lut_ok = false;                          // the K* tables of this block are made when it meets its first entry
-  for (uint32_t seg = blockIdx.x; seg < a.wl_segs; seg += gridDim.x) {
+  // MFX_REST_SPLIT blocks share a segment (block b: segment b / SPLIT, every SPLIT-th group of 256 entries from b % SPLIT on)
+  for (uint32_t sb = blockIdx.x; sb < a.wl_segs * MFX_REST_SPLIT; sb += gridDim.x) {
+    const uint32_t seg = sb / MFX_REST_SPLIT, part = sb % MFX_REST_SPLIT;
     const uint32_t n = (uint32_t)__hip_atomic_load(reinterpret_cast<unsigned long long *>(&a.wl[2 + seg]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (n == 0u) continue;                                     // block-uniform
+    if (n <= part * MFX_BLOCK) continue;                       // block-uniform
     if (!ready) { mfx_hist_lds_init(H, ka); lut_ok = H.lut_ok != 0u; ready = true; }
     const uint4 *ent = reinterpret_cast<const uint4 *>(a.wl + MFX_WL_HEADER) + (uint64_t)seg * a.wl_segcap;
-    for (uint32_t i0 = 0; i0 < n; i0 += MFX_BLOCK) {           // block-uniform trip count
+    for (uint32_t i0 = part * MFX_BLOCK; i0 < n; i0 += MFX_REST_SPLIT * MFX_BLOCK) {           // block-uniform trip count
       const uint32_t i = i0 + tid;
       const bool live = i < n;
       uint4 e = make_uint4(0u, 0u, 0u, 0u);
       if (live) e = ent[i];
       bool missing = false;
       if (live) {
-        uint2 x = mfx_c_lookup(a.t, ((uint64_t)e.y << 32) | e.x);
+        const uint64_t km = ((uint64_t)e.y << 32) | e.x;
+        uint2 x = make_uint2(0u, 0u);
+        const uint32_t mode = (e.w >> 29) & 3u;
+        if (mode == 2u) x = mfx_c_fields(a.t, km, e.z);         // the slot's low word is known: the exact counts of its saturated fields (side table), the read filter
+        else if (!a.t.quot) {                                    // k <= 21: the key field is the k-mer, the entry has its home line -- no placement to find again
+          mfx_probe pr;
+          pr.lineA = e.z; pr.lineB = a.t.mz_w > 0 ? mfx_range32(mfx_hash64(km), a.t.nlines) : e.z; pr.b0 = 0u; pr.fkey = km;
+          unsigned long long word = 0;
+          bool beyond;
+          // deep: its home line and the next are known to be full of other k-mers: from candidate line 2 on
+          if (mfx_c_find(a.t, pr, mode == 1u ? 2u : 0u, word, beyond)) x = mfx_c_fields(a.t, km, (uint32_t)word);
+        } else x = mfx_c_lookup(a.t, km);
         if (e.w >> 31) { x.x += x.x; x.y += x.y; }             // an even-k palindrome: value(fmer) + value(rmer) is the same slot twice (mfx_hist_kernel)
         uint64_t kfx = 0;
         missing = mfx_hist_eval_fx(H, ka, lut_ok, x.x, x.y, n_over0, kfx);
-        if (kfx) atomicAdd(reinterpret_cast<unsigned long long *>(&kfx_words[e.w & 0x7fffffffu]), (unsigned long long)kfx);
+        if (kfx) atomicAdd(reinterpret_cast<unsigned long long *>(&kfx_words[e.w & 0x1fffffffu]), (unsigned long long)kfx);
+      }
+      uint32_t ctg = 0u;                                         // the entry's contig, from its tile (the slot is (tile of the launch) * 4 + wave)
+      if (missing) {
+        const uint64_t li = (e.w & 0x1fffffffu) / (MFX_BLOCK / 64);
+        const uint64_t tile = a.part_n == 1 ? a.tile_begin + li
+                                             : ((((li >> a.part_shift) * a.part_n + a.part_rank) << a.part_shift) | (li & ((1ull << a.part_shift) - 1ull)));
+        ctg = a.tile_contig[tile];
       }
       // the missing k-mers of a contig: the lanes of a wave that hold the same contig add together (a list runs along the sequence)
       uint64_t todo = __ballot(missing);
       while (todo) {
         const int leader = __ffsll((unsigned long long)todo) - 1;
-        const uint32_t lc = (uint32_t)__shfl((int)e.z, leader, 64);
-        const uint64_t same = __ballot(missing && e.z == lc) & todo;
+        const uint32_t lc = (uint32_t)__shfl((int)ctg, leader, 64);
+        const uint64_t same = __ballot(missing && ctg == lc) & todo;
         if ((int)(tid & 63u) == leader) atomicAdd(reinterpret_cast<unsigned long long *>(&c_kmis[lc]), (unsigned long long)__popcll(same));
         todo &= ~same;
       }
       if (missing) n_missing++;
     }
-    __syncthreads();
-    if (tid == 0) a.wl[2 + seg] = 0;                           // the segment is empty again for the next launch
   }
   if (!ready) return;                                          // (block-uniform)
   {

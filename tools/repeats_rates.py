@@ -61,7 +61,7 @@ def main():
             ev.hist_launch(seqs, 0, seqs.ntiles, counts, kover, stream=stream)
             torch.cuda.synchronize()
             dc = ev.debug_counters()
-            dbg = [dc["first_pass"], dc["second_pass"], dc["side_table"], dc["line_scans"]]
+            dbg = [dc["first_pass"], dc["second_pass"], dc["side_table"], dc["line_scans"], dc.get("side_not_in_two_slots", 0), dc.get("ended_per_lane", 0)]
             ev.debug(False)
         except Exception as e:
             print("debug counters: %r" % (e,), file=sys.stderr)
