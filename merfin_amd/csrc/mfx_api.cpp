@@ -1777,7 +1777,6 @@ static int ensure_tile_partials(mfx_eval *ev, uint64_t ntiles) {
   const uint64_t need = mfx_k_tile_partials_words(ntiles);
   if (need > ev->tile_partials_cap) {
     if (ev->d_tile_partials) (void)hipFree(ev->d_tile_partials);
-  for (auto &w : ev->d_wl) if (w) (void)hipFree(w);
     ev->d_tile_partials = nullptr;
     ev->tile_partials_cap = 0;
     MFX_HIP(hipMalloc((void **)&ev->d_tile_partials, need * sizeof(double)));
@@ -1873,7 +1872,8 @@ static int hist_launch(mfx_eval *ev, const mfx_seq *seq, uint64_t tile_begin, ui
   a.ks.ovf = ev->d_ovf;
   a.dbg = ev->d_dbg;
   if (a.t.compact && canon && ntl < (1ull << 27)) {          // the probe's rare endings are listed and ended by mfx_hist_rest_kernel (mfx_kernels.hip)
-    rc = ensure_worklist(ev, ctr_slot, ntl);
+    // (a streamed run's chunks grow to 128 MB of bases: its lists are made for that size at its first chunk, not re-made as they grow)
+    rc = ensure_worklist(ev, ctr_slot, chunk_of_total ? std::max<uint64_t>(ntl, std::min<uint64_t>(chunk_of_total, (128ull << 20) / MFX_TILE)) : ntl);
     if (rc) return rc;
     const uint64_t segs = std::min<uint64_t>((uint64_t)ev->grid, ntl);     // the main kernel's grid: one segment per block
     if (ev->d_wl[ctr_slot] && segs <= MFX_WL_HEADER - 2) {

@@ -33,8 +33,8 @@ def _cores():
     return n
 
 
-@pytest.fixture(scope="module")
-def sample():
+@pytest.fixture(scope="module", params=[0, 3], ids=["iid_world", "repeats_world_3pct"])
+def sample(request):
     torch = pytest.importorskip("torch")
     import gc
     import merfin_amd as m
@@ -43,7 +43,10 @@ def sample():
     gc.collect()
     torch.cuda.empty_cache()
     # the FULL databases (every read k-mer, as merylExactLookup::load holds them) are what the oracle looks up in
-    ix, seqs, asm, info = st.build_world(m, BASES, k=K, lam=LAM, ncontigs=8, seed=st.SEED + 1)
+    # params: SURVEY 8(d)'s i.i.d. genome, and the `repeats` world at its 3 % level (tools/synth_torch.py: inject_repeats -- Alu-like
+    # families, satellite arrays, an exact 5-mer tandem array, rDNA-like arrays: several percent of the positions carry read counts beyond
+    # the compact slot's 11-bit fields and repeat-family buckets overflow two lines: the worklist of mfx_hist_rest_kernel is busy)
+    ix, seqs, asm, info = st.build_world(m, BASES, k=K, lam=LAM, ncontigs=8, seed=st.SEED + 1, repeats=request.param)
     ek, er, ea = ix.export()
     ix.close()
     del ix
@@ -56,7 +59,7 @@ def sample():
     del R, A
     read = (ek[er > 0], er[er > 0])
     del ek, er, ea
-    yield m, torch, seqs, asm, contigs, read, (probK, probP), (g, ka, km)
+    yield m, torch, seqs, asm, contigs, read, (probK, probP), (g, ka, km), request.param
     del seqs, asm
     gc.collect()
     torch.cuda.empty_cache()
@@ -73,7 +76,7 @@ def _seq_index(m, seqs, read, bases):
 
 @pytest.mark.parametrize("load_factor", [None, "0.5"])
 def test_bench_path_equals_the_oracle_where_every_probe_ending_occurs(sample, load_factor, monkeypatch):
-    m, torch, seqs, asm, contigs, read, (probK, probP), (g, ka, km) = sample
+    m, torch, seqs, asm, contigs, read, (probK, probP), (g, ka, km), repeats = sample
     trim = lambda a: np.trim_zeros(np.asarray(a), "b")
 
     def assert_hist_equal(res, g, ka, km, k):
@@ -107,6 +110,9 @@ def test_bench_path_equals_the_oracle_where_every_probe_ending_occurs(sample, lo
     scale = BASES / 256e6
     assert c["first_pass"] > 2e6 * scale, c                    # ~3 % of the k-mers are not in their first mini-bucket
     assert c["side_table"] > 1e5 * scale, c                    # the tandem repeats' saturated read counts
+    if repeats:
+        assert c["side_table"] > 0.01 * g.kasm, c              # percent of the positions, not a handful
+        assert c["line_scans"] > 1e4 * scale, c                # repeat-family buckets beyond two lines: listed for mfx_hist_rest_kernel
     if load_factor:
         assert c["second_pass"] > 1e5 * scale, c               # home lines full of other k-mers
     assert c["second_pass"] > 0, c

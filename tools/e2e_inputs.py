@@ -63,6 +63,8 @@ def write_inputs(m, st, torch, bases, outdir, ncontigs=24, k=21, lam=26.0, seed=
     rk, rv = sorted_nonzero(torch, ek, er, k)
     readdb = os.path.join(outdir, "read.mfxk")
     m.db_write_flat(readdb, k, rk, rv)
+    text_sample = os.path.join(outdir, "text_sample.npz")      # the first k-mers of the database, for text_convert_sample
+    np.savez(text_sample, km=rk[:20_000_000], rv=rv[:20_000_000])
     placeddb = None
     if placed:                                                 # the same database in the PLACED form (what `merfin -convert -placed` makes), next to it
         del rk, rv
@@ -86,7 +88,7 @@ def write_inputs(m, st, torch, bases, outdir, ncontigs=24, k=21, lam=26.0, seed=
             if rows * 80 < len(a):
                 f.write(a[rows * 80:].tobytes() + b"\n")
             del out_
-    return {"fasta": fasta, "readdb": readdb, "placeddb": placeddb, "placed_db_bytes": os.path.getsize(placeddb) if placeddb else None, "read_kmers": n_read, "db_bytes": os.path.getsize(readdb), "fasta_bytes": os.path.getsize(fasta),
+    return {"fasta": fasta, "readdb": readdb, "text_sample": text_sample, "placeddb": placeddb, "placed_db_bytes": os.path.getsize(placeddb) if placeddb else None, "read_kmers": n_read, "db_bytes": os.path.getsize(readdb), "fasta_bytes": os.path.getsize(fasta),
             "lens": [len(a) for a in contigs], "write_s": time.time() - t0}
 
 
@@ -112,3 +114,42 @@ def run_cli_hist(root, inp, peak=26.0, prob=None, out_hist=None, env=None):
                     except ValueError:
                         pass
     return r.returncode, wall, phases, r.stderr
+
+
+def text_convert_sample(root, m, inp, outdir, k, n_lines=20_000_000):
+    """What a user who starts from `meryl print` TEXT pays once: the first n_lines k-mers of the read database written as text
+    (<kmer>\t<count>), converted by `merfin -convert` (host only), timed; the full database's conversion is extrapolated from the rate."""
+    import subprocess
+    import numpy as np
+    if not inp.get("text_sample") or not os.path.exists(inp["text_sample"]):
+        return None
+    z = np.load(inp["text_sample"])
+    km, rv = z["km"][:n_lines].astype(np.uint64), z["rv"][:n_lines]
+    n = len(km)
+    if n == 0:
+        return None
+    rows = np.empty((n, k + 7), dtype=np.uint8)
+    lut = np.frombuffer(b"ACTG", dtype=np.uint8)
+    for i in range(k):
+        rows[:, i] = lut[((km >> np.uint64(2 * (k - 1 - i))) & np.uint64(3)).astype(np.intp)]
+    v = np.minimum(rv, 99999).astype(np.int64)
+    rows[:, k] = 9
+    for d in range(5):
+        rows[:, k + 1 + d] = 48 + (v // 10 ** (4 - d)) % 10
+    rows[:, k + 6] = 10
+    txt = os.path.join(outdir, "sample.txt")
+    rows.tofile(txt)
+    del rows
+    exe = os.path.join(root, "merfin_amd", "bin", "merfin")
+    t = time.time()
+    r = subprocess.run([exe, "-convert", txt, "-output", os.path.join(outdir, "sample.mfxk")], stdin=subprocess.DEVNULL, capture_output=True, text=True)
+    dt = time.time() - t
+    size = os.path.getsize(txt)
+    os.unlink(txt)
+    if r.returncode != 0:
+        raise RuntimeError("merfin -convert failed: " + r.stderr[-300:])
+    rate = n / dt
+    return {"text_kmers": n, "text_bytes": size, "convert_s": dt, "convert_kmers_per_s": rate,
+            "convert_s_full_db_extrapolated": inp["read_kmers"] / rate,
+            "note": "`merfin -convert` of a %d-line `meryl print`-style text sample of the same database (host only: parse, sort check, delta-code); the full database's "
+                    "conversion time is this rate times its k-mers -- paid once per database, not per run" % n}
