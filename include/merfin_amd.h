@@ -348,6 +348,14 @@ int      mfx_hist_run_streamed_multi(mfx_eval *const *evs, mfx_seq *const *seqs,
 int      mfx_hist_run_streamed_range(mfx_eval *ev, mfx_seq *seq, const char *const *bases, uint64_t tile_begin, uint64_t tile_end,
                                      uint64_t *d_counts, double *d_kover);
 int      mfx_hist_stream_share(uint64_t ntiles, uint32_t rank, uint32_t nranks, uint64_t *tile_begin, uint64_t *tile_end);
+/* How the bases of a streamed run cross the link is chosen per call (mfx_hist_run_streamed / _multi / _range) from two measured rates: what
+ * the host threads the call has ENCODE, and what the device's LINK moves from pinned memory.  While the encoders are the faster the bases
+ * cross packed (above); when they are not -- a rank of N processes has 1/N of the host's cores and a link of its own -- pinned sources cross as
+ * plain bytes by DMA, no host thread touches them, and the planes are made on the device (mfx_pack_kernel); the evaluation is the same
+ * launches over the same planes, the result the same bit for bit.  MFX_STREAM_TRANSPORT=pack | ascii forces either.
+ * mfx_diag_stream_rates measures the two rates on demand (nothing cached): `threads` host threads encoding n bases of `src` at once, and --
+ * src pinned -- up to 256 MB of it over `device`'s link; 0 for a rate that could not be measured. */
+int      mfx_diag_stream_rates(int device, const char *src, uint64_t n, uint32_t threads, double *enc_gbs, double *link_gbs);
 /* The host-side encoder of that transport (AVX-512 / AVX2 / scalar, chosen at run time; ~28 GB/s per core of an EPYC
  * 9575F): n bases -> ceil(n/32) words.  codes[w] holds bases 32w..32w+31, the first in the two HIGHEST bits,
  * code = (c >> 1) & 3 (A 0, C 1, T 2, G 3, either case); valid[w] holds one bit per base, the first in the highest

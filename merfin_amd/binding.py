@@ -78,7 +78,7 @@ SYMBOLS = [
     "mfx_diag_gather_rate",
     "mfx_eval_create", "mfx_eval_free", "mfx_eval_nbins", "mfx_eval_debug_enable", "mfx_eval_debug_counters", "mfx_getK", "mfx_getKmetric", "mfx_histoQV",
     "mfx_hist_run", "mfx_hist_result_free", "mfx_hist_launch", "mfx_hist_launch_cyclic", "mfx_hist_result_from_counts",
-    "mfx_hist_take_overflow", "mfx_hist_report",
+    "mfx_hist_take_overflow", "mfx_hist_report", "mfx_diag_stream_rates",
     "mfx_pack_bases", "mfx_host_threads_share", "mfx_dump_values", "mfx_dump_contig", "mfx_dump_values_sharded", "mfx_dump_contig_sharded", "mfx_variants_run_sharded", "mfx_vcf_load", "mfx_vcf_free", "mfx_variants_run_vcf", "mfx_vcf_prepare", "mfx_completeness", "mfx_completeness_pieces", "mfx_variants_run",
     "mfx_index_set_shard", "mfx_router_create", "mfx_router_free", "mfx_route_tiles", "mfx_hist_keys_launch",
 ]
@@ -194,6 +194,7 @@ def load_library():
     L.mfx_hist_launch_cyclic.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]
     L.mfx_hist_result_from_counts.argtypes = [C.c_uint32, u64p, C.c_double, C.c_uint32, C.POINTER(_HistResult)]
     L.mfx_hist_take_overflow.argtypes = [vp, u64p, C.c_uint64, u64p]
+    L.mfx_diag_stream_rates.argtypes = [C.c_int, vp, C.c_uint64, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.mfx_hist_report.argtypes = [C.POINTER(_HistResult), C.c_int, C.c_char_p, C.c_char_p]
     L.mfx_dump_values.argtypes = [vp, vp, C.c_uint32, C.c_uint64, C.c_uint64, u32p, u32p, u64p, u64p]
     L.mfx_dump_contig.argtypes = [vp, vp, C.c_uint32, C.c_char_p, C.c_char_p, C.c_int, u64p, u64p]
@@ -944,6 +945,15 @@ def hist_parts(evaluators, sequences, contig_ids, ncontigs_total):
     r = HistResult()
     _check(load_library().mfx_hist_run_parts(evs, sqs, idp, n, int(ncontigs_total), C.byref(r.c)))
     return r
+
+
+def stream_rates(src, threads, device=0):
+    """(GB/s `threads` host threads encode `src` -- a PinnedBuffer view or any contiguous uint8 array -- at, GB/s the device's link moves it at: 0 when
+    src is not pinned): the two rates a streamed run's transport is chosen from (mfx_diag_stream_rates)"""
+    a = np.ascontiguousarray(src)
+    enc, link = C.c_double(0), C.c_double(0)
+    _check(load_library().mfx_diag_stream_rates(device, C.c_void_p(a.ctypes.data), a.nbytes, threads, C.byref(enc), C.byref(link)))
+    return enc.value, link.value
 
 
 def gather_rate(table_bytes, device=0):

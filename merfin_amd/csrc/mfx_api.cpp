@@ -2265,6 +2265,62 @@ static bool pack_cpus(int mode, int node, const cpu_set_t *near, unsigned w, cpu
 // base never reaches the device (seq->bases_stale; unpacked on demand by mfx_seq_ensure_ascii).
 // part != nullptr: only the tiles [part->tl, part->th) are encoded, uploaded and evaluated (one device's share of a run over several:
 // mfx_hist_run_streamed_multi / mfx_hist_run_streamed_range); the sequence object then holds that part only (mfx_seq::partial).
+// The two rates that decide how a streamed run's bases cross the link (hist_run_streamed_packed): what W host threads ENCODE (GB of
+// bases per second, all of them at once: they share the memory system) and what the device's LINK moves from pinned host memory.
+// Measured once per process and (W | device) on the caller's own buffers -- every thread encodes 4 MB of the first contig into a scratch of
+// its own, 32 MB of it are copied to the device buffer they go to anyway -- ~1.5 ms together; MFX_STREAM_ENC_GBS / MFX_STREAM_LINK_GBS override.
+static double stream_encode_gbs(WorkerPool *pool, unsigned W, const uint8_t *src, uint64_t n) {
+  static std::mutex mu;
+  static std::map<unsigned, double> cache;
+  if (const char *e = getenv("MFX_STREAM_ENC_GBS")) if (atof(e) > 0) return atof(e);
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(W);
+    if (it != cache.end()) return it->second;
+  }
+  const uint64_t per = std::min<uint64_t>(4u << 20, n / std::max(1u, W) / 32 * 32);
+  if (!pool || per < (1u << 16)) return 0.0;                  // too little to measure: no estimate
+  std::vector<std::vector<uint64_t>> sc(W);
+  for (auto &v : sc) v.resize(per / 32 + per / 64 + 2);
+  auto run = [&](unsigned w) {
+    uint64_t *codes = sc[w].data();
+    mfx_pack_bases(src + (uint64_t)w * per, per, codes, reinterpret_cast<uint32_t *>(codes + per / 32 + 1));
+  };
+  pool->start(run); pool->wait();                              // (first touch of the scratch)
+  const auto t0 = std::chrono::steady_clock::now();
+  pool->start(run); pool->wait();
+  const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  const double gbs = dt > 0 ? (double)per * W / dt / 1e9 : 0.0;
+  std::lock_guard<std::mutex> lk(mu);
+  cache[W] = gbs;
+  return gbs;
+}
+static double stream_link_gbs(int device, uint8_t *d_dst, const uint8_t *pinned_src, uint64_t n, hipStream_t st) {
+  static std::mutex mu;
+  static std::map<int, double> cache;
+  if (const char *e = getenv("MFX_STREAM_LINK_GBS")) if (atof(e) > 0) return atof(e);
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(device);
+    if (it != cache.end()) return it->second;
+  }
+  const uint64_t m = std::min<uint64_t>(32u << 20, n);
+  if (m < (4u << 20)) return 0.0;
+  hipEvent_t a = nullptr, b = nullptr;
+  double gbs = 0.0;
+  if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess &&
+      hipMemcpyAsync(d_dst, pinned_src, 1u << 20, hipMemcpyHostToDevice, st) == hipSuccess &&          // (wakes the link up)
+      hipEventRecord(a, st) == hipSuccess && hipMemcpyAsync(d_dst, pinned_src, m, hipMemcpyHostToDevice, st) == hipSuccess &&
+      hipEventRecord(b, st) == hipSuccess && hipEventSynchronize(b) == hipSuccess) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, a, b) == hipSuccess && ms > 0) gbs = (double)m / (ms * 1e-3) / 1e9;
+  } else (void)hipGetLastError();
+  if (a) (void)hipEventDestroy(a);
+  if (b) (void)hipEventDestroy(b);
+  if (gbs > 0) { std::lock_guard<std::mutex> lk(mu); cache[device] = gbs; }
+  return gbs;
+}
+
 struct StreamPart {
   uint64_t tl = 0, th = 0;
   uint64_t *d_counts = nullptr;          // caller's device image / koverCpy to accumulate into (cleared by the caller); null: the evaluator's own, returned on the host
@@ -2389,6 +2445,30 @@ static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *cons
   if (ev->pool && static_cast<WorkerPool *>(ev->pool)->W != W) { delete static_cast<WorkerPool *>(ev->pool); ev->pool = nullptr; }
   if (!ev->pool) ev->pool = new WorkerPool(W);
   uint8_t *const *stage = ev->h_pack;
+  // TRANSPORT.  Host-packed (0.25-0.375 bytes per base over the link, the encoders' work in front of it) is the faster way while the
+  // host threads THIS call has encode faster than its link moves plain bytes -- one process with the host's cores to itself: 150-190 GB/s
+  // against 56.  A rank of N processes has 1/N of the cores but a link of its own: from N = 4 on (16-core quota) its threads are slower than
+  // its link, and the run of the whole node is bound by the host's encoders whatever N.  Then the bases cross as they
+  // are -- DMA straight out of the caller's pinned buffers, no host thread touches them -- and mfx_pack_kernel makes the planes on the
+  // device (3 GB of bytes: 1.5 ms of its HBM); the evaluation is the same launches over the same planes, bit for bit.  Pinned sources
+  // only (pageable ones would need a host copy as dear as the encoding).  MFX_STREAM_TRANSPORT=pack | ascii forces either.
+  bool link_ascii = false;
+  {
+    bool all_pinned = seq->ncontigs > 0;
+    for (uint32_t c = 0; c < seq->ncontigs && all_pinned; ++c) all_pinned = seq->len[c] == 0 || host_ptr_is_pinned(bases[c]);
+    const char *tp = getenv("MFX_STREAM_TRANSPORT");
+    if (tp && !strcmp(tp, "ascii")) link_ascii = all_pinned;
+    else if (tp && !strcmp(tp, "pack")) link_ascii = false;
+    else if (all_pinned && seq->ncontigs && seq->len[0] >= (32u << 20)) {
+      if (int brc = seq_need_bases(seq)) return brc;
+      if (!R.copy) MFX_HIP(hipStreamCreateWithFlags(&R.copy, hipStreamNonBlocking));
+      const double enc = stream_encode_gbs(static_cast<WorkerPool *>(ev->pool), W, reinterpret_cast<const uint8_t *>(bases[0]), seq->len[0]);
+      const double link = stream_link_gbs(ev->device, seq->d_bases, reinterpret_cast<const uint8_t *>(bases[0]), seq->len[0], R.copy);
+      link_ascii = enc > 0 && link > 0 && enc < link;
+      if (timing) fprintf(stderr, "[mfx stream] transport: %u host threads encode %.1f GB/s, the link moves %.1f GB/s -> %s\n", W, enc, link, link_ascii ? "plain bytes + device-side packing" : "host-packed planes");
+    }
+    if (link_ascii) if (int brc = seq_need_bases(seq)) return brc;
+  }
   cpu_set_t near_cpus;
   int src_node = -1;
   const bool bind = seq->ncontigs && bases[0] && cpus_near(bases[0], &near_cpus, &src_node);      // the encoders run next to the memory they read
@@ -2396,6 +2476,7 @@ static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *cons
   if (const char *pp = getenv("MFX_PACK_PLACE")) place = !strcmp(pp, "os") ? 0 : !strcmp(pp, "node") ? 1 : !strcmp(pp, "all") ? 3 : 2;
   if (const char *nb = getenv("MFX_NUMA_BIND")) if (atoi(nb) == 0) place = 0;
   auto work = [&, W](unsigned w) {
+    if (link_ascii) return;                                      // the bases cross the link as they are
     cpu_set_t mine;
     if (pack_cpus(place, src_node, bind ? &near_cpus : nullptr, w, &mine)) (void)pthread_setaffinity_np(pthread_self(), sizeof(mine), &mine);
     for (size_t ci = 0; ci < chunks.size(); ++ci) {
@@ -2482,9 +2563,16 @@ static int hist_run_streamed_packed(mfx_eval *ev, mfx_seq *seq, const char *cons
       allowed.store((int64_t)(ci - 1 + NB), std::memory_order_release);
     }
     if (timing >= 2) ct[ci].wait_buf = now();
-    while (done[ci].load(std::memory_order_acquire) < W) std::this_thread::yield();
+    if (!link_ascii) while (done[ci].load(std::memory_order_acquire) < W) std::this_thread::yield();
     if (timing >= 2) { ct[ci].enq = now(); (void)hipEventRecord(ct[ci].c0, cs); }
-    if (c.hi > c.lo) {
+    if (link_ascii && c.hi > c.lo) {
+      // the chunk's pieces by DMA out of the caller's pinned buffers (the gaps between contigs stay the buffer's zero bytes), then the
+      // planes of its words on the device, behind the copies on the same stream; a word shared with the chunk before is rewritten with
+      // the value it has (that chunk's kernel may still read it)
+      for (const Piece &pc : c.pieces)
+        STREAMED_HIP(hipMemcpyAsync(seq->d_bases + seq->off[pc.contig] + pc.pos, bases[pc.contig] + pc.pos, pc.n, hipMemcpyHostToDevice, cs));
+      STREAMED_HIP(mfx_k_pack(seq->d_bases + c.lo, seq->d_codes + c.lo / 32, seq->d_valid + c.lo / 32, (c.hi - c.lo) / 32, cs));
+    } else if (c.hi > c.lo) {
       const uint64_t nw = (c.hi - c.lo) / 32;
       STREAMED_HIP(hipMemcpyAsync(seq->d_codes + c.lo / 32, stage[b], nw * 8, hipMemcpyHostToDevice, cs));
       // the sparse form pays (8 bytes per listed word against 4 per word sent whole) only while fewer than half of the chunk's
@@ -2690,6 +2778,54 @@ static int seq_upload_packed(mfx_seq *seq, const char *const *bases) {
     fprintf(stderr, "-- packed upload: chunk plan %.3f s, planes %.3f, pinned staging + stream %.3f, encode + copy %.3f (%u threads, %zu chunks), release %.3f\n",
             tm[1] - tm[0], tm[2] - tm[1], tm[3] - tm[2], tm[4] - tm[3], W, chunks.size(), now() - tm[4]);
   return ok ? MFX_OK : mfx_fail(MFX_E_HIP, "packed upload of the sequence failed: %s", hipGetErrorString(hipGetLastError()));
+}
+
+// The two rates of the transport decision, measured on demand (bench.py's model of SURVEY 8(d)'s metric at N GPUs: a rank of N has
+// host_threads / N encoders and a link of its own): `threads` host threads encoding `src` (pinned or not) at once, and -- src pinned --
+// 32 MB of it over this device's link.  Nothing is cached.
+extern "C" int mfx_diag_stream_rates(int device, const char *src, uint64_t n, uint32_t threads, double *enc_gbs, double *link_gbs) {
+  if (!src || !enc_gbs || !link_gbs || threads == 0 || threads > 256) return mfx_fail(MFX_E_INVAL, "mfx_diag_stream_rates: bad argument");
+  if (device < 0 || device >= mfx_device_count()) return mfx_fail(MFX_E_NODEVICE, "mfx_diag_stream_rates: device %d of %d", device, mfx_device_count());
+  *enc_gbs = *link_gbs = 0.0;
+  {
+    WorkerPool pool(threads);
+    const uint64_t per = std::min<uint64_t>(16u << 20, n / threads / 32 * 32);
+    if (per >= (1u << 16)) {
+      std::vector<std::vector<uint64_t>> sc(threads);
+      for (auto &v : sc) v.resize(per / 32 + per / 64 + 2);
+      auto run = [&](unsigned w) { mfx_pack_bases(reinterpret_cast<const uint8_t *>(src) + (uint64_t)w * per, per, sc[w].data(), reinterpret_cast<uint32_t *>(sc[w].data() + per / 32 + 1)); };
+      pool.start(run); pool.wait();
+      double best = 0;
+      for (int rep = 0; rep < 3; ++rep) {
+        const auto t0 = std::chrono::steady_clock::now();
+        pool.start(run); pool.wait();
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (dt > 0) best = std::max(best, (double)per * threads / dt / 1e9);
+      }
+      *enc_gbs = best;
+    }
+  }
+  if (host_ptr_is_pinned(src) && n >= (4u << 20)) {
+    DevGuard g(device);
+    const uint64_t m = std::min<uint64_t>(256u << 20, n);
+    uint8_t *d = nullptr;
+    hipStream_t st = nullptr;
+    hipEvent_t a = nullptr, b = nullptr;
+    if (hipMalloc((void **)&d, m) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipEventCreate(&a) == hipSuccess &&
+        hipEventCreate(&b) == hipSuccess && hipMemcpyAsync(d, src, 1u << 20, hipMemcpyHostToDevice, st) == hipSuccess) {
+      for (int rep = 0; rep < 2; ++rep) {
+        float ms = 0;
+        if (hipEventRecord(a, st) == hipSuccess && hipMemcpyAsync(d, src, m, hipMemcpyHostToDevice, st) == hipSuccess && hipEventRecord(b, st) == hipSuccess &&
+            hipEventSynchronize(b) == hipSuccess && hipEventElapsedTime(&ms, a, b) == hipSuccess && ms > 0)
+          *link_gbs = std::max(*link_gbs, (double)m / (ms * 1e-3) / 1e9);
+      }
+    } else (void)hipGetLastError();
+    if (a) (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
+    if (st) (void)hipStreamDestroy(st);
+    if (d) (void)hipFree(d);
+  }
+  return MFX_OK;
 }
 
 extern "C" int mfx_hist_run_streamed(mfx_eval *ev, mfx_seq *seq, const char *const *bases, mfx_hist_result *out) {

@@ -25,14 +25,17 @@ def _same(a, b):
     assert a.koverCpy == b.koverCpy                      # bit-identical: same values, same summation tree
 
 
-@pytest.mark.parametrize("transport", ["packed", "ascii"])
+@pytest.mark.parametrize("transport", ["packed", "ascii", "link_bytes"])
 @pytest.mark.parametrize("shape", ["few_large", "many_small", "edges"])
 def test_streamed_equals_resident_and_oracle(shape, transport, monkeypatch):
-    """transport: "packed" = the default (2-bit codes + validity bits over PCIe, the kernel reads packed tiles),
-    "ascii" = MFX_STREAM_ASCII=1 (one byte per base; what k > 31 uses)"""
+    """transport: "packed" = host-packed planes (2-bit codes + validity bits over PCIe, the kernel reads packed tiles) forced,
+    "ascii" = MFX_STREAM_ASCII=1 (one byte per base, the kernel encodes its tiles; what k > 31 uses), "link_bytes" = what a rank of
+    many takes when its share of the host's threads encodes slower than its link moves plain bytes (MFX_STREAM_TRANSPORT=ascii forces
+    it): pinned sources cross by DMA as they are and mfx_pack_kernel makes the planes on the device (pageable sources stay host-packed)"""
     import merfin_amd as m
     if transport == "ascii":
         monkeypatch.setenv("MFX_STREAM_ASCII", "1")
+    monkeypatch.setenv("MFX_STREAM_TRANSPORT", "ascii" if transport == "link_bytes" else "pack")
     k, peak = 21, 17.3
     r = synth.rng(311)
     if shape == "few_large":
@@ -136,6 +139,19 @@ def test_streamed_invalid_bases_just_behind_a_chunk_cut():
     s = m.Sequences.create(list(sizes))
     for _ in range(6):                                        # the race this guards against was a matter of timing
         _same(ev.hist_streamed(s, contigs), resident)
+    # the plain-bytes transport (pinned sources, planes made on the device) over the same cuts: a chunk's first words are the halo
+    # words the chunk before may still be reading -- rewritten with the values they have
+    pins = [m.PinnedBuffer(n) for n in sizes]
+    for pb, c in zip(pins, contigs):
+        pb.array[:] = c
+    import os
+    os.environ["MFX_STREAM_TRANSPORT"] = "ascii"
+    try:
+        s3 = m.Sequences.create(list(sizes))
+        for _ in range(4):
+            _same(ev.hist_streamed(s3, [pb.array for pb in pins]), resident)
+    finally:
+        os.environ.pop("MFX_STREAM_TRANSPORT", None)
 
 
 @pytest.fixture(scope="module")
@@ -146,13 +162,16 @@ def five_mb_world():
     return k, peak, contigs, read, asm, g, ka, km
 
 
+@pytest.mark.parametrize("transport", ["pack", "ascii", "auto"])
 @pytest.mark.parametrize("nslots", [2, 3, 8])
-def test_streamed_over_several_slots_equals_resident_bit_for_bit(nslots):
+def test_streamed_over_several_slots_equals_resident_bit_for_bit(nslots, transport, monkeypatch):
     """SURVEY 8(d)'s evaluate phase over N devices (mfx_hist_run_streamed_multi; the slots are N contexts on device 0 here, distinct
     devices in tests/test_gpu_multidevice.py): every slot uploads and evaluates only its contiguous share of the tiles; bins, counters,
     per-contig counters AND koverCpy equal the single resident launch to the last bit (shares are cut at multiples of 1024 tiles, the
     host adds the first-level sums in the device's order)."""
     import merfin_amd as m
+    if transport != "auto":
+        monkeypatch.setenv("MFX_STREAM_TRANSPORT", transport)     # both transports (auto: chosen from the measured rates), same bits
     k, peak = 21, 9.0
     r = synth.rng(331)
     sizes = (2300 * 4096 + 77, 5, 700 * 4096 + 4095, 0, 260 * 4096)      # 3263 tiles: cuts at 1024 / 2048 / 3072 for 3 slots
@@ -175,6 +194,10 @@ def test_streamed_over_several_slots_equals_resident_bit_for_bit(nslots):
     assert resident.koverCpy > 0 and 0 < resident.kmissing < resident.kasm
     evs = [m.Evaluator(ix, m.KParams(peak)) for _ in range(nslots)]
     sqs = [m.Sequences.create(list(sizes)) for _ in range(nslots)]
+    pins = [m.PinnedBuffer(n) for n in sizes]                  # pinned sources: the only ones the plain-bytes transport takes
+    for pb, c in zip(pins, contigs):
+        pb.array[:] = c
+    contigs = [pb.array for pb in pins]
     for rep in range(2):                                       # the second run re-arms every slot's buffers
         _same(m.hist_streamed_multi(evs, sqs, contigs), resident)
     # a slot's sequence object holds its part only: whole-sequence calls are refused until something is uploaded whole
