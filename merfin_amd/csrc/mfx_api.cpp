@@ -2281,12 +2281,13 @@ static double stream_encode_gbs(WorkerPool *pool, unsigned W, const uint8_t *src
   const uint64_t per = std::min<uint64_t>(4u << 20, n / std::max(1u, W) / 32 * 32);
   if (!pool || per < (1u << 16)) return 0.0;                  // too little to measure: no estimate
   std::vector<std::vector<uint64_t>> sc(W);
-  for (auto &v : sc) v.resize(per / 32 + per / 64 + 2);
+  for (auto &v : sc) v.assign(per / 32 + per / 64 + 2, 1);      // (written: the scratch's pages exist before the clock starts)
+  // ONE pass over bases nobody has read yet (the tail of the contig: a second pass over the same 4 MB per thread would be served by the L3)
+  const uint8_t *from = src + (n - (uint64_t)W * per) / 128 * 128;
   auto run = [&](unsigned w) {
     uint64_t *codes = sc[w].data();
-    mfx_pack_bases(src + (uint64_t)w * per, per, codes, reinterpret_cast<uint32_t *>(codes + per / 32 + 1));
+    mfx_pack_bases(from + (uint64_t)w * per, per, codes, reinterpret_cast<uint32_t *>(codes + per / 32 + 1));
   };
-  pool->start(run); pool->wait();                              // (first touch of the scratch)
   const auto t0 = std::chrono::steady_clock::now();
   pool->start(run); pool->wait();
   const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -2788,15 +2789,18 @@ extern "C" int mfx_diag_stream_rates(int device, const char *src, uint64_t n, ui
   if (device < 0 || device >= mfx_device_count()) return mfx_fail(MFX_E_NODEVICE, "mfx_diag_stream_rates: device %d of %d", device, mfx_device_count());
   *enc_gbs = *link_gbs = 0.0;
   {
-    WorkerPool pool(threads);
-    const uint64_t per = std::min<uint64_t>(16u << 20, n / threads / 32 * 32);
+    WorkerPool pool(threads, true);                              // (spread over the L3 domains, as the run's own encoders are)
+    // every pass reads bases no pass before it has read (a second pass over the same bytes would be served by the L3: 256 MB on the EPYC
+    // of the measured boxes): up to three passes of `threads` x 32 MB, as far as n reaches; the best one counts
+    const uint64_t per = std::min<uint64_t>(32u << 20, n / threads / 128 * 128);
     if (per >= (1u << 16)) {
       std::vector<std::vector<uint64_t>> sc(threads);
-      for (auto &v : sc) v.resize(per / 32 + per / 64 + 2);
-      auto run = [&](unsigned w) { mfx_pack_bases(reinterpret_cast<const uint8_t *>(src) + (uint64_t)w * per, per, sc[w].data(), reinterpret_cast<uint32_t *>(sc[w].data() + per / 32 + 1)); };
-      pool.start(run); pool.wait();
+      for (auto &v : sc) v.assign(per / 32 + per / 64 + 2, 1);  // (written: the scratch's pages exist before the clock starts)
+      const uint64_t passes = std::max<uint64_t>(1, std::min<uint64_t>(3, n / (per * threads)));
       double best = 0;
-      for (int rep = 0; rep < 3; ++rep) {
+      for (uint64_t rep = 0; rep < passes; ++rep) {
+        const uint8_t *from = reinterpret_cast<const uint8_t *>(src) + rep * per * threads;
+        auto run = [&](unsigned w) { mfx_pack_bases(from + (uint64_t)w * per, per, sc[w].data(), reinterpret_cast<uint32_t *>(sc[w].data() + per / 32 + 1)); };
         const auto t0 = std::chrono::steady_clock::now();
         pool.start(run); pool.wait();
         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -1735,14 +1735,15 @@ __device__ __forceinline__ uint32_t mfx_lane_lookup8(const mfx_table_view &c, mf
   // per line -- 0.2 % of the queries of a genome with human-like repeat families, a fifth of the kernel's time (profiles/r06_repeats_ab.txt)
   // -- so the -hist kernel only LISTS such a query (push) and mfx_hist_rest_kernel ends it, every lane on an entry of its own.
   uint32_t pushed = 0u;
-  if (Push::enabled) {
-    bool rare = false;
+  bool rare = false;
 #pragma unroll
-    for (int j = 0; j < B; ++j) rare |= st[j] >= 0xfcu && st[j] <= 0xfeu;
-    if (__any(rare)) {                                         // wave-uniform
+  for (int j = 0; j < B; ++j) rare |= st[j] - 0xfcu <= 2u;   // 0xfc .. 0xfe
+  if (!__any(rare)) return pushed;                            // wave-uniform: nine batches in ten of an i.i.d. genome end here
+  if (Push::enabled) {
+    {
 #pragma unroll
       for (int j = 0; j < B; ++j) {
-        const bool want = st[j] >= 0xfcu && st[j] <= 0xfeu;
+        const bool want = st[j] - 0xfcu <= 2u;
         if (!__any(want)) continue;
         if (dbg && want) atomicAdd(&dbg[st[j] == 0xfeu ? 4 : 3], 1ull);
 #if MFX_V_DIAG_NOPUSH
