@@ -674,6 +674,9 @@ int main(int argc, char **argv) {
   }
   if (!G.devices.empty()) G.device = G.devices[0];
   else G.devices.push_back(G.device);
+  // load_Kmetric first (merfin-globals.C:21-62 runs before the databases are opened; host only -- a compressed table's decompressor has
+  // come and gone before the HIP runtime starts)
+  if (!load_Kmetric(G)) return 1;
   // (the device check stays on this thread, before anything else is started: the HIP runtime coming up on a thread of its own
   // while this one spawns a decompressor for -sequence was seen to come up with no device)
   for (int d : G.devices)
@@ -700,8 +703,6 @@ int main(int argc, char **argv) {
     steps.emplace_back(what, std::chrono::duration<double>(t - t_sub).count());
     t_sub = t;
   };
-
-  if (!load_Kmetric(G)) return 1;
 
   // load_Kmers, merfin-globals.C:114-163: the read DB defines k
   mfx_db_info rdb, adb;

@@ -1158,6 +1158,7 @@ extern "C" void mfx_db_stage_boost(mfx_db_stage *S) {
 
 extern "C" mfx_db_stage *mfx_db_stage_begin(const char *path, int device) {
   if (!path) { mfx_fail(MFX_E_INVAL, "mfx_db_stage_begin: null argument"); return nullptr; }
+  if (device < 0 || device >= mfx_device_count()) { mfx_fail(MFX_E_NODEVICE, "mfx_db_stage_begin: HIP device %d not available (%d visible)", device, mfx_device_count()); return nullptr; }
   if (const char *e = getenv("MFX_DB_STAGE")) if (atoi(e) == 0) { mfx_fail(MFX_E_INVAL, "staged load disabled (MFX_DB_STAGE=0)"); return nullptr; }
   std::unique_ptr<mfx_db_stage> S(new mfx_db_stage);
   S->t_begin = stage_now();
@@ -1170,6 +1171,7 @@ extern "C" mfx_db_stage *mfx_db_stage_begin(const char *path, int device) {
   S->off0 = S->file_off(0);
   S->payload_bytes = S->file_off(S->info.nblocks) - S->off0;
   DevGuard g(device);
+  if (!g.ok) { mfx_fail(MFX_E_HIP, "hipSetDevice(%d) failed", device); return drop(S.release()); }
   size_t free_b = 0, total_b = 0;
   double tq = stage_now();
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); mfx_fail(MFX_E_HIP, "hipMemGetInfo failed"); return drop(S.release()); }

@@ -1318,6 +1318,13 @@ void mfx_place_keys_host(int k, const uint64_t *kmers, uint64_t n, uint64_t *out
 // any accepted database -> the PLACED flat form: the records sorted by where the compact table puts them
 static int mfx_db_convert_placed_impl(const char *in_path, const char *out_path, uint64_t *n_out) {
   if (!in_path || !out_path) return mfx_fail(MFX_E_INVAL, "mfx_db_convert_placed: null argument");
+  {
+    // k first: a database this form cannot hold (k = 31: P takes 65 bits) is refused before its tens of GB are converted and read back
+    mfx_db_info pi;
+    if (int prc = mfx_db_probe(in_path, &pi)) return prc;
+    if (pi.k < MFX_PLACE_MIN_K || pi.k > MFX_PLACE_MAX_K)
+      return mfx_fail(MFX_E_INVAL, "'%s' holds %d-mers: a placed database holds %d <= k <= %d (use -convert without -placed)", in_path, pi.k, MFX_PLACE_MIN_K, MFX_PLACE_MAX_K);
+  }
   // through the sorted flat form in memory: read (any form), then re-key
   std::string tmp = std::string(out_path) + ".tmp-sorted";
   uint64_t n = 0;
