@@ -247,9 +247,9 @@ __device__ __forceinline__ bool mfx_hist_eval(mfx_hist_lds &H, const mfx_kstar_a
 // the exact tables cover comes from ka.underq -- filled once per evaluator by the SAME fp64 routines (mfx_eval_create) -- instead of a
 // probability load, an fp64 division and a conversion in a branch that some lane of most waves takes (1-2 % of the k-mers have
 // asmK > readK: 60 % of the waves' evaluations had to walk through it).
-template <class Counter>
+template <class Counter, class Sum>
 __device__ __forceinline__ bool mfx_hist_eval_fx(mfx_hist_lds &H, const mfx_kstar_args &ka, bool lut_ok, uint32_t readV,
-                                                 uint32_t asmV, Counter &n_over0, uint64_t &kfx) {
+                                                 uint32_t asmV, Counter &n_over0, Sum &kfx) {
   double readK, prob;
   uint32_t rki = 0xffffffffu;                                  // readK as an integer when the tables apply
   if (lut_ok && readV < MFX_MAXP_LDS) {

@@ -2310,12 +2310,12 @@ __global__ __launch_bounds__(MFX_BLOCK, (mfx_hist_tune<CANON, COMPACT, KF>::bloc
     // evaluates at most 16 k-mers of a tile: 16 terms below 2^52 each, a count of at most 16)
     // (a 32-bit add to the word's high half: the 64-bit constant 1 << 56 was hoisted out of the loop as a register pair -- and spilled)
     struct lds_bump { unsigned long long *w; __device__ __forceinline__ void operator++(int) { (void)__hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(w) + 1, 1u << 24, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } };
+    struct lds_sum { unsigned long long *w; __device__ __forceinline__ void operator+=(uint64_t v) { (void)__hip_atomic_fetch_add(w, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } };
     auto eval1 = [&](uint32_t rvv, uint32_t avv) {
       if (kfx_lds) {
-        uint64_t t = 0;
         lds_bump bump{kfxw};
-        if (mfx_hist_eval_fx(H, ka, lut_ok, rvv, avv, bump, t)) n_missing++;
-        if (t) (void)__hip_atomic_fetch_add(kfxw, (unsigned long long)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        lds_sum sum{kfxw};                                       // (added where the term is made: the `asmK > readK` branch)
+        if (mfx_hist_eval_fx(H, ka, lut_ok, rvv, avv, bump, sum)) n_missing++;
       } else if (mfx_hist_eval_fx(H, ka, lut_ok, rvv, avv, n_over0, kfx)) n_missing++;
     };
     // mod-minimizer placement: the wave finds its home lines together (mfx_wave_mod_line)
