@@ -171,15 +171,8 @@ __device__ __forceinline__ void mfx_ovf_add(uint64_t *ovf, uint64_t key, uint64_
 }
 
 // called by the lanes of a wave that evaluated a k-mer into a far bin (any subset of the wave: a divergent branch)
-#ifndef MFX_V_OVF_SIMPLE
-#define MFX_V_OVF_SIMPLE 0            // DIAGNOSTIC builds only
-#endif
 __device__ __forceinline__ void mfx_ovf_record(const mfx_kstar_args &ka, bool under, uint32_t idx) {
   const uint64_t key = (under ? 0ull : (1ull << 63)) | idx;
-#if MFX_V_OVF_SIMPLE
-  atomicAdd((unsigned long long *)&ka.counts[2ull * ka.nbins + 2], 1ull + (key & 0ull));
-  return;
-#endif
   const uint32_t lane = threadIdx.x & 63u;
   uint64_t todo = __ballot(1);                                 // the lanes that are here
   while (todo) {
