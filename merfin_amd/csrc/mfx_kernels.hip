@@ -1836,7 +1836,6 @@ __device__ __forceinline__ uint32_t mfx_lane_probe_defer(const mfx_table_view &c
     av[j] = (found && !sat) ? r_av : 0u;
     st[j] = !ok[j] ? 0xffu : (found ? (sat ? 0xfeu : 0xffu) : (room ? 0xffu : 1u));  // an empty slot before the key: absent (value 0, merfin-globals.C:84)
   }
-  mfx_side_direct<B>(c, st, rv, av, keyof, dbg);               // saturated count fields: slot 0 of the side table's line, per lane
   uint32_t defer = 0u;
 #pragma unroll
   for (int j = 0; j < B; ++j) {
@@ -1858,11 +1857,13 @@ __device__ __forceinline__ uint32_t mfx_lane_probe_defer(const mfx_table_view &c
   }
   // the rare endings that cannot wait (the k-mer itself is at hand only here): a saturated count whose exact value is not in slot 0
   // of its side-table line, a query the mailbox had no room for -- onto the -hist kernel's worklist (mfx_lane_lookup8), else per lane
-  if (Push::enabled) {
-    bool rare = false;
+  bool rare = false;
 #pragma unroll
-    for (int j = 0; j < B; ++j) rare |= st[j] == 0xfcu || st[j] == 0xfeu;
-    if (__any(rare)) {                                         // wave-uniform
+  for (int j = 0; j < B; ++j) rare |= (st[j] & 0xfdu) == 0xfcu;       // 0xfc, 0xfe
+  if (!__any(rare)) return defer;                              // wave-uniform: ONE test per batch guards everything below
+  mfx_side_direct<B>(c, st, rv, av, keyof, dbg);               // saturated count fields: slots 0 / 1 of the side table's line, per lane
+  if (Push::enabled) {
+    {
 #pragma unroll
       for (int j = 0; j < B; ++j) {
         const bool want = st[j] == 0xfcu || st[j] == 0xfeu;
