@@ -1514,6 +1514,9 @@ __device__ __forceinline__ uint2 mfx_sat_fill(uint32_t lo, uint32_t xr, uint32_t
 #ifndef MFX_V_DIAG_NOSIDE
 #define MFX_V_DIAG_NOSIDE 0           // DIAGNOSTIC builds only (wrong results): saturated fields taken as counts / rare endings dropped
 #endif
+#ifndef MFX_V_SIDE_LATE
+#define MFX_V_SIDE_LATE 1             // the side probe of the undeferred form behind the passes, under the rare endings' ONE guard (0: in front of them, A/B: 3 % level 134.6 -> 138.1 G, i.i.d. 150.7 -> 151.0, 10 % level 111.6 -> 110.8; profiles/r06_repeats_ab.txt)
+#endif
 #ifndef MFX_V_DIAG_NOPUSH
 #define MFX_V_DIAG_NOPUSH 0
 #endif
@@ -1631,9 +1634,11 @@ __device__ __forceinline__ uint32_t mfx_lane_lookup8(const mfx_table_view &c, mf
     av[j] = (found && !sat) ? r_av : 0u;
     st[j] = !ok[j] ? 0xffu : (found ? (sat ? 0xfeu : 0xffu) : (room ? 0xffu : 1u));  // an empty slot before the key: absent (value 0, merfin-globals.C:84)
   }
-  // ---- saturated count fields: slots 0 and 1 of the side table's line, per lane (what is not there stays 0xfe; a saturated field
-  // met by a PASS below is listed with the rare endings: a second instance of this code behind the passes cost the i.i.d. genome 3 %)
+  // ---- (A/B form only: the side probe of saturated count fields in front of the passes; the shipped form runs it behind them, where
+  // ONE test per batch guards it together with the listing -- and a saturated field met by a PASS is served by it as well)
+#if !MFX_V_SIDE_LATE
   mfx_side_direct<B>(c, st, rv, av, keyof, dbg);
+#endif
   // ---- the queries that were not in their first mini-bucket (3 % at load factor 0.225): compacted into this wave's mailbox
   // and served 8 per step by the cooperative whole-line probe -- the 8 lanes of a group fetch the query's HOME line with one
   // coalesced request, so that whichever mini-bucket the k-mer went to, one more round trip finds it
@@ -1739,6 +1744,11 @@ __device__ __forceinline__ uint32_t mfx_lane_lookup8(const mfx_table_view &c, mf
 #pragma unroll
   for (int j = 0; j < B; ++j) rare |= st[j] - 0xfcu <= 2u;   // 0xfc .. 0xfe
   if (!__any(rare)) return pushed;                            // wave-uniform: nine batches in ten of an i.i.d. genome end here
+#if MFX_V_SIDE_LATE
+  // ---- saturated count fields (met by the first load or by a pass): slots 0 and 1 of the side table's line, per lane; what is not
+  // there stays 0xfe
+  mfx_side_direct<B>(c, st, rv, av, keyof, dbg);
+#endif
   if (Push::enabled) {
     {
 #pragma unroll
