@@ -214,6 +214,9 @@ int mfx_index_build_for_hist(mfx_index *ix, const mfx_seq *seq, const char *read
 typedef struct mfx_db_stage mfx_db_stage;
 mfx_db_stage *mfx_db_stage_begin(const char *read_db_path, int device);
 int           mfx_index_build_for_hist_staged(mfx_index *ix, const mfx_seq *seq, mfx_db_stage *stage, uint64_t minV, uint64_t maxV);
+/* mfx_index_load_db of a staged database (side 0: -readmers, the -min/-max filter applies; 1: -seqmers): only the decode + insert kernels are
+ * left to run.  What the path-only index of the variant modes loads both of its databases with (mfx_index_claim_paths). */
+int           mfx_index_load_db_staged(mfx_index *ix, mfx_db_stage *stage, int side, uint64_t minV, uint64_t maxV);
 void          mfx_db_stage_free(mfx_db_stage *stage);
 /* Until this call the stage reads the file with a few threads only (the host is busy reading and encoding the sequence; MFX_DB_STAGE_THREADS,
  * default 8); call it when the sequence is uploaded. */
@@ -560,6 +563,19 @@ int mfx_variants_run_vcf(mfx_eval *ev, mfx_vcf *vcf, const char *const *names, c
  * sequences must stay where they are until the run is over.  Once per handle. */
 int mfx_vcf_prepare(mfx_vcf *vcf, int k, const char *const *names, const char *const *bases, const uint64_t *lens,
                     uint32_t ncontigs, const mfx_variant_opts *opts);
+/* The PATH-ONLY index of the variant modes (round 6).  varMer::score (varMer.C:76-84) is the only place the variant modes ask the lookup
+ * tables anything, and what it asks for are the k-mers of the enumerated paths; the reference nevertheless loads both databases whole
+ * (load_Kmers, merfin-globals.C:114-163).  A prepared call set knows every path before a database is opened:
+ *   mfx_vcf_prepare(vcf, k, ...);  mfx_vcf_path_bound(vcf, &n);            -- n: k-mer positions of all path text >= their distinct k-mers
+ *   ix = mfx_index_create_for_seq(k, n + 1024, max_gb, device);
+ *   mfx_index_claim_paths(ix, vcf, NULL);                                   -- the paths made on the device as the run makes them, their k-mers claimed
+ *   mfx_index_load_db(ix, seqmers, 1, ...)  (or mfx_index_count_claimed(ix, assembly, 0));   mfx_index_load_db(ix, readmers, 0, minV, maxV);
+ *   ev = mfx_eval_create(ix, ...);  mfx_variants_run_vcf(ev, vcf, ...);     -- same records, byte for byte, as on the full index
+ * Both databases only UPDATE the claimed k-mers (a k-mer of no path never gets a slot).  The index is bound to the handle: another call set,
+ * an unprepared run, -hist / -dump of a sequence are refused on it (MFX_E_INVAL).  k <= 31; a non-canonical database makes the load
+ * return MFX_E_NONCANON as for every sequence-only index (build the full one). */
+int mfx_vcf_path_bound(const mfx_vcf *vcf, uint64_t *positions);
+int mfx_index_claim_paths(mfx_index *ix, mfx_vcf *vcf, uint64_t *n_positions);
 /* The same over an index sharded across nslots evaluators (slot d = shard d of nslots): every batch of path text is
  * scored by mfx_dump_values_sharded; clustering, enumeration, selectors and output are the code above. */
 int mfx_variants_run_sharded(mfx_eval *const *evs, uint32_t nslots, const char *vcf_path, const char *const *names,

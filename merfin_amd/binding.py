@@ -63,7 +63,7 @@ _lib = None
 SYMBOLS = [
     "mfx_last_error", "mfx_last_error_code", "mfx_version", "mfx_device_count", "mfx_device_warm",
     "mfx_index_create", "mfx_index_free", "mfx_index_estimate_gb", "mfx_index_add_read", "mfx_index_add_asm",
-    "mfx_index_count_asm", "mfx_index_build_for_hist", "mfx_index_count_claimed", "mfx_hist_run_parts", "mfx_index_create_for_seq", "mfx_index_create_for_seq_lf", "mfx_index_create_lf", "mfx_db_stage_begin", "mfx_index_build_for_hist_staged", "mfx_db_stage_free", "mfx_db_stage_boost", "mfx_index_estimate_gb_for_seq", "mfx_index_claim_seq", "mfx_index_value", "mfx_index_get_info", "mfx_index_export",
+    "mfx_index_count_asm", "mfx_index_build_for_hist", "mfx_index_count_claimed", "mfx_hist_run_parts", "mfx_index_create_for_seq", "mfx_index_create_for_seq_lf", "mfx_index_create_lf", "mfx_db_stage_begin", "mfx_index_build_for_hist_staged", "mfx_index_load_db_staged", "mfx_db_stage_free", "mfx_db_stage_boost", "mfx_index_estimate_gb_for_seq", "mfx_index_claim_seq", "mfx_index_value", "mfx_index_get_info", "mfx_index_export",
     "mfx_db_probe", "mfx_index_load_db", "mfx_index_load_db_multi", "mfx_db_write_flat", "mfx_db_convert", "mfx_db_convert_placed", "mfx_db_write_flat_placed", "mfx_db_place_keys", "mfx_index_save", "mfx_index_load",
     "mfx_index_set_fingerprint", "mfx_index_get_origin",
     "mfx_host_alloc", "mfx_host_free", "mfx_seq_create", "mfx_hist_run_streamed",
@@ -79,7 +79,7 @@ SYMBOLS = [
     "mfx_eval_create", "mfx_eval_free", "mfx_eval_nbins", "mfx_eval_debug_enable", "mfx_eval_debug_counters", "mfx_getK", "mfx_getKmetric", "mfx_histoQV",
     "mfx_hist_run", "mfx_hist_result_free", "mfx_hist_launch", "mfx_hist_launch_cyclic", "mfx_hist_result_from_counts",
     "mfx_hist_take_overflow", "mfx_hist_report", "mfx_diag_stream_rates",
-    "mfx_pack_bases", "mfx_host_threads_share", "mfx_dump_values", "mfx_dump_contig", "mfx_dump_values_sharded", "mfx_dump_contig_sharded", "mfx_variants_run_sharded", "mfx_vcf_load", "mfx_vcf_free", "mfx_variants_run_vcf", "mfx_vcf_prepare", "mfx_completeness", "mfx_completeness_pieces", "mfx_variants_run",
+    "mfx_pack_bases", "mfx_host_threads_share", "mfx_dump_values", "mfx_dump_contig", "mfx_dump_values_sharded", "mfx_dump_contig_sharded", "mfx_variants_run_sharded", "mfx_vcf_load", "mfx_vcf_free", "mfx_variants_run_vcf", "mfx_vcf_prepare", "mfx_vcf_path_bound", "mfx_index_claim_paths", "mfx_completeness", "mfx_completeness_pieces", "mfx_variants_run",
     "mfx_index_set_shard", "mfx_router_create", "mfx_router_free", "mfx_route_tiles", "mfx_hist_keys_launch",
 ]
 
@@ -138,6 +138,7 @@ def load_library():
     L.mfx_db_stage_begin.restype = vp
     L.mfx_db_stage_begin.argtypes = [C.c_char_p, C.c_int]
     L.mfx_index_build_for_hist_staged.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64]
+    L.mfx_index_load_db_staged.argtypes = [vp, vp, C.c_int, C.c_uint64, C.c_uint64]
     L.mfx_db_stage_free.restype = None
     L.mfx_db_stage_free.argtypes = [vp]
     L.mfx_db_stage_boost.restype = None
@@ -219,6 +220,8 @@ def load_library():
     L.mfx_variants_run_vcf.argtypes = [vp, vp, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), u64p, C.c_uint32,
                                        C.POINTER(_VarOpts), C.c_char_p, C.c_char_p, u64p]
     L.mfx_vcf_prepare.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), u64p, C.c_uint32, C.POINTER(_VarOpts)]
+    L.mfx_vcf_path_bound.argtypes = [vp, u64p]
+    L.mfx_index_claim_paths.argtypes = [vp, vp, u64p]
     L.mfx_index_set_fingerprint.argtypes = [vp, C.c_uint64]
     L.mfx_index_get_origin.argtypes = [vp, u64p, u64p, u64p]
     L.mfx_host_threads_share.restype = None
@@ -452,6 +455,10 @@ class Index:
     def build_for_hist_staged(self, seqs, stage, minV=0, maxV=2**64 - 1):
         """the same from a DbStage (mfx_db_stage_begin): the database has been on its way into device memory since the stage was made"""
         _check(load_library().mfx_index_build_for_hist_staged(self.h, seqs.h, stage.h, minV, maxV))
+
+    def load_db_staged(self, stage, side, minV=0, maxV=2**64 - 1):
+        """load_db of a DbStage: only the decode + insert kernels are left to run (side 0 -readmers, 1 -seqmers)"""
+        _check(load_library().mfx_index_load_db_staged(self.h, stage.h, int(side), minV, maxV))
 
     def claim_seq(self, seqs, stream=None):
         _check(load_library().mfx_index_claim_seq(self.h, seqs.h, C.c_void_p(stream or 0)))
@@ -978,6 +985,19 @@ class LoadedVcf:
         lens = np.array([len(c) for c in contigs], dtype=np.uint64)
         o = _VarOpts(VARIANT_MODES[mode], comb, 1 if nosplit else 0, debug_path.encode() if debug_path else None)
         _check(load_library().mfx_vcf_prepare(self.h, int(k), nm, arr, lens.ctypes.data_as(C.POINTER(C.c_uint64)), n, C.byref(o)))
+
+    def path_bound(self):
+        """k-mer positions of all path text of the prepared call set: the capacity of its path-only index (mfx_vcf_path_bound)"""
+        n = C.c_uint64(0)
+        _check(load_library().mfx_vcf_path_bound(self.h, C.byref(n)))
+        return n.value
+
+    def claim_paths(self, index):
+        """the k-mers of every path claimed on a sequence-only index (Index.for_sequence): the PATH-ONLY index of the variant modes
+        (mfx_index_claim_paths); the databases then update those k-mers only and Evaluator.variants_loaded on this handle runs on it"""
+        n = C.c_uint64(0)
+        _check(load_library().mfx_index_claim_paths(index.h, self.h, C.byref(n)))
+        return n.value
 
     def close(self):
         if self.h:

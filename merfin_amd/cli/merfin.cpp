@@ -724,8 +724,21 @@ int main(int argc, char **argv) {
   // moving into device memory NOW, on a thread of their own (mfx_db_stage_begin) -- under the FASTA read, the sequence upload, the
   // table's allocation and the kernel that claims the sequence's k-mers.  Any other database form, too little free memory,
   // MFX_DB_STAGE=0: no stage, the build reads the database when it gets there.
-  mfx_db_stage *stage = nullptr;
-  struct StageGuard { mfx_db_stage *&s; ~StageGuard() { if (s) mfx_db_stage_free(s); s = nullptr; } } stageGuard{stage};
+  // The variant modes ask the lookup tables for the k-mers of the enumerated PATHS and nothing else (varMer::score, varMer.C:76-84): one slot
+  // on one device prepares the call set first (mfx_vcf_prepare: host work), claims exactly those k-mers on a sequence-only index
+  // (mfx_index_claim_paths) and lets both databases update them -- the PATH-ONLY index, a tenth of the full tables (3 Gb, 3.8 M calls:
+  // ~25 GB instead of 216).  Not with -index (the image caches the full tables), k > 31, several slots; MFX_CLI_PATH_INDEX=0 /
+  // MFX_CLI_FULL_INDEX=1: the full tables.
+  bool pathOnly = false;
+  {
+    const char *vs = getenv("MFX_VARIANT_SLOTS");
+    const size_t slots = (vs && atoi(vs) > 0) ? (size_t)atoi(vs) : G.devices.size();
+    const char *pe = getenv("MFX_CLI_PATH_INDEX"), *pa = getenv("MFX_CLI_VCF_AHEAD");
+    pathOnly = variantMode && G.vcfName && G.seqName && slots == 1 && !G.sharded && k <= 31 && !G.indexName && !(pe && atoi(pe) == 0) && !(pa && atoi(pa) == 0) &&
+               !(getenv("MFX_CLI_FULL_INDEX") && atoi(getenv("MFX_CLI_FULL_INDEX")));
+  }
+  mfx_db_stage *stage = nullptr, *stageAsm = nullptr;              // (stageAsm: -seqmers of the path-only index)
+  struct StageGuard { mfx_db_stage *&s; ~StageGuard() { if (s) mfx_db_stage_free(s); s = nullptr; } } stageGuard{stage}, stageAsmGuard{stageAsm};
   // (MFX_CLI_STAGE_FIRST=0: the stage begins after the device is warmed up.  Measured, profiles/r05_stager_diag.txt: the warm-up then takes
   // 0.06 instead of 0.25 s, but the 0.15-0.2 s that the process's first allocations / queue / kernel cost move into the stager's start, the
   // claim kernel is launched at the same 0.35 s, and with stager, FASTA reader and encoder all at full speed in the first 0.3 s the process
@@ -735,6 +748,9 @@ int main(int argc, char **argv) {
     const bool histLike = (G.reportType == OP_HIST || G.reportType == OP_DUMP) && !G.sharded && k <= 31 && G.seqName && !G.seqDBname && !G.indexName &&
                           G.devices.size() == 1 && !(getenv("MFX_CLI_FULL_INDEX") && atoi(getenv("MFX_CLI_FULL_INDEX")));
     if (histLike && rdb.format == MFX_DB_FLAT) stage = mfx_db_stage_begin(G.readDBname, G.device);
+    // the path-only index of the variant modes: both databases move while the sequences and the VCF are read and the call set is prepared
+    if (pathOnly && rdb.format == MFX_DB_FLAT) stage = mfx_db_stage_begin(G.readDBname, G.device);
+    if (pathOnly && G.seqDBname && adb.format == MFX_DB_FLAT) stageAsm = mfx_db_stage_begin(G.seqDBname, G.device);
   };
   if (stageFirst) begin_stage();
   lap("probe k-mer databases");
@@ -789,7 +805,7 @@ int main(int argc, char **argv) {
   const bool compressed = G.seqName && mfx_suffix_tool(G.seqName) != nullptr;
   const bool wantOverlap = ov ? atoi(ov) != 0 : compressed;
   const uint64_t basesBound = (G.seqName && !G.seqDBname && wantOverlap && !seqOnly) ? bases_upper_bound(G.seqName) : 0;
-  const bool deferSeq = G.seqName && !G.sharded && !seqOnly && wantOverlap && (G.seqDBname || basesBound > 0);
+  const bool deferSeq = G.seqName && !G.sharded && !seqOnly && !pathOnly && wantOverlap && (G.seqDBname || basesBound > 0);   // (the path-only index needs the sequences first)
   // while the reader thread is on the file: the device's context, the library's code object and the pinned-memory path come
   // up here instead of inside the first upload (~0.07 s; an error here is left to that upload to report).  Not with a
   // decompressor child around (see the device check above) and not for several devices (their slots come up in parallel).
@@ -843,7 +859,7 @@ int main(int argc, char **argv) {
     const char *pa = getenv("MFX_CLI_VCF_AHEAD");
     const bool dbgAhead = G.debug;
     if (variantMode && G.vcfName && slots == 1 && !G.sharded && !(pa && atoi(pa) == 0))
-      vcfAhead = std::async(std::launch::async, [&G, &vcfAheadError, &recs, &bases, &lens, k, dbgAhead, deferSeq]() {
+      vcfAhead = std::async(std::launch::async, [&G, &vcfAheadError, &recs, &bases, &lens, k, dbgAhead, deferSeq, pathOnly]() {
         mfx_vcf *v = mfx_vcf_load(G.vcfName);
         if (!v) { vcfAheadError = mfx_last_error(); return v; }    // (errors are per thread: carried to the caller's)
         // MFX_CLI_VCF_AHEAD=2: ... and its clusters merged, their allele combinations enumerated and packed here as well (mfx_vcf_prepare:
@@ -852,7 +868,7 @@ int main(int argc, char **argv) {
         // down -- config 4 at 3 Gb 2.02-2.07 s with the load alone ahead, 2.67-2.75 s with stage A too (profiles/r05_cfg4_cli_ahead.txt).
         const char *pa2 = getenv("MFX_CLI_VCF_AHEAD");
         // (never while the sequences are still being read -- deferSeq: finish_seq() fills recs / bases / lens on the main thread later)
-        if (!(pa2 && atoi(pa2) == 2) || deferSeq) return v;
+        if (!((pa2 && atoi(pa2) == 2) || pathOnly) || deferSeq) return v;       // (the path-only index is built FROM the prepared call set)
         std::vector<const char *> nm(recs.size());
         for (size_t c = 0; c < recs.size(); ++c) nm[c] = recs[c].name.c_str();
         mfx_variant_opts o;
@@ -896,6 +912,62 @@ int main(int argc, char **argv) {
       mfx_index_free(ix);
       ix = nullptr;
     }
+  }
+  mfx_vcf *vcfReady = nullptr;                                      // the call set taken from vcfAhead (prepared): the run below uses it
+  struct VcfReadyGuard { mfx_vcf *&v; ~VcfReadyGuard() { if (v) mfx_vcf_free(v); v = nullptr; } } vcfReadyGuard{vcfReady};
+  if (!ix && pathOnly && vcfAhead.valid()) {
+    vcfReady = vcfAhead.get();
+    if (!vcfReady) { fprintf(stderr, "ERROR: variant scoring: %s\n", vcfAheadError.c_str()); return 1; }
+    if (stage) mfx_db_stage_boost(stage);                           // the host's threads are free: the databases' readers may have them all
+    if (stageAsm) mfx_db_stage_boost(stageAsm);
+    step("(before the index: sequences, VCF, clusters and their paths)");
+    uint64_t positions = 0;
+    if (mfx_vcf_path_bound(vcfReady, &positions)) DIE_MFX("sizing the path-only index");
+    fprintf(stderr, "--\n-- Memory needed: %.3f GB (the %d-mers of the variants' paths: at most %lu)\n-- Memory limit:  %.3f GB%s\n--\n",
+            mfx_index_estimate_gb_for_seq(k, positions + 1024), k, (unsigned long)positions, G.maxMemory, G.maxMemory > 0 ? "" : " (none)");
+    ix = mfx_index_create_for_seq_lf(k, positions + 1024, G.maxMemory, G.device, 0.7);
+    if (!ix) fprintf(stderr, "-- The path-only index does not fit (%s); building the full lookup tables instead.\n", mfx_last_error());
+    step("create the table");
+    int lrc = 0;
+    if (ix) {
+      fprintf(stderr, "-- Claiming the %d-mers of the variants' paths on the GPU.\n", k);
+      if (mfx_index_claim_paths(ix, vcfReady, nullptr)) {
+        fprintf(stderr, "-- %s\n-- Building the full lookup tables instead.\n", mfx_last_error());
+        mfx_index_free(ix);
+        ix = nullptr;
+      }
+      step("claim the paths' k-mers");
+    }
+    if (ix) {
+      if (G.seqDBname) {
+        fprintf(stderr, "-- Loading kmers from '%s' into lookup table.\n", G.seqDBname);
+        lrc = stageAsm ? mfx_index_load_db_staged(ix, stageAsm, 1, 0, ~0ull) : mfx_index_load_db(ix, G.seqDBname, 1, 0, ~0ull);
+        if (stageAsm) { mfx_db_stage_free(stageAsm); stageAsm = nullptr; }
+        if (lrc && lrc != MFX_E_NONCANON) DIE_MFX("loading -seqmers");
+        step("load -seqmers");
+      } else {
+        // replaces `meryl count k=.. <seq> output <seq>.meryl` (merfin-globals.C:182-186) for the k-mers that will be asked for
+        fprintf(stderr, "-- No -seqmer given. Counting the %d-mers of '%s' on the GPU.\n", k, G.seqName);
+        if (!seq && !make_seq()) DIE_MFX("uploading sequences");
+        if (mfx_index_count_claimed(ix, seq, nullptr)) DIE_MFX("counting sequence k-mers");
+        step("count the sequence's k-mers");
+      }
+      if (!lrc) {
+        fprintf(stderr, "-- Loading kmers from '%s' into lookup table.\n", G.readDBname);
+        lrc = stage ? mfx_index_load_db_staged(ix, stage, 0, G.minV, G.maxV) : mfx_index_load_db(ix, G.readDBname, 0, G.minV, G.maxV);
+        if (lrc && lrc != MFX_E_NONCANON) DIE_MFX("loading -readmers");
+        step("load -readmers");
+      }
+      if (lrc == MFX_E_NONCANON) {
+        fprintf(stderr, "-- A k-mer database is not canonical; building the full lookup tables instead.\n");
+        mfx_index_free(ix);
+        ix = nullptr;
+      }
+    }
+    // (the staged bytes are not needed by the run; a fall-back to the full tables reads the files)
+    if (stage) { mfx_db_stage_free(stage); stage = nullptr; }
+    if (stageAsm) { mfx_db_stage_free(stageAsm); stageAsm = nullptr; }
+    if (!ix) pathOnly = false;                                      // (the prepared call set runs on the full tables as well)
   }
   if (!ix && seqOnly) {
     const uint64_t capacity = totalBases + 1024;                  // a sequence has at most one new k-mer per base
@@ -1231,8 +1303,9 @@ int main(int argc, char **argv) {
       for (size_t d = 0; d < N; ++d) if (!errs[d].empty()) { fprintf(stderr, "ERROR: variant scoring (slot %zu): %s\n", d, errs[d].c_str()); drop_parts(); return 1; }
       if (!concat_parts(outName, parts, true)) { fprintf(stderr, "ERROR: cannot write '%s'.\n", outName.c_str()); drop_parts(); return 1; }
       for (uint64_t x : ncls) ncl += x;
-    } else if (vcfAhead.valid()) {
-      mfx_vcf *vcf = vcfAhead.get();
+    } else if (vcfReady || vcfAhead.valid()) {
+      mfx_vcf *vcf = vcfReady ? vcfReady : vcfAhead.get();
+      vcfReady = nullptr;
       if (!vcf) { fprintf(stderr, "ERROR: variant scoring: %s\n", vcfAheadError.c_str()); return 1; }
       const int vrc = mfx_variants_run_vcf(ev, vcf, names.data(), bases.data(), lens.data(), (uint32_t)recs.size(), &vo, outName.c_str(), nullptr, &ncl);
       // (leaving the 4 M records to the process's exit instead of freeing them here was measured: 0.1 s less in this phase, the same wall --

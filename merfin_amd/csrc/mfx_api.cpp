@@ -1207,14 +1207,15 @@ extern "C" mfx_db_stage *mfx_db_stage_begin(const char *path, int device) {
   return raw;
 }
 
-extern "C" int mfx_index_build_for_hist_staged(mfx_index *ix, const mfx_seq *seq, mfx_db_stage *S, uint64_t minV, uint64_t maxV) {
-  if (!ix || !seq || !S) return mfx_fail(MFX_E_INVAL, "mfx_index_build_for_hist_staged: null argument");
-  if (ix->device != S->device) return mfx_fail(MFX_E_INVAL, "mfx_index_build_for_hist_staged: index and staged database live on different devices");
+// seq != nullptr: the claim / count kernel of the sequence first (mfx_index_build_for_hist_staged); nullptr: the staged database alone, into side
+// `side` of a table whose k-mers are there or claimed already (mfx_index_load_db_staged)
+static int staged_load(mfx_index *ix, const mfx_seq *seq, mfx_db_stage *S, int side, uint64_t minV, uint64_t maxV, const char *who) {
+  if (ix->device != S->device) return mfx_fail(MFX_E_INVAL, "%s: index and staged database live on different devices", who);
   if (S->info.k != ix->k) return mfx_fail(MFX_E_INVAL, "'%s' holds %d-mers but the index is built for k=%d", S->path.c_str(), S->info.k, ix->k);
-  if (ix->wide()) return mfx_fail(MFX_E_INVAL, "mfx_index_build_for_hist_staged: k <= 31 only");
+  if (ix->wide()) return mfx_fail(MFX_E_INVAL, "%s: k <= 31 only", who);
   const bool timing = getenv("MFX_INGEST_TIMING") != nullptr;
   const double t0 = stage_now();
-  int rc = set_read_filter(ix, minV, maxV);
+  int rc = side == 0 ? set_read_filter(ix, minV, maxV) : MFX_OK;
   if (rc) return rc;
   DevGuard g(ix->device);
   hipStream_t is[MFX_INGEST_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
@@ -1231,10 +1232,12 @@ extern "C" int mfx_index_build_for_hist_staged(mfx_index *ix, const mfx_seq *seq
   for (auto &st : is) STAGED_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   STAGED_HIP(hipEventCreateWithFlags(&counted, hipEventDisableTiming));
   // the claim / count kernel on the first insert stream; every insert stream waits for it
-  rc = index_count(ix, seq, 1, is[0], "mfx_index_build_for_hist_staged", false, /*no_wait=*/true);
-  if (rc) { release(); return rc; }
-  STAGED_HIP(hipEventRecord(counted, is[0]));
-  for (int i = 1; i < MFX_INGEST_STREAMS; ++i) STAGED_HIP(hipStreamWaitEvent(is[i], counted, 0));
+  if (seq) {
+    rc = index_count(ix, seq, 1, is[0], who, false, /*no_wait=*/true);
+    if (rc) { release(); return rc; }
+    STAGED_HIP(hipEventRecord(counted, is[0]));
+    for (int i = 1; i < MFX_INGEST_STREAMS; ++i) STAGED_HIP(hipStreamWaitEvent(is[i], counted, 0));
+  }
   ix->frozen = true;
   const double t1 = stage_now();
   double t_wait = 0;
@@ -1249,8 +1252,8 @@ extern "C" int mfx_index_build_for_hist_staged(mfx_index *ix, const mfx_seq *seq
     hipStream_t st = is[c % MFX_INGEST_STREAMS];
     STAGED_HIP(hipStreamWaitEvent(st, ch.copied, 0));
     const uint64_t nb = ch.b1 - ch.b0, m = std::min<uint64_t>(S->info.n - ch.b0 * MFX_DELTA_BLOCK, nb * MFX_DELTA_BLOCK);
-    STAGED_HIP(S->info.placed ? mfx_k_table_add_placed(ix->view(), reinterpret_cast<const uint64_t *>(S->d_payload), S->d_dir + 2 * ch.b0, (uint32_t)nb, m, S->off0, 0, ix->d_meta, st)
-                              : mfx_k_table_add_delta(ix->view(), reinterpret_cast<const uint64_t *>(S->d_payload), S->d_dir + 2 * ch.b0, (uint32_t)nb, m, S->off0, 0, ix->d_meta, st));
+    STAGED_HIP(S->info.placed ? mfx_k_table_add_placed(ix->view(), reinterpret_cast<const uint64_t *>(S->d_payload), S->d_dir + 2 * ch.b0, (uint32_t)nb, m, S->off0, side, ix->d_meta, st)
+                              : mfx_k_table_add_delta(ix->view(), reinterpret_cast<const uint64_t *>(S->d_payload), S->d_dir + 2 * ch.b0, (uint32_t)nb, m, S->off0, side, ix->d_meta, st));
   }
   // the escapes, from the staged copy: an ordinary update of (k-mer, count) arrays that are already on the device
   while (!S->esc_ready.load(std::memory_order_acquire)) {
@@ -1259,7 +1262,7 @@ extern "C" int mfx_index_build_for_hist_staged(mfx_index *ix, const mfx_seq *seq
   }
   if (S->info.n_escape) {
     STAGED_HIP(hipStreamWaitEvent(is[0], S->esc_copied, 0));
-    STAGED_HIP(mfx_k_table_add(ix->view(), S->d_esc_k, S->d_esc_v, S->info.n_escape, 0, ix->d_meta, is[0]));
+    STAGED_HIP(mfx_k_table_add(ix->view(), S->d_esc_k, S->d_esc_v, S->info.n_escape, side, ix->d_meta, is[0]));
   }
   const double t2 = stage_now();
   for (auto &st : is) STAGED_HIP(hipStreamSynchronize(st));
@@ -1282,6 +1285,17 @@ extern "C" int mfx_index_build_for_hist_staged(mfx_index *ix, const mfx_seq *seq
               ph ? "after" : "before", (unsigned long)S->n_part[ph], S->b_part[ph] / 1e9, S->t_part[ph][0], S->t_part[ph][1],
               S->t_part[ph][1] > 0 ? S->b_part[ph] / 1e9 / S->t_part[ph][1] : 0.0, S->t_part[ph][2]);
   return rc;
+}
+
+extern "C" int mfx_index_build_for_hist_staged(mfx_index *ix, const mfx_seq *seq, mfx_db_stage *S, uint64_t minV, uint64_t maxV) {
+  if (!ix || !seq || !S) return mfx_fail(MFX_E_INVAL, "mfx_index_build_for_hist_staged: null argument");
+  return staged_load(ix, seq, S, 0, minV, maxV, "mfx_index_build_for_hist_staged");
+}
+// mfx_index_load_db of a STAGED database: its bytes have been on their way into device memory since mfx_db_stage_begin; only the decode +
+// insert kernels are left (side 0: -readmers with the -min/-max filter, 1: -seqmers).  Same table as mfx_index_load_db.
+extern "C" int mfx_index_load_db_staged(mfx_index *ix, mfx_db_stage *S, int side, uint64_t minV, uint64_t maxV) {
+  if (!ix || !S || (side != 0 && side != 1)) return mfx_fail(MFX_E_INVAL, "mfx_index_load_db_staged: null argument or side not 0 / 1");
+  return staged_load(ix, nullptr, S, side, minV, maxV, "mfx_index_load_db_staged");
 }
 
 // P (mfx_place.h) of n k-mers -- canonicalised first --: on_device != 0: both arrays are device pointers on `device` (tools that sort a
@@ -1463,8 +1477,14 @@ int mfx_seq_digest32(const mfx_seq *s, uint32_t *out) {
   return MFX_OK;
 }
 
+thread_local bool t_mfx_path_lookup = false;     // set by the variant modes around the lookups of THEIR path text (mfx_variants.cpp)
 int mfx_check_seq_of_index(const mfx_index *ix, const mfx_seq *s, const char *who) {
   if (!ix->seq_only || ix->seq_digest == 0) return MFX_OK;
+  if (ix->paths_token) {
+    if (t_mfx_path_lookup) return MFX_OK;
+    return mfx_fail(MFX_E_INVAL, "%s: this index holds the k-mers of a variant call set's PATHS (mfx_index_claim_paths) and answers the variant modes of that "
+                    "call set only; build the index from the sequence (mfx_index_create_for_seq) or use a full index", who);
+  }
   uint32_t d = 0;
   if (int rc = mfx_seq_digest32(s, &d)) return rc;
   if (d != ix->seq_digest)
@@ -3988,7 +4008,7 @@ int mfx_score_paths(mfx_eval *ev, const char *text, uint64_t len, const mfx_path
   int canon = 0;
   int rc = index_canonical(ev->ix, &canon);
   if (rc) return rc;
-  if (ev->ix->seq_only) return mfx_fail(MFX_E_INVAL, "mfx_score_paths: a sequence-only index holds the k-mers of one sequence; alternative paths need the full index");
+  if (ev->ix->seq_only && !ev->ix->paths_token) return mfx_fail(MFX_E_INVAL, "mfx_score_paths: a sequence-only index holds the k-mers of one sequence; alternative paths need the full index (or the path-only one: mfx_index_claim_paths)");
   DevBuf<uint32_t> dr, da, dlen, dnv, dvidx, dvlen, dnum;
   DevBuf<int32_t> dgt;
   DevBuf<uint64_t> ds, doff, dvoff, dcf;
@@ -4044,7 +4064,7 @@ int mfx_score_paths(mfx_eval *ev, const char *text, uint64_t len, const mfx_path
 int mfx_score_paths_trv(mfx_eval *ev, const char *text, uint64_t len, const mfx_path_table *pt, const mfx_trv_batch *tb, int need_dk, uint32_t *numM, double *totdk) {
   if (!ev || !pt || !tb || (len && !text) || !numM || (need_dk && !totdk) || (tb->ncl && (!tb->cl || !tb->var || !tb->al || !tb->np || !tb->status || !tb->p_len || !tb->gt)))
     return mfx_fail(MFX_E_INVAL, "mfx_score_paths_trv: null argument");
-  if (ev->ix->seq_only) return mfx_fail(MFX_E_INVAL, "mfx_score_paths: a sequence-only index holds the k-mers of one sequence; alternative paths need the full index");
+  if (ev->ix->seq_only && !ev->ix->paths_token) return mfx_fail(MFX_E_INVAL, "mfx_score_paths: a sequence-only index holds the k-mers of one sequence; alternative paths need the full index (or the path-only one: mfx_index_claim_paths)");
   const uint64_t hp = pt->npaths, hv = pt->nvals, NP = hp + tb->path_cap, NV = hv + tb->row_cap;
   const uint64_t total = std::max<uint64_t>(tb->text_end, len);
   if (NP == 0 || total == 0) return MFX_OK;
@@ -4146,6 +4166,86 @@ int mfx_score_paths_trv(mfx_eval *ev, const char *text, uint64_t len, const mfx_
     if (tb->row_cap) MFX_HIP(hipMemcpy(tb->gt, dgt.p + hv, tb->row_cap * 4, hipMemcpyDeviceToHost));
   }
   return MFX_OK;
+}
+
+int mfx_claim_paths_batch(mfx_index *ix, uint8_t **scratch, uint64_t *scratch_bytes, const char *text, uint64_t len, const mfx_trv_batch *tb, uint64_t *bad) {
+  if (!ix || !scratch || !scratch_bytes || (len && !text) || (tb && tb->ncl && (!tb->cl || !tb->var || !tb->al || !tb->status)))
+    return mfx_fail(MFX_E_INVAL, "mfx_index_claim_paths: null argument");
+  if (!ix->seq_only || ix->wide()) return mfx_fail(MFX_E_INVAL, "mfx_index_claim_paths: not a sequence-only index of k <= %d (mfx_index_create_for_seq)", MFX_MAX_K_NARROW);
+  if (ix->frozen) return mfx_fail(MFX_E_INVAL, "mfx_index_claim_paths: this index already took counts; its k-mers must all be claimed before the first add / load");
+  if (bad) *bad = 0;
+  const uint64_t ncl = tb ? tb->ncl : 0, NP = tb ? tb->path_cap : 0, NV = tb ? tb->row_cap : 0;
+  const uint64_t total = std::max<uint64_t>(tb ? tb->text_end : 0, len);
+  if (total == 0) return MFX_OK;
+  DevGuard g(ix->device);
+  const uint64_t ntiles = (total + MFX_TILE - 1) / MFX_TILE;
+  const uint64_t text_bytes = (ntiles + 2) * MFX_TILE + 256;          // (the tile loads of the claim kernel reach a tile past the end)
+  uint64_t need = 0;
+  auto piece = [&](uint64_t bytes) { const uint64_t at = need; need += (bytes + 255) & ~255ull; return at; };
+  const uint64_t o_text = piece(text_bytes), o_geo = piece(4 * 8), o_off = piece((NP ? NP : 1) * 8), o_len = piece((NP ? NP : 1) * 4), o_nv = piece((NP ? NP : 1) * 4),
+                 o_voff = piece((NP ? NP : 1) * 8), o_cf = piece((NP ? NP : 1) * 8), o_gt = piece((NV ? NV : 1) * 4), o_vidx = piece((NV ? NV : 1) * 4), o_vlen = piece((NV ? NV : 1) * 4),
+                 o_cl = piece((ncl ? ncl : 1) * sizeof(mfx_trv_cluster)), o_var = piece((tb ? tb->nvar : 0) * sizeof(mfx_trv_variant) + 8),
+                 o_all = piece((tb ? tb->nal : 0) * sizeof(mfx_trv_allele) + 8), o_win = piece((tb ? tb->win_bytes : 0) + 8), o_alt = piece((tb ? tb->al_bytes : 0) + 8),
+                 o_np = piece((ncl ? ncl : 1) * 4), o_st = piece((ncl ? ncl : 1) * 4);
+  if (need > *scratch_bytes) {
+    if (*scratch) { (void)hipFree(*scratch); *scratch = nullptr; *scratch_bytes = 0; }
+    const uint64_t want = need + need / 4;
+    if (hipMalloc((void **)scratch, want) != hipSuccess) { (void)hipGetLastError(); *scratch = nullptr; return mfx_fail(MFX_E_NOMEM, "mfx_index_claim_paths: no device memory for a batch of paths (%.1f GB)", want / 1e9); }
+    *scratch_bytes = want;
+  }
+  uint8_t *const B = *scratch;
+  hipStream_t st = nullptr;
+  MFX_HIP(mfx_memset_now(B + o_text + len, '\n', text_bytes - len));
+  if (len) MFX_HIP(hipMemcpyAsync(B + o_text, text, len, hipMemcpyHostToDevice, st));
+  const uint64_t geo[4] = {0, total, 0, ntiles};                        // contig_off[1], contig_len[1], tile_start[2] of the one contig the text is
+  MFX_HIP(hipMemcpyAsync(B + o_geo, geo, sizeof(geo), hipMemcpyHostToDevice, st));
+  if (ncl) {
+    MFX_HIP(hipMemcpyAsync(B + o_cl, tb->cl, ncl * sizeof(mfx_trv_cluster), hipMemcpyHostToDevice, st));
+    MFX_HIP(hipMemcpyAsync(B + o_var, tb->var, tb->nvar * sizeof(mfx_trv_variant), hipMemcpyHostToDevice, st));
+    if (tb->nal) MFX_HIP(hipMemcpyAsync(B + o_all, tb->al, tb->nal * sizeof(mfx_trv_allele), hipMemcpyHostToDevice, st));
+    if (tb->win_bytes) MFX_HIP(hipMemcpyAsync(B + o_win, tb->win_text, tb->win_bytes, hipMemcpyHostToDevice, st));
+    if (tb->al_bytes) MFX_HIP(hipMemcpyAsync(B + o_alt, tb->al_text, tb->al_bytes, hipMemcpyHostToDevice, st));
+    mfx_trv_out o;
+    o.text = reinterpret_cast<char *>(B + o_text);
+    o.p_off = reinterpret_cast<uint64_t *>(B + o_off); o.p_voff = reinterpret_cast<uint64_t *>(B + o_voff); o.p_cfirst = reinterpret_cast<uint64_t *>(B + o_cf);
+    o.p_len = reinterpret_cast<uint32_t *>(B + o_len); o.p_nv = reinterpret_cast<uint32_t *>(B + o_nv);
+    o.gt = reinterpret_cast<int32_t *>(B + o_gt); o.vidx = reinterpret_cast<uint32_t *>(B + o_vidx); o.vlen = reinterpret_cast<uint32_t *>(B + o_vlen);
+    o.table_base = 0; o.row_base = 0;
+    MFX_HIP(mfx_k_var_traverse(reinterpret_cast<const mfx_trv_cluster *>(B + o_cl), ncl, reinterpret_cast<const mfx_trv_variant *>(B + o_var),
+                               reinterpret_cast<const mfx_trv_allele *>(B + o_all), reinterpret_cast<const char *>(B + o_win), reinterpret_cast<const char *>(B + o_alt), o,
+                               reinterpret_cast<uint32_t *>(B + o_np), reinterpret_cast<uint32_t *>(B + o_st), st));
+  }
+  mfx_count_args a;
+  a.t = ix->view();
+  a.bases = B + o_text;
+  const uint64_t *geo_d = reinterpret_cast<const uint64_t *>(B + o_geo);
+  a.contig_off = geo_d; a.contig_len = geo_d + 1; a.tile_start = geo_d + 2;
+  a.ncontigs = 1;
+  a.ntiles = ntiles;
+  a.meta = ix->d_meta;
+  a.count = 0;
+  MFX_HIP(mfx_k_count(a, st));
+  if (ncl) {
+    MFX_HIP(hipMemcpy(tb->status, B + o_st, ncl * 4, hipMemcpyDeviceToHost));
+    uint64_t nb = 0;
+    for (uint64_t c = 0; c < ncl; ++c) nb += tb->status[c] != MFX_TRV_OK;
+    if (bad) *bad = nb;
+  } else MFX_HIP(hipStreamSynchronize(st));                             // (the host's text may go once this returns)
+  return MFX_OK;
+}
+int mfx_claim_paths_finish(mfx_index *ix, uint64_t token) {
+  if (!ix) return mfx_fail(MFX_E_INVAL, "mfx_index_claim_paths: null argument");
+  DevGuard g(ix->device);
+  MFX_HIP(hipDeviceSynchronize());
+  if (int rc = index_check(ix)) return rc;
+  ix->paths_token = token ? token : 1;
+  ix->seq_digest = (uint32_t)(token >> 32) | 0x80000000u;              // (no sequence's k-mers: -hist / -dump of a sequence on this index are refused, mfx_check_seq_of_index)
+  return MFX_OK;
+}
+void mfx_claim_paths_release(int device, uint8_t *scratch) {
+  if (!scratch) return;
+  DevGuard g(device);
+  (void)hipFree(scratch);
 }
 
 extern "C" int mfx_dump_values_sharded(mfx_eval *const *evs, const mfx_seq *const *seqs, uint32_t nslots, uint32_t contig,

@@ -166,6 +166,7 @@ struct mfx_index {
   bool      quot = false;       // compact, k > 21: quotient form of the key field
   bool      frozen = false;     // an add / load happened: no more claims
   uint64_t  side_nlines = 0;    // compact: lines of the side table, which follows the nlines main lines in d_slots
+  uint64_t  paths_token = 0;    // seq_only: the k-mers are those of a prepared VCF's PATHS (mfx_index_claim_paths), not a sequence's: the token of that call set
   uint32_t  seq_digest = 0;     // seq_only: content digest of the sequence the k-mers were claimed from (0: not recorded);
                                 // evaluating another sequence on it is refused (mfx_seq_digest32, mfx_api.cpp)
   uint64_t  total_lines() const { return nlines + side_nlines; }
@@ -203,6 +204,7 @@ struct mfx_seq {
 int mfx_seq_digest32(const mfx_seq *s, uint32_t *out);
 // refuses (MFX_E_INVAL) the evaluation of a sequence other than the one a sequence-only index was claimed from
 int mfx_check_seq_of_index(const mfx_index *ix, const mfx_seq *s, const char *who);
+extern thread_local bool t_mfx_path_lookup;       // the calling thread looks the variant modes' own path text up: a path-only index answers (mfx_api.cpp)
 
 // The paths of a batch of variant clusters inside their packed text, for the device-side varMer::score (mfx_api.cpp:
 // mfx_score_paths; kernel mfx_var_score_kernel): host arrays
@@ -239,6 +241,14 @@ struct mfx_trv_batch {
   int32_t *gt = nullptr;                         // [row_cap] out: the genotype rows
 };
 int mfx_score_paths_trv(mfx_eval *ev, const char *text, uint64_t len, const mfx_path_table *pt, const mfx_trv_batch *tb, int need_dk, uint32_t *numM, double *totdk);
+
+// The PATH-ONLY index of the variant modes (mfx_index_claim_paths, mfx_variants.cpp): a batch's text is put together on the device exactly as
+// mfx_score_paths_trv does -- the host's paths copied in, the other clusters enumerated by the traverse kernel -- and the claim kernel of
+// mfx_index_claim_seq runs over it as over ONE contig (every path is followed by '\n': no k-mer spans two).  `scratch`: the caller's device
+// buffer, grown here, released with mfx_claim_paths_release; *bad: clusters the device could not enumerate (tb->status comes back).
+int  mfx_claim_paths_batch(mfx_index *ix, uint8_t **scratch, uint64_t *scratch_bytes, const char *text, uint64_t len, const mfx_trv_batch *tb, uint64_t *bad);
+int  mfx_claim_paths_finish(mfx_index *ix, uint64_t token);          // waits, checks the table, binds the index to the prepared call set `token`
+void mfx_claim_paths_release(int device, uint8_t *scratch);
 
 int mfx_seq_partial_error(const mfx_seq *s, const char *who);     // MFX_E_INVAL: the sequence object holds a part only
 int mfx_seq_ensure_ascii(const mfx_seq *s);      // unpacks the planes into d_bases if a packed upload left them newer (mfx_api.cpp)

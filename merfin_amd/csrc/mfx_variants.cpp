@@ -766,6 +766,7 @@ struct VarPrepared {
   std::string head_log, tail_log;   // clustering's lines; what was logged after the last batch was queued
   std::deque<VarBatch> batches;
   double t_phase[3] = {0, 0, 0};    // cluster, enumerate, pack (seconds; diagnostics)
+  uint64_t token = 0;               // of this prepared call set, unique in the process: what a path-only index that claimed its paths is bound to (mfx_index_claim_paths)
 };
 
 // dynamic parallel-for over [0, n) on the host threads the library may use
@@ -1026,8 +1027,14 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
     return mfx_fail(MFX_E_INVAL, "mfx_variants_run: null argument");
   const int mode = opts->mode;
   if (mode < MFX_VAR_FILTER || mode > MFX_VAR_LOOSE) return mfx_fail(MFX_E_INVAL, "mfx_variants_run: unknown mode %d", mode);
-  if (!prepare_only && ev->ix->seq_only)      // the alternative paths ask for k-mers the sequence does not hold (varMer.C:76-84)
-    return mfx_fail(MFX_E_INVAL, "mfx_variants_run: a sequence-only index holds the k-mers of one sequence; the variant modes need a full index (mfx_index_create)");
+  // the alternative paths ask for k-mers the sequence does not hold (varMer.C:76-84): a sequence-only index answers them only if it claimed
+  // exactly THESE paths (mfx_index_claim_paths on the prepared call set that is run here)
+  const bool path_index = !prepare_only && ev->ix->seq_only && ev->ix->paths_token != 0;
+  if (!prepare_only && ev->ix->seq_only && !(path_index && loaded && loaded->prep && loaded->prep->token == ev->ix->paths_token))
+    return mfx_fail(MFX_E_INVAL, path_index ? "mfx_variants_run: this path-only index claimed the paths of ANOTHER prepared call set (mfx_index_claim_paths); it answers "
+                                               "mfx_variants_run_vcf on that handle only"
+                                            : "mfx_variants_run: a sequence-only index holds the k-mers of one sequence; the variant modes need a full index (mfx_index_create) "
+                                              "or the path-only one of their call set (mfx_vcf_prepare + mfx_index_claim_paths)");
   const uint32_t K = prepare_only ? prepK : (uint32_t)ev->ix->k;
   const uint32_t comb = opts->comb ? opts->comb : 15;
   // a prepared VCF: its stage A was run for one k / -comb / -nosplit and one set of sequences
@@ -1398,6 +1405,8 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
       // or more than the room reserved): the whole batch is enumerated on the host, as without the device's traverse
       bool redo = false;
       for (uint32_t st : bt.t_status) redo = redo || st != MFX_TRV_OK;
+      if (redo && path_index)                                           // (mfx_index_claim_paths refuses such a call set: never reached)
+        return mfx_fail(MFX_E_INVAL, "mfx_variants_run: a cluster must be enumerated on the host, whose paths this path-only index did not claim");
       if (redo) {
         stage_a(bt, true, true);
         int r = stage_b(bt, nullptr);
@@ -1594,6 +1603,14 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
   if (rc == MFX_OK) rc = flush();
   if (making) {
     making->tail_log = take_log();
+    {
+      static std::atomic<uint64_t> prepared_sets{0};
+      uint64_t h = 0xcbf29ce484222325ULL;
+      auto mix = [&](uint64_t x) { h ^= x; h *= 0x100000001b3ULL; };
+      mix(K); mix(comb); mix(making->nosplit);
+      for (const VarBatch &b : batches) { mix(b.jobs.size()); mix(b.packed.size()); mix(b.t_text_end); mix(b.t_path_cap); }
+      making->token = ((prepared_sets.fetch_add(1) + 1) << 32) | (h & 0xffffffffu);
+    }
     making->t_phase[0] = t_phase[0]; making->t_phase[1] = t_phase[1]; making->t_phase[2] = t_phase[2];
     if (timing) fprintf(stderr, "[mfx_variants] prepared ahead: cluster %.2fs  enumerate %.2fs  pack %.2fs  (%zu batches)\n", t_phase[0], t_phase[1], t_phase[2],
                         batches.size() - 1);
@@ -1640,6 +1657,7 @@ extern "C" int mfx_variants_run(mfx_eval *ev, const char *vcf_path, const char *
   PathValues values = [ev](const char *text, uint64_t len, uint32_t *rv, uint32_t *av) -> int {
     mfx_seq *ps = mfx_seq_upload(ev->device, &text, &len, 1);
     if (!ps) return mfx_last_error_code();
+    struct PathLookup { PathLookup() { t_mfx_path_lookup = true; } ~PathLookup() { t_mfx_path_lookup = false; } } pathLookup;   // (a path-only index answers this text)
     int r = mfx_dump_values(ev, ps, 0, 0, len, rv, av, nullptr, nullptr);
     mfx_seq_free(ps);
     return r;
@@ -1688,6 +1706,51 @@ extern "C" int mfx_vcf_prepare(mfx_vcf *vcf, int k, const char *const *names, co
   });
 }
 
+// The PATH-ONLY index of the variant modes.  -filter / -polish / -better / -loose ask the lookup tables for the k-mers of the enumerated
+// paths and for nothing else (varMer::score, varMer.C:76-84; the reference loads both databases whole, merfin-globals.C:114-163): a prepared call
+// set (mfx_vcf_prepare) knows those paths before any database is read, so a sequence-only index claims exactly their k-mers and both databases
+// then only UPDATE them -- a few hundred million slots instead of every read k-mer (3 Gb human, 3.8 M calls: a table of ~25 GB instead of 216).
+// mfx_vcf_path_bound: the k-mer positions of all batches' text (an upper bound of the distinct k-mers: the capacity of the index);
+// mfx_index_claim_paths: every batch's text is made on the device as the run will make it and claimed; the index is then bound to this handle
+// (another call set, or a sequence's -hist / -dump, are refused).  A cluster the device cannot enumerate makes the call fail: use the full index.
+extern "C" int mfx_vcf_path_bound(const mfx_vcf *vcf, uint64_t *positions) {
+  if (!vcf || !positions) return mfx_fail(MFX_E_INVAL, "mfx_vcf_path_bound: null argument");
+  if (!vcf->prep) return mfx_fail(MFX_E_INVAL, "mfx_vcf_path_bound: the VCF is not prepared (mfx_vcf_prepare)");
+  uint64_t n = 0;
+  for (const VarBatch &b : vcf->prep->batches) n += std::max<uint64_t>(b.t_text_end, b.packed.size());
+  *positions = n;
+  return MFX_OK;
+}
+extern "C" int mfx_index_claim_paths(mfx_index *ix, mfx_vcf *vcf, uint64_t *n_positions) {
+  if (!ix || !vcf) return mfx_fail(MFX_E_INVAL, "mfx_index_claim_paths: null argument");
+  VarPrepared *prep = vcf->prep;
+  if (!prep) return mfx_fail(MFX_E_INVAL, "mfx_index_claim_paths: the VCF is not prepared (mfx_vcf_prepare)");
+  if (vcf->used) return mfx_fail(MFX_E_INVAL, "mfx_index_claim_paths: the prepared VCF was run already");
+  if ((uint32_t)ix->k != prep->k) return mfx_fail(MFX_E_INVAL, "mfx_index_claim_paths: the VCF was prepared for k = %u, the index holds %d-mers", prep->k, ix->k);
+  return variants_guarded("mfx_index_claim_paths", [&]() -> int {
+    uint8_t *scratch = nullptr;
+    uint64_t scratch_bytes = 0, positions = 0;
+    struct Release { int dev; uint8_t *&p; ~Release() { mfx_claim_paths_release(dev, p); } } release{ix->device, scratch};
+    for (VarBatch &b : prep->batches) {
+      if (b.jobs.empty()) continue;
+      mfx_trv_batch tb;
+      if (!b.t_cl.empty()) {
+        tb.ncl = b.t_cl.size(); tb.nvar = b.t_var.size(); tb.nal = b.t_al.size(); tb.win_bytes = b.t_win.size(); tb.al_bytes = b.t_alt.size();
+        tb.cl = b.t_cl.data(); tb.var = b.t_var.data(); tb.al = b.t_al.data(); tb.win_text = b.t_win.data(); tb.al_text = b.t_alt.data();
+        tb.text_end = b.t_text_end; tb.path_cap = b.t_path_cap; tb.row_cap = b.t_row_cap;
+        tb.np = b.t_np.data(); tb.status = b.t_status.data(); tb.p_len = b.t_plen.data(); tb.gt = b.t_gt.data();
+      }
+      uint64_t bad = 0;
+      if (int rc = mfx_claim_paths_batch(ix, &scratch, &scratch_bytes, b.packed.data(), b.packed.size(), b.t_cl.empty() ? nullptr : &tb, &bad)) return rc;
+      if (bad) return mfx_fail(MFX_E_INVAL, "mfx_index_claim_paths: %lu clusters of the call set cannot be enumerated on the device (their paths are made on the host "
+                                            "during the run); use the full index (mfx_index_create)", (unsigned long)bad);
+      positions += std::max<uint64_t>(b.t_text_end, b.packed.size());
+    }
+    if (n_positions) *n_positions = positions;
+    return mfx_claim_paths_finish(ix, prep->token);
+  });
+}
+
 extern "C" int mfx_variants_run_vcf(mfx_eval *ev, mfx_vcf *vcf, const char *const *names, const char *const *bases,
                                     const uint64_t *lens, uint32_t ncontigs, const mfx_variant_opts *opts,
                                     const char *out_path, const char *log_path, uint64_t *n_clusters) {
@@ -1695,6 +1758,7 @@ extern "C" int mfx_variants_run_vcf(mfx_eval *ev, mfx_vcf *vcf, const char *cons
   PathValues values = [ev](const char *text, uint64_t len, uint32_t *rv, uint32_t *av) -> int {
     mfx_seq *ps = mfx_seq_upload(ev->device, &text, &len, 1);
     if (!ps) return mfx_last_error_code();
+    struct PathLookup { PathLookup() { t_mfx_path_lookup = true; } ~PathLookup() { t_mfx_path_lookup = false; } } pathLookup;   // (a path-only index answers this text)
     int r = mfx_dump_values(ev, ps, 0, 0, len, rv, av, nullptr, nullptr);
     mfx_seq_free(ps);
     return r;

@@ -178,6 +178,42 @@ def test_cli_variant_modes(tmp_path, mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seqmers", [True, False])
+@pytest.mark.parametrize("k", [21, 27])
+def test_cli_variant_modes_on_the_path_only_index(tmp_path, seqmers, k):
+    """one slot on one device builds the PATH-ONLY index (the call set prepared first, its paths' k-mers claimed, both databases update-only;
+    without -seqmers the assembly side is counted over the uploaded sequence): the records of the oracle and of the full tables
+    (MFX_CLI_PATH_INDEX=0), byte for byte"""
+    import merfin_amd as m
+    peak = 17.3
+    names, asm, vcf, read, amers = synth.variant_world(k=k, peak=peak, seed=62)
+    vp = str(tmp_path / "in.vcf")
+    open(vp, "w").write(vcf)
+    p = po.Params(k, peak)
+    R, A = po.Lookup(k, *read), po.Lookup(k, *amers)
+    po.variants_run(p, R, A, "polish", vp, names, asm, str(tmp_path / "o.vcf"))
+    fa = str(tmp_path / "asm.fasta")
+    with open(fa, "wb") as f:
+        for n, c in zip(names, asm):
+            f.write(b">" + n.encode() + b"\n" + c + b"\n")
+    m.db_write_flat(str(tmp_path / "read.mfxk"), k, *read)
+    m.db_write_flat(str(tmp_path / "asm.mfxk"), k, *amers)
+    args = ["-polish", "-sequence", fa, "-readmers", str(tmp_path / "read.mfxk"), "-vcf", vp, "-peak", str(peak)]
+    if seqmers:
+        args += ["-seqmers", str(tmp_path / "asm.mfxk")]
+    r = run(args + ["-output", str(tmp_path / "path")])
+    assert r.returncode == 0, r.stderr
+    assert "Claiming the %d-mers of the variants' paths" % k in r.stderr
+    r2 = run(args + ["-output", str(tmp_path / "full")], env=dict(os.environ, MFX_CLI_PATH_INDEX="0"))
+    assert r2.returncode == 0, r2.stderr
+    assert "variants' paths" not in r2.stderr
+    want = (tmp_path / "o.vcf").read_text()
+    assert (tmp_path / "path.polish.vcf").read_text() == want
+    assert (tmp_path / "full.polish.vcf").read_text() == want
+    assert len([l for l in want.splitlines() if not l.startswith("#")]) > 20
+
+
+@pytest.mark.gpu
 def test_cli_fastq_input_and_lowercase(tmp_path):
     """-sequence may be FASTQ (merfin.C:195); quality lines must not be parsed as bases."""
     import merfin_amd as m

@@ -87,6 +87,27 @@ if len(sys.argv) > 3 and sys.argv[3] == "cli":
         for nm, a in zip(names, asm):
             f.write(b">" + nm.encode() + b"\n" + a + b"\n")
     torch.cuda.empty_cache()
+    if os.environ.get("MFX_CFG4_PATH_AB"):
+        # the PATH-ONLY index (the default of one slot: the call set prepared first, its paths' k-mers claimed, both databases staged and
+        # update-only) against the full tables (MFX_CLI_PATH_INDEX=0), alternating; the records must be the same bytes
+        ref_out = None
+        for rep, pi in enumerate(os.environ["MFX_CFG4_PATH_AB"].split(",")):
+            time.sleep(float(os.environ.get("MFX_CFG4_SLEEP", "0")))
+            t0 = time.time()
+            r = subprocess.run([exe, "-polish", "-sequence", out + "/asm.fasta", "-readmers", out + "/read.mfxk", "-seqmers", out + "/asm.mfxk", "-peak", str(lam),
+                                "-vcf", vcf, "-output", out + "/cli_p" + pi], capture_output=True, text=True,
+                               env=dict(os.environ, MFX_CLI_TIMING="2", MFX_VAR_TIMING="1", MFX_INGEST_TIMING="1", MFX_CLI_PATH_INDEX=pi))
+            dt = time.time() - t0
+            data = open(out + "/cli_p" + pi + ".polish.vcf").read() if r.returncode == 0 else ""
+            if ref_out is None:
+                ref_out = data
+            print("merfin -polish MFX_CLI_PATH_INDEX=%s (%s): rc=%d wall=%.2fs same=%s %d bytes" % (pi, "path-only index" if pi == "1" else "full tables", r.returncode, dt,
+                                                                                                data == ref_out, len(data)), flush=True)
+            print("    " + "\n    ".join(l for l in r.stderr.splitlines() if "timing" in l or "ERROR" in l or "Memory needed" in l or "staged build" in l or "stager " in l and "sequence was in" in l
+                                          or "mfx_variants]" in l and "load:" not in l))
+        api = open(out + "/out.polish.vcf").read()
+        print("API -polish on the full index == the CLI's records: %s" % (api == ref_out))
+        sys.exit(0)
     for devs in ("0", "0,0,0,0,0,0,0,0"):
         time.sleep(float(os.environ.get("MFX_CFG4_SLEEP", "0")))
         t0 = time.time()
