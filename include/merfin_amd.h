@@ -64,6 +64,9 @@ int         mfx_device_count(void);
 /* Optional (no reference counterpart): bring the device's context, this library's code object and the pinned-memory path up
  * now -- what the first upload would otherwise pay (~0.07 s) -- e.g. on a helper thread while the caller reads its FASTA. */
 int         mfx_device_warm(int device);
+/* free / total device memory in bytes (hipMemGetInfo): what a caller sizes its choice of index by (`merfin` takes the path-only index of the
+ * variant modes when the full tables would not fit) */
+int         mfx_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes);
 
 /* ------------------------------------------------------------------------ */
 /* Index: replaces the two merylExactLookup objects readLookup / asmLookup  */
@@ -576,6 +579,12 @@ int mfx_vcf_prepare(mfx_vcf *vcf, int k, const char *const *names, const char *c
  * return MFX_E_NONCANON as for every sequence-only index (build the full one). */
 int mfx_vcf_path_bound(const mfx_vcf *vcf, uint64_t *positions);
 int mfx_index_claim_paths(mfx_index *ix, mfx_vcf *vcf, uint64_t *n_positions);
+/* The three steps above as ONE pass (what `merfin` does): the table is made as soon as the clusters are merged and every batch's k-mers are
+ * claimed on the device while the host prepares the next batch.  *out: the claimed index, or NULL (with MFX_OK: the handle is prepared and runs
+ * on a full index) when this call set cannot have one -- no memory for the table, a cluster the device cannot enumerate; mfx_last_error says why.
+ * load_factor 0: the library's choice. */
+int mfx_vcf_prepare_path_index(mfx_vcf *vcf, int k, const char *const *names, const char *const *bases, const uint64_t *lens, uint32_t ncontigs,
+                               const mfx_variant_opts *opts, double max_gb, int device, double load_factor, mfx_index **out);
 /* The same over an index sharded across nslots evaluators (slot d = shard d of nslots): every batch of path text is
  * scored by mfx_dump_values_sharded; clustering, enumeration, selectors and output are the code above. */
 int mfx_variants_run_sharded(mfx_eval *const *evs, uint32_t nslots, const char *vcf_path, const char *const *names,

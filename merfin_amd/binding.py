@@ -61,7 +61,7 @@ _lib = None
 
 # every symbol include/merfin_amd.h declares (tests check the .so exports all of them)
 SYMBOLS = [
-    "mfx_last_error", "mfx_last_error_code", "mfx_version", "mfx_device_count", "mfx_device_warm",
+    "mfx_last_error", "mfx_last_error_code", "mfx_version", "mfx_device_count", "mfx_device_warm", "mfx_device_memory",
     "mfx_index_create", "mfx_index_free", "mfx_index_estimate_gb", "mfx_index_add_read", "mfx_index_add_asm",
     "mfx_index_count_asm", "mfx_index_build_for_hist", "mfx_index_count_claimed", "mfx_hist_run_parts", "mfx_index_create_for_seq", "mfx_index_create_for_seq_lf", "mfx_index_create_lf", "mfx_db_stage_begin", "mfx_index_build_for_hist_staged", "mfx_index_load_db_staged", "mfx_db_stage_free", "mfx_db_stage_boost", "mfx_index_estimate_gb_for_seq", "mfx_index_claim_seq", "mfx_index_value", "mfx_index_get_info", "mfx_index_export",
     "mfx_db_probe", "mfx_index_load_db", "mfx_index_load_db_multi", "mfx_db_write_flat", "mfx_db_convert", "mfx_db_convert_placed", "mfx_db_write_flat_placed", "mfx_db_place_keys", "mfx_index_save", "mfx_index_load",
@@ -79,7 +79,7 @@ SYMBOLS = [
     "mfx_eval_create", "mfx_eval_free", "mfx_eval_nbins", "mfx_eval_debug_enable", "mfx_eval_debug_counters", "mfx_getK", "mfx_getKmetric", "mfx_histoQV",
     "mfx_hist_run", "mfx_hist_result_free", "mfx_hist_launch", "mfx_hist_launch_cyclic", "mfx_hist_result_from_counts",
     "mfx_hist_take_overflow", "mfx_hist_report", "mfx_diag_stream_rates",
-    "mfx_pack_bases", "mfx_host_threads_share", "mfx_dump_values", "mfx_dump_contig", "mfx_dump_values_sharded", "mfx_dump_contig_sharded", "mfx_variants_run_sharded", "mfx_vcf_load", "mfx_vcf_free", "mfx_variants_run_vcf", "mfx_vcf_prepare", "mfx_vcf_path_bound", "mfx_index_claim_paths", "mfx_completeness", "mfx_completeness_pieces", "mfx_variants_run",
+    "mfx_pack_bases", "mfx_host_threads_share", "mfx_dump_values", "mfx_dump_contig", "mfx_dump_values_sharded", "mfx_dump_contig_sharded", "mfx_variants_run_sharded", "mfx_vcf_load", "mfx_vcf_free", "mfx_variants_run_vcf", "mfx_vcf_prepare", "mfx_vcf_path_bound", "mfx_index_claim_paths", "mfx_vcf_prepare_path_index", "mfx_completeness", "mfx_completeness_pieces", "mfx_variants_run",
     "mfx_index_set_shard", "mfx_router_create", "mfx_router_free", "mfx_route_tiles", "mfx_hist_keys_launch",
 ]
 
@@ -118,6 +118,7 @@ def load_library():
     L.mfx_last_error_code.restype = C.c_int
     L.mfx_device_count.restype = C.c_int
     L.mfx_device_warm.argtypes = [C.c_int]
+    L.mfx_device_memory.argtypes = [C.c_int, u64p, u64p]
     L.mfx_index_create.restype = vp
     L.mfx_index_create.argtypes = [C.c_int, C.c_uint64, C.c_double, C.c_int]
     L.mfx_index_free.argtypes = [vp]
@@ -222,6 +223,8 @@ def load_library():
     L.mfx_vcf_prepare.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), u64p, C.c_uint32, C.POINTER(_VarOpts)]
     L.mfx_vcf_path_bound.argtypes = [vp, u64p]
     L.mfx_index_claim_paths.argtypes = [vp, vp, u64p]
+    L.mfx_vcf_prepare_path_index.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), u64p, C.c_uint32, C.POINTER(_VarOpts), C.c_double, C.c_int, C.c_double,
+                                             C.POINTER(vp)]
     L.mfx_index_set_fingerprint.argtypes = [vp, C.c_uint64]
     L.mfx_index_get_origin.argtypes = [vp, u64p, u64p, u64p]
     L.mfx_host_threads_share.restype = None
@@ -283,6 +286,13 @@ def device_count():
 def device_warm(device=0):
     """context, code object and pinned-memory path of the device brought up now (mfx_device_warm)"""
     _check(load_library().mfx_device_warm(device))
+
+
+def device_memory(device=0):
+    """(free, total) bytes of the device's memory (mfx_device_memory)"""
+    f, t = C.c_uint64(0), C.c_uint64(0)
+    _check(load_library().mfx_device_memory(device, C.byref(f), C.byref(t)))
+    return f.value, t.value
 
 
 def hist_words(nbins, ncontigs):
@@ -985,6 +995,23 @@ class LoadedVcf:
         lens = np.array([len(c) for c in contigs], dtype=np.uint64)
         o = _VarOpts(VARIANT_MODES[mode], comb, 1 if nosplit else 0, debug_path.encode() if debug_path else None)
         _check(load_library().mfx_vcf_prepare(self.h, int(k), nm, arr, lens.ctypes.data_as(C.POINTER(C.c_uint64)), n, C.byref(o)))
+
+    def prepare_path_index(self, k, mode, names, contigs, comb=15, nosplit=False, debug_path=None, max_gb=0.0, device=0, load_factor=0.0):
+        """prepare + the path-only index in one pass (mfx_vcf_prepare_path_index): the claimed Index (load the databases next), or None when
+        this call set cannot have one (the handle is prepared either way)"""
+        n = len(contigs)
+        nm = (C.c_char_p * n)(*[x.encode() for x in names])
+        arr = (C.c_char_p * n)(*contigs)
+        lens = np.array([len(c) for c in contigs], dtype=np.uint64)
+        o = _VarOpts(VARIANT_MODES[mode], comb, 1 if nosplit else 0, debug_path.encode() if debug_path else None)
+        h = C.c_void_p(None)
+        _check(load_library().mfx_vcf_prepare_path_index(self.h, int(k), nm, arr, lens.ctypes.data_as(C.POINTER(C.c_uint64)), n, C.byref(o), float(max_gb), int(device),
+                                                         float(load_factor), C.byref(h)))
+        if not h.value:
+            return None
+        ix = Index(0, 0, device=device, _handle=h.value)
+        ix.k = int(k)
+        return ix
 
     def path_bound(self):
         """k-mer positions of all path text of the prepared call set: the capacity of its path-only index (mfx_vcf_path_bound)"""

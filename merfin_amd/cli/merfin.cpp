@@ -724,19 +724,7 @@ int main(int argc, char **argv) {
   // moving into device memory NOW, on a thread of their own (mfx_db_stage_begin) -- under the FASTA read, the sequence upload, the
   // table's allocation and the kernel that claims the sequence's k-mers.  Any other database form, too little free memory,
   // MFX_DB_STAGE=0: no stage, the build reads the database when it gets there.
-  // The variant modes ask the lookup tables for the k-mers of the enumerated PATHS and nothing else (varMer::score, varMer.C:76-84): one slot
-  // on one device prepares the call set first (mfx_vcf_prepare: host work), claims exactly those k-mers on a sequence-only index
-  // (mfx_index_claim_paths) and lets both databases update them -- the PATH-ONLY index, a tenth of the full tables (3 Gb, 3.8 M calls:
-  // ~25 GB instead of 216).  Not with -index (the image caches the full tables), k > 31, several slots; MFX_CLI_PATH_INDEX=0 /
-  // MFX_CLI_FULL_INDEX=1: the full tables.
-  bool pathOnly = false;
-  {
-    const char *vs = getenv("MFX_VARIANT_SLOTS");
-    const size_t slots = (vs && atoi(vs) > 0) ? (size_t)atoi(vs) : G.devices.size();
-    const char *pe = getenv("MFX_CLI_PATH_INDEX"), *pa = getenv("MFX_CLI_VCF_AHEAD");
-    pathOnly = variantMode && G.vcfName && G.seqName && slots == 1 && !G.sharded && k <= 31 && !G.indexName && !(pe && atoi(pe) == 0) && !(pa && atoi(pa) == 0) &&
-               !(getenv("MFX_CLI_FULL_INDEX") && atoi(getenv("MFX_CLI_FULL_INDEX")));
-  }
+  bool pathOnly = false;                                            // the variant modes on the path-only index of their call set (decided below)
   mfx_db_stage *stage = nullptr, *stageAsm = nullptr;              // (stageAsm: -seqmers of the path-only index)
   struct StageGuard { mfx_db_stage *&s; ~StageGuard() { if (s) mfx_db_stage_free(s); s = nullptr; } } stageGuard{stage}, stageAsmGuard{stageAsm};
   // (MFX_CLI_STAGE_FIRST=0: the stage begins after the device is warmed up.  Measured, profiles/r05_stager_diag.txt: the warm-up then takes
@@ -748,7 +736,10 @@ int main(int argc, char **argv) {
     const bool histLike = (G.reportType == OP_HIST || G.reportType == OP_DUMP) && !G.sharded && k <= 31 && G.seqName && !G.seqDBname && !G.indexName &&
                           G.devices.size() == 1 && !(getenv("MFX_CLI_FULL_INDEX") && atoi(getenv("MFX_CLI_FULL_INDEX")));
     if (histLike && rdb.format == MFX_DB_FLAT) stage = mfx_db_stage_begin(G.readDBname, G.device);
-    // the path-only index of the variant modes: both databases move while the sequences and the VCF are read and the call set is prepared
+  };
+  // the path-only index of the variant modes: both databases move while the call set is prepared and its paths are claimed -- from the moment
+  // the sequences are in (under the FASTA reader the stagers' threads cost it 0.2 s of a 3 Gb file on a 16-core quota)
+  auto begin_path_stages = [&]() {
     if (pathOnly && rdb.format == MFX_DB_FLAT) stage = mfx_db_stage_begin(G.readDBname, G.device);
     if (pathOnly && G.seqDBname && adb.format == MFX_DB_FLAT) stageAsm = mfx_db_stage_begin(G.seqDBname, G.device);
   };
@@ -776,6 +767,41 @@ int main(int argc, char **argv) {
       seqReadFailed = sf->finish() != 0;      // a decompressor that died mid-stream: the records read so far are NOT the file
     });
   }
+  // The variant modes ask the lookup tables for the k-mers of the enumerated PATHS and nothing else (varMer::score, varMer.C:76-84): one slot
+  // on one device can prepare the call set first (host work), claim exactly those k-mers on a sequence-only index while it does
+  // (mfx_vcf_prepare_path_index) and let both databases update them -- the PATH-ONLY index, a thirteenth of the full tables (3 Gb, 3.7 M calls:
+  // 10.3 GB instead of 137; device work of the build 0.27 instead of 0.65 s).  Its price is the order: the VCF and the clusters' paths come
+  // BEFORE the index instead of under its build -- on a 16-core host 1.9-2.1 s against 1.55-1.65 s of wall (profiles/r06_cfg4_cli.txt).  So it
+  // is what a run takes when the full tables do not fit (-memory, or 90 % of the device's free memory), and MFX_CLI_PATH_INDEX=1 / 0 says
+  // so explicitly.  Not with -index (the image caches the full tables), k > 31, several slots, MFX_CLI_VCF_AHEAD=0.
+  {
+    const char *vs = getenv("MFX_VARIANT_SLOTS");
+    const size_t slots = (vs && atoi(vs) > 0) ? (size_t)atoi(vs) : G.devices.size();
+    const char *pe = getenv("MFX_CLI_PATH_INDEX"), *pa = getenv("MFX_CLI_VCF_AHEAD");
+    const bool can = variantMode && G.vcfName && G.seqName && slots == 1 && !G.sharded && k <= 31 && !G.indexName && !(pa && atoi(pa) == 0) &&
+                     !(getenv("MFX_CLI_FULL_INDEX") && atoi(getenv("MFX_CLI_FULL_INDEX")));
+    if (can && pe) pathOnly = atoi(pe) != 0;
+    else if (can) {
+      const uint64_t capacity = rdb.n_kmers + (G.seqDBname ? adb.n_kmers : bases_upper_bound(G.seqName)) + 1024;
+      const double fullGB = mfx_index_estimate_gb(k, capacity);
+      uint64_t freeB = 0, totalB = 0;
+      const bool known = mfx_device_memory(G.device, &freeB, &totalB) == MFX_OK;
+      pathOnly = (G.maxMemory > 0 && fullGB > G.maxMemory) || (known && fullGB * 1e9 > 0.9 * (double)freeB);
+      if (pathOnly)
+        fprintf(stderr, "-- The full lookup tables would take %.1f GB (%s %.1f GB): building the path-only index of the call set instead.\n", fullGB,
+                G.maxMemory > 0 && fullGB > G.maxMemory ? "-memory allows" : "free on the device:", G.maxMemory > 0 && fullGB > G.maxMemory ? G.maxMemory : freeB / 1e9);
+    }
+  }
+  // the path-only index is built FROM the call set: its VCF is read and parsed (host work only) while the FASTA file is
+  std::future<mfx_vcf *> vcfLoad;
+  std::string vcfAheadError;
+  struct VcfLoadGuard { std::future<mfx_vcf *> &f; ~VcfLoadGuard() { if (f.valid()) mfx_vcf_free(f.get()); } } vcfLoadGuard{vcfLoad};
+  if (pathOnly)
+    vcfLoad = std::async(std::launch::async, [&G, &vcfAheadError]() {
+      mfx_vcf *v = mfx_vcf_load(G.vcfName);
+      if (!v) vcfAheadError = mfx_last_error();                    // (errors are per thread: carried to the caller's)
+      return v;
+    });
   bool seqDone = false;
   auto finish_seq = [&]() {
     if (seqDone) return;
@@ -812,6 +838,7 @@ int main(int argc, char **argv) {
   if (G.seqName && !compressed && G.devices.size() == 1 && !(getenv("MFX_CLI_WARM") && !atoi(getenv("MFX_CLI_WARM")))) (void)mfx_device_warm(G.device);
   if (!stageFirst) begin_stage();
   if (!deferSeq) finish_seq();
+  if (pathOnly) begin_path_stages();
   if (G.sharded) {
     if (G.devices.size() < 2) {
       fprintf(stderr, "ERROR: -sharded needs at least two -devices.\n");
@@ -852,14 +879,13 @@ int main(int argc, char **argv) {
   // (merfin opens it after load_Kmers, merfin-globals.C:201-219; 0.15 s of a 4 M-call set).  An error is reported where the
   // VCF is opened below.  Several slots split the file per slot instead.
   std::future<mfx_vcf *> vcfAhead;
-  std::string vcfAheadError;
   {
     const char *vs = getenv("MFX_VARIANT_SLOTS");
     const size_t slots = (vs && atoi(vs) > 0) ? (size_t)atoi(vs) : G.devices.size();
     const char *pa = getenv("MFX_CLI_VCF_AHEAD");
     const bool dbgAhead = G.debug;
-    if (variantMode && G.vcfName && slots == 1 && !G.sharded && !(pa && atoi(pa) == 0))
-      vcfAhead = std::async(std::launch::async, [&G, &vcfAheadError, &recs, &bases, &lens, k, dbgAhead, deferSeq, pathOnly]() {
+    if (variantMode && G.vcfName && slots == 1 && !G.sharded && !(pa && atoi(pa) == 0) && !pathOnly)
+      vcfAhead = std::async(std::launch::async, [&G, &vcfAheadError, &recs, &bases, &lens, k, dbgAhead, deferSeq]() {
         mfx_vcf *v = mfx_vcf_load(G.vcfName);
         if (!v) { vcfAheadError = mfx_last_error(); return v; }    // (errors are per thread: carried to the caller's)
         // MFX_CLI_VCF_AHEAD=2: ... and its clusters merged, their allele combinations enumerated and packed here as well (mfx_vcf_prepare:
@@ -868,7 +894,7 @@ int main(int argc, char **argv) {
         // down -- config 4 at 3 Gb 2.02-2.07 s with the load alone ahead, 2.67-2.75 s with stage A too (profiles/r05_cfg4_cli_ahead.txt).
         const char *pa2 = getenv("MFX_CLI_VCF_AHEAD");
         // (never while the sequences are still being read -- deferSeq: finish_seq() fills recs / bases / lens on the main thread later)
-        if (!((pa2 && atoi(pa2) == 2) || pathOnly) || deferSeq) return v;       // (the path-only index is built FROM the prepared call set)
+        if (!(pa2 && atoi(pa2) == 2) || deferSeq) return v;
         std::vector<const char *> nm(recs.size());
         for (size_t c = 0; c < recs.size(); ++c) nm[c] = recs[c].name.c_str();
         mfx_variant_opts o;
@@ -915,29 +941,35 @@ int main(int argc, char **argv) {
   }
   mfx_vcf *vcfReady = nullptr;                                      // the call set taken from vcfAhead (prepared): the run below uses it
   struct VcfReadyGuard { mfx_vcf *&v; ~VcfReadyGuard() { if (v) mfx_vcf_free(v); v = nullptr; } } vcfReadyGuard{vcfReady};
-  if (!ix && pathOnly && vcfAhead.valid()) {
-    vcfReady = vcfAhead.get();
+  if (!ix && pathOnly && vcfLoad.valid()) {
+    vcfReady = vcfLoad.get();
     if (!vcfReady) { fprintf(stderr, "ERROR: variant scoring: %s\n", vcfAheadError.c_str()); return 1; }
+    step("(before the index: sequences, VCF)");
+    // the clusters merged, the table made from the bound of their path text, then batch by batch: the paths' tables packed on the host, their
+    // k-mers claimed on the device under the next batch's packing (mfx_vcf_prepare_path_index)
+    fprintf(stderr, "-- Claiming the %d-mers of the variants' paths on the GPU.\n", k);
+    {
+      std::vector<const char *> nm(recs.size());
+      for (size_t c = 0; c < recs.size(); ++c) nm[c] = recs[c].name.c_str();
+      mfx_variant_opts o;
+      o.mode = G.reportType;
+      o.comb = G.comb;
+      o.nosplit = G.nosplit ? 1 : 0;
+      o.debug_path = G.debug ? "-" : nullptr;                       // (only whether it is set matters here)
+      if (mfx_vcf_prepare_path_index(vcfReady, k, nm.data(), bases.data(), lens.data(), (uint32_t)recs.size(), &o, G.maxMemory, G.device, 0.7, &ix))
+        DIE_MFX("preparing the call set");
+      if (!ix) fprintf(stderr, "-- %s\n-- Building the full lookup tables instead.\n", mfx_last_error());
+    }
+    if (ix) {
+      mfx_index_info info;
+      if (mfx_index_get_info(ix, &info)) DIE_MFX("reading the path-only index");
+      fprintf(stderr, "--\n-- Memory needed: %.3f GB (the %d-mers of the variants' paths: %lu)\n-- Memory limit:  %.3f GB%s\n--\n", info.bytes / 1e9, k,
+              (unsigned long)info.distinct, G.maxMemory, G.maxMemory > 0 ? "" : " (none)");
+    }
     if (stage) mfx_db_stage_boost(stage);                           // the host's threads are free: the databases' readers may have them all
     if (stageAsm) mfx_db_stage_boost(stageAsm);
-    step("(before the index: sequences, VCF, clusters and their paths)");
-    uint64_t positions = 0;
-    if (mfx_vcf_path_bound(vcfReady, &positions)) DIE_MFX("sizing the path-only index");
-    fprintf(stderr, "--\n-- Memory needed: %.3f GB (the %d-mers of the variants' paths: at most %lu)\n-- Memory limit:  %.3f GB%s\n--\n",
-            mfx_index_estimate_gb_for_seq(k, positions + 1024), k, (unsigned long)positions, G.maxMemory, G.maxMemory > 0 ? "" : " (none)");
-    ix = mfx_index_create_for_seq_lf(k, positions + 1024, G.maxMemory, G.device, 0.7);
-    if (!ix) fprintf(stderr, "-- The path-only index does not fit (%s); building the full lookup tables instead.\n", mfx_last_error());
-    step("create the table");
+    step("prepare the call set + claim the paths' k-mers");
     int lrc = 0;
-    if (ix) {
-      fprintf(stderr, "-- Claiming the %d-mers of the variants' paths on the GPU.\n", k);
-      if (mfx_index_claim_paths(ix, vcfReady, nullptr)) {
-        fprintf(stderr, "-- %s\n-- Building the full lookup tables instead.\n", mfx_last_error());
-        mfx_index_free(ix);
-        ix = nullptr;
-      }
-      step("claim the paths' k-mers");
-    }
     if (ix) {
       if (G.seqDBname) {
         fprintf(stderr, "-- Loading kmers from '%s' into lookup table.\n", G.seqDBname);

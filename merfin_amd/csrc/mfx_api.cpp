@@ -77,6 +77,20 @@ extern "C" int mfx_diag_gather_rate(int device, uint64_t table_bytes, double *li
   return MFX_OK;
 }
 
+extern "C" int mfx_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes) {
+  if (device < 0 || device >= mfx_device_count()) return mfx_fail(MFX_E_NODEVICE, "HIP device %d not available", device);
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  MFX_HIP(hipSetDevice(device));
+  size_t f = 0, t = 0;
+  const hipError_t e = hipMemGetInfo(&f, &t);
+  if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+  if (e != hipSuccess) return mfx_fail(MFX_E_HIP, "hipMemGetInfo failed: %s", hipGetErrorString(e));
+  if (free_bytes) *free_bytes = f;
+  if (total_bytes) *total_bytes = t;
+  return MFX_OK;
+}
+
 extern "C" int mfx_device_warm(int device) {
   if (device < 0 || device >= mfx_device_count()) return mfx_fail(MFX_E_NODEVICE, "HIP device %d not available", device);
   int prev = -1;
@@ -1245,7 +1259,7 @@ static int staged_load(mfx_index *ix, const mfx_seq *seq, mfx_db_stage *S, int s
     const double tw = stage_now();
     while (S->enqueued.load(std::memory_order_acquire) <= (int64_t)c) {
       if (S->failed.load()) { release(); return mfx_fail(MFX_E_IO, "'%s': %s", S->path.c_str(), S->error.c_str()); }
-      std::this_thread::yield();
+      std::this_thread::sleep_for(std::chrono::microseconds(50));     // (not a yield spin: under a CPU quota it would hold a core against the stager's readers)
     }
     t_wait += stage_now() - tw;
     const mfx_db_stage::Chunk &ch = S->chunks[c];
@@ -1258,7 +1272,7 @@ static int staged_load(mfx_index *ix, const mfx_seq *seq, mfx_db_stage *S, int s
   // the escapes, from the staged copy: an ordinary update of (k-mer, count) arrays that are already on the device
   while (!S->esc_ready.load(std::memory_order_acquire)) {
     if (S->failed.load()) { release(); return mfx_fail(MFX_E_IO, "'%s': %s", S->path.c_str(), S->error.c_str()); }
-    std::this_thread::yield();
+    std::this_thread::sleep_for(std::chrono::microseconds(50));
   }
   if (S->info.n_escape) {
     STAGED_HIP(hipStreamWaitEvent(is[0], S->esc_copied, 0));

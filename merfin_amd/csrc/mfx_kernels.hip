@@ -1068,6 +1068,10 @@ __global__ __launch_bounds__(256) void mfx_table_add_placed_kernel(mfx_table_vie
           v[i] = (uint32_t)mfx_bits_at(pw, vbit0 + (uint64_t)e * vb, vb);
           if (v[i] == (1u << vb) - 1u) v[i] = 0u;              // escape: added separately (the file's escape list)
           if (run >> mfx_p_bits(t.k)) { if (v[i]) ++T.wide; v[i] = 0u; }      // (a damaged record: wider than any P of this k)
+          // ... or one that no converter writes: a number equal to the one before it (the records ascend strictly), a number whose k-mer is not
+          // canonical (every P of a canonical k-mer decodes to it; most other numbers do not).  Counted with the wide ones (MFX_E_FORMAT), not applied:
+          // the plain stores below rely on one record per slot.
+          if (v[i] && ((e > 0u && d[i] == 0ull) || mfx_p_revcomp(key[i], t.k) < key[i])) { ++T.wide; v[i] = 0u; }
           if (placed) pr[i] = t.quot ? mfx_home_placed(t, key[i], top, hi, pm) : mfx_home_placed_direct(t, key[i], top, pm);
         }
       }

@@ -1015,10 +1015,21 @@ using PathValues = std::function<int(const char *, uint64_t, uint32_t *, uint32_
 using PathScores = std::function<int(const char *, uint64_t, const mfx_path_table &, const mfx_trv_batch *, int, uint32_t *, double *)>;
 
 // (not static: tools/variants_host_bench.cpp drives the host side with a synthetic `values`, without a device)
+// (prepare) the PATH-ONLY index made while the call set is prepared: on_bound is told the k-mer positions of all path text once the clusters are
+// merged (it makes the table; != 0: no claims, the preparation goes on), claim runs one batch's text through mfx_claim_paths_batch -- on a thread
+// of its own, under stage A of the next batch
+struct PathClaims {
+  std::function<int(uint64_t)> on_bound;
+  std::function<int(const char *, uint64_t, const mfx_trv_batch *, uint64_t *)> claim;
+  bool active = false;
+  uint64_t positions = 0, bad = 0;
+  int rc = MFX_OK;
+  std::string err;
+};
 int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const char *vcf_path, const char *const *names, const char *const *bases,
                          const uint64_t *lens, uint32_t ncontigs, const mfx_variant_opts *opts,
                          const char *out_path, const char *log_path, uint64_t *n_clusters, const PathScores &scores = PathScores(),
-                         mfx_vcf *loaded = nullptr, uint32_t prepK = 0) {
+                         mfx_vcf *loaded = nullptr, uint32_t prepK = 0, PathClaims *claims = nullptr) {
   // prepK != 0: PREPARE only (mfx_vcf_prepare) -- the clusters of `loaded` are merged for k = prepK and stage A of every batch is run and
   // kept in loaded->prep; no evaluator, no output.  A later run on `loaded` starts from there.
   const bool prepare_only = prepK != 0;
@@ -1288,7 +1299,8 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
       }
       bt.t_cl.resize(ncl); bt.t_var.resize(nvar); bt.t_al.resize(nal); bt.t_win.resize(nwin); bt.t_alt.resize(nalt);
       bt.t_text_end = total + ntext; bt.t_path_cap = npath; bt.t_row_cap = nrow;
-      bt.t_np.assign(ncl, 0); bt.t_status.assign(ncl, 0); bt.t_plen.resize(npath); bt.t_gt.resize(nrow);
+      bt.t_np.assign(ncl, 0); bt.t_status.assign(ncl, 0);
+      if (!making) { bt.t_plen.resize(npath); bt.t_gt.resize(nrow); }   // (what comes BACK from stage B: a prepared batch takes the room when it gets there)
       if (ncl)
         parallel_for(nruns, [&](size_t ri) {
           const PathArena &ar = bt.arenas[ri];
@@ -1311,7 +1323,7 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
       bt.tables = true;
       bt.p_off.resize(np); bt.p_voff.resize(np); bt.p_cfirst.resize(np); bt.p_len.resize(np); bt.p_nv.resize(np);
       bt.p_gt.resize(nvals); bt.p_vidx.resize(nvals); bt.p_vlen.resize(nvals);
-      bt.numM.resize(np + bt.t_path_cap); bt.totdk.resize(np + bt.t_path_cap);
+      if (!making) { bt.numM.resize(np + bt.t_path_cap); bt.totdk.resize(np + bt.t_path_cap); }
       parallel_for(nruns, [&](size_t ri) {
         const PathArena &ar = bt.arenas[ri];
         for (size_t i = ri * RUN, e = std::min(jobs.size(), (ri + 1) * RUN); i < e; ++i) {
@@ -1347,6 +1359,10 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
     const bool on_device = (bool)scores && dbg == nullptr && bt.tables;  // -debug wants the per-position values: scored on the host
     if ((total || !bt.t_cl.empty()) && on_device) {
       bt.scored = true;
+      if (bt.numM.size() != bt.p_off.size() + bt.t_path_cap) {           // (a prepared batch: see stage A)
+        bt.t_plen.resize(bt.t_path_cap); bt.t_gt.resize(bt.t_row_cap);
+        bt.numM.resize(bt.p_off.size() + bt.t_path_cap); bt.totdk.resize(bt.p_off.size() + bt.t_path_cap);
+      }
       Batch *bp = &bt;
       const int need_dk = mode == MFX_VAR_POLISH ? 1 : 0;
       std::shared_future<int> prev = prevb ? prevb->gpu : std::shared_future<int>();
@@ -1533,6 +1549,27 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
     if (making) {
       batches[cur_b].prelude = take_log();
       stage_a(batches[cur_b], making->with_tables);
+      if (claims && claims->active) {
+        // the batch's k-mers are claimed on the device while the host prepares the next batch; one claim at a time (they share the scratch)
+        Batch *bp = &batches[cur_b];
+        std::shared_future<int> prev = cur_b ? batches[cur_b - 1].gpu : std::shared_future<int>();
+        bp->gpu = std::async(std::launch::async, [bp, prev, claims]() mutable {
+          if (prev.valid() && prev.get() != MFX_OK) return (int)MFX_E_INVAL;       // (an earlier batch failed: its error is the one reported)
+          prev = std::shared_future<int>();
+          mfx_trv_batch tb;
+          if (!bp->t_cl.empty()) {
+            tb.ncl = bp->t_cl.size(); tb.nvar = bp->t_var.size(); tb.nal = bp->t_al.size(); tb.win_bytes = bp->t_win.size(); tb.al_bytes = bp->t_alt.size();
+            tb.cl = bp->t_cl.data(); tb.var = bp->t_var.data(); tb.al = bp->t_al.data(); tb.win_text = bp->t_win.data(); tb.al_text = bp->t_alt.data();
+            tb.text_end = bp->t_text_end; tb.path_cap = bp->t_path_cap; tb.row_cap = bp->t_row_cap;
+            tb.np = bp->t_np.data(); tb.status = bp->t_status.data();
+          }
+          uint64_t bad = 0;
+          const int r = claims->claim(bp->packed.data(), bp->packed.size(), bp->t_cl.empty() ? nullptr : &tb, &bad);
+          if (r) bp->err = mfx_last_error();
+          else if (bad) { bp->err = std::to_string(bad) + " clusters of the call set cannot be enumerated on the device (their paths are made on the host during the run)"; return (int)MFX_E_INVAL; }
+          return r;
+        });
+      }
       batches.emplace_back();
       cur_b = batches.size() - 1;
       batches[cur_b].jobs.reserve(65536);
@@ -1562,6 +1599,41 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
     for (Batch &bt : batches) if (bt.gpu.valid()) (void)bt.gpu.get();
     t_phase[0] += prep->t_phase[0]; t_phase[1] += prep->t_phase[1]; t_phase[2] += prep->t_phase[2];
   } else {
+  // upper bound of a cluster's path text: (product of allele counts) x (window + longest alleles)
+  auto cluster_text_bound = [](const Cluster *cl, uint32_t rStart, uint32_t rEnd) -> uint64_t {
+    double npaths = 1;
+    uint64_t plen = (uint64_t)(rEnd - rStart) + 1;
+    for (const Variant *v : cl->vars) {
+      npaths *= (double)std::max<size_t>(v->nalleles(), 1);
+      size_t longest = 0;
+      for (size_t ai = 0; ai < v->nalleles(); ++ai) longest = std::max<size_t>(longest, v->allele(ai).size());
+      plen += longest;
+    }
+    return (uint64_t)std::min(npaths, 4194304.0) * plen;
+  };
+  if (making && claims && claims->on_bound) {
+    // the path-only index is made HERE, before the first batch: the k-mer positions of all path text, from the clusters alone (the loop below
+    // without its log lines)
+    uint64_t bound = 0;
+    for (uint32_t c = 0; c < ncontigs; ++c) {
+      auto it = db.by_chr.find(names[c]);
+      if (it == db.by_chr.end()) continue;
+      const uint64_t seqLen = lens[c];
+      for (const Cluster *cl : it->second) {
+        uint32_t rStart = cl->rStart, rEnd = cl->rEnd;
+        const uint32_t pad = K - 1;
+        rStart = rStart > pad ? rStart - pad : 0;
+        if (rEnd < seqLen - pad) rEnd += pad; else rEnd = (uint32_t)seqLen;
+        if (!(rStart <= rEnd && (uint64_t)rEnd <= seqLen) || cl->vars.size() > comb) continue;
+        bound += cluster_text_bound(cl, rStart, rEnd);
+      }
+    }
+    claims->positions = bound;
+    const int brc = claims->on_bound(bound);
+    claims->active = brc == MFX_OK;
+    if (brc) { claims->rc = brc; claims->err = mfx_last_error(); }
+    lap(0);
+  }
   uint64_t est_bytes = 0;
   for (uint32_t c = 0; c < ncontigs && rc == MFX_OK; ++c) {
     auto it = db.by_chr.find(names[c]);
@@ -1586,21 +1658,20 @@ int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const 
       jobs.emplace_back();
       Job &jb = jobs.back();
       jb.cl = cl; jb.contig = c; jb.rStart = rStart; jb.rEnd = rEnd;
-      // upper bound of this cluster's path text: (product of allele counts) x (window + longest ALTs)
-      double npaths = 1;
-      uint64_t plen = (uint64_t)(rEnd - rStart) + 1;
-      for (const Variant *v : cl->vars) {
-        npaths *= (double)std::max<size_t>(v->nalleles(), 1);
-        size_t longest = 0;
-        for (size_t ai = 0; ai < v->nalleles(); ++ai) longest = std::max<size_t>(longest, v->allele(ai).size());
-        plen += longest;
-      }
-      est_bytes += (uint64_t)std::min(npaths, 4194304.0) * plen;
+      est_bytes += cluster_text_bound(cl, rStart, rEnd);
       if (est_bytes >= BATCH_BYTES || jobs.size() >= 65536) { rc = flush(); est_bytes = 0; }
       if (rc) break;
     }
   }
   if (rc == MFX_OK) rc = flush();
+  if (making && claims && claims->active) {
+    for (Batch &bt : batches) {
+      if (!bt.gpu.valid()) continue;
+      const int r = bt.gpu.get();
+      if (r && claims->rc == MFX_OK && !bt.err.empty()) { claims->rc = r; claims->err = bt.err; }
+      bt.gpu = std::shared_future<int>();
+    }
+  }
   if (making) {
     making->tail_log = take_log();
     {
@@ -1748,6 +1819,38 @@ extern "C" int mfx_index_claim_paths(mfx_index *ix, mfx_vcf *vcf, uint64_t *n_po
     }
     if (n_positions) *n_positions = positions;
     return mfx_claim_paths_finish(ix, prep->token);
+  });
+}
+
+// mfx_vcf_prepare + mfx_index_create_for_seq_lf + mfx_index_claim_paths as ONE pass: the table is made as soon as the clusters are merged (its
+// capacity is the bound of their path text), and every batch's k-mers are claimed on the device while the host prepares the next batch -- the
+// claims (0.13 s of a 3.7 M-call human set) disappear under the preparation.  *out: the claimed index (the databases come next), or NULL with
+// MFX_OK when the path-only index cannot be made for this call set (no memory, a cluster the device cannot enumerate: mfx_last_error says why) --
+// the handle is prepared either way and runs on a full index as well.
+extern "C" int mfx_vcf_prepare_path_index(mfx_vcf *vcf, int k, const char *const *names, const char *const *bases, const uint64_t *lens, uint32_t ncontigs,
+                                          const mfx_variant_opts *opts, double max_gb, int device, double load_factor, mfx_index **out) {
+  if (!vcf || !opts || !out || k < 1 || k > MFX_MAX_K_NARROW) return mfx_fail(MFX_E_INVAL, "mfx_vcf_prepare_path_index: null argument or k out of range (k <= %d)", MFX_MAX_K_NARROW);
+  *out = nullptr;
+  return variants_guarded("mfx_vcf_prepare_path_index", [&]() -> int {
+    mfx_index *ix = nullptr;
+    uint8_t *scratch = nullptr;
+    uint64_t scratch_bytes = 0;
+    struct Release { int dev; uint8_t *&p; mfx_index *&ix; ~Release() { mfx_claim_paths_release(dev, p); if (ix) mfx_index_free(ix); } } release{device, scratch, ix};
+    PathClaims claims;
+    claims.on_bound = [&](uint64_t bound) -> int {
+      ix = load_factor > 0 ? mfx_index_create_for_seq_lf(k, bound + 1024, max_gb, device, load_factor) : mfx_index_create_for_seq(k, bound + 1024, max_gb, device);
+      return ix ? MFX_OK : mfx_last_error_code();
+    };
+    claims.claim = [&](const char *text, uint64_t len, const mfx_trv_batch *tb, uint64_t *bad) -> int { return mfx_claim_paths_batch(ix, &scratch, &scratch_bytes, text, len, tb, bad); };
+    const int rc = mfx_variants_run_values(nullptr, PathValues(), nullptr, names, bases, lens, ncontigs, opts, nullptr, nullptr, nullptr, PathScores(), vcf, (uint32_t)k, &claims);
+    if (rc) return rc;
+    if (claims.rc == MFX_OK && ix) {
+      const int frc = mfx_claim_paths_finish(ix, vcf->prep->token);
+      if (frc == MFX_OK) { *out = ix; ix = nullptr; return MFX_OK; }
+      claims.rc = frc; claims.err = mfx_last_error();
+    }
+    (void)mfx_fail(claims.rc ? claims.rc : MFX_E_INVAL, "no path-only index for this call set: %s", claims.err.c_str());     // (the reason; the call itself succeeded)
+    return MFX_OK;
   });
 }
 

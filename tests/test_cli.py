@@ -181,9 +181,9 @@ def test_cli_variant_modes(tmp_path, mode):
 @pytest.mark.parametrize("seqmers", [True, False])
 @pytest.mark.parametrize("k", [21, 27])
 def test_cli_variant_modes_on_the_path_only_index(tmp_path, seqmers, k):
-    """one slot on one device builds the PATH-ONLY index (the call set prepared first, its paths' k-mers claimed, both databases update-only;
-    without -seqmers the assembly side is counted over the uploaded sequence): the records of the oracle and of the full tables
-    (MFX_CLI_PATH_INDEX=0), byte for byte"""
+    """MFX_CLI_PATH_INDEX=1 (or full tables that would not fit the device): one slot on one device builds the PATH-ONLY index (the call set
+    prepared first, its paths' k-mers claimed meanwhile, both databases update-only; without -seqmers the assembly side is counted over the
+    uploaded sequence): the records of the oracle and of the full tables (MFX_CLI_PATH_INDEX=0), byte for byte"""
     import merfin_amd as m
     peak = 17.3
     names, asm, vcf, read, amers = synth.variant_world(k=k, peak=peak, seed=62)
@@ -201,12 +201,15 @@ def test_cli_variant_modes_on_the_path_only_index(tmp_path, seqmers, k):
     args = ["-polish", "-sequence", fa, "-readmers", str(tmp_path / "read.mfxk"), "-vcf", vp, "-peak", str(peak)]
     if seqmers:
         args += ["-seqmers", str(tmp_path / "asm.mfxk")]
-    r = run(args + ["-output", str(tmp_path / "path")])
+    r = run(args + ["-output", str(tmp_path / "path")], env=dict(os.environ, MFX_CLI_PATH_INDEX="1"))
     assert r.returncode == 0, r.stderr
     assert "Claiming the %d-mers of the variants' paths" % k in r.stderr
     r2 = run(args + ["-output", str(tmp_path / "full")], env=dict(os.environ, MFX_CLI_PATH_INDEX="0"))
     assert r2.returncode == 0, r2.stderr
     assert "variants' paths" not in r2.stderr
+    r3 = run(args + ["-debug", "-output", str(tmp_path / "dbg")], env=dict(os.environ, MFX_CLI_PATH_INDEX="1"))      # -debug: host-enumerated text is what is claimed
+    assert r3.returncode == 0, r3.stderr
+    assert (tmp_path / "dbg.polish.vcf").read_text() == (tmp_path / "o.vcf").read_text()
     want = (tmp_path / "o.vcf").read_text()
     assert (tmp_path / "path.polish.vcf").read_text() == want
     assert (tmp_path / "full.polish.vcf").read_text() == want

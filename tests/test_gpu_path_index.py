@@ -34,15 +34,24 @@ def _path_index(m, k, loaded, read, amers):
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode,k,seed,comb,nosplit", [("polish", 21, 78, 15, False), ("filter", 21, 79, 15, False), ("better", 27, 80, 6, False),
                                                       ("loose", 31, 81, 15, True), ("strict", 15, 83, 4, False), ("polish", 11, 84, 15, False)])
-def test_path_only_index_gives_the_records_of_the_full_tables(tmp_path, mode, k, seed, comb, nosplit):
+@pytest.mark.parametrize("fused", [False, True])
+def test_path_only_index_gives_the_records_of_the_full_tables(tmp_path, mode, k, seed, comb, nosplit, fused):
+    """fused: mfx_vcf_prepare_path_index (what the CLI calls: the table made once the clusters are merged, every batch claimed under the
+    preparation of the next) instead of prepare / path_bound / Index.for_seq / claim_paths"""
     import merfin_amd as m
     peak = 17.3
     names, asm, vp, read, amers = _world(tmp_path, k, peak, seed)
     ix, ev = _full(m, k, read, amers, peak)
     n_a = ev.variants(mode, vp, names, asm, str(tmp_path / "a.vcf"), comb=comb, nosplit=nosplit, log_path=str(tmp_path / "a.log"))
     loaded = m.LoadedVcf(vp)
-    loaded.prepare(k, mode, names, asm, comb=comb, nosplit=nosplit)
-    px = _path_index(m, k, loaded, read, amers)
+    if fused:
+        px = loaded.prepare_path_index(k, mode, names, asm, comb=comb, nosplit=nosplit)
+        assert px is not None
+        px.add_asm(*amers)
+        px.add_read(*read)
+    else:
+        loaded.prepare(k, mode, names, asm, comb=comb, nosplit=nosplit)
+        px = _path_index(m, k, loaded, read, amers)
     info = px.info()
     assert info["seq_only"] and 0 < info["distinct"] <= loaded.path_bound()       # the claimed k-mers: the paths', whatever the databases hold
     pev = m.Evaluator(px, m.KParams(peak))
@@ -75,6 +84,28 @@ def test_path_only_index_with_debug_and_host_enumeration(tmp_path, monkeypatch, 
                               log_path=str(tmp_path / "b.log"))
     assert n_a == n_b and n_a > 0
     for ext in ("vcf", "log") + (() if host_paths else ("dbg",)):
+        assert open(tmp_path / ("a." + ext), "rb").read() == open(tmp_path / ("b." + ext), "rb").read(), ext
+    loaded.close()
+
+
+@pytest.mark.gpu
+def test_path_only_index_claimed_batch_by_batch(tmp_path, monkeypatch):
+    """one cluster per batch (MFX_VAR_BATCH_MB=0): hundreds of claims chained behind one another under the preparation"""
+    import merfin_amd as m
+    monkeypatch.setenv("MFX_VAR_BATCH_MB", "0")
+    k, peak = 21, 17.3
+    names, asm, vp, read, amers = _world(tmp_path, k, peak, 88)
+    ix, ev = _full(m, k, read, amers, peak)
+    n_a = ev.variants("polish", vp, names, asm, str(tmp_path / "a.vcf"), log_path=str(tmp_path / "a.log"))
+    loaded = m.LoadedVcf(vp)
+    px = loaded.prepare_path_index(k, "polish", names, asm)
+    assert px is not None and px.info()["distinct"] > 0
+    px.add_asm(*amers)
+    px.add_read(*read)
+    pev = m.Evaluator(px, m.KParams(peak))
+    n_b = pev.variants_loaded("polish", loaded, names, asm, str(tmp_path / "b.vcf"), log_path=str(tmp_path / "b.log"))
+    assert n_a == n_b and n_a > 0
+    for ext in ("vcf", "log"):
         assert open(tmp_path / ("a." + ext), "rb").read() == open(tmp_path / ("b." + ext), "rb").read(), ext
     loaded.close()
 

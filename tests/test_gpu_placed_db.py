@@ -111,3 +111,27 @@ def test_cli_hist_from_a_placed_database(tmp_path, golden_dir):
             assert r.returncode == 0, r.stderr
             assert (tmp_path / "h").read_bytes() == open(g("case1.hist"), "rb").read()
             assert open(g("case1.summary")).read() in r.stderr
+
+
+@pytest.mark.parametrize("k", [21, 27])
+def test_placed_records_that_are_no_placement_number_are_refused(k, tmp_path):
+    """a placed file is applied with plain stores, one record per slot, at the place its own pieces name: numbers that ascend but
+    are no canonical k-mer's P -- a damaged or hand-made file -- must fail the load (MFX_E_FORMAT), not land in the table"""
+    m = _mfx()
+    contigs, read, asm = synth.world(k=k, peak=11.0, seed=90 + k)
+    good = np.sort(m.db_place_keys(k, read[0]))
+    rng = np.random.default_rng(3)
+    junk = rng.integers(1, 1 << 62, 256, dtype=np.uint64) >> np.uint64(62 - min(62, 2 * k + 3))
+    bad = np.unique(np.concatenate([good, junk]))
+    assert len(bad) > len(good)
+    path = str(tmp_path / "bad.mfxk")
+    m.db_write_flat_placed(path, k, bad, np.full(len(bad), 7, dtype=np.uint32))
+    seqs = m.Sequences(contigs)
+    ix = m.Index.for_seq(k, sum(len(c) for c in contigs) + 16)
+    with pytest.raises(m.MfxError) as e:
+        ix.build_for_hist(seqs, path)
+    assert "damaged" in str(e.value) or "wider" in str(e.value)
+    ok = str(tmp_path / "ok.mfxk")                                 # the same records without the junk load
+    m.db_write_flat_placed(ok, k, good, np.full(len(good), 7, dtype=np.uint32))
+    ix2 = m.Index.for_seq(k, sum(len(c) for c in contigs) + 16)
+    ix2.build_for_hist(seqs, ok)
