@@ -126,14 +126,15 @@ int mfx_db_write_flat(const char *path, int k, const uint64_t *kmers, const uint
  * device is touched.  One pass makes every later load of the database a matter of its bytes over PCIe (a 30x human read
  * set: a minute of text parsing -> half a second).  CLI: merfin -convert <db> -output <file>.  n_kmers may be null. */
 int mfx_db_convert(const char *in_path, const char *out_path, uint64_t *n_kmers);
-/* ... -> the PLACED flat form (13 <= k <= 30, canonical databases): the records are not the k-mers but the numbers P of
+/* ... -> the PLACED flat form (13 <= k <= 31, canonical databases): the records are not the k-mers but the numbers P of
  * csrc/mfx_place.h -- one to one with the canonical k-mers, and ascending P means ascending LINE of the sequence-only index's compact
  * table, whatever its size -- sorted and delta-coded (~3 bits more per record than the k-mer-sorted form).  What it buys: the kernel
  * that applies the database to the table (load_Kmers, merfin-globals.C:155-159, as a run pays it) walks the table line after line,
  * every line read and written once, instead of reading one random line per record.  Such a file loads into ANY table (the k-mers are
  * recovered from P on the device; only the compact table under its default placement takes the shortcut).  CLI: merfin -convert <db>
  * -placed -output <file>.  mfx_db_write_flat_placed writes one from ascending P and counts (mfx_db_place_keys gives P of k-mers: host
- * arrays, or device arrays on `device` for a tool that sorts on the GPU). */
+ * arrays, or device arrays on `device` for a tool that sorts on the GPU); both for k <= 30 -- the P of a 31-mer takes 65 bits, its file holds
+ * P >> 1 with the strand bit in the record's count field and is made by mfx_db_convert_placed alone. */
 int mfx_db_convert_placed(const char *in_path, const char *out_path, uint64_t *n_kmers);
 int mfx_db_write_flat_placed(const char *path, int k, const uint64_t *pkeys, const uint32_t *values, uint64_t n);
 int mfx_db_place_keys(int k, const uint64_t *kmers, uint64_t n, uint64_t *out, int on_device, int device);

@@ -56,7 +56,7 @@ static void usage(const char *exe) {
           "    -seqmers db       assembly k-mer database; default: counted from -sequence on the GPU\n"
           "    -convert db       no report: rewrite the k-mer database <db> (any accepted form) as -output <file> in the flat form\n"
           "                      (sorted k-mers in delta-coded blocks; loads at the speed of the PCIe link)\n"
-          "    -placed           with -convert: the records sorted by their PLACE in the table -hist / -dump build (13 <= k <= 30,\n"
+          "    -placed           with -convert: the records sorted by their PLACE in the table -hist / -dump build (13 <= k <= 31,\n"
           "                      canonical databases): such a database is applied to the table line after line\n"
           "    -device d         HIP device (default 0)\n"
           "    -devices list     several GPUs of this node driven by this one process, e.g. 0-7 or 0,2,5 (-hist: the index is\n"

@@ -1316,7 +1316,8 @@ extern "C" int mfx_index_load_db_staged(mfx_index *ix, mfx_db_stage *S, int side
 // database on the GPU); else host arrays, host threads
 extern "C" int mfx_db_place_keys(int k, const uint64_t *kmers, uint64_t n, uint64_t *out, int on_device, int device) {
   if (n && (!kmers || !out)) return mfx_fail(MFX_E_INVAL, "mfx_db_place_keys: null argument");
-  if (k < MFX_PLACE_MIN_K || k > MFX_PLACE_MAX_K) return mfx_fail(MFX_E_INVAL, "mfx_db_place_keys: %d <= k <= %d (k = %d)", MFX_PLACE_MIN_K, MFX_PLACE_MAX_K, k);
+  if (k < MFX_PLACE_MIN_K || k > MFX_PLACE_MAX_K || mfx_p_split(k))      // (k = 31: P takes 65 bits; its placed database is made by mfx_db_convert_placed)
+    return mfx_fail(MFX_E_INVAL, "mfx_db_place_keys: %d <= k <= 30 (k = %d)", MFX_PLACE_MIN_K, k);
   if (!on_device) { mfx_place_keys_host(k, kmers, n, out); return MFX_OK; }
   DevGuard g(device);
   MFX_HIP(mfx_k_place_keys(k, kmers, n, out, nullptr));

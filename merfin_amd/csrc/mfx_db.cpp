@@ -105,7 +105,7 @@ const char *flat_header_problem(const FlatHeader &h, uint64_t fsize) {
   const uint64_t rest = body - h.n_escape * 12;
   if (h.flags & FLAT_PLACED) {
     if (!(h.flags & FLAT_DELTA)) return "a placed database is delta-coded";
-    if (h.k < (uint32_t)MFX_PLACE_MIN_K || h.k > (uint32_t)MFX_PLACE_MAX_K) return "placed records hold 13 <= k <= 30";
+    if (h.k < (uint32_t)MFX_PLACE_MIN_K || h.k > (uint32_t)MFX_PLACE_MAX_K) return "placed records hold 13 <= k <= 31";
     if (flat_place_version(h) != MFX_PLACE_VERSION) return "placed by another version of the placement functions (convert the database again)";
   }
   if (h.flags & FLAT_DELTA) {
@@ -671,7 +671,19 @@ void par_blocks(uint64_t nblocks, F &&fn) {                   // fn(b) for every
 
 // 0 = written; 1 = the k-mers are not strictly ascending (the caller writes another form); < 0: error
 // placed: `kmers` are the numbers P of mfx_place.h (ascending); the escape list then holds the k-mers they decode to
-int write_flat_delta(FILE *f, const char *path, FlatHeader h, const uint64_t *kmers, const uint32_t *values, uint64_t n, bool placed = false) {
+// sbits (placed, k = 31: mfx_place.h, mfx_p_split): the strand bit of every record; `kmers` are then the numbers P >> 1 -- ascending, equal for a
+// pair that differs in the strand bit alone (0 first) -- and a record's count field holds count << 1 | s (a count of 2^21 or more is an escape)
+int write_flat_delta(FILE *f, const char *path, FlatHeader h, const uint64_t *kmers, const uint32_t *true_values, uint64_t n, bool placed = false,
+                     const uint8_t *sbits = nullptr) {
+  std::vector<uint32_t> folded;
+  if (sbits) {
+    folded.resize(n);
+    par_blocks((n + 65535) / 65536, [&](uint64_t b) {
+      for (uint64_t i = b * 65536, e = std::min<uint64_t>(n, i + 65536); i < e; ++i)
+        folded[i] = true_values[i] >= (1u << (MFX_DELTA_MAX_VBITS - 1)) ? 0xffffffffu : (true_values[i] << 1) | (uint32_t)(sbits[i] & 1u);
+    });
+  }
+  const uint32_t *values = sbits ? folded.data() : true_values;
   const uint64_t nblocks = (n + MFX_DELTA_BLOCK - 1) / MFX_DELTA_BLOCK;
   auto cnt_of = [&](uint64_t b) { return (uint32_t)std::min<uint64_t>(MFX_DELTA_BLOCK, n - b * MFX_DELTA_BLOCK); };
   const bool timing = getenv("MFX_DB_TIMING") != nullptr;
@@ -683,7 +695,8 @@ int write_flat_delta(FILE *f, const char *path, FlatHeader h, const uint64_t *km
   par_blocks(nblocks, [&](uint64_t b) {
     const uint64_t o = b * MFX_DELTA_BLOCK;
     const uint32_t cnt = cnt_of(b);
-    for (uint32_t i = (b ? 0 : 1); i < cnt; ++i) if (kmers[o + i] <= kmers[o + i - 1]) { unsorted = 1; return; }
+    for (uint32_t i = (b ? 0 : 1); i < cnt; ++i)
+      if (kmers[o + i] < kmers[o + i - 1] || (kmers[o + i] == kmers[o + i - 1] && !(sbits && sbits[o + i - 1] < sbits[o + i]))) { unsorted = 1; return; }
     plan[b] = plan_delta_block(kmers + o, values + o, cnt);
   });
   if (unsorted) return 1;
@@ -730,8 +743,8 @@ int write_flat_delta(FILE *f, const char *path, FlatHeader h, const uint64_t *km
     for (uint64_t i = b * MFX_DELTA_BLOCK, e = i + cnt_of(b); i < e; ++i)
       if (values[i] >= esc) {
         uint32_t top, hi, pm;
-        ek.push_back(placed ? mfx_p_decode((int)h.k, kmers[i], top, hi, pm) : kmers[i]);
-        ev.push_back(values[i]);
+        ek.push_back(placed ? mfx_p_decode_s((int)h.k, kmers[i], sbits ? sbits[i] : 0u, top, hi, pm) : kmers[i]);
+        ev.push_back(true_values[i]);
       }
   }
   ok = ok && ek.size() == h.n_escape &&
@@ -1077,6 +1090,8 @@ int read_flat_host(const std::string &path, int *k_out, std::vector<uint64_t> &k
   const size_t kw = h.k > (uint32_t)MFX_MAX_K_NARROW ? 2 : 1;
   try { keys.resize(h.n * kw); vals.resize(h.n); }
   catch (const std::exception &) { fclose(f); return mfx_fail(MFX_E_NOMEM, "'%s': no memory for %lu k-mers", path.c_str(), (unsigned long)h.n); }
+  struct EscSplit { uint64_t i, p; uint32_t s; };              // an escaped record of a placed 31-mer file: position, stored number, strand bit (2: not known yet)
+  std::vector<EscSplit> esc_split;
   auto escapes = [&]() -> bool {                              // the side list of a packed / delta file: counts by k-mer
     std::vector<uint64_t> ek(h.n_escape);
     std::vector<uint32_t> ev(h.n_escape);
@@ -1087,6 +1102,15 @@ int read_flat_host(const std::string &path, int *k_out, std::vector<uint64_t> &k
     for (uint64_t i = 0; i < h.n; ++i)
       if (vals[i] == 0xffffffffu && !e.empty()) {             // marked below
         auto it = std::lower_bound(e.begin(), e.end(), std::make_pair(keys[i], 0u));
+        if ((it == e.end() || it->first != keys[i]) && !esc_split.empty()) {
+          // a placed 31-mer whose strand bit the block does not say (no twin beside it): the other strand's k-mer then
+          auto es = std::lower_bound(esc_split.begin(), esc_split.end(), i, [](const EscSplit &a, uint64_t x) { return a.i < x; });
+          if (es != esc_split.end() && es->i == i && es->s == 2u) {
+            uint32_t top, hi, pm;
+            keys[i] = mfx_p_decode_s((int)h.k, es->p, 1u, top, hi, pm);
+            it = std::lower_bound(e.begin(), e.end(), std::make_pair(keys[i], 0u));
+          }
+        }
         if (it == e.end() || it->first != keys[i]) return false;
         vals[i] = it->second;
       }
@@ -1117,8 +1141,23 @@ int read_flat_host(const std::string &path, int *k_out, std::vector<uint64_t> &k
     }
     if (h.flags & FLAT_PLACED) {                              // the records are placement numbers: back to k-mers (in the file's order)
       for (uint64_t i = 0; i < h.n; ++i) if (!flat_rec_fits(keys[i], h)) return bad("a placed record is wider than 2k + 3 bits");
+      const bool split = mfx_p_split((int)h.k);               // k = 31: the count field holds count << 1 | strand bit
+      // (an ESCAPED record's field is all ones: its strand bit is the second of a pair of equal numbers', or whichever of the two k-mers the
+      // escape list holds -- resolved in escapes() below from the numbers kept here)
+      if (split)
+        for (uint64_t i = 0; i < h.n; ++i)
+          if (vals[i] == 0xffffffffu)
+            esc_split.push_back({i, keys[i], (i > 0 && keys[i - 1] == keys[i]) ? 1u : (i + 1 < h.n && keys[i + 1] == keys[i]) ? 0u : 2u});
       par_blocks((h.n + 65535) / 65536, [&](uint64_t b) {
-        for (uint64_t i = b * 65536, e = std::min<uint64_t>(h.n, i + 65536); i < e; ++i) { uint32_t top, hi, pm; keys[i] = mfx_p_decode((int)h.k, keys[i], top, hi, pm); }
+        for (uint64_t i = b * 65536, e = std::min<uint64_t>(h.n, i + 65536); i < e; ++i) {
+          uint32_t top, hi, pm, sb = 0;
+          if (split && vals[i] != 0xffffffffu) { sb = vals[i] & 1u; vals[i] >>= 1; }
+          else if (split) {
+            auto it = std::lower_bound(esc_split.begin(), esc_split.end(), i, [](const EscSplit &a, uint64_t x) { return a.i < x; });
+            sb = it->s == 1u ? 1u : 0u;
+          }
+          keys[i] = mfx_p_decode_s((int)h.k, keys[i], sb, top, hi, pm);
+        }
       });
     }
     if (fseek(f, (long)(dir[2 * nblocks + 1] & 0xffffffffffffull), SEEK_SET) != 0 || !escapes()) return bad("inconsistent escape list");
@@ -1280,11 +1319,14 @@ static int mfx_db_convert_impl(const char *in_path, const char *out_path, uint64
 }
 
 // the flat form of ascending placement numbers P (mfx_place.h) and their counts
-static int mfx_db_write_flat_placed_impl(const char *path, int k, const uint64_t *pkeys, const uint32_t *values, uint64_t n) {
+// sbits: the strand bits of a k = 31 file's records (mfx_place.h, mfx_p_split), pkeys then the numbers P >> 1; the C ABI's writer (arrays of P) serves k <= 30
+static int mfx_db_write_flat_placed_impl(const char *path, int k, const uint64_t *pkeys, const uint32_t *values, uint64_t n, const uint8_t *sbits = nullptr) {
   if (!path || (n && (!pkeys || !values))) return mfx_fail(MFX_E_INVAL, "mfx_db_write_flat_placed: null argument");
   if (k < MFX_PLACE_MIN_K || k > MFX_PLACE_MAX_K) return mfx_fail(MFX_E_INVAL, "a placed database holds %d <= k <= %d (k = %d)", MFX_PLACE_MIN_K, MFX_PLACE_MAX_K, k);
+  if (mfx_p_split(k) != (sbits != nullptr))
+    return mfx_fail(MFX_E_INVAL, "mfx_db_write_flat_placed: the placement number of a %d-mer takes 65 bits; its placed database is made by mfx_db_convert_placed (merfin -convert -placed)", k);
   if (!n) return mfx_fail(MFX_E_INVAL, "mfx_db_write_flat_placed: no k-mers");
-  for (uint64_t i = 0; i < n; ++i)
+  for (uint64_t i = 0; i < n && !sbits; ++i)
     if (pkeys[i] >> mfx_p_bits(k)) return mfx_fail(MFX_E_INVAL, "mfx_db_write_flat_placed: record %lu is wider than a placement number of this k", (unsigned long)i);
   FILE *f = fopen(path, "wb");
   if (!f) return mfx_fail(MFX_E_IO, "cannot open '%s' for writing", path);
@@ -1294,7 +1336,7 @@ static int mfx_db_write_flat_placed_impl(const char *path, int k, const uint64_t
   h.flags = 0;
   h.n = n;
   h.n_escape = 0;
-  int rc = write_flat_delta(f, path, h, pkeys, values, n, true);
+  int rc = write_flat_delta(f, path, h, pkeys, values, n, true, sbits);
   if (fclose(f) != 0 && rc == 0) rc = mfx_fail(MFX_E_IO, "short write to '%s'", path);
   if (rc == 1) rc = mfx_fail(MFX_E_INVAL, "mfx_db_write_flat_placed: the records are not strictly ascending");
   return rc;
@@ -1306,11 +1348,13 @@ extern "C" int mfx_db_write_flat_placed(const char *path, int k, const uint64_t 
 }
 
 // P of n canonical k-mers, on the host (mfx_place.h; the device form: mfx_db_place_keys in mfx_api.cpp)
-void mfx_place_keys_host(int k, const uint64_t *kmers, uint64_t n, uint64_t *out) {
+void mfx_place_keys_host(int k, const uint64_t *kmers, uint64_t n, uint64_t *out, uint8_t *sbits_out) {      // sbits_out: k = 31 (out then holds P >> 1)
   par_blocks((n + 65535) / 65536, [&](uint64_t b) {
     for (uint64_t i = b * 65536, e = std::min<uint64_t>(n, i + 65536); i < e; ++i) {
       const uint64_t key = kmers[i], rc = mfx_p_revcomp(key, k);
-      out[i] = mfx_p_encode(k, key < rc ? key : rc);
+      uint32_t sb;
+      out[i] = mfx_p_encode_s(k, key < rc ? key : rc, sb);
+      if (sbits_out) sbits_out[i] = (uint8_t)sb;
     }
   });
 }
@@ -1319,7 +1363,7 @@ void mfx_place_keys_host(int k, const uint64_t *kmers, uint64_t n, uint64_t *out
 static int mfx_db_convert_placed_impl(const char *in_path, const char *out_path, uint64_t *n_out) {
   if (!in_path || !out_path) return mfx_fail(MFX_E_INVAL, "mfx_db_convert_placed: null argument");
   {
-    // k first: a database this form cannot hold (k = 31: P takes 65 bits) is refused before its tens of GB are converted and read back
+    // k first: a database this form cannot hold is refused before its tens of GB are converted and read back
     mfx_db_info pi;
     if (int prc = mfx_db_probe(in_path, &pi)) return prc;
     if (pi.k < MFX_PLACE_MIN_K || pi.k > MFX_PLACE_MAX_K)
@@ -1344,10 +1388,38 @@ static int mfx_db_convert_placed_impl(const char *in_path, const char *out_path,
       if (keys[i] > mfx_p_revcomp(keys[i], k)) { noncanon = 1; return; }
   });
   if (noncanon) return mfx_fail(MFX_E_NONCANON, "'%s' is not canonical: a placed database holds canonical k-mers (the sequence-only index it feeds does)", in_path);
-  mfx_place_keys_host(k, keys.data(), vals.size(), keys.data());
-  sort_pairs(k, keys, vals, mfx_p_bits(k));
   if (n_out) *n_out = vals.size();
-  return mfx_db_write_flat_placed(out_path, k, keys.data(), vals.data(), vals.size());
+  if (!mfx_p_split(k)) {
+    mfx_place_keys_host(k, keys.data(), vals.size(), keys.data(), nullptr);
+    sort_pairs(k, keys, vals, mfx_p_bits(k));
+    return mfx_db_write_flat_placed(out_path, k, keys.data(), vals.data(), vals.size());
+  }
+  // k = 31: the stored number is P >> 1, the strand bit beside it.  The records of either strand bit are sorted on their own and merged, the
+  // s = 0 one of an equal pair first (the order of the 65-bit P)
+  const uint64_t N = vals.size();
+  std::vector<uint8_t> sb(N);
+  mfx_place_keys_host(k, keys.data(), N, keys.data(), sb.data());
+  std::vector<uint64_t> k1;
+  std::vector<uint32_t> v1;
+  {
+    uint64_t n0 = 0;
+    for (uint64_t i = 0; i < N; ++i) {
+      if (sb[i]) { k1.push_back(keys[i]); v1.push_back(vals[i]); }
+      else { keys[n0] = keys[i]; vals[n0] = vals[i]; ++n0; }
+    }
+    keys.resize(n0); vals.resize(n0);
+  }
+  sort_pairs(k, keys, vals, 64);
+  sort_pairs(k, k1, v1, 64);
+  std::vector<uint64_t> mk(N);
+  std::vector<uint32_t> mv(N);
+  for (uint64_t a = 0, b = 0, o = 0; o < N; ++o) {
+    const bool take0 = b == k1.size() || (a < keys.size() && keys[a] <= k1[b]);
+    if (take0) { mk[o] = keys[a]; mv[o] = vals[a]; sb[o] = 0; ++a; }
+    else { mk[o] = k1[b]; mv[o] = v1[b]; sb[o] = 1; ++b; }
+  }
+  std::vector<uint64_t>().swap(keys); std::vector<uint64_t>().swap(k1);
+  return mfx_db_write_flat_placed_impl(out_path, k, mk.data(), mv.data(), N, sb.data());
 }
 extern "C" int mfx_db_convert_placed(const char *in_path, const char *out_path, uint64_t *n_out) {
   try { return mfx_db_convert_placed_impl(in_path, out_path, n_out); }

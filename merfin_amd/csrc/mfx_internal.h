@@ -57,7 +57,7 @@ int  mfx_index_add_multi(struct mfx_index *const *ixs, uint32_t nix, const uint6
 void mfx_index_ingest_release(struct mfx_index *ix);
 // a delta-coded flat database opened for the staged load (mfx_db.cpp; mfx_api.cpp: mfx_db_stage)
 struct mfx_flat_delta_info { int k = 0, placed = 0; uint64_t n = 0, n_escape = 0, nblocks = 0, escapes_off = 0, fsize = 0; };
-void mfx_place_keys_host(int k, const uint64_t *kmers, uint64_t n, uint64_t *out);      // mfx_db.cpp: P (mfx_place.h) of canonical k-mers, host threads
+void mfx_place_keys_host(int k, const uint64_t *kmers, uint64_t n, uint64_t *out, uint8_t *sbits_out = nullptr);      // mfx_db.cpp: P (mfx_place.h) of canonical k-mers, host threads; k = 31: P >> 1 and the strand bits
 int  mfx_flat_delta_open(const char *path, int *fd_out, mfx_flat_delta_info *info, std::vector<uint64_t> &dir);
 
 // host threads the library may use: min(hardware, cgroup CPU quota, 64), or MFX_HOST_THREADS

@@ -971,7 +971,7 @@ __global__ __launch_bounds__(256) void mfx_table_add_delta_kernel(mfx_table_view
 
 // The probe of a k-mer whose placement pieces are known (a record of a PLACED database: mfx_place.h) -- no t-mer scan, no window
 // choice: the line and the first mini-bucket come from `top`, window and strand, the quotient form's key field from the same pieces.
-// Valid for the QUOTIENT form of the compact layout (22 <= k <= 30) under its default placement; the direct form (k <= 21) takes its
+// Valid for the QUOTIENT form of the compact layout (22 <= k <= 31) under its default placement; the direct form (k <= 21) takes its
 // first mini-bucket from the t-mer's offset, which a record does not carry (mfx_mod_place).
 __device__ __forceinline__ mfx_probe mfx_home_placed(const mfx_table_view &t, uint64_t key, uint32_t top, uint32_t hi, uint32_t meta) {
   mfx_probe pr;
@@ -1021,6 +1021,7 @@ __global__ __launch_bounds__(256) void mfx_table_add_placed_kernel(mfx_table_vie
   // records per lane (the k-mer-sorted kernel's split) every line of the block was touched in four rounds, and left the L2 in between
   // (measured: every table line written back 4.7 times, profiles/r05_e2e_placed.txt).
   constexpr uint32_t ROUND = 256u * 4u;
+  const bool split = mfx_p_split(t.k);
   __shared__ uint64_t wsum[4];
   __shared__ uint64_t s_base;
   mfx_tally T;
@@ -1064,14 +1065,16 @@ __global__ __launch_bounds__(256) void mfx_table_add_placed_kernel(mfx_table_vie
         run += d[i];
         if (e < cnt) {
           uint32_t top, hi, pm;
-          key[i] = mfx_p_decode(t.k, run, top, hi, pm);
           v[i] = (uint32_t)mfx_bits_at(pw, vbit0 + (uint64_t)e * vb, vb);
           if (v[i] == (1u << vb) - 1u) v[i] = 0u;              // escape: added separately (the file's escape list)
-          if (run >> mfx_p_bits(t.k)) { if (v[i]) ++T.wide; v[i] = 0u; }      // (a damaged record: wider than any P of this k)
+          uint32_t sb = 0u;
+          if (split) { sb = v[i] & 1u; v[i] >>= 1; }           // k = 31: the strand bit of P travels in the count field (mfx_place.h)
+          key[i] = mfx_p_decode_s(t.k, run, sb, top, hi, pm);
+          if (!split && (run >> mfx_p_bits(t.k))) { if (v[i]) ++T.wide; v[i] = 0u; }      // (a damaged record: wider than any P of this k)
           // ... or one that no converter writes: a number equal to the one before it (the records ascend strictly), a number whose k-mer is not
           // canonical (every P of a canonical k-mer decodes to it; most other numbers do not).  Counted with the wide ones (MFX_E_FORMAT), not applied:
           // the plain stores below rely on one record per slot.
-          if (v[i] && ((e > 0u && d[i] == 0ull) || mfx_p_revcomp(key[i], t.k) < key[i])) { ++T.wide; v[i] = 0u; }
+          if (v[i] && ((e > 0u && d[i] == 0ull && !(split && sb)) || mfx_p_revcomp(key[i], t.k) < key[i])) { ++T.wide; v[i] = 0u; }   // (k = 31: the s = 1 twin of a stored number follows it)
           if (placed) pr[i] = t.quot ? mfx_home_placed(t, key[i], top, hi, pm) : mfx_home_placed_direct(t, key[i], top, pm);
         }
       }

@@ -7,11 +7,12 @@
 // (quotient form: its window and strand, mfx_p_bucket; direct form: the sampling t-mer's offset, mfx_mod_place).  So the pieces
 //     c (2m bits), s (c stands reversed in the k-mer), j (its window, 0..3), e (the 3 bases around it)
 // ARE the k-mer, one to one, and the 64-bit number
-//     P = top : 32 | high bits of c : 2m - 32 | s : 1 | j : 2 | e : 6                      (2k + 3 bits for k >= 19: k <= 30)
+//     P = top : 32 | high bits of c : 2m - 32 | s : 1 | j : 2 | e : 6                      (2k + 3 bits for k >= 19: 64 bits hold it for k <= 30)
 // is one to one with it as well -- and ascending P means ascending line, for a table of ANY size.  A database whose records are
 // sorted by P ("placed", mfx_db.cpp FLAT_PLACED) is therefore applied to the table line after line: every line is read once and
 // written once instead of one random line per record (round 5; what the reference pays per run in load_Kmers,
-// merfin-globals.C:114-163).  The quotient form of the table (22 <= k <= 31) keeps only what the line does not say of the same
+// merfin-globals.C:114-163).  k = 31 (round 6): P takes 65 bits; the record holds P >> 1 and the strand bit s travels in its count field
+// (mfx_p_encode_s below).  The quotient form of the table (22 <= k <= 31) keeps only what the line does not say of the same
 // pieces (mfx_q_place).  Everything here is integer arithmetic on uint32 / uint64: host (the converter, the tests) and device
 // (the table's kernels) agree by construction.
 #pragma once
@@ -25,7 +26,7 @@
 #endif
 
 constexpr int MFX_PLACE_W = 4;                 // windows of the compact layout's mod-minimizer
-constexpr int MFX_PLACE_MIN_K = 13, MFX_PLACE_MAX_K = 30;     // k of a placed database (k = 31: P would take 65 bits)
+constexpr int MFX_PLACE_MIN_K = 13, MFX_PLACE_MAX_K = 31;     // k of a placed database (k = 31: P takes 65 bits -- its strand bit travels beside it, mfx_p_encode_s)
 constexpr uint32_t MFX_PLACE_VERSION = 1u;     // of the functions below; a placed database records it (another version: refused)
 
 // the sampling t-mer's length: 4 .. 7 with (k - t) % 4 == 3, so that a k-mer and its reverse complement sample the same window
@@ -117,15 +118,35 @@ MFX_PHD uint64_t mfx_p_encode(int k, uint64_t key) {
 
 // P -> the canonical k-mer and the pieces a table needs to place it (top, j); a P no k-mer encodes gives a k-mer that does not
 // encode back to it (the loaders check what they can: the k-mer's width)
-MFX_PHD uint64_t mfx_p_decode(int k, uint64_t P, uint32_t &top, uint32_t &hi, uint32_t &meta) {
+// (pieces: meta / hi / top are handed in instead of cut from P -- mfx_p_decode_s below)
+MFX_PHD uint64_t mfx_p_decode(int k, uint64_t P, uint32_t &top, uint32_t &hi, uint32_t &meta, bool pieces = false, uint32_t meta_in = 0, uint32_t hi_in = 0, uint32_t top_in = 0) {
   const int m = k - 3, R = mfx_p_hibits(k);
-  meta = (uint32_t)P & 511u;
-  hi = (uint32_t)(P >> 9) & (uint32_t)((1ull << R) - 1ull);
-  top = (uint32_t)(P >> (R + 9));
+  meta = pieces ? meta_in : (uint32_t)P & 511u;
+  hi = pieces ? hi_in : (uint32_t)(P >> 9) & (uint32_t)((1ull << R) - 1ull);
+  top = pieces ? top_in : (uint32_t)(P >> (R + 9));
   const uint32_t sbit = meta & 1u, j = (meta >> 1) & 3u, e = (meta >> 3) & 63u;
   const uint64_t c = ((uint64_t)hi << 32) | mfx_p_unmix(top, hi);
   const uint64_t mmer = sbit ? mfx_p_revcomp(c, m) : c;
   const uint64_t left = e >> (2 * (3 - j)), right = e & ((1u << (2 * (3 - j))) - 1u);
   return (left << (2 * (m + 3 - (int)j))) | (mmer << (2 * (3 - j))) | right;
 }
-MFX_PHD int mfx_p_bits(int k) { return 32 + mfx_p_hibits(k) + 9; }      // 2k + 3 for k >= 19 (41 below: `top` has 32 bits whatever the minimizer's length)
+// k = 31: P = top : 32 | hi : 24 | s | j | e would take 65 bits.  A placed record then holds P >> 1 -- everything but the strand bit s, 64 bits,
+// ascending P >> 1 is still ascending line -- and s travels beside it: bit 0 of the record's count field, the count above it (mfx_db.cpp,
+// mfx_table_add_placed_kernel).  Two k-mers that differ in s alone share the stored number (s = 0 first).  k <= 30: s_out = 0, the number is P.
+MFX_PHD bool mfx_p_split(int k) { return k > 30; }
+MFX_PHD uint64_t mfx_p_encode_s(int k, uint64_t key, uint32_t &s_out) {
+  if (!mfx_p_split(k)) { s_out = 0u; return mfx_p_encode(k, key); }
+  uint64_t c;
+  uint32_t sbit, j, e;
+  mfx_p_parts(k, key, mfx_p_revcomp(key, k), c, sbit, j, e);
+  const int R = mfx_p_hibits(k);
+  const uint32_t hi = (uint32_t)(c >> 32), top = mfx_p_mix((uint32_t)c, hi);
+  s_out = sbit;
+  return ((uint64_t)top << (R + 8)) | ((uint64_t)hi << 8) | (uint64_t)(j | (e << 2));
+}
+MFX_PHD uint64_t mfx_p_decode_s(int k, uint64_t P, uint32_t s_in, uint32_t &top, uint32_t &hi, uint32_t &meta) {
+  if (!mfx_p_split(k)) return mfx_p_decode(k, P, top, hi, meta);
+  const int R = mfx_p_hibits(k);
+  return mfx_p_decode(k, 0ull, top, hi, meta, true, ((uint32_t)(P & 255u) << 1) | (s_in & 1u), (uint32_t)(P >> 8) & (uint32_t)((1ull << R) - 1ull), (uint32_t)(P >> (R + 8)));
+}
+MFX_PHD int mfx_p_bits(int k) { return mfx_p_split(k) ? 64 : 32 + mfx_p_hibits(k) + 9; }      // of the STORED number: 2k + 3 for 19 <= k <= 30 (41 below: `top` has 32 bits whatever the minimizer's length)

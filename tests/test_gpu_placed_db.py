@@ -44,7 +44,7 @@ def _padded(k, read, asm, n_extra=200000, seed=5):
     return keys[o], vals[o]
 
 
-@pytest.mark.parametrize("k", [13, 17, 21, 22, 27, 30])
+@pytest.mark.parametrize("k", [13, 17, 21, 22, 27, 30, 31])
 def test_placed_database_builds_the_same_table(k, tmp_path, monkeypatch):
     import torch
     m = _mfx()
@@ -52,14 +52,27 @@ def test_placed_database_builds_the_same_table(k, tmp_path, monkeypatch):
     contigs, read, asm = synth.world(k=k, peak=peak, seed=70 + k)
     keys, vals = _padded(k, read, asm)
     vals[::501] = 5000 + (np.arange(len(vals[::501])) % 7).astype(np.uint32) * 100000      # counts beyond any block's field: the escape list
+    vals[7::1009] = 3000000000                                                              # ... and beyond 31 bits (k = 31 folds its strand bit into the field)
     truth = dict(zip(keys.tolist(), vals.tolist()))
     flat, placed = str(tmp_path / "r.mfxk"), str(tmp_path / "p.mfxk")
     m.db_write_flat(flat, k, keys, vals)
     assert m.db_convert_placed(flat, placed) == len(keys)
-    # the placement numbers: device == host
-    host = m.db_place_keys(k, keys)
-    dev = m.db_place_keys(k, torch.from_numpy(keys.view(np.int64)).cuda()).cpu().numpy().view(np.uint64)
-    np.testing.assert_array_equal(dev, host)
+    if k <= 30:                                               # the placement numbers: device == host (k = 31: 65 bits, made inside the converter only)
+        host = m.db_place_keys(k, keys)
+        dev = m.db_place_keys(k, torch.from_numpy(keys.view(np.int64)).cuda()).cpu().numpy().view(np.uint64)
+        np.testing.assert_array_equal(dev, host)
+    else:
+        with pytest.raises(m.MfxError):
+            m.db_place_keys(k, keys)
+    # ... and back: the placed file converted to the sorted form holds the k-mers and counts it was made of
+    back = str(tmp_path / "back.mfxk")
+    assert m.db_convert(placed, back) == len(keys)
+    ixb = m.Index(k, len(keys) + 16)
+    ixb.load_db(back, 0)
+    bk, br, _ = _export_sorted(ixb)
+    np.testing.assert_array_equal(bk, keys)
+    np.testing.assert_array_equal(br, vals)
+    del ixb
     seqs = m.Sequences(contigs)
     nb = sum(len(c) for c in contigs)
     lo, hi = 2, 4000000

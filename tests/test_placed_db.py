@@ -123,10 +123,13 @@ def test_placed_form_refusals(tmp_path):
         km = canon(r, k, 100)
         flat = str(tmp_path / ("f%d" % k))
         m.db_write_flat(flat, k, km, np.ones(len(km), dtype=np.uint32))
-        with pytest.raises(m.MfxError, match="placed database holds"):
-            m.db_convert_placed(flat, str(tmp_path / "x"))
+        if k == 12:
+            with pytest.raises(m.MfxError, match="placed database holds"):
+                m.db_convert_placed(flat, str(tmp_path / "x"))
         with pytest.raises(m.MfxError):
-            m.db_place_keys(k, km)
+            m.db_place_keys(k, km)                             # (k = 31: P takes 65 bits -- the converter alone makes that file, below)
+        with pytest.raises(m.MfxError):
+            m.db_write_flat_placed(str(tmp_path / "w"), k, np.arange(1, 50, dtype=np.uint64), np.ones(49, dtype=np.uint32))
     k = 21
     km = canon(r, k, 200)
     nc = np.array([revcomp(int(x), k) for x in km if revcomp(int(x), k) != int(x)], dtype=np.uint64)
@@ -146,6 +149,49 @@ def test_placed_form_refusals(tmp_path):
     open(bad, "wb").write(bytes(raw))
     with pytest.raises(m.MfxError, match="another version"):
         m.db_convert(bad, str(tmp_path / "z"))
+
+
+def test_placed_31mers_carry_the_strand_bit_in_the_count_field(tmp_path):
+    """k = 31: P takes 65 bits; the file holds P >> 1 and bit 0 of a record's count field is the strand bit (mfx_place.h, mfx_p_encode_s).
+    Two k-mers that differ in that bit alone share the stored number; an ESCAPED record's field is all ones, so its strand is what the
+    pair or the escape list says.  placed -> sorted must give back the k-mers and counts, every combination of escaped / plain twins."""
+    m = _m()
+    k, mm = 31, 28
+    r = np.random.default_rng(931)
+    km = set(canon(r, k, 4000).tolist())
+    twins = []
+    while len(twins) < 8:
+        j = int(r.integers(0, 4))
+        c = int(r.integers(0, 1 << 56))
+        if revcomp(c, mm) == c:
+            continue
+        e = int(r.integers(0, 64))
+        left, right = e >> (2 * (3 - j)), e & ((1 << (2 * (3 - j))) - 1)
+        a = (left << (2 * (mm + 3 - j))) | (c << (2 * (3 - j))) | right
+        b = (left << (2 * (mm + 3 - j))) | (revcomp(c, mm) << (2 * (3 - j))) | right
+        if a > revcomp(a, k) or b > revcomp(b, k):
+            continue                                           # both must be canonical k-mers
+        pa, pb = model_encode(k, a)[0], model_encode(k, b)[0]
+        if pa >> 1 == pb >> 1 and pa != pb:
+            twins.append((a, b) if pa < pb else (b, a))
+    for a, b in twins:
+        km.update((a, b))
+    km = np.array(sorted(km), dtype=np.uint64)
+    vals = (1 + (km % np.uint64(3000))).astype(np.uint32)
+    vals[::89] = 2 ** 31 + 9                                   # escapes, beyond 31 bits
+    vals[5::97] = (1 << 21) + 3                                # fits a 22-bit field as a count, not with the strand bit beside it
+    big = np.uint32(3000000011)
+    combos = [(7, 9), (big, 9), (7, big), (big, big), (2 ** 21 - 1, 2 ** 21), (1, 1), (big, 1), (1, big)]
+    pos = {int(x): i for i, x in enumerate(km.tolist())}
+    for (a, b), (va, vb) in zip(twins, combos):
+        vals[pos[a]], vals[pos[b]] = va, vb
+    flat, placed, back = (str(tmp_path / n) for n in ("flat.mfxk", "placed.mfxk", "back.mfxk"))
+    m.db_write_flat(flat, k, km, vals)
+    assert m.db_convert_placed(flat, placed) == len(km)
+    info = m.db_probe(placed)
+    assert info.get("placed") and info["k"] == k and info["n_kmers"] == len(km)
+    assert m.db_convert(placed, back) == len(km)
+    assert open(back, "rb").read() == open(flat, "rb").read()
 
 
 def test_cli_convert_placed(tmp_path):
