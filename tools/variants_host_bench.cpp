@@ -14,7 +14,7 @@ using PathValues = std::function<int(const char *, uint64_t, uint32_t *, uint32_
 using PathScores = std::function<int(const char *, uint64_t, const mfx_path_table &, const mfx_trv_batch *, int, uint32_t *, double *)>;
 int mfx_variants_run_values(const mfx_eval *ev, const PathValues &values, const char *vcf_path, const char *const *names, const char *const *bases,
                             const uint64_t *lens, uint32_t ncontigs, const mfx_variant_opts *opts, const char *out_path, const char *log_path,
-                            uint64_t *n_clusters, const PathScores &scores, struct mfx_vcf *loaded, uint32_t prepK = 0);
+                            uint64_t *n_clusters, const PathScores &scores, struct mfx_vcf *loaded, uint32_t prepK = 0, struct PathClaims *claims = nullptr);
 extern "C" int mfx_vcf_prepare(struct mfx_vcf *vcf, int k, const char *const *names, const char *const *bases, const uint64_t *lens, uint32_t ncontigs,
                                const mfx_variant_opts *opts);
 extern "C" struct mfx_vcf *mfx_vcf_load(const char *vcf_path);
