@@ -1221,15 +1221,13 @@ void sort_pairs(int k, std::vector<uint64_t> &keys, std::vector<uint32_t> &vals,
 }
 }  // namespace
 
-static int mfx_db_convert_impl(const char *in_path, const char *out_path, uint64_t *n_out) {
-  if (!in_path || !out_path) return mfx_fail(MFX_E_INVAL, "mfx_db_convert: null argument");
+// any accepted database -> its k-mers (k <= 31: ascending, every k-mer once) and counts in memory: what mfx_db_convert writes and
+// mfx_db_convert_placed re-keys.  t_read / t_order: seconds (diagnostics)
+static int read_db_sorted(const char *in_path, int *k_out, std::vector<uint64_t> &keys, std::vector<uint32_t> &vals, double *t_read = nullptr, double *t_order = nullptr) {
   const std::string p(in_path);
   const int fmt = detect(p);
   if (!fmt) return mfx_fail(MFX_E_IO, "k-mer database '%s' does not exist", in_path);
   int k = 0, rc = MFX_OK;
-  std::vector<uint64_t> keys;
-  std::vector<uint32_t> vals;
-  const bool timing = getenv("MFX_DB_TIMING") != nullptr;
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t0 = now();
   auto gather = [&](std::vector<Collected> &parts, size_t kw) {   // parts in input order -> one pair of arrays
@@ -1311,10 +1309,25 @@ static int mfx_db_convert_impl(const char *in_path, const char *out_path, uint64
         if (keys[i] == keys[i - 1]) return mfx_fail(MFX_E_FORMAT, "'%s' lists a k-mer twice; a database holds every k-mer once", in_path);
     }
   }
+  *k_out = k;
+  if (t_read) *t_read = t1 - t0;
+  if (t_order) *t_order = now() - t1;
+  return MFX_OK;
+}
+
+static int mfx_db_convert_impl(const char *in_path, const char *out_path, uint64_t *n_out) {
+  if (!in_path || !out_path) return mfx_fail(MFX_E_INVAL, "mfx_db_convert: null argument");
+  int k = 0;
+  std::vector<uint64_t> keys;
+  std::vector<uint32_t> vals;
+  double t_read = 0, t_order = 0;
+  int rc = read_db_sorted(in_path, &k, keys, vals, &t_read, &t_order);
+  if (rc) return rc;
   if (n_out) *n_out = vals.size();
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t2 = now();
   rc = mfx_db_write_flat(out_path, k, keys.data(), vals.data(), vals.size());
-  if (timing) fprintf(stderr, "[mfx db] convert: read %.2f s, order %.2f s, write %.2f s\n", t1 - t0, t2 - t1, now() - t2);
+  if (getenv("MFX_DB_TIMING")) fprintf(stderr, "[mfx db] convert: read %.2f s, order %.2f s, write %.2f s\n", t_read, t_order, now() - t2);
   return rc;
 }
 
@@ -1369,17 +1382,11 @@ static int mfx_db_convert_placed_impl(const char *in_path, const char *out_path,
     if (pi.k < MFX_PLACE_MIN_K || pi.k > MFX_PLACE_MAX_K)
       return mfx_fail(MFX_E_INVAL, "'%s' holds %d-mers: a placed database holds %d <= k <= %d (use -convert without -placed)", in_path, pi.k, MFX_PLACE_MIN_K, MFX_PLACE_MAX_K);
   }
-  // through the sorted flat form in memory: read (any form), then re-key
-  std::string tmp = std::string(out_path) + ".tmp-sorted";
-  uint64_t n = 0;
-  int rc = mfx_db_convert(in_path, tmp.c_str(), &n);
-  if (rc) { unlink(tmp.c_str()); return rc; }
+  // the database's k-mers in memory (any form), then re-keyed -- no intermediate file
   int k = 0;
   std::vector<uint64_t> keys;
   std::vector<uint32_t> vals;
-  rc = read_flat_host(tmp, &k, keys, vals);
-  unlink(tmp.c_str());
-  if (rc) return rc;
+  if (int rc = read_db_sorted(in_path, &k, keys, vals)) return rc;
   if (k < MFX_PLACE_MIN_K || k > MFX_PLACE_MAX_K)
     return mfx_fail(MFX_E_INVAL, "'%s' holds %d-mers: a placed database holds %d <= k <= %d (use -convert without -placed)", in_path, k, MFX_PLACE_MIN_K, MFX_PLACE_MAX_K);
   std::atomic<int> noncanon{0};
