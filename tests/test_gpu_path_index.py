@@ -181,3 +181,32 @@ def test_path_only_index_from_database_files_and_the_sequence(tmp_path):
         assert n_a == n_b
         assert open(tmp_path / "a.vcf", "rb").read() == open(tmp_path / (tag + ".vcf"), "rb").read(), tag
         loaded.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(300, 312)))
+def test_randomized_call_sets_on_the_path_only_index_match_the_oracle(tmp_path, seed):
+    """seeded sweep (mode, k odd / even, -comb, -nosplit, peak, burst density, contig sizes): the records and the log of the run on the
+    path-only index against the ORACLE's restatement of vcf.C / merfin-variants.C / varMer.C on the full lookup tables"""
+    import merfin_amd as m
+    from oracle import pyoracle as po
+    r = np.random.default_rng(seed)
+    mode = ["filter", "polish", "better", "strict", "loose"][int(r.integers(0, 5))]
+    k = int(r.choice([9, 12, 15, 21, 22, 27, 31]))
+    comb, nosplit, peak = int(r.integers(2, 17)), bool(r.random() < 0.3), float(r.choice([9.0, 17.3, 26.0]))
+    names, asm, vp, read, amers = _world(tmp_path, k, peak, seed, burst=float(r.choice([0.03, 0.08, 0.15])),
+                                         sizes=tuple(int(x) for x in r.choice([300, 2500, 6000, 12000], size=int(r.integers(2, 5)))))
+    n_o = po.variants_run(po.Params(k, peak), po.Lookup(k, *read), po.Lookup(k, *amers), mode, vp, names, asm, str(tmp_path / "o.vcf"), comb=comb, nosplit=nosplit,
+                          log_path=str(tmp_path / "o.log"))
+    loaded = m.LoadedVcf(vp)
+    px = loaded.prepare_path_index(k, mode, names, asm, comb=comb, nosplit=nosplit)
+    assert px is not None
+    px.add_read(*read)                                         # (either order: both only update what the paths claimed)
+    px.add_asm(*amers)
+    pev = m.Evaluator(px, m.KParams(peak))
+    n_g = pev.variants_loaded(mode, loaded, names, asm, str(tmp_path / "g.vcf"), comb=comb, nosplit=nosplit, log_path=str(tmp_path / "g.log"))
+    assert n_o == n_g
+    assert open(tmp_path / "g.vcf").read() == open(tmp_path / "o.vcf").read()
+    special = lambda p: sorted(l for l in open(p).read().splitlines() if l.startswith("PANIC") or l.startswith("[ WARNING ]"))
+    assert special(tmp_path / "g.log") == special(tmp_path / "o.log")
+    loaded.close()
