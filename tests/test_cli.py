@@ -196,8 +196,9 @@ def test_cli_variant_modes_on_the_path_only_index(tmp_path, seqmers, k):
     with open(fa, "wb") as f:
         for n, c in zip(names, asm):
             f.write(b">" + n.encode() + b"\n" + c + b"\n")
-    m.db_write_flat(str(tmp_path / "read.mfxk"), k, *read)
-    m.db_write_flat(str(tmp_path / "asm.mfxk"), k, *amers)
+    for name, (kk, vv) in (("read", read), ("asm", amers)):           # sorted: delta-coded files, which the path-only build STAGES into device memory
+        o = np.argsort(kk)
+        m.db_write_flat(str(tmp_path / (name + ".mfxk")), k, kk[o], vv[o])
     args = ["-polish", "-sequence", fa, "-readmers", str(tmp_path / "read.mfxk"), "-vcf", vp, "-peak", str(peak)]
     if seqmers:
         args += ["-seqmers", str(tmp_path / "asm.mfxk")]
@@ -207,6 +208,9 @@ def test_cli_variant_modes_on_the_path_only_index(tmp_path, seqmers, k):
     r2 = run(args + ["-output", str(tmp_path / "full")], env=dict(os.environ, MFX_CLI_PATH_INDEX="0"))
     assert r2.returncode == 0, r2.stderr
     assert "variants' paths" not in r2.stderr
+    r4 = run(args + ["-output", str(tmp_path / "unstaged")], env=dict(os.environ, MFX_CLI_PATH_INDEX="1", MFX_DB_STAGE="0"))      # the path-only index from the files, unstaged
+    assert r4.returncode == 0, r4.stderr
+    assert (tmp_path / "unstaged.polish.vcf").read_text() == (tmp_path / "o.vcf").read_text()
     r3 = run(args + ["-debug", "-output", str(tmp_path / "dbg")], env=dict(os.environ, MFX_CLI_PATH_INDEX="1"))      # -debug: host-enumerated text is what is claimed
     assert r3.returncode == 0, r3.stderr
     assert (tmp_path / "dbg.polish.vcf").read_text() == (tmp_path / "o.vcf").read_text()

@@ -91,18 +91,20 @@ if len(sys.argv) > 3 and sys.argv[3] == "cli":
         # the PATH-ONLY index (the default of one slot: the call set prepared first, its paths' k-mers claimed, both databases staged and
         # update-only) against the full tables (MFX_CLI_PATH_INDEX=0), alternating; the records must be the same bytes
         ref_out = None
-        for rep, pi in enumerate(os.environ["MFX_CFG4_PATH_AB"].split(",")):
+        for rep, tok in enumerate(os.environ["MFX_CFG4_PATH_AB"].split(",")):
+            pi, _, extra = tok.partition(":")                     # "0:MFX_CLI_FULL_STAGE=0": the full tables with the databases read when the build gets there
+            xenv = dict(kv.split("=", 1) for kv in extra.split(":") if kv)
             time.sleep(float(os.environ.get("MFX_CFG4_SLEEP", "0")))
             t0 = time.time()
             r = subprocess.run([exe, "-polish", "-sequence", out + "/asm.fasta", "-readmers", out + "/read.mfxk", "-seqmers", out + "/asm.mfxk", "-peak", str(lam),
                                 "-vcf", vcf, "-output", out + "/cli_p" + pi], capture_output=True, text=True,
-                               env=dict(os.environ, MFX_CLI_TIMING="2", MFX_VAR_TIMING="1", MFX_INGEST_TIMING="1", MFX_CLI_PATH_INDEX=pi))
+                               env=dict(os.environ, MFX_CLI_TIMING="2", MFX_VAR_TIMING="1", MFX_INGEST_TIMING="1", MFX_CLI_PATH_INDEX=pi, **xenv))
             dt = time.time() - t0
             data = open(out + "/cli_p" + pi + ".polish.vcf").read() if r.returncode == 0 else ""
             if ref_out is None:
                 ref_out = data
-            print("merfin -polish MFX_CLI_PATH_INDEX=%s (%s): rc=%d wall=%.2fs same=%s %d bytes" % (pi, "path-only index" if pi == "1" else "full tables", r.returncode, dt,
-                                                                                                data == ref_out, len(data)), flush=True)
+            print("merfin -polish MFX_CLI_PATH_INDEX=%s %s(%s): rc=%d wall=%.2fs same=%s %d bytes" % (pi, extra + " " if extra else "", "path-only index" if pi == "1" else "full tables", r.returncode, dt,
+                                                                                                  data == ref_out, len(data)), flush=True)
             print("    " + "\n    ".join(l for l in r.stderr.splitlines() if "timing" in l or "ERROR" in l or "Memory needed" in l or "staged build" in l or "stager " in l and "sequence was in" in l
                                           or "mfx_variants]" in l and "load:" not in l))
         api = open(out + "/out.polish.vcf").read()
